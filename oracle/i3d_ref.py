@@ -1,0 +1,450 @@
+"""oracle/i3d_ref.py -- fp32 torch-CPU restatement of the STEP model forward path.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Functional, table-driven: every routine
+takes a flat ``state_dict``-style mapping (the reference's own key names) and plain tensors in the
+reference's own logical layouts, and calls torch's CPU fp32 operators -- the same arithmetic
+library the reference itself delegates to (SURVEY.md 8c "third-party arithmetic").
+
+Pinned by tests/golden/*.npz, generated from the imported reference by oracle/make_golden.py
+(tests/test_oracle_golden.py).  Reference citations are to /root/reference.
+"""
+import math
+import zlib
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import roi_align_forward as _roi_align_c
+from . import roi_pool_forward as _roi_pool_c
+
+# ---------------------------------------------------------------------------------------------
+# Architecture tables (models/i3dpt.py:175-231, models/networks.py:120-132)
+# stage = (kind, index in base_model Sequential, args)
+BACKBONE = [
+    ("conv", 0, (3, 64, (7, 7, 7), (2, 2, 2))),
+    ("pool", 1, ((1, 3, 3), (1, 2, 2))),
+    ("conv", 2, (64, 64, (1, 1, 1), (1, 1, 1))),
+    ("conv", 3, (64, 192, (3, 3, 3), (1, 1, 1))),
+    ("pool", 4, ((1, 3, 3), (1, 2, 2))),
+    ("mixed", 5, (192, (64, 96, 128, 16, 32, 32))),
+    ("mixed", 6, (256, (128, 128, 192, 32, 96, 64))),
+    ("pool", 7, ((3, 3, 3), (2, 2, 2))),
+    ("mixed", 8, (480, (192, 96, 208, 16, 48, 64))),
+    ("mixed", 9, (512, (160, 112, 224, 24, 64, 64))),
+    ("mixed", 10, (512, (128, 128, 256, 24, 64, 64))),
+    ("mixed", 11, (512, (112, 144, 288, 32, 64, 64))),
+    ("mixed", 12, (528, (256, 160, 320, 32, 128, 128))),
+]
+MIXED_5B = (832, (256, 160, 320, 32, 128, 128))   # i3dpt.py:170,228
+MIXED_5C = (832, (384, 192, 384, 48, 128, 128))   # i3dpt.py:171,229
+BN_EPS = 1e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# TF "SAME" padding (models/i3dpt.py:14-31): pad_along = max(k - s, 0), front = //2, back = rest;
+# independent of the input size.
+def tf_same_pad(kernel, stride):
+    pads = []
+    for k, s in zip(kernel, stride):
+        along = max(k - s, 0)
+        pads.append((along // 2, along - along // 2))
+    return pads  # [(d_front,d_back),(h_front,h_back),(w_front,w_back)]
+
+
+def _pad3d(x, pads):
+    (df, db), (hf, hb), (wf, wb) = pads
+    # The reference hands (h_t,h_b,w_t,w_b,d_t,d_b) to F.pad, i.e. applies the H pads to W and vice
+    # versa (i3dpt.py:26-31); all kernels are square in H,W so the result is the same.
+    return F.pad(x, (wf, wb, hf, hb, df, db), value=0.0)
+
+
+def unit3d(x, sd, prefix, stride=(1, 1, 1), bn=True, relu=True):
+    """conv (+bias) -> BN(eval) -> ReLU on NCDHW.  models/i3dpt.py:43-111."""
+    w = sd[prefix + ".conv3d.weight"]
+    b = sd.get(prefix + ".conv3d.bias")
+    x = _pad3d(x, tf_same_pad(tuple(w.shape[2:]), stride))
+    y = F.conv3d(x, w, b, stride=stride)
+    if bn:
+        y = F.batch_norm(y, sd[prefix + ".batch3d.running_mean"], sd[prefix + ".batch3d.running_var"],
+                         sd[prefix + ".batch3d.weight"], sd[prefix + ".batch3d.bias"], False, 0.0, BN_EPS)
+    return F.relu(y) if relu else y
+
+
+def maxpool_tf(x, kernel, stride):
+    """ConstantPad3d(0) then MaxPool3d(ceil_mode=True).  models/i3dpt.py:114-126.
+    The padded taps carry the VALUE 0 (not -inf)."""
+    return F.max_pool3d(_pad3d(x, tf_same_pad(kernel, stride)), kernel, stride, ceil_mode=True)
+
+
+def mixed(x, sd, prefix):
+    """Inception block, concat order b0,b1,b2,b3.  models/i3dpt.py:129-163."""
+    b0 = unit3d(x, sd, prefix + ".branch_0")
+    b1 = unit3d(unit3d(x, sd, prefix + ".branch_1.0"), sd, prefix + ".branch_1.1")
+    b2 = unit3d(unit3d(x, sd, prefix + ".branch_2.0"), sd, prefix + ".branch_2.1")
+    b3 = unit3d(maxpool_tf(x, (3, 3, 3), (1, 1, 1)), sd, prefix + ".branch_3.1")
+    return torch.cat((b0, b1, b2, b3), 1)
+
+
+def basenet_forward(images, sd, prefix="base_model", return_stages=False):
+    """images [N,T,3,H,W] -> conv_feat [N,T',832,H',W'].  models/networks.py:69-83."""
+    x = images.permute(0, 2, 1, 3, 4)
+    stages = []
+    for kind, idx, args in BACKBONE:
+        p = "%s.%d" % (prefix, idx)
+        if kind == "conv":
+            x = unit3d(x, sd, p, stride=args[3])
+        elif kind == "pool":
+            x = maxpool_tf(x, args[0], args[1])
+        else:
+            x = mixed(x, sd, p)
+        stages.append(x)
+    out = x.permute(0, 2, 1, 3, 4)
+    return (out, stages) if return_stages else out
+
+
+def contextnet_forward(conv_feat, sd, prefix="i3d_conv_context"):
+    """conv_feat [B,T,832,25,25] -> [B,1024,T,1,1].  models/two_branch.py:113-138."""
+    x = conv_feat.permute(0, 2, 1, 3, 4)
+    x = maxpool_tf(x, (1, 3, 3), (1, 2, 2))
+    x = mixed(x, sd, prefix + ".1")
+    x = mixed(x, sd, prefix + ".2")
+    return F.avg_pool3d(x, (1, 13, 13), (1, 1, 1))
+
+
+def roinet_forward(conv_feat, tubes, pool_mode="align", pool_size=7):
+    """conv_feat [B,T,C,H,W] (contiguous), tubes [N,T,5] -> [N*T,C,7,7].  models/networks.py:35-47
+    through the C oracle (cpu/ROIAlign_cpu.cpp / cuda/ROIPool_cuda.cu)."""
+    B, T, C, H, W = conv_feat.shape
+    feat = conv_feat.reshape(-1, C, H, W).contiguous().numpy()
+    rois = tubes.reshape(-1, 5).contiguous().numpy()
+    if pool_mode == "align":
+        out = _roi_align_c(feat, rois, (pool_size, pool_size), 1.0 / 16.0, 0)
+    else:
+        out, _ = _roi_pool_c(feat, rois, (pool_size, pool_size), 1.0 / 16.0)
+    return torch.from_numpy(out)
+
+
+# utils/tube_utils.py:127-189
+def center_size(boxes):
+    w = boxes[:, 2] - boxes[:, 0] + 1.0
+    h = boxes[:, 3] - boxes[:, 1] + 1.0
+    return boxes[:, 0] + 0.5 * w, boxes[:, 1] + 0.5 * h, w, h
+
+
+def encode_coef(gt, tubes):
+    gx, gy, gw, gh = center_size(gt)
+    x, y, w, h = center_size(tubes)
+    return torch.stack(((gx - x) / w, (gy - y) / h, torch.log(gw / w), torch.log(gh / h)), dim=1)
+
+
+def decode_coef(anchors, deltas):
+    x, y, w, h = center_size(anchors)
+    px = w * deltas[:, 0] + x
+    py = h * deltas[:, 1] + y
+    pw = w * torch.exp(deltas[:, 2])
+    ph = h * torch.exp(deltas[:, 3])
+    return torch.stack((px - 0.5 * pw, py - 0.5 * ph, px + 0.5 * pw - 1, py + 0.5 * ph - 1), dim=1)
+
+
+def _bottleneck(x, sd, p, resample):
+    """models/two_branch.py:60-111 (2-D, no BN, no bias)."""
+    if resample:
+        res = F.conv2d(x, sd[p + ".conv1.weight"])
+        y = F.relu(F.conv2d(x, sd[p + ".conv2.weight"]))
+        y = F.relu(F.conv2d(y, sd[p + ".conv3.weight"], padding=1))
+        y = F.conv2d(y, sd[p + ".conv4.weight"])
+    else:
+        res = x
+        y = F.relu(F.conv2d(x, sd[p + ".conv1.weight"]))
+        y = F.relu(F.conv2d(y, sd[p + ".conv2.weight"], padding=1))
+        y = F.conv2d(y, sd[p + ".conv3.weight"])
+    return F.relu(y + res)
+
+
+def twobranch_forward(global_feat, context_feat, sd, T=3, cls_only=False, tubes=None, targets=None):
+    """Eval-mode (dropout off) restatement of TwoBranchNet.forward, models/two_branch.py:205-342.
+    global_feat [N,Tl,832,7,7]; context_feat [N,1024,Tl,1,1] or None.
+    Returns (global_prob, local_loc, first_loc, last_loc, loss_cls, loss_loc, loss_nbr)."""
+    N, Tl, C, W, H = global_feat.shape
+    chunks = int(Tl / T)
+    chunk_idx = [j * T + int(T / 2) for j in range(chunks)]
+    half = int(T / 2)
+
+    g = global_feat.permute(0, 2, 1, 3, 4)
+    g = mixed(mixed(g, sd, "i3d_conv.0"), sd, "i3d_conv.1")                    # :235
+    g = F.conv3d(g, sd["downsample.weight"], sd["downsample.bias"])             # :236
+    flat = g.permute(0, 2, 1, 3, 4).contiguous().view(N, Tl, -1, 1, 1)          # :239
+    flat = flat.permute(0, 2, 1, 3, 4).contiguous()                             # :240
+    if context_feat is not None:
+        flat = torch.cat([flat, context_feat], dim=1)                           # :243
+    logits = F.conv3d(flat, sd["global_cls.weight"], sd["global_cls.bias"])     # :246
+    logits = logits.squeeze(3).squeeze(3).mean(2)                               # :247-249
+
+    zero = torch.tensor([0.0])
+    local_loc, first_loc, last_loc = zero, zero, zero
+    if not cls_only:
+        lf = torch.cat([global_feat.permute(0, 2, 1, 3, 4), g], dim=1)          # :255-256
+        lf = lf.permute(0, 2, 1, 3, 4).contiguous().view(N * Tl, -1, W, H)      # :258
+        lf = _bottleneck(lf, sd, "local_conv.0", True)
+        lf = _bottleneck(lf, sd, "local_conv.1", False)
+        lf = _bottleneck(lf, sd, "local_conv.2", False)
+        lf = F.conv2d(lf, sd["downsample2.weight"], sd["downsample2.bias"])     # :260
+        lf = lf.reshape(lf.size(0), -1)                                         # :262
+        local_loc = F.linear(lf, sd["local_reg.weight"], sd["local_reg.bias"]).view(N, Tl, -1)
+        lo, hi = chunk_idx[0] - half, chunk_idx[0] + half + 1
+        lo2, hi2 = chunk_idx[-1] - half, chunk_idx[-1] + half + 1
+        lfv = lf.view(N, Tl, -1)
+        first_loc = local_loc[:, lo:hi] + F.linear(lfv[:, lo:hi].reshape(N * T, -1), sd["neighbor_reg1.weight"],
+                                                   sd["neighbor_reg1.bias"]).view(N, T, -1)   # :265-269
+        last_loc = local_loc[:, lo2:hi2] + F.linear(lfv[:, lo2:hi2].reshape(N * T, -1), sd["neighbor_reg2.weight"],
+                                                    sd["neighbor_reg2.bias"]).view(N, T, -1)  # :266-270
+        center_pred = local_loc[:, chunk_idx[int(chunks / 2)]].reshape(N, -1)
+        first_pred = first_loc[:, half].reshape(N, -1)
+        last_pred = last_loc[:, half].reshape(N, -1)
+
+    loss_cls = torch.tensor(0.0)
+    loss_loc = torch.tensor(0.0)
+    loss_nbr = torch.tensor(0.0)
+    if targets is not None:                                                      # :281-333
+        ct, ft, lt = targets[:, 1], targets[:, 0], targets[:, -1]
+        ctube = tubes[:, chunk_idx[int(chunks / 2)]]
+        ftube = tubes[:, chunk_idx[0]]
+        ltube = tubes[:, chunk_idx[-1]]
+        m = ct[:, 4].view(-1, 1)
+        if m.sum():
+            loss_cls = F.binary_cross_entropy_with_logits(logits, ct[:, 6:] * m, reduction="none")
+        if not cls_only:
+            tgt = encode_coef(ct[:, :4], ctube.reshape(-1, 5)[:, 1:])
+            m = ct[:, 5].view(-1, 1).repeat(1, 4)
+            if m.sum():
+                loss_loc = (F.smooth_l1_loss(center_pred, tgt, reduction="none") * m).sum() / m.sum()
+            ntgt = encode_coef(torch.cat([ft[:, :4], lt[:, :4]], 0),
+                               torch.cat([ftube.reshape(-1, 5)[:, 1:], ltube.reshape(-1, 5)[:, 1:]], 0))
+            nm = torch.cat([ft[:, 5].view(-1, 1).repeat(1, 4), lt[:, 5].view(-1, 1).repeat(1, 4)], 0)
+            if nm.sum():
+                npred = torch.cat([first_pred, last_pred], 0)
+                loss_nbr = (F.smooth_l1_loss(npred, ntgt, reduction="none") * nm).sum() / nm.sum()
+    return (torch.sigmoid(logits), local_loc, first_loc, last_loc,
+            loss_cls.view(-1), loss_loc.view(-1), loss_nbr.view(-1))
+
+
+# ---------------------------------------------------------------------------------------------
+# Step driver restatement (utils/utils.py:15-131), eval mode, numpy host glue kept as in the
+# reference.  nets_sd = {'det_net0': sd, 'det_net1': sd, ...}.
+def flatten_tubes(tubes_list):
+    """utils/tube_utils.py:214-246 with batch_idx=True."""
+    T = tubes_list[0].shape[1]
+    flat, nums = [], []
+    for i, t in enumerate(tubes_list):
+        nums.append(t.shape[0])
+        if t.shape[0] == 0:
+            continue
+        idx = np.tile((np.arange(T) + i * T).reshape(1, T, 1), (t.shape[0], 1, 1)).astype(t.dtype)
+        flat.append(np.concatenate((idx, t.copy()), axis=2))
+    return np.concatenate(flat, axis=0), nums
+
+
+def valid_tubes(tubes, width=400, height=400):
+    """utils/tube_utils.py:59-92."""
+    n, T, _ = tubes.shape
+    b = tubes.reshape(-1, 4)
+    b[:, 0] = np.maximum(0, b[:, 0])
+    b[:, 1] = np.maximum(0, b[:, 1])
+    b[:, 2] = np.minimum(width, b[:, 2])
+    b[:, 3] = np.minimum(height, b[:, 3])
+    bad = ~((b[:, 0] < b[:, 2] - 2) & (b[:, 1] < b[:, 3] - 2))
+    b[bad, 0] = 0
+    b[bad, 1] = 0
+    b[bad, 2] = width
+    b[bad, 3] = height
+    return b.reshape(n, T, 4)
+
+
+def inference(conv_feat, context_feat, nets_sd, tubes_list, T=3, num_chunks=None, max_iter=3,
+              image_size=(400, 400), num_classes=60, pool_mode="align"):
+    """temporal_mode == 'predict' only (what the shipped scripts use)."""
+    num_chunks = num_chunks or {1: 1, 2: 1, 3: 3}
+    flat, nums = flatten_tubes(tubes_list)
+    flat = torch.from_numpy(flat.astype(np.float32))
+    history = []
+    for i in range(1, max_iter + 1):
+        chunks = num_chunks[i]
+        t0 = int((num_chunks[max_iter] - chunks) / 2) * T
+        tl = chunks * T
+        cidx = [j * T + int(T / 2) for j in range(chunks)]
+        half = int(T / 2)
+        pooled = roinet_forward(conv_feat[:, t0:t0 + tl].contiguous(), flat, pool_mode)
+        pooled = pooled.view(-1, tl, *pooled.shape[1:])
+        ctx = None
+        if context_feat is not None:
+            bidx = (flat[:, 0, 0] / tl).to(torch.int64)           # utils.py:57 int(idx/T_length)
+            ctx = context_feat[bidx][:, :, t0:t0 + tl].contiguous()
+        prob, loc, first, last, _, _, _ = twobranch_forward(pooled, ctx, nets_sd["det_net%d" % (i - 1)], T=T)
+        pred_prob = prob.view(-1, 1, num_classes).expand(-1, tl, -1)
+        pred_loc = decode_coef(flat.view(-1, 5)[:, 1:], loc.reshape(-1, 4)).view(loc.shape)
+        pf = decode_coef(flat[:, cidx[0] - half:cidx[0] + half + 1].reshape(-1, 5)[:, 1:],
+                         first.reshape(-1, 4)).view(first.shape)
+        pl = decode_coef(flat[:, cidx[-1] - half:cidx[-1] + half + 1].reshape(-1, 5)[:, 1:],
+                         last.reshape(-1, 4)).view(last.shape)
+        history.append({"pred_prob": pred_prob, "pred_loc": pred_loc, "pred_first_loc": pf,
+                        "pred_last_loc": pl, "tubes_nums": list(nums)})
+        sel, cnt = [], 0
+        for b in range(len(nums)):
+            s, cnt = cnt, cnt + nums[b]
+            cur = pred_loc[s:cnt]
+            if i < max_iter and num_chunks[i + 1] == num_chunks[i] + 2:
+                cur = torch.cat([pf[s:cnt], cur, pl[s:cnt]], dim=1)
+            sel.append(valid_tubes(cur.numpy().copy(), image_size[0], image_size[1]))
+        flat, nums = flatten_tubes(sel)
+        flat = torch.from_numpy(flat.astype(np.float32))
+    return history
+
+
+# ---------------------------------------------------------------------------------------------
+# Deterministic closed-form fillers: a pure function of (name, flat index), independent of any RNG
+# stream, so the fixture generator (reference side) and the tests (our side) build identical
+# weights and inputs without shipping them.
+def _hash01(n, seed):
+    i = np.arange(n, dtype=np.float64)
+    v = np.sin(i * 12.9898 + seed * 78.233 + 0.5) * 43758.5453
+    return v - np.floor(v)
+
+
+def _seed(name):
+    return float(zlib.crc32(name.encode()) % 9973) + 1.0
+
+
+def fill_tensor(name, shape, kind):
+    n = int(np.prod(shape)) if len(shape) else 1
+    u = _hash01(n, _seed(name)) * 2.0 - 1.0           # U(-1,1)
+    if kind == "conv":                                 # He-uniform on fan_in keeps activations O(1)
+        fan_in = int(np.prod(shape[1:]))
+        v = u * math.sqrt(6.0 / fan_in)
+    elif kind == "fc":
+        fan_in = int(np.prod(shape[1:]))
+        v = u * math.sqrt(3.0 / fan_in) * 0.04          # small box deltas, as a trained regressor gives
+    elif kind == "bias":
+        v = u * 0.05
+    elif kind == "bn_gamma":
+        v = 1.0 + 0.1 * u
+    elif kind == "bn_beta":
+        v = 0.05 * u
+    elif kind == "bn_mean":
+        v = 0.1 * u
+    elif kind == "bn_var":
+        v = 1.0 + 0.25 * u
+    elif kind == "image":
+        v = u
+    elif kind == "feat":                               # post-ReLU-like feature map
+        v = np.maximum(u, 0.0) * 1.5
+    else:
+        raise ValueError(kind)
+    return torch.from_numpy(np.asarray(v, dtype=np.float32).reshape(shape))
+
+
+def fill_state_dict(shapes, tag=""):
+    """shapes: {key: shape}.  Returns {key: tensor} using the closed-form filler."""
+    sd = {}
+    for k, shp in shapes.items():
+        shp = tuple(shp)
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros((), dtype=torch.int64)
+            continue
+        if "batch3d." in k:
+            kind = {"weight": "bn_gamma", "bias": "bn_beta", "running_mean": "bn_mean",
+                    "running_var": "bn_var"}[k.rsplit(".", 1)[1]]
+        elif k.endswith(".bias"):
+            kind = "bias"
+        elif len(shp) == 2:
+            kind = "fc"
+        else:
+            kind = "conv"
+        sd[k] = fill_tensor(tag + k, shp, kind)
+    return sd
+
+
+def backbone_shapes(prefix="base_model"):
+    """state_dict key -> shape for BaseNet (270 keys)."""
+    out = {}
+
+    def unit(p, ci, co, k):
+        out[p + ".conv3d.weight"] = (co, ci) + tuple(k)
+        for s in ("weight", "bias", "running_mean", "running_var"):
+            out[p + ".batch3d." + s] = (co,)
+        out[p + ".batch3d.num_batches_tracked"] = ()
+
+    def mix(p, ci, oc):
+        unit(p + ".branch_0", ci, oc[0], (1, 1, 1))
+        unit(p + ".branch_1.0", ci, oc[1], (1, 1, 1))
+        unit(p + ".branch_1.1", oc[1], oc[2], (3, 3, 3))
+        unit(p + ".branch_2.0", ci, oc[3], (1, 1, 1))
+        unit(p + ".branch_2.1", oc[3], oc[4], (3, 3, 3))
+        unit(p + ".branch_3.1", ci, oc[5], (1, 1, 1))
+
+    for kind, idx, args in BACKBONE:
+        p = "%s.%d" % (prefix, idx)
+        if kind == "conv":
+            unit(p, args[0], args[1], args[2])
+        elif kind == "mixed":
+            mix(p, args[0], args[1])
+    return out
+
+
+def head_i3d_shapes(prefix, first_index):
+    """5b/5c pair: prefix.<first_index>, prefix.<first_index+1>."""
+    out = {}
+    for j, (ci, oc) in enumerate((MIXED_5B, MIXED_5C)):
+        p = "%s.%d" % (prefix, first_index + j)
+        for name, a, b, k in (("branch_0", ci, oc[0], 1), ("branch_1.0", ci, oc[1], 1), ("branch_1.1", oc[1], oc[2], 3),
+                              ("branch_2.0", ci, oc[3], 1), ("branch_2.1", oc[3], oc[4], 3), ("branch_3.1", ci, oc[5], 1)):
+            q = p + "." + name
+            out[q + ".conv3d.weight"] = (b, a, k, k, k)
+            for s in ("weight", "bias", "running_mean", "running_var"):
+                out[q + ".batch3d." + s] = (b,)
+            out[q + ".batch3d.num_batches_tracked"] = ()
+    return out
+
+
+def context_shapes():
+    return head_i3d_shapes("i3d_conv_context", 1)
+
+
+def twobranch_shapes(fc_dim=256, pool_size=7, num_classes=60, no_context=False, cls_only=False):
+    out = head_i3d_shapes("i3d_conv", 0)
+    out["downsample.weight"] = (fc_dim, 1024, 1, 1, 1)
+    out["downsample.bias"] = (fc_dim,)
+    cin = fc_dim * pool_size ** 2 + (0 if no_context else 1024)
+    out["global_cls.weight"] = (num_classes, cin, 1, 1, 1)
+    out["global_cls.bias"] = (num_classes,)
+    if not cls_only:
+        out["local_conv.0.conv1.weight"] = (1024, 832 + fc_dim, 1, 1)
+        out["local_conv.0.conv2.weight"] = (256, 832 + fc_dim, 1, 1)
+        out["local_conv.0.conv3.weight"] = (256, 256, 3, 3)
+        out["local_conv.0.conv4.weight"] = (1024, 256, 1, 1)
+        for j in (1, 2):
+            out["local_conv.%d.conv1.weight" % j] = (256, 1024, 1, 1)
+            out["local_conv.%d.conv2.weight" % j] = (256, 256, 3, 3)
+            out["local_conv.%d.conv3.weight" % j] = (1024, 256, 1, 1)
+        out["downsample2.weight"] = (fc_dim, 1024, 1, 1)
+        out["downsample2.bias"] = (fc_dim,)
+        for nme in ("local_reg", "neighbor_reg1", "neighbor_reg2"):
+            out[nme + ".weight"] = (4, fc_dim * pool_size ** 2)
+            out[nme + ".bias"] = (4,)
+    return out
+
+
+def anchors(scales=(4.0 / 3.0, 2.0), overlaps=(5.0 / 6.0, 3.0 / 4.0)):
+    """data/data_utils.py:19-45 (34 anchors for the default mode "1")."""
+    out = []
+    for scale, overlap in zip(scales, overlaps):
+        size = 1.0 / scale
+        stride = size * (1 - overlap)
+        i = 0
+        while i + size <= 1:
+            j = 0
+            while j + size <= 1:
+                out.append([i, j, i + size, j + size])
+                j += stride
+            i += stride
+    return np.asarray(out, dtype=np.float32)

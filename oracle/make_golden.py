@@ -1,0 +1,302 @@
+"""oracle/make_golden.py -- generate tests/golden/*.npz FROM THE REFERENCE ITSELF.
+
+Runs only where /root/reference exists (the build container).  It imports the reference's Python
+(models/, utils/) from where it lies, with
+  * empty stand-in modules for `torchvision` and `cv2` (imported by models/networks.py:11 and
+    data/data_utils.py:9 but never used on this path), and
+  * `external.maskrcnn_benchmark.roi_layers._C` = oracle/_ref/_C.so, the reference's own C++ CPU
+    operators compiled from its sources (make -C oracle ref),
+fills every parameter/buffer with the closed-form filler of oracle/i3d_ref.py (a pure function
+of the state_dict key and the flat index -- no RNG stream, no weights shipped), runs the reference
+and stores inputs that cannot be regenerated plus the expected outputs.
+
+The fixtures are data only (inputs and outputs); no reference source text is stored.
+
+    python -m oracle.make_golden            # from the repo root
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("STEP_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def import_reference():
+    from oracle import load_reference_C
+
+    sys.path.insert(0, REF)
+    sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    sys.modules["external.maskrcnn_benchmark.roi_layers._C"] = load_reference_C()
+    import models  # noqa: F401  (reference)
+    import utils.utils as ref_utils  # reference
+
+    # On CPU tensors `pred_loc.cpu().numpy()` (utils/utils.py:107-120) ALIASES the tensor stored in
+    # `history`, so the in-place clamping of valid_tubes (utils/tube_utils.py:73-92) would overwrite the
+    # recorded predictions -- an artefact of running the reference on CPU; on its real (GPU) path
+    # `.cpu()` copies.  Give valid_tubes a copy so that the fixtures record what the GPU path records.
+    _vt = ref_utils.valid_tubes
+    ref_utils.valid_tubes = lambda tubes, **kw: _vt(tubes.copy(), **kw)
+    from external.maskrcnn_benchmark.roi_layers import nms, ROIAlign  # reference python API
+    return models, ref_utils, nms, ROIAlign
+
+
+def cfg(**kw):
+    base = dict(base_net="i3d", kinetics_pretrain=None, freeze_stats=True, freeze_affine=True, fp16=False, T=3,
+                num_classes=60, fc_dim=256, dropout=0.0, pool_size=7, no_context=False, max_iter=3,
+                NUM_CHUNKS={1: 1, 2: 1, 3: 3, 4: 3}, temporal_mode="predict", image_size=(400, 400),
+                pool_mode="align")
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def fill_module(mod, tag=""):
+    from oracle.i3d_ref import fill_state_dict
+
+    shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+    mod.load_state_dict(fill_state_dict(shapes, tag))
+    return shapes
+
+
+def stage_digest(t):
+    """Small digest of a big activation: stats + a strided 256-element sample."""
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // 256)
+    return {"mean": float(f.double().mean()), "absmax": float(f.abs().max()), "l2": float(f.double().norm()),
+            "step": step, "sample": f[::step][:256].numpy().copy()}
+
+
+def main():
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    models, ref_utils, ref_nms, RefROIAlign = import_reference()
+    from oracle import i3d_ref as R
+    C = sys.modules["external.maskrcnn_benchmark.roi_layers._C"]
+    keyinfo = {}
+
+    # ---------------------------------------------------------------- 1. ROIAlign fwd + NMS (reference C++)
+    g = {}
+    feat = R.fill_tensor("golden.roi.feat", (3, 6, 25, 25), "image")
+    rois = np.array([
+        [0, 0, 0, 400, 400],            # whole frame -> 4x4 samples per bin
+        [1, 100.3, 57.9, 101.0, 58.2],  # < 1 px -> forced 1x1
+        [2, 310.5, 200.25, 400, 399.5], # touches x=400
+        [0, 13.7, 91.2, 250.9, 333.3],  # fractional
+        [1.0, -40, -30, 90, 120],       # partly outside (negative)
+        [2.0, 350, 350, 470, 520],      # partly outside (beyond)
+        [0, -200, -200, -100, -100],    # fully outside: every sample void
+        [1, 200, 100, 100, 50],         # malformed (x2<x1): max(size,1)
+        [2, 0, 0, 15.99, 15.99],        # first cell only
+        [0, 384, 384, 400, 400],        # last cell, clamps y_low>=H-1
+    ], dtype=np.float32)
+    g["align_rois"] = rois
+    for tag, pooled, sr in (("p7s0", (7, 7), 0), ("p7s2", (7, 7), 2), ("p3x5s0", (3, 5), 0)):
+        out = C.roi_align_forward(feat, torch.from_numpy(rois), 1.0 / 16.0, pooled[0], pooled[1], sr)
+        g["align_out_" + tag] = out.numpy()
+    out0 = C.roi_align_forward(feat, torch.zeros((0, 5)), 1.0 / 16.0, 7, 7, 0)
+    assert out0.shape == (0, 6, 7, 7)
+    # the python-level reference API on a tube-shaped call (networks.py:44)
+    rs = np.random.RandomState(7)
+    conv = R.fill_tensor("golden.roi.conv", (2, 3, 16, 25, 25), "feat")
+    tubes = []
+    for b in range(2):
+        for _ in range(4):
+            x1, y1 = rs.uniform(0, 300, 2)
+            w, h = rs.uniform(20, 99, 2)
+            for t in range(3):
+                dx, dy = rs.uniform(-6, 6, 2)
+                tubes.append([b * 3 + t, x1 + dx, y1 + dy, x1 + dx + w, y1 + dy + h])
+    tubes = np.asarray(tubes, np.float32).reshape(8, 3, 5)
+    g["tube_rois"] = tubes
+    g["tube_out"] = RefROIAlign((7, 7), 1.0 / 16.0, 0)(conv.view(-1, 16, 25, 25), torch.from_numpy(tubes).view(-1, 5)).numpy()
+
+    def rand_boxes(n, rs, span=400.0):
+        xy = rs.uniform(0, span * 0.7, (n, 2))
+        wh = rs.uniform(8, span * 0.5, (n, 2))
+        return np.concatenate([xy, np.minimum(xy + wh, span)], 1).astype(np.float32)
+
+    nms_cases = []
+    for n, thr in ((34, 0.4), (11, 0.4), (200, 0.5), (1, 0.4), (64, 0.3), (65, 0.7), (129, 0.4)):
+        b = rand_boxes(n, rs)
+        s = rs.permutation(n).astype(np.float32) / n + 0.001      # tie-free
+        nms_cases.append((b, s, thr))
+    # clustered boxes (heavy suppression)
+    base = rand_boxes(6, rs)
+    b = np.repeat(base, 10, 0) + rs.uniform(-6, 6, (60, 4)).astype(np.float32)
+    nms_cases.append((b.astype(np.float32), (rs.permutation(60).astype(np.float32) + 1) / 61, 0.4))
+    # threshold equality: IoU of these two boxes is exactly 0.5 (areas 100 and 50, inter 50):  >= suppresses
+    b = np.array([[0, 0, 9, 9], [0, 0, 9, 4], [50, 50, 59, 59]], np.float32)
+    nms_cases.append((b, np.array([0.9, 0.8, 0.7], np.float32), 0.5))
+    # identical boxes, distinct scores
+    b = np.tile(np.array([[10, 10, 50, 60]], np.float32), (5, 1))
+    nms_cases.append((b, np.array([0.1, 0.5, 0.3, 0.9, 0.2], np.float32), 0.4))
+    for i, (b, s, thr) in enumerate(nms_cases):
+        keep = ref_nms(torch.from_numpy(b), torch.from_numpy(s), thr)
+        assert keep.dtype == torch.int64
+        g["nms%d_boxes" % i], g["nms%d_scores" % i] = b, s
+        g["nms%d_thr" % i] = np.float32(thr)
+        g["nms%d_keep" % i] = keep.numpy()
+    g["nms_count"] = np.int64(len(nms_cases))
+    assert ref_nms(torch.zeros((0, 4)), torch.zeros((0,)), 0.4).numel() == 0
+    np.savez_compressed(os.path.join(OUT, "roi_nms_golden.npz"), **g)
+    print("roi_nms_golden: %d arrays" % len(g))
+
+    # ---------------------------------------------------------------- 2. C1: BaseNet on [1,8,3,112,112]
+    base = models.BaseNet(cfg())
+    keyinfo["BaseNet"] = {k: list(v) for k, v in fill_module(base).items()}
+    keyinfo["BaseNet_trainable"] = [k for k, p in base.named_parameters() if p.requires_grad]
+    base.eval()
+    g = {}
+    x = R.fill_tensor("golden.c1.images", (1, 8, 3, 112, 112), "image")
+    stages = []
+    hooks = [m.register_forward_hook(lambda _m, _i, o: stages.append(o)) for m in base.base_model]
+    with torch.no_grad():
+        y = base(x)
+    for h in hooks:
+        h.remove()
+    assert tuple(y.shape) == (1, 2, 832, 7, 7)
+    g["conv_feat"] = y.contiguous().numpy()
+    for i, s in enumerate(stages):
+        d = stage_digest(s)
+        g["stage%d_shape" % i] = np.asarray(s.shape)
+        g["stage%d_stats" % i] = np.asarray([d["mean"], d["absmax"], d["l2"], d["step"]], np.float64)
+        g["stage%d_sample" % i] = d["sample"]
+    np.savez_compressed(os.path.join(OUT, "i3d_c1_golden.npz"), **g)
+    print("i3d_c1_golden ok, absmax out %.4f" % float(y.abs().max()))
+
+    # ---------------------------------------------------------------- 3. single ops: pools, one Mixed, one unit
+    from models.i3dpt import MaxPool3dTFPadding, Mixed, Unit3Dpy
+    g = {}
+    xin = R.fill_tensor("golden.pool.in", (2, 5, 6, 9, 11), "image")      # has negative values
+    for tag, k, s in (("k133s122", (1, 3, 3), (1, 2, 2)), ("k333s222", (3, 3, 3), (2, 2, 2)),
+                      ("k333s111", (3, 3, 3), (1, 1, 1)), ("k222s222", (2, 2, 2), (2, 2, 2))):
+        g["pool_" + tag] = MaxPool3dTFPadding(k, s)(xin).numpy()
+    g["pool_allneg"] = MaxPool3dTFPadding((3, 3, 3), (2, 2, 2))(-torch.ones(1, 1, 4, 5, 5)).numpy()
+    mx = Mixed(24, [8, 12, 16, 4, 8, 8])
+    keyinfo["Mixed_small"] = {k: list(v) for k, v in fill_module(mx, "golden.mixed.").items()}
+    mx.eval()
+    xm = R.fill_tensor("golden.mixed.in", (2, 24, 3, 9, 7), "feat")
+    with torch.no_grad():
+        g["mixed_out"] = mx(xm).numpy()
+    for tag, ci, co, k, s, shp in (("stem", 3, 16, (7, 7, 7), (2, 2, 2), (1, 3, 9, 21, 19)),
+                                   ("k3", 20, 24, (3, 3, 3), (1, 1, 1), (2, 20, 3, 6, 7)),
+                                   ("k1", 20, 12, (1, 1, 1), (1, 1, 1), (2, 20, 3, 6, 7))):
+        u = Unit3Dpy(ci, co, kernel_size=k, stride=s)
+        fill_module(u, "golden.unit." + tag + ".")
+        u.eval()
+        with torch.no_grad():
+            g["unit_%s_out" % tag] = u(R.fill_tensor("golden.unit.%s.in" % tag, shp, "image")).numpy()
+    np.savez_compressed(os.path.join(OUT, "ops_golden.npz"), **g)
+    print("ops_golden ok")
+
+    # ---------------------------------------------------------------- 4. heads: ContextNet, TwoBranchNet (+losses)
+    g = {}
+    ctx = models.ContextNet(cfg())
+    keyinfo["ContextNet"] = {k: list(v) for k, v in fill_module(ctx).items()}
+    ctx.eval()
+    cf = R.fill_tensor("golden.ctx.feat", (1, 3, 832, 25, 25), "feat")
+    with torch.no_grad():
+        g["context_out"] = ctx(cf).numpy()
+    det = models.TwoBranchNet(cfg())
+    keyinfo["TwoBranchNet"] = {k: list(v) for k, v in fill_module(det, "det0.").items()}
+    keyinfo["TwoBranchNet_trainable"] = [k for k, p in det.named_parameters() if p.requires_grad]
+    det_cls = models.TwoBranchNet(cfg(), cls_only=True)
+    keyinfo["TwoBranchNet_cls_only"] = {k: list(v.shape) for k, v in det_cls.state_dict().items()}
+    det.set_device("cpu")
+    det.eval()
+    for tl in (3, 9):
+        pf = R.fill_tensor("golden.det.pooled%d" % tl, (2, tl, 832, 7, 7), "feat")
+        cx = R.fill_tensor("golden.det.ctx%d" % tl, (2, 1024, tl, 1, 1), "feat")
+        with torch.no_grad():
+            o = det(pf, context_feat=cx)
+        for nme, t in zip(("prob", "loc", "first", "last"), o[:4]):
+            g["det_T%d_%s" % (tl, nme)] = t.numpy()
+    # losses, Tl = 3
+    pf = R.fill_tensor("golden.det.pooled3", (2, 3, 832, 7, 7), "feat")
+    cx = R.fill_tensor("golden.det.ctx3", (2, 1024, 3, 1, 1), "feat")
+    tubes = np.zeros((2, 3, 5), np.float32)
+    tubes[0, :, 1:] = [60, 80, 220, 300]
+    tubes[1, :, 1:] = [150, 40, 330, 280]
+    tubes[:, :, 0] = np.arange(3)[None]
+    targets = np.zeros((2, 3, 66), np.float32)
+    targets[0, :, :4] = [[70, 85, 215, 310], [72, 86, 230, 305], [75, 90, 226, 300]]
+    targets[1, :, :4] = [[140, 50, 320, 270], [150, 45, 335, 290], [149, 38, 340, 284]]
+    targets[:, :, 4] = [[1, 1, 1], [0, 0, 0]]      # cls indicator (second tube = background)
+    targets[:, :, 5] = [[1, 1, 0], [1, 1, 1]]      # regression indicator
+    targets[0, :, 6 + 3] = 1
+    targets[0, :, 6 + 17] = 1
+    targets[1, :, 6 + 40] = 1
+    g["loss_tubes"], g["loss_targets"] = tubes, targets
+    with torch.no_grad():
+        o = det(pf, context_feat=cx, tubes=torch.from_numpy(tubes), targets=torch.from_numpy(targets))
+    g["loss_cls"], g["loss_loc"], g["loss_nbr"] = o[4].numpy(), o[5].numpy(), o[6].numpy()
+    np.savez_compressed(os.path.join(OUT, "head_golden.npz"), **g)
+    print("head_golden ok; losses", o[4].mean().item(), o[5].item(), o[6].item())
+
+    # ---------------------------------------------------------------- 5. reference inference() on a synthetic conv_feat
+    g = {}
+    args = cfg()
+    nets = {"roi_net": models.ROINet("align", 7)}
+    for i in range(3):
+        d = models.TwoBranchNet(args)
+        fill_module(d, "det%d." % i)
+        d.set_device("cpu")
+        d.eval()
+        nets["det_net%d" % i] = d
+    anchors = R.anchors()
+    assert anchors.shape == (34, 4)
+    keyinfo["anchors34"] = anchors.tolist()
+    for ntubes in (11, 34):
+        conv_feat = R.fill_tensor("golden.inf.feat", (2, 9, 832, 25, 25), "feat")
+        with torch.no_grad():
+            context = ctx(conv_feat)
+        tl = [np.tile((anchors[:ntubes] * 400.0)[:, None, :], (1, 3, 1)).astype(np.float32) for _ in range(2)]
+        # make clip 1 differ from clip 0
+        tl[1] = tl[1][::-1].copy()
+        with torch.no_grad():
+            history, _ = ref_utils.inference(args, conv_feat, context, nets, 3, [t.copy() for t in tl])
+        for i, h in enumerate(history):
+            for k in ("pred_prob", "pred_loc", "pred_first_loc", "pred_last_loc"):
+                a = h[k].numpy()
+                if k == "pred_prob":
+                    a = a[:, 0]                       # identical over T (expand)
+                g["n%d_step%d_%s" % (ntubes, i, k)] = a
+            g["n%d_step%d_nums" % (ntubes, i)] = np.asarray(h["tubes_nums"])
+        g["n%d_context" % ntubes] = context.numpy()
+    np.savez_compressed(os.path.join(OUT, "inference_golden.npz"), **g)
+    print("inference_golden ok")
+
+    # ---------------------------------------------------------------- 6. end to end, AVA-shaped clip (C3, B=1, 11 tubes)
+    g = {}
+    x = R.fill_tensor("golden.c3.images", (1, 36, 3, 400, 400), "image")
+    with torch.no_grad():
+        conv_feat = base(x)
+        context = ctx(conv_feat)
+        tl = [np.tile((anchors[:11] * 400.0)[:, None, :], (1, 3, 1)).astype(np.float32)]
+        history, _ = ref_utils.inference(args, conv_feat, context, nets, 3, tl)
+    assert tuple(conv_feat.shape) == (1, 9, 832, 25, 25)
+    d = stage_digest(conv_feat.contiguous())
+    g["conv_feat_stats"] = np.asarray([d["mean"], d["absmax"], d["l2"], d["step"]], np.float64)
+    g["conv_feat_sample"] = d["sample"]
+    g["conv_feat_slice"] = conv_feat[0, :, ::13, ::4, ::4].contiguous().numpy()
+    g["context"] = context.numpy()
+    for i, h in enumerate(history):
+        g["step%d_pred_prob" % i] = h["pred_prob"].numpy()[:, 0]
+        for k in ("pred_loc", "pred_first_loc", "pred_last_loc"):
+            g["step%d_%s" % (i, k)] = h[k].numpy()
+    np.savez_compressed(os.path.join(OUT, "e2e_c3_golden.npz"), **g)
+    print("e2e_c3_golden ok")
+
+    with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
+        json.dump(keyinfo, f, indent=0, sort_keys=True)
+    print("done ->", OUT)
+
+
+if __name__ == "__main__":
+    main()

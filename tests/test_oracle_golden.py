@@ -1,0 +1,202 @@
+"""The oracle (oracle/step_oracle.c, oracle/i3d_ref.py) against the golden vectors produced by the
+reference itself (oracle/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import i3d_ref as R
+
+from conftest import GOLDEN
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def test_roi_align_forward_bit_exact(golden):
+    g = golden("roi_nms_golden")
+    feat = R.fill_tensor("golden.roi.feat", (3, 6, 25, 25), "image").numpy()
+    for tag, pooled, sr in (("p7s0", (7, 7), 0), ("p7s2", (7, 7), 2), ("p3x5s0", (3, 5), 0)):
+        out = oracle.roi_align_forward(feat, g["align_rois"], pooled, 1.0 / 16.0, sr)
+        assert np.array_equal(out, g["align_out_" + tag]), tag
+    assert oracle.roi_align_forward(feat, np.zeros((0, 5), np.float32), (7, 7), 1 / 16., 0).shape == (0, 6, 7, 7)
+
+
+def test_roi_align_tube_call(golden):
+    g = golden("roi_nms_golden")
+    conv = R.fill_tensor("golden.roi.conv", (2, 3, 16, 25, 25), "feat")
+    out = R.roinet_forward(conv, torch.from_numpy(g["tube_rois"]))
+    assert np.array_equal(out.numpy(), g["tube_out"])
+
+
+def test_nms_bit_exact(golden):
+    g = golden("roi_nms_golden")
+    for i in range(int(g["nms_count"])):
+        keep = oracle.nms(g["nms%d_boxes" % i], g["nms%d_scores" % i], float(g["nms%d_thr" % i]))
+        assert keep.dtype == np.int64
+        assert np.array_equal(keep, g["nms%d_keep" % i]), i
+    assert oracle.nms(np.zeros((0, 4)), np.zeros((0,)), 0.4).size == 0
+
+
+def test_nms_threshold_equality_uses_ge(golden):
+    g = golden("roi_nms_golden")
+    # case 8 of make_golden: IoU == thr == 0.5 exactly; the CPU reference suppresses (>=)
+    i = 8
+    assert float(g["nms%d_thr" % i]) == 0.5
+    assert list(g["nms%d_keep" % i]) == [0, 2]
+
+
+def test_nms_batched_matches_single():
+    rs = np.random.RandomState(3)
+    G, kmax = 7, 40
+    boxes = np.zeros((G, kmax, 4), np.float32)
+    scores = np.zeros((G, kmax), np.float32)
+    counts = rs.randint(0, kmax + 1, G).astype(np.int32)
+    counts[0], counts[1] = 0, kmax
+    for gi in range(G):
+        xy = rs.uniform(0, 300, (kmax, 2))
+        wh = rs.uniform(10, 120, (kmax, 2))
+        boxes[gi] = np.concatenate([xy, xy + wh], 1)
+        scores[gi] = rs.permutation(kmax) / kmax
+    mask = oracle.nms_batched(boxes, scores, counts, 0.4)
+    for gi in range(G):
+        k = oracle.nms(boxes[gi, :counts[gi]], scores[gi, :counts[gi]], 0.4)
+        exp = np.zeros(kmax, np.uint8)
+        exp[k] = 1
+        assert np.array_equal(mask[gi], exp)
+
+
+def test_roi_align_backward_is_adjoint_of_forward():
+    rs = np.random.RandomState(0)
+    B, C, H, W = 3, 4, 25, 25
+    x = rs.randn(B, C, H, W).astype(np.float32)
+    rois = np.array([[0, 0, 0, 400, 400], [1, 33.3, 50.1, 180.7, 222.2], [2, -20, 300, 90, 450],
+                     [1, 100, 100, 100.5, 100.5], [0, 384, 384, 400, 400]], np.float32)
+    for sr in (0, 2):
+        y = oracle.roi_align_forward(x, rois, (7, 7), 1 / 16., sr)
+        g = rs.randn(*y.shape).astype(np.float32)
+        gx = oracle.roi_align_backward(g, rois, (7, 7), 1 / 16., sr, x.shape)
+        lhs = float((y.astype(np.float64) * g).sum())
+        rhs = float((x.astype(np.float64) * gx).sum())
+        assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+
+
+def test_roi_pool_hand_cases():
+    # 1 channel 4x4 ramp, scale 1: ROI (0,0,3,3) pooled 2x2 -> max of each 2x2 quadrant
+    x = np.arange(16, dtype=np.float32).reshape(1, 1, 4, 4)
+    out, arg = oracle.roi_pool_forward(x, np.array([[0, 0, 0, 3, 3]], np.float32), (2, 2), 1.0)
+    assert out.reshape(-1).tolist() == [5, 7, 13, 15]
+    assert arg.reshape(-1).tolist() == [5, 7, 13, 15]
+    # ROI entirely outside -> empty bins: value 0, argmax -1
+    out, arg = oracle.roi_pool_forward(x, np.array([[0, 10, 10, 12, 12]], np.float32), (2, 2), 1.0)
+    assert out.reshape(-1).tolist() == [0, 0, 0, 0] and arg.reshape(-1).tolist() == [-1] * 4
+    # round(): 0.5 rounds away from zero -> start 1
+    out, _ = oracle.roi_pool_forward(x, np.array([[0, 0.5, 0.5, 1.4, 1.4]], np.float32), (1, 1), 1.0)
+    assert out.reshape(-1).tolist() == [5]
+    g = np.ones((1, 1, 2, 2), np.float32)
+    _, arg = oracle.roi_pool_forward(x, np.array([[0, 0, 0, 3, 3]], np.float32), (2, 2), 1.0)
+    gi = oracle.roi_pool_backward(g, arg, np.array([[0, 0, 0, 3, 3]], np.float32), (2, 2), x.shape)
+    assert gi.sum() == 4 and gi.reshape(-1)[[5, 7, 13, 15]].tolist() == [1, 1, 1, 1]
+
+
+def test_shape_tables_match_reference_state_dicts():
+    info = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
+    for name, table in (("BaseNet", R.backbone_shapes()), ("ContextNet", R.context_shapes()),
+                        ("TwoBranchNet", R.twobranch_shapes()), ("TwoBranchNet_cls_only", R.twobranch_shapes(cls_only=True))):
+        ref = {k: tuple(v) for k, v in info[name].items()}
+        assert set(ref) == set(table), name
+        for k in ref:
+            assert tuple(table[k]) == ref[k], (name, k)
+    assert len(info["BaseNet"]) == 270 and len(info["ContextNet"]) == 72 and len(info["TwoBranchNet"]) == 94
+    assert np.allclose(R.anchors(), np.asarray(info["anchors34"], np.float32))
+
+
+def test_backbone_c1(golden):
+    g = golden("i3d_c1_golden")
+    sd = R.fill_state_dict(R.backbone_shapes())
+    x = R.fill_tensor("golden.c1.images", (1, 8, 3, 112, 112), "image")
+    with torch.no_grad():
+        y, stages = R.basenet_forward(x, sd, return_stages=True)
+    assert tuple(y.shape) == (1, 2, 832, 7, 7)
+    assert rel_err(y.contiguous().numpy(), g["conv_feat"]) < 1e-5
+    for i, s in enumerate(stages):
+        assert list(s.shape) == list(g["stage%d_shape" % i])
+        step = int(g["stage%d_stats" % i][3])
+        assert rel_err(s.reshape(-1)[::step][:256].numpy(), g["stage%d_sample" % i]) < 1e-5, i
+
+
+def test_single_ops(golden):
+    g = golden("ops_golden")
+    xin = R.fill_tensor("golden.pool.in", (2, 5, 6, 9, 11), "image")
+    for tag, k, s in (("k133s122", (1, 3, 3), (1, 2, 2)), ("k333s222", (3, 3, 3), (2, 2, 2)),
+                      ("k333s111", (3, 3, 3), (1, 1, 1)), ("k222s222", (2, 2, 2), (2, 2, 2))):
+        assert np.array_equal(R.maxpool_tf(xin, k, s).numpy(), g["pool_" + tag]), tag
+    # zero-valued (not -inf) padding: an all -1 input gives 0 where the window overhangs
+    out = R.maxpool_tf(-torch.ones(1, 1, 4, 5, 5), (3, 3, 3), (2, 2, 2)).numpy()
+    assert np.array_equal(out, g["pool_allneg"]) and out.max() == 0.0 and out.min() == -1.0
+    info = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
+    sd = R.fill_state_dict({k: tuple(v) for k, v in info["Mixed_small"].items()}, "golden.mixed.")
+    sd = {"m." + k: v for k, v in sd.items()}
+    xm = R.fill_tensor("golden.mixed.in", (2, 24, 3, 9, 7), "feat")
+    with torch.no_grad():
+        assert rel_err(R.mixed(xm, sd, "m").numpy(), g["mixed_out"]) < 1e-5
+    for tag, ci, co, k, s, shp in (("stem", 3, 16, (7, 7, 7), (2, 2, 2), (1, 3, 9, 21, 19)),
+                                   ("k3", 20, 24, (3, 3, 3), (1, 1, 1), (2, 20, 3, 6, 7)),
+                                   ("k1", 20, 12, (1, 1, 1), (1, 1, 1), (2, 20, 3, 6, 7))):
+        shapes = {"conv3d.weight": (co, ci) + k}
+        for nme in ("weight", "bias", "running_mean", "running_var"):
+            shapes["batch3d." + nme] = (co,)
+        sd = {"u." + kk: v for kk, v in R.fill_state_dict(shapes, "golden.unit." + tag + ".").items()}
+        with torch.no_grad():
+            y = R.unit3d(R.fill_tensor("golden.unit.%s.in" % tag, shp, "image"), sd, "u", stride=s)
+        assert rel_err(y.numpy(), g["unit_%s_out" % tag]) < 1e-5, tag
+
+
+def test_heads(golden):
+    g = golden("head_golden")
+    sdc = R.fill_state_dict(R.context_shapes())
+    cf = R.fill_tensor("golden.ctx.feat", (1, 3, 832, 25, 25), "feat")
+    with torch.no_grad():
+        assert rel_err(R.contextnet_forward(cf, sdc).numpy(), g["context_out"]) < 1e-5
+    sd = R.fill_state_dict(R.twobranch_shapes(), "det0.")
+    for tl in (3, 9):
+        pf = R.fill_tensor("golden.det.pooled%d" % tl, (2, tl, 832, 7, 7), "feat")
+        cx = R.fill_tensor("golden.det.ctx%d" % tl, (2, 1024, tl, 1, 1), "feat")
+        with torch.no_grad():
+            o = R.twobranch_forward(pf, cx, sd)
+        for nme, t in zip(("prob", "loc", "first", "last"), o[:4]):
+            assert rel_err(t.numpy(), g["det_T%d_%s" % (tl, nme)]) < 1e-4, (tl, nme)
+    pf = R.fill_tensor("golden.det.pooled3", (2, 3, 832, 7, 7), "feat")
+    cx = R.fill_tensor("golden.det.ctx3", (2, 1024, 3, 1, 1), "feat")
+    with torch.no_grad():
+        o = R.twobranch_forward(pf, cx, sd, tubes=torch.from_numpy(g["loss_tubes"]),
+                                targets=torch.from_numpy(g["loss_targets"]))
+    assert rel_err(o[4].numpy(), g["loss_cls"]) < 1e-4
+    assert rel_err(o[5].numpy(), g["loss_loc"]) < 1e-4
+    assert rel_err(o[6].numpy(), g["loss_nbr"]) < 1e-4
+
+
+@pytest.mark.parametrize("ntubes", [11, 34])
+def test_inference_history(golden, ntubes):
+    g = golden("inference_golden")
+    conv_feat = R.fill_tensor("golden.inf.feat", (2, 9, 832, 25, 25), "feat")
+    with torch.no_grad():
+        context = R.contextnet_forward(conv_feat, R.fill_state_dict(R.context_shapes()))
+    assert rel_err(context.numpy(), g["n%d_context" % ntubes]) < 1e-5
+    nets = {"det_net%d" % i: R.fill_state_dict(R.twobranch_shapes(), "det%d." % i) for i in range(3)}
+    a = R.anchors()[:ntubes] * 400.0
+    tl = [np.tile(a[:, None, :], (1, 3, 1)).astype(np.float32) for _ in range(2)]
+    tl[1] = tl[1][::-1].copy()
+    with torch.no_grad():
+        hist = R.inference(conv_feat, context, nets, tl)
+    for i, h in enumerate(hist):
+        assert list(h["tubes_nums"]) == list(g["n%d_step%d_nums" % (ntubes, i)])
+        assert rel_err(h["pred_prob"][:, 0].numpy(), g["n%d_step%d_pred_prob" % (ntubes, i)]) < 1e-4
+        for k in ("pred_loc", "pred_first_loc", "pred_last_loc"):
+            assert rel_err(h[k].numpy(), g["n%d_step%d_%s" % (ntubes, i, k)]) < 1e-4, (i, k)
