@@ -1,0 +1,186 @@
+/*
+ * include/step_amd.h -- C ABI of libstep_amd.so, the MI355X (gfx950) implementation of the STEP
+ * hot path: ROIAlign / ROIPool / NMS operators and the I3D conv / pool building blocks.
+ *
+ * This is the drop-in boundary.  It replaces the five pybind11 symbols of the reference's native
+ * extension `external.maskrcnn_benchmark.roi_layers._C`
+ *     (/root/reference/external/maskrcnn_benchmark/csrc/vision.cpp:30-36)
+ * and the cuDNN calls behind torch.nn.Conv3d/BatchNorm3d/MaxPool3d/AvgPool3d/Conv2d/Linear that
+ * models/i3dpt.py and models/two_branch.py lean on.  INTEGRATION.md shows the binding a
+ * maintainer of the reference adds.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, explicit sizes, a hipStream_t passed as void*.  No torch types.
+ *   - the library never allocates, frees or retains memory: outputs and scratch are the caller's
+ *     (reference: outputs are fresh ATen tensors, ROIAlign_cuda.cu:295,340; scratch THCudaMalloc,
+ *     nms.cu:113).
+ *   - every entry point is asynchronous on `stream`, re-entrant and stateless (nn.DataParallel
+ *     calls replicas from one thread per GPU; the caller selects the device).
+ *   - return value: 0 ok; <0 bad argument (STEP_E_*); >0 a hipError_t from the launch.
+ *     (reference: AT_ASSERTM / THCudaCheck throw -> Python RuntimeError; our Python layer raises
+ *     RuntimeError on any non-zero status.)
+ *   - empty inputs (K == 0, n == 0) return 0 without launching (ROIAlign_cuda.cu:302-305,
+ *     nms.h:41-42).
+ */
+#ifndef STEP_AMD_H
+#define STEP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STEP_API __attribute__((visibility("default")))
+
+typedef void* step_stream_t; /* hipStream_t */
+
+/* element types of feature / activation tensors */
+enum { STEP_F32 = 0, STEP_BF16 = 1, STEP_F16 = 2 };
+/* physical layout of a 4-D feature map passed to the ROI operators */
+enum { STEP_NCHW = 0, STEP_NHWC = 1 };
+
+enum {
+    STEP_OK = 0,
+    STEP_E_DTYPE = -1,
+    STEP_E_SHAPE = -2,
+    STEP_E_NULL = -3,
+    STEP_E_UNSUPPORTED = -4,
+    STEP_E_ALIGN = -5
+};
+
+/* Library identity: returns "step_amd <version> gfx950"; abi is bumped on any signature change. */
+STEP_API const char* step_version(void);
+STEP_API int step_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * ROIAlign forward.     replaces _C.roi_align_forward   (csrc/ROIAlign.h:35-48,
+ *                       cuda/ROIAlign_cuda.cu:88-146,281-323; cpu/ROIAlign_cpu.cpp:137-281)
+ * feat  [B,C,H,W] (STEP_NCHW) or [B,H,W,C] (STEP_NHWC), dtype `dtype`
+ * rois  [K,5] fp32 rows (batch_index_as_float, x1, y1, x2, y2) in input-image pixels
+ * out   [K,C,ph,pw] (NCHW) or [K,ph,pw,C] (NHWC), same dtype as feat
+ * "3-D ROIAlign over tubes" = this call on feat.view(B*T,...) with rois = tubes.view(-1,5)
+ * (models/networks.py:42-45).
+ */
+STEP_API int step_roi_align_forward(const void* feat, int dtype, int layout, const float* rois, int K, int B,
+                                    int C, int H, int W, int pooled_h, int pooled_w, float spatial_scale,
+                                    int sampling_ratio, void* out, step_stream_t stream);
+
+/* ROIAlign backward.    replaces _C.roi_align_backward  (csrc/ROIAlign.h:51-69,
+ *                       cuda/ROIAlign_cuda.cu:201-278,326-370)
+ * grad [K,C,ph,pw] / [K,ph,pw,C]  ->  grad_feat [B,C,H,W] / [B,H,W,C].  grad_feat is zeroed here
+ * (ROIAlign_cuda.cu:340) and accumulated with fp32 atomics (fp32 only).
+ */
+STEP_API int step_roi_align_backward(const float* grad, int layout, const float* rois, int K, int B, int C, int H,
+                                     int W, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                                     float* grad_feat, step_stream_t stream);
+
+/* ROIPool forward.      replaces _C.roi_pool_forward    (csrc/ROIPool.h:35-48,
+ *                       cuda/ROIPool_cuda.cu:40-101,134-180)
+ * argmax: int32, same shape/layout as out; value h*W+w of the winning cell, -1 for empty bins.
+ */
+STEP_API int step_roi_pool_forward(const void* feat, int dtype, int layout, const float* rois, int K, int B, int C,
+                                   int H, int W, int pooled_h, int pooled_w, float spatial_scale, void* out,
+                                   int32_t* argmax, step_stream_t stream);
+
+/* ROIPool backward.     replaces _C.roi_pool_backward   (csrc/ROIPool.h:50-69,
+ *                       cuda/ROIPool_cuda.cu:103-132,183-226).  fp32, atomics. */
+STEP_API int step_roi_pool_backward(const float* grad, const int32_t* argmax, int layout, const float* rois, int K,
+                                    int B, int C, int H, int W, int pooled_h, int pooled_w, float* grad_feat,
+                                    step_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * NMS, batched over independent groups.   replaces _C.nms   (csrc/nms.h:34-52)
+ * Semantics are those of the reference CPU operator every reference script actually reaches
+ * (cpu/nms_cpu.cpp:29-89; test.py:158-161 moves boxes to the CPU first): greedy, "+1" areas,
+ * suppress when IoU >= threshold, score ties broken by lower index, bit-exact fp32 arithmetic.
+ *   boxes  [G,kmax,4] fp32 (x1,y1,x2,y2)    scores [G,kmax] fp32    counts [G] int32 (<= kmax)
+ *   keep   [G,kmax] uint8, 1 where the box survives (indices ascending == nonzero(keep))
+ * A single nms(dets, scores, thr) call is G = 1.  "nms_3d" over tubes = one group per
+ * (clip, class) holding the middle-frame boxes (test.py:174-195).
+ *   scratch: step_nms_scratch_bytes(G,kmax) bytes (may be NULL when that returns 0).
+ */
+STEP_API size_t step_nms_scratch_bytes(int G, int kmax);
+STEP_API int step_nms_batched(const float* boxes, const float* scores, const int32_t* counts, int G, int kmax,
+                              float threshold, uint8_t* keep, void* scratch, step_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused convolution unit on channels-last activations:
+ *     y = act( conv(x, w) * scale[c] + shift[c] (+ residual) )
+ * replaces Unit3Dpy = ConstantPad3d + Conv3d + BatchNorm3d(eval) + ReLU (models/i3dpt.py:43-111),
+ * the biased 1x1x1 convs and Linear layers of TwoBranchNet (models/two_branch.py:182-200) and the
+ * 2-D Bottleneck convs (two_branch.py:60-111; a 2-D conv is the kd = 1 case with D = frames).
+ *
+ *  x  [N, D, H, W, x_cstride] channels-last; the conv reads channels [x_coff, x_coff+Cin)
+ *  y  [N, Do, Ho, Wo, y_cstride]; the conv writes channels [y_coff, y_coff+Cout)  (this is how an
+ *     Inception block's torch.cat (i3dpt.py:162) disappears: branches write channel slices)
+ *  res (optional) same geometry as y with its own cstride/coff, added before the activation.
+ *  Stride is 1 in every dimension and padding is TF-"SAME" = k/2 per side (i3dpt.py:14-40) for
+ *  this entry point; the strided 7x7x7 stem has its own entry point below.
+ *  Weights are pre-packed by step_conv_pack_weight into MFMA fragment order.
+ *  scale/shift are fp32 [Cout]: folded eval-mode BN (scale = gamma/sqrt(var+eps),
+ *  shift = beta - mean*scale) or (1, bias) or NULL (=> 1, 0).
+ */
+typedef struct step_conv_desc {
+    int dtype;                 /* STEP_F32 | STEP_BF16 | STEP_F16 (activations and packed weights) */
+    int N, D, H, W;            /* input (= output) spatial extent */
+    int Cin, Cout;
+    int kd, kh, kw;            /* 1x1x1, 3x3x3 or 1x3x3 */
+    int x_cstride, x_coff;
+    int y_cstride, y_coff;
+    int res_cstride, res_coff; /* used when res != NULL */
+    int relu;
+} step_conv_desc;
+
+/* number of ELEMENTS (of dtype) of the packed weight for a conv [Cout,Cin,kd,kh,kw] */
+STEP_API size_t step_conv_packed_elems(int Cout, int Cin, int kd, int kh, int kw);
+/* pack torch-layout weights  w[Cout][Cin][kd][kh][kw] (fp32, DEVICE) into fragment order, casting
+ * to `dtype`.  `perm_c` (optional, device int32 [Cin]) remaps input channels: packed channel c reads
+ * w[:, perm_c[c]] -- used to fold the NCHW->NHWC flatten order of Linear / global_cls weights
+ * (two_branch.py:239-240,262) into the weights once. */
+STEP_API int step_conv_pack_weight(const float* w, int Cout, int Cin, int kd, int kh, int kw, int dtype,
+                                   const int32_t* perm_c, void* packed, step_stream_t stream);
+STEP_API int step_conv_forward(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale,
+                               const float* shift, const void* res, void* y, step_stream_t stream);
+
+/* The I3D stem: 7x7x7 stride-2 conv, Cin = 3, TF-SAME padding (2 front, 3 back) + BN + ReLU
+ * (models/i3dpt.py:186-191) reading the clip in the reference's own input layout
+ *   x [N, T, 3, H, W] (what BaseNet.forward receives, models/networks.py:69-77)
+ * and writing channels-last y [N, To, Ho, Wo, Cout] with To = ceil(T/2) etc. */
+STEP_API size_t step_stem_packed_elems(int Cout);
+STEP_API int step_stem_pack_weight(const float* w /*[Cout,3,7,7,7]*/, int Cout, int dtype, void* packed,
+                                   step_stream_t stream);
+STEP_API int step_stem_forward(int dtype, const void* x, int N, int T, int H, int W, const void* w_packed,
+                               const float* scale, const float* shift, int Cout, void* y, int y_cstride,
+                               int y_coff, step_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * TF-"SAME" max pool on channels-last activations.  replaces MaxPool3dTFPadding =
+ * ConstantPad3d(0) + MaxPool3d(ceil_mode=True) (models/i3dpt.py:114-126): the explicit TF pad
+ * (max(k-s,0), split floor/ceil, back-heavy) carries the VALUE 0; positions beyond it that a
+ * ceil-mode window overhangs are ignored.
+ *  x [N,D,H,W,x_cstride] channels [x_coff, x_coff+C)  ->  y [N,Do,Ho,Wo,y_cstride] at y_coff
+ *  Do/Ho/Wo are given by step_pool_out_size(L, k, s).
+ */
+STEP_API int step_pool_out_size(int L, int k, int s);
+STEP_API int step_maxpool3d_tf(int dtype, const void* x, int N, int D, int H, int W, int C, int x_cstride,
+                               int x_coff, int kd, int kh, int kw, int sd, int sh, int sw, void* y, int y_cstride,
+                               int y_coff, step_stream_t stream);
+
+/* Average pool over a full (kh x kw) window, stride 1, no padding ("VALID"), kd = 1.
+ * replaces nn.AvgPool3d((1,13,13),(1,1,1)) of ContextNet (models/two_branch.py:127,136).
+ * x [N,D,H,W,C] -> y [N,D,H-kh+1,W-kw+1,C] */
+STEP_API int step_avgpool_hw(int dtype, const void* x, int N, int D, int H, int W, int C, int kh, int kw, void* y,
+                             step_stream_t stream);
+
+/* Layout / dtype conversion between the reference's NCDHW-style logical tensors and channels-last.
+ *  src [N, C, S] (S = D*H*W flattened, i.e. torch-contiguous NCDHW)  <->  dst [N, S, C]
+ *  to_channels_last = 1: NCS -> NSC ; 0: NSC -> NCS.  src/dst dtypes may differ (cast). */
+STEP_API int step_transpose_cs(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int C, long long S,
+                               int to_channels_last, step_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STEP_AMD_H */

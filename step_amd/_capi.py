@@ -1,0 +1,59 @@
+"""ctypes declarations of the C ABI in include/step_amd.h (one place, used by the product loader
+step_amd/_lib.py and by the test-only emulation harness in tests/emul)."""
+import ctypes as C
+
+F32, BF16, F16 = 0, 1, 2
+NCHW, NHWC = 0, 1
+ABI_VERSION = 1
+
+vp, fp, ip, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # raw device addresses
+i, f, ll, sz = C.c_int, C.c_float, C.c_longlong, C.c_size_t
+
+
+class ConvDesc(C.Structure):
+    """struct step_conv_desc (include/step_amd.h)"""
+    _fields_ = [(n, C.c_int) for n in (
+        "dtype", "N", "D", "H", "W", "Cin", "Cout", "kd", "kh", "kw", "x_cstride", "x_coff", "y_cstride", "y_coff",
+        "res_cstride", "res_coff", "relu")]
+
+
+SIGNATURES = {
+    "step_version": (C.c_char_p, []),
+    "step_abi_version": (i, []),
+    "step_roi_align_forward": (i, [vp, i, i, fp, i, i, i, i, i, i, i, f, i, vp, vp]),
+    "step_roi_align_backward": (i, [fp, i, fp, i, i, i, i, i, i, i, f, i, fp, vp]),
+    "step_roi_pool_forward": (i, [vp, i, i, fp, i, i, i, i, i, i, i, f, vp, ip, vp]),
+    "step_roi_pool_backward": (i, [fp, ip, i, fp, i, i, i, i, i, i, i, fp, vp]),
+    "step_nms_scratch_bytes": (sz, [i, i]),
+    "step_nms_batched": (i, [fp, fp, ip, i, i, f, u8p, vp, vp]),
+    "step_conv_packed_elems": (sz, [i, i, i, i, i]),
+    "step_conv_pack_weight": (i, [fp, i, i, i, i, i, i, ip, vp, vp]),
+    "step_conv_forward": (i, [C.POINTER(ConvDesc), vp, vp, fp, fp, vp, vp, vp]),
+    "step_stem_packed_elems": (sz, [i]),
+    "step_stem_pack_weight": (i, [fp, i, i, vp, vp]),
+    "step_stem_forward": (i, [i, vp, i, i, i, i, vp, fp, fp, i, vp, i, i, vp]),
+    "step_pool_out_size": (i, [i, i, i]),
+    "step_maxpool3d_tf": (i, [i, vp, i, i, i, i, i, i, i, i, i, i, i, i, i, vp, i, i, vp]),
+    "step_avgpool_hw": (i, [i, vp, i, i, i, i, i, i, i, vp, vp]),
+    "step_transpose_cs": (i, [vp, i, vp, i, i, i, ll, i, vp]),
+}
+
+
+def declare(lib):
+    """Attach argtypes/restype for every symbol of include/step_amd.h; raises AttributeError when the
+    library does not export one of them."""
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_ERR = {-1: "unsupported dtype", -2: "bad shape", -3: "null pointer", -4: "unsupported configuration",
+        -5: "misaligned pointer or channel count"}
+
+
+def check(status, what):
+    if status != 0:
+        msg = _ERR.get(status, "hipError_t %d" % status) if status < 0 else "hipError_t %d" % status
+        raise RuntimeError("%s failed: %s" % (what, msg))

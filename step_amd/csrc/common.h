@@ -1,0 +1,136 @@
+// step_amd/csrc/common.h -- shared device helpers for the gfx950 (CDNA4) kernels.
+//
+// One source, two builds:
+//   * product : hipcc --offload-arch=gfx950  -> libstep_amd.so (the only thing step_amd loads)
+//   * STEP_EMUL (tests/emul only): the same kernel bodies compiled for the host and run by a
+//     fiber-based SIMT interpreter so that index logic can be checked without a GPU.  The
+//     emulation build is test infrastructure; it is never loaded by the product path.
+#pragma once
+#include <stdint.h>
+#include <float.h>
+#include <math.h>
+
+#ifdef STEP_EMUL
+#include "hipemu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+#include "../../include/step_amd.h"
+
+namespace step {
+
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- storage element types ---------------------------------------------------------------
+struct bf16_t { unsigned short v; };
+struct f16_t { unsigned short v; };
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) {
+    unsigned int u = ((unsigned int)h) << 16;
+    return __builtin_bit_cast(float, u);
+}
+// round-to-nearest-even, NaN kept quiet (same as torch's float -> bfloat16)
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    unsigned int u = __builtin_bit_cast(unsigned int, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float f16_bits_to_f32(unsigned short h) {
+    _Float16 x = __builtin_bit_cast(_Float16, h);
+    return (float)x;
+}
+__device__ __forceinline__ unsigned short f32_to_f16_bits(float f) {
+    _Float16 x = (_Float16)f;
+    return __builtin_bit_cast(unsigned short, x);
+}
+
+template <typename T> struct elem;
+template <> struct elem<float> {
+    static constexpr int dtype = STEP_F32;
+    static constexpr int VEC = 4;  // elements per 16 bytes
+    __device__ static __forceinline__ float to_f32(float x) { return x; }
+    __device__ static __forceinline__ float from_f32(float x) { return x; }
+};
+template <> struct elem<bf16_t> {
+    static constexpr int dtype = STEP_BF16;
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ float to_f32(bf16_t x) { return bf16_bits_to_f32(x.v); }
+    __device__ static __forceinline__ bf16_t from_f32(float x) { bf16_t r; r.v = f32_to_bf16_bits(x); return r; }
+};
+template <> struct elem<f16_t> {
+    static constexpr int dtype = STEP_F16;
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ float to_f32(f16_t x) { return f16_bits_to_f32(x.v); }
+    __device__ static __forceinline__ f16_t from_f32(float x) { f16_t r; r.v = f32_to_f16_bits(x); return r; }
+};
+
+// ---- 32x32 MFMA "k16 step": D(32x32) += A(32x16) * B(16x32) --------------------------------
+// Operand convention used by every kernel here: lane l holds, for row/col (l & 31), the EIGHT
+// consecutive k values  kbase + 8*(l>>5) + {0..7}  of its operand.
+//   16-bit types: exactly the v_mfma_f32_32x32x16_{bf16,f16} fragment (one instruction).
+//   fp32        : eight v_mfma_f32_32x32x2_f32, instruction j consuming element j of both
+//                 operands (k = kbase + j from lanes 0-31 and kbase + 8 + j from lanes 32-63);
+//                 exact fp32 FMA chain -- this is the parity path.
+// C/D layout (dtype independent): col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
+template <typename T> struct frag;
+template <> struct frag<float> { typedef f32x8 type; };
+template <> struct frag<bf16_t> { typedef u16x8 type; };
+template <> struct frag<f16_t> { typedef u16x8 type; };
+
+#ifndef STEP_EMUL
+typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_hw __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void mma_k16(const f32x8& a, const f32x8& b, f32x16& c, float) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_k16(const u16x8& a, const u16x8& b, f32x16& c, bf16_t) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_k16(const u16x8& a, const u16x8& b, f32x16& c, f16_t) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_hw, a), __builtin_bit_cast(f16x8_hw, b), c, 0, 0, 0);
+}
+#else
+// host interpreter versions (tests/emul/hipemu.h)
+__device__ inline void mma_k16(const f32x8& a, const f32x8& b, f32x16& c, float) {
+    float fa[8], fb[8];
+    for (int j = 0; j < 8; ++j) { fa[j] = a[j]; fb[j] = b[j]; }
+    hipemu::mfma_32x32_k16(fa, fb, c, /*f32 pairing*/ true);
+}
+__device__ inline void mma_k16(const u16x8& a, const u16x8& b, f32x16& c, bf16_t) {
+    float fa[8], fb[8];
+    for (int j = 0; j < 8; ++j) { fa[j] = bf16_bits_to_f32(a[j]); fb[j] = bf16_bits_to_f32(b[j]); }
+    hipemu::mfma_32x32_k16(fa, fb, c, false);
+}
+__device__ inline void mma_k16(const u16x8& a, const u16x8& b, f32x16& c, f16_t) {
+    float fa[8], fb[8];
+    for (int j = 0; j < 8; ++j) { fa[j] = f16_bits_to_f32(a[j]); fb[j] = f16_bits_to_f32(b[j]); }
+    hipemu::mfma_32x32_k16(fa, fb, c, false);
+}
+#endif
+
+__device__ __forceinline__ int cd_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ---- launch helper -------------------------------------------------------------------------
+#ifdef STEP_EMUL
+#define STEP_LAUNCH(kernel, grid, block, stream, ...) \
+    hipemu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+#define STEP_LAUNCH_CHECK() 0
+#else
+#define STEP_LAUNCH(kernel, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kernel, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__)
+#define STEP_LAUNCH_CHECK() ((int)hipGetLastError())
+#endif
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline long long ceil_div64(long long a, long long b) { return (a + b - 1) / b; }
+
+}  // namespace step

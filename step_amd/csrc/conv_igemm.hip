@@ -1,0 +1,575 @@
+// step_amd/csrc/conv_igemm.hip -- fused conv + per-channel affine (+residual) + ReLU on
+// channels-last activations for gfx950: im2col-free implicit GEMM on the matrix cores.
+//
+// Replaces, for the STEP hot path, what the reference obtains from cuDNN through
+//   Unit3Dpy   = ConstantPad3d + Conv3d + BatchNorm3d(eval) + ReLU   (models/i3dpt.py:43-111)
+//   Conv3d 1x1x1 / Conv2d 1x1, 3x3 / Linear of TwoBranchNet           (models/two_branch.py:60-111,182-200)
+// as three or four separate kernels plus a pad copy and, per Inception block, a torch.cat copy
+// (i3dpt.py:162).  Here one launch computes
+//     y[.., y_coff + co] = act( sum_{tap,ci} x[pix+tap][x_coff + ci] * w[co][ci][tap] * scale[co] + shift[co] (+ res) )
+// straight into a channel slice of the consumer's buffer.
+//
+// MI355X mapping
+//   * activations are NDHWC, so the GEMM K axis (tap, ci) is contiguous in ci: a workgroup
+//     stages one 32-channel slab of its input halo tile ([kd][TH+kh-1][TW+kw-1] pixels) into LDS
+//     ONCE with coalesced 16-byte loads and every tap re-reads it from LDS at a shifted base --
+//     no im2col matrix exists anywhere (the 27x input re-use of a 3x3x3 conv is served by LDS,
+//     not by HBM/L2).  Padding is a load predicate.
+//   * 64-wide wavefronts, 4 per workgroup; each wave owns a 32-pixel x (32*NB)-channel
+//     accumulator built from v_mfma_f32_32x32x16_{bf16,f16} (fp32 accumulate).  The fp32
+//     instantiation of the SAME code uses v_mfma_f32_32x32x2_f32 -- an exact fp32 FMA chain --
+//     and is the parity path against the fp32 oracle.
+//   * weights are pre-packed once into MFMA B-fragment order ([co/32][tap][ci/16][lane][8]), so
+//     a wave's B operand is one fully coalesced 1 KiB load that stays L2 resident.
+//   * LDS slab pixels are 64 B (16-bit) / 128 B (fp32) wide; 16-byte slots are XOR-swizzled by
+//     the pixel index so the ds_read_b128 of the 32 pixels of a fragment spread over the banks.
+#include "common.h"
+
+namespace step {
+
+constexpr int CK = 32;  // channels per LDS slab (two k16 MFMA steps)
+
+struct ConvParams {
+    const void* x; const void* w; const float* scale; const float* shift; const void* res; void* y;
+    int N, D, H, W, Cin, Cout;
+    int x_cstride, x_coff, y_cstride, y_coff, r_cstride, r_coff;
+    int relu;
+    int tiles_h, tiles_w;
+    int nchunks;   // ceil(Cin / 32)
+    int nblk32;    // ceil(Cout / 32)
+    long long Mtot;  // N*D*H*W
+};
+
+template <typename T> struct Ld16;  // 16-byte LDS / global vector of T
+template <> struct Ld16<float> { typedef f32x4 type; };
+template <> struct Ld16<bf16_t> { typedef u16x8 type; };
+template <> struct Ld16<f16_t> { typedef u16x8 type; };
+
+template <typename T>
+__device__ __forceinline__ typename frag<T>::type lds_read_frag(const unsigned char* pix_base, int j, int khalf, int sw);
+template <>
+__device__ __forceinline__ f32x8 lds_read_frag<float>(const unsigned char* pix_base, int j, int khalf, int sw) {
+    const int s0 = j * 4 + khalf * 2;
+    f32x4 lo = *(const f32x4*)(pix_base + ((s0 ^ sw) << 4));
+    f32x4 hi = *(const f32x4*)(pix_base + (((s0 + 1) ^ sw) << 4));
+    f32x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+template <>
+__device__ __forceinline__ u16x8 lds_read_frag<bf16_t>(const unsigned char* pix_base, int j, int khalf, int sw) {
+    return *(const u16x8*)(pix_base + (((j * 2 + khalf) ^ sw) << 4));
+}
+template <>
+__device__ __forceinline__ u16x8 lds_read_frag<f16_t>(const unsigned char* pix_base, int j, int khalf, int sw) {
+    return *(const u16x8*)(pix_base + (((j * 2 + khalf) ^ sw) << 4));
+}
+
+template <typename T>
+__device__ __forceinline__ typename frag<T>::type load_b_frag(const T* p) {  // p -> this lane's 8 elements
+    return *(const typename frag<T>::type*)p;
+}
+
+// TWL: log2(tile width); tile = (128 >> TWL) rows x (1 << TWL) cols of output pixels in one (n, d)
+// plane.  FLAT (1x1x1 only): the tile is 128 consecutive pixels of the flattened N*D*H*W axis.
+template <typename T, int TWL, int NB, int KD, int KH, int KW, bool FLAT>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+    constexpr int TW = 1 << TWL, TH = 128 >> TWL;
+    constexpr int HH_ = TH + KH - 1, HW_ = TW + KW - 1;
+    constexpr int NPIX = FLAT ? 128 : KD * HH_ * HW_;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int VEC = 16 / ES;
+    constexpr int PITCH = CK * ES;
+    constexpr int SLOTS = PITCH / 16;
+    constexpr int PPR = 16 / SLOTS;
+    constexpr int NTAPS = KD * KH * KW;
+    constexpr int NVEC = NPIX * SLOTS;
+    constexpr int ITER = (NVEC + 255) / 256;
+    typedef typename Ld16<T>::type vec16;
+    typedef typename frag<T>::type frag_t;
+
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX * PITCH];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int khalf = lane >> 5;
+    const int m = wave * 32 + (lane & 31);
+    const int th = m >> TWL, tw = m & (TW - 1);
+
+    // ---- which tile
+    int n = 0, d = 0, h0 = 0, w0 = 0;
+    long long m0 = 0;
+    if (FLAT) {
+        m0 = (long long)blockIdx.x * 128;
+    } else {
+        int t = blockIdx.x;
+        const int tw_i = t % p.tiles_w; t /= p.tiles_w;
+        const int th_i = t % p.tiles_h; t /= p.tiles_h;
+        d = t % p.D;
+        n = t / p.D;
+        h0 = th_i * TH;
+        w0 = tw_i * TW;
+    }
+    const int nb0 = blockIdx.y * NB;
+    const int KC16 = p.nchunks * 2;
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const T* xg = (const T*)p.x;
+    const T* wg = (const T*)p.w;
+
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        if (chunk) __syncthreads();  // all waves finished reading the previous slab
+        // ---- stage the 32-channel slab of the halo tile
+        vec16 stage[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int v = tid + it * 256;
+            vec16 val;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) val[e] = 0;
+            if (v < NVEC) {
+                const int pix = v / SLOTS, slot = v % SLOTS;
+                const int c = chunk * CK + slot * VEC;
+                bool inb;
+                size_t gpix;
+                if (FLAT) {
+                    const long long gm = m0 + pix;
+                    inb = gm < p.Mtot;
+                    gpix = (size_t)gm;
+                } else {
+                    const int plane = pix / (HH_ * HW_), rem = pix % (HH_ * HW_);
+                    const int r = rem / HW_, cc = rem % HW_;
+                    const int id = d + plane - KD / 2, ih = h0 + r - KH / 2, iw = w0 + cc - KW / 2;
+                    inb = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                    gpix = (((size_t)n * p.D + id) * p.H + ih) * p.W + iw;
+                }
+                if (inb && c < p.Cin) val = *(const vec16*)(xg + gpix * p.x_cstride + p.x_coff + c);
+            }
+            stage[it] = val;
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int v = tid + it * 256;
+            if (v < NVEC) {
+                const int pix = v / SLOTS, slot = v % SLOTS;
+                const int sw = (pix / PPR) % SLOTS;
+                *(vec16*)(lds + pix * PITCH + ((slot ^ sw) << 4)) = stage[it];
+            }
+        }
+        __syncthreads();
+
+        // ---- taps x 2 k16 steps x NB accumulators
+#pragma unroll 1
+        for (int kd = 0; kd < KD; ++kd) {
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh) {
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) {
+                    const int tap = (kd * KH + kh) * KW + kw;
+                    const int hp = FLAT ? m : ((kd * HH_ + th + kh) * HW_ + tw + kw);
+                    const int sw = (hp / PPR) % SLOTS;
+                    const unsigned char* pb = lds + hp * PITCH;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const frag_t a = lds_read_frag<T>(pb, j, khalf, sw);
+                        const int kc16 = chunk * 2 + j;
+#pragma unroll
+                        for (int i = 0; i < NB; ++i) {
+                            if (nb0 + i < p.nblk32) {  // wave-uniform
+                                const T* bp = wg + ((((size_t)(nb0 + i) * NTAPS + tap) * KC16 + kc16) * 64 + lane) * 8;
+                                const frag_t b = load_b_frag<T>(bp);
+                                mma_k16(a, b, acc[i], T());
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: affine (+residual) + ReLU, store channel slice
+    T* yg = (T*)p.y;
+    const T* rg = (const T*)p.res;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int co = (nb0 + i) * 32 + (lane & 31);
+        if (nb0 + i < p.nblk32 && co < p.Cout) {
+            const float sc = p.scale ? p.scale[co] : 1.f;
+            const float sh = p.shift ? p.shift[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = wave * 32 + cd_row(r, lane);
+                bool ok;
+                size_t opix;
+                if (FLAT) {
+                    const long long gm = m0 + mm;
+                    ok = gm < p.Mtot;
+                    opix = (size_t)gm;
+                } else {
+                    const int oh = h0 + (mm >> TWL), ow = w0 + (mm & (TW - 1));
+                    ok = oh < p.H && ow < p.W;
+                    opix = (((size_t)n * p.D + d) * p.H + oh) * p.W + ow;
+                }
+                if (ok) {
+                    float v = acc[i][r] * sc + sh;
+                    if (rg) v += elem<T>::to_f32(rg[opix * p.r_cstride + p.r_coff + co]);
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    yg[opix * p.y_cstride + p.y_coff + co] = elem<T>::from_f32(v);
+                }
+            }
+        }
+    }
+}
+
+// ---- weight packing: torch [Cout][Cin][taps] fp32 -> [nb32][tap][kc16][lane][8] of T ----------
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, const int32_t* __restrict__ perm, T* __restrict__ out,
+                                   int Cout, int Cin, int ntaps, int KC16, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const int e = (int)(idx & 7);
+        const int lane = (int)((idx >> 3) & 63);
+        long long q = idx >> 9;
+        const int kc16 = (int)(q % KC16); q /= KC16;
+        const int tap = (int)(q % ntaps);
+        const int nb = (int)(q / ntaps);
+        const int co = nb * 32 + (lane & 31);
+        const int ci = kc16 * 16 + (lane >> 5) * 8 + e;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) {
+            const int cs = perm ? perm[ci] : ci;
+            v = w[((size_t)co * Cin + cs) * ntaps + tap];
+        }
+        out[idx] = elem<T>::from_f32(v);
+    }
+}
+
+// ============================================================================================
+// The I3D stem: 7x7x7, stride 2, Cin = 3, pad (2 front, 3 back) + affine + ReLU.
+// Input in the reference's own layout x[N][T][3][H][W]; output channels-last.
+// The slab in LDS is [7 frames][2*TH+5 rows][40 cols] pixels of 4 channels (c = 3 is zero) and
+// the GEMM K axis is ordered (kd, kh, kw(8, the 8th tap has zero weight), c(4)): the 8 taps x 4
+// channels an output pixel needs from one input row are 32 CONTIGUOUS, 16-byte aligned
+// elements, so the stride-2 gather is again a plain ds_read_b128 per lane.  K = 7*7*32 = 1568.
+constexpr int STEM_TH = 8, STEM_TW = 16;
+constexpr int STEM_ROWS = 2 * STEM_TH + 5, STEM_COLS = 40;
+
+struct StemParams {
+    const void* x; const void* w; const float* scale; const float* shift; void* y;
+    int N, T, H, W, To, Ho, Wo, Cout, y_cstride, y_coff;
+    int tiles_h, tiles_w, nblk32;
+};
+
+template <typename T, int NB>
+__global__ __launch_bounds__(256) void stem_igemm_kernel(StemParams p) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int PIXB = 4 * ES;  // bytes per LDS pixel (4 channels)
+    constexpr int NPIX = 7 * STEM_ROWS * STEM_COLS;
+    typedef typename frag<T>::type frag_t;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX * PIXB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int khalf = lane >> 5;
+    const int m = wave * 32 + (lane & 31);
+    const int th = m >> 4, tw = m & 15;
+
+    int t = blockIdx.x;
+    const int tw_i = t % p.tiles_w; t /= p.tiles_w;
+    const int th_i = t % p.tiles_h; t /= p.tiles_h;
+    const int od = t % p.To;
+    const int n = t / p.To;
+    const int oh0 = th_i * STEM_TH, ow0 = tw_i * STEM_TW;
+    const int nb0 = blockIdx.y * NB;
+
+    // ---- stage: LDS col cl <-> input col iw = 2*ow0 - 4 + cl ; row r <-> ih = 2*oh0 - 2 + r ;
+    //      frame f <-> it = 2*od - 2 + f.  Items = 4 consecutive cols of one (frame,row).
+    const T* xg = (const T*)p.x;
+    const bool vec_ok = (p.W % 4) == 0;
+    for (int item = tid; item < 7 * STEM_ROWS * (STEM_COLS / 4); item += 256) {
+        const int cq = item % (STEM_COLS / 4);
+        const int r = (item / (STEM_COLS / 4)) % STEM_ROWS;
+        const int f = item / ((STEM_COLS / 4) * STEM_ROWS);
+        const int it = 2 * od - 2 + f, ih = 2 * oh0 - 2 + r, iw0 = 2 * ow0 - 4 + cq * 4;
+        T px[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) px[a][c] = elem<T>::from_f32(0.f);
+        if (it >= 0 && it < p.T && ih >= 0 && ih < p.H) {
+            const size_t base = (((size_t)n * p.T + it) * 3) * p.H * p.W + (size_t)ih * p.W;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const T* src = xg + base + (size_t)c * p.H * p.W;
+                if (vec_ok && iw0 >= 0 && iw0 + 3 < p.W) {
+                    typedef unsigned int uvec __attribute__((ext_vector_type(ES)));   // 4 elements = 2*ES... bytes
+                    uvec raw = *(const uvec*)(src + iw0);
+                    T v4[4];
+                    __builtin_memcpy(v4, &raw, sizeof(v4));
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) px[a][c] = v4[a];
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        if (iw0 + a >= 0 && iw0 + a < p.W) px[a][c] = src[iw0 + a];
+                }
+            }
+        }
+        unsigned char* dst = lds + ((f * STEM_ROWS + r) * STEM_COLS + cq * 4) * PIXB;
+#pragma unroll
+        for (int q = 0; q < (4 * PIXB) / 16; ++q) {
+            u32x4 tmp;
+            __builtin_memcpy(&tmp, (const unsigned char*)&px[0][0] + 16 * q, 16);
+            *(u32x4*)(dst + 16 * q) = tmp;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const T* wg = (const T*)p.w;
+#pragma unroll 1
+    for (int kd = 0; kd < 7; ++kd) {
+#pragma unroll 1
+        for (int kh = 0; kh < 7; ++kh) {
+            // pixel (2*tw + 2 + 0) of row (2*th + kh) of frame kd; this lane's 8 elements of step j
+            // start at tap kw = 4*j + 2*khalf
+            const unsigned char* rowb = lds + ((kd * STEM_ROWS + 2 * th + kh) * STEM_COLS + 2 * tw + 2) * PIXB;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned char* ap = rowb + (4 * j + 2 * khalf) * PIXB;
+                frag_t a;
+                {
+                    u32x4 h2[ES / 2];
+#pragma unroll
+                    for (int q = 0; q < ES / 2; ++q) h2[q] = *(const u32x4*)(ap + 16 * q);
+                    __builtin_memcpy(&a, h2, sizeof(a));
+                }
+                const int ks = (kd * 7 + kh) * 2 + j;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    if (nb0 + i < p.nblk32) {
+                        const T* bp = wg + (((size_t)(nb0 + i) * 98 + ks) * 64 + lane) * 8;
+                        const frag_t b = load_b_frag<T>(bp);
+                        mma_k16(a, b, acc[i], T());
+                    }
+                }
+            }
+        }
+    }
+
+    T* yg = (T*)p.y;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int co = (nb0 + i) * 32 + (lane & 31);
+        if (nb0 + i < p.nblk32 && co < p.Cout) {
+            const float sc = p.scale ? p.scale[co] : 1.f;
+            const float sh = p.shift ? p.shift[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = wave * 32 + cd_row(r, lane);
+                const int oh = oh0 + (mm >> 4), ow = ow0 + (mm & 15);
+                if (oh < p.Ho && ow < p.Wo) {
+                    float v = fmaxf(acc[i][r] * sc + sh, 0.f);
+                    const size_t opix = (((size_t)n * p.To + od) * p.Ho + oh) * p.Wo + ow;
+                    yg[opix * p.y_cstride + p.y_coff + co] = elem<T>::from_f32(v);
+                }
+            }
+        }
+    }
+}
+
+// torch [Cout][3][7][7][7] fp32 -> [nb32][kd][kh][j][lane][8]; element e: kw = 4j + 2*(lane>>5) + (e>>2), c = e&3
+template <typename T>
+__global__ void stem_pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const int e = (int)(idx & 7);
+        const int lane = (int)((idx >> 3) & 63);
+        long long q = idx >> 9;
+        const int ks = (int)(q % 98);
+        const int nb = (int)(q / 98);
+        const int j = ks & 1, kh = (ks >> 1) % 7, kd = (ks >> 1) / 7;
+        const int kw = 4 * j + 2 * (lane >> 5) + (e >> 2), c = e & 3;
+        const int co = nb * 32 + (lane & 31);
+        float v = 0.f;
+        if (co < Cout && c < 3 && kw < 7) v = w[((((size_t)co * 3 + c) * 7 + kd) * 7 + kh) * 7 + kw];
+        out[idx] = elem<T>::from_f32(v);
+    }
+}
+
+// ---- host-side dispatch --------------------------------------------------------------------
+static inline unsigned flat_grid(long long total, int block) {
+    long long g = ceil_div64(total, block);
+    if (g > 16384) g = 16384;
+    return (unsigned)g;
+}
+
+template <typename T, int TWL, int KD, int KH, int KW, bool FLAT>
+static int launch_nb(const ConvParams& p, int NB, dim3 grid, step_stream_t stream) {
+    switch (NB) {
+        case 1: STEP_LAUNCH((conv_igemm_kernel<T, TWL, 1, KD, KH, KW, FLAT>), grid, dim3(256), stream, p); break;
+        case 2: STEP_LAUNCH((conv_igemm_kernel<T, TWL, 2, KD, KH, KW, FLAT>), grid, dim3(256), stream, p); break;
+        case 3: STEP_LAUNCH((conv_igemm_kernel<T, TWL, 3, KD, KH, KW, FLAT>), grid, dim3(256), stream, p); break;
+        default: STEP_LAUNCH((conv_igemm_kernel<T, TWL, 4, KD, KH, KW, FLAT>), grid, dim3(256), stream, p); break;
+    }
+    return STEP_LAUNCH_CHECK();
+}
+
+// pick the accumulator depth: least padded work first, then the deepest tile that still gives the
+// chip enough workgroups (256 CUs, several resident workgroups each)
+static int pick_nb(int nblk32, long long mtiles) {
+    int best = 1;
+    long long best_cost = -1;
+    const int cand[4] = {4, 3, 2, 1};
+    for (int k = 0; k < 4; ++k) {
+        const int nb = cand[k];
+        const long long groups = ceil_div(nblk32, nb);
+        const long long wgs = groups * mtiles;
+        // time ~ (#rounds of 1024 resident workgroups) x (per-workgroup time: nb MFMA units + ~2 units of
+        // slab staging); ties go to the deeper tile (less re-staging traffic)
+        const long long cost = ceil_div64(wgs, 1024) * (nb + 2) * 8 - nb;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nb; }
+    }
+    return best;
+}
+
+template <typename T>
+static int conv_forward_t(const step_conv_desc* d, ConvParams p, step_stream_t stream) {
+    constexpr int VEC = elem<T>::VEC;
+    if (d->Cin % VEC || d->x_cstride % VEC || d->x_coff % VEC) return STEP_E_ALIGN;
+    if (((uintptr_t)p.x % 16) || ((uintptr_t)p.w % 16)) return STEP_E_ALIGN;
+    const bool k1 = d->kd == 1 && d->kh == 1 && d->kw == 1;
+    const bool k333 = d->kd == 3 && d->kh == 3 && d->kw == 3;
+    const bool k133 = d->kd == 1 && d->kh == 3 && d->kw == 3;
+    if (k1) {
+        const long long mtiles = ceil_div64(p.Mtot, 128);
+        const int NB = pick_nb(p.nblk32, mtiles);
+        dim3 grid((unsigned)mtiles, (unsigned)ceil_div(p.nblk32, NB));
+        return launch_nb<T, 4, 1, 1, 1, true>(p, NB, grid, stream);
+    }
+    if (!k333 && !k133) return STEP_E_UNSUPPORTED;
+    // tile shape: 8x16 or 4x32 output pixels, whichever wastes fewer pixels on this H x W
+    const long long w16 = (long long)ceil_div(d->H, 8) * ceil_div(d->W, 16);
+    const long long w32 = (long long)ceil_div(d->H, 4) * ceil_div(d->W, 32);
+    const bool wide = w32 < w16;
+    p.tiles_h = wide ? ceil_div(d->H, 4) : ceil_div(d->H, 8);
+    p.tiles_w = wide ? ceil_div(d->W, 32) : ceil_div(d->W, 16);
+    const long long mtiles = (long long)d->N * d->D * p.tiles_h * p.tiles_w;
+    const int NB = pick_nb(p.nblk32, mtiles);
+    dim3 grid((unsigned)mtiles, (unsigned)ceil_div(p.nblk32, NB));
+    if (k333) return wide ? launch_nb<T, 5, 3, 3, 3, false>(p, NB, grid, stream) : launch_nb<T, 4, 3, 3, 3, false>(p, NB, grid, stream);
+    return wide ? launch_nb<T, 5, 1, 3, 3, false>(p, NB, grid, stream) : launch_nb<T, 4, 1, 3, 3, false>(p, NB, grid, stream);
+}
+
+template <typename T>
+static int stem_forward_t(StemParams p, step_stream_t stream) {
+    dim3 grid((unsigned)((long long)p.N * p.To * p.tiles_h * p.tiles_w), (unsigned)ceil_div(p.nblk32, 2));
+    STEP_LAUNCH((stem_igemm_kernel<T, 2>), grid, dim3(256), stream, p);
+    return STEP_LAUNCH_CHECK();
+}
+
+}  // namespace step
+
+using namespace step;
+
+extern "C" {
+
+size_t step_conv_packed_elems(int Cout, int Cin, int kd, int kh, int kw) {
+    return (size_t)ceil_div(Cout, 32) * kd * kh * kw * (ceil_div(Cin, CK) * 2) * 512;
+}
+
+int step_conv_pack_weight(const float* w, int Cout, int Cin, int kd, int kh, int kw, int dtype, const int32_t* perm,
+                          void* packed, step_stream_t stream) {
+    if (Cout <= 0 || Cin <= 0 || kd <= 0 || kh <= 0 || kw <= 0) return STEP_E_SHAPE;
+    if (!w || !packed) return STEP_E_NULL;
+    const long long total = (long long)step_conv_packed_elems(Cout, Cin, kd, kh, kw);
+    const int KC16 = ceil_div(Cin, CK) * 2, ntaps = kd * kh * kw;
+    const dim3 grid(flat_grid(total, 256));
+    switch (dtype) {
+        case STEP_F32: STEP_LAUNCH((pack_weight_kernel<float>), grid, dim3(256), stream, w, perm, (float*)packed, Cout, Cin, ntaps, KC16, total); break;
+        case STEP_BF16: STEP_LAUNCH((pack_weight_kernel<bf16_t>), grid, dim3(256), stream, w, perm, (bf16_t*)packed, Cout, Cin, ntaps, KC16, total); break;
+        case STEP_F16: STEP_LAUNCH((pack_weight_kernel<f16_t>), grid, dim3(256), stream, w, perm, (f16_t*)packed, Cout, Cin, ntaps, KC16, total); break;
+        default: return STEP_E_DTYPE;
+    }
+    return STEP_LAUNCH_CHECK();
+}
+
+int step_conv_forward(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale,
+                      const float* shift, const void* res, void* y, step_stream_t stream) {
+    if (!d) return STEP_E_NULL;
+    if (d->N < 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return STEP_E_SHAPE;
+    if (d->x_coff < 0 || d->x_coff + d->Cin > d->x_cstride || d->y_coff < 0 || d->y_coff + d->Cout > d->y_cstride)
+        return STEP_E_SHAPE;
+    if (res && (d->res_coff < 0 || d->res_coff + d->Cout > d->res_cstride)) return STEP_E_SHAPE;
+    if (d->N == 0) return STEP_OK;
+    if (!x || !w_packed || !y) return STEP_E_NULL;
+    ConvParams p;
+    p.x = x; p.w = w_packed; p.scale = scale; p.shift = shift; p.res = res; p.y = y;
+    p.N = d->N; p.D = d->D; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
+    p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
+    p.r_cstride = d->res_cstride; p.r_coff = d->res_coff;
+    p.relu = d->relu;
+    p.tiles_h = p.tiles_w = 0;
+    p.nchunks = ceil_div(d->Cin, CK);
+    p.nblk32 = ceil_div(d->Cout, 32);
+    p.Mtot = (long long)d->N * d->D * d->H * d->W;
+    switch (d->dtype) {
+        case STEP_F32: return conv_forward_t<float>(d, p, stream);
+        case STEP_BF16: return conv_forward_t<bf16_t>(d, p, stream);
+        case STEP_F16: return conv_forward_t<f16_t>(d, p, stream);
+    }
+    return STEP_E_DTYPE;
+}
+
+size_t step_stem_packed_elems(int Cout) { return (size_t)ceil_div(Cout, 32) * 98 * 512; }
+
+int step_stem_pack_weight(const float* w, int Cout, int dtype, void* packed, step_stream_t stream) {
+    if (Cout <= 0) return STEP_E_SHAPE;
+    if (!w || !packed) return STEP_E_NULL;
+    const long long total = (long long)step_stem_packed_elems(Cout);
+    const dim3 grid(flat_grid(total, 256));
+    switch (dtype) {
+        case STEP_F32: STEP_LAUNCH((stem_pack_weight_kernel<float>), grid, dim3(256), stream, w, (float*)packed, Cout, total); break;
+        case STEP_BF16: STEP_LAUNCH((stem_pack_weight_kernel<bf16_t>), grid, dim3(256), stream, w, (bf16_t*)packed, Cout, total); break;
+        case STEP_F16: STEP_LAUNCH((stem_pack_weight_kernel<f16_t>), grid, dim3(256), stream, w, (f16_t*)packed, Cout, total); break;
+        default: return STEP_E_DTYPE;
+    }
+    return STEP_LAUNCH_CHECK();
+}
+
+int step_stem_forward(int dtype, const void* x, int N, int T, int H, int W, const void* w_packed, const float* scale,
+                      const float* shift, int Cout, void* y, int y_cstride, int y_coff, step_stream_t stream) {
+    if (N < 0 || T <= 0 || H <= 0 || W <= 0 || Cout <= 0) return STEP_E_SHAPE;
+    if (y_coff < 0 || y_coff + Cout > y_cstride) return STEP_E_SHAPE;
+    if (N == 0) return STEP_OK;
+    if (!x || !w_packed || !y) return STEP_E_NULL;
+    if (((uintptr_t)x % 16) || ((uintptr_t)w_packed % 16)) return STEP_E_ALIGN;
+    StemParams p;
+    p.x = x; p.w = w_packed; p.scale = scale; p.shift = shift; p.y = y;
+    p.N = N; p.T = T; p.H = H; p.W = W;
+    p.To = (T + 5 - 7) / 2 + 1; p.Ho = (H + 5 - 7) / 2 + 1; p.Wo = (W + 5 - 7) / 2 + 1;
+    if (p.To <= 0 || p.Ho <= 0 || p.Wo <= 0) return STEP_E_SHAPE;
+    p.Cout = Cout; p.y_cstride = y_cstride; p.y_coff = y_coff;
+    p.tiles_h = ceil_div(p.Ho, STEM_TH); p.tiles_w = ceil_div(p.Wo, STEM_TW);
+    p.nblk32 = ceil_div(Cout, 32);
+    switch (dtype) {
+        case STEP_F32: return stem_forward_t<float>(p, stream);
+        case STEP_BF16: return stem_forward_t<bf16_t>(p, stream);
+        case STEP_F16: return stem_forward_t<f16_t>(p, stream);
+    }
+    return STEP_E_DTYPE;
+}
+
+const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
+int step_abi_version(void) { return 1; }
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+// step_amd/csrc/nms.hip -- batched greedy NMS for gfx950, bit-exact with the reference CPU op.
+//
+// Replaces  external/maskrcnn_benchmark/csrc/cpu/nms_cpu.cpp:29-89 (the operator every reference
+// script actually reaches: test.py:158-161,192 / train.py:513-515,547 / demo.py:124-126,158 move the
+// boxes to the CPU first) and csrc/cuda/nms.cu:47-155 (64x64 bit-mask tiles + a serial host
+// reduction behind a blocking D2H copy).
+//
+// STEP calls nms once per (step, clip, class) on <= 34..109 middle-frame boxes: 180*B tiny serial
+// CPU calls per batch.  Here all groups go in ONE launch:
+//   * kmax <= 64  : one 64-lane wavefront per group, boxes live in registers, the greedy scan is a
+//                   loop of cross-lane broadcasts -- no LDS, no global scratch, no host round trip;
+//   * kmax  > 64  : one 256-thread workgroup per group with a global scratch rank table.
+// Arithmetic: "+1" areas, IoU = inter / (area_i + area_j - inter) with every operation rounded
+// separately (__f*_rn: no FMA contraction), suppress when IoU >= threshold (nms_cpu.cpp:84 -- the
+// CUDA op uses '>', nms.cu:84; parity target is the CPU op), ties in score broken by lower index.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace step {
+
+__device__ __forceinline__ float box_area(float x1, float y1, float x2, float y2) {
+    return __fmul_rn(__fadd_rn(__fsub_rn(x2, x1), 1.f), __fadd_rn(__fsub_rn(y2, y1), 1.f));  // nms_cpu.cpp:46
+}
+
+// i = the kept (higher score) box, j = the candidate.  nms_cpu.cpp:73-84
+__device__ __forceinline__ bool iou_ge(float ix1, float iy1, float ix2, float iy2, float iarea, float jx1, float jy1,
+                                       float jx2, float jy2, float jarea, float thr) {
+    float xx1 = fmaxf(ix1, jx1), yy1 = fmaxf(iy1, jy1);
+    float xx2 = fminf(ix2, jx2), yy2 = fminf(iy2, jy2);
+    float w = fmaxf(0.f, __fadd_rn(__fsub_rn(xx2, xx1), 1.f));
+    float h = fmaxf(0.f, __fadd_rn(__fsub_rn(yy2, yy1), 1.f));
+    float inter = __fmul_rn(w, h);
+    float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(iarea, jarea), inter));
+    return ovr >= thr;
+}
+
+// One wavefront per group, n <= 64.
+__global__ void nms_wave_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                const int32_t* __restrict__ counts, int kmax, float thr, uint8_t* __restrict__ keep) {
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;  // blockDim.x == 64
+    const int n = min(counts[g], kmax);
+    const bool valid = lane < n;
+    float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, s = 0.f;
+    if (valid) {
+        const float* b = boxes + ((size_t)g * kmax + lane) * 4;
+        x1 = b[0]; y1 = b[1]; x2 = b[2]; y2 = b[3];
+        s = scores[(size_t)g * kmax + lane];
+    }
+    const float area = box_area(x1, y1, x2, y2);
+    // stable descending rank (ties: lower index first)
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+        float sj = __shfl(s, j);
+        rank += (sj > s || (sj == s && j < lane)) ? 1 : 0;
+    }
+    bool suppressed = false;
+    for (int r = 0; r < n; ++r) {
+        unsigned long long m = __ballot(valid && rank == r);
+        int i = __builtin_ctzll(m);  // exactly one lane has rank r
+        unsigned long long sm = __ballot(suppressed);
+        float bx1 = __shfl(x1, i), by1 = __shfl(y1, i), bx2 = __shfl(x2, i), by2 = __shfl(y2, i);
+        float barea = __shfl(area, i);
+        if ((sm >> i) & 1ull) continue;  // wave-uniform
+        if (valid && !suppressed && rank > r && iou_ge(bx1, by1, bx2, by2, barea, x1, y1, x2, y2, area, thr))
+            suppressed = true;
+    }
+    if (lane < kmax) keep[(size_t)g * kmax + lane] = (valid && !suppressed) ? 1 : 0;
+}
+
+// One 256-thread workgroup per group, any n.  scratch: order int32[G*kmax], sup uint8[G*kmax].
+__global__ void nms_block_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                 const int32_t* __restrict__ counts, int kmax, float thr, uint8_t* __restrict__ keep,
+                                 int32_t* order_all, uint8_t* sup_all) {
+    const int g = blockIdx.x;
+    const int n = min(counts[g], kmax);
+    const float* B = boxes + (size_t)g * kmax * 4;
+    const float* S = scores + (size_t)g * kmax;
+    int32_t* order = order_all + (size_t)g * kmax;
+    uint8_t* sup = sup_all + (size_t)g * kmax;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float s = S[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            float sj = S[j];
+            rank += (sj > s || (sj == s && j < i)) ? 1 : 0;
+        }
+        order[rank] = i;
+        sup[i] = 0;
+    }
+    __syncthreads();
+    for (int r = 0; r < n; ++r) {
+        const int i = order[r];
+        const bool isup = sup[i] != 0;  // uniform: written before the last barrier
+        if (!isup) {
+            const float ix1 = B[4 * i], iy1 = B[4 * i + 1], ix2 = B[4 * i + 2], iy2 = B[4 * i + 3];
+            const float iarea = box_area(ix1, iy1, ix2, iy2);
+            for (int q = r + 1 + threadIdx.x; q < n; q += blockDim.x) {
+                const int j = order[q];
+                if (sup[j]) continue;
+                const float jx1 = B[4 * j], jy1 = B[4 * j + 1], jx2 = B[4 * j + 2], jy2 = B[4 * j + 3];
+                if (iou_ge(ix1, iy1, ix2, iy2, iarea, jx1, jy1, jx2, jy2, box_area(jx1, jy1, jx2, jy2), thr)) sup[j] = 1;
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < kmax; i += blockDim.x) keep[(size_t)g * kmax + i] = (i < n && !sup[i]) ? 1 : 0;
+}
+
+}  // namespace step
+
+using namespace step;
+
+extern "C" {
+
+size_t step_nms_scratch_bytes(int G, int kmax) {
+    if (G <= 0 || kmax <= 64) return 0;
+    return (size_t)G * kmax * 5 + 16;
+}
+
+int step_nms_batched(const float* boxes, const float* scores, const int32_t* counts, int G, int kmax, float threshold,
+                     uint8_t* keep, void* scratch, step_stream_t stream) {
+    if (G < 0 || kmax < 0) return STEP_E_SHAPE;
+    if (G == 0 || kmax == 0) return STEP_OK;
+    if (!boxes || !scores || !counts || !keep) return STEP_E_NULL;
+    if (kmax <= 64) {
+        STEP_LAUNCH((nms_wave_kernel), dim3(G), dim3(64), stream, boxes, scores, counts, kmax, threshold, keep);
+    } else {
+        if (!scratch) return STEP_E_NULL;
+        int32_t* order = (int32_t*)scratch;
+        uint8_t* sup = (uint8_t*)scratch + (size_t)G * kmax * 4;
+        STEP_LAUNCH((nms_block_kernel), dim3(G), dim3(256), stream, boxes, scores, counts, kmax, threshold, keep, order,
+                    sup);
+    }
+    return STEP_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -1,0 +1,465 @@
+// step_amd/csrc/roi.hip -- ROIAlign / ROIPool forward + backward for gfx950.
+//
+// From-scratch replacements for the reference's CUDA operators
+//   external/maskrcnn_benchmark/csrc/cuda/ROIAlign_cuda.cu  (RoIAlignForward :88-146,
+//       RoIAlignBackwardFeature :201-278, bilinear_interpolate :39-86,149-199)
+//   external/maskrcnn_benchmark/csrc/cuda/ROIPool_cuda.cu   (RoIPoolFForward :40-101,
+//       RoIPoolFBackward :103-132)
+//
+// MI355X design.  The reference maps one thread to one output SCALAR of an NCHW tensor, so the
+// four bilinear taps of every sample are scattered 4-byte reads with the channel as the slowest
+// index.  Here the native layout is channels-last ([B,H,W,C]): one workgroup owns one
+// (roi, bin), its lanes run along C in 16-byte vectors, and every tap is one fully coalesced
+// row read (C = 832 fp32 -> 3.3 KB contiguous per tap).  The op is gather/HBM-bound; there is
+// nothing for MFMA to do.  An NCHW path (thread per scalar) is kept for callers that hand over
+// torch-contiguous tensors, with the same arithmetic.
+//
+// Arithmetic follows the reference operation for operation (no FMA contraction in this file),
+// so fp32 results are bit-identical to cpu/ROIAlign_cpu.cpp.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace step {
+
+struct RoiGeom {
+    int batch;
+    float start_w, start_h, bin_h, bin_w;
+    int grid_h, grid_w;
+    float count;
+};
+
+// ROIAlign_cuda.cu:101-124 / ROIAlign_cpu.cpp:160-189
+__device__ __forceinline__ RoiGeom roi_geom(const float* r, float scale, int ph, int pw, int sampling_ratio) {
+    RoiGeom g;
+    g.batch = (int)r[0];
+    g.start_w = r[1] * scale;  // no rounding
+    g.start_h = r[2] * scale;
+    float end_w = r[3] * scale;
+    float end_h = r[4] * scale;
+    float roi_w = fmaxf(end_w - g.start_w, 1.f);  // malformed ROIs are forced to 1x1
+    float roi_h = fmaxf(end_h - g.start_h, 1.f);
+    g.bin_h = roi_h / (float)ph;
+    g.bin_w = roi_w / (float)pw;
+    g.grid_h = (sampling_ratio > 0) ? sampling_ratio : (int)ceilf(roi_h / (float)ph);
+    g.grid_w = (sampling_ratio > 0) ? sampling_ratio : (int)ceilf(roi_w / (float)pw);
+    g.count = (float)(g.grid_h * g.grid_w);
+    return g;
+}
+
+struct Tap {
+    int y_low, y_high, x_low, x_high;  // -1 => void sample
+    float w1, w2, w3, w4;
+};
+
+// ROIAlign_cuda.cu:39-86 / :149-199
+__device__ __forceinline__ Tap bilinear_tap(int height, int width, float y, float x) {
+    Tap t;
+    if (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width) {
+        t.y_low = t.y_high = t.x_low = t.x_high = -1;
+        t.w1 = t.w2 = t.w3 = t.w4 = 0.f;
+        return t;
+    }
+    if (y <= 0) y = 0;
+    if (x <= 0) x = 0;
+    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+    if (y_low >= height - 1) { y_high = y_low = height - 1; y = (float)y_low; } else { y_high = y_low + 1; }
+    if (x_low >= width - 1) { x_high = x_low = width - 1; x = (float)x_low; } else { x_high = x_low + 1; }
+    float ly = y - (float)y_low, lx = x - (float)x_low;
+    float hy = 1.f - ly, hx = 1.f - lx;
+    t.w1 = hy * hx; t.w2 = hy * lx; t.w3 = ly * hx; t.w4 = ly * lx;
+    t.y_low = y_low; t.y_high = y_high; t.x_low = x_low; t.x_high = x_high;
+    return t;
+}
+
+__device__ __forceinline__ float sample_y(const RoiGeom& g, int p, int iy) {
+    return g.start_h + (float)p * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+}
+__device__ __forceinline__ float sample_x(const RoiGeom& g, int q, int ix) {
+    return g.start_w + (float)q * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+}
+
+template <typename T, int V> struct VecIO {
+    __device__ static __forceinline__ void load(const T* p, float (&f)[V]) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) f[i] = elem<T>::to_f32(p[i]);
+    }
+    __device__ static __forceinline__ void store(T* p, const float (&f)[V]) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) p[i] = elem<T>::from_f32(f[i]);
+    }
+};
+// 16-byte specialisations
+template <> struct VecIO<float, 4> {
+    __device__ static __forceinline__ void load(const float* p, float (&f)[4]) {
+        f32x4 v = *(const f32x4*)p;
+        f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+    }
+    __device__ static __forceinline__ void store(float* p, const float (&f)[4]) {
+        f32x4 v = {f[0], f[1], f[2], f[3]};
+        *(f32x4*)p = v;
+    }
+};
+template <typename T> struct VecIO16 {
+    __device__ static __forceinline__ void load(const T* p, float (&f)[8]) {
+        u16x8 v = *(const u16x8*)p;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { T e; e.v = v[i]; f[i] = elem<T>::to_f32(e); }
+    }
+    __device__ static __forceinline__ void store(T* p, const float (&f)[8]) {
+        u16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = elem<T>::from_f32(f[i]).v;
+        *(u16x8*)p = v;
+    }
+};
+template <> struct VecIO<bf16_t, 8> : VecIO16<bf16_t> {};
+template <> struct VecIO<f16_t, 8> : VecIO16<f16_t> {};
+
+// ---------------------------------------------------------------------------------------------
+// ROIAlign forward, channels-last.  grid = K*ph*pw workgroups, lanes along C in vectors of V.
+template <typename T, int V>
+__global__ void roi_align_fwd_nhwc_kernel(const T* __restrict__ feat, const float* __restrict__ rois, int C, int H,
+                                          int W, int ph, int pw, float scale, int sampling_ratio,
+                                          T* __restrict__ out) {
+    const int bin = blockIdx.x;
+    const int n = bin / (ph * pw);
+    const int p = (bin / pw) % ph;
+    const int q = bin % pw;
+    const RoiGeom g = roi_geom(rois + 5 * n, scale, ph, pw, sampling_ratio);
+    const T* base = feat + (size_t)g.batch * H * W * C;
+    for (int c = threadIdx.x * V; c < C; c += blockDim.x * V) {
+        float acc[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] = 0.f;
+        for (int iy = 0; iy < g.grid_h; ++iy) {
+            const float y = sample_y(g, p, iy);
+            for (int ix = 0; ix < g.grid_w; ++ix) {
+                const float x = sample_x(g, q, ix);
+                const Tap t = bilinear_tap(H, W, y, x);
+                if (t.y_low < 0) continue;  // contributes exactly 0
+                float v1[V], v2[V], v3[V], v4[V];
+                VecIO<T, V>::load(base + ((size_t)t.y_low * W + t.x_low) * C + c, v1);
+                VecIO<T, V>::load(base + ((size_t)t.y_low * W + t.x_high) * C + c, v2);
+                VecIO<T, V>::load(base + ((size_t)t.y_high * W + t.x_low) * C + c, v3);
+                VecIO<T, V>::load(base + ((size_t)t.y_high * W + t.x_high) * C + c, v4);
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    float val = t.w1 * v1[i] + t.w2 * v2[i] + t.w3 * v3[i] + t.w4 * v4[i];
+                    acc[i] += val;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] /= g.count;
+        VecIO<T, V>::store(out + (size_t)bin * C + c, acc);
+    }
+}
+
+// ROIAlign forward, NCHW (thread per output scalar; same arithmetic).
+template <typename T>
+__global__ void roi_align_fwd_nchw_kernel(const T* __restrict__ feat, const float* __restrict__ rois, long long total,
+                                          int C, int H, int W, int ph, int pw, float scale, int sampling_ratio,
+                                          T* __restrict__ out) {
+    for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
+         index += (long long)blockDim.x * gridDim.x) {
+        const int q = (int)(index % pw);
+        const int p = (int)((index / pw) % ph);
+        const int c = (int)((index / pw / ph) % C);
+        const int n = (int)(index / pw / ph / C);
+        const RoiGeom g = roi_geom(rois + 5 * n, scale, ph, pw, sampling_ratio);
+        const T* d = feat + ((size_t)g.batch * C + c) * H * W;
+        float acc = 0.f;
+        for (int iy = 0; iy < g.grid_h; ++iy) {
+            const float y = sample_y(g, p, iy);
+            for (int ix = 0; ix < g.grid_w; ++ix) {
+                const float x = sample_x(g, q, ix);
+                const Tap t = bilinear_tap(H, W, y, x);
+                if (t.y_low < 0) continue;
+                float v1 = elem<T>::to_f32(d[t.y_low * W + t.x_low]);
+                float v2 = elem<T>::to_f32(d[t.y_low * W + t.x_high]);
+                float v3 = elem<T>::to_f32(d[t.y_high * W + t.x_low]);
+                float v4 = elem<T>::to_f32(d[t.y_high * W + t.x_high]);
+                float val = t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4;
+                acc += val;
+            }
+        }
+        acc /= g.count;
+        out[index] = elem<T>::from_f32(acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ROIAlign backward (fp32, atomics).  ROIAlign_cuda.cu:201-278.
+__global__ void roi_align_bwd_nhwc_kernel(const float* __restrict__ grad, const float* __restrict__ rois, int C, int H,
+                                          int W, int ph, int pw, float scale, int sampling_ratio,
+                                          float* __restrict__ gfeat) {
+    const int bin = blockIdx.x;
+    const int n = bin / (ph * pw);
+    const int p = (bin / pw) % ph;
+    const int q = bin % pw;
+    const RoiGeom g = roi_geom(rois + 5 * n, scale, ph, pw, sampling_ratio);
+    float* base = gfeat + (size_t)g.batch * H * W * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float gtop = grad[(size_t)bin * C + c];
+        for (int iy = 0; iy < g.grid_h; ++iy) {
+            const float y = sample_y(g, p, iy);
+            for (int ix = 0; ix < g.grid_w; ++ix) {
+                const float x = sample_x(g, q, ix);
+                const Tap t = bilinear_tap(H, W, y, x);
+                if (t.y_low < 0) continue;
+                float g1 = gtop * t.w1 / g.count;
+                float g2 = gtop * t.w2 / g.count;
+                float g3 = gtop * t.w3 / g.count;
+                float g4 = gtop * t.w4 / g.count;
+                atomicAdd(base + ((size_t)t.y_low * W + t.x_low) * C + c, g1);
+                atomicAdd(base + ((size_t)t.y_low * W + t.x_high) * C + c, g2);
+                atomicAdd(base + ((size_t)t.y_high * W + t.x_low) * C + c, g3);
+                atomicAdd(base + ((size_t)t.y_high * W + t.x_high) * C + c, g4);
+            }
+        }
+    }
+}
+
+__global__ void roi_align_bwd_nchw_kernel(const float* __restrict__ grad, const float* __restrict__ rois,
+                                          long long total, int C, int H, int W, int ph, int pw, float scale,
+                                          int sampling_ratio, float* __restrict__ gfeat) {
+    for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
+         index += (long long)blockDim.x * gridDim.x) {
+        const int q = (int)(index % pw);
+        const int p = (int)((index / pw) % ph);
+        const int c = (int)((index / pw / ph) % C);
+        const int n = (int)(index / pw / ph / C);
+        const RoiGeom g = roi_geom(rois + 5 * n, scale, ph, pw, sampling_ratio);
+        float* d = gfeat + ((size_t)g.batch * C + c) * H * W;
+        const float gtop = grad[index];
+        for (int iy = 0; iy < g.grid_h; ++iy) {
+            const float y = sample_y(g, p, iy);
+            for (int ix = 0; ix < g.grid_w; ++ix) {
+                const float x = sample_x(g, q, ix);
+                const Tap t = bilinear_tap(H, W, y, x);
+                if (t.y_low < 0) continue;
+                atomicAdd(d + t.y_low * W + t.x_low, gtop * t.w1 / g.count);
+                atomicAdd(d + t.y_low * W + t.x_high, gtop * t.w2 / g.count);
+                atomicAdd(d + t.y_high * W + t.x_low, gtop * t.w3 / g.count);
+                atomicAdd(d + t.y_high * W + t.x_high, gtop * t.w4 / g.count);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ROIPool.  ROIPool_cuda.cu:40-132.
+struct PoolBin { int batch, hstart, hend, wstart, wend; };
+
+__device__ __forceinline__ PoolBin roi_pool_bin(const float* r, float scale, int ph, int pw, int p, int q, int H, int W) {
+    PoolBin b;
+    b.batch = (int)r[0];
+    int sw = (int)roundf(r[1] * scale);
+    int sh = (int)roundf(r[2] * scale);
+    int ew = (int)roundf(r[3] * scale);
+    int eh = (int)roundf(r[4] * scale);
+    int rw = max(ew - sw + 1, 1);
+    int rh = max(eh - sh + 1, 1);
+    float bin_h = (float)rh / (float)ph;
+    float bin_w = (float)rw / (float)pw;
+    int hstart = (int)floorf((float)p * bin_h);
+    int wstart = (int)floorf((float)q * bin_w);
+    int hend = (int)ceilf((float)(p + 1) * bin_h);
+    int wend = (int)ceilf((float)(q + 1) * bin_w);
+    b.hstart = min(max(hstart + sh, 0), H);
+    b.hend = min(max(hend + sh, 0), H);
+    b.wstart = min(max(wstart + sw, 0), W);
+    b.wend = min(max(wend + sw, 0), W);
+    return b;
+}
+
+template <typename T>
+__global__ void roi_pool_fwd_nhwc_kernel(const T* __restrict__ feat, const float* __restrict__ rois, int C, int H, int W,
+                                         int ph, int pw, float scale, T* __restrict__ out, int32_t* __restrict__ argmax) {
+    const int bin = blockIdx.x;
+    const int n = bin / (ph * pw);
+    const int p = (bin / pw) % ph;
+    const int q = bin % pw;
+    const PoolBin b = roi_pool_bin(rois + 5 * n, scale, ph, pw, p, q, H, W);
+    const bool empty = (b.hend <= b.hstart) || (b.wend <= b.wstart);
+    const T* base = feat + (size_t)b.batch * H * W * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float maxval = empty ? 0.f : -FLT_MAX;
+        int maxidx = -1;
+        for (int h = b.hstart; h < b.hend; ++h)
+            for (int w = b.wstart; w < b.wend; ++w) {
+                float v = elem<T>::to_f32(base[((size_t)h * W + w) * C + c]);
+                if (v > maxval) { maxval = v; maxidx = h * W + w; }
+            }
+        out[(size_t)bin * C + c] = elem<T>::from_f32(maxval);
+        argmax[(size_t)bin * C + c] = maxidx;
+    }
+}
+
+template <typename T>
+__global__ void roi_pool_fwd_nchw_kernel(const T* __restrict__ feat, const float* __restrict__ rois, long long total,
+                                         int C, int H, int W, int ph, int pw, float scale, T* __restrict__ out,
+                                         int32_t* __restrict__ argmax) {
+    for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
+         index += (long long)blockDim.x * gridDim.x) {
+        const int q = (int)(index % pw);
+        const int p = (int)((index / pw) % ph);
+        const int c = (int)((index / pw / ph) % C);
+        const int n = (int)(index / pw / ph / C);
+        const PoolBin b = roi_pool_bin(rois + 5 * n, scale, ph, pw, p, q, H, W);
+        const bool empty = (b.hend <= b.hstart) || (b.wend <= b.wstart);
+        const T* d = feat + ((size_t)b.batch * C + c) * H * W;
+        float maxval = empty ? 0.f : -FLT_MAX;
+        int maxidx = -1;
+        for (int h = b.hstart; h < b.hend; ++h)
+            for (int w = b.wstart; w < b.wend; ++w) {
+                float v = elem<T>::to_f32(d[h * W + w]);
+                if (v > maxval) { maxval = v; maxidx = h * W + w; }
+            }
+        out[index] = elem<T>::from_f32(maxval);
+        argmax[index] = maxidx;
+    }
+}
+
+// layout: 0 = NCHW (index = ((n*C+c)*ph+p)*pw+q), 1 = NHWC (index = ((n*ph+p)*pw+q)*C+c)
+__global__ void roi_pool_bwd_kernel(const float* __restrict__ grad, const int32_t* __restrict__ argmax,
+                                    const float* __restrict__ rois, long long total, int layout, int C, int H, int W,
+                                    int ph, int pw, float* __restrict__ gfeat) {
+    for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
+         index += (long long)blockDim.x * gridDim.x) {
+        int c, n;
+        if (layout == STEP_NCHW) {
+            c = (int)((index / pw / ph) % C);
+            n = (int)(index / pw / ph / C);
+        } else {
+            c = (int)(index % C);
+            n = (int)(index / C / pw / ph);
+        }
+        const int a = argmax[index];
+        if (a == -1) continue;
+        const int batch = (int)rois[5 * n];
+        if (layout == STEP_NCHW)
+            atomicAdd(gfeat + ((size_t)batch * C + c) * H * W + a, grad[index]);
+        else
+            atomicAdd(gfeat + ((size_t)batch * H * W + a) * C + c, grad[index]);
+    }
+}
+
+static inline int lanes_for(int items) {
+    int t = 64;
+    while (t < items && t < 256) t <<= 1;
+    return t;
+}
+static inline unsigned flat_grid(long long total, int block) {
+    long long g = ceil_div64(total, block);
+    if (g > 8192) g = 8192;  // grid-stride the rest: 256 CUs x 8 workgroups x 4
+    return (unsigned)g;
+}
+
+template <typename T>
+static int roi_align_forward_t(const void* feat, int layout, const float* rois, int K, int C, int H, int W, int ph,
+                               int pw, float scale, int sr, void* out, step_stream_t stream) {
+    constexpr int V = elem<T>::VEC;
+    if (layout == STEP_NHWC) {
+        if (C % V == 0 && ((uintptr_t)feat % 16) == 0 && ((uintptr_t)out % 16) == 0) {
+            STEP_LAUNCH((roi_align_fwd_nhwc_kernel<T, V>), dim3(K * ph * pw), dim3(lanes_for(C / V)), stream,
+                        (const T*)feat, rois, C, H, W, ph, pw, scale, sr, (T*)out);
+        } else {
+            STEP_LAUNCH((roi_align_fwd_nhwc_kernel<T, 1>), dim3(K * ph * pw), dim3(lanes_for(C)), stream,
+                        (const T*)feat, rois, C, H, W, ph, pw, scale, sr, (T*)out);
+        }
+    } else {
+        long long total = (long long)K * C * ph * pw;
+        STEP_LAUNCH((roi_align_fwd_nchw_kernel<T>), dim3(flat_grid(total, 256)), dim3(256), stream, (const T*)feat,
+                    rois, total, C, H, W, ph, pw, scale, sr, (T*)out);
+    }
+    return STEP_LAUNCH_CHECK();
+}
+
+template <typename T>
+static int roi_pool_forward_t(const void* feat, int layout, const float* rois, int K, int C, int H, int W, int ph,
+                              int pw, float scale, void* out, int32_t* argmax, step_stream_t stream) {
+    if (layout == STEP_NHWC) {
+        STEP_LAUNCH((roi_pool_fwd_nhwc_kernel<T>), dim3(K * ph * pw), dim3(lanes_for(C)), stream, (const T*)feat, rois,
+                    C, H, W, ph, pw, scale, (T*)out, argmax);
+    } else {
+        long long total = (long long)K * C * ph * pw;
+        STEP_LAUNCH((roi_pool_fwd_nchw_kernel<T>), dim3(flat_grid(total, 256)), dim3(256), stream, (const T*)feat,
+                    rois, total, C, H, W, ph, pw, scale, (T*)out, argmax);
+    }
+    return STEP_LAUNCH_CHECK();
+}
+
+}  // namespace step
+
+using namespace step;
+
+extern "C" {
+
+int step_roi_align_forward(const void* feat, int dtype, int layout, const float* rois, int K, int B, int C, int H,
+                           int W, int ph, int pw, float scale, int sr, void* out, step_stream_t stream) {
+    if (K < 0 || B < 0 || C <= 0 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0) return STEP_E_SHAPE;
+    if (layout != STEP_NCHW && layout != STEP_NHWC) return STEP_E_UNSUPPORTED;
+    if (K == 0) return STEP_OK;
+    if (!feat || !rois || !out) return STEP_E_NULL;
+    switch (dtype) {
+        case STEP_F32: return roi_align_forward_t<float>(feat, layout, rois, K, C, H, W, ph, pw, scale, sr, out, stream);
+        case STEP_BF16: return roi_align_forward_t<bf16_t>(feat, layout, rois, K, C, H, W, ph, pw, scale, sr, out, stream);
+        case STEP_F16: return roi_align_forward_t<f16_t>(feat, layout, rois, K, C, H, W, ph, pw, scale, sr, out, stream);
+    }
+    return STEP_E_DTYPE;
+}
+
+int step_roi_align_backward(const float* grad, int layout, const float* rois, int K, int B, int C, int H, int W,
+                            int ph, int pw, float scale, int sr, float* gfeat, step_stream_t stream) {
+    if (K < 0 || B < 0 || C <= 0 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0) return STEP_E_SHAPE;
+    if (layout != STEP_NCHW && layout != STEP_NHWC) return STEP_E_UNSUPPORTED;
+    if (B == 0) return STEP_OK;
+    if (!gfeat) return STEP_E_NULL;
+    int rc = (int)hipMemsetAsync(gfeat, 0, sizeof(float) * (size_t)B * C * H * W, (hipStream_t)stream);
+    if (rc) return rc;
+    if (K == 0) return STEP_OK;
+    if (!grad || !rois) return STEP_E_NULL;
+    if (layout == STEP_NHWC) {
+        STEP_LAUNCH((roi_align_bwd_nhwc_kernel), dim3(K * ph * pw), dim3(lanes_for(C)), stream, grad, rois, C, H, W, ph,
+                    pw, scale, sr, gfeat);
+    } else {
+        long long total = (long long)K * C * ph * pw;
+        STEP_LAUNCH((roi_align_bwd_nchw_kernel), dim3(flat_grid(total, 256)), dim3(256), stream, grad, rois, total, C,
+                    H, W, ph, pw, scale, sr, gfeat);
+    }
+    return STEP_LAUNCH_CHECK();
+}
+
+int step_roi_pool_forward(const void* feat, int dtype, int layout, const float* rois, int K, int B, int C, int H,
+                          int W, int ph, int pw, float scale, void* out, int32_t* argmax, step_stream_t stream) {
+    if (K < 0 || B < 0 || C <= 0 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0) return STEP_E_SHAPE;
+    if (layout != STEP_NCHW && layout != STEP_NHWC) return STEP_E_UNSUPPORTED;
+    if (K == 0) return STEP_OK;
+    if (!feat || !rois || !out || !argmax) return STEP_E_NULL;
+    switch (dtype) {
+        case STEP_F32: return roi_pool_forward_t<float>(feat, layout, rois, K, C, H, W, ph, pw, scale, out, argmax, stream);
+        case STEP_BF16: return roi_pool_forward_t<bf16_t>(feat, layout, rois, K, C, H, W, ph, pw, scale, out, argmax, stream);
+        case STEP_F16: return roi_pool_forward_t<f16_t>(feat, layout, rois, K, C, H, W, ph, pw, scale, out, argmax, stream);
+    }
+    return STEP_E_DTYPE;
+}
+
+int step_roi_pool_backward(const float* grad, const int32_t* argmax, int layout, const float* rois, int K, int B,
+                           int C, int H, int W, int ph, int pw, float* gfeat, step_stream_t stream) {
+    if (K < 0 || B < 0 || C <= 0 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0) return STEP_E_SHAPE;
+    if (layout != STEP_NCHW && layout != STEP_NHWC) return STEP_E_UNSUPPORTED;
+    if (B == 0) return STEP_OK;
+    if (!gfeat) return STEP_E_NULL;
+    int rc = (int)hipMemsetAsync(gfeat, 0, sizeof(float) * (size_t)B * C * H * W, (hipStream_t)stream);
+    if (rc) return rc;
+    if (K == 0) return STEP_OK;
+    if (!grad || !rois || !argmax) return STEP_E_NULL;
+    long long total = (long long)K * C * ph * pw;
+    STEP_LAUNCH((roi_pool_bwd_kernel), dim3(flat_grid(total, 256)), dim3(256), stream, grad, argmax, rois, total,
+                layout, C, H, W, ph, pw, gfeat);
+    return STEP_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -1,0 +1,218 @@
+// tests/emul/hipemu.cpp -- fiber scheduler for the host-side SIMT interpreter (TEST ONLY).
+#include "hipemu.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <atomic>
+#include <thread>
+#include <vector>
+
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size hipemu_switch,.-hipemu_switch
+)");
+
+namespace hipemu {
+thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+
+namespace {
+constexpr size_t kStack = 192 * 1024;
+enum { YIELD_BLOCK = 0, YIELD_WAVE = 1 };
+
+struct Wave {
+    int arrived = 0;
+    unsigned gen = 0;
+    int released = 0;
+    alignas(64) char scratch[64 * 256];
+};
+struct Block {
+    int n = 0;
+    int cur = 0;
+    int live = 0;
+    int yield_scope = YIELD_BLOCK;
+    std::vector<void*> sp;
+    std::vector<char> done;
+    std::vector<dim3> tid;
+    void* sched_sp = nullptr;
+    int bar_arrived = 0;
+    unsigned bar_gen = 0;
+    std::vector<Wave> waves;
+    const std::function<void()>* body = nullptr;
+    char* stacks = nullptr;
+    size_t stacks_cap = 0;
+};
+thread_local Block* t_blk = nullptr;
+
+void yield_to_sched(int scope) {
+    Block* b = t_blk;
+    b->yield_scope = scope;
+    hipemu_switch(&b->sp[b->cur], b->sched_sp);
+}
+
+void fiber_main() {
+    Block* b = t_blk;
+    (*b->body)();
+    b->done[b->cur] = 1;
+    b->live--;
+    if (b->live > 0 && b->bar_arrived == b->live) {   // the others are all waiting at a barrier
+        b->bar_arrived = 0;
+        b->bar_gen++;
+    }
+    yield_to_sched(YIELD_BLOCK);
+    fprintf(stderr, "hipemu: resumed a finished fiber\n");
+    abort();
+}
+
+void run_block(Block* b, dim3 bidx, dim3 bdim, dim3 gdim, const std::function<void()>& body) {
+    int n = (int)(bdim.x * bdim.y * bdim.z);
+    if (n % 64) { fprintf(stderr, "hipemu: block size %d is not a multiple of 64\n", n); abort(); }
+    b->n = n; b->live = n; b->cur = n - 1; b->body = &body; b->yield_scope = YIELD_BLOCK;
+    b->sp.assign(n, nullptr); b->done.assign(n, 0); b->tid.resize(n);
+    b->bar_arrived = 0;
+    b->waves.resize(n / 64);
+    for (auto& w : b->waves) { w.arrived = 0; w.released = 0; }
+    if (b->stacks_cap < (size_t)n * kStack) {
+        free(b->stacks);
+        b->stacks = (char*)aligned_alloc(4096, (size_t)n * kStack);
+        b->stacks_cap = (size_t)n * kStack;
+    }
+    for (int i = 0; i < n; ++i) {
+        b->tid[i] = dim3(i % bdim.x, (i / bdim.x) % bdim.y, i / (bdim.x * bdim.y));
+        uintptr_t top = ((uintptr_t)(b->stacks + (size_t)(i + 1) * kStack)) & ~(uintptr_t)15;
+        void** s = (void**)top;
+        *(--s) = nullptr;                 // fake return address of fiber_main
+        *(--s) = (void*)&fiber_main;      // popped by `ret` in hipemu_switch
+        for (int r = 0; r < 6; ++r) *(--s) = nullptr;
+        b->sp[i] = (void*)s;
+    }
+    t_blockIdx = bidx; t_blockDim = bdim; t_gridDim = gdim;
+    t_blk = b;
+    int i = 0;
+    while (b->live > 0) {
+        // pick next runnable fiber
+        if (b->yield_scope == YIELD_WAVE) {
+            int w0 = (b->cur / 64) * 64;
+            int k = b->cur;
+            for (int t = 0; t < 64; ++t) { k = w0 + ((k - w0 + 1) & 63); if (!b->done[k]) break; }
+            if (b->done[k]) { b->yield_scope = YIELD_BLOCK; continue; }
+            i = k;
+        } else {
+            int k = b->cur;
+            for (int t = 0; t < n; ++t) { k = (k + 1) % n; if (!b->done[k]) break; }
+            i = k;
+        }
+        b->cur = i;
+        t_threadIdx = b->tid[i];
+        b->yield_scope = YIELD_BLOCK;
+        hipemu_switch(&b->sched_sp, b->sp[i]);
+    }
+    t_blk = nullptr;
+}
+}  // namespace
+
+void block_barrier() {
+    Block* b = t_blk;
+    unsigned g = b->bar_gen;
+    if (++b->bar_arrived == b->live) {   // finished fibers do not take part (as on hardware)
+        b->bar_arrived = 0;
+        b->bar_gen++;
+        return;
+    }
+    while (b->bar_gen == g) yield_to_sched(YIELD_BLOCK);
+}
+
+char* exchange_begin(const void* mine, int bytes) {
+    Block* b = t_blk;
+    Wave& w = b->waves[b->cur / 64];
+    memcpy(w.scratch + 256 * (b->cur & 63), mine, (size_t)bytes);
+    unsigned g = w.gen;
+    if (++w.arrived == 64) {
+        w.arrived = 0;
+        w.released = 0;
+        w.gen++;
+    } else {
+        while (w.gen == g) yield_to_sched(YIELD_WAVE);
+    }
+    return w.scratch;
+}
+
+void exchange_end() {
+    Block* b = t_blk;
+    Wave& w = b->waves[b->cur / 64];
+    // second phase: nobody may overwrite the scratch until all 64 lanes have read it
+    unsigned g = w.gen;
+    if (++w.released == 64) {
+        w.released = 0;
+        w.gen++;
+    } else {
+        while (w.gen == g) yield_to_sched(YIELD_WAVE);
+    }
+}
+
+void mfma_32x32_k16(const float (&a)[8], const float (&b)[8], f32x16& c, bool f32_pairing) {
+    float mine[16];
+    for (int j = 0; j < 8; ++j) { mine[j] = a[j]; mine[8 + j] = b[j]; }
+    char* s = exchange_begin(mine, 64);
+    int lane = (int)(t_threadIdx.x & 63);   // kernels here use 1-D blocks
+    int col = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = c[r];
+        const float* a0 = (const float*)(s + 256 * row);
+        const float* a1 = (const float*)(s + 256 * (row + 32));
+        const float* b0 = (const float*)(s + 256 * col) + 8;
+        const float* b1 = (const float*)(s + 256 * (col + 32)) + 8;
+        if (f32_pairing) {
+            for (int j = 0; j < 8; ++j) { acc = fmaf(a0[j], b0[j], acc); acc = fmaf(a1[j], b1[j], acc); }
+        } else {
+            for (int j = 0; j < 8; ++j) acc = fmaf(a0[j], b0[j], acc);
+            for (int j = 0; j < 8; ++j) acc = fmaf(a1[j], b1[j], acc);
+        }
+        c[r] = acc;
+    }
+    exchange_end();
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+    long long nblocks = (long long)grid.x * grid.y * grid.z;
+    if (nblocks <= 0) return;
+    unsigned hw = std::thread::hardware_concurrency();
+    const char* e = getenv("HIPEMU_THREADS");
+    if (e) hw = (unsigned)atoi(e);
+    if (hw < 1) hw = 1;
+    unsigned nth = (unsigned)(nblocks < (long long)hw ? nblocks : hw);
+    std::atomic<long long> next{0};
+    auto worker = [&]() {
+        static thread_local Block blk;
+        for (;;) {
+            long long i = next.fetch_add(1);
+            if (i >= nblocks) break;
+            dim3 bi((unsigned)(i % grid.x), (unsigned)((i / grid.x) % grid.y), (unsigned)(i / ((long long)grid.x * grid.y)));
+            run_block(&blk, bi, block, grid, body);
+        }
+    };
+    if (nth == 1) { worker(); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nth; ++t) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+}
+}  // namespace hipemu
