@@ -1,0 +1,485 @@
+"""Backend-agnostic parity cases for the C ABI (include/step_amd.h): every case runs the kernels
+through `bk` (tests/backends.py: host interpreter or the real gfx950 library) and checks the result
+against the oracle (oracle/) or the golden vectors (tests/golden)."""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import oracle
+from oracle import i3d_ref as R
+from step_amd import _capi
+
+F32, BF16, F16 = _capi.F32, _capi.BF16, _capi.F16
+NCHW, NHWC = _capi.NCHW, _capi.NHWC
+NP_DT = {F32: np.float32, BF16: np.uint16, F16: np.float16}
+
+
+# ------------------------------------------------------------------ dtype helpers
+def to_bf16_bits(x):
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def from_bf16_bits(b):
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def encode(x, dt):
+    x = np.ascontiguousarray(x, np.float32)
+    return x if dt == F32 else (to_bf16_bits(x) if dt == BF16 else x.astype(np.float16))
+
+
+def decode(a, dt):
+    return a if dt == F32 else (from_bf16_bits(a) if dt == BF16 else a.astype(np.float32))
+
+
+def quantize(x, dt):
+    return decode(encode(x, dt), dt)
+
+
+def tol(dt):
+    # fp32: summation-order noise only.  16-bit: one rounding of the stored output (inputs are
+    # quantised identically on both sides, accumulation is fp32 on both sides).
+    return {F32: 2e-5, BF16: 2 ** -7, F16: 2 ** -9}[dt]
+
+
+def nhwc(x):
+    return np.ascontiguousarray(np.transpose(x, (0, 2, 3, 1)))
+
+
+def nchw(x):
+    return np.ascontiguousarray(np.transpose(x, (0, 3, 1, 2)))
+
+
+def cl(x):   # NCDHW -> NDHWC
+    return np.ascontiguousarray(np.transpose(x, (0, 2, 3, 4, 1)))
+
+
+def uncl(x):
+    return np.ascontiguousarray(np.transpose(x, (0, 4, 1, 2, 3)))
+
+
+# ------------------------------------------------------------------ op runners
+def run_roi_align(bk, feat_nchw, rois, pooled, scale, sr, layout, dt=F32):
+    B, C, H, W = feat_nchw.shape
+    K = rois.shape[0]
+    ph, pw = pooled
+    f = bk.dev(encode(feat_nchw if layout == NCHW else nhwc(feat_nchw), dt))
+    r = bk.dev(np.ascontiguousarray(rois, np.float32))
+    out = bk.dev(np.zeros((K, C, ph, pw) if layout == NCHW else (K, ph, pw, C), NP_DT[dt]))
+    rc = bk.lib.step_roi_align_forward(f.ptr, dt, layout, r.ptr, K, B, C, H, W, ph, pw, scale, sr, out.ptr, bk.stream)
+    assert rc == 0, rc
+    o = decode(out.get(), dt)
+    return o if layout == NCHW else nchw(o)
+
+
+def run_nms(bk, boxes, scores, counts, thr):
+    G, kmax = scores.shape
+    b, s, c = bk.dev(boxes), bk.dev(scores), bk.dev(counts)
+    keep = bk.dev(np.full((G, kmax), 9, np.uint8))
+    nb = bk.lib.step_nms_scratch_bytes(G, kmax)
+    scratch = bk.dev(np.zeros(max(nb, 1), np.uint8))
+    rc = bk.lib.step_nms_batched(b.ptr, s.ptr, c.ptr, G, kmax, thr, keep.ptr, scratch.ptr if nb else None, bk.stream)
+    assert rc == 0, rc
+    return keep.get()
+
+
+def pack_weight(bk, w, dt, perm=None):
+    Cout, Cin, kd, kh, kw = w.shape
+    n = bk.lib.step_conv_packed_elems(Cout, Cin, kd, kh, kw)
+    out = bk.dev(np.zeros(n, NP_DT[dt]))
+    wd = bk.dev(np.ascontiguousarray(w, np.float32))
+    p = bk.dev(None if perm is None else np.ascontiguousarray(perm, np.int32))
+    assert bk.lib.step_conv_pack_weight(wd.ptr, Cout, Cin, kd, kh, kw, dt, p.ptr, out.ptr, bk.stream) == 0
+    return out
+
+
+def run_conv(bk, x, w, scale, shift, dt, relu=True, res=None, x_pad=(0, 0), y_pad=(0, 0)):
+    """x NCDHW fp32, w torch layout; x_pad/y_pad = extra channels (before, after) in the buffers."""
+    N, Cin, D, H, W = x.shape
+    Cout = w.shape[0]
+    xc = cl(x)
+    xb = np.zeros(xc.shape[:-1] + (x_pad[0] + Cin + x_pad[1],), np.float32)
+    xb[..., x_pad[0]:x_pad[0] + Cin] = xc
+    xb[..., :x_pad[0]] = 77.0           # must never be read
+    xb[..., x_pad[0] + Cin:] = -55.0
+    xe = bk.dev(encode(xb, dt))
+    yb = bk.dev(np.zeros((N, D, H, W, y_pad[0] + Cout + y_pad[1]), NP_DT[dt]))
+    wp = pack_weight(bk, w, dt)
+    d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=w.shape[2], kh=w.shape[3], kw=w.shape[4],
+                       x_cstride=xb.shape[-1], x_coff=x_pad[0], y_cstride=y_pad[0] + Cout + y_pad[1], y_coff=y_pad[0],
+                       res_cstride=Cout, res_coff=0, relu=int(relu))
+    re = bk.dev(None if res is None else encode(cl(res), dt))
+    sc = bk.dev(None if scale is None else np.ascontiguousarray(scale, np.float32))
+    sh = bk.dev(None if shift is None else np.ascontiguousarray(shift, np.float32))
+    rc = bk.lib.step_conv_forward(ctypes.byref(d), xe.ptr, wp.ptr, sc.ptr, sh.ptr, re.ptr, yb.ptr, bk.stream)
+    assert rc == 0, rc
+    y = decode(yb.get(), dt)
+    assert not y[..., :y_pad[0]].any() and not y[..., y_pad[0] + Cout:].any()
+    return uncl(y[..., y_pad[0]:y_pad[0] + Cout])
+
+
+def ref_conv(x, w, scale, shift, dt, relu=True, res=None):
+    xq = torch.from_numpy(quantize(x, dt))
+    wq = torch.from_numpy(quantize(w, dt))
+    y = F.conv3d(xq, wq, padding=tuple(k // 2 for k in w.shape[2:]))
+    if scale is not None:
+        y = y * torch.from_numpy(scale).view(1, -1, 1, 1, 1)
+    if shift is not None:
+        y = y + torch.from_numpy(shift).view(1, -1, 1, 1, 1)
+    if res is not None:
+        y = y + torch.from_numpy(quantize(res, dt))
+    return (F.relu(y) if relu else y).numpy()
+
+
+def run_stem(bk, x_ntchw, w, scale, shift, dt):
+    N, T, _, H, W = x_ntchw.shape
+    Cout = w.shape[0]
+    wp = bk.dev(np.zeros(bk.lib.step_stem_packed_elems(Cout), NP_DT[dt]))
+    wd = bk.dev(np.ascontiguousarray(w, np.float32))
+    assert bk.lib.step_stem_pack_weight(wd.ptr, Cout, dt, wp.ptr, bk.stream) == 0
+    To, Ho, Wo = (T - 2) // 2 + 1, (H - 2) // 2 + 1, (W - 2) // 2 + 1
+    y = bk.dev(np.zeros((N, To, Ho, Wo, Cout), NP_DT[dt]))
+    xe, sc, sh = bk.dev(encode(x_ntchw, dt)), bk.dev(scale), bk.dev(shift)
+    rc = bk.lib.step_stem_forward(dt, xe.ptr, N, T, H, W, wp.ptr, sc.ptr, sh.ptr, Cout, y.ptr, Cout, 0, bk.stream)
+    assert rc == 0, rc
+    return uncl(decode(y.get(), dt))
+
+
+def ref_stem(x, w, scale, shift, dt):
+    xq = torch.from_numpy(quantize(x, dt)).permute(0, 2, 1, 3, 4)
+    y = F.conv3d(F.pad(xq, (2, 3, 2, 3, 2, 3)), torch.from_numpy(quantize(w, dt)), stride=2)
+    return F.relu(y * torch.from_numpy(scale).view(1, -1, 1, 1, 1) + torch.from_numpy(shift).view(1, -1, 1, 1, 1)).numpy()
+
+
+# ------------------------------------------------------------------ cases (bk, golden)
+def case_roi_align_forward_golden_bit_exact(bk, golden):
+    g = golden("roi_nms_golden")
+    feat = R.fill_tensor("golden.roi.feat", (3, 6, 25, 25), "image").numpy()   # C=6: scalar-lane path
+    for layout in (NCHW, NHWC):
+        for tag, pooled, sr in (("p7s0", (7, 7), 0), ("p7s2", (7, 7), 2), ("p3x5s0", (3, 5), 0)):
+            out = run_roi_align(bk, feat, g["align_rois"], pooled, 1 / 16., sr, layout)
+            assert np.array_equal(out, g["align_out_" + tag]), (layout, tag)
+
+
+def case_roi_align_forward_vector_path_and_tubes(bk, golden):
+    g = golden("roi_nms_golden")
+    conv = R.fill_tensor("golden.roi.conv", (2, 3, 16, 25, 25), "feat").numpy().reshape(6, 16, 25, 25)
+    out = run_roi_align(bk, conv, g["tube_rois"].reshape(-1, 5), (7, 7), 1 / 16., 0, NHWC)   # C=16: 16-byte lanes
+    assert np.array_equal(out, g["tube_out"])
+
+
+def case_roi_align_forward_16bit(bk, golden):
+    rs = np.random.RandomState(1)
+    x = rs.randn(2, 16, 13, 11).astype(np.float32)
+    rois = np.array([[0, 3, 5, 150, 120], [1, 20, 30, 60.5, 99.25]], np.float32)
+    for dt in (BF16, F16):
+        ref = oracle.roi_align_forward(quantize(x, dt), rois, (7, 7), 1 / 16., 0)
+        for layout in (NCHW, NHWC):
+            out = run_roi_align(bk, x, rois, (7, 7), 1 / 16., 0, layout, dt)
+            assert np.abs(out - ref).max() <= tol(dt) * np.abs(ref).max()
+
+
+def case_roi_align_backward(bk, golden):
+    rs = np.random.RandomState(2)
+    B, C, H, W = 2, 8, 9, 12
+    rois = np.array([[0, 0, 0, 190, 140], [1, 33.3, 20.1, 120.7, 100.2], [1, -20, 100, 90, 250], [0, 50, 50, 50.5, 50.5]], np.float32)
+    K = rois.shape[0]
+    for layout in (NCHW, NHWC):
+        for sr in (0, 2):
+            g = rs.randn(K, C, 7, 7).astype(np.float32)
+            ref = oracle.roi_align_backward(g, rois, (7, 7), 1 / 16., sr, (B, C, H, W))
+            gi = bk.dev(np.full((B, C, H, W) if layout == NCHW else (B, H, W, C), 7.0, np.float32))   # op must zero it
+            gg, r = bk.dev(g if layout == NCHW else nhwc(g)), bk.dev(rois)
+            rc = bk.lib.step_roi_align_backward(gg.ptr, layout, r.ptr, K, B, C, H, W, 7, 7, 1 / 16., sr, gi.ptr, bk.stream)
+            assert rc == 0
+            got = gi.get() if layout == NCHW else nchw(gi.get())
+            assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())   # atomics: order differs
+
+
+def case_roi_pool_forward_backward(bk, golden):
+    rs = np.random.RandomState(3)
+    B, C, H, W = 2, 5, 10, 13
+    x = rs.randn(B, C, H, W).astype(np.float32)
+    rois = np.array([[0, 0, 0, 200, 150], [1, 17, 9, 88, 140], [0, 300, 300, 400, 400], [1, 40, 40, 41, 41], [0, -30, -10, 50, 60]], np.float32)
+    K = rois.shape[0]
+    ref, refarg = oracle.roi_pool_forward(x, rois, (7, 7), 1 / 16.)
+    for layout in (NCHW, NHWC):
+        xx, r = bk.dev(x if layout == NCHW else nhwc(x)), bk.dev(rois)
+        oshape = (K, C, 7, 7) if layout == NCHW else (K, 7, 7, C)
+        out, arg = bk.dev(np.zeros(oshape, np.float32)), bk.dev(np.zeros(oshape, np.int32))
+        assert bk.lib.step_roi_pool_forward(xx.ptr, F32, layout, r.ptr, K, B, C, H, W, 7, 7, 1 / 16., out.ptr, arg.ptr, bk.stream) == 0
+        o, a = (out.get(), arg.get()) if layout == NCHW else (nchw(out.get()), nchw(arg.get()))
+        assert np.array_equal(o, ref) and np.array_equal(a, refarg)
+        g = rs.randn(K, C, 7, 7).astype(np.float32)
+        refg = oracle.roi_pool_backward(g, refarg, rois, (7, 7), x.shape)
+        gg = bk.dev(g if layout == NCHW else nhwc(g))
+        gi = bk.dev(np.full(xx.get().shape, 3.0, np.float32))
+        assert bk.lib.step_roi_pool_backward(gg.ptr, arg.ptr, layout, r.ptr, K, B, C, H, W, 7, 7, gi.ptr, bk.stream) == 0
+        got = gi.get() if layout == NCHW else nchw(gi.get())
+        assert np.abs(got - refg).max() <= 1e-5
+
+
+def case_roi_empty_and_bad_args(bk, golden):
+    L = bk.lib
+    x = bk.dev(np.zeros((1, 4, 4, 8), np.float32))
+    assert L.step_roi_align_forward(x.ptr, 0, 1, None, 0, 1, 8, 4, 4, 7, 7, 1.0, 0, None, bk.stream) == 0      # K = 0
+    assert L.step_roi_align_forward(x.ptr, 9, 1, x.ptr, 1, 1, 8, 4, 4, 7, 7, 1.0, 0, x.ptr, bk.stream) == -1   # dtype
+    assert L.step_roi_align_forward(None, 0, 1, x.ptr, 1, 1, 8, 4, 4, 7, 7, 1.0, 0, x.ptr, bk.stream) == -3    # null
+    assert L.step_roi_align_forward(x.ptr, 0, 5, x.ptr, 1, 1, 8, 4, 4, 7, 7, 1.0, 0, x.ptr, bk.stream) == -4   # layout
+    assert L.step_nms_batched(None, None, None, 0, 34, 0.4, None, None, bk.stream) == 0                          # G = 0
+    assert L.step_abi_version() == _capi.ABI_VERSION and b"gfx950" in L.step_version()
+
+
+def case_nms_golden_bit_exact(bk, golden):
+    g = golden("roi_nms_golden")
+    for i in range(int(g["nms_count"])):
+        b, s, thr = g["nms%d_boxes" % i], g["nms%d_scores" % i], float(g["nms%d_thr" % i])
+        keep = run_nms(bk, b[None].copy(), s[None].copy(), np.array([b.shape[0]], np.int32), thr)
+        assert np.array_equal(np.nonzero(keep[0])[0], g["nms%d_keep" % i]), i
+
+
+def case_nms_batched_groups_and_ties(bk, golden):
+    for kmax in (11, 34, 64, 109):
+        rs = np.random.RandomState(kmax)
+        G = 9
+        boxes = np.zeros((G, kmax, 4), np.float32)
+        scores = np.zeros((G, kmax), np.float32)
+        counts = rs.randint(0, kmax + 1, G).astype(np.int32)
+        counts[0], counts[1] = 0, kmax
+        for gi in range(G):
+            xy = rs.uniform(0, 300, (kmax, 2))
+            wh = rs.uniform(10, 150, (kmax, 2))
+            boxes[gi] = np.concatenate([xy, xy + wh], 1)
+            scores[gi] = rs.randint(0, 6, kmax) / 6.0          # many exact ties -> lower index first
+        keep = run_nms(bk, boxes, scores, counts, 0.4)
+        assert np.array_equal(keep, oracle.nms_batched(boxes, scores, counts, 0.4)), kmax
+
+
+POOLS = [((1, 3, 3), (1, 2, 2)), ((3, 3, 3), (2, 2, 2)), ((3, 3, 3), (1, 1, 1)), ((2, 2, 2), (2, 2, 2))]
+
+
+def case_maxpool_tf(bk, golden):
+    L = bk.lib
+    rs = np.random.RandomState(5)
+    N, C, D, H, W = 2, 16, 5, 9, 7                    # odd sizes: ceil-mode overhang, negative values
+    x = rs.randn(N, C, D, H, W).astype(np.float32)
+    for k, s in POOLS:
+        for dt in (F32, BF16):
+            ref = R.maxpool_tf(torch.from_numpy(quantize(x, dt)), k, s).numpy()
+            Do, Ho, Wo = (L.step_pool_out_size(a, b, c) for a, b, c in zip((D, H, W), k, s))
+            assert ref.shape == (N, C, Do, Ho, Wo)
+            xcl = bk.dev(encode(cl(x), dt))
+            ycs, yoff = 40, 8                          # write into a channel slice of a wider buffer
+            y = bk.dev(np.zeros((N, Do, Ho, Wo, ycs), NP_DT[dt]))
+            rc = L.step_maxpool3d_tf(dt, xcl.ptr, N, D, H, W, C, C, 0, k[0], k[1], k[2], s[0], s[1], s[2], y.ptr, ycs, yoff, bk.stream)
+            assert rc == 0
+            yy = decode(y.get(), dt)
+            assert np.array_equal(uncl(yy[..., yoff:yoff + C]), ref), (k, s, dt)
+            assert not yy[..., :yoff].any() and not yy[..., yoff + C:].any()
+
+
+def case_maxpool_zero_pad_value(bk, golden):
+    g = golden("ops_golden")
+    x = bk.dev(-np.ones((1, 4, 5, 5, 4), np.float32))
+    y = bk.dev(np.zeros((1, 2, 3, 3, 4), np.float32))
+    assert bk.lib.step_maxpool3d_tf(0, x.ptr, 1, 4, 5, 5, 4, 4, 0, 3, 3, 3, 2, 2, 2, y.ptr, 4, 0, bk.stream) == 0
+    yy = uncl(y.get())
+    assert np.array_equal(yy[:, :1], g["pool_allneg"]) and yy.max() == 0.0 and yy.min() == -1.0
+
+
+def case_pool_golden(bk, golden):
+    g = golden("ops_golden")
+    x = R.fill_tensor("golden.pool.in", (2, 5, 6, 9, 11), "image").numpy()
+    xp = np.zeros((2, 8, 6, 9, 11), np.float32)       # C=5 padded to 8 channels (16-byte lanes)
+    xp[:, :5] = x
+    for tag, k, s in (("k133s122", (1, 3, 3), (1, 2, 2)), ("k333s222", (3, 3, 3), (2, 2, 2)),
+                      ("k333s111", (3, 3, 3), (1, 1, 1)), ("k222s222", (2, 2, 2), (2, 2, 2))):
+        ref = g["pool_" + tag]
+        xd = bk.dev(cl(xp))
+        y = bk.dev(np.zeros((2,) + ref.shape[2:] + (8,), np.float32))
+        assert bk.lib.step_maxpool3d_tf(0, xd.ptr, 2, 6, 9, 11, 8, 8, 0, k[0], k[1], k[2], s[0], s[1], s[2], y.ptr, 8, 0, bk.stream) == 0
+        assert np.array_equal(uncl(y.get())[:, :5], ref), tag
+
+
+def case_avgpool_hw(bk, golden):
+    rs = np.random.RandomState(6)
+    x = rs.randn(2, 8, 3, 13, 13).astype(np.float32)
+    ref = F.avg_pool3d(torch.from_numpy(x), (1, 13, 13), (1, 1, 1)).numpy()
+    xcl, y = bk.dev(cl(x)), bk.dev(np.zeros((2, 3, 1, 1, 8), np.float32))
+    assert bk.lib.step_avgpool_hw(0, xcl.ptr, 2, 3, 13, 13, 8, 13, 13, y.ptr, bk.stream) == 0
+    assert np.abs(uncl(y.get()) - ref).max() < 1e-6
+
+
+def case_transpose_cs(bk, golden):
+    rs = np.random.RandomState(7)
+    x = rs.randn(2, 37, 50).astype(np.float32)
+    xd, y = bk.dev(x), bk.dev(np.zeros((2, 50, 37), np.float32))
+    assert bk.lib.step_transpose_cs(xd.ptr, 0, y.ptr, 0, 2, 37, 50, 1, bk.stream) == 0
+    assert np.array_equal(y.get(), np.transpose(x, (0, 2, 1)))
+    z = bk.dev(np.zeros_like(x))
+    assert bk.lib.step_transpose_cs(y.ptr, 0, z.ptr, 0, 2, 37, 50, 0, bk.stream) == 0
+    assert np.array_equal(z.get(), x)
+    yb = bk.dev(np.zeros((2, 50, 37), np.uint16))
+    assert bk.lib.step_transpose_cs(xd.ptr, 0, yb.ptr, 1, 2, 37, 50, 1, bk.stream) == 0
+    assert np.array_equal(yb.get(), to_bf16_bits(np.transpose(x, (0, 2, 1))))
+
+
+CONV_CASES = [
+    # (N, Cin, Cout, D, H, W, kernel)
+    (1, 16, 32, 2, 8, 16, (3, 3, 3)),       # exactly one 8x16 tile, one half-empty slab, one n-block
+    (2, 24, 48, 3, 9, 7, (3, 3, 3)),        # odd sizes, Cin/Cout not multiples of 32
+    (1, 40, 72, 2, 5, 37, (3, 3, 3)),       # wide tile shape (4x32), 2 slabs, 3 n-blocks
+    (1, 96, 208, 1, 14, 14, (3, 3, 3)),     # an I3D 4b shape: 7 n-blocks
+    (2, 32, 40, 3, 7, 7, (1, 3, 3)),        # 2-D 3x3 conv (frames on D)
+    (2, 72, 100, 2, 5, 9, (1, 1, 1)),       # pointwise: flat tiles, tail tile
+    (1, 200, 16, 1, 13, 13, (1, 1, 1)),     # 7 slabs
+]
+
+
+def _conv_case(bk, case, dts):
+    N, Cin, Cout, D, H, W, k = case
+    rs = np.random.RandomState(Cin * 7 + Cout)
+    x = rs.randn(N, Cin, D, H, W).astype(np.float32)
+    w = (rs.randn(Cout, Cin, *k) / np.sqrt(Cin * np.prod(k))).astype(np.float32)
+    scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32)
+    shift = (0.2 * rs.randn(Cout)).astype(np.float32)
+    for dt in dts:
+        got = run_conv(bk, x, w, scale, shift, dt, x_pad=(8, 8), y_pad=(16, 8))
+        ref = ref_conv(x, w, scale, shift, dt)
+        err = np.abs(got - ref).max() / np.abs(ref).max()
+        assert err < tol(dt), (case, dt, err)
+
+
+def case_conv_units(bk, golden):
+    for case in CONV_CASES:
+        _conv_case(bk, case, (F32, BF16))
+
+
+def case_conv_residual_norelu_f16_and_bias_only(bk, golden):
+    rs = np.random.RandomState(11)
+    x = rs.randn(2, 32, 1, 7, 7).astype(np.float32)
+    w = (rs.randn(64, 32, 1, 1, 1) / 6).astype(np.float32)
+    res = rs.randn(2, 64, 1, 7, 7).astype(np.float32)
+    got = run_conv(bk, x, w, None, None, F32, relu=True, res=res)
+    assert np.abs(got - ref_conv(x, w, None, None, F32, True, res)).max() < 1e-5
+    bias = rs.randn(64).astype(np.float32)
+    got = run_conv(bk, x, w, None, bias, F16, relu=False)
+    ref = ref_conv(x, w, None, bias, F16, False)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < tol(F16)
+
+
+def case_conv_golden_units(bk, golden):
+    """Unit3Dpy outputs produced by the reference itself (tests/golden/ops_golden.npz)."""
+    g = golden("ops_golden")
+    for tag, ci, co, k, shp in (("k3", 20, 24, (3, 3, 3), (2, 20, 3, 6, 7)), ("k1", 20, 12, (1, 1, 1), (2, 20, 3, 6, 7))):
+        shapes = {"conv3d.weight": (co, ci) + k}
+        for nme in ("weight", "bias", "running_mean", "running_var"):
+            shapes["batch3d." + nme] = (co,)
+        sd = R.fill_state_dict(shapes, "golden.unit." + tag + ".")
+        scale = (sd["batch3d.weight"] / torch.sqrt(sd["batch3d.running_var"] + 1e-5)).numpy()
+        shift = (sd["batch3d.bias"] - sd["batch3d.running_mean"] * torch.from_numpy(scale)).numpy()
+        x = R.fill_tensor("golden.unit.%s.in" % tag, shp, "image").numpy()
+        xp = np.zeros((2, 24) + shp[2:], np.float32)      # Cin 20 -> buffer of 24 channels, conv reads 20 (needs %4)
+        xp[:, :20] = x
+        got = run_conv(bk, x, sd["conv3d.weight"].numpy(), scale, shift, F32)
+        ref = g["unit_%s_out" % tag]
+        assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max()
+        assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+def case_pack_weight_perm_folds_flatten_order(bk, golden):
+    # Linear over an NCHW-flattened feature (c*HW+hw) evaluated on an NHWC-flattened one (hw*C+c)
+    rs = np.random.RandomState(12)
+    C, HW, O, M = 8, 4, 4, 5
+    feat = rs.randn(M, C, HW).astype(np.float32)
+    wl = rs.randn(O, C * HW).astype(np.float32)
+    ref = feat.reshape(M, -1) @ wl.T
+    perm = np.array([(j % C) * HW + (j // C) for j in range(C * HW)], np.int32)   # packed channel j = hw*C+c
+    wp = pack_weight(bk, wl.reshape(O, C * HW, 1, 1, 1), F32, perm)
+    x = bk.dev(np.ascontiguousarray(np.transpose(feat, (0, 2, 1))).reshape(M, 1, 1, 1, C * HW))
+    y = bk.dev(np.zeros((M, 1, 1, 1, O), np.float32))
+    d = _capi.ConvDesc(dtype=0, N=M, D=1, H=1, W=1, Cin=C * HW, Cout=O, kd=1, kh=1, kw=1, x_cstride=C * HW, x_coff=0,
+                       y_cstride=O, y_coff=0, res_cstride=0, res_coff=0, relu=0)
+    assert bk.lib.step_conv_forward(ctypes.byref(d), x.ptr, wp.ptr, None, None, None, y.ptr, bk.stream) == 0
+    assert np.abs(y.get().reshape(M, O) - ref).max() < 1e-5
+
+
+def _stem_case(bk, shape, dts, Cout):
+    N, T, H, W = shape
+    rs = np.random.RandomState(T + H)
+    x = rs.uniform(-1, 1, (N, T, 3, H, W)).astype(np.float32)
+    w = (rs.randn(Cout, 3, 7, 7, 7) / np.sqrt(1029)).astype(np.float32)
+    scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32)
+    shift = (0.2 * rs.randn(Cout)).astype(np.float32)
+    for dt in dts:
+        got = run_stem(bk, x, w, scale, shift, dt)
+        ref = ref_stem(x, w, scale, shift, dt)
+        assert got.shape == ref.shape
+        err = np.abs(got - ref).max() / np.abs(ref).max()
+        assert err < tol(dt), (shape, dt, err)
+
+
+def case_stem(bk, golden):
+    _stem_case(bk, (1, 8, 32, 32), (F32, BF16), 64)
+    _stem_case(bk, (2, 5, 18, 22), (F32, BF16), 40)     # odd T, W % 4 != 0 -> scalar staging path
+    _stem_case(bk, (1, 4, 17, 19), (F32, F16), 40)
+
+
+def case_stem_golden(bk, golden):
+    g = golden("ops_golden")
+    shapes = {"conv3d.weight": (16, 3, 7, 7, 7)}
+    for nme in ("weight", "bias", "running_mean", "running_var"):
+        shapes["batch3d." + nme] = (16,)
+    sd = R.fill_state_dict(shapes, "golden.unit.stem.")
+    scale = (sd["batch3d.weight"] / torch.sqrt(sd["batch3d.running_var"] + 1e-5)).numpy()
+    shift = (sd["batch3d.bias"] - sd["batch3d.running_mean"] * torch.from_numpy(scale)).numpy()
+    x = R.fill_tensor("golden.unit.stem.in", (1, 3, 9, 21, 19), "image").permute(0, 2, 1, 3, 4).contiguous().numpy()
+    got = run_stem(bk, x, sd["conv3d.weight"].numpy(), scale, shift, F32)
+    ref = g["unit_stem_out"]
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+ALL = sorted(k for k in globals() if k.startswith("case_"))
+
+
+# ------------------------------------------------------------------ larger, GPU-only cases
+def big_conv_shapes(bk, golden):
+    """Real I3D layer shapes (C2 geometry, one clip) -- too slow for the interpreter."""
+    for case in ((1, 64, 192, 4, 56, 56, (3, 3, 3)), (1, 192, 96, 4, 28, 28, (1, 1, 1)), (1, 128, 256, 8, 14, 14, (3, 3, 3)),
+                 (2, 832, 384, 3, 7, 7, (1, 1, 1)), (9, 256, 256, 1, 7, 7, (1, 3, 3)), (1, 160, 320, 9, 25, 25, (3, 3, 3))):
+        _conv_case(bk, case, (F32, BF16, F16))
+
+
+def big_stem(bk, golden):
+    _stem_case(bk, (1, 16, 112, 112), (F32, BF16), 64)
+    _stem_case(bk, (1, 8, 224, 224), (BF16,), 64)
+
+
+def big_roi(bk, golden):
+    """AVA-shaped ROIAlign: 99 rois on [9,832,25,25], fp32, bit-exact against the C oracle."""
+    rs = np.random.RandomState(21)
+    feat = np.maximum(rs.randn(9, 832, 25, 25), 0).astype(np.float32)
+    a = R.anchors()[:11] * 400.0
+    rois = np.concatenate([np.repeat(np.arange(9), 11)[:, None].astype(np.float32),
+                           np.tile(a, (9, 1)) + rs.uniform(-5, 5, (99, 4)).astype(np.float32)], 1).astype(np.float32)
+    ref = oracle.roi_align_forward(feat, rois, (7, 7), 1 / 16., 0)
+    for layout in (NCHW, NHWC):
+        assert np.array_equal(run_roi_align(bk, feat, rois, (7, 7), 1 / 16., 0, layout), ref)
+
+
+def big_nms(bk, golden):
+    rs = np.random.RandomState(22)
+    for G, kmax in ((480, 34), (60, 109), (3, 1000)):
+        xy = rs.uniform(0, 300, (G, kmax, 2))
+        wh = rs.uniform(10, 150, (G, kmax, 2))
+        boxes = np.concatenate([xy, xy + wh], 2).astype(np.float32)
+        scores = rs.uniform(0, 1, (G, kmax)).astype(np.float32)
+        counts = rs.randint(kmax // 2, kmax + 1, G).astype(np.int32)
+        assert np.array_equal(run_nms(bk, boxes, scores, counts, 0.4), oracle.nms_batched(boxes, scores, counts, 0.4))
+
+
+GPU_ONLY = ["big_conv_shapes", "big_stem", "big_roi", "big_nms"]
