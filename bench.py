@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the STEP hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "C2"): the I3D backbone (BaseNet, conv3d_1a ... mixed_4f) forward,
+bf16 storage / fp32 accumulate, on a batch of 8 synthetic clips [8, 32, 3, 224, 224] per GPU that is
+already resident in HBM.  A "step" is one forward over one batch.  With N GPUs every rank processes its
+own batch (clips shard by clip, no data-path collective, weak scaling); value = clips of all ranks /
+max-over-ranks time.
+
+One JSON line is printed by rank 0: the contract fields plus
+  "roofline"     for the dominant kernel of the step (largest share of GPU time), from HIP events
+                 recorded around every launch on the launch stream during an instrumented pass;
+  "cpu_baseline" the torch-CPU fp32 restatement of the same backbone (oracle/i3d_ref.py) timed on
+                 this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CLIPS_PER_GPU = 8
+T_IN, HW_IN = 32, 224
+PEAK = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}          # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+# algorithmic work of BaseNet at C2 per clip: 109.29 GFLOP, 304.9 MB activations + 15.0 MB weights/batch
+GFLOP_PER_CLIP = 109.29
+ACT_MB_PER_CLIP, W_MB = 304.9, 15.0
+
+
+def cfg():
+    from types import SimpleNamespace as NS
+    return NS(base_net="i3d", kinetics_pretrain=None, freeze_stats=True, freeze_affine=True, fp16=False)
+
+
+def build_net(device, seed=123):
+    import step_amd
+    torch.manual_seed(seed)                                      # config.py:38 man_seed
+    net = step_amd.BaseNet(cfg())
+    # random-init weights of the real architecture (no checkpoints offline): He-scaled convs, mild BN stats
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.Conv3d):
+                torch.nn.init.kaiming_uniform_(m.weight, a=0.0)
+            elif isinstance(m, torch.nn.BatchNorm3d):
+                m.weight.uniform_(0.9, 1.1)
+                m.bias.uniform_(-0.05, 0.05)
+                m.running_mean.uniform_(-0.1, 0.1)
+                m.running_var.uniform_(0.8, 1.2)
+    return net.to(device).eval()
+
+
+def cpu_baseline(net, seconds_budget=25.0):
+    """The oracle's torch-CPU fp32 BaseNet on single clips [1,32,3,224,224], all host cores."""
+    from oracle import i3d_ref as R
+    sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(123)
+    x = torch.rand(1, T_IN, 3, HW_IN, HW_IN, generator=g) * 2 - 1
+    with torch.no_grad():
+        R.basenet_forward(x, sd)                                 # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            R.basenet_forward(x, sd)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > seconds_budget or n >= 8:
+                break
+    return {"value": round(n / el, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d single-clip [1,32,3,224,224] fp32 forwards of oracle/i3d_ref.basenet_forward (torch CPU) after 1 warm-up, %.1f s" % (n, el)}
+
+
+def roofline(net, x, dtype_name):
+    """Instrumented pass: HIP events around every launch (on the launch stream), 3 forwards."""
+    from step_amd import ops
+    ops.PROFILE = []
+    with torch.no_grad():
+        for _ in range(3):
+            net(x)
+    torch.cuda.synchronize()
+    rec, ops.PROFILE = ops.PROFILE, None
+    agg = {}
+    for name, flops, nbytes, e0, e1 in rec:
+        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1)
+        a[2] += flops
+        a[3] += nbytes
+    total_ms = sum(a[1] for a in agg.values())
+    name, (cnt, ms, flops, nbytes) = max(agg.items(), key=lambda kv: kv[1][1])
+    avg_ms = ms / cnt
+    tf = (flops / cnt) / (avg_ms * 1e-3) / 1e12
+    hbm_time = (nbytes / cnt) / (PEAK_HBM_GBS * 1e9)
+    mfma_time = (flops / cnt) / (PEAK[dtype_name] * 1e12)
+    traffic, tsrc = None, None
+    tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            if tj.get("kernel") == name:
+                traffic, tsrc = tj.get("hbm_bytes_per_launch"), tj.get("source")
+        except Exception:
+            pass
+    out = {"kernel": name, "bound": "mfma" if mfma_time >= hbm_time else "hbm",
+           "achieved": round(tf, 2), "peak": PEAK[dtype_name], "unit": "TFLOP/s", "frac": round(tf / PEAK[dtype_name], 4),
+           "traffic": traffic, "launches_per_step": cnt // 3, "avg_launch_ms": round(avg_ms, 4),
+           "share_of_gpu_time": round(ms / total_ms, 3),
+           "algorithmic_gflop_per_launch": round(flops / cnt / 1e9, 3),
+           "algorithmic_mb_per_launch": round(nbytes / cnt / 1e6, 3)}
+    if tsrc:
+        out["traffic_source"] = tsrc
+    table = sorted(((n_, a[1] / 3, a[0] // 3, a[2] / max(a[1], 1e-9) / 1e9) for n_, a in agg.items()), key=lambda r: -r[1])
+    return out, table, total_ms / 3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
+    net = build_net(dev)
+    g = torch.Generator(device="cpu").manual_seed(123 + rank)
+    x = (torch.rand(CLIPS_PER_GPU, T_IN, 3, HW_IN, HW_IN, generator=g) * 2 - 1).to(dev).to(tdt)   # U(-1,1), resident in HBM
+
+    with torch.no_grad():
+        y = net(x)                                               # packs weights, warms the allocator
+        torch.cuda.synchronize()
+        assert tuple(y.shape) == (CLIPS_PER_GPU, 8, 832, 14, 14) and bool(torch.isfinite(y.float()).all())
+        graph = None
+        if not a.no_graph:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    net(x)
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()                       # a hipGraph of the whole forward
+            with torch.cuda.graph(graph):
+                y = net(x)
+
+        def step():
+            if graph is not None:
+                graph.replay()
+            else:
+                net(x)
+
+        for _ in range(a.warmup):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    out = None
+    if rank == 0:
+        clips = world * CLIPS_PER_GPU * a.steps
+        val = clips / el
+        out = {"metric": "clips_per_sec_T32_224", "value": round(val, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps,
+               "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+               "config": {"workload": "C2: I3D backbone (BaseNet conv3d_1a..mixed_4f) forward, %d x [3,32,224,224] clips per GPU, "
+                                      "inputs resident in HBM, random-init weights" % CLIPS_PER_GPU,
+                          "clips_per_gpu": CLIPS_PER_GPU, "T": T_IN, "HW": HW_IN, "parallelism": "clip-sharded replicas x%d (no data-path collective)" % world,
+                          "launch": "eager" if graph is None else "hipGraph replay"}}
+        per_gpu = val / world
+        out["backbone_roofline"] = {
+            "hbm_frac": round(per_gpu * (ACT_MB_PER_CLIP + W_MB / CLIPS_PER_GPU) * 1e6 / (PEAK_HBM_GBS * 1e9), 4),
+            "mfma_frac": round(per_gpu * GFLOP_PER_CLIP * 1e9 / (PEAK[a.dtype] * 1e12), 4),
+            "note": "whole-backbone algorithmic bytes (BASELINE.md: 304.9 MB/clip + 15 MB weights/batch) and FLOPs (109.29 GFLOP/clip) "
+                    "per second per GPU over the 8 TB/s HBM and dense MFMA peaks"}
+    # roofline of the dominant kernel (every rank could, rank 0 reports)
+    if rank == 0:
+        with torch.no_grad():
+            rl, table, gpu_ms = roofline(net, x, a.dtype)
+        out["roofline"] = rl
+        out["kernel_time_ms_per_step"] = round(gpu_ms, 4)
+        if a.verbose:
+            for n_, ms, cnt, gfs in table:
+                print("%9.4f ms %3d x  %8.1f TFLOP/s  %s" % (ms, cnt, gfs / 1e3, n_), file=sys.stderr)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(net)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -144,6 +144,10 @@ STEP_API int step_conv_pack_weight(const float* w, int Cout, int Cin, int kd, in
 STEP_API int step_conv_forward(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale,
                                const float* shift, const void* res, void* y, step_stream_t stream);
 
+/* Diagnostic: the name (as rocprofv3 prints it) of the kernel instantiation step_conv_forward launches
+ * for this descriptor -- lets bench.py attribute time and algorithmic work to profiler rows. */
+STEP_API int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen);
+
 /* The I3D stem: 7x7x7 stride-2 conv, Cin = 3, TF-SAME padding (2 front, 3 back) + BN + ReLU
  * (models/i3dpt.py:186-191) reading the clip in the reference's own input layout
  *   x [N, T, 3, H, W] (what BaseNet.forward receives, models/networks.py:69-77)

@@ -1,0 +1,8 @@
+"""step_amd -- MI355X (gfx950) implementation of the STEP hot path: I3D backbone, two-branch head,
+ROIAlign / ROIPool / NMS.  Drop-in for the reference's `models` package and
+`external.maskrcnn_benchmark.roi_layers` package."""
+from .backbone import BaseNet, build_base_i3d, weights_init  # noqa: F401
+from .heads import ContextNet, ROINet, TwoBranchNet  # noqa: F401
+
+__all__ = ["BaseNet", "ROINet", "TwoBranchNet", "ContextNet"]
+__version__ = "0.1.0"

@@ -29,6 +29,7 @@ SIGNATURES = {
     "step_conv_packed_elems": (sz, [i, i, i, i, i]),
     "step_conv_pack_weight": (i, [fp, i, i, i, i, i, i, ip, vp, vp]),
     "step_conv_forward": (i, [C.POINTER(ConvDesc), vp, vp, fp, fp, vp, vp, vp]),
+    "step_conv_kernel_name": (i, [C.POINTER(ConvDesc), C.c_char_p, i]),
     "step_stem_packed_elems": (sz, [i]),
     "step_stem_pack_weight": (i, [fp, i, i, vp, vp]),
     "step_stem_forward": (i, [i, vp, i, i, i, i, vp, fp, fp, i, vp, i, i, vp]),

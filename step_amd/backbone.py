@@ -1,0 +1,409 @@
+"""step_amd/backbone.py -- the Inception-I3D building blocks and BaseNet on the gfx950 kernels.
+
+Host-side mirror of the reference interface (same constructor arguments, forward signatures,
+parameter / buffer names and state_dict keys):
+    Unit3D, MaxPoolTF, Mixed           <->  models/i3dpt.py:43-163   (Unit3Dpy, MaxPool3dTFPadding, Mixed)
+    BaseNet, build_base_i3d            <->  models/networks.py:50-142
+
+The modules own ordinary nn.Parameters / buffers (inside nn.Conv3d / nn.BatchNorm3d containers so
+that checkpoints, `weights_init`, utils/solver.get_params and the reference's "classname contains
+BatchNorm" logic keep working), but forward() never calls torch's conv/bn/pool: it calls the HIP
+kernels through step_amd.ops on CHANNELS-LAST activations ([N,T,H,W,C]).  A block's four branches
+write straight into channel slices of one output buffer (no torch.cat), eval-mode BN is folded into
+a per-channel scale/shift applied in the conv epilogue, TF-SAME padding is a load predicate.
+
+Training note (round 1): forward is always the HIP path; when gradients are required the conv unit
+records a torch autograd node whose backward uses torch's convolution_backward on the same
+channels-last buffers (see _ConvUnitFn) -- hand-written dgrad/wgrad kernels are the next step.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+BN_EPS = 1e-5
+
+# (models/i3dpt.py:213-231) in_channels, [b0, b1a, b1b, b2a, b2b, b3]
+MIXED_CFG = {
+    "3b": (192, (64, 96, 128, 16, 32, 32)), "3c": (256, (128, 128, 192, 32, 96, 64)),
+    "4b": (480, (192, 96, 208, 16, 48, 64)), "4c": (512, (160, 112, 224, 24, 64, 64)),
+    "4d": (512, (128, 128, 256, 24, 64, 64)), "4e": (512, (112, 144, 288, 32, 64, 64)),
+    "4f": (528, (256, 160, 320, 32, 128, 128)), "5b": (832, (256, 160, 320, 32, 128, 128)),
+    "5c": (832, (384, 192, 384, 48, 128, 128)),
+}
+
+
+def _ver(*tensors):
+    return tuple((t.data_ptr(), t._version, t.device) for t in tensors if t is not None)
+
+
+class _ConvUnitFn(torch.autograd.Function):
+    """Autograd node around the fused HIP conv unit  y = act(conv(x, w) * scale + shift (+ res)).
+    forward = the HIP kernel (always).  backward (interim, see module docstring) = torch's
+    convolution_backward on the same channels-last buffers.  `w_eff` is the EFFECTIVE weight
+    [Cout, Cin_eff, kd, kh, kw] (after the unit's channel slice / permutation), produced by
+    differentiable view ops so autograd routes its gradient back to the parameter."""
+
+    @staticmethod
+    def forward(ctx, x, w_eff, scale, shift, res, unit, relu):
+        y = unit._launch(x.detach(), relu, None if res is None else res.detach(), None)
+        ctx.save_for_backward(x, w_eff, scale, shift, y, res)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w_eff, scale, shift, y, res = ctx.saved_tensors
+        k = tuple(w_eff.shape[2:])
+        g = gy.float()
+        if ctx.relu:
+            g = g * (y > 0).to(g.dtype)
+        C = g.shape[-1]
+        gres = g.to(res.dtype) if (res is not None and ctx.needs_input_grad[4]) else None
+        gshift = g.reshape(-1, C).sum(0) if (shift is not None and ctx.needs_input_grad[3]) else None
+        gscale = None
+        if scale is not None and ctx.needs_input_grad[2]:
+            pre = y.float() - (shift.view(1, 1, 1, 1, -1) if shift is not None else 0.0)
+            if res is not None:
+                pre = pre - res.float()
+            gscale = (g * pre / scale.view(1, 1, 1, 1, -1)).reshape(-1, C).sum(0)
+        gconv = g * scale.view(1, 1, 1, 1, -1) if scale is not None else g
+        xv = x.float().permute(0, 4, 1, 2, 3)          # channels-last buffers viewed as NCDHW for aten
+        gv = gconv.permute(0, 4, 1, 2, 3)
+        gx, gw, _ = torch.ops.aten.convolution_backward(gv, xv, w_eff.float(), None, [1, 1, 1], [kk // 2 for kk in k],
+                                                        [1, 1, 1], False, [0, 0, 0], 1,
+                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        if gx is not None:
+            gx = gx.permute(0, 2, 3, 4, 1).to(x.dtype)
+        if gw is not None:
+            gw = gw.to(w_eff.dtype)
+        return gx, gw, gscale, gshift, gres, None, None
+
+
+class ConvUnit:
+    """Helper (not an nn.Module): owns the packed-weight / folded-affine caches of ONE conv and
+    launches it.  `weight_fn()` returns the nn.Parameter in torch layout; `bn` an nn.BatchNorm3d or
+    None; `bias_fn()` an nn.Parameter or None; `perm` an optional input-channel permutation folded in
+    at pack time (effective channel j reads weight channel perm[j]); `cin_slice` restricts the conv
+    to input channels [lo, hi) of the weight (a conv over a channel concat becomes two accumulating
+    launches)."""
+
+    def __init__(self, weight_fn, k, bn=None, bias_fn=None, perm=None, cin_slice=None):
+        self.weight_fn, self.bias_fn, self.bn = weight_fn, bias_fn, bn
+        self.k = tuple(k)
+        self.perm, self.cin_slice = perm, cin_slice
+        self._packed = {}
+        self._affine = None
+
+    @property
+    def cout(self):
+        return self.weight_fn().shape[0]
+
+    def effective_weight(self):
+        """[Cout, Cin_eff, kd, kh, kw] via differentiable view / gather ops."""
+        w = self.weight_fn()
+        w = w.reshape(w.shape[0], w.shape[1], -1)
+        if self.cin_slice is not None:
+            w = w[:, self.cin_slice[0]:self.cin_slice[1]]
+        if self.perm is not None:
+            w = w.index_select(1, self.perm.to(device=w.device, dtype=torch.long))
+        return w.reshape(w.shape[0], w.shape[1], *self.k)
+
+    def packed(self, dtype):
+        w = self.weight_fn()
+        key = (dtype, w.device)
+        ver = _ver(w)
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                hit = (ver, ops.pack_conv_weight(self.effective_weight(), dtype))
+            self._packed[key] = hit
+        return hit[1]
+
+    def _bn_affine(self):
+        bn = self.bn
+        scale = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
+        return scale, bn.bias.float() - bn.running_mean.float() * scale
+
+    def affine(self, differentiable=False):
+        """fp32 (scale, shift) of the epilogue: folded eval-mode BN, or (None, bias), or (None, None)."""
+        if self.bn is not None:
+            bn = self.bn
+            if bn.training:
+                raise NotImplementedError("step_amd: batch-statistics BatchNorm is not on the hot path "
+                                          "(the reference always runs with freeze_stats=True); call .eval()/.train() "
+                                          "on the owning net so that BN modules are in eval mode")
+            if differentiable and (bn.weight.requires_grad or bn.bias.requires_grad):
+                return self._bn_affine()
+            ver = _ver(bn.weight, bn.bias, bn.running_mean, bn.running_var)
+            if self._affine is None or self._affine[0] != ver:
+                with torch.no_grad():
+                    scale, shift = self._bn_affine()
+                self._affine = (ver, scale.contiguous(), shift.contiguous())
+            return self._affine[1], self._affine[2]
+        if self.bias_fn is not None:
+            b = self.bias_fn()
+            return None, (b if b.dtype == torch.float32 else b.float())
+        return None, None
+
+    def _launch(self, x, relu, res, out):
+        scale, shift = self.affine()
+        if shift is not None:
+            shift = shift.detach().contiguous()
+        return ops.conv_forward(x, self.packed(x.dtype), self.cout, self.k, scale, shift, relu, res, out)
+
+    def __call__(self, x, relu=True, res=None, out=None):
+        w = self.weight_fn()
+        need_grad = torch.is_grad_enabled() and (
+            x.requires_grad or w.requires_grad or (res is not None and res.requires_grad)
+            or (self.bias_fn is not None and self.bias_fn().requires_grad)
+            or (self.bn is not None and (self.bn.weight.requires_grad or self.bn.bias.requires_grad)))
+        if not need_grad:
+            return self._launch(x, relu, res, out)
+        scale, shift = self.affine(differentiable=True)
+        y = _ConvUnitFn.apply(x, self.effective_weight(), scale, shift, res, self, relu)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+
+
+class Unit3D(nn.Module):
+    """conv3d (+ frozen BN) + ReLU.  Keys: conv3d.weight[, conv3d.bias], batch3d.{weight,bias,running_*}."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=(1, 1, 1), stride=(1, 1, 1), use_bias=False, use_bn=True,
+                 relu=True):
+        super().__init__()
+        self.kernel_size, self.stride, self.relu = tuple(kernel_size), tuple(stride), relu
+        self.conv3d = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, bias=use_bias)
+        if use_bn:
+            self.batch3d = nn.BatchNorm3d(out_channels, eps=BN_EPS)
+        self.is_stem = self.kernel_size == (7, 7, 7)
+        if self.is_stem:
+            assert self.stride == (2, 2, 2) and in_channels == 3
+            self._stem_packed = {}
+            self._unit = ConvUnit(lambda: self.conv3d.weight, (7, 7, 7), bn=getattr(self, "batch3d", None))
+        else:
+            assert self.stride == (1, 1, 1)
+            self._unit = ConvUnit(lambda: self.conv3d.weight, self.kernel_size, bn=getattr(self, "batch3d", None),
+                                  bias_fn=(lambda: self.conv3d.bias) if use_bias else None)
+
+    def forward(self, x, out=None):
+        if self.is_stem:
+            return self._forward_stem(x, out)
+        return self._unit(x, relu=self.relu, out=out)
+
+    def _forward_stem(self, x, out):
+        """x is the clip in the reference layout [N,T,3,H,W]."""
+        w = self.conv3d.weight
+        key = (x.dtype, w.device)
+        ver = _ver(w)
+        hit = self._stem_packed.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, ops.pack_stem_weight(w, x.dtype))
+            self._stem_packed[key] = hit
+        scale, shift = self._unit.affine()
+        if torch.is_grad_enabled() and w.requires_grad:
+            return _StemFn.apply(x, w, scale, shift, self, hit[1])
+        return ops.stem_forward(x, hit[1], w.shape[0], scale, shift, out)
+
+
+class _StemFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, scale, shift, unit, packed):
+        y = ops.stem_forward(x.detach(), packed, w.shape[0], scale, shift)
+        ctx.save_for_backward(x, w, scale, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, scale, y = ctx.saved_tensors
+        g = gy.float() * (y > 0).to(torch.float32) * scale.view(1, 1, 1, 1, -1)
+        xv = torch.nn.functional.pad(x.float().permute(0, 2, 1, 3, 4), (2, 3, 2, 3, 2, 3))
+        _, gw, _ = torch.ops.aten.convolution_backward(g.permute(0, 4, 1, 2, 3), xv, w.float(), None, [2, 2, 2], [0, 0, 0],
+                                                       [1, 1, 1], False, [0, 0, 0], 1, [False, True, False])
+        return None, gw.to(w.dtype), None, None, None, None
+
+
+class MaxPoolTF(nn.Module):
+    """TF-SAME max pool (zero-VALUED padding, ceil_mode).  models/i3dpt.py:114-126."""
+
+    def __init__(self, kernel_size, stride):
+        super().__init__()
+        self.kernel_size, self.stride = tuple(kernel_size), tuple(stride)
+
+    def forward(self, x, out=None):
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _MaxPoolFn.apply(x, self.kernel_size, self.stride)
+        return ops.maxpool_tf(x, self.kernel_size, self.stride, out)
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    """Interim backward: re-evaluates the same pool with torch on channels-last views."""
+
+    @staticmethod
+    def forward(ctx, x, k, s):
+        ctx.k, ctx.s = k, s
+        ctx.save_for_backward(x)
+        return ops.maxpool_tf(x.detach(), k, s)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        k, s = ctx.k, ctx.s
+        with torch.enable_grad():
+            xv = x.detach().float().permute(0, 4, 1, 2, 3).requires_grad_(True)
+            pads = []
+            for kk, ss in zip(reversed(k), reversed(s)):
+                a = max(kk - ss, 0)
+                pads += [a // 2, a - a // 2]
+            yv = torch.nn.functional.max_pool3d(torch.nn.functional.pad(xv, pads), k, s, ceil_mode=True)
+            (gx,) = torch.autograd.grad(yv, xv, gy.float().permute(0, 4, 1, 2, 3))
+        return gx.permute(0, 2, 3, 4, 1).to(x.dtype), None, None
+
+
+class Mixed(nn.Module):
+    """Inception block; the four branches write channel slices of one buffer (order b0,b1,b2,b3)."""
+
+    def __init__(self, in_channels, oc):
+        super().__init__()
+        self.oc = tuple(oc)
+        self.branch_0 = Unit3D(in_channels, oc[0])
+        self.branch_1 = nn.Sequential(Unit3D(in_channels, oc[1]), Unit3D(oc[1], oc[2], (3, 3, 3)))
+        self.branch_2 = nn.Sequential(Unit3D(in_channels, oc[3]), Unit3D(oc[3], oc[4], (3, 3, 3)))
+        self.branch_3 = nn.Sequential(MaxPoolTF((3, 3, 3), (1, 1, 1)), Unit3D(in_channels, oc[5]))
+        self.out_channels = oc[0] + oc[2] + oc[4] + oc[5]
+
+    def forward(self, x, out=None):
+        oc = self.oc
+        N, D, H, W, _ = x.shape
+        grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if grad:
+            # autograd path: branches return fresh tensors, concatenated by torch (bookkeeping only)
+            y = torch.cat([self.branch_0(x), self.branch_1[1](self.branch_1[0](x)), self.branch_2[1](self.branch_2[0](x)),
+                           self.branch_3[1](self.branch_3[0](x))], dim=-1)
+            if out is not None:
+                out.copy_(y)
+                return out
+            return y
+        if out is None:
+            out = torch.empty((N, D, H, W, self.out_channels), dtype=x.dtype, device=x.device)
+        c0, c1, c2 = oc[0], oc[0] + oc[2], oc[0] + oc[2] + oc[4]
+        self.branch_0(x, out=out[..., :c0])
+        # the two bottleneck 1x1x1 outputs share one scratch buffer; the 3x3x3 convs read its slices
+        t = torch.empty((N, D, H, W, oc[1] + oc[3]), dtype=x.dtype, device=x.device)
+        self.branch_1[0](x, out=t[..., :oc[1]])
+        self.branch_2[0](x, out=t[..., oc[1]:])
+        self.branch_1[1](t[..., :oc[1]], out=out[..., c0:c1])
+        self.branch_2[1](t[..., oc[1]:], out=out[..., c1:c2])
+        p = self.branch_3[0](x)
+        self.branch_3[1](p, out=out[..., c2:])
+        return out
+
+
+def build_base_i3d(kinetics_pretrain=None, freeze_affine=True):
+    """The 13 backbone stages in an nn.Sequential whose indices (0..12) are part of the parameter-name
+    contract (models/networks.py:107-142; utils/solver.py:21-37 string-matches `base_model.N`)."""
+    stages = [
+        Unit3D(3, 64, (7, 7, 7), (2, 2, 2)),            # 0  conv3d_1a_7x7
+        MaxPoolTF((1, 3, 3), (1, 2, 2)),                # 1  maxPool3d_2a_3x3
+        Unit3D(64, 64, (1, 1, 1)),                      # 2  conv3d_2b_1x1
+        Unit3D(64, 192, (3, 3, 3)),                     # 3  conv3d_2c_3x3
+        MaxPoolTF((1, 3, 3), (1, 2, 2)),                # 4  maxPool3d_3a_3x3
+        Mixed(*MIXED_CFG["3b"]), Mixed(*MIXED_CFG["3c"]),   # 5, 6
+        MaxPoolTF((3, 3, 3), (2, 2, 2)),                # 7  maxPool3d_4a_3x3
+        Mixed(*MIXED_CFG["4b"]), Mixed(*MIXED_CFG["4c"]), Mixed(*MIXED_CFG["4d"]), Mixed(*MIXED_CFG["4e"]),
+        Mixed(*MIXED_CFG["4f"]),                        # 8..12
+    ]
+    base_model = nn.Sequential(*stages)
+    if kinetics_pretrain is not None:
+        import os
+        if not os.path.isfile(kinetics_pretrain):
+            raise ValueError("Kinetics_pretrain doesn't exist: {}".format(kinetics_pretrain))
+        load_i3d_checkpoint_into_backbone(base_model, torch.load(kinetics_pretrain, map_location="cpu"))
+    if freeze_affine:
+        freeze_bn_affine(base_model)
+    return base_model
+
+
+I3D_STAGE_NAMES = ["conv3d_1a_7x7", "maxPool3d_2a_3x3", "conv3d_2b_1x1", "conv3d_2c_3x3", "maxPool3d_3a_3x3", "mixed_3b",
+                   "mixed_3c", "maxPool3d_4a_3x3", "mixed_4b", "mixed_4c", "mixed_4d", "mixed_4e", "mixed_4f"]
+
+
+def load_i3d_checkpoint_into_backbone(base_model, sd):
+    """A Kinetics I3D checkpoint is keyed by the I3D attribute names (models/i3dpt.py:186-231);
+    networks.py:113-132 loads it into the full I3D and then slices 13 stages out."""
+    mapped = {}
+    for idx, name in enumerate(I3D_STAGE_NAMES):
+        pre = name + "."
+        for k, v in sd.items():
+            if k.startswith(pre):
+                mapped["%d.%s" % (idx, k[len(pre):])] = v
+    missing = [k for k in base_model.state_dict() if k not in mapped]
+    if missing:
+        raise RuntimeError("I3D checkpoint is missing keys: %s ..." % missing[:4])
+    base_model.load_state_dict(mapped)
+
+
+def freeze_bn_affine(module):
+    for m in module.modules():
+        if isinstance(m, nn.modules.batchnorm._BatchNorm):
+            for p in m.parameters():
+                p.requires_grad = False
+
+
+def set_bn_eval(module, half=False):
+    for m in module.modules():
+        if isinstance(m, nn.modules.batchnorm._BatchNorm):
+            m.eval()
+            if half:
+                m.half()
+
+
+def weights_init(m):
+    """models/networks.py:101-105"""
+    if isinstance(m, (nn.Conv2d, nn.Linear, nn.Conv3d)):
+        nn.init.xavier_normal_(m.weight.data)
+        if m.bias is not None:
+            nn.init.constant_(m.bias.data, 0.0)
+
+
+def as_channels_last_5d(t):
+    """logical [N,T,C,H,W] (any strides) -> physical [N,T,H,W,C] contiguous tensor (zero-copy when the
+    tensor already is a permuted view of one, e.g. our own BaseNet / ROIAlign outputs)."""
+    v = t.permute(0, 1, 3, 4, 2)
+    if v.is_contiguous():
+        return v
+    N, T, C, H, W = t.shape
+    if t.is_contiguous():
+        return ops.to_channels_last(t.reshape(N * T, C, H, W)).view(N, T, H, W, C)
+    return v.contiguous()
+
+
+class BaseNet(nn.Module):
+    """Backbone: I3D up to mixed_4f.  forward(x [N,T,3,H,W]) -> conv_feat logical [N,T',832,H',W']
+    (a permuted VIEW of the channels-last buffer, like the reference returns a permuted view,
+    models/networks.py:69-83)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.base_name = cfg.base_net
+        self.kinetics_pretrain = cfg.kinetics_pretrain
+        self.freeze_stats = cfg.freeze_stats
+        self.freeze_affine = cfg.freeze_affine
+        self.fp16 = cfg.fp16
+        if self.base_name != "i3d":
+            raise NotImplementedError
+        self.base_model = build_base_i3d(self.kinetics_pretrain, self.freeze_affine)
+
+    def forward(self, x):
+        if x.dim() != 5 or x.shape[2] != 3:
+            raise RuntimeError("BaseNet expects [batch, T, 3, H, W]")
+        y = self.base_model(x.contiguous())
+        return y.permute(0, 1, 4, 2, 3)
+
+    def train(self, mode=True):
+        nn.Module.train(self, mode)
+        if mode and self.freeze_stats:
+            set_bn_eval(self.base_model, half=False)   # BN is folded in fp32 whatever the activation dtype
+        return self

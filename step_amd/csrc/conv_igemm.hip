@@ -24,6 +24,7 @@
 //   * LDS slab pixels are 64 B (16-bit) / 128 B (fp32) wide; 16-byte slots are XOR-swizzled by
 //     the pixel index so the ds_read_b128 of the 32 pixels of a fragment spread over the banks.
 #include "common.h"
+#include <stdio.h>
 
 namespace step {
 
@@ -442,32 +443,48 @@ static int pick_nb(int nblk32, long long mtiles) {
     return best;
 }
 
+// Which instantiation a descriptor maps to (also used by step_conv_kernel_name so that bench.py can
+// attribute time and work to the kernel name rocprofv3 reports).
+struct ConvPlan { bool ok, flat, wide; int NB, tiles_h, tiles_w; long long mtiles; };
+
+static ConvPlan conv_plan(const step_conv_desc* d) {
+    ConvPlan pl;
+    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0;
+    const int nblk32 = ceil_div(d->Cout, 32);
+    const bool k1 = d->kd == 1 && d->kh == 1 && d->kw == 1;
+    const bool k333 = d->kd == 3 && d->kh == 3 && d->kw == 3;
+    const bool k133 = d->kd == 1 && d->kh == 3 && d->kw == 3;
+    pl.flat = k1;
+    if (k1) {
+        pl.mtiles = ceil_div64((long long)d->N * d->D * d->H * d->W, 128);
+    } else if (k333 || k133) {
+        // tile shape: 8x16 or 4x32 output pixels, whichever wastes fewer pixels on this H x W
+        const long long w16 = (long long)ceil_div(d->H, 8) * ceil_div(d->W, 16);
+        const long long w32 = (long long)ceil_div(d->H, 4) * ceil_div(d->W, 32);
+        pl.wide = w32 < w16;
+        pl.tiles_h = pl.wide ? ceil_div(d->H, 4) : ceil_div(d->H, 8);
+        pl.tiles_w = pl.wide ? ceil_div(d->W, 32) : ceil_div(d->W, 16);
+        pl.mtiles = (long long)d->N * d->D * pl.tiles_h * pl.tiles_w;
+    } else {
+        pl.ok = false; pl.mtiles = 0;
+    }
+    pl.NB = pick_nb(nblk32, pl.mtiles);
+    return pl;
+}
+
 template <typename T>
 static int conv_forward_t(const step_conv_desc* d, ConvParams p, step_stream_t stream) {
     constexpr int VEC = elem<T>::VEC;
     if (d->Cin % VEC || d->x_cstride % VEC || d->x_coff % VEC) return STEP_E_ALIGN;
     if (((uintptr_t)p.x % 16) || ((uintptr_t)p.w % 16)) return STEP_E_ALIGN;
-    const bool k1 = d->kd == 1 && d->kh == 1 && d->kw == 1;
-    const bool k333 = d->kd == 3 && d->kh == 3 && d->kw == 3;
-    const bool k133 = d->kd == 1 && d->kh == 3 && d->kw == 3;
-    if (k1) {
-        const long long mtiles = ceil_div64(p.Mtot, 128);
-        const int NB = pick_nb(p.nblk32, mtiles);
-        dim3 grid((unsigned)mtiles, (unsigned)ceil_div(p.nblk32, NB));
-        return launch_nb<T, 4, 1, 1, 1, true>(p, NB, grid, stream);
-    }
-    if (!k333 && !k133) return STEP_E_UNSUPPORTED;
-    // tile shape: 8x16 or 4x32 output pixels, whichever wastes fewer pixels on this H x W
-    const long long w16 = (long long)ceil_div(d->H, 8) * ceil_div(d->W, 16);
-    const long long w32 = (long long)ceil_div(d->H, 4) * ceil_div(d->W, 32);
-    const bool wide = w32 < w16;
-    p.tiles_h = wide ? ceil_div(d->H, 4) : ceil_div(d->H, 8);
-    p.tiles_w = wide ? ceil_div(d->W, 32) : ceil_div(d->W, 16);
-    const long long mtiles = (long long)d->N * d->D * p.tiles_h * p.tiles_w;
-    const int NB = pick_nb(p.nblk32, mtiles);
-    dim3 grid((unsigned)mtiles, (unsigned)ceil_div(p.nblk32, NB));
-    if (k333) return wide ? launch_nb<T, 5, 3, 3, 3, false>(p, NB, grid, stream) : launch_nb<T, 4, 3, 3, 3, false>(p, NB, grid, stream);
-    return wide ? launch_nb<T, 5, 1, 3, 3, false>(p, NB, grid, stream) : launch_nb<T, 4, 1, 3, 3, false>(p, NB, grid, stream);
+    const ConvPlan pl = conv_plan(d);
+    if (!pl.ok) return STEP_E_UNSUPPORTED;
+    p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w;
+    dim3 grid((unsigned)pl.mtiles, (unsigned)ceil_div(p.nblk32, pl.NB));
+    if (pl.flat) return launch_nb<T, 4, 1, 1, 1, true>(p, pl.NB, grid, stream);
+    if (d->kd == 3)
+        return pl.wide ? launch_nb<T, 5, 3, 3, 3, false>(p, pl.NB, grid, stream) : launch_nb<T, 4, 3, 3, 3, false>(p, pl.NB, grid, stream);
+    return pl.wide ? launch_nb<T, 5, 1, 3, 3, false>(p, pl.NB, grid, stream) : launch_nb<T, 4, 1, 3, 3, false>(p, pl.NB, grid, stream);
 }
 
 template <typename T>
@@ -567,6 +584,16 @@ int step_stem_forward(int dtype, const void* x, int N, int T, int H, int W, cons
         case STEP_F16: return stem_forward_t<f16_t>(p, stream);
     }
     return STEP_E_DTYPE;
+}
+
+int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
+    if (!d || !buf || buflen <= 0) return STEP_E_NULL;
+    const ConvPlan pl = conv_plan(d);
+    if (!pl.ok) return STEP_E_UNSUPPORTED;
+    const char* t = d->dtype == STEP_F32 ? "float" : (d->dtype == STEP_BF16 ? "step::bf16_t" : "step::f16_t");
+    snprintf(buf, (size_t)buflen, "void step::conv_igemm_kernel<%s, %d, %d, %d, %d, %d, %s>(step::ConvParams)", t,
+             pl.flat ? 4 : (pl.wide ? 5 : 4), pl.NB, d->kd, d->kh, d->kw, pl.flat ? "true" : "false");
+    return STEP_OK;
 }
 
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }

@@ -1,0 +1,329 @@
+"""step_amd/heads.py -- ROINet, ContextNet and TwoBranchNet on the gfx950 kernels.
+
+Host-side mirror of the reference interface:
+    ROINet                      <->  models/networks.py:17-47
+    ContextNet, TwoBranchNet    <->  models/two_branch.py:113-374
+Same constructor arguments (a Namespace-like cfg), forward signatures / return tuples, parameter
+names and state_dict keys; `.set_device`, `.train()` overrides that keep BN in eval mode.
+
+What changes underneath: activations stay channels-last end to end, so the reference's
+  * two `permute().contiguous()` transposes of the pooled features (two_branch.py:239-240,258),
+  * the `torch.cat` of [global_feat, global_feat_conv] and of the context vector (:243,:256),
+disappear -- the NCHW flatten order of `global_cls` / `local_reg` / `neighbor_reg*` weights is
+folded into the packed weights once (channel permutation), a conv over a channel concat is issued
+as two accumulating launches over the two sources, and the three Linear(12544->4) regressors are
+one GEMM.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .backbone import (MIXED_CFG, ConvUnit, MaxPoolTF, Mixed, as_channels_last_5d, freeze_bn_affine, set_bn_eval,
+                       weights_init)
+from .roi_layers import ROIAlign, ROIPool
+from .tube_math import encode_coef
+
+
+class ROINet(nn.Module):
+    """ROI pool | align over tubes: frames are flattened into the batch axis and each tube box is a
+    2-D ROI on its own frame (models/networks.py:35-47)."""
+
+    def __init__(self, pool_mode, pool_size=7):
+        super().__init__()
+        self.pool_mode, self.pool_size = pool_mode, pool_size
+        if pool_mode == "pool":
+            self.pool_layer = ROIPool((pool_size, pool_size), 1.0 / 16.0)
+        elif pool_mode == "align":
+            self.pool_layer = ROIAlign((pool_size, pool_size), 1.0 / 16.0, 0)
+        else:
+            raise NotImplementedError
+
+    def forward(self, conv_feat, tubes):
+        """conv_feat logical [B,T,C,H,W]; tubes [num_tubes,T,5] (col 0 = frame index b*T+t).
+        Returns logical [num_tubes*T, C, 7, 7] (channels-last physical when conv_feat is)."""
+        B, T, C, H, W = conv_feat.shape
+        v = conv_feat.permute(0, 1, 3, 4, 2)
+        if v.is_contiguous():                      # our channels-last buffer: zero-copy 4-D view
+            feat4 = v.reshape(B * T, H, W, C).permute(0, 3, 1, 2)
+        else:
+            feat4 = conv_feat.reshape(-1, C, H, W)
+        return self.pool_layer(feat4, tubes.reshape(-1, 5).detach())
+
+
+def _build_head_i3d(with_pool):
+    mods = ([MaxPoolTF((1, 3, 3), (1, 2, 2))] if with_pool else []) + [Mixed(*MIXED_CFG["5b"]), Mixed(*MIXED_CFG["5c"])]
+    return nn.Sequential(*mods)
+
+
+def _load_head_pretrain(seq, kinetics_pretrain, first_index):
+    import os
+    if not os.path.isfile(kinetics_pretrain):
+        raise ValueError("Kinetics_pretrain doesn't exist: {}".format(kinetics_pretrain))
+    sd = torch.load(kinetics_pretrain, map_location="cpu")
+    mapped = {}
+    for j, name in enumerate(("mixed_5b", "mixed_5c")):
+        for k, v in sd.items():
+            if k.startswith(name + "."):
+                mapped["%d.%s" % (first_index + j, k[len(name) + 1:])] = v
+    seq.load_state_dict(mapped)
+
+
+class ContextNet(nn.Module):
+    """Context branch: pool + mixed_5b + mixed_5c over the whole frame, 13x13 average
+    (models/two_branch.py:113-161).  forward(conv_feat [B,T,832,25,25]) -> [B,1024,T,1,1]."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.T = cfg.T
+        self.freeze_stats, self.freeze_affine, self.fp16 = cfg.freeze_stats, cfg.freeze_affine, cfg.fp16
+        self.i3d_conv_context = _build_head_i3d(with_pool=True)      # keys i3d_conv_context.{1,2}.*
+        if cfg.kinetics_pretrain is not None:
+            _load_head_pretrain(self.i3d_conv_context, cfg.kinetics_pretrain, 1)
+        if self.freeze_affine:
+            freeze_bn_affine(self.i3d_conv_context)
+        if self.freeze_stats:
+            set_bn_eval(self.i3d_conv_context)
+
+    def forward(self, conv_feat):
+        x = as_channels_last_5d(conv_feat)
+        x = self.i3d_conv_context(x)
+        if x.shape[2] < 13 or x.shape[3] < 13:
+            raise RuntimeError("ContextNet needs >= 13x13 maps after its pool (400x400 clips), got %dx%d" % (x.shape[2], x.shape[3]))
+        y = ops.avgpool_hw(x, 13, 13) if not (torch.is_grad_enabled() and x.requires_grad) else \
+            F.avg_pool3d(x.permute(0, 4, 1, 2, 3), (1, 13, 13), (1, 1, 1)).permute(0, 2, 3, 4, 1)
+        return y.permute(0, 4, 1, 2, 3)
+
+    def set_device(self, device):
+        self.device = device
+
+    def train(self, mode=True):
+        nn.Module.train(self, mode)
+        if mode and self.freeze_stats:
+            set_bn_eval(self.i3d_conv_context)
+        return self
+
+
+class _Bottleneck(nn.Module):
+    """2-D bottleneck, no BN, no bias (models/two_branch.py:60-84); parameter holders only."""
+
+    def __init__(self, inplanes, planes):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, padding=1, bias=False)
+        self.conv3 = nn.Conv2d(planes, inplanes, kernel_size=1, bias=False)
+        self.u1 = ConvUnit(lambda: self.conv1.weight, (1, 1, 1))
+        self.u2 = ConvUnit(lambda: self.conv2.weight, (1, 3, 3))
+        self.u3 = ConvUnit(lambda: self.conv3.weight, (1, 1, 1))
+
+    def forward(self, x):
+        o = self.u2(self.u1(x, relu=True), relu=True)
+        return self.u3(o, relu=True, res=x)
+
+
+class _BottleneckResample(nn.Module):
+    """models/two_branch.py:86-111.  Its input is the channel concat [a | b]; conv1 / conv2 run as two
+    accumulating launches over the two sources instead of materialising the concat."""
+
+    def __init__(self, in_a, in_b, outplanes, planes):
+        super().__init__()
+        inplanes = in_a + in_b
+        self.conv1 = nn.Conv2d(inplanes, outplanes, kernel_size=1, bias=False)
+        self.conv2 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.conv3 = nn.Conv2d(planes, planes, kernel_size=3, padding=1, bias=False)
+        self.conv4 = nn.Conv2d(planes, outplanes, kernel_size=1, bias=False)
+        self.u1a = ConvUnit(lambda: self.conv1.weight, (1, 1, 1), cin_slice=(0, in_a))
+        self.u1b = ConvUnit(lambda: self.conv1.weight, (1, 1, 1), cin_slice=(in_a, inplanes))
+        self.u2a = ConvUnit(lambda: self.conv2.weight, (1, 1, 1), cin_slice=(0, in_a))
+        self.u2b = ConvUnit(lambda: self.conv2.weight, (1, 1, 1), cin_slice=(in_a, inplanes))
+        self.u3 = ConvUnit(lambda: self.conv3.weight, (1, 3, 3))
+        self.u4 = ConvUnit(lambda: self.conv4.weight, (1, 1, 1))
+
+    def forward(self, a, b):
+        res = self.u1b(b, relu=False, res=self.u1a(a, relu=False))
+        o = self.u2b(b, relu=True, res=self.u2a(a, relu=False))
+        o = self.u3(o, relu=True)
+        return self.u4(o, relu=True, res=res)
+
+
+class _LocalConv(nn.Sequential):
+    """keys local_conv.{0,1,2}.*"""
+
+    def forward(self, a, b):
+        x = self[0](a, b)
+        x = self[1](x)
+        return self[2](x)
+
+
+def _nhwc_flatten_perm(channels, hw):
+    """effective (channels-last flattened) index j = p*channels + c  ->  reference index c*hw + p"""
+    j = torch.arange(channels * hw)
+    return (j % channels) * hw + (j // channels)
+
+
+class TwoBranchNet(nn.Module):
+    """Global (classification) + local (box regression) head, models/two_branch.py:164-374."""
+
+    def __init__(self, cfg, cls_only=False):
+        super().__init__()
+        self.num_classes, self.T, self.base_net = cfg.num_classes, cfg.T, cfg.base_net
+        self.freeze_stats, self.freeze_affine = cfg.freeze_stats, cfg.freeze_affine
+        self.fc_dim, self.dropout_prob, self.pool_size = cfg.fc_dim, cfg.dropout, cfg.pool_size
+        self.no_context, self.fp16, self.cls_only = cfg.no_context, cfg.fp16, cls_only
+        if self.base_net != "i3d":
+            raise NotImplementedError
+        P2 = self.pool_size ** 2
+        flat = self.fc_dim * P2
+
+        self.i3d_conv = _build_head_i3d(with_pool=False)             # keys i3d_conv.{0,1}.*
+        if cfg.kinetics_pretrain is not None:
+            _load_head_pretrain(self.i3d_conv, cfg.kinetics_pretrain, 0)
+        if self.freeze_affine:
+            freeze_bn_affine(self.i3d_conv)
+        self.downsample = nn.Conv3d(1024, self.fc_dim, kernel_size=1, stride=1, bias=True)
+        self.dropout = nn.Dropout(self.dropout_prob)
+        self.global_cls = nn.Conv3d(flat + (0 if self.no_context else 1024), self.num_classes, (1, 1, 1), bias=True)
+        self._u_down = ConvUnit(lambda: self.downsample.weight, (1, 1, 1), bias_fn=lambda: self.downsample.bias)
+        perm = _nhwc_flatten_perm(self.fc_dim, P2)
+        self._u_cls_feat = ConvUnit(lambda: self.global_cls.weight, (1, 1, 1), bias_fn=lambda: self.global_cls.bias,
+                                    cin_slice=(0, flat), perm=perm)
+        if not self.no_context:
+            self._u_cls_ctx = ConvUnit(lambda: self.global_cls.weight, (1, 1, 1), cin_slice=(flat, flat + 1024))
+
+        if not self.cls_only:
+            self.local_conv = _LocalConv(_BottleneckResample(832, self.fc_dim, 1024, 256), _Bottleneck(1024, 256),
+                                         _Bottleneck(1024, 256))
+            self.downsample2 = nn.Conv2d(1024, self.fc_dim, kernel_size=1, stride=1, bias=True)
+            self.local_reg = nn.Linear(flat, 4)
+            self.neighbor_reg1 = nn.Linear(flat, 4)     # tube t-1
+            self.neighbor_reg2 = nn.Linear(flat, 4)     # tube t+1
+            self._u_down2 = ConvUnit(lambda: self.downsample2.weight, (1, 1, 1), bias_fn=lambda: self.downsample2.bias)
+            # the three regressors share their input: one GEMM with 12 output columns
+            self._u_reg = ConvUnit(lambda: torch.cat([self.local_reg.weight, self.neighbor_reg1.weight, self.neighbor_reg2.weight], 0),
+                                   (1, 1, 1), bias_fn=lambda: torch.cat([self.local_reg.bias, self.neighbor_reg1.bias, self.neighbor_reg2.bias], 0),
+                                   perm=perm)
+            self._reg_cache = None
+        self._init_net()
+        if self.freeze_stats:
+            set_bn_eval(self.i3d_conv)
+        self.device = None
+
+    def _init_net(self):
+        self.global_cls.apply(weights_init)
+        self.downsample.apply(weights_init)
+        if not self.cls_only:
+            self.local_conv.apply(weights_init)
+            self.local_reg.apply(weights_init)
+            self.downsample2.apply(weights_init)
+            self.neighbor_reg1.apply(weights_init)
+            self.neighbor_reg2.apply(weights_init)
+
+    def set_device(self, device):
+        self.device = device
+
+    def train(self, mode=True):
+        nn.Module.train(self, mode)
+        if mode and self.freeze_stats:
+            set_bn_eval(self.i3d_conv)
+        return self
+
+    # the fused regressor weight is a torch.cat of three parameters: cache the cat (and hence the pack)
+    def _reg_unit(self):
+        ps = (self.local_reg.weight, self.neighbor_reg1.weight, self.neighbor_reg2.weight, self.local_reg.bias,
+              self.neighbor_reg1.bias, self.neighbor_reg2.bias)
+        ver = tuple((p.data_ptr(), p._version, p.device) for p in ps)
+        grad = torch.is_grad_enabled() and any(p.requires_grad for p in ps)
+        if grad:
+            return self._u_reg                    # differentiable cat each call
+        if self._reg_cache is None or self._reg_cache[0] != ver:
+            with torch.no_grad():
+                w = torch.cat(ps[:3], 0)
+                b = torch.cat(ps[3:], 0)
+            unit = ConvUnit(lambda: w, (1, 1, 1), bias_fn=lambda: b, perm=self._u_reg.perm)
+            self._reg_cache = (ver, unit)
+        return self._reg_cache[1]
+
+    def forward(self, global_feat, context_feat=None, tubes=None, targets=None):
+        """global_feat: ROI-pooled features, logical [num_tubes, Tl, 832, 7, 7]
+        context_feat: logical [num_tubes, 1024, Tl, 1, 1] or None
+        tubes [num_tubes, Tl, 5], targets [num_tubes, 3, 6+num_classes] (training only)
+        Returns (global_prob [N,classes], local_loc [N,Tl,4], first_loc [N,T,4], last_loc [N,T,4],
+                 loss_global_cls, loss_local_loc, loss_neighbor_loc)   -- two_branch.py:205-342"""
+        dev = self.device if self.device is not None else global_feat.device
+        global_feat = global_feat.to(dev)
+        if context_feat is not None:
+            context_feat = context_feat.to(dev)
+        N, Tl, C, W, H = global_feat.shape
+        chunks = int(Tl / self.T)
+        chunk_idx = [j * self.T + int(self.T / 2) for j in range(chunks)]
+        half_T = int(self.T / 2)
+        P2 = self.pool_size ** 2
+
+        # ---- global branch
+        g = as_channels_last_5d(global_feat)                       # [N,Tl,7,7,832]
+        gc = self._u_down(self.i3d_conv(g), relu=False)            # [N,Tl,7,7,fc_dim]
+        flat = gc.reshape(N * Tl, 1, 1, 1, self.fc_dim * P2)       # (hw, c) order; weights are permuted to match
+        if self.training and self.dropout_prob > 0:
+            flat = self.dropout(flat)
+        if context_feat is not None:
+            ctx = context_feat.permute(0, 2, 3, 4, 1).reshape(N * Tl, 1, 1, 1, -1).to(gc.dtype).contiguous()
+            if self.training and self.dropout_prob > 0:
+                ctx = self.dropout(ctx)
+            logits = self._u_cls_ctx(ctx, relu=False, res=self._u_cls_feat(flat, relu=False))
+        else:
+            logits = self._u_cls_feat(flat, relu=False)
+        global_class = logits.reshape(N, Tl, self.num_classes).float().mean(1)
+
+        # ---- local branch
+        zero = torch.tensor([0.0], device=global_class.device, dtype=global_class.dtype)
+        local_loc, first_loc, last_loc = zero, zero.clone(), zero.clone()
+        if not self.cls_only:
+            a = g.reshape(N * Tl, 1, W, H, C)                      # frames as batch, D = 1
+            b = gc.reshape(N * Tl, 1, W, H, self.fc_dim)
+            lf = self.local_conv(a, b)                             # [N*Tl,1,7,7,1024]
+            lf = self._u_down2(lf, relu=False)                     # [N*Tl,1,7,7,fc_dim]
+            if self.training and self.dropout_prob > 0:
+                lf = self.dropout(lf)
+            reg = self._reg_unit()(lf.reshape(N * Tl, 1, 1, 1, self.fc_dim * P2), relu=False)
+            reg = reg.reshape(N, Tl, 12).float()
+            local_loc = reg[..., 0:4].contiguous()
+            lo, hi = chunk_idx[0] - half_T, chunk_idx[0] + half_T + 1
+            lo2, hi2 = chunk_idx[-1] - half_T, chunk_idx[-1] + half_T + 1
+            first_loc = local_loc[:, lo:hi] + reg[:, lo:hi, 4:8]          # two_branch.py:265-269
+            last_loc = local_loc[:, lo2:hi2] + reg[:, lo2:hi2, 8:12]     # :266-270
+            center_pred = local_loc[:, chunk_idx[int(chunks / 2)]].reshape(N, -1)
+            first_pred = first_loc[:, half_T].reshape(N, -1)
+            last_pred = last_loc[:, half_T].reshape(N, -1)
+
+        # ---- losses (two_branch.py:276-333)
+        loss_global_cls = torch.tensor(0.0, device=global_class.device)
+        loss_local_loc = torch.tensor(0.0, device=global_class.device)
+        loss_neighbor_loc = torch.tensor(0.0, device=global_class.device)
+        if targets is not None:
+            tubes = tubes.to(dev)
+            targets = targets.to(dev)
+            center_targets, first_targets, last_targets = targets[:, 1], targets[:, 0], targets[:, -1]
+            center_tubes = tubes[:, chunk_idx[int(chunks / 2)]]
+            first_tubes, last_tubes = tubes[:, chunk_idx[0]], tubes[:, chunk_idx[-1]]
+            with torch.no_grad():
+                mask = center_targets[:, 4].reshape(-1, 1)
+            if mask.sum():
+                loss_global_cls = F.binary_cross_entropy_with_logits(global_class, center_targets[:, 6:] * mask, reduction="none")
+            if not self.cls_only:
+                tgt = encode_coef(center_targets[:, :4].clone(), center_tubes.reshape(-1, 5)[:, 1:])
+                with torch.no_grad():
+                    mask = center_targets[:, 5].reshape(-1, 1).repeat(1, 4)
+                if mask.sum():
+                    l = F.smooth_l1_loss(center_pred, tgt, reduction="none")
+                    loss_local_loc = torch.sum(l * mask) / torch.sum(mask)
+                ntgt = encode_coef(torch.cat([first_targets[:, :4], last_targets[:, :4]], 0),
+                                   torch.cat([first_tubes.reshape(-1, 5)[:, 1:], last_tubes.reshape(-1, 5)[:, 1:]], 0))
+                with torch.no_grad():
+                    nmask = torch.cat([first_targets[:, 5].reshape(-1, 1).repeat(1, 4),
+                                       last_targets[:, 5].reshape(-1, 1).repeat(1, 4)], 0)
+                if nmask.sum():
+                    l = F.smooth_l1_loss(torch.cat([first_pred, last_pred], 0), ntgt, reduction="none")
+                    loss_neighbor_loc = torch.sum(l * nmask) / torch.sum(nmask)
+
+        return (torch.sigmoid(global_class), local_loc, first_loc, last_loc, loss_global_cls.reshape(-1),
+                loss_local_loc.reshape(-1), loss_neighbor_loc.reshape(-1))

@@ -1,0 +1,322 @@
+"""step_amd/ops.py -- torch-tensor front-end to the C ABI (include/step_amd.h).
+
+PyTorch is used here only for device memory, streams and autograd bookkeeping; every operator
+below is one call into libstep_amd.so.  Activations are CHANNELS-LAST: a 5-D activation is a
+contiguous tensor [N, D, H, W, C] (possibly a channel slice [.., c0:c1] of a wider buffer).
+"""
+import ctypes
+
+import torch
+
+from . import _capi, _lib
+
+DT = {torch.float32: _capi.F32, torch.bfloat16: _capi.BF16, torch.float16: _capi.F16}
+
+# Optional per-launch instrumentation (bench.py's roofline leg): when PROFILE is a list, every kernel
+# launch below is bracketed by two HIP events on the launch stream and a record
+# (kernel_name, algorithmic_flops, algorithmic_bytes, start_event, end_event) is appended.
+PROFILE = None
+
+
+class _Prof:
+    __slots__ = ("name", "flops", "bytes", "e0")
+
+    def __init__(self, name, flops, nbytes):
+        self.name, self.flops, self.bytes = name, flops, nbytes
+
+    def __enter__(self):
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE.append((self.name, self.flops, self.bytes, self.e0, e1))
+        return False
+
+
+class _NoProf:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOPROF = _NoProf()
+_ES = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2}
+_TNAME = {torch.float32: "float", torch.bfloat16: "step::bf16_t", torch.float16: "step::f16_t"}
+
+
+def _dt(t):
+    try:
+        return DT[t.dtype]
+    except KeyError:
+        raise RuntimeError("step_amd: unsupported dtype %s (float32 / bfloat16 / float16)" % t.dtype)
+
+
+def _chan_slice(t):
+    """(base_tensor_ptr_holder, cstride, coff) of a channels-last tensor that may be a slice of the
+    last dim of a wider contiguous buffer."""
+    if t.stride(-1) != 1:
+        raise RuntimeError("step_amd: activation is not channels-last")
+    cs = t.stride(-2) if t.dim() >= 2 else t.size(-1)
+    # all leading dims must be dense over a [.., cs] buffer
+    exp = cs
+    for i in range(t.dim() - 2, -1, -1):
+        if t.size(i) != 1 and t.stride(i) != exp:
+            raise RuntimeError("step_amd: activation must be a channel slice of a dense channels-last buffer")
+        exp *= t.size(i)
+    return cs
+
+
+class ActView:
+    """A channels-last activation: tensor [N,D,H,W,C] whose last dim may be a slice of a wider buffer."""
+    __slots__ = ("t", "cs")
+
+    def __init__(self, t):
+        self.t = t
+        self.cs = _chan_slice(t)
+
+
+def conv_packed_elems(Cout, Cin, k):
+    return _lib.lib().step_conv_packed_elems(Cout, Cin, k[0], k[1], k[2])
+
+
+def pack_conv_weight(w, dtype, perm=None):
+    """w: fp32 [Cout, Cin, kd, kh, kw] (or 2-D/4-D, reshaped by the caller) on the device."""
+    L = _lib.lib()
+    w = w.detach().contiguous().float()
+    Cout, Cin, kd, kh, kw = w.shape
+    out = torch.empty(L.step_conv_packed_elems(Cout, Cin, kd, kh, kw), dtype=dtype, device=w.device)
+    _capi.check(L.step_conv_pack_weight(_lib.dptr(w), Cout, Cin, kd, kh, kw, DT[dtype], _lib.dptr(perm), _lib.dptr(out),
+                                        _lib.stream_ptr(w.device)), "step_conv_pack_weight")
+    return out
+
+
+def pack_stem_weight(w, dtype):
+    L = _lib.lib()
+    w = w.detach().contiguous().float()
+    out = torch.empty(L.step_stem_packed_elems(w.shape[0]), dtype=dtype, device=w.device)
+    _capi.check(L.step_stem_pack_weight(_lib.dptr(w), w.shape[0], DT[dtype], _lib.dptr(out), _lib.stream_ptr(w.device)),
+                "step_stem_pack_weight")
+    return out
+
+
+def conv_forward(x, w_packed, Cout, k, scale=None, shift=None, relu=True, res=None, out=None):
+    """x: channels-last [N,D,H,W,Cin] (may be a channel slice); out: optional channel slice to write
+    into (same N,D,H,W, Cout channels); returns out."""
+    L = _lib.lib()
+    N, D, H, W, Cin = x.shape
+    xcs = _chan_slice(x)
+    if out is None:
+        out = torch.empty((N, D, H, W, Cout), dtype=x.dtype, device=x.device)
+    ycs = _chan_slice(out)
+    d = _capi.ConvDesc(dtype=_dt(x), N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2],
+                       x_cstride=xcs, x_coff=0, y_cstride=ycs, y_coff=0,
+                       res_cstride=(_chan_slice(res) if res is not None else 0), res_coff=0, relu=int(bool(relu)))
+    prof = _NOPROF
+    if PROFILE is not None:
+        buf = ctypes.create_string_buffer(256)
+        L.step_conv_kernel_name(ctypes.byref(d), buf, 256)
+        pix = N * D * H * W
+        prof = _Prof(buf.value.decode(), 2.0 * pix * Cout * Cin * k[0] * k[1] * k[2],
+                     (pix * (Cin + Cout) + Cout * Cin * k[0] * k[1] * k[2]) * _ES[x.dtype])
+    with prof:
+        _capi.check(L.step_conv_forward(ctypes.byref(d), _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift),
+                                        _lib.dptr(res), _lib.dptr(out), _lib.stream_ptr(x.device)), "step_conv_forward")
+    return out
+
+
+def stem_forward(x, w_packed, Cout, scale, shift, out=None):
+    """x: [N,T,3,H,W] contiguous (the reference's input layout) -> channels-last [N,To,Ho,Wo,Cout]"""
+    L = _lib.lib()
+    N, T, C, H, W = x.shape
+    if C != 3 or not x.is_contiguous():
+        raise RuntimeError("step_amd: stem expects a contiguous [N,T,3,H,W] clip")
+    To, Ho, Wo = (T - 2) // 2 + 1, (H - 2) // 2 + 1, (W - 2) // 2 + 1
+    if out is None:
+        out = torch.empty((N, To, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+    prof = _NOPROF
+    if PROFILE is not None:
+        pix = N * To * Ho * Wo
+        prof = _Prof("void step::stem_igemm_kernel<%s, 2>(step::StemParams)" % _TNAME[x.dtype], 2.0 * pix * Cout * 1029,
+                     (x.numel() + pix * Cout + Cout * 1029) * _ES[x.dtype])
+    with prof:
+        _capi.check(L.step_stem_forward(_dt(x), _lib.dptr(x), N, T, H, W, _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift),
+                                        Cout, _lib.dptr(out), _chan_slice(out), 0, _lib.stream_ptr(x.device)), "step_stem_forward")
+    return out
+
+
+def pool_out_size(L_, k, s):
+    return _lib.lib().step_pool_out_size(L_, k, s)
+
+
+def maxpool_tf(x, k, s, out=None):
+    L = _lib.lib()
+    N, D, H, W, C = x.shape
+    if out is None:
+        out = torch.empty((N, L.step_pool_out_size(D, k[0], s[0]), L.step_pool_out_size(H, k[1], s[1]),
+                           L.step_pool_out_size(W, k[2], s[2]), C), dtype=x.dtype, device=x.device)
+    prof = _NOPROF
+    if PROFILE is not None:
+        prof = _Prof("void step::maxpool3d_tf_kernel<%s>(%s const*, %s*, step::PoolParams, long long)" % ((_TNAME[x.dtype],) * 3),
+                     0.0, (x.numel() + out.numel()) * _ES[x.dtype])
+    with prof:
+        _capi.check(L.step_maxpool3d_tf(_dt(x), _lib.dptr(x), N, D, H, W, C, _chan_slice(x), 0, k[0], k[1], k[2], s[0], s[1], s[2],
+                                        _lib.dptr(out), _chan_slice(out), 0, _lib.stream_ptr(x.device)), "step_maxpool3d_tf")
+    return out
+
+
+def avgpool_hw(x, kh, kw):
+    L = _lib.lib()
+    N, D, H, W, C = x.shape
+    if not x.is_contiguous():
+        x = x.contiguous()
+    out = torch.empty((N, D, H - kh + 1, W - kw + 1, C), dtype=x.dtype, device=x.device)
+    _capi.check(L.step_avgpool_hw(_dt(x), _lib.dptr(x), N, D, H, W, C, kh, kw, _lib.dptr(out), _lib.stream_ptr(x.device)),
+                "step_avgpool_hw")
+    return out
+
+
+def to_channels_last(x, dtype=None):
+    """logical [N, C, *spatial] torch-contiguous -> [N, *spatial, C] contiguous (optionally cast)."""
+    L = _lib.lib()
+    x = x.contiguous()
+    N, C = x.shape[0], x.shape[1]
+    S = 1
+    for v in x.shape[2:]:
+        S *= v
+    dtype = dtype or x.dtype
+    out = torch.empty((N,) + tuple(x.shape[2:]) + (C,), dtype=dtype, device=x.device)
+    _capi.check(L.step_transpose_cs(_lib.dptr(x), DT[x.dtype], _lib.dptr(out), DT[dtype], N, C, S, 1, _lib.stream_ptr(x.device)),
+                "step_transpose_cs")
+    return out
+
+
+def from_channels_last(x, dtype=None):
+    """[N, *spatial, C] contiguous -> torch-contiguous [N, C, *spatial]."""
+    L = _lib.lib()
+    x = x.contiguous()
+    N, C = x.shape[0], x.shape[-1]
+    S = 1
+    for v in x.shape[1:-1]:
+        S *= v
+    dtype = dtype or x.dtype
+    out = torch.empty((N, C) + tuple(x.shape[1:-1]), dtype=dtype, device=x.device)
+    _capi.check(L.step_transpose_cs(_lib.dptr(x), DT[x.dtype], _lib.dptr(out), DT[dtype], N, C, S, 0, _lib.stream_ptr(x.device)),
+                "step_transpose_cs")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# ROI operators on raw tensors.  `layout`: NCHW for torch-contiguous maps, NHWC for channels-last.
+def _roi_layout(inp):
+    """inp: logical [B,C,H,W].  Returns (layout, dense tensor to hand to the kernel)."""
+    if inp.dim() != 4:
+        raise RuntimeError("step_amd: ROI ops expect a 4-D feature map [B,C,H,W]")
+    if inp.is_contiguous():
+        return _capi.NCHW, inp
+    if inp.is_contiguous(memory_format=torch.channels_last) or inp.permute(0, 2, 3, 1).is_contiguous():
+        return _capi.NHWC, inp
+    return _capi.NCHW, inp.contiguous()
+
+
+def _rois_f32(rois, device):
+    r = rois.detach()
+    if r.dtype != torch.float32:
+        r = r.float()
+    if r.device != device:
+        r = r.to(device)
+    return r.contiguous()
+
+
+def roi_align_forward(inp, rois, ph, pw, scale, sampling_ratio):
+    L = _lib.lib()
+    layout, inp = _roi_layout(inp)
+    B, C, H, W = inp.shape
+    rois = _rois_f32(rois, inp.device)
+    K = rois.shape[0]
+    if layout == _capi.NHWC:
+        out = torch.empty((K, ph, pw, C), dtype=inp.dtype, device=inp.device).permute(0, 3, 1, 2)
+    else:
+        out = torch.empty((K, C, ph, pw), dtype=inp.dtype, device=inp.device)
+    _capi.check(L.step_roi_align_forward(_lib.dptr(inp), _dt(inp), layout, _lib.dptr(rois) if K else None, K, B, C, H, W,
+                                         ph, pw, float(scale), int(sampling_ratio), _lib.dptr(out) if K else None,
+                                         _lib.stream_ptr(inp.device)), "step_roi_align_forward")
+    return out
+
+
+def roi_align_backward(grad, rois, ph, pw, scale, sampling_ratio, B, C, H, W):
+    L = _lib.lib()
+    g = grad.float()
+    if g.is_contiguous():
+        layout = _capi.NCHW
+        gin = torch.empty((B, C, H, W), dtype=torch.float32, device=g.device)
+    elif g.permute(0, 2, 3, 1).is_contiguous():
+        layout = _capi.NHWC
+        gin = torch.empty((B, H, W, C), dtype=torch.float32, device=g.device).permute(0, 3, 1, 2)
+    else:
+        layout, g = _capi.NCHW, g.contiguous()
+        gin = torch.empty((B, C, H, W), dtype=torch.float32, device=g.device)
+    rois = _rois_f32(rois, g.device)
+    K = rois.shape[0]
+    _capi.check(L.step_roi_align_backward(_lib.dptr(g) if K else None, layout, _lib.dptr(rois) if K else None, K, B, C, H, W,
+                                          ph, pw, float(scale), int(sampling_ratio), _lib.dptr(gin), _lib.stream_ptr(g.device)),
+                "step_roi_align_backward")
+    return gin.to(grad.dtype)
+
+
+def roi_pool_forward(inp, rois, ph, pw, scale):
+    L = _lib.lib()
+    layout, inp = _roi_layout(inp)
+    B, C, H, W = inp.shape
+    rois = _rois_f32(rois, inp.device)
+    K = rois.shape[0]
+    if layout == _capi.NHWC:
+        out = torch.empty((K, ph, pw, C), dtype=inp.dtype, device=inp.device).permute(0, 3, 1, 2)
+        arg = torch.zeros((K, ph, pw, C), dtype=torch.int32, device=inp.device).permute(0, 3, 1, 2)
+    else:
+        out = torch.empty((K, C, ph, pw), dtype=inp.dtype, device=inp.device)
+        arg = torch.zeros((K, C, ph, pw), dtype=torch.int32, device=inp.device)
+    _capi.check(L.step_roi_pool_forward(_lib.dptr(inp), _dt(inp), layout, _lib.dptr(rois) if K else None, K, B, C, H, W, ph, pw,
+                                        float(scale), _lib.dptr(out) if K else None, _lib.dptr(arg) if K else None,
+                                        _lib.stream_ptr(inp.device)), "step_roi_pool_forward")
+    return out, arg
+
+
+def roi_pool_backward(grad, argmax, rois, ph, pw, B, C, H, W):
+    L = _lib.lib()
+    g = grad.float()
+    nhwc = (not argmax.is_contiguous()) and argmax.permute(0, 2, 3, 1).is_contiguous()
+    if nhwc:
+        layout = _capi.NHWC
+        if not g.permute(0, 2, 3, 1).is_contiguous():
+            g = g.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        gin = torch.empty((B, H, W, C), dtype=torch.float32, device=g.device).permute(0, 3, 1, 2)
+    else:
+        layout, g = _capi.NCHW, g.contiguous()
+        gin = torch.empty((B, C, H, W), dtype=torch.float32, device=g.device)
+    rois = _rois_f32(rois, g.device)
+    K = rois.shape[0]
+    _capi.check(L.step_roi_pool_backward(_lib.dptr(g) if K else None, _lib.dptr(argmax) if K else None, layout,
+                                         _lib.dptr(rois) if K else None, K, B, C, H, W, ph, pw, _lib.dptr(gin),
+                                         _lib.stream_ptr(g.device)), "step_roi_pool_backward")
+    return gin.to(grad.dtype)
+
+
+def nms_batched(boxes, scores, counts, threshold):
+    """boxes [G,kmax,4] fp32, scores [G,kmax] fp32, counts [G] int32 (all on one device)
+    -> keep mask uint8 [G,kmax] on the same device (no host round trip)."""
+    L = _lib.lib()
+    boxes, scores, counts = boxes.contiguous().float(), scores.contiguous().float(), counts.contiguous().to(torch.int32)
+    G, kmax = scores.shape
+    keep = torch.zeros((G, kmax), dtype=torch.uint8, device=boxes.device)
+    if G == 0 or kmax == 0:
+        return keep
+    nb = L.step_nms_scratch_bytes(G, kmax)
+    scratch = torch.empty(nb, dtype=torch.uint8, device=boxes.device) if nb else None
+    _capi.check(L.step_nms_batched(_lib.dptr(boxes), _lib.dptr(scores), _lib.dptr(counts), G, kmax, float(threshold),
+                                   _lib.dptr(keep), _lib.dptr(scratch), _lib.stream_ptr(boxes.device)), "step_nms_batched")
+    return keep

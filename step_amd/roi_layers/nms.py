@@ -1,0 +1,36 @@
+"""NMS operator API (reference: roi_layers/nms.py:38, csrc/nms.h:34-52).
+
+`nms(dets[k,4], scores[k], thr)` returns the kept ORIGINAL indices in ascending order as an int64
+CPU tensor -- what the reference returns on every path (cpu/nms_cpu.cpp:88; the CUDA op also returns
+a CPU tensor, nms.cu:151-154) -- with the reference CPU op's semantics (IoU >= thr suppresses),
+bit-exact.  Inputs may live on the GPU (no `.cpu()` needed first) or on the CPU (the reference's
+callers move them there, test.py:158-160: they are uploaded, the work still happens on the GPU).
+
+`nms_batched` is the tube-batched form ("nms_3d"): every (clip, class) group in one launch, result
+left on the device as a keep mask.
+"""
+import torch
+
+from .. import ops
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("step_amd: no ROCm device available and there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def nms(dets, scores, threshold):
+    if dets.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64, device="cpu")
+    dev = dets.device if dets.is_cuda else _device()
+    b = dets.detach().to(device=dev, dtype=torch.float32).reshape(1, -1, 4)
+    s = scores.detach().to(device=dev, dtype=torch.float32).reshape(1, -1)
+    counts = torch.tensor([b.shape[1]], dtype=torch.int32, device=dev)
+    keep = ops.nms_batched(b, s, counts, threshold)
+    return torch.nonzero(keep[0]).squeeze(1).to("cpu", torch.int64)
+
+
+def nms_batched(boxes, scores, counts, threshold):
+    """boxes [G,kmax,4], scores [G,kmax], counts [G] on one device -> uint8 keep mask [G,kmax]."""
+    return ops.nms_batched(boxes, scores, counts, threshold)

@@ -1,0 +1,66 @@
+"""step_amd/tube_math.py -- box / tube parameterisation used inside the hot path
+(reference: utils/tube_utils.py:127-189, called from models/two_branch.py:306,320 and
+utils/utils.py:68-79).  Tiny element-wise torch math on [n,4] boxes (x1,y1,x2,y2), "+1" pixel sizes."""
+import numpy as np
+import torch
+
+
+def get_center_size(boxes):
+    w = boxes[:, 2] - boxes[:, 0] + 1.0
+    h = boxes[:, 3] - boxes[:, 1] + 1.0
+    return boxes[:, 0] + 0.5 * w, boxes[:, 1] + 0.5 * h, w, h
+
+
+def encode_coef(gt_tubes, tubes):
+    """regression target of gt w.r.t. proposal: ((gx-x)/w, (gy-y)/h, log(gw/w), log(gh/h))"""
+    gx, gy, gw, gh = get_center_size(gt_tubes)
+    x, y, w, h = get_center_size(tubes)
+    return torch.stack(((gx - x) / w, (gy - y) / h, torch.log(gw / w), torch.log(gh / h)), dim=1)
+
+
+def decode_coef(anchors, deltas):
+    """inverse of encode_coef; the max corner gets -1 (tube_utils.py:186-187)"""
+    x, y, w, h = get_center_size(anchors)
+    px = w * deltas[:, 0] + x
+    py = h * deltas[:, 1] + y
+    pw = w * torch.exp(deltas[:, 2])
+    ph = h * torch.exp(deltas[:, 3])
+    return torch.stack((px - 0.5 * pw, py - 0.5 * ph, px + 0.5 * pw - 1, py + 0.5 * ph - 1), dim=1)
+
+
+def flatten_tubes(tubes, batch_idx=False):
+    """list of [n_i,T,dim] arrays -> ([sum n_i, T, dim(+1)], [n_i]); col 0 = frame index b*T+t
+    (tube_utils.py:214-246)."""
+    T = tubes[0].shape[1]
+    flat, nums = [], []
+    for i, t in enumerate(tubes):
+        nums.append(t.shape[0])
+        if t.shape[0] == 0:
+            continue
+        if batch_idx:
+            idx = np.broadcast_to((np.arange(T) + i * T).reshape(1, T, 1), (t.shape[0], T, 1)).astype(t.dtype)
+            flat.append(np.concatenate((idx, t), axis=2))
+        else:
+            flat.append(t.copy())
+    return np.concatenate(flat, axis=0), nums
+
+
+def valid_tubes(tubes, width=400, height=400):
+    """clamp to the image; boxes that are not at least 3 px in each direction become the whole
+    image (tube_utils.py:59-92), vectorised.  Works on numpy arrays or torch tensors (returns a copy)."""
+    if isinstance(tubes, np.ndarray):
+        b = tubes.reshape(-1, 4).copy()
+        b[:, 0] = np.maximum(0, b[:, 0])
+        b[:, 1] = np.maximum(0, b[:, 1])
+        b[:, 2] = np.minimum(width, b[:, 2])
+        b[:, 3] = np.minimum(height, b[:, 3])
+        bad = ~((b[:, 0] < b[:, 2] - 2) & (b[:, 1] < b[:, 3] - 2))
+        b[bad] = np.asarray([0, 0, width, height], dtype=b.dtype)
+        return b.reshape(tubes.shape)
+    b = tubes.reshape(-1, 4)
+    x1, y1 = b[:, 0].clamp(min=0), b[:, 1].clamp(min=0)
+    x2, y2 = b[:, 2].clamp(max=width), b[:, 3].clamp(max=height)
+    bad = ~((x1 < x2 - 2) & (y1 < y2 - 2))
+    whole = torch.tensor([0, 0, width, height], dtype=b.dtype, device=b.device)
+    out = torch.where(bad[:, None], whole[None], torch.stack((x1, y1, x2, y2), 1))
+    return out.reshape(tubes.shape)

@@ -10,7 +10,7 @@ import torch
 import oracle
 from oracle import i3d_ref as R
 
-from conftest import GOLDEN
+from tests.conftest import GOLDEN
 
 
 def rel_err(a, b):
