@@ -63,11 +63,24 @@ def cpu_baseline(net, seconds_budget=25.0):
     """The oracle's torch-CPU fp32 BaseNet on single clips [1,32,3,224,224], all host cores."""
     from oracle import i3d_ref as R
     sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     g = torch.Generator().manual_seed(123)
     x = torch.rand(1, T_IN, 3, HW_IN, HW_IN, generator=g) * 2 - 1
     with torch.no_grad():
+        # torch's CPU conv3d does not scale to hundreds of threads: probe a few thread counts on a
+        # quarter-length clip and keep the fastest for the timed sample
+        best, best_t = None, None
+        for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
+            torch.set_num_threads(th)
+            R.basenet_forward(x[:, :8], sd)
+            t0 = time.perf_counter()
+            R.basenet_forward(x[:, :8], sd)
+            dt = time.perf_counter() - t0
+            if best_t is None or dt < best_t:
+                best, best_t = th, dt
+            if dt > 6.0:
+                break
+        torch.set_num_threads(best)
         R.basenet_forward(x, sd)                                 # warm-up
         n, t0 = 0, time.perf_counter()
         while True:
@@ -119,7 +132,7 @@ def roofline(net, x, dtype_name):
            "algorithmic_mb_per_launch": round(nbytes / cnt / 1e6, 3)}
     if tsrc:
         out["traffic_source"] = tsrc
-    table = sorted(((n_, a[1] / 3, a[0] // 3, a[2] / max(a[1], 1e-9) / 1e9) for n_, a in agg.items()), key=lambda r: -r[1])
+    table = sorted(((n_, a[1] / 3, a[0] // 3, a[2] / max(a[1], 1e-9) / 1e9) for n_, a in agg.items()), key=lambda r: -r[1])   # TFLOP/s = flops / ms / 1e9
     return out, table, total_ms / 3
 
 
@@ -221,7 +234,7 @@ def main():
         out["kernel_time_ms_per_step"] = round(gpu_ms, 4)
         if a.verbose:
             for n_, ms, cnt, gfs in table:
-                print("%9.4f ms %3d x  %8.1f TFLOP/s  %s" % (ms, cnt, gfs / 1e3, n_), file=sys.stderr)
+                print("%9.4f ms %3d x  %8.1f TFLOP/s  %s" % (ms, cnt, gfs, n_), file=sys.stderr)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(net)
         print(json.dumps(out))
