@@ -117,6 +117,20 @@ __device__ inline void mma_k16(const u16x8& a, const u16x8& b, f32x16& c, f16_t)
 }
 #endif
 
+// ---- LDS-DMA: each lane copies 16 B from its own global address to  lds_base + lane*16 ----------
+// (global_load_lds_dwordx4: the LDS destination is the wave-uniform base + lane x 16, the data never
+// passes through VGPRs; completion is tracked by vmcnt -- a following __syncthreads() drains it.)
+#ifndef STEP_EMUL
+__device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_base_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_base_uniform, 16, 0, 0);
+}
+#else
+__device__ inline void glds16(const void* gsrc_lane, void* lds_base_uniform) {
+    __builtin_memcpy((unsigned char*)lds_base_uniform + 16 * (threadIdx.x & 63), gsrc_lane, 16);
+}
+#endif
+
 __device__ __forceinline__ int cd_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // ---- launch helper -------------------------------------------------------------------------

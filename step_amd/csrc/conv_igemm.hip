@@ -25,6 +25,7 @@
 //     the pixel index so the ds_read_b128 of the 32 pixels of a fragment spread over the banks.
 #include "common.h"
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace step {
 
@@ -37,6 +38,7 @@ struct ConvParams {
     int relu;
     int tiles_h, tiles_w;
     int nchunks;   // ceil(Cin / 32)
+    int nchunks32; // same (the packed-weight K extent is 2*nchunks32 k16 blocks)
     int nblk32;    // ceil(Cout / 32)
     long long Mtot;  // N*D*H*W
 };
@@ -64,6 +66,41 @@ template <>
 __device__ __forceinline__ u16x8 lds_read_frag<f16_t>(const unsigned char* pix_base, int j, int khalf, int sw) {
     return *(const u16x8*)(pix_base + (((j * 2 + khalf) ^ sw) << 4));
 }
+
+// 64-byte-per-pixel slab (conv_tap_kernel): 4 slots; fp32 holds 16 channels (one k16 step),
+// 16-bit types 32 channels (two k16 steps)
+template <typename T>
+__device__ __forceinline__ typename frag<T>::type lds_read_slab64(const unsigned char* pix_base, int j, int khalf, int sw);
+template <>
+__device__ __forceinline__ f32x8 lds_read_slab64<float>(const unsigned char* pix_base, int, int khalf, int sw) {
+    const int s0 = khalf * 2;
+    f32x4 lo = *(const f32x4*)(pix_base + ((s0 ^ sw) << 4));
+    f32x4 hi = *(const f32x4*)(pix_base + (((s0 + 1) ^ sw) << 4));
+    f32x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+template <>
+__device__ __forceinline__ u16x8 lds_read_slab64<bf16_t>(const unsigned char* pix_base, int j, int khalf, int sw) {
+    return *(const u16x8*)(pix_base + (((j * 2 + khalf) ^ sw) << 4));
+}
+template <>
+__device__ __forceinline__ u16x8 lds_read_slab64<f16_t>(const unsigned char* pix_base, int j, int khalf, int sw) {
+    return *(const u16x8*)(pix_base + (((j * 2 + khalf) ^ sw) << 4));
+}
+// B fragment out of the LDS copy of the packed weights (p already includes the lane offset)
+template <typename T>
+__device__ __forceinline__ typename frag<T>::type lds_read_bfrag(const unsigned char* p);
+template <>
+__device__ __forceinline__ f32x8 lds_read_bfrag<float>(const unsigned char* p) {
+    f32x4 lo = *(const f32x4*)p;
+    f32x4 hi = *(const f32x4*)(p + 16);
+    f32x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+template <>
+__device__ __forceinline__ u16x8 lds_read_bfrag<bf16_t>(const unsigned char* p) { return *(const u16x8*)p; }
+template <>
+__device__ __forceinline__ u16x8 lds_read_bfrag<f16_t>(const unsigned char* p) { return *(const u16x8*)p; }
 
 template <typename T>
 __device__ __forceinline__ typename frag<T>::type load_b_frag(const T* p) {  // p -> this lane's 8 elements
@@ -220,6 +257,203 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                     if (rg) v += elem<T>::to_f32(rg[opix * p.r_cstride + p.r_coff + co]);
                     if (p.relu) v = fmaxf(v, 0.f);
                     yg[opix * p.y_cstride + p.y_coff + co] = elem<T>::from_f32(v);
+                }
+            }
+        }
+    }
+}
+
+// ============================================================================================
+// conv_tap_kernel -- the heavy 3x3x3 / 1x3x3 path.
+//
+// 512 threads = 8 wavefronts own a 256-pixel x (64*NB)-channel output tile.  Waves are arranged
+// 4 (pixels) x 2 (channels); each wave accumulates 2 x NB 32x32 MFMA tiles (64 px x 32*NB ch).
+//   * A: the 64-byte-per-pixel slab (32 channels of 16-bit data, 16 of fp32) of the input halo tile
+//     ([kd][TH+kh-1][TW+kw-1] pixels) is staged into LDS once per slab; all taps read it at shifted
+//     bases (im2col-free).
+//   * B: the weights of ONE tap x slab x tile-channels (4*NB KiB, already in MFMA fragment order in
+//     global memory) are brought in by LDS-DMA (global_load_lds, 16 B per lane, no VGPRs) into a
+//     double buffer: the DMA of tap t+1 flies while the MFMAs of tap t run; one barrier per tap.
+//     Every B fragment read from LDS feeds 2 MFMAs and every A fragment NB MFMAs, so a k16 step
+//     costs (2 + NB) ds_read_b128 for 2*NB MFMAs and the weights cross the L2->CU path once per
+//     256 pixels instead of once per 32.
+template <typename T, int TWL, int NB, int KD, int KH, int KW>
+__global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
+    constexpr int TW = 1 << TWL, TH = 256 >> TWL;
+    constexpr int HH_ = TH + KH - 1, HW_ = TW + KW - 1;
+    constexpr int NPIX = KD * HH_ * HW_;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int VEC = 16 / ES;
+    constexpr int CKT = 64 / ES;          // channels per slab: 32 (16-bit) / 16 (fp32)
+    constexpr int KS = CKT / 16;          // k16 steps per slab
+    constexpr int PITCH = 80, SLOTS = 4;   // 64 B of data + 16 B pad: consecutive pixels rotate through the LDS banks, and a tap
+                                           // shift is a compile-time byte offset (folds into the ds_read immediate)
+    constexpr int NTAPS = KD * KH * KW;
+    constexpr int NVEC = NPIX * SLOTS;
+    constexpr int ITER = (NVEC + 511) / 512;
+    constexpr int FRAGB = 512 * ES;       // bytes of one B fragment (64 lanes x 8 elements)
+    constexpr int NBT = 2 * NB;           // 32-channel blocks per workgroup tile
+    constexpr int BTILE = NBT * KS * FRAGB;
+    constexpr int NPIECE = BTILE / 1024;  // 1 KiB LDS-DMA pieces per tap
+    typedef typename Ld16<T>::type vec16;
+    typedef typename frag<T>::type frag_t;
+
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX * PITCH + 2 * BTILE];
+    unsigned char* const ldsA = lds;
+    unsigned char* const ldsB = lds + NPIX * PITCH;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int khalf = lane >> 5;
+    const int wm = wave & 3, wn = wave >> 2;
+
+    int t = blockIdx.x;
+    const int tw_i = t % p.tiles_w; t /= p.tiles_w;
+    const int th_i = t % p.tiles_h; t /= p.tiles_h;
+    const int d = t % p.D;
+    const int n = t / p.D;
+    const int h0 = th_i * TH, w0 = tw_i * TW;
+    const int nb0 = blockIdx.y * NBT;
+    const int KC16 = p.nchunks32 * 2;
+    const int nslab = (p.Cin + CKT - 1) / CKT;
+
+    const T* xg = (const T*)p.x;
+    const T* wg = (const T*)p.w;
+
+    // LDS address of this lane's two accumulator rows (before the tap shift), incl. its k half
+    const unsigned char* abase[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int m = wm * 64 + mb * 32 + (lane & 31);
+        abase[mb] = ldsA + ((m >> TWL) * HW_ + (m & (TW - 1))) * PITCH + khalf * (16 * (ES == 4 ? 2 : 1));
+    }
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][i][r] = 0.f;
+
+    auto stage_A = [&](int slab) {
+        vec16 stage[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int v = tid + it * 512;
+            vec16 val;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) val[e] = 0;
+            if (v < NVEC) {
+                const int pix = v / SLOTS, slot = v % SLOTS;
+                const int c = slab * CKT + slot * VEC;
+                const int plane = pix / (HH_ * HW_), rem = pix % (HH_ * HW_);
+                const int r = rem / HW_, cc = rem % HW_;
+                const int id = d + plane - KD / 2, ih = h0 + r - KH / 2, iw = w0 + cc - KW / 2;
+                const bool inb = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                if (inb && c < p.Cin) {
+                    const size_t gpix = (((size_t)n * p.D + id) * p.H + ih) * p.W + iw;
+                    val = *(const vec16*)(xg + gpix * p.x_cstride + p.x_coff + c);
+                }
+            }
+            stage[it] = val;
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int v = tid + it * 512;
+            if (v < NVEC) {
+                const int pix = v / SLOTS, slot = v % SLOTS;
+                *(vec16*)(ldsA + pix * PITCH + (slot << 4)) = stage[it];
+            }
+        }
+    };
+
+    // LDS-DMA of the B tile of (slab, tap) into buffer `buf`
+    auto dma_B = [&](int slab, int tap, int buf) {
+        unsigned char* dst = ldsB + buf * BTILE;
+#pragma unroll
+        for (int q = 0; q < (NPIECE + 7) / 8; ++q) {
+            const int pc = wave + q * 8;                 // wave-uniform piece id
+            if (pc < NPIECE) {
+                const int f = pc / (FRAGB / 1024), sub = pc % (FRAGB / 1024);
+                const int nbl = f / KS, ks = f % KS;
+                if (nb0 + nbl < p.nblk32) {
+                    const int kc16 = slab * KS + ks;
+                    const unsigned char* src = (const unsigned char*)(wg + ((((size_t)(nb0 + nbl) * NTAPS + tap) * KC16 + kc16) * 512)) + sub * 1024 + lane * 16;
+                    glds16(src, dst + pc * 1024);
+                }
+            }
+        }
+    };
+
+    stage_A(0);
+    dma_B(0, 0, 0);
+    __syncthreads();
+
+    int step = 0;
+    for (int slab = 0; slab < nslab; ++slab) {
+#pragma unroll 1
+        for (int kd = 0; kd < KD; ++kd) {
+#pragma unroll 1
+            for (int kh = 0; kh < KH; ++kh) {
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) {
+                    const int tap = (kd * KH + kh) * KW + kw;
+                    const int cur = step & 1;
+                    // prefetch the next tap's weights while this tap computes
+                    if (tap + 1 < NTAPS) dma_B(slab, tap + 1, cur ^ 1);
+                    else if (slab + 1 < nslab) dma_B(slab + 1, 0, cur ^ 1);
+
+                    const unsigned char* bb = ldsB + cur * BTILE + (wn * NB) * KS * FRAGB + lane * (8 * ES);
+                    const int shift = ((kd * HH_ + kh) * HW_ + kw) * PITCH;
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) {
+                        frag_t a[2];
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb) a[mb] = lds_read_bfrag<T>(abase[mb] + shift + j * 32);
+#pragma unroll
+                        for (int i = 0; i < NB; ++i) {
+                            if (nb0 + wn * NB + i < p.nblk32) {   // wave-uniform
+                                const frag_t b = lds_read_bfrag<T>(bb + (i * KS + j) * FRAGB);
+                                mma_k16(a[0], b, acc[0][i], T());
+                                mma_k16(a[1], b, acc[1][i], T());
+                            }
+                        }
+                    }
+                    ++step;
+                    if (tap + 1 == NTAPS && slab + 1 < nslab) {
+                        __syncthreads();          // everyone is done with this slab of A
+                        stage_A(slab + 1);
+                    }
+                    __syncthreads();              // DMA landed (vmcnt drained) + buffer hand-over
+                }
+            }
+        }
+    }
+
+    // ---- epilogue
+    T* yg = (T*)p.y;
+    const T* rg = (const T*)p.res;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int nbg = nb0 + wn * NB + i;
+        const int co = nbg * 32 + (lane & 31);
+        if (nbg < p.nblk32 && co < p.Cout) {
+            const float sc = p.scale ? p.scale[co] : 1.f;
+            const float sh = p.shift ? p.shift[co] : 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mm = wm * 64 + mb * 32 + cd_row(r, lane);
+                    const int oh = h0 + (mm >> TWL), ow = w0 + (mm & (TW - 1));
+                    if (oh < p.H && ow < p.W) {
+                        const size_t opix = (((size_t)n * p.D + d) * p.H + oh) * p.W + ow;
+                        float v = acc[mb][i][r] * sc + sh;
+                        if (rg) v += elem<T>::to_f32(rg[opix * p.r_cstride + p.r_coff + co]);
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        yg[opix * p.y_cstride + p.y_coff + co] = elem<T>::from_f32(v);
+                    }
                 }
             }
         }
@@ -445,11 +679,34 @@ static int pick_nb(int nblk32, long long mtiles) {
 
 // Which instantiation a descriptor maps to (also used by step_conv_kernel_name so that bench.py can
 // attribute time and work to the kernel name rocprofv3 reports).
-struct ConvPlan { bool ok, flat, wide; int NB, tiles_h, tiles_w; long long mtiles; };
+//   impl 0: conv_igemm_kernel (4 waves, 128-px tile, weights straight from L2)  -- 1x1x1 and small problems
+//   impl 1: conv_tap_kernel   (8 waves, 256-px tile, weights through an LDS-DMA double buffer)
+struct ConvPlan { bool ok, flat, wide; int impl, NB, tiles_h, tiles_w; long long mtiles; };
+
+static int pick_nb_tap(int nblk32, long long mtiles) {
+    int best = 1;
+    double best_cost = -1;
+    for (int nb = 4; nb >= 1; --nb) {
+        const long long groups = ceil_div(nblk32, 2 * nb);
+        const long long wgs = groups * mtiles;
+        // one 512-thread workgroup per CU: rounds of 256; per-workgroup time ~ 2*nb MFMA units + fixed part
+        const double cost = (double)ceil_div64(wgs, 256) * (2.0 * nb + 1.5) - 0.01 * nb;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nb; }
+    }
+    return best;
+}
+
+static int conv_impl_override() {   // tuning aid: STEP_CONV_IMPL=igemm|tap forces one implementation
+    const char* e = getenv("STEP_CONV_IMPL");
+    if (!e) return -1;
+    if (e[0] == 'i') return 0;
+    if (e[0] == 't') return 1;
+    return -1;
+}
 
 static ConvPlan conv_plan(const step_conv_desc* d) {
     ConvPlan pl;
-    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0;
+    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0;
     const int nblk32 = ceil_div(d->Cout, 32);
     const bool k1 = d->kd == 1 && d->kh == 1 && d->kw == 1;
     const bool k333 = d->kd == 3 && d->kh == 3 && d->kw == 3;
@@ -457,19 +714,45 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
     pl.flat = k1;
     if (k1) {
         pl.mtiles = ceil_div64((long long)d->N * d->D * d->H * d->W, 128);
-    } else if (k333 || k133) {
-        // tile shape: 8x16 or 4x32 output pixels, whichever wastes fewer pixels on this H x W
-        const long long w16 = (long long)ceil_div(d->H, 8) * ceil_div(d->W, 16);
-        const long long w32 = (long long)ceil_div(d->H, 4) * ceil_div(d->W, 32);
-        pl.wide = w32 < w16;
-        pl.tiles_h = pl.wide ? ceil_div(d->H, 4) : ceil_div(d->H, 8);
-        pl.tiles_w = pl.wide ? ceil_div(d->W, 32) : ceil_div(d->W, 16);
-        pl.mtiles = (long long)d->N * d->D * pl.tiles_h * pl.tiles_w;
-    } else {
-        pl.ok = false; pl.mtiles = 0;
+        pl.NB = pick_nb(nblk32, pl.mtiles);
+        return pl;
     }
+    if (!k333 && !k133) { pl.ok = false; pl.mtiles = 0; pl.NB = 1; return pl; }
+    const int ov = conv_impl_override();
+    // 256-pixel tiles (16x16 or 8x32), whichever wastes fewer pixels on this H x W
+    const long long t16 = (long long)ceil_div(d->H, 16) * ceil_div(d->W, 16);
+    const long long t32 = (long long)ceil_div(d->H, 8) * ceil_div(d->W, 32);
+    const long long mt256 = (long long)d->N * d->D * (t32 < t16 ? t32 : t16);
+    const bool use_tap = ov == 1 || (ov != 0 && mt256 * ceil_div(nblk32, 2) >= 64);
+    if (use_tap) {
+        pl.impl = 1;
+        pl.wide = t32 < t16;
+        pl.tiles_h = pl.wide ? ceil_div(d->H, 8) : ceil_div(d->H, 16);
+        pl.tiles_w = pl.wide ? ceil_div(d->W, 32) : ceil_div(d->W, 16);
+        pl.mtiles = mt256;
+        pl.NB = pick_nb_tap(nblk32, pl.mtiles);
+        return pl;
+    }
+    // 128-pixel tiles: 8x16 or 4x32
+    const long long w16 = (long long)ceil_div(d->H, 8) * ceil_div(d->W, 16);
+    const long long w32 = (long long)ceil_div(d->H, 4) * ceil_div(d->W, 32);
+    pl.wide = w32 < w16;
+    pl.tiles_h = pl.wide ? ceil_div(d->H, 4) : ceil_div(d->H, 8);
+    pl.tiles_w = pl.wide ? ceil_div(d->W, 32) : ceil_div(d->W, 16);
+    pl.mtiles = (long long)d->N * d->D * pl.tiles_h * pl.tiles_w;
     pl.NB = pick_nb(nblk32, pl.mtiles);
     return pl;
+}
+
+template <typename T, int TWL, int KD, int KH, int KW>
+static int launch_tap(const ConvParams& p, int NB, dim3 grid, step_stream_t stream) {
+    switch (NB) {
+        case 1: STEP_LAUNCH((conv_tap_kernel<T, TWL, 1, KD, KH, KW>), grid, dim3(512), stream, p); break;
+        case 2: STEP_LAUNCH((conv_tap_kernel<T, TWL, 2, KD, KH, KW>), grid, dim3(512), stream, p); break;
+        case 3: STEP_LAUNCH((conv_tap_kernel<T, TWL, 3, KD, KH, KW>), grid, dim3(512), stream, p); break;
+        default: STEP_LAUNCH((conv_tap_kernel<T, TWL, 4, KD, KH, KW>), grid, dim3(512), stream, p); break;
+    }
+    return STEP_LAUNCH_CHECK();
 }
 
 template <typename T>
@@ -480,6 +763,12 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, step_stream_t s
     const ConvPlan pl = conv_plan(d);
     if (!pl.ok) return STEP_E_UNSUPPORTED;
     p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w;
+    if (pl.impl == 1) {
+        dim3 grid((unsigned)pl.mtiles, (unsigned)ceil_div(p.nblk32, 2 * pl.NB));
+        if (d->kd == 3)
+            return pl.wide ? launch_tap<T, 5, 3, 3, 3>(p, pl.NB, grid, stream) : launch_tap<T, 4, 3, 3, 3>(p, pl.NB, grid, stream);
+        return pl.wide ? launch_tap<T, 5, 1, 3, 3>(p, pl.NB, grid, stream) : launch_tap<T, 4, 1, 3, 3>(p, pl.NB, grid, stream);
+    }
     dim3 grid((unsigned)pl.mtiles, (unsigned)ceil_div(p.nblk32, pl.NB));
     if (pl.flat) return launch_nb<T, 4, 1, 1, 1, true>(p, pl.NB, grid, stream);
     if (d->kd == 3)
@@ -537,6 +826,7 @@ int step_conv_forward(const step_conv_desc* d, const void* x, const void* w_pack
     p.relu = d->relu;
     p.tiles_h = p.tiles_w = 0;
     p.nchunks = ceil_div(d->Cin, CK);
+    p.nchunks32 = p.nchunks;
     p.nblk32 = ceil_div(d->Cout, 32);
     p.Mtot = (long long)d->N * d->D * d->H * d->W;
     switch (d->dtype) {
@@ -591,8 +881,12 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
     const ConvPlan pl = conv_plan(d);
     if (!pl.ok) return STEP_E_UNSUPPORTED;
     const char* t = d->dtype == STEP_F32 ? "float" : (d->dtype == STEP_BF16 ? "step::bf16_t" : "step::f16_t");
-    snprintf(buf, (size_t)buflen, "void step::conv_igemm_kernel<%s, %d, %d, %d, %d, %d, %s>(step::ConvParams)", t,
-             pl.flat ? 4 : (pl.wide ? 5 : 4), pl.NB, d->kd, d->kh, d->kw, pl.flat ? "true" : "false");
+    if (pl.impl == 1)
+        snprintf(buf, (size_t)buflen, "void step::conv_tap_kernel<%s, %d, %d, %d, %d, %d>(step::ConvParams)", t,
+                 pl.wide ? 5 : 4, pl.NB, d->kd, d->kh, d->kw);
+    else
+        snprintf(buf, (size_t)buflen, "void step::conv_igemm_kernel<%s, %d, %d, %d, %d, %d, %s>(step::ConvParams)", t,
+                 pl.flat ? 4 : (pl.wide ? 5 : 4), pl.NB, d->kd, d->kh, d->kw, pl.flat ? "true" : "false");
     return STEP_OK;
 }
 
