@@ -58,18 +58,24 @@ template <> struct elem<float> {
     static constexpr int VEC = 4;  // elements per 16 bytes
     __device__ static __forceinline__ float to_f32(float x) { return x; }
     __device__ static __forceinline__ float from_f32(float x) { return x; }
+    __device__ static __forceinline__ unsigned short bits16(float) { return 0; }      // 16-bit helpers: unused for fp32
+    __device__ static __forceinline__ float from_bits16(unsigned short) { return 0.f; }
 };
 template <> struct elem<bf16_t> {
     static constexpr int dtype = STEP_BF16;
     static constexpr int VEC = 8;
     __device__ static __forceinline__ float to_f32(bf16_t x) { return bf16_bits_to_f32(x.v); }
     __device__ static __forceinline__ bf16_t from_f32(float x) { bf16_t r; r.v = f32_to_bf16_bits(x); return r; }
+    __device__ static __forceinline__ unsigned short bits16(float x) { return f32_to_bf16_bits(x); }
+    __device__ static __forceinline__ float from_bits16(unsigned short h) { return bf16_bits_to_f32(h); }
 };
 template <> struct elem<f16_t> {
     static constexpr int dtype = STEP_F16;
     static constexpr int VEC = 8;
     __device__ static __forceinline__ float to_f32(f16_t x) { return f16_bits_to_f32(x.v); }
     __device__ static __forceinline__ f16_t from_f32(float x) { f16_t r; r.v = f32_to_f16_bits(x); return r; }
+    __device__ static __forceinline__ unsigned short bits16(float x) { return f32_to_f16_bits(x); }
+    __device__ static __forceinline__ float from_bits16(unsigned short h) { return f16_bits_to_f32(h); }
 };
 
 // ---- 32x32 MFMA "k16 step": D(32x32) += A(32x16) * B(16x32) --------------------------------

@@ -26,6 +26,7 @@
 #include "common.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace step {
 
@@ -39,6 +40,7 @@ struct ConvParams {
     int tiles_h, tiles_w;
     int nchunks;   // ceil(Cin / 32)
     int nchunks32; // same (the packed-weight K extent is 2*nchunks32 k16 blocks)
+    int vec_epi;   // 16-byte output stores are legal (channel strides/offsets % 8 == 0, pointers 16-B aligned)
     int nblk32;    // ceil(Cout / 32)
     long long Mtot;  // N*D*H*W
 };
@@ -268,15 +270,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 //
 // 512 threads = 8 wavefronts own a 256-pixel x (64*NB)-channel output tile.  Waves are arranged
 // 4 (pixels) x 2 (channels); each wave accumulates 2 x NB 32x32 MFMA tiles (64 px x 32*NB ch).
-//   * A: the 64-byte-per-pixel slab (32 channels of 16-bit data, 16 of fp32) of the input halo tile
+//   * A: a 64-byte-per-pixel slab (32 channels of 16-bit data, 16 of fp32) of the input halo tile
 //     ([kd][TH+kh-1][TW+kw-1] pixels) is staged into LDS once per slab; all taps read it at shifted
-//     bases (im2col-free).
+//     bases (im2col-free).  Pixels sit at an 80-byte pitch (64 B + 16 B pad): consecutive pixels
+//     rotate through the LDS banks without an XOR swizzle and a tap shift is a plain byte offset.
 //   * B: the weights of ONE tap x slab x tile-channels (4*NB KiB, already in MFMA fragment order in
-//     global memory) are brought in by LDS-DMA (global_load_lds, 16 B per lane, no VGPRs) into a
-//     double buffer: the DMA of tap t+1 flies while the MFMAs of tap t run; one barrier per tap.
-//     Every B fragment read from LDS feeds 2 MFMAs and every A fragment NB MFMAs, so a k16 step
-//     costs (2 + NB) ds_read_b128 for 2*NB MFMAs and the weights cross the L2->CU path once per
-//     256 pixels instead of once per 32.
+//     global memory, so the copy is linear) go global -> registers -> LDS through a double-buffered
+//     LDS tile with a two-taps-deep register prefetch: the loads for tap s+2 are issued before the
+//     MFMAs of tap s, the registers loaded one tap earlier are written to LDS after them, one
+//     barrier per tap.  Every B fragment read from LDS feeds 2 MFMAs and every A fragment NB MFMAs
+//     (a k16 step costs 2 + NB ds_read_b128 for 2*NB MFMAs), and the weights cross the L2 -> CU
+//     path once per 256 pixels instead of once per 32.
 template <typename T, int TWL, int NB, int KD, int KH, int KW>
 __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
     constexpr int TW = 1 << TWL, TH = 256 >> TWL;
@@ -286,24 +290,30 @@ __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
     constexpr int VEC = 16 / ES;
     constexpr int CKT = 64 / ES;          // channels per slab: 32 (16-bit) / 16 (fp32)
     constexpr int KS = CKT / 16;          // k16 steps per slab
-    constexpr int PITCH = 80, SLOTS = 4;   // 64 B of data + 16 B pad: consecutive pixels rotate through the LDS banks, and a tap
-                                           // shift is a compile-time byte offset (folds into the ds_read immediate)
+    constexpr int PITCH = 80, SLOTS = 4;
     constexpr int NTAPS = KD * KH * KW;
     constexpr int NVEC = NPIX * SLOTS;
     constexpr int ITER = (NVEC + 511) / 512;
     constexpr int FRAGB = 512 * ES;       // bytes of one B fragment (64 lanes x 8 elements)
+    constexpr int FRAGV = FRAGB / 16;     // 16-byte vectors per fragment
     constexpr int NBT = 2 * NB;           // 32-channel blocks per workgroup tile
     constexpr int BTILE = NBT * KS * FRAGB;
-    constexpr int NPIECE = BTILE / 1024;  // 1 KiB LDS-DMA pieces per tap
+    constexpr int BVEC = BTILE / 16;      // 16-byte vectors per tap tile
+    constexpr int Q = (BVEC + 511) / 512; // vectors per thread per tap
     typedef typename Ld16<T>::type vec16;
     typedef typename frag<T>::type frag_t;
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX * PITCH + 2 * BTILE];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX * PITCH + 3 * BTILE];
     unsigned char* const ldsA = lds;
     unsigned char* const ldsB = lds + NPIX * PITCH;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+#ifdef STEP_EMUL
+    const int wave = tid >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> scalar branches
+#endif
     const int khalf = lane >> 5;
     const int wm = wave & 3, wn = wave >> 2;
 
@@ -316,16 +326,17 @@ __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
     const int nb0 = blockIdx.y * NBT;
     const int KC16 = p.nchunks32 * 2;
     const int nslab = (p.Cin + CKT - 1) / CKT;
+    const int S = nslab * NTAPS;          // pipeline steps
 
     const T* xg = (const T*)p.x;
-    const T* wg = (const T*)p.w;
+    const unsigned char* wg = (const unsigned char*)p.w;
 
     // LDS address of this lane's two accumulator rows (before the tap shift), incl. its k half
     const unsigned char* abase[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
         const int m = wm * 64 + mb * 32 + (lane & 31);
-        abase[mb] = ldsA + ((m >> TWL) * HW_ + (m & (TW - 1))) * PITCH + khalf * (16 * (ES == 4 ? 2 : 1));
+        abase[mb] = ldsA + ((m >> TWL) * HW_ + (m & (TW - 1))) * PITCH + khalf * (ES == 4 ? 32 : 16);
     }
 
     f32x16 acc[2][NB];
@@ -368,72 +379,163 @@ __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
         }
     };
 
-    // LDS-DMA of the B tile of (slab, tap) into buffer `buf`
-    auto dma_B = [&](int slab, int tap, int buf) {
-        unsigned char* dst = ldsB + buf * BTILE;
+    // global -> registers: this thread's vectors of the B tile of a pipeline step.  Branch-free on
+    // purpose (a predicated load makes the compiler drain vmcnt at the loop head): threads without a
+    // vector re-load the last one, and channel blocks past Cout re-load the last real block -- their
+    // accumulators are never stored.  The per-thread part of the address is computed ONCE; a step
+    // only adds a wave-uniform byte offset ((tap * KC16 + slab * KS) fragments).
+    const unsigned char* wthr[Q];
+    int ldsoff[Q];
 #pragma unroll
-        for (int q = 0; q < (NPIECE + 7) / 8; ++q) {
-            const int pc = wave + q * 8;                 // wave-uniform piece id
-            if (pc < NPIECE) {
-                const int f = pc / (FRAGB / 1024), sub = pc % (FRAGB / 1024);
-                const int nbl = f / KS, ks = f % KS;
-                if (nb0 + nbl < p.nblk32) {
-                    const int kc16 = slab * KS + ks;
-                    const unsigned char* src = (const unsigned char*)(wg + ((((size_t)(nb0 + nbl) * NTAPS + tap) * KC16 + kc16) * 512)) + sub * 1024 + lane * 16;
-                    glds16(src, dst + pc * 1024);
-                }
-            }
-        }
+    for (int q = 0; q < Q; ++q) {
+        const int v = min(tid + q * 512, BVEC - 1);
+        const int f = v / FRAGV, within = v % FRAGV;
+        const int nbl = f / KS, ks = f % KS;
+        const int nbg = min(nb0 + nbl, p.nblk32 - 1);
+        wthr[q] = wg + ((size_t)nbg * NTAPS * KC16 + ks) * FRAGB + within * 16;
+        ldsoff[q] = (tid + q * 512 < BVEC) ? (tid + q * 512) * 16 : -1;
+    }
+    auto load_B = [&](int slab_, int tap_, u32x4 (&r)[Q]) {
+        const size_t off = (size_t)(tap_ * KC16 + slab_ * KS) * FRAGB;      // scalar
+#pragma unroll
+        for (int q = 0; q < Q; ++q) r[q] = *(const u32x4*)(wthr[q] + off);
+    };
+    auto store_B = [&](int bufoff, const u32x4 (&r)[Q]) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+            if (ldsoff[q] >= 0) *(u32x4*)(ldsB + bufoff + ldsoff[q]) = r[q];
     };
 
-    stage_A(0);
-    dma_B(0, 0, 0);
-    __syncthreads();
+    // Pipeline (per step s = one tap of one slab):
+    //   weights: ONE register set R and THREE LDS buffers.  During step s, R (tile s+2) is written to
+    //     buffer (s+2)%3 -- last read during step s-1's prefetch -- and re-issued for tile s+3; the
+    //     only vector-memory operations outstanding at its wait are its own (exact vmcnt).
+    //   fragments: two register sets.  The ds_reads of step s+1 (buffer (s+1)%3, complete since the
+    //     barrier that ended step s-1) are issued BEFORE the MFMAs of step s, so LDS latency, the
+    //     weight hand-over and the barrier all hide behind matrix work; one barrier per step.
+    //   A slab switch drains the pipeline once per 27 (9) taps.
+    u32x4 R[Q];
+    frag_t fa[2][KS][2], fb[2][KS][NB];
 
-    int step = 0;
-    for (int slab = 0; slab < nslab; ++slab) {
-#pragma unroll 1
-        for (int kd = 0; kd < KD; ++kd) {
-#pragma unroll 1
-            for (int kh = 0; kh < KH; ++kh) {
+    const unsigned char* const bwave = ldsB + (wn * NB) * KS * FRAGB + lane * (8 * ES);
+    auto read_frags = [&](auto setc, int bufoff, int shift) {
+        constexpr int SET = decltype(setc)::value;
 #pragma unroll
-                for (int kw = 0; kw < KW; ++kw) {
-                    const int tap = (kd * KH + kh) * KW + kw;
-                    const int cur = step & 1;
-                    // prefetch the next tap's weights while this tap computes
-                    if (tap + 1 < NTAPS) dma_B(slab, tap + 1, cur ^ 1);
-                    else if (slab + 1 < nslab) dma_B(slab + 1, 0, cur ^ 1);
-
-                    const unsigned char* bb = ldsB + cur * BTILE + (wn * NB) * KS * FRAGB + lane * (8 * ES);
-                    const int shift = ((kd * HH_ + kh) * HW_ + kw) * PITCH;
+        for (int j = 0; j < KS; ++j) {
 #pragma unroll
-                    for (int j = 0; j < KS; ++j) {
-                        frag_t a[2];
+            for (int mb = 0; mb < 2; ++mb) fa[SET][j][mb] = lds_read_bfrag<T>(abase[mb] + shift + j * 32);
 #pragma unroll
-                        for (int mb = 0; mb < 2; ++mb) a[mb] = lds_read_bfrag<T>(abase[mb] + shift + j * 32);
-#pragma unroll
-                        for (int i = 0; i < NB; ++i) {
-                            if (nb0 + wn * NB + i < p.nblk32) {   // wave-uniform
-                                const frag_t b = lds_read_bfrag<T>(bb + (i * KS + j) * FRAGB);
-                                mma_k16(a[0], b, acc[0][i], T());
-                                mma_k16(a[1], b, acc[1][i], T());
-                            }
-                        }
-                    }
-                    ++step;
-                    if (tap + 1 == NTAPS && slab + 1 < nslab) {
-                        __syncthreads();          // everyone is done with this slab of A
-                        stage_A(slab + 1);
-                    }
-                    __syncthreads();              // DMA landed (vmcnt drained) + buffer hand-over
-                }
-            }
+            for (int i = 0; i < NB; ++i) fb[SET][j][i] = lds_read_bfrag<T>(bwave + bufoff + (i * KS + j) * FRAGB);
         }
+    };
+    auto mma_all = [&](auto setc) {
+        constexpr int SET = decltype(setc)::value;
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {   // channel blocks past Cout compute on a duplicate block and are never stored
+                mma_k16(fa[SET][j][0], fb[SET][j][i], acc[0][i], T());
+                mma_k16(fa[SET][j][1], fb[SET][j][i], acc[1][i], T());
+            }
+    };
+
+    // step cursors (all wave-uniform scalars): c1 = step s+1 (fragment prefetch), c3 = step s+3 (weight
+    // loads).  b* = byte offset of the LDS weight buffer of step s+1 / s+2.
+    struct Cur { int slab, kd, kh, kw, tap; };
+    auto advance = [&](Cur& c) -> bool {   // returns true when the cursor enters a new slab
+        ++c.tap;
+        if (++c.kw == KW) { c.kw = 0; if (++c.kh == KH) { c.kh = 0; if (++c.kd == KD) { c.kd = 0; c.tap = 0; ++c.slab; return true; } } }
+        return false;
+    };
+    Cur c1 = {0, 0, 0, 0, 0}, c3 = {0, 0, 0, 0, 0};
+
+    stage_A(0);
+    load_B(0, 0, R);
+    store_B(0, R);
+    advance(c3);
+    if (S > 1) { load_B(c3.slab, c3.tap, R); store_B(BTILE, R); }
+    advance(c3);
+    if (S > 2) load_B(c3.slab, c3.tap, R);
+    advance(c3);                                           // c3 -> step 3
+    __syncthreads();
+    read_frags(std::integral_constant<int, 0>(), 0, 0);
+
+    int b1 = BTILE, b2 = 2 * BTILE;                        // buffers of step s+1, s+2
+    auto step = [&](auto setc, int s_) {
+        constexpr int SET = decltype(setc)::value;
+        const bool new_slab = advance(c1);                 // c1 = coordinates of step s_+1
+        const bool has_next = s_ + 1 < S;
+        if (has_next && !new_slab)
+            read_frags(std::integral_constant<int, SET ^ 1>(), b1, ((c1.kd * HH_ + c1.kh) * HW_ + c1.kw) * PITCH);
+        mma_all(setc);
+        if (s_ + 2 < S) store_B(b2, R);
+        if (s_ + 3 < S) load_B(c3.slab, c3.tap, R);
+        advance(c3);
+        if (has_next && new_slab) {
+            __syncthreads();                              // every wave is done with this slab of A
+            stage_A(c1.slab);
+            __syncthreads();
+            read_frags(std::integral_constant<int, SET ^ 1>(), b1, 0);
+        }
+        __syncthreads();
+        const int nb = (b2 == 2 * BTILE) ? 0 : b2 + BTILE; // rotate the three buffers
+        b1 = b2; b2 = nb;
+    };
+#pragma unroll 1
+    for (int s_ = 0; s_ < S; s_ += 2) {
+        step(std::integral_constant<int, 0>(), s_);
+        if (s_ + 1 < S) step(std::integral_constant<int, 1>(), s_ + 1);
     }
 
     // ---- epilogue
     T* yg = (T*)p.y;
     const T* rg = (const T*)p.res;
+    if (ES == 2 && p.vec_epi) {
+        // 16-bit outputs: transpose the accumulators through LDS (fp32, 128 pixels at a time) so that
+        // every lane stores 16 contiguous bytes (8 channels of one pixel): 8x fewer store instructions
+        // than the accumulator layout allows (2 B per lane, 64 B runs) and whole-line writes.
+        constexpr int BN = NBT * 32, G = BN / 8;
+        float* ot = (float*)lds;
+        float sc[NB], sh[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int co = min((nb0 + wn * NB + i) * 32 + (lane & 31), p.Cout - 1);
+            sc[i] = p.scale ? p.scale[co] : 1.f;
+            sh[i] = p.shift ? p.shift[co] : 0.f;
+        }
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            if (mb) __syncthreads();                      // previous half has been read out
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ot[(wm * 32 + cd_row(r, lane)) * BN + (wn * NB + i) * 32 + (lane & 31)] = acc[mb][i][r] * sc[i] + sh[i];
+            __syncthreads();
+            for (int idx = tid; idx < 128 * G; idx += 512) {
+                const int row = idx / G, g = idx % G;
+                const int mm = (row >> 5) * 64 + mb * 32 + (row & 31);
+                const int oh = h0 + (mm >> TWL), ow = w0 + (mm & (TW - 1));
+                const int co = nb0 * 32 + g * 8;
+                if (oh < p.H && ow < p.W && co < p.Cout) {
+                    const size_t opix = (((size_t)n * p.D + d) * p.H + oh) * p.W + ow;
+                    const f32x4 lo = *(const f32x4*)(ot + row * BN + g * 8);
+                    const f32x4 hi = *(const f32x4*)(ot + row * BN + g * 8 + 4);
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if (rg) {
+                        const u16x8 rv = *(const u16x8*)(rg + opix * p.r_cstride + p.r_coff + co);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += elem<T>::from_bits16(rv[e]);
+                    }
+                    u16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = elem<T>::bits16(p.relu ? fmaxf(v[e], 0.f) : v[e]);
+                    *(u16x8*)(yg + opix * p.y_cstride + p.y_coff + co) = o;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int nbg = nb0 + wn * NB + i;
@@ -686,7 +788,7 @@ struct ConvPlan { bool ok, flat, wide; int impl, NB, tiles_h, tiles_w; long long
 static int pick_nb_tap(int nblk32, long long mtiles) {
     int best = 1;
     double best_cost = -1;
-    for (int nb = 4; nb >= 1; --nb) {
+    for (int nb = 3; nb >= 1; --nb) {   // 2 fragment sets + 2*nb accumulators must fit 256 VGPRs: nb <= 3
         const long long groups = ceil_div(nblk32, 2 * nb);
         const long long wgs = groups * mtiles;
         // one 512-thread workgroup per CU: rounds of 256; per-workgroup time ~ 2*nb MFMA units + fixed part
@@ -723,7 +825,9 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
     const long long t16 = (long long)ceil_div(d->H, 16) * ceil_div(d->W, 16);
     const long long t32 = (long long)ceil_div(d->H, 8) * ceil_div(d->W, 32);
     const long long mt256 = (long long)d->N * d->D * (t32 < t16 ? t32 : t16);
-    const bool use_tap = ov == 1 || (ov != 0 && mt256 * ceil_div(nblk32, 2) >= 64);
+    // small-Cin / few-tile problems stay on the 4-wave kernel (measured: tap wins from Cin >= 64, or
+    // Cin >= 32 on the large maps)
+    const bool use_tap = ov == 1 || (ov != 0 && (d->Cin >= 64 || (d->Cin >= 32 && mt256 >= 256)));
     if (use_tap) {
         pl.impl = 1;
         pl.wide = t32 < t16;
@@ -749,8 +853,7 @@ static int launch_tap(const ConvParams& p, int NB, dim3 grid, step_stream_t stre
     switch (NB) {
         case 1: STEP_LAUNCH((conv_tap_kernel<T, TWL, 1, KD, KH, KW>), grid, dim3(512), stream, p); break;
         case 2: STEP_LAUNCH((conv_tap_kernel<T, TWL, 2, KD, KH, KW>), grid, dim3(512), stream, p); break;
-        case 3: STEP_LAUNCH((conv_tap_kernel<T, TWL, 3, KD, KH, KW>), grid, dim3(512), stream, p); break;
-        default: STEP_LAUNCH((conv_tap_kernel<T, TWL, 4, KD, KH, KW>), grid, dim3(512), stream, p); break;
+        default: STEP_LAUNCH((conv_tap_kernel<T, TWL, 3, KD, KH, KW>), grid, dim3(512), stream, p); break;
     }
     return STEP_LAUNCH_CHECK();
 }
@@ -827,6 +930,8 @@ int step_conv_forward(const step_conv_desc* d, const void* x, const void* w_pack
     p.tiles_h = p.tiles_w = 0;
     p.nchunks = ceil_div(d->Cin, CK);
     p.nchunks32 = p.nchunks;
+    p.vec_epi = (d->y_cstride % 8 == 0) && (d->y_coff % 8 == 0) && (d->Cout % 8 == 0) && (((uintptr_t)y) % 16 == 0) &&
+                (!res || ((d->res_cstride % 8 == 0) && (d->res_coff % 8 == 0) && (((uintptr_t)res) % 16 == 0)));
     p.nblk32 = ceil_div(d->Cout, 32);
     p.Mtot = (long long)d->N * d->D * d->H * d->W;
     switch (d->dtype) {

@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--dtype", type=int, default=_capi.BF16)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--only", default="", help="comma list of layer names (skips stem/pool)")
+    ap.add_argument("--custom", action="append", default=[], help="name,Cin,Cout,k,D,H,W (repeatable)")
     a = ap.parse_args()
     L = _lib.lib()
     dt, tdt = a.dtype, TORCH_DT[a.dtype]
@@ -49,6 +51,17 @@ def main():
     st = _lib.stream_ptr()
     B = a.batch
     tot_ms, tot_gf = 0.0, 0.0
+    only = set(x for x in a.only.split(",") if x)
+    if a.custom:
+        cl = []
+        for c in a.custom:
+            f = c.split(",")
+            cl.append((f[0],) + tuple(int(v) for v in f[1:]))
+        run_layers(L, dt, tdt, dev, st, B, a, cl)
+        return
+    if only:
+        run_layers(L, dt, tdt, dev, st, B, a, [l for l in LAYERS if l[0] in only])
+        return
     # stem
     x = (torch.rand(B, 32, 3, 224, 224, device=dev) * 2 - 1).to(tdt)
     w = torch.randn(64, 3, 7, 7, 7, device=dev) * 0.03
@@ -68,7 +81,11 @@ def main():
     byts = (y.numel() + y2.numel()) * y.element_size()
     print("%-8s %8.3f ms %8.1f GB/s" % ("pool2a", ms, byts / ms / 1e6))
     tot_ms += ms
-    for name, ci, co, k, D, H, W in LAYERS:
+    run_layers(L, dt, tdt, dev, st, B, a, LAYERS, tot_ms, tot_gf)
+
+
+def run_layers(L, dt, tdt, dev, st, B, a, layers, tot_ms=0.0, tot_gf=0.0):
+    for name, ci, co, k, D, H, W in layers:
         x = torch.randn(B, D, H, W, ci, device=dev).to(tdt)
         w = torch.randn(co, ci, k, k, k, device=dev) * (1.0 / (ci * k ** 3) ** 0.5)
         wp = torch.empty(L.step_conv_packed_elems(co, ci, k, k, k), dtype=tdt, device=dev)
