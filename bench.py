@@ -112,7 +112,6 @@ def roofline(net, x, dtype_name):
     total_ms = sum(a[1] for a in agg.values())
     name, (cnt, ms, flops, nbytes) = max(agg.items(), key=lambda kv: kv[1][1])
     avg_ms = ms / cnt
-    tf = (flops / cnt) / (avg_ms * 1e-3) / 1e12
     hbm_time = (nbytes / cnt) / (PEAK_HBM_GBS * 1e9)
     mfma_time = (flops / cnt) / (PEAK[dtype_name] * 1e12)
     traffic, tsrc = None, None
@@ -124,12 +123,18 @@ def roofline(net, x, dtype_name):
                 traffic, tsrc = tj.get("hbm_bytes_per_launch"), tj.get("source")
         except Exception:
             pass
-    out = {"kernel": name, "bound": "mfma" if mfma_time >= hbm_time else "hbm",
-           "achieved": round(tf, 2), "peak": PEAK[dtype_name], "unit": "TFLOP/s", "frac": round(tf / PEAK[dtype_name], 4),
-           "traffic": traffic, "launches_per_step": cnt // 3, "avg_launch_ms": round(avg_ms, 4),
-           "share_of_gpu_time": round(ms / total_ms, 3),
-           "algorithmic_gflop_per_launch": round(flops / cnt / 1e9, 3),
-           "algorithmic_mb_per_launch": round(nbytes / cnt / 1e6, 3)}
+    if mfma_time >= hbm_time:      # matrix-bound kernel: algorithmic FLOP/s against the dense MFMA peak
+        ach = (flops / cnt) / (avg_ms * 1e-3) / 1e12
+        out = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK[dtype_name], "unit": "TFLOP/s",
+               "frac": round(ach / PEAK[dtype_name], 4)}
+    else:                          # streaming kernel: algorithmic bytes/s against the HBM peak
+        ach = (nbytes / cnt) / (avg_ms * 1e-3) / 1e9
+        out = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+               "frac": round(ach / PEAK_HBM_GBS, 4)}
+    out.update({"traffic": traffic, "launches_per_step": cnt // 3, "avg_launch_ms": round(avg_ms, 4),
+                "share_of_gpu_time": round(ms / total_ms, 3),
+                "algorithmic_gflop_per_launch": round(flops / cnt / 1e9, 3),
+                "algorithmic_mb_per_launch": round(nbytes / cnt / 1e6, 3)})
     if tsrc:
         out["traffic_source"] = tsrc
     table = sorted(((n_, a[1] / 3, a[0] // 3, a[2] / max(a[1], 1e-9) / 1e9) for n_, a in agg.items()), key=lambda r: -r[1])   # TFLOP/s = flops / ms / 1e9

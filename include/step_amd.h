@@ -131,6 +131,13 @@ typedef struct step_conv_desc {
     int y_cstride, y_coff;
     int res_cstride, res_coff; /* used when res != NULL */
     int relu;
+    /* optional second destination (1x1x1 convs only): output channels [split, Cout) are written to y2 at
+     * channel (co - split) + y2_coff of a [N,D,H,W,y2_cstride] buffer instead of y.  split = 0 => unused.
+     * This is how the three 1x1x1 convs of an Inception block that read the same input (branch_0 and the
+     * two bottlenecks, i3dpt.py:133-148) run as ONE GEMM: branch_0 lands in the block's output slice, the
+     * bottlenecks in the scratch buffer the 3x3x3 convs read. */
+    int split;
+    int y2_cstride, y2_coff;
 } step_conv_desc;
 
 /* number of ELEMENTS (of dtype) of the packed weight for a conv [Cout,Cin,kd,kh,kw] */
@@ -142,7 +149,7 @@ STEP_API size_t step_conv_packed_elems(int Cout, int Cin, int kd, int kh, int kw
 STEP_API int step_conv_pack_weight(const float* w, int Cout, int Cin, int kd, int kh, int kw, int dtype,
                                    const int32_t* perm_c, void* packed, step_stream_t stream);
 STEP_API int step_conv_forward(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale,
-                               const float* shift, const void* res, void* y, step_stream_t stream);
+                               const float* shift, const void* res, void* y, void* y2, step_stream_t stream);
 
 /* Diagnostic: the name (as rocprofv3 prints it) of the kernel instantiation step_conv_forward launches
  * for this descriptor -- lets bench.py attribute time and algorithmic work to profiler rows. */

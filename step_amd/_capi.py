@@ -4,7 +4,7 @@ import ctypes as C
 
 F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 vp, fp, ip, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # raw device addresses
 i, f, ll, sz = C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -14,7 +14,7 @@ class ConvDesc(C.Structure):
     """struct step_conv_desc (include/step_amd.h)"""
     _fields_ = [(n, C.c_int) for n in (
         "dtype", "N", "D", "H", "W", "Cin", "Cout", "kd", "kh", "kw", "x_cstride", "x_coff", "y_cstride", "y_coff",
-        "res_cstride", "res_coff", "relu")]
+        "res_cstride", "res_coff", "relu", "split", "y2_cstride", "y2_coff")]
 
 
 SIGNATURES = {
@@ -28,7 +28,7 @@ SIGNATURES = {
     "step_nms_batched": (i, [fp, fp, ip, i, i, f, u8p, vp, vp]),
     "step_conv_packed_elems": (sz, [i, i, i, i, i]),
     "step_conv_pack_weight": (i, [fp, i, i, i, i, i, i, ip, vp, vp]),
-    "step_conv_forward": (i, [C.POINTER(ConvDesc), vp, vp, fp, fp, vp, vp, vp]),
+    "step_conv_forward": (i, [C.POINTER(ConvDesc), vp, vp, fp, fp, vp, vp, vp, vp]),
     "step_conv_kernel_name": (i, [C.POINTER(ConvDesc), C.c_char_p, i]),
     "step_stem_packed_elems": (sz, [i]),
     "step_stem_pack_weight": (i, [fp, i, i, vp, vp]),

@@ -262,6 +262,34 @@ class _MaxPoolFn(torch.autograd.Function):
         return gx.permute(0, 2, 3, 4, 1).to(x.dtype), None, None
 
 
+class _FusedPointwise:
+    """The 1x1x1 convs of an Inception block that read the block input (branch_0, branch_1.0,
+    branch_2.0) as ONE launch: their weights and folded BN affines are concatenated along Cout and the
+    kernel's two-destination epilogue sends the first unit's channels to `out` and the rest to `out2`
+    (the input is read once instead of three times; 2 launches fewer per block).  Inference only."""
+
+    def __init__(self, units):
+        self.units = units
+        self._cache = {}
+
+    def __call__(self, x, out, out2):
+        us = self.units
+        key = (x.dtype, us[0].conv3d.weight.device)
+        ver = tuple(v for u in us for v in _ver(u.conv3d.weight, u.batch3d.weight, u.batch3d.bias, u.batch3d.running_mean,
+                                                u.batch3d.running_var))
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                w = torch.cat([u.conv3d.weight for u in us], 0)
+                aff = [u._unit.affine() for u in us]
+                scale = torch.cat([a[0] for a in aff]).contiguous()
+                shift = torch.cat([a[1] for a in aff]).contiguous()
+                hit = (ver, ops.pack_conv_weight(w, x.dtype), scale, shift, w.shape[0], us[0].conv3d.weight.shape[0])
+            self._cache[key] = hit
+        _, packed, scale, shift, cout, split = hit
+        ops.conv_forward(x, packed, cout, (1, 1, 1), scale, shift, True, None, out, out2, split)
+
+
 class Mixed(nn.Module):
     """Inception block; the four branches write channel slices of one buffer (order b0,b1,b2,b3)."""
 
@@ -273,6 +301,7 @@ class Mixed(nn.Module):
         self.branch_2 = nn.Sequential(Unit3D(in_channels, oc[3]), Unit3D(oc[3], oc[4], (3, 3, 3)))
         self.branch_3 = nn.Sequential(MaxPoolTF((3, 3, 3), (1, 1, 1)), Unit3D(in_channels, oc[5]))
         self.out_channels = oc[0] + oc[2] + oc[4] + oc[5]
+        self._fused = _FusedPointwise((self.branch_0, self.branch_1[0], self.branch_2[0]))
 
     def forward(self, x, out=None):
         oc = self.oc
@@ -289,11 +318,10 @@ class Mixed(nn.Module):
         if out is None:
             out = torch.empty((N, D, H, W, self.out_channels), dtype=x.dtype, device=x.device)
         c0, c1, c2 = oc[0], oc[0] + oc[2], oc[0] + oc[2] + oc[4]
-        self.branch_0(x, out=out[..., :c0])
-        # the two bottleneck 1x1x1 outputs share one scratch buffer; the 3x3x3 convs read its slices
+        # branch_0 and the two bottleneck 1x1x1 convs: one launch; the bottleneck outputs share one
+        # scratch buffer whose slices the 3x3x3 convs read
         t = torch.empty((N, D, H, W, oc[1] + oc[3]), dtype=x.dtype, device=x.device)
-        self.branch_1[0](x, out=t[..., :oc[1]])
-        self.branch_2[0](x, out=t[..., oc[1]:])
+        self._fused(x, out[..., :c0], t)
         self.branch_1[1](t[..., :oc[1]], out=out[..., c0:c1])
         self.branch_2[1](t[..., oc[1]:], out=out[..., c1:c2])
         p = self.branch_3[0](x)

@@ -33,7 +33,8 @@ namespace step {
 constexpr int CK = 32;  // channels per LDS slab (two k16 MFMA steps)
 
 struct ConvParams {
-    const void* x; const void* w; const float* scale; const float* shift; const void* res; void* y;
+    const void* x; const void* w; const float* scale; const float* shift; const void* res; void* y; void* y2;
+    int split, y2_cstride, y2_coff;
     int N, D, H, W, Cin, Cout;
     int x_cstride, x_coff, y_cstride, y_coff, r_cstride, r_coff;
     int relu;
@@ -258,7 +259,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                     float v = acc[i][r] * sc + sh;
                     if (rg) v += elem<T>::to_f32(rg[opix * p.r_cstride + p.r_coff + co]);
                     if (p.relu) v = fmaxf(v, 0.f);
-                    yg[opix * p.y_cstride + p.y_coff + co] = elem<T>::from_f32(v);
+                    if (p.split > 0 && co >= p.split)
+                        ((T*)p.y2)[opix * p.y2_cstride + p.y2_coff + (co - p.split)] = elem<T>::from_f32(v);
+                    else
+                        yg[opix * p.y_cstride + p.y_coff + co] = elem<T>::from_f32(v);
                 }
             }
         }
@@ -1134,16 +1138,24 @@ int step_conv_pack_weight(const float* w, int Cout, int Cin, int kd, int kh, int
 }
 
 int step_conv_forward(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale,
-                      const float* shift, const void* res, void* y, step_stream_t stream) {
+                      const float* shift, const void* res, void* y, void* y2, step_stream_t stream) {
     if (!d) return STEP_E_NULL;
     if (d->N < 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return STEP_E_SHAPE;
-    if (d->x_coff < 0 || d->x_coff + d->Cin > d->x_cstride || d->y_coff < 0 || d->y_coff + d->Cout > d->y_cstride)
+    const int split = (d->split > 0 && d->split < d->Cout) ? d->split : 0;
+    const int cout_y = split ? split : d->Cout;
+    if (d->x_coff < 0 || d->x_coff + d->Cin > d->x_cstride || d->y_coff < 0 || d->y_coff + cout_y > d->y_cstride)
         return STEP_E_SHAPE;
+    if (split) {
+        if (!(d->kd == 1 && d->kh == 1 && d->kw == 1)) return STEP_E_UNSUPPORTED;
+        if (!y2) return STEP_E_NULL;
+        if (d->y2_coff < 0 || d->y2_coff + (d->Cout - split) > d->y2_cstride) return STEP_E_SHAPE;
+    }
     if (res && (d->res_coff < 0 || d->res_coff + d->Cout > d->res_cstride)) return STEP_E_SHAPE;
     if (d->N == 0) return STEP_OK;
     if (!x || !w_packed || !y) return STEP_E_NULL;
     ConvParams p;
-    p.x = x; p.w = w_packed; p.scale = scale; p.shift = shift; p.res = res; p.y = y;
+    p.x = x; p.w = w_packed; p.scale = scale; p.shift = shift; p.res = res; p.y = y; p.y2 = y2;
+    p.split = split; p.y2_cstride = d->y2_cstride; p.y2_coff = d->y2_coff;
     p.N = d->N; p.D = d->D; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
     p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
     p.r_cstride = d->res_cstride; p.r_coff = d->res_coff;
@@ -1218,6 +1230,6 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
 }
 
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 1; }
+int step_abi_version(void) { return 2; }
 
 }  // extern "C"

@@ -98,6 +98,62 @@ __global__ void maxpool3d_tf_kernel(const T* __restrict__ x, T* __restrict__ y, 
     }
 }
 
+// 3x3x3, stride 1, TF-SAME (pad 1 each side, zero-VALUED) max pool -- the `branch_3` pool of every
+// Inception block (models/i3dpt.py:151-155).  A thread owns one (n, d, h, 16-byte channel vector) row
+// and slides along w: the max over the 9 (d+-1, h+-1) neighbours of column w is computed once and
+// reused by the three outputs it belongs to, so an output costs 9 vector loads instead of 27.
+template <typename T>
+__global__ void maxpool333_s1_kernel(const T* __restrict__ x, T* __restrict__ y, PoolParams p, long long total) {
+    constexpr int V = elem<T>::VEC;
+    typedef typename Vec16<T, V>::raw raw;
+    const int CV = p.C / V;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const int cv = (int)(idx % CV);
+        long long q = idx / CV;
+        const int h = (int)(q % p.H); q /= p.H;
+        const int d = (int)(q % p.D);
+        const int n = (int)(q / p.D);
+        // column max over (d-1..d+1, h-1..h+1) at a given w; out-of-range rows/frames are the zero pad
+        auto colmax = [&](int w, float (&m)[V]) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) m[i] = -FLT_MAX;
+            if (w < 0 || w >= p.W) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) m[i] = 0.f;     // the whole column lies in the pad
+                return;
+            }
+#pragma unroll
+            for (int a = -1; a <= 1; ++a)
+#pragma unroll
+                for (int b = -1; b <= 1; ++b) {
+                    const int id = d + a, ih = h + b;
+                    if (id >= 0 && id < p.D && ih >= 0 && ih < p.H) {
+                        float f[V];
+                        Vec16<T, V>::unpack(*(const raw*)(x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + w) * p.x_cstride + p.x_coff + cv * V), f);
+#pragma unroll
+                        for (int i = 0; i < V; ++i) m[i] = fmaxf(m[i], f[i]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < V; ++i) m[i] = fmaxf(m[i], 0.f);
+                    }
+                }
+        };
+        float m0[V], m1[V], m2[V];
+        colmax(-1, m0);
+        colmax(0, m1);
+        for (int w = 0; w < p.W; ++w) {
+            colmax(w + 1, m2);
+            float o[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) o[i] = fmaxf(fmaxf(m0[i], m1[i]), m2[i]);
+            *(raw*)(y + ((((size_t)n * p.D + d) * p.H + h) * p.W + w) * p.y_cstride + p.y_coff + cv * V) = Vec16<T, V>::pack(o);
+#pragma unroll
+            for (int i = 0; i < V; ++i) { m0[i] = m1[i]; m1[i] = m2[i]; }
+        }
+    }
+}
+
 template <typename T>
 __global__ void avgpool_hw_kernel(const T* __restrict__ x, T* __restrict__ y, int ND, int H, int W, int C, int kh,
                                   int kw, long long total) {
@@ -164,6 +220,12 @@ template <typename T>
 static int maxpool_t(const void* x, void* y, const PoolParams& p, step_stream_t stream) {
     constexpr int V = elem<T>::VEC;
     if (p.C % V || p.x_cstride % V || p.x_coff % V || p.y_cstride % V || p.y_coff % V) return STEP_E_ALIGN;
+    if (p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1) {
+        const long long rows = (long long)p.N * p.D * p.H * (p.C / V);
+        if (rows == 0) return STEP_OK;
+        STEP_LAUNCH((maxpool333_s1_kernel<T>), dim3(flat_grid(rows, 256)), dim3(256), stream, (const T*)x, (T*)y, p, rows);
+        return STEP_LAUNCH_CHECK();
+    }
     long long total = (long long)p.N * p.Do * p.Ho * p.Wo * (p.C / V);
     if (total == 0) return STEP_OK;
     STEP_LAUNCH((maxpool3d_tf_kernel<T>), dim3(flat_grid(total, 256)), dim3(256), stream, (const T*)x, (T*)y, p, total);

@@ -104,18 +104,20 @@ def pack_stem_weight(w, dtype):
     return out
 
 
-def conv_forward(x, w_packed, Cout, k, scale=None, shift=None, relu=True, res=None, out=None):
+def conv_forward(x, w_packed, Cout, k, scale=None, shift=None, relu=True, res=None, out=None, out2=None, split=0):
     """x: channels-last [N,D,H,W,Cin] (may be a channel slice); out: optional channel slice to write
-    into (same N,D,H,W, Cout channels); returns out."""
+    into (same N,D,H,W, Cout channels); returns out.  With split > 0 (1x1x1 only) output channels
+    [0, split) go to `out` and [split, Cout) to `out2`."""
     L = _lib.lib()
     N, D, H, W, Cin = x.shape
     xcs = _chan_slice(x)
     if out is None:
-        out = torch.empty((N, D, H, W, Cout), dtype=x.dtype, device=x.device)
+        out = torch.empty((N, D, H, W, split if split else Cout), dtype=x.dtype, device=x.device)
     ycs = _chan_slice(out)
     d = _capi.ConvDesc(dtype=_dt(x), N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2],
                        x_cstride=xcs, x_coff=0, y_cstride=ycs, y_coff=0,
-                       res_cstride=(_chan_slice(res) if res is not None else 0), res_coff=0, relu=int(bool(relu)))
+                       res_cstride=(_chan_slice(res) if res is not None else 0), res_coff=0, relu=int(bool(relu)),
+                       split=int(split), y2_cstride=(_chan_slice(out2) if out2 is not None else 0), y2_coff=0)
     prof = _NOPROF
     if PROFILE is not None:
         buf = ctypes.create_string_buffer(256)
@@ -125,7 +127,7 @@ def conv_forward(x, w_packed, Cout, k, scale=None, shift=None, relu=True, res=No
                      (pix * (Cin + Cout) + Cout * Cin * k[0] * k[1] * k[2]) * _ES[x.dtype])
     with prof:
         _capi.check(L.step_conv_forward(ctypes.byref(d), _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift),
-                                        _lib.dptr(res), _lib.dptr(out), _lib.stream_ptr(x.device)), "step_conv_forward")
+                                        _lib.dptr(res), _lib.dptr(out), _lib.dptr(out2), _lib.stream_ptr(x.device)), "step_conv_forward")
     return out
 
 
@@ -141,7 +143,9 @@ def stem_forward(x, w_packed, Cout, scale, shift, out=None):
     prof = _NOPROF
     if PROFILE is not None:
         pix = N * To * Ho * Wo
-        prof = _Prof("void step::stem_igemm_kernel<%s, 2>(step::StemParams)" % _TNAME[x.dtype], 2.0 * pix * Cout * 1029,
+        kname = "void step::stem_igemm_kernel<float, 2>(step::StemParams)" if x.dtype == torch.float32 else \
+            "void step::stem_tap_kernel<%s>(step::StemParams)" % _TNAME[x.dtype]
+        prof = _Prof(kname, 2.0 * pix * Cout * 1029,
                      (x.numel() + pix * Cout + Cout * 1029) * _ES[x.dtype])
     with prof:
         _capi.check(L.step_stem_forward(_dt(x), _lib.dptr(x), N, T, H, W, _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift),
@@ -161,7 +165,8 @@ def maxpool_tf(x, k, s, out=None):
                            L.step_pool_out_size(W, k[2], s[2]), C), dtype=x.dtype, device=x.device)
     prof = _NOPROF
     if PROFILE is not None:
-        prof = _Prof("void step::maxpool3d_tf_kernel<%s>(%s const*, %s*, step::PoolParams, long long)" % ((_TNAME[x.dtype],) * 3),
+        kn = "maxpool333_s1_kernel" if (tuple(k) == (3, 3, 3) and tuple(s) == (1, 1, 1)) else "maxpool3d_tf_kernel"
+        prof = _Prof("void step::%s<%s>(%s const*, %s*, step::PoolParams, long long)" % ((kn,) + (_TNAME[x.dtype],) * 3),
                      0.0, (x.numel() + out.numel()) * _ES[x.dtype])
     with prof:
         _capi.check(L.step_maxpool3d_tf(_dt(x), _lib.dptr(x), N, D, H, W, C, _chan_slice(x), 0, k[0], k[1], k[2], s[0], s[1], s[2],

@@ -110,11 +110,11 @@ def run_conv(bk, x, w, scale, shift, dt, relu=True, res=None, x_pad=(0, 0), y_pa
     wp = pack_weight(bk, w, dt)
     d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=w.shape[2], kh=w.shape[3], kw=w.shape[4],
                        x_cstride=xb.shape[-1], x_coff=x_pad[0], y_cstride=y_pad[0] + Cout + y_pad[1], y_coff=y_pad[0],
-                       res_cstride=Cout, res_coff=0, relu=int(relu))
+                       res_cstride=Cout, res_coff=0, relu=int(relu), split=0, y2_cstride=0, y2_coff=0)
     re = bk.dev(None if res is None else encode(cl(res), dt))
     sc = bk.dev(None if scale is None else np.ascontiguousarray(scale, np.float32))
     sh = bk.dev(None if shift is None else np.ascontiguousarray(shift, np.float32))
-    rc = bk.lib.step_conv_forward(ctypes.byref(d), xe.ptr, wp.ptr, sc.ptr, sh.ptr, re.ptr, yb.ptr, bk.stream)
+    rc = bk.lib.step_conv_forward(ctypes.byref(d), xe.ptr, wp.ptr, sc.ptr, sh.ptr, re.ptr, yb.ptr, None, bk.stream)
     assert rc == 0, rc
     y = decode(yb.get(), dt)
     assert not y[..., :y_pad[0]].any() and not y[..., y_pad[0] + Cout:].any()
@@ -390,6 +390,35 @@ def case_conv_golden_units(bk, golden):
         assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
 
 
+def case_conv_split_two_destinations(bk, golden):
+    """1x1x1 conv whose output channels [0,split) and [split,Cout) land in two different buffers."""
+    rs = np.random.RandomState(13)
+    N, Cin, D, H, W = 2, 48, 2, 5, 7
+    co_a, co_b = 40, 56                      # split inside a 32-channel block on purpose
+    x = rs.randn(N, Cin, D, H, W).astype(np.float32)
+    w = (rs.randn(co_a + co_b, Cin, 1, 1, 1) / 7).astype(np.float32)
+    scale = (1 + 0.1 * rs.randn(co_a + co_b)).astype(np.float32)
+    shift = (0.2 * rs.randn(co_a + co_b)).astype(np.float32)
+    for dt in (F32, BF16):
+        ref = ref_conv(x, w, scale, shift, dt)
+        xe = bk.dev(encode(cl(x), dt))
+        wp = pack_weight(bk, w, dt)
+        ya = bk.dev(np.zeros((N, D, H, W, 64), NP_DT[dt]))     # slice [8, 48) of a 64-wide buffer
+        yb = bk.dev(np.zeros((N, D, H, W, 72), NP_DT[dt]))     # slice [16, 72)
+        d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=co_a + co_b, kd=1, kh=1, kw=1, x_cstride=Cin, x_coff=0,
+                           y_cstride=64, y_coff=8, res_cstride=0, res_coff=0, relu=1, split=co_a, y2_cstride=72, y2_coff=16)
+        sc, sh = bk.dev(scale), bk.dev(shift)
+        assert bk.lib.step_conv_forward(ctypes.byref(d), xe.ptr, wp.ptr, sc.ptr, sh.ptr, None, ya.ptr, yb.ptr, bk.stream) == 0
+        a, b = decode(ya.get(), dt), decode(yb.get(), dt)
+        assert not a[..., :8].any() and not a[..., 48:].any() and not b[..., :16].any()
+        got = np.concatenate([uncl(a[..., 8:48]), uncl(b[..., 16:72])], 1)
+        assert np.abs(got - ref).max() / np.abs(ref).max() < tol(dt)
+    # a 3x3x3 conv refuses a split
+    d = _capi.ConvDesc(dtype=F32, N=1, D=1, H=4, W=4, Cin=8, Cout=64, kd=3, kh=3, kw=3, x_cstride=8, x_coff=0, y_cstride=32,
+                       y_coff=0, res_cstride=0, res_coff=0, relu=1, split=32, y2_cstride=32, y2_coff=0)
+    assert bk.lib.step_conv_forward(ctypes.byref(d), xe.ptr, wp.ptr, None, None, None, ya.ptr, yb.ptr, bk.stream) == -4
+
+
 def case_pack_weight_perm_folds_flatten_order(bk, golden):
     # Linear over an NCHW-flattened feature (c*HW+hw) evaluated on an NHWC-flattened one (hw*C+c)
     rs = np.random.RandomState(12)
@@ -402,8 +431,8 @@ def case_pack_weight_perm_folds_flatten_order(bk, golden):
     x = bk.dev(np.ascontiguousarray(np.transpose(feat, (0, 2, 1))).reshape(M, 1, 1, 1, C * HW))
     y = bk.dev(np.zeros((M, 1, 1, 1, O), np.float32))
     d = _capi.ConvDesc(dtype=0, N=M, D=1, H=1, W=1, Cin=C * HW, Cout=O, kd=1, kh=1, kw=1, x_cstride=C * HW, x_coff=0,
-                       y_cstride=O, y_coff=0, res_cstride=0, res_coff=0, relu=0)
-    assert bk.lib.step_conv_forward(ctypes.byref(d), x.ptr, wp.ptr, None, None, None, y.ptr, bk.stream) == 0
+                       y_cstride=O, y_coff=0, res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)
+    assert bk.lib.step_conv_forward(ctypes.byref(d), x.ptr, wp.ptr, None, None, None, y.ptr, None, bk.stream) == 0
     assert np.abs(y.get().reshape(M, O) - ref).max() < 1e-5
 
 

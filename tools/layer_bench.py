@@ -94,8 +94,8 @@ def run_layers(L, dt, tdt, dev, st, B, a, layers, tot_ms=0.0, tot_gf=0.0):
         sh = torch.zeros(co, device=dev)
         y = torch.empty(B, D, H, W, co, dtype=tdt, device=dev)
         d = _capi.ConvDesc(dtype=dt, N=B, D=D, H=H, W=W, Cin=ci, Cout=co, kd=k, kh=k, kw=k, x_cstride=ci, x_coff=0,
-                           y_cstride=co, y_coff=0, res_cstride=0, res_coff=0, relu=1)
-        ms = time_it(lambda: _capi.check(L.step_conv_forward(ctypes.byref(d), _lib.dptr(x), _lib.dptr(wp), _lib.dptr(sc), _lib.dptr(sh), None, _lib.dptr(y), st), name), a.iters)
+                           y_cstride=co, y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+        ms = time_it(lambda: _capi.check(L.step_conv_forward(ctypes.byref(d), _lib.dptr(x), _lib.dptr(wp), _lib.dptr(sc), _lib.dptr(sh), None, _lib.dptr(y), None, st), name), a.iters)
         gf = 2.0 * B * D * H * W * co * ci * k ** 3 / 1e9
         byts = (x.numel() + y.numel() + wp.numel()) * x.element_size()
         print("%-8s %8.3f ms %8.1f TFLOP/s %8.1f GB/s" % (name, ms, gf / ms, byts / ms / 1e6))
