@@ -1,0 +1,123 @@
+"""step_amd/dist.py -- one-process-per-GPU data parallelism for the STEP hot path.
+
+The reference's only parallelism is nn.DataParallel (one process, per-iteration parameter broadcast,
+scatter/gather, reduce-add to GPU 0) plus manual placement of head i on GPU (i+1) % G
+(train.py:142-148).  Here every rank owns a full replica and its own slice of the clip batch -- every
+tensor on the path is per clip, BN is frozen, so:
+  * inference (BASELINE configs C2, C3, C5): NO collective on the data path; ranks are replicas and
+    clips/s adds up (bench.py);
+  * training (C4): exactly one exchange per step -- the gradient average -- done as a few large
+    flattened all-reduces (RCCL over xGMI; `backend="nccl"` is RCCL on ROCm).  xGMI is point-to-point,
+    7 links per GPU, so a ring all-reduce is per-link bound: buckets are kept large (default 64 MiB) to
+    amortise latency, and the 177.7 MB of fp32 gradients of the full model is 3 buckets.
+The same code runs over gloo on CPU (tests/test_dist_gloo.py).
+"""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend=None):
+    """Initialise the default process group from the torchrun environment (RANK/WORLD_SIZE/MASTER_*)."""
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world == 1:
+        return 0, 1
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    kw = {}
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        kw["device_id"] = torch.device("cuda", local)
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def shard_clips(n_clips, rank, world):
+    """Indices of the clips rank `rank` processes: r, r+world, r+2*world, ...."""
+    return list(range(rank, n_clips, world))
+
+
+def broadcast_parameters(modules, src=0):
+    """Make every replica start from rank `src`'s parameters and buffers (once, at start-up)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for m in modules:
+        for t in list(m.parameters()) + list(m.buffers()):
+            dist.broadcast(t.data, src)
+
+
+def allreduce_gradients(params, bucket_bytes=64 << 20, average=True, weight=None):
+    """Average (or sum) the .grad of `params` over all ranks with a few large flattened all-reduces.
+
+    weight: optional per-rank scalar (e.g. the number of selected tubes on this rank).  When given, the
+    result is sum_r(weight_r * grad_r) / sum_r(weight_r) -- the single-process value of a loss that is a
+    mean over ALL ranks' samples (the reference's masked means are per batch, two_branch.py:312,333)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    world = dist.get_world_size()
+    params = [p for p in params if p.requires_grad]
+    dev = params[0].device if params else torch.device("cpu")
+    scale = None
+    if weight is not None:
+        wsum = torch.tensor([float(weight)], device=dev, dtype=torch.float32)
+        dist.all_reduce(wsum)
+        scale = float(weight) / float(wsum.item())
+    nb = 0
+    bucket, size = [], 0
+
+    def flush():
+        nonlocal bucket, size, nb
+        if not bucket:
+            return
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        if scale is not None:
+            flat.mul_(scale)
+        dist.all_reduce(flat)
+        if scale is None and average:
+            flat.div_(world)
+        off = 0
+        for g in bucket:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        nb += 1
+        bucket, size = [], 0
+
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        g = p.grad
+        if bucket and (g.dtype != bucket[0].dtype or size + g.numel() * g.element_size() > bucket_bytes):
+            flush()
+        bucket.append(g)
+        size += g.numel() * g.element_size()
+    flush()
+    return nb
+
+
+def timed_steps(step_fn, steps, sync=None):
+    """The bench contract: barrier + device sync, `steps` calls, device sync + barrier, MAX over ranks."""
+    sync = sync or (torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None))
+    sync()
+    if dist.is_initialized():
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync()
+    if dist.is_initialized():
+        dist.barrier()
+    sync()
+    el = time.perf_counter() - t0
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return el

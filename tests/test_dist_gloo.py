@@ -1,0 +1,86 @@
+"""The N>1 path on CPU: two gloo ranks (world_size 2).  Checks that clip sharding + the bucketed
+gradient all-reduce reproduce the single-process gradients on the concatenated batch, that the
+weighted form reproduces a global masked mean, and the bench timing reduction (max over ranks)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Conv3d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Flatten(), torch.nn.Linear(4 * 2 * 4 * 4, 5))
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from step_amd import dist as D
+    r, w = D.init("gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(1)
+    clips = torch.randn(6, 3, 2, 4, 4)
+    target = torch.randn(6, 5)
+    mask = torch.tensor([1., 1, 0, 1, 0, 1])
+    model = _model()
+    if rank == 1:                                  # replicas must be made identical by the broadcast
+        for p in model.parameters():
+            p.data.add_(1.0)
+    D.broadcast_parameters([model])
+    idx = D.shard_clips(6, rank, world)
+    assert idx == list(range(rank, 6, world))
+    # (a) plain mean loss: equal shard sizes -> average of rank means == global mean
+    model.zero_grad()
+    ((model(clips[idx]) - target[idx]) ** 2).mean().backward()
+    nb = D.allreduce_gradients(list(model.parameters()), bucket_bytes=256)     # tiny buckets: several all-reduces
+    g_plain = [p.grad.clone() for p in model.parameters()]
+    # (b) masked mean: weight each rank by its mask count
+    model.zero_grad()
+    m = mask[idx]
+    (((model(clips[idx]) - target[idx]) ** 2).mean(1) * m).sum().div(m.sum()).backward()
+    D.allreduce_gradients(list(model.parameters()), weight=float(m.sum()))
+    g_masked = [p.grad.clone() for p in model.parameters()]
+    el = D.timed_steps(lambda: None if rank == 0 else __import__("time").sleep(0.05), 2, sync=lambda: None)
+    if rank == 0:
+        q.put((nb, g_plain, g_masked, el))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gradient_allreduce_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    nb, g_plain, g_masked, el = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    torch.manual_seed(1)
+    clips = torch.randn(6, 3, 2, 4, 4)
+    target = torch.randn(6, 5)
+    mask = torch.tensor([1., 1, 0, 1, 0, 1])
+    model = _model()
+    model.zero_grad()
+    ((model(clips) - target) ** 2).mean().backward()
+    for a, p in zip(g_plain, model.parameters()):
+        assert torch.allclose(a, p.grad, rtol=1e-5, atol=1e-6)
+    model.zero_grad()
+    (((model(clips) - target) ** 2).mean(1) * mask).sum().div(mask.sum()).backward()
+    for a, p in zip(g_masked, model.parameters()):
+        assert torch.allclose(a, p.grad, rtol=1e-5, atol=1e-6)
+    assert nb >= 2                                   # bucketing really split the gradient
+    assert el >= 0.1                                 # max over ranks: rank 1 slept 2 x 50 ms
