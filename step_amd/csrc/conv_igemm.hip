@@ -128,10 +128,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     typedef typename Ld16<T>::type vec16;
     typedef typename frag<T>::type frag_t;
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX * PITCH];
+    constexpr int LDSB = (NPIX * PITCH > 16384) ? NPIX * PITCH : 16384;   // >= the 16 KB epilogue transpose buffer
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDSB];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+#ifdef STEP_EMUL
+    const int wave = tid >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
     const int khalf = lane >> 5;
     const int m = wave * 32 + (lane & 31);
     const int th = m >> TWL, tw = m & (TW - 1);
@@ -162,10 +168,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     const T* xg = (const T*)p.x;
     const T* wg = (const T*)p.w;
 
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-        if (chunk) __syncthreads();  // all waves finished reading the previous slab
-        // ---- stage the 32-channel slab of the halo tile
-        vec16 stage[ITER];
+    // this lane's B-fragment base per channel block (blocks past Cout re-read the last real block; their
+    // accumulators are never stored) -- keeps the inner loop free of branches
+    const T* wb[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) wb[i] = wg + ((size_t)min(nb0 + i, p.nblk32 - 1) * NTAPS * KC16 * 64 + lane) * 8;
+
+    // slab staging through registers: the loads of slab c+1 are issued as soon as slab c is in LDS and
+    // fly during its MFMAs
+    vec16 stage[ITER];
+    auto load_slab = [&](int chunk) {
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int v = tid + it * 256;
@@ -192,6 +204,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
             }
             stage[it] = val;
         }
+    };
+    auto store_slab = [&]() {
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int v = tid + it * 256;
@@ -201,7 +215,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                 *(vec16*)(lds + pix * PITCH + ((slot ^ sw) << 4)) = stage[it];
             }
         }
+    };
+
+    load_slab(0);
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        if (chunk) __syncthreads();  // all waves finished reading the previous slab
+        store_slab();
         __syncthreads();
+        if (chunk + 1 < p.nchunks) load_slab(chunk + 1);
 
         // ---- taps x 2 k16 steps x NB accumulators
 #pragma unroll 1
@@ -217,14 +238,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const frag_t a = lds_read_frag<T>(pb, j, khalf, sw);
-                        const int kc16 = chunk * 2 + j;
+                        const size_t koff = ((size_t)tap * KC16 + chunk * 2 + j) * 512;
 #pragma unroll
                         for (int i = 0; i < NB; ++i) {
-                            if (nb0 + i < p.nblk32) {  // wave-uniform
-                                const T* bp = wg + ((((size_t)(nb0 + i) * NTAPS + tap) * KC16 + kc16) * 64 + lane) * 8;
-                                const frag_t b = load_b_frag<T>(bp);
-                                mma_k16(a, b, acc[i], T());
-                            }
+                            const frag_t b = load_b_frag<T>(wb[i] + koff);
+                            mma_k16(a, b, acc[i], T());
                         }
                     }
                 }
@@ -232,9 +250,60 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         }
     }
 
-    // ---- epilogue: affine (+residual) + ReLU, store channel slice
+    // ---- epilogue: affine (+residual) + ReLU, store channel slice(s)
     T* yg = (T*)p.y;
     const T* rg = (const T*)p.res;
+    if (ES == 2 && p.vec_epi) {
+        // 16-bit outputs: per 32-channel block, transpose the accumulators through LDS (fp32) so that each
+        // lane stores 16 contiguous bytes (8 channels of one pixel) instead of 2.
+        float* ot = (float*)lds;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (nb0 + i >= p.nblk32) break;                       // block-uniform
+            const int cl = min((nb0 + i) * 32 + (lane & 31), p.Cout - 1);
+            const float sc = p.scale ? p.scale[cl] : 1.f;
+            const float sh = p.shift ? p.shift[cl] : 0.f;
+            __syncthreads();                                      // LDS is free (main loop / previous block read out)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[(wave * 32 + cd_row(r, lane)) * 32 + (lane & 31)] = acc[i][r] * sc + sh;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int idx = tid + q * 256;
+                const int row = idx >> 2, g = idx & 3;
+                const int co = (nb0 + i) * 32 + g * 8;
+                bool ok;
+                size_t opix;
+                if (FLAT) {
+                    const long long gm = m0 + row;
+                    ok = gm < p.Mtot;
+                    opix = (size_t)gm;
+                } else {
+                    const int oh = h0 + (row >> TWL), ow = w0 + (row & (TW - 1));
+                    ok = oh < p.H && ow < p.W;
+                    opix = (((size_t)n * p.D + d) * p.H + oh) * p.W + ow;
+                }
+                if (ok && co < p.Cout) {
+                    const f32x4 lo = *(const f32x4*)(ot + row * 32 + g * 8);
+                    const f32x4 hi = *(const f32x4*)(ot + row * 32 + g * 8 + 4);
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if (rg) {
+                        const u16x8 rv = *(const u16x8*)(rg + opix * p.r_cstride + p.r_coff + co);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += elem<T>::from_bits16(rv[e]);
+                    }
+                    u16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = elem<T>::bits16(p.relu ? fmaxf(v[e], 0.f) : v[e]);
+                    if (p.split > 0 && co >= p.split)
+                        *(u16x8*)((T*)p.y2 + opix * p.y2_cstride + p.y2_coff + (co - p.split)) = o;
+                    else
+                        *(u16x8*)(yg + opix * p.y_cstride + p.y_coff + co) = o;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int co = (nb0 + i) * 32 + (lane & 31);
@@ -1164,7 +1233,8 @@ int step_conv_forward(const step_conv_desc* d, const void* x, const void* w_pack
     p.nchunks = ceil_div(d->Cin, CK);
     p.nchunks32 = p.nchunks;
     p.vec_epi = (d->y_cstride % 8 == 0) && (d->y_coff % 8 == 0) && (d->Cout % 8 == 0) && (((uintptr_t)y) % 16 == 0) &&
-                (!res || ((d->res_cstride % 8 == 0) && (d->res_coff % 8 == 0) && (((uintptr_t)res) % 16 == 0)));
+                (!res || ((d->res_cstride % 8 == 0) && (d->res_coff % 8 == 0) && (((uintptr_t)res) % 16 == 0))) &&
+                (!split || ((split % 8 == 0) && (d->y2_cstride % 8 == 0) && (d->y2_coff % 8 == 0) && (((uintptr_t)y2) % 16 == 0)));
     p.nblk32 = ceil_div(d->Cout, 32);
     p.Mtot = (long long)d->N * d->D * d->H * d->W;
     switch (d->dtype) {
