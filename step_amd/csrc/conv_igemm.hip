@@ -32,6 +32,10 @@ namespace step {
 
 constexpr int CK = 32;  // channels per LDS slab (two k16 MFMA steps)
 
+// The packed weight layout is [Cout/32][taps_padded][Cin/16][lane][8]: an odd tap count > 1 is padded with
+// one all-zero tap so that kernels can walk taps two at a time without a tail case.
+__host__ __device__ constexpr int taps_padded(int ntaps) { return (ntaps > 1 && (ntaps & 1)) ? ntaps + 1 : ntaps; }
+
 struct ConvParams {
     const void* x; const void* w; const float* scale; const float* shift; const void* res; void* y; void* y2;
     int split, y2_cstride, y2_coff;
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     // accumulators are never stored) -- keeps the inner loop free of branches
     const T* wb[NB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) wb[i] = wg + ((size_t)min(nb0 + i, p.nblk32 - 1) * NTAPS * KC16 * 64 + lane) * 8;
+    for (int i = 0; i < NB; ++i) wb[i] = wg + ((size_t)min(nb0 + i, p.nblk32 - 1) * taps_padded(NTAPS) * KC16 * 64 + lane) * 8;
 
     // slab staging through registers: the loads of slab c+1 are issued as soon as slab c is in LDS and
     // fly during its MFMAs
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 //     barrier per tap.  Every B fragment read from LDS feeds 2 MFMAs and every A fragment NB MFMAs
 //     (a k16 step costs 2 + NB ds_read_b128 for 2*NB MFMAs), and the weights cross the L2 -> CU
 //     path once per 256 pixels instead of once per 32.
-template <typename T, int TWL, int NB, int KD, int KH, int KW>
+template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS>
 __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
     constexpr int TW = 1 << TWL, TH = 256 >> TWL;
     constexpr int HH_ = TH + KH - 1, HW_ = TW + KW - 1;
@@ -373,10 +377,13 @@ __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
     constexpr int BTILE = NBT * KS * FRAGB;
     constexpr int BVEC = BTILE / 16;      // 16-byte vectors per tap tile
     constexpr int Q = (BVEC + 511) / 512; // vectors per thread per tap
+    constexpr int NTP = taps_padded(NTAPS);                 // packed taps (odd counts carry one zero tap)
+    constexpr int SPS = (TPS == 1) ? NTAPS : NTP / TPS;     // pipeline steps per slab (TPS taps per barrier)
+    constexpr int BSTEP = TPS * BTILE;                      // LDS weight bytes per step
     typedef typename Ld16<T>::type vec16;
     typedef typename frag<T>::type frag_t;
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX * PITCH + 3 * BTILE];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX * PITCH + 3 * BSTEP];
     unsigned char* const ldsA = lds;
     unsigned char* const ldsB = lds + NPIX * PITCH;
 
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
     const int nb0 = blockIdx.y * NBT;
     const int KC16 = p.nchunks32 * 2;
     const int nslab = (p.Cin + CKT - 1) / CKT;
-    const int S = nslab * NTAPS;          // pipeline steps
+    const int S = nslab * SPS;            // pipeline steps
 
     const T* xg = (const T*)p.x;
     const unsigned char* wg = (const unsigned char*)p.w;
@@ -465,29 +472,34 @@ __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
         const int f = v / FRAGV, within = v % FRAGV;
         const int nbl = f / KS, ks = f % KS;
         const int nbg = min(nb0 + nbl, p.nblk32 - 1);
-        wthr[q] = wg + ((size_t)nbg * NTAPS * KC16 + ks) * FRAGB + within * 16;
+        wthr[q] = wg + ((size_t)nbg * taps_padded(NTAPS) * KC16 + ks) * FRAGB + within * 16;
         ldsoff[q] = (tid + q * 512 < BVEC) ? (tid + q * 512) * 16 : -1;
     }
-    auto load_B = [&](int slab_, int tap_, u32x4 (&r)[Q]) {
-        const size_t off = (size_t)(tap_ * KC16 + slab_ * KS) * FRAGB;      // scalar
+    auto load_B = [&](int slab_, int sis_, u32x4 (&r)[TPS * Q]) {         // sis_ = step index within the slab
 #pragma unroll
-        for (int q = 0; q < Q; ++q) r[q] = *(const u32x4*)(wthr[q] + off);
+        for (int tp = 0; tp < TPS; ++tp) {
+            const size_t off = (size_t)((sis_ * TPS + tp) * KC16 + slab_ * KS) * FRAGB;      // scalar
+#pragma unroll
+            for (int q = 0; q < Q; ++q) r[tp * Q + q] = *(const u32x4*)(wthr[q] + off);
+        }
     };
-    auto store_B = [&](int bufoff, const u32x4 (&r)[Q]) {
+    auto store_B = [&](int bufoff, const u32x4 (&r)[TPS * Q]) {
 #pragma unroll
-        for (int q = 0; q < Q; ++q)
-            if (ldsoff[q] >= 0) *(u32x4*)(ldsB + bufoff + ldsoff[q]) = r[q];
+        for (int tp = 0; tp < TPS; ++tp)
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                if (ldsoff[q] >= 0) *(u32x4*)(ldsB + bufoff + tp * BTILE + ldsoff[q]) = r[tp * Q + q];
     };
 
-    // Pipeline (per step s = one tap of one slab):
-    //   weights: ONE register set R and THREE LDS buffers.  During step s, R (tile s+2) is written to
-    //     buffer (s+2)%3 -- last read during step s-1's prefetch -- and re-issued for tile s+3; the
-    //     only vector-memory operations outstanding at its wait are its own (exact vmcnt).
-    //   fragments: two register sets.  The ds_reads of step s+1 (buffer (s+1)%3, complete since the
-    //     barrier that ended step s-1) are issued BEFORE the MFMAs of step s, so LDS latency, the
-    //     weight hand-over and the barrier all hide behind matrix work; one barrier per step.
-    //   A slab switch drains the pipeline once per 27 (9) taps.
-    u32x4 R[Q];
+    // Pipeline.  A STEP = TPS taps of one slab = one barrier; a SLOT = one tap.
+    //   weights: ONE register set R and THREE LDS step-buffers.  During step s, R (step s+2) is written to
+    //     buffer (s+2)%3 -- last read during step s-1 -- and re-issued for step s+3; the only vector-
+    //     memory operations outstanding at its wait are its own (exact vmcnt).
+    //   fragments: two register sets alternating per slot.  The ds_reads of slot u+1 are issued BEFORE
+    //     the MFMAs of slot u (for the first slot of a step they come from the next buffer, complete
+    //     since the previous barrier), so LDS latency, the weight hand-over and the barrier hide behind
+    //     matrix work.  A slab switch drains the pipeline once per slab.
+    u32x4 R[TPS * Q];
     frag_t fa[2][KS][2], fb[2][KS][NB];
 
     const unsigned char* const bwave = ldsB + (wn * NB) * KS * FRAGB + lane * (8 * ES);
@@ -511,53 +523,70 @@ __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
                 mma_k16(fa[SET][j][1], fb[SET][j][i], acc[1][i], T());
             }
     };
-
-    // step cursors (all wave-uniform scalars): c1 = step s+1 (fragment prefetch), c3 = step s+3 (weight
-    // loads).  b* = byte offset of the LDS weight buffer of step s+1 / s+2.
-    struct Cur { int slab, kd, kh, kw, tap; };
-    auto advance = [&](Cur& c) -> bool {   // returns true when the cursor enters a new slab
-        ++c.tap;
-        if (++c.kw == KW) { c.kw = 0; if (++c.kh == KH) { c.kh = 0; if (++c.kd == KD) { c.kd = 0; c.tap = 0; ++c.slab; return true; } } }
-        return false;
+    // LDS byte shift of tap t of the slab (the zero tap of an odd tap count reads tap 0's pixels)
+    auto tap_shift = [&](int t_) {
+        const int tt = (t_ < NTAPS) ? t_ : 0;
+        return (((tt / (KH * KW)) * HH_ + (tt / KW) % KH) * HW_ + tt % KW) * PITCH;
     };
-    Cur c1 = {0, 0, 0, 0, 0}, c3 = {0, 0, 0, 0, 0};
+
+    // (slab, step-in-slab) cursors: c0 = current step, c3 = step + 3 (weight loads)
+    int slab0 = 0, sis0 = 0, slab3 = 0, sis3 = 0;
+    auto adv = [&](int& sl, int& si) { if (++si == SPS) { si = 0; ++sl; } };
 
     stage_A(0);
     load_B(0, 0, R);
     store_B(0, R);
-    advance(c3);
-    if (S > 1) { load_B(c3.slab, c3.tap, R); store_B(BTILE, R); }
-    advance(c3);
-    if (S > 2) load_B(c3.slab, c3.tap, R);
-    advance(c3);                                           // c3 -> step 3
+    adv(slab3, sis3);
+    if (S > 1) { load_B(slab3, sis3, R); store_B(BSTEP, R); }
+    adv(slab3, sis3);
+    if (S > 2) load_B(slab3, sis3, R);
+    adv(slab3, sis3);                                      // -> step 3
     __syncthreads();
     read_frags(std::integral_constant<int, 0>(), 0, 0);
 
-    int b1 = BTILE, b2 = 2 * BTILE;                        // buffers of step s+1, s+2
-    auto step = [&](auto setc, int s_) {
+    int b0 = 0, b1 = BSTEP, b2 = 2 * BSTEP;                // LDS buffers of step s, s+1, s+2
+    int s_ = 0;                                            // current step
+    auto slot = [&](auto setc, auto tpc) {
         constexpr int SET = decltype(setc)::value;
-        const bool new_slab = advance(c1);                 // c1 = coordinates of step s_+1
-        const bool has_next = s_ + 1 < S;
-        if (has_next && !new_slab)
-            read_frags(std::integral_constant<int, SET ^ 1>(), b1, ((c1.kd * HH_ + c1.kh) * HW_ + c1.kw) * PITCH);
-        mma_all(setc);
-        if (s_ + 2 < S) store_B(b2, R);
-        if (s_ + 3 < S) load_B(c3.slab, c3.tap, R);
-        advance(c3);
-        if (has_next && new_slab) {
-            __syncthreads();                              // every wave is done with this slab of A
-            stage_A(c1.slab);
-            __syncthreads();
-            read_frags(std::integral_constant<int, SET ^ 1>(), b1, 0);
+        constexpr int TP = decltype(tpc)::value;           // tap slot within the step
+        constexpr bool LAST = (TP == TPS - 1);
+        bool new_slab = false;
+        if (!LAST) {                                       // next slot: same step, same weight buffer
+            read_frags(std::integral_constant<int, SET ^ 1>(), b0 + (TP + 1) * BTILE, tap_shift(sis0 * TPS + TP + 1));
+        } else {                                           // next slot opens step s+1
+            new_slab = (sis0 + 1 == SPS);
+            if (s_ + 1 < S && !new_slab)
+                read_frags(std::integral_constant<int, SET ^ 1>(), b1, tap_shift((sis0 + 1) * TPS));
         }
-        __syncthreads();
-        const int nb = (b2 == 2 * BTILE) ? 0 : b2 + BTILE; // rotate the three buffers
-        b1 = b2; b2 = nb;
+        mma_all(setc);
+        if (LAST) {
+            if (s_ + 2 < S) store_B(b2, R);
+            if (s_ + 3 < S) load_B(slab3, sis3, R);
+            adv(slab3, sis3);
+            if (s_ + 1 < S && new_slab) {
+                __syncthreads();                          // every wave is done with this slab of A
+                stage_A(slab0 + 1);
+                __syncthreads();
+                read_frags(std::integral_constant<int, SET ^ 1>(), b1, 0);
+            }
+            __syncthreads();
+            const int t0 = b0; b0 = b1; b1 = b2; b2 = t0;  // rotate the three buffers
+            adv(slab0, sis0);
+            ++s_;
+        }
     };
+    if (TPS == 2) {
 #pragma unroll 1
-    for (int s_ = 0; s_ < S; s_ += 2) {
-        step(std::integral_constant<int, 0>(), s_);
-        if (s_ + 1 < S) step(std::integral_constant<int, 1>(), s_ + 1);
+        while (s_ < S) {
+            slot(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+            slot(std::integral_constant<int, 1>(), std::integral_constant<int, TPS - 1>());
+        }
+    } else {
+#pragma unroll 1
+        while (s_ < S) {
+            slot(std::integral_constant<int, 0>(), std::integral_constant<int, TPS - 1>());
+            if (s_ < S) slot(std::integral_constant<int, 1>(), std::integral_constant<int, TPS - 1>());
+        }
     }
 
     // ---- epilogue
@@ -645,12 +674,13 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, const int32_t* _
         const int lane = (int)((idx >> 3) & 63);
         long long q = idx >> 9;
         const int kc16 = (int)(q % KC16); q /= KC16;
-        const int tap = (int)(q % ntaps);
-        const int nb = (int)(q / ntaps);
+        const int ntp = taps_padded(ntaps);
+        const int tap = (int)(q % ntp);
+        const int nb = (int)(q / ntp);
         const int co = nb * 32 + (lane & 31);
         const int ci = kc16 * 16 + (lane >> 5) * 8 + e;
         float v = 0.f;
-        if (co < Cout && ci < Cin) {
+        if (co < Cout && ci < Cin && tap < ntaps) {
             const int cs = perm ? perm[ci] : ci;
             v = w[((size_t)co * Cin + cs) * ntaps + tap];
         }
@@ -1069,7 +1099,7 @@ static int pick_nb(int nblk32, long long mtiles) {
 // attribute time and work to the kernel name rocprofv3 reports).
 //   impl 0: conv_igemm_kernel (4 waves, 128-px tile, weights straight from L2)  -- 1x1x1 and small problems
 //   impl 1: conv_tap_kernel   (8 waves, 256-px tile, weights through an LDS-DMA double buffer)
-struct ConvPlan { bool ok, flat, wide; int impl, NB, tiles_h, tiles_w; long long mtiles; };
+struct ConvPlan { bool ok, flat, wide; int impl, NB, tps, tiles_h, tiles_w; long long mtiles; };
 
 static int pick_nb_tap(int nblk32, long long mtiles) {
     int best = 1;
@@ -1084,17 +1114,17 @@ static int pick_nb_tap(int nblk32, long long mtiles) {
     return best;
 }
 
-static int conv_impl_override() {   // tuning aid: STEP_CONV_IMPL=igemm|tap forces one implementation
+static int conv_impl_override() {   // tuning aid: STEP_CONV_IMPL=igemm|tap|tap2 forces one implementation
     const char* e = getenv("STEP_CONV_IMPL");
     if (!e) return -1;
     if (e[0] == 'i') return 0;
-    if (e[0] == 't') return 1;
+    if (e[0] == 't') return (e[1] && e[2] && e[3] == '2') ? 2 : 1;
     return -1;
 }
 
 static ConvPlan conv_plan(const step_conv_desc* d) {
     ConvPlan pl;
-    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0;
+    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1;
     const int nblk32 = ceil_div(d->Cout, 32);
     const bool k1 = d->kd == 1 && d->kh == 1 && d->kw == 1;
     const bool k333 = d->kd == 3 && d->kh == 3 && d->kw == 3;
@@ -1113,9 +1143,10 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
     const long long mt256 = (long long)d->N * d->D * (t32 < t16 ? t32 : t16);
     // small-Cin / few-tile problems stay on the 4-wave kernel (measured: tap wins from Cin >= 64, or
     // Cin >= 32 on the large maps)
-    const bool use_tap = ov == 1 || (ov != 0 && (d->Cin >= 64 || (d->Cin >= 32 && mt256 >= 256)));
+    const bool use_tap = ov >= 1 || (ov != 0 && (d->Cin >= 64 || (d->Cin >= 32 && mt256 >= 256)));
     if (use_tap) {
         pl.impl = 1;
+        pl.tps = (ov == 1) ? 1 : 2;     // two taps per barrier measured 6-15 % faster than one (STEP_CONV_IMPL=tap forces one)
         pl.wide = t32 < t16;
         pl.tiles_h = pl.wide ? ceil_div(d->H, 8) : ceil_div(d->H, 16);
         pl.tiles_w = pl.wide ? ceil_div(d->W, 32) : ceil_div(d->W, 16);
@@ -1135,11 +1166,19 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
 }
 
 template <typename T, int TWL, int KD, int KH, int KW>
-static int launch_tap(const ConvParams& p, int NB, dim3 grid, step_stream_t stream) {
-    switch (NB) {
-        case 1: STEP_LAUNCH((conv_tap_kernel<T, TWL, 1, KD, KH, KW>), grid, dim3(512), stream, p); break;
-        case 2: STEP_LAUNCH((conv_tap_kernel<T, TWL, 2, KD, KH, KW>), grid, dim3(512), stream, p); break;
-        default: STEP_LAUNCH((conv_tap_kernel<T, TWL, 3, KD, KH, KW>), grid, dim3(512), stream, p); break;
+static int launch_tap(const ConvParams& p, int NB, int tps, dim3 grid, step_stream_t stream) {
+    if (tps == 2) {
+        switch (NB) {
+            case 1: STEP_LAUNCH((conv_tap_kernel<T, TWL, 1, KD, KH, KW, 2>), grid, dim3(512), stream, p); break;
+            case 2: STEP_LAUNCH((conv_tap_kernel<T, TWL, 2, KD, KH, KW, 2>), grid, dim3(512), stream, p); break;
+            default: STEP_LAUNCH((conv_tap_kernel<T, TWL, 3, KD, KH, KW, 2>), grid, dim3(512), stream, p); break;
+        }
+    } else {
+        switch (NB) {
+            case 1: STEP_LAUNCH((conv_tap_kernel<T, TWL, 1, KD, KH, KW, 1>), grid, dim3(512), stream, p); break;
+            case 2: STEP_LAUNCH((conv_tap_kernel<T, TWL, 2, KD, KH, KW, 1>), grid, dim3(512), stream, p); break;
+            default: STEP_LAUNCH((conv_tap_kernel<T, TWL, 3, KD, KH, KW, 1>), grid, dim3(512), stream, p); break;
+        }
     }
     return STEP_LAUNCH_CHECK();
 }
@@ -1155,8 +1194,8 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, step_stream_t s
     if (pl.impl == 1) {
         dim3 grid((unsigned)pl.mtiles, (unsigned)ceil_div(p.nblk32, 2 * pl.NB));
         if (d->kd == 3)
-            return pl.wide ? launch_tap<T, 5, 3, 3, 3>(p, pl.NB, grid, stream) : launch_tap<T, 4, 3, 3, 3>(p, pl.NB, grid, stream);
-        return pl.wide ? launch_tap<T, 5, 1, 3, 3>(p, pl.NB, grid, stream) : launch_tap<T, 4, 1, 3, 3>(p, pl.NB, grid, stream);
+            return pl.wide ? launch_tap<T, 5, 3, 3, 3>(p, pl.NB, pl.tps, grid, stream) : launch_tap<T, 4, 3, 3, 3>(p, pl.NB, pl.tps, grid, stream);
+        return pl.wide ? launch_tap<T, 5, 1, 3, 3>(p, pl.NB, pl.tps, grid, stream) : launch_tap<T, 4, 1, 3, 3>(p, pl.NB, pl.tps, grid, stream);
     }
     dim3 grid((unsigned)pl.mtiles, (unsigned)ceil_div(p.nblk32, pl.NB));
     if (pl.flat) return launch_nb<T, 4, 1, 1, 1, true>(p, pl.NB, grid, stream);
@@ -1187,7 +1226,7 @@ using namespace step;
 extern "C" {
 
 size_t step_conv_packed_elems(int Cout, int Cin, int kd, int kh, int kw) {
-    return (size_t)ceil_div(Cout, 32) * kd * kh * kw * (ceil_div(Cin, CK) * 2) * 512;
+    return (size_t)ceil_div(Cout, 32) * taps_padded(kd * kh * kw) * (ceil_div(Cin, CK) * 2) * 512;
 }
 
 int step_conv_pack_weight(const float* w, int Cout, int Cin, int kd, int kh, int kw, int dtype, const int32_t* perm,
@@ -1291,8 +1330,8 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
     if (!pl.ok) return STEP_E_UNSUPPORTED;
     const char* t = d->dtype == STEP_F32 ? "float" : (d->dtype == STEP_BF16 ? "step::bf16_t" : "step::f16_t");
     if (pl.impl == 1)
-        snprintf(buf, (size_t)buflen, "void step::conv_tap_kernel<%s, %d, %d, %d, %d, %d>(step::ConvParams)", t,
-                 pl.wide ? 5 : 4, pl.NB, d->kd, d->kh, d->kw);
+        snprintf(buf, (size_t)buflen, "void step::conv_tap_kernel<%s, %d, %d, %d, %d, %d, %d>(step::ConvParams)", t,
+                 pl.wide ? 5 : 4, pl.NB, d->kd, d->kh, d->kw, pl.tps);
     else
         snprintf(buf, (size_t)buflen, "void step::conv_igemm_kernel<%s, %d, %d, %d, %d, %d, %s>(step::ConvParams)", t,
                  pl.flat ? 4 : (pl.wide ? 5 : 4), pl.NB, d->kd, d->kh, d->kw, pl.flat ? "true" : "false");
