@@ -318,15 +318,45 @@ class Mixed(nn.Module):
         if out is None:
             out = torch.empty((N, D, H, W, self.out_channels), dtype=x.dtype, device=x.device)
         c0, c1, c2 = oc[0], oc[0] + oc[2], oc[0] + oc[2] + oc[4]
-        # branch_0 and the two bottleneck 1x1x1 convs: one launch; the bottleneck outputs share one
-        # scratch buffer whose slices the 3x3x3 convs read
         t = torch.empty((N, D, H, W, oc[1] + oc[3]), dtype=x.dtype, device=x.device)
-        self._fused(x, out[..., :c0], t)
-        self.branch_1[1](t[..., :oc[1]], out=out[..., c0:c1])
-        self.branch_2[1](t[..., oc[1]:], out=out[..., c1:c2])
-        p = self.branch_3[0](x)
-        self.branch_3[1](p, out=out[..., c2:])
+        if not (BRANCH_STREAMS and x.is_cuda):
+            # branch_0 and the two bottleneck 1x1x1 convs: one launch; the bottleneck outputs share one
+            # scratch buffer whose slices the 3x3x3 convs read
+            self._fused(x, out[..., :c0], t)
+            self.branch_1[1](t[..., :oc[1]], out=out[..., c0:c1])
+            self.branch_2[1](t[..., oc[1]:], out=out[..., c1:c2])
+            p = self.branch_3[0](x)
+            self.branch_3[1](p, out=out[..., c2:])
+            return out
+        # The branches are independent: run them on three HIP streams (fork/join with events -- under
+        # hipGraph capture these become parallel graph branches).  Most of these launches do not fill
+        # 256 CUs on the 28x28 / 14x14 maps, so they overlap instead of queueing behind each other.
+        main = torch.cuda.current_stream(x.device)
+        s1, s2 = _side_streams(x.device)
+        s2.wait_stream(main)
+        with torch.cuda.stream(s2):                        # branch_3: pool -> 1x1x1
+            p = self.branch_3[0](x)
+            self.branch_3[1](p, out=out[..., c2:])
+        self._fused(x, out[..., :c0], t)                   # main: fused 1x1x1 convs
+        s1.wait_stream(main)
+        with torch.cuda.stream(s1):                        # branch_2: small 3x3x3
+            self.branch_2[1](t[..., oc[1]:], out=out[..., c1:c2])
+        self.branch_1[1](t[..., :oc[1]], out=out[..., c0:c1])   # main: the big 3x3x3
+        main.wait_stream(s1)
+        main.wait_stream(s2)
+        p.record_stream(main)
         return out
+
+
+BRANCH_STREAMS = True          # run the independent Inception branches on side streams (inference path)
+_SIDE = {}
+
+
+def _side_streams(device):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _SIDE:
+        _SIDE[key] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+    return _SIDE[key]
 
 
 def build_base_i3d(kinetics_pretrain=None, freeze_affine=True):
