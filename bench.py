@@ -95,12 +95,14 @@ def cpu_baseline(net, seconds_budget=25.0):
 
 def roofline(net, x, dtype_name):
     """Instrumented pass: HIP events around every launch (on the launch stream), 3 forwards."""
-    from step_amd import ops
+    from step_amd import backbone, ops
     ops.PROFILE = []
-    with torch.no_grad():
+    saved, backbone.BRANCH_STREAMS = backbone.BRANCH_STREAMS, False      # one stream: launches do not overlap, so an
+    with torch.no_grad():                                                 # event pair times exactly one kernel
         for _ in range(3):
             net(x)
     torch.cuda.synchronize()
+    backbone.BRANCH_STREAMS = saved
     rec, ops.PROFILE = ops.PROFILE, None
     agg = {}
     for name, flops, nbytes, e0, e1 in rec:

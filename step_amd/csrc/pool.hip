@@ -107,7 +107,7 @@ __global__ void maxpool3d_tf_kernel(const T* __restrict__ x, T* __restrict__ y, 
 // while the current outputs are computed from LDS, and every lane moves 16 bytes.
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool333_s1_kernel(const T* __restrict__ x, T* __restrict__ y, PoolParams p,
-                                                            int tiles_h, int tiles_w, int cchunks) {
+                                                            int tiles_h, int tiles_w, int cchunks, int dseg) {
     constexpr int V = elem<T>::VEC;
     typedef typename Vec16<T, V>::raw raw;
     constexpr int TH = 8, TW = 16, HH = TH + 2, HW = TW + 2, SL = 4;       // SL 16-byte slots per pixel
@@ -151,11 +151,14 @@ __global__ __launch_bounds__(256) void maxpool333_s1_kernel(const T* __restrict_
         }
     };
 
+    // this workgroup walks the planes [dbeg, dend) of its column (grid.y segments along D: more workgroups
+    // in flight on the small maps; a segment re-reads one halo plane on each side)
+    const int dbeg = blockIdx.y * dseg, dend = min(dbeg + dseg, p.D);
     raw r[NLD];
-    load_plane(-1, r); store_plane(3, r);          // plane d-1 of the first window = zero pad (slot (d-1)&3)
-    load_plane(0, r);  store_plane(0, r);
-    load_plane(1, r);                               // in flight
-    for (int d = 0; d < p.D; ++d) {
+    load_plane(dbeg - 1, r); store_plane((dbeg - 1) & 3, r);
+    load_plane(dbeg, r);     store_plane(dbeg & 3, r);
+    load_plane(dbeg + 1, r);                        // in flight
+    for (int d = dbeg; d < dend; ++d) {
         store_plane((d + 1) & 3, r);                // plane d+1 (zero plane when d+1 == D)
         __syncthreads();
         if (d + 2 <= p.D) load_plane(d + 2, r);     // next window's new plane flies during the compute below
@@ -260,7 +263,11 @@ static int maxpool_t(const void* x, void* y, const PoolParams& p, step_stream_t 
         const int tiles_h = ceil_div(p.H, 8), tiles_w = ceil_div(p.W, 16), cchunks = ceil_div(p.C, 4 * V);
         const long long blocks = (long long)p.N * tiles_h * tiles_w * cchunks;
         if (blocks == 0) return STEP_OK;
-        STEP_LAUNCH((maxpool333_s1_kernel<T>), dim3((unsigned)blocks), dim3(256), stream, (const T*)x, (T*)y, p, tiles_h, tiles_w, cchunks);
+        // split D until there are a few thousand workgroups (but keep >= 4 planes per segment)
+        int nseg = 1;
+        while (blocks * nseg < 2048 && p.D / (nseg * 2) >= 4) nseg *= 2;
+        const int dseg = ceil_div(p.D, nseg);
+        STEP_LAUNCH((maxpool333_s1_kernel<T>), dim3((unsigned)blocks, (unsigned)ceil_div(p.D, dseg)), dim3(256), stream, (const T*)x, (T*)y, p, tiles_h, tiles_w, cchunks, dseg);
         return STEP_LAUNCH_CHECK();
     }
     long long total = (long long)p.N * p.Do * p.Ho * p.Wo * (p.C / V);

@@ -281,6 +281,18 @@ def case_maxpool_tf(bk, golden):
             assert not yy[..., :yoff].any() and not yy[..., yoff + C:].any()
 
 
+def case_maxpool_s1_long_d_segments(bk, golden):
+    """3x3x3 stride-1 pool on a long D axis: the rolling-window kernel splits D into segments with halos."""
+    rs = np.random.RandomState(8)
+    N, C, D, H, W = 1, 16, 17, 9, 19
+    x = rs.randn(N, C, D, H, W).astype(np.float32)
+    ref = R.maxpool_tf(torch.from_numpy(x), (3, 3, 3), (1, 1, 1)).numpy()
+    xd = bk.dev(cl(x))
+    y = bk.dev(np.zeros((N, D, H, W, C), np.float32))
+    assert bk.lib.step_maxpool3d_tf(0, xd.ptr, N, D, H, W, C, C, 0, 3, 3, 3, 1, 1, 1, y.ptr, C, 0, bk.stream) == 0
+    assert np.array_equal(uncl(y.get()), ref)
+
+
 def case_maxpool_zero_pad_value(bk, golden):
     g = golden("ops_golden")
     x = bk.dev(-np.ones((1, 4, 5, 5, 4), np.float32))
