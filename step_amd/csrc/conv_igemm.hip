@@ -358,8 +358,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 //     barrier per tap.  Every B fragment read from LDS feeds 2 MFMAs and every A fragment NB MFMAs
 //     (a k16 step costs 2 + NB ds_read_b128 for 2*NB MFMAs), and the weights cross the L2 -> CU
 //     path once per 256 pixels instead of once per 32.
-template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS>
-__global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
+// MB = 32-pixel accumulator rows per wave: MB = 2 -> 8 waves (4 x 2, 512 threads, 2 waves per SIMD);
+// MB = 4 -> 4 waves (2 x 2, 256 threads, ONE wave per SIMD with the whole 512-register file: a 128-pixel x
+// 96-channel wave tile reads (4 + NB) fragments per 4*NB MFMAs -- 30 % less LDS traffic per MFMA).
+template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB>
+__global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParams p) {
+    constexpr int NT = (MB == 2) ? 512 : 256;   // threads
+    constexpr int WM = 8 / MB;                  // waves along the pixel axis (x 2 along channels)
+    constexpr int MBP = MB / 2;                 // accumulator rows per wave per epilogue pass
     constexpr int TW = 1 << TWL, TH = 256 >> TWL;
     constexpr int HH_ = TH + KH - 1, HW_ = TW + KW - 1;
     constexpr int NPIX = KD * HH_ * HW_;
@@ -370,13 +376,13 @@ __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
     constexpr int PITCH = 80, SLOTS = 4;
     constexpr int NTAPS = KD * KH * KW;
     constexpr int NVEC = NPIX * SLOTS;
-    constexpr int ITER = (NVEC + 511) / 512;
+    constexpr int ITER = (NVEC + NT - 1) / NT;
     constexpr int FRAGB = 512 * ES;       // bytes of one B fragment (64 lanes x 8 elements)
     constexpr int FRAGV = FRAGB / 16;     // 16-byte vectors per fragment
     constexpr int NBT = 2 * NB;           // 32-channel blocks per workgroup tile
     constexpr int BTILE = NBT * KS * FRAGB;
     constexpr int BVEC = BTILE / 16;      // 16-byte vectors per tap tile
-    constexpr int Q = (BVEC + 511) / 512; // vectors per thread per tap
+    constexpr int Q = (BVEC + NT - 1) / NT; // vectors per thread per tap
     constexpr int NTP = taps_padded(NTAPS);                 // packed taps (odd counts carry one zero tap)
     constexpr int SPS = (TPS == 1) ? NTAPS : NTP / TPS;     // pipeline steps per slab (TPS taps per barrier)
     constexpr int BSTEP = TPS * BTILE;                      // LDS weight bytes per step
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> scalar branches
 #endif
     const int khalf = lane >> 5;
-    const int wm = wave & 3, wn = wave >> 2;
+    const int wm = wave % WM, wn = wave / WM;
 
     int t = blockIdx.x;
     const int tw_i = t % p.tiles_w; t /= p.tiles_w;
@@ -412,16 +418,16 @@ __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
     const unsigned char* wg = (const unsigned char*)p.w;
 
     // LDS address of this lane's two accumulator rows (before the tap shift), incl. its k half
-    const unsigned char* abase[2];
+    const unsigned char* abase[MB];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-        const int m = wm * 64 + mb * 32 + (lane & 31);
+    for (int mb = 0; mb < MB; ++mb) {
+        const int m = wm * (MB * 32) + mb * 32 + (lane & 31);
         abase[mb] = ldsA + ((m >> TWL) * HW_ + (m & (TW - 1))) * PITCH + khalf * (ES == 4 ? 32 : 16);
     }
 
-    f32x16 acc[2][NB];
+    f32x16 acc[MB][NB];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
         vec16 stage[ITER];
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
-            const int v = tid + it * 512;
+            const int v = tid + it * NT;
             vec16 val;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) val[e] = 0;
@@ -451,7 +457,7 @@ __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
         }
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
-            const int v = tid + it * 512;
+            const int v = tid + it * NT;
             if (v < NVEC) {
                 const int pix = v / SLOTS, slot = v % SLOTS;
                 *(vec16*)(ldsA + pix * PITCH + (slot << 4)) = stage[it];
@@ -468,12 +474,12 @@ __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
     int ldsoff[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        const int v = min(tid + q * 512, BVEC - 1);
+        const int v = min(tid + q * NT, BVEC - 1);
         const int f = v / FRAGV, within = v % FRAGV;
         const int nbl = f / KS, ks = f % KS;
         const int nbg = min(nb0 + nbl, p.nblk32 - 1);
         wthr[q] = wg + ((size_t)nbg * taps_padded(NTAPS) * KC16 + ks) * FRAGB + within * 16;
-        ldsoff[q] = (tid + q * 512 < BVEC) ? (tid + q * 512) * 16 : -1;
+        ldsoff[q] = (tid + q * NT < BVEC) ? (tid + q * NT) * 16 : -1;
     }
     auto load_B = [&](int slab_, int sis_, u32x4 (&r)[TPS * Q]) {         // sis_ = step index within the slab
 #pragma unroll
@@ -500,7 +506,7 @@ __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
     //     since the previous barrier), so LDS latency, the weight hand-over and the barrier hide behind
     //     matrix work.  A slab switch drains the pipeline once per slab.
     u32x4 R[TPS * Q];
-    frag_t fa[2][KS][2], fb[2][KS][NB];
+    frag_t fa[2][KS][MB], fb[2][KS][NB];
 
     const unsigned char* const bwave = ldsB + (wn * NB) * KS * FRAGB + lane * (8 * ES);
     auto read_frags = [&](auto setc, int bufoff, int shift) {
@@ -508,7 +514,7 @@ __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) fa[SET][j][mb] = lds_read_bfrag<T>(abase[mb] + shift + j * 32);
+            for (int mb = 0; mb < MB; ++mb) fa[SET][j][mb] = lds_read_bfrag<T>(abase[mb] + shift + j * 32);
 #pragma unroll
             for (int i = 0; i < NB; ++i) fb[SET][j][i] = lds_read_bfrag<T>(bwave + bufoff + (i * KS + j) * FRAGB);
         }
@@ -519,8 +525,8 @@ __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
         for (int j = 0; j < KS; ++j)
 #pragma unroll
             for (int i = 0; i < NB; ++i) {   // channel blocks past Cout compute on a duplicate block and are never stored
-                mma_k16(fa[SET][j][0], fb[SET][j][i], acc[0][i], T());
-                mma_k16(fa[SET][j][1], fb[SET][j][i], acc[1][i], T());
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) mma_k16(fa[SET][j][mb], fb[SET][j][i], acc[mb][i], T());
             }
     };
     // LDS byte shift of tap t of the slab (the zero tap of an odd tap count reads tap 0's pixels)
@@ -606,17 +612,21 @@ __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
             sh[i] = p.shift ? p.shift[co] : 0.f;
         }
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            if (mb) __syncthreads();                      // previous half has been read out
+        for (int ps = 0; ps < 2; ++ps) {                  // two passes of 128 pixels
+            if (ps) __syncthreads();                      // previous half has been read out
 #pragma unroll
-            for (int i = 0; i < NB; ++i)
+            for (int mbl = 0; mbl < MBP; ++mbl)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    ot[(wm * 32 + cd_row(r, lane)) * BN + (wn * NB + i) * 32 + (lane & 31)] = acc[mb][i][r] * sc[i] + sh[i];
+                for (int i = 0; i < NB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        ot[((wm * MBP + mbl) * 32 + cd_row(r, lane)) * BN + (wn * NB + i) * 32 + (lane & 31)] =
+                            acc[ps * MBP + mbl][i][r] * sc[i] + sh[i];
             __syncthreads();
-            for (int idx = tid; idx < 128 * G; idx += 512) {
+            for (int idx = tid; idx < 128 * G; idx += NT) {
                 const int row = idx / G, g = idx % G;
-                const int mm = (row >> 5) * 64 + mb * 32 + (row & 31);
+                // row = (wm*MBP + mbl)*32 + rr  ->  tile pixel wm*(MB*32) + (ps*MBP + mbl)*32 + rr
+                const int mm = ((row >> 5) / MBP) * (MB * 32) + (ps * MBP + (row >> 5) % MBP) * 32 + (row & 31);
                 const int oh = h0 + (mm >> TWL), ow = w0 + (mm & (TW - 1));
                 const int co = nb0 * 32 + g * 8;
                 if (oh < p.H && ow < p.W && co < p.Cout) {
@@ -646,10 +656,10 @@ __global__ __launch_bounds__(512) void conv_tap_kernel(ConvParams p) {
             const float sc = p.scale ? p.scale[co] : 1.f;
             const float sh = p.shift ? p.shift[co] : 0.f;
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
+            for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int mm = wm * 64 + mb * 32 + cd_row(r, lane);
+                    const int mm = wm * (MB * 32) + mb * 32 + cd_row(r, lane);
                     const int oh = h0 + (mm >> TWL), ow = w0 + (mm & (TW - 1));
                     if (oh < p.H && ow < p.W) {
                         const size_t opix = (((size_t)n * p.D + d) * p.H + oh) * p.W + ow;
@@ -1099,7 +1109,7 @@ static int pick_nb(int nblk32, long long mtiles) {
 // attribute time and work to the kernel name rocprofv3 reports).
 //   impl 0: conv_igemm_kernel (4 waves, 128-px tile, weights straight from L2)  -- 1x1x1 and small problems
 //   impl 1: conv_tap_kernel   (8 waves, 256-px tile, weights through an LDS-DMA double buffer)
-struct ConvPlan { bool ok, flat, wide; int impl, NB, tps, tiles_h, tiles_w; long long mtiles; };
+struct ConvPlan { bool ok, flat, wide; int impl, NB, tps, mb, tiles_h, tiles_w; long long mtiles; };
 
 static int pick_nb_tap(int nblk32, long long mtiles) {
     int best = 1;
@@ -1118,13 +1128,13 @@ static int conv_impl_override() {   // tuning aid: STEP_CONV_IMPL=igemm|tap|tap2
     const char* e = getenv("STEP_CONV_IMPL");
     if (!e) return -1;
     if (e[0] == 'i') return 0;
-    if (e[0] == 't') return (e[1] && e[2] && e[3] == '2') ? 2 : 1;
+    if (e[0] == 't') return (e[1] && e[2] && e[3] == '2') ? 2 : ((e[1] && e[2] && e[3] == '4') ? 4 : 1);
     return -1;
 }
 
 static ConvPlan conv_plan(const step_conv_desc* d) {
     ConvPlan pl;
-    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1;
+    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1; pl.mb = 2;
     const int nblk32 = ceil_div(d->Cout, 32);
     const bool k1 = d->kd == 1 && d->kh == 1 && d->kw == 1;
     const bool k333 = d->kd == 3 && d->kh == 3 && d->kw == 3;
@@ -1147,6 +1157,7 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
     if (use_tap) {
         pl.impl = 1;
         pl.tps = (ov == 1) ? 1 : 2;     // two taps per barrier measured 6-15 % faster than one (STEP_CONV_IMPL=tap forces one)
+        pl.mb = (ov == 4) ? 4 : 2;      // STEP_CONV_IMPL=tap4: the 4-wave, 128-pixel-per-wave variant
         pl.wide = t32 < t16;
         pl.tiles_h = pl.wide ? ceil_div(d->H, 8) : ceil_div(d->H, 16);
         pl.tiles_w = pl.wide ? ceil_div(d->W, 32) : ceil_div(d->W, 16);
@@ -1166,20 +1177,28 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
 }
 
 template <typename T, int TWL, int KD, int KH, int KW>
-static int launch_tap(const ConvParams& p, int NB, int tps, dim3 grid, step_stream_t stream) {
-    if (tps == 2) {
+static int launch_tap(const ConvParams& p, int NB, int tps, int mb, dim3 grid, step_stream_t stream) {
+#define STEP_TAP(NB_, TPS_, MB_) STEP_LAUNCH((conv_tap_kernel<T, TWL, NB_, KD, KH, KW, TPS_, MB_>), grid, dim3(MB_ == 2 ? 512 : 256), stream, p)
+    if (mb == 4) {
         switch (NB) {
-            case 1: STEP_LAUNCH((conv_tap_kernel<T, TWL, 1, KD, KH, KW, 2>), grid, dim3(512), stream, p); break;
-            case 2: STEP_LAUNCH((conv_tap_kernel<T, TWL, 2, KD, KH, KW, 2>), grid, dim3(512), stream, p); break;
-            default: STEP_LAUNCH((conv_tap_kernel<T, TWL, 3, KD, KH, KW, 2>), grid, dim3(512), stream, p); break;
+            case 1: STEP_TAP(1, 2, 4); break;
+            case 2: STEP_TAP(2, 2, 4); break;
+            default: STEP_TAP(3, 2, 4); break;
+        }
+    } else if (tps == 2) {
+        switch (NB) {
+            case 1: STEP_TAP(1, 2, 2); break;
+            case 2: STEP_TAP(2, 2, 2); break;
+            default: STEP_TAP(3, 2, 2); break;
         }
     } else {
         switch (NB) {
-            case 1: STEP_LAUNCH((conv_tap_kernel<T, TWL, 1, KD, KH, KW, 1>), grid, dim3(512), stream, p); break;
-            case 2: STEP_LAUNCH((conv_tap_kernel<T, TWL, 2, KD, KH, KW, 1>), grid, dim3(512), stream, p); break;
-            default: STEP_LAUNCH((conv_tap_kernel<T, TWL, 3, KD, KH, KW, 1>), grid, dim3(512), stream, p); break;
+            case 1: STEP_TAP(1, 1, 2); break;
+            case 2: STEP_TAP(2, 1, 2); break;
+            default: STEP_TAP(3, 1, 2); break;
         }
     }
+#undef STEP_TAP
     return STEP_LAUNCH_CHECK();
 }
 
@@ -1194,8 +1213,8 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, step_stream_t s
     if (pl.impl == 1) {
         dim3 grid((unsigned)pl.mtiles, (unsigned)ceil_div(p.nblk32, 2 * pl.NB));
         if (d->kd == 3)
-            return pl.wide ? launch_tap<T, 5, 3, 3, 3>(p, pl.NB, pl.tps, grid, stream) : launch_tap<T, 4, 3, 3, 3>(p, pl.NB, pl.tps, grid, stream);
-        return pl.wide ? launch_tap<T, 5, 1, 3, 3>(p, pl.NB, pl.tps, grid, stream) : launch_tap<T, 4, 1, 3, 3>(p, pl.NB, pl.tps, grid, stream);
+            return pl.wide ? launch_tap<T, 5, 3, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream) : launch_tap<T, 4, 3, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
+        return pl.wide ? launch_tap<T, 5, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream) : launch_tap<T, 4, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
     }
     dim3 grid((unsigned)pl.mtiles, (unsigned)ceil_div(p.nblk32, pl.NB));
     if (pl.flat) return launch_nb<T, 4, 1, 1, 1, true>(p, pl.NB, grid, stream);
@@ -1330,8 +1349,8 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
     if (!pl.ok) return STEP_E_UNSUPPORTED;
     const char* t = d->dtype == STEP_F32 ? "float" : (d->dtype == STEP_BF16 ? "step::bf16_t" : "step::f16_t");
     if (pl.impl == 1)
-        snprintf(buf, (size_t)buflen, "void step::conv_tap_kernel<%s, %d, %d, %d, %d, %d, %d>(step::ConvParams)", t,
-                 pl.wide ? 5 : 4, pl.NB, d->kd, d->kh, d->kw, pl.tps);
+        snprintf(buf, (size_t)buflen, "void step::conv_tap_kernel<%s, %d, %d, %d, %d, %d, %d, %d>(step::ConvParams)", t,
+                 pl.wide ? 5 : 4, pl.NB, d->kd, d->kh, d->kw, pl.mb == 4 ? 2 : pl.tps, pl.mb);
     else
         snprintf(buf, (size_t)buflen, "void step::conv_igemm_kernel<%s, %d, %d, %d, %d, %d, %s>(step::ConvParams)", t,
                  pl.flat ? 4 : (pl.wide ? 5 : 4), pl.NB, d->kd, d->kh, d->kw, pl.flat ? "true" : "false");
