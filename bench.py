@@ -30,6 +30,9 @@ sys.path.insert(0, ROOT)
 
 CLIPS_PER_GPU = 8
 T_IN, HW_IN = 32, 224
+# --config c5 (BASELINE configs[4], long-clip stress): T=64, 400x400, fp16, 4 clips per GPU (= batch 32 on 8 GPUs)
+CONFIGS = {"c2": dict(clips=8, T=32, HW=224, dtype="bf16", gflop=109.29, act_mb=304.9, name="C2"),
+           "c5": dict(clips=4, T=64, HW=400, dtype="f16", gflop=696.98, act_mb=1944.6, name="C5")}
 PEAK = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}          # dense MFMA TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 # algorithmic work of BaseNet at C2 per clip: 109.29 GFLOP, 304.9 MB activations + 15.0 MB weights/batch
@@ -65,7 +68,7 @@ def cpu_baseline(net, seconds_budget=25.0):
     sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
     ncpu = os.cpu_count() or 1
     g = torch.Generator().manual_seed(123)
-    x = torch.rand(1, T_IN, 3, HW_IN, HW_IN, generator=g) * 2 - 1
+    x = torch.rand(1, 32, 3, 224, 224, generator=g) * 2 - 1     # the CPU sample is always a C2-shaped clip
     with torch.no_grad():
         # torch's CPU conv3d does not scale to hundreds of threads: probe a few thread counts on a
         # quarter-length clip and keep the fastest for the timed sample
@@ -148,11 +151,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="c2 = headline (default); c5 = long-clip stress")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
+    global CLIPS_PER_GPU, T_IN, HW_IN, GFLOP_PER_CLIP, ACT_MB_PER_CLIP
+    c = CONFIGS[a.config]
+    CLIPS_PER_GPU, T_IN, HW_IN, GFLOP_PER_CLIP, ACT_MB_PER_CLIP = c["clips"], c["T"], c["HW"], c["gflop"], c["act_mb"]
+    a.dtype = a.dtype or c["dtype"]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -178,7 +186,7 @@ def main():
     with torch.no_grad():
         y = net(x)                                               # packs weights, warms the allocator
         torch.cuda.synchronize()
-        assert tuple(y.shape) == (CLIPS_PER_GPU, 8, 832, 14, 14) and bool(torch.isfinite(y.float()).all())
+        assert tuple(y.shape) == (CLIPS_PER_GPU, T_IN // 4, 832, -(-HW_IN // 16), -(-HW_IN // 16)) and bool(torch.isfinite(y.float()).all())
         graph = None
         if not a.no_graph:
             s = torch.cuda.Stream()
@@ -220,18 +228,18 @@ def main():
     if rank == 0:
         clips = world * CLIPS_PER_GPU * a.steps
         val = clips / el
-        out = {"metric": "clips_per_sec_T32_224", "value": round(val, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps,
+        out = {"metric": "clips_per_sec_T%d_%d" % (T_IN, HW_IN), "value": round(val, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": "C2: I3D backbone (BaseNet conv3d_1a..mixed_4f) forward, %d x [3,32,224,224] clips per GPU, "
-                                      "inputs resident in HBM, random-init weights" % CLIPS_PER_GPU,
+               "config": {"workload": "%s: I3D backbone (BaseNet conv3d_1a..mixed_4f) forward, %d x [3,%d,%d,%d] clips per GPU, "
+                                      "inputs resident in HBM, random-init weights" % (c["name"], CLIPS_PER_GPU, T_IN, HW_IN, HW_IN),
                           "clips_per_gpu": CLIPS_PER_GPU, "T": T_IN, "HW": HW_IN, "parallelism": "clip-sharded replicas x%d (no data-path collective)" % world,
                           "launch": "eager" if graph is None else "hipGraph replay"}}
         per_gpu = val / world
         out["backbone_roofline"] = {
             "hbm_frac": round(per_gpu * (ACT_MB_PER_CLIP + W_MB / CLIPS_PER_GPU) * 1e6 / (PEAK_HBM_GBS * 1e9), 4),
             "mfma_frac": round(per_gpu * GFLOP_PER_CLIP * 1e9 / (PEAK[a.dtype] * 1e12), 4),
-            "note": "whole-backbone algorithmic bytes (BASELINE.md: 304.9 MB/clip + 15 MB weights/batch) and FLOPs (109.29 GFLOP/clip) "
+            "note": "whole-backbone algorithmic bytes (BASELINE.md sec. 2: %.1f MB/clip + 15 MB weights/batch) and FLOPs (%.2f GFLOP/clip) " % (ACT_MB_PER_CLIP, GFLOP_PER_CLIP) +
                     "per second per GPU over the 8 TB/s HBM and dense MFMA peaks"}
     # roofline of the dominant kernel (every rank could, rank 0 reports)
     if rank == 0:

@@ -44,7 +44,15 @@ def inference(args, conv_feat, context_feat, nets, exec_iter, tubes):
         raise NotImplementedError("step_amd.driver.inference implements temporal_mode='predict'")
     dev = conv_feat.device
     flat, nums = _flat_tubes(tubes, dev)
-    clip_of = torch.repeat_interleave(torch.arange(len(nums), device=dev), torch.tensor(nums, device=dev))
+    clip_of = torch.as_tensor(np.repeat(np.arange(len(nums)), nums), device=dev)
+    return inference_flat(args, conv_feat, context_feat, nets, exec_iter, flat, nums, clip_of)
+
+
+def inference_flat(args, conv_feat, context_feat, nets, exec_iter, flat, nums, clip_of):
+    """The device-resident core of `inference`: flat [N,T,5] tubes (col 0 = frame index), nums = tubes per
+    clip, clip_of [N] = clip index of every tube.  Pure tensor ops with static shapes and no host
+    synchronisation, so the whole multi-step pipeline can be captured in a hipGraph (GraphedInference)."""
+    dev = conv_feat.device
     history, trajectory = [], []
     for i in range(1, exec_iter + 1):
         chunks = args.NUM_CHUNKS[i]
@@ -123,3 +131,43 @@ def postprocess(args, history, conf_thresh=0.01, nms_thresh=0.4, topk=300):
             bx, cls = bx[sel], cls[sel]
         out.append((bx, sc, cls))
     return out
+
+
+class GraphedInference:
+    """BaseNet -> ContextNet -> multi-step inference for a FIXED batch size / tubes-per-clip, captured once
+    in a hipGraph and replayed: the ~200 small launches of the three refinement steps stop being bound by
+    Python / launch latency.  `__call__(images, tubes)` copies the inputs into the captured buffers, replays
+    and returns (history, conv_feat, context_feat) -- static tensors that the next call overwrites."""
+
+    def __init__(self, args, base_net, context_net, nets, images, tubes):
+        self.args, self.base, self.ctx, self.nets = args, base_net, context_net, nets
+        dev = images.device
+        self.images = images.clone()
+        flat, self.nums = _flat_tubes(tubes, dev)
+        self.flat0 = flat.clone()
+        self.clip_of = torch.as_tensor(np.repeat(np.arange(len(self.nums)), self.nums), device=dev)
+        with torch.no_grad():
+            s = torch.cuda.Stream(dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                for _ in range(2):                        # warm-up: packs weights, fills caches and the allocator
+                    self._run()
+            torch.cuda.current_stream(dev).wait_stream(s)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self._run()
+
+    def _run(self):
+        cf = self.base(self.images)
+        cx = self.ctx(cf) if not self.args.no_context else None
+        hist, _ = inference_flat(self.args, cf, cx, self.nets, self.args.max_iter, self.flat0, self.nums, self.clip_of)
+        return hist, cf, cx
+
+    def __call__(self, images, tubes=None):
+        self.images.copy_(images)
+        if tubes is not None:
+            flat, nums = _flat_tubes(tubes, images.device)
+            assert nums == self.nums, "GraphedInference was captured for %s tubes per clip" % (self.nums,)
+            self.flat0.copy_(flat)
+        self.graph.replay()
+        return self.out

@@ -275,7 +275,7 @@ class TwoBranchNet(nn.Module):
         global_class = logits.reshape(N, Tl, self.num_classes).float().mean(1)
 
         # ---- local branch
-        zero = torch.tensor([0.0], device=global_class.device, dtype=global_class.dtype)
+        zero = torch.zeros(1, device=global_class.device, dtype=global_class.dtype)      # fill kernel: capturable
         local_loc, first_loc, last_loc = zero, zero.clone(), zero.clone()
         if not self.cls_only:
             a = g.reshape(N * Tl, 1, W, H, C)                      # frames as batch, D = 1
@@ -296,9 +296,9 @@ class TwoBranchNet(nn.Module):
             last_pred = last_loc[:, half_T].reshape(N, -1)
 
         # ---- losses (two_branch.py:276-333)
-        loss_global_cls = torch.tensor(0.0, device=global_class.device)
-        loss_local_loc = torch.tensor(0.0, device=global_class.device)
-        loss_neighbor_loc = torch.tensor(0.0, device=global_class.device)
+        loss_global_cls = torch.zeros((), device=global_class.device)
+        loss_local_loc = torch.zeros((), device=global_class.device)
+        loss_neighbor_loc = torch.zeros((), device=global_class.device)
         if targets is not None:
             tubes = tubes.to(dev)
             targets = targets.to(dev)

@@ -61,6 +61,8 @@ def valid_tubes(tubes, width=400, height=400):
     x1, y1 = b[:, 0].clamp(min=0), b[:, 1].clamp(min=0)
     x2, y2 = b[:, 2].clamp(max=width), b[:, 3].clamp(max=height)
     bad = ~((x1 < x2 - 2) & (y1 < y2 - 2))
-    whole = torch.tensor([0, 0, width, height], dtype=b.dtype, device=b.device)
-    out = torch.where(bad[:, None], whole[None], torch.stack((x1, y1, x2, y2), 1))
+    # fill kernels only (no host->device scalar copies): the whole step loop is hipGraph-capturable
+    out = torch.stack((torch.where(bad, torch.zeros_like(x1), x1), torch.where(bad, torch.zeros_like(y1), y1),
+                       torch.where(bad, torch.full_like(x2, float(width)), x2),
+                       torch.where(bad, torch.full_like(y2, float(height)), y2)), 1)
     return out.reshape(tubes.shape)

@@ -13,7 +13,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import step_amd  # noqa: E402
 from oracle import i3d_ref as R  # noqa: E402  (anchors table only)
-from step_amd.driver import inference, postprocess  # noqa: E402
+from step_amd.driver import GraphedInference, inference, postprocess  # noqa: E402
 
 
 def cfg(**kw):
@@ -68,6 +68,21 @@ def main():
     kept = sum(int(o[1].numel()) for o in out)
     print("C3 inference: batch %d x [36,3,400,400] %s, %d tubes/clip: %.2f ms/batch = %.1f clips/s  (detections kept: %d)"
           % (a.batch, a.dtype, a.tubes, el * 1e3, a.batch / el, kept))
+    # the same pipeline captured in a hipGraph
+    gi = GraphedInference(args, base, ctx, nets, x, tubes)
+    with torch.no_grad():
+        h2, _, _ = gi(x)
+        ref_hist = inference(args, base(x), ctx(base(x)), nets, 3, tubes)[0]
+        err = max(float((a["pred_loc"].float() - b["pred_loc"].float()).abs().max()) for a, b in zip(h2, ref_hist))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.iters):
+            h2, _, _ = gi(x)
+            out = postprocess(args, h2)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / a.iters
+    print("C3 inference, hipGraph replay + postprocess: %.2f ms/batch = %.1f clips/s  (max |pred_loc diff| vs eager %.3g)"
+          % (el * 1e3, a.batch / el, err))
     # stage split
     with torch.no_grad():
         for name, fn in (("backbone", lambda: base(x)),):
