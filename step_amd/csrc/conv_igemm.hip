@@ -116,16 +116,18 @@ __device__ __forceinline__ typename frag<T>::type load_b_frag(const T* p) {  // 
 
 // TWL: log2(tile width); tile = (128 >> TWL) rows x (1 << TWL) cols of output pixels in one (n, d)
 // plane.  FLAT (1x1x1 only): the tile is 128 consecutive pixels of the flattened N*D*H*W axis.
-template <typename T, int TWL, int NB, int KD, int KH, int KW, bool FLAT>
+// CKT: channels per LDS slab (32, or 128 for pointwise convs with a deep Cin: 4x fewer barriers per K).
+template <typename T, int TWL, int NB, int KD, int KH, int KW, bool FLAT, int CKT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     constexpr int TW = 1 << TWL, TH = 128 >> TWL;
     constexpr int HH_ = TH + KH - 1, HW_ = TW + KW - 1;
     constexpr int NPIX = FLAT ? 128 : KD * HH_ * HW_;
     constexpr int ES = (int)sizeof(T);
     constexpr int VEC = 16 / ES;
-    constexpr int PITCH = CK * ES;
+    constexpr int PITCH = CKT * ES;
+    constexpr int KSTEPS = CKT / 16;
     constexpr int SLOTS = PITCH / 16;
-    constexpr int PPR = 16 / SLOTS;
+    constexpr int PPR = (16 / SLOTS) > 0 ? (16 / SLOTS) : 1;   // pixels per 256-byte LDS row (>= 1)
     constexpr int NTAPS = KD * KH * KW;
     constexpr int NVEC = NPIX * SLOTS;
     constexpr int ITER = (NVEC + 255) / 256;
@@ -162,6 +164,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     }
     const int nb0 = blockIdx.y * NB;
     const int KC16 = p.nchunks * 2;
+    const int nslab = (p.Cin + CKT - 1) / CKT;
 
     f32x16 acc[NB];
 #pragma unroll
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
             for (int e = 0; e < VEC; ++e) val[e] = 0;
             if (v < NVEC) {
                 const int pix = v / SLOTS, slot = v % SLOTS;
-                const int c = chunk * CK + slot * VEC;
+                const int c = chunk * CKT + slot * VEC;
                 bool inb;
                 size_t gpix;
                 if (FLAT) {
@@ -222,11 +225,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     };
 
     load_slab(0);
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    for (int chunk = 0; chunk < nslab; ++chunk) {
         if (chunk) __syncthreads();  // all waves finished reading the previous slab
         store_slab();
         __syncthreads();
-        if (chunk + 1 < p.nchunks) load_slab(chunk + 1);
+        if (chunk + 1 < nslab) load_slab(chunk + 1);
 
         // ---- taps x 2 k16 steps x NB accumulators
 #pragma unroll 1
@@ -240,9 +243,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                     const int sw = (hp / PPR) % SLOTS;
                     const unsigned char* pb = lds + hp * PITCH;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < KSTEPS; ++j) {
+                        if (chunk * KSTEPS + j >= KC16) break;          // uniform: the packed K extent ends here
                         const frag_t a = lds_read_frag<T>(pb, j, khalf, sw);
-                        const size_t koff = ((size_t)tap * KC16 + chunk * 2 + j) * 512;
+                        const size_t koff = ((size_t)tap * KC16 + chunk * KSTEPS + j) * 512;
 #pragma unroll
                         for (int i = 0; i < NB; ++i) {
                             const frag_t b = load_b_frag<T>(wb[i] + koff);
@@ -1076,13 +1080,13 @@ static inline unsigned flat_grid(long long total, int block) {
     return (unsigned)g;
 }
 
-template <typename T, int TWL, int KD, int KH, int KW, bool FLAT>
+template <typename T, int TWL, int KD, int KH, int KW, bool FLAT, int CKT>
 static int launch_nb(const ConvParams& p, int NB, dim3 grid, step_stream_t stream) {
     switch (NB) {
-        case 1: STEP_LAUNCH((conv_igemm_kernel<T, TWL, 1, KD, KH, KW, FLAT>), grid, dim3(256), stream, p); break;
-        case 2: STEP_LAUNCH((conv_igemm_kernel<T, TWL, 2, KD, KH, KW, FLAT>), grid, dim3(256), stream, p); break;
-        case 3: STEP_LAUNCH((conv_igemm_kernel<T, TWL, 3, KD, KH, KW, FLAT>), grid, dim3(256), stream, p); break;
-        default: STEP_LAUNCH((conv_igemm_kernel<T, TWL, 4, KD, KH, KW, FLAT>), grid, dim3(256), stream, p); break;
+        case 1: STEP_LAUNCH((conv_igemm_kernel<T, TWL, 1, KD, KH, KW, FLAT, CKT>), grid, dim3(256), stream, p); break;
+        case 2: STEP_LAUNCH((conv_igemm_kernel<T, TWL, 2, KD, KH, KW, FLAT, CKT>), grid, dim3(256), stream, p); break;
+        case 3: STEP_LAUNCH((conv_igemm_kernel<T, TWL, 3, KD, KH, KW, FLAT, CKT>), grid, dim3(256), stream, p); break;
+        default: STEP_LAUNCH((conv_igemm_kernel<T, TWL, 4, KD, KH, KW, FLAT, CKT>), grid, dim3(256), stream, p); break;
     }
     return STEP_LAUNCH_CHECK();
 }
@@ -1109,7 +1113,7 @@ static int pick_nb(int nblk32, long long mtiles) {
 // attribute time and work to the kernel name rocprofv3 reports).
 //   impl 0: conv_igemm_kernel (4 waves, 128-px tile, weights straight from L2)  -- 1x1x1 and small problems
 //   impl 1: conv_tap_kernel   (8 waves, 256-px tile, weights through an LDS-DMA double buffer)
-struct ConvPlan { bool ok, flat, wide; int impl, NB, tps, mb, tiles_h, tiles_w; long long mtiles; };
+struct ConvPlan { bool ok, flat, wide, deep; int impl, NB, tps, mb, tiles_h, tiles_w; long long mtiles; };
 
 static int pick_nb_tap(int nblk32, long long mtiles) {
     int best = 1;
@@ -1134,7 +1138,7 @@ static int conv_impl_override() {   // tuning aid: STEP_CONV_IMPL=igemm|tap|tap2
 
 static ConvPlan conv_plan(const step_conv_desc* d) {
     ConvPlan pl;
-    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1; pl.mb = 2;
+    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1; pl.mb = 2; pl.deep = false;
     const int nblk32 = ceil_div(d->Cout, 32);
     const bool k1 = d->kd == 1 && d->kh == 1 && d->kw == 1;
     const bool k333 = d->kd == 3 && d->kh == 3 && d->kw == 3;
@@ -1143,6 +1147,8 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
     if (k1) {
         pl.mtiles = ceil_div64((long long)d->N * d->D * d->H * d->W, 128);
         pl.NB = pick_nb(nblk32, pl.mtiles);
+        pl.deep = d->Cin >= 256;        // 128-channel slabs: 4x fewer barriers along a deep K
+        if (const char* e = getenv("STEP_CONV_DEEP")) pl.deep = (e[0] == '1');   // tuning aid
         return pl;
     }
     if (!k333 && !k133) { pl.ok = false; pl.mtiles = 0; pl.NB = 1; return pl; }
@@ -1217,10 +1223,11 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, step_stream_t s
         return pl.wide ? launch_tap<T, 5, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream) : launch_tap<T, 4, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
     }
     dim3 grid((unsigned)pl.mtiles, (unsigned)ceil_div(p.nblk32, pl.NB));
-    if (pl.flat) return launch_nb<T, 4, 1, 1, 1, true>(p, pl.NB, grid, stream);
+    if (pl.flat)
+        return pl.deep ? launch_nb<T, 4, 1, 1, 1, true, 128>(p, pl.NB, grid, stream) : launch_nb<T, 4, 1, 1, 1, true, 32>(p, pl.NB, grid, stream);
     if (d->kd == 3)
-        return pl.wide ? launch_nb<T, 5, 3, 3, 3, false>(p, pl.NB, grid, stream) : launch_nb<T, 4, 3, 3, 3, false>(p, pl.NB, grid, stream);
-    return pl.wide ? launch_nb<T, 5, 1, 3, 3, false>(p, pl.NB, grid, stream) : launch_nb<T, 4, 1, 3, 3, false>(p, pl.NB, grid, stream);
+        return pl.wide ? launch_nb<T, 5, 3, 3, 3, false, 32>(p, pl.NB, grid, stream) : launch_nb<T, 4, 3, 3, 3, false, 32>(p, pl.NB, grid, stream);
+    return pl.wide ? launch_nb<T, 5, 1, 3, 3, false, 32>(p, pl.NB, grid, stream) : launch_nb<T, 4, 1, 3, 3, false, 32>(p, pl.NB, grid, stream);
 }
 
 template <typename T>
@@ -1352,8 +1359,8 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
         snprintf(buf, (size_t)buflen, "void step::conv_tap_kernel<%s, %d, %d, %d, %d, %d, %d, %d>(step::ConvParams)", t,
                  pl.wide ? 5 : 4, pl.NB, d->kd, d->kh, d->kw, pl.mb == 4 ? 2 : pl.tps, pl.mb);
     else
-        snprintf(buf, (size_t)buflen, "void step::conv_igemm_kernel<%s, %d, %d, %d, %d, %d, %s>(step::ConvParams)", t,
-                 pl.flat ? 4 : (pl.wide ? 5 : 4), pl.NB, d->kd, d->kh, d->kw, pl.flat ? "true" : "false");
+        snprintf(buf, (size_t)buflen, "void step::conv_igemm_kernel<%s, %d, %d, %d, %d, %d, %s, %d>(step::ConvParams)", t,
+                 pl.flat ? 4 : (pl.wide ? 5 : 4), pl.NB, d->kd, d->kh, d->kw, pl.flat ? "true" : "false", pl.deep ? 128 : 32);
     return STEP_OK;
 }
 

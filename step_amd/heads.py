@@ -43,12 +43,24 @@ class ROINet(nn.Module):
         """conv_feat logical [B,T,C,H,W]; tubes [num_tubes,T,5] (col 0 = frame index b*T+t).
         Returns logical [num_tubes*T, C, 7, 7] (channels-last physical when conv_feat is)."""
         B, T, C, H, W = conv_feat.shape
+        rois = tubes.reshape(-1, 5).detach()
         v = conv_feat.permute(0, 1, 3, 4, 2)
         if v.is_contiguous():                      # our channels-last buffer: zero-copy 4-D view
             feat4 = v.reshape(B * T, H, W, C).permute(0, 3, 1, 2)
+        elif (v.stride(4) == 1 and v.stride(3) == C and v.stride(2) == W * C and v.stride(1) == H * W * C
+              and v.stride(0) % v.stride(1) == 0):
+            # a T-slice conv_feat[:, t0:t0+T] of a channels-last buffer with T_all frames per clip
+            # (utils/utils.py:48 slices like this): keep the buffer in place, address frame b*T+t of the
+            # slice as frame b*T_all + t of a strided [B*T_all, ...] view that starts at the slice
+            fstride = v.stride(1)
+            t_all = v.stride(0) // fstride
+            feat4 = torch.as_strided(v, (B * t_all - (t_all - T), H, W, C), (fstride, W * C, C, 1)).permute(0, 3, 1, 2)
+            idx = rois[:, 0]
+            b = torch.floor(idx / T)
+            rois = torch.cat([(b * t_all + (idx - b * T)).unsqueeze(1), rois[:, 1:]], dim=1)
         else:
             feat4 = conv_feat.reshape(-1, C, H, W)
-        return self.pool_layer(feat4, tubes.reshape(-1, 5).detach())
+        return self.pool_layer(feat4, rois)
 
 
 def _build_head_i3d(with_pool):

@@ -348,6 +348,7 @@ CONV_CASES = [
     (2, 32, 40, 3, 7, 7, (1, 3, 3)),        # 2-D 3x3 conv (frames on D)
     (2, 72, 100, 2, 5, 9, (1, 1, 1)),       # pointwise: flat tiles, tail tile
     (1, 200, 16, 1, 13, 13, (1, 1, 1)),     # 7 slabs
+    (2, 264, 40, 1, 5, 9, (1, 1, 1)),       # deep pointwise: 128-channel slabs, ragged last slab (264 = 2*128 + 8)
 ]
 
 

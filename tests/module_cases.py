@@ -143,6 +143,11 @@ def case_roinet_layouts(dev, golden):
     # the reference's call pattern: slice then .contiguous()  (utils/utils.py:48)
     out3 = net(cl[:, 0:3].contiguous(), tubes)
     assert np.array_equal(np_(out3), g["tube_out"])
+    # a T-slice of a longer channels-last feature (what the step driver passes): zero-copy path
+    long_cl = torch.cat([cl.new_zeros(2, 2, 16, 25, 25).permute(0, 1, 3, 4, 2), cl.permute(0, 1, 3, 4, 2),
+                         cl.new_ones(2, 1, 16, 25, 25).permute(0, 1, 3, 4, 2)], 1).contiguous().permute(0, 1, 4, 2, 3)
+    out4 = net(long_cl[:, 2:5], tubes)
+    assert out4.permute(0, 2, 3, 1).is_contiguous() and np.array_equal(np_(out4), g["tube_out"])
     pool = step_amd.ROINet("pool", 7)
     a, b = pool(conv, tubes), pool(cl, tubes)
     assert np.array_equal(np_(a), np_(b))
