@@ -12,9 +12,10 @@ kernels through step_amd.ops on CHANNELS-LAST activations ([N,T,H,W,C]).  A bloc
 write straight into channel slices of one output buffer (no torch.cat), eval-mode BN is folded into
 a per-channel scale/shift applied in the conv epilogue, TF-SAME padding is a load predicate.
 
-Training note (round 1): forward is always the HIP path; when gradients are required the conv unit
-records a torch autograd node whose backward uses torch's convolution_backward on the same
-channels-last buffers (see _ConvUnitFn) -- hand-written dgrad/wgrad kernels are the next step.
+Training note (round 1): forward is always the HIP path.  When gradients are required the conv unit
+records a torch autograd node (_ConvUnitFn): the DATA gradient runs on the same HIP conv kernels (taps
+flipped, channel roles swapped), the WEIGHT gradient still uses torch's convolution_backward on the
+same channels-last buffers -- a hand-written wgrad kernel is the next step.
 """
 import torch
 import torch.nn as nn
@@ -39,8 +40,8 @@ def _ver(*tensors):
 
 class _ConvUnitFn(torch.autograd.Function):
     """Autograd node around the fused HIP conv unit  y = act(conv(x, w) * scale + shift (+ res)).
-    forward = the HIP kernel (always).  backward (interim, see module docstring) = torch's
-    convolution_backward on the same channels-last buffers.  `w_eff` is the EFFECTIVE weight
+    forward = the HIP kernel (always).  backward: data gradient = the HIP kernel again; weight gradient
+    (interim, see module docstring) = torch's convolution_backward on the same channels-last buffers.  `w_eff` is the EFFECTIVE weight
     [Cout, Cin_eff, kd, kh, kw] (after the unit's channel slice / permutation), produced by
     differentiable view ops so autograd routes its gradient back to the parameter."""
 
@@ -68,14 +69,19 @@ class _ConvUnitFn(torch.autograd.Function):
                 pre = pre - res.float()
             gscale = (g * pre / scale.view(1, 1, 1, 1, -1)).reshape(-1, C).sum(0)
         gconv = g * scale.view(1, 1, 1, 1, -1) if scale is not None else g
-        xv = x.float().permute(0, 4, 1, 2, 3)          # channels-last buffers viewed as NCDHW for aten
-        gv = gconv.permute(0, 4, 1, 2, 3)
-        gx, gw, _ = torch.ops.aten.convolution_backward(gv, xv, w_eff.float(), None, [1, 1, 1], [kk // 2 for kk in k],
-                                                        [1, 1, 1], False, [0, 0, 0], 1,
-                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
-        if gx is not None:
-            gx = gx.permute(0, 2, 3, 4, 1).to(x.dtype)
-        if gw is not None:
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            # data gradient = the SAME fused HIP conv on the output gradient with the taps flipped and the
+            # channel roles swapped (stride 1, SAME padding): no torch / MIOpen kernel on this leg
+            w_t = w_eff.detach().flip(2, 3, 4).transpose(0, 1).contiguous()
+            gin = gconv.to(x.dtype).contiguous()
+            gx = ops.conv_forward(gin, ops.pack_conv_weight(w_t, x.dtype), w_t.shape[0], k, None, None, False, None, None)
+        if ctx.needs_input_grad[1]:
+            # weight gradient (interim): torch's convolution_backward on channels-last views
+            xv = x.float().permute(0, 4, 1, 2, 3)
+            gv = gconv.permute(0, 4, 1, 2, 3)
+            _, gw, _ = torch.ops.aten.convolution_backward(gv, xv, w_eff.float(), None, [1, 1, 1], [kk // 2 for kk in k],
+                                                           [1, 1, 1], False, [0, 0, 0], 1, [False, True, False])
             gw = gw.to(w_eff.dtype)
         return gx, gw, gscale, gshift, gres, None, None
 

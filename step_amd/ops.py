@@ -57,8 +57,8 @@ def _dt(t):
 
 
 def _chan_slice(t):
-    """(base_tensor_ptr_holder, cstride, coff) of a channels-last tensor that may be a slice of the
-    last dim of a wider contiguous buffer."""
+    """Channel stride (elements between consecutive pixels) of a channels-last tensor that may be a slice
+    of the last dim of a wider dense buffer; raises if the tensor is anything else."""
     if t.stride(-1) != 1:
         raise RuntimeError("step_amd: activation is not channels-last")
     cs = t.stride(-2) if t.dim() >= 2 else t.size(-1)
@@ -69,15 +69,6 @@ def _chan_slice(t):
             raise RuntimeError("step_amd: activation must be a channel slice of a dense channels-last buffer")
         exp *= t.size(i)
     return cs
-
-
-class ActView:
-    """A channels-last activation: tensor [N,D,H,W,C] whose last dim may be a slice of a wider buffer."""
-    __slots__ = ("t", "cs")
-
-    def __init__(self, t):
-        self.t = t
-        self.cs = _chan_slice(t)
 
 
 def conv_packed_elems(Cout, Cin, k):

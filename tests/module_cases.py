@@ -90,6 +90,21 @@ def case_basenet_c1_golden(dev, golden):
     assert err < 1e-4, err          # in practice ~1e-6: fp32 MFMA is an exact FMA chain
 
 
+def case_basenet_c1_16bit_error(dev, golden):
+    """bf16 / fp16 storage (fp32 accumulate) through all 45 conv units: measured error against the
+    reference's fp32 output.  8-bit-mantissa storage cannot meet the 1e-3 bar of the fp32 path (SURVEY 7-2);
+    the bound asserted here is what 45 layers of one-rounding-per-layer give in practice."""
+    g = golden("i3d_c1_golden")
+    net = fill(step_amd.BaseNet(cfg())).to(dev).eval()
+    x = R.fill_tensor("golden.c1.images", (1, 8, 3, 112, 112), "image").to(dev)
+    for dt, bound in ((torch.bfloat16, 2e-2), (torch.float16, 4e-3)):
+        with torch.no_grad():
+            y = net(x.to(dt))
+        assert y.dtype == dt
+        e = rel(np_(y), g["conv_feat"])
+        assert e < bound, (dt, e)
+
+
 def case_context_golden(dev, golden):
     g = golden("head_golden")
     net = fill(step_amd.ContextNet(cfg())).to(dev).eval()
@@ -253,4 +268,4 @@ def case_training_step_matches_torch_autograd(dev, golden):
 
 CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_golden", "case_context_golden",
              "case_twobranch_T3_and_losses_golden", "case_roinet_layouts", "case_training_step_matches_torch_autograd"]
-GPU_CASES = CPU_CASES + ["case_twobranch_T9_golden", "case_inference_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
+GPU_CASES = CPU_CASES + ["case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_inference_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
