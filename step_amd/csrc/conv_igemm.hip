@@ -42,7 +42,7 @@ struct ConvParams {
     int N, D, H, W, Cin, Cout;
     int x_cstride, x_coff, y_cstride, y_coff, r_cstride, r_coff;
     int relu;
-    int tiles_h, tiles_w;
+    int tiles_h, tiles_w, tiles_d;
     int nchunks;   // ceil(Cin / 32)
     int nchunks32; // same (the packed-weight K extent is 2*nchunks32 k16 blocks)
     int vec_epi;   // 16-byte output stores are legal (channel strides/offsets % 8 == 0, pointers 16-B aligned)
@@ -370,9 +370,14 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
     constexpr int NT = (MB == 2) ? 512 : 256;   // threads
     constexpr int WM = 8 / MB;                  // waves along the pixel axis (x 2 along channels)
     constexpr int MBP = MB / 2;                 // accumulator rows per wave per epilogue pass
-    constexpr int TW = 1 << TWL, TH = 256 >> TWL;
+    // tile shapes: TWL = 4 -> 1 plane x 16 x 16, TWL = 5 -> 1 x 8 x 32, TWL = 3 -> 4 planes x 8 x 8 (small maps:
+    // 7x7 ROI features would fill 19 % of a 16x16 tile; four planes of 8x8 fill 77 %)
+    constexpr int TDL = (TWL == 3) ? 2 : 0, TD = 1 << TDL;
+    constexpr int TW = 1 << TWL, TH = 256 >> (TWL + TDL);
+    constexpr int THL = (TH == 16) ? 4 : 3;                 // log2(TH): 16 -> 4, 8 -> 3
     constexpr int HH_ = TH + KH - 1, HW_ = TW + KW - 1;
-    constexpr int NPIX = KD * HH_ * HW_;
+    constexpr int PD = TD + KD - 1;                         // input planes under the tile
+    constexpr int NPIX = PD * HH_ * HW_;
     constexpr int ES = (int)sizeof(T);
     constexpr int VEC = 16 / ES;
     constexpr int CKT = 64 / ES;          // channels per slab: 32 (16-bit) / 16 (fp32)
@@ -410,8 +415,8 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
     int t = blockIdx.x;
     const int tw_i = t % p.tiles_w; t /= p.tiles_w;
     const int th_i = t % p.tiles_h; t /= p.tiles_h;
-    const int d = t % p.D;
-    const int n = t / p.D;
+    const int d0 = (t % p.tiles_d) * TD;
+    const int n = t / p.tiles_d;
     const int h0 = th_i * TH, w0 = tw_i * TW;
     const int nb0 = blockIdx.y * NBT;
     const int KC16 = p.nchunks32 * 2;
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int m = wm * (MB * 32) + mb * 32 + (lane & 31);
-        abase[mb] = ldsA + ((m >> TWL) * HW_ + (m & (TW - 1))) * PITCH + khalf * (ES == 4 ? 32 : 16);
+        abase[mb] = ldsA + (((m >> (TWL + THL)) * HH_ + ((m >> TWL) & (TH - 1))) * HW_ + (m & (TW - 1))) * PITCH + khalf * (ES == 4 ? 32 : 16);
     }
 
     f32x16 acc[MB][NB];
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
                 const int c = slab * CKT + slot * VEC;
                 const int plane = pix / (HH_ * HW_), rem = pix % (HH_ * HW_);
                 const int r = rem / HW_, cc = rem % HW_;
-                const int id = d + plane - KD / 2, ih = h0 + r - KH / 2, iw = w0 + cc - KW / 2;
+                const int id = d0 + plane - KD / 2, ih = h0 + r - KH / 2, iw = w0 + cc - KW / 2;
                 const bool inb = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
                 if (inb && c < p.Cin) {
                     const size_t gpix = (((size_t)n * p.D + id) * p.H + ih) * p.W + iw;
@@ -631,10 +636,10 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
                 const int row = idx / G, g = idx % G;
                 // row = (wm*MBP + mbl)*32 + rr  ->  tile pixel wm*(MB*32) + (ps*MBP + mbl)*32 + rr
                 const int mm = ((row >> 5) / MBP) * (MB * 32) + (ps * MBP + (row >> 5) % MBP) * 32 + (row & 31);
-                const int oh = h0 + (mm >> TWL), ow = w0 + (mm & (TW - 1));
+                const int od = d0 + (mm >> (TWL + THL)), oh = h0 + ((mm >> TWL) & (TH - 1)), ow = w0 + (mm & (TW - 1));
                 const int co = nb0 * 32 + g * 8;
-                if (oh < p.H && ow < p.W && co < p.Cout) {
-                    const size_t opix = (((size_t)n * p.D + d) * p.H + oh) * p.W + ow;
+                if (od < p.D && oh < p.H && ow < p.W && co < p.Cout) {
+                    const size_t opix = (((size_t)n * p.D + od) * p.H + oh) * p.W + ow;
                     const f32x4 lo = *(const f32x4*)(ot + row * BN + g * 8);
                     const f32x4 hi = *(const f32x4*)(ot + row * BN + g * 8 + 4);
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -664,13 +669,243 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int mm = wm * (MB * 32) + mb * 32 + cd_row(r, lane);
-                    const int oh = h0 + (mm >> TWL), ow = w0 + (mm & (TW - 1));
-                    if (oh < p.H && ow < p.W) {
-                        const size_t opix = (((size_t)n * p.D + d) * p.H + oh) * p.W + ow;
+                    const int od = d0 + (mm >> (TWL + THL)), oh = h0 + ((mm >> TWL) & (TH - 1)), ow = w0 + (mm & (TW - 1));
+                    if (od < p.D && oh < p.H && ow < p.W) {
+                        const size_t opix = (((size_t)n * p.D + od) * p.H + oh) * p.W + ow;
                         float v = acc[mb][i][r] * sc + sh;
                         if (rg) v += elem<T>::to_f32(rg[opix * p.r_cstride + p.r_coff + co]);
                         if (p.relu) v = fmaxf(v, 0.f);
                         yg[opix * p.y_cstride + p.y_coff + co] = elem<T>::from_f32(v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ============================================================================================
+// conv_pw_kernel -- pointwise (1x1x1) convs / Linear layers with a deep K: a streaming GEMM.
+// 512 threads = 8 wavefronts (4 x 2) own 256 consecutive pixels x (64*NB) channels; each wave a
+// 64-pixel x (32*NB)-channel block.  One pipeline step = one 64-byte slab of input channels (32 x
+// 16-bit / 16 x fp32).  BOTH operands stream: the A slab (256 pixels x 64 B, 80-byte pitch) and the
+// weight tile go global -> one register set each -> three-buffer LDS rings; fragments are double-
+// buffered in registers, so the ds_reads of step s+1 are issued before the MFMAs of step s and there
+// is one barrier per step (the conv_tap_kernel pipeline without a resident halo tile).  Loads are
+// branch-free (clamped addresses + bit masks) so the compiler keeps exact vmcnt waits in the loop.
+template <typename T, int NB>
+__global__ __launch_bounds__(512) void conv_pw_kernel(ConvParams p) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int VEC = 16 / ES;
+    constexpr int CKT = 64 / ES, KS = CKT / 16;
+    constexpr int PITCH = 80;
+    constexpr int ATILE = 256 * PITCH;                       // 20480 B
+    constexpr int FRAGB = 512 * ES, FRAGV = FRAGB / 16;
+    constexpr int NBT = 2 * NB;
+    constexpr int BTILE = NBT * KS * FRAGB;
+    constexpr int BVEC = BTILE / 16;
+    constexpr int Q = (BVEC + 511) / 512;
+    typedef typename frag<T>::type frag_t;
+
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * ATILE + 3 * BTILE];
+    unsigned char* const ldsA = lds;
+    unsigned char* const ldsB = lds + 3 * ATILE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+#ifdef STEP_EMUL
+    const int wave = tid >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const int khalf = lane >> 5;
+    const int wm = wave & 3, wn = wave >> 2;
+    const long long m0 = (long long)blockIdx.x * 256;
+    const int nb0 = blockIdx.y * NBT;
+    const int KC16 = p.nchunks32 * 2;
+    const int S = (p.Cin + CKT - 1) / CKT;
+
+    const unsigned char* xg = (const unsigned char*)p.x;
+    const unsigned char* wg = (const unsigned char*)p.w;
+
+    // A: two 16-byte vectors per thread per step (pixel = v / 4, slot = v % 4)
+    const unsigned char* athr[2];
+    unsigned int amask[2];
+    int acol[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int v = tid + q * 512;
+        const int pix = v >> 2, slot = v & 3;
+        const long long gm = m0 + pix;
+        const bool ok = gm < p.Mtot;
+        athr[q] = xg + ((size_t)(ok ? gm : 0) * p.x_cstride + p.x_coff) * ES;
+        amask[q] = ok ? 0xffffffffu : 0u;
+        acol[q] = slot * VEC;
+    }
+    // B: this thread's vectors of a step tile (as conv_tap_kernel)
+    const unsigned char* wthr[Q];
+    int ldsoff[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int v = min(tid + q * 512, BVEC - 1);
+        const int f = v / FRAGV, within = v % FRAGV;
+        const int nbl = f / KS, ks = f % KS;
+        const int nbg = min(nb0 + nbl, p.nblk32 - 1);
+        wthr[q] = wg + ((size_t)nbg * KC16 + ks) * FRAGB + within * 16;
+        ldsoff[q] = (tid + q * 512 < BVEC) ? (tid + q * 512) * 16 : -1;
+    }
+    u32x4 RA[2], RB[Q];
+    auto load_step = [&](int s_) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = s_ * CKT + acol[q];
+            const bool cok = c < p.Cin;                                   // whole vector in or out (Cin % VEC == 0)
+            const u32x4 raw = *(const u32x4*)(athr[q] + (size_t)(cok ? c : 0) * ES);
+            const unsigned int mk = cok ? amask[q] : 0u;
+            RA[q] = raw & mk;
+        }
+        const size_t off = (size_t)(s_ * KS) * FRAGB;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) RB[q] = *(const u32x4*)(wthr[q] + off);
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int v = tid + q * 512;
+            *(u32x4*)(ldsA + buf * ATILE + (v >> 2) * PITCH + ((v & 3) << 4)) = RA[q];
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+            if (ldsoff[q] >= 0) *(u32x4*)(ldsB + buf * BTILE + ldsoff[q]) = RB[q];
+    };
+
+    const unsigned char* abase[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) abase[mb] = ldsA + (wm * 64 + mb * 32 + (lane & 31)) * PITCH + khalf * (ES == 4 ? 32 : 16);
+    const unsigned char* const bwave = ldsB + (wn * NB) * KS * FRAGB + lane * (8 * ES);
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][i][r] = 0.f;
+
+    frag_t fa[2][KS][2], fb[2][KS][NB];
+    auto read_frags = [&](auto setc, int buf) {
+        constexpr int SET = decltype(setc)::value;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) fa[SET][j][mb] = lds_read_bfrag<T>(abase[mb] + buf * ATILE + j * 32);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) fb[SET][j][i] = lds_read_bfrag<T>(bwave + buf * BTILE + (i * KS + j) * FRAGB);
+        }
+    };
+    auto mma_all = [&](auto setc) {
+        constexpr int SET = decltype(setc)::value;
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                mma_k16(fa[SET][j][0], fb[SET][j][i], acc[0][i], T());
+                mma_k16(fa[SET][j][1], fb[SET][j][i], acc[1][i], T());
+            }
+    };
+
+    load_step(0); store_step(0);
+    if (S > 1) { load_step(1); store_step(1); }
+    if (S > 2) load_step(2);
+    __syncthreads();
+    read_frags(std::integral_constant<int, 0>(), 0);
+
+    int b1 = 1, b2 = 2, s_ = 0;
+    auto step = [&](auto setc) {
+        constexpr int SET = decltype(setc)::value;
+        if (s_ + 1 < S) read_frags(std::integral_constant<int, SET ^ 1>(), b1);
+        mma_all(setc);
+        if (s_ + 2 < S) store_step(b2);
+        if (s_ + 3 < S) load_step(s_ + 3);
+        __syncthreads();
+        const int nb = (b2 == 2) ? 0 : b2 + 1;
+        b1 = b2; b2 = nb;
+        ++s_;
+    };
+#pragma unroll 1
+    while (s_ < S) {
+        step(std::integral_constant<int, 0>());
+        if (s_ < S) step(std::integral_constant<int, 1>());
+    }
+
+    // ---- epilogue (two destinations supported)
+    T* yg = (T*)p.y;
+    const T* rg = (const T*)p.res;
+    if (ES == 2 && p.vec_epi) {
+        constexpr int BN = NBT * 32, G = BN / 8;
+        float* ot = (float*)lds;
+        float sc[NB], sh[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int co = min((nb0 + wn * NB + i) * 32 + (lane & 31), p.Cout - 1);
+            sc[i] = p.scale ? p.scale[co] : 1.f;
+            sh[i] = p.shift ? p.shift[co] : 0.f;
+        }
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            if (mb) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ot[(wm * 32 + cd_row(r, lane)) * BN + (wn * NB + i) * 32 + (lane & 31)] = acc[mb][i][r] * sc[i] + sh[i];
+            __syncthreads();
+            for (int idx = tid; idx < 128 * G; idx += 512) {
+                const int row = idx / G, g = idx % G;
+                const long long gm = m0 + (row >> 5) * 64 + mb * 32 + (row & 31);
+                const int co = nb0 * 32 + g * 8;
+                if (gm < p.Mtot && co < p.Cout) {
+                    const size_t opix = (size_t)gm;
+                    const f32x4 lo = *(const f32x4*)(ot + row * BN + g * 8);
+                    const f32x4 hi = *(const f32x4*)(ot + row * BN + g * 8 + 4);
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if (rg) {
+                        const u16x8 rv = *(const u16x8*)(rg + opix * p.r_cstride + p.r_coff + co);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += elem<T>::from_bits16(rv[e]);
+                    }
+                    u16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = elem<T>::bits16(p.relu ? fmaxf(v[e], 0.f) : v[e]);
+                    if (p.split > 0 && co >= p.split)
+                        *(u16x8*)((T*)p.y2 + opix * p.y2_cstride + p.y2_coff + (co - p.split)) = o;
+                    else
+                        *(u16x8*)(yg + opix * p.y_cstride + p.y_coff + co) = o;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int nbg = nb0 + wn * NB + i;
+        const int co = nbg * 32 + (lane & 31);
+        if (nbg < p.nblk32 && co < p.Cout) {
+            const float sc = p.scale ? p.scale[co] : 1.f;
+            const float sh = p.shift ? p.shift[co] : 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long gm = m0 + wm * 64 + mb * 32 + cd_row(r, lane);
+                    if (gm < p.Mtot) {
+                        const size_t opix = (size_t)gm;
+                        float v = acc[mb][i][r] * sc + sh;
+                        if (rg) v += elem<T>::to_f32(rg[opix * p.r_cstride + p.r_coff + co]);
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        if (p.split > 0 && co >= p.split)
+                            ((T*)p.y2)[opix * p.y2_cstride + p.y2_coff + (co - p.split)] = elem<T>::from_f32(v);
+                        else
+                            yg[opix * p.y_cstride + p.y_coff + co] = elem<T>::from_f32(v);
                     }
                 }
             }
@@ -1113,7 +1348,7 @@ static int pick_nb(int nblk32, long long mtiles) {
 // attribute time and work to the kernel name rocprofv3 reports).
 //   impl 0: conv_igemm_kernel (4 waves, 128-px tile, weights straight from L2)  -- 1x1x1 and small problems
 //   impl 1: conv_tap_kernel   (8 waves, 256-px tile, weights through an LDS-DMA double buffer)
-struct ConvPlan { bool ok, flat, wide, deep; int impl, NB, tps, mb, tiles_h, tiles_w; long long mtiles; };
+struct ConvPlan { bool ok, flat, wide, deep; int impl, NB, tps, mb, twl, tiles_h, tiles_w, tiles_d; long long mtiles; };
 
 static int pick_nb_tap(int nblk32, long long mtiles) {
     int best = 1;
@@ -1132,13 +1367,22 @@ static int conv_impl_override() {   // tuning aid: STEP_CONV_IMPL=igemm|tap|tap2
     const char* e = getenv("STEP_CONV_IMPL");
     if (!e) return -1;
     if (e[0] == 'i') return 0;
+    if (e[0] == 'p') return 5;      // pw: force the streaming pointwise GEMM for every 1x1x1 conv
     if (e[0] == 't') return (e[1] && e[2] && e[3] == '2') ? 2 : ((e[1] && e[2] && e[3] == '4') ? 4 : 1);
     return -1;
 }
 
+// A kernel with kd == 1 never looks across planes, so clips and frames are one axis: fold N into D.  The
+// plane-folded tile shape then also applies to [N*T, 1, 7, 7, C] head tensors without the caller reshaping.
+static step_conv_desc canonical_desc(const step_conv_desc* d) {
+    step_conv_desc e = *d;
+    if (e.kd == 1 && (long long)e.N * e.D <= 0x7fffffffLL) { e.D *= e.N; e.N = 1; }
+    return e;
+}
+
 static ConvPlan conv_plan(const step_conv_desc* d) {
     ConvPlan pl;
-    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1; pl.mb = 2; pl.deep = false;
+    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1; pl.mb = 2; pl.deep = false; pl.twl = 4; pl.tiles_d = d->D;
     const int nblk32 = ceil_div(d->Cout, 32);
     const bool k1 = d->kd == 1 && d->kh == 1 && d->kw == 1;
     const bool k333 = d->kd == 3 && d->kh == 3 && d->kw == 3;
@@ -1147,16 +1391,31 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
     if (k1) {
         pl.mtiles = ceil_div64((long long)d->N * d->D * d->H * d->W, 128);
         pl.NB = pick_nb(nblk32, pl.mtiles);
+        // deep-K pointwise convs on enough pixels: the streaming 8-wave GEMM (STEP_CONV_IMPL=igemm forces the other)
+        const long long mt256 = ceil_div64((long long)d->N * d->D * d->H * d->W, 256);
+        const int ov1 = conv_impl_override();
+        if (ov1 == 5 || (ov1 != 0 && d->Cin >= 128 && d->Cout >= 64 && mt256 * ceil_div(nblk32, 2) >= 32)) {
+            pl.impl = 2;
+            pl.mtiles = mt256;
+            pl.NB = pick_nb_tap(nblk32, mt256);
+            return pl;
+        }
         pl.deep = d->Cin >= 256;        // 128-channel slabs: 4x fewer barriers along a deep K
         if (const char* e = getenv("STEP_CONV_DEEP")) pl.deep = (e[0] == '1');   // tuning aid
         return pl;
     }
     if (!k333 && !k133) { pl.ok = false; pl.mtiles = 0; pl.NB = 1; return pl; }
     const int ov = conv_impl_override();
-    // 256-pixel tiles (16x16 or 8x32), whichever wastes fewer pixels on this H x W
-    const long long t16 = (long long)ceil_div(d->H, 16) * ceil_div(d->W, 16);
-    const long long t32 = (long long)ceil_div(d->H, 8) * ceil_div(d->W, 32);
-    const long long mt256 = (long long)d->N * d->D * (t32 < t16 ? t32 : t16);
+    // 256-pixel tiles: 1 plane x 16x16, 1 x 8x32 or 4 planes x 8x8 -- whichever covers N x D x H x W with the
+    // fewest tiles (ties: in that order)
+    const long long t16 = (long long)d->D * ceil_div(d->H, 16) * ceil_div(d->W, 16);
+    const long long t32 = (long long)d->D * ceil_div(d->H, 8) * ceil_div(d->W, 32);
+    const long long t8 = (long long)ceil_div(d->D, 4) * ceil_div(d->H, 8) * ceil_div(d->W, 8);
+    int twl = 4;
+    long long tbest = t16;
+    if (t32 < tbest) { tbest = t32; twl = 5; }
+    if (t8 < tbest) { tbest = t8; twl = 3; }
+    const long long mt256 = (long long)d->N * tbest;
     // small-Cin / few-tile problems stay on the 4-wave kernel (measured: tap wins from Cin >= 64, or
     // Cin >= 32 on the large maps)
     const bool use_tap = ov >= 1 || (ov != 0 && (d->Cin >= 64 || (d->Cin >= 32 && mt256 >= 256)));
@@ -1164,9 +1423,11 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
         pl.impl = 1;
         pl.tps = (ov == 1) ? 1 : 2;     // two taps per barrier measured 6-15 % faster than one (STEP_CONV_IMPL=tap forces one)
         pl.mb = (ov == 4) ? 4 : 2;      // STEP_CONV_IMPL=tap4: the 4-wave, 128-pixel-per-wave variant
-        pl.wide = t32 < t16;
-        pl.tiles_h = pl.wide ? ceil_div(d->H, 8) : ceil_div(d->H, 16);
-        pl.tiles_w = pl.wide ? ceil_div(d->W, 32) : ceil_div(d->W, 16);
+        pl.twl = twl;
+        pl.wide = twl == 5;
+        pl.tiles_d = twl == 3 ? ceil_div(d->D, 4) : d->D;
+        pl.tiles_h = twl == 4 ? ceil_div(d->H, 16) : ceil_div(d->H, 8);
+        pl.tiles_w = twl == 4 ? ceil_div(d->W, 16) : (twl == 5 ? ceil_div(d->W, 32) : ceil_div(d->W, 8));
         pl.mtiles = mt256;
         pl.NB = pick_nb_tap(nblk32, pl.mtiles);
         return pl;
@@ -1215,11 +1476,23 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, step_stream_t s
     if (((uintptr_t)p.x % 16) || ((uintptr_t)p.w % 16)) return STEP_E_ALIGN;
     const ConvPlan pl = conv_plan(d);
     if (!pl.ok) return STEP_E_UNSUPPORTED;
-    p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w;
+    p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.tiles_d = pl.tiles_d;
+    if (pl.impl == 2) {
+        dim3 grid((unsigned)pl.mtiles, (unsigned)ceil_div(p.nblk32, 2 * pl.NB));
+        switch (pl.NB) {
+            case 1: STEP_LAUNCH((conv_pw_kernel<T, 1>), grid, dim3(512), stream, p); break;
+            case 2: STEP_LAUNCH((conv_pw_kernel<T, 2>), grid, dim3(512), stream, p); break;
+            default: STEP_LAUNCH((conv_pw_kernel<T, 3>), grid, dim3(512), stream, p); break;
+        }
+        return STEP_LAUNCH_CHECK();
+    }
     if (pl.impl == 1) {
         dim3 grid((unsigned)pl.mtiles, (unsigned)ceil_div(p.nblk32, 2 * pl.NB));
-        if (d->kd == 3)
+        if (d->kd == 3) {
+            if (pl.twl == 3) return launch_tap<T, 3, 3, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
             return pl.wide ? launch_tap<T, 5, 3, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream) : launch_tap<T, 4, 3, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
+        }
+        if (pl.twl == 3) return launch_tap<T, 3, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
         return pl.wide ? launch_tap<T, 5, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream) : launch_tap<T, 4, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
     }
     dim3 grid((unsigned)pl.mtiles, (unsigned)ceil_div(p.nblk32, pl.NB));
@@ -1287,6 +1560,8 @@ int step_conv_forward(const step_conv_desc* d, const void* x, const void* w_pack
     if (res && (d->res_coff < 0 || d->res_coff + d->Cout > d->res_cstride)) return STEP_E_SHAPE;
     if (d->N == 0) return STEP_OK;
     if (!x || !w_packed || !y) return STEP_E_NULL;
+    const step_conv_desc canon = canonical_desc(d);
+    d = &canon;
     ConvParams p;
     p.x = x; p.w = w_packed; p.scale = scale; p.shift = shift; p.res = res; p.y = y; p.y2 = y2;
     p.split = split; p.y2_cstride = d->y2_cstride; p.y2_coff = d->y2_coff;
@@ -1294,7 +1569,7 @@ int step_conv_forward(const step_conv_desc* d, const void* x, const void* w_pack
     p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
     p.r_cstride = d->res_cstride; p.r_coff = d->res_coff;
     p.relu = d->relu;
-    p.tiles_h = p.tiles_w = 0;
+    p.tiles_h = p.tiles_w = 0; p.tiles_d = d->D;
     p.nchunks = ceil_div(d->Cin, CK);
     p.nchunks32 = p.nchunks;
     p.vec_epi = (d->y_cstride % 8 == 0) && (d->y_coff % 8 == 0) && (d->Cout % 8 == 0) && (((uintptr_t)y) % 16 == 0) &&
@@ -1352,12 +1627,16 @@ int step_stem_forward(int dtype, const void* x, int N, int T, int H, int W, cons
 
 int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
     if (!d || !buf || buflen <= 0) return STEP_E_NULL;
+    const step_conv_desc canon = canonical_desc(d);
+    d = &canon;
     const ConvPlan pl = conv_plan(d);
     if (!pl.ok) return STEP_E_UNSUPPORTED;
     const char* t = d->dtype == STEP_F32 ? "float" : (d->dtype == STEP_BF16 ? "step::bf16_t" : "step::f16_t");
-    if (pl.impl == 1)
+    if (pl.impl == 2)
+        snprintf(buf, (size_t)buflen, "void step::conv_pw_kernel<%s, %d>(step::ConvParams)", t, pl.NB);
+    else if (pl.impl == 1)
         snprintf(buf, (size_t)buflen, "void step::conv_tap_kernel<%s, %d, %d, %d, %d, %d, %d, %d>(step::ConvParams)", t,
-                 pl.wide ? 5 : 4, pl.NB, d->kd, d->kh, d->kw, pl.mb == 4 ? 2 : pl.tps, pl.mb);
+                 pl.twl, pl.NB, d->kd, d->kh, d->kw, pl.mb == 4 ? 2 : pl.tps, pl.mb);
     else
         snprintf(buf, (size_t)buflen, "void step::conv_igemm_kernel<%s, %d, %d, %d, %d, %d, %s, %d>(step::ConvParams)", t,
                  pl.flat ? 4 : (pl.wide ? 5 : 4), pl.NB, d->kd, d->kh, d->kw, pl.flat ? "true" : "false", pl.deep ? 128 : 32);

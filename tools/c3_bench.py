@@ -85,7 +85,22 @@ def main():
           % (el * 1e3, a.batch / el, err))
     # stage split
     with torch.no_grad():
-        for name, fn in (("backbone", lambda: base(x)),):
+        cf0 = base(x)
+        cx0 = ctx(cf0)
+        from step_amd.driver import _flat_tubes
+        flat0, nums0 = _flat_tubes(tubes, dev)
+        pooled3 = nets["roi_net"](cf0[:, 3:6], flat0).reshape(-1, 3, 832, 7, 7)
+        flat9 = torch.cat([flat0, flat0, flat0], 1).clone()
+        flat9[:, :, 0] = (flat0[:, :1, 0] // 3 * 9) + torch.arange(9, device=dev).view(1, 9)
+        pooled9 = nets["roi_net"](cf0, flat9).reshape(-1, 9, 832, 7, 7)
+        clip_of = torch.as_tensor(np.repeat(np.arange(len(nums0)), nums0), device=dev)
+        c3_ = cx0[clip_of][:, :, 3:6]
+        c9_ = cx0[clip_of]
+        for name, fn in (("backbone", lambda: base(x)), ("context", lambda: ctx(cf0)),
+                         ("roialign T3", lambda: nets["roi_net"](cf0[:, 3:6], flat0)),
+                         ("roialign T9", lambda: nets["roi_net"](cf0, flat9)),
+                         ("head T=3", lambda: nets["det_net0"](pooled3, context_feat=c3_)),
+                         ("head T=9", lambda: nets["det_net2"](pooled9, context_feat=c9_))):
             fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(a.iters):
                 fn()
