@@ -165,6 +165,8 @@ STEP_API int step_stem_pack_weight(const float* w /*[Cout,3,7,7,7]*/, int Cout, 
 STEP_API int step_stem_forward(int dtype, const void* x, int N, int T, int H, int W, const void* w_packed,
                                const float* scale, const float* shift, int Cout, void* y, int y_cstride,
                                int y_coff, step_stream_t stream);
+/* Diagnostic, as step_conv_kernel_name: the kernel step_stem_forward launches for this dtype. */
+STEP_API int step_stem_kernel_name(int dtype, char* buf, int buflen);
 
 /* ------------------------------------------------------------------------------------------
  * TF-"SAME" max pool on channels-last activations.  replaces MaxPool3dTFPadding =

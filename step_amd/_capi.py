@@ -4,7 +4,7 @@ import ctypes as C
 
 F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 vp, fp, ip, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # raw device addresses
 i, f, ll, sz = C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -33,6 +33,7 @@ SIGNATURES = {
     "step_stem_packed_elems": (sz, [i]),
     "step_stem_pack_weight": (i, [fp, i, i, vp, vp]),
     "step_stem_forward": (i, [i, vp, i, i, i, i, vp, fp, fp, i, vp, i, i, vp]),
+    "step_stem_kernel_name": (i, [i, C.c_char_p, i]),
     "step_pool_out_size": (i, [i, i, i]),
     "step_maxpool3d_tf": (i, [i, vp, i, i, i, i, i, i, i, i, i, i, i, i, i, vp, i, i, vp]),
     "step_avgpool_hw": (i, [i, vp, i, i, i, i, i, i, i, vp, vp]),

@@ -12,8 +12,11 @@
 
 #ifdef STEP_EMUL
 #include "hipemu.h"
+#define STEP_WAVES_PER_SIMD(n)
 #else
 #include <hip/hip_runtime.h>
+// register budget: make the compiler fit n wavefronts per SIMD (512 / n VGPRs each)
+#define STEP_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #endif
 
 #include "../../include/step_amd.h"

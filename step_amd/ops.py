@@ -134,9 +134,9 @@ def stem_forward(x, w_packed, Cout, scale, shift, out=None):
     prof = _NOPROF
     if PROFILE is not None:
         pix = N * To * Ho * Wo
-        kname = "void step::stem_igemm_kernel<float, 2>(step::StemParams)" if x.dtype == torch.float32 else \
-            "void step::stem_tap_kernel<%s>(step::StemParams)" % _TNAME[x.dtype]
-        prof = _Prof(kname, 2.0 * pix * Cout * 1029,
+        buf = ctypes.create_string_buffer(256)
+        _capi.check(L.step_stem_kernel_name(_dt(x), buf, 256), "step_stem_kernel_name")
+        prof = _Prof(buf.value.decode(), 2.0 * pix * Cout * 1029,
                      (x.numel() + pix * Cout + Cout * 1029) * _ES[x.dtype])
     with prof:
         _capi.check(L.step_stem_forward(_dt(x), _lib.dptr(x), N, T, H, W, _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift),
