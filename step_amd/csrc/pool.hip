@@ -8,6 +8,7 @@
 // (models/two_branch.py:127).  Both are pure HBM-bound streaming ops: lanes run along C in
 // 16-byte vectors, so every tap is a fully coalesced row segment.
 #include "common.h"
+#include <stdlib.h>
 
 namespace step {
 
@@ -98,98 +99,222 @@ __global__ void maxpool3d_tf_kernel(const T* __restrict__ x, T* __restrict__ y, 
     }
 }
 
-// 3x3x3, stride 1, TF-SAME (pad 1 each side, zero-VALUED) max pool -- the `branch_3` pool of every
-// Inception block (models/i3dpt.py:151-155).
-// A 256-thread workgroup owns an 8x16-pixel x 64-byte (32 x 16-bit / 16 x fp32 channels) column of the
-// volume and walks along D with a rolling window of input planes in LDS (4 slots of [10][18] pixels: the
-// three planes of the current window + the one being fetched).  Every input plane is read from global
-// memory ONCE per column (1.4x the tile with its halo) instead of 27 times, the next plane's loads fly
-// while the current outputs are computed from LDS, and every lane moves 16 bytes.
-template <typename T>
-__global__ __launch_bounds__(256) void maxpool333_s1_kernel(const T* __restrict__ x, T* __restrict__ y, PoolParams p,
-                                                            int tiles_h, int tiles_w, int cchunks, int dseg) {
+// element-wise max of two 16-byte channel vectors in the storage type (the max of two representable
+// values is representable: no rounding anywhere in a max pool).  enc / dec map a vector to and from the
+// form the max is taken in.
+template <typename T> struct VecMax;
+template <> struct VecMax<float> {
+    __device__ static __forceinline__ f32x4 enc(const f32x4& a) { return a; }
+    __device__ static __forceinline__ f32x4 dec(const f32x4& a) { return a; }
+    __device__ static __forceinline__ f32x4 lowest() { const float m = -__builtin_inff(); f32x4 r = {m, m, m, m}; return r; }
+    __device__ static __forceinline__ f32x4 max(const f32x4& a, const f32x4& b) {
+        f32x4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = fmaxf(a[i], b[i]);
+        return r;
+    }
+};
+#ifndef STEP_EMUL
+template <> struct VecMax<f16_t> {
+    __device__ static __forceinline__ u16x8 enc(const u16x8& a) { return a; }
+    __device__ static __forceinline__ u16x8 dec(const u16x8& a) { return a; }
+    __device__ static __forceinline__ u16x8 lowest() { u16x8 r; for (int i = 0; i < 8; ++i) r[i] = 0xfc00; return r; }   // -inf
+    __device__ static __forceinline__ u16x8 max(const u16x8& a, const u16x8& b) {          // v_pk_max_f16
+        return __builtin_bit_cast(u16x8, __builtin_elementwise_max(__builtin_bit_cast(f16x8_hw, a), __builtin_bit_cast(f16x8_hw, b)));
+    }
+};
+template <> struct VecMax<bf16_t> {
+    // gfx950 has no packed bf16 max, and widening to fp32 costs ~9 VALU ops per pair (measured: the pool was
+    // VALU-bound).  A sign-magnitude float orders like the unsigned integer  x ^ (x < 0 ? 0xffff : 0x8000),
+    // so planes are re-keyed once when they enter LDS (3 ops per pair), every max is one v_pk_max_u16 per pair,
+    // and the result is mapped back once before the store.  (-0 < +0 and NaN above +inf: NaN propagates.)
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    __device__ static __forceinline__ u16x8 enc(const u16x8& a) {
+        const u16x8 neg = __builtin_bit_cast(u16x8, __builtin_bit_cast(s16x8, a) >> 15);   // 0xffff where negative
+        return a ^ (neg | (unsigned short)0x8000);
+    }
+    __device__ static __forceinline__ u16x8 dec(const u16x8& k) {
+        const u16x8 pos = __builtin_bit_cast(u16x8, __builtin_bit_cast(s16x8, k) >> 15);   // 0xffff where the value was >= 0
+        return k ^ (~pos | (unsigned short)0x8000);
+    }
+    __device__ static __forceinline__ u16x8 lowest() { u16x8 r; for (int i = 0; i < 8; ++i) r[i] = 0; return r; }        // below every key
+    __device__ static __forceinline__ u16x8 max(const u16x8& a, const u16x8& b) { return __builtin_elementwise_max(a, b); }
+};
+#else
+template <typename T> struct VecMax {
+    __device__ static inline u16x8 enc(const u16x8& a) { return a; }
+    __device__ static inline u16x8 dec(const u16x8& a) { return a; }
+    __device__ static inline u16x8 lowest() {                                  // -inf in the storage type
+        float f[8];
+        for (int i = 0; i < 8; ++i) f[i] = -__builtin_inff();
+        return Vec16<T, 8>::pack(f);
+    }
+    __device__ static inline u16x8 max(const u16x8& a, const u16x8& b) {
+        float fa[8], fb[8];
+        Vec16<T, 8>::unpack(a, fa); Vec16<T, 8>::unpack(b, fb);
+        for (int i = 0; i < 8; ++i) fa[i] = fmaxf(fa[i], fb[i]);
+        return Vec16<T, 8>::pack(fa);
+    }
+};
+#endif
+
+// Separable TF-SAME max pool for the window / stride combinations of the backbone:
+//   (3,3,3)/(1,1,1)  the branch_3 pool of every Inception block (models/i3dpt.py:151-155)
+//   (1,3,3)/(1,2,2)  maxPool3d_2a_3x3, maxPool3d_3a_3x3      (models/i3dpt.py:193,199)
+//   (3,3,3)/(2,2,2)  maxPool3d_4a_3x3                        (models/i3dpt.py:206)
+// HBM-bound work: 2 bytes moved per element against up to 26 comparisons, so the job is to touch every input
+// element once and to keep the comparisons cheap.
+// A 256-thread workgroup owns a tile of TH x TW output pixels x 64 bytes of channels and walks along D.
+// The 3-D max is separable and done in three stages per input plane:
+//   W : the plane's input tile (LDS, (TH-1)*SH+KH rows x (TW-1)*SW+KW cols) -> row-wise KW-max at stride SW -> 2nd LDS buffer
+//   H : column-wise KH-max at stride SH of that buffer -> the plane's 2-D window max, in registers
+//   D : max with the previous planes' 2-D maxima, which every thread keeps in registers (rolling window);
+//       an output plane is emitted every SD input planes
+// i.e. KW + KH LDS reads per 16-byte 2-D result instead of KD*KH*KW global reads per output, every input plane is
+// read from global memory once per column (the next plane's loads fly during the two passes), and all
+// comparisons run in the storage type (VecMax).  Padding follows PoolParams: a position inside the explicit TF
+// pad carries 0, a position beyond it (ceil-mode overhang) carries the lowest key and never wins.
+// Tiles: at most 14x14 outputs at stride 1 and 7x7 at stride 2 (a 16x16 / 15x15 input tile); 28x28 maps split
+// into 2x2 stride-1 tiles whose halos are L2 hits (the launch order keeps neighbouring tiles on one XCD).
+constexpr int PP_SL = 4;                            // 16-byte vectors per pixel per workgroup (64 B contiguous)
+constexpr int PP_R = 4;                             // load items per thread per plane: 16*16*4 / 256
+constexpr int PP_MAXIN = 16;                        // max input tile edge
+
+template <typename T, int KD, int KH, int KW, int SD, int SH, int SW>
+__global__ __launch_bounds__(256) void maxpool_sep_kernel(const T* __restrict__ x, T* __restrict__ y, PoolParams p,
+                                                          int TH, int TW, int tiles_h, int tiles_w, int cchunks, int dseg, int nseg) {
     constexpr int V = elem<T>::VEC;
     typedef typename Vec16<T, V>::raw raw;
-    constexpr int TH = 8, TW = 16, HH = TH + 2, HW = TW + 2, SL = 4;       // SL 16-byte slots per pixel
-    constexpr int PLANE = HH * HW * SL;                                      // vectors per plane (720)
-    constexpr int NLD = (PLANE + 255) / 256;                                 // vectors per thread per plane (3)
-    __shared__ __attribute__((aligned(16))) raw lds[4 * PLANE];
+    constexpr int SL = PP_SL, R = PP_R;
+    __shared__ __attribute__((aligned(16))) raw lds_raw[PP_MAXIN * PP_MAXIN * SL];
+    __shared__ __attribute__((aligned(16))) raw lds_w[PP_MAXIN * PP_MAXIN * SL];
 
     const int tid = threadIdx.x;
+    // launch order -> XCD: consecutive workgroup ids go round-robin over the 8 XCDs; remap so that ids that
+    // are neighbours in (tile, D segment) order -- which share halos -- land on the same XCD (one L2)
     int t = blockIdx.x;
-    const int cc = t % cchunks; t /= cchunks;
+    if ((gridDim.x & 7) == 0) t = (t & 7) * (gridDim.x >> 3) + (t >> 3);
     const int tw_i = t % tiles_w; t /= tiles_w;
-    const int th_i = t % tiles_h;
-    const int n = t / tiles_h;
-    const int h0 = th_i * TH, w0 = tw_i * TW;
-    const int c0 = cc * SL * V;                                              // first channel of this chunk
+    const int th_i = t % tiles_h; t /= tiles_h;
+    const int seg = t % nseg; t /= nseg;
+    const int cc = t % cchunks;
+    const int n = t / cchunks;
+    const int oh0 = th_i * TH, ow0 = tw_i * TW;
+    const int c0 = cc * SL * V;
+    const int IR = (TH - 1) * SH + KH, IC = (TW - 1) * SW + KW;      // input tile
 
     raw zero;
 #pragma unroll
     for (int i = 0; i < V; ++i) zero[i] = 0;
+    const raw kzero = VecMax<T>::enc(zero), klow = VecMax<T>::lowest();
 
-    auto load_plane = [&](int d, raw (&r)[NLD]) {                            // global -> registers (zero outside)
+    // ---- per-thread item tables (the same every plane)
+    int ld_goff[R], ld_loff[R];          // load items: element offset inside a plane (-1: pad = 0, -2: overhang = lowest), LDS index (-1: none)
+    int wp_off[R];                       // W-pass items: lds_raw index of the window's first vector (lds_w index = the item itself)
+    const int n_ld = IR * IC * SL, n_wp = IR * TW * SL, n_hp = TH * TW * SL;
 #pragma unroll
-        for (int q = 0; q < NLD; ++q) {
-            const int v = tid + q * 256;
+    for (int q = 0; q < R; ++q) {
+        const int item = tid + q * 256;
+        {
+            const int sl = item % SL, pix = item / SL;
+            const int r = pix / IC, cl = pix % IC;
+            const int pr = oh0 * SH + r, pc = ow0 * SW + cl;           // padded coordinates
+            const int ih = pr - p.pfh, iw = pc - p.pfw, c = c0 + sl * V;
+            ld_loff[q] = item < n_ld ? item : -1;
+            ld_goff[q] = (pr >= p.Lph || pc >= p.Lpw) ? -2
+                       : ((ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && c < p.C) ? (ih * p.W + iw) * p.x_cstride + p.x_coff + c : -1);
+        }
+        {
+            const int sl = item % SL, pix = item / SL;
+            const int r = pix / TW, ow = pix % TW;
+            wp_off[q] = item < n_wp ? (r * IC + ow * SW) * SL + sl : -1;
+        }
+    }
+    // H-pass items: lds_w index of the window's first vector, output offset inside a plane (-1: none);
+    // TH*TW*SL <= 784 items at stride 1 (4 per thread), <= 196 at stride 2 (1 per thread)
+    constexpr int RH = (SH == 1 && SW == 1) ? R : 1;
+    int hp_offs[RH], hp_goffs[RH];
+#pragma unroll
+    for (int q = 0; q < RH; ++q) {
+        const int item = tid + q * 256;
+        const int sl = item % SL, pix = item / SL;
+        const int oh = pix / TW, ow = pix % TW;
+        const int gh = oh0 + oh, gw = ow0 + ow, c = c0 + sl * V;
+        hp_offs[q] = item < n_hp ? (oh * SH * TW + ow) * SL + sl : -1;
+        hp_goffs[q] = (item < n_hp && gh < p.Ho && gw < p.Wo && c < p.C) ? (gh * p.Wo + gw) * p.y_cstride + p.y_coff + c : -1;
+    }
+    const size_t xplane = (size_t)p.H * p.W * p.x_cstride, yplane = (size_t)p.Ho * p.Wo * p.y_cstride;
+    const T* xn = x + (size_t)n * p.D * xplane;
+    T* yn = y + (size_t)n * p.Do * yplane;
+
+    // padded plane pd <-> input plane pd - pfd; class 0: real, 1: explicit pad (all zero), 2: beyond the pad (never wins)
+    auto plane_class = [&](int pd) { return pd >= p.Lpd ? 2 : ((pd - p.pfd >= 0 && pd - p.pfd < p.D) ? 0 : 1); };
+    auto load_plane = [&](int pd, raw (&r)[R]) {
+        const int d = pd - p.pfd;
+        const bool real = plane_class(pd) == 0;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
             raw val = zero;
-            if (v < PLANE && d >= 0 && d < p.D) {
-                const int pix = v / SL, sl = v % SL;
-                const int ih = h0 + pix / HW - 1, iw = w0 + pix % HW - 1;
-                const int c = c0 + sl * V;
-                if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && c < p.C)
-                    val = *(const raw*)(x + ((((size_t)n * p.D + d) * p.H + ih) * p.W + iw) * p.x_cstride + p.x_coff + c);
-            }
+            if (real && ld_goff[q] >= 0) val = *(const raw*)(xn + (size_t)d * xplane + ld_goff[q]);
             r[q] = val;
         }
     };
-    auto store_plane = [&](int slot, const raw (&r)[NLD]) {
-#pragma unroll
-        for (int q = 0; q < NLD; ++q) {
-            const int v = tid + q * 256;
-            if (v < PLANE) lds[slot * PLANE + v] = r[q];
-        }
-    };
 
-    // this workgroup walks the planes [dbeg, dend) of its column (grid.y segments along D: more workgroups
-    // in flight on the small maps; a segment re-reads one halo plane on each side)
-    const int dbeg = blockIdx.y * dseg, dend = min(dbeg + dseg, p.D);
-    raw r[NLD];
-    load_plane(dbeg - 1, r); store_plane((dbeg - 1) & 3, r);
-    load_plane(dbeg, r);     store_plane(dbeg & 3, r);
-    load_plane(dbeg + 1, r);                        // in flight
-    for (int d = dbeg; d < dend; ++d) {
-        store_plane((d + 1) & 3, r);                // plane d+1 (zero plane when d+1 == D)
-        __syncthreads();
-        if (d + 2 <= p.D) load_plane(d + 2, r);     // next window's new plane flies during the compute below
-        // outputs of plane d: 128 pixels x 4 vectors = 512 items, 2 per thread
+    // output planes [obeg, oend) of this column <- padded input planes [obeg*SD, (oend-1)*SD + KD)
+    const int obeg = seg * dseg, oend = min(obeg + dseg, p.Do);
+    const int pbeg = obeg * SD, pend = (oend - 1) * SD + KD;
+    raw rg[R], m1[RH], m2[RH];                           // plane in flight; 2-D maxima of the two previous planes
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int item = tid + q * 256;
-            const int sl = item % SL, pix = item / SL;
-            const int oh = pix / TW, ow = pix % TW;
-            float m[V];
+    for (int q = 0; q < RH; ++q) { m1[q] = klow; m2[q] = klow; }
+    load_plane(pbeg, rg);
+    for (int pd = pbeg; pd < pend; ++pd) {
+        const int cls = plane_class(pd);                 // workgroup-uniform
+        raw m0[RH];
+        if (cls == 0) {
 #pragma unroll
-            for (int i = 0; i < V; ++i) m[i] = -FLT_MAX;
+            for (int q = 0; q < R; ++q)
+                if (ld_loff[q] >= 0) lds_raw[ld_loff[q]] = ld_goff[q] == -2 ? klow : VecMax<T>::enc(rg[q]);
+            __syncthreads();                             // input tile visible; previous H pass done with lds_w
+            if (pd + 1 < pend) load_plane(pd + 1, rg);   // flies during both passes
 #pragma unroll
-            for (int a = -1; a <= 1; ++a) {
-                const raw* pl = lds + ((d + a) & 3) * PLANE;
+            for (int q = 0; q < R; ++q)
+                if (wp_off[q] >= 0) {
+                    const raw* s0 = lds_raw + wp_off[q];
+                    raw m = s0[0];
 #pragma unroll
-                for (int b = 0; b < 3; ++b)
+                    for (int k = 1; k < KW; ++k) m = VecMax<T>::max(m, s0[k * SL]);
+                    lds_w[tid + q * 256] = m;
+                }
+            __syncthreads();
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        float f[V];
-                        Vec16<T, V>::unpack(pl[((oh + b) * HW + ow + c) * SL + sl], f);
+            for (int q = 0; q < RH; ++q) {
+                m0[q] = klow;
+                if (hp_offs[q] >= 0) {
+                    const raw* s0 = lds_w + hp_offs[q];
+                    raw m = s0[0];
 #pragma unroll
-                        for (int i = 0; i < V; ++i) m[i] = fmaxf(m[i], f[i]);
-                    }
+                    for (int k = 1; k < KH; ++k) m = VecMax<T>::max(m, s0[k * TW * SL]);
+                    m0[q] = m;
+                }
             }
-            const int gh = h0 + oh, gw = w0 + ow, c = c0 + sl * V;
-            if (gh < p.H && gw < p.W && c < p.C)
-                *(raw*)(y + ((((size_t)n * p.D + d) * p.H + gh) * p.W + gw) * p.y_cstride + p.y_coff + c) = Vec16<T, V>::pack(m);
+        } else {
+            if (pd + 1 < pend) load_plane(pd + 1, rg);
+#pragma unroll
+            for (int q = 0; q < RH; ++q) m0[q] = cls == 1 ? kzero : klow;
         }
-        // no trailing barrier: the slot refilled next iteration ((d+2)&3 = plane d-2) was last read in
-        // iteration d-1, and every thread has passed this iteration's barrier since
+        // D stage: the window of output plane od = (pd - KD + 1) / SD ends at this plane
+        const int w0p = pd - (KD - 1);
+        const bool emit = w0p >= pbeg && (w0p % SD) == 0;
+#pragma unroll
+        for (int q = 0; q < RH; ++q) {
+            if (emit && hp_goffs[q] >= 0) {
+                raw m = m0[q];
+                if (KD >= 2) m = VecMax<T>::max(m, m1[q]);
+                if (KD >= 3) m = VecMax<T>::max(m, m2[q]);
+                *(raw*)(yn + (size_t)(w0p / SD) * yplane + hp_goffs[q]) = VecMax<T>::dec(m);
+            }
+            m2[q] = m1[q]; m1[q] = m0[q];
+        }
     }
 }
 
@@ -259,15 +384,32 @@ template <typename T>
 static int maxpool_t(const void* x, void* y, const PoolParams& p, step_stream_t stream) {
     constexpr int V = elem<T>::VEC;
     if (p.C % V || p.x_cstride % V || p.x_coff % V || p.y_cstride % V || p.y_coff % V) return STEP_E_ALIGN;
-    if (p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1) {
-        const int tiles_h = ceil_div(p.H, 8), tiles_w = ceil_div(p.W, 16), cchunks = ceil_div(p.C, 4 * V);
+    const int ksig = p.kd * 100 + p.kh * 10 + p.kw, ssig = p.sd * 100 + p.sh * 10 + p.sw;
+    const bool sep = (ksig == 333 && ssig == 111) || (ksig == 133 && ssig == 122) || (ksig == 333 && ssig == 222);
+    static const bool force_direct = getenv("STEP_POOL_DIRECT") != nullptr;        // tuning aid / A-B against the direct kernel
+    if (sep && !force_direct) {
+        // balanced tiles: at most 14x14 outputs at stride 1, 7x7 at stride 2; 64 bytes of channels per workgroup
+        const int maxt = p.sh == 1 ? 14 : 7;
+        const int tiles_h = ceil_div(p.Ho, maxt), tiles_w = ceil_div(p.Wo, maxt), cchunks = ceil_div(p.C, PP_SL * V);
+        const int TH = ceil_div(p.Ho, tiles_h), TW = ceil_div(p.Wo, tiles_w);
         const long long blocks = (long long)p.N * tiles_h * tiles_w * cchunks;
         if (blocks == 0) return STEP_OK;
-        // split D until there are a few thousand workgroups (but keep >= 4 planes per segment)
+        // split D until there are ~1000 workgroups; with kd = 3 every segment re-reads planes of its neighbours,
+        // so keep >= 4 output planes per segment (kd = 1: no dependence along D)
+        static const int target = getenv("STEP_POOL_BLOCKS") ? atoi(getenv("STEP_POOL_BLOCKS")) : 1024;     // tuning aids
+        static const int minseg_e = getenv("STEP_POOL_MINSEG") ? atoi(getenv("STEP_POOL_MINSEG")) : 4;
+        const int minseg = p.kd == 1 ? 1 : minseg_e;
         int nseg = 1;
-        while (blocks * nseg < 2048 && p.D / (nseg * 2) >= 4) nseg *= 2;
-        const int dseg = ceil_div(p.D, nseg);
-        STEP_LAUNCH((maxpool333_s1_kernel<T>), dim3((unsigned)blocks, (unsigned)ceil_div(p.D, dseg)), dim3(256), stream, (const T*)x, (T*)y, p, tiles_h, tiles_w, cchunks, dseg);
+        while (blocks * nseg < target && p.Do / (nseg * 2) >= minseg) nseg *= 2;
+        const int dseg = ceil_div(p.Do, nseg);
+        nseg = ceil_div(p.Do, dseg);
+        const dim3 grid((unsigned)(blocks * nseg));
+#define STEP_POOL_SEP(KD_, KH_, KW_, SD_, SH_, SW_) \
+        STEP_LAUNCH((maxpool_sep_kernel<T, KD_, KH_, KW_, SD_, SH_, SW_>), grid, dim3(256), stream, (const T*)x, (T*)y, p, TH, TW, tiles_h, tiles_w, cchunks, dseg, nseg)
+        if (ssig == 111) STEP_POOL_SEP(3, 3, 3, 1, 1, 1);
+        else if (ksig == 133) STEP_POOL_SEP(1, 3, 3, 1, 2, 2);
+        else STEP_POOL_SEP(3, 3, 3, 2, 2, 2);
+#undef STEP_POOL_SEP
         return STEP_LAUNCH_CHECK();
     }
     long long total = (long long)p.N * p.Do * p.Ho * p.Wo * (p.C / V);

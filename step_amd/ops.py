@@ -5,6 +5,7 @@ below is one call into libstep_amd.so.  Activations are CHANNELS-LAST: a 5-D act
 contiguous tensor [N, D, H, W, C] (possibly a channel slice [.., c0:c1] of a wider buffer).
 """
 import ctypes
+import os
 
 import torch
 
@@ -156,8 +157,12 @@ def maxpool_tf(x, k, s, out=None):
                            L.step_pool_out_size(W, k[2], s[2]), C), dtype=x.dtype, device=x.device)
     prof = _NOPROF
     if PROFILE is not None:
-        kn = "maxpool333_s1_kernel" if (tuple(k) == (3, 3, 3) and tuple(s) == (1, 1, 1)) else "maxpool3d_tf_kernel"
-        prof = _Prof("void step::%s<%s>(%s const*, %s*, step::PoolParams, long long)" % ((kn,) + (_TNAME[x.dtype],) * 3),
+        ks = (tuple(k), tuple(s))
+        sep = ks in (((3, 3, 3), (1, 1, 1)), ((1, 3, 3), (1, 2, 2)), ((3, 3, 3), (2, 2, 2))) and not os.environ.get("STEP_POOL_DIRECT")
+        tn = _TNAME[x.dtype]
+        kn = ("maxpool_sep_kernel<%s, %d, %d, %d, %d, %d, %d>" % ((tn,) + ks[0] + ks[1]), ", int" * 7) if sep else \
+            ("maxpool3d_tf_kernel<%s>" % tn, ", long long")
+        prof = _Prof("void step::%s(%s const*, %s*, step::PoolParams%s)" % (kn[0], tn, tn, kn[1]),
                      0.0, (x.numel() + out.numel()) * _ES[x.dtype])
     with prof:
         _capi.check(L.step_maxpool3d_tf(_dt(x), _lib.dptr(x), N, D, H, W, C, _chan_slice(x), 0, k[0], k[1], k[2], s[0], s[1], s[2],

@@ -291,6 +291,17 @@ def case_maxpool_s1_long_d_segments(bk, golden):
     y = bk.dev(np.zeros((N, D, H, W, C), np.float32))
     assert bk.lib.step_maxpool3d_tf(0, xd.ptr, N, D, H, W, C, C, 0, 3, 3, 3, 1, 1, 1, y.ptr, C, 0, bk.stream) == 0
     assert np.array_equal(uncl(y.get()), ref)
+    # 16-bit storage (the max is taken in the storage type: exact), ragged channel chunk (40 = 32 + 8), 2x2 tiles
+    N, C, D, H, W = 2, 40, 3, 15, 16
+    x = rs.randn(N, C, D, H, W).astype(np.float32)
+    for dt in (BF16, F16):
+        ref = R.maxpool_tf(torch.from_numpy(quantize(x, dt)), (3, 3, 3), (1, 1, 1)).numpy()
+        xd = bk.dev(encode(cl(x), dt))
+        y = bk.dev(np.zeros((N, D, H, W, 48), NP_DT[dt]))
+        assert bk.lib.step_maxpool3d_tf(dt, xd.ptr, N, D, H, W, C, C, 0, 3, 3, 3, 1, 1, 1, y.ptr, 48, 8, bk.stream) == 0
+        yy = decode(y.get(), dt)
+        assert np.array_equal(uncl(yy[..., 8:]), ref), dt
+        assert not yy[..., :8].any()
 
 
 def case_maxpool_zero_pad_value(bk, golden):
