@@ -125,20 +125,20 @@ template <> struct VecMax<f16_t> {
 };
 template <> struct VecMax<bf16_t> {
     // gfx950 has no packed bf16 max, and widening to fp32 costs ~9 VALU ops per pair (measured: the pool was
-    // VALU-bound).  A sign-magnitude float orders like the unsigned integer  x ^ (x < 0 ? 0xffff : 0x8000),
-    // so planes are re-keyed once when they enter LDS (3 ops per pair), every max is one v_pk_max_u16 per pair,
-    // and the result is mapped back once before the store.  (-0 < +0 and NaN above +inf: NaN propagates.)
+    // VALU-bound).  A sign-magnitude float orders like the two's-complement integer  x ^ ((x >> 15) & 0x7fff)
+    // (negative values get their magnitude bits flipped), so planes are re-keyed once when they enter LDS (3 ops
+    // per pair), every max is one v_pk_max_i16 per pair, and the same map brings the result back before the
+    // store.  0 keeps the key 0; -0 < +0; NaN orders beyond +-inf, so a positive NaN propagates.
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     __device__ static __forceinline__ u16x8 enc(const u16x8& a) {
-        const u16x8 neg = __builtin_bit_cast(u16x8, __builtin_bit_cast(s16x8, a) >> 15);   // 0xffff where negative
-        return a ^ (neg | (unsigned short)0x8000);
+        const s16x8 sa = __builtin_bit_cast(s16x8, a);
+        return __builtin_bit_cast(u16x8, sa ^ ((sa >> 15) & (short)0x7fff));
     }
-    __device__ static __forceinline__ u16x8 dec(const u16x8& k) {
-        const u16x8 pos = __builtin_bit_cast(u16x8, __builtin_bit_cast(s16x8, k) >> 15);   // 0xffff where the value was >= 0
-        return k ^ (~pos | (unsigned short)0x8000);
+    __device__ static __forceinline__ u16x8 dec(const u16x8& k) { return enc(k); }
+    __device__ static __forceinline__ u16x8 lowest() { u16x8 r; for (int i = 0; i < 8; ++i) r[i] = 0x8000; return r; }   // below every key
+    __device__ static __forceinline__ u16x8 max(const u16x8& a, const u16x8& b) {
+        return __builtin_bit_cast(u16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b)));
     }
-    __device__ static __forceinline__ u16x8 lowest() { u16x8 r; for (int i = 0; i < 8; ++i) r[i] = 0; return r; }        // below every key
-    __device__ static __forceinline__ u16x8 max(const u16x8& a, const u16x8& b) { return __builtin_elementwise_max(a, b); }
 };
 #else
 template <typename T> struct VecMax {
@@ -180,12 +180,12 @@ constexpr int PP_SL = 4;                            // 16-byte vectors per pixel
 constexpr int PP_R = 4;                             // load items per thread per plane: 16*16*4 / 256
 constexpr int PP_MAXIN = 16;                        // max input tile edge
 
-template <typename T, int KD, int KH, int KW, int SD, int SH, int SW>
-__global__ __launch_bounds__(256) void maxpool_sep_kernel(const T* __restrict__ x, T* __restrict__ y, PoolParams p,
+template <typename T, int KD, int KH, int KW, int SD, int SH, int SW, int NT>
+__global__ __launch_bounds__(NT) void maxpool_sep_kernel(const T* __restrict__ x, T* __restrict__ y, PoolParams p,
                                                           int TH, int TW, int tiles_h, int tiles_w, int cchunks, int dseg, int nseg) {
     constexpr int V = elem<T>::VEC;
     typedef typename Vec16<T, V>::raw raw;
-    constexpr int SL = PP_SL, R = PP_R;
+    constexpr int SL = PP_SL, R = PP_R * 256 / NT;        // NT = 256: 4 items per thread per pass, NT = 1024: 1
     __shared__ __attribute__((aligned(16))) raw lds_raw[PP_MAXIN * PP_MAXIN * SL];
     __shared__ __attribute__((aligned(16))) raw lds_w[PP_MAXIN * PP_MAXIN * SL];
 
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void maxpool_sep_kernel(const T* __restrict__ 
     const int n_ld = IR * IC * SL, n_wp = IR * TW * SL, n_hp = TH * TW * SL;
 #pragma unroll
     for (int q = 0; q < R; ++q) {
-        const int item = tid + q * 256;
+        const int item = tid + q * NT;
         {
             const int sl = item % SL, pix = item / SL;
             const int r = pix / IC, cl = pix % IC;
@@ -232,11 +232,11 @@ __global__ __launch_bounds__(256) void maxpool_sep_kernel(const T* __restrict__ 
     }
     // H-pass items: lds_w index of the window's first vector, output offset inside a plane (-1: none);
     // TH*TW*SL <= 784 items at stride 1 (4 per thread), <= 196 at stride 2 (1 per thread)
-    constexpr int RH = (SH == 1 && SW == 1) ? R : 1;
+    constexpr int RH = (SH == 1 && SW == 1) ? R : 1;   // (NT = 1024: 1)
     int hp_offs[RH], hp_goffs[RH];
 #pragma unroll
     for (int q = 0; q < RH; ++q) {
-        const int item = tid + q * 256;
+        const int item = tid + q * NT;
         const int sl = item % SL, pix = item / SL;
         const int oh = pix / TW, ow = pix % TW;
         const int gh = oh0 + oh, gw = ow0 + ow, c = c0 + sl * V;
@@ -247,11 +247,12 @@ __global__ __launch_bounds__(256) void maxpool_sep_kernel(const T* __restrict__ 
     const T* xn = x + (size_t)n * p.D * xplane;
     T* yn = y + (size_t)n * p.Do * yplane;
 
+    const int pend_ = (min(seg * dseg + dseg, p.Do) - 1) * SD + KD;      // one past this column's last padded plane
     // padded plane pd <-> input plane pd - pfd; class 0: real, 1: explicit pad (all zero), 2: beyond the pad (never wins)
     auto plane_class = [&](int pd) { return pd >= p.Lpd ? 2 : ((pd - p.pfd >= 0 && pd - p.pfd < p.D) ? 0 : 1); };
     auto load_plane = [&](int pd, raw (&r)[R]) {
         const int d = pd - p.pfd;
-        const bool real = plane_class(pd) == 0;
+        const bool real = plane_class(pd) == 0 && pd < pend_;
 #pragma unroll
         for (int q = 0; q < R; ++q) {
             raw val = zero;
@@ -263,19 +264,25 @@ __global__ __launch_bounds__(256) void maxpool_sep_kernel(const T* __restrict__ 
     // output planes [obeg, oend) of this column <- padded input planes [obeg*SD, (oend-1)*SD + KD)
     const int obeg = seg * dseg, oend = min(obeg + dseg, p.Do);
     const int pbeg = obeg * SD, pend = (oend - 1) * SD + KD;
-    raw rg[R], m1[RH], m2[RH];                           // plane in flight; 2-D maxima of the two previous planes
+    // pad / overhang positions of the input tile are the same for every plane: written once
+#pragma unroll
+    for (int q = 0; q < R; ++q)
+        if (ld_loff[q] >= 0 && ld_goff[q] < 0) lds_raw[ld_loff[q]] = ld_goff[q] == -2 ? klow : kzero;
+
+    raw m1[RH], m2[RH];                                  // 2-D maxima of the two previous planes
 #pragma unroll
     for (int q = 0; q < RH; ++q) { m1[q] = klow; m2[q] = klow; }
-    load_plane(pbeg, rg);
-    for (int pd = pbeg; pd < pend; ++pd) {
+    // one input plane: rg holds it on entry and the next plane on exit (its loads fly during the two passes;
+    // a second plane in flight measured no faster and costs 16 VGPRs)
+    auto step = [&](int pd, raw (&rg)[R]) {
         const int cls = plane_class(pd);                 // workgroup-uniform
         raw m0[RH];
         if (cls == 0) {
 #pragma unroll
             for (int q = 0; q < R; ++q)
-                if (ld_loff[q] >= 0) lds_raw[ld_loff[q]] = ld_goff[q] == -2 ? klow : VecMax<T>::enc(rg[q]);
+                if (ld_goff[q] >= 0) lds_raw[ld_loff[q]] = VecMax<T>::enc(rg[q]);
             __syncthreads();                             // input tile visible; previous H pass done with lds_w
-            if (pd + 1 < pend) load_plane(pd + 1, rg);   // flies during both passes
+            load_plane(pd + 1, rg);
 #pragma unroll
             for (int q = 0; q < R; ++q)
                 if (wp_off[q] >= 0) {
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(256) void maxpool_sep_kernel(const T* __restrict__ 
                     raw m = s0[0];
 #pragma unroll
                     for (int k = 1; k < KW; ++k) m = VecMax<T>::max(m, s0[k * SL]);
-                    lds_w[tid + q * 256] = m;
+                    lds_w[tid + q * NT] = m;
                 }
             __syncthreads();
 #pragma unroll
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(256) void maxpool_sep_kernel(const T* __restrict__ 
                 }
             }
         } else {
-            if (pd + 1 < pend) load_plane(pd + 1, rg);
+            load_plane(pd + 1, rg);
 #pragma unroll
             for (int q = 0; q < RH; ++q) m0[q] = cls == 1 ? kzero : klow;
         }
@@ -315,7 +322,10 @@ __global__ __launch_bounds__(256) void maxpool_sep_kernel(const T* __restrict__ 
             }
             m2[q] = m1[q]; m1[q] = m0[q];
         }
-    }
+    };
+    raw rg[R];
+    load_plane(pbeg, rg);
+    for (int pd = pbeg; pd < pend; ++pd) step(pd, rg);
 }
 
 template <typename T>
@@ -404,11 +414,14 @@ static int maxpool_t(const void* x, void* y, const PoolParams& p, step_stream_t 
         const int dseg = ceil_div(p.Do, nseg);
         nseg = ceil_div(p.Do, dseg);
         const dim3 grid((unsigned)(blocks * nseg));
+        static const int nt_e = getenv("STEP_POOL_NT") ? atoi(getenv("STEP_POOL_NT")) : 0;
+        const bool wide = nt_e ? nt_e == 1024 : false;
 #define STEP_POOL_SEP(KD_, KH_, KW_, SD_, SH_, SW_) \
-        STEP_LAUNCH((maxpool_sep_kernel<T, KD_, KH_, KW_, SD_, SH_, SW_>), grid, dim3(256), stream, (const T*)x, (T*)y, p, TH, TW, tiles_h, tiles_w, cchunks, dseg, nseg)
-        if (ssig == 111) STEP_POOL_SEP(3, 3, 3, 1, 1, 1);
-        else if (ksig == 133) STEP_POOL_SEP(1, 3, 3, 1, 2, 2);
-        else STEP_POOL_SEP(3, 3, 3, 2, 2, 2);
+        if (wide) STEP_LAUNCH((maxpool_sep_kernel<T, KD_, KH_, KW_, SD_, SH_, SW_, 1024>), grid, dim3(1024), stream, (const T*)x, (T*)y, p, TH, TW, tiles_h, tiles_w, cchunks, dseg, nseg); \
+        else STEP_LAUNCH((maxpool_sep_kernel<T, KD_, KH_, KW_, SD_, SH_, SW_, 256>), grid, dim3(256), stream, (const T*)x, (T*)y, p, TH, TW, tiles_h, tiles_w, cchunks, dseg, nseg)
+        if (ssig == 111) { STEP_POOL_SEP(3, 3, 3, 1, 1, 1); }
+        else if (ksig == 133) { STEP_POOL_SEP(1, 3, 3, 1, 2, 2); }
+        else { STEP_POOL_SEP(3, 3, 3, 2, 2, 2); }
 #undef STEP_POOL_SEP
         return STEP_LAUNCH_CHECK();
     }
