@@ -507,14 +507,15 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
     };
 
     // Pipeline.  A STEP = TPS taps of one slab = one barrier; a SLOT = one tap.
-    //   weights: ONE register set R and THREE LDS step-buffers.  During step s, R (step s+2) is written to
-    //     buffer (s+2)%3 -- last read during step s-1 -- and re-issued for step s+3; the only vector-
-    //     memory operations outstanding at its wait are its own (exact vmcnt).
+    //   weights: TWO register sets (R0 on even steps, R1 on odd ones) and THREE LDS step-buffers.  During step s
+    //     the set of that parity, which holds step s+2 (loaded during step s-2), is written to buffer (s+2)%3
+    //     -- last read during step s-1 -- and re-issued for step s+4: two steps of matrix work (~1500 cycles)
+    //     cover the L2 latency of the weight stream; with one set the load -> store distance was a single step.
     //   fragments: two register sets alternating per slot.  The ds_reads of slot u+1 are issued BEFORE
     //     the MFMAs of slot u (for the first slot of a step they come from the next buffer, complete
     //     since the previous barrier), so LDS latency, the weight hand-over and the barrier hide behind
     //     matrix work.  A slab switch drains the pipeline once per slab.
-    u32x4 R[TPS * Q];
+    u32x4 R0[TPS * Q], R1[TPS * Q];
     frag_t fa[2][KS][MB], fb[2][KS][NB];
 
     const unsigned char* const bwave = ldsB + (wn * NB) * KS * FRAGB + lane * (8 * ES);
@@ -544,24 +545,28 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
         return (((tt / (KH * KW)) * HH_ + (tt / KW) % KH) * HW_ + tt % KW) * PITCH;
     };
 
-    // (slab, step-in-slab) cursors: c0 = current step, c3 = step + 3 (weight loads)
+    // (slab, step-in-slab) cursors: c0 = current step, c3 = step + 4 (weight loads)
     int slab0 = 0, sis0 = 0, slab3 = 0, sis3 = 0;
     auto adv = [&](int& sl, int& si) { if (++si == SPS) { si = 0; ++sl; } };
+    auto adv_clamped = [&]() { adv(slab3, sis3); if (slab3 >= nslab) { slab3 = nslab - 1; sis3 = SPS - 1; } };   // past the end: re-read the last tile
 
     stage_A(0);
-    load_B(0, 0, R);
-    store_B(0, R);
-    adv(slab3, sis3);
-    if (S > 1) { load_B(slab3, sis3, R); store_B(BSTEP, R); }
-    adv(slab3, sis3);
-    if (S > 2) load_B(slab3, sis3, R);
-    adv(slab3, sis3);                                      // -> step 3
+    load_B(0, 0, R0);
+    adv_clamped();
+    load_B(slab3, sis3, R1);
+    adv_clamped();
+    store_B(0, R0);
+    load_B(slab3, sis3, R0);                               // step 2
+    adv_clamped();
+    store_B(BSTEP, R1);
+    load_B(slab3, sis3, R1);                               // step 3
+    adv_clamped();                                         // -> step 4
     __syncthreads();
     read_frags(std::integral_constant<int, 0>(), 0, 0);
 
     int b0 = 0, b1 = BSTEP, b2 = 2 * BSTEP;                // LDS buffers of step s, s+1, s+2
     int s_ = 0;                                            // current step
-    auto slot = [&](auto setc, auto tpc) {
+    auto slot = [&](auto setc, auto tpc, u32x4 (&R)[TPS * Q]) {
         constexpr int SET = decltype(setc)::value;
         constexpr int TP = decltype(tpc)::value;           // tap slot within the step
         constexpr bool LAST = (TP == TPS - 1);
@@ -575,9 +580,9 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
         }
         mma_all(setc);
         if (LAST) {
-            if (s_ + 2 < S) store_B(b2, R);
-            if (s_ + 3 < S) load_B(slab3, sis3, R);
-            adv(slab3, sis3);
+            store_B(b2, R);                                // (past the end: a duplicate tile into a buffer nobody reads)
+            load_B(slab3, sis3, R);
+            adv_clamped();
             if (s_ + 1 < S && new_slab) {
                 __syncthreads();                          // every wave is done with this slab of A
                 stage_A(slab0 + 1);
@@ -593,14 +598,18 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
     if (TPS == 2) {
 #pragma unroll 1
         while (s_ < S) {
-            slot(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
-            slot(std::integral_constant<int, 1>(), std::integral_constant<int, TPS - 1>());
+            slot(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), R0);
+            slot(std::integral_constant<int, 1>(), std::integral_constant<int, TPS - 1>(), R0);
+            if (s_ < S) {
+                slot(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), R1);
+                slot(std::integral_constant<int, 1>(), std::integral_constant<int, TPS - 1>(), R1);
+            }
         }
     } else {
 #pragma unroll 1
         while (s_ < S) {
-            slot(std::integral_constant<int, 0>(), std::integral_constant<int, TPS - 1>());
-            if (s_ < S) slot(std::integral_constant<int, 1>(), std::integral_constant<int, TPS - 1>());
+            slot(std::integral_constant<int, 0>(), std::integral_constant<int, TPS - 1>(), R0);
+            if (s_ < S) slot(std::integral_constant<int, 1>(), std::integral_constant<int, TPS - 1>(), R1);
         }
     }
 
@@ -706,7 +715,8 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(ConvParams p) {
     constexpr int Q = (BVEC + 511) / 512;
     typedef typename frag<T>::type frag_t;
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * ATILE + 3 * BTILE];
+    constexpr int BSTRIDE = Q * 512 * 16;                    // weight buffer pitch: every thread stores all its Q vectors (no predicate)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * ATILE + 3 * BSTRIDE];
     unsigned char* const ldsA = lds;
     unsigned char* const ldsB = lds + 3 * ATILE;
 
@@ -751,31 +761,37 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(ConvParams p) {
         const int nbl = f / KS, ks = f % KS;
         const int nbg = min(nb0 + nbl, p.nblk32 - 1);
         wthr[q] = wg + ((size_t)nbg * KC16 + ks) * FRAGB + within * 16;
-        ldsoff[q] = (tid + q * 512 < BVEC) ? (tid + q * 512) * 16 : -1;
+        ldsoff[q] = (tid + q * 512) * 16;
     }
-    u32x4 RA[2], RB[Q];
-    auto load_step = [&](int s_) {
+    // global -> register ring of DR step slabs -> LDS ring of 3: a slab is loaded DR steps before it is written to
+    // LDS (4 steps of matrix work cover the HBM latency; with one register set the load -> store distance was a
+    // single step and the K loop ran latency-bound)
+    constexpr int DR = 4;
+    u32x4 RA[DR][2], RB[DR][Q];
+    auto load_step = [&](auto rc, int s_) {
+        constexpr int RS = decltype(rc)::value;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int c = s_ * CKT + acol[q];
             const bool cok = c < p.Cin;                                   // whole vector in or out (Cin % VEC == 0)
-            const u32x4 raw = *(const u32x4*)(athr[q] + (size_t)(cok ? c : 0) * ES);
-            const unsigned int mk = cok ? amask[q] : 0u;
-            RA[q] = raw & mk;
+            RA[RS][q] = *(const u32x4*)(athr[q] + (size_t)(cok ? c : 0) * ES);     // masked when it is written to LDS: an
+                                                                                    // AND here would wait for the load at once
         }
-        const size_t off = (size_t)(s_ * KS) * FRAGB;
+        const size_t off = (size_t)(min(s_, S - 1) * KS) * FRAGB;       // past the end: a harmless re-read of the last tile
 #pragma unroll
-        for (int q = 0; q < Q; ++q) RB[q] = *(const u32x4*)(wthr[q] + off);
+        for (int q = 0; q < Q; ++q) RB[RS][q] = *(const u32x4*)(wthr[q] + off);
     };
-    auto store_step = [&](int buf) {
+    auto store_step = [&](auto rc, int buf, int slab) {
+        constexpr int RS = decltype(rc)::value;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int v = tid + q * 512;
-            *(u32x4*)(ldsA + buf * ATILE + (v >> 2) * PITCH + ((v & 3) << 4)) = RA[q];
+            const unsigned int mk = (slab * CKT + acol[q] < p.Cin) ? amask[q] : 0u;
+            *(u32x4*)(ldsA + buf * ATILE + (v >> 2) * PITCH + ((v & 3) << 4)) = RA[RS][q] & mk;
         }
 #pragma unroll
         for (int q = 0; q < Q; ++q)
-            if (ldsoff[q] >= 0) *(u32x4*)(ldsB + buf * BTILE + ldsoff[q]) = RB[q];
+            *(u32x4*)(ldsB + buf * BSTRIDE + ldsoff[q]) = RB[RS][q];
     };
 
     const unsigned char* abase[2];
@@ -799,7 +815,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(ConvParams p) {
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) fa[SET][j][mb] = lds_read_bfrag<T>(abase[mb] + buf * ATILE + j * 32);
 #pragma unroll
-            for (int i = 0; i < NB; ++i) fb[SET][j][i] = lds_read_bfrag<T>(bwave + buf * BTILE + (i * KS + j) * FRAGB);
+            for (int i = 0; i < NB; ++i) fb[SET][j][i] = lds_read_bfrag<T>(bwave + buf * BSTRIDE + (i * KS + j) * FRAGB);
         }
     };
     auto mma_all = [&](auto setc) {
@@ -813,28 +829,44 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(ConvParams p) {
             }
     };
 
-    load_step(0); store_step(0);
-    if (S > 1) { load_step(1); store_step(1); }
-    if (S > 2) load_step(2);
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+    // prologue: steps 0..3 in flight at once, 0 and 1 to LDS, 4 and 5 take their register sets
+    load_step(I0(), 0); load_step(I1(), 1); load_step(I2(), 2); load_step(I3(), 3);
+    store_step(I0(), 0, 0);
+    store_step(I1(), 1, 1);
+    load_step(I0(), 4); load_step(I1(), 5);
     __syncthreads();
-    read_frags(std::integral_constant<int, 0>(), 0);
+    read_frags(I0(), 0);
 
     int b1 = 1, b2 = 2, s_ = 0;
-    auto step = [&](auto setc) {
+    // step s: register set (s + 2) & 3 holds slab s + 2 -> LDS buffer (s + 2) % 3, then reloads slab s + 6.
+    // No predicates inside (loads past the end are clamped and masked, the surplus fragment read hits a valid
+    // buffer): any branch in the loop makes the compiler fall back to vmcnt(0) waits.
+    auto step = [&](auto setc, auto rc) {
         constexpr int SET = decltype(setc)::value;
-        if (s_ + 1 < S) read_frags(std::integral_constant<int, SET ^ 1>(), b1);
+        read_frags(std::integral_constant<int, SET ^ 1>(), b1);
         mma_all(setc);
-        if (s_ + 2 < S) store_step(b2);
-        if (s_ + 3 < S) load_step(s_ + 3);
+        store_step(rc, b2, s_ + 2);
+        load_step(rc, s_ + 6);
         __syncthreads();
         const int nb = (b2 == 2) ? 0 : b2 + 1;
         b1 = b2; b2 = nb;
         ++s_;
     };
 #pragma unroll 1
-    while (s_ < S) {
-        step(std::integral_constant<int, 0>());
-        if (s_ < S) step(std::integral_constant<int, 1>());
+    while (s_ + 4 <= S) {
+        step(I0(), I2());
+        step(I1(), I3());
+        step(I0(), I0());
+        step(I1(), I1());
+    }
+    if (s_ < S) {                                            // 1..3 remaining steps
+        step(I0(), I2());
+        if (s_ < S) step(I1(), I3());
+        if (s_ < S) step(I0(), I0());
     }
 
     // ---- epilogue (two destinations supported)

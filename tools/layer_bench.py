@@ -98,7 +98,9 @@ def run_layers(L, dt, tdt, dev, st, B, a, layers, tot_ms=0.0, tot_gf=0.0):
         ms = time_it(lambda: _capi.check(L.step_conv_forward(ctypes.byref(d), _lib.dptr(x), _lib.dptr(wp), _lib.dptr(sc), _lib.dptr(sh), None, _lib.dptr(y), None, st), name), a.iters)
         gf = 2.0 * B * D * H * W * co * ci * k ** 3 / 1e9
         byts = (x.numel() + y.numel() + wp.numel()) * x.element_size()
-        print("%-8s %8.3f ms %8.1f TFLOP/s %8.1f GB/s" % (name, ms, gf / ms, byts / ms / 1e6))
+        kn = ctypes.create_string_buffer(256)
+        L.step_conv_kernel_name(ctypes.byref(d), kn, 256)
+        print("%-8s %8.3f ms %8.1f TFLOP/s %8.1f GB/s  %s" % (name, ms, gf / ms, byts / ms / 1e6, kn.value.decode()[11:60]))
         tot_ms += ms
         tot_gf += gf
     print("listed layers: %.3f ms, %.1f GFLOP, %.1f TFLOP/s" % (tot_ms, tot_gf, tot_gf / tot_ms))
