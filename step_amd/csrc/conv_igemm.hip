@@ -375,7 +375,16 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
     constexpr int TDL = (TWL == 3) ? 2 : 0, TD = 1 << TDL;
     constexpr int TW = 1 << TWL, TH = 256 >> (TWL + TDL);
     constexpr int THL = (TH == 16) ? 4 : 3;                 // log2(TH): 16 -> 4, 8 -> 3
-    constexpr int HH_ = TH + KH - 1, HW_ = TW + KW - 1;
+    // LDS bank conflicts of the A-fragment reads.  ds_read_b128 is serviced in four 16-lane groups ({0-3,12-15,20-27},
+    // {4-11,16-19,28-31}, and the same + 32); with the 80-byte pixel pitch a group is conflict-free iff its 16 lanes
+    // read pixels whose linear halo indices are distinct mod 16.  Lanes 0..31 of an MFMA row block are 32
+    // consecutive tile pixels: one 32-pixel row (8x32 tile: conflict-free as is), two 16-pixel rows (16x16: row
+    // pitch 18 = 2 mod 16 -> 2-way) or four 8-pixel rows (4x8x8: row pitch 10 -> 3-way; measured: 37 % of the LDS
+    // cycles of the 2c layer were conflicts).  Fix: the assignment of accumulator rows to tile COLUMNS is free, so
+    // odd rows of the 16x16 tile are rotated by 2 columns, and the 4x8x8 tile gets a 12-pixel row pitch plus a
+    // swap of the column halves on rows 1, 2 (mod 4); the epilogue applies the same map (tile_col).
+    constexpr int HWPAD = (TWL == 3) ? 2 : 0;
+    constexpr int HH_ = TH + KH - 1, HWV = TW + KW - 1, HW_ = HWV + HWPAD;   // HWV: columns that hold data
     constexpr int PD = TD + KD - 1;                         // input planes under the tile
     constexpr int NPIX = PD * HH_ * HW_;
     constexpr int ES = (int)sizeof(T);
@@ -402,6 +411,11 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
     unsigned char* const ldsA = lds;
     unsigned char* const ldsB = lds + NPIX * PITCH;
 
+    auto tile_col = [](int th, int j) {                    // tile row th, accumulator-row column slot j -> tile column
+        if (TWL == 4) return (th & 1) ? ((j + 14) & 15) : j;
+        if (TWL == 3) return (((th & 3) == 1) || ((th & 3) == 2)) ? (j ^ 4) : j;
+        return j;
+    };
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 #ifdef STEP_EMUL
@@ -431,7 +445,8 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int m = wm * (MB * 32) + mb * 32 + (lane & 31);
-        abase[mb] = ldsA + (((m >> (TWL + THL)) * HH_ + ((m >> TWL) & (TH - 1))) * HW_ + (m & (TW - 1))) * PITCH + khalf * (ES == 4 ? 32 : 16);
+        const int th_ = (m >> TWL) & (TH - 1);
+        abase[mb] = ldsA + (((m >> (TWL + THL)) * HH_ + th_) * HW_ + tile_col(th_, m & (TW - 1))) * PITCH + khalf * (ES == 4 ? 32 : 16);
     }
 
     f32x16 acc[MB][NB];
@@ -456,7 +471,7 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
                 const int plane = pix / (HH_ * HW_), rem = pix % (HH_ * HW_);
                 const int r = rem / HW_, cc = rem % HW_;
                 const int id = d0 + plane - KD / 2, ih = h0 + r - KH / 2, iw = w0 + cc - KW / 2;
-                const bool inb = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                const bool inb = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && cc < HWV;
                 if (inb && c < p.Cin) {
                     const size_t gpix = (((size_t)n * p.D + id) * p.H + ih) * p.W + iw;
                     val = *(const vec16*)(xg + gpix * p.x_cstride + p.x_coff + c);
@@ -645,7 +660,8 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
                 const int row = idx / G, g = idx % G;
                 // row = (wm*MBP + mbl)*32 + rr  ->  tile pixel wm*(MB*32) + (ps*MBP + mbl)*32 + rr
                 const int mm = ((row >> 5) / MBP) * (MB * 32) + (ps * MBP + (row >> 5) % MBP) * 32 + (row & 31);
-                const int od = d0 + (mm >> (TWL + THL)), oh = h0 + ((mm >> TWL) & (TH - 1)), ow = w0 + (mm & (TW - 1));
+                const int thl = (mm >> TWL) & (TH - 1);
+                    const int od = d0 + (mm >> (TWL + THL)), oh = h0 + thl, ow = w0 + tile_col(thl, mm & (TW - 1));
                 const int co = nb0 * 32 + g * 8;
                 if (od < p.D && oh < p.H && ow < p.W && co < p.Cout) {
                     const size_t opix = (((size_t)n * p.D + od) * p.H + oh) * p.W + ow;
@@ -678,7 +694,8 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int mm = wm * (MB * 32) + mb * 32 + cd_row(r, lane);
-                    const int od = d0 + (mm >> (TWL + THL)), oh = h0 + ((mm >> TWL) & (TH - 1)), ow = w0 + (mm & (TW - 1));
+                    const int thl = (mm >> TWL) & (TH - 1);
+                    const int od = d0 + (mm >> (TWL + THL)), oh = h0 + thl, ow = w0 + tile_col(thl, mm & (TW - 1));
                     if (od < p.D && oh < p.H && ow < p.W) {
                         const size_t opix = (((size_t)n * p.D + od) * p.H + oh) * p.W + ow;
                         float v = acc[mb][i][r] * sc + sh;
@@ -1459,7 +1476,10 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
     const unsigned char* abase[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
-        const int th = wave * 4 + mb * 2 + ((lane & 31) >> 4), tw = lane & 15;
+        // rows {0, 2} of the wave's 4-row strip in block 0, {1, 3} in block 1: ds_read2_b32 is serviced per 32-lane
+        // half with 32 banks, lanes 0-15 cover the banks 3*tw mod 32 and 4 input rows further down (960 B = 16 banks)
+        // lanes 16-31 cover exactly the other 16 (rows {0, 1} together were a 2-way conflict on every fragment read)
+        const int th = wave * 4 + mb + 2 * ((lane & 31) >> 4), tw = lane & 15;
         abase[mb] = ldsA + (2 * th) * PITCH + (2 * tw + 2) * 6;
     }
     const int kh_row = khalf * PITCH, kh_q = khalf * 16;
@@ -1565,7 +1585,7 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
         __syncthreads();
         for (int idx = tid; idx < 128 * G; idx += 256) {
             const int row = idx / G, g = idx % G;
-            const int oh = oh0 + (row >> 5) * 4 + mb * 2 + ((row & 31) >> 4), ow = ow0 + (row & 15);
+            const int oh = oh0 + (row >> 5) * 4 + mb + 2 * ((row & 31) >> 4), ow = ow0 + (row & 15);
             const int co = nb0 * 32 + g * 8;
             if (oh < p.Ho && ow < p.Wo && co < p.Cout) {
                 const size_t opix = (((size_t)n * p.To + od) * p.Ho + oh) * p.Wo + ow;
