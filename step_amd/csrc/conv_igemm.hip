@@ -43,6 +43,7 @@ struct ConvParams {
     int x_cstride, x_coff, y_cstride, y_coff, r_cstride, r_coff;
     int relu;
     int tiles_h, tiles_w, tiles_d;
+    int gtd, gth, gtw;   // box of a general (TWL = 0) conv_tap tile, gtd*gth*gtw <= 256
     int nchunks;   // ceil(Cin / 32)
     int nchunks32; // same (the packed-weight K extent is 2*nchunks32 k16 blocks)
     int vec_epi;   // 16-byte output stores are legal (channel strides/offsets % 8 == 0, pointers 16-B aligned)
@@ -365,16 +366,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 // MB = 32-pixel accumulator rows per wave: MB = 2 -> 8 waves (4 x 2, 512 threads, 2 waves per SIMD);
 // MB = 4 -> 4 waves (2 x 2, 256 threads, ONE wave per SIMD with the whole 512-register file: a 128-pixel x
 // 96-channel wave tile reads (4 + NB) fragments per 4*NB MFMAs -- 30 % less LDS traffic per MFMA).
+constexpr int CONV_GEN_NPIX = 768;   // LDS halo pixels reserved for a general (runtime-shaped) tile: 60 KiB
+
 template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB>
 __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParams p) {
     constexpr int NT = (MB == 2) ? 512 : 256;   // threads
     constexpr int WM = 8 / MB;                  // waves along the pixel axis (x 2 along channels)
     constexpr int MBP = MB / 2;                 // accumulator rows per wave per epilogue pass
     // tile shapes: TWL = 4 -> 1 plane x 16 x 16, TWL = 5 -> 1 x 8 x 32, TWL = 3 -> 4 planes x 8 x 8 (small maps:
-    // 7x7 ROI features would fill 19 % of a 16x16 tile; four planes of 8x8 fill 77 %)
-    constexpr int TDL = (TWL == 3) ? 2 : 0, TD = 1 << TDL;
-    constexpr int TW = 1 << TWL, TH = 256 >> (TWL + TDL);
-    constexpr int THL = (TH == 16) ? 4 : 3;                 // log2(TH): 16 -> 4, 8 -> 3
+    // 7x7 ROI features would fill 19 % of a 16x16 tile; four planes of 8x8 fill 77 %), TWL = 0 -> a box of
+    // p.gtd x p.gth x p.gtw <= 256 pixels chosen at launch (GEN): power-of-two tiles cover a 28x28 map at 77 %,
+    // a 50x50 one at 70 %; 2x4x28 and 2x5x25 boxes reach 88 % and 98 %.  The index arithmetic of a GEN tile uses
+    // divisions, but only outside the step loop.
+    constexpr bool GEN = (TWL == 0);
+    constexpr int TDL = (TWL == 3) ? 2 : 0;
+    constexpr int THL = GEN ? 0 : (((256 >> (TWL + TDL)) == 16) ? 4 : 3);   // log2(TH): 16 -> 4, 8 -> 3
+    const int TD = GEN ? p.gtd : (1 << TDL);
+    const int TW = GEN ? p.gtw : (1 << TWL), TH = GEN ? p.gth : (256 >> (TWL + TDL));
+    const int TPX = TD * TH * TW;                           // pixels of the tile (256 unless GEN)
     // LDS bank conflicts of the A-fragment reads.  ds_read_b128 is serviced in four 16-lane groups ({0-3,12-15,20-27},
     // {4-11,16-19,28-31}, and the same + 32); with the 80-byte pixel pitch a group is conflict-free iff its 16 lanes
     // read pixels whose linear halo indices are distinct mod 16.  Lanes 0..31 of an MFMA row block are 32
@@ -384,17 +393,18 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
     // odd rows of the 16x16 tile are rotated by 2 columns, and the 4x8x8 tile gets a 12-pixel row pitch plus a
     // swap of the column halves on rows 1, 2 (mod 4); the epilogue applies the same map (tile_col).
     constexpr int HWPAD = (TWL == 3) ? 2 : 0;
-    constexpr int HH_ = TH + KH - 1, HWV = TW + KW - 1, HW_ = HWV + HWPAD;   // HWV: columns that hold data
-    constexpr int PD = TD + KD - 1;                         // input planes under the tile
-    constexpr int NPIX = PD * HH_ * HW_;
+    const int HH_ = TH + KH - 1, HWV = TW + KW - 1, HW_ = HWV + HWPAD;   // HWV: columns that hold data
+    const int PD = TD + KD - 1;                             // input planes under the tile
+    const int NPIX = PD * HH_ * HW_;
+    constexpr int NPIX_MAX = GEN ? CONV_GEN_NPIX : ((1 << TDL) + KD - 1) * ((256 >> (TWL + TDL)) + KH - 1) * ((1 << TWL) + KW - 1 + HWPAD);
     constexpr int ES = (int)sizeof(T);
     constexpr int VEC = 16 / ES;
     constexpr int CKT = 64 / ES;          // channels per slab: 32 (16-bit) / 16 (fp32)
     constexpr int KS = CKT / 16;          // k16 steps per slab
     constexpr int PITCH = 80, SLOTS = 4;
     constexpr int NTAPS = KD * KH * KW;
-    constexpr int NVEC = NPIX * SLOTS;
-    constexpr int ITER = (NVEC + NT - 1) / NT;
+    const int NVEC = NPIX * SLOTS;
+    constexpr int ITER = (NPIX_MAX * SLOTS + NT - 1) / NT;
     constexpr int FRAGB = 512 * ES;       // bytes of one B fragment (64 lanes x 8 elements)
     constexpr int FRAGV = FRAGB / 16;     // 16-byte vectors per fragment
     constexpr int NBT = 2 * NB;           // 32-channel blocks per workgroup tile
@@ -407,9 +417,18 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
     typedef typename Ld16<T>::type vec16;
     typedef typename frag<T>::type frag_t;
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX * PITCH + 3 * BSTEP];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX_MAX * PITCH + 3 * BSTEP];
     unsigned char* const ldsA = lds;
-    unsigned char* const ldsB = lds + NPIX * PITCH;
+    unsigned char* const ldsB = lds + NPIX_MAX * PITCH;
+    // tile pixel index m (accumulator row) -> box coordinates; rows past the box of a GEN tile alias pixel 0
+    auto tile_pix = [&](int m, int& td, int& th, int& tw) {
+        if (GEN) {
+            const int mc = m < TPX ? m : 0;
+            tw = mc % TW; const int q = mc / TW; th = q % TH; td = q / TH;
+        } else {
+            td = m >> (TWL + THL); th = (m >> TWL) & (TH - 1); tw = m & (TW - 1);
+        }
+    };
 
     auto tile_col = [](int th, int j) {                    // tile row th, accumulator-row column slot j -> tile column
         if (TWL == 4) return (th & 1) ? ((j + 14) & 15) : j;
@@ -432,6 +451,7 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
     const int d0 = (t % p.tiles_d) * TD;
     const int n = t / p.tiles_d;
     const int h0 = th_i * TH, w0 = tw_i * TW;
+    const int HHW = HH_ * HW_;
     const int nb0 = blockIdx.y * NBT;
     const int KC16 = p.nchunks32 * 2;
     const int nslab = (p.Cin + CKT - 1) / CKT;
@@ -445,8 +465,9 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int m = wm * (MB * 32) + mb * 32 + (lane & 31);
-        const int th_ = (m >> TWL) & (TH - 1);
-        abase[mb] = ldsA + (((m >> (TWL + THL)) * HH_ + th_) * HW_ + tile_col(th_, m & (TW - 1))) * PITCH + khalf * (ES == 4 ? 32 : 16);
+        int td_, th_, tw_;
+        tile_pix(m, td_, th_, tw_);
+        abase[mb] = ldsA + ((td_ * HH_ + th_) * HW_ + tile_col(th_, tw_)) * PITCH + khalf * (ES == 4 ? 32 : 16);
     }
 
     f32x16 acc[MB][NB];
@@ -468,7 +489,7 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
             if (v < NVEC) {
                 const int pix = v / SLOTS, slot = v % SLOTS;
                 const int c = slab * CKT + slot * VEC;
-                const int plane = pix / (HH_ * HW_), rem = pix % (HH_ * HW_);
+                const int plane = pix / HHW, rem = pix % HHW;
                 const int r = rem / HW_, cc = rem % HW_;
                 const int id = d0 + plane - KD / 2, ih = h0 + r - KH / 2, iw = w0 + cc - KW / 2;
                 const bool inb = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && cc < HWV;
@@ -660,10 +681,11 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
                 const int row = idx / G, g = idx % G;
                 // row = (wm*MBP + mbl)*32 + rr  ->  tile pixel wm*(MB*32) + (ps*MBP + mbl)*32 + rr
                 const int mm = ((row >> 5) / MBP) * (MB * 32) + (ps * MBP + (row >> 5) % MBP) * 32 + (row & 31);
-                const int thl = (mm >> TWL) & (TH - 1);
-                    const int od = d0 + (mm >> (TWL + THL)), oh = h0 + thl, ow = w0 + tile_col(thl, mm & (TW - 1));
+                int tdl, thl, twl;
+                tile_pix(mm, tdl, thl, twl);
+                const int od = d0 + tdl, oh = h0 + thl, ow = w0 + tile_col(thl, twl);
                 const int co = nb0 * 32 + g * 8;
-                if (od < p.D && oh < p.H && ow < p.W && co < p.Cout) {
+                if ((!GEN || mm < TPX) && od < p.D && oh < p.H && ow < p.W && co < p.Cout) {
                     const size_t opix = (((size_t)n * p.D + od) * p.H + oh) * p.W + ow;
                     const f32x4 lo = *(const f32x4*)(ot + row * BN + g * 8);
                     const f32x4 hi = *(const f32x4*)(ot + row * BN + g * 8 + 4);
@@ -694,9 +716,10 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int mm = wm * (MB * 32) + mb * 32 + cd_row(r, lane);
-                    const int thl = (mm >> TWL) & (TH - 1);
-                    const int od = d0 + (mm >> (TWL + THL)), oh = h0 + thl, ow = w0 + tile_col(thl, mm & (TW - 1));
-                    if (od < p.D && oh < p.H && ow < p.W) {
+                    int tdl, thl, twl;
+                    tile_pix(mm, tdl, thl, twl);
+                    const int od = d0 + tdl, oh = h0 + thl, ow = w0 + tile_col(thl, twl);
+                    if ((!GEN || mm < TPX) && od < p.D && oh < p.H && ow < p.W) {
                         const size_t opix = (((size_t)n * p.D + od) * p.H + oh) * p.W + ow;
                         float v = acc[mb][i][r] * sc + sh;
                         if (rg) v += elem<T>::to_f32(rg[opix * p.r_cstride + p.r_coff + co]);
@@ -1686,7 +1709,7 @@ static int pick_nb(int nblk32, long long mtiles) {
 // attribute time and work to the kernel name rocprofv3 reports).
 //   impl 0: conv_igemm_kernel (4 waves, 128-px tile, weights straight from L2)  -- 1x1x1 and small problems
 //   impl 1: conv_tap_kernel   (8 waves, 256-px tile, weights through an LDS-DMA double buffer)
-struct ConvPlan { bool ok, flat, wide, deep; int impl, NB, tps, mb, twl, tiles_h, tiles_w, tiles_d; long long mtiles; };
+struct ConvPlan { bool ok, flat, wide, deep; int impl, NB, tps, mb, twl, tiles_h, tiles_w, tiles_d, gtd, gth, gtw; long long mtiles; };
 
 static int pick_nb_tap(int nblk32, long long mtiles) {
     int best = 1;
@@ -1718,9 +1741,31 @@ static step_conv_desc canonical_desc(const step_conv_desc* d) {
     return e;
 }
 
+// best general box (td, th, tw) for conv_tap_kernel<TWL = 0>: td*th*tw <= 256 pixels, halo within the LDS
+// reservation; fewest tiles wins, then the smaller halo
+static long long best_gen_box(int D, int H, int W, int kd, int* btd, int* bth, int* btw) {
+    long long best = -1; int bhalo = 0;
+    for (int kw_ = 1; kw_ <= 8; ++kw_) {
+        const int tw = ceil_div(W, kw_);
+        if (tw > 256) continue;
+        for (int kh_ = 1; kh_ <= H; ++kh_) {
+            const int th = ceil_div(H, kh_);
+            if (th * tw > 256) continue;
+            if (kh_ > 1 && th == ceil_div(H, kh_ - 1)) continue;
+            for (int td = 1; td <= D && td * th * tw <= 256; ++td) {
+                const int halo = (td + kd - 1) * (th + 2) * (tw + 2);
+                if (halo > CONV_GEN_NPIX) break;
+                const long long tiles = (long long)ceil_div(D, td) * ceil_div(H, th) * ceil_div(W, tw);
+                if (best < 0 || tiles < best || (tiles == best && halo < bhalo)) { best = tiles; bhalo = halo; *btd = td; *bth = th; *btw = tw; }
+            }
+        }
+    }
+    return best;
+}
+
 static ConvPlan conv_plan(const step_conv_desc* d) {
     ConvPlan pl;
-    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1; pl.mb = 2; pl.deep = false; pl.twl = 4; pl.tiles_d = d->D;
+    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1; pl.mb = 2; pl.deep = false; pl.twl = 4; pl.tiles_d = d->D; pl.gtd = pl.gth = pl.gtw = 1;
     const int nblk32 = ceil_div(d->Cout, 32);
     const bool k1 = d->kd == 1 && d->kh == 1 && d->kw == 1;
     const bool k333 = d->kd == 3 && d->kh == 3 && d->kw == 3;
@@ -1750,9 +1795,17 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
     const long long t32 = (long long)d->D * ceil_div(d->H, 8) * ceil_div(d->W, 32);
     const long long t8 = (long long)ceil_div(d->D, 4) * ceil_div(d->H, 8) * ceil_div(d->W, 8);
     int twl = 4;
-    long long tbest = t16;
+    long long tbest = t16;   // (per clip)
     if (t32 < tbest) { tbest = t32; twl = 5; }
     if (t8 < tbest) { tbest = t8; twl = 3; }
+    // a general box when it needs at least 7 % fewer tiles than the best power-of-two shape (its index arithmetic
+    // divides and its LDS reads are not conflict-free; STEP_CONV_GEN=0 disables it)
+    int gtd = 1, gth = 1, gtw = 1;
+    static const bool gen_ok = !(getenv("STEP_CONV_GEN") && atoi(getenv("STEP_CONV_GEN")) == 0);
+    if (gen_ok) {
+        const long long tg = best_gen_box(d->D, d->H, d->W, d->kd, &gtd, &gth, &gtw);
+        if (tg > 0 && tg * 100 <= tbest * 93) { tbest = tg; twl = 0; }
+    }
     const long long mt256 = (long long)d->N * tbest;
     // few-tile, small-Cin problems stay on the 4-wave 128-pixel kernel (more workgroups); everything else -- the
     // Cin = 16/32 branches of the Inception blocks included (measured: 9 x 3x3x3 layers 0.253 ms against 0.317 ms) --
@@ -1764,9 +1817,14 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
         pl.mb = (ov == 4) ? 4 : 2;      // STEP_CONV_IMPL=tap4: the 4-wave, 128-pixel-per-wave variant
         pl.twl = twl;
         pl.wide = twl == 5;
-        pl.tiles_d = twl == 3 ? ceil_div(d->D, 4) : d->D;
-        pl.tiles_h = twl == 4 ? ceil_div(d->H, 16) : ceil_div(d->H, 8);
-        pl.tiles_w = twl == 4 ? ceil_div(d->W, 16) : (twl == 5 ? ceil_div(d->W, 32) : ceil_div(d->W, 8));
+        pl.gtd = gtd; pl.gth = gth; pl.gtw = gtw;
+        if (twl == 0) {
+            pl.tiles_d = ceil_div(d->D, gtd); pl.tiles_h = ceil_div(d->H, gth); pl.tiles_w = ceil_div(d->W, gtw);
+        } else {
+            pl.tiles_d = twl == 3 ? ceil_div(d->D, 4) : d->D;
+            pl.tiles_h = twl == 4 ? ceil_div(d->H, 16) : ceil_div(d->H, 8);
+            pl.tiles_w = twl == 4 ? ceil_div(d->W, 16) : (twl == 5 ? ceil_div(d->W, 32) : ceil_div(d->W, 8));
+        }
         pl.mtiles = mt256;
         pl.NB = pick_nb_tap(nblk32, pl.mtiles);
         return pl;
@@ -1816,6 +1874,7 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, step_stream_t s
     const ConvPlan pl = conv_plan(d);
     if (!pl.ok) return STEP_E_UNSUPPORTED;
     p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.tiles_d = pl.tiles_d;
+    p.gtd = pl.gtd; p.gth = pl.gth; p.gtw = pl.gtw;
     if (pl.impl == 2) {
         dim3 grid((unsigned)pl.mtiles, (unsigned)ceil_div(p.nblk32, 2 * pl.NB));
         switch (pl.NB) {
@@ -1828,9 +1887,11 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, step_stream_t s
     if (pl.impl == 1) {
         dim3 grid((unsigned)pl.mtiles, (unsigned)ceil_div(p.nblk32, 2 * pl.NB));
         if (d->kd == 3) {
+            if (pl.twl == 0) return launch_tap<T, 0, 3, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
             if (pl.twl == 3) return launch_tap<T, 3, 3, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
             return pl.wide ? launch_tap<T, 5, 3, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream) : launch_tap<T, 4, 3, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
         }
+        if (pl.twl == 0) return launch_tap<T, 0, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
         if (pl.twl == 3) return launch_tap<T, 3, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
         return pl.wide ? launch_tap<T, 5, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream) : launch_tap<T, 4, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
     }
@@ -1919,7 +1980,7 @@ int step_conv_forward(const step_conv_desc* d, const void* x, const void* w_pack
     p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
     p.r_cstride = d->res_cstride; p.r_coff = d->res_coff;
     p.relu = d->relu;
-    p.tiles_h = p.tiles_w = 0; p.tiles_d = d->D;
+    p.tiles_h = p.tiles_w = 0; p.tiles_d = d->D; p.gtd = p.gth = p.gtw = 1;
     p.nchunks = ceil_div(d->Cin, CK);
     p.nchunks32 = p.nchunks;
     p.vec_epi = (d->y_cstride % 8 == 0) && (d->y_coff % 8 == 0) && (d->Cout % 8 == 0) && (((uintptr_t)y) % 16 == 0) &&

@@ -362,6 +362,8 @@ CONV_CASES = [
     (2, 264, 40, 1, 5, 9, (1, 1, 1)),       # deep pointwise: 128-channel slabs, ragged last slab (264 = 2*128 + 8)
     (1, 64, 40, 9, 7, 7, (1, 3, 3)),        # plane-folded tiles (4 planes x 8x8): 2-D conv over 9 frames, ragged last tile (9 = 2*4 + 1)
     (2, 64, 32, 5, 7, 6, (3, 3, 3)),        # plane-folded tiles with a 3-D kernel: 6-plane halo, clip boundary inside the grid
+    (1, 64, 40, 3, 9, 28, (3, 3, 3)),       # general box tiles (28 wide: 1x9x28 = 252 pixels, rows past the box masked)
+    (1, 72, 32, 9, 7, 7, (1, 3, 3)),        # general box 5x7x7 on 7x7 maps (2-D conv over 9 frames), ragged last box
 ]
 
 

@@ -52,7 +52,9 @@ def _worker(rank, world, port, q):
     g_masked = [p.grad.clone() for p in model.parameters()]
     el = D.timed_steps(lambda: None if rank == 0 else __import__("time").sleep(0.05), 2, sync=lambda: None)
     if rank == 0:
-        q.put((nb, g_plain, g_masked, el))
+        # numpy arrays travel by value; torch tensors would be shared through file descriptors that may be gone
+        # by the time the parent unpickles them
+        q.put((nb, [g.numpy() for g in g_plain], [g.numpy() for g in g_masked], el))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -66,6 +68,8 @@ def test_two_rank_gradient_allreduce_matches_single_process():
     for p in procs:
         p.start()
     nb, g_plain, g_masked, el = q.get()
+    g_plain = [torch.from_numpy(g) for g in g_plain]
+    g_masked = [torch.from_numpy(g) for g in g_masked]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
