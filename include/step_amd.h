@@ -151,6 +151,15 @@ STEP_API int step_conv_pack_weight(const float* w, int Cout, int Cin, int kd, in
 STEP_API int step_conv_forward(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale,
                                const float* shift, const void* res, void* y, void* y2, step_stream_t stream);
 
+/* Same, with a caller-owned scratch buffer.  Few-row / very-deep-K pointwise layers (the heads' Linear(12544 -> 60 / 12),
+ * models/two_branch.py:196,209-211) are split along K over the whole chip when `ws` holds at least
+ * step_conv_workspace_bytes(d) bytes (16-byte aligned; contents are scratch, no initialisation needed); with ws = NULL
+ * or for every other layer this is step_conv_forward.  The library never allocates: the caller owns ws. */
+STEP_API size_t step_conv_workspace_bytes(const step_conv_desc* d);
+STEP_API int step_conv_forward_ws(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale,
+                                  const float* shift, const void* res, void* y, void* y2, void* ws, size_t ws_bytes,
+                                  step_stream_t stream);
+
 /* Diagnostic: the name (as rocprofv3 prints it) of the kernel instantiation step_conv_forward launches
  * for this descriptor -- lets bench.py attribute time and algorithmic work to profiler rows. */
 STEP_API int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen);

@@ -985,6 +985,86 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(ConvParams p) {
     }
 }
 
+// ============================================================================================
+// pw_splitk_kernel -- pointwise convs / Linear layers with FEW rows and a very deep K (the heads'
+// Linear(12544 -> 60 / 12) on N*Tl <= a few hundred rows: two_branch.py:196,209-211).  As a tiled GEMM this is
+// 2-8 workgroups walking 98 slabs one after the other (measured 228 us per call); it is weight- and
+// activation-bandwidth work that wants the whole chip.  Here K is split across workgroups:
+//   grid = (32-channel block, K chunk, 128-row tile); 4 waves per workgroup take the chunk's k16 steps
+//   round-robin, reading A fragments straight from global memory (16 B per lane, the MFMA operand layout)
+//   and B fragments from the fragment-ordered packed weights (1 KiB per wave, fully coalesced): no LDS and
+//   no barrier in the loop.  The four waves' accumulators are summed through LDS and written as one fp32
+//   partial tile to ws[chunk][row][channel]; pw_splitk_finish_kernel sums the chunks in a fixed order
+//   (deterministic, no atomics), applies affine / residual / ReLU and stores in the storage type.
+template <typename T, int MBK>
+__global__ __launch_bounds__(256) void pw_splitk_kernel(ConvParams p, float* __restrict__ ws, int kchunk16, int mpad, int cpad) {
+    static_assert(sizeof(T) == 2, "16-bit storage types only");
+    typedef typename frag<T>::type frag_t;
+    __shared__ float red[4][MBK * 32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, khalf = lane >> 5;
+    const int nb = blockIdx.x;
+    const long long m0 = (long long)blockIdx.z * (MBK * 32);
+    const int KC16 = p.nchunks32 * 2;
+    const int ks_beg = blockIdx.y * kchunk16, ks_end = min(ks_beg + kchunk16, KC16);
+    const T* xg = (const T*)p.x;
+    const T* wg = (const T*)p.w + ((size_t)nb * KC16 * 64 + lane) * 8;
+
+    const T* arow[MBK];
+    bool rok[MBK];
+#pragma unroll
+    for (int mb = 0; mb < MBK; ++mb) {
+        const long long r = m0 + mb * 32 + (lane & 31);
+        rok[mb] = r < p.Mtot;
+        arow[mb] = xg + (size_t)(rok[mb] ? r : 0) * p.x_cstride + p.x_coff + khalf * 8;
+    }
+    f32x16 acc[MBK];
+#pragma unroll
+    for (int mb = 0; mb < MBK; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+
+    for (int ks = ks_beg + wave; ks < ks_end; ks += 4) {
+        const frag_t b = load_b_frag<T>(wg + (size_t)ks * 512);
+        const int c = ks * 16 + khalf * 8;
+        const bool cok = c < p.Cin;                        // Cin % 8 == 0: a fragment half is all in or all out
+#pragma unroll
+        for (int mb = 0; mb < MBK; ++mb) {
+            frag_t a;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = 0;
+            if (cok && rok[mb]) a = *(const frag_t*)(arow[mb] + ks * 16);
+            mma_k16(a, b, acc[mb], T());
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < MBK; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][mb * 32 + cd_row(r, lane)][lane & 31] = acc[mb][r];
+    __syncthreads();
+    float* out = ws + ((size_t)blockIdx.y * mpad + m0) * cpad + nb * 32;
+    for (int idx = tid; idx < MBK * 32 * 32; idx += 256) {
+        const int row = idx >> 5, col = idx & 31;
+        if (m0 + row < mpad)
+            out[(size_t)row * cpad + col] = (red[0][row][col] + red[1][row][col]) + (red[2][row][col] + red[3][row][col]);
+    }
+}
+
+template <typename T>
+__global__ void pw_splitk_finish_kernel(ConvParams p, const float* __restrict__ ws, int ksplit, int mpad, int cpad) {
+    const long long total = p.Mtot * p.Cout;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)blockDim.x * gridDim.x) {
+        const long long row = idx / p.Cout;
+        const int co = (int)(idx % p.Cout);
+        float v = 0.f;
+        for (int k = 0; k < ksplit; ++k) v += ws[((size_t)k * mpad + row) * cpad + co];
+        v = v * (p.scale ? p.scale[co] : 1.f) + (p.shift ? p.shift[co] : 0.f);
+        if (p.res) v += elem<T>::to_f32(((const T*)p.res)[(size_t)row * p.r_cstride + p.r_coff + co]);
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.split > 0 && co >= p.split) ((T*)p.y2)[(size_t)row * p.y2_cstride + p.y2_coff + (co - p.split)] = elem<T>::from_f32(v);
+        else ((T*)p.y)[(size_t)row * p.y_cstride + p.y_coff + co] = elem<T>::from_f32(v);
+    }
+}
+
 // ---- weight packing: torch [Cout][Cin][taps] fp32 -> [nb32][tap][kc16][lane][8] of T ----------
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, const int32_t* __restrict__ perm, T* __restrict__ out,
@@ -1709,7 +1789,7 @@ static int pick_nb(int nblk32, long long mtiles) {
 // attribute time and work to the kernel name rocprofv3 reports).
 //   impl 0: conv_igemm_kernel (4 waves, 128-px tile, weights straight from L2)  -- 1x1x1 and small problems
 //   impl 1: conv_tap_kernel   (8 waves, 256-px tile, weights through an LDS-DMA double buffer)
-struct ConvPlan { bool ok, flat, wide, deep; int impl, NB, tps, mb, twl, tiles_h, tiles_w, tiles_d, gtd, gth, gtw; long long mtiles; };
+struct ConvPlan { bool ok, flat, wide, deep; int impl, NB, tps, mb, twl, tiles_h, tiles_w, tiles_d, gtd, gth, gtw, ksplit, kchunk16, mbk, mpad, cpad; long long mtiles; };
 
 static int pick_nb_tap(int nblk32, long long mtiles) {
     int best = 1;
@@ -1765,7 +1845,7 @@ static long long best_gen_box(int D, int H, int W, int kd, int* btd, int* bth, i
 
 static ConvPlan conv_plan(const step_conv_desc* d) {
     ConvPlan pl;
-    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1; pl.mb = 2; pl.deep = false; pl.twl = 4; pl.tiles_d = d->D; pl.gtd = pl.gth = pl.gtw = 1;
+    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1; pl.mb = 2; pl.deep = false; pl.twl = 4; pl.tiles_d = d->D; pl.gtd = pl.gth = pl.gtw = 1; pl.ksplit = 0; pl.kchunk16 = 0; pl.mbk = 0; pl.mpad = 0; pl.cpad = 0;
     const int nblk32 = ceil_div(d->Cout, 32);
     const bool k1 = d->kd == 1 && d->kh == 1 && d->kw == 1;
     const bool k333 = d->kd == 3 && d->kh == 3 && d->kw == 3;
@@ -1781,6 +1861,27 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
             pl.impl = 2;
             pl.mtiles = mt256;
             pl.NB = pick_nb_tap(nblk32, mt256);
+            return pl;
+        }
+        // few rows x very deep K (the heads' Linear layers): split K over the chip (needs the workspace of
+        // step_conv_forward_ws; STEP_CONV_SPLITK=0 disables)
+        static const bool splitk_ok = !(getenv("STEP_CONV_SPLITK") && atoi(getenv("STEP_CONV_SPLITK")) == 0);
+        const long long M = (long long)d->N * d->D * d->H * d->W;
+        if (splitk_ok && ov1 != 0 && d->dtype != STEP_F32 && d->Cin >= 2048 && M <= 1024 && pl.mtiles * nblk32 < 64) {
+            pl.impl = 3;
+            pl.mbk = M <= 32 ? 1 : (M <= 64 ? 2 : 4);
+            const int KC16 = ceil_div(d->Cin, CK) * 2;
+            const long long mt = ceil_div64(M, pl.mbk * 32);
+            // ~512 workgroups, at least 8 k16 steps (2 per wave) each
+            int ks = (int)(512 / (mt * nblk32));
+            if (ks < 1) ks = 1;
+            pl.kchunk16 = ceil_div(KC16, ks);
+            if (pl.kchunk16 < 8) pl.kchunk16 = 8;
+            pl.ksplit = ceil_div(KC16, pl.kchunk16);
+            pl.mpad = (int)(mt * pl.mbk * 32);
+            pl.cpad = nblk32 * 32;
+            pl.mtiles = mt;
+            pl.NB = 1;
             return pl;
         }
         pl.deep = d->Cin >= 256;        // 128-channel slabs: 4x fewer barriers along a deep K
@@ -1869,12 +1970,35 @@ static int launch_tap(const ConvParams& p, int NB, int tps, int mb, dim3 grid, s
 }
 
 template <typename T>
-static int conv_forward_t(const step_conv_desc* d, ConvParams p, step_stream_t stream) {
+static int splitk_forward_t(const ConvPlan& pl, const ConvParams& p, float* ws, step_stream_t stream) { return STEP_E_UNSUPPORTED; }
+template <typename T16>
+static int splitk_forward_16(const ConvPlan& pl, const ConvParams& p, float* ws, step_stream_t stream) {
+    dim3 grid((unsigned)p.nblk32, (unsigned)pl.ksplit, (unsigned)pl.mtiles);
+    switch (pl.mbk) {
+        case 1: STEP_LAUNCH((pw_splitk_kernel<T16, 1>), grid, dim3(256), stream, p, ws, pl.kchunk16, pl.mpad, pl.cpad); break;
+        case 2: STEP_LAUNCH((pw_splitk_kernel<T16, 2>), grid, dim3(256), stream, p, ws, pl.kchunk16, pl.mpad, pl.cpad); break;
+        default: STEP_LAUNCH((pw_splitk_kernel<T16, 4>), grid, dim3(256), stream, p, ws, pl.kchunk16, pl.mpad, pl.cpad); break;
+    }
+    const long long total = p.Mtot * p.Cout;
+    STEP_LAUNCH((pw_splitk_finish_kernel<T16>), dim3(flat_grid(total, 256)), dim3(256), stream, p, (const float*)ws, pl.ksplit, pl.mpad, pl.cpad);
+    return STEP_LAUNCH_CHECK();
+}
+template <> int splitk_forward_t<bf16_t>(const ConvPlan& pl, const ConvParams& p, float* ws, step_stream_t stream) { return splitk_forward_16<bf16_t>(pl, p, ws, stream); }
+template <> int splitk_forward_t<f16_t>(const ConvPlan& pl, const ConvParams& p, float* ws, step_stream_t stream) { return splitk_forward_16<f16_t>(pl, p, ws, stream); }
+
+template <typename T>
+static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_t ws_bytes, step_stream_t stream) {
     constexpr int VEC = elem<T>::VEC;
     if (d->Cin % VEC || d->x_cstride % VEC || d->x_coff % VEC) return STEP_E_ALIGN;
     if (((uintptr_t)p.x % 16) || ((uintptr_t)p.w % 16)) return STEP_E_ALIGN;
-    const ConvPlan pl = conv_plan(d);
+    ConvPlan pl = conv_plan(d);
     if (!pl.ok) return STEP_E_UNSUPPORTED;
+    if (pl.impl == 3) {
+        const size_t need = (size_t)pl.ksplit * pl.mpad * pl.cpad * sizeof(float);
+        if (ws && ws_bytes >= need && ((uintptr_t)ws % 16) == 0) return splitk_forward_t<T>(pl, p, (float*)ws, stream);
+        // no workspace (plain step_conv_forward): the tiled kernel
+        pl.impl = 0; pl.mtiles = ceil_div64(p.Mtot, 128); pl.NB = pick_nb(p.nblk32, pl.mtiles); pl.deep = d->Cin >= 256;
+    }
     p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.tiles_d = pl.tiles_d;
     p.gtd = pl.gtd; p.gth = pl.gth; p.gtw = pl.gtw;
     if (pl.impl == 2) {
@@ -1957,8 +2081,20 @@ int step_conv_pack_weight(const float* w, int Cout, int Cin, int kd, int kh, int
     return STEP_LAUNCH_CHECK();
 }
 
+size_t step_conv_workspace_bytes(const step_conv_desc* d) {
+    if (!d || d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return 0;
+    const step_conv_desc canon = canonical_desc(d);
+    const ConvPlan pl = conv_plan(&canon);
+    return (pl.ok && pl.impl == 3) ? (size_t)pl.ksplit * pl.mpad * pl.cpad * sizeof(float) : 0;
+}
+
 int step_conv_forward(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale,
                       const float* shift, const void* res, void* y, void* y2, step_stream_t stream) {
+    return step_conv_forward_ws(d, x, w_packed, scale, shift, res, y, y2, nullptr, 0, stream);
+}
+
+int step_conv_forward_ws(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale,
+                         const float* shift, const void* res, void* y, void* y2, void* ws, size_t ws_bytes, step_stream_t stream) {
     if (!d) return STEP_E_NULL;
     if (d->N < 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return STEP_E_SHAPE;
     const int split = (d->split > 0 && d->split < d->Cout) ? d->split : 0;
@@ -1991,9 +2127,9 @@ int step_conv_forward(const step_conv_desc* d, const void* x, const void* w_pack
     p.nblk32 = ceil_div(d->Cout, 32);
     p.Mtot = (long long)d->N * d->D * d->H * d->W;
     switch (d->dtype) {
-        case STEP_F32: return conv_forward_t<float>(d, p, stream);
-        case STEP_BF16: return conv_forward_t<bf16_t>(d, p, stream);
-        case STEP_F16: return conv_forward_t<f16_t>(d, p, stream);
+        case STEP_F32: return conv_forward_t<float>(d, p, ws, ws_bytes, stream);
+        case STEP_BF16: return conv_forward_t<bf16_t>(d, p, ws, ws_bytes, stream);
+        case STEP_F16: return conv_forward_t<f16_t>(d, p, ws, ws_bytes, stream);
     }
     return STEP_E_DTYPE;
 }
@@ -2068,7 +2204,9 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
     const ConvPlan pl = conv_plan(d);
     if (!pl.ok) return STEP_E_UNSUPPORTED;
     const char* t = d->dtype == STEP_F32 ? "float" : (d->dtype == STEP_BF16 ? "step::bf16_t" : "step::f16_t");
-    if (pl.impl == 2)
+    if (pl.impl == 3)
+        snprintf(buf, (size_t)buflen, "void step::pw_splitk_kernel<%s, %d>(step::ConvParams, float*, int, int, int)", t, pl.mbk);
+    else if (pl.impl == 2)
         snprintf(buf, (size_t)buflen, "void step::conv_pw_kernel<%s, %d>(step::ConvParams)", t, pl.NB);
     else if (pl.impl == 1)
         snprintf(buf, (size_t)buflen, "void step::conv_tap_kernel<%s, %d, %d, %d, %d, %d, %d, %d>(step::ConvParams)", t,
@@ -2080,6 +2218,6 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
 }
 
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 3; }
+int step_abi_version(void) { return 4; }
 
 }  // extern "C"

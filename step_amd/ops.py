@@ -117,9 +117,12 @@ def conv_forward(x, w_packed, Cout, k, scale=None, shift=None, relu=True, res=No
         pix = N * D * H * W
         prof = _Prof(buf.value.decode(), 2.0 * pix * Cout * Cin * k[0] * k[1] * k[2],
                      (pix * (Cin + Cout) + Cout * Cin * k[0] * k[1] * k[2]) * _ES[x.dtype])
+    wsb = L.step_conv_workspace_bytes(ctypes.byref(d))            # > 0 only for the split-K Linear layers of the heads
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
     with prof:
-        _capi.check(L.step_conv_forward(ctypes.byref(d), _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift),
-                                        _lib.dptr(res), _lib.dptr(out), _lib.dptr(out2), _lib.stream_ptr(x.device)), "step_conv_forward")
+        _capi.check(L.step_conv_forward_ws(ctypes.byref(d), _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift),
+                                           _lib.dptr(res), _lib.dptr(out), _lib.dptr(out2), _lib.dptr(ws), wsb,
+                                           _lib.stream_ptr(x.device)), "step_conv_forward_ws")
     return out
 
 

@@ -96,8 +96,9 @@ def pack_weight(bk, w, dt, perm=None):
     return out
 
 
-def run_conv(bk, x, w, scale, shift, dt, relu=True, res=None, x_pad=(0, 0), y_pad=(0, 0)):
-    """x NCDHW fp32, w torch layout; x_pad/y_pad = extra channels (before, after) in the buffers."""
+def run_conv(bk, x, w, scale, shift, dt, relu=True, res=None, x_pad=(0, 0), y_pad=(0, 0), use_ws=False):
+    """x NCDHW fp32, w torch layout; x_pad/y_pad = extra channels (before, after) in the buffers.
+    use_ws: call step_conv_forward_ws with the scratch buffer step_conv_workspace_bytes asks for."""
     N, Cin, D, H, W = x.shape
     Cout = w.shape[0]
     xc = cl(x)
@@ -114,7 +115,13 @@ def run_conv(bk, x, w, scale, shift, dt, relu=True, res=None, x_pad=(0, 0), y_pa
     re = bk.dev(None if res is None else encode(cl(res), dt))
     sc = bk.dev(None if scale is None else np.ascontiguousarray(scale, np.float32))
     sh = bk.dev(None if shift is None else np.ascontiguousarray(shift, np.float32))
-    rc = bk.lib.step_conv_forward(ctypes.byref(d), xe.ptr, wp.ptr, sc.ptr, sh.ptr, re.ptr, yb.ptr, None, bk.stream)
+    if use_ws:
+        nb = bk.lib.step_conv_workspace_bytes(ctypes.byref(d))
+        run_conv.last_ws_bytes = nb
+        ws = bk.dev(np.full(max(nb, 16) // 4, np.nan, np.float32))      # scratch needs no initialisation: poison it
+        rc = bk.lib.step_conv_forward_ws(ctypes.byref(d), xe.ptr, wp.ptr, sc.ptr, sh.ptr, re.ptr, yb.ptr, None, ws.ptr, nb, bk.stream)
+    else:
+        rc = bk.lib.step_conv_forward(ctypes.byref(d), xe.ptr, wp.ptr, sc.ptr, sh.ptr, re.ptr, yb.ptr, None, bk.stream)
     assert rc == 0, rc
     y = decode(yb.get(), dt)
     assert not y[..., :y_pad[0]].any() and not y[..., y_pad[0] + Cout:].any()
@@ -416,6 +423,29 @@ def case_conv_golden_units(bk, golden):
         ref = g["unit_%s_out" % tag]
         assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max()
         assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+def case_conv_splitk_few_rows_deep_k(bk, golden):
+    """The heads' Linear layers: a handful of rows, K in the thousands, 12 / 60 outputs -> K split over workgroups
+    through the caller's workspace; without a workspace the tiled kernel must give the same numbers."""
+    rs = np.random.RandomState(21)
+    for (rows, Cin, Cout) in ((5, 2056, 12), (70, 2048, 60)):          # ragged K (2056 = 128*16 + 8), 1 and 3 row blocks
+        x = rs.randn(rows, Cin, 1, 1, 1).astype(np.float32)
+        w = (rs.randn(Cout, Cin, 1, 1, 1) / np.sqrt(Cin)).astype(np.float32)
+        shift = (0.2 * rs.randn(Cout)).astype(np.float32)
+        res = rs.randn(rows, Cout, 1, 1, 1).astype(np.float32)
+        for dt in (BF16, F16):
+            ref = ref_conv(x, w, None, shift, dt, relu=False, res=res)
+            got = run_conv(bk, x, w, None, shift, dt, relu=False, res=res, y_pad=(4, 4), use_ws=True)
+            assert run_conv.last_ws_bytes > 0, "split-K path not taken"
+            plain = run_conv(bk, x, w, None, shift, dt, relu=False, res=res, y_pad=(4, 4))
+            for y in (got, plain):
+                err = np.abs(y - ref).max() / np.abs(ref).max()
+                assert err < tol(dt), (rows, Cin, Cout, dt, err)
+    # fp32 and shallow layers never ask for a workspace
+    d = _capi.ConvDesc(dtype=F32, N=5, D=1, H=1, W=1, Cin=4096, Cout=12, kd=1, kh=1, kw=1, x_cstride=4096, x_coff=0, y_cstride=12,
+                       y_coff=0, res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)
+    assert bk.lib.step_conv_workspace_bytes(ctypes.byref(d)) == 0
 
 
 def case_conv_split_two_destinations(bk, golden):
