@@ -1822,12 +1822,15 @@ static step_conv_desc canonical_desc(const step_conv_desc* d) {
 }
 
 // best general box (td, th, tw) for conv_tap_kernel<TWL = 0>: td*th*tw <= 256 pixels, halo within the LDS
-// reservation; fewest tiles wins, then the smaller halo
+// reservation; fewest tiles wins, then the smaller halo.  Rows stay wide (the whole map width or half of it):
+// a box of short rows, e.g. 16x4x4 on a 28x28 map, needs the fewest tiles (49 against 64) but measured 70 % more
+// time per tile -- eight 4-pixel rows per MFMA row block conflict in LDS and the halo is 2.5x the tile.
 static long long best_gen_box(int D, int H, int W, int kd, int* btd, int* bth, int* btw) {
     long long best = -1; int bhalo = 0;
     for (int kw_ = 1; kw_ <= 8; ++kw_) {
         const int tw = ceil_div(W, kw_);
         if (tw > 256) continue;
+        if (kw_ > 2 && tw < 16) break;
         for (int kh_ = 1; kh_ <= H; ++kh_) {
             const int th = ceil_div(H, kh_);
             if (th * tw > 256) continue;
@@ -1899,15 +1902,15 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
     long long tbest = t16;   // (per clip)
     if (t32 < tbest) { tbest = t32; twl = 5; }
     if (t8 < tbest) { tbest = t8; twl = 3; }
-    // a general box when it needs at least 15 % fewer tiles than the best power-of-two shape: a box tile costs
-    // ~10-20 % more than a power-of-two one (its staging index arithmetic divides, its LDS reads are not
-    // conflict-free) -- measured on the C2 28x28 / 14x14 layers, where 12.5 % fewer tiles ran 8 % SLOWER; the
-    // 50x50 / 25x25 / 100x100 maps of 400x400 clips need 28 % fewer tiles and gain.  STEP_CONV_GEN=0 disables it.
+    // a general box when it needs at least 7 % fewer tiles than the best power-of-two shape (its staging index
+    // arithmetic divides and its LDS reads are not conflict-free, ~5 % per tile).  Measured: C2 (28x28 / 14x14 maps,
+    // 12.5 % fewer tiles) +1.2 % clips/s, the 400x400 backbone (50x50 / 25x25 / 100x100 maps, 28 % fewer tiles) +9 %.
+    // STEP_CONV_GEN=<percent> moves the threshold, 0 disables the general boxes.
     int gtd = 1, gth = 1, gtw = 1;
-    static const bool gen_ok = !(getenv("STEP_CONV_GEN") && atoi(getenv("STEP_CONV_GEN")) == 0);
-    if (gen_ok) {
+    static const int gen_pct = getenv("STEP_CONV_GEN") ? atoi(getenv("STEP_CONV_GEN")) : 93;    // 0 disables
+    if (gen_pct > 0) {
         const long long tg = best_gen_box(d->D, d->H, d->W, d->kd, &gtd, &gth, &gtw);
-        if (tg > 0 && tg * 100 <= tbest * 85) { tbest = tg; twl = 0; }
+        if (tg > 0 && tg * 100 <= tbest * gen_pct) { tbest = tg; twl = 0; }
     }
     const long long mt256 = (long long)d->N * tbest;
     // few-tile, small-Cin problems stay on the 4-wave 128-pixel kernel (more workgroups); everything else -- the
