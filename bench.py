@@ -124,8 +124,8 @@ def roofline(net, x, dtype_name):
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
-            if tj.get("kernel") == name:
-                traffic, tsrc = tj.get("hbm_bytes_per_launch"), tj.get("source")
+            if name in tj.get("kernels", {}):
+                traffic, tsrc = tj["kernels"][name].get("hbm_bytes_per_launch"), tj.get("source")
         except Exception:
             pass
     if mfma_time >= hbm_time:      # matrix-bound kernel: algorithmic FLOP/s against the dense MFMA peak

@@ -21,21 +21,24 @@ def mean_counter(d, kernel_substr, counter):
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 
-def main(fetch_dir, write_dir, kernel, out):
-    f, nf = mean_counter(fetch_dir, kernel, "FETCH_SIZE")
-    w, nw = mean_counter(write_dir, kernel, "WRITE_SIZE")
-    if f is None or w is None:
-        print("kernel not found in the PMC output")
-        return 1
-    rd = f * 1024 * 2          # gfx950: FETCH_SIZE counts 64 B per 128-B request
-    wr = w * 1024
-    j = {"kernel": kernel, "hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr),
-         "launches_sampled": [nf, nw],
+def main(fetch_dir, write_dir, out, *kernels):
+    """kernels: full kernel names as rocprofv3 prints them (bench.py looks its dominant kernel up by that name)."""
+    res = {}
+    for kernel in kernels:
+        f, nf = mean_counter(fetch_dir, kernel, "FETCH_SIZE")
+        w, nw = mean_counter(write_dir, kernel, "WRITE_SIZE")
+        if f is None or w is None:
+            print("kernel not found in the PMC output: %s" % kernel)
+            continue
+        rd = f * 1024 * 2          # gfx950: FETCH_SIZE counts 64 B per 128-B request
+        wr = w * 1024
+        res[kernel] = {"hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr), "launches_sampled": [nf, nw]}
+    j = {"kernels": res,
          "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); FETCH_SIZE x1024 x2 (gfx950 correction), WRITE_SIZE x1024"}
     json.dump(j, open(out, "w"), indent=1)
     print(json.dumps(j))
-    return 0
+    return 0 if res else 1
 
 
 if __name__ == "__main__":
-    sys.exit(main(*sys.argv[1:5]))
+    sys.exit(main(*sys.argv[1:]))
