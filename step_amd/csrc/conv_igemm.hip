@@ -44,12 +44,28 @@ struct ConvParams {
     int relu;
     int tiles_h, tiles_w, tiles_d;
     int gtd, gth, gtw;   // box of a general (TWL = 0) conv_tap tile, gtd*gth*gtw <= 256
+    int gx, gy;          // logical grid: gx pixel tiles x gy channel groups (launched as a 1-D grid, see grid_coords)
     int nchunks;   // ceil(Cin / 32)
     int nchunks32; // same (the packed-weight K extent is 2*nchunks32 k16 blocks)
     int vec_epi;   // 16-byte output stores are legal (channel strides/offsets % 8 == 0, pointers 16-B aligned)
     int nblk32;    // ceil(Cout / 32)
     long long Mtot;  // N*D*H*W
 };
+
+// Launch order -> XCD.  Workgroup ids go round-robin over the 8 XCDs (each with its own L2), so with a plain 2-D grid
+// the channel groups of one pixel tile -- which read the SAME activations -- and spatially adjacent tiles -- which
+// share halos -- end up on different L2s and every one of them fetches its input from HBM / MALL again (PMC on the
+// 3c fused 1x1x1: FETCH 178 MB against 51 MB of input, three channel groups).  The grid is therefore 1-D, padded to
+// a multiple of 8, and remapped: ids that are consecutive on one XCD walk the channel groups of a tile first, then
+// the neighbouring tiles.  Returns false for the padding workgroups (they exit before any barrier).
+__device__ __forceinline__ bool grid_coords(const ConvParams& p, int& bx, int& by) {
+    const unsigned id = blockIdx.x, G = gridDim.x;
+    const unsigned L = (G & 7) ? id : (id & 7) * (G >> 3) + (id >> 3);
+    if (L >= (unsigned)p.gx * (unsigned)p.gy) return false;
+    bx = (int)(L / (unsigned)p.gy);
+    by = (int)(L % (unsigned)p.gy);
+    return true;
+}
 
 template <typename T> struct Ld16;  // 16-byte LDS / global vector of T
 template <> struct Ld16<float> { typedef f32x4 type; };
@@ -152,10 +168,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     // ---- which tile
     int n = 0, d = 0, h0 = 0, w0 = 0;
     long long m0 = 0;
+    int gbx, gby;
+    if (!grid_coords(p, gbx, gby)) return;
     if (FLAT) {
-        m0 = (long long)blockIdx.x * 128;
+        m0 = (long long)gbx * 128;
     } else {
-        int t = blockIdx.x;
+        int t = gbx;
         const int tw_i = t % p.tiles_w; t /= p.tiles_w;
         const int th_i = t % p.tiles_h; t /= p.tiles_h;
         d = t % p.D;
@@ -163,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         h0 = th_i * TH;
         w0 = tw_i * TW;
     }
-    const int nb0 = blockIdx.y * NB;
+    const int nb0 = gby * NB;
     const int KC16 = p.nchunks * 2;
     const int nslab = (p.Cin + CKT - 1) / CKT;
 
@@ -445,14 +463,16 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
     const int khalf = lane >> 5;
     const int wm = wave % WM, wn = wave / WM;
 
-    int t = blockIdx.x;
+    int gbx, gby;
+    if (!grid_coords(p, gbx, gby)) return;
+    int t = gbx;
     const int tw_i = t % p.tiles_w; t /= p.tiles_w;
     const int th_i = t % p.tiles_h; t /= p.tiles_h;
     const int d0 = (t % p.tiles_d) * TD;
     const int n = t / p.tiles_d;
     const int h0 = th_i * TH, w0 = tw_i * TW;
     const int HHW = HH_ * HW_;
-    const int nb0 = blockIdx.y * NBT;
+    const int nb0 = gby * NBT;
     const int KC16 = p.nchunks32 * 2;
     const int nslab = (p.Cin + CKT - 1) / CKT;
     const int S = nslab * SPS;            // pipeline steps
@@ -769,8 +789,10 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(ConvParams p) {
 #endif
     const int khalf = lane >> 5;
     const int wm = wave & 3, wn = wave >> 2;
-    const long long m0 = (long long)blockIdx.x * 256;
-    const int nb0 = blockIdx.y * NBT;
+    int gbx, gby;
+    if (!grid_coords(p, gbx, gby)) return;
+    const long long m0 = (long long)gbx * 256;
+    const int nb0 = gby * NBT;
     const int KC16 = p.nchunks32 * 2;
     const int S = (p.Cin + CKT - 1) / CKT;
 
@@ -2004,8 +2026,13 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_
     }
     p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.tiles_d = pl.tiles_d;
     p.gtd = pl.gtd; p.gth = pl.gth; p.gtw = pl.gtw;
+    auto grid1d = [&](int groups) {                   // logical (mtiles x groups) grid as a 1-D launch padded to 8
+        p.gx = (int)pl.mtiles; p.gy = groups;
+        const long long tot = pl.mtiles * groups;
+        return dim3((unsigned)((tot + 7) / 8 * 8));
+    };
     if (pl.impl == 2) {
-        dim3 grid((unsigned)pl.mtiles, (unsigned)ceil_div(p.nblk32, 2 * pl.NB));
+        dim3 grid = grid1d(ceil_div(p.nblk32, 2 * pl.NB));
         switch (pl.NB) {
             case 1: STEP_LAUNCH((conv_pw_kernel<T, 1>), grid, dim3(512), stream, p); break;
             case 2: STEP_LAUNCH((conv_pw_kernel<T, 2>), grid, dim3(512), stream, p); break;
@@ -2014,7 +2041,7 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_
         return STEP_LAUNCH_CHECK();
     }
     if (pl.impl == 1) {
-        dim3 grid((unsigned)pl.mtiles, (unsigned)ceil_div(p.nblk32, 2 * pl.NB));
+        dim3 grid = grid1d(ceil_div(p.nblk32, 2 * pl.NB));
         if (d->kd == 3) {
             if (pl.twl == 0) return launch_tap<T, 0, 3, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
             if (pl.twl == 3) return launch_tap<T, 3, 3, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
@@ -2024,7 +2051,7 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_
         if (pl.twl == 3) return launch_tap<T, 3, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
         return pl.wide ? launch_tap<T, 5, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream) : launch_tap<T, 4, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
     }
-    dim3 grid((unsigned)pl.mtiles, (unsigned)ceil_div(p.nblk32, pl.NB));
+    dim3 grid = grid1d(ceil_div(p.nblk32, pl.NB));
     if (pl.flat)
         return pl.deep ? launch_nb<T, 4, 1, 1, 1, true, 128>(p, pl.NB, grid, stream) : launch_nb<T, 4, 1, 1, 1, true, 32>(p, pl.NB, grid, stream);
     if (d->kd == 3)
@@ -2121,7 +2148,7 @@ int step_conv_forward_ws(const step_conv_desc* d, const void* x, const void* w_p
     p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
     p.r_cstride = d->res_cstride; p.r_coff = d->res_coff;
     p.relu = d->relu;
-    p.tiles_h = p.tiles_w = 0; p.tiles_d = d->D; p.gtd = p.gth = p.gtw = 1;
+    p.tiles_h = p.tiles_w = 0; p.tiles_d = d->D; p.gtd = p.gth = p.gtw = 1; p.gx = p.gy = 0;
     p.nchunks = ceil_div(d->Cin, CK);
     p.nchunks32 = p.nchunks;
     p.vec_epi = (d->y_cstride % 8 == 0) && (d->y_coff % 8 == 0) && (d->Cout % 8 == 0) && (((uintptr_t)y) % 16 == 0) &&

@@ -121,7 +121,11 @@ def main():
         targets[:, :, 5] = 1
         targets[:, :, 6 + 7] = 1
         t0 = time.perf_counter()
-        for _ in range(2):
+        for it in range(4):
+            if it == 2:                                   # two warm-up steps (library kernel selection, weight packs)
+                torch.cuda.synchronize()
+                print("   (2 warm-up training steps: %.1f s)" % (time.perf_counter() - t0))
+                t0 = time.perf_counter()
             opt.zero_grad()
             cf = base(xb)
             cx = ctx(cf)
