@@ -160,6 +160,14 @@ STEP_API int step_conv_forward_ws(const step_conv_desc* d, const void* x, const 
                                   const float* shift, const void* res, void* y, void* y2, void* ws, size_t ws_bytes,
                                   step_stream_t stream);
 
+/* Weight gradient of the same conv (training, train.py:257-348; replaces the cuDNN wgrad behind Conv3d/Conv2d/Linear
+ * .backward):  dw[co][ci][kd][kh][kw] (fp32, torch's weight layout) (+)= sum_p dy[p][co] * x[p + tap][ci].
+ * x is the forward input described by d (x_cstride / x_coff, dtype), dy the fp32 gradient w.r.t. the conv output
+ * BEFORE the affine epilogue, laid out [N,D,H,W,y_cstride] at y_coff.  accumulate = 0 zero-fills dw first.
+ * Different wavefronts meet in fp32 atomics: results are deterministic up to fp32 summation order. */
+STEP_API int step_conv_wgrad(const step_conv_desc* d, const void* x, const float* dy, float* dw, int accumulate,
+                             step_stream_t stream);
+
 /* Diagnostic: the name (as rocprofv3 prints it) of the kernel instantiation step_conv_forward launches
  * for this descriptor -- lets bench.py attribute time and algorithmic work to profiler rows. */
 STEP_API int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen);

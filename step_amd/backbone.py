@@ -40,8 +40,8 @@ def _ver(*tensors):
 
 class _ConvUnitFn(torch.autograd.Function):
     """Autograd node around the fused HIP conv unit  y = act(conv(x, w) * scale + shift (+ res)).
-    forward = the HIP kernel (always).  backward: data gradient = the HIP kernel again; weight gradient
-    (interim, see module docstring) = torch's convolution_backward on the same channels-last buffers.  `w_eff` is the EFFECTIVE weight
+    forward = the HIP kernel (always).  backward: data gradient = the HIP kernel again; weight gradient = the HIP
+    wgrad kernel (step_conv_wgrad).  `w_eff` is the EFFECTIVE weight
     [Cout, Cin_eff, kd, kh, kw] (after the unit's channel slice / permutation), produced by
     differentiable view ops so autograd routes its gradient back to the parameter."""
 
@@ -77,12 +77,8 @@ class _ConvUnitFn(torch.autograd.Function):
             gin = gconv.to(x.dtype).contiguous()
             gx = ops.conv_forward(gin, ops.pack_conv_weight(w_t, x.dtype), w_t.shape[0], k, None, None, False, None, None)
         if ctx.needs_input_grad[1]:
-            # weight gradient (interim): torch's convolution_backward on channels-last views
-            xv = x.float().permute(0, 4, 1, 2, 3)
-            gv = gconv.permute(0, 4, 1, 2, 3)
-            _, gw, _ = torch.ops.aten.convolution_backward(gv, xv, w_eff.float(), None, [1, 1, 1], [kk // 2 for kk in k],
-                                                           [1, 1, 1], False, [0, 0, 0], 1, [False, True, False])
-            gw = gw.to(w_eff.dtype)
+            # weight gradient = the HIP wgrad kernel (fp32 MFMA over the pixel axis) on the same channels-last buffers
+            gw = ops.conv_wgrad(x, gconv, w_eff.shape[0], k).to(w_eff.dtype)
         return gx, gw, gscale, gshift, gres, None, None
 
 

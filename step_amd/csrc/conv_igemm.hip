@@ -1087,6 +1087,96 @@ __global__ void pw_splitk_finish_kernel(ConvParams p, const float* __restrict__ 
     }
 }
 
+// ============================================================================================
+// conv_wgrad_kernel -- weight gradient of a stride-1 SAME conv on channels-last tensors (train.py:257-348):
+//     dW[co][ci][tap] = sum over pixels p of  dY[p][co] * X[p + tap][ci]
+// A GEMM whose reduction axis is the PIXEL axis.  With channels innermost a lane's 16-bit MFMA fragment (8
+// consecutive k for one row) would be a strided gather; the fp32 instruction v_mfma_f32_32x32x2_f32 takes ONE k
+// per lane per issue, so with lanes along the channel axis every operand element is a plain coalesced load
+// (32 consecutive channels of one pixel) -- no transposed copies, no LDS.  16-bit activations are widened on
+// load; dY is fp32 (the epilogue's ReLU mask / BN scale are applied in fp32 by the caller).  Exact fp32 FMA
+// chains per wavefront; partial sums of different wavefronts meet in fp32 atomics on dW.
+//   wavefront job = one (n, d) plane (or one chunk of pixels of a pointwise layer) x one tap x one
+//   (32*MB x 32*NB) tile of (co, ci); no barriers, four independent wavefronts per workgroup.
+struct WgradParams {
+    const void* x; const float* dy; float* dw;
+    int N, D, H, W, Cin, Cout, kd, kh, kw;
+    int x_cstride, x_coff, dy_cstride, dy_coff;
+    int cot, cit;                 // tiles along Cout / Cin
+    long long jobs;               // N * D planes
+};
+
+template <typename T, int MB, int NB>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, khalf = lane >> 5;
+    const long long job = (long long)blockIdx.x * 4 + wave;
+    if (job >= p.jobs) return;                               // wave-uniform; the kernel has no barrier
+    int t = blockIdx.y;
+    const int cit_i = t % p.cit; t /= p.cit;
+    const int cot_i = t % p.cot;
+    const int tap = t / p.cot;
+    const int ntaps = p.kd * p.kh * p.kw;
+    const int kw_ = tap % p.kw, kh_ = (tap / p.kw) % p.kh, kd_ = tap / (p.kw * p.kh);
+    const int n = (int)(job / p.D), d = (int)(job % p.D);
+    const int id = d + kd_ - p.kd / 2;
+    if (id < 0 || id >= p.D) return;                         // this tap sees only zero padding from this plane
+    const int co0 = cot_i * 32 * MB, ci0 = cit_i * 32 * NB;
+
+    int coc[MB], cic[NB];
+    bool cook[MB], ciok[NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) { const int c = co0 + mb * 32 + m; cook[mb] = c < p.Cout; coc[mb] = cook[mb] ? c : p.Cout - 1; }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { const int c = ci0 + nb * 32 + m; ciok[nb] = c < p.Cin; cic[nb] = ciok[nb] ? c : p.Cin - 1; }
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+    for (int h = 0; h < p.H; ++h) {
+        const int ih = h + kh_ - p.kh / 2;
+        if (ih < 0 || ih >= p.H) continue;
+        const float* dyrow = p.dy + ((((size_t)n * p.D + d) * p.H + h) * p.W) * p.dy_cstride + p.dy_coff;
+        const T* xrow = (const T*)p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W) * p.x_cstride + p.x_coff;
+        for (int w0 = 0; w0 < p.W; w0 += 16) {
+            f32x8 a[MB], b[NB];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int w = w0 + 8 * khalf + j, iw = w + kw_ - p.kw / 2;
+                const bool aok = w < p.W, bok = aok && iw >= 0 && iw < p.W;
+                const int wc = aok ? w : p.W - 1, iwc = bok ? iw : 0;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const float v = dyrow[(size_t)wc * p.dy_cstride + coc[mb]];
+                    a[mb][j] = (aok && cook[mb]) ? v : 0.f;
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float v = elem<T>::to_f32(xrow[(size_t)iwc * p.x_cstride + cic[nb]]);
+                    b[nb][j] = (bok && ciok[nb]) ? v : 0.f;
+                }
+            }
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) mma_k16(a[mb], b[nb], acc[mb][nb], float());
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + mb * 32 + cd_row(r, lane), ci = ci0 + nb * 32 + (lane & 31);
+                if (co < p.Cout && ci < p.Cin) atomicAdd(p.dw + ((size_t)co * p.Cin + ci) * ntaps + tap, acc[mb][nb][r]);
+            }
+}
+
 // ---- weight packing: torch [Cout][Cin][taps] fp32 -> [nb32][tap][kc16][lane][8] of T ----------
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, const int32_t* __restrict__ perm, T* __restrict__ out,
@@ -1814,6 +1904,8 @@ static int pick_nb(int nblk32, long long mtiles) {
 struct ConvPlan { bool ok, flat, wide, deep; int impl, NB, tps, mb, twl, tiles_h, tiles_w, tiles_d, gtd, gth, gtw, ksplit, kchunk16, mbk, mpad, cpad; long long mtiles; };
 
 static int pick_nb_tap(int nblk32, long long mtiles) {
+    static const int forced = getenv("STEP_CONV_NB") ? atoi(getenv("STEP_CONV_NB")) : 0;     // tuning aid
+    if (forced >= 1 && forced <= 3) return forced;
     int best = 1;
     double best_cost = -1;
     for (int nb = 3; nb >= 1; --nb) {   // 2 fragment sets + 2*nb accumulators must fit 256 VGPRs: nb <= 3
@@ -1942,7 +2034,7 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
     if (use_tap) {
         pl.impl = 1;
         pl.tps = (ov == 1) ? 1 : 2;     // two taps per barrier measured 6-15 % faster than one (STEP_CONV_IMPL=tap forces one)
-        pl.mb = (ov == 4) ? 4 : 2;      // STEP_CONV_IMPL=tap4: the 4-wave, 128-pixel-per-wave variant
+        pl.mb = 2;                      // (the 4-wave MB = 4 form of the kernel template spills at NB >= 2 and is not instantiated)
         pl.twl = twl;
         pl.wide = twl == 5;
         pl.gtd = gtd; pl.gth = gth; pl.gtw = gtw;
@@ -1971,13 +2063,7 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
 template <typename T, int TWL, int KD, int KH, int KW>
 static int launch_tap(const ConvParams& p, int NB, int tps, int mb, dim3 grid, step_stream_t stream) {
 #define STEP_TAP(NB_, TPS_, MB_) STEP_LAUNCH((conv_tap_kernel<T, TWL, NB_, KD, KH, KW, TPS_, MB_>), grid, dim3(MB_ == 2 ? 512 : 256), stream, p)
-    if (mb == 4) {
-        switch (NB) {
-            case 1: STEP_TAP(1, 2, 4); break;
-            case 2: STEP_TAP(2, 2, 4); break;
-            default: STEP_TAP(3, 2, 4); break;
-        }
-    } else if (tps == 2) {
+    if (tps == 2) {
         switch (NB) {
             case 1: STEP_TAP(1, 2, 2); break;
             case 2: STEP_TAP(2, 2, 2); break;
@@ -2108,6 +2194,68 @@ int step_conv_pack_weight(const float* w, int Cout, int Cin, int kd, int kh, int
         case STEP_F16: STEP_LAUNCH((pack_weight_kernel<f16_t>), grid, dim3(256), stream, w, perm, (f16_t*)packed, Cout, Cin, ntaps, KC16, total); break;
         default: return STEP_E_DTYPE;
     }
+    return STEP_LAUNCH_CHECK();
+}
+
+int step_conv_wgrad(const step_conv_desc* d, const void* x, const float* dy, float* dw, int accumulate, step_stream_t stream) {
+    if (!d) return STEP_E_NULL;
+    if (d->N < 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return STEP_E_SHAPE;
+    if (d->kd <= 0 || d->kh <= 0 || d->kw <= 0 || !(d->kd & 1) || !(d->kh & 1) || !(d->kw & 1)) return STEP_E_UNSUPPORTED;
+    if (d->x_coff < 0 || d->x_coff + d->Cin > d->x_cstride || d->y_coff < 0 || d->y_coff + d->Cout > d->y_cstride) return STEP_E_SHAPE;
+    if (!dw) return STEP_E_NULL;
+    const int ntaps = d->kd * d->kh * d->kw;
+    if (!accumulate) {
+        const int e = (int)hipMemsetAsync(dw, 0, (size_t)d->Cout * d->Cin * ntaps * sizeof(float), (hipStream_t)stream);
+        if (e != 0) return e;
+    }
+    if (d->N == 0) return STEP_OK;
+    if (!x || !dy) return STEP_E_NULL;
+    WgradParams p;
+    p.x = x; p.dy = dy; p.dw = dw;
+    p.N = d->N; p.D = d->D; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.kd = d->kd; p.kh = d->kh; p.kw = d->kw;
+    p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.dy_cstride = d->y_cstride; p.dy_coff = d->y_coff;
+    if (ntaps == 1) {
+        // pointwise: no neighbourhood, so the pixel axis is cut into chunks of 1024 ("rows" of one long plane list)
+        const long long M = (long long)d->N * d->D * d->H * d->W;
+        const int chunk = 1024;
+        if (M > 0x7fffffffLL) return STEP_E_UNSUPPORTED;
+        // (n, d, h) collapse into full chunks; the ragged tail is a second launch
+        const long long full = M / chunk;
+        const int tail = (int)(M % chunk);
+        int rc = STEP_OK;
+        auto launch = [&](long long jobs, int W, size_t pix0) {
+            p.N = 1; p.D = (int)jobs; p.H = 1; p.W = W; p.jobs = jobs;
+            p.x = (const char*)x + pix0 * d->x_cstride * (d->dtype == STEP_F32 ? 4 : 2);
+            p.dy = dy + pix0 * d->y_cstride;
+            const bool narrow = d->Cin <= 32;
+            p.cot = ceil_div(d->Cout, 64); p.cit = ceil_div(d->Cin, narrow ? 32 : 64);
+            dim3 grid((unsigned)ceil_div64(jobs, 4), (unsigned)(p.cot * p.cit));
+#define STEP_WG(T_) do { if (narrow) STEP_LAUNCH((conv_wgrad_kernel<T_, 2, 1>), grid, dim3(256), stream, p); \
+                         else STEP_LAUNCH((conv_wgrad_kernel<T_, 2, 2>), grid, dim3(256), stream, p); } while (0)
+            switch (d->dtype) {
+                case STEP_F32: STEP_WG(float); break;
+                case STEP_BF16: STEP_WG(bf16_t); break;
+                case STEP_F16: STEP_WG(f16_t); break;
+                default: rc = STEP_E_DTYPE;
+            }
+        };
+        if (full) launch(full, chunk, 0);
+        if (rc == STEP_OK && tail) launch(1, tail, (size_t)full * chunk);
+        return rc != STEP_OK ? rc : STEP_LAUNCH_CHECK();
+    }
+    p.jobs = (long long)d->N * d->D;
+    const bool narrow = d->Cin <= 32;
+    p.cot = ceil_div(d->Cout, 64); p.cit = ceil_div(d->Cin, narrow ? 32 : 64);
+    const long long gy = (long long)ntaps * p.cot * p.cit;
+    if (gy > 65535) return STEP_E_UNSUPPORTED;
+    dim3 grid((unsigned)ceil_div64(p.jobs, 4), (unsigned)gy);
+    switch (d->dtype) {
+        case STEP_F32: STEP_WG(float); break;
+        case STEP_BF16: STEP_WG(bf16_t); break;
+        case STEP_F16: STEP_WG(f16_t); break;
+        default: return STEP_E_DTYPE;
+    }
+#undef STEP_WG
     return STEP_LAUNCH_CHECK();
 }
 
@@ -2248,6 +2396,6 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
 }
 
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 4; }
+int step_abi_version(void) { return 5; }
 
 }  // extern "C"

@@ -126,6 +126,25 @@ def conv_forward(x, w_packed, Cout, k, scale=None, shift=None, relu=True, res=No
     return out
 
 
+def conv_wgrad(x, gy, Cout, k):
+    """Weight gradient of the stride-1 SAME conv: x channels-last [N,D,H,W,Cin] (any storage dtype, may be a channel
+    slice), gy fp32 channels-last [N,D,H,W,Cout] (gradient w.r.t. the conv output before the affine epilogue).
+    Returns fp32 [Cout, Cin, kd, kh, kw]."""
+    L = _lib.lib()
+    N, D, H, W, Cin = x.shape
+    if gy.dtype != torch.float32:
+        gy = gy.float()
+    if not gy.is_contiguous():
+        gy = gy.contiguous()
+    dw = torch.empty((Cout, Cin) + tuple(k), dtype=torch.float32, device=x.device)
+    d = _capi.ConvDesc(dtype=_dt(x), N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2],
+                       x_cstride=_chan_slice(x), x_coff=0, y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=0,
+                       split=0, y2_cstride=0, y2_coff=0)
+    _capi.check(L.step_conv_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(dw), 0, _lib.stream_ptr(x.device)),
+                "step_conv_wgrad")
+    return dw
+
+
 def stem_forward(x, w_packed, Cout, scale, shift, out=None):
     """x: [N,T,3,H,W] contiguous (the reference's input layout) -> channels-last [N,To,Ho,Wo,Cout]"""
     L = _lib.lib()
