@@ -182,6 +182,11 @@ STEP_API int step_stem_pack_weight(const float* w /*[Cout,3,7,7,7]*/, int Cout, 
 STEP_API int step_stem_forward(int dtype, const void* x, int N, int T, int H, int W, const void* w_packed,
                                const float* scale, const float* shift, int Cout, void* y, int y_cstride,
                                int y_coff, step_stream_t stream);
+/* Weight gradient of the stem: dw[Cout][3][7][7][7] (fp32, torch layout) (+)= sum over output pixels of
+ * dy[n,to,ho,wo,co] * x_padded[...]; x as in step_stem_forward, dy fp32 contiguous [N,To,Ho,Wo,Cout] (gradient before
+ * the affine epilogue).  The stem needs no data gradient (its input is the clip). */
+STEP_API int step_stem_wgrad(int dtype, const void* x, int N, int T, int H, int W, const float* dy, int Cout, float* dw,
+                             int accumulate, step_stream_t stream);
 /* Diagnostic, as step_conv_kernel_name: the kernel step_stem_forward launches for this dtype. */
 STEP_API int step_stem_kernel_name(int dtype, char* buf, int buflen);
 

@@ -37,6 +37,7 @@ SIGNATURES = {
     "step_stem_pack_weight": (i, [fp, i, i, vp, vp]),
     "step_stem_forward": (i, [i, vp, i, i, i, i, vp, fp, fp, i, vp, i, i, vp]),
     "step_stem_kernel_name": (i, [i, C.c_char_p, i]),
+    "step_stem_wgrad": (i, [i, vp, i, i, i, i, fp, i, fp, i, vp]),
     "step_pool_out_size": (i, [i, i, i]),
     "step_maxpool3d_tf": (i, [i, vp, i, i, i, i, i, i, i, i, i, i, i, i, i, vp, i, i, vp]),
     "step_avgpool_hw": (i, [i, vp, i, i, i, i, i, i, i, vp, vp]),

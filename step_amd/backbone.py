@@ -221,9 +221,7 @@ class _StemFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, w, scale, y = ctx.saved_tensors
         g = gy.float() * (y > 0).to(torch.float32) * scale.view(1, 1, 1, 1, -1)
-        xv = torch.nn.functional.pad(x.float().permute(0, 2, 1, 3, 4), (2, 3, 2, 3, 2, 3))
-        _, gw, _ = torch.ops.aten.convolution_backward(g.permute(0, 4, 1, 2, 3), xv, w.float(), None, [2, 2, 2], [0, 0, 0],
-                                                       [1, 1, 1], False, [0, 0, 0], 1, [False, True, False])
+        gw = ops.stem_wgrad(x.contiguous(), g, w.shape[0])         # HIP (the clip itself needs no gradient)
         return None, gw.to(w.dtype), None, None, None, None
 
 

@@ -1177,6 +1177,76 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
             }
 }
 
+// stem_wgrad_kernel -- weight gradient of the 7x7x7 stride-2 stem (Cin = 3) from the clip in its own [N,T,3,H,W]
+// layout.  Same scheme as conv_wgrad_kernel (fp32 MFMA, reduction over output pixels, lanes along channels), but
+// with only 3 input channels the B operand's 32 columns are the (kw, c) pairs of one (kd, kh) row of the filter
+// (21 of 32 used): one wavefront job = one output plane (n, od) x one (kd, kh) x 64 output channels.
+struct StemWgradParams {
+    const void* x; const float* dy; float* dw;
+    int N, T, H, W, To, Ho, Wo, Cout, cot;
+    long long jobs;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, khalf = lane >> 5;
+    const long long job = (long long)blockIdx.x * 4 + wave;
+    if (job >= p.jobs) return;
+    int t = blockIdx.y;
+    const int cot_i = t % p.cot; t /= p.cot;
+    const int kh_ = t % 7, kd_ = t / 7;
+    const int n = (int)(job / p.To), od = (int)(job % p.To);
+    const int it = 2 * od + kd_ - 2;
+    if (it < 0 || it >= p.T) return;
+    const int co0 = cot_i * 64;
+    const int kw_ = m / 3, c_ = m % 3;
+    const bool nok = m < 21;
+    int coc[2]; bool cook[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) { const int c = co0 + mb * 32 + m; cook[mb] = c < p.Cout; coc[mb] = cook[mb] ? c : p.Cout - 1; }
+    f32x16 acc[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+    const T* xpl = (const T*)p.x + (((size_t)n * p.T + it) * 3 + (nok ? c_ : 0)) * p.H * p.W;
+    for (int oh = 0; oh < p.Ho; ++oh) {
+        const int ih = 2 * oh + kh_ - 2;
+        if (ih < 0 || ih >= p.H) continue;
+        const float* dyrow = p.dy + ((((size_t)n * p.To + od) * p.Ho + oh) * p.Wo) * p.Cout;
+        const T* xrow = xpl + (size_t)ih * p.W;
+        for (int w0 = 0; w0 < p.Wo; w0 += 16) {
+            f32x8 a[2], b;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ow = w0 + 8 * khalf + j, iw = 2 * ow + kw_ - 2;
+                const bool aok = ow < p.Wo, bok = aok && nok && iw >= 0 && iw < p.W;
+                const int owc = aok ? ow : p.Wo - 1, iwc = bok ? iw : 0;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const float v = dyrow[(size_t)owc * p.Cout + coc[mb]];
+                    a[mb][j] = (aok && cook[mb]) ? v : 0.f;
+                }
+                const float xv = elem<T>::to_f32(xrow[iwc]);
+                b[j] = bok ? xv : 0.f;
+            }
+            mma_k16(a[0], b, acc[0], float());
+            mma_k16(a[1], b, acc[1], float());
+        }
+    }
+    const int nn = lane & 31;
+    if (nn < 21) {
+        const int kw2 = nn / 3, c2 = nn % 3;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + mb * 32 + cd_row(r, lane);
+                if (co < p.Cout) atomicAdd(p.dw + ((((size_t)co * 3 + c2) * 7 + kd_) * 7 + kh_) * 7 + kw2, acc[mb][r]);
+            }
+    }
+}
+
 // ---- weight packing: torch [Cout][Cin][taps] fp32 -> [nb32][tap][kc16][lane][8] of T ----------
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, const int32_t* __restrict__ perm, T* __restrict__ out,
@@ -2363,6 +2433,32 @@ int step_stem_forward(int dtype, const void* x, int N, int T, int H, int W, cons
         case STEP_F16: return ov == 0 ? stem_forward_t<f16_t>(p, stream) : (ov == 1 ? stem_tap_forward_t<f16_t>(p, stream) : stem_stream_forward_t<f16_t>(p, stream));
     }
     return STEP_E_DTYPE;
+}
+
+int step_stem_wgrad(int dtype, const void* x, int N, int T, int H, int W, const float* dy, int Cout, float* dw, int accumulate,
+                    step_stream_t stream) {
+    if (N < 0 || T <= 0 || H <= 0 || W <= 0 || Cout <= 0) return STEP_E_SHAPE;
+    if (!dw) return STEP_E_NULL;
+    if (!accumulate) {
+        const int e = (int)hipMemsetAsync(dw, 0, (size_t)Cout * 3 * 343 * sizeof(float), (hipStream_t)stream);
+        if (e != 0) return e;
+    }
+    if (N == 0) return STEP_OK;
+    if (!x || !dy) return STEP_E_NULL;
+    StemWgradParams p;
+    p.x = x; p.dy = dy; p.dw = dw; p.N = N; p.T = T; p.H = H; p.W = W;
+    p.To = (T + 5 - 7) / 2 + 1; p.Ho = (H + 5 - 7) / 2 + 1; p.Wo = (W + 5 - 7) / 2 + 1;
+    if (p.To <= 0 || p.Ho <= 0 || p.Wo <= 0) return STEP_E_SHAPE;
+    p.Cout = Cout; p.cot = ceil_div(Cout, 64);
+    p.jobs = (long long)N * p.To;
+    dim3 grid((unsigned)ceil_div64(p.jobs, 4), (unsigned)(49 * p.cot));
+    switch (dtype) {
+        case STEP_F32: STEP_LAUNCH((stem_wgrad_kernel<float>), grid, dim3(256), stream, p); break;
+        case STEP_BF16: STEP_LAUNCH((stem_wgrad_kernel<bf16_t>), grid, dim3(256), stream, p); break;
+        case STEP_F16: STEP_LAUNCH((stem_wgrad_kernel<f16_t>), grid, dim3(256), stream, p); break;
+        default: return STEP_E_DTYPE;
+    }
+    return STEP_LAUNCH_CHECK();
 }
 
 int step_stem_kernel_name(int dtype, char* buf, int buflen) {

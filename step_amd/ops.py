@@ -167,6 +167,17 @@ def stem_forward(x, w_packed, Cout, scale, shift, out=None):
     return out
 
 
+def stem_wgrad(x, gy, Cout):
+    """x [N,T,3,H,W] (the clip), gy fp32 channels-last [N,To,Ho,Wo,Cout] -> fp32 [Cout,3,7,7,7]"""
+    L = _lib.lib()
+    N, T, C, H, W = x.shape
+    gy = gy.float().contiguous()
+    dw = torch.empty((Cout, 3, 7, 7, 7), dtype=torch.float32, device=x.device)
+    _capi.check(L.step_stem_wgrad(_dt(x), _lib.dptr(x), N, T, H, W, _lib.dptr(gy), Cout, _lib.dptr(dw), 0, _lib.stream_ptr(x.device)),
+                "step_stem_wgrad")
+    return dw
+
+
 def pool_out_size(L_, k, s):
     return _lib.lib().step_pool_out_size(L_, k, s)
 

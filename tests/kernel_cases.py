@@ -484,6 +484,28 @@ def case_conv_wgrad(bk, golden):
     assert bk.lib.step_conv_wgrad(ctypes.byref(d), None, None, None, 0, bk.stream) < 0     # even kernels: unsupported / null
 
 
+def case_stem_wgrad(bk, golden):
+    rs = np.random.RandomState(44)
+    N, T, H, W, Cout = 2, 6, 13, 20, 40                     # odd / ragged sizes; Cout not a multiple of 32
+    x = rs.randn(N, T, 3, H, W).astype(np.float32)
+    To, Ho, Wo = (T - 2) // 2 + 1, (H - 2) // 2 + 1, (W - 2) // 2 + 1
+    gy = rs.randn(N, Cout, To, Ho, Wo).astype(np.float32)
+    for dt in (F32, BF16):
+        xq = torch.from_numpy(quantize(x, dt))
+        w = torch.zeros(Cout, 3, 7, 7, 7, requires_grad=True)
+        xp = F.pad(xq.permute(0, 2, 1, 3, 4), (2, 3, 2, 3, 2, 3))
+        y = F.conv3d(xp, w, stride=2)
+        assert tuple(y.shape[2:]) == (To, Ho, Wo)
+        y.backward(torch.from_numpy(gy))
+        ref = w.grad.numpy()
+        xd = bk.dev(encode(x, dt))
+        gd = bk.dev(np.ascontiguousarray(cl(gy), np.float32))
+        dw = bk.dev(np.full((Cout, 3, 7, 7, 7), -3.0, np.float32))
+        assert bk.lib.step_stem_wgrad(dt, xd.ptr, N, T, H, W, gd.ptr, Cout, dw.ptr, 0, bk.stream) == 0
+        err = np.abs(dw.get() - ref).max() / np.abs(ref).max()
+        assert err < 2e-5, (dt, err)
+
+
 def case_conv_split_two_destinations(bk, golden):
     """1x1x1 conv whose output channels [0,split) and [split,Cout) land in two different buffers."""
     rs = np.random.RandomState(13)
