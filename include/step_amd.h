@@ -203,6 +203,13 @@ STEP_API int step_maxpool3d_tf(int dtype, const void* x, int N, int D, int H, in
                                int x_coff, int kd, int kh, int kw, int sd, int sh, int sw, void* y, int y_cstride,
                                int y_coff, step_stream_t stream);
 
+/* Backward of step_maxpool3d_tf (training): gx[N,D,H,W,C] (fp32, contiguous, zero-filled by the call) receives
+ * gy[N,Do,Ho,Wo,C] (fp32, contiguous) at the first maximum of each window in (d,h,w) scan order -- torch's MaxPool3d
+ * rule on the explicitly zero-padded tensor; a window won by a pad element drops its gradient. */
+STEP_API int step_maxpool3d_tf_backward(int dtype, const void* x, int N, int D, int H, int W, int C, int x_cstride,
+                                        int x_coff, int kd, int kh, int kw, int sd, int sh, int sw, const float* gy,
+                                        float* gx, step_stream_t stream);
+
 /* Average pool over a full (kh x kw) window, stride 1, no padding ("VALID"), kd = 1.
  * replaces nn.AvgPool3d((1,13,13),(1,1,1)) of ContextNet (models/two_branch.py:127,136).
  * x [N,D,H,W,C] -> y [N,D,H-kh+1,W-kw+1,C] */

@@ -12,10 +12,11 @@ kernels through step_amd.ops on CHANNELS-LAST activations ([N,T,H,W,C]).  A bloc
 write straight into channel slices of one output buffer (no torch.cat), eval-mode BN is folded into
 a per-channel scale/shift applied in the conv epilogue, TF-SAME padding is a load predicate.
 
-Training note (round 1): forward is always the HIP path.  When gradients are required the conv unit
-records a torch autograd node (_ConvUnitFn): the DATA gradient runs on the same HIP conv kernels (taps
-flipped, channel roles swapped), the WEIGHT gradient still uses torch's convolution_backward on the
-same channels-last buffers -- a hand-written wgrad kernel is the next step.
+Training: forward is always the HIP path.  When gradients are required the conv unit records a torch
+autograd node (_ConvUnitFn) whose backward is HIP as well: the DATA gradient runs on the same conv kernels
+(taps flipped, channel roles swapped), the WEIGHT gradient on step_conv_wgrad / step_stem_wgrad (fp32 MFMA over
+the pixel axis), the pools on step_maxpool3d_tf_backward.  No torch / MIOpen convolution or pooling kernel is
+called on either pass; torch does the element-wise mask / scale arithmetic around them.
 """
 import torch
 import torch.nn as nn
@@ -239,7 +240,7 @@ class MaxPoolTF(nn.Module):
 
 
 class _MaxPoolFn(torch.autograd.Function):
-    """Interim backward: re-evaluates the same pool with torch on channels-last views."""
+    """forward and backward = the HIP pool kernels (the gradient goes to the first maximum of a window, torch's rule)."""
 
     @staticmethod
     def forward(ctx, x, k, s):
@@ -250,16 +251,7 @@ class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         (x,) = ctx.saved_tensors
-        k, s = ctx.k, ctx.s
-        with torch.enable_grad():
-            xv = x.detach().float().permute(0, 4, 1, 2, 3).requires_grad_(True)
-            pads = []
-            for kk, ss in zip(reversed(k), reversed(s)):
-                a = max(kk - ss, 0)
-                pads += [a // 2, a - a // 2]
-            yv = torch.nn.functional.max_pool3d(torch.nn.functional.pad(xv, pads), k, s, ceil_mode=True)
-            (gx,) = torch.autograd.grad(yv, xv, gy.float().permute(0, 4, 1, 2, 3))
-        return gx.permute(0, 2, 3, 4, 1).to(x.dtype), None, None
+        return ops.maxpool_tf_backward(x, gy, ctx.k, ctx.s).to(x.dtype), None, None
 
 
 class _FusedPointwise:

@@ -328,6 +328,46 @@ __global__ __launch_bounds__(NT) void maxpool_sep_kernel(const T* __restrict__ x
     for (int pd = pbeg; pd < pend; ++pd) step(pd, rg);
 }
 
+// Backward of the TF-SAME max pool (training): the gradient of an output goes to the FIRST maximum of its window in
+// (d, h, w) scan order -- torch's MaxPool3d rule (`val > max`), applied to the explicitly zero-padded tensor as
+// MaxPool3dTFPadding builds it (models/i3dpt.py:114-126): when a pad element wins, the gradient is dropped.
+// One thread per (output pixel, channel), lanes along C (coalesced taps); fp32 atomics into gx.
+template <typename T>
+__global__ void maxpool3d_tf_bwd_kernel(const T* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx, PoolParams p,
+                                        long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const int c = (int)(idx % p.C);
+        long long pix = idx / p.C;
+        const int ow = (int)(pix % p.Wo); pix /= p.Wo;
+        const int oh = (int)(pix % p.Ho); pix /= p.Ho;
+        const int od = (int)(pix % p.Do);
+        const int n = (int)(pix / p.Do);
+        float best = -__builtin_inff();
+        long long arg = -1;
+        for (int a = 0; a < p.kd; ++a) {
+            const int pd = od * p.sd + a;
+            if (pd >= p.Lpd) break;
+            const int id = pd - p.pfd;
+            for (int b = 0; b < p.kh; ++b) {
+                const int phh = oh * p.sh + b;
+                if (phh >= p.Lph) break;
+                const int ih = phh - p.pfh;
+                for (int cc = 0; cc < p.kw; ++cc) {
+                    const int pw = ow * p.sw + cc;
+                    if (pw >= p.Lpw) break;
+                    const int iw = pw - p.pfw;
+                    const bool inb = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                    const long long pos = (((long long)n * p.D + id) * p.H + ih) * p.W + iw;
+                    const float v = inb ? elem<T>::to_f32(x[(size_t)pos * p.x_cstride + p.x_coff + c]) : 0.f;
+                    if (v > best) { best = v; arg = inb ? pos : -1; }
+                }
+            }
+        }
+        if (arg >= 0) atomicAdd(gx + (size_t)arg * p.C + c, gy[idx]);
+    }
+}
+
 template <typename T>
 __global__ void avgpool_hw_kernel(const T* __restrict__ x, T* __restrict__ y, int ND, int H, int W, int C, int kh,
                                   int kw, long long total) {
@@ -478,6 +518,33 @@ int step_maxpool3d_tf(int dtype, const void* x, int N, int D, int H, int W, int 
         case STEP_F16: return maxpool_t<f16_t>(x, y, p, stream);
     }
     return STEP_E_DTYPE;
+}
+
+int step_maxpool3d_tf_backward(int dtype, const void* x, int N, int D, int H, int W, int C, int x_cstride, int x_coff, int kd,
+                               int kh, int kw, int sd, int sh, int sw, const float* gy, float* gx, step_stream_t stream) {
+    if (N < 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || kd <= 0 || kh <= 0 || kw <= 0 || sd <= 0 || sh <= 0 || sw <= 0)
+        return STEP_E_SHAPE;
+    if (x_coff < 0 || x_coff + C > x_cstride) return STEP_E_SHAPE;
+    if (N == 0) return STEP_OK;
+    if (!x || !gy || !gx) return STEP_E_NULL;
+    PoolParams p;
+    p.N = N; p.D = D; p.H = H; p.W = W; p.C = C; p.x_cstride = x_cstride; p.x_coff = x_coff;
+    p.Do = pool_out_size(D, kd, sd); p.Ho = pool_out_size(H, kh, sh); p.Wo = pool_out_size(W, kw, sw);
+    p.y_cstride = C; p.y_coff = 0;
+    p.kd = kd; p.kh = kh; p.kw = kw; p.sd = sd; p.sh = sh; p.sw = sw;
+    p.pfd = tf_pad_front(kd, sd); p.pfh = tf_pad_front(kh, sh); p.pfw = tf_pad_front(kw, sw);
+    p.Lpd = D + tf_pad_total(kd, sd); p.Lph = H + tf_pad_total(kh, sh); p.Lpw = W + tf_pad_total(kw, sw);
+    int rc = (int)hipMemsetAsync(gx, 0, sizeof(float) * (size_t)N * D * H * W * C, (hipStream_t)stream);
+    if (rc != 0) return rc;
+    const long long total = (long long)N * p.Do * p.Ho * p.Wo * C;
+    const dim3 grid(flat_grid(total, 256));
+    switch (dtype) {
+        case STEP_F32: STEP_LAUNCH((maxpool3d_tf_bwd_kernel<float>), grid, dim3(256), stream, (const float*)x, gy, gx, p, total); break;
+        case STEP_BF16: STEP_LAUNCH((maxpool3d_tf_bwd_kernel<bf16_t>), grid, dim3(256), stream, (const bf16_t*)x, gy, gx, p, total); break;
+        case STEP_F16: STEP_LAUNCH((maxpool3d_tf_bwd_kernel<f16_t>), grid, dim3(256), stream, (const f16_t*)x, gy, gx, p, total); break;
+        default: return STEP_E_DTYPE;
+    }
+    return STEP_LAUNCH_CHECK();
 }
 
 int step_avgpool_hw(int dtype, const void* x, int N, int D, int H, int W, int C, int kh, int kw, void* y,

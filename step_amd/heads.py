@@ -102,8 +102,7 @@ class ContextNet(nn.Module):
         x = self.i3d_conv_context(x)
         if x.shape[2] < 13 or x.shape[3] < 13:
             raise RuntimeError("ContextNet needs >= 13x13 maps after its pool (400x400 clips), got %dx%d" % (x.shape[2], x.shape[3]))
-        y = ops.avgpool_hw(x, 13, 13) if not (torch.is_grad_enabled() and x.requires_grad) else \
-            F.avg_pool3d(x.permute(0, 4, 1, 2, 3), (1, 13, 13), (1, 1, 1)).permute(0, 2, 3, 4, 1)
+        y = _AvgPoolFn.apply(x) if (torch.is_grad_enabled() and x.requires_grad) else ops.avgpool_hw(x, 13, 13)
         return y.permute(0, 4, 1, 2, 3)
 
     def set_device(self, device):
@@ -114,6 +113,26 @@ class ContextNet(nn.Module):
         if mode and self.freeze_stats:
             set_bn_eval(self.i3d_conv_context)
         return self
+
+
+class _AvgPoolFn(torch.autograd.Function):
+    """AvgPool3d((1,13,13)) of ContextNet (two_branch.py:127) with the HIP forward.  On the 13x13 maps of 400x400
+    clips the window is the whole map, so the backward is a broadcast of gy / 169; other sizes take the windowed sum."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return ops.avgpool_hw(x.detach(), 13, 13)
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, D, H, W, C = ctx.shape
+        g = gy / 169.0
+        if H == 13 and W == 13:
+            return g.expand(N, D, H, W, C).contiguous()
+        gx = F.conv_transpose2d(g.permute(0, 1, 4, 2, 3).reshape(N * D * C, 1, H - 12, W - 12),
+                                torch.ones(1, 1, 13, 13, device=gy.device, dtype=g.dtype))
+        return gx.reshape(N, D, C, H, W).permute(0, 1, 3, 4, 2).contiguous()
 
 
 class _Bottleneck(nn.Module):

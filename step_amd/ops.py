@@ -203,6 +203,17 @@ def maxpool_tf(x, k, s, out=None):
     return out
 
 
+def maxpool_tf_backward(x, gy, k, s):
+    """x channels-last [N,D,H,W,C] (the pool's input), gy [N,Do,Ho,Wo,C] -> fp32 gx [N,D,H,W,C]"""
+    L = _lib.lib()
+    N, D, H, W, C = x.shape
+    gy = gy.float().contiguous()
+    gx = torch.empty((N, D, H, W, C), dtype=torch.float32, device=x.device)
+    _capi.check(L.step_maxpool3d_tf_backward(_dt(x), _lib.dptr(x), N, D, H, W, C, _chan_slice(x), 0, k[0], k[1], k[2], s[0], s[1], s[2],
+                                             _lib.dptr(gy), _lib.dptr(gx), _lib.stream_ptr(x.device)), "step_maxpool3d_tf_backward")
+    return gx
+
+
 def avgpool_hw(x, kh, kw):
     L = _lib.lib()
     N, D, H, W, C = x.shape

@@ -321,6 +321,32 @@ def case_maxpool_zero_pad_value(bk, golden):
     assert np.array_equal(yy[:, :1], g["pool_allneg"]) and yy.max() == 0.0 and yy.min() == -1.0
 
 
+def case_maxpool_backward(bk, golden):
+    """Pool backward against torch autograd of ConstantPad3d(0) + MaxPool3d(ceil_mode) (i3dpt.py:114-126), incl. ties
+    between real zeros and pad zeros (post-ReLU data) and all-negative windows won by the pad."""
+    L = bk.lib
+    rs = np.random.RandomState(9)
+    N, C, D, H, W = 2, 8, 5, 9, 7
+    x = rs.randn(N, C, D, H, W).astype(np.float32)
+    x[0] = np.maximum(x[0], 0)                          # clip 0: post-ReLU data, many exact zeros (ties)
+    for k, s in POOLS:
+        xt = torch.from_numpy(x).requires_grad_(True)
+        pads = []
+        for kk, ss in zip(reversed(k), reversed(s)):
+            a = max(kk - ss, 0)
+            pads += [a // 2, a - a // 2]
+        y = F.max_pool3d(F.pad(xt, pads), k, s, ceil_mode=True)
+        gy = rs.randn(*y.shape).astype(np.float32)
+        y.backward(torch.from_numpy(gy))
+        ref = xt.grad.numpy()
+        xd = bk.dev(cl(x))
+        gyd = bk.dev(np.ascontiguousarray(cl(gy)))
+        gxd = bk.dev(np.full((N, D, H, W, C), 5.0, np.float32))
+        assert L.step_maxpool3d_tf_backward(0, xd.ptr, N, D, H, W, C, C, 0, k[0], k[1], k[2], s[0], s[1], s[2], gyd.ptr, gxd.ptr, bk.stream) == 0
+        got = uncl(gxd.get())
+        assert np.allclose(got, ref, rtol=1e-6, atol=1e-6), (k, s, np.abs(got - ref).max())
+
+
 def case_pool_golden(bk, golden):
     g = golden("ops_golden")
     x = R.fill_tensor("golden.pool.in", (2, 5, 6, 9, 11), "image").numpy()
