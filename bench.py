@@ -170,13 +170,21 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and not os.environ.get("STEP_BENCH_SHARE_GPU"):
+        raise SystemExit("bench.py: local rank %d but only %d visible GPU(s)" % (local_rank, ndev))
+    local_dev = local_rank % ndev                                # STEP_BENCH_SHARE_GPU=1: functional test of the N > 1 path on one GPU
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("STEP_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only for the shared-GPU test
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
     net = build_net(dev)
@@ -220,7 +228,7 @@ def main():
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        t = torch.tensor([el], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
