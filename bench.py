@@ -62,7 +62,7 @@ def build_net(device, seed=123):
     return net.to(device).eval()
 
 
-def cpu_baseline(net, seconds_budget=25.0):
+def cpu_baseline(net, seconds_budget=12.0):
     """The oracle's torch-CPU fp32 BaseNet on single clips [1,32,3,224,224], all host cores."""
     from oracle import i3d_ref as R
     sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
@@ -90,7 +90,7 @@ def cpu_baseline(net, seconds_budget=25.0):
             R.basenet_forward(x, sd)
             n += 1
             el = time.perf_counter() - t0
-            if el > seconds_budget or n >= 8:
+            if el > seconds_budget or n >= 64:
                 break
     return {"value": round(n / el, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "%d single-clip [1,32,3,224,224] fp32 forwards of oracle/i3d_ref.basenet_forward (torch CPU) after 1 warm-up, %.1f s" % (n, el)}
