@@ -13,10 +13,12 @@
 #ifdef STEP_EMUL
 #include "hipemu.h"
 #define STEP_WAVES_PER_SIMD(n)
+#define STEP_WAVES_PER_SIMD_MIN(n)
 #else
 #include <hip/hip_runtime.h>
 // register budget: make the compiler fit n wavefronts per SIMD (512 / n VGPRs each)
 #define STEP_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#define STEP_WAVES_PER_SIMD_MIN(n) __attribute__((amdgpu_waves_per_eu(n)))
 #endif
 
 #include "../../include/step_amd.h"

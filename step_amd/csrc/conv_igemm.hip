@@ -384,10 +384,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 // MB = 32-pixel accumulator rows per wave: MB = 2 -> 8 waves (4 x 2, 512 threads, 2 waves per SIMD);
 // MB = 4 -> 4 waves (2 x 2, 256 threads, ONE wave per SIMD with the whole 512-register file: a 128-pixel x
 // 96-channel wave tile reads (4 + NB) fragments per 4*NB MFMAs -- 30 % less LDS traffic per MFMA).
-constexpr int CONV_GEN_NPIX = 768;   // LDS halo pixels reserved for a general (runtime-shaped) tile: 60 KiB
+constexpr int CONV_GEN_NPIX = 768;         // LDS halo pixels reserved for a general (runtime-shaped) tile: 60 KiB
+constexpr int CONV_GEN_NPIX_SMALL = 640;   // ... in the NB = 1 instantiation: 50 KiB + 24 KiB of weights = two workgroups
+                                           // per CU (the small 14x14 / 7x7 layers are latency-bound with one)
 
 template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB>
-__global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParams p) {
+__global__ __launch_bounds__(MB == 2 ? 512 : 256, (NB == 1 && TWL == 0) ? 4 : 2)
+void conv_tap_kernel(ConvParams p) {
     constexpr int NT = (MB == 2) ? 512 : 256;   // threads
     constexpr int WM = 8 / MB;                  // waves along the pixel axis (x 2 along channels)
     constexpr int MBP = MB / 2;                 // accumulator rows per wave per epilogue pass
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(MB == 2 ? 512 : 256) void conv_tap_kernel(ConvParam
     const int HH_ = TH + KH - 1, HWV = TW + KW - 1, HW_ = HWV + HWPAD;   // HWV: columns that hold data
     const int PD = TD + KD - 1;                             // input planes under the tile
     const int NPIX = PD * HH_ * HW_;
-    constexpr int NPIX_MAX = GEN ? CONV_GEN_NPIX : ((1 << TDL) + KD - 1) * ((256 >> (TWL + TDL)) + KH - 1) * ((1 << TWL) + KW - 1 + HWPAD);
+    constexpr int NPIX_MAX = GEN ? (NB == 1 ? CONV_GEN_NPIX_SMALL : CONV_GEN_NPIX) : ((1 << TDL) + KD - 1) * ((256 >> (TWL + TDL)) + KH - 1) * ((1 << TWL) + KW - 1 + HWPAD);
     constexpr int ES = (int)sizeof(T);
     constexpr int VEC = 16 / ES;
     constexpr int CKT = 64 / ES;          // channels per slab: 32 (16-bit) / 16 (fp32)
@@ -2009,7 +2012,7 @@ static step_conv_desc canonical_desc(const step_conv_desc* d) {
 // reservation; fewest tiles wins, then the smaller halo.  Rows stay wide (the whole map width or half of it):
 // a box of short rows, e.g. 16x4x4 on a 28x28 map, needs the fewest tiles (49 against 64) but measured 70 % more
 // time per tile -- eight 4-pixel rows per MFMA row block conflict in LDS and the halo is 2.5x the tile.
-static long long best_gen_box(int D, int H, int W, int kd, int* btd, int* bth, int* btw) {
+static long long best_gen_box(int D, int H, int W, int kd, int npix_limit, int* btd, int* bth, int* btw) {
     long long best = -1; int bhalo = 0;
     for (int kw_ = 1; kw_ <= 8; ++kw_) {
         const int tw = ceil_div(W, kw_);
@@ -2021,7 +2024,7 @@ static long long best_gen_box(int D, int H, int W, int kd, int* btd, int* bth, i
             if (kh_ > 1 && th == ceil_div(H, kh_ - 1)) continue;
             for (int td = 1; td <= D && td * th * tw <= 256; ++td) {
                 const int halo = (td + kd - 1) * (th + 2) * (tw + 2);
-                if (halo > CONV_GEN_NPIX) break;
+                if (halo > npix_limit) break;
                 const long long tiles = (long long)ceil_div(D, td) * ceil_div(H, th) * ceil_div(W, tw);
                 if (best < 0 || tiles < best || (tiles == best && halo < bhalo)) { best = tiles; bhalo = halo; *btd = td; *bth = th; *btw = tw; }
             }
@@ -2092,9 +2095,21 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
     // STEP_CONV_GEN=<percent> moves the threshold, 0 disables the general boxes.
     int gtd = 1, gth = 1, gtw = 1;
     static const int gen_pct = getenv("STEP_CONV_GEN") ? atoi(getenv("STEP_CONV_GEN")) : 93;    // 0 disables
+    const int twl_p2 = twl;
+    const long long tbest_p2 = tbest;
     if (gen_pct > 0) {
-        const long long tg = best_gen_box(d->D, d->H, d->W, d->kd, &gtd, &gth, &gtw);
+        const long long tg = best_gen_box(d->D, d->H, d->W, d->kd, CONV_GEN_NPIX, &gtd, &gth, &gtw);
         if (tg > 0 && tg * 100 <= tbest * gen_pct) { tbest = tg; twl = 0; }
+        if (twl == 0 && pick_nb_tap(nblk32, (long long)d->N * tbest) == 1) {
+            // the NB = 1 instantiation reserves a smaller halo (two workgroups per CU): the box must fit it
+            int std_ = 1, sth = 1, stw = 1;
+            const long long ts = best_gen_box(d->D, d->H, d->W, d->kd, CONV_GEN_NPIX_SMALL, &std_, &sth, &stw);
+            if (ts > 0 && ts * 100 <= tbest_p2 * gen_pct && pick_nb_tap(nblk32, (long long)d->N * ts) == 1) {
+                tbest = ts; gtd = std_; gth = sth; gtw = stw;
+            } else {
+                tbest = tbest_p2; twl = twl_p2;
+            }
+        }
     }
     const long long mt256 = (long long)d->N * tbest;
     // few-tile, small-Cin problems stay on the 4-wave 128-pixel kernel (more workgroups); everything else -- the
