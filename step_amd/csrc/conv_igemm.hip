@@ -1187,6 +1187,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 struct StemWgradParams {
     const void* x; const float* dy; float* dw;
     int N, T, H, W, To, Ho, Wo, Cout, cot;
+    int rows, hchunks;            // output rows per job, jobs per output plane
     long long jobs;
 };
 
@@ -1198,7 +1199,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradParams p) {
     int t = blockIdx.y;
     const int cot_i = t % p.cot; t /= p.cot;
     const int kh_ = t % 7, kd_ = t / 7;
-    const int n = (int)(job / p.To), od = (int)(job % p.To);
+    const int hc = (int)(job % p.hchunks);
+    const long long plane = job / p.hchunks;
+    const int n = (int)(plane / p.To), od = (int)(plane % p.To);
     const int it = 2 * od + kd_ - 2;
     if (it < 0 || it >= p.T) return;
     const int co0 = cot_i * 64;
@@ -1213,7 +1216,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
     const T* xpl = (const T*)p.x + (((size_t)n * p.T + it) * 3 + (nok ? c_ : 0)) * p.H * p.W;
-    for (int oh = 0; oh < p.Ho; ++oh) {
+    for (int oh = hc * p.rows; oh < min((hc + 1) * p.rows, p.Ho); ++oh) {
         const int ih = 2 * oh + kh_ - 2;
         if (ih < 0 || ih >= p.H) continue;
         const float* dyrow = p.dy + ((((size_t)n * p.To + od) * p.Ho + oh) * p.Wo) * p.Cout;
@@ -2465,7 +2468,8 @@ int step_stem_wgrad(int dtype, const void* x, int N, int T, int H, int W, const 
     p.To = (T + 5 - 7) / 2 + 1; p.Ho = (H + 5 - 7) / 2 + 1; p.Wo = (W + 5 - 7) / 2 + 1;
     if (p.To <= 0 || p.Ho <= 0 || p.Wo <= 0) return STEP_E_SHAPE;
     p.Cout = Cout; p.cot = ceil_div(Cout, 64);
-    p.jobs = (long long)N * p.To;
+    p.rows = 8; p.hchunks = ceil_div(p.Ho, p.rows);       // 8 output rows per wavefront job: enough jobs for one clip
+    p.jobs = (long long)N * p.To * p.hchunks;
     dim3 grid((unsigned)ceil_div64(p.jobs, 4), (unsigned)(49 * p.cot));
     switch (dtype) {
         case STEP_F32: STEP_LAUNCH((stem_wgrad_kernel<float>), grid, dim3(256), stream, p); break;
