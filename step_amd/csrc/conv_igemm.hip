@@ -1106,7 +1106,9 @@ struct WgradParams {
     int N, D, H, W, Cin, Cout, kd, kh, kw;
     int x_cstride, x_coff, dy_cstride, dy_coff;
     int cot, cit;                 // tiles along Cout / Cin
-    long long jobs;               // N * D planes
+    int rows;                     // (n, d, h) rows per wavefront job
+    long long total_rows;         // N * D * H
+    long long jobs;               // ceil(total_rows / rows)
 };
 
 template <typename T, int MB, int NB>
@@ -1120,9 +1122,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     const int tap = t / p.cot;
     const int ntaps = p.kd * p.kh * p.kw;
     const int kw_ = tap % p.kw, kh_ = (tap / p.kw) % p.kh, kd_ = tap / (p.kw * p.kh);
-    const int n = (int)(job / p.D), d = (int)(job % p.D);
-    const int id = d + kd_ - p.kd / 2;
-    if (id < 0 || id >= p.D) return;                         // this tap sees only zero padding from this plane
     const int co0 = cot_i * 32 * MB, ci0 = cit_i * 32 * NB;
 
     int coc[MB], cic[NB];
@@ -1140,9 +1139,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 
-    for (int h = 0; h < p.H; ++h) {
-        const int ih = h + kh_ - p.kh / 2;
-        if (ih < 0 || ih >= p.H) continue;
+    const long long r_end = min((job + 1) * (long long)p.rows, p.total_rows);
+    for (long long rr = job * (long long)p.rows; rr < r_end; ++rr) {
+        const int h = (int)(rr % p.H);
+        const long long plane = rr / p.H;
+        const int n = (int)(plane / p.D), d = (int)(plane % p.D);
+        const int id = d + kd_ - p.kd / 2, ih = h + kh_ - p.kh / 2;
+        if (id < 0 || id >= p.D || ih < 0 || ih >= p.H) continue;        // this tap sees only zero padding from this row
         const float* dyrow = p.dy + ((((size_t)n * p.D + d) * p.H + h) * p.W) * p.dy_cstride + p.dy_coff;
         const T* xrow = (const T*)p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W) * p.x_cstride + p.x_coff;
         for (int w0 = 0; w0 < p.W; w0 += 16) {
@@ -2305,14 +2308,22 @@ int step_conv_wgrad(const step_conv_desc* d, const void* x, const float* dy, flo
     if (ntaps == 1) {
         // pointwise: no neighbourhood, so the pixel axis is cut into chunks of 1024 ("rows" of one long plane list)
         const long long M = (long long)d->N * d->D * d->H * d->W;
-        const int chunk = 1024;
         if (M > 0x7fffffffLL) return STEP_E_UNSUPPORTED;
+        // pixels per wavefront job: ~6000 jobs per launch (see below), a multiple of the 16-pixel MFMA step
+        static const int wg_jobs_pw = getenv("STEP_WGRAD_JOBS") ? atoi(getenv("STEP_WGRAD_JOBS")) : 6144;
+        const long long tiles = (long long)ceil_div(d->Cout, 64) * ceil_div(d->Cin, d->Cin <= 32 ? 32 : 64);
+        long long want = wg_jobs_pw / (tiles > 0 ? tiles : 1);
+        if (want < 1) want = 1;
+        long long ch = (ceil_div64(M, want) + 15) / 16 * 16;
+        if (ch < 64) ch = 64;
+        if (ch > 65536) ch = 65536;
+        const int chunk = (int)ch;
         // (n, d, h) collapse into full chunks; the ragged tail is a second launch
         const long long full = M / chunk;
         const int tail = (int)(M % chunk);
         int rc = STEP_OK;
         auto launch = [&](long long jobs, int W, size_t pix0) {
-            p.N = 1; p.D = (int)jobs; p.H = 1; p.W = W; p.jobs = jobs;
+            p.N = 1; p.D = (int)jobs; p.H = 1; p.W = W; p.jobs = jobs; p.rows = 1; p.total_rows = jobs;
             p.x = (const char*)x + pix0 * d->x_cstride * (d->dtype == STEP_F32 ? 4 : 2);
             p.dy = dy + pix0 * d->y_cstride;
             const bool narrow = d->Cin <= 32;
@@ -2331,10 +2342,24 @@ int step_conv_wgrad(const step_conv_desc* d, const void* x, const float* dy, flo
         if (rc == STEP_OK && tail) launch(1, tail, (size_t)full * chunk);
         return rc != STEP_OK ? rc : STEP_LAUNCH_CHECK();
     }
-    p.jobs = (long long)d->N * d->D;
     const bool narrow = d->Cin <= 32;
     p.cot = ceil_div(d->Cout, 64); p.cit = ceil_div(d->Cin, narrow ? 32 : 64);
     const long long gy = (long long)ntaps * p.cot * p.cit;
+    // (n, d, h) rows per wavefront job.  Two opposite pressures (PMC): the kernel hides its load latency only with
+    // several wavefronts per SIMD (1.6 per SIMD -> matrix pipe 18 % busy), but every job ends in one set of fp32
+    // atomics (a 64x64 tile = 4096 of them; the 14x14 layers spent their time in 81 M atomics with one job per
+    // plane).  Aim at ~6000 wavefront jobs per launch, whatever the map size.
+    static const int wg_jobs = getenv("STEP_WGRAD_JOBS") ? atoi(getenv("STEP_WGRAD_JOBS")) : 6144;
+    p.total_rows = (long long)d->N * d->D * d->H;
+    {
+        long long want = wg_jobs / (gy > 0 ? gy : 1);
+        if (want < 1) want = 1;
+        long long rows = ceil_div64(p.total_rows, want);
+        if (rows < 1) rows = 1;
+        if (rows > 0x3fffffff) rows = 0x3fffffff;
+        p.rows = (int)rows;
+    }
+    p.jobs = ceil_div64(p.total_rows, p.rows);
     if (gy > 65535) return STEP_E_UNSUPPORTED;
     dim3 grid((unsigned)ceil_div64(p.jobs, 4), (unsigned)gy);
     switch (d->dtype) {
