@@ -1,0 +1,144 @@
+// step_amd/csrc/conv_common.h -- shared by the conv translation units (conv_igemm.hip, conv_tap_*.hip, conv_pw.hip,
+// conv_wgrad.hip, stem.hip): kernel parameter blocks, the XCD-aware grid remap, LDS / fragment helpers, the launch
+// plan and the cross-unit launch entry points.
+#pragma once
+#include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+
+namespace step {
+
+
+constexpr int CK = 32;  // channels per LDS slab (two k16 MFMA steps)
+
+// The packed weight layout is [Cout/32][taps_padded][Cin/16][lane][8]: an odd tap count > 1 is padded with
+// one all-zero tap so that kernels can walk taps two at a time without a tail case.
+__host__ __device__ constexpr int taps_padded(int ntaps) { return (ntaps > 1 && (ntaps & 1)) ? ntaps + 1 : ntaps; }
+
+struct ConvParams {
+    const void* x; const void* w; const float* scale; const float* shift; const void* res; void* y; void* y2;
+    int split, y2_cstride, y2_coff;
+    int N, D, H, W, Cin, Cout;
+    int x_cstride, x_coff, y_cstride, y_coff, r_cstride, r_coff;
+    int relu;
+    int tiles_h, tiles_w, tiles_d;
+    int gtd, gth, gtw;   // box of a general (TWL = 0) conv_tap tile, gtd*gth*gtw <= 256
+    int gx, gy;          // logical grid: gx pixel tiles x gy channel groups (launched as a 1-D grid, see grid_coords)
+    int nchunks;   // ceil(Cin / 32)
+    int nchunks32; // same (the packed-weight K extent is 2*nchunks32 k16 blocks)
+    int vec_epi;   // 16-byte output stores are legal (channel strides/offsets % 8 == 0, pointers 16-B aligned)
+    int nblk32;    // ceil(Cout / 32)
+    long long Mtot;  // N*D*H*W
+};
+
+// Launch order -> XCD.  Workgroup ids go round-robin over the 8 XCDs (each with its own L2), so with a plain 2-D grid
+// the channel groups of one pixel tile -- which read the SAME activations -- and spatially adjacent tiles -- which
+// share halos -- end up on different L2s and every one of them fetches its input from HBM / MALL again (PMC on the
+// 3c fused 1x1x1: FETCH 178 MB against 51 MB of input, three channel groups).  The grid is therefore 1-D, padded to
+// a multiple of 8, and remapped: ids that are consecutive on one XCD walk the channel groups of a tile first, then
+// the neighbouring tiles.  Returns false for the padding workgroups (they exit before any barrier).
+__device__ __forceinline__ bool grid_coords(const ConvParams& p, int& bx, int& by) {
+    const unsigned id = blockIdx.x, G = gridDim.x;
+    const unsigned L = (G & 7) ? id : (id & 7) * (G >> 3) + (id >> 3);
+    if (L >= (unsigned)p.gx * (unsigned)p.gy) return false;
+    bx = (int)(L / (unsigned)p.gy);
+    by = (int)(L % (unsigned)p.gy);
+    return true;
+}
+
+template <typename T> struct Ld16;  // 16-byte LDS / global vector of T
+template <> struct Ld16<float> { typedef f32x4 type; };
+template <> struct Ld16<bf16_t> { typedef u16x8 type; };
+template <> struct Ld16<f16_t> { typedef u16x8 type; };
+
+template <typename T>
+__device__ __forceinline__ typename frag<T>::type lds_read_frag(const unsigned char* pix_base, int j, int khalf, int sw);
+template <>
+__device__ __forceinline__ f32x8 lds_read_frag<float>(const unsigned char* pix_base, int j, int khalf, int sw) {
+    const int s0 = j * 4 + khalf * 2;
+    f32x4 lo = *(const f32x4*)(pix_base + ((s0 ^ sw) << 4));
+    f32x4 hi = *(const f32x4*)(pix_base + (((s0 + 1) ^ sw) << 4));
+    f32x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+template <>
+__device__ __forceinline__ u16x8 lds_read_frag<bf16_t>(const unsigned char* pix_base, int j, int khalf, int sw) {
+    return *(const u16x8*)(pix_base + (((j * 2 + khalf) ^ sw) << 4));
+}
+template <>
+__device__ __forceinline__ u16x8 lds_read_frag<f16_t>(const unsigned char* pix_base, int j, int khalf, int sw) {
+    return *(const u16x8*)(pix_base + (((j * 2 + khalf) ^ sw) << 4));
+}
+
+// 64-byte-per-pixel slab (conv_tap_kernel): 4 slots; fp32 holds 16 channels (one k16 step),
+// 16-bit types 32 channels (two k16 steps)
+template <typename T>
+__device__ __forceinline__ typename frag<T>::type lds_read_slab64(const unsigned char* pix_base, int j, int khalf, int sw);
+template <>
+__device__ __forceinline__ f32x8 lds_read_slab64<float>(const unsigned char* pix_base, int, int khalf, int sw) {
+    const int s0 = khalf * 2;
+    f32x4 lo = *(const f32x4*)(pix_base + ((s0 ^ sw) << 4));
+    f32x4 hi = *(const f32x4*)(pix_base + (((s0 + 1) ^ sw) << 4));
+    f32x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+template <>
+__device__ __forceinline__ u16x8 lds_read_slab64<bf16_t>(const unsigned char* pix_base, int j, int khalf, int sw) {
+    return *(const u16x8*)(pix_base + (((j * 2 + khalf) ^ sw) << 4));
+}
+template <>
+__device__ __forceinline__ u16x8 lds_read_slab64<f16_t>(const unsigned char* pix_base, int j, int khalf, int sw) {
+    return *(const u16x8*)(pix_base + (((j * 2 + khalf) ^ sw) << 4));
+}
+// B fragment out of the LDS copy of the packed weights (p already includes the lane offset)
+template <typename T>
+__device__ __forceinline__ typename frag<T>::type lds_read_bfrag(const unsigned char* p);
+template <>
+__device__ __forceinline__ f32x8 lds_read_bfrag<float>(const unsigned char* p) {
+    f32x4 lo = *(const f32x4*)p;
+    f32x4 hi = *(const f32x4*)(p + 16);
+    f32x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+template <>
+__device__ __forceinline__ u16x8 lds_read_bfrag<bf16_t>(const unsigned char* p) { return *(const u16x8*)p; }
+template <>
+__device__ __forceinline__ u16x8 lds_read_bfrag<f16_t>(const unsigned char* p) { return *(const u16x8*)p; }
+
+template <typename T>
+__device__ __forceinline__ typename frag<T>::type load_b_frag(const T* p) {  // p -> this lane's 8 elements
+    return *(const typename frag<T>::type*)p;
+}
+
+// TWL: log2(tile width); tile = (128 >> TWL) rows x (1 << TWL) cols of output pixels in one (n, d)
+// plane.  FLAT (1x1x1 only): the tile is 128 consecutive pixels of the flattened N*D*H*W axis.
+// CKT: channels per LDS slab (32, or 128 for pointwise convs with a deep Cin: 4x fewer barriers per K).
+constexpr int CONV_GEN_NPIX = 768;         // LDS halo pixels reserved for a general (runtime-shaped) tile: 60 KiB
+constexpr int CONV_GEN_NPIX_SMALL = 640;   // ... in the NB = 1 instantiation: 50 KiB + 24 KiB of weights = two workgroups
+                                           // per CU (the small 14x14 / 7x7 layers are latency-bound with one)
+
+static inline unsigned flat_grid(long long total, int block) {
+    long long g = ceil_div64(total, block);
+    if (g > 16384) g = 16384;
+    return (unsigned)g;
+}
+
+
+struct ConvPlan { bool ok, flat, wide, deep; int impl, NB, tps, mb, twl, tiles_h, tiles_w, tiles_d, gtd, gth, gtw, ksplit, kchunk16, mbk, mpad, cpad; long long mtiles; };
+
+static inline int conv_impl_override() {   // tuning aid: STEP_CONV_IMPL=igemm|tap|tap2 forces one implementation
+    const char* e = getenv("STEP_CONV_IMPL");
+    if (!e) return -1;
+    if (e[0] == 'i') return 0;
+    if (e[0] == 'p') return 5;      // pw: force the streaming pointwise GEMM for every 1x1x1 conv
+    if (e[0] == 't') return (e[1] && e[2] && e[3] == '2') ? 2 : ((e[1] && e[2] && e[3] == '4') ? 4 : 1);
+    return -1;
+}
+
+// launchers defined in the other translation units (explicitly instantiated for float, bf16_t, f16_t)
+template <typename T> int conv_tap_launch(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream);   // conv_tap_<dtype>.hip
+template <typename T> int conv_pw_launch(int NB, const ConvParams& p, dim3 grid, step_stream_t stream);                        // conv_pw.hip
+template <typename T> int conv_splitk_launch(const ConvPlan& pl, const ConvParams& p, float* ws, step_stream_t stream);        // conv_pw.hip
+
+}  // namespace step

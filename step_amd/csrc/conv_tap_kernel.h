@@ -1,0 +1,430 @@
+// step_amd/csrc/conv_tap_kernel.h -- the pipelined 8-wave implicit-GEMM conv kernel (3x3x3 and 1x3x3 windows) and its
+// launcher template; included by conv_tap_f32.hip / conv_tap_bf16.hip / conv_tap_f16.hip (one storage type per
+// translation unit, so the three build in parallel).
+#pragma once
+#include "conv_common.h"
+
+namespace step {
+
+// ============================================================================================
+// conv_tap_kernel -- the heavy 3x3x3 / 1x3x3 path.
+//
+// 512 threads = 8 wavefronts own a 256-pixel x (64*NB)-channel output tile.  Waves are arranged
+// 4 (pixels) x 2 (channels); each wave accumulates 2 x NB 32x32 MFMA tiles (64 px x 32*NB ch).
+//   * A: a 64-byte-per-pixel slab (32 channels of 16-bit data, 16 of fp32) of the input halo tile
+//     ([kd][TH+kh-1][TW+kw-1] pixels) is staged into LDS once per slab; all taps read it at shifted
+//     bases (im2col-free).  Pixels sit at an 80-byte pitch (64 B + 16 B pad): consecutive pixels
+//     rotate through the LDS banks without an XOR swizzle and a tap shift is a plain byte offset.
+//   * B: the weights of ONE tap x slab x tile-channels (4*NB KiB, already in MFMA fragment order in
+//     global memory, so the copy is linear) go global -> registers -> LDS through a double-buffered
+//     LDS tile with a two-taps-deep register prefetch: the loads for tap s+2 are issued before the
+//     MFMAs of tap s, the registers loaded one tap earlier are written to LDS after them, one
+//     barrier per tap.  Every B fragment read from LDS feeds 2 MFMAs and every A fragment NB MFMAs
+//     (a k16 step costs 2 + NB ds_read_b128 for 2*NB MFMAs), and the weights cross the L2 -> CU
+//     path once per 256 pixels instead of once per 32.
+// MB = 32-pixel accumulator rows per wave: MB = 2 -> 8 waves (4 x 2, 512 threads, 2 waves per SIMD);
+// MB = 4 -> 4 waves (2 x 2, 256 threads, ONE wave per SIMD with the whole 512-register file: a 128-pixel x
+// 96-channel wave tile reads (4 + NB) fragments per 4*NB MFMAs -- 30 % less LDS traffic per MFMA).
+
+template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB>
+__global__ __launch_bounds__(MB == 2 ? 512 : 256, (NB == 1 && TWL == 0) ? 4 : 2)
+void conv_tap_kernel(ConvParams p) {
+    constexpr int NT = (MB == 2) ? 512 : 256;   // threads
+    constexpr int WM = 8 / MB;                  // waves along the pixel axis (x 2 along channels)
+    constexpr int MBP = MB / 2;                 // accumulator rows per wave per epilogue pass
+    // tile shapes: TWL = 4 -> 1 plane x 16 x 16, TWL = 5 -> 1 x 8 x 32, TWL = 3 -> 4 planes x 8 x 8 (small maps:
+    // 7x7 ROI features would fill 19 % of a 16x16 tile; four planes of 8x8 fill 77 %), TWL = 0 -> a box of
+    // p.gtd x p.gth x p.gtw <= 256 pixels chosen at launch (GEN): power-of-two tiles cover a 28x28 map at 77 %,
+    // a 50x50 one at 70 %; 2x4x28 and 2x5x25 boxes reach 88 % and 98 %.  The index arithmetic of a GEN tile uses
+    // divisions, but only outside the step loop.
+    constexpr bool GEN = (TWL == 0);
+    constexpr int TDL = (TWL == 3) ? 2 : 0;
+    constexpr int THL = GEN ? 0 : (((256 >> (TWL + TDL)) == 16) ? 4 : 3);   // log2(TH): 16 -> 4, 8 -> 3
+    const int TD = GEN ? p.gtd : (1 << TDL);
+    const int TW = GEN ? p.gtw : (1 << TWL), TH = GEN ? p.gth : (256 >> (TWL + TDL));
+    const int TPX = TD * TH * TW;                           // pixels of the tile (256 unless GEN)
+    // LDS bank conflicts of the A-fragment reads.  ds_read_b128 is serviced in four 16-lane groups ({0-3,12-15,20-27},
+    // {4-11,16-19,28-31}, and the same + 32); with the 80-byte pixel pitch a group is conflict-free iff its 16 lanes
+    // read pixels whose linear halo indices are distinct mod 16.  Lanes 0..31 of an MFMA row block are 32
+    // consecutive tile pixels: one 32-pixel row (8x32 tile: conflict-free as is), two 16-pixel rows (16x16: row
+    // pitch 18 = 2 mod 16 -> 2-way) or four 8-pixel rows (4x8x8: row pitch 10 -> 3-way; measured: 37 % of the LDS
+    // cycles of the 2c layer were conflicts).  Fix: the assignment of accumulator rows to tile COLUMNS is free, so
+    // odd rows of the 16x16 tile are rotated by 2 columns, and the 4x8x8 tile gets a 12-pixel row pitch plus a
+    // swap of the column halves on rows 1, 2 (mod 4); the epilogue applies the same map (tile_col).
+    constexpr int HWPAD = (TWL == 3) ? 2 : 0;
+    const int HH_ = TH + KH - 1, HWV = TW + KW - 1, HW_ = HWV + HWPAD;   // HWV: columns that hold data
+    const int PD = TD + KD - 1;                             // input planes under the tile
+    const int NPIX = PD * HH_ * HW_;
+    constexpr int NPIX_MAX = GEN ? (NB == 1 ? CONV_GEN_NPIX_SMALL : CONV_GEN_NPIX) : ((1 << TDL) + KD - 1) * ((256 >> (TWL + TDL)) + KH - 1) * ((1 << TWL) + KW - 1 + HWPAD);
+    constexpr int ES = (int)sizeof(T);
+    constexpr int VEC = 16 / ES;
+    constexpr int CKT = 64 / ES;          // channels per slab: 32 (16-bit) / 16 (fp32)
+    constexpr int KS = CKT / 16;          // k16 steps per slab
+    constexpr int PITCH = 80, SLOTS = 4;
+    constexpr int NTAPS = KD * KH * KW;
+    const int NVEC = NPIX * SLOTS;
+    constexpr int ITER = (NPIX_MAX * SLOTS + NT - 1) / NT;
+    constexpr int FRAGB = 512 * ES;       // bytes of one B fragment (64 lanes x 8 elements)
+    constexpr int FRAGV = FRAGB / 16;     // 16-byte vectors per fragment
+    constexpr int NBT = 2 * NB;           // 32-channel blocks per workgroup tile
+    constexpr int BTILE = NBT * KS * FRAGB;
+    constexpr int BVEC = BTILE / 16;      // 16-byte vectors per tap tile
+    constexpr int Q = (BVEC + NT - 1) / NT; // vectors per thread per tap
+    constexpr int NTP = taps_padded(NTAPS);                 // packed taps (odd counts carry one zero tap)
+    constexpr int SPS = (TPS == 1) ? NTAPS : NTP / TPS;     // pipeline steps per slab (TPS taps per barrier)
+    constexpr int BSTEP = TPS * BTILE;                      // LDS weight bytes per step
+    typedef typename Ld16<T>::type vec16;
+    typedef typename frag<T>::type frag_t;
+
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX_MAX * PITCH + 3 * BSTEP];
+    unsigned char* const ldsA = lds;
+    unsigned char* const ldsB = lds + NPIX_MAX * PITCH;
+    // tile pixel index m (accumulator row) -> box coordinates; rows past the box of a GEN tile alias pixel 0
+    auto tile_pix = [&](int m, int& td, int& th, int& tw) {
+        if (GEN) {
+            const int mc = m < TPX ? m : 0;
+            tw = mc % TW; const int q = mc / TW; th = q % TH; td = q / TH;
+        } else {
+            td = m >> (TWL + THL); th = (m >> TWL) & (TH - 1); tw = m & (TW - 1);
+        }
+    };
+
+    auto tile_col = [](int th, int j) {                    // tile row th, accumulator-row column slot j -> tile column
+        if (TWL == 4) return (th & 1) ? ((j + 14) & 15) : j;
+        if (TWL == 3) return (((th & 3) == 1) || ((th & 3) == 2)) ? (j ^ 4) : j;
+        return j;
+    };
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+#ifdef STEP_EMUL
+    const int wave = tid >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> scalar branches
+#endif
+    const int khalf = lane >> 5;
+    const int wm = wave % WM, wn = wave / WM;
+
+    int gbx, gby;
+    if (!grid_coords(p, gbx, gby)) return;
+    int t = gbx;
+    const int tw_i = t % p.tiles_w; t /= p.tiles_w;
+    const int th_i = t % p.tiles_h; t /= p.tiles_h;
+    const int d0 = (t % p.tiles_d) * TD;
+    const int n = t / p.tiles_d;
+    const int h0 = th_i * TH, w0 = tw_i * TW;
+    const int HHW = HH_ * HW_;
+    const int nb0 = gby * NBT;
+    const int KC16 = p.nchunks32 * 2;
+    const int nslab = (p.Cin + CKT - 1) / CKT;
+    const int S = nslab * SPS;            // pipeline steps
+
+    const T* xg = (const T*)p.x;
+    const unsigned char* wg = (const unsigned char*)p.w;
+
+    // LDS address of this lane's two accumulator rows (before the tap shift), incl. its k half
+    const unsigned char* abase[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int m = wm * (MB * 32) + mb * 32 + (lane & 31);
+        int td_, th_, tw_;
+        tile_pix(m, td_, th_, tw_);
+        abase[mb] = ldsA + ((td_ * HH_ + th_) * HW_ + tile_col(th_, tw_)) * PITCH + khalf * (ES == 4 ? 32 : 16);
+    }
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][i][r] = 0.f;
+
+    auto stage_A = [&](int slab) {
+        vec16 stage[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int v = tid + it * NT;
+            vec16 val;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) val[e] = 0;
+            if (v < NVEC) {
+                const int pix = v / SLOTS, slot = v % SLOTS;
+                const int c = slab * CKT + slot * VEC;
+                const int plane = pix / HHW, rem = pix % HHW;
+                const int r = rem / HW_, cc = rem % HW_;
+                const int id = d0 + plane - KD / 2, ih = h0 + r - KH / 2, iw = w0 + cc - KW / 2;
+                const bool inb = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && cc < HWV;
+                if (inb && c < p.Cin) {
+                    const size_t gpix = (((size_t)n * p.D + id) * p.H + ih) * p.W + iw;
+                    val = *(const vec16*)(xg + gpix * p.x_cstride + p.x_coff + c);
+                }
+            }
+            stage[it] = val;
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int v = tid + it * NT;
+            if (v < NVEC) {
+                const int pix = v / SLOTS, slot = v % SLOTS;
+                *(vec16*)(ldsA + pix * PITCH + (slot << 4)) = stage[it];
+            }
+        }
+    };
+
+    // global -> registers: this thread's vectors of the B tile of a pipeline step.  Branch-free on
+    // purpose (a predicated load makes the compiler drain vmcnt at the loop head): threads without a
+    // vector re-load the last one, and channel blocks past Cout re-load the last real block -- their
+    // accumulators are never stored.  The per-thread part of the address is computed ONCE; a step
+    // only adds a wave-uniform byte offset ((tap * KC16 + slab * KS) fragments).
+    const unsigned char* wthr[Q];
+    int ldsoff[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int v = min(tid + q * NT, BVEC - 1);
+        const int f = v / FRAGV, within = v % FRAGV;
+        const int nbl = f / KS, ks = f % KS;
+        const int nbg = min(nb0 + nbl, p.nblk32 - 1);
+        wthr[q] = wg + ((size_t)nbg * taps_padded(NTAPS) * KC16 + ks) * FRAGB + within * 16;
+        ldsoff[q] = (tid + q * NT < BVEC) ? (tid + q * NT) * 16 : -1;
+    }
+    auto load_B = [&](int slab_, int sis_, u32x4 (&r)[TPS * Q]) {         // sis_ = step index within the slab
+#pragma unroll
+        for (int tp = 0; tp < TPS; ++tp) {
+            const size_t off = (size_t)((sis_ * TPS + tp) * KC16 + slab_ * KS) * FRAGB;      // scalar
+#pragma unroll
+            for (int q = 0; q < Q; ++q) r[tp * Q + q] = *(const u32x4*)(wthr[q] + off);
+        }
+    };
+    auto store_B = [&](int bufoff, const u32x4 (&r)[TPS * Q]) {
+#pragma unroll
+        for (int tp = 0; tp < TPS; ++tp)
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                if (ldsoff[q] >= 0) *(u32x4*)(ldsB + bufoff + tp * BTILE + ldsoff[q]) = r[tp * Q + q];
+    };
+
+    // Pipeline.  A STEP = TPS taps of one slab = one barrier; a SLOT = one tap.
+    //   weights: TWO register sets (R0 on even steps, R1 on odd ones) and THREE LDS step-buffers.  During step s
+    //     the set of that parity, which holds step s+2 (loaded during step s-2), is written to buffer (s+2)%3
+    //     -- last read during step s-1 -- and re-issued for step s+4: two steps of matrix work (~1500 cycles)
+    //     cover the L2 latency of the weight stream; with one set the load -> store distance was a single step.
+    //   fragments: two register sets alternating per slot.  The ds_reads of slot u+1 are issued BEFORE
+    //     the MFMAs of slot u (for the first slot of a step they come from the next buffer, complete
+    //     since the previous barrier), so LDS latency, the weight hand-over and the barrier hide behind
+    //     matrix work.  A slab switch drains the pipeline once per slab.
+    u32x4 R0[TPS * Q], R1[TPS * Q];
+    frag_t fa[2][KS][MB], fb[2][KS][NB];
+
+    const unsigned char* const bwave = ldsB + (wn * NB) * KS * FRAGB + lane * (8 * ES);
+    auto read_frags = [&](auto setc, int bufoff, int shift) {
+        constexpr int SET = decltype(setc)::value;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) fa[SET][j][mb] = lds_read_bfrag<T>(abase[mb] + shift + j * 32);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) fb[SET][j][i] = lds_read_bfrag<T>(bwave + bufoff + (i * KS + j) * FRAGB);
+        }
+    };
+    auto mma_all = [&](auto setc) {
+        constexpr int SET = decltype(setc)::value;
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {   // channel blocks past Cout compute on a duplicate block and are never stored
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) mma_k16(fa[SET][j][mb], fb[SET][j][i], acc[mb][i], T());
+            }
+    };
+    // LDS byte shift of tap t of the slab (the zero tap of an odd tap count reads tap 0's pixels)
+    auto tap_shift = [&](int t_) {
+        const int tt = (t_ < NTAPS) ? t_ : 0;
+        return (((tt / (KH * KW)) * HH_ + (tt / KW) % KH) * HW_ + tt % KW) * PITCH;
+    };
+
+    // (slab, step-in-slab) cursors: c0 = current step, c3 = step + 4 (weight loads)
+    int slab0 = 0, sis0 = 0, slab3 = 0, sis3 = 0;
+    auto adv = [&](int& sl, int& si) { if (++si == SPS) { si = 0; ++sl; } };
+    auto adv_clamped = [&]() { adv(slab3, sis3); if (slab3 >= nslab) { slab3 = nslab - 1; sis3 = SPS - 1; } };   // past the end: re-read the last tile
+
+    stage_A(0);
+    load_B(0, 0, R0);
+    adv_clamped();
+    load_B(slab3, sis3, R1);
+    adv_clamped();
+    store_B(0, R0);
+    load_B(slab3, sis3, R0);                               // step 2
+    adv_clamped();
+    store_B(BSTEP, R1);
+    load_B(slab3, sis3, R1);                               // step 3
+    adv_clamped();                                         // -> step 4
+    __syncthreads();
+    read_frags(std::integral_constant<int, 0>(), 0, 0);
+
+    int b0 = 0, b1 = BSTEP, b2 = 2 * BSTEP;                // LDS buffers of step s, s+1, s+2
+    int s_ = 0;                                            // current step
+    auto slot = [&](auto setc, auto tpc, u32x4 (&R)[TPS * Q]) {
+        constexpr int SET = decltype(setc)::value;
+        constexpr int TP = decltype(tpc)::value;           // tap slot within the step
+        constexpr bool LAST = (TP == TPS - 1);
+        bool new_slab = false;
+        if (!LAST) {                                       // next slot: same step, same weight buffer
+            read_frags(std::integral_constant<int, SET ^ 1>(), b0 + (TP + 1) * BTILE, tap_shift(sis0 * TPS + TP + 1));
+        } else {                                           // next slot opens step s+1
+            new_slab = (sis0 + 1 == SPS);
+            if (s_ + 1 < S && !new_slab)
+                read_frags(std::integral_constant<int, SET ^ 1>(), b1, tap_shift((sis0 + 1) * TPS));
+        }
+        mma_all(setc);
+        if (LAST) {
+            store_B(b2, R);                                // (past the end: a duplicate tile into a buffer nobody reads)
+            load_B(slab3, sis3, R);
+            adv_clamped();
+            if (s_ + 1 < S && new_slab) {
+                __syncthreads();                          // every wave is done with this slab of A
+                stage_A(slab0 + 1);
+                __syncthreads();
+                read_frags(std::integral_constant<int, SET ^ 1>(), b1, 0);
+            }
+            __syncthreads();
+            const int t0 = b0; b0 = b1; b1 = b2; b2 = t0;  // rotate the three buffers
+            adv(slab0, sis0);
+            ++s_;
+        }
+    };
+    if (TPS == 2) {
+#pragma unroll 1
+        while (s_ < S) {
+            slot(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), R0);
+            slot(std::integral_constant<int, 1>(), std::integral_constant<int, TPS - 1>(), R0);
+            if (s_ < S) {
+                slot(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), R1);
+                slot(std::integral_constant<int, 1>(), std::integral_constant<int, TPS - 1>(), R1);
+            }
+        }
+    } else {
+#pragma unroll 1
+        while (s_ < S) {
+            slot(std::integral_constant<int, 0>(), std::integral_constant<int, TPS - 1>(), R0);
+            if (s_ < S) slot(std::integral_constant<int, 1>(), std::integral_constant<int, TPS - 1>(), R1);
+        }
+    }
+
+    // ---- epilogue
+    T* yg = (T*)p.y;
+    const T* rg = (const T*)p.res;
+    if (ES == 2 && p.vec_epi) {
+        // 16-bit outputs: transpose the accumulators through LDS (fp32, 128 pixels at a time) so that
+        // every lane stores 16 contiguous bytes (8 channels of one pixel): 8x fewer store instructions
+        // than the accumulator layout allows (2 B per lane, 64 B runs) and whole-line writes.
+        constexpr int BN = NBT * 32, G = BN / 8;
+        float* ot = (float*)lds;
+        float sc[NB], sh[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int co = min((nb0 + wn * NB + i) * 32 + (lane & 31), p.Cout - 1);
+            sc[i] = p.scale ? p.scale[co] : 1.f;
+            sh[i] = p.shift ? p.shift[co] : 0.f;
+        }
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {                  // two passes of 128 pixels
+            if (ps) __syncthreads();                      // previous half has been read out
+#pragma unroll
+            for (int mbl = 0; mbl < MBP; ++mbl)
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        ot[((wm * MBP + mbl) * 32 + cd_row(r, lane)) * BN + (wn * NB + i) * 32 + (lane & 31)] =
+                            acc[ps * MBP + mbl][i][r] * sc[i] + sh[i];
+            __syncthreads();
+            for (int idx = tid; idx < 128 * G; idx += NT) {
+                const int row = idx / G, g = idx % G;
+                // row = (wm*MBP + mbl)*32 + rr  ->  tile pixel wm*(MB*32) + (ps*MBP + mbl)*32 + rr
+                const int mm = ((row >> 5) / MBP) * (MB * 32) + (ps * MBP + (row >> 5) % MBP) * 32 + (row & 31);
+                int tdl, thl, twl;
+                tile_pix(mm, tdl, thl, twl);
+                const int od = d0 + tdl, oh = h0 + thl, ow = w0 + tile_col(thl, twl);
+                const int co = nb0 * 32 + g * 8;
+                if ((!GEN || mm < TPX) && od < p.D && oh < p.H && ow < p.W && co < p.Cout) {
+                    const size_t opix = (((size_t)n * p.D + od) * p.H + oh) * p.W + ow;
+                    const f32x4 lo = *(const f32x4*)(ot + row * BN + g * 8);
+                    const f32x4 hi = *(const f32x4*)(ot + row * BN + g * 8 + 4);
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if (rg) {
+                        const u16x8 rv = *(const u16x8*)(rg + opix * p.r_cstride + p.r_coff + co);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += elem<T>::from_bits16(rv[e]);
+                    }
+                    u16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = elem<T>::bits16(p.relu ? fmaxf(v[e], 0.f) : v[e]);
+                    *(u16x8*)(yg + opix * p.y_cstride + p.y_coff + co) = o;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int nbg = nb0 + wn * NB + i;
+        const int co = nbg * 32 + (lane & 31);
+        if (nbg < p.nblk32 && co < p.Cout) {
+            const float sc = p.scale ? p.scale[co] : 1.f;
+            const float sh = p.shift ? p.shift[co] : 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mm = wm * (MB * 32) + mb * 32 + cd_row(r, lane);
+                    int tdl, thl, twl;
+                    tile_pix(mm, tdl, thl, twl);
+                    const int od = d0 + tdl, oh = h0 + thl, ow = w0 + tile_col(thl, twl);
+                    if ((!GEN || mm < TPX) && od < p.D && oh < p.H && ow < p.W) {
+                        const size_t opix = (((size_t)n * p.D + od) * p.H + oh) * p.W + ow;
+                        float v = acc[mb][i][r] * sc + sh;
+                        if (rg) v += elem<T>::to_f32(rg[opix * p.r_cstride + p.r_coff + co]);
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        yg[opix * p.y_cstride + p.y_coff + co] = elem<T>::from_f32(v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+
+template <typename T, int TWL, int KD, int KH, int KW>
+static int launch_tap(const ConvParams& p, int NB, int tps, int mb, dim3 grid, step_stream_t stream) {
+#define STEP_TAP(NB_, TPS_, MB_) STEP_LAUNCH((conv_tap_kernel<T, TWL, NB_, KD, KH, KW, TPS_, MB_>), grid, dim3(MB_ == 2 ? 512 : 256), stream, p)
+    if (tps == 2) {
+        switch (NB) {
+            case 1: STEP_TAP(1, 2, 2); break;
+            case 2: STEP_TAP(2, 2, 2); break;
+            default: STEP_TAP(3, 2, 2); break;
+        }
+    } else {
+        switch (NB) {
+            case 1: STEP_TAP(1, 1, 2); break;
+            case 2: STEP_TAP(2, 1, 2); break;
+            default: STEP_TAP(3, 1, 2); break;
+        }
+    }
+#undef STEP_TAP
+    return STEP_LAUNCH_CHECK();
+}
+
+
+template <typename T>
+int conv_tap_launch(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream) {
+    if (kd == 3) {
+        if (pl.twl == 0) return launch_tap<T, 0, 3, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
+        if (pl.twl == 3) return launch_tap<T, 3, 3, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
+        return pl.wide ? launch_tap<T, 5, 3, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream) : launch_tap<T, 4, 3, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
+    }
+    if (pl.twl == 0) return launch_tap<T, 0, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
+    if (pl.twl == 3) return launch_tap<T, 3, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
+    return pl.wide ? launch_tap<T, 5, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream) : launch_tap<T, 4, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
+}
+
+}  // namespace step

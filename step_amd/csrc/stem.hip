@@ -1,0 +1,767 @@
+// step_amd/csrc/stem.hip -- the I3D stem (7x7x7, stride 2, Cin = 3): stem_igemm_kernel (fp32 parity path),
+// stem_tap_kernel, stem_stream_kernel (dense K axis, default for 16-bit storage), their weight packers and the C entry
+// points step_stem_*.
+#include "conv_common.h"
+
+namespace step {
+
+// ============================================================================================
+// The I3D stem: 7x7x7, stride 2, Cin = 3, pad (2 front, 3 back) + affine + ReLU.
+// Input in the reference's own layout x[N][T][3][H][W]; output channels-last.
+// The slab in LDS is [7 frames][2*TH+5 rows][40 cols] pixels of 4 channels (c = 3 is zero) and
+// the GEMM K axis is ordered (kd, kh, kw(8, the 8th tap has zero weight), c(4)): the 8 taps x 4
+// channels an output pixel needs from one input row are 32 CONTIGUOUS, 16-byte aligned
+// elements, so the stride-2 gather is again a plain ds_read_b128 per lane.  K = 7*7*32 = 1568.
+constexpr int STEM_TH = 8, STEM_TW = 16;
+constexpr int STEM_ROWS = 2 * STEM_TH + 5, STEM_COLS = 40;
+
+struct StemParams {
+    const void* x; const void* w; const float* scale; const float* shift; void* y;
+    int N, T, H, W, To, Ho, Wo, Cout, y_cstride, y_coff;
+    int tiles_h, tiles_w, nblk32;
+};
+
+template <typename T, int NB>
+__global__ __launch_bounds__(256) void stem_igemm_kernel(StemParams p) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int PIXB = 4 * ES;  // bytes per LDS pixel (4 channels)
+    constexpr int NPIX = 7 * STEM_ROWS * STEM_COLS;
+    typedef typename frag<T>::type frag_t;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX * PIXB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int khalf = lane >> 5;
+    const int m = wave * 32 + (lane & 31);
+    const int th = m >> 4, tw = m & 15;
+
+    int t = blockIdx.x;
+    const int tw_i = t % p.tiles_w; t /= p.tiles_w;
+    const int th_i = t % p.tiles_h; t /= p.tiles_h;
+    const int od = t % p.To;
+    const int n = t / p.To;
+    const int oh0 = th_i * STEM_TH, ow0 = tw_i * STEM_TW;
+    const int nb0 = blockIdx.y * NB;
+
+    // ---- stage: LDS col cl <-> input col iw = 2*ow0 - 4 + cl ; row r <-> ih = 2*oh0 - 2 + r ;
+    //      frame f <-> it = 2*od - 2 + f.  Items = 4 consecutive cols of one (frame,row).
+    const T* xg = (const T*)p.x;
+    const bool vec_ok = (p.W % 4) == 0;
+    for (int item = tid; item < 7 * STEM_ROWS * (STEM_COLS / 4); item += 256) {
+        const int cq = item % (STEM_COLS / 4);
+        const int r = (item / (STEM_COLS / 4)) % STEM_ROWS;
+        const int f = item / ((STEM_COLS / 4) * STEM_ROWS);
+        const int it = 2 * od - 2 + f, ih = 2 * oh0 - 2 + r, iw0 = 2 * ow0 - 4 + cq * 4;
+        T px[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) px[a][c] = elem<T>::from_f32(0.f);
+        if (it >= 0 && it < p.T && ih >= 0 && ih < p.H) {
+            const size_t base = (((size_t)n * p.T + it) * 3) * p.H * p.W + (size_t)ih * p.W;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const T* src = xg + base + (size_t)c * p.H * p.W;
+                if (vec_ok && iw0 >= 0 && iw0 + 3 < p.W) {
+                    typedef unsigned int uvec __attribute__((ext_vector_type(ES)));   // 4 elements = 2*ES... bytes
+                    uvec raw = *(const uvec*)(src + iw0);
+                    T v4[4];
+                    __builtin_memcpy(v4, &raw, sizeof(v4));
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) px[a][c] = v4[a];
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        if (iw0 + a >= 0 && iw0 + a < p.W) px[a][c] = src[iw0 + a];
+                }
+            }
+        }
+        unsigned char* dst = lds + ((f * STEM_ROWS + r) * STEM_COLS + cq * 4) * PIXB;
+#pragma unroll
+        for (int q = 0; q < (4 * PIXB) / 16; ++q) {
+            u32x4 tmp;
+            __builtin_memcpy(&tmp, (const unsigned char*)&px[0][0] + 16 * q, 16);
+            *(u32x4*)(dst + 16 * q) = tmp;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const T* wg = (const T*)p.w;
+#pragma unroll 1
+    for (int kd = 0; kd < 7; ++kd) {
+#pragma unroll 1
+        for (int kh = 0; kh < 7; ++kh) {
+            // pixel (2*tw + 2 + 0) of row (2*th + kh) of frame kd; this lane's 8 elements of step j
+            // start at tap kw = 4*j + 2*khalf
+            const unsigned char* rowb = lds + ((kd * STEM_ROWS + 2 * th + kh) * STEM_COLS + 2 * tw + 2) * PIXB;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned char* ap = rowb + (4 * j + 2 * khalf) * PIXB;
+                frag_t a;
+                {
+                    u32x4 h2[ES / 2];
+#pragma unroll
+                    for (int q = 0; q < ES / 2; ++q) h2[q] = *(const u32x4*)(ap + 16 * q);
+                    __builtin_memcpy(&a, h2, sizeof(a));
+                }
+                const int ks = (kd * 7 + kh) * 2 + j;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    if (nb0 + i < p.nblk32) {
+                        const T* bp = wg + (((size_t)(nb0 + i) * 98 + ks) * 64 + lane) * 8;
+                        const frag_t b = load_b_frag<T>(bp);
+                        mma_k16(a, b, acc[i], T());
+                    }
+                }
+            }
+        }
+    }
+
+    T* yg = (T*)p.y;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int co = (nb0 + i) * 32 + (lane & 31);
+        if (nb0 + i < p.nblk32 && co < p.Cout) {
+            const float sc = p.scale ? p.scale[co] : 1.f;
+            const float sh = p.shift ? p.shift[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = wave * 32 + cd_row(r, lane);
+                const int oh = oh0 + (mm >> 4), ow = ow0 + (mm & 15);
+                if (oh < p.Ho && ow < p.Wo) {
+                    float v = fmaxf(acc[i][r] * sc + sh, 0.f);
+                    const size_t opix = (((size_t)n * p.To + od) * p.Ho + oh) * p.Wo + ow;
+                    yg[opix * p.y_cstride + p.y_coff + co] = elem<T>::from_f32(v);
+                }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// stem_tap_kernel (16-bit types): the pipelined form of the stem.
+// 256 threads = 4 wavefronts own a 16x16-pixel x 64-channel output tile of one output frame; each
+// wave accumulates a 64-pixel x 64-channel block (2 x 2 MFMA tiles).  One pipeline step = one
+// (kd, kh) pair = 32 K values (8 kw taps x 4 channels), 49 steps.
+//   * input frames go through a 3-slot LDS ring ([37 rows][40 cols] pixels of 4 channels each): frame
+//     kd+2 is loaded into registers at the first step of frame kd and written to the slot frame kd-1
+//     left, so only 35 KB of LDS hold the 7-frame receptive field and 3 workgroups fit on a CU
+//     (their staging bubbles fill each other's matrix work);
+//   * weights: one register set + 3 LDS buffers, fragments: 2 register sets (as conv_tap_kernel);
+//   * epilogue: LDS transpose, 16-byte stores.
+constexpr int STP_ROWS = 37, STP_COLS = 40;
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_tap_kernel(StemParams p) {
+    static_assert(sizeof(T) == 2, "16-bit storage types only");
+    constexpr int PIXB = 8;                         // 4 channels x 2 B
+    constexpr int FRAME = STP_ROWS * STP_COLS * PIXB;   // 11840 B
+    constexpr int NB = 2, KS = 2, FRAGB = 1024;
+    constexpr int BTILE = NB * KS * FRAGB;          // 4 KiB per step
+    constexpr int S = 49;
+    constexpr int ITEMS = STP_ROWS * (STP_COLS / 4);   // 4-pixel items per frame
+    constexpr int FQ = (ITEMS + 255) / 256;         // items per thread per frame (2)
+    typedef u16x8 frag_t;
+
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * FRAME + 3 * BTILE];
+    unsigned char* const ldsA = lds;
+    unsigned char* const ldsB = lds + 3 * FRAME;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+#ifdef STEP_EMUL
+    const int wave = tid >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const int khalf = lane >> 5;
+
+    int t = blockIdx.x;
+    const int tw_i = t % p.tiles_w; t /= p.tiles_w;
+    const int th_i = t % p.tiles_h; t /= p.tiles_h;
+    const int od = t % p.To;
+    const int n = t / p.To;
+    const int oh0 = th_i * 16, ow0 = tw_i * 16;
+    const int nb0 = blockIdx.y * NB;
+
+    const T* xg = (const T*)p.x;
+    const unsigned char* wg = (const unsigned char*)p.w;
+    const bool vec_ok = (p.W % 4) == 0;
+
+    // ---- frame staging: LDS col cl <-> input col 2*ow0 - 4 + cl, row r <-> input row 2*oh0 - 2 + r
+    struct Item { u16x4 c[3]; };
+    auto load_frame = [&](int f, Item (&it)[FQ]) {
+        const int ifr = 2 * od - 2 + f;
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) {
+            const int item = tid + q * 256;
+            const int cq = item % (STP_COLS / 4), r = item / (STP_COLS / 4);
+            const int ih = 2 * oh0 - 2 + r, iw0 = 2 * ow0 - 4 + cq * 4;
+            const bool rowok = item < ITEMS && ifr >= 0 && ifr < p.T && ih >= 0 && ih < p.H;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                u16x4 v = {0, 0, 0, 0};
+                if (rowok) {
+                    const unsigned short* src = (const unsigned short*)xg + ((((size_t)n * p.T + ifr) * 3 + c) * p.H + ih) * p.W;
+                    if (vec_ok && iw0 >= 0 && iw0 + 3 < p.W) {
+                        v = *(const u16x4*)(src + iw0);
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+                            if (iw0 + a >= 0 && iw0 + a < p.W) v[a] = src[iw0 + a];
+                    }
+                }
+                it[q].c[c] = v;
+            }
+        }
+    };
+    auto store_frame = [&](int slot, const Item (&it)[FQ]) {
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) {
+            const int item = tid + q * 256;
+            if (item < ITEMS) {
+                const int cq = item % (STP_COLS / 4), r = item / (STP_COLS / 4);
+                unsigned char* dst = ldsA + slot * FRAME + (r * STP_COLS + cq * 4) * PIXB;
+                const u16x8 lo = {it[q].c[0][0], it[q].c[1][0], it[q].c[2][0], 0, it[q].c[0][1], it[q].c[1][1], it[q].c[2][1], 0};
+                const u16x8 hi = {it[q].c[0][2], it[q].c[1][2], it[q].c[2][2], 0, it[q].c[0][3], it[q].c[1][3], it[q].c[2][3], 0};
+                *(u16x8*)dst = lo;
+                *(u16x8*)(dst + 16) = hi;
+            }
+        }
+    };
+
+    // ---- weights: thread tid owns one 16-byte vector of the 4 KiB step tile
+    const int bf = tid >> 6;                                   // fragment (nbl, j)
+    const unsigned char* wthr = wg + (((size_t)min(nb0 + (bf >> 1), p.nblk32 - 1) * 98 + (bf & 1)) * 64 + (tid & 63)) * 16;
+    auto load_B = [&](int s_) { return *(const u32x4*)(wthr + (size_t)s_ * 2 * FRAGB); };
+
+    // ---- this lane's A base: pixel (2*th, 2*tw + 2) of the slot, + its k half
+    const unsigned char* abase[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int th = wave * 4 + mb * 2 + ((lane & 31) >> 4), tw = lane & 15;
+        abase[mb] = ldsA + ((2 * th) * STP_COLS + 2 * tw + 2 + 2 * khalf) * PIXB;
+    }
+    const unsigned char* const bwave = ldsB + lane * 16;
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][i][r] = 0.f;
+
+    frag_t fa[2][KS][2], fb[2][KS][NB];
+    auto read_frags = [&](auto setc, int bufoff, int aoff) {
+        constexpr int SET = decltype(setc)::value;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) fa[SET][j][mb] = *(const frag_t*)(abase[mb] + aoff + j * 32);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) fb[SET][j][i] = *(const frag_t*)(bwave + bufoff + (i * KS + j) * FRAGB);
+        }
+    };
+    auto mma_all = [&](auto setc) {
+        constexpr int SET = decltype(setc)::value;
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                mma_k16(fa[SET][j][0], fb[SET][j][i], acc[0][i], T());
+                mma_k16(fa[SET][j][1], fb[SET][j][i], acc[1][i], T());
+            }
+    };
+
+    // ---- prologue: frames 0 and 1, weight tiles 0 and 1, tile 2 in flight
+    Item fr[FQ];
+    load_frame(0, fr); store_frame(0, fr);
+    load_frame(1, fr); store_frame(1, fr);
+    u32x4 R = load_B(0);
+    *(u32x4*)(ldsB + tid * 16) = R;
+    R = load_B(1);
+    *(u32x4*)(ldsB + BTILE + tid * 16) = R;
+    R = load_B(2);
+    __syncthreads();
+    read_frags(std::integral_constant<int, 0>(), 0, 0);
+
+    int b1 = BTILE, b2 = 2 * BTILE;
+    int kd1 = 0, kh1 = 0;                              // coordinates of step s+1
+    auto step = [&](auto setc, int s_) {
+        constexpr int SET = decltype(setc)::value;
+        const int kh = kh1, kd = kd1;                  // this step
+        if (++kh1 == 7) { kh1 = 0; ++kd1; }
+        if (kh == 0 && kd + 2 < 7) load_frame(kd + 2, fr);          // in flight over three steps
+        if (s_ + 1 < S) read_frags(std::integral_constant<int, SET ^ 1>(), b1, (kd1 % 3) * FRAME + kh1 * (STP_COLS * PIXB));
+        mma_all(setc);
+        if (s_ + 2 < S) *(u32x4*)(ldsB + b2 + tid * 16) = R;
+        if (s_ + 3 < S) R = load_B(s_ + 3);
+        if (kh == 3 && kd + 2 < 7) store_frame((kd + 2) % 3, fr);   // the slot of frame kd-1 (last read 4+ steps ago)
+        __syncthreads();
+        const int nb = (b2 == 2 * BTILE) ? 0 : b2 + BTILE;
+        b1 = b2; b2 = nb;
+    };
+#pragma unroll 1
+    for (int s_ = 0; s_ < S; s_ += 2) {
+        step(std::integral_constant<int, 0>(), s_);
+        if (s_ + 1 < S) step(std::integral_constant<int, 1>(), s_ + 1);
+    }
+
+    // ---- epilogue: affine + ReLU, LDS transpose (fp32, 128 pixels at a time), 16-byte stores
+    T* yg = (T*)p.y;
+    constexpr int BN = NB * 32, G = BN / 8;
+    float* ot = (float*)lds;
+    float sc[NB], sh[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int co = min((nb0 + i) * 32 + (lane & 31), p.Cout - 1);
+        sc[i] = p.scale ? p.scale[co] : 1.f;
+        sh[i] = p.shift ? p.shift[co] : 0.f;
+    }
+    const bool vec_epi = (p.y_cstride % 8 == 0) && (p.y_coff % 8 == 0) && (p.Cout % 8 == 0) && (((uintptr_t)p.y) % 16 == 0);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        if (mb) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ot[(wave * 32 + cd_row(r, lane)) * BN + i * 32 + (lane & 31)] = fmaxf(acc[mb][i][r] * sc[i] + sh[i], 0.f);
+        __syncthreads();
+        for (int idx = tid; idx < 128 * G; idx += 256) {
+            const int row = idx / G, g = idx % G;
+            // row = wave*32 + rr ; pixel: th = wave*4 + mb*2 + (rr >> 4), tw = rr & 15
+            const int oh = oh0 + (row >> 5) * 4 + mb * 2 + ((row & 31) >> 4), ow = ow0 + (row & 15);
+            const int co = nb0 * 32 + g * 8;
+            if (oh < p.Ho && ow < p.Wo && co < p.Cout) {
+                const size_t opix = (((size_t)n * p.To + od) * p.Ho + oh) * p.Wo + ow;
+                const float* src = ot + row * BN + g * 8;
+                if (vec_epi) {
+                    u16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = elem<T>::bits16(src[e]);
+                    *(u16x8*)(yg + opix * p.y_cstride + p.y_coff + co) = o;
+                } else {
+                    for (int e = 0; e < 8; ++e)
+                        if (co + e < p.Cout) yg[opix * p.y_cstride + p.y_coff + co + e] = elem<T>::from_f32(src[e]);
+                }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// stem_stream_kernel (16-bit types): the stem with a dense K axis.
+// stem_tap_kernel keeps 4-channel pixels and 8 kw taps per row so that every fragment is one aligned
+// 16-byte LDS read -- at the price of multiplying 32 K values per (kd, kh) row of which 21 are real.
+// Here a frame row in LDS is the plain element stream [col][3 channels] (6 bytes per pixel, 240 bytes per
+// row), so the 7 taps x 3 channels an output pixel needs from a row are 21 CONSECUTIVE elements starting at
+// byte 12*tw + 12: three 8-element fragments (q = 0, 1, 2; the last 3 elements belong to the pixel after the
+// window and meet zero weights).  Those addresses are only 4-byte aligned: a misaligned ds_read_b128
+// measures 6.6x slower than an aligned one on gfx950, two ds_read2_b32 run at the full LDS rate
+// (tools/ubench/lds_align.hip), so fragments are read as two 8-byte halves with 4-byte alignment.
+// K order inside a frame (11 MFMA K-steps of 16, against 14 before):
+//   j = 0..8 : rows (2*rp, 2*rp + 1), rp = j / 3, fragment q = j % 3; the lower lane half (k 0..7) takes
+//              the even row, the upper half the odd row (+240 bytes);
+//   j = 9    : row 6, q = 0 (lower half) and q = 1 (upper half);
+//   j = 10   : row 6, q = 2 (lower half); the upper half multiplies zero weights.
+// 77 K-steps per tile instead of 98.  Everything else follows stem_tap_kernel: 4 waves x (2 x 2 MFMA
+// tiles) on a 16x16-pixel x 64-channel tile, 3-slot frame ring, weights through 3 LDS buffers (tiles of
+// 4, 4 and 3 K-steps per frame: tile t of every frame lives in buffer t), one barrier per weight tile,
+// fragments double-buffered in registers per K-step.
+constexpr int STS_PITCH = 240;                      // bytes per LDS frame row (40 px x 3 ch x 2 B)
+constexpr int STS_FRAME = STP_ROWS * STS_PITCH;     // 8880 B
+constexpr int STS_KSTEPS = 77;
+
+__device__ __forceinline__ u16x8 lds_read_frag_a4(const unsigned char* p) {
+    typedef unsigned int u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+    const u32x2_a4 lo = *(const u32x2_a4*)p;
+    const u32x2_a4 hi = *(const u32x2_a4*)(p + 8);
+    const u32x4 v = {lo.x, lo.y, hi.x, hi.y};
+    u16x8 r;
+    __builtin_memcpy(&r, &v, 16);
+    return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel(StemParams p) {
+    static_assert(sizeof(T) == 2, "16-bit storage types only");
+    constexpr int FRAME = STS_FRAME, PITCH = STS_PITCH;
+    constexpr int NB = 2, FRAGB = 1024;
+    constexpr int NBREG = 4 * FRAGB;                // one n-block's share of a weight buffer (up to 4 K-steps)
+    constexpr int BBUF = NB * NBREG;                // 8 KiB
+    constexpr int ITEMS = STP_ROWS * (STP_COLS / 4);   // 4-pixel items per frame
+    constexpr int FQ = (ITEMS + 255) / 256;
+    constexpr int NTILES = 21;                      // weight tiles: 3 per frame
+    typedef u16x8 frag_t;
+
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * FRAME + 3 * BBUF];
+    unsigned char* const ldsA = lds;
+    unsigned char* const ldsB = lds + 3 * FRAME;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+#ifdef STEP_EMUL
+    const int wave = tid >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const int khalf = lane >> 5;
+
+    int t = blockIdx.x;
+    const int tw_i = t % p.tiles_w; t /= p.tiles_w;
+    const int th_i = t % p.tiles_h; t /= p.tiles_h;
+    const int od = t % p.To;
+    const int n = t / p.To;
+    const int oh0 = th_i * 16, ow0 = tw_i * 16;
+    const int nb0 = blockIdx.y * NB;
+
+    const T* xg = (const T*)p.x;
+    const unsigned char* wg = (const unsigned char*)p.w;
+    const bool vec_ok = (p.W % 4) == 0;
+
+    // ---- frame staging: LDS col cl <-> input col 2*ow0 - 4 + cl, row r <-> input row 2*oh0 - 2 + r
+    struct Item { u16x4 c[3]; };
+    auto load_frame = [&](int f, Item (&it)[FQ]) {
+        const int ifr = 2 * od - 2 + f;
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) {
+            const int item = tid + q * 256;
+            const int cq = item % (STP_COLS / 4), r = item / (STP_COLS / 4);
+            const int ih = 2 * oh0 - 2 + r, iw0 = 2 * ow0 - 4 + cq * 4;
+            const bool rowok = item < ITEMS && ifr >= 0 && ifr < p.T && ih >= 0 && ih < p.H;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                u16x4 v = {0, 0, 0, 0};
+                if (rowok) {
+                    const unsigned short* src = (const unsigned short*)xg + ((((size_t)n * p.T + ifr) * 3 + c) * p.H + ih) * p.W;
+                    if (vec_ok && iw0 >= 0 && iw0 + 3 < p.W) {
+                        v = *(const u16x4*)(src + iw0);
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+                            if (iw0 + a >= 0 && iw0 + a < p.W) v[a] = src[iw0 + a];
+                    }
+                }
+                it[q].c[c] = v;
+            }
+        }
+    };
+    auto store_frame = [&](int slotoff, const Item (&it)[FQ]) {
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) {
+            const int item = tid + q * 256;
+            if (item < ITEMS) {
+                const int cq = item % (STP_COLS / 4), r = item / (STP_COLS / 4);
+                unsigned char* dst = ldsA + slotoff + r * PITCH + cq * 24;
+                const u16x4 v0 = {it[q].c[0][0], it[q].c[1][0], it[q].c[2][0], it[q].c[0][1]};
+                const u16x4 v1 = {it[q].c[1][1], it[q].c[2][1], it[q].c[0][2], it[q].c[1][2]};
+                const u16x4 v2 = {it[q].c[2][2], it[q].c[0][3], it[q].c[1][3], it[q].c[2][3]};
+                *(u16x4*)dst = v0;
+                *(u16x4*)(dst + 8) = v1;
+                *(u16x4*)(dst + 16) = v2;
+            }
+        }
+    };
+
+    // ---- weights: thread tid moves one 16-byte vector per n-block of a tile (K-steps kstep0 .. kstep0+3;
+    //      the 3-K-step tiles carry one K-step of the next tile along, never read)
+    const unsigned char* wthr[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+        wthr[i] = wg + ((size_t)min(nb0 + i, p.nblk32 - 1) * STS_KSTEPS) * FRAGB + tid * 16;
+    struct BReg { u32x4 v[NB]; };
+    auto load_B = [&](int tile) {
+        tile = min(tile, NTILES - 1);
+        const int ks0 = (tile / 3) * 11 + (tile % 3) * 4;
+        BReg r;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) r.v[i] = *(const u32x4*)(wthr[i] + (size_t)ks0 * FRAGB);
+        return r;
+    };
+    auto store_B = [&](int buf, const BReg& r) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *(u32x4*)(ldsB + buf * BBUF + i * NBREG + tid * 16) = r.v[i];
+    };
+
+    // ---- this lane's A base: element stream of row 2*th at pixel 2*tw + 2
+    const unsigned char* abase[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        // rows {0, 2} of the wave's 4-row strip in block 0, {1, 3} in block 1: ds_read2_b32 is serviced per 32-lane
+        // half with 32 banks, lanes 0-15 cover the banks 3*tw mod 32 and 4 input rows further down (960 B = 16 banks)
+        // lanes 16-31 cover exactly the other 16 (rows {0, 1} together were a 2-way conflict on every fragment read)
+        const int th = wave * 4 + mb + 2 * ((lane & 31) >> 4), tw = lane & 15;
+        abase[mb] = ldsA + (2 * th) * PITCH + (2 * tw + 2) * 6;
+    }
+    const int kh_row = khalf * PITCH, kh_q = khalf * 16;
+    const unsigned char* const bwave = ldsB + lane * 16;
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][i][r] = 0.f;
+
+    frag_t fa[2][2], fb[2][NB];
+    // fragments of K-step j (0..10) of the frame whose slot starts at byte `slotoff`
+    auto read_frags = [&](auto setc, auto jc, int slotoff) {
+        constexpr int SET = decltype(setc)::value;
+        constexpr int J = decltype(jc)::value;
+        const int aoff = slotoff + (J < 9 ? (2 * (J / 3)) * PITCH + (J % 3) * 16 + kh_row : (J == 9 ? 6 * PITCH + kh_q : 6 * PITCH + 32));
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) fa[SET][mb] = lds_read_frag_a4(abase[mb] + aoff);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) fb[SET][i] = *(const frag_t*)(bwave + (J / 4) * BBUF + i * NBREG + (J % 4) * FRAGB);
+    };
+    auto mma_all = [&](auto setc) {
+        constexpr int SET = decltype(setc)::value;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            mma_k16(fa[SET][0], fb[SET][i], acc[0][i], T());
+            mma_k16(fa[SET][1], fb[SET][i], acc[1][i], T());
+        }
+    };
+
+    // ---- prologue: frames 0 and 1, weight tiles 0 and 1, tile 2 in flight
+    Item fr[FQ];
+    load_frame(0, fr); store_frame(0, fr);
+    load_frame(1, fr); store_frame(FRAME, fr);
+    BReg R = load_B(0);
+    store_B(0, R);
+    R = load_B(1);
+    store_B(1, R);
+    R = load_B(2);
+    __syncthreads();
+    read_frags(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), 0);
+
+    int cur = 0, nxt = FRAME, nn = 2 * FRAME;          // slot byte offsets of frames kd, kd+1, kd+2
+    // one frame = 11 K-steps; P = parity of the frame's first K-step (11 is odd, so it alternates)
+    auto frame_iter = [&](auto pc, int kd) {
+        constexpr int P = decltype(pc)::value;
+        if (kd + 2 < 7) load_frame(kd + 2, fr);                     // in flight until the second barrier
+#define STS_KSTEP(J)                                                                                                  \
+        {                                                                                                             \
+            if (J < 10) read_frags(std::integral_constant<int, (P + J + 1) & 1>(), std::integral_constant<int, (J + 1) % 11>(), cur); \
+            else        read_frags(std::integral_constant<int, (P + J + 1) & 1>(), std::integral_constant<int, 0>(), nxt);            \
+            mma_all(std::integral_constant<int, (P + J) & 1>());                                                      \
+        }
+#define STS_TILE_END(TI)                                                                                              \
+        {                                                                                                             \
+            store_B((TI + 2) % 3, R);                  /* tile 3*kd + TI + 2 -> its home buffer */                  \
+            R = load_B(3 * kd + TI + 3);                                                                              \
+        }
+        STS_KSTEP(0) STS_KSTEP(1) STS_KSTEP(2) STS_KSTEP(3)
+        STS_TILE_END(0)
+        __syncthreads();
+        STS_KSTEP(4) STS_KSTEP(5) STS_KSTEP(6) STS_KSTEP(7)
+        STS_TILE_END(1)
+        if (kd + 2 < 7) store_frame(nn, fr);           // the slot frame kd-1 left (last read before the previous frame's last barrier)
+        __syncthreads();
+        STS_KSTEP(8) STS_KSTEP(9) STS_KSTEP(10)
+        STS_TILE_END(2)
+        __syncthreads();
+#undef STS_KSTEP
+#undef STS_TILE_END
+        const int tmp = cur; cur = nxt; nxt = nn; nn = tmp;
+    };
+#pragma unroll 1
+    for (int kd = 0; kd < 6; kd += 2) {
+        frame_iter(std::integral_constant<int, 0>(), kd);
+        frame_iter(std::integral_constant<int, 1>(), kd + 1);
+    }
+    frame_iter(std::integral_constant<int, 0>(), 6);
+
+    // ---- epilogue: affine + ReLU, LDS transpose (fp32, 128 pixels at a time), 16-byte stores
+    T* yg = (T*)p.y;
+    constexpr int BN = NB * 32, G = BN / 8;
+    float* ot = (float*)lds;
+    float sc[NB], sh[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int co = min((nb0 + i) * 32 + (lane & 31), p.Cout - 1);
+        sc[i] = p.scale ? p.scale[co] : 1.f;
+        sh[i] = p.shift ? p.shift[co] : 0.f;
+    }
+    const bool vec_epi = (p.y_cstride % 8 == 0) && (p.y_coff % 8 == 0) && (p.Cout % 8 == 0) && (((uintptr_t)p.y) % 16 == 0);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        if (mb) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ot[(wave * 32 + cd_row(r, lane)) * BN + i * 32 + (lane & 31)] = fmaxf(acc[mb][i][r] * sc[i] + sh[i], 0.f);
+        __syncthreads();
+        for (int idx = tid; idx < 128 * G; idx += 256) {
+            const int row = idx / G, g = idx % G;
+            const int oh = oh0 + (row >> 5) * 4 + mb + 2 * ((row & 31) >> 4), ow = ow0 + (row & 15);
+            const int co = nb0 * 32 + g * 8;
+            if (oh < p.Ho && ow < p.Wo && co < p.Cout) {
+                const size_t opix = (((size_t)n * p.To + od) * p.Ho + oh) * p.Wo + ow;
+                const float* src = ot + row * BN + g * 8;
+                if (vec_epi) {
+                    u16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = elem<T>::bits16(src[e]);
+                    *(u16x8*)(yg + opix * p.y_cstride + p.y_coff + co) = o;
+                } else {
+                    for (int e = 0; e < 8; ++e)
+                        if (co + e < p.Cout) yg[opix * p.y_cstride + p.y_coff + co + e] = elem<T>::from_f32(src[e]);
+                }
+            }
+        }
+    }
+}
+
+// torch [Cout][3][7][7][7] fp32 -> [nb32][77 K-steps][lane][8] (+ one zero K-step at the very end) for stem_stream_kernel
+template <typename T>
+__global__ void stem_stream_pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const int e = (int)(idx & 7);
+        const int lane = (int)((idx >> 3) & 63);
+        const long long q = idx >> 9;
+        const int ks = (int)(q % STS_KSTEPS);
+        const long long nb = q / STS_KSTEPS;
+        const int kd = ks / 11, j = ks % 11, khalf = lane >> 5;
+        int kh, fq;                                  // row and fragment of this lane half; fq < 0: zero
+        if (j < 9) { kh = 2 * (j / 3) + khalf; fq = j % 3; }
+        else if (j == 9) { kh = 6; fq = khalf; }
+        else { kh = 6; fq = khalf ? -1 : 2; }
+        const int se = 8 * fq + e, kw = se / 3, c = se % 3;
+        const long long co = nb * 32 + (lane & 31);
+        float v = 0.f;
+        if (fq >= 0 && co < Cout && kw < 7) v = w[((((size_t)co * 3 + c) * 7 + kd) * 7 + kh) * 7 + kw];
+        out[idx] = elem<T>::from_f32(v);
+    }
+}
+
+// torch [Cout][3][7][7][7] fp32 -> [nb32][kd][kh][j][lane][8]; element e: kw = 4j + 2*(lane>>5) + (e>>2), c = e&3
+template <typename T>
+__global__ void stem_pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)blockDim.x * gridDim.x) {
+        const int e = (int)(idx & 7);
+        const int lane = (int)((idx >> 3) & 63);
+        long long q = idx >> 9;
+        const int ks = (int)(q % 98);
+        const int nb = (int)(q / 98);
+        const int j = ks & 1, kh = (ks >> 1) % 7, kd = (ks >> 1) / 7;
+        const int kw = 4 * j + 2 * (lane >> 5) + (e >> 2), c = e & 3;
+        const int co = nb * 32 + (lane & 31);
+        float v = 0.f;
+        if (co < Cout && c < 3 && kw < 7) v = w[((((size_t)co * 3 + c) * 7 + kd) * 7 + kh) * 7 + kw];
+        out[idx] = elem<T>::from_f32(v);
+    }
+}
+
+
+template <typename T>
+static int stem_forward_t(StemParams p, step_stream_t stream) {
+    dim3 grid((unsigned)((long long)p.N * p.To * p.tiles_h * p.tiles_w), (unsigned)ceil_div(p.nblk32, 2));
+    STEP_LAUNCH((stem_igemm_kernel<T, 2>), grid, dim3(256), stream, p);
+    return STEP_LAUNCH_CHECK();
+}
+
+static inline size_t stem_stream_offset(int Cout) { return (size_t)ceil_div(Cout, 32) * 98 * 512; }
+
+template <typename T>
+static int stem_stream_forward_t(StemParams p, step_stream_t stream) {
+    p.w = (const T*)p.w + stem_stream_offset(p.Cout);
+    p.tiles_h = ceil_div(p.Ho, 16); p.tiles_w = ceil_div(p.Wo, 16);
+    dim3 grid((unsigned)((long long)p.N * p.To * p.tiles_h * p.tiles_w), (unsigned)ceil_div(p.nblk32, 2));
+    STEP_LAUNCH((stem_stream_kernel<T>), grid, dim3(256), stream, p);
+    return STEP_LAUNCH_CHECK();
+}
+
+template <typename T>
+static int stem_tap_forward_t(StemParams p, step_stream_t stream) {
+    p.tiles_h = ceil_div(p.Ho, 16); p.tiles_w = ceil_div(p.Wo, 16);
+    dim3 grid((unsigned)((long long)p.N * p.To * p.tiles_h * p.tiles_w), (unsigned)ceil_div(p.nblk32, 2));
+    STEP_LAUNCH((stem_tap_kernel<T>), grid, dim3(256), stream, p);
+    return STEP_LAUNCH_CHECK();
+}
+
+
+}  // namespace step
+
+using namespace step;
+
+extern "C" {
+
+// two images back to back: [nb32][98 K-steps] (stem_igemm_kernel / stem_tap_kernel) and
+// [nb32][77 K-steps] + one zero K-step (stem_stream_kernel, 16-bit types)
+size_t step_stem_packed_elems(int Cout) { return stem_stream_offset(Cout) + ((size_t)ceil_div(Cout, 32) * STS_KSTEPS + 1) * 512; }
+
+int step_stem_pack_weight(const float* w, int Cout, int dtype, void* packed, step_stream_t stream) {
+    if (Cout <= 0) return STEP_E_SHAPE;
+    if (!w || !packed) return STEP_E_NULL;
+    const long long total = (long long)stem_stream_offset(Cout);
+    const long long total2 = (long long)step_stem_packed_elems(Cout) - total;
+    const dim3 grid(flat_grid(total, 256)), grid2(flat_grid(total2, 256));
+    switch (dtype) {
+        case STEP_F32:
+            STEP_LAUNCH((stem_pack_weight_kernel<float>), grid, dim3(256), stream, w, (float*)packed, Cout, total);
+            STEP_LAUNCH((stem_stream_pack_weight_kernel<float>), grid2, dim3(256), stream, w, (float*)packed + total, Cout, total2);
+            break;
+        case STEP_BF16:
+            STEP_LAUNCH((stem_pack_weight_kernel<bf16_t>), grid, dim3(256), stream, w, (bf16_t*)packed, Cout, total);
+            STEP_LAUNCH((stem_stream_pack_weight_kernel<bf16_t>), grid2, dim3(256), stream, w, (bf16_t*)packed + total, Cout, total2);
+            break;
+        case STEP_F16:
+            STEP_LAUNCH((stem_pack_weight_kernel<f16_t>), grid, dim3(256), stream, w, (f16_t*)packed, Cout, total);
+            STEP_LAUNCH((stem_stream_pack_weight_kernel<f16_t>), grid2, dim3(256), stream, w, (f16_t*)packed + total, Cout, total2);
+            break;
+        default: return STEP_E_DTYPE;
+    }
+    return STEP_LAUNCH_CHECK();
+}
+
+int step_stem_forward(int dtype, const void* x, int N, int T, int H, int W, const void* w_packed, const float* scale,
+                      const float* shift, int Cout, void* y, int y_cstride, int y_coff, step_stream_t stream) {
+    if (N < 0 || T <= 0 || H <= 0 || W <= 0 || Cout <= 0) return STEP_E_SHAPE;
+    if (y_coff < 0 || y_coff + Cout > y_cstride) return STEP_E_SHAPE;
+    if (N == 0) return STEP_OK;
+    if (!x || !w_packed || !y) return STEP_E_NULL;
+    if (((uintptr_t)x % 16) || ((uintptr_t)w_packed % 16)) return STEP_E_ALIGN;
+    StemParams p;
+    p.x = x; p.w = w_packed; p.scale = scale; p.shift = shift; p.y = y;
+    p.N = N; p.T = T; p.H = H; p.W = W;
+    p.To = (T + 5 - 7) / 2 + 1; p.Ho = (H + 5 - 7) / 2 + 1; p.Wo = (W + 5 - 7) / 2 + 1;
+    if (p.To <= 0 || p.Ho <= 0 || p.Wo <= 0) return STEP_E_SHAPE;
+    p.Cout = Cout; p.y_cstride = y_cstride; p.y_coff = y_coff;
+    p.tiles_h = ceil_div(p.Ho, STEM_TH); p.tiles_w = ceil_div(p.Wo, STEM_TW);
+    p.nblk32 = ceil_div(Cout, 32);
+    const int ov = conv_impl_override();
+    switch (dtype) {
+        case STEP_F32: return stem_forward_t<float>(p, stream);
+        // STEP_CONV_IMPL=igemm / tap select the two older stems (A/B measurements, tests); default = dense-K stream stem
+        case STEP_BF16: return ov == 0 ? stem_forward_t<bf16_t>(p, stream) : (ov == 1 ? stem_tap_forward_t<bf16_t>(p, stream) : stem_stream_forward_t<bf16_t>(p, stream));
+        case STEP_F16: return ov == 0 ? stem_forward_t<f16_t>(p, stream) : (ov == 1 ? stem_tap_forward_t<f16_t>(p, stream) : stem_stream_forward_t<f16_t>(p, stream));
+    }
+    return STEP_E_DTYPE;
+}
+
+
+int step_stem_kernel_name(int dtype, char* buf, int buflen) {
+    if (!buf || buflen <= 0) return STEP_E_NULL;
+    const int ov = conv_impl_override();
+    const char* t = dtype == STEP_F32 ? "float" : (dtype == STEP_BF16 ? "step::bf16_t" : "step::f16_t");
+    if (dtype != STEP_F32 && dtype != STEP_BF16 && dtype != STEP_F16) return STEP_E_DTYPE;
+    if (dtype == STEP_F32 || ov == 0) snprintf(buf, (size_t)buflen, "void step::stem_igemm_kernel<%s, 2>(step::StemParams)", t);
+    else snprintf(buf, (size_t)buflen, "void step::%s<%s>(step::StemParams)", ov == 1 ? "stem_tap_kernel" : "stem_stream_kernel", t);
+    return STEP_OK;
+}
+
+
+}  // extern "C"
