@@ -66,3 +66,21 @@ def valid_tubes(tubes, width=400, height=400):
                        torch.where(bad, torch.full_like(x2, float(width)), x2),
                        torch.where(bad, torch.full_like(y2, float(height)), y2)), 1)
     return out.reshape(tubes.shape)
+
+
+def generate_anchors(scales=(4.0 / 3.0, 2.0), overlaps=(5.0 / 6.0, 3.0 / 4.0)):
+    """The initial tube grid of the default anchor mode "1": for each (scale, overlap) a regular grid of square boxes
+    of side 1/scale with stride side*(1-overlap), normalised [x1, y1, x2, y2] -- 9 + 25 = 34 boxes
+    (data/data_utils.py:19-45)."""
+    out = []
+    for scale, overlap in zip(scales, overlaps):
+        size = 1.0 / scale
+        stride = size * (1 - overlap)
+        i = 0
+        while i + size <= 1:
+            j = 0
+            while j + size <= 1:
+                out.append([i, j, i + size, j + size])
+                j += stride
+            i += stride
+    return np.asarray(out, dtype=np.float32)

@@ -12,8 +12,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import step_amd  # noqa: E402
-from oracle import i3d_ref as R  # noqa: E402  (anchors table only)
 from step_amd.driver import GraphedInference, inference, postprocess  # noqa: E402
+from step_amd.tube_math import generate_anchors  # noqa: E402
 
 
 def cfg(**kw):
@@ -48,7 +48,7 @@ def main():
             for nme in ("local_reg", "neighbor_reg1", "neighbor_reg2"):
                 getattr(nets["det_net%d" % i], nme).weight.mul_(0.05)
     x = (torch.rand(a.batch, 36, 3, 400, 400, device=dev) * 2 - 1).to(tdt)
-    anchors = R.anchors()[:a.tubes] * 400.0
+    anchors = generate_anchors()[:a.tubes] * 400.0
     tubes = [np.tile(anchors[:, None, :], (1, 3, 1)).astype(np.float32) for _ in range(a.batch)]
 
     def run():
