@@ -415,7 +415,10 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
 #endif
     const int khalf = lane >> 5;
 
+    // XCD-aware launch order (see grid_coords in conv_common.h): tiles that are neighbours in (w, h, frame) order --
+    // they share input halos and frames -- are consecutive on ONE XCD instead of round-robin over the eight L2s
     int t = blockIdx.x;
+    if ((gridDim.x & 7) == 0) t = (t & 7) * (gridDim.x >> 3) + (t >> 3);
     const int tw_i = t % p.tiles_w; t /= p.tiles_w;
     const int th_i = t % p.tiles_h; t /= p.tiles_h;
     const int od = t % p.To;
