@@ -32,7 +32,10 @@ CLIPS_PER_GPU = 8
 T_IN, HW_IN = 32, 224
 # --config c5 (BASELINE configs[4], long-clip stress): T=64, 400x400, fp16, 4 clips per GPU (= batch 32 on 8 GPUs)
 CONFIGS = {"c2": dict(clips=8, T=32, HW=224, dtype="bf16", gflop=109.29, act_mb=304.9, name="C2"),
-           "c5": dict(clips=4, T=64, HW=400, dtype="f16", gflop=696.98, act_mb=1944.6, name="C5")}
+           "c5": dict(clips=4, T=64, HW=400, dtype="f16", gflop=696.98, act_mb=1944.6, name="C5"),
+           # full pipelines (step_amd/workloads.py): C3 = 3-step two_branch inference + NMS, C4 = one training step
+           "c3": dict(clips=4, T=36, HW=400, dtype="bf16", gflop=392.05 + 14.46 + 158.0, act_mb=1093.9, name="C3"),
+           "c4": dict(clips=1, T=36, HW=400, dtype="f32", gflop=3 * (392.05 + 14.46), act_mb=2187.7, name="C4")}
 PEAK = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}          # dense MFMA TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 # algorithmic work of BaseNet at C2 per clip: 109.29 GFLOP, 304.9 MB activations + 15.0 MB weights/batch
@@ -151,7 +154,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="c2 = headline (default); c5 = long-clip stress")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS),
+                    help="c2 = headline backbone forward (default); c5 = long-clip stress; c3 = full inference; c4 = training step")
     ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -187,6 +191,8 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
+    if a.config in ("c3", "c4"):
+        return pipeline_bench(a, c, dev, tdt, rank, world, dist)
     net = build_net(dev)
     g = torch.Generator(device="cpu").manual_seed(123 + rank)
     x = (torch.rand(CLIPS_PER_GPU, T_IN, 3, HW_IN, HW_IN, generator=g) * 2 - 1).to(dev).to(tdt)   # U(-1,1), resident in HBM
@@ -260,6 +266,72 @@ def main():
                 print("%9.4f ms %3d x  %8.1f TFLOP/s  %s" % (ms, cnt, gfs, n_), file=sys.stderr)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(net)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def pipeline_bench(a, c, dev, tdt, rank, world, dist):
+    """--config c3 / c4: the whole-pipeline workloads (not the headline metric; same timing contract)."""
+    from step_amd import backbone, ops, workloads
+    if a.config == "c3":
+        w = workloads.C3Inference(dev, tdt, batch=CLIPS_PER_GPU, tubes=11, seed=123 + rank, graph=not a.no_graph)
+        what = "C3: full two_branch inference (I3D backbone + ContextNet + 3 refinement steps with ROIAlign over 11 tubes/clip + " \
+               "batched per-class NMS), %d x [36,3,400,400] clips per GPU" % CLIPS_PER_GPU
+        metric = "clips_per_sec_inference_T36_400"
+    else:
+        w = workloads.C4TrainStep(dev, batch=CLIPS_PER_GPU, seed=123 + rank)
+        what = "C4: one training step (backbone + ContextNet + head 0, BCE + smooth-L1 losses, gradient all-reduce, Adam), " \
+               "%d x [36,3,400,400] clip(s) per GPU, 5 tubes/clip" % CLIPS_PER_GPU
+        metric = "clips_per_sec_train_T36_400"
+    for _ in range(max(a.warmup, 2)):
+        w.step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        w.step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    if rank == 0:
+        val = world * CLIPS_PER_GPU * a.steps / el
+        out = {"metric": metric, "value": round(val, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": max(a.warmup, 2),
+               "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": a.dtype, "data": "synthetic",
+               "config": {"workload": what + ", inputs resident in HBM, random-init weights", "clips_per_gpu": CLIPS_PER_GPU, "T": 36, "HW": 400,
+                          "parallelism": "clip-sharded replicas x%d (%s)" % (world, "no data-path collective" if a.config == "c3" else "one gradient all-reduce per step"),
+                          "launch": "hipGraph replay + eager post-processing" if (a.config == "c3" and not a.no_graph) else "eager"}}
+        # dominant kernel of one eager, single-stream, instrumented step
+        ops.PROFILE = []
+        saved, backbone.BRANCH_STREAMS = backbone.BRANCH_STREAMS, False
+        (w.eager if a.config == "c3" else w.step)()
+        torch.cuda.synchronize()
+        backbone.BRANCH_STREAMS = saved
+        rec, ops.PROFILE = ops.PROFILE, None
+        agg = {}
+        for name, flops, nbytes, e0, e1 in rec:
+            r = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+            r[0] += 1; r[1] += e0.elapsed_time(e1); r[2] += flops; r[3] += nbytes
+        if agg:
+            name, (cnt, ms, flops, nbytes) = max(agg.items(), key=lambda kv: kv[1][1])
+            mf = flops / (PEAK[a.dtype] * 1e12) >= nbytes / (PEAK_HBM_GBS * 1e9)
+            ach = (flops / (ms * 1e-3) / 1e12) if mf else (nbytes / (ms * 1e-3) / 1e9)
+            peak = PEAK[a.dtype] if mf else PEAK_HBM_GBS
+            out["roofline"] = {"kernel": name, "bound": "mfma" if mf else "hbm", "achieved": round(ach, 2), "peak": peak,
+                               "unit": "TFLOP/s" if mf else "GB/s", "frac": round(ach / peak, 4), "traffic": None,
+                               "launches_per_step": cnt, "avg_launch_ms": round(ms / cnt, 4),
+                               "share_of_instrumented_kernel_time": round(ms / sum(v[1] for v in agg.values()), 3),
+                               "note": "instrumented forward launches of step_amd.ops (backward / torch glue kernels are not in this table)"}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -1,0 +1,114 @@
+"""step_amd/workloads.py -- synthetic BASELINE workloads C3 (full two_branch inference) and C4 (one training step) built
+from the product modules; used by bench.py --config c3|c4 and tools/c3_bench.py.  Random-init weights of the real
+architectures, synthetic clips and the reference's default anchor grid (there are no datasets or checkpoints offline)."""
+from types import SimpleNamespace as NS
+
+import numpy as np
+import torch
+
+from . import BaseNet, ContextNet, ROINet, TwoBranchNet
+from . import dist as sdist
+from .driver import GraphedInference, inference, postprocess
+from .tube_math import generate_anchors
+
+
+def step_cfg(**kw):
+    """The attributes of the reference's argparse namespace the modules read (config.py; scripts/train_step.sh)."""
+    base = dict(base_net="i3d", kinetics_pretrain=None, freeze_stats=True, freeze_affine=True, fp16=False, T=3, num_classes=60,
+                fc_dim=256, dropout=0.0, pool_size=7, no_context=False, max_iter=3, NUM_CHUNKS={1: 1, 2: 1, 3: 3, 4: 3},
+                temporal_mode="predict", image_size=(400, 400), pool_mode="align")
+    base.update(kw)
+    return NS(**base)
+
+
+def build_nets(dev, seed=123, heads=3):
+    args = step_cfg()
+    torch.manual_seed(seed)                                       # config.py:38 man_seed
+    base = BaseNet(args).to(dev).eval()
+    ctx = ContextNet(args).to(dev).eval()
+    nets = {"roi_net": ROINet("align", 7)}
+    for i in range(heads):
+        d = TwoBranchNet(args).to(dev).eval()
+        d.set_device(dev)
+        nets["det_net%d" % i] = d
+    with torch.no_grad():                                         # keep box deltas small, like a trained regressor
+        for i in range(heads):
+            for nme in ("local_reg", "neighbor_reg1", "neighbor_reg2"):
+                getattr(nets["det_net%d" % i], nme).weight.mul_(0.05)
+    return args, base, ctx, nets
+
+
+class C3Inference:
+    """B clips [36,3,400,400], `tubes` initial tubes per clip, 3 refinement steps, batched per-class NMS (test.py:140-218)."""
+
+    def __init__(self, dev, dtype, batch=4, tubes=11, seed=123, graph=True):
+        self.args, self.base, self.ctx, self.nets = build_nets(dev, seed)
+        g = torch.Generator().manual_seed(seed)
+        self.x = (torch.rand(batch, 36, 3, 400, 400, generator=g) * 2 - 1).to(dev).to(dtype)
+        anchors = generate_anchors()[:tubes] * 400.0
+        self.tubes = [np.tile(anchors[:, None, :], (1, 3, 1)).astype(np.float32) for _ in range(batch)]
+        self.batch = batch
+        self.graphed = GraphedInference(self.args, self.base, self.ctx, self.nets, self.x, self.tubes) if graph else None
+
+    def eager(self):
+        with torch.no_grad():
+            cf = self.base(self.x)
+            cx = self.ctx(cf)
+            hist, _ = inference(self.args, cf, cx, self.nets, 3, self.tubes)
+            return postprocess(self.args, hist)
+
+    def step(self):
+        if self.graphed is None:
+            return self.eager()
+        with torch.no_grad():
+            hist, _, _ = self.graphed(self.x)
+            return postprocess(self.args, hist)
+
+
+class C4TrainStep:
+    """One optimisation step on `batch` AVA-shaped clips per rank (fp32): backbone + context + head 0, the three losses of
+    train.py:318-331 (lambda_reg 5, lambda_nbr 1), gradient all-reduce over ranks (step_amd.dist), Adam."""
+
+    def __init__(self, dev, batch=1, tubes_per_clip=5, seed=123):
+        self.args, self.base, self.ctx, self.nets = build_nets(dev, seed, heads=1)
+        self.mods = [self.base, self.ctx, self.nets["det_net0"]]
+        for m in self.mods:
+            m.train()
+        self.params = [p for m in self.mods for p in m.parameters() if p.requires_grad]
+        self.opt = torch.optim.Adam(self.params, lr=1e-5)
+        g = torch.Generator().manual_seed(seed)
+        self.x = (torch.rand(batch, 36, 3, 400, 400, generator=g) * 2 - 1).to(dev)
+        anchors = generate_anchors()[:tubes_per_clip] * 400.0
+        tb = torch.from_numpy(np.tile(anchors[:, None, :], (1, 3, 1)).astype(np.float32)).to(dev)      # [K,3,4]
+        K = tubes_per_clip
+        flats, tgts = [], []
+        for b in range(batch):
+            fr = (b * 9 + 3 + torch.arange(3, device=dev, dtype=torch.float32)).view(1, 3, 1).expand(K, 3, 1)   # frames 3..5 of clip b
+            flats.append(torch.cat([fr, tb], 2))
+            t = torch.zeros(K, 3, 66, device=dev)
+            t[:, :, :4] = tb + 4.0
+            t[:, :, 4] = 1
+            t[:, :, 5] = 1
+            t[:, :, 6 + 7] = 1
+            tgts.append(t)
+        self.flat = torch.cat(flats, 0)
+        self.targets = torch.cat(tgts, 0)
+        self.clip_of = torch.arange(batch, device=dev).repeat_interleave(K)
+        self.batch, self.K = batch, K
+        self.loss = None
+
+    def step(self):
+        self.opt.zero_grad()
+        cf = self.base(self.x)                                    # [B,9,832,25,25]
+        cx = self.ctx(cf)                                         # [B,1024,9,1,1]
+        B = self.batch
+        pooled = self.nets["roi_net"](cf, self.flat)              # frame index column addresses frame b*9 + t of cf
+        pooled = pooled.reshape(B * self.K, 3, *pooled.shape[1:])
+        ctx_t = cx[self.clip_of][:, :, 3:6]
+        o = self.nets["det_net0"](pooled, context_feat=ctx_t, tubes=self.flat, targets=self.targets)
+        loss = o[4].mean() + 5 * o[5].mean() + o[6].mean()
+        loss.backward()
+        sdist.allreduce_gradients(self.params)
+        self.opt.step()
+        self.loss = loss.detach()
+        return self.loss

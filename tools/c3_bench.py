@@ -5,23 +5,15 @@ import argparse
 import os
 import sys
 import time
-from types import SimpleNamespace as NS
 
 import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import step_amd  # noqa: E402
+import step_amd  # noqa: E402,F401
+from step_amd import workloads  # noqa: E402
 from step_amd.driver import GraphedInference, inference, postprocess  # noqa: E402
 from step_amd.tube_math import generate_anchors  # noqa: E402
-
-
-def cfg(**kw):
-    base = dict(base_net="i3d", kinetics_pretrain=None, freeze_stats=True, freeze_affine=True, fp16=False, T=3, num_classes=60,
-                fc_dim=256, dropout=0.0, pool_size=7, no_context=False, max_iter=3, NUM_CHUNKS={1: 1, 2: 1, 3: 3, 4: 3},
-                temporal_mode="predict", image_size=(400, 400), pool_mode="align")
-    base.update(kw)
-    return NS(**base)
 
 
 def main():
@@ -34,19 +26,7 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
-    args = cfg()
-    torch.manual_seed(123)
-    base = step_amd.BaseNet(args).to(dev).eval()
-    ctx = step_amd.ContextNet(args).to(dev).eval()
-    nets = {"roi_net": step_amd.ROINet("align", 7)}
-    for i in range(3):
-        d = step_amd.TwoBranchNet(args).to(dev).eval()
-        d.set_device(dev)
-        nets["det_net%d" % i] = d
-    with torch.no_grad():                      # keep box deltas small like a trained regressor
-        for i in range(3):
-            for nme in ("local_reg", "neighbor_reg1", "neighbor_reg2"):
-                getattr(nets["det_net%d" % i], nme).weight.mul_(0.05)
+    args, base, ctx, nets = workloads.build_nets(dev)
     x = (torch.rand(a.batch, 36, 3, 400, 400, device=dev) * 2 - 1).to(tdt)
     anchors = generate_anchors()[:a.tubes] * 400.0
     tubes = [np.tile(anchors[:, None, :], (1, 3, 1)).astype(np.float32) for _ in range(a.batch)]
@@ -107,38 +87,19 @@ def main():
             torch.cuda.synchronize()
             print("   %-10s %.2f ms/batch" % (name, (time.perf_counter() - t0) / a.iters * 1e3))
     if a.train:
-        # C4: one training step of the three heads + context + backbone on this GPU (fp32), gradients through autograd
-        xb = x[:1].float()
-        for m in [base, ctx] + [nets["det_net%d" % i] for i in range(3)]:
-            m.train()
-        params = [p for m in [base, ctx] + [nets["det_net%d" % i] for i in range(3)] for p in m.parameters() if p.requires_grad]
-        opt = torch.optim.Adam(params, lr=1e-5)
-        tb = torch.from_numpy(np.tile(anchors[:5, None, :], (1, 3, 1)).astype(np.float32)).to(dev)
-        flat = torch.cat([torch.arange(3, device=dev, dtype=torch.float32).view(1, 3, 1).expand(5, 3, 1), tb], 2)
-        targets = torch.zeros(5, 3, 66, device=dev)
-        targets[:, :, :4] = tb + 4.0
-        targets[:, :, 4] = 1
-        targets[:, :, 5] = 1
-        targets[:, :, 6 + 7] = 1
+        # C4: one training step (fp32) of backbone + context + head 0 on this GPU -- step_amd.workloads.C4TrainStep
+        del base, ctx, nets
+        w = workloads.C4TrainStep(dev, batch=1)
         t0 = time.perf_counter()
         for it in range(4):
-            if it == 2:                                   # two warm-up steps (library kernel selection, weight packs)
+            if it == 2:                                   # two warm-up steps (weight packs, allocator)
                 torch.cuda.synchronize()
                 print("   (2 warm-up training steps: %.1f s)" % (time.perf_counter() - t0))
                 t0 = time.perf_counter()
-            opt.zero_grad()
-            cf = base(xb)
-            cx = ctx(cf)
-            pooled = nets["roi_net"](cf[:, 3:6], flat)
-            pooled = pooled.reshape(5, 3, *pooled.shape[1:])
-            o = nets["det_net0"](pooled, context_feat=cx[:, :, 3:6].expand(5, -1, -1, -1, -1), tubes=flat, targets=targets)
-            loss = o[4].mean() + 5 * o[5].mean() + o[6].mean()
-            loss.backward()
-            step_amd.dist.allreduce_gradients(params)
-            opt.step()
+            loss = w.step()
         torch.cuda.synchronize()
         print("C4 training step (1 clip, fp32, head 0): %.1f ms, loss %.4f, grads finite: %s"
-              % ((time.perf_counter() - t0) / 2 * 1e3, float(loss), all(bool(torch.isfinite(p.grad).all()) for p in params if p.grad is not None)))
+              % ((time.perf_counter() - t0) / 2 * 1e3, float(loss), all(bool(torch.isfinite(p.grad).all()) for p in w.params if p.grad is not None)))
 
 
 if __name__ == "__main__":
