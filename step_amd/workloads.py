@@ -66,33 +66,39 @@ class C3Inference:
 
 
 class C4TrainStep:
-    """One optimisation step on `batch` AVA-shaped clips per rank (fp32): backbone + context + head 0, the three losses of
-    train.py:318-331 (lambda_reg 5, lambda_nbr 1), gradient all-reduce over ranks (step_amd.dist), Adam."""
+    """One optimisation step on `batch` AVA-shaped clips per rank (fp32): backbone + ContextNet + the max_iter = 3 heads on
+    tubes of 3, 3 and 9 frames (NUM_CHUNKS 1, 1, 3), the three losses of train.py:318-331 summed over the steps
+    (lambda_reg 5, lambda_nbr 1), gradient all-reduce over ranks (step_amd.dist), Adam.  The reference's proposal
+    selection between steps (utils/utils.py:135-423, host Python) is not part of the hot path: every step trains on the
+    same `tubes_per_clip` anchor tubes, extended to the step's length."""
 
-    def __init__(self, dev, batch=1, tubes_per_clip=5, seed=123):
-        self.args, self.base, self.ctx, self.nets = build_nets(dev, seed, heads=1)
-        self.mods = [self.base, self.ctx, self.nets["det_net0"]]
+    def __init__(self, dev, batch=1, tubes_per_clip=5, seed=123, max_iter=3):
+        self.args, self.base, self.ctx, self.nets = build_nets(dev, seed, heads=max_iter)
+        self.heads = [self.nets["det_net%d" % i] for i in range(max_iter)]
+        self.mods = [self.base, self.ctx] + self.heads
         for m in self.mods:
             m.train()
         self.params = [p for m in self.mods for p in m.parameters() if p.requires_grad]
         self.opt = torch.optim.Adam(self.params, lr=1e-5)
         g = torch.Generator().manual_seed(seed)
         self.x = (torch.rand(batch, 36, 3, 400, 400, generator=g) * 2 - 1).to(dev)
-        anchors = generate_anchors()[:tubes_per_clip] * 400.0
-        tb = torch.from_numpy(np.tile(anchors[:, None, :], (1, 3, 1)).astype(np.float32)).to(dev)      # [K,3,4]
+        anchors = torch.from_numpy(generate_anchors()[:tubes_per_clip] * 400.0).to(dev)                  # [K,4]
         K = tubes_per_clip
-        flats, tgts = [], []
-        for b in range(batch):
-            fr = (b * 9 + 3 + torch.arange(3, device=dev, dtype=torch.float32)).view(1, 3, 1).expand(K, 3, 1)   # frames 3..5 of clip b
-            flats.append(torch.cat([fr, tb], 2))
-            t = torch.zeros(K, 3, 66, device=dev)
-            t[:, :, :4] = tb + 4.0
-            t[:, :, 4] = 1
-            t[:, :, 5] = 1
-            t[:, :, 6 + 7] = 1
-            tgts.append(t)
-        self.flat = torch.cat(flats, 0)
-        self.targets = torch.cat(tgts, 0)
+        self.steps = []
+        for it in range(max_iter):
+            Tl = 3 * self.args.NUM_CHUNKS[it + 1]
+            t0 = (9 - Tl) // 2                                     # centred window of the 9 feature frames (utils.py:41-43)
+            flats = []
+            for b in range(batch):
+                fr = (b * 9 + t0 + torch.arange(Tl, device=dev, dtype=torch.float32)).view(1, Tl, 1).expand(K, Tl, 1)
+                flats.append(torch.cat([fr, anchors.view(K, 1, 4).expand(K, Tl, 4)], 2))
+            self.steps.append((Tl, t0, torch.cat(flats, 0).contiguous()))
+        t = torch.zeros(batch * K, 3, 66, device=dev)
+        t[:, :, :4] = anchors.repeat(batch, 1).view(batch * K, 1, 4) + 4.0
+        t[:, :, 4] = 1
+        t[:, :, 5] = 1
+        t[:, :, 6 + 7] = 1
+        self.targets = t
         self.clip_of = torch.arange(batch, device=dev).repeat_interleave(K)
         self.batch, self.K = batch, K
         self.loss = None
@@ -101,12 +107,12 @@ class C4TrainStep:
         self.opt.zero_grad()
         cf = self.base(self.x)                                    # [B,9,832,25,25]
         cx = self.ctx(cf)                                         # [B,1024,9,1,1]
-        B = self.batch
-        pooled = self.nets["roi_net"](cf, self.flat)              # frame index column addresses frame b*9 + t of cf
-        pooled = pooled.reshape(B * self.K, 3, *pooled.shape[1:])
-        ctx_t = cx[self.clip_of][:, :, 3:6]
-        o = self.nets["det_net0"](pooled, context_feat=ctx_t, tubes=self.flat, targets=self.targets)
-        loss = o[4].mean() + 5 * o[5].mean() + o[6].mean()
+        loss = 0.0
+        for head, (Tl, t0, flat) in zip(self.heads, self.steps):
+            pooled = self.nets["roi_net"](cf, flat)               # the frame-index column addresses frame b*9 + t of cf
+            pooled = pooled.reshape(self.batch * self.K, Tl, *pooled.shape[1:])
+            o = head(pooled, context_feat=cx[self.clip_of][:, :, t0:t0 + Tl], tubes=flat, targets=self.targets)
+            loss = loss + o[4].mean() + 5 * o[5].mean() + o[6].mean()
         loss.backward()
         sdist.allreduce_gradients(self.params)
         self.opt.step()

@@ -87,7 +87,7 @@ def main():
             torch.cuda.synchronize()
             print("   %-10s %.2f ms/batch" % (name, (time.perf_counter() - t0) / a.iters * 1e3))
     if a.train:
-        # C4: one training step (fp32) of backbone + context + head 0 on this GPU -- step_amd.workloads.C4TrainStep
+        # C4: one training step (fp32) of backbone + context + 3 heads on this GPU -- step_amd.workloads.C4TrainStep
         del base, ctx, nets
         w = workloads.C4TrainStep(dev, batch=1)
         t0 = time.perf_counter()
@@ -98,7 +98,7 @@ def main():
                 t0 = time.perf_counter()
             loss = w.step()
         torch.cuda.synchronize()
-        print("C4 training step (1 clip, fp32, head 0): %.1f ms, loss %.4f, grads finite: %s"
+        print("C4 training step (1 clip, fp32, 3 heads): %.1f ms, loss %.4f, grads finite: %s"
               % ((time.perf_counter() - t0) / 2 * 1e3, float(loss), all(bool(torch.isfinite(p.grad).all()) for p in w.params if p.grad is not None)))
 
 
