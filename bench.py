@@ -281,7 +281,7 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
                "batched per-class NMS), %d x [36,3,400,400] clips per GPU" % CLIPS_PER_GPU
         metric = "clips_per_sec_inference_T36_400"
     else:
-        w = workloads.C4TrainStep(dev, batch=CLIPS_PER_GPU, seed=123 + rank)
+        w = workloads.C4TrainStep(dev, batch=CLIPS_PER_GPU, seed=123 + rank, dtype=tdt)
         what = "C4: one training step (backbone + ContextNet + max_iter=3 heads on 3/3/9-frame tubes, BCE + smooth-L1 losses, gradient all-reduce, Adam), " \
                "%d x [36,3,400,400] clip(s) per GPU, 5 tubes/clip" % CLIPS_PER_GPU
         metric = "clips_per_sec_train_T36_400"

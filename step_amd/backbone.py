@@ -76,6 +76,11 @@ class _ConvUnitFn(torch.autograd.Function):
             # channel roles swapped (stride 1, SAME padding): no torch / MIOpen kernel on this leg
             w_t = w_eff.detach().flip(2, 3, 4).transpose(0, 1).contiguous()
             gin = gconv.to(x.dtype).contiguous()
+            vec = 16 // gin.element_size()                       # the kernels move 16-byte channel vectors
+            padc = (-gin.shape[-1]) % vec
+            if padc:                                             # e.g. the 60-class / 12-column Linear layers in 16-bit
+                gin = torch.nn.functional.pad(gin, (0, padc))
+                w_t = torch.nn.functional.pad(w_t, (0, 0, 0, 0, 0, 0, 0, padc))
             gx = ops.conv_forward(gin, ops.pack_conv_weight(w_t, x.dtype), w_t.shape[0], k, None, None, False, None, None)
         if ctx.needs_input_grad[1]:
             # weight gradient = the HIP wgrad kernel (fp32 MFMA over the pixel axis) on the same channels-last buffers

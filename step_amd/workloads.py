@@ -72,7 +72,7 @@ class C4TrainStep:
     selection between steps (utils/utils.py:135-423, host Python) is not part of the hot path: every step trains on the
     same `tubes_per_clip` anchor tubes, extended to the step's length."""
 
-    def __init__(self, dev, batch=1, tubes_per_clip=5, seed=123, max_iter=3):
+    def __init__(self, dev, batch=1, tubes_per_clip=5, seed=123, max_iter=3, dtype=torch.float32):
         self.args, self.base, self.ctx, self.nets = build_nets(dev, seed, heads=max_iter)
         self.heads = [self.nets["det_net%d" % i] for i in range(max_iter)]
         self.mods = [self.base, self.ctx] + self.heads
@@ -81,7 +81,9 @@ class C4TrainStep:
         self.params = [p for m in self.mods for p in m.parameters() if p.requires_grad]
         self.opt = torch.optim.Adam(self.params, lr=1e-5)
         g = torch.Generator().manual_seed(seed)
-        self.x = (torch.rand(batch, 36, 3, 400, 400, generator=g) * 2 - 1).to(dev)
+        # fp32 master weights either way; a 16-bit clip makes every activation / data gradient 16-bit (fp32 accumulate),
+        # weight gradients stay fp32
+        self.x = (torch.rand(batch, 36, 3, 400, 400, generator=g) * 2 - 1).to(dev).to(dtype)
         anchors = torch.from_numpy(generate_anchors()[:tubes_per_clip] * 400.0).to(dev)                  # [K,4]
         K = tubes_per_clip
         self.steps = []

@@ -266,6 +266,31 @@ def case_training_step_matches_torch_autograd(dev, golden):
     assert checked == len(info["TwoBranchNet_trainable"])
 
 
+def case_training_step_16bit_storage(dev, golden):
+    """The same training step with bf16 activations (fp32 master weights, fp32 weight gradients): every gradient is
+    finite and follows the fp32 run (16-bit activations and data gradients: a few per cent in relative L2).  Exercises
+    the 16-bit data-gradient path of layers whose channel counts are not multiples of 8 (60 classes, 12 regressor
+    columns), which must be padded to the kernels' 16-byte channel vectors."""
+    g = golden("head_golden")
+    pf = R.fill_tensor("golden.det.pooled3", (2, 3, 832, 7, 7), "feat").to(dev)
+    cx = R.fill_tensor("golden.det.ctx3", (2, 1024, 3, 1, 1), "feat").to(dev)
+    tubes, targets = torch.from_numpy(g["loss_tubes"]).to(dev), torch.from_numpy(g["loss_targets"]).to(dev)
+    grads = {}
+    for dt in (torch.float32, torch.bfloat16):
+        net = fill(step_amd.TwoBranchNet(cfg()), "det0.").to(dev)
+        net.set_device(dev)
+        net.train()
+        o = net(pf.to(dt), context_feat=cx.to(dt), tubes=tubes, targets=targets)
+        (o[4].mean() + 5.0 * o[5].mean() + o[6].mean()).backward()
+        grads[dt] = {k: np_(p.grad).astype(np.float64) for k, p in net.named_parameters() if p.requires_grad}
+        assert all(np.isfinite(v).all() for v in grads[dt].values())
+    worst = 0.0
+    for k, a in grads[torch.bfloat16].items():
+        b = grads[torch.float32][k]
+        worst = max(worst, float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)))
+    assert worst < 0.15, worst
+
+
 def case_c2_full_size_properties(dev, golden):
     """BASELINE C2 at its full size (8 x [32,3,224,224], bf16) -- too big for the oracle, so parity is checked through
     size-independent properties:
@@ -293,4 +318,4 @@ def case_c2_full_size_properties(dev, golden):
 
 CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_golden", "case_context_golden",
              "case_twobranch_T3_and_losses_golden", "case_roinet_layouts", "case_training_step_matches_torch_autograd"]
-GPU_CASES = CPU_CASES + ["case_c2_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_inference_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
+GPU_CASES = CPU_CASES + ["case_training_step_16bit_storage", "case_c2_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_inference_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
