@@ -152,8 +152,8 @@ def roofline(net, x, dtype_name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS),
                     help="c2 = headline backbone forward (default); c5 = long-clip stress; c3 = full inference; c4 = training step")
     ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32"])
