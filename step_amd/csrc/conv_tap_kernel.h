@@ -15,16 +15,16 @@ namespace step {
 //     ([kd][TH+kh-1][TW+kw-1] pixels) is staged into LDS once per slab; all taps read it at shifted
 //     bases (im2col-free).  Pixels sit at an 80-byte pitch (64 B + 16 B pad): consecutive pixels
 //     rotate through the LDS banks without an XOR swizzle and a tap shift is a plain byte offset.
-//   * B: the weights of ONE tap x slab x tile-channels (4*NB KiB, already in MFMA fragment order in
-//     global memory, so the copy is linear) go global -> registers -> LDS through a double-buffered
-//     LDS tile with a two-taps-deep register prefetch: the loads for tap s+2 are issued before the
-//     MFMAs of tap s, the registers loaded one tap earlier are written to LDS after them, one
-//     barrier per tap.  Every B fragment read from LDS feeds 2 MFMAs and every A fragment NB MFMAs
-//     (a k16 step costs 2 + NB ds_read_b128 for 2*NB MFMAs), and the weights cross the L2 -> CU
-//     path once per 256 pixels instead of once per 32.
-// MB = 32-pixel accumulator rows per wave: MB = 2 -> 8 waves (4 x 2, 512 threads, 2 waves per SIMD);
-// MB = 4 -> 4 waves (2 x 2, 256 threads, ONE wave per SIMD with the whole 512-register file: a 128-pixel x
-// 96-channel wave tile reads (4 + NB) fragments per 4*NB MFMAs -- 30 % less LDS traffic per MFMA).
+//   * B: the weights of TPS taps x slab x tile-channels (TPS * 4*NB KiB per pipeline step, already in MFMA fragment
+//     order in global memory, so the copy is linear) go global -> two register sets -> three LDS step buffers: a
+//     step's weights are loaded four steps before they are used and written to LDS two steps before; fragments are
+//     double-buffered in registers per tap, one barrier per step.  Every B fragment read from LDS feeds 2 MFMAs and
+//     every A fragment NB MFMAs (a k16 step costs 2 + NB ds_read_b128 for 2*NB MFMAs), and the weights cross the
+//     L2 -> CU path once per 256 pixels instead of once per 32.
+//   * Launch order, tile shapes and the bank-conflict-free row-to-column maps: see grid_coords (conv_common.h) and
+//     the comments at TDL / HWPAD / tile_col below.
+// MB = 32-pixel accumulator rows per wave: MB = 2 -> 8 waves (4 x 2, 512 threads, 2 waves per SIMD) is the only
+// instantiated form (a 4-wave MB = 4 form -- 30 % less LDS traffic per MFMA -- spills at NB >= 2).
 
 template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB>
 __global__ __launch_bounds__(MB == 2 ? 512 : 256, (NB == 1 && TWL == 0) ? 4 : 2)
