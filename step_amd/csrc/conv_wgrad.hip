@@ -64,20 +64,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
         const T* xrow = (const T*)p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W) * p.x_cstride + p.x_coff;
         for (int w0 = 0; w0 < p.W; w0 += 16) {
             f32x8 a[MB], b[NB];
+            // Channel masks are not needed: rows / columns of a ragged (co, ci) tile read a clamped channel and their
+            // accumulators are never stored.  Pixel masks matter only on the first / last step of a row.
+            const int sh = kw_ - p.kw / 2;
+            if (w0 + sh >= 0 && w0 + 16 + sh <= p.W && w0 + 16 <= p.W) {           // interior step (wave-uniform): plain loads
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int w = w0 + 8 * khalf + j, iw = w + kw_ - p.kw / 2;
-                const bool aok = w < p.W, bok = aok && iw >= 0 && iw < p.W;
-                const int wc = aok ? w : p.W - 1, iwc = bok ? iw : 0;
+                for (int j = 0; j < 8; ++j) {
+                    const int w = w0 + 8 * khalf + j;
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const float v = dyrow[(size_t)wc * p.dy_cstride + coc[mb]];
-                    a[mb][j] = (aok && cook[mb]) ? v : 0.f;
+                    for (int mb = 0; mb < MB; ++mb) a[mb][j] = dyrow[(size_t)w * p.dy_cstride + coc[mb]];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) b[nb][j] = elem<T>::to_f32(xrow[(size_t)(w + sh) * p.x_cstride + cic[nb]]);
                 }
+            } else {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const float v = elem<T>::to_f32(xrow[(size_t)iwc * p.x_cstride + cic[nb]]);
-                    b[nb][j] = (bok && ciok[nb]) ? v : 0.f;
+                for (int j = 0; j < 8; ++j) {
+                    const int w = w0 + 8 * khalf + j, iw = w + sh;
+                    const bool aok = w < p.W, bok = aok && iw >= 0 && iw < p.W;
+                    const int wc = aok ? w : p.W - 1, iwc = bok ? iw : 0;
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const float v = dyrow[(size_t)wc * p.dy_cstride + coc[mb]];
+                        a[mb][j] = aok ? v : 0.f;
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const float v = elem<T>::to_f32(xrow[(size_t)iwc * p.x_cstride + cic[nb]]);
+                        b[nb][j] = bok ? v : 0.f;
+                    }
                 }
             }
 #pragma unroll
@@ -140,18 +154,30 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradParams p) {
         const T* xrow = xpl + (size_t)ih * p.W;
         for (int w0 = 0; w0 < p.Wo; w0 += 16) {
             f32x8 a[2], b;
+            // interior step (wave-uniform): all 16 output pixels exist and all 7 taps of each fall inside the row ->
+            // plain loads (channel / (kw, c) masks are unnecessary: surplus accumulator rows and columns are never stored)
+            if (w0 + 16 <= p.Wo && 2 * w0 - 2 >= 0 && 2 * (w0 + 15) + 4 < p.W) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int ow = w0 + 8 * khalf + j, iw = 2 * ow + kw_ - 2;
-                const bool aok = ow < p.Wo, bok = aok && nok && iw >= 0 && iw < p.W;
-                const int owc = aok ? ow : p.Wo - 1, iwc = bok ? iw : 0;
+                for (int j = 0; j < 8; ++j) {
+                    const int ow = w0 + 8 * khalf + j;
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
-                    const float v = dyrow[(size_t)owc * p.Cout + coc[mb]];
-                    a[mb][j] = (aok && cook[mb]) ? v : 0.f;
+                    for (int mb = 0; mb < 2; ++mb) a[mb][j] = dyrow[(size_t)ow * p.Cout + coc[mb]];
+                    b[j] = elem<T>::to_f32(xrow[2 * ow + (nok ? kw_ : 0) - 2]);
                 }
-                const float xv = elem<T>::to_f32(xrow[iwc]);
-                b[j] = bok ? xv : 0.f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ow = w0 + 8 * khalf + j, iw = 2 * ow + kw_ - 2;
+                    const bool aok = ow < p.Wo, bok = aok && nok && iw >= 0 && iw < p.W;
+                    const int owc = aok ? ow : p.Wo - 1, iwc = bok ? iw : 0;
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        const float v = dyrow[(size_t)owc * p.Cout + coc[mb]];
+                        a[mb][j] = aok ? v : 0.f;
+                    }
+                    const float xv = elem<T>::to_f32(xrow[iwc]);
+                    b[j] = bok ? xv : 0.f;
+                }
             }
             mma_k16(a[0], b, acc[0], float());
             mma_k16(a[1], b, acc[1], float());

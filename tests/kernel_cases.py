@@ -512,7 +512,7 @@ def case_conv_wgrad(bk, golden):
 
 def case_stem_wgrad(bk, golden):
     rs = np.random.RandomState(44)
-    N, T, H, W, Cout = 2, 6, 37, 20, 40                     # odd / ragged sizes (Ho = 18: three row chunks, the last ragged); Cout not a multiple of 32
+    N, T, H, W, Cout = 1, 6, 21, 70, 40                     # Ho = 10 (two row chunks), Wo = 35 (edge, interior and edge steps); Cout not a multiple of 32
     x = rs.randn(N, T, 3, H, W).astype(np.float32)
     To, Ho, Wo = (T - 2) // 2 + 1, (H - 2) // 2 + 1, (W - 2) // 2 + 1
     gy = rs.randn(N, Cout, To, Ho, Wo).astype(np.float32)
