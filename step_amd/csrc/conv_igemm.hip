@@ -396,7 +396,7 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
         // step_conv_forward_ws; STEP_CONV_SPLITK=0 disables)
         static const bool splitk_ok = !(getenv("STEP_CONV_SPLITK") && atoi(getenv("STEP_CONV_SPLITK")) == 0);
         const long long M = (long long)d->N * d->D * d->H * d->W;
-        if (splitk_ok && ov1 != 0 && d->dtype != STEP_F32 && d->Cin >= 2048 && M <= 1024 && pl.mtiles * nblk32 < 64) {
+        if (splitk_ok && ov1 != 0 && d->Cin >= 2048 && (d->Cin % 8) == 0 && M <= 1024 && pl.mtiles * nblk32 < 64) {
             pl.impl = 3;
             pl.mbk = M <= 32 ? 1 : (M <= 64 ? 2 : 4);
             const int KC16 = ceil_div(d->Cin, CK) * 2;

@@ -273,7 +273,6 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(ConvParams p) {
 //   (deterministic, no atomics), applies affine / residual / ReLU and stores in the storage type.
 template <typename T, int MBK>
 __global__ __launch_bounds__(256) void pw_splitk_kernel(ConvParams p, float* __restrict__ ws, int kchunk16, int mpad, int cpad) {
-    static_assert(sizeof(T) == 2, "16-bit storage types only");
     typedef typename frag<T>::type frag_t;
     __shared__ float red[4][MBK * 32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, khalf = lane >> 5;
@@ -307,7 +306,13 @@ __global__ __launch_bounds__(256) void pw_splitk_kernel(ConvParams p, float* __r
             frag_t a;
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[e] = 0;
-            if (cok && rok[mb]) a = *(const frag_t*)(arow[mb] + ks * 16);
+            if (cok && rok[mb]) {                          // 16 bytes per lane for 16-bit storage, 2 x 16 bytes for fp32
+                typedef typename Ld16<T>::type v16;
+                v16 part[sizeof(frag_t) / 16];
+#pragma unroll
+                for (int q = 0; q < (int)(sizeof(frag_t) / 16); ++q) part[q] = *(const v16*)(arow[mb] + ks * 16 + q * (16 / (int)sizeof(T)));
+                __builtin_memcpy(&a, part, sizeof(a));
+            }
             mma_k16(a, b, acc[mb], T());
         }
     }
@@ -341,10 +346,8 @@ __global__ void pw_splitk_finish_kernel(ConvParams p, const float* __restrict__ 
 }
 
 
-template <typename T>
-static int splitk_forward_t(const ConvPlan& pl, const ConvParams& p, float* ws, step_stream_t stream) { return STEP_E_UNSUPPORTED; }
 template <typename T16>
-static int splitk_forward_16(const ConvPlan& pl, const ConvParams& p, float* ws, step_stream_t stream) {
+static int splitk_forward_t(const ConvPlan& pl, const ConvParams& p, float* ws, step_stream_t stream) {
     dim3 grid((unsigned)p.nblk32, (unsigned)pl.ksplit, (unsigned)pl.mtiles);
     switch (pl.mbk) {
         case 1: STEP_LAUNCH((pw_splitk_kernel<T16, 1>), grid, dim3(256), stream, p, ws, pl.kchunk16, pl.mpad, pl.cpad); break;
@@ -355,8 +358,6 @@ static int splitk_forward_16(const ConvPlan& pl, const ConvParams& p, float* ws,
     STEP_LAUNCH((pw_splitk_finish_kernel<T16>), dim3(flat_grid(total, 256)), dim3(256), stream, p, (const float*)ws, pl.ksplit, pl.mpad, pl.cpad);
     return STEP_LAUNCH_CHECK();
 }
-template <> int splitk_forward_t<bf16_t>(const ConvPlan& pl, const ConvParams& p, float* ws, step_stream_t stream) { return splitk_forward_16<bf16_t>(pl, p, ws, stream); }
-template <> int splitk_forward_t<f16_t>(const ConvPlan& pl, const ConvParams& p, float* ws, step_stream_t stream) { return splitk_forward_16<f16_t>(pl, p, ws, stream); }
 
 
 template <typename T>

@@ -461,7 +461,7 @@ def case_conv_splitk_few_rows_deep_k(bk, golden):
         w = (rs.randn(Cout, Cin, 1, 1, 1) / np.sqrt(Cin)).astype(np.float32)
         shift = (0.2 * rs.randn(Cout)).astype(np.float32)
         res = rs.randn(rows, Cout, 1, 1, 1).astype(np.float32)
-        for dt in (BF16, F16):
+        for dt in (BF16, F16, F32):
             ref = ref_conv(x, w, None, shift, dt, relu=False, res=res)
             got = run_conv(bk, x, w, None, shift, dt, relu=False, res=res, y_pad=(4, 4), use_ws=True)
             if not os.environ.get("STEP_CONV_IMPL"):                  # a forced implementation bypasses the planner
@@ -470,8 +470,8 @@ def case_conv_splitk_few_rows_deep_k(bk, golden):
             for y in (got, plain):
                 err = np.abs(y - ref).max() / np.abs(ref).max()
                 assert err < tol(dt), (rows, Cin, Cout, dt, err)
-    # fp32 and shallow layers never ask for a workspace
-    d = _capi.ConvDesc(dtype=F32, N=5, D=1, H=1, W=1, Cin=4096, Cout=12, kd=1, kh=1, kw=1, x_cstride=4096, x_coff=0, y_cstride=12,
+    # shallow layers never ask for a workspace
+    d = _capi.ConvDesc(dtype=F32, N=5, D=1, H=1, W=1, Cin=1024, Cout=12, kd=1, kh=1, kw=1, x_cstride=1024, x_coff=0, y_cstride=12,
                        y_coff=0, res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)
     assert bk.lib.step_conv_workspace_bytes(ctypes.byref(d)) == 0
 
