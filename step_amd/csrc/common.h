@@ -41,8 +41,14 @@ __device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) {
     unsigned int u = ((unsigned int)h) << 16;
     return __builtin_bit_cast(float, u);
 }
-// round-to-nearest-even, NaN kept quiet (same as torch's float -> bfloat16)
+// round-to-nearest-even, NaN kept quiet (same as torch's float -> bfloat16).  On the device this is the hardware
+// conversion (v_cvt_pk_bf16_f32 on gfx950: one instruction per PAIR of values; the bit-twiddling form below costs ~7
+// VALU operations per value and was a quarter of the epilogues' vector work); the host interpreter keeps the
+// portable form.  Both are IEEE round-to-nearest-even, so finite results are bit-identical.
 __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+#ifndef STEP_EMUL
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
+#endif
     unsigned int u = __builtin_bit_cast(unsigned int, f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
     u += 0x7fffu + ((u >> 16) & 1u);
