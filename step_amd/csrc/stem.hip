@@ -432,26 +432,50 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
 
     // ---- frame staging: LDS col cl <-> input col 2*ow0 - 4 + cl, row r <-> input row 2*oh0 - 2 + r
     struct Item { u16x4 c[3]; };
+    // per-thread item table (frame-invariant): element offset of the item's 4 columns inside a channel plane, or -1
+    // when the quad lies outside the image.  With W % 4 == 0 a quad is entirely inside or entirely outside (the tile
+    // origin 2*ow0 - 4 is a multiple of 4), so the frame loop needs no division, no branch and no partial quad.
+    int qoff[FQ];
+#pragma unroll
+    for (int q = 0; q < FQ; ++q) {
+        const int item = tid + q * 256;
+        const int cq = item % (STP_COLS / 4), r = item / (STP_COLS / 4);
+        const int ih = 2 * oh0 - 2 + r, iw0 = 2 * ow0 - 4 + cq * 4;
+        qoff[q] = (item < ITEMS && ih >= 0 && ih < p.H && iw0 >= 0 && iw0 + 3 < p.W) ? ih * p.W + iw0 : -1;
+    }
+    const size_t plane_elems = (size_t)p.H * p.W;
     auto load_frame = [&](int f, Item (&it)[FQ]) {
         const int ifr = 2 * od - 2 + f;
+        const bool frok = ifr >= 0 && ifr < p.T;                 // workgroup-uniform
+        const unsigned short* fbase = (const unsigned short*)xg + ((size_t)n * p.T + (frok ? ifr : 0)) * 3 * plane_elems;
+        if (vec_ok) {
 #pragma unroll
-        for (int q = 0; q < FQ; ++q) {
+            for (int q = 0; q < FQ; ++q) {
+                const bool ok = frok && qoff[q] >= 0;
+                const unsigned short* src = fbase + (ok ? qoff[q] : 0);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const u16x4 v = *(const u16x4*)(src + c * plane_elems);
+                    const u16x4 z = {0, 0, 0, 0};
+                    it[q].c[c] = ok ? v : z;
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) {                           // W % 4 != 0: element-wise with bounds checks
             const int item = tid + q * 256;
             const int cq = item % (STP_COLS / 4), r = item / (STP_COLS / 4);
             const int ih = 2 * oh0 - 2 + r, iw0 = 2 * ow0 - 4 + cq * 4;
-            const bool rowok = item < ITEMS && ifr >= 0 && ifr < p.T && ih >= 0 && ih < p.H;
+            const bool rowok = item < ITEMS && frok && ih >= 0 && ih < p.H;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 u16x4 v = {0, 0, 0, 0};
                 if (rowok) {
-                    const unsigned short* src = (const unsigned short*)xg + ((((size_t)n * p.T + ifr) * 3 + c) * p.H + ih) * p.W;
-                    if (vec_ok && iw0 >= 0 && iw0 + 3 < p.W) {
-                        v = *(const u16x4*)(src + iw0);
-                    } else {
+                    const unsigned short* src = fbase + c * plane_elems + (size_t)ih * p.W;
 #pragma unroll
-                        for (int a = 0; a < 4; ++a)
-                            if (iw0 + a >= 0 && iw0 + a < p.W) v[a] = src[iw0 + a];
-                    }
+                    for (int a = 0; a < 4; ++a)
+                        if (iw0 + a >= 0 && iw0 + a < p.W) v[a] = src[iw0 + a];
                 }
                 it[q].c[c] = v;
             }
