@@ -236,10 +236,23 @@ void conv_tap_kernel(ConvParams p) {
                 for (int mb = 0; mb < MB; ++mb) mma_k16(fa[SET][j][mb], fb[SET][j][i], acc[mb][i], T());
             }
     };
-    // LDS byte shift of tap t of the slab (the zero tap of an odd tap count reads tap 0's pixels)
-    auto tap_shift = [&](int t_) {
-        const int tt = (t_ < NTAPS) ? t_ : 0;
-        return (((tt / (KH * KW)) * HH_ + (tt / KW) % KH) * HW_ + tt % KW) * PITCH;
+    // LDS byte shift of the NEXT tap to prefetch, advanced incrementally (kw, kh, kd counters): computing it from the
+    // tap index costs two scalar divisions per tap, and the scalar unit is shared by the CU's eight wavefronts -- the
+    // step loop carried ~150 scalar instructions per 24 MFMAs per wave (ISA count), enough to keep it ~80 % busy.
+    // Taps run kd-major; the zero tap that pads an odd tap count and the first tap of the next slab both read shift 0.
+    int nshift = 0, tidx = 0, kw_c = 0, kh_c = 0;
+    auto advance_tap = [&]() {
+        ++tidx;
+        if (tidx >= NTAPS) {
+            nshift = 0; kw_c = 0; kh_c = 0;
+            if (tidx == ((TPS == 1) ? NTAPS : NTP)) tidx = 0;        // one tap per step walks the 27 real taps only
+            return;
+        }
+        ++kw_c; nshift += PITCH;
+        if (kw_c == KW) {
+            kw_c = 0; nshift += (HW_ - KW) * PITCH;
+            if (++kh_c == KH) { kh_c = 0; nshift += (HH_ - KH) * HW_ * PITCH; }
+        }
     };
 
     // (slab, step-in-slab) cursors: c0 = current step, c3 = step + 4 (weight loads)
@@ -269,11 +282,13 @@ void conv_tap_kernel(ConvParams p) {
         constexpr bool LAST = (TP == TPS - 1);
         bool new_slab = false;
         if (!LAST) {                                       // next slot: same step, same weight buffer
-            read_frags(std::integral_constant<int, SET ^ 1>(), b0 + (TP + 1) * BTILE, tap_shift(sis0 * TPS + TP + 1));
+            advance_tap();
+            read_frags(std::integral_constant<int, SET ^ 1>(), b0 + (TP + 1) * BTILE, nshift);
         } else {                                           // next slot opens step s+1
             new_slab = (sis0 + 1 == SPS);
+            advance_tap();                                 // (a new slab restarts at tap 0: shift 0)
             if (s_ + 1 < S && !new_slab)
-                read_frags(std::integral_constant<int, SET ^ 1>(), b1, tap_shift((sis0 + 1) * TPS));
+                read_frags(std::integral_constant<int, SET ^ 1>(), b1, nshift);
         }
         mma_all(setc);
         if (LAST) {

@@ -6,7 +6,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "step_amd", "csrc", sys.argv[1] + ".hip")
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 out = "/tmp/isa_%s.s" % sys.argv[1]
-if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+newest = max(os.path.getmtime(os.path.join(os.path.dirname(src), f)) for f in os.listdir(os.path.dirname(src)) if f.endswith((".hip", ".h")))
+if not os.path.exists(out) or os.path.getmtime(out) < newest:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-strict-aliasing", "-w",
                            "--cuda-device-only", "-S", "-x", "hip", src, "-o", out])
 s = open(out).read()
