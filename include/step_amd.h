@@ -222,6 +222,14 @@ STEP_API int step_avgpool_hw(int dtype, const void* x, int N, int D, int H, int 
 STEP_API int step_transpose_cs(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int C, long long S,
                                int to_channels_last, step_stream_t stream);
 
+/* Clip ingest: uint8 frames [N,T,H,W,3] (device memory; the decoder's layout, data/ava.py:298-338) -> the normalised
+ * clip [N,T,3,H,W] in `dtype` that step_stem_forward / BaseNet.forward take.  Same fp32 arithmetic, in the same order, as
+ * the reference's host-side ConvertFromInts(scale) + SubtractMeans + DivideStds (data/augmentations.py:68-111,600-612):
+ * scale 0: x, 1: x/255, 2: x*2/255 - 1; then (v - mean[c]) / std[c].  mean3 / std3 are HOST pointers to 3 floats (NULL = 0 / 1).
+ * Frames must already have the network's resolution (the reference resizes on the host between the two steps). */
+STEP_API int step_clip_from_u8(const unsigned char* frames, int N, int T, int H, int W, int scale, const float* mean3,
+                               const float* std3, int dtype, void* clip, step_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -368,6 +368,31 @@ __global__ void maxpool3d_tf_bwd_kernel(const T* __restrict__ x, const float* __
     }
 }
 
+// Clip ingest: decoded frames arrive as uint8 [N,T,H,W,3] (what cv2 / the data loader hands over,
+// data/ava.py:298-338); the reference converts on the host -- ConvertFromInts(scale), SubtractMeans, DivideStds
+// (data/augmentations.py:68-111,600-612) -- and ships fp32 [T,3,H,W] over PCIe (4x the bytes).  Here the uint8 frames
+// are transferred and this kernel writes the normalised clip in the layout BaseNet.forward takes ([N,T,3,H,W]).
+// Same fp32 operation order as the numpy code (no FMA contraction): ((x*2)/255 - 1 - mean[c]) / std[c] for scale 2.
+template <typename T>
+__global__ void clip_from_u8_kernel(const unsigned char* __restrict__ src, T* __restrict__ dst, int HW, long long frames, int scale,
+                                    float m0, float m1, float m2, float s0, float s1, float s2, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)blockDim.x * gridDim.x) {
+        const long long f = idx / HW;
+        const int pix = (int)(idx % HW);
+        const unsigned char* s3 = src + (f * HW + pix) * 3;
+        T* d = dst + f * 3 * HW + pix;
+        const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = (float)s3[c];
+            if (scale == 1) v = __fdiv_rn(v, 255.f);
+            else if (scale == 2) v = __fsub_rn(__fdiv_rn(__fmul_rn(v, 2.f), 255.f), 1.f);
+            v = __fdiv_rn(__fsub_rn(v, mean[c]), stdv[c]);
+            d[(size_t)c * HW] = elem<T>::from_f32(v);
+        }
+    }
+}
+
 template <typename T>
 __global__ void avgpool_hw_kernel(const T* __restrict__ x, T* __restrict__ y, int ND, int H, int W, int C, int kh,
                                   int kw, long long total) {
@@ -542,6 +567,24 @@ int step_maxpool3d_tf_backward(int dtype, const void* x, int N, int D, int H, in
         case STEP_F32: STEP_LAUNCH((maxpool3d_tf_bwd_kernel<float>), grid, dim3(256), stream, (const float*)x, gy, gx, p, total); break;
         case STEP_BF16: STEP_LAUNCH((maxpool3d_tf_bwd_kernel<bf16_t>), grid, dim3(256), stream, (const bf16_t*)x, gy, gx, p, total); break;
         case STEP_F16: STEP_LAUNCH((maxpool3d_tf_bwd_kernel<f16_t>), grid, dim3(256), stream, (const f16_t*)x, gy, gx, p, total); break;
+        default: return STEP_E_DTYPE;
+    }
+    return STEP_LAUNCH_CHECK();
+}
+
+int step_clip_from_u8(const unsigned char* frames, int N, int T, int H, int W, int scale, const float* mean3, const float* std3,
+                      int dtype, void* clip, step_stream_t stream) {
+    if (N < 0 || T <= 0 || H <= 0 || W <= 0 || scale < 0 || scale > 2) return STEP_E_SHAPE;
+    if (N == 0) return STEP_OK;
+    if (!frames || !clip) return STEP_E_NULL;
+    const float m0 = mean3 ? mean3[0] : 0.f, m1 = mean3 ? mean3[1] : 0.f, m2 = mean3 ? mean3[2] : 0.f;   // host pointers (3 floats)
+    const float s0 = std3 ? std3[0] : 1.f, s1 = std3 ? std3[1] : 1.f, s2 = std3 ? std3[2] : 1.f;
+    const long long fr = (long long)N * T, total = fr * H * W;
+    const dim3 grid(flat_grid(total, 256));
+    switch (dtype) {
+        case STEP_F32: STEP_LAUNCH((clip_from_u8_kernel<float>), grid, dim3(256), stream, frames, (float*)clip, H * W, fr, scale, m0, m1, m2, s0, s1, s2, total); break;
+        case STEP_BF16: STEP_LAUNCH((clip_from_u8_kernel<bf16_t>), grid, dim3(256), stream, frames, (bf16_t*)clip, H * W, fr, scale, m0, m1, m2, s0, s1, s2, total); break;
+        case STEP_F16: STEP_LAUNCH((clip_from_u8_kernel<f16_t>), grid, dim3(256), stream, frames, (f16_t*)clip, H * W, fr, scale, m0, m1, m2, s0, s1, s2, total); break;
         default: return STEP_E_DTYPE;
     }
     return STEP_LAUNCH_CHECK();

@@ -214,6 +214,22 @@ def maxpool_tf_backward(x, gy, k, s):
     return gx
 
 
+def clip_from_u8(frames, dtype=torch.float32, scale=2, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0)):
+    """uint8 frames [N,T,H,W,3] on the device -> normalised clip [N,T,3,H,W] (the reference's ConvertFromInts(scale) +
+    SubtractMeans + DivideStds, data/augmentations.py:68-111, done after the PCIe transfer instead of before it)."""
+    L = _lib.lib()
+    if frames.dtype != torch.uint8 or frames.dim() != 5 or frames.shape[-1] != 3 or not frames.is_contiguous():
+        raise RuntimeError("step_amd: clip_from_u8 expects contiguous uint8 frames [N,T,H,W,3]")
+    N, T, H, W, _ = frames.shape
+    out = torch.empty((N, T, 3, H, W), dtype=dtype, device=frames.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    sd = (ctypes.c_float * 3)(*[float(v) for v in std])
+    code = {torch.float32: _capi.F32, torch.bfloat16: _capi.BF16, torch.float16: _capi.F16}[dtype]
+    _capi.check(L.step_clip_from_u8(_lib.dptr(frames), N, T, H, W, int(scale), m, sd, code, _lib.dptr(out), _lib.stream_ptr(frames.device)),
+                "step_clip_from_u8")
+    return out
+
+
 def avgpool_hw(x, kh, kw):
     L = _lib.lib()
     N, D, H, W, C = x.shape

@@ -361,6 +361,39 @@ def case_pool_golden(bk, golden):
         assert np.array_equal(uncl(y.get())[:, :5], ref), tag
 
 
+def case_clip_from_u8(bk, golden):
+    """uint8 HWC frames -> normalised [N,T,3,H,W] clip: bit-exact against the numpy arithmetic of the reference's
+    ConvertFromInts / SubtractMeans / DivideStds (data/augmentations.py:68-111), all three scale modes."""
+    rs = np.random.RandomState(77)
+    N, T, H, W = 2, 3, 5, 7
+    fr = rs.randint(0, 256, (N, T, H, W, 3)).astype(np.uint8)
+    fr[0, 0, 0, 0] = (0, 255, 128)
+    mean, std = np.array([0.1, -0.2, 0.3], np.float32), np.array([1.0, 0.5, 2.0], np.float32)
+    for scale in (0, 1, 2):
+        img = fr.copy()
+        if scale == 0:
+            ref = img.astype(np.float32)
+        elif scale == 1:
+            ref = img.astype(np.float32) / 255.
+        else:
+            ref = np.clip(img, 0, 255).astype(np.float32) * 2 / 255 - 1.
+        ref = ref.astype(np.float32)
+        ref -= mean
+        ref /= std
+        ref = np.ascontiguousarray(np.transpose(ref, (0, 1, 4, 2, 3)))
+        src = bk.dev(fr)
+        out = bk.dev(np.zeros((N, T, 3, H, W), np.float32))
+        m = (ctypes.c_float * 3)(*mean.tolist())
+        sd = (ctypes.c_float * 3)(*std.tolist())
+        assert bk.lib.step_clip_from_u8(src.ptr, N, T, H, W, scale, m, sd, F32, out.ptr, bk.stream) == 0
+        assert np.array_equal(out.get(), ref), scale
+    outb = bk.dev(np.zeros((N, T, 3, H, W), np.uint16))
+    assert bk.lib.step_clip_from_u8(bk.dev(fr).ptr, N, T, H, W, 2, None, None, BF16, outb.ptr, bk.stream) == 0
+    ref2 = np.transpose(fr.astype(np.float32) * 2 / 255 - 1., (0, 1, 4, 2, 3))
+    assert np.array_equal(outb.get(), to_bf16_bits(ref2))
+    assert bk.lib.step_clip_from_u8(None, N, T, H, W, 3, None, None, F32, out.ptr, bk.stream) < 0
+
+
 def case_avgpool_hw(bk, golden):
     rs = np.random.RandomState(6)
     x = rs.randn(2, 8, 3, 13, 13).astype(np.float32)
