@@ -187,10 +187,11 @@ void conv_tap_kernel(ConvParams p) {
         wthr[q] = wg + ((size_t)nbg * taps_padded(NTAPS) * KC16 + ks) * FRAGB + within * 16;
         ldsoff[q] = (tid + q * NT < BVEC) ? (tid + q * NT) * 16 : -1;
     }
-    auto load_B = [&](int slab_, int sis_, u32x4 (&r)[TPS * Q]) {         // sis_ = step index within the slab
+    const unsigned wtap = (unsigned)KC16 * FRAGB;                       // bytes between consecutive taps of one channel block
+    auto load_B = [&](unsigned woff, u32x4 (&r)[TPS * Q]) {             // woff = byte offset of the step's first tap (scalar)
 #pragma unroll
         for (int tp = 0; tp < TPS; ++tp) {
-            const size_t off = (size_t)((sis_ * TPS + tp) * KC16 + slab_ * KS) * FRAGB;      // scalar
+            const size_t off = (size_t)woff + (size_t)tp * wtap;
 #pragma unroll
             for (int q = 0; q < Q; ++q) r[tp * Q + q] = *(const u32x4*)(wthr[q] + off);
         }
@@ -257,19 +258,24 @@ void conv_tap_kernel(ConvParams p) {
 
     // (slab, step-in-slab) cursors: c0 = current step, c3 = step + 4 (weight loads)
     int slab0 = 0, sis0 = 0, slab3 = 0, sis3 = 0;
+    unsigned woff3 = 0;                                     // running weight offset of the step the cursor points at (no multiplies per step)
     auto adv = [&](int& sl, int& si) { if (++si == SPS) { si = 0; ++sl; } };
-    auto adv_clamped = [&]() { adv(slab3, sis3); if (slab3 >= nslab) { slab3 = nslab - 1; sis3 = SPS - 1; } };   // past the end: re-read the last tile
+    auto adv_clamped = [&]() {                             // past the end: stay on (re-read) the last tile
+        if (slab3 == nslab - 1 && sis3 == SPS - 1) return;
+        woff3 += (unsigned)TPS * wtap;
+        if (++sis3 == SPS) { sis3 = 0; ++slab3; woff3 = (unsigned)slab3 * KS * FRAGB; }
+    };
 
     stage_A(0);
-    load_B(0, 0, R0);
+    load_B(0u, R0);
     adv_clamped();
-    load_B(slab3, sis3, R1);
+    load_B(woff3, R1);
     adv_clamped();
     store_B(0, R0);
-    load_B(slab3, sis3, R0);                               // step 2
+    load_B(woff3, R0);                               // step 2
     adv_clamped();
     store_B(BSTEP, R1);
-    load_B(slab3, sis3, R1);                               // step 3
+    load_B(woff3, R1);                               // step 3
     adv_clamped();                                         // -> step 4
     __syncthreads();
     read_frags(std::integral_constant<int, 0>(), 0, 0);
@@ -293,7 +299,7 @@ void conv_tap_kernel(ConvParams p) {
         mma_all(setc);
         if (LAST) {
             store_B(b2, R);                                // (past the end: a duplicate tile into a buffer nobody reads)
-            load_B(slab3, sis3, R);
+            load_B(woff3, R);
             adv_clamped();
             if (s_ + 1 < S && new_slab) {
                 __syncthreads();                          // every wave is done with this slab of A
