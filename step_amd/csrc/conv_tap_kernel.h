@@ -72,7 +72,12 @@ void conv_tap_kernel(ConvParams p) {
     constexpr int Q = (BVEC + NT - 1) / NT; // vectors per thread per tap
     constexpr int NTP = taps_padded(NTAPS);                 // packed taps (odd counts carry one zero tap)
     constexpr int SPS = (TPS == 1) ? NTAPS : NTP / TPS;     // pipeline steps per slab (TPS taps per barrier)
-    constexpr int BSTEP = TPS * BTILE;                      // LDS weight bytes per step
+    // LDS pitch of one tap's weight tile.  When the tile is not a whole number of 512-thread rounds (NB = 3: 768 vectors)
+    // its last round is predicated -- a handful of exec-masked blocks in the step loop; if LDS has room the tile is
+    // padded to whole rounds instead and every thread stores unconditionally (its surplus vectors are never read).
+    constexpr bool PADB = (BVEC % NT) != 0 && (NPIX_MAX * PITCH + 3 * TPS * Q * NT * 16) <= 160 * 1024;
+    constexpr int BPITCH = PADB ? Q * NT * 16 : BTILE;
+    constexpr int BSTEP = TPS * BPITCH;                     // LDS weight bytes per step
     typedef typename Ld16<T>::type vec16;
     typedef typename frag<T>::type frag_t;
 
@@ -185,7 +190,7 @@ void conv_tap_kernel(ConvParams p) {
         const int nbl = f / KS, ks = f % KS;
         const int nbg = min(nb0 + nbl, p.nblk32 - 1);
         wthr[q] = wg + ((size_t)nbg * taps_padded(NTAPS) * KC16 + ks) * FRAGB + within * 16;
-        ldsoff[q] = (tid + q * NT < BVEC) ? (tid + q * NT) * 16 : -1;
+        ldsoff[q] = (PADB || tid + q * NT < BVEC) ? (tid + q * NT) * 16 : -1;
     }
     const unsigned wtap = (unsigned)KC16 * FRAGB;                       // bytes between consecutive taps of one channel block
     auto load_B = [&](unsigned woff, u32x4 (&r)[TPS * Q]) {             // woff = byte offset of the step's first tap (scalar)
@@ -201,7 +206,7 @@ void conv_tap_kernel(ConvParams p) {
         for (int tp = 0; tp < TPS; ++tp)
 #pragma unroll
             for (int q = 0; q < Q; ++q)
-                if (ldsoff[q] >= 0) *(u32x4*)(ldsB + bufoff + tp * BTILE + ldsoff[q]) = r[tp * Q + q];
+                if (PADB || ldsoff[q] >= 0) *(u32x4*)(ldsB + bufoff + tp * BPITCH + ldsoff[q]) = r[tp * Q + q];
     };
 
     // Pipeline.  A STEP = TPS taps of one slab = one barrier; a SLOT = one tap.
@@ -289,7 +294,7 @@ void conv_tap_kernel(ConvParams p) {
         bool new_slab = false;
         if (!LAST) {                                       // next slot: same step, same weight buffer
             advance_tap();
-            read_frags(std::integral_constant<int, SET ^ 1>(), b0 + (TP + 1) * BTILE, nshift);
+            read_frags(std::integral_constant<int, SET ^ 1>(), b0 + (TP + 1) * BPITCH, nshift);
         } else {                                           // next slot opens step s+1
             new_slab = (sis0 + 1 == SPS);
             advance_tap();                                 // (a new slab restarts at tap 0: shift 0)
