@@ -454,7 +454,9 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
     // few-tile, small-Cin problems stay on the 4-wave 128-pixel kernel (more workgroups); everything else -- the
     // Cin = 16/32 branches of the Inception blocks included (measured: 9 x 3x3x3 layers 0.253 ms against 0.317 ms) --
     // runs the pipelined kernel
-    const bool use_tap = ov >= 1 || (ov != 0 && (d->Cin >= 64 || mt256 >= 32));
+    // (conv_tap_kernel keeps 32-bit element offsets of its halo vectors)
+    const bool fits32 = ((unsigned long long)d->N * d->D * d->H * d->W + 1) * (unsigned long long)d->x_cstride < 0xffffffffULL;
+    const bool use_tap = fits32 && (ov >= 1 || (ov != 0 && (d->Cin >= 64 || mt256 >= 32)));
     if (use_tap) {
         pl.impl = 1;
         pl.tps = (ov == 1) ? 1 : 2;     // two taps per barrier measured 6-15 % faster than one (STEP_CONV_IMPL=tap forces one)

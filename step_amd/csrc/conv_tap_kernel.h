@@ -75,7 +75,7 @@ void conv_tap_kernel(ConvParams p) {
     // LDS pitch of one tap's weight tile.  When the tile is not a whole number of 512-thread rounds (NB = 3: 768 vectors)
     // its last round is predicated -- a handful of exec-masked blocks in the step loop; if LDS has room the tile is
     // padded to whole rounds instead and every thread stores unconditionally (its surplus vectors are never read).
-    constexpr bool PADB = (BVEC % NT) != 0 && (NPIX_MAX * PITCH + 3 * TPS * Q * NT * 16) <= 160 * 1024;
+    constexpr bool PADB = BVEC > NT && (BVEC % NT) != 0 && (NPIX_MAX * PITCH + 3 * TPS * Q * NT * 16) <= 160 * 1024;   // (a tile below one round, NB = 1, is a wave-uniform predicate)
     constexpr int BPITCH = PADB ? Q * NT * 16 : BTILE;
     constexpr int BSTEP = TPS * BPITCH;                     // LDS weight bytes per step
     typedef typename Ld16<T>::type vec16;
@@ -144,6 +144,27 @@ void conv_tap_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][i][r] = 0.f;
 
+    // Per-thread staging table (the same for every slab): element offset of each of this thread's halo vectors, or
+    // ~0u outside the image / the halo.  Decoding a vector index into (plane, row, column) takes divisions -- by
+    // run-time box dimensions in the general-tile instantiation -- which used to be redone for every slab.
+    // (32-bit offsets: the planner sends tensors of >= 2^32 elements to conv_igemm_kernel.)
+    unsigned goff[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int v = tid + it * NT;
+        goff[it] = ~0u;
+        if (v < NVEC) {
+            const int pix = v / SLOTS, slot = v % SLOTS;
+            const int plane = pix / HHW, rem = pix % HHW;
+            const int r = rem / HW_, cc = rem % HW_;
+            const int id = d0 + plane - KD / 2, ih = h0 + r - KH / 2, iw = w0 + cc - KW / 2;
+            const bool inb = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && cc < HWV;
+            if (inb) {
+                const size_t gpix = (((size_t)n * p.D + id) * p.H + ih) * p.W + iw;
+                goff[it] = (unsigned)(gpix * p.x_cstride + p.x_coff + slot * VEC);
+            }
+        }
+    }
     auto stage_A = [&](int slab) {
         vec16 stage[ITER];
 #pragma unroll
@@ -152,18 +173,8 @@ void conv_tap_kernel(ConvParams p) {
             vec16 val;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) val[e] = 0;
-            if (v < NVEC) {
-                const int pix = v / SLOTS, slot = v % SLOTS;
-                const int c = slab * CKT + slot * VEC;
-                const int plane = pix / HHW, rem = pix % HHW;
-                const int r = rem / HW_, cc = rem % HW_;
-                const int id = d0 + plane - KD / 2, ih = h0 + r - KH / 2, iw = w0 + cc - KW / 2;
-                const bool inb = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && cc < HWV;
-                if (inb && c < p.Cin) {
-                    const size_t gpix = (((size_t)n * p.D + id) * p.H + ih) * p.W + iw;
-                    val = *(const vec16*)(xg + gpix * p.x_cstride + p.x_coff + c);
-                }
-            }
+            const int c = slab * CKT + (v % SLOTS) * VEC;
+            if (goff[it] != ~0u && c < p.Cin) val = *(const vec16*)(xg + (size_t)goff[it] + slab * CKT);
             stage[it] = val;
         }
 #pragma unroll
