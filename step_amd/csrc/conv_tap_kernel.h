@@ -81,7 +81,9 @@ void conv_tap_kernel(ConvParams p) {
     typedef typename Ld16<T>::type vec16;
     typedef typename frag<T>::type frag_t;
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX_MAX * PITCH + 3 * BSTEP];
+    constexpr int EPI_BYTES = (ES == 2) ? 128 * NBT * 32 * 4 + 1024 : 0;     // fp32 transpose buffer of the 16-bit epilogue + pixel table
+    constexpr int LDS_BYTES = (NPIX_MAX * PITCH + 3 * BSTEP) > EPI_BYTES ? (NPIX_MAX * PITCH + 3 * BSTEP) : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     unsigned char* const ldsA = lds;
     unsigned char* const ldsB = lds + NPIX_MAX * PITCH;
     // tile pixel index m (accumulator row) -> box coordinates; rows past the box of a GEN tile alias pixel 0
@@ -356,6 +358,17 @@ void conv_tap_kernel(ConvParams p) {
         // than the accumulator layout allows (2 B per lane, 64 B runs) and whole-line writes.
         constexpr int BN = NBT * 32, G = BN / 8;
         float* ot = (float*)lds;
+        // output pixel of every accumulator row, decoded ONCE per tile pixel (a general box divides by run-time
+        // extents; the store loop below visits each pixel G/… times) into a 1 KiB table behind the transpose buffer
+        static_assert(ES != 2 || sizeof(lds) >= 128 * BN * 4 + 1024, "no room for the pixel table");
+        int* const pixtab = (int*)(lds + sizeof(lds) - 1024);
+        if (tid < 256) {
+            int tdl, thl, twl;
+            tile_pix(tid, tdl, thl, twl);
+            const int od = d0 + tdl, oh = h0 + thl, ow = w0 + tile_col(thl, twl);
+            const bool ok = (!GEN || tid < TPX) && od < p.D && oh < p.H && ow < p.W;
+            pixtab[tid] = ok ? (int)((((long long)n * p.D + od) * p.H + oh) * p.W + ow) : -1;
+        }
         float sc[NB], sh[NB];
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -379,12 +392,10 @@ void conv_tap_kernel(ConvParams p) {
                 const int row = idx / G, g = idx % G;
                 // row = (wm*MBP + mbl)*32 + rr  ->  tile pixel wm*(MB*32) + (ps*MBP + mbl)*32 + rr
                 const int mm = ((row >> 5) / MBP) * (MB * 32) + (ps * MBP + (row >> 5) % MBP) * 32 + (row & 31);
-                int tdl, thl, twl;
-                tile_pix(mm, tdl, thl, twl);
-                const int od = d0 + tdl, oh = h0 + thl, ow = w0 + tile_col(thl, twl);
+                const int px = pixtab[mm];
                 const int co = nb0 * 32 + g * 8;
-                if ((!GEN || mm < TPX) && od < p.D && oh < p.H && ow < p.W && co < p.Cout) {
-                    const size_t opix = (((size_t)n * p.D + od) * p.H + oh) * p.W + ow;
+                if (px >= 0 && co < p.Cout) {
+                    const size_t opix = (size_t)px;
                     const f32x4 lo = *(const f32x4*)(ot + row * BN + g * 8);
                     const f32x4 hi = *(const f32x4*)(ot + row * BN + g * 8 + 4);
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
