@@ -303,6 +303,14 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
         t = torch.tensor([el], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    # dominant kernel of one eager, single-stream, instrumented step -- run by EVERY rank (the C4 step contains the
+    # gradient all-reduce: a collective issued by rank 0 alone would dead-lock against the others' final barrier)
+    ops.PROFILE = []
+    saved, backbone.BRANCH_STREAMS = backbone.BRANCH_STREAMS, False
+    (w.eager if a.config == "c3" else w.step)()
+    torch.cuda.synchronize()
+    backbone.BRANCH_STREAMS = saved
+    REC, ops.PROFILE = ops.PROFILE, None
     if rank == 0:
         val = world * CLIPS_PER_GPU * a.steps / el
         out = {"metric": metric, "value": round(val, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": max(a.warmup, 2),
@@ -311,13 +319,7 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
                "config": {"workload": what + ", inputs resident in HBM, random-init weights", "clips_per_gpu": CLIPS_PER_GPU, "T": 36, "HW": 400,
                           "parallelism": "clip-sharded replicas x%d (%s)" % (world, "no data-path collective" if a.config == "c3" else "one gradient all-reduce per step"),
                           "launch": "hipGraph replay + eager post-processing" if (a.config == "c3" and not a.no_graph) else "eager"}}
-        # dominant kernel of one eager, single-stream, instrumented step
-        ops.PROFILE = []
-        saved, backbone.BRANCH_STREAMS = backbone.BRANCH_STREAMS, False
-        (w.eager if a.config == "c3" else w.step)()
-        torch.cuda.synchronize()
-        backbone.BRANCH_STREAMS = saved
-        rec, ops.PROFILE = ops.PROFILE, None
+        rec = REC
         agg = {}
         for name, flops, nbytes, e0, e1 in rec:
             r = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
