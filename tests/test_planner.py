@@ -1,0 +1,59 @@
+"""The launch planner of libstep_amd.so (host code, no GPU needed): step_conv_kernel_name / step_conv_workspace_bytes pin
+which kernel family a layer shape is sent to, so a planner regression shows up on the CPU box."""
+import ctypes
+import os
+
+import pytest
+
+from step_amd import _capi
+
+LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "step_amd", "libstep_amd.so")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        pytest.skip("libstep_amd.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    for k in ("STEP_CONV_IMPL", "STEP_CONV_GEN", "STEP_CONV_NB", "STEP_CONV_SPLITK"):
+        assert not os.environ.get(k), "planner test needs the default dispatch (unset %s)" % k
+    L = ctypes.CDLL(LIB)
+    L.step_conv_kernel_name.restype = ctypes.c_int
+    L.step_conv_workspace_bytes.restype = ctypes.c_size_t
+    return L
+
+
+def name(L, dt, N, Cin, Cout, k, D, H, W):
+    d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2], x_cstride=Cin, x_coff=0, y_cstride=Cout,
+                       y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+    buf = ctypes.create_string_buffer(256)
+    assert L.step_conv_kernel_name(ctypes.byref(d), buf, 256) == 0
+    return buf.value.decode(), L.step_conv_workspace_bytes(ctypes.byref(d))
+
+
+def test_planner_dispatch(lib):
+    BF, F32 = _capi.BF16, _capi.F32
+    # conv3d_2c at C2: the pipelined kernel on 4-plane 8x8 tiles (56x56 maps tile exactly), 192 channels in one workgroup
+    n, ws = name(lib, BF, 8, 64, 192, (3, 3, 3), 16, 56, 56)
+    assert "conv_tap_kernel<step::bf16_t, 3, 3, 3, 3, 3, 2, 2>" in n and ws == 0
+    # 400x400 clips: 50x50 maps get a general box (power-of-two tiles would waste 30 %)
+    n, _ = name(lib, BF, 4, 128, 192, (3, 3, 3), 18, 50, 50)
+    assert "conv_tap_kernel<step::bf16_t, 0," in n
+    # the heads' 2-D convs: N folds into D, plane-folded general boxes on 7x7 maps
+    n, _ = name(lib, BF, 132, 256, 256, (1, 3, 3), 1, 7, 7)
+    assert "conv_tap_kernel<step::bf16_t, 0, " in n and ", 1, 3, 3," in n
+    # deep pointwise layers stream through the 8-wave GEMM, shallow ones stay on the 4-wave kernel
+    assert "conv_pw_kernel" in name(lib, BF, 8, 256, 288, (1, 1, 1), 16, 28, 28)[0]
+    assert "conv_igemm_kernel" in name(lib, BF, 8, 64, 64, (1, 1, 1), 16, 56, 56)[0]
+    # few rows x very deep K (Linear 12544 -> 60 on 132 rows): split-K with a caller-owned workspace, fp32 included
+    for dt in (BF, F32):
+        n, ws = name(lib, dt, 132, 12544, 60, (1, 1, 1), 1, 1, 1)
+        assert "pw_splitk_kernel" in n and ws > 0 and ws % 4 == 0
+    # tensors of >= 2^32 elements fall back to the 64-bit-offset kernel
+    n, _ = name(lib, BF, 64, 64, 192, (3, 3, 3), 64, 512, 512)
+    assert "conv_igemm_kernel" in n
+
+
+def test_abi_and_symbols(lib):
+    assert lib.step_abi_version() == _capi.ABI_VERSION
+    for sym in _capi.SIGNATURES:
+        assert hasattr(lib, sym), sym
