@@ -82,26 +82,38 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(ConvParams p) {
     // single step and the K loop ran latency-bound)
     constexpr int DR = 4;
     u32x4 RA[DR][2], RB[DR][Q];
-    auto load_step = [&](auto rc, int s_) {
+    // FULL = whole slabs (Cin % CKT == 0) and a whole 256-pixel tile: no channel / pixel masks anywhere in the loop
+    // (workgroup-uniform; the vector ALU work per step drops by two thirds)
+    const bool full_tile = (p.Cin % CKT) == 0 && m0 + 256 <= p.Mtot;
+    auto load_step = [&](auto rc, int s_, auto fullc) {
         constexpr int RS = decltype(rc)::value;
+        constexpr bool FULL = decltype(fullc)::value;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int c = s_ * CKT + acol[q];
-            const bool cok = c < p.Cin;                                   // whole vector in or out (Cin % VEC == 0)
-            RA[RS][q] = *(const u32x4*)(athr[q] + (size_t)(cok ? c : 0) * ES);     // masked when it is written to LDS: an
-                                                                                    // AND here would wait for the load at once
+            if (FULL) {
+                RA[RS][q] = *(const u32x4*)(athr[q] + (size_t)(min(s_, S - 1) * CKT + acol[q]) * ES);   // past the end: re-read the last slab
+            } else {
+                const int c = s_ * CKT + acol[q];
+                const bool cok = c < p.Cin;                               // whole vector in or out (Cin % VEC == 0)
+                RA[RS][q] = *(const u32x4*)(athr[q] + (size_t)(cok ? c : 0) * ES); // masked when it is written to LDS: an
+            }                                                                       // AND here would wait for the load at once
         }
         const size_t off = (size_t)(min(s_, S - 1) * KS) * FRAGB;       // past the end: a harmless re-read of the last tile
 #pragma unroll
         for (int q = 0; q < Q; ++q) RB[RS][q] = *(const u32x4*)(wthr[q] + off);
     };
-    auto store_step = [&](auto rc, int buf, int slab) {
+    auto store_step = [&](auto rc, int buf, int slab, auto fullc) {
         constexpr int RS = decltype(rc)::value;
+        constexpr bool FULL = decltype(fullc)::value;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int v = tid + q * 512;
-            const unsigned int mk = (slab * CKT + acol[q] < p.Cin) ? amask[q] : 0u;
-            *(u32x4*)(ldsA + buf * ATILE + (v >> 2) * PITCH + ((v & 3) << 4)) = RA[RS][q] & mk;
+            if (FULL) {
+                *(u32x4*)(ldsA + buf * ATILE + (v >> 2) * PITCH + ((v & 3) << 4)) = RA[RS][q];
+            } else {
+                const unsigned int mk = (slab * CKT + acol[q] < p.Cin) ? amask[q] : 0u;
+                *(u32x4*)(ldsA + buf * ATILE + (v >> 2) * PITCH + ((v & 3) << 4)) = RA[RS][q] & mk;
+            }
         }
 #pragma unroll
         for (int q = 0; q < Q; ++q)
@@ -147,41 +159,44 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(ConvParams p) {
     typedef std::integral_constant<int, 1> I1;
     typedef std::integral_constant<int, 2> I2;
     typedef std::integral_constant<int, 3> I3;
-    // prologue: steps 0..3 in flight at once, 0 and 1 to LDS, 4 and 5 take their register sets
-    load_step(I0(), 0); load_step(I1(), 1); load_step(I2(), 2); load_step(I3(), 3);
-    store_step(I0(), 0, 0);
-    store_step(I1(), 1, 1);
-    load_step(I0(), 4); load_step(I1(), 5);
-    __syncthreads();
-    read_frags(I0(), 0);
-
     int b1 = 1, b2 = 2, s_ = 0;
     // step s: register set (s + 2) & 3 holds slab s + 2 -> LDS buffer (s + 2) % 3, then reloads slab s + 6.
     // No predicates inside (loads past the end are clamped and masked, the surplus fragment read hits a valid
     // buffer): any branch in the loop makes the compiler fall back to vmcnt(0) waits.
-    auto step = [&](auto setc, auto rc) {
-        constexpr int SET = decltype(setc)::value;
-        read_frags(std::integral_constant<int, SET ^ 1>(), b1);
-        mma_all(setc);
-        store_step(rc, b2, s_ + 2);
-        load_step(rc, s_ + 6);
+    auto run = [&](auto fullc) {
+        // prologue: steps 0..3 in flight at once, 0 and 1 to LDS, 4 and 5 take their register sets
+        load_step(I0(), 0, fullc); load_step(I1(), 1, fullc); load_step(I2(), 2, fullc); load_step(I3(), 3, fullc);
+        store_step(I0(), 0, 0, fullc);
+        store_step(I1(), 1, 1, fullc);
+        load_step(I0(), 4, fullc); load_step(I1(), 5, fullc);
         __syncthreads();
-        const int nb = (b2 == 2) ? 0 : b2 + 1;
-        b1 = b2; b2 = nb;
-        ++s_;
-    };
+        read_frags(I0(), 0);
+        auto step = [&](auto setc, auto rc) {
+            constexpr int SET = decltype(setc)::value;
+            read_frags(std::integral_constant<int, SET ^ 1>(), b1);
+            mma_all(setc);
+            store_step(rc, b2, s_ + 2, fullc);
+            load_step(rc, s_ + 6, fullc);
+            __syncthreads();
+            const int nb = (b2 == 2) ? 0 : b2 + 1;
+            b1 = b2; b2 = nb;
+            ++s_;
+        };
 #pragma unroll 1
-    while (s_ + 4 <= S) {
-        step(I0(), I2());
-        step(I1(), I3());
-        step(I0(), I0());
-        step(I1(), I1());
-    }
-    if (s_ < S) {                                            // 1..3 remaining steps
-        step(I0(), I2());
-        if (s_ < S) step(I1(), I3());
-        if (s_ < S) step(I0(), I0());
-    }
+        while (s_ + 4 <= S) {
+            step(I0(), I2());
+            step(I1(), I3());
+            step(I0(), I0());
+            step(I1(), I1());
+        }
+        if (s_ < S) {                                        // 1..3 remaining steps
+            step(I0(), I2());
+            if (s_ < S) step(I1(), I3());
+            if (s_ < S) step(I0(), I0());
+        }
+    };
+    if (full_tile) run(std::true_type());
+    else run(std::false_type());
 
     // ---- epilogue (two destinations supported)
     T* yg = (T*)p.y;
