@@ -230,6 +230,19 @@ STEP_API int step_transpose_cs(const void* src, int src_dtype, void* dst, int ds
 STEP_API int step_clip_from_u8(const unsigned char* frames, int N, int T, int H, int W, int scale, const float* mean3,
                                const float* std3, int dtype, void* clip, step_stream_t stream);
 
+/* Fused multi-tensor Adam over flat fp32 arenas: replaces optimizer.step() of torch.optim.Adam(params, lr=args.det_lr)
+ * (train.py:126,348) over the single-tensor parameter groups of utils/solver.py:12-93 (per-group lr / weight_decay; the
+ * schedulers of solver.py:96-180 rewrite group['lr'] between steps).  param / grad / exp_avg / exp_avg_sq: n fp32 elements
+ * each (n % 4 == 0, 16-byte aligned).  Segment s covers elements [seg_end[s-1], seg_end[s]) (seg_end ascending, every entry
+ * a multiple of 4, seg_end[n_seg-1] == n) and uses seg_lr[s], seg_wd[s]; the three tables are DEVICE arrays, n_seg <= 4096.
+ * Arithmetic = torch/optim/adam.py::_single_tensor_adam (amsgrad off): g = grad*grad_scale + wd*p; m += (g-m)(1-beta1);
+ * v = v*beta2 + (1-beta2) g*g; p -= lr/(1-beta1^step) * m / (sqrt(v)/sqrt(1-beta2^step) + eps).  step counts from 1.
+ * beta1 / beta2 / eps are doubles as in torch (1 - beta is taken in double).  grad_scale folds the 1/world_size of the gradient average (or 1/loss_scale) into the same pass; zero_grad != 0 clears the
+ * gradient arena on the way out (optimizer.zero_grad(), train.py:287). */
+STEP_API int step_adam_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                            const long long* seg_end, const float* seg_lr, const float* seg_wd, int n_seg, double beta1,
+                            double beta2, double eps, int step, float grad_scale, int zero_grad, step_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,6 +4,7 @@ ROIAlign / ROIPool / NMS.  Drop-in for the reference's `models` package and
 from .backbone import BaseNet, build_base_i3d, weights_init  # noqa: F401
 from .heads import ContextNet, ROINet, TwoBranchNet  # noqa: F401
 from . import dist  # noqa: F401
+from .optim import FlatAdam  # noqa: F401
 
 __all__ = ["BaseNet", "ROINet", "TwoBranchNet", "ContextNet"]
 __version__ = "0.1.0"

@@ -52,6 +52,27 @@ def broadcast_parameters(modules, src=0):
             dist.broadcast(t.data, src)
 
 
+def allreduce_flat(flat, weight=None, chunk_bytes=512 << 20):
+    """SUM-all-reduce the contiguous gradient arena of step_amd.optim.FlatAdam in place -- one collective (a few for
+    arenas beyond chunk_bytes), no bucket copies -- and return the factor that turns the sum into the average, to be
+    handed to FlatAdam.step(grad_scale=...) so the division rides in the optimizer pass.
+
+    weight: optional per-rank scalar as in allreduce_gradients(); the local arena is pre-multiplied by it and the
+    returned factor is 1 / sum_r(weight_r)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 1.0
+    factor = 1.0 / dist.get_world_size()
+    if weight is not None:
+        wsum = torch.tensor([float(weight)], device=flat.device, dtype=torch.float32)
+        dist.all_reduce(wsum)
+        flat.mul_(float(weight))
+        factor = 1.0 / float(wsum.item())
+    step = max(1, chunk_bytes // flat.element_size())
+    for o in range(0, flat.numel(), step):
+        dist.all_reduce(flat[o:o + step])
+    return factor
+
+
 def allreduce_gradients(params, bucket_bytes=64 << 20, average=True, weight=None):
     """Average (or sum) the .grad of `params` over all ranks with a few large flattened all-reduces.
 

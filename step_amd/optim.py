@@ -1,0 +1,181 @@
+"""step_amd/optim.py -- FlatAdam: the optimizer of the training step.
+
+The reference builds `optim.Adam(params, lr=args.det_lr)` (train.py:126) over the single-tensor parameter groups of
+utils/solver.py:12-93 (each with its own lr / weight_decay) and calls `optimizer.step()` once per iteration
+(train.py:348); its schedulers (solver.py:96-180) rewrite `group['lr']` between steps.  Same constructor, same
+`param_groups` / `zero_grad` / `step` / `state_dict` surface here, but MI355X-first underneath:
+
+* every trainable parameter is re-homed into ONE flat fp32 arena (`p.data` becomes a view of it), its gradient into
+  a second arena (`p.grad` is a view; autograd accumulates in place), the two Adam moments into two more;
+* `step()` is ONE launch of `step_adam_flat` (include/step_amd.h) over the arenas -- pure HBM streaming, 28 B/element;
+* the gradient arena is one contiguous buffer, so the data-parallel exchange is a single large RCCL all-reduce
+  (`step_amd.dist.allreduce_flat`, no bucket copies: xGMI rings are per-link bound, few large messages win), and the
+  1/world_size of the average and the gradient clear are folded into the Adam pass (`grad_scale`, `zero_grad`).
+"""
+import torch
+
+from . import _capi, _lib
+
+_ALIGN = 64          # elements (256 B): every tensor starts on its own cache line; segment ends stay multiples of 4
+
+
+class FlatAdam:
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        groups = list(params)
+        if not groups:
+            raise ValueError("FlatAdam: empty parameter list")
+        if not isinstance(groups[0], dict):
+            groups = [{"params": groups}]
+        self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
+        self.param_groups = []
+        for g in groups:
+            g = dict(g)
+            ps = g["params"]
+            g["params"] = [ps] if isinstance(ps, torch.Tensor) else list(ps)
+            for k, v in self.defaults.items():
+                g.setdefault(k, v)
+            self.param_groups.append(g)
+        b, e = self.param_groups[0]["betas"], self.param_groups[0]["eps"]
+        if any(tuple(g["betas"]) != tuple(b) or g["eps"] != e for g in self.param_groups):
+            raise ValueError("FlatAdam: betas / eps must be the same for every group (one launch)")
+        self._entries = []                                       # (group index, parameter, offset, numel)
+        seen = set()
+        off = 0
+        for gi, g in enumerate(self.param_groups):
+            for p in g["params"]:
+                if id(p) in seen:
+                    raise ValueError("FlatAdam: a parameter appears in more than one group")
+                seen.add(id(p))
+                if not p.requires_grad:
+                    continue
+                if p.dtype != torch.float32:
+                    raise RuntimeError("FlatAdam: fp32 master parameters expected, got %s" % p.dtype)
+                self._entries.append((gi, p, off, p.numel()))
+                off += -(-p.numel() // _ALIGN) * _ALIGN
+        if not self._entries:
+            raise ValueError("FlatAdam: no trainable parameter")
+        if len(self._entries) > 4096:
+            raise RuntimeError("FlatAdam: more than 4096 tensors")
+        dev = self._entries[0][1].device
+        if any(p.device != dev for _, p, _, _ in self._entries):
+            raise RuntimeError("FlatAdam: all parameters must live on one device (one process per GPU)")
+        _lib.dptr(self._entries[0][1].data)                      # refuses non-device tensors: there is no CPU fallback
+        self.device, self.numel = dev, off
+        self.flat_param = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for _, p, o, n in self._entries:
+                self.flat_param[o:o + n].copy_(p.data.reshape(-1))
+                p.data = self.flat_param[o:o + n].view(p.shape)
+                if p.grad is not None:
+                    self.flat_grad[o:o + n].copy_(p.grad.reshape(-1))
+                p.grad = self.flat_grad[o:o + n].view(p.shape)
+        ends = [o + -(-n // _ALIGN) * _ALIGN for _, _, o, n in self._entries]
+        self._seg_end = torch.tensor(ends, dtype=torch.int64, device=dev)
+        self._seg_lr = torch.zeros(len(ends), dtype=torch.float32, device=dev)
+        self._seg_wd = torch.zeros(len(ends), dtype=torch.float32, device=dev)
+        self._tables = None
+        self.step_count = 0
+
+    # -- torch.optim.Optimizer surface ---------------------------------------------------------------------------
+    def zero_grad(self, set_to_none=False):
+        """optimizer.zero_grad() (train.py:287).  Gradients stay views of the arena (set_to_none is ignored)."""
+        self.flat_grad.zero_()
+        for _, p, o, n in self._entries:
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                p.grad = self.flat_grad[o:o + n].view(p.shape)
+
+    def _gather_stray_grads(self):
+        # a caller that replaced p.grad (set_to_none, grad = tensor): fold it back into the arena
+        base = self.flat_grad.data_ptr()
+        for _, p, o, n in self._entries:
+            g = p.grad
+            if g is None:
+                self.flat_grad[o:o + n].zero_()
+                p.grad = self.flat_grad[o:o + n].view(p.shape)
+            elif g.data_ptr() != base + 4 * o:
+                self.flat_grad[o:o + n].copy_(g.reshape(-1))
+                p.grad = self.flat_grad[o:o + n].view(p.shape)
+
+    def _refresh_tables(self):
+        lr = [float(self.param_groups[gi]["lr"]) for gi, _, _, _ in self._entries]
+        wd = [float(self.param_groups[gi]["weight_decay"]) for gi, _, _, _ in self._entries]
+        if self._tables != (lr, wd):                             # the schedulers rewrite group['lr'] every iteration
+            self._seg_lr.copy_(torch.tensor(lr, dtype=torch.float32))
+            self._seg_wd.copy_(torch.tensor(wd, dtype=torch.float32))
+            self._tables = (lr, wd)
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0, zero_grad=False):
+        """optimizer.step() (train.py:348): one kernel launch.  grad_scale multiplies every gradient on the way in
+        (1/world_size after a SUM all-reduce, 1/loss_scale); zero_grad=True clears the gradient arena in the same pass."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._gather_stray_grads()
+        self._refresh_tables()
+        self.step_count += 1
+        g0 = self.param_groups[0]
+        L = _lib.lib()
+        _capi.check(L.step_adam_flat(_lib.dptr(self.flat_param), _lib.dptr(self.flat_grad), _lib.dptr(self.exp_avg),
+                                     _lib.dptr(self.exp_avg_sq), self.numel, _lib.dptr(self._seg_end), _lib.dptr(self._seg_lr),
+                                     _lib.dptr(self._seg_wd), len(self._entries), float(g0["betas"][0]), float(g0["betas"][1]),
+                                     float(g0["eps"]), self.step_count, float(grad_scale), int(bool(zero_grad)),
+                                     _lib.stream_ptr(self.device)), "step_adam_flat")
+        # the kernel wrote through raw pointers: bump the autograd version counters (the packed-weight caches of
+        # backbone.py / heads.py are keyed on them)
+        torch.autograd.graph.increment_version([p for _, p, _, _ in self._entries])
+        return loss
+
+    def state_dict(self):
+        """Same structure as torch.optim.Adam.state_dict() (checkpoints: train.py:382,437)."""
+        state, idx = {}, {}
+        k = 0
+        packed_groups = []
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                idx[id(p)] = k
+                ids.append(k)
+                k += 1
+            pg = {kk: vv for kk, vv in g.items() if kk != "params"}
+            pg["params"] = ids
+            packed_groups.append(pg)
+        if self.step_count:
+            for _, p, o, n in self._entries:
+                state[idx[id(p)]] = {"step": torch.tensor(float(self.step_count)),
+                                     "exp_avg": self.exp_avg[o:o + n].view(p.shape).clone(),
+                                     "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape).clone()}
+        return {"state": state, "param_groups": packed_groups}
+
+    def load_state_dict(self, sd):
+        """optimizer.load_state_dict(checkpoint['optimizer']) (train.py:205); accepts torch.optim.Adam's own dicts."""
+        groups = sd["param_groups"]
+        if len(groups) != len(self.param_groups) or any(len(a["params"]) != len(b["params"]) for a, b in zip(groups, self.param_groups)):
+            raise ValueError("FlatAdam.load_state_dict: parameter groups do not match")
+        idx = {}
+        for a, b in zip(groups, self.param_groups):
+            for k, p in zip(a["params"], b["params"]):
+                idx[id(p)] = k
+            for kk, vv in a.items():
+                if kk != "params":
+                    b[kk] = vv
+        steps = set()
+        with torch.no_grad():
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            for _, p, o, n in self._entries:
+                st = sd["state"].get(idx[id(p)])
+                if st is None:
+                    steps.add(0)
+                    continue
+                steps.add(int(float(st["step"])))
+                self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+        if len(steps) != 1:
+            raise ValueError("FlatAdam.load_state_dict: parameters are at different step counts %s" % sorted(steps))
+        self.step_count = steps.pop()
+        self._tables = None

@@ -9,6 +9,7 @@ import torch
 from . import BaseNet, ContextNet, ROINet, TwoBranchNet
 from . import dist as sdist
 from .driver import GraphedInference, inference, postprocess
+from .optim import FlatAdam
 from .tube_math import generate_anchors
 
 
@@ -68,7 +69,8 @@ class C3Inference:
 class C4TrainStep:
     """One optimisation step on `batch` AVA-shaped clips per rank (fp32): backbone + ContextNet + the max_iter = 3 heads on
     tubes of 3, 3 and 9 frames (NUM_CHUNKS 1, 1, 3), the three losses of train.py:318-331 summed over the steps
-    (lambda_reg 5, lambda_nbr 1), gradient all-reduce over ranks (step_amd.dist), Adam.  The reference's proposal
+    (lambda_reg 5, lambda_nbr 1), ONE flat gradient all-reduce over ranks (step_amd.dist.allreduce_flat), ONE fused Adam
+    launch that also applies 1/world and clears the gradients (step_amd.optim.FlatAdam).  The reference's proposal
     selection between steps (utils/utils.py:135-423, host Python) is not part of the hot path: every step trains on the
     same `tubes_per_clip` anchor tubes, extended to the step's length."""
 
@@ -79,7 +81,7 @@ class C4TrainStep:
         for m in self.mods:
             m.train()
         self.params = [p for m in self.mods for p in m.parameters() if p.requires_grad]
-        self.opt = torch.optim.Adam(self.params, lr=1e-5)
+        self.opt = FlatAdam(self.params, lr=1e-5)
         g = torch.Generator().manual_seed(seed)
         # fp32 master weights either way; a 16-bit clip makes every activation / data gradient 16-bit (fp32 accumulate),
         # weight gradients stay fp32
@@ -106,7 +108,6 @@ class C4TrainStep:
         self.loss = None
 
     def step(self):
-        self.opt.zero_grad()
         cf = self.base(self.x)                                    # [B,9,832,25,25]
         cx = self.ctx(cf)                                         # [B,1024,9,1,1]
         loss = 0.0
@@ -116,7 +117,7 @@ class C4TrainStep:
             o = head(pooled, context_feat=cx[self.clip_of][:, :, t0:t0 + Tl], tubes=flat, targets=self.targets)
             loss = loss + o[4].mean() + 5 * o[5].mean() + o[6].mean()
         loss.backward()
-        sdist.allreduce_gradients(self.params)
-        self.opt.step()
+        scale = sdist.allreduce_flat(self.opt.flat_grad)
+        self.opt.step(grad_scale=scale, zero_grad=True)          # gradients are clean for the next backward
         self.loss = loss.detach()
         return self.loss

@@ -394,6 +394,53 @@ def case_clip_from_u8(bk, golden):
     assert bk.lib.step_clip_from_u8(None, N, T, H, W, 3, None, None, F32, out.ptr, bk.stream) < 0
 
 
+def case_adam_flat(bk, golden):
+    """One launch over a flat arena against torch.optim.Adam (what train.py:126 constructs) stepping the same tensors as
+    single-tensor groups with their own lr / weight_decay (utils/solver.py:12-93); three steps, gradient scale, fused
+    gradient clear.  Tolerance 2e-6 relative to max|p| per step (fp32 rounding order: lerp / addcdiv are fused there)."""
+    rs = np.random.RandomState(11)
+    sizes = [12, 64, 4, 100, 28, 1000]                      # multiples of 4 (the arena pads every tensor to that)
+    lrs = [1e-3, 2e-3, 5e-4, 1e-3, 1e-2, 3e-4]
+    wds = [0.0, 1e-2, 0.0, 1e-4, 0.0, 1e-7]
+    n = sum(sizes)
+    p0 = rs.randn(n).astype(np.float32)
+    tp = []
+    off = 0
+    for sz_ in sizes:
+        tp.append(torch.nn.Parameter(torch.from_numpy(p0[off:off + sz_].copy())))
+        off += sz_
+    opt = torch.optim.Adam([{"params": [t], "lr": lr, "weight_decay": wd} for t, lr, wd in zip(tp, lrs, wds)], lr=1e-3)
+    P, M, V = bk.dev(p0), bk.dev(np.zeros(n, np.float32)), bk.dev(np.zeros(n, np.float32))
+    ends = bk.dev(np.cumsum(sizes).astype(np.int64))
+    LR, WD = bk.dev(np.array(lrs, np.float32)), bk.dev(np.array(wds, np.float32))
+    scale = 0.25
+    for step_no in (1, 2, 3):
+        g = (rs.randn(n) * (10.0 ** rs.uniform(-4, 1, n))).astype(np.float32)
+        off = 0
+        for t, sz_ in zip(tp, sizes):
+            t.grad = torch.from_numpy(g[off:off + sz_] * np.float32(scale))
+            off += sz_
+        opt.step()
+        G = bk.dev(g)
+        zero = int(step_no != 2)
+        assert bk.lib.step_adam_flat(P.ptr, G.ptr, M.ptr, V.ptr, n, ends.ptr, LR.ptr, WD.ptr, len(sizes), 0.9, 0.999, 1e-8,
+                                     step_no, scale, zero, bk.stream) == 0
+        ref = np.concatenate([t.detach().numpy() for t in tp])
+        refm = np.concatenate([opt.state[t]["exp_avg"].numpy() for t in tp])
+        refv = np.concatenate([opt.state[t]["exp_avg_sq"].numpy() for t in tp])
+        assert np.abs(P.get() - ref).max() <= 2e-6 * np.abs(ref).max(), step_no
+        ga = np.abs(g * np.float32(scale)) + 1e-2                 # moments: a few ulp of the operands (m may cancel against g)
+        assert np.all(np.abs(M.get() - refm) <= 1e-5 * np.abs(refm) + 1e-6 * ga), step_no
+        assert np.all(np.abs(V.get() - refv) <= 1e-5 * np.abs(refv) + 1e-6 * ga * ga), step_no
+        assert np.array_equal(G.get(), np.zeros(n, np.float32) if zero else g)
+    assert bk.lib.step_adam_flat(P.ptr, G.ptr, M.ptr, V.ptr, n + 2, ends.ptr, LR.ptr, WD.ptr, len(sizes), 0.9, 0.999, 1e-8, 1, 1.0,
+                                 0, bk.stream) < 0                                        # n % 4
+    assert bk.lib.step_adam_flat(P.ptr, G.ptr, M.ptr, V.ptr, n, ends.ptr, LR.ptr, WD.ptr, len(sizes), 0.9, 0.999, 1e-8, 0, 1.0,
+                                 0, bk.stream) < 0                                        # steps count from 1
+    assert bk.lib.step_adam_flat(P.ptr, G.ptr, M.ptr, V.ptr, 0, ends.ptr, LR.ptr, WD.ptr, len(sizes), 0.9, 0.999, 1e-8, 1, 1.0,
+                                 0, bk.stream) == 0                                       # empty arena: no launch
+
+
 def case_avgpool_hw(bk, golden):
     rs = np.random.RandomState(6)
     x = rs.randn(2, 8, 3, 13, 13).astype(np.float32)

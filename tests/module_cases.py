@@ -266,6 +266,61 @@ def case_training_step_matches_torch_autograd(dev, golden):
     assert checked == len(info["TwoBranchNet_trainable"])
 
 
+def case_flat_adam_matches_torch(dev, golden):
+    """step_amd.optim.FlatAdam against torch.optim.Adam (train.py:126) on the parameter groups utils/solver.py builds
+    (bias: 2x lr, no decay): three steps with an lr change in between (the schedulers rewrite group['lr']), a stray
+    .grad replacement, the fused gradient clear, the autograd version bump and a state_dict round trip INTO torch's Adam."""
+    torch.manual_seed(5)
+    shapes = [(7, 3, 1, 3, 3), (7,), (5, 7), (5,), (130,)]
+    ref = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ref]
+
+    def groups(ps):
+        return [{"params": [p], "lr": 2e-3 if p.dim() == 1 else 1e-3, "weight_decay": 0 if p.dim() == 1 else 1e-4} for p in ps]
+
+    o_ref = torch.optim.Adam(groups(ref), lr=1e-3)
+    o = step_amd.FlatAdam(groups(mine), lr=1e-3)
+    assert len(o.param_groups) == len(o_ref.param_groups) and o.param_groups[1]["lr"] == 2e-3
+    for p, q in zip(ref, mine):
+        assert torch.equal(p.detach(), q.detach().cpu())         # re-homing into the arena keeps the values
+    for it in range(3):
+        if it == 1:
+            for a, b in zip(o_ref.param_groups, o.param_groups):
+                a["lr"] *= 0.5
+                b["lr"] *= 0.5
+        o_ref.zero_grad()
+        if it != 2:
+            o.zero_grad()                                        # it == 2 relies on the clear fused into step 1
+        vers = [q._version for q in mine]
+        for i, (p, q) in enumerate(zip(ref, mine)):
+            w = torch.randn(p.shape)
+            (p * w).sum().mul(3.0).backward()
+            if it == 0 and i == 2:
+                q.grad = (w * 1.5).to(dev)                       # a caller that replaced .grad (not doubled below, hence 1.5):
+                stray = q                                        # step() folds it back into the arena
+            else:
+                (q * w.to(dev)).sum().mul(3.0).backward()
+        o_ref.step()
+        o.flat_grad.mul_(0.5)                                    # grad_scale 2 on halved gradients == the same update
+        o.step(grad_scale=2.0, zero_grad=(it == 1))
+        assert stray.grad.data_ptr() == o.flat_grad.data_ptr() + 4 * 256     # 189 -> 192, 7 -> 64 elements before it
+        for p, q, v in zip(ref, mine, vers):
+            assert q._version > v
+            assert rel(np_(q), p.detach().numpy()) < 2e-6, (it, tuple(p.shape))
+        if it == 1:
+            assert float(o.flat_grad.abs().max()) == 0.0
+    sd = o.state_dict()
+    o2 = torch.optim.Adam(groups([torch.nn.Parameter(q.detach().cpu().clone()) for q in mine]), lr=1e-3)
+    o2.load_state_dict({"state": {k: {kk: vv.cpu() for kk, vv in st.items()} for k, st in sd["state"].items()},
+                        "param_groups": sd["param_groups"]})
+    for k, p in enumerate(ref):
+        assert rel(o2.state[o2.param_groups[k]["params"][0]]["exp_avg_sq"].numpy(), o_ref.state[p]["exp_avg_sq"].numpy()) < 1e-5
+        assert float(o2.state[o2.param_groups[k]["params"][0]]["step"]) == 3.0
+    o3 = step_amd.FlatAdam(groups([torch.nn.Parameter(q.detach().clone()) for q in mine]), lr=1e-3)
+    o3.load_state_dict(o_ref.state_dict())
+    assert o3.step_count == 3 and rel(np_(o3.exp_avg), np_(o.exp_avg)) < 1e-5
+
+
 def case_training_step_16bit_storage(dev, golden):
     """The same training step with bf16 activations (fp32 master weights, fp32 weight gradients): every gradient is
     finite and follows the fp32 run (16-bit activations and data gradients: a few per cent in relative L2).  Exercises
@@ -317,5 +372,6 @@ def case_c2_full_size_properties(dev, golden):
 
 
 CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_golden", "case_context_golden",
-             "case_twobranch_T3_and_losses_golden", "case_roinet_layouts", "case_training_step_matches_torch_autograd"]
+             "case_twobranch_T3_and_losses_golden", "case_roinet_layouts", "case_training_step_matches_torch_autograd",
+             "case_flat_adam_matches_torch"]
 GPU_CASES = CPU_CASES + ["case_training_step_16bit_storage", "case_c2_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_inference_golden", "case_inference_golden_34", "case_e2e_c3_golden"]

@@ -4,6 +4,7 @@ weighted form reproduces a global masked mean, and the bench timing reduction (m
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -50,11 +51,22 @@ def _worker(rank, world, port, q):
     (((model(clips[idx]) - target[idx]) ** 2).mean(1) * m).sum().div(m.sum()).backward()
     D.allreduce_gradients(list(model.parameters()), weight=float(m.sum()))
     g_masked = [p.grad.clone() for p in model.parameters()]
+    # (c) the flat-arena exchange of step_amd.optim.FlatAdam: ONE all-reduce (SUM) + the factor for the optimizer pass
+    model.zero_grad()
+    ((model(clips[idx]) - target[idx]) ** 2).mean().backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    f_plain = D.allreduce_flat(flat)
+    flat_plain = flat * f_plain
+    model.zero_grad()
+    (((model(clips[idx]) - target[idx]) ** 2).mean(1) * m).sum().div(m.sum()).backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    f_w = D.allreduce_flat(flat, weight=float(m.sum()), chunk_bytes=64)     # tiny chunks: several collectives
+    flat_w = flat * f_w
     el = D.timed_steps(lambda: None if rank == 0 else __import__("time").sleep(0.05), 2, sync=lambda: None)
     if rank == 0:
         # numpy arrays travel by value; torch tensors would be shared through file descriptors that may be gone
         # by the time the parent unpickles them
-        q.put((nb, [g.numpy() for g in g_plain], [g.numpy() for g in g_masked], el))
+        q.put((nb, [g.numpy() for g in g_plain], [g.numpy() for g in g_masked], el, flat_plain.numpy(), flat_w.numpy(), f_plain))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -67,7 +79,7 @@ def test_two_rank_gradient_allreduce_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    nb, g_plain, g_masked, el = q.get()
+    nb, g_plain, g_masked, el, flat_plain, flat_w, f_plain = q.get()
     g_plain = [torch.from_numpy(g) for g in g_plain]
     g_masked = [torch.from_numpy(g) for g in g_masked]
     for p in procs:
@@ -86,5 +98,8 @@ def test_two_rank_gradient_allreduce_matches_single_process():
     (((model(clips) - target) ** 2).mean(1) * mask).sum().div(mask.sum()).backward()
     for a, p in zip(g_masked, model.parameters()):
         assert torch.allclose(a, p.grad, rtol=1e-5, atol=1e-6)
+    assert f_plain == 0.5
+    assert np.allclose(flat_plain, torch.cat([g.reshape(-1) for g in g_plain]).numpy(), rtol=1e-5, atol=1e-6)
+    assert np.allclose(flat_w, torch.cat([g.reshape(-1) for g in g_masked]).numpy(), rtol=1e-5, atol=1e-6)
     assert nb >= 2                                   # bucketing really split the gradient
     assert el >= 0.1                                 # max over ranks: rank 1 slept 2 x 50 ms
