@@ -19,33 +19,21 @@ from . import _capi, _lib
 _ALIGN = 64          # elements (256 B): every tensor starts on its own cache line; segment ends stay multiples of 4
 
 
-class FlatAdam:
+class FlatAdam(torch.optim.Optimizer):
+    """A torch.optim.Optimizer (the reference's schedulers subclass torch's _LRScheduler, which insists on one:
+    utils/solver.py:96,141) whose whole state lives in four flat arenas."""
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        groups = list(params)
-        if not groups:
-            raise ValueError("FlatAdam: empty parameter list")
-        if not isinstance(groups[0], dict):
-            groups = [{"params": groups}]
-        self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
-        self.param_groups = []
-        for g in groups:
-            g = dict(g)
-            ps = g["params"]
-            g["params"] = [ps] if isinstance(ps, torch.Tensor) else list(ps)
-            for k, v in self.defaults.items():
-                g.setdefault(k, v)
-            self.param_groups.append(g)
+        # the base class normalises `params` into self.param_groups (fills lr / betas / eps / weight_decay defaults,
+        # rejects duplicates) exactly as it does for torch.optim.Adam
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         b, e = self.param_groups[0]["betas"], self.param_groups[0]["eps"]
         if any(tuple(g["betas"]) != tuple(b) or g["eps"] != e for g in self.param_groups):
             raise ValueError("FlatAdam: betas / eps must be the same for every group (one launch)")
         self._entries = []                                       # (group index, parameter, offset, numel)
-        seen = set()
         off = 0
         for gi, g in enumerate(self.param_groups):
             for p in g["params"]:
-                if id(p) in seen:
-                    raise ValueError("FlatAdam: a parameter appears in more than one group")
-                seen.add(id(p))
                 if not p.requires_grad:
                     continue
                 if p.dtype != torch.float32:

@@ -281,13 +281,13 @@ def case_flat_adam_matches_torch(dev, golden):
     o_ref = torch.optim.Adam(groups(ref), lr=1e-3)
     o = step_amd.FlatAdam(groups(mine), lr=1e-3)
     assert len(o.param_groups) == len(o_ref.param_groups) and o.param_groups[1]["lr"] == 2e-3
+    # the reference's schedulers are torch _LRScheduler subclasses (utils/solver.py:96,141): they must accept it
+    sch = [torch.optim.lr_scheduler.LambdaLR(x, lambda k: 0.5 if k == 1 else 1.0) for x in (o_ref, o)]
     for p, q in zip(ref, mine):
         assert torch.equal(p.detach(), q.detach().cpu())         # re-homing into the arena keeps the values
     for it in range(3):
-        if it == 1:
-            for a, b in zip(o_ref.param_groups, o.param_groups):
-                a["lr"] *= 0.5
-                b["lr"] *= 0.5
+        assert [g_["lr"] for g_ in o.param_groups] == [g_["lr"] for g_ in o_ref.param_groups]
+        assert o.param_groups[0]["lr"] == (5e-4 if it == 1 else 1e-3)
         o_ref.zero_grad()
         if it != 2:
             o.zero_grad()                                        # it == 2 relies on the clear fused into step 1
@@ -303,6 +303,8 @@ def case_flat_adam_matches_torch(dev, golden):
         o_ref.step()
         o.flat_grad.mul_(0.5)                                    # grad_scale 2 on halved gradients == the same update
         o.step(grad_scale=2.0, zero_grad=(it == 1))
+        for x in sch:
+            x.step()
         assert stray.grad.data_ptr() == o.flat_grad.data_ptr() + 4 * 256     # 189 -> 192, 7 -> 64 elements before it
         for p, q, v in zip(ref, mine, vers):
             assert q._version > v
