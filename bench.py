@@ -280,6 +280,13 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
         what = "C3: full two_branch inference (I3D backbone + ContextNet + 3 refinement steps with ROIAlign over 11 tubes/clip + " \
                "batched per-class NMS), %d x [36,3,400,400] clips per GPU" % CLIPS_PER_GPU
         metric = "clips_per_sec_inference_T36_400"
+    elif os.environ.get("STEP_BENCH_SELECT", "0") == "1":
+        # the reference's whole iteration: eval inference over the first two steps + train_select between the steps
+        w = workloads.C4SelectTrainStep(dev, batch=CLIPS_PER_GPU, seed=123 + rank, dtype=tdt)
+        what = "C4 (with proposal selection, train.py:257-348): backbone + ContextNet, no-grad inference() over 2 steps on 34 tubes/clip, " \
+               "train_select (<= 5 positives + 2x negatives per clip and step) + ROIAlign + head + losses for the 3 steps, backward, " \
+               "flat gradient all-reduce, fused Adam, %d x [36,3,400,400] clip(s) per GPU" % CLIPS_PER_GPU
+        metric = "clips_per_sec_train_T36_400"
     else:
         w = workloads.C4TrainStep(dev, batch=CLIPS_PER_GPU, seed=123 + rank, dtype=tdt)
         what = "C4: one training step (backbone + ContextNet + max_iter=3 heads on 3/3/9-frame tubes, BCE + smooth-L1 losses, gradient all-reduce, Adam), " \

@@ -42,7 +42,7 @@ def import_reference():
     # recorded predictions -- an artefact of running the reference on CPU; on its real (GPU) path
     # `.cpu()` copies.  Give valid_tubes a copy so that the fixtures record what the GPU path records.
     _vt = ref_utils.valid_tubes
-    ref_utils.valid_tubes = lambda tubes, **kw: _vt(tubes.copy(), **kw)
+    ref_utils.valid_tubes = lambda tubes, *a, **kw: _vt(tubes.copy(), *a, **kw)
     from external.maskrcnn_benchmark.roi_layers import nms, ROIAlign  # reference python API
     return models, ref_utils, nms, ROIAlign
 
@@ -298,5 +298,91 @@ def main():
     print("done ->", OUT)
 
 
+def selection_cases():
+    """Seeded synthetic inputs of the training sample selection (utils/utils.py:135-423): per case the ground truths of
+    two clips [G, max_chunks, 4 + classes], the initial proposals, and a fake `history` of the previous step."""
+    import random as pyrandom
+
+    nc = 60
+    anchors = None
+    from oracle import i3d_ref as R
+    anchors = (R.anchors() * 400.0).astype(np.float32)
+    cases = []
+    for ci, (seed, sampling, topk, neg_ratio, max_pos, mode) in enumerate((
+            (1, "softmax", -1, 2, 5, "predict"), (2, "random", 300, 2, 5, "predict"), (3, "uniform", 120, 1, 2, "predict"),
+            (4, "softmax", -1, 2, 5, "mean"), (5, "softmax", 60, 3, 1, "predict"))):
+        rs = np.random.RandomState(1000 + seed)
+        targets = []
+        for b in range(2):
+            G = int(rs.randint(1, 5)) if ci != 4 else 7
+            t = np.zeros((G, 3, 4 + nc), np.float32)
+            for gidx in range(G):
+                a = anchors[rs.randint(0, 34)] + rs.uniform(-25, 25, 4).astype(np.float32)
+                for c in range(3):
+                    if c == 1 or rs.rand() < 0.7:                       # neighbour chunks may be padding (all zero)
+                        t[gidx, c, :4] = a + rs.uniform(-6, 6, 4).astype(np.float32) * (c != 1)
+                        t[gidx, c, 4 + rs.randint(0, nc, 3)] = 1
+            targets.append(t)
+        tubes = [np.tile(anchors[:, None, :], (1, 3, 1)).astype(np.float32) for _ in range(2)]
+        nums = [34, 20]
+        n = sum(nums)
+        hist = {}
+        prob = rs.rand(n, 1, nc).astype(np.float32) ** 4
+        prob[3] = prob[4]                                               # exact score ties between tubes
+        hist["pred_prob"] = np.tile(prob, (1, 3, 1))
+        base = np.concatenate([anchors[:34], anchors[:20]], 0)[:, None, :] + rs.uniform(-30, 30, (n, 3, 4)).astype(np.float32)
+        hist["pred_loc"] = base.astype(np.float32)
+        hist["pred_first_loc"] = (base + rs.uniform(-10, 10, (n, 3, 4))).astype(np.float32)
+        hist["pred_last_loc"] = (base + rs.uniform(-10, 10, (n, 3, 4))).astype(np.float32)
+        hist["pred_loc"][5] = -50.0                                     # clamps to an invalid box -> whole image
+        hist["tubes_nums"] = nums
+        a = cfg(cls_thresh=[0.2, 0.35, 0.5], reg_thresh=[0.2, 0.35, 0.5], max_pos_num=max_pos, neg_ratio=neg_ratio,
+                selection_sampling=sampling, topk=topk, temporal_mode=mode)
+        cases.append((seed, a, targets, tubes, hist))
+    return cases, pyrandom
+
+
+def selection_main():
+    """tests/golden/selection_golden.npz: what the reference's train_select / select_proposals / compute_tube_iou return for
+    the seeded cases above, with `random.seed(s); np.random.seed(s)` set right before every call."""
+    _, ref_utils, _, _ = import_reference()
+    import utils.tube_utils as ref_tu  # reference
+
+    cases, pyrandom = selection_cases()
+    g = {}
+    for ci, (seed, a, targets, tubes, hist) in enumerate(cases):
+        th = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in hist.items()}
+        for k in ("neg_ratio", "max_pos_num", "topk"):
+            g["c%d_%s" % (ci, k)] = np.asarray(getattr(a, k))
+        g["c%d_sampling" % ci] = np.asarray(a.selection_sampling)
+        g["c%d_mode" % ci] = np.asarray(a.temporal_mode)
+        g["c%d_seed" % ci] = np.asarray(seed)
+        for b, t in enumerate(targets):
+            g["c%d_targets%d" % (ci, b)] = t
+        for k in ("pred_prob", "pred_loc", "pred_first_loc", "pred_last_loc"):
+            g["c%d_hist_%s" % (ci, k)] = hist[k][:, :1] if k == "pred_prob" else hist[k]
+        for step in (1, 2, 3):
+            pyrandom.seed(seed * 10 + step)
+            np.random.seed(seed * 10 + step)
+            sel, tgt = ref_utils.train_select(step, th if step > 1 else None, [t.copy() for t in targets],
+                                              [t.copy() for t in tubes], a)
+            for b in range(2):
+                g["c%d_s%d_sel%d" % (ci, step, b)] = sel[b]
+                g["c%d_s%d_tgt%d" % (ci, step, b)] = tgt[b]
+        g["c%d_iou" % ci] = ref_tu.compute_tube_iou(targets[0][:, :, :4], hist["pred_loc"][:9])
+    # IoU edge cases: padding tubes, touching and nested boxes
+    t1 = np.array([[[0, 0, 10, 10], [0, 0, 0, 0]], [[0, 0, 0, 0], [0, 0, 0, 0]], [[5, 5, 20, 30], [1, 2, 3, 4]]], np.float32)
+    t2 = np.array([[[10, 0, 20, 10], [0, 0, 5, 5]], [[2, 2, 8, 8], [1, 2, 3, 4]], [[0, 0, 0, 0], [0, 0, 0, 0]]], np.float32)
+    g["edge_t1"], g["edge_t2"] = t1, t2
+    with np.errstate(all="ignore"):
+        g["edge_iou"] = ref_tu.compute_tube_iou(t1, t2)
+    np.savez_compressed(os.path.join(OUT, "selection_golden.npz"), **g)
+    print("selection_golden ok", len(g), "arrays")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "selection":
+        selection_main()
+    else:
+        main()
+        selection_main()

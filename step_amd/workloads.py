@@ -10,6 +10,8 @@ from . import BaseNet, ContextNet, ROINet, TwoBranchNet
 from . import dist as sdist
 from .driver import GraphedInference, inference, postprocess
 from .optim import FlatAdam
+from .selection import train_select
+from .driver import _flat_tubes
 from .tube_math import generate_anchors
 
 
@@ -17,7 +19,10 @@ def step_cfg(**kw):
     """The attributes of the reference's argparse namespace the modules read (config.py; scripts/train_step.sh)."""
     base = dict(base_net="i3d", kinetics_pretrain=None, freeze_stats=True, freeze_affine=True, fp16=False, T=3, num_classes=60,
                 fc_dim=256, dropout=0.0, pool_size=7, no_context=False, max_iter=3, NUM_CHUNKS={1: 1, 2: 1, 3: 3, 4: 3},
-                temporal_mode="predict", image_size=(400, 400), pool_mode="align")
+                temporal_mode="predict", image_size=(400, 400), pool_mode="align",
+                # training sample selection (config.py:64-76 with the values of scripts/train_step.sh:43-48)
+                topk=-1, cls_thresh=[0.2, 0.35, 0.5], reg_thresh=[0.2, 0.35, 0.5], max_pos_num=5, neg_ratio=2,
+                selection_sampling="softmax", lambda_reg=5.0, lambda_neighbor=1.0)
     base.update(kw)
     return NS(**base)
 
@@ -119,5 +124,60 @@ class C4TrainStep:
         loss.backward()
         scale = sdist.allreduce_flat(self.opt.flat_grad)
         self.opt.step(grad_scale=scale, zero_grad=True)          # gradients are clean for the next backward
+        self.loss = loss.detach()
+        return self.loss
+
+
+class C4SelectTrainStep(C4TrainStep):
+    """The reference's whole training iteration (train.py:257-348), proposal selection included: backbone + ContextNet with
+    gradients; an eval-mode, no-grad inference() over the first max_iter-1 steps to get the refined tubes; then for every
+    step train_select() (step_amd.selection: the reference's sampling, same RNG streams) picks positives / negatives among
+    them, ROIAlign pools the selected tubes, the step's head returns the three losses; one backward, one flat gradient
+    all-reduce, one fused Adam launch.  `targets`: 2 ground-truth tubes per clip with 3 positive classes each."""
+
+    def __init__(self, dev, batch=1, seed=123, dtype=torch.float32, tubes_per_clip=34):
+        super().__init__(dev, batch=batch, tubes_per_clip=5, seed=seed, max_iter=3, dtype=dtype)
+        rs = np.random.RandomState(seed)
+        anchors = (generate_anchors()[:tubes_per_clip] * 400.0).astype(np.float32)
+        self.init_tubes = [np.tile(anchors[:, None, :], (1, 3, 1)) for _ in range(batch)]
+        self.gt = []
+        for _ in range(batch):
+            t = np.zeros((2, 3, 4 + 60), np.float32)
+            for g_ in range(2):
+                box = anchors[rs.randint(0, len(anchors))] + rs.uniform(-20, 20, 4).astype(np.float32)
+                for c in range(3):
+                    t[g_, c, :4] = box + rs.uniform(-5, 5, 4).astype(np.float32)
+                t[g_, :, 4 + rs.randint(0, 60, 3)] = 1
+            self.gt.append(t)
+        self.selected = []
+
+    def step(self):
+        a = self.args
+        cf = self.base(self.x)
+        cx = self.ctx(cf)
+        for m in self.mods:
+            m.eval()
+        with torch.no_grad():
+            history, _ = inference(a, cf.detach(), cx.detach(), self.nets, a.max_iter - 1, self.init_tubes)
+        for m in self.mods:
+            m.train()
+        loss = 0.0
+        self.selected = []
+        for i in range(1, a.max_iter + 1):
+            chunks, max_chunks = a.NUM_CHUNKS[i], a.NUM_CHUNKS[a.max_iter]
+            t0 = int((max_chunks - chunks) / 2) * a.T
+            Tl = chunks * a.T
+            sel, tgt = train_select(i, history[i - 2] if i > 1 else None, self.gt, self.init_tubes, a)
+            self.selected.append([len(s_) for s_ in sel])
+            flat, nums = _flat_tubes(sel, cf.device)
+            targets = torch.from_numpy(np.concatenate(tgt, axis=0)).to(cf.device)
+            clip_of = torch.as_tensor(np.repeat(np.arange(len(nums)), nums), device=cf.device)
+            pooled = self.nets["roi_net"](cf[:, t0:t0 + Tl], flat)
+            pooled = pooled.reshape(flat.shape[0], Tl, *pooled.shape[1:])
+            o = self.heads[i - 1](pooled, context_feat=cx[clip_of][:, :, t0:t0 + Tl], tubes=flat, targets=targets)
+            loss = loss + o[4].mean() + a.lambda_reg * o[5].mean() + a.lambda_neighbor * o[6].mean()
+        loss.backward()
+        scale = sdist.allreduce_flat(self.opt.flat_grad)
+        self.opt.step(grad_scale=scale, zero_grad=True)
         self.loss = loss.detach()
         return self.loss

@@ -323,6 +323,39 @@ def case_flat_adam_matches_torch(dev, golden):
     assert o3.step_count == 3 and rel(np_(o3.exp_avg), np_(o.exp_avg)) < 1e-5
 
 
+def case_training_iteration_with_selection(dev, golden):
+    """The whole iteration of train.py:257-348 on one AVA-shaped clip (step_amd.workloads.C4SelectTrainStep): no-grad
+    inference, train_select between the steps, three heads, backward, fused Adam.  Checks what is size-independent: per step
+    at most max_pos_num positives + neg_ratio x negatives per clip, a finite loss, every trainable tensor updated through the
+    flat arena (autograd version bumped, packed-weight caches refreshed: the second step's loss differs), and determinism --
+    the same seeds give the same selection and bit-identical losses."""
+    import random
+    from step_amd import workloads
+
+    def run():
+        random.seed(7)
+        np.random.seed(7)
+        w = workloads.C4SelectTrainStep(dev, batch=1, seed=11)
+        for g_ in w.opt.param_groups:
+            g_["lr"] = 1e-4
+        p0 = w.opt.flat_param.clone()
+        vers = [p._version for p in w.params]
+        l1 = float(w.step())
+        sel1 = [list(x) for x in w.selected]
+        l2 = float(w.step())
+        assert all(p._version > v for p, v in zip(w.params, vers))
+        moved = float((w.opt.flat_param - p0).abs().max())
+        return l1, l2, sel1, moved, w
+
+    l1, l2, sel, moved, w = run()
+    assert np.isfinite(l1) and np.isfinite(l2) and l1 != l2
+    assert len(sel) == 3 and all(1 <= n <= 5 + 2 * 5 for s_ in sel for n in s_), sel
+    assert 0 < moved < 1e-2                                      # Adam: at most ~lr per step
+    assert float(w.opt.flat_grad.abs().max()) == 0.0             # cleared inside the optimizer pass
+    m1, m2, sel2, _, _ = run()
+    assert sel2 == sel and m1 == l1
+
+
 def case_training_step_16bit_storage(dev, golden):
     """The same training step with bf16 activations (fp32 master weights, fp32 weight gradients): every gradient is
     finite and follows the fp32 run (16-bit activations and data gradients: a few per cent in relative L2).  Exercises
@@ -376,4 +409,4 @@ def case_c2_full_size_properties(dev, golden):
 CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_golden", "case_context_golden",
              "case_twobranch_T3_and_losses_golden", "case_roinet_layouts", "case_training_step_matches_torch_autograd",
              "case_flat_adam_matches_torch"]
-GPU_CASES = CPU_CASES + ["case_training_step_16bit_storage", "case_c2_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_inference_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
+GPU_CASES = CPU_CASES + ["case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_inference_golden", "case_inference_golden_34", "case_e2e_c3_golden"]

@@ -1,5 +1,8 @@
 """Host-side helpers of the product layer against the oracle's restatement (no GPU)."""
+import os
+
 import numpy as np
+import pytest
 
 from oracle import i3d_ref as R
 from step_amd.tube_math import generate_anchors
@@ -10,3 +13,53 @@ def test_generate_anchors_matches_oracle():
     assert a.shape == (34, 4)                          # 9 + 25 boxes of anchor mode "1" (data/data_utils.py:19-45)
     assert np.array_equal(a, R.anchors())
     assert (a >= 0).all() and (a <= 1 + 1e-6).all()
+
+
+# ---------------------------------------------------------------- training sample selection
+def _selection_args(g, ci):
+    from types import SimpleNamespace as NS
+    return NS(T=3, NUM_CHUNKS={1: 1, 2: 1, 3: 3, 4: 3}, max_iter=3, num_classes=60, image_size=(400, 400),
+              cls_thresh=[0.2, 0.35, 0.5], reg_thresh=[0.2, 0.35, 0.5], max_pos_num=int(g["c%d_max_pos_num" % ci]),
+              neg_ratio=int(g["c%d_neg_ratio" % ci]), topk=int(g["c%d_topk" % ci]),
+              selection_sampling=str(g["c%d_sampling" % ci]), temporal_mode=str(g["c%d_mode" % ci]))
+
+
+@pytest.mark.parametrize("ci", range(5))
+def test_train_select_matches_reference(ci):
+    """step_amd.selection.train_select against what the reference's train_select (utils/utils.py:135-339) returned for the
+    same inputs and the same `random` / `numpy.random` seeds (oracle/make_golden.py selection): same tubes selected, in the
+    same order, bit for bit, with the same target rows -- all three steps (initial proposals; refined tubes; extended tubes
+    with neighbour targets), softmax / random / uniform sampling, top-k, score ties, an invalid box."""
+    import random
+
+    from step_amd import selection as S
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "selection_golden.npz"))
+    args = _selection_args(g, ci)
+    seed = int(g["c%d_seed" % ci])
+    targets = [g["c%d_targets%d" % (ci, b)] for b in range(2)]
+    anchors = (generate_anchors() * 400.0).astype(np.float32)
+    tubes = [np.tile(anchors[:, None, :], (1, 3, 1)).astype(np.float32) for _ in range(2)]
+    hist = {k: g["c%d_hist_%s" % (ci, k)] for k in ("pred_loc", "pred_first_loc", "pred_last_loc")}
+    hist["pred_prob"] = np.tile(g["c%d_hist_pred_prob" % ci], (1, 3, 1))
+    hist["tubes_nums"] = [34, 20]
+    for step in (1, 2, 3):
+        random.seed(seed * 10 + step)
+        np.random.seed(seed * 10 + step)
+        sel, tgt = S.train_select(step, hist if step > 1 else None, targets, tubes, args)
+        for b in range(2):
+            ref_sel, ref_tgt = g["c%d_s%d_sel%d" % (ci, step, b)], g["c%d_s%d_tgt%d" % (ci, step, b)]
+            assert sel[b].shape == ref_sel.shape and sel[b].dtype == ref_sel.dtype, (step, b)
+            assert np.array_equal(sel[b], ref_sel), (step, b)
+            assert np.array_equal(tgt[b], ref_tgt), (step, b)
+    assert np.array_equal(S.tube_iou(targets[0][:, :, :4], hist["pred_loc"][:9]), g["c%d_iou" % ci], equal_nan=True)   # 0/0 pairs: nan in both
+
+
+def test_tube_iou_edge_cases_match_reference():
+    """padding tubes (all zero) score 0 against everything, touching boxes 0, degenerate pairs nan -- compute_tube_iou
+    (utils/tube_utils.py:308-351) bit for bit."""
+    from step_amd import selection as S
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "selection_golden.npz"))
+    out = S.tube_iou(g["edge_t1"], g["edge_t2"])
+    assert np.array_equal(out, g["edge_iou"], equal_nan=True)
+    with pytest.raises(AssertionError):
+        S.tube_iou(np.zeros((1, 2, 4), np.float32), np.zeros((1, 3, 4), np.float32))
