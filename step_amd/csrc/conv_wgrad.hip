@@ -203,6 +203,17 @@ using namespace step;
 
 extern "C" {
 
+// Every wavefront job ends in one set of fp32 atomics on its 64x64 (x tap) tile of dw: ~0.2 us per job at the rate the
+// L2 sustains (measured: 5832 jobs on a 7x7 head layer = 1.16 ms for 2.9 GFLOP), against ~0.13 us of MFMA work per pixel
+// of a job.  So a job must cover some hundred pixels or the launch is bound by the atomics, however small the map:
+// the head layers on 7x7 maps ran at 0.3-4 TFLOP/s with the fixed ~6000-job split.  Swept on the C4 step (143 wgrad
+// launches, ms in total): 16 px -> 37.4, 128 -> 24.0, 256 -> 21.5, 512 -> 22.1, 720 -> 22.7, 1440 -> 28.0, 5760 -> 43.5.
+static int wgrad_min_pixels() {
+    const char* e = getenv("STEP_WGRAD_MINPIX");               // read per call (tests exercise both regimes in one process)
+    const int x = e ? atoi(e) : 0;
+    return x > 0 ? (x + 15) / 16 * 16 : 512;
+}
+
 int step_conv_wgrad(const step_conv_desc* d, const void* x, const float* dy, float* dw, int accumulate, step_stream_t stream) {
     if (!d) return STEP_E_NULL;
     if (d->N < 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return STEP_E_SHAPE;
@@ -230,7 +241,7 @@ int step_conv_wgrad(const step_conv_desc* d, const void* x, const float* dy, flo
         long long want = wg_jobs_pw / (tiles > 0 ? tiles : 1);
         if (want < 1) want = 1;
         long long ch = (ceil_div64(M, want) + 15) / 16 * 16;
-        if (ch < 64) ch = 64;
+        if (ch < wgrad_min_pixels()) ch = wgrad_min_pixels();
         if (ch > 65536) ch = 65536;
         const int chunk = (int)ch;
         // (n, d, h) collapse into full chunks; the ragged tail is a second launch
@@ -270,6 +281,9 @@ int step_conv_wgrad(const step_conv_desc* d, const void* x, const float* dy, flo
         long long want = wg_jobs / (gy > 0 ? gy : 1);
         if (want < 1) want = 1;
         long long rows = ceil_div64(p.total_rows, want);
+        const long long rows_min = ceil_div64(wgrad_min_pixels(), d->W);      // small maps: fewer, longer jobs (see above)
+        if (rows < rows_min) rows = rows_min;
+        if (rows > p.total_rows) rows = p.total_rows;
         if (rows < 1) rows = 1;
         if (rows > 0x3fffffff) rows = 0x3fffffff;
         p.rows = (int)rows;

@@ -561,30 +561,46 @@ def case_conv_wgrad(bk, golden):
     rs = np.random.RandomState(33)
     cases = [(2, 24, 40, 3, 5, 19, (3, 3, 3)),      # ragged channels (24 -> one 32-block), 19 pixels per row (16 + 3)
              (1, 72, 100, 2, 6, 7, (1, 3, 3)),      # 2-D kernel, two ci / co tiles
-             (1, 40, 70, 1, 9, 130, (1, 1, 1))]     # pointwise: 1170 pixels = one full chunk of 1024 + a tail of 146
-    for (N, Cin, Cout, D, H, W, k) in cases:
-        x = rs.randn(N, Cin, D, H, W).astype(np.float32)
-        gy = rs.randn(N, Cout, D, H, W).astype(np.float32)
-        for dt in (F32, BF16):
-            xq = torch.from_numpy(quantize(x, dt)).requires_grad_(False)
-            w = torch.zeros(Cout, Cin, *k, requires_grad=True)
-            F.conv3d(xq, w, padding=tuple(kk // 2 for kk in k)).backward(torch.from_numpy(gy))
-            ref = w.grad.numpy()
-            xpad = np.zeros((N, D, H, W, 8 + Cin), np.float32)
-            xpad[..., 8:] = cl(x)
-            xpad[..., :8] = 1e6                       # channels before the slice: must never be read
-            xd = bk.dev(encode(xpad, dt))
-            gd = bk.dev(np.ascontiguousarray(cl(gy), np.float32))
-            dw = bk.dev(np.full((Cout, Cin) + k, 7.0, np.float32))     # accumulate = 0 must overwrite
-            d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2], x_cstride=8 + Cin, x_coff=8,
-                               y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)
-            assert bk.lib.step_conv_wgrad(ctypes.byref(d), xd.ptr, gd.ptr, dw.ptr, 0, bk.stream) == 0
-            got = dw.get()
-            err = np.abs(got - ref).max() / np.abs(ref).max()
-            assert err < 2e-5, (N, Cin, Cout, k, dt, err)
-            assert bk.lib.step_conv_wgrad(ctypes.byref(d), xd.ptr, gd.ptr, dw.ptr, 1, bk.stream) == 0    # accumulate
-            err2 = np.abs(dw.get() - 2 * ref).max() / np.abs(ref).max()
-            assert err2 < 4e-5, err2
+             (1, 40, 70, 1, 9, 130, (1, 1, 1))]     # pointwise: 1170 pixels = full chunks + a ragged tail launch
+    # STEP_WGRAD_MINPIX = pixels a wavefront job covers at least (default 512: these small maps become one or two jobs per
+    # tile); 64 and 256 force several row-range jobs per tile -- jobs that cross planes and clips, ragged last jobs,
+    # pointwise chunks of 64 / 256 pixels with a tail launch
+    saved = os.environ.get("STEP_WGRAD_MINPIX")
+    try:
+        for minpix in ("64", "256", None):
+            if minpix is None:
+                os.environ.pop("STEP_WGRAD_MINPIX", None)
+            else:
+                os.environ["STEP_WGRAD_MINPIX"] = minpix
+            for (N, Cin, Cout, D, H, W, k) in cases:
+                x = rs.randn(N, Cin, D, H, W).astype(np.float32)
+                gy = rs.randn(N, Cout, D, H, W).astype(np.float32)
+                for dt in (F32, BF16):
+                    xq = torch.from_numpy(quantize(x, dt)).requires_grad_(False)
+                    w = torch.zeros(Cout, Cin, *k, requires_grad=True)
+                    F.conv3d(xq, w, padding=tuple(kk // 2 for kk in k)).backward(torch.from_numpy(gy))
+                    ref = w.grad.numpy()
+                    xpad = np.zeros((N, D, H, W, 8 + Cin), np.float32)
+                    xpad[..., 8:] = cl(x)
+                    xpad[..., :8] = 1e6                       # channels before the slice: must never be read
+                    xd = bk.dev(encode(xpad, dt))
+                    gd = bk.dev(np.ascontiguousarray(cl(gy), np.float32))
+                    dw = bk.dev(np.full((Cout, Cin) + k, 7.0, np.float32))     # accumulate = 0 must overwrite
+                    d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2], x_cstride=8 + Cin, x_coff=8,
+                                       y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)
+                    assert bk.lib.step_conv_wgrad(ctypes.byref(d), xd.ptr, gd.ptr, dw.ptr, 0, bk.stream) == 0
+                    got = dw.get()
+                    err = np.abs(got - ref).max() / np.abs(ref).max()
+                    assert err < 2e-5, (N, Cin, Cout, k, dt, minpix, err)
+                    assert bk.lib.step_conv_wgrad(ctypes.byref(d), xd.ptr, gd.ptr, dw.ptr, 1, bk.stream) == 0    # accumulate
+                    err2 = np.abs(dw.get() - 2 * ref).max() / np.abs(ref).max()
+                    assert err2 < 4e-5, err2
+    finally:
+        if saved is None:
+            os.environ.pop("STEP_WGRAD_MINPIX", None)
+        else:
+            os.environ["STEP_WGRAD_MINPIX"] = saved
+
     d = _capi.ConvDesc(dtype=F32, N=1, D=1, H=4, W=4, Cin=8, Cout=8, kd=1, kh=2, kw=2, x_cstride=8, x_coff=0, y_cstride=8, y_coff=0,
                        res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)
     assert bk.lib.step_conv_wgrad(ctypes.byref(d), None, None, None, 0, bk.stream) < 0     # even kernels: unsupported / null
