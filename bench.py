@@ -340,7 +340,7 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
                                "unit": "TFLOP/s" if mf else "GB/s", "frac": round(ach / peak, 4), "traffic": None,
                                "launches_per_step": cnt, "avg_launch_ms": round(ms / cnt, 4),
                                "share_of_instrumented_kernel_time": round(ms / sum(v[1] for v in agg.values()), 3),
-                               "note": "instrumented forward launches of step_amd.ops (backward / torch glue kernels are not in this table)"}
+                               "note": "instrumented launches of step_amd.ops: conv / stem / pool forward, the data-gradient convs and conv weight gradients (torch glue kernels are not in this table)"}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

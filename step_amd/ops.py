@@ -140,8 +140,16 @@ def conv_wgrad(x, gy, Cout, k):
     d = _capi.ConvDesc(dtype=_dt(x), N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2],
                        x_cstride=_chan_slice(x), x_coff=0, y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=0,
                        split=0, y2_cstride=0, y2_coff=0)
-    _capi.check(L.step_conv_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(dw), 0, _lib.stream_ptr(x.device)),
-                "step_conv_wgrad")
+    prof = _NOPROF
+    if PROFILE is not None:
+        pix = N * D * H * W
+        # algorithmic: x and dy read once, dw written once (fp32); the kernel variant is chosen by Cin inside the library
+        prof = _Prof("void step::conv_wgrad_kernel<%s, 2, %d>(step::WgradParams)" % (_TNAME[x.dtype], 1 if Cin <= 32 else 2),
+                     2.0 * pix * Cout * Cin * k[0] * k[1] * k[2],
+                     pix * (Cin * x.element_size() + Cout * 4) + 4.0 * Cout * Cin * k[0] * k[1] * k[2])
+    with prof:
+        _capi.check(L.step_conv_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(dw), 0, _lib.stream_ptr(x.device)),
+                    "step_conv_wgrad")
     return dw
 
 
