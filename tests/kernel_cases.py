@@ -749,4 +749,84 @@ def big_nms(bk, golden):
         assert np.array_equal(run_nms(bk, boxes, scores, counts, 0.4), oracle.nms_batched(boxes, scores, counts, 0.4))
 
 
-GPU_ONLY = ["big_conv_shapes", "big_stem", "big_roi", "big_nms"]
+def big_wgrad_full_size_properties(bk, golden):
+    """Weight gradients at the C4 layer sizes (AVA clip: conv3d_2c on 18x100x100, a 25x25 Inception conv, the heads' convs on
+    7x7 maps), where no CPU oracle finishes in seconds -- size-independent properties instead:
+      * the job split does not matter: one-row jobs (STEP_WGRAD_MINPIX=16), the default and one job per tile
+        (STEP_WGRAD_MINPIX=10^6) agree to fp32 summation-order noise;
+      * linearity in dy: wgrad(x, a + b) == wgrad(x, a) + wgrad(x, b);
+      * a checksum against a dense contraction: sum over taps and input channels of dw[co] for an all-ones x equals the
+        (border-clipped) tap counts times sum(dy[co]) -- evaluated in closed form."""
+    import torch
+    rs = np.random.RandomState(8)
+    for (N, Cin, Cout, D, H, W, k) in ((1, 64, 192, 18, 100, 100, (3, 3, 3)), (1, 160, 320, 9, 25, 25, (3, 3, 3)),
+                                       (15, 256, 256, 1, 7, 7, (1, 3, 3)), (5, 192, 384, 3, 7, 7, (3, 3, 3)), (45, 256, 1024, 1, 7, 7, (1, 1, 1))):
+        x = torch.randn(N, D, H, W, Cin).numpy()
+        a = torch.randn(N, D, H, W, Cout).numpy()
+        b = torch.randn(N, D, H, W, Cout).numpy()
+        xd = bk.dev(x)
+        d = _capi.ConvDesc(dtype=F32, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2], x_cstride=Cin, x_coff=0,
+                           y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)
+
+        def wg(xbuf, dy, minpix=None):
+            saved = os.environ.get("STEP_WGRAD_MINPIX")
+            if minpix is not None:
+                os.environ["STEP_WGRAD_MINPIX"] = minpix
+            try:
+                dw = bk.dev(np.zeros((Cout, Cin) + k, np.float32))
+                assert bk.lib.step_conv_wgrad(ctypes.byref(d), xbuf.ptr, bk.dev(dy).ptr, dw.ptr, 0, bk.stream) == 0
+                return dw.get()
+            finally:
+                if saved is None:
+                    os.environ.pop("STEP_WGRAD_MINPIX", None)
+                else:
+                    os.environ["STEP_WGRAD_MINPIX"] = saved
+
+        base = wg(xd, a)
+        scale = np.abs(base).max()
+        for mp in ("16", "1000000"):
+            assert np.abs(wg(xd, a, mp) - base).max() < 2e-5 * scale, (Cin, Cout, k, mp)
+        assert np.abs(wg(xd, a + b) - (base + wg(xd, b))).max() < 2e-5 * scale, (Cin, Cout, k)
+        ones = bk.dev(np.ones((N, D, H, W, Cin), np.float32))
+        got = wg(ones, a).astype(np.float64)
+        # dw[co, ci, t] = sum of dy[co] over the output pixels whose tap t lands inside the map
+        dy = a.astype(np.float64)
+        for t in np.ndindex(*k):
+            o = [t[i] - k[i] // 2 for i in range(3)]
+            sl = tuple(slice(max(0, -o[i]), (D, H, W)[i] - max(0, o[i])) for i in range(3))
+            want = dy[(slice(None),) + sl].sum(axis=(0, 1, 2, 3))
+            assert np.abs(got[(slice(None), 0) + t] - want).max() < 1e-4 * max(1.0, np.abs(want).max()), (Cin, Cout, k, t)
+
+
+def big_adam_full_size(bk, golden):
+    """The fused Adam at the C4 parameter count (44.4 M fp32) against torch's own Adam on the same device:
+    2 steps, per-segment lr / weight_decay, 2e-6 of max|p|."""
+    import torch
+    torch.manual_seed(3)
+    sizes = [4_000_000 + 64 * i for i in range(11)]                 # multiples of 4
+    n = sum(sizes)
+    assert abs(n - 44_422_936) < 500_000
+    ps = [torch.nn.Parameter(torch.randn(s_, device="cuda") * 0.05) for s_ in sizes]
+    lrs = [1e-3 * (1 + i % 3) for i in range(len(sizes))]
+    wds = [0.0 if i % 2 else 1e-4 for i in range(len(sizes))]
+    opt = torch.optim.Adam([{"params": [p], "lr": lr, "weight_decay": wd} for p, lr, wd in zip(ps, lrs, wds)], lr=1e-3)
+    P = torch.cat([p.detach().reshape(-1) for p in ps]).clone()
+    M, V = torch.zeros_like(P), torch.zeros_like(P)
+    ends = torch.tensor(np.cumsum(sizes), dtype=torch.int64, device="cuda")
+    LR, WD = torch.tensor(lrs, device="cuda"), torch.tensor(wds, device="cuda")
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    for step_no in (1, 2):
+        G = torch.randn(n, device="cuda")
+        off = 0
+        for p, s_ in zip(ps, sizes):
+            p.grad = G[off:off + s_].clone()
+            off += s_
+        opt.step()
+        assert bk.lib.step_adam_flat(vp(P), vp(G), vp(M), vp(V), n, vp(ends), vp(LR), vp(WD), len(sizes), 0.9, 0.999, 1e-8, step_no, 1.0, 1,
+                                     bk.stream) == 0
+        ref = torch.cat([p.detach().reshape(-1) for p in ps])
+        assert float((P - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), step_no
+        assert float(G.abs().max()) == 0.0
+
+
+GPU_ONLY = ["big_conv_shapes", "big_stem", "big_roi", "big_nms", "big_wgrad_full_size_properties", "big_adam_full_size"]
