@@ -243,6 +243,17 @@ STEP_API int step_adam_flat(float* param, float* grad, float* exp_avg, float* ex
                             const long long* seg_end, const float* seg_lr, const float* seg_wd, int n_seg, double beta1,
                             double beta2, double eps, int step, float grad_scale, int zero_grad, step_stream_t stream);
 
+/* Activation gradient of the fused conv unit (the backward of Unit3Dpy's BatchNorm3d(eval) + ReLU, models/i3dpt.py:100-111,
+ * and of the Bottleneck ReLUs, two_branch.py:60-111, which autograd runs as separate element-wise kernels in the reference):
+ *   g[m][c] = gy[m][c] * (relu ? y[m][c] > 0 : 1) * (scale ? scale[c] : 1)      m < M pixels, c < C channels (channels-last)
+ * written as fp32 into g32 (operand of step_conv_wgrad; may be NULL) and / or in `dtype` into g_act (operand of the
+ * data-gradient step_conv_forward; may be NULL), both dense [M, C].  y / g_act have `dtype`; gy has gy_dtype = STEP_F32 or
+ * `dtype`; y and gy may be channel slices of wider channels-last buffers (y_cstride / gy_cstride = elements between
+ * consecutive pixels, 0 = C): the Inception branches write into and read their gradient from the concat buffer.
+ * C or a stride not a multiple of 4 -> STEP_E_UNSUPPORTED (the caller keeps torch's element-wise path for those few layers). */
+STEP_API int step_act_grad(int dtype, const void* y, int y_cstride, int gy_dtype, const void* gy, int gy_cstride, const float* scale,
+                           long long M, int C, int relu, float* g32, void* g_act, step_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

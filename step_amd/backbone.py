@@ -54,9 +54,31 @@ class _ConvUnitFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    def _dgrad(gin, w_eff, dtype, k):
+        # data gradient = the SAME fused HIP conv on the output gradient with the taps flipped and the
+        # channel roles swapped (stride 1, SAME padding): no torch / MIOpen kernel on this leg
+        w_t = w_eff.detach().flip(2, 3, 4).transpose(0, 1).contiguous()
+        vec = 16 // gin.element_size()                           # the kernels move 16-byte channel vectors
+        padc = (-gin.shape[-1]) % vec
+        if padc:                                                 # e.g. the 60-class / 12-column Linear layers in 16-bit
+            gin = torch.nn.functional.pad(gin, (0, padc))
+            w_t = torch.nn.functional.pad(w_t, (0, 0, 0, 0, 0, 0, 0, padc))
+        return ops.conv_forward(gin, ops.pack_conv_weight(w_t, dtype), w_t.shape[0], k, None, None, False, None, None)
+
+    @staticmethod
     def backward(ctx, gy):
         x, w_eff, scale, shift, y, res = ctx.saved_tensors
         k = tuple(w_eff.shape[2:])
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (ctx.needs_input_grad[2] or ctx.needs_input_grad[3] or (res is not None and ctx.needs_input_grad[4])):
+            # frozen affine, no residual (every backbone / Inception unit): only the conv's own gradients are wanted, so the
+            # cast / ReLU mask / scale / cast chain is ONE HIP pass producing the wgrad operand (fp32) and the dgrad operand
+            fused = ops.act_grad(y, gy, scale, ctx.relu, want_f32=need_w, want_act=need_x) if (need_x or need_w) else (None, None)
+            if fused is not None:
+                g32, gact = fused
+                gx = _ConvUnitFn._dgrad(gact, w_eff, x.dtype, k) if need_x else None
+                gw = ops.conv_wgrad(x, g32, w_eff.shape[0], k).to(w_eff.dtype) if need_w else None
+                return gx, gw, None, None, None, None, None
         g = gy.float()
         if ctx.relu:
             g = g * (y > 0).to(g.dtype)
@@ -72,16 +94,7 @@ class _ConvUnitFn(torch.autograd.Function):
         gconv = g * scale.view(1, 1, 1, 1, -1) if scale is not None else g
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            # data gradient = the SAME fused HIP conv on the output gradient with the taps flipped and the
-            # channel roles swapped (stride 1, SAME padding): no torch / MIOpen kernel on this leg
-            w_t = w_eff.detach().flip(2, 3, 4).transpose(0, 1).contiguous()
-            gin = gconv.to(x.dtype).contiguous()
-            vec = 16 // gin.element_size()                       # the kernels move 16-byte channel vectors
-            padc = (-gin.shape[-1]) % vec
-            if padc:                                             # e.g. the 60-class / 12-column Linear layers in 16-bit
-                gin = torch.nn.functional.pad(gin, (0, padc))
-                w_t = torch.nn.functional.pad(w_t, (0, 0, 0, 0, 0, 0, 0, padc))
-            gx = ops.conv_forward(gin, ops.pack_conv_weight(w_t, x.dtype), w_t.shape[0], k, None, None, False, None, None)
+            gx = _ConvUnitFn._dgrad(gconv.to(x.dtype).contiguous(), w_eff, x.dtype, k)
         if ctx.needs_input_grad[1]:
             # weight gradient = the HIP wgrad kernel (fp32 MFMA over the pixel axis) on the same channels-last buffers
             gw = ops.conv_wgrad(x, gconv, w_eff.shape[0], k).to(w_eff.dtype)

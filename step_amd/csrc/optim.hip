@@ -57,6 +57,62 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, f
     }
 }
 
+// ---- activation gradient of the fused conv unit ---------------------------------------------------------------------
+// backward of  y = relu(conv * scale[c] + shift[c])  up to the conv:  g = gy * (y > 0) * scale[c], written once as fp32
+// (operand of the weight-gradient kernel) and / or once in the activation dtype (operand of the data-gradient conv).
+// One read of y and gy instead of the cast / compare / multiply / multiply / cast chain of element-wise passes.
+typedef unsigned short u16x4_t __attribute__((ext_vector_type(4)));
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    __device__ static __forceinline__ f32x4 load(const float* p) { return *(const f32x4*)p; }
+    __device__ static __forceinline__ void store(float* p, const f32x4& v) { *(f32x4*)p = v; }
+};
+template <typename T> struct Vec4 {
+    __device__ static __forceinline__ f32x4 load(const T* p) {
+        const u16x4_t r = *(const u16x4_t*)p;
+        return f32x4{elem<T>::from_bits16(r[0]), elem<T>::from_bits16(r[1]), elem<T>::from_bits16(r[2]), elem<T>::from_bits16(r[3])};
+    }
+    __device__ static __forceinline__ void store(T* p, const f32x4& v) {
+        *(u16x4_t*)p = u16x4_t{elem<T>::bits16(v[0]), elem<T>::bits16(v[1]), elem<T>::bits16(v[2]), elem<T>::bits16(v[3])};
+    }
+};
+
+template <typename TY, typename TG>
+__global__ __launch_bounds__(256) void act_grad_kernel(const TY* __restrict__ y, const TG* __restrict__ gy, const float* __restrict__ scale,
+                                                       long long nvec, int C, int y_cs, int gy_cs, int relu, float* __restrict__ g32,
+                                                       TY* __restrict__ gt) {
+    const int cv = C >> 2;                                                   // C % 4 == 0: a vector never straddles two pixels
+    for (long long vec = (long long)blockIdx.x * blockDim.x + threadIdx.x; vec < nvec; vec += (long long)blockDim.x * gridDim.x) {
+        const long long m = vec / cv;                                        // pixel; y / gy may be channel slices of wider buffers
+        const int c = (int)(vec - m * cv) << 2;
+        const long long e = vec * 4;                                         // the outputs are dense [M, C]
+        f32x4 g = Vec4<TG>::load(gy + m * gy_cs + c);
+        if (scale) {
+            const f32x4 s = *(const f32x4*)(scale + c);
+            g = f32x4{g[0] * s[0], g[1] * s[1], g[2] * s[2], g[3] * s[3]};
+        }
+        if (relu) {
+            const f32x4 yv = Vec4<TY>::load(y + m * y_cs + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (!(yv[j] > 0.f)) g[j] = 0.f;
+        }
+        if (g32) *(f32x4*)(g32 + e) = g;
+        if (gt) Vec4<TY>::store(gt + e, g);
+    }
+}
+
+template <typename TY, typename TG>
+static int act_grad_t(const void* y, int y_cs, const void* gy, int gy_cs, const float* scale, long long M, int C, int relu, float* g32, void* gt,
+                      step_stream_t stream) {
+    const long long nvec = M * C / 4;
+    long long blocks = (nvec + 255) / 256;
+    if (blocks > 256LL * 64) blocks = 256LL * 64;
+    STEP_LAUNCH((act_grad_kernel<TY, TG>), dim3((unsigned)blocks), dim3(256), stream, (const TY*)y, (const TG*)gy, scale, nvec, C, y_cs, gy_cs, relu, g32,
+                (TY*)gt);
+    return STEP_LAUNCH_CHECK();
+}
+
 }  // namespace step
 
 using namespace step;
@@ -87,6 +143,33 @@ int step_adam_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
                     seg_end, seg_lr, seg_wd, n_seg, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, bc1,
                     bc2_sqrt, grad_scale, zero_grad);
     return STEP_LAUNCH_CHECK();
+}
+
+int step_act_grad(int dtype, const void* y, int y_cstride, int gy_dtype, const void* gy, int gy_cstride, const float* scale, long long M, int C,
+                  int relu, float* g32, void* g_act, step_stream_t stream) {
+    if (M < 0 || C <= 0) return STEP_E_SHAPE;
+    if (y_cstride == 0) y_cstride = C;
+    if (gy_cstride == 0) gy_cstride = C;
+    if (y_cstride < C || gy_cstride < C) return STEP_E_SHAPE;
+    if ((C & 3) || (y_cstride & 3) || (gy_cstride & 3)) return STEP_E_UNSUPPORTED;     // 4-channel vectors
+    {
+        const int yb = dtype == STEP_F32 ? 16 : 8, gb = gy_dtype == STEP_F32 ? 16 : 8;
+        if ((relu && ((uintptr_t)y & (yb - 1))) || ((uintptr_t)gy & (gb - 1)) || ((uintptr_t)g32 & 15) || ((uintptr_t)g_act & (yb - 1)) ||
+            ((uintptr_t)scale & 15))
+            return STEP_E_ALIGN;
+    }
+    if (M == 0) return STEP_OK;
+    if (!gy || (relu && !y) || (!g32 && !g_act)) return STEP_E_NULL;
+    if (gy_dtype != STEP_F32 && gy_dtype != dtype) return STEP_E_DTYPE;
+    const bool gf = gy_dtype == STEP_F32;
+    switch (dtype) {
+        case STEP_F32: return act_grad_t<float, float>(y, y_cstride, gy, gy_cstride, scale, M, C, relu, g32, g_act, stream);
+        case STEP_BF16: return gf ? act_grad_t<bf16_t, float>(y, y_cstride, gy, gy_cstride, scale, M, C, relu, g32, g_act, stream)
+                                  : act_grad_t<bf16_t, bf16_t>(y, y_cstride, gy, gy_cstride, scale, M, C, relu, g32, g_act, stream);
+        case STEP_F16: return gf ? act_grad_t<f16_t, float>(y, y_cstride, gy, gy_cstride, scale, M, C, relu, g32, g_act, stream)
+                                 : act_grad_t<f16_t, f16_t>(y, y_cstride, gy, gy_cstride, scale, M, C, relu, g32, g_act, stream);
+    }
+    return STEP_E_DTYPE;
 }
 
 }  // extern "C"

@@ -153,6 +153,34 @@ def conv_wgrad(x, gy, Cout, k):
     return dw
 
 
+def act_grad(y, gy, scale, relu, want_f32=True, want_act=False):
+    """Activation gradient of the fused conv unit: g = gy * (y > 0) * scale[c] in one pass (step_act_grad).
+    y / gy channels-last (possibly channel slices); returns (g fp32 or None, g in y.dtype or None), dense.
+    Returns None when the layout is outside the kernel's contract (channels not a multiple of 4): the caller then keeps
+    torch's element-wise ops."""
+    C = y.shape[-1]
+    if C % 4 or gy.dtype not in (torch.float32, y.dtype) or gy.stride(-1) != 1 or y.stride(-1) != 1:
+        return None
+    try:
+        ycs, gcs = _chan_slice(y), _chan_slice(gy)
+    except RuntimeError:
+        return None
+    es_y, es_g = y.element_size(), gy.element_size()
+    if ycs % 4 or gcs % 4 or y.data_ptr() % (4 * es_y) or gy.data_ptr() % (4 * es_g):
+        return None
+    M = y.numel() // C
+    same = y.dtype == torch.float32
+    g32 = torch.empty(y.shape, dtype=torch.float32, device=y.device) if (want_f32 or (want_act and same)) else None
+    gact = torch.empty(y.shape, dtype=y.dtype, device=y.device) if (want_act and not same) else None
+    sc = None
+    if scale is not None:
+        sc = scale if (scale.dtype == torch.float32 and scale.is_contiguous()) else scale.float().contiguous()
+    L = _lib.lib()
+    _capi.check(L.step_act_grad(_dt(y), _lib.dptr(y), ycs, DT[gy.dtype], _lib.dptr(gy), gcs, _lib.dptr(sc), M, C, int(bool(relu)),
+                                _lib.dptr(g32), _lib.dptr(gact), _lib.stream_ptr(y.device)), "step_act_grad")
+    return (g32 if want_f32 or same else None), (g32 if same else gact)
+
+
 def stem_forward(x, w_packed, Cout, scale, shift, out=None):
     """x: [N,T,3,H,W] contiguous (the reference's input layout) -> channels-last [N,To,Ho,Wo,Cout]"""
     L = _lib.lib()

@@ -441,6 +441,50 @@ def case_adam_flat(bk, golden):
                                  0, bk.stream) == 0                                       # empty arena: no launch
 
 
+def case_act_grad(bk, golden):
+    """g = gy * (y > 0) * scale[c] against the torch element-wise chain of the unit's backward (cast, mask, multiply, cast):
+    bit-exact in fp32 and after the rounding to the 16-bit activation type; both outputs, either alone, no relu / no scale."""
+    rs = np.random.RandomState(21)
+    M, C = 37, 24
+    y = rs.randn(M, C).astype(np.float32)
+    y[::5] = 0.0                                                 # y == 0 is masked (strict >)
+    gy = rs.randn(M, C).astype(np.float32)
+    scale = (1 + 0.3 * rs.randn(C)).astype(np.float32)
+    for dt in (F32, BF16, F16):
+        yq, gq = quantize(y, dt), quantize(gy, dt)
+        for g_dt, gsrc in ((F32, gy), (dt, gq)):
+            for relu in (1, 0):
+                for sc in (scale, None):
+                    ref = gsrc.copy()
+                    if sc is not None:
+                        ref = ref * sc[None, :]
+                    if relu:
+                        ref = ref * (yq > 0)
+                    ref = ref.astype(np.float32)
+                    yd, gd = bk.dev(encode(yq, dt)), bk.dev(encode(gsrc, g_dt))
+                    o32 = bk.dev(np.full((M, C), 9.0, np.float32))
+                    oT = bk.dev(encode(np.full((M, C), 9.0, np.float32), dt))
+                    sd = bk.dev(sc) if sc is not None else None
+                    assert bk.lib.step_act_grad(dt, yd.ptr, 0, g_dt, gd.ptr, 0, sd.ptr if sd else None, M, C, relu, o32.ptr, oT.ptr, bk.stream) == 0
+                    assert np.array_equal(o32.get(), ref), (dt, g_dt, relu)
+                    assert np.array_equal(decode(oT.get(), dt), quantize(ref, dt)), (dt, g_dt, relu)
+    yd, gd = bk.dev(y), bk.dev(gy)
+    o32 = bk.dev(np.zeros((M, C), np.float32))
+    assert bk.lib.step_act_grad(F32, yd.ptr, 0, F32, gd.ptr, 0, None, M, C, 1, o32.ptr, None, bk.stream) == 0      # fp32 output only
+    assert np.array_equal(o32.get(), gy * (y > 0))
+    # channel slices: y = columns [8, 16) of a 24-wide buffer, gy = columns [4, 12) of the other one
+    o8 = bk.dev(np.zeros((M, 8), np.float32))
+    s8 = bk.dev(scale[:8].copy())
+    off = lambda p_, nbytes: ctypes.c_void_p((p_.value if isinstance(p_, ctypes.c_void_p) else int(p_)) + nbytes)
+    assert bk.lib.step_act_grad(F32, off(yd.ptr, 8 * 4), C, F32, off(gd.ptr, 4 * 4), C, s8.ptr, M, 8, 1, o8.ptr, None, bk.stream) == 0
+    assert np.array_equal(o8.get(), (gy[:, 4:12] * scale[None, :8] * (y[:, 8:16] > 0)).astype(np.float32))
+    assert bk.lib.step_act_grad(F32, yd.ptr, 0, F32, gd.ptr, 0, None, M, 22, 1, o32.ptr, None, bk.stream) == -4     # C % 4: caller falls back
+    assert bk.lib.step_act_grad(F32, yd.ptr, 0, BF16, gd.ptr, 0, None, M, C, 1, o32.ptr, None, bk.stream) < 0
+    assert bk.lib.step_act_grad(F32, None, 0, F32, gd.ptr, 0, None, M, C, 1, o32.ptr, None, bk.stream) < 0
+    assert bk.lib.step_act_grad(F32, yd.ptr, 8, F32, gd.ptr, 0, None, M, C, 1, o32.ptr, None, bk.stream) < 0        # stride < C
+    assert bk.lib.step_act_grad(F32, yd.ptr, 0, F32, gd.ptr, 0, None, 0, C, 1, o32.ptr, None, bk.stream) == 0
+
+
 def case_avgpool_hw(bk, golden):
     rs = np.random.RandomState(6)
     x = rs.randn(2, 8, 3, 13, 13).astype(np.float32)
@@ -758,7 +802,7 @@ def big_wgrad_full_size_properties(bk, golden):
       * a checksum against a dense contraction: sum over taps and input channels of dw[co] for an all-ones x equals the
         (border-clipped) tap counts times sum(dy[co]) -- evaluated in closed form."""
     import torch
-    rs = np.random.RandomState(8)
+    torch.manual_seed(8)
     for (N, Cin, Cout, D, H, W, k) in ((1, 64, 192, 18, 100, 100, (3, 3, 3)), (1, 160, 320, 9, 25, 25, (3, 3, 3)),
                                        (15, 256, 256, 1, 7, 7, (1, 3, 3)), (5, 192, 384, 3, 7, 7, (3, 3, 3)), (45, 256, 1024, 1, 7, 7, (1, 1, 1))):
         x = torch.randn(N, D, H, W, Cin).numpy()
@@ -784,8 +828,10 @@ def big_wgrad_full_size_properties(bk, golden):
 
         base = wg(xd, a)
         scale = np.abs(base).max()
-        for mp in ("16", "1000000"):
-            assert np.abs(wg(xd, a, mp) - base).max() < 2e-5 * scale, (Cin, Cout, k, mp)
+        # one job per tile = one fp32 chain over every pixel of the map (180 000 terms for conv3d_2c): its rounding noise
+        # grows with the chain length, hence the wider bound there
+        for mp, bound in (("16", 2e-5), ("1000000", 1e-4)):
+            assert np.abs(wg(xd, a, mp) - base).max() < bound * scale, (Cin, Cout, k, mp)
         assert np.abs(wg(xd, a + b) - (base + wg(xd, b))).max() < 2e-5 * scale, (Cin, Cout, k)
         ones = bk.dev(np.ones((N, D, H, W, Cin), np.float32))
         got = wg(ones, a).astype(np.float64)
