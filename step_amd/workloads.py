@@ -80,9 +80,12 @@ class C4TrainStep:
     same `tubes_per_clip` anchor tubes, extended to the step's length."""
 
     def __init__(self, dev, batch=1, tubes_per_clip=5, seed=123, max_iter=3, dtype=torch.float32):
-        self.args, self.base, self.ctx, self.nets = build_nets(dev, seed, heads=max_iter)
+        # replicas: the same weights on every rank (same init seed, then rank 0's copy is broadcast once, as DDP does);
+        # `seed` only varies the rank's clips
+        self.args, self.base, self.ctx, self.nets = build_nets(dev, 123, heads=max_iter)
         self.heads = [self.nets["det_net%d" % i] for i in range(max_iter)]
         self.mods = [self.base, self.ctx] + self.heads
+        sdist.broadcast_parameters(self.mods)
         for m in self.mods:
             m.train()
         self.params = [p for m in self.mods for p in m.parameters() if p.requires_grad]
