@@ -71,6 +71,13 @@ class C3Inference:
             return postprocess(self.args, hist)
 
 
+def ava_clips(seed, batch):
+    """`batch` synthetic AVA-shaped clips [36,3,400,400] in U(-1,1) (what ConvertFromInts(scale=2) yields), a pure function of
+    the seed: rank r of a data-parallel job draws ava_clips(123 + r, ...)."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(batch, 36, 3, 400, 400, generator=g) * 2 - 1
+
+
 class C4TrainStep:
     """One optimisation step on `batch` AVA-shaped clips per rank (fp32): backbone + ContextNet + the max_iter = 3 heads on
     tubes of 3, 3 and 9 frames (NUM_CHUNKS 1, 1, 3), the three losses of train.py:318-331 summed over the steps
@@ -90,10 +97,9 @@ class C4TrainStep:
             m.train()
         self.params = [p for m in self.mods for p in m.parameters() if p.requires_grad]
         self.opt = FlatAdam(self.params, lr=1e-5)
-        g = torch.Generator().manual_seed(seed)
         # fp32 master weights either way; a 16-bit clip makes every activation / data gradient 16-bit (fp32 accumulate),
         # weight gradients stay fp32
-        self.x = (torch.rand(batch, 36, 3, 400, 400, generator=g) * 2 - 1).to(dev).to(dtype)
+        self.x = ava_clips(seed, batch).to(dev).to(dtype)
         anchors = torch.from_numpy(generate_anchors()[:tubes_per_clip] * 400.0).to(dev)                  # [K,4]
         K = tubes_per_clip
         self.steps = []
@@ -115,7 +121,8 @@ class C4TrainStep:
         self.batch, self.K = batch, K
         self.loss = None
 
-    def step(self):
+    def forward_backward(self):
+        """Losses of the three steps and their gradients (into FlatAdam's gradient arena); no exchange, no update."""
         cf = self.base(self.x)                                    # [B,9,832,25,25]
         cx = self.ctx(cf)                                         # [B,1024,9,1,1]
         loss = 0.0
@@ -125,6 +132,10 @@ class C4TrainStep:
             o = head(pooled, context_feat=cx[self.clip_of][:, :, t0:t0 + Tl], tubes=flat, targets=self.targets)
             loss = loss + o[4].mean() + 5 * o[5].mean() + o[6].mean()
         loss.backward()
+        return loss
+
+    def step(self):
+        loss = self.forward_backward()
         scale = sdist.allreduce_flat(self.opt.flat_grad)
         self.opt.step(grad_scale=scale, zero_grad=True)          # gradients are clean for the next backward
         self.loss = loss.detach()

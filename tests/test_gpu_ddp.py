@@ -1,0 +1,78 @@
+"""Data-parallel training step on the GPU: two ranks, one AVA clip each, sharing the one GPU of the
+test box over gloo -- the averaged gradient after `allreduce_flat` equals the single-process gradient on the two-clip batch
+(dropout 0, equal tube counts per rank, so the mean of the rank means is the global mean)."""
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _probe(flat, entries):
+    """A fixed sample of the gradient arena plus one L2 norm per tensor (the arena itself is 178 MB)."""
+    idx = torch.from_numpy(np.random.RandomState(0).randint(0, flat.numel(), 65536)).to(flat.device)
+    norms = torch.stack([flat[o:o + n].norm() for _, _, o, n in entries])
+    return flat[idx].cpu().numpy(), norms.cpu().numpy()
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from step_amd import dist as D, workloads
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    w = workloads.C4TrainStep(dev, batch=1, seed=123 + rank)
+    loss = w.forward_backward()
+    f = D.allreduce_flat(w.opt.flat_grad)
+    sample, norms = _probe(w.opt.flat_grad * f, w.opt._entries)
+    lsum = torch.tensor([float(loss)])
+    dist.all_reduce(lsum)
+    p0 = w.opt.flat_param[:4096].cpu().numpy()
+    if rank == 0:
+        q.put((sample, norms, float(lsum) / world, f, p0))
+    else:
+        q.put(("p", p0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_equals_single_process_on_the_concatenated_batch():
+    from step_amd import workloads
+
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(), q.get()]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    main = [g for g in got if g[0] is not None and not isinstance(g[0], str)][0]
+    other = [g for g in got if isinstance(g[0], str)][0]
+    sample, norms, loss2, factor, p0 = main
+    assert factor == 0.5
+    assert np.array_equal(p0, other[1])                          # replicas start from the same (broadcast) weights
+    dev = torch.device("cuda:0")
+    w = workloads.C4TrainStep(dev, batch=2, seed=123)
+    w.x = torch.cat([workloads.ava_clips(123, 1), workloads.ava_clips(124, 1)]).to(dev)
+    loss1 = float(w.forward_backward())
+    ref_sample, ref_norms = _probe(w.opt.flat_grad, w.opt._entries)
+    assert abs(loss1 - loss2) < 1e-4 * abs(loss1), (loss1, loss2)
+    # fp32 atomics and batch-dependent tilings reorder sums; a pre-activation within ~1e-7 of zero may flip its ReLU
+    e = np.linalg.norm(sample - ref_sample) / np.linalg.norm(ref_sample)
+    en = np.abs(norms - ref_norms).max() / ref_norms.max()
+    assert e < 1e-2 and en < 1e-2, (e, en)
