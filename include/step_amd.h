@@ -148,6 +148,13 @@ STEP_API size_t step_conv_packed_elems(int Cout, int Cin, int kd, int kh, int kw
  * (two_branch.py:239-240,262) into the weights once. */
 STEP_API int step_conv_pack_weight(const float* w, int Cout, int Cin, int kd, int kh, int kw, int dtype,
                                    const int32_t* perm_c, void* packed, step_stream_t stream);
+/* The packed weight of the DATA-GRADIENT conv, straight from the forward weight w[Cout][Cin][kd][kh][kw] (fp32, DEVICE; odd
+ * kernels): the conv gy [.., cin_pad] -> gx [.., Cin] of Conv3d/Conv2d/Linear.backward uses w with the channel roles swapped
+ * and every tap axis flipped; cin_pad >= Cout is the gradient's channel count after the caller's padding to 16-byte vectors
+ * (the extra input channels get zero weights).  Size: step_conv_packed_elems(Cin, cin_pad, kd, kh, kw).  Same image as
+ * step_conv_pack_weight on the flipped / transposed / padded tensor, without materialising it. */
+STEP_API int step_conv_pack_weight_dgrad(const float* w, int Cout, int Cin, int kd, int kh, int kw, int dtype, int cin_pad,
+                                         void* packed, step_stream_t stream);
 STEP_API int step_conv_forward(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale,
                                const float* shift, const void* res, void* y, void* y2, step_stream_t stream);
 

@@ -55,15 +55,15 @@ class _ConvUnitFn(torch.autograd.Function):
 
     @staticmethod
     def _dgrad(gin, w_eff, dtype, k):
-        # data gradient = the SAME fused HIP conv on the output gradient with the taps flipped and the
-        # channel roles swapped (stride 1, SAME padding): no torch / MIOpen kernel on this leg
-        w_t = w_eff.detach().flip(2, 3, 4).transpose(0, 1).contiguous()
+        # data gradient = the SAME fused HIP conv on the output gradient with the taps flipped and the channel roles
+        # swapped (stride 1, SAME padding): no torch / MIOpen kernel on this leg; the flipped / transposed weight is
+        # never materialised (step_conv_pack_weight_dgrad packs it straight from w)
         vec = 16 // gin.element_size()                           # the kernels move 16-byte channel vectors
         padc = (-gin.shape[-1]) % vec
         if padc:                                                 # e.g. the 60-class / 12-column Linear layers in 16-bit
             gin = torch.nn.functional.pad(gin, (0, padc))
-            w_t = torch.nn.functional.pad(w_t, (0, 0, 0, 0, 0, 0, 0, padc))
-        return ops.conv_forward(gin, ops.pack_conv_weight(w_t, dtype), w_t.shape[0], k, None, None, False, None, None)
+        wp = ops.pack_conv_weight_dgrad(w_eff, dtype, gin.shape[-1])
+        return ops.conv_forward(gin, wp, w_eff.shape[1], k, None, None, False, None, None)
 
     @staticmethod
     def backward(ctx, gy):

@@ -264,9 +264,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 
 
 // ---- weight packing: torch [Cout][Cin][taps] fp32 -> [nb32][tap][kc16][lane][8] of T ----------
-template <typename T>
+// DGRAD: pack the weight of the DATA-GRADIENT conv straight from the forward weight w [Cw][Cout][taps] (Cw = the forward
+// conv's output channels): effective weight [Cout][Cw][taps] with every tap axis flipped (= the linear tap index
+// reversed), input channels >= Cw (the caller's 16-byte padding) zero.
+template <typename T, bool DGRAD>
 __global__ void pack_weight_kernel(const float* __restrict__ w, const int32_t* __restrict__ perm, T* __restrict__ out,
-                                   int Cout, int Cin, int ntaps, int KC16, long long total) {
+                                   int Cout, int Cin, int ntaps, int KC16, long long total, int Cw) {
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)blockDim.x * gridDim.x) {
         const int e = (int)(idx & 7);
@@ -279,7 +282,9 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, const int32_t* _
         const int co = nb * 32 + (lane & 31);
         const int ci = kc16 * 16 + (lane >> 5) * 8 + e;
         float v = 0.f;
-        if (co < Cout && ci < Cin && tap < ntaps) {
+        if (DGRAD) {
+            if (co < Cout && ci < Cw && tap < ntaps) v = w[((size_t)ci * Cout + co) * ntaps + (ntaps - 1 - tap)];
+        } else if (co < Cout && ci < Cin && tap < ntaps) {
             const int cs = perm ? perm[ci] : ci;
             v = w[((size_t)co * Cin + cs) * ntaps + tap];
         }
@@ -542,9 +547,28 @@ int step_conv_pack_weight(const float* w, int Cout, int Cin, int kd, int kh, int
     const int KC16 = ceil_div(Cin, CK) * 2, ntaps = kd * kh * kw;
     const dim3 grid(flat_grid(total, 256));
     switch (dtype) {
-        case STEP_F32: STEP_LAUNCH((pack_weight_kernel<float>), grid, dim3(256), stream, w, perm, (float*)packed, Cout, Cin, ntaps, KC16, total); break;
-        case STEP_BF16: STEP_LAUNCH((pack_weight_kernel<bf16_t>), grid, dim3(256), stream, w, perm, (bf16_t*)packed, Cout, Cin, ntaps, KC16, total); break;
-        case STEP_F16: STEP_LAUNCH((pack_weight_kernel<f16_t>), grid, dim3(256), stream, w, perm, (f16_t*)packed, Cout, Cin, ntaps, KC16, total); break;
+        case STEP_F32: STEP_LAUNCH((pack_weight_kernel<float, false>), grid, dim3(256), stream, w, perm, (float*)packed, Cout, Cin, ntaps, KC16, total, 0); break;
+        case STEP_BF16: STEP_LAUNCH((pack_weight_kernel<bf16_t, false>), grid, dim3(256), stream, w, perm, (bf16_t*)packed, Cout, Cin, ntaps, KC16, total, 0); break;
+        case STEP_F16: STEP_LAUNCH((pack_weight_kernel<f16_t, false>), grid, dim3(256), stream, w, perm, (f16_t*)packed, Cout, Cin, ntaps, KC16, total, 0); break;
+        default: return STEP_E_DTYPE;
+    }
+    return STEP_LAUNCH_CHECK();
+}
+
+int step_conv_pack_weight_dgrad(const float* w, int Cout, int Cin, int kd, int kh, int kw, int dtype, int cin_pad, void* packed,
+                                step_stream_t stream) {
+    // w [Cout][Cin][taps] = the FORWARD weight; the packed image is the one step_conv_forward wants for the conv
+    // gy [.., cin_pad >= Cout] -> gx [.., Cin]
+    if (Cout <= 0 || Cin <= 0 || kd <= 0 || kh <= 0 || kw <= 0 || cin_pad < Cout) return STEP_E_SHAPE;
+    if (!(kd & 1) || !(kh & 1) || !(kw & 1)) return STEP_E_UNSUPPORTED;       // SAME padding is symmetric for odd kernels only
+    if (!w || !packed) return STEP_E_NULL;
+    const long long total = (long long)step_conv_packed_elems(Cin, cin_pad, kd, kh, kw);
+    const int KC16 = ceil_div(cin_pad, CK) * 2, ntaps = kd * kh * kw;
+    const dim3 grid(flat_grid(total, 256));
+    switch (dtype) {
+        case STEP_F32: STEP_LAUNCH((pack_weight_kernel<float, true>), grid, dim3(256), stream, w, nullptr, (float*)packed, Cin, cin_pad, ntaps, KC16, total, Cout); break;
+        case STEP_BF16: STEP_LAUNCH((pack_weight_kernel<bf16_t, true>), grid, dim3(256), stream, w, nullptr, (bf16_t*)packed, Cin, cin_pad, ntaps, KC16, total, Cout); break;
+        case STEP_F16: STEP_LAUNCH((pack_weight_kernel<f16_t, true>), grid, dim3(256), stream, w, nullptr, (f16_t*)packed, Cin, cin_pad, ntaps, KC16, total, Cout); break;
         default: return STEP_E_DTYPE;
     }
     return STEP_LAUNCH_CHECK();
@@ -626,7 +650,7 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
 }
 
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 9; }
+int step_abi_version(void) { return 10; }
 
 }  // extern "C"
 

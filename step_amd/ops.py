@@ -87,6 +87,18 @@ def pack_conv_weight(w, dtype, perm=None):
     return out
 
 
+def pack_conv_weight_dgrad(w, dtype, cin_pad):
+    """Packed weight of the data-gradient conv (taps flipped, channel roles swapped, input channels padded to cin_pad) from
+    the forward weight w [Cout, Cin, kd, kh, kw] in one kernel."""
+    L = _lib.lib()
+    w = w.detach().contiguous().float()
+    Cout, Cin, kd, kh, kw = w.shape
+    out = torch.empty(L.step_conv_packed_elems(Cin, cin_pad, kd, kh, kw), dtype=dtype, device=w.device)
+    _capi.check(L.step_conv_pack_weight_dgrad(_lib.dptr(w), Cout, Cin, kd, kh, kw, DT[dtype], cin_pad, _lib.dptr(out),
+                                              _lib.stream_ptr(w.device)), "step_conv_pack_weight_dgrad")
+    return out
+
+
 def pack_stem_weight(w, dtype):
     L = _lib.lib()
     w = w.detach().contiguous().float()

@@ -441,6 +441,25 @@ def case_adam_flat(bk, golden):
                                  0, bk.stream) == 0                                       # empty arena: no launch
 
 
+def case_pack_weight_dgrad(bk, golden):
+    """step_conv_pack_weight_dgrad == step_conv_pack_weight of the flipped / transposed / zero-padded weight, bit for bit."""
+    rs = np.random.RandomState(17)
+    for (Cout, Cin, k, pad) in ((40, 24, (3, 3, 3), 0), (12, 72, (1, 1, 1), 4), (20, 33, (1, 3, 3), 12)):
+        w = rs.randn(Cout, Cin, *k).astype(np.float32)
+        wt = np.ascontiguousarray(np.flip(w, (2, 3, 4)).transpose(1, 0, 2, 3, 4))           # [Cin, Cout, ...]
+        wt = np.concatenate([wt, np.zeros((Cin, pad) + k, np.float32)], 1) if pad else wt
+        for dt in (F32, BF16, F16):
+            n = bk.lib.step_conv_packed_elems(Cin, Cout + pad, *k)
+            a = bk.dev(np.zeros(n, np.float32 if dt == F32 else np.uint16))
+            b = bk.dev(np.zeros(n, np.float32 if dt == F32 else np.uint16))
+            assert bk.lib.step_conv_pack_weight(bk.dev(np.ascontiguousarray(wt)).ptr, Cin, Cout + pad, k[0], k[1], k[2], dt, None, a.ptr, bk.stream) == 0
+            assert bk.lib.step_conv_pack_weight_dgrad(bk.dev(w).ptr, Cout, Cin, k[0], k[1], k[2], dt, Cout + pad, b.ptr, bk.stream) == 0
+            assert np.array_equal(a.get(), b.get()), (Cout, Cin, k, dt)
+    w = bk.dev(np.zeros((4, 4, 1, 2, 2), np.float32))
+    assert bk.lib.step_conv_pack_weight_dgrad(w.ptr, 4, 4, 1, 2, 2, F32, 4, w.ptr, bk.stream) < 0       # even kernel
+    assert bk.lib.step_conv_pack_weight_dgrad(w.ptr, 4, 4, 1, 1, 1, F32, 3, w.ptr, bk.stream) < 0       # cin_pad < Cout
+
+
 def case_act_grad(bk, golden):
     """g = gy * (y > 0) * scale[c] against the torch element-wise chain of the unit's backward (cast, mask, multiply, cast):
     bit-exact in fp32 and after the rounding to the 16-bit activation type; both outputs, either alone, no relu / no scale."""
