@@ -53,6 +53,7 @@ class _ConvUnitFn(torch.autograd.Function):
         y = unit._launch(x.detach(), relu, None if res is None else res.detach(), None)
         ctx.save_for_backward(x, w_eff, scale, shift, y, res)
         ctx.relu = relu
+        ctx.unit = unit
         return y
 
     @staticmethod
@@ -78,6 +79,22 @@ class _ConvUnitFn(torch.autograd.Function):
             fused = ops.act_grad(y, gy, scale, ctx.relu, want_f32=need_w, want_act=need_x) if (need_x or need_w) else (None, None)
             if fused is not None:
                 g32, gact = fused
+                target = _wgrad_target(ctx.unit, w_eff) if (need_w and WGRAD_INTO_GRAD and x.is_cuda and ops.PROFILE is None) else None
+                if target is not None:
+                    # opt-in (wgrad_into_grad()): the weight gradient is ACCUMULATED straight into the parameter's .grad (the
+                    # FlatAdam arena) by the kernel's own atomics, on a side stream that nobody waits for until
+                    # wgrad_sync() -- no clear, no autograd add, and the latency-bound weight-gradient launches overlap the
+                    # rest of the backward pass instead of sitting in its critical path
+                    main = torch.cuda.current_stream(x.device)
+                    side = _side_streams(x.device)[0]
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        ops.conv_wgrad(x, g32, w_eff.shape[0], k, into=target)
+                    x.record_stream(side)
+                    g32.record_stream(side)
+                    _PENDING[0] = True
+                    gx = _ConvUnitFn._dgrad(gact, w_eff, x.dtype, k) if need_x else None
+                    return gx, None, None, None, None, None, None
                 if need_x and need_w and WGRAD_SIDE_STREAM and x.is_cuda and x.dtype == torch.float32 and ops.PROFILE is None:
                     # the two gradients are independent: the weight gradient (many of them latency-bound launches that fill a
                     # fraction of the chip) runs on a side stream beside the data-gradient conv.  Measured on the C4 step:
@@ -372,6 +389,48 @@ class Mixed(nn.Module):
         main.wait_stream(s2)
         p.record_stream(main)
         return out
+
+
+WGRAD_INTO_GRAD = False        # see wgrad_into_grad()
+_PENDING = [False]
+
+
+def _wgrad_target(unit, w_eff):
+    """The dense fp32 .grad of the unit's weight parameter when the effective weight IS that parameter (no channel slice /
+    permutation) and a gradient buffer exists; else None (the caller returns the gradient through autograd)."""
+    if unit.cin_slice is not None or unit.perm is not None:
+        return None
+    w = unit.weight_fn()
+    g = w.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.numel() != w_eff.numel() or not w.requires_grad:
+        return None
+    return g
+
+
+class wgrad_into_grad:
+    """Context manager for a training step whose optimizer owns persistent gradient buffers (step_amd.optim.FlatAdam):
+    inside it the conv units add their weight gradients into `weight.grad` directly, asynchronously on a side stream.
+    Leaving the context (or calling wgrad_sync()) makes the current stream wait for them.  Not for torch.autograd.grad()
+    or double backward: the weight gradient bypasses autograd."""
+
+    def __enter__(self):
+        global WGRAD_INTO_GRAD
+        self.prev, WGRAD_INTO_GRAD = WGRAD_INTO_GRAD, True
+        return self
+
+    def __exit__(self, *exc):
+        global WGRAD_INTO_GRAD
+        WGRAD_INTO_GRAD = self.prev
+        wgrad_sync()
+        return False
+
+
+def wgrad_sync():
+    """Order every weight gradient launched on the side stream before what the current stream does next."""
+    if _PENDING[0] and torch.cuda.is_available():
+        for dev_key, streams in list(_SIDE.items()):
+            torch.cuda.current_stream(torch.device(dev_key[0], dev_key[1])).wait_stream(streams[0])
+        _PENDING[0] = False
 
 
 BRANCH_STREAMS = True          # run the independent Inception branches on side streams (inference path)

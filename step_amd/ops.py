@@ -138,17 +138,23 @@ def conv_forward(x, w_packed, Cout, k, scale=None, shift=None, relu=True, res=No
     return out
 
 
-def conv_wgrad(x, gy, Cout, k):
+def conv_wgrad(x, gy, Cout, k, into=None):
     """Weight gradient of the stride-1 SAME conv: x channels-last [N,D,H,W,Cin] (any storage dtype, may be a channel
     slice), gy fp32 channels-last [N,D,H,W,Cout] (gradient w.r.t. the conv output before the affine epilogue).
-    Returns fp32 [Cout, Cin, kd, kh, kw]."""
+    Returns fp32 [Cout, Cin, kd, kh, kw]; with `into` (a dense fp32 tensor of that many elements, e.g. the parameter's
+    .grad) the result is ACCUMULATED into it instead (the kernel's accumulate mode: no clear, no separate add)."""
     L = _lib.lib()
     N, D, H, W, Cin = x.shape
     if gy.dtype != torch.float32:
         gy = gy.float()
     if not gy.is_contiguous():
         gy = gy.contiguous()
-    dw = torch.empty((Cout, Cin) + tuple(k), dtype=torch.float32, device=x.device)
+    if into is not None:
+        if into.dtype != torch.float32 or not into.is_contiguous() or into.numel() != Cout * Cin * k[0] * k[1] * k[2]:
+            raise RuntimeError("step_amd: conv_wgrad(into=...) wants a dense fp32 tensor of Cout*Cin*taps elements")
+        dw = into
+    else:
+        dw = torch.empty((Cout, Cin) + tuple(k), dtype=torch.float32, device=x.device)
     d = _capi.ConvDesc(dtype=_dt(x), N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2],
                        x_cstride=_chan_slice(x), x_coff=0, y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=0,
                        split=0, y2_cstride=0, y2_coff=0)
@@ -160,8 +166,8 @@ def conv_wgrad(x, gy, Cout, k):
                      2.0 * pix * Cout * Cin * k[0] * k[1] * k[2],
                      pix * (Cin * x.element_size() + Cout * 4) + 4.0 * Cout * Cin * k[0] * k[1] * k[2])
     with prof:
-        _capi.check(L.step_conv_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(dw), 0, _lib.stream_ptr(x.device)),
-                    "step_conv_wgrad")
+        _capi.check(L.step_conv_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(dw), int(into is not None),
+                                      _lib.stream_ptr(x.device)), "step_conv_wgrad")
     return dw
 
 

@@ -103,6 +103,8 @@ class FlatAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        from .backbone import wgrad_sync
+        wgrad_sync()                                             # weight gradients still in flight on the side stream
         self._gather_stray_grads()
         self._refresh_tables()
         self.step_count += 1

@@ -9,6 +9,7 @@ import torch
 from . import BaseNet, ContextNet, ROINet, TwoBranchNet
 from . import dist as sdist
 from .driver import GraphedInference, inference, postprocess
+from .backbone import wgrad_into_grad
 from .optim import FlatAdam
 from .selection import train_select
 from .driver import _flat_tubes
@@ -131,7 +132,8 @@ class C4TrainStep:
             pooled = pooled.reshape(self.batch * self.K, Tl, *pooled.shape[1:])
             o = head(pooled, context_feat=cx[self.clip_of][:, :, t0:t0 + Tl], tubes=flat, targets=self.targets)
             loss = loss + o[4].mean() + 5 * o[5].mean() + o[6].mean()
-        loss.backward()
+        with wgrad_into_grad():                                   # weight gradients go straight into FlatAdam's arena
+            loss.backward()
         return loss
 
     def step(self):
@@ -190,7 +192,8 @@ class C4SelectTrainStep(C4TrainStep):
             pooled = pooled.reshape(flat.shape[0], Tl, *pooled.shape[1:])
             o = self.heads[i - 1](pooled, context_feat=cx[clip_of][:, :, t0:t0 + Tl], tubes=flat, targets=targets)
             loss = loss + o[4].mean() + a.lambda_reg * o[5].mean() + a.lambda_neighbor * o[6].mean()
-        loss.backward()
+        with wgrad_into_grad():
+            loss.backward()
         scale = sdist.allreduce_flat(self.opt.flat_grad)
         self.opt.step(grad_scale=scale, zero_grad=True)
         self.loss = loss.detach()

@@ -323,6 +323,40 @@ def case_flat_adam_matches_torch(dev, golden):
     assert o3.step_count == 3 and rel(np_(o3.exp_avg), np_(o.exp_avg)) < 1e-5
 
 
+def case_wgrad_into_grad_matches_autograd(dev, golden):
+    """backbone.wgrad_into_grad(): weight gradients accumulated straight into .grad on a side stream equal the ones autograd
+    delivers (same kernels, same operands; only the fp32 atomics' order differs), they ADD to what .grad already holds, and
+    parameters the shortcut does not cover (biases, permuted / sliced weights) still arrive through autograd."""
+    from step_amd import backbone
+    g = golden("head_golden")
+    net = fill(step_amd.TwoBranchNet(cfg()), "det0.").to(dev)
+    net.set_device(dev)
+    net.train()
+    pf = R.fill_tensor("golden.det.pooled3", (2, 3, 832, 7, 7), "feat").to(dev)
+    cx = R.fill_tensor("golden.det.ctx3", (2, 1024, 3, 1, 1), "feat").to(dev)
+    tubes, targets = torch.from_numpy(g["loss_tubes"]).to(dev), torch.from_numpy(g["loss_targets"]).to(dev)
+
+    def loss():
+        o = net(pf, context_feat=cx, tubes=tubes, targets=targets)
+        return o[4].mean() + 5.0 * o[5].mean() + o[6].mean()
+
+    loss().backward()
+    ref = {k: p.grad.clone() for k, p in net.named_parameters() if p.requires_grad}
+    for p in net.parameters():
+        if p.requires_grad:
+            p.grad = torch.ones_like(p)                         # persistent buffers holding something already
+    with backbone.wgrad_into_grad():
+        loss().backward()
+    direct = 0
+    for k, p in net.named_parameters():
+        if not p.requires_grad:
+            continue
+        a, b = np_(p.grad).astype(np.float64) - 1.0, np_(ref[k]).astype(np.float64)
+        e = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+        assert e < 1e-4, (k, e)
+    assert not backbone._PENDING[0] and not backbone.WGRAD_INTO_GRAD
+
+
 def case_training_iteration_with_selection(dev, golden):
     """The whole iteration of train.py:257-348 on one AVA-shaped clip (step_amd.workloads.C4SelectTrainStep): no-grad
     inference, train_select between the steps, three heads, backward, fused Adam.  Checks what is size-independent: per step
@@ -409,4 +443,4 @@ def case_c2_full_size_properties(dev, golden):
 CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_golden", "case_context_golden",
              "case_twobranch_T3_and_losses_golden", "case_roinet_layouts", "case_training_step_matches_torch_autograd",
              "case_flat_adam_matches_torch"]
-GPU_CASES = CPU_CASES + ["case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_inference_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
+GPU_CASES = CPU_CASES + ["case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_inference_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
