@@ -73,10 +73,12 @@ class _ConvUnitFn(torch.autograd.Function):
         x, w_eff, scale, shift, y, res = ctx.saved_tensors
         k = tuple(w_eff.shape[2:])
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        if not (ctx.needs_input_grad[2] or ctx.needs_input_grad[3] or (res is not None and ctx.needs_input_grad[4])):
+        need_res = res is not None and ctx.needs_input_grad[4]
+        if not (ctx.needs_input_grad[2] or ctx.needs_input_grad[3] or (need_res and (scale is not None or res.dtype != x.dtype))):
             # frozen affine, no residual (every backbone / Inception unit): only the conv's own gradients are wanted, so the
             # cast / ReLU mask / scale / cast chain is ONE HIP pass producing the wgrad operand (fp32) and the dgrad operand
-            fused = ops.act_grad(y, gy, scale, ctx.relu, want_f32=need_w, want_act=need_x) if (need_x or need_w) else (None, None)
+            # (a residual input without an affine -- the Bottlenecks' third conv -- receives the same masked gradient as the conv)
+            fused = ops.act_grad(y, gy, scale, ctx.relu, want_f32=need_w, want_act=need_x or need_res) if (need_x or need_w or need_res) else (None, None)
             if fused is not None:
                 g32, gact = fused
                 target = _wgrad_target(ctx.unit, w_eff) if (need_w and WGRAD_INTO_GRAD and x.is_cuda and ops.PROFILE is None) else None
@@ -94,7 +96,7 @@ class _ConvUnitFn(torch.autograd.Function):
                     g32.record_stream(side)
                     _PENDING[0] = True
                     gx = _ConvUnitFn._dgrad(gact, w_eff, x.dtype, k) if need_x else None
-                    return gx, None, None, None, None, None, None
+                    return gx, None, None, None, (gact if need_res else None), None, None
                 if need_x and need_w and WGRAD_SIDE_STREAM and x.is_cuda and x.dtype == torch.float32 and ops.PROFILE is None:
                     # the two gradients are independent: the weight gradient (many of them latency-bound launches that fill a
                     # fraction of the chip) runs on a side stream beside the data-gradient conv.  Measured on the C4 step:
@@ -108,10 +110,10 @@ class _ConvUnitFn(torch.autograd.Function):
                     gx = _ConvUnitFn._dgrad(gact, w_eff, x.dtype, k)
                     main.wait_stream(side)
                     gw.record_stream(main)
-                    return gx, gw, None, None, None, None, None
+                    return gx, gw, None, None, (gact if need_res else None), None, None
                 gx = _ConvUnitFn._dgrad(gact, w_eff, x.dtype, k) if need_x else None
                 gw = ops.conv_wgrad(x, g32, w_eff.shape[0], k).to(w_eff.dtype) if need_w else None
-                return gx, gw, None, None, None, None, None
+                return gx, gw, None, None, (gact if need_res else None), None, None
         g = gy.float()
         if ctx.relu:
             g = g * (y > 0).to(g.dtype)
