@@ -376,6 +376,37 @@ def selection_main():
     g["edge_t1"], g["edge_t2"] = t1, t2
     with np.errstate(all="ignore"):
         g["edge_iou"] = ref_tu.compute_tube_iou(t1, t2)
+    # select_proposals on its own: more ground truths than proposals, duplicate proposals, nothing above the threshold,
+    # no negatives wanted, scores given / derived from the IoUs, every sampling mode
+    rs = np.random.RandomState(77)
+    edge = []
+    for ei, (G, A, thr, max_pos, sampling, neg_ratio, with_scores) in enumerate((
+            (7, 3, 0.2, 5, "random", 2, False), (2, 12, 0.2, 5, "softmax", 2, True), (3, 10, 0.99, 2, "uniform", 1, True),
+            (1, 6, 0.1, 5, "random", 0, False), (4, 40, 0.35, 3, "softmax", 3, False), (5, 9, 0.5, 1, "uniform", 2, True))):
+        gt = np.zeros((G, 1, 4), np.float32)
+        xy = rs.uniform(0, 250, (G, 2)); wh = rs.uniform(40, 150, (G, 2))
+        gt[:, 0] = np.concatenate([xy, xy + wh], 1)
+        an = np.zeros((A, 1, 4), np.float32)
+        for a_ in range(A):
+            src = gt[rs.randint(0, G), 0] if rs.rand() < 0.6 else np.concatenate([rs.uniform(0, 300, 2), rs.uniform(300, 400, 2)])
+            an[a_, 0] = src + rs.uniform(-20, 20, 4)
+        if ei == 1:
+            an[3] = an[2]                                               # duplicates: ties in every ranking
+            an[4] = an[2]
+        sc = rs.rand(A).astype(np.float32) if with_scores else None
+        pyrandom.seed(500 + ei)
+        np.random.seed(500 + ei)
+        with np.errstate(all="ignore"):
+            pos, neg, ious = ref_utils.select_proposals(gt.copy(), an.copy(), None if sc is None else sc.copy(), thr, max_pos, sampling, neg_ratio)
+        g["e%d_gt" % ei], g["e%d_an" % ei] = gt, an
+        if sc is not None:
+            g["e%d_scores" % ei] = sc
+        g["e%d_cfg" % ei] = np.asarray([thr, max_pos, neg_ratio], np.float64)
+        g["e%d_sampling" % ei] = np.asarray(sampling)
+        g["e%d_pos" % ei] = np.asarray([(int(a_), int(b_)) for a_, b_ in pos], np.int64).reshape(-1, 2)
+        g["e%d_neg" % ei] = np.asarray([(int(a_), int(b_)) for a_, b_ in neg], np.int64).reshape(-1, 2)
+        g["e%d_ious" % ei] = ious
+    g["n_edge"] = np.asarray(6)
     np.savez_compressed(os.path.join(OUT, "selection_golden.npz"), **g)
     print("selection_golden ok", len(g), "arrays")
 

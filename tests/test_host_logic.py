@@ -63,3 +63,36 @@ def test_tube_iou_edge_cases_match_reference():
     assert np.array_equal(out, g["edge_iou"], equal_nan=True)
     with pytest.raises(AssertionError):
         S.tube_iou(np.zeros((1, 2, 4), np.float32), np.zeros((1, 3, 4), np.float32))
+
+
+@pytest.mark.parametrize("ei", range(6))
+def test_select_proposals_edge_cases_match_reference(ei):
+    """select_proposals (utils/utils.py:341-423) alone, same seeds: more ground truths than proposals, duplicate proposals,
+    nothing above the threshold, neg_ratio 0, given / IoU-derived scores, the three sampling modes -- same (gt, proposal)
+    pairs in the same order, same IoU table."""
+    import random
+
+    from step_amd import selection as S
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "selection_golden.npz"))
+    thr, max_pos, neg_ratio = g["e%d_cfg" % ei]
+    sc = g["e%d_scores" % ei] if ("e%d_scores" % ei) in g.files else None
+    random.seed(500 + ei)
+    np.random.seed(500 + ei)
+    pos, neg, ious = S.select_proposals(g["e%d_gt" % ei], g["e%d_an" % ei], sc, float(thr), int(max_pos), str(g["e%d_sampling" % ei]),
+                                        int(neg_ratio))
+    assert np.array_equal(np.asarray(pos, np.int64).reshape(-1, 2), g["e%d_pos" % ei])
+    assert np.array_equal(np.asarray(neg, np.int64).reshape(-1, 2), g["e%d_neg" % ei])
+    assert np.array_equal(ious, g["e%d_ious" % ei], equal_nan=True)
+
+
+def test_flat_adam_refuses_what_it_cannot_run():
+    """No CPU fallback and no silent approximation: CPU parameters, non-fp32 masters and per-group betas raise."""
+    import torch
+    from step_amd import FlatAdam
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        FlatAdam([torch.nn.Parameter(torch.zeros(8))], lr=1e-3)
+    with pytest.raises(RuntimeError, match="fp32 master"):
+        FlatAdam([torch.nn.Parameter(torch.zeros(8, dtype=torch.bfloat16))], lr=1e-3)
+    a, b = torch.nn.Parameter(torch.zeros(8)), torch.nn.Parameter(torch.zeros(8))
+    with pytest.raises(ValueError, match="betas"):
+        FlatAdam([{"params": [a]}, {"params": [b], "betas": (0.5, 0.9)}], lr=1e-3)
