@@ -323,6 +323,35 @@ def case_flat_adam_matches_torch(dev, golden):
     assert o3.step_count == 3 and rel(np_(o3.exp_avg), np_(o.exp_avg)) < 1e-5
 
 
+def case_wgrad_into_and_targets(dev, golden):
+    """ops.conv_wgrad(into=...) adds to what the buffer holds (the kernel's accumulate mode) and refuses buffers of the wrong
+    kind; backbone._wgrad_target only offers a parameter's .grad when the effective weight IS the parameter."""
+    from step_amd import backbone, ops
+    torch.manual_seed(2)
+    x = torch.randn(1, 2, 5, 6, 8).to(dev)
+    gy = torch.randn(1, 2, 5, 6, 16).to(dev)
+    ref = ops.conv_wgrad(x, gy, 16, (1, 3, 3))
+    buf = torch.full((16, 8, 1, 3, 3), 2.0, device=dev)
+    out = ops.conv_wgrad(x, gy, 16, (1, 3, 3), into=buf)
+    assert out is buf and rel(np_(buf) - 2.0, np_(ref)) < 1e-5
+    for bad in (torch.zeros(16, 8, 1, 3, 3, dtype=torch.float64, device=dev), torch.zeros(16, 8, 1, 3, 2, device=dev),
+                torch.zeros(16, 16, 1, 3, 3, device=dev)[:, ::2]):
+        try:
+            ops.conv_wgrad(x, gy, 16, (1, 3, 3), into=bad)
+        except RuntimeError:
+            continue
+        raise AssertionError("conv_wgrad(into=...) accepted a %s %s buffer" % (bad.dtype, tuple(bad.shape)))
+    conv = torch.nn.Conv3d(8, 16, (1, 3, 3), bias=False).to(dev)
+    plain = backbone.ConvUnit(lambda: conv.weight, (1, 3, 3))
+    sliced = backbone.ConvUnit(lambda: conv.weight, (1, 3, 3), cin_slice=(0, 4))
+    assert backbone._wgrad_target(plain, plain.effective_weight()) is None          # no gradient buffer yet
+    conv.weight.grad = torch.zeros_like(conv.weight)
+    assert backbone._wgrad_target(plain, plain.effective_weight()) is conv.weight.grad
+    assert backbone._wgrad_target(sliced, sliced.effective_weight()) is None        # a channel slice goes through autograd
+    conv.weight.requires_grad_(False)
+    assert backbone._wgrad_target(plain, plain.effective_weight()) is None
+
+
 def case_wgrad_into_grad_matches_autograd(dev, golden):
     """backbone.wgrad_into_grad(): weight gradients accumulated straight into .grad on a side stream equal the ones autograd
     delivers (same kernels, same operands; only the fp32 atomics' order differs), they ADD to what .grad already holds, and
@@ -442,5 +471,5 @@ def case_c2_full_size_properties(dev, golden):
 
 CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_golden", "case_context_golden",
              "case_twobranch_T3_and_losses_golden", "case_roinet_layouts", "case_training_step_matches_torch_autograd",
-             "case_flat_adam_matches_torch"]
+             "case_flat_adam_matches_torch", "case_wgrad_into_and_targets"]
 GPU_CASES = CPU_CASES + ["case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_inference_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
