@@ -6,8 +6,9 @@
  * extension `external.maskrcnn_benchmark.roi_layers._C`
  *     (/root/reference/external/maskrcnn_benchmark/csrc/vision.cpp:30-36)
  * and the cuDNN calls behind torch.nn.Conv3d/BatchNorm3d/MaxPool3d/AvgPool3d/Conv2d/Linear that
- * models/i3dpt.py and models/two_branch.py lean on.  INTEGRATION.md shows the binding a
- * maintainer of the reference adds.
+ * models/i3dpt.py and models/two_branch.py lean on -- forward, and for the training step (train.py:257-348) their
+ * backward (data / weight gradients, pool and activation gradients) and the Adam update.  INTEGRATION.md shows the
+ * binding a maintainer of the reference adds.
  *
  * Conventions
  *   - plain C: raw DEVICE pointers, explicit sizes, a hipStream_t passed as void*.  No torch types.
