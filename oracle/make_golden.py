@@ -310,11 +310,11 @@ def selection_cases():
     cases = []
     for ci, (seed, sampling, topk, neg_ratio, max_pos, mode) in enumerate((
             (1, "softmax", -1, 2, 5, "predict"), (2, "random", 300, 2, 5, "predict"), (3, "uniform", 120, 1, 2, "predict"),
-            (4, "softmax", -1, 2, 5, "mean"), (5, "softmax", 60, 3, 1, "predict"))):
+            (4, "softmax", -1, 2, 5, "mean"), (5, "softmax", 60, 3, 1, "predict"), (6, "random", -1, 2, 4, "extrapolate"))):
         rs = np.random.RandomState(1000 + seed)
         targets = []
         for b in range(2):
-            G = int(rs.randint(1, 5)) if ci != 4 else 7
+            G = int(rs.randint(1, 5)) if ci != 4 else 7                  # (case 4: more ground truths than max_pos_num)
             t = np.zeros((G, 3, 4 + nc), np.float32)
             for gidx in range(G):
                 a = anchors[rs.randint(0, 34)] + rs.uniform(-25, 25, 4).astype(np.float32)
@@ -407,13 +407,63 @@ def selection_main():
         g["e%d_neg" % ei] = np.asarray([(int(a_), int(b_)) for a_, b_ in neg], np.int64).reshape(-1, 2)
         g["e%d_ious" % ei] = ious
     g["n_edge"] = np.asarray(6)
+    g["n_cases"] = np.asarray(len(cases))
     np.savez_compressed(os.path.join(OUT, "selection_golden.npz"), **g)
     print("selection_golden ok", len(g), "arrays")
+
+
+def modes_main():
+    """tests/golden/inference_modes_golden.npz: the reference's inference() (utils/utils.py:15-131) with temporal_mode
+    "extrapolate" and "mean" (the tube extension between steps 2 and 3 without the head's neighbour regressions), same
+    synthetic conv_feat / heads / 11 tubes as inference_golden.npz."""
+    models, ref_utils, _, _ = import_reference()
+    from oracle import i3d_ref as R
+
+    args = cfg()
+    ctx = models.ContextNet(args)
+    fill_module(ctx)
+    ctx.set_device("cpu")
+    ctx.eval()
+    nets = {"roi_net": models.ROINet("align", 7)}
+    for i in range(3):
+        d = models.TwoBranchNet(args)
+        fill_module(d, "det%d." % i)
+        d.set_device("cpu")
+        d.eval()
+        nets["det_net%d" % i] = d
+    anchors = R.anchors()
+    conv_feat = R.fill_tensor("golden.inf.feat", (2, 9, 832, 25, 25), "feat")
+    with torch.no_grad():
+        context = ctx(conv_feat)
+    g = {}
+    for mode in ("extrapolate", "mean"):
+        a = cfg(temporal_mode=mode)
+        tl = [np.tile((anchors[:11] * 400.0)[:, None, :], (1, 3, 1)).astype(np.float32) for _ in range(2)]
+        tl[1] = tl[1][::-1].copy()
+        with torch.no_grad():
+            history, traj = ref_utils.inference(a, conv_feat, context, nets, 3, [t.copy() for t in tl])
+        for i, h in enumerate(history):
+            g["%s_step%d_pred_prob" % (mode, i)] = h["pred_prob"].numpy()[:, 0]
+            g["%s_step%d_pred_loc" % (mode, i)] = h["pred_loc"].numpy()
+        g["%s_step1_proposals" % mode] = np.concatenate([t[0] for t in traj[1]], 0)      # the extended tubes fed to step 3
+    # extrapolate_tubes on its own
+    rs = np.random.RandomState(5)
+    import utils.tube_utils as ref_tu  # reference
+    t = (rs.uniform(0, 400, (7, 3, 4))).astype(np.float32)
+    t[0, :, 0] = 1.0; t[0, 1, 0] = 30.0                                                    # extrapolates below 0 / beyond 399
+    g["ext_in"] = t
+    g["ext_out_T3"] = ref_tu.extrapolate_tubes(t.copy(), 3)
+    g["ext_out_T6"] = ref_tu.extrapolate_tubes(np.tile(t, (1, 2, 1)).copy(), 6)
+    np.savez_compressed(os.path.join(OUT, "inference_modes_golden.npz"), **g)
+    print("inference_modes_golden ok", len(g), "arrays")
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "selection":
         selection_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "modes":
+        modes_main()
     else:
         main()
         selection_main()
+        modes_main()

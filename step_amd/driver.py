@@ -12,13 +12,13 @@ Differences from the reference's host glue (they do not change results):
     (tube_utils.py:84-88);
   * the ROI-pooled features are produced channels-last by the NHWC ROIAlign kernel straight from the
     channels-last backbone feature (no `.contiguous()` transpose of the slice, utils.py:48).
-Only temporal_mode == "predict" (what every shipped script uses) and "extrapolate"-free schedules
-are implemented here.
+All three temporal modes of the reference are implemented (utils.py:102-120): "predict" (every shipped script: the head's
+neighbour regressions extend the tube), "extrapolate" (linear, tube_utils.py:159-176) and "mean".
 """
 import numpy as np
 import torch
 
-from .tube_math import decode_coef, valid_tubes
+from .tube_math import extrapolate_tubes, decode_coef, valid_tubes
 
 
 def _flat_tubes(tubes_list, device, dtype=torch.float32):
@@ -40,8 +40,8 @@ def inference(args, conv_feat, context_feat, nets, exec_iter, tubes):
     conv_feat [B,T_all,C,H,W] (BaseNet output), context_feat [B,1024,T_all,1,1] or None,
     nets: {'roi_net': ROINet, 'det_net0': TwoBranchNet, ...}, tubes: list of [n_i,T,4] per clip.
     Returns (history, trajectory) like the reference."""
-    if getattr(args, "temporal_mode", "predict") != "predict":
-        raise NotImplementedError("step_amd.driver.inference implements temporal_mode='predict'")
+    if getattr(args, "temporal_mode", "predict") not in ("predict", "extrapolate", "mean"):
+        raise NotImplementedError("step_amd.driver.inference: temporal_mode %r" % (args.temporal_mode,))
     dev = conv_feat.device
     flat, nums = _flat_tubes(tubes, dev)
     clip_of = torch.as_tensor(np.repeat(np.arange(len(nums)), nums), device=dev)
@@ -80,7 +80,14 @@ def inference_flat(args, conv_feat, context_feat, nets, exec_iter, flat, nums, c
 
         # next step's proposals (utils.py:91-129), all clips at once
         if i < args.max_iter and args.NUM_CHUNKS[i + 1] == args.NUM_CHUNKS[i] + 2:
-            prop = torch.cat([pred_first, pred_loc, pred_last], dim=1)
+            mode = getattr(args, "temporal_mode", "predict")
+            if mode == "predict":
+                prop = torch.cat([pred_first, pred_loc, pred_last], dim=1)
+            elif mode == "extrapolate":
+                prop = extrapolate_tubes(pred_loc, args.T)
+            else:                                               # the tube's mean box on both sides (utils.py:116-120)
+                m = pred_loc.mean(dim=1, keepdim=True).expand(-1, args.T, -1)
+                prop = torch.cat([m, pred_loc, m], dim=1)
         else:
             prop = pred_loc
         prop = valid_tubes(prop, width=args.image_size[0], height=args.image_size[1])

@@ -11,13 +11,13 @@ exactly, because they decide WHICH tubes are trained on:
   two `np.random.choice(..., replace=False)`), so that with the same seeds the same proposals are selected
   (tests/golden/selection_golden.npz was recorded from the reference).
 
-Only `temporal_mode` "predict" (every shipped script) and "mean" are supported, like step_amd/driver.py.
+All three `temporal_mode`s ("predict": every shipped script; "extrapolate"; "mean") are supported, like step_amd/driver.py.
 """
 import random
 
 import numpy as np
 
-from .tube_math import valid_tubes
+from .tube_math import extrapolate_tubes, valid_tubes
 
 
 def box_iou(a, b):
@@ -139,7 +139,7 @@ def train_select(step, history, targets, tubes, args):
     (`history`: pred_prob [N,T,C], pred_loc [N,T,4], pred_first_loc / pred_last_loc [N,T,4], tubes_nums).  Every selected tube
     comes with one target row per loss frame [first neighbour, centre, last neighbour], each
     [x1,y1,x2,y2, cls flag, reg flag, class labels...]."""
-    if args.temporal_mode not in ("predict", "mean"):
+    if args.temporal_mode not in ("predict", "extrapolate", "mean"):
         raise NotImplementedError("temporal_mode %r" % (args.temporal_mode,))
     chunks, max_chunks = args.NUM_CHUNKS[step], args.NUM_CHUNKS[args.max_iter]
     T = args.T
@@ -194,6 +194,8 @@ def train_select(step, history, targets, tubes, args):
             if predict:
                 sel = np.concatenate((cand_first[rows_a].astype(np.float32).reshape(R, T, 4), sel,
                                       cand_last[rows_a].astype(np.float32).reshape(R, T, 4)), axis=1)
+            elif args.temporal_mode == "extrapolate":
+                sel = extrapolate_tubes(sel, T)
             else:
                 m = np.tile(np.mean(sel, axis=1, keepdims=True), (1, T, 1))
                 sel = np.concatenate((m, sel, m), axis=1)

@@ -68,6 +68,32 @@ def valid_tubes(tubes, width=400, height=400):
     return out.reshape(tubes.shape)
 
 
+def extrapolate_tubes(tubes, T=6, height=400, width=400):
+    """[n, Tl, 4] -> [n, Tl + 2T, 4]: T frames of linear extrapolation on either side, frame by frame from the two frames T
+    apart ((T/(T-1)) a - (1/(T-1)) b), then clamped to [0, width-1] x [0, height-1] (tube_utils.py:159-176; the reference calls
+    it with the default 400 x 400 whatever the image size).  numpy in -> numpy out (fp32), torch in -> torch out (same device,
+    element-wise kernels only: no host synchronisation)."""
+    is_np = isinstance(tubes, np.ndarray)
+    n, Tl = tubes.shape[0], tubes.shape[1]
+    if is_np:
+        new = np.zeros((n, Tl + 2 * T, tubes.shape[2]), dtype=np.float32)
+    else:
+        new = torch.zeros((n, Tl + 2 * T, tubes.shape[2]), dtype=torch.float32, device=tubes.device)
+    new[:, T:T + Tl] = tubes
+    L = Tl + 2 * T
+    for i in range(T):
+        new[:, L - T + i] = (T / (T - 1)) * new[:, L - T + i - 1] - (1 / (T - 1)) * new[:, L - T + i - T]
+        new[:, T - i - 1] = (T / (T - 1)) * new[:, T - i] - (1 / (T - 1)) * new[:, T - i + T - 1]
+    if is_np:
+        new[:, :, 0] = np.maximum(0, new[:, :, 0])
+        new[:, :, 1] = np.maximum(0, new[:, :, 1])
+        new[:, :, 2] = np.minimum(width - 1, new[:, :, 2])
+        new[:, :, 3] = np.minimum(height - 1, new[:, :, 3])
+        return new
+    lo = torch.stack((new[..., 0].clamp(min=0), new[..., 1].clamp(min=0), new[..., 2].clamp(max=width - 1), new[..., 3].clamp(max=height - 1)), -1)
+    return lo
+
+
 def generate_anchors(scales=(4.0 / 3.0, 2.0), overlaps=(5.0 / 6.0, 3.0 / 4.0)):
     """The initial tube grid of the default anchor mode "1": for each (scale, overlap) a regular grid of square boxes
     of side 1/scale with stride side*(1-overlap), normalised [x1, y1, x2, y2] -- 9 + 25 = 34 boxes

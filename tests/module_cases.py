@@ -196,6 +196,35 @@ def case_inference_golden(dev, golden, ntubes=11):
             assert e < 1e-3, (i, k, e)
 
 
+def case_inference_modes_golden(dev, golden):
+    """temporal_mode "extrapolate" and "mean" (utils/utils.py:108-120) against the reference's own inference(): the tubes fed to
+    step 3 are extended by linear extrapolation / by the tube's mean box instead of the head's neighbour regressions."""
+    g = golden("inference_modes_golden")
+    conv_feat = R.fill_tensor("golden.inf.feat", (2, 9, 832, 25, 25), "feat").to(dev)
+    conv_cl = conv_feat.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
+    ctxnet = fill(step_amd.ContextNet(cfg())).to(dev).eval()
+    nets = {"roi_net": step_amd.ROINet("align", 7)}
+    for i in range(3):
+        d = fill(step_amd.TwoBranchNet(cfg()), "det%d." % i).to(dev).eval()
+        d.set_device(dev)
+        nets["det_net%d" % i] = d
+    a = R.anchors()[:11] * 400.0
+    tl = [np.tile(a[:, None, :], (1, 3, 1)).astype(np.float32) for _ in range(2)]
+    tl[1] = tl[1][::-1].copy()
+    for mode in ("extrapolate", "mean"):
+        args = cfg(temporal_mode=mode)
+        with torch.no_grad():
+            hist, traj = inference(args, conv_cl, ctxnet(conv_cl), nets, 3, tl)
+        assert tuple(traj[1][0].shape) == (22, 9, 4)
+        e = rel(np_(traj[1][0]), g["%s_step1_proposals" % mode])
+        assert e < 1e-3, (mode, "proposals", e)
+        for i, h in enumerate(hist):
+            for k, ref in (("pred_prob", g["%s_step%d_pred_prob" % (mode, i)]), ("pred_loc", g["%s_step%d_pred_loc" % (mode, i)])):
+                got = np_(h[k][:, 0]) if k == "pred_prob" else np_(h[k])
+                e = rel(got, ref)
+                assert e < 1e-3, (mode, i, k, e)
+
+
 def case_inference_golden_34(dev, golden):
     case_inference_golden(dev, golden, 34)
 
@@ -472,4 +501,4 @@ def case_c2_full_size_properties(dev, golden):
 CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_golden", "case_context_golden",
              "case_twobranch_T3_and_losses_golden", "case_roinet_layouts", "case_training_step_matches_torch_autograd",
              "case_flat_adam_matches_torch", "case_wgrad_into_and_targets"]
-GPU_CASES = CPU_CASES + ["case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_inference_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
+GPU_CASES = CPU_CASES + ["case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]

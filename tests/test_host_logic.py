@@ -24,12 +24,13 @@ def _selection_args(g, ci):
               selection_sampling=str(g["c%d_sampling" % ci]), temporal_mode=str(g["c%d_mode" % ci]))
 
 
-@pytest.mark.parametrize("ci", range(5))
+@pytest.mark.parametrize("ci", range(6))
 def test_train_select_matches_reference(ci):
     """step_amd.selection.train_select against what the reference's train_select (utils/utils.py:135-339) returned for the
     same inputs and the same `random` / `numpy.random` seeds (oracle/make_golden.py selection): same tubes selected, in the
     same order, bit for bit, with the same target rows -- all three steps (initial proposals; refined tubes; extended tubes
-    with neighbour targets), softmax / random / uniform sampling, top-k, score ties, an invalid box."""
+    with neighbour targets), softmax / random / uniform sampling, top-k, score ties, an invalid box; temporal modes predict,
+    mean and extrapolate."""
     import random
 
     from step_amd import selection as S
@@ -96,3 +97,18 @@ def test_flat_adam_refuses_what_it_cannot_run():
     a, b = torch.nn.Parameter(torch.zeros(8)), torch.nn.Parameter(torch.zeros(8))
     with pytest.raises(ValueError, match="betas"):
         FlatAdam([{"params": [a]}, {"params": [b], "betas": (0.5, 0.9)}], lr=1e-3)
+
+
+def test_extrapolate_tubes_matches_reference():
+    """tube_utils.extrapolate_tubes (utils/tube_utils.py:159-176), numpy and torch forms, bit for bit -- including the clamps
+    to [0, 399] the reference applies whatever the image size."""
+    import torch
+    from step_amd.tube_math import extrapolate_tubes
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "inference_modes_golden.npz"))
+    t = g["ext_in"]
+    assert np.array_equal(extrapolate_tubes(t.copy(), 3), g["ext_out_T3"])
+    assert np.array_equal(extrapolate_tubes(np.tile(t, (1, 2, 1)), 6), g["ext_out_T6"])
+    assert np.array_equal(extrapolate_tubes(torch.from_numpy(t), 3).numpy(), g["ext_out_T3"])
+    assert np.array_equal(extrapolate_tubes(torch.from_numpy(np.tile(t, (1, 2, 1))), 6).numpy(), g["ext_out_T6"])
+    r = g["ext_out_T3"]                                          # only the near corner is clamped below, the far one above
+    assert r[..., :2].min() == 0.0 and r[..., 2:].max() == 399.0
