@@ -458,8 +458,34 @@ def modes_main():
     print("inference_modes_golden ok", len(g), "arrays")
 
 
+def variants_main():
+    """tests/golden/head_variants_golden.npz: the reference's TwoBranchNet in its two other configurations -- `cls_only=True`
+    (two_branch.py:166-202: no regressors) and `no_context=True` (no ContextNet feature) -- on the head_golden inputs."""
+    models, _, _, _ = import_reference()
+    from oracle import i3d_ref as R
+
+    g = {}
+    pf = R.fill_tensor("golden.det.pooled3", (2, 3, 832, 7, 7), "feat")
+    cx = R.fill_tensor("golden.det.ctx3", (2, 1024, 3, 1, 1), "feat")
+    for tag, net, kw in (("cls_only", models.TwoBranchNet(cfg(), cls_only=True), dict(context_feat=cx)),
+                         ("no_context", models.TwoBranchNet(cfg(no_context=True)), dict())):
+        fill_module(net, "det0.")
+        net.set_device("cpu")
+        net.eval()
+        with torch.no_grad():
+            o = net(pf, **kw)
+        for nme, t in zip(("prob", "loc", "first", "last"), o[:4]):
+            if t is not None and torch.is_tensor(t):
+                g["%s_%s" % (tag, nme)] = t.numpy()
+        g["%s_present" % tag] = np.asarray([int(t is not None and torch.is_tensor(t)) for t in o[:4]])
+    np.savez_compressed(os.path.join(OUT, "head_variants_golden.npz"), **g)
+    print("head_variants_golden ok", sorted(g))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "selection":
+    if len(sys.argv) > 1 and sys.argv[1] == "variants":
+        variants_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "selection":
         selection_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "modes":
         modes_main()
@@ -467,3 +493,4 @@ if __name__ == "__main__":
         main()
         selection_main()
         modes_main()
+        variants_main()

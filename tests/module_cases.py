@@ -140,6 +140,28 @@ def case_twobranch_T3_and_losses_golden(dev, golden):
     assert o[4].shape == (120,) and o[5].shape == (1,) and o[6].shape == (1,)
 
 
+def case_twobranch_variants_golden(dev, golden):
+    """The head's two other configurations against the reference: cls_only=True (no regressors: the three location outputs
+    are the reference's (1,)-shaped zero placeholders) and no_context=True (global_cls without the ContextNet feature)."""
+    g = golden("head_variants_golden")
+    pf = R.fill_tensor("golden.det.pooled3", (2, 3, 832, 7, 7), "feat").to(dev)
+    cx = R.fill_tensor("golden.det.ctx3", (2, 1024, 3, 1, 1), "feat").to(dev)
+    for tag, net, kw in (("cls_only", step_amd.TwoBranchNet(cfg(), cls_only=True), dict(context_feat=cx)),
+                         ("no_context", step_amd.TwoBranchNet(cfg(no_context=True)), dict())):
+        net = fill(net, "det0.").to(dev).eval()
+        net.set_device(dev)
+        with torch.no_grad():
+            o = net(pf, **kw)
+        for nme, t in zip(("prob", "loc", "first", "last"), o[:4]):
+            ref = g["%s_%s" % (tag, nme)]
+            assert tuple(t.shape) == ref.shape, (tag, nme, tuple(t.shape), ref.shape)
+            if np.abs(ref).max() == 0:
+                assert float(t.abs().max()) == 0.0, (tag, nme)
+            else:
+                e = rel(np_(t), ref)
+                assert e < 1e-3, (tag, nme, e)
+
+
 def case_twobranch_T9_golden(dev, golden):
     _twobranch(dev, golden, 9)
 
@@ -500,5 +522,5 @@ def case_c2_full_size_properties(dev, golden):
 
 CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_golden", "case_context_golden",
              "case_twobranch_T3_and_losses_golden", "case_roinet_layouts", "case_training_step_matches_torch_autograd",
-             "case_flat_adam_matches_torch", "case_wgrad_into_and_targets"]
+             "case_flat_adam_matches_torch", "case_wgrad_into_and_targets", "case_twobranch_variants_golden"]
 GPU_CASES = CPU_CASES + ["case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
