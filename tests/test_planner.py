@@ -54,6 +54,15 @@ def test_planner_dispatch(lib):
 
 
 def test_abi_and_symbols(lib):
+    """Every entry point include/step_amd.h declares is exported by the library and bound in step_amd/_capi.py (and nothing
+    is bound that the header does not declare); no compute call is made."""
+    import os
+    import re
+
     assert lib.step_abi_version() == _capi.ABI_VERSION
-    for sym in _capi.SIGNATURES:
-        assert hasattr(lib, sym), sym
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "step_amd.h")).read()
+    declared = set(re.findall(r"STEP_API\s+[\w\s\*]+?\b(step_\w+)\s*\(", hdr))
+    assert len(declared) >= 29, sorted(declared)
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), "declared in the header but not exported: " + sym
+    assert declared == set(_capi.SIGNATURES), (sorted(declared - set(_capi.SIGNATURES)), sorted(set(_capi.SIGNATURES) - declared))
