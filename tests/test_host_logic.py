@@ -112,3 +112,28 @@ def test_extrapolate_tubes_matches_reference():
     assert np.array_equal(extrapolate_tubes(torch.from_numpy(np.tile(t, (1, 2, 1))), 6).numpy(), g["ext_out_T6"])
     r = g["ext_out_T3"]                                          # only the near corner is clamped below, the far one above
     assert r[..., :2].min() == 0.0 and r[..., 2:].max() == 399.0
+
+
+def test_tube_iou_oracle_pinned_and_array_version_agrees():
+    """oracle/selection_ref.py (scalar restatement) reproduces the reference's recorded compute_tube_iou outputs; the array
+    version the product uses agrees with it bit for bit on random tubes (overlapping, disjoint, touching, padding, degenerate)."""
+    from oracle import selection_ref as SR
+    from step_amd import selection as S
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "selection_golden.npz"))
+    for ci in range(int(g["n_cases"])):
+        a, b = g["c%d_targets0" % ci][:, :, :4], g["c%d_hist_pred_loc" % ci][:9]
+        assert np.array_equal(SR.tube_iou(a, b), g["c%d_iou" % ci], equal_nan=True)
+    assert np.array_equal(SR.tube_iou(g["edge_t1"], g["edge_t2"]), g["edge_iou"], equal_nan=True)
+    rs = np.random.RandomState(3)
+    for _ in range(40):
+        n1, n2, T = rs.randint(1, 6), rs.randint(1, 8), rs.randint(1, 5)
+        def tubes(n):
+            xy = rs.uniform(-20, 300, (n, T, 2)); wh = rs.uniform(-5, 160, (n, T, 2))
+            t = np.concatenate([xy, xy + wh], 2).astype(np.float32)
+            t[rs.rand(n) < 0.15] = 0                                 # padding tubes
+            t[rs.rand(n, T) < 0.1] = 0                               # padding frames
+            return np.round(t) if rs.rand() < 0.3 else t            # integer coordinates: exact ties / touching boxes
+        a, b = tubes(n1), tubes(n2)
+        if rs.rand() < 0.3:
+            b[0] = a[0]
+        assert np.array_equal(S.tube_iou(a, b), SR.tube_iou(a, b), equal_nan=True)
