@@ -482,8 +482,44 @@ def variants_main():
     print("head_variants_golden ok", sorted(g))
 
 
+def tube_math_main():
+    """tests/golden/tube_math_golden.npz: the reference's box / tube helpers on random inputs (utils/tube_utils.py:59-92,
+    127-189, 214-246): valid_tubes (numpy and torch), get_center_size, encode_coef, decode_coef, flatten_tubes."""
+    import_reference()
+    import utils.tube_utils as tu  # reference
+
+    rs = np.random.RandomState(9)
+    g = {}
+    t = rs.uniform(-60, 460, (9, 3, 4)).astype(np.float32)
+    t[..., 2:] = t[..., :2] + rs.uniform(-4, 200, (9, 3, 2)).astype(np.float32)       # some boxes thinner than 3 px / inverted
+    t[0, 0] = [10, 10, 12, 50]                                                          # x2 - 2 == x1: not valid (strict <)
+    t[0, 1] = [10, 10, 12.5, 13.5]
+    g["vt_in"] = t
+    g["vt_np"] = tu.valid_tubes(t.copy(), 400, 400)
+    g["vt_np_320x240"] = tu.valid_tubes(t.copy(), 320, 240)
+    g["vt_torch"] = tu.valid_tubes(torch.from_numpy(t.copy()), 400, 400).numpy()
+    a = rs.uniform(0, 300, (50, 2)); wh = rs.uniform(1, 150, (50, 2))
+    boxes = np.concatenate([a, a + wh], 1).astype(np.float32)
+    gt = (boxes + rs.uniform(-15, 15, boxes.shape)).astype(np.float32)
+    deltas = (rs.randn(50, 4) * 0.3).astype(np.float32)
+    g["boxes"], g["gt"], g["deltas"] = boxes, gt, deltas
+    g["center_size"] = np.stack([v.numpy() for v in tu.get_center_size(torch.from_numpy(boxes))])
+    g["encode"] = tu.encode_coef(torch.from_numpy(gt), torch.from_numpy(boxes)).numpy()
+    g["decode"] = tu.decode_coef(torch.from_numpy(boxes), torch.from_numpy(deltas)).numpy()
+    tl = [rs.uniform(0, 400, (n, 3, 4)).astype(np.float32) for n in (4, 0, 2)]
+    for flag in (False, True):
+        flat, nums = tu.flatten_tubes([x.copy() for x in tl], batch_idx=flag)
+        g["flat_%d" % flag], g["flat_nums_%d" % flag] = np.asarray(flat), np.asarray(nums)
+    for i, x in enumerate(tl):
+        g["flat_in%d" % i] = x
+    np.savez_compressed(os.path.join(OUT, "tube_math_golden.npz"), **g)
+    print("tube_math_golden ok", len(g), "arrays")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "variants":
+    if len(sys.argv) > 1 and sys.argv[1] == "tube_math":
+        tube_math_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "variants":
         variants_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "selection":
         selection_main()
@@ -494,3 +530,4 @@ if __name__ == "__main__":
         selection_main()
         modes_main()
         variants_main()
+        tube_math_main()

@@ -137,3 +137,26 @@ def test_tube_iou_oracle_pinned_and_array_version_agrees():
         if rs.rand() < 0.3:
             b[0] = a[0]
         assert np.array_equal(S.tube_iou(a, b), SR.tube_iou(a, b), equal_nan=True)
+
+
+def test_tube_math_matches_reference_helpers():
+    """step_amd.tube_math against the reference's own utils/tube_utils.py helpers on random inputs (tube_math_golden.npz):
+    valid_tubes numpy + torch forms (clamp, then boxes not wider AND taller than 2 px become the whole image -- strict <),
+    get_center_size / encode_coef / decode_coef (+1 pixel sizes, -1 on the far corner), flatten_tubes with and without the
+    frame-index column and with an empty clip.  Bit for bit."""
+    import torch
+    from step_amd import tube_math as TM
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tube_math_golden.npz"))
+    t = g["vt_in"]
+    assert np.array_equal(TM.valid_tubes(t.copy(), 400, 400), g["vt_np"])
+    assert np.array_equal(TM.valid_tubes(t.copy(), 320, 240), g["vt_np_320x240"])
+    assert np.array_equal(TM.valid_tubes(torch.from_numpy(t.copy()), 400, 400).numpy(), g["vt_torch"])
+    assert np.array_equal(g["vt_np"], g["vt_torch"])
+    boxes, gt, deltas = (torch.from_numpy(g[k]) for k in ("boxes", "gt", "deltas"))
+    assert np.array_equal(np.stack([v.numpy() for v in TM.get_center_size(boxes)]), g["center_size"])
+    assert np.array_equal(TM.encode_coef(gt, boxes).numpy(), g["encode"])
+    assert np.array_equal(TM.decode_coef(boxes, deltas).numpy(), g["decode"])
+    tl = [g["flat_in%d" % i] for i in range(3)]
+    for flag in (False, True):
+        flat, nums = TM.flatten_tubes([x.copy() for x in tl], batch_idx=flag)
+        assert np.array_equal(flat, g["flat_%d" % flag]) and list(nums) == list(g["flat_nums_%d" % flag])
