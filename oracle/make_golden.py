@@ -512,6 +512,12 @@ def tube_math_main():
         g["flat_%d" % flag], g["flat_nums_%d" % flag] = np.asarray(flat), np.asarray(nums)
     for i, x in enumerate(tl):
         g["flat_in%d" % i] = x
+    # the initial tube grids of the four anchor modes (data/ava.py:342-354 -> data/data_utils.py:19-45)
+    from data.data_utils import generate_anchors as ref_anchors  # reference
+    for mode, (sc, ov) in {"1": ([4 / 3, 2], [5 / 6, 3 / 4]), "2": ([4 / 3, 2, 3], [5 / 6, 3 / 4, 1 / 2]),
+                           "3": ([4 / 3, 2, 3, 4], [5 / 6, 3 / 4, 1 / 2, 1 / 4]),
+                           "4": ([4 / 3, 2, 3, 4, 5], [5 / 6, 3 / 4, 1 / 2, 1 / 4, 0])}.items():
+        g["anchors_mode%s" % mode] = ref_anchors(sc, ov)
     np.savez_compressed(os.path.join(OUT, "tube_math_golden.npz"), **g)
     print("tube_math_golden ok", len(g), "arrays")
 

@@ -110,3 +110,16 @@ def generate_anchors(scales=(4.0 / 3.0, 2.0), overlaps=(5.0 / 6.0, 3.0 / 4.0)):
                 j += stride
             i += stride
     return np.asarray(out, dtype=np.float32)
+
+
+ANCHOR_MODES = {"1": ((4 / 3, 2), (5 / 6, 3 / 4)), "2": ((4 / 3, 2, 3), (5 / 6, 3 / 4, 1 / 2)),
+                "3": ((4 / 3, 2, 3, 4), (5 / 6, 3 / 4, 1 / 2, 1 / 4)), "4": ((4 / 3, 2, 3, 4, 5), (5 / 6, 3 / 4, 1 / 2, 1 / 4, 0))}
+
+
+def anchor_tubes(anchor_mode="1", T=3):
+    """[n, T, 4] normalised initial tubes of `--anchor_mode` 1 | 2 | 3 | 4 (34 / 59 / 84 / 109 tubes; config.py:93,
+    data/ava.py:342-354): the anchor grid repeated over the T frames; any other mode is the reference's single void tube."""
+    if anchor_mode not in ANCHOR_MODES:
+        return np.zeros([1, T, 4])
+    a = generate_anchors(*ANCHOR_MODES[anchor_mode])
+    return np.tile(np.expand_dims(a, axis=1), (1, T, 1))

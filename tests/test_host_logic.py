@@ -160,3 +160,8 @@ def test_tube_math_matches_reference_helpers():
     for flag in (False, True):
         flat, nums = TM.flatten_tubes([x.copy() for x in tl], batch_idx=flag)
         assert np.array_equal(flat, g["flat_%d" % flag]) and list(nums) == list(g["flat_nums_%d" % flag])
+    for mode, n in (("1", 34), ("2", 59), ("3", 84), ("4", 109)):            # the four --anchor_mode grids (data/ava.py:342-354)
+        at = TM.anchor_tubes(mode, T=3)
+        assert at.shape == (n, 3, 4) and at.dtype == np.float32
+        assert np.array_equal(at[:, 0], g["anchors_mode%s" % mode]) and np.array_equal(at[:, 2], at[:, 0])
+    assert TM.anchor_tubes("0", T=9).shape == (1, 9, 4) and not TM.anchor_tubes("0", T=9).any()
