@@ -95,7 +95,16 @@ def cpu_baseline(net, seconds_budget=12.0):
             el = time.perf_counter() - t0
             if el > seconds_budget or n >= 64:
                 break
-    return {"value": round(n / el, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    # cores = the threads the timed sample actually ran on (the fastest of the probed thread counts); host_cores = what the box has
+    return {"value": round(n / el, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "host_cores": ncpu, "cpu_model": model, "kind": "port",
             "sample": "%d single-clip [1,32,3,224,224] fp32 forwards of oracle/i3d_ref.basenet_forward (torch CPU) after 1 warm-up, %.1f s" % (n, el)}
 
 
@@ -149,6 +158,19 @@ def roofline(net, x, dtype_name):
     return out, table, total_ms / 3
 
 
+def spawn_ranks(n):
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,9 +191,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and a.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run (the form the
+        # driver uses itself), same arguments; the ranks rendezvous over 127.0.0.1 and rank 0 prints the JSON line
+        return spawn_ranks(a.gpus)
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (there is no CPU fallback)")
     ndev = torch.cuda.device_count()
@@ -248,7 +273,9 @@ def main():
                "config": {"workload": "%s: I3D backbone (BaseNet conv3d_1a..mixed_4f) forward, %d x [3,%d,%d,%d] clips per GPU, "
                                       "inputs resident in HBM, random-init weights" % (c["name"], CLIPS_PER_GPU, T_IN, HW_IN, HW_IN),
                           "clips_per_gpu": CLIPS_PER_GPU, "T": T_IN, "HW": HW_IN, "parallelism": "clip-sharded replicas x%d (no data-path collective)" % world,
-                          "launch": "eager" if graph is None else "hipGraph replay"}}
+                          "launch": "eager" if graph is None else "hipGraph replay"},
+               "ranks": {"world_size": world, "backend": (dist.get_backend() + " (RCCL over xGMI)" if dist.get_backend() == "nccl" else dist.get_backend()) if dist is not None else None,
+                         "devices_visible": ndev}}
         per_gpu = val / world
         out["backbone_roofline"] = {
             "hbm_frac": round(per_gpu * (ACT_MB_PER_CLIP + W_MB / CLIPS_PER_GPU) * 1e6 / (PEAK_HBM_GBS * 1e9), 4),
@@ -325,7 +352,9 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
                "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": what + ", inputs resident in HBM, random-init weights", "clips_per_gpu": CLIPS_PER_GPU, "T": 36, "HW": 400,
                           "parallelism": "clip-sharded replicas x%d (%s)" % (world, "no data-path collective" if a.config == "c3" else "one gradient all-reduce per step"),
-                          "launch": "hipGraph replay + eager post-processing" if (a.config == "c3" and not a.no_graph) else "eager"}}
+                          "launch": "hipGraph replay + eager post-processing" if (a.config == "c3" and not a.no_graph) else "eager"},
+               "ranks": {"world_size": world, "backend": (dist.get_backend() + " (RCCL over xGMI)" if dist.get_backend() == "nccl" else dist.get_backend()) if dist is not None else None,
+                         "devices_visible": torch.cuda.device_count()}}
         rec = REC
         agg = {}
         for name, flops, nbytes, e0, e1 in rec:

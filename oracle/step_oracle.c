@@ -20,7 +20,7 @@
  *       sources where they lie) and against tests/golden/roi_nms_golden.npz.
  *   orc_roi_align_backward          : the reference has no CPU implementation
  *       (ROIAlign.h:68); pinned indirectly as the exact adjoint of the
- *       forward (<fwd(x),g> == <x,bwd(g)>) -- tests/test_oracle_adjoint.py.
+ *       forward (<fwd(x),g> == <x,bwd(g)>) -- tests/test_oracle_golden.py (test_roi_align_backward_is_adjoint).
  *   orc_roi_pool_forward/backward   : the reference has no CPU implementation
  *       (ROIPool.h:47,68): PARITY UNPINNED beyond hand-computed cases.
  */
@@ -264,6 +264,8 @@ typedef struct { float s; int64_t i; } orc_sk_t;
 static int orc_sk_cmp(const void* a, const void* b)
 {
     const orc_sk_t* x = (const orc_sk_t*)a; const orc_sk_t* y = (const orc_sk_t*)b;
+    const int nx = x->s != x->s, ny = y->s != y->s;   /* torch's sort puts NaN first in descending order (observed on _ref/_C.so) */
+    if (nx != ny) return nx ? -1 : 1;
     if (x->s > y->s) return -1;
     if (x->s < y->s) return 1;
     return (x->i < y->i) ? -1 : (x->i > y->i);

@@ -95,6 +95,8 @@ class _ConvUnitFn(torch.autograd.Function):
                     x.record_stream(side)
                     g32.record_stream(side)
                     _PENDING[0] = True
+                    if GRAD_READY is not None:                   # this parameter bypasses autograd's accumulate hook
+                        GRAD_READY(ctx.unit.weight_fn(), side)
                     gx = _ConvUnitFn._dgrad(gact, w_eff, x.dtype, k) if need_x else None
                     return gx, None, None, None, (gact if need_res else None), None, None
                 if need_x and need_w and WGRAD_SIDE_STREAM and x.is_cuda and x.dtype == torch.float32 and ops.PROFILE is None:
@@ -144,10 +146,13 @@ class ConvUnit:
     to input channels [lo, hi) of the weight (a conv over a channel concat becomes two accumulating
     launches)."""
 
-    def __init__(self, weight_fn, k, bn=None, bias_fn=None, perm=None, cin_slice=None):
+    def __init__(self, weight_fn, k, bn=None, bias_fn=None, perm=None, cin_slice=None, version_fn=None):
         self.weight_fn, self.bias_fn, self.bn = weight_fn, bias_fn, bn
         self.k = tuple(k)
         self.perm, self.cin_slice = perm, cin_slice
+        # version_fn: key of the packed-weight cache when weight_fn() builds a NEW tensor on every call (a torch.cat of
+        # several parameters): the temporary's (data_ptr, _version) says nothing about the parameters behind it
+        self.version_fn = version_fn
         self._packed = {}
         self._affine = None
 
@@ -166,10 +171,17 @@ class ConvUnit:
         return w.reshape(w.shape[0], w.shape[1], *self.k)
 
     def packed(self, dtype):
-        w = self.weight_fn()
-        key = (dtype, w.device)
-        ver = _ver(w)
-        hit = self._packed.get(key)
+        if self.version_fn is not None:
+            ver = self.version_fn()
+            key = (dtype, ver[0][2] if ver else None)
+            hit = self._packed.get(key)
+            if hit is not None and hit[0] == ver:
+                return hit[1]
+        else:
+            w = self.weight_fn()
+            key = (dtype, w.device)
+            ver = _ver(w)
+            hit = self._packed.get(key)
         if hit is None or hit[0] != ver:
             with torch.no_grad():
                 hit = (ver, ops.pack_conv_weight(self.effective_weight(), dtype))
@@ -258,25 +270,35 @@ class Unit3D(nn.Module):
         if hit is None or hit[0] != ver:
             hit = (ver, ops.pack_stem_weight(w, x.dtype))
             self._stem_packed[key] = hit
-        scale, shift = self._unit.affine()
-        if torch.is_grad_enabled() and w.requires_grad:
+        bn = getattr(self, "batch3d", None)
+        bn_grad = bn is not None and (bn.weight.requires_grad or bn.bias.requires_grad)
+        if torch.is_grad_enabled() and (w.requires_grad or bn_grad):
+            scale, shift = self._unit.affine(differentiable=True)      # --freeze_affine False: the BN affine trains too
             return _StemFn.apply(x, w, scale, shift, self, hit[1])
+        scale, shift = self._unit.affine()
         return ops.stem_forward(x, hit[1], w.shape[0], scale, shift, out)
 
 
 class _StemFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, scale, shift, unit, packed):
-        y = ops.stem_forward(x.detach(), packed, w.shape[0], scale, shift)
-        ctx.save_for_backward(x, w, scale, y)
+        y = ops.stem_forward(x.detach(), packed, w.shape[0], scale.detach().contiguous(), shift.detach().contiguous())
+        ctx.save_for_backward(x, w, scale, shift, y)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w, scale, y = ctx.saved_tensors
-        g = gy.float() * (y > 0).to(torch.float32) * scale.view(1, 1, 1, 1, -1)
-        gw = ops.stem_wgrad(x.contiguous(), g, w.shape[0])         # HIP (the clip itself needs no gradient)
-        return None, gw.to(w.dtype), None, None, None, None
+        x, w, scale, shift, y = ctx.saved_tensors
+        g = gy.float() * (y > 0).to(torch.float32)
+        C = g.shape[-1]
+        gw = gscale = gshift = None
+        if ctx.needs_input_grad[3]:
+            gshift = g.reshape(-1, C).sum(0)
+        if ctx.needs_input_grad[2]:                                    # same formulas as _ConvUnitFn (pre-affine output = (y - shift) / scale)
+            gscale = (g * (y.float() - shift.view(1, 1, 1, 1, -1)) / scale.view(1, 1, 1, 1, -1)).reshape(-1, C).sum(0)
+        if ctx.needs_input_grad[1]:
+            gw = ops.stem_wgrad(x.contiguous(), g * scale.view(1, 1, 1, 1, -1), w.shape[0]).to(w.dtype)   # HIP (the clip itself needs no gradient)
+        return None, gw, gscale, gshift, None, None
 
 
 class MaxPoolTF(nn.Module):
@@ -394,6 +416,7 @@ class Mixed(nn.Module):
 
 
 WGRAD_INTO_GRAD = False        # see wgrad_into_grad()
+GRAD_READY = None              # step_amd.dist.BucketedReducer.ready while a backward pass is being overlapped with the exchange
 _PENDING = [False]
 
 

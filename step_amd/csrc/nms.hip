@@ -35,6 +35,15 @@ __device__ __forceinline__ bool iou_ge(float ix1, float iy1, float ix2, float iy
     return ovr >= thr;
 }
 
+// Score order: descending, ties by lower index.  NaN scores sort FIRST (torch's sort, which the reference uses at
+// nms_cpu.cpp:50, treats NaN as the largest value); without this rule NaNs compare false both ways, ranks collide and
+// the rank -> lane lookup below would be undefined.
+__device__ __forceinline__ bool score_before(float sj, int j, float s, int i) {
+    const bool nj = sj != sj, ni = s != s;
+    if (nj || ni) return nj && (!ni || j < i);
+    return sj > s || (sj == s && j < i);
+}
+
 // One wavefront per group, n <= 64.
 __global__ void nms_wave_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                 const int32_t* __restrict__ counts, int kmax, float thr, uint8_t* __restrict__ keep) {
@@ -53,7 +62,7 @@ __global__ void nms_wave_kernel(const float* __restrict__ boxes, const float* __
     int rank = 0;
     for (int j = 0; j < n; ++j) {
         float sj = __shfl(s, j);
-        rank += (sj > s || (sj == s && j < lane)) ? 1 : 0;
+        rank += score_before(sj, j, s, lane) ? 1 : 0;
     }
     bool suppressed = false;
     for (int r = 0; r < n; ++r) {
@@ -84,7 +93,7 @@ __global__ void nms_block_kernel(const float* __restrict__ boxes, const float* _
         int rank = 0;
         for (int j = 0; j < n; ++j) {
             float sj = S[j];
-            rank += (sj > s || (sj == s && j < i)) ? 1 : 0;
+            rank += score_before(sj, j, s, i) ? 1 : 0;
         }
         order[rank] = i;
         sup[i] = 0;

@@ -73,6 +73,143 @@ def allreduce_flat(flat, weight=None, chunk_bytes=512 << 20):
     return factor
 
 
+class BucketedReducer:
+    """The gradient exchange of the training step, overlapped with the backward pass (replaces the
+    reduce-add of nn.DataParallel, train.py:142-148).
+
+    FlatAdam's gradient arena is cut into contiguous buckets of ~bucket_bytes.  Backward produces gradients roughly from
+    the END of the arena (heads) to its FRONT (stem), so buckets are exchanged in descending arena order: as soon as
+    every tensor of the next bucket in that order has its gradient (autograd's post-accumulate hook, or the conv units'
+    direct side-stream accumulation under backbone.wgrad_into_grad()), its in-place SUM all-reduce is issued on a
+    communication stream that waits for the producing streams only -- the rest of backward keeps running on the main
+    stream.  xGMI rings are per-link bound: a bucket is one large message (default 32 MiB, 6 for the 178 MB arena), not
+    one message per tensor.
+
+    The ISSUE ORDER is fixed (bucket B-1, B-2, ..., 0) whatever the readiness order, and finish() issues whatever backward
+    did not reach (parameters without a gradient this step), so every rank issues the same sequence of collectives --
+    RCCL matches collectives by order, not by address.
+
+        red = BucketedReducer(opt)            # once
+        red.begin(weight=None)                # before backward
+        with wgrad_into_grad(): loss.backward()
+        scale = red.finish()                  # joins the communication stream
+        opt.step(grad_scale=scale, zero_grad=True)
+    """
+
+    def __init__(self, opt, bucket_bytes=32 << 20):
+        self.opt = opt
+        self.flat = opt.flat_grad
+        entries = opt._entries                                  # (group, param, offset, numel), ascending offsets
+        cap = max(1, bucket_bytes // 4)
+        self.buckets = []                                        # [lo, hi, n_tensors]
+        self.bucket_of = {}
+        lo, cnt = 0, 0
+        for k, (_, p, o, n) in enumerate(entries):
+            end = entries[k + 1][2] if k + 1 < len(entries) else opt.numel
+            self.bucket_of[id(p)] = len(self.buckets)
+            cnt += 1
+            if end - lo >= cap or k + 1 == len(entries):
+                self.buckets.append((lo, end, cnt))
+                lo, cnt = end, 0
+        self.active = dist.is_initialized() and dist.get_world_size() > 1
+        self.cuda = self.flat.is_cuda
+        self.comm = torch.cuda.Stream(self.flat.device) if self.cuda else None
+        self._hooks = [p.register_post_accumulate_grad_hook(self._autograd_ready) for _, p, _, _ in entries]
+        self._armed = False
+        self.issued_during_backward = 0
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        from . import backbone
+        if backbone.GRAD_READY is self.ready:
+            backbone.GRAD_READY = None
+
+    def begin(self, weight=None):
+        """Arm for one backward pass.  weight: optional per-rank scalar as in allreduce_flat()."""
+        from . import backbone
+        self.pending = [c for _, _, c in self.buckets]
+        self.seen = set()
+        self.next = len(self.buckets) - 1                        # next bucket to issue (descending)
+        self.works = []
+        self.side = []                                           # producer streams to wait for, per bucket
+        self.side_streams = [set() for _ in self.buckets]
+        self.weight = None
+        self.factor = 1.0
+        self.issued_during_backward = 0
+        if self.active:
+            self.factor = 1.0 / dist.get_world_size()
+            if weight is not None:
+                wsum = torch.tensor([float(weight)], device=self.flat.device, dtype=torch.float32)
+                dist.all_reduce(wsum)
+                self.weight = float(weight)
+                self.factor = 1.0 / float(wsum.item())
+        backbone.GRAD_READY = self.ready
+        self._armed = True
+
+    def _autograd_ready(self, p):
+        if self._armed:
+            self.ready(p, None)
+
+    def ready(self, p, stream=None):
+        """`p`'s gradient for this step is complete (as far as the host is concerned: the producing kernel has been
+        launched on `stream`, None = the current stream)."""
+        if not self._armed:
+            return
+        b = self.bucket_of.get(id(p))
+        if b is None:
+            return
+        if id(p) in self.seen:
+            raise RuntimeError("BucketedReducer: a second gradient for the same parameter in one backward pass "
+                               "(its bucket may already be in flight)")
+        self.seen.add(id(p))
+        if stream is not None:
+            self.side_streams[b].add(stream)
+        self.pending[b] -= 1
+        while self.next >= 0 and self.pending[self.next] == 0:
+            self._issue(self.next)
+            self.issued_during_backward += 1
+            self.next -= 1
+
+    def _issue(self, b):
+        lo, hi, _ = self.buckets[b]
+        if not self.active:
+            return
+        seg = self.flat[lo:hi]
+        if self.cuda:
+            main = torch.cuda.current_stream(self.flat.device)
+            self.comm.wait_stream(main)                          # every gradient kernel issued so far on the main stream
+            for s_ in self.side_streams[b]:
+                self.comm.wait_stream(s_)                        # ... and the direct weight-gradient accumulations
+            with torch.cuda.stream(self.comm):
+                if self.weight is not None:
+                    seg.mul_(self.weight)
+                self.works.append(dist.all_reduce(seg, async_op=True))
+        else:
+            if self.weight is not None:
+                seg.mul_(self.weight)
+            self.works.append(dist.all_reduce(seg, async_op=True))
+
+    def finish(self):
+        """Issue the buckets backward did not complete (same order on every rank), wait for all of them, return the
+        factor that turns the sums into the average (for FlatAdam.step(grad_scale=...))."""
+        from . import backbone
+        self._armed = False
+        backbone.GRAD_READY = None
+        if self.cuda:
+            backbone.wgrad_sync()                                # late side-stream accumulations -> ordered before the main stream
+        while self.next >= 0:
+            self._issue(self.next)
+            self.next -= 1
+        for w in self.works:
+            w.wait()                                             # nccl: the current stream waits for the collective
+        if self.cuda and self.active:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.comm)
+        self.works = []
+        return self.factor
+
+
 def allreduce_gradients(params, bucket_bytes=64 << 20, average=True, weight=None):
     """Average (or sum) the .grad of `params` over all ranks with a few large flattened all-reduces.
 

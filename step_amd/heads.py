@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .backbone import (MIXED_CFG, ConvUnit, MaxPoolTF, Mixed, as_channels_last_5d, freeze_bn_affine, set_bn_eval,
+from .backbone import (MIXED_CFG, ConvUnit, _ver, MaxPoolTF, Mixed, as_channels_last_5d, freeze_bn_affine, set_bn_eval,
                        weights_init)
 from .roi_layers import ROIAlign, ROIPool
 from .tube_math import encode_coef
@@ -230,9 +230,10 @@ class TwoBranchNet(nn.Module):
             self.neighbor_reg2 = nn.Linear(flat, 4)     # tube t+1
             self._u_down2 = ConvUnit(lambda: self.downsample2.weight, (1, 1, 1), bias_fn=lambda: self.downsample2.bias)
             # the three regressors share their input: one GEMM with 12 output columns
+            # (grad mode: a differentiable cat per call; the pack cache is keyed on the three PARAMETERS, not on the temporary)
             self._u_reg = ConvUnit(lambda: torch.cat([self.local_reg.weight, self.neighbor_reg1.weight, self.neighbor_reg2.weight], 0),
                                    (1, 1, 1), bias_fn=lambda: torch.cat([self.local_reg.bias, self.neighbor_reg1.bias, self.neighbor_reg2.bias], 0),
-                                   perm=perm)
+                                   perm=perm, version_fn=lambda: _ver(self.local_reg.weight, self.neighbor_reg1.weight, self.neighbor_reg2.weight))
             self._reg_cache = None
         self._init_net()
         if self.freeze_stats:

@@ -98,6 +98,9 @@ class C4TrainStep:
             m.train()
         self.params = [p for m in self.mods for p in m.parameters() if p.requires_grad]
         self.opt = FlatAdam(self.params, lr=1e-5)
+        # the gradient exchange runs bucket by bucket on a communication stream WHILE backward is still producing the
+        # earlier layers' gradients (step_amd.dist.BucketedReducer); single-process runs issue nothing
+        self.reducer = sdist.BucketedReducer(self.opt)
         # fp32 master weights either way; a 16-bit clip makes every activation / data gradient 16-bit (fp32 accumulate),
         # weight gradients stay fp32
         self.x = ava_clips(seed, batch).to(dev).to(dtype)
@@ -122,8 +125,9 @@ class C4TrainStep:
         self.batch, self.K = batch, K
         self.loss = None
 
-    def forward_backward(self):
-        """Losses of the three steps and their gradients (into FlatAdam's gradient arena); no exchange, no update."""
+    def forward_backward(self, exchange=False):
+        """Losses of the three steps and their gradients (into FlatAdam's gradient arena); no update.  exchange=True overlaps
+        the bucketed gradient all-reduce with the backward pass and leaves the averaging factor in self.scale."""
         cf = self.base(self.x)                                    # [B,9,832,25,25]
         cx = self.ctx(cf)                                         # [B,1024,9,1,1]
         loss = 0.0
@@ -132,14 +136,16 @@ class C4TrainStep:
             pooled = pooled.reshape(self.batch * self.K, Tl, *pooled.shape[1:])
             o = head(pooled, context_feat=cx[self.clip_of][:, :, t0:t0 + Tl], tubes=flat, targets=self.targets)
             loss = loss + o[4].mean() + 5 * o[5].mean() + o[6].mean()
+        if exchange:
+            self.reducer.begin()
         with wgrad_into_grad():                                   # weight gradients go straight into FlatAdam's arena
             loss.backward()
+        self.scale = self.reducer.finish() if exchange else 1.0
         return loss
 
     def step(self):
-        loss = self.forward_backward()
-        scale = sdist.allreduce_flat(self.opt.flat_grad)
-        self.opt.step(grad_scale=scale, zero_grad=True)          # gradients are clean for the next backward
+        loss = self.forward_backward(exchange=True)
+        self.opt.step(grad_scale=self.scale, zero_grad=True)     # gradients are clean for the next backward
         self.loss = loss.detach()
         return self.loss
 
@@ -192,9 +198,10 @@ class C4SelectTrainStep(C4TrainStep):
             pooled = pooled.reshape(flat.shape[0], Tl, *pooled.shape[1:])
             o = self.heads[i - 1](pooled, context_feat=cx[clip_of][:, :, t0:t0 + Tl], tubes=flat, targets=targets)
             loss = loss + o[4].mean() + a.lambda_reg * o[5].mean() + a.lambda_neighbor * o[6].mean()
+        self.reducer.begin()
         with wgrad_into_grad():
             loss.backward()
-        scale = sdist.allreduce_flat(self.opt.flat_grad)
+        scale = self.reducer.finish()
         self.opt.step(grad_scale=scale, zero_grad=True)
         self.loss = loss.detach()
         return self.loss

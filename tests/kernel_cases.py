@@ -266,6 +266,24 @@ def case_nms_batched_groups_and_ties(bk, golden):
         assert np.array_equal(keep, oracle.nms_batched(boxes, scores, counts, 0.4)), kmax
 
 
+def case_nms_nan_scores(bk, golden):
+    """NaN scores rank first (torch's sort order, which the reference inherits); ranks stay a permutation, so neither the
+    wave kernel's rank -> lane lookup nor the block kernel's order table is undefined."""
+    for kmax in (12, 34, 80):
+        rs = np.random.RandomState(7 + kmax)
+        G = 5
+        boxes = np.zeros((G, kmax, 4), np.float32)
+        scores = np.zeros((G, kmax), np.float32)
+        for gi in range(G):
+            xy = rs.uniform(0, 200, (kmax, 2))
+            boxes[gi] = np.concatenate([xy, xy + rs.uniform(20, 150, (kmax, 2))], 1)
+            scores[gi] = rs.permutation(kmax) / kmax
+            scores[gi, rs.choice(kmax, gi, replace=False)] = np.nan      # 0..4 NaNs per group
+        counts = np.full(G, kmax, np.int32)
+        keep = run_nms(bk, boxes, scores, counts, 0.3)
+        assert np.array_equal(keep, oracle.nms_batched(boxes, scores, counts, 0.3)), kmax
+
+
 POOLS = [((1, 3, 3), (1, 2, 2)), ((3, 3, 3), (2, 2, 2)), ((3, 3, 3), (1, 1, 1)), ((2, 2, 2), (2, 2, 2))]
 
 

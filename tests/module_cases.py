@@ -495,6 +495,50 @@ def case_training_step_16bit_storage(dev, golden):
     assert worst < 0.15, worst
 
 
+def case_reg_unit_pack_follows_weight_updates(dev, golden):
+    """The fused regressor unit (three Linear layers as one GEMM) in GRAD mode: its weight_fn is a fresh torch.cat per call, so
+    the packed-weight cache must be keyed on the three parameters -- a temporary's (data_ptr, _version) can repeat after an
+    optimizer step and silently serve stale weights to the forward while backward sees fresh ones.  Also: the stem's BN affine
+    receives gradients when it is trainable (--freeze_affine False)."""
+    net = fill(step_amd.TwoBranchNet(cfg()), "det0.").to(dev)
+    net.set_device(dev)
+    net.train()
+    u = net._reg_unit()
+    assert u is net._u_reg
+    p1 = u.packed(torch.float32)
+    assert u.packed(torch.float32) is p1                         # steady state: a cache hit, no re-pack per call
+    p1 = p1.clone()
+    for it in range(3):
+        with torch.no_grad():
+            net.neighbor_reg1.weight.add_(0.5)
+        junk = [torch.empty_like(net.local_reg.weight) for _ in range(it)]      # perturb the allocator's reuse pattern
+        p2 = net._reg_unit().packed(torch.float32)
+        assert not torch.equal(p1, p2), it
+        with torch.no_grad():
+            fresh = net._reg_unit().packed(torch.float32)        # the no-grad path builds its own cat + pack
+        assert torch.equal(p2, fresh), it
+        p1 = p2.clone()
+        del junk
+    # stem BN affine gradient (ADVICE r1): trainable affine -> gradients equal the oracle's autograd
+    base = fill(step_amd.BaseNet(cfg(freeze_affine=False))).to(dev)
+    base.train()
+    stem = base.base_model[0]
+    assert stem.batch3d.weight.requires_grad
+    x = R.fill_tensor("golden.stemaff.images", (1, 6, 3, 20, 20), "image").to(dev)
+    y = stem(x)
+    wgt = R.fill_tensor("golden.stemaff.w", tuple(y.shape), "feat").to(dev)
+    (y * wgt).sum().backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k)
+          for k, v in base.state_dict().items() if k.startswith("base_model.0.")}
+    yo = R.unit3d(x.cpu().permute(0, 2, 1, 3, 4), sd, "base_model.0", stride=(2, 2, 2))
+    (yo.permute(0, 2, 3, 4, 1) * wgt.cpu()).sum().backward()
+    for k in ("conv3d.weight", "batch3d.weight", "batch3d.bias"):
+        a = np_(dict(stem.named_parameters())[k].grad).astype(np.float64)
+        b = sd["base_model.0." + k].grad.numpy().astype(np.float64)
+        e = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+        assert e < 1e-3, (k, e)
+
+
 def case_c2_full_size_properties(dev, golden):
     """BASELINE C2 at its full size (8 x [32,3,224,224], bf16) -- too big for the oracle, so parity is checked through
     size-independent properties:
@@ -522,5 +566,6 @@ def case_c2_full_size_properties(dev, golden):
 
 CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_golden", "case_context_golden",
              "case_twobranch_T3_and_losses_golden", "case_roinet_layouts", "case_training_step_matches_torch_autograd",
-             "case_flat_adam_matches_torch", "case_wgrad_into_and_targets", "case_twobranch_variants_golden"]
+             "case_flat_adam_matches_torch", "case_wgrad_into_and_targets", "case_twobranch_variants_golden",
+             "case_reg_unit_pack_follows_weight_updates"]
 GPU_CASES = CPU_CASES + ["case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]

@@ -62,11 +62,43 @@ def _worker(rank, world, port, q):
     flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
     f_w = D.allreduce_flat(flat, weight=float(m.sum()), chunk_bytes=64)     # tiny chunks: several collectives
     flat_w = flat * f_w
+    # (d) the OVERLAPPED exchange (BucketedReducer): buckets of FlatAdam's arena all-reduced from autograd's
+    # post-accumulate hooks while backward is still running, in a fixed issue order; a parameter that gets no gradient on
+    # ONE rank only (rank 1 skips the extra head) must not change the sequence of collectives.  The optimizer's arenas
+    # live on the CPU here through the test-only interpreter patch (FlatAdam itself refuses host tensors).
+    from tests.emul.patch import emulated_kernels
+    from step_amd.optim import FlatAdam
+    with emulated_kernels():
+        extra = torch.nn.Linear(5, 3)
+        torch.manual_seed(3)
+        torch.nn.init.normal_(extra.weight)
+        params = list(model.parameters()) + list(extra.parameters())
+        opt = FlatAdam(params, lr=1e-3)
+        red = D.BucketedReducer(opt, bucket_bytes=256)
+        nbuckets = len(red.buckets)
+        outs = []
+        for use_weight in (False, True):
+            opt.zero_grad()
+            red.begin(weight=float(m.sum()) if use_weight else None)
+            y = model(clips[idx])
+            if use_weight:
+                loss = (((y - target[idx]) ** 2).mean(1) * m).sum().div(m.sum())
+            else:
+                loss = ((y - target[idx]) ** 2).mean()
+            if rank == 0:
+                loss = loss + 0.0 * extra(y).sum() + 0.5 * (extra(y.detach()) ** 2).mean()
+            loss.backward()
+            during = red.issued_during_backward
+            f = red.finish()
+            outs.append(((opt.flat_grad * f).numpy().copy(), during, f))
+        red.close()
+        offs = [(o, n) for _, _, o, n in opt._entries]
     el = D.timed_steps(lambda: None if rank == 0 else __import__("time").sleep(0.05), 2, sync=lambda: None)
     if rank == 0:
         # numpy arrays travel by value; torch tensors would be shared through file descriptors that may be gone
         # by the time the parent unpickles them
-        q.put((nb, [g.numpy() for g in g_plain], [g.numpy() for g in g_masked], el, flat_plain.numpy(), flat_w.numpy(), f_plain))
+        q.put((nb, [g.numpy() for g in g_plain], [g.numpy() for g in g_masked], el, flat_plain.numpy(), flat_w.numpy(), f_plain,
+               outs, offs, nbuckets))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -79,7 +111,7 @@ def test_two_rank_gradient_allreduce_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    nb, g_plain, g_masked, el, flat_plain, flat_w, f_plain = q.get()
+    nb, g_plain, g_masked, el, flat_plain, flat_w, f_plain, outs, offs, nbuckets = q.get()
     g_plain = [torch.from_numpy(g) for g in g_plain]
     g_masked = [torch.from_numpy(g) for g in g_masked]
     for p in procs:
@@ -101,5 +133,12 @@ def test_two_rank_gradient_allreduce_matches_single_process():
     assert f_plain == 0.5
     assert np.allclose(flat_plain, torch.cat([g.reshape(-1) for g in g_plain]).numpy(), rtol=1e-5, atol=1e-6)
     assert np.allclose(flat_w, torch.cat([g.reshape(-1) for g in g_masked]).numpy(), rtol=1e-5, atol=1e-6)
+    # (d) overlapped buckets == the single-shot exchange on the model's own parameters (the extra head trains on rank 0 only)
+    assert nbuckets >= 3
+    for (arena, during, f), want in zip(outs, (g_plain, g_masked)):
+        for (o, n), g in zip(offs, want):
+            assert np.allclose(arena[o:o + n], g.reshape(-1).numpy(), rtol=1e-5, atol=1e-6)
+        assert during >= 1                           # at least one bucket left while backward was still running
+    assert outs[0][2] == 0.5 and abs(outs[1][2] - 1.0 / float(mask.sum())) < 1e-7
     assert nb >= 2                                   # bucketing really split the gradient
     assert el >= 0.1                                 # max over ranks: rank 1 slept 2 x 50 ms

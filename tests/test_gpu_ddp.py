@@ -1,5 +1,5 @@
-"""Data-parallel training step on the GPU: two ranks, one AVA clip each, sharing the one GPU of the
-test box over gloo -- the averaged gradient after `allreduce_flat` equals the single-process gradient on the two-clip batch
+"""Data-parallel training step on the GPU: two ranks, one AVA clip each -- over RCCL with one GPU per
+rank when the box has two, else sharing the one GPU of the test box over gloo -- the averaged gradient after `allreduce_flat` equals the single-process gradient on the two-clip batch
 (dropout 0, equal tube counts per rank, so the mean of the rank means is the global mean)."""
 import socket
 
@@ -30,17 +30,31 @@ def _worker(rank, world, port, q):
     import torch.distributed as dist
     from step_amd import dist as D, workloads
 
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    dev = torch.device("cuda:0")
+    # >= 2 GPUs visible: one rank per GPU over RCCL ("nccl" IS RCCL on ROCm) -- the production path; the 1-GPU test box
+    # shares its GPU between the ranks, which RCCL refuses, so there the exchange runs over gloo
+    ndev = torch.cuda.device_count()
+    if ndev >= world:
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world, device_id=dev)
+    else:
+        dev = torch.device("cuda:0")
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     w = workloads.C4TrainStep(dev, batch=1, seed=123 + rank)
     loss = w.forward_backward()
     f = D.allreduce_flat(w.opt.flat_grad)
     sample, norms = _probe(w.opt.flat_grad * f, w.opt._entries)
-    lsum = torch.tensor([float(loss)])
+    lsum = torch.tensor([float(loss)], device=dev if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(lsum)
     p0 = w.opt.flat_param[:4096].cpu().numpy()
+    # the same gradients through the OVERLAPPED exchange (BucketedReducer: buckets leave on a communication stream while
+    # backward is still running): must equal the single-shot exchange above
+    w.opt.zero_grad()
+    w.forward_backward(exchange=True)
+    sample_b, norms_b = _probe(w.opt.flat_grad * w.scale, w.opt._entries)
+    during, nb = w.reducer.issued_during_backward, len(w.reducer.buckets)
     if rank == 0:
-        q.put((sample, norms, float(lsum) / world, f, p0))
+        q.put((sample, norms, float(lsum) / world, f, p0, sample_b, norms_b, during, nb, w.scale))
     else:
         q.put(("p", p0))
     dist.barrier()
@@ -63,8 +77,11 @@ def test_two_rank_gradient_equals_single_process_on_the_concatenated_batch():
         assert p.exitcode == 0
     main = [g for g in got if g[0] is not None and not isinstance(g[0], str)][0]
     other = [g for g in got if isinstance(g[0], str)][0]
-    sample, norms, loss2, factor, p0 = main
-    assert factor == 0.5
+    sample, norms, loss2, factor, p0, sample_b, norms_b, during, nb, scale_b = main
+    assert factor == 0.5 and scale_b == 0.5
+    assert nb >= 5 and during >= nb - 2, (during, nb)            # 178 MB arena in 32 MiB buckets; all but the front ones left during backward
+    eb = np.linalg.norm(sample_b - sample) / np.linalg.norm(sample)
+    assert eb < 1e-4 and np.abs(norms_b - norms).max() < 1e-4 * norms.max(), eb
     assert np.array_equal(p0, other[1])                          # replicas start from the same (broadcast) weights
     dev = torch.device("cuda:0")
     w = workloads.C4TrainStep(dev, batch=2, seed=123)

@@ -49,6 +49,19 @@ def test_nms_random(refC, seed):
         assert np.array_equal(oracle.nms(boxes, scores, thr), ref)
 
 
+def test_nms_nan_scores_sort_first(refC):
+    """NaN scores: torch's descending sort (nms_cpu.cpp:48) ranks them first; the restatement follows."""
+    rs = np.random.RandomState(7)
+    for n in (12, 34, 80):
+        xy = rs.uniform(0, 200, (n, 2))
+        boxes = np.concatenate([xy, xy + rs.uniform(20, 150, (n, 2))], 1).astype(np.float32)
+        scores = (rs.permutation(n) / n).astype(np.float32)
+        scores[[3, n // 2]] = np.nan                                 # two NaNs that each overlap other boxes
+        ref = refC.nms(torch.from_numpy(boxes), torch.from_numpy(scores), 0.3).numpy()
+        assert len(ref) < n
+        assert np.array_equal(oracle.nms(boxes, scores, 0.3), ref)
+
+
 def test_reference_has_no_cpu_backward_or_roipool(refC):
     # csrc/ROIAlign.h:68, csrc/ROIPool.h:47,68 -- this is why those oracles are pinned indirectly
     x = torch.zeros(1, 1, 4, 4)
