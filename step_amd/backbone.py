@@ -544,7 +544,7 @@ def as_channels_last_5d(t):
     if v.is_contiguous():
         return v
     N, T, C, H, W = t.shape
-    if t.is_contiguous():
+    if t.is_contiguous() and not (torch.is_grad_enabled() and t.requires_grad):   # (the HIP transpose records no autograd node)
         return ops.to_channels_last(t.reshape(N * T, C, H, W)).view(N, T, H, W, C)
     return v.contiguous()
 

@@ -317,6 +317,93 @@ def case_training_step_matches_torch_autograd(dev, golden):
     assert checked == len(info["TwoBranchNet_trainable"])
 
 
+def _grad_check(named_params, sd, tol, what):
+    checked = 0
+    for k, p in named_params:
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, (what, k)
+        a, b = np_(p.grad).astype(np.float64), sd[k].grad.numpy().astype(np.float64)
+        e = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+        assert e < tol, (what, k, e)
+        checked += 1
+    return checked
+
+
+def _oracle_sd(net):
+    return {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and "batch3d" not in k)
+            for k, v in net.state_dict().items()}
+
+
+def case_basenet_backward_matches_oracle_autograd(dev, golden):
+    """a-19, the backbone leg of train.py:257-348: a scalar back-propagated through the WHOLE BaseNet in training mode --
+    _StemFn (stem weight gradient), every _MaxPoolFn, Mixed's autograd branch (torch.cat of the four branches), the 3x3x3
+    and 1x1x1 data-gradient convs and the weight-gradient kernels -- and all 45 trainable gradients compared with torch
+    autograd through oracle/i3d_ref.basenet_forward on the same weights, fp32, relative L2 < 1e-3.  The loss sums every
+    output element with a signed weight, so a ReLU whose pre-activation sits within rounding of zero moves the result by
+    ~1e-6, not by per cents as in the tiny head fixture.  C1 clip on the GPU, a 32x32 clip on the interpreter."""
+    shape = (1, 8, 3, 112, 112) if dev != "cpu" else (1, 4, 3, 32, 32)
+    net = fill(step_amd.BaseNet(cfg())).to(dev)
+    net.train()
+    x = (torch.rand(*shape, generator=torch.Generator().manual_seed(10)) * 2 - 1).to(dev)
+    y = net(x)
+    wgt = R.fill_tensor("golden.bwd.base.w", tuple(y.shape), "image")
+    (y * wgt.to(dev)).sum().backward()
+    sd = _oracle_sd(net)
+    yo = R.basenet_forward(x.cpu(), sd)
+    assert rel(np_(y), yo.detach().numpy()) < 1e-4
+    (yo * wgt).sum().backward()
+    n = _grad_check(net.named_parameters(), sd, 1e-3, "BaseNet")
+    assert n == 45
+
+
+def case_contextnet_backward_matches_oracle_autograd(dev, golden):
+    """The ContextNet leg: MaxPoolTF((1,3,3),(1,2,2)) -> mixed_5b -> mixed_5c -> 13x13 average with gradients, parameter
+    gradients AND the gradient handed back to the backbone feature, against autograd through the oracle."""
+    T = 2 if dev != "cpu" else 1
+    net = fill(step_amd.ContextNet(cfg())).to(dev)
+    net.train()
+    # (a generator-drawn feature, not the sin-hash filler: that one is quasi-periodic, two pool windows of one channel can
+    # hold values one ulp apart and the max-pool gradient then goes to whichever the summation order favours)
+    cf = torch.relu(torch.randn(1, T, 832, 25, 25, generator=torch.Generator().manual_seed(11))) * 1.5
+    a = cf.clone().to(dev).requires_grad_(True)
+    y = net(a)
+    wgt = R.fill_tensor("golden.bwd.ctx.w", tuple(y.shape), "image")
+    (y * wgt.to(dev)).sum().backward()
+    sd = _oracle_sd(net)
+    b = cf.clone().requires_grad_(True)
+    yo = R.contextnet_forward(b, sd)
+    assert rel(np_(y), yo.detach().numpy()) < 1e-4
+    (yo * wgt).sum().backward()
+    n = _grad_check(net.named_parameters(), sd, 1e-3, "ContextNet")
+    assert n == 12
+    ga, gb = np_(a.grad).astype(np.float64), b.grad.numpy().astype(np.float64)
+    e = float(np.linalg.norm(ga - gb) / np.linalg.norm(gb))
+    assert e < 1e-3, e
+
+
+def case_base_context_chain_backward(dev, golden):
+    """BaseNet -> ContextNet chained on an [1,8,3,400,400] clip (feature [1,2,832,25,25]): the loss reads both the context
+    vector and the backbone feature, as the training step does (heads read conv_feat through ROIAlign, train.py:296-331), so
+    the backbone's gradients are the SUM of two paths.  All 57 trainable gradients against the oracle's autograd."""
+    base = fill(step_amd.BaseNet(cfg())).to(dev)
+    ctxn = fill(step_amd.ContextNet(cfg())).to(dev)
+    base.train()
+    ctxn.train()
+    x = (torch.rand(1, 8, 3, 400, 400, generator=torch.Generator().manual_seed(12)) * 2 - 1).to(dev)
+    cf = base(x)
+    cx = ctxn(cf)
+    w1 = R.fill_tensor("golden.bwd.chain.w1", tuple(cx.shape), "image")
+    w2 = R.fill_tensor("golden.bwd.chain.w2", tuple(cf.shape), "image") * 0.01
+    ((cx * w1.to(dev)).sum() + (cf * w2.to(dev)).sum()).backward()
+    sdb, sdc = _oracle_sd(base), _oracle_sd(ctxn)
+    cfo = R.basenet_forward(x.cpu(), sdb)
+    cxo = R.contextnet_forward(cfo, sdc)
+    ((cxo * w1).sum() + (cfo * w2).sum()).backward()
+    assert _grad_check(base.named_parameters(), sdb, 1e-3, "chain.BaseNet") == 45
+    assert _grad_check(ctxn.named_parameters(), sdc, 1e-3, "chain.ContextNet") == 12
+
+
 def case_flat_adam_matches_torch(dev, golden):
     """step_amd.optim.FlatAdam against torch.optim.Adam (train.py:126) on the parameter groups utils/solver.py builds
     (bias: 2x lr, no decay): three steps with an lr change in between (the schedulers rewrite group['lr']), a stray
@@ -567,5 +654,6 @@ def case_c2_full_size_properties(dev, golden):
 CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_golden", "case_context_golden",
              "case_twobranch_T3_and_losses_golden", "case_roinet_layouts", "case_training_step_matches_torch_autograd",
              "case_flat_adam_matches_torch", "case_wgrad_into_and_targets", "case_twobranch_variants_golden",
-             "case_reg_unit_pack_follows_weight_updates"]
-GPU_CASES = CPU_CASES + ["case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
+             "case_reg_unit_pack_follows_weight_updates", "case_basenet_backward_matches_oracle_autograd",
+             "case_contextnet_backward_matches_oracle_autograd"]
+GPU_CASES = CPU_CASES + ["case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
