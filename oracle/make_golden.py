@@ -522,8 +522,83 @@ def tube_math_main():
     print("tube_math_golden ok", len(g), "arrays")
 
 
+def postprocess_history(seed, nums, num_classes=60):
+    """A seeded synthetic `history` (utils/utils.py:81-85) that exercises every branch of the evaluation loop: scores below
+    conf_thresh, exact score ties inside and across classes, whole classes without a detection, boxes that valid_tubes
+    clamps, and degenerate boxes it replaces by the whole image."""
+    rs = np.random.RandomState(seed)
+    N = int(sum(nums))
+    hist = []
+    for Tl in (3, 3, 9):
+        xy = rs.uniform(-30, 330, (N, Tl, 2))
+        wh = rs.uniform(-5, 160, (N, Tl, 2))                          # some negative / < 2 px sizes -> whole-image boxes
+        loc = np.concatenate([xy, xy + wh], 2).astype(np.float32)
+        loc[rs.rand(N) < 0.3] += rs.uniform(0, 120, (1, 1, 4)).astype(np.float32)   # clusters of overlapping boxes
+        prob = rs.rand(N, num_classes).astype(np.float32) ** 6        # most scores tiny
+        prob[rs.rand(N, num_classes) < 0.25] = 0.005                  # below conf_thresh
+        prob = np.round(prob * 16) / 16 * (rs.rand(N, num_classes) < 0.5) + prob * 0.02   # ties: multiples of 1/16 + small
+        prob[:, 7] = 0.0                                              # a class with no detection at all
+        prob[:, 9] = 0.5                                              # a class where every box ties
+        prob = prob.astype(np.float32)
+        hist.append({"pred_prob": np.repeat(prob[:, None, :], Tl, axis=1), "pred_loc": loc, "tubes_nums": list(nums)})
+    return hist
+
+
+def postprocess_main():
+    """Run the evaluation loop of the reference's test.py (:157-210 -- it is inline code of main(), not a function) on the
+    seeded history: the loop's source is read from the reference where it lies, compiled and executed here with the
+    reference's own nms / valid_tubes; the fixture records, for every row the loop writes, (iteration, clip, class, box, score)
+    in the order written, plus the text lines themselves."""
+    import io
+    import textwrap
+    models, ref_utils, ref_nms, _ = import_reference()
+    from utils.tube_utils import valid_tubes as ref_valid_tubes   # reference
+    src = open(os.path.join(REF, "test.py")).read().split("\n")
+    beg = next(k for k, l in enumerate(src) if l.strip() == "# loop for each  iteration")
+    end = next(k for k, l in enumerate(src) if k > beg and l.strip() == "fout.close()")
+    body = textwrap.dedent("\n".join(src[beg:end]))
+    code = compile(body, os.path.join(REF, "test.py") + ":eval-loop", "exec")
+    g = {}
+    nums = [11, 7, 9]
+    cases = {"all": dict(evaluate_topk=-1, topk=-1), "top20": dict(evaluate_topk=1, topk=20), "topm1": dict(evaluate_topk=5, topk=-1)}
+    hist_np = postprocess_history(2024, nums)
+    for i, h in enumerate(hist_np):
+        g["hist%d_prob" % i] = h["pred_prob"][:, 0].copy()
+        g["hist%d_loc" % i] = h["pred_loc"]
+    g["nums"] = np.asarray(nums)
+    for tag, kw in cases.items():
+        args = types.SimpleNamespace(num_classes=60, conf_thresh=0.01, nms_thresh=0.4, **kw)
+        history = [{"pred_prob": torch.from_numpy(h["pred_prob"].copy()), "pred_loc": torch.from_numpy(h["pred_loc"].copy()),
+                    "tubes_nums": list(nums)} for h in hist_np]
+        rows, lines = [], []
+
+        class Sink:
+            def __init__(self, ns):
+                self.ns = ns
+
+            def write(self, text):
+                ns = self.ns                                     # the loop's own variables at the moment it writes a row
+                rows.append([ns["i"], ns["b"], ns["cl_ind"]] + [float(v) for v in ns["box"]] + [float(ns["s"])])
+                lines.append(text)
+
+        ns = {"np": np, "nms": ref_nms, "valid_tubes": ref_valid_tubes, "args": args, "history": history,
+              "infos": [{"video_name": "vid%d" % b, "fid": 900 + b} for b in range(len(nums))],
+              "label_dict": {c: c + 1 for c in range(60)}, "width": 400, "height": 400}
+        ns["fouts"] = [Sink(ns) for _ in history]
+        exec(code, ns)
+        r = np.asarray(rows, np.float64)
+        g[tag + "_meta"] = r[:, :3].astype(np.int32)
+        g[tag + "_box"] = r[:, 3:7].astype(np.float32)
+        g[tag + "_score"] = r[:, 7].astype(np.float32)
+        g[tag + "_lines"] = np.asarray(lines)
+        print("postprocess", tag, len(rows), "rows")
+    np.savez_compressed(os.path.join(OUT, "postprocess_golden.npz"), **g)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "tube_math":
+    if len(sys.argv) > 1 and sys.argv[1] == "postprocess":
+        postprocess_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "tube_math":
         tube_math_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "variants":
         variants_main()
@@ -537,3 +612,4 @@ if __name__ == "__main__":
         modes_main()
         variants_main()
         tube_math_main()
+        postprocess_main()

@@ -39,13 +39,23 @@ def inference(args, conv_feat, context_feat, nets, exec_iter, tubes):
     """args: Namespace with T, NUM_CHUNKS, max_iter, num_classes, image_size, no_context, temporal_mode
     conv_feat [B,T_all,C,H,W] (BaseNet output), context_feat [B,1024,T_all,1,1] or None,
     nets: {'roi_net': ROINet, 'det_net0': TwoBranchNet, ...}, tubes: list of [n_i,T,4] per clip.
-    Returns (history, trajectory) like the reference."""
+    Returns (history, trajectory) in the reference's form: history[i] = {pred_prob [N,Tl,classes], pred_loc [N,Tl,4],
+    pred_first_loc / pred_last_loc [N,T,4] (None unless temporal_mode == "predict"), tubes_nums}, detached;
+    trajectory[i] = per clip (numpy proposals for the next step, class index [n,Tl])."""
     if getattr(args, "temporal_mode", "predict") not in ("predict", "extrapolate", "mean"):
         raise NotImplementedError("step_amd.driver.inference: temporal_mode %r" % (args.temporal_mode,))
     dev = conv_feat.device
     flat, nums = _flat_tubes(tubes, dev)
     clip_of = torch.as_tensor(np.repeat(np.arange(len(nums)), nums), device=dev)
-    return inference_flat(args, conv_feat, context_feat, nets, exec_iter, flat, nums, clip_of)
+    history, traj = inference_flat(args, conv_feat, context_feat, nets, exec_iter, flat, nums, clip_of)
+    # the reference's trajectory (utils.py:87-124): per step, per clip (numpy proposals [n,T',4], class index [n,Tl])
+    trajectory = []
+    for (prop, cls), h in zip(traj, history):
+        Tl = h["pred_loc"].shape[1]
+        props = np.split(prop.detach().cpu().numpy(), np.cumsum(nums)[:-1], axis=0)
+        classes = torch.split(cls.view(-1, 1).expand(-1, Tl), nums, dim=0)
+        trajectory.append(list(zip(props, classes)))
+    return history, trajectory
 
 
 def inference_flat(args, conv_feat, context_feat, nets, exec_iter, flat, nums, clip_of):
@@ -75,12 +85,13 @@ def inference_flat(args, conv_feat, context_feat, nets, exec_iter, flat, nums, c
         lo2, hi2 = chunk_idx[-1] - half_T, chunk_idx[-1] + half_T + 1
         pred_first = decode_coef(flat[:, lo:hi].reshape(-1, 5)[:, 1:], first_loc.reshape(-1, 4)).view(first_loc.shape)
         pred_last = decode_coef(flat[:, lo2:hi2].reshape(-1, 5)[:, 1:], last_loc.reshape(-1, 4)).view(last_loc.shape)
-        history.append({"pred_prob": pred_prob, "pred_loc": pred_loc, "pred_first_loc": pred_first,
-                        "pred_last_loc": pred_last, "tubes_nums": list(nums)})
+        mode = getattr(args, "temporal_mode", "predict")
+        history.append({"pred_prob": pred_prob.detach(), "pred_loc": pred_loc.detach(),            # utils.py:81-85 (.data)
+                        "pred_first_loc": pred_first.detach() if mode == "predict" else None,
+                        "pred_last_loc": pred_last.detach() if mode == "predict" else None, "tubes_nums": list(nums)})
 
         # next step's proposals (utils.py:91-129), all clips at once
         if i < args.max_iter and args.NUM_CHUNKS[i + 1] == args.NUM_CHUNKS[i] + 2:
-            mode = getattr(args, "temporal_mode", "predict")
             if mode == "predict":
                 prop = torch.cat([pred_first, pred_loc, pred_last], dim=1)
             elif mode == "extrapolate":
@@ -98,46 +109,91 @@ def inference_flat(args, conv_feat, context_feat, nets, exec_iter, flat, nums, c
     return history, trajectory
 
 
-def postprocess(args, history, conf_thresh=0.01, nms_thresh=0.4, topk=300):
-    """Per-(clip, class) NMS on the middle-frame boxes of the final step -- the batched form of the
-    reference's Python loop over 60 classes (test.py:157-218).  One nms launch for all groups.
-    Returns a list (per clip) of (boxes [m,4] normalised, scores [m], labels [m])."""
+def _clip_groups(nums, device):
+    """Index tables of the ragged (clip, tube) layout: gather index [B,kmax] into the flat tube axis (clamped) and the
+    validity mask [B,kmax]; built from host ints without touching the device data."""
+    B, kmax = len(nums), max(max(nums), 1)
+    n = torch.as_tensor(nums, device=device, dtype=torch.int64)
+    start = torch.cumsum(n, 0) - n
+    j = torch.arange(kmax, device=device, dtype=torch.int64)
+    valid = j.view(1, kmax) < n.view(B, 1)
+    idx = (start.view(B, 1) + j.view(1, kmax)).clamp_(max=max(int(sum(nums)) - 1, 0))
+    return idx, valid
+
+
+def postprocess(args, history, conf_thresh=None, nms_thresh=None, evaluate_topk=None, topk=None, iterations=None):
+    """The evaluation loop of test.py:157-210 (the same code is inlined in train.py:512-573 and demo.py:123-174) as batched
+    tensor operations: for EVERY refinement iteration and every clip, per class: mask the middle-frame scores with
+    `score > conf_thresh`, valid_tubes() the middle-frame boxes (its 400 x 400 default, as the reference calls it), greedy
+    NMS, normalise by the frame size; then the reference's row order -- classes ascending, kept tubes in ascending original
+    order -- or, with evaluate_topk > 0, its stable ascending score sort, reversed, cut at `[:args.topk]` (including what that
+    slice does for topk = -1).  All (clip, class) groups of an iteration go through ONE nms launch (the reference makes
+    60 x B serial CPU calls) and there is no Python loop over classes or boxes; one host synchronisation per iteration
+    fetches the row counts for the per-clip split.
+
+    Thresholds default to args.conf_thresh / nms_thresh / evaluate_topk / topk (config.py:62-65).
+    Returns a list over iterations of lists over clips of dicts {boxes [m,4] fp32 normalised, scores [m], labels [m] (class
+    index), tubes [m] (index of the tube inside its clip)} in the order the reference writes its CSV rows."""
     from .roi_layers import nms_batched
 
-    h = history[-1]
-    nums = h["tubes_nums"]
-    Tl = h["pred_loc"].shape[1]
-    mid = Tl // 2
-    boxes = valid_tubes(h["pred_loc"][:, mid:mid + 1].float(), args.image_size[0], args.image_size[1])[:, 0]   # [N,4]
-    scores = h["pred_prob"][:, mid].float()                                                                   # [N,classes]
-    dev = boxes.device
-    B, kmax, NC = len(nums), max(nums), scores.shape[1]
-    gb = torch.zeros((B, NC, kmax, 4), device=dev)
-    gs = torch.full((B, NC, kmax), -1.0, device=dev)
-    start = 0
-    for b, n in enumerate(nums):
-        gb[b, :, :n] = boxes[start:start + n].unsqueeze(0)
-        gs[b, :, :n] = scores[start:start + n].t()
-        start += n
-    # reference masks score > conf_thresh BEFORE nms (test.py:180-186): push the others past `counts`
-    valid = gs > conf_thresh
-    order = torch.argsort((~valid).to(torch.int8), dim=2, stable=True)             # valid boxes first, original order kept
-    gb = torch.gather(gb, 2, order.unsqueeze(-1).expand(-1, -1, -1, 4))
-    gs = torch.gather(gs, 2, order)
-    counts = valid.sum(2).to(torch.int32)
-    keep = nms_batched(gb.view(B * NC, kmax, 4), gs.view(B * NC, kmax), counts.view(-1), nms_thresh).view(B, NC, kmax).bool()
-    out = []
+    conf = float(getattr(args, "conf_thresh", 0.01) if conf_thresh is None else conf_thresh)
+    thr = float(getattr(args, "nms_thresh", 0.4) if nms_thresh is None else nms_thresh)
+    etopk = int(getattr(args, "evaluate_topk", -1) if evaluate_topk is None else evaluate_topk)
+    topk = int(getattr(args, "topk", -1) if topk is None else topk)
     W, H = float(args.image_size[0]), float(args.image_size[1])
-    for b in range(B):
-        kb = keep[b]
-        cls = torch.nonzero(kb)[:, 0]
-        bx = gb[b][kb] / torch.tensor([W, H, W, H], device=dev)
-        sc = gs[b][kb]
-        if topk > 0 and sc.numel() > topk:
-            sc, sel = torch.topk(sc, topk)
-            bx, cls = bx[sel], cls[sel]
-        out.append((bx, sc, cls))
+    out = []
+    for it, h in enumerate(history):
+        if iterations is not None and it not in iterations:
+            continue
+        nums = [int(v) for v in h["tubes_nums"]]
+        prob, loc = h["pred_prob"], h["pred_loc"]
+        dev = loc.device
+        B, NC = len(nums), prob.shape[-1]
+        if B == 0 or sum(nums) == 0:
+            e = torch.zeros(0, device=dev)
+            out.append([{"boxes": e.view(0, 4), "scores": e, "labels": e.long(), "tubes": e.long()} for _ in nums])
+            continue
+        boxes = valid_tubes(loc[:, int(loc.shape[1] / 2)].float().unsqueeze(1))[:, 0]                 # [N,4] (test.py:161,191)
+        scores = prob[:, int(prob.shape[1] / 2)].float()                                              # [N,NC] (:159)
+        idx, valid = _clip_groups(nums, dev)
+        kmax = idx.shape[1]
+        gs = scores[idx].permute(0, 2, 1)                                                             # [B,NC,kmax]
+        mask = (gs > conf) & valid.view(B, 1, kmax)                                                   # :180
+        # the reference compacts the masked boxes before nms (order kept): move them to the front of each group
+        order = torch.argsort((~mask).to(torch.int8), dim=2, stable=True)
+        gs = torch.gather(gs, 2, order)
+        gb = boxes[idx].view(B, 1, kmax, 4).expand(B, NC, kmax, 4)
+        gb = torch.gather(gb, 2, order.unsqueeze(-1).expand(B, NC, kmax, 4)).contiguous()
+        counts = mask.sum(2).to(torch.int32)
+        keep = nms_batched(gb.view(B * NC, kmax, 4), gs.reshape(B * NC, kmax), counts.view(-1), thr).view(B, NC, kmax).bool()
+        # rows in the reference's order: clip, class ascending, kept tube ascending == row-major order of `keep`
+        kb, kc, kj = torch.nonzero(keep, as_tuple=True)
+        rb = gb[kb, kc, kj] / torch.tensor([W, H, W, H], device=dev)                                  # :197-198
+        rs = gs[kb, kc, kj]
+        rt = order[kb, kc, kj]
+        per_clip = torch.bincount(kb, minlength=B).tolist()                                           # the one host sync
+        clips = []
+        for bx, sc, cl, tb in zip(rb.split(per_clip), rs.split(per_clip), kc.split(per_clip), rt.split(per_clip)):
+            if etopk > 0:                                                                             # :205-208
+                # list.sort(key=score) is stable and ascending, then reversed: descending with ties in REVERSED row order
+                sel = torch.flip(torch.argsort(sc, stable=True), dims=(0,))[:topk]
+                bx, sc, cl, tb = bx[sel], sc[sel], cl[sel], tb[sel]
+            clips.append({"boxes": bx, "scores": sc, "labels": cl, "tubes": tb})
+        out.append(clips)
     return out
+
+
+def detections_csv(dets, infos, label_dict=None):
+    """The text test.py:210-218 writes for one iteration: `dets` = one entry of postprocess()'s result, infos = per clip
+    {'video_name', 'fid'}; label_dict maps class index -> label id (identity + 1 when None)."""
+    lines = []
+    for d, info in zip(dets, infos):
+        bx, sc, cl = d["boxes"].cpu().numpy(), d["scores"].cpu().numpy(), d["labels"].cpu().numpy()
+        for k in range(len(sc)):
+            lab = int(cl[k]) + 1 if label_dict is None else label_dict[int(cl[k])]
+            lines.append("{0},{1:04},{2:.4},{3:.4},{4:.4},{5:.4},{6},{7:.4}\n".format(
+                info["video_name"], info["fid"], bx[k, 0], bx[k, 1], bx[k, 2], bx[k, 3], lab, sc[k]))
+    return lines
 
 
 class GraphedInference:

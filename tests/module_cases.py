@@ -237,14 +237,59 @@ def case_inference_modes_golden(dev, golden):
         args = cfg(temporal_mode=mode)
         with torch.no_grad():
             hist, traj = inference(args, conv_cl, ctxnet(conv_cl), nets, 3, tl)
-        assert tuple(traj[1][0].shape) == (22, 9, 4)
-        e = rel(np_(traj[1][0]), g["%s_step1_proposals" % mode])
+        # the reference's trajectory form: per step, per clip (numpy proposals, class index [n,Tl])
+        assert len(traj) == 3 and len(traj[1]) == 2 and isinstance(traj[1][0][0], np.ndarray)
+        assert tuple(traj[1][0][1].shape) == (11, 3) and traj[1][0][1].dtype == torch.int64
+        assert hist[1]["pred_first_loc"] is None and hist[1]["pred_last_loc"] is None        # utils.py:83-84
+        props = np.concatenate([c[0] for c in traj[1]], axis=0)
+        assert props.shape == (22, 9, 4)
+        e = rel(props, g["%s_step1_proposals" % mode])
         assert e < 1e-3, (mode, "proposals", e)
         for i, h in enumerate(hist):
             for k, ref in (("pred_prob", g["%s_step%d_pred_prob" % (mode, i)]), ("pred_loc", g["%s_step%d_pred_loc" % (mode, i)])):
                 got = np_(h[k][:, 0]) if k == "pred_prob" else np_(h[k])
                 e = rel(got, ref)
                 assert e < 1e-3, (mode, i, k, e)
+
+
+def case_postprocess_golden(dev, golden):
+    """driver.postprocess (batched per-(clip, class) device NMS, every refinement iteration, tensor ops only) against the rows
+    the reference's own evaluation loop wrote for a seeded history with ragged clips (test.py:157-210, recorded by
+    oracle/make_golden.py): same rows in the same order, boxes / scores bit-identical, and the same CSV text; all three
+    evaluate_topk / topk settings including the reference's `[:-1]` slice."""
+    from step_amd.driver import detections_csv, postprocess
+    g = golden("postprocess_golden")
+    nums = [int(v) for v in g["nums"]]
+    hist = []
+    for i in range(3):
+        loc = torch.from_numpy(g["hist%d_loc" % i]).to(dev)
+        prob = torch.from_numpy(g["hist%d_prob" % i]).to(dev)
+        hist.append({"pred_prob": prob.unsqueeze(1).expand(-1, loc.shape[1], -1), "pred_loc": loc, "tubes_nums": nums})
+    for tag, kw in (("all", dict(evaluate_topk=-1, topk=-1)), ("top20", dict(evaluate_topk=1, topk=20)), ("topm1", dict(evaluate_topk=5, topk=-1))):
+        args = cfg(conf_thresh=0.01, nms_thresh=0.4, **kw)
+        dets = postprocess(args, hist)
+        assert len(dets) == 3 and all(len(d) == len(nums) for d in dets)
+        meta, box, score, lines = [], [], [], []
+        for it, clips in enumerate(dets):
+            for b, d in enumerate(clips):
+                m = int(d["scores"].shape[0])
+                meta += [[it, b, int(c)] for c in d["labels"].cpu()]
+                box.append(np_(d["boxes"]).reshape(m, 4))
+                score.append(np_(d["scores"]))
+                assert bool((d["tubes"] < nums[b]).all())
+            lines += detections_csv(clips, [{"video_name": "vid%d" % b, "fid": 900 + b} for b in range(len(nums))])
+        assert np.array_equal(np.asarray(meta, np.int32), g[tag + "_meta"]), tag
+        assert np.array_equal(np.concatenate(box), g[tag + "_box"]), tag
+        assert np.array_equal(np.concatenate(score), g[tag + "_score"]), tag
+        assert lines == [str(x) for x in g[tag + "_lines"]], tag
+    # one iteration only, and an empty clip in the batch
+    only = postprocess(cfg(), hist, iterations=(2,))
+    assert len(only) == 1
+    h0 = {"pred_prob": hist[0]["pred_prob"][:18], "pred_loc": hist[0]["pred_loc"][:18], "tubes_nums": [11, 0, 7]}
+    d0 = postprocess(cfg(), [h0])[0]
+    assert d0[1]["scores"].numel() == 0
+    full = postprocess(cfg(), hist, iterations=(0,))[0]
+    assert torch.equal(d0[0]["boxes"], full[0]["boxes"]) and torch.equal(d0[2]["scores"], full[1]["scores"])
 
 
 def case_inference_golden_34(dev, golden):
@@ -655,5 +700,5 @@ CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_g
              "case_twobranch_T3_and_losses_golden", "case_roinet_layouts", "case_training_step_matches_torch_autograd",
              "case_flat_adam_matches_torch", "case_wgrad_into_and_targets", "case_twobranch_variants_golden",
              "case_reg_unit_pack_follows_weight_updates", "case_basenet_backward_matches_oracle_autograd",
-             "case_contextnet_backward_matches_oracle_autograd"]
+             "case_contextnet_backward_matches_oracle_autograd", "case_postprocess_golden"]
 GPU_CASES = CPU_CASES + ["case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]

@@ -200,3 +200,36 @@ def test_inference_history(golden, ntubes):
         assert rel_err(h["pred_prob"][:, 0].numpy(), g["n%d_step%d_pred_prob" % (ntubes, i)]) < 1e-4
         for k in ("pred_loc", "pred_first_loc", "pred_last_loc"):
             assert rel_err(h[k].numpy(), g["n%d_step%d_%s" % (ntubes, i, k)]) < 1e-4, (i, k)
+
+
+POST_CASES = {"all": dict(evaluate_topk=-1, topk=-1), "top20": dict(evaluate_topk=1, topk=20), "topm1": dict(evaluate_topk=5, topk=-1)}
+
+
+def postprocess_fixture_history(g):
+    nums = [int(v) for v in g["nums"]]
+    hist = []
+    for i in range(3):
+        loc = g["hist%d_loc" % i]
+        hist.append({"pred_prob": np.repeat(g["hist%d_prob" % i][:, None, :], loc.shape[1], axis=1), "pred_loc": loc, "tubes_nums": nums})
+    return hist
+
+
+@pytest.mark.parametrize("tag", sorted(POST_CASES))
+def test_postprocess_restatement_matches_the_reference_loop(golden, tag):
+    """oracle/postprocess_ref.py against what the reference's own evaluation loop (test.py:157-210, executed by
+    oracle/make_golden.py on a seeded history) wrote: same rows, same order, bit-identical boxes and scores, and the same
+    CSV text."""
+    from oracle import postprocess_ref as P
+    g = golden("postprocess_golden")
+    rows = P.postprocess(postprocess_fixture_history(g), **POST_CASES[tag])
+    meta, box, score = g[tag + "_meta"], g[tag + "_box"], g[tag + "_score"]
+    assert len(rows) == len(meta)
+    got_meta = np.asarray([[r[0], r[1], r[2]] for r in rows], np.int32)
+    assert np.array_equal(got_meta, meta)
+    assert np.array_equal(np.asarray([r[3:7] for r in rows], np.float32), box)
+    assert np.array_equal(np.asarray([r[7] for r in rows], np.float32), score)
+    lines = [P.csv_line("vid%d" % r[1], 900 + r[1], r[3:7], r[2] + 1, r[7]) for r in rows]
+    assert lines == [str(x) for x in g[tag + "_lines"]]
+    if tag == "topm1":                                   # the reference's `[:args.topk]` with topk = -1 drops the last row
+        full = P.postprocess(postprocess_fixture_history(g), evaluate_topk=-1, topk=-1)
+        assert len(rows) == len(full) - 9
