@@ -149,7 +149,9 @@ class BucketedReducer:
         self._armed = True
 
     def _autograd_ready(self, p):
-        if self._armed:
+        # (autograd runs this hook for EVERY leaf it reaches, also when the gradient that arrives is undefined -- which is
+        # what the conv units return for a weight whose gradient they accumulated themselves and announced already)
+        if self._armed and id(p) not in self.seen:
             self.ready(p, None)
 
     def ready(self, p, stream=None):

@@ -24,6 +24,26 @@ def _model():
     return torch.nn.Sequential(torch.nn.Conv3d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Flatten(), torch.nn.Linear(4 * 2 * 4 * 4, 5))
 
 
+class _DirectLinear(torch.autograd.Function):
+    """Mimics the conv units under backbone.wgrad_into_grad(): the weight gradient is ADDED to weight.grad by the op itself,
+    announced through backbone.GRAD_READY, and autograd gets None for it (its post-accumulate hook still fires for that
+    parameter -- with an undefined gradient -- which the reducer must not count as a second gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        from step_amd import backbone
+        x, w = ctx.saved_tensors
+        w.grad.add_(g.t() @ x)
+        if backbone.GRAD_READY is not None:
+            backbone.GRAD_READY(w, None)
+        return g @ w, None
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from step_amd import dist as D
@@ -86,7 +106,7 @@ def _worker(rank, world, port, q):
             else:
                 loss = ((y - target[idx]) ** 2).mean()
             if rank == 0:
-                loss = loss + 0.0 * extra(y).sum() + 0.5 * (extra(y.detach()) ** 2).mean()
+                loss = loss + 0.5 * ((_DirectLinear.apply(y.detach(), extra.weight) + extra.bias) ** 2).mean()
             loss.backward()
             during = red.issued_during_backward
             f = red.finish()
