@@ -118,6 +118,14 @@ constexpr int CONV_GEN_NPIX = 768;         // LDS halo pixels reserved for a gen
 constexpr int CONV_GEN_NPIX_SMALL = 640;   // ... in the NB = 1 instantiation: 50 KiB + 24 KiB of weights = two workgroups
                                            // per CU (the small 14x14 / 7x7 layers are latency-bound with one)
 
+// WV = 4 (two resident workgroups per CU): 36 KiB (NB = 3) / 24 KiB of weight step buffers leave 44 / 56 KiB of the 80 KiB
+// per-workgroup budget for the halo of a general box of <= 128 pixels
+constexpr int CONV_GEN_NPIX4 = 544;
+constexpr int CONV_GEN_NPIX4_WIDE = 688;
+__host__ __device__ constexpr int conv_gen_npix(int wv, int nb) {
+    return wv == 8 ? (nb == 1 ? CONV_GEN_NPIX_SMALL : CONV_GEN_NPIX) : (nb >= 3 ? CONV_GEN_NPIX4 : CONV_GEN_NPIX4_WIDE);
+}
+
 static inline unsigned flat_grid(long long total, int block) {
     long long g = ceil_div64(total, block);
     if (g > 16384) g = 16384;
@@ -125,7 +133,7 @@ static inline unsigned flat_grid(long long total, int block) {
 }
 
 
-struct ConvPlan { bool ok, flat, wide, deep; int impl, NB, tps, mb, twl, tiles_h, tiles_w, tiles_d, gtd, gth, gtw, ksplit, kchunk16, mbk, mpad, cpad; long long mtiles; };
+struct ConvPlan { bool ok, flat, wide, deep; int impl, NB, tps, mb, wv, twl, tiles_h, tiles_w, tiles_d, gtd, gth, gtw, ksplit, kchunk16, mbk, mpad, cpad; long long mtiles; };
 
 static inline int conv_impl_override() {   // tuning aid: STEP_CONV_IMPL=igemm|tap|tap2 forces one implementation
     const char* e = getenv("STEP_CONV_IMPL");
@@ -138,7 +146,7 @@ static inline int conv_impl_override() {   // tuning aid: STEP_CONV_IMPL=igemm|t
 
 // launchers defined in the other translation units (explicitly instantiated for float, bf16_t, f16_t)
 template <typename T> int conv_tap_launch(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream);   // conv_tap_<dtype>.hip
-template <typename T> int conv_pw_launch(int NB, const ConvParams& p, dim3 grid, step_stream_t stream);                        // conv_pw.hip
+template <typename T> int conv_pw_launch(int NB, int wv, const ConvParams& p, dim3 grid, step_stream_t stream);                        // conv_pw.hip
 template <typename T> int conv_splitk_launch(const ConvPlan& pl, const ConvParams& p, float* ws, step_stream_t stream);        // conv_pw.hip
 
 }  // namespace step

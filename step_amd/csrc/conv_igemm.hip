@@ -328,16 +328,17 @@ static int pick_nb(int nblk32, long long mtiles) {
 //   impl 1: conv_tap_kernel   (8 waves, 256-px tile, weights through an LDS-DMA double buffer)
 
 
-static int pick_nb_tap(int nblk32, long long mtiles) {
-    static const int forced = getenv("STEP_CONV_NB") ? atoi(getenv("STEP_CONV_NB")) : 0;     // tuning aid
+static int pick_nb_tap(int nblk32, long long mtiles, int slots = 256) {
+    const int forced = getenv("STEP_CONV_NB") ? atoi(getenv("STEP_CONV_NB")) : 0;     // tuning aid / tests (read per call)
     if (forced >= 1 && forced <= 3) return forced;
     int best = 1;
     double best_cost = -1;
     for (int nb = 3; nb >= 1; --nb) {   // 2 fragment sets + 2*nb accumulators must fit 256 VGPRs: nb <= 3
         const long long groups = ceil_div(nblk32, 2 * nb);
         const long long wgs = groups * mtiles;
-        // one 512-thread workgroup per CU: rounds of 256; per-workgroup time ~ 2*nb MFMA units + fixed part
-        const double cost = (double)ceil_div64(wgs, 256) * (2.0 * nb + 1.5) - 0.01 * nb;
+        // `slots` resident workgroups on the chip (256 eight-wave ones, 512 four-wave ones): rounds of that many;
+        // per-workgroup time ~ 2*nb MFMA units + fixed part
+        const double cost = (double)ceil_div64(wgs, slots) * (2.0 * nb + 1.5) - 0.01 * nb;
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nb; }
     }
     return best;
@@ -356,17 +357,17 @@ static step_conv_desc canonical_desc(const step_conv_desc* d) {
 // reservation; fewest tiles wins, then the smaller halo.  Rows stay wide (the whole map width or half of it):
 // a box of short rows, e.g. 16x4x4 on a 28x28 map, needs the fewest tiles (49 against 64) but measured 70 % more
 // time per tile -- eight 4-pixel rows per MFMA row block conflict in LDS and the halo is 2.5x the tile.
-static long long best_gen_box(int D, int H, int W, int kd, int npix_limit, int* btd, int* bth, int* btw) {
+static long long best_gen_box(int D, int H, int W, int kd, int npix_limit, int* btd, int* bth, int* btw, int pxmax = 256) {
     long long best = -1; int bhalo = 0;
     for (int kw_ = 1; kw_ <= 8; ++kw_) {
         const int tw = ceil_div(W, kw_);
-        if (tw > 256) continue;
+        if (tw > pxmax) continue;
         if (kw_ > 2 && tw < 16) break;
         for (int kh_ = 1; kh_ <= H; ++kh_) {
             const int th = ceil_div(H, kh_);
-            if (th * tw > 256) continue;
+            if (th * tw > pxmax) continue;
             if (kh_ > 1 && th == ceil_div(H, kh_ - 1)) continue;
-            for (int td = 1; td <= D && td * th * tw <= 256; ++td) {
+            for (int td = 1; td <= D && td * th * tw <= pxmax; ++td) {
                 const int halo = (td + kd - 1) * (th + 2) * (tw + 2);
                 if (halo > npix_limit) break;
                 const long long tiles = (long long)ceil_div(D, td) * ceil_div(H, th) * ceil_div(W, tw);
@@ -377,9 +378,20 @@ static long long best_gen_box(int D, int H, int W, int kd, int npix_limit, int* 
     return best;
 }
 
+// Which form of conv_tap_kernel: measured rule (DESIGN.md, 3x3x3 family).
+static bool prefer_four_waves(const ConvPlan& p8, const ConvPlan& p4, const step_conv_desc* d) {
+    (void)p8; (void)p4; (void)d;
+    return false;
+}
+
+static bool prefer_four_waves_pw(const step_conv_desc* d) {
+    (void)d;
+    return false;
+}
+
 static ConvPlan conv_plan(const step_conv_desc* d) {
     ConvPlan pl;
-    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1; pl.mb = 2; pl.deep = false; pl.twl = 4; pl.tiles_d = d->D; pl.gtd = pl.gth = pl.gtw = 1; pl.ksplit = 0; pl.kchunk16 = 0; pl.mbk = 0; pl.mpad = 0; pl.cpad = 0;
+    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1; pl.mb = 2; pl.wv = 8; pl.deep = false; pl.twl = 4; pl.tiles_d = d->D; pl.gtd = pl.gth = pl.gtw = 1; pl.ksplit = 0; pl.kchunk16 = 0; pl.mbk = 0; pl.mpad = 0; pl.cpad = 0;
     const int nblk32 = ceil_div(d->Cout, 32);
     const bool k1 = d->kd == 1 && d->kh == 1 && d->kw == 1;
     const bool k333 = d->kd == 3 && d->kh == 3 && d->kw == 3;
@@ -393,8 +405,11 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
         const int ov1 = conv_impl_override();
         if (ov1 == 5 || (ov1 != 0 && d->Cin >= 128 && d->Cout >= 64 && mt256 * ceil_div(nblk32, 2) >= 32)) {
             pl.impl = 2;
-            pl.mtiles = mt256;
-            pl.NB = pick_nb_tap(nblk32, mt256);
+            const int waves_env = getenv("STEP_CONV_WAVES") ? atoi(getenv("STEP_CONV_WAVES")) : 0;      // tuning aid / tests: 4 | 8
+            const bool four = waves_env == 4 || (waves_env != 8 && prefer_four_waves_pw(d));
+            pl.wv = four ? 4 : 8;
+            pl.mtiles = four ? ceil_div64((long long)d->N * d->D * d->H * d->W, 128) : mt256;
+            pl.NB = pick_nb_tap(nblk32, pl.mtiles, four ? 512 : 256);
             return pl;
         }
         // few rows x very deep K (the heads' Linear layers): split K over the chip (needs the workspace of
@@ -456,6 +471,46 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
         }
     }
     const long long mt256 = (long long)d->N * tbest;
+    // ---- the four-wave form (128-pixel tiles, two resident workgroups per CU; conv_tap_kernel.h): its own tile search
+    const int waves_env = getenv("STEP_CONV_WAVES") ? atoi(getenv("STEP_CONV_WAVES")) : 0;      // tuning aid / tests: 4 | 8 (read per call)
+    ConvPlan p4 = pl;
+    bool have4 = false;
+    {
+        const long long a16 = (long long)d->D * ceil_div(d->H, 8) * ceil_div(d->W, 16);
+        const long long a32 = (long long)d->D * ceil_div(d->H, 4) * ceil_div(d->W, 32);
+        const long long a8 = (long long)ceil_div(d->D, 2) * ceil_div(d->H, 8) * ceil_div(d->W, 8);
+        int tw4 = 4;
+        long long tb4 = a16;
+        if (a8 < tb4) { tb4 = a8; tw4 = 3; }
+        // (the 4 x 32 shape only when it beats both: its 612-pixel halo does not leave room for a second workgroup)
+        if (a32 * 100 < tb4 * 90) { tb4 = a32; tw4 = 5; }
+        int g4d = 1, g4h = 1, g4w = 1;
+        if (gen_pct > 0) {
+            int limit = CONV_GEN_NPIX4_WIDE;
+            for (int pass = 0; pass < 2; ++pass) {
+                int td_ = 1, th_ = 1, tw_ = 1;
+                const long long tg = best_gen_box(d->D, d->H, d->W, d->kd, limit, &td_, &th_, &tw_, 128);
+                if (!(tg > 0 && tg * 100 <= tb4 * gen_pct)) break;
+                const int nb = pick_nb_tap(nblk32, (long long)d->N * tg, 512);
+                if (nb >= 3 && limit != CONV_GEN_NPIX4) { limit = CONV_GEN_NPIX4; continue; }    // NB = 3 reserves a smaller halo
+                tb4 = tg; tw4 = 0; g4d = td_; g4h = th_; g4w = tw_;
+                break;
+            }
+        }
+        p4.wv = 4; p4.twl = tw4; p4.wide = tw4 == 5; p4.gtd = g4d; p4.gth = g4h; p4.gtw = g4w;
+        if (tw4 == 0) {
+            p4.tiles_d = ceil_div(d->D, g4d); p4.tiles_h = ceil_div(d->H, g4h); p4.tiles_w = ceil_div(d->W, g4w);
+        } else {
+            p4.tiles_d = tw4 == 3 ? ceil_div(d->D, 2) : d->D;
+            p4.tiles_h = tw4 == 5 ? ceil_div(d->H, 4) : ceil_div(d->H, 8);
+            p4.tiles_w = tw4 == 4 ? ceil_div(d->W, 16) : (tw4 == 5 ? ceil_div(d->W, 32) : ceil_div(d->W, 8));
+        }
+        p4.mtiles = (long long)d->N * tb4;
+        p4.NB = pick_nb_tap(nblk32, p4.mtiles, 512);
+        if (tw4 == 0 && p4.NB >= 3 && (g4d + d->kd - 1) * (g4h + 2) * (g4w + 2) > CONV_GEN_NPIX4) p4.NB = 2;   // (forced NB with a wide box)
+        p4.impl = 1; p4.tps = p4.NB == 1 ? 2 : 1; p4.mb = 2;
+        have4 = true;
+    }
     // few-tile, small-Cin problems stay on the 4-wave 128-pixel kernel (more workgroups); everything else -- the
     // Cin = 16/32 branches of the Inception blocks included (measured: 9 x 3x3x3 layers 0.253 ms against 0.317 ms) --
     // runs the pipelined kernel
@@ -478,6 +533,7 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
         }
         pl.mtiles = mt256;
         pl.NB = pick_nb_tap(nblk32, pl.mtiles);
+        if (have4 && ov != 1 && (waves_env == 4 || (waves_env != 8 && prefer_four_waves(pl, p4, d)))) return p4;
         return pl;
     }
     // 128-pixel tiles: 8x16 or 4x32
@@ -514,7 +570,7 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_
     };
     if (pl.impl == 2) {
         dim3 grid = grid1d(ceil_div(p.nblk32, 2 * pl.NB));
-        return conv_pw_launch<T>(pl.NB, p, grid, stream);
+        return conv_pw_launch<T>(pl.NB, pl.wv, p, grid, stream);
     }
     if (pl.impl == 1) {
         dim3 grid = grid1d(ceil_div(p.nblk32, 2 * pl.NB));
@@ -639,10 +695,10 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
     if (pl.impl == 3)
         snprintf(buf, (size_t)buflen, "void step::pw_splitk_kernel<%s, %d>(step::ConvParams, float*, int, int, int)", t, pl.mbk);
     else if (pl.impl == 2)
-        snprintf(buf, (size_t)buflen, "void step::conv_pw_kernel<%s, %d>(step::ConvParams)", t, pl.NB);
+        snprintf(buf, (size_t)buflen, "void step::conv_pw_kernel<%s, %d, %d>(step::ConvParams)", t, pl.NB, pl.wv);
     else if (pl.impl == 1)
-        snprintf(buf, (size_t)buflen, "void step::conv_tap_kernel<%s, %d, %d, %d, %d, %d, %d, %d>(step::ConvParams)", t,
-                 pl.twl, pl.NB, d->kd, d->kh, d->kw, pl.mb == 4 ? 2 : pl.tps, pl.mb);
+        snprintf(buf, (size_t)buflen, "void step::conv_tap_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d>(step::ConvParams)", t,
+                 pl.twl, pl.NB, d->kd, d->kh, d->kw, pl.tps, pl.mb, pl.wv);
     else
         snprintf(buf, (size_t)buflen, "void step::conv_igemm_kernel<%s, %d, %d, %d, %d, %d, %s, %d>(step::ConvParams)", t,
                  pl.flat ? 4 : (pl.wide ? 5 : 4), pl.NB, d->kd, d->kh, d->kw, pl.flat ? "true" : "false", pl.deep ? 128 : 32);

@@ -13,21 +13,26 @@ namespace step {
 // buffered in registers, so the ds_reads of step s+1 are issued before the MFMAs of step s and there
 // is one barrier per step (the conv_tap_kernel pipeline without a resident halo tile).  Loads are
 // branch-free (clamped addresses + bit masks) so the compiler keeps exact vmcnt waits in the loop.
-template <typename T, int NB>
-__global__ __launch_bounds__(512) void conv_pw_kernel(ConvParams p) {
+// WV = wavefronts per workgroup: 8 (256 pixels, one resident workgroup per CU: 132 KiB of LDS at NB = 3) or 4 (128 pixels,
+// <= 68 KiB: two resident workgroups per CU -- the short K loops of the Inception 1x1x1 convs (6-16 steps) are
+// latency-bound with one: every workgroup's prologue, its first HBM round trip and its epilogue are exposed).
+template <typename T, int NB, int WV>
+__global__ __launch_bounds__(WV * 64, 2) void conv_pw_kernel(ConvParams p) {
+    static_assert(WV == 8 || WV == 4, "8 or 4 waves");
+    constexpr int NT = WV * 64, WM = WV / 2, TPX = WM * 64, EROWS = WM * 32;
     constexpr int ES = (int)sizeof(T);
     constexpr int VEC = 16 / ES;
     constexpr int CKT = 64 / ES, KS = CKT / 16;
     constexpr int PITCH = 80;
-    constexpr int ATILE = 256 * PITCH;                       // 20480 B
+    constexpr int ATILE = TPX * PITCH;                       // 20480 B (WV = 8) / 10240 B
     constexpr int FRAGB = 512 * ES, FRAGV = FRAGB / 16;
     constexpr int NBT = 2 * NB;
     constexpr int BTILE = NBT * KS * FRAGB;
     constexpr int BVEC = BTILE / 16;
-    constexpr int Q = (BVEC + 511) / 512;
+    constexpr int Q = (BVEC + NT - 1) / NT;
     typedef typename frag<T>::type frag_t;
 
-    constexpr int BSTRIDE = Q * 512 * 16;                    // weight buffer pitch: every thread stores all its Q vectors (no predicate)
+    constexpr int BSTRIDE = Q * NT * 16;                    // weight buffer pitch: every thread stores all its Q vectors (no predicate)
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * ATILE + 3 * BSTRIDE];
     unsigned char* const ldsA = lds;
     unsigned char* const ldsB = lds + 3 * ATILE;
@@ -40,10 +45,10 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(ConvParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
     const int khalf = lane >> 5;
-    const int wm = wave & 3, wn = wave >> 2;
+    const int wm = wave % WM, wn = wave / WM;
     int gbx, gby;
     if (!grid_coords(p, gbx, gby)) return;
-    const long long m0 = (long long)gbx * 256;
+    const long long m0 = (long long)gbx * TPX;
     const int nb0 = gby * NBT;
     const int KC16 = p.nchunks32 * 2;
     const int S = (p.Cin + CKT - 1) / CKT;
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(ConvParams p) {
     int acol[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const int v = tid + q * 512;
+        const int v = tid + q * NT;
         const int pix = v >> 2, slot = v & 3;
         const long long gm = m0 + pix;
         const bool ok = gm < p.Mtot;
@@ -70,21 +75,23 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(ConvParams p) {
     int ldsoff[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        const int v = min(tid + q * 512, BVEC - 1);
+        const int v = min(tid + q * NT, BVEC - 1);
         const int f = v / FRAGV, within = v % FRAGV;
         const int nbl = f / KS, ks = f % KS;
         const int nbg = min(nb0 + nbl, p.nblk32 - 1);
         wthr[q] = wg + ((size_t)nbg * KC16 + ks) * FRAGB + within * 16;
-        ldsoff[q] = (tid + q * 512) * 16;
+        ldsoff[q] = (tid + q * NT) * 16;
     }
     // global -> register ring of DR step slabs -> LDS ring of 3: a slab is loaded DR steps before it is written to
     // LDS (4 steps of matrix work cover the HBM latency; with one register set the load -> store distance was a
     // single step and the K loop ran latency-bound)
-    constexpr int DR = 4;
+    // (four-wave NB = 3: 3 weight vectors per thread per step -- four register sets would spill; two suffice when a second
+    // resident workgroup covers the latency)
+    constexpr int DR = (WV == 4 && NB == 3) ? 2 : 4;
     u32x4 RA[DR][2], RB[DR][Q];
     // FULL = whole slabs (Cin % CKT == 0) and a whole 256-pixel tile: no channel / pixel masks anywhere in the loop
     // (workgroup-uniform; the vector ALU work per step drops by two thirds)
-    const bool full_tile = (p.Cin % CKT) == 0 && m0 + 256 <= p.Mtot;
+    const bool full_tile = (p.Cin % CKT) == 0 && m0 + TPX <= p.Mtot;
     auto load_step = [&](auto rc, int s_, auto fullc) {
         constexpr int RS = decltype(rc)::value;
         constexpr bool FULL = decltype(fullc)::value;
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(ConvParams p) {
         constexpr bool FULL = decltype(fullc)::value;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int v = tid + q * 512;
+            const int v = tid + q * NT;
             if (FULL) {
                 *(u32x4*)(ldsA + buf * ATILE + (v >> 2) * PITCH + ((v & 3) << 4)) = RA[RS][q];
             } else {
@@ -157,18 +164,19 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(ConvParams p) {
 
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
-    typedef std::integral_constant<int, 2> I2;
-    typedef std::integral_constant<int, 3> I3;
+    typedef std::integral_constant<int, 2 % DR> I2;
+    typedef std::integral_constant<int, 3 % DR> I3;
     int b1 = 1, b2 = 2, s_ = 0;
-    // step s: register set (s + 2) & 3 holds slab s + 2 -> LDS buffer (s + 2) % 3, then reloads slab s + 6.
+    // step s: register set (s + 2) % DR holds slab s + 2 -> LDS buffer (s + 2) % 3, then reloads slab s + 2 + DR.
     // No predicates inside (loads past the end are clamped and masked, the surplus fragment read hits a valid
     // buffer): any branch in the loop makes the compiler fall back to vmcnt(0) waits.
     auto run = [&](auto fullc) {
-        // prologue: steps 0..3 in flight at once, 0 and 1 to LDS, 4 and 5 take their register sets
-        load_step(I0(), 0, fullc); load_step(I1(), 1, fullc); load_step(I2(), 2, fullc); load_step(I3(), 3, fullc);
+        // prologue: steps 0..DR-1 in flight at once, 0 and 1 to LDS, DR and DR+1 take their register sets
+        load_step(I0(), 0, fullc); load_step(I1(), 1, fullc);
+        if (DR == 4) { load_step(I2(), 2, fullc); load_step(I3(), 3, fullc); }
         store_step(I0(), 0, 0, fullc);
         store_step(I1(), 1, 1, fullc);
-        load_step(I0(), 4, fullc); load_step(I1(), 5, fullc);
+        load_step(I0(), DR, fullc); load_step(I1(), DR + 1, fullc);
         __syncthreads();
         read_frags(I0(), 0);
         auto step = [&](auto setc, auto rc) {
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(ConvParams p) {
             read_frags(std::integral_constant<int, SET ^ 1>(), b1);
             mma_all(setc);
             store_step(rc, b2, s_ + 2, fullc);
-            load_step(rc, s_ + 6, fullc);
+            load_step(rc, s_ + 2 + DR, fullc);
             __syncthreads();
             const int nb = (b2 == 2) ? 0 : b2 + 1;
             b1 = b2; b2 = nb;
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(ConvParams p) {
                 for (int r = 0; r < 16; ++r)
                     ot[(wm * 32 + cd_row(r, lane)) * BN + (wn * NB + i) * 32 + (lane & 31)] = acc[mb][i][r] * sc[i] + sh[i];
             __syncthreads();
-            for (int idx = tid; idx < 128 * G; idx += 512) {
+            for (int idx = tid; idx < EROWS * G; idx += NT) {
                 const int row = idx / G, g = idx % G;
                 const long long gm = m0 + (row >> 5) * 64 + mb * 32 + (row & 31);
                 const int co = nb0 * 32 + g * 8;
@@ -376,20 +384,28 @@ static int splitk_forward_t(const ConvPlan& pl, const ConvParams& p, float* ws, 
 
 
 template <typename T>
-int conv_pw_launch(int NB, const ConvParams& p, dim3 grid, step_stream_t stream) {
+int conv_pw_launch(int NB, int wv, const ConvParams& p, dim3 grid, step_stream_t stream) {
+    if (wv == 4) {
+        switch (NB) {
+            case 1: STEP_LAUNCH((conv_pw_kernel<T, 1, 4>), grid, dim3(256), stream, p); break;
+            case 2: STEP_LAUNCH((conv_pw_kernel<T, 2, 4>), grid, dim3(256), stream, p); break;
+            default: STEP_LAUNCH((conv_pw_kernel<T, 3, 4>), grid, dim3(256), stream, p); break;
+        }
+        return STEP_LAUNCH_CHECK();
+    }
     switch (NB) {
-        case 1: STEP_LAUNCH((conv_pw_kernel<T, 1>), grid, dim3(512), stream, p); break;
-        case 2: STEP_LAUNCH((conv_pw_kernel<T, 2>), grid, dim3(512), stream, p); break;
-        default: STEP_LAUNCH((conv_pw_kernel<T, 3>), grid, dim3(512), stream, p); break;
+        case 1: STEP_LAUNCH((conv_pw_kernel<T, 1, 8>), grid, dim3(512), stream, p); break;
+        case 2: STEP_LAUNCH((conv_pw_kernel<T, 2, 8>), grid, dim3(512), stream, p); break;
+        default: STEP_LAUNCH((conv_pw_kernel<T, 3, 8>), grid, dim3(512), stream, p); break;
     }
     return STEP_LAUNCH_CHECK();
 }
 template <typename T>
 int conv_splitk_launch(const ConvPlan& pl, const ConvParams& p, float* ws, step_stream_t stream) { return splitk_forward_t<T>(pl, p, ws, stream); }
 
-template int conv_pw_launch<float>(int, const ConvParams&, dim3, step_stream_t);
-template int conv_pw_launch<bf16_t>(int, const ConvParams&, dim3, step_stream_t);
-template int conv_pw_launch<f16_t>(int, const ConvParams&, dim3, step_stream_t);
+template int conv_pw_launch<float>(int, int, const ConvParams&, dim3, step_stream_t);
+template int conv_pw_launch<bf16_t>(int, int, const ConvParams&, dim3, step_stream_t);
+template int conv_pw_launch<f16_t>(int, int, const ConvParams&, dim3, step_stream_t);
 template int conv_splitk_launch<float>(const ConvPlan&, const ConvParams&, float*, step_stream_t);
 template int conv_splitk_launch<bf16_t>(const ConvPlan&, const ConvParams&, float*, step_stream_t);
 template int conv_splitk_launch<f16_t>(const ConvPlan&, const ConvParams&, float*, step_stream_t);

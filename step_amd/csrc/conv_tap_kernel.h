@@ -26,23 +26,32 @@ namespace step {
 // MB = 32-pixel accumulator rows per wave: MB = 2 -> 8 waves (4 x 2, 512 threads, 2 waves per SIMD) is the only
 // instantiated form (a 4-wave MB = 4 form -- 30 % less LDS traffic per MFMA -- spills at NB >= 2).
 
-template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB>
-__global__ __launch_bounds__(MB == 2 ? 512 : 256, (NB == 1 && TWL == 0) ? 4 : 2)
+// WV = wavefronts per workgroup.  WV = 8: the 256-pixel tile above, ONE workgroup per CU (up to ~150 KiB of LDS).  WV = 4:
+// the same per-wave work (64 pixels x 32*NB channels) on a 128-pixel tile with one tap per barrier, sized so that TWO
+// workgroups are resident per CU (<= 80 KiB of LDS each): they are not lock-stepped by each other's barriers, and one
+// workgroup's prologue / slab switch / epilogue (about a fifth of a workgroup's lifetime on conv3d_2c, all of it
+// exposed with a single resident workgroup) overlaps the other's matrix work.
+template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB, int WV>
+__global__ __launch_bounds__(WV * 64, (WV == 8 && NB == 1 && TWL == 0) ? 4 : 2)
 void conv_tap_kernel(ConvParams p) {
-    constexpr int NT = (MB == 2) ? 512 : 256;   // threads
-    constexpr int WM = 8 / MB;                  // waves along the pixel axis (x 2 along channels)
+    static_assert(MB == 2 && (WV == 8 || WV == 4), "two accumulator rows per wave; 8 or 4 waves");
+    constexpr int NT = WV * 64;                 // threads
+    constexpr int WM = WV / 2;                  // waves along the pixel axis (x 2 along channels)
     constexpr int MBP = MB / 2;                 // accumulator rows per wave per epilogue pass
+    constexpr int TPXM = WM * MB * 32;          // pixels of a full tile: 256 (WV = 8) or 128 (WV = 4)
     // tile shapes: TWL = 4 -> 1 plane x 16 x 16, TWL = 5 -> 1 x 8 x 32, TWL = 3 -> 4 planes x 8 x 8 (small maps:
     // 7x7 ROI features would fill 19 % of a 16x16 tile; four planes of 8x8 fill 77 %), TWL = 0 -> a box of
     // p.gtd x p.gth x p.gtw <= 256 pixels chosen at launch (GEN): power-of-two tiles cover a 28x28 map at 77 %,
     // a 50x50 one at 70 %; 2x4x28 and 2x5x25 boxes reach 88 % and 98 %.  The index arithmetic of a GEN tile uses
     // divisions, but only outside the step loop.
+    // (WV = 4 halves the tile along its leading axis: 8 x 16, 4 x 32, 2 planes x 8 x 8, or a general box <= 128 pixels)
     constexpr bool GEN = (TWL == 0);
-    constexpr int TDL = (TWL == 3) ? 2 : 0;
-    constexpr int THL = GEN ? 0 : (((256 >> (TWL + TDL)) == 16) ? 4 : 3);   // log2(TH): 16 -> 4, 8 -> 3
+    constexpr int TDL = (TWL == 3) ? (TPXM == 256 ? 2 : 1) : 0;
+    constexpr int THC = GEN ? 1 : (TPXM >> (TWL + TDL));                     // tile rows of a power-of-two tile: 16, 8 or 4
+    constexpr int THL = GEN ? 0 : (THC == 16 ? 4 : (THC == 8 ? 3 : 2));      // log2(TH)
     const int TD = GEN ? p.gtd : (1 << TDL);
-    const int TW = GEN ? p.gtw : (1 << TWL), TH = GEN ? p.gth : (256 >> (TWL + TDL));
-    const int TPX = TD * TH * TW;                           // pixels of the tile (256 unless GEN)
+    const int TW = GEN ? p.gtw : (1 << TWL), TH = GEN ? p.gth : THC;
+    const int TPX = TD * TH * TW;                           // pixels of the tile (TPXM unless GEN)
     // LDS bank conflicts of the A-fragment reads.  ds_read_b128 is serviced in four 16-lane groups ({0-3,12-15,20-27},
     // {4-11,16-19,28-31}, and the same + 32); with the 80-byte pixel pitch a group is conflict-free iff its 16 lanes
     // read pixels whose linear halo indices are distinct mod 16.  Lanes 0..31 of an MFMA row block are 32
@@ -55,7 +64,7 @@ void conv_tap_kernel(ConvParams p) {
     const int HH_ = TH + KH - 1, HWV = TW + KW - 1, HW_ = HWV + HWPAD;   // HWV: columns that hold data
     const int PD = TD + KD - 1;                             // input planes under the tile
     const int NPIX = PD * HH_ * HW_;
-    constexpr int NPIX_MAX = GEN ? (NB == 1 ? CONV_GEN_NPIX_SMALL : CONV_GEN_NPIX) : ((1 << TDL) + KD - 1) * ((256 >> (TWL + TDL)) + KH - 1) * ((1 << TWL) + KW - 1 + HWPAD);
+    constexpr int NPIX_MAX = GEN ? conv_gen_npix(WV, NB) : ((1 << TDL) + KD - 1) * (THC + KH - 1) * ((1 << TWL) + KW - 1 + HWPAD);
     constexpr int ES = (int)sizeof(T);
     constexpr int VEC = 16 / ES;
     constexpr int CKT = 64 / ES;          // channels per slab: 32 (16-bit) / 16 (fp32)
@@ -81,7 +90,8 @@ void conv_tap_kernel(ConvParams p) {
     typedef typename Ld16<T>::type vec16;
     typedef typename frag<T>::type frag_t;
 
-    constexpr int EPI_BYTES = (ES == 2) ? 128 * NBT * 32 * 4 + 1024 : 0;     // fp32 transpose buffer of the 16-bit epilogue + pixel table
+    constexpr int EROWS = WM * MBP * 32;                                      // pixels per epilogue pass: 128 (WV = 8) or 64
+    constexpr int EPI_BYTES = (ES == 2) ? EROWS * NBT * 32 * 4 + 1024 : 0;   // fp32 transpose buffer of the 16-bit epilogue + pixel table
     constexpr int LDS_BYTES = (NPIX_MAX * PITCH + 3 * BSTEP) > EPI_BYTES ? (NPIX_MAX * PITCH + 3 * BSTEP) : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     unsigned char* const ldsA = lds;
@@ -360,9 +370,9 @@ void conv_tap_kernel(ConvParams p) {
         float* ot = (float*)lds;
         // output pixel of every accumulator row, decoded ONCE per tile pixel (a general box divides by run-time
         // extents; the store loop below visits each pixel G/… times) into a 1 KiB table behind the transpose buffer
-        static_assert(ES != 2 || sizeof(lds) >= 128 * BN * 4 + 1024, "no room for the pixel table");
+        static_assert(ES != 2 || sizeof(lds) >= EROWS * BN * 4 + 1024, "no room for the pixel table");
         int* const pixtab = (int*)(lds + sizeof(lds) - 1024);
-        if (tid < 256) {
+        if (tid < TPXM) {
             int tdl, thl, twl;
             tile_pix(tid, tdl, thl, twl);
             const int od = d0 + tdl, oh = h0 + thl, ow = w0 + tile_col(thl, twl);
@@ -377,7 +387,7 @@ void conv_tap_kernel(ConvParams p) {
             sh[i] = p.shift ? p.shift[co] : 0.f;
         }
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {                  // two passes of 128 pixels
+        for (int ps = 0; ps < 2; ++ps) {                  // two passes of EROWS pixels
             if (ps) __syncthreads();                      // previous half has been read out
 #pragma unroll
             for (int mbl = 0; mbl < MBP; ++mbl)
@@ -388,7 +398,7 @@ void conv_tap_kernel(ConvParams p) {
                         ot[((wm * MBP + mbl) * 32 + cd_row(r, lane)) * BN + (wn * NB + i) * 32 + (lane & 31)] =
                             acc[ps * MBP + mbl][i][r] * sc[i] + sh[i];
             __syncthreads();
-            for (int idx = tid; idx < 128 * G; idx += NT) {
+            for (int idx = tid; idx < EROWS * G; idx += NT) {
                 const int row = idx / G, g = idx % G;
                 // row = (wm*MBP + mbl)*32 + rr  ->  tile pixel wm*(MB*32) + (ps*MBP + mbl)*32 + rr
                 const int mm = ((row >> 5) / MBP) * (MB * 32) + (ps * MBP + (row >> 5) % MBP) * 32 + (row & 31);
@@ -443,9 +453,16 @@ void conv_tap_kernel(ConvParams p) {
 
 
 template <typename T, int TWL, int KD, int KH, int KW>
-static int launch_tap(const ConvParams& p, int NB, int tps, int mb, dim3 grid, step_stream_t stream) {
-#define STEP_TAP(NB_, TPS_, MB_) STEP_LAUNCH((conv_tap_kernel<T, TWL, NB_, KD, KH, KW, TPS_, MB_>), grid, dim3(MB_ == 2 ? 512 : 256), stream, p)
-    if (tps == 2) {
+static int launch_tap(const ConvParams& p, int NB, int tps, int wv, dim3 grid, step_stream_t stream) {
+#define STEP_TAP(NB_, TPS_, MB_) STEP_LAUNCH((conv_tap_kernel<T, TWL, NB_, KD, KH, KW, TPS_, MB_, 8>), grid, dim3(512), stream, p)
+#define STEP_TAP4(NB_, TPS_) STEP_LAUNCH((conv_tap_kernel<T, TWL, NB_, KD, KH, KW, TPS_, 2, 4>), grid, dim3(256), stream, p)
+    if (wv == 4) {                     // two resident workgroups per CU: one tap per barrier (NB = 1: two, its weight tiles are small)
+        switch (NB) {
+            case 1: STEP_TAP4(1, 2); break;
+            case 2: STEP_TAP4(2, 1); break;
+            default: STEP_TAP4(3, 1); break;
+        }
+    } else if (tps == 2) {
         switch (NB) {
             case 1: STEP_TAP(1, 2, 2); break;
             case 2: STEP_TAP(2, 2, 2); break;
@@ -459,6 +476,7 @@ static int launch_tap(const ConvParams& p, int NB, int tps, int mb, dim3 grid, s
         }
     }
 #undef STEP_TAP
+#undef STEP_TAP4
     return STEP_LAUNCH_CHECK();
 }
 
@@ -466,13 +484,13 @@ static int launch_tap(const ConvParams& p, int NB, int tps, int mb, dim3 grid, s
 template <typename T>
 int conv_tap_launch(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream) {
     if (kd == 3) {
-        if (pl.twl == 0) return launch_tap<T, 0, 3, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
-        if (pl.twl == 3) return launch_tap<T, 3, 3, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
-        return pl.wide ? launch_tap<T, 5, 3, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream) : launch_tap<T, 4, 3, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
+        if (pl.twl == 0) return launch_tap<T, 0, 3, 3, 3>(p, pl.NB, pl.tps, pl.wv, grid, stream);
+        if (pl.twl == 3) return launch_tap<T, 3, 3, 3, 3>(p, pl.NB, pl.tps, pl.wv, grid, stream);
+        return pl.wide ? launch_tap<T, 5, 3, 3, 3>(p, pl.NB, pl.tps, pl.wv, grid, stream) : launch_tap<T, 4, 3, 3, 3>(p, pl.NB, pl.tps, pl.wv, grid, stream);
     }
-    if (pl.twl == 0) return launch_tap<T, 0, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
-    if (pl.twl == 3) return launch_tap<T, 3, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
-    return pl.wide ? launch_tap<T, 5, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream) : launch_tap<T, 4, 1, 3, 3>(p, pl.NB, pl.tps, pl.mb, grid, stream);
+    if (pl.twl == 0) return launch_tap<T, 0, 1, 3, 3>(p, pl.NB, pl.tps, pl.wv, grid, stream);
+    if (pl.twl == 3) return launch_tap<T, 3, 1, 3, 3>(p, pl.NB, pl.tps, pl.wv, grid, stream);
+    return pl.wide ? launch_tap<T, 5, 1, 3, 3>(p, pl.NB, pl.tps, pl.wv, grid, stream) : launch_tap<T, 4, 1, 3, 3>(p, pl.NB, pl.tps, pl.wv, grid, stream);
 }
 
 }  // namespace step

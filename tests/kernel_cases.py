@@ -581,6 +581,45 @@ def case_conv_units(bk, golden):
         _conv_case(bk, case, (F32, BF16))
 
 
+def case_conv_units_four_wave_form(bk, golden):
+    """The same shapes through the FOUR-wave form of conv_tap_kernel (128-pixel tiles: 8x16, 2 planes x 8x8, general boxes
+    <= 128 pixels, one tap per barrier; STEP_CONV_WAVES=4 makes the planner choose it wherever the tap kernel runs), plus
+    shapes that make each of its tile kinds ragged."""
+    saved = os.environ.get("STEP_CONV_WAVES")
+    os.environ["STEP_CONV_WAVES"] = "4"
+    try:
+        d = _capi.ConvDesc(dtype=BF16, N=1, D=2, H=8, W=16, Cin=64, Cout=96, kd=3, kh=3, kw=3, x_cstride=64, x_coff=0, y_cstride=96,
+                           y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+        buf = ctypes.create_string_buffer(256)
+        assert bk.lib.step_conv_kernel_name(ctypes.byref(d), buf, 256) == 0
+        assert buf.value.decode().endswith(", 2, 4>(step::ConvParams)"), buf.value      # ..., TPS, MB = 2, WV = 4>
+        extra = [(1, 64, 192, 3, 9, 17, (3, 3, 3)),     # NB = 3: 8x16 tiles, ragged in H and W, two slabs
+                 (1, 96, 130, 5, 8, 8, (3, 3, 3)),      # 2 planes x 8x8, ragged plane pairs (5 = 2*2 + 1), 5 channel blocks
+                 (2, 32, 64, 2, 6, 21, (1, 3, 3))]      # 2-D kernel, general box on a 6x21 map
+        for case in CONV_CASES + extra:
+            if case[6] != (1, 1, 1):
+                _conv_case(bk, case, (F32, BF16))
+        # the streaming pointwise GEMM in its four-wave form (128-pixel tiles), every accumulator depth; NB = 3 runs the
+        # two-deep register ring
+        pw = [(1, 136, 200, 1, 40, 52, (1, 1, 1)),      # ragged K (136 = 4*32 + 8), ragged last pixel tile, 7 channel blocks
+              (2, 128, 128, 2, 25, 41, (1, 1, 1))]      # whole slabs, tail tile
+        for nb in ("1", "2", "3"):
+            os.environ["STEP_CONV_NB"] = nb
+            for case in pw:
+                N, Cin, Cout, D, H, W, k = case
+                d = _capi.ConvDesc(dtype=BF16, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=Cin, x_coff=0,
+                                   y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+                assert bk.lib.step_conv_kernel_name(ctypes.byref(d), buf, 256) == 0
+                assert ("conv_pw_kernel<step::bf16_t, %s, 4>" % nb) in buf.value.decode(), buf.value
+                _conv_case(bk, case, (F32, BF16))
+    finally:
+        os.environ.pop("STEP_CONV_NB", None)
+        if saved is None:
+            os.environ.pop("STEP_CONV_WAVES", None)
+        else:
+            os.environ["STEP_CONV_WAVES"] = saved
+
+
 def case_conv_residual_norelu_f16_and_bias_only(bk, golden):
     rs = np.random.RandomState(11)
     x = rs.randn(2, 32, 1, 7, 7).astype(np.float32)
