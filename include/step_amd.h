@@ -168,6 +168,20 @@ STEP_API int step_conv_forward_ws(const step_conv_desc* d, const void* x, const 
                                   const float* shift, const void* res, void* y, void* y2, void* ws, size_t ws_bytes,
                                   step_stream_t stream);
 
+/* The branch_3 path of an Inception block in one launch:
+ *     y = act( conv1x1x1( maxpool3d_tf(x; window 3x3x3, stride 1) ) * scale[c] + shift[c] )
+ * replaces MaxPool3dTFPadding((3,3,3),(1,1,1)) followed by Unit3Dpy(1x1x1) (models/i3dpt.py:151-155,160): the pooled
+ * tensor is never written to memory.  d describes the 1x1x1 conv (kd = kh = kw = 1, split = 0; x / y geometry, channel
+ * strides and offsets as in step_conv_forward); the pool has the TF-"SAME" semantics of step_maxpool3d_tf (positions
+ * outside the tensor carry the VALUE 0 and take part in the max).  w_packed: step_conv_pack_weight of the conv's
+ * [Cout,Cin,1,1,1] weight.  Results are bit-identical to step_maxpool3d_tf followed by step_conv_forward (a max has no
+ * rounding and the K order of the accumulation is the same).  STEP_E_UNSUPPORTED for tensors of >= 2^32 elements (the
+ * caller runs the two launches instead). */
+STEP_API int step_pool3_conv1_forward(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale,
+                                      const float* shift, void* y, step_stream_t stream);
+/* Diagnostic, as step_conv_kernel_name. */
+STEP_API int step_pool3_conv1_kernel_name(const step_conv_desc* d, char* buf, int buflen);
+
 /* Weight gradient of the same conv (training, train.py:257-348; replaces the cuDNN wgrad behind Conv3d/Conv2d/Linear
  * .backward):  dw[co][ci][kd][kh][kw] (fp32, torch's weight layout) (+)= sum_p dy[p][co] * x[p + tap][ci].
  * x is the forward input described by d (x_cstride / x_coff, dtype), dy the fp32 gradient w.r.t. the conv output

@@ -392,8 +392,7 @@ class Mixed(nn.Module):
             self._fused(x, out[..., :c0], t)
             self.branch_1[1](t[..., :oc[1]], out=out[..., c0:c1])
             self.branch_2[1](t[..., oc[1]:], out=out[..., c1:c2])
-            p = self.branch_3[0](x)
-            self.branch_3[1](p, out=out[..., c2:])
+            self._branch_3(x, out[..., c2:])
             return out
         # The branches are independent: run them on three HIP streams (fork/join with events -- under
         # hipGraph capture these become parallel graph branches).  Most of these launches do not fill
@@ -401,9 +400,8 @@ class Mixed(nn.Module):
         main = torch.cuda.current_stream(x.device)
         s1, s2 = _side_streams(x.device)
         s2.wait_stream(main)
-        with torch.cuda.stream(s2):                        # branch_3: pool -> 1x1x1
-            p = self.branch_3[0](x)
-            self.branch_3[1](p, out=out[..., c2:])
+        with torch.cuda.stream(s2):                        # branch_3: pool -> 1x1x1 (one fused launch)
+            p = self._branch_3(x, out[..., c2:])
         self._fused(x, out[..., :c0], t)                   # main: fused 1x1x1 convs
         s1.wait_stream(main)
         with torch.cuda.stream(s1):                        # branch_2: small 3x3x3
@@ -411,8 +409,24 @@ class Mixed(nn.Module):
         self.branch_1[1](t[..., :oc[1]], out=out[..., c0:c1])   # main: the big 3x3x3
         main.wait_stream(s1)
         main.wait_stream(s2)
-        p.record_stream(main)
+        if p is not None:
+            p.record_stream(main)
         return out
+
+    def _branch_3(self, x, out):
+        """max pool 3x3x3 / 1 -> 1x1x1 unit into `out` (inference path).  One launch (step_pool3_conv1_forward: the pooled
+        tensor never reaches memory); returns the pooled scratch tensor when the two-launch form had to be used, else None."""
+        pool, unit = self.branch_3[0], self.branch_3[1]
+        if FUSE_POOL_CONV and pool.kernel_size == (3, 3, 3) and pool.stride == (1, 1, 1):
+            cu = unit._unit
+            scale, shift = cu.affine()
+            if shift is not None:
+                shift = shift.detach().contiguous()
+            if ops.pool3_conv1_forward(x, cu.packed(x.dtype), cu.cout, scale, shift, unit.relu, out) is not None:
+                return None
+        p = pool(x)
+        unit(p, out=out)
+        return p
 
 
 WGRAD_INTO_GRAD = False        # see wgrad_into_grad()
@@ -458,6 +472,7 @@ def wgrad_sync():
         _PENDING[0] = False
 
 
+FUSE_POOL_CONV = os.environ.get("STEP_FUSE_POOL_CONV", "1") != "0"   # branch_3 of an Inception block as one launch
 BRANCH_STREAMS = True          # run the independent Inception branches on side streams (inference path)
 WGRAD_SIDE_STREAM = os.environ.get("STEP_WGRAD_STREAM", "1") != "0"   # training: weight gradient beside the data gradient
 _SIDE = {}

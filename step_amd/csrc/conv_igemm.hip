@@ -379,14 +379,22 @@ static long long best_gen_box(int D, int H, int W, int kd, int npix_limit, int* 
 }
 
 // Which form of conv_tap_kernel: measured rule (DESIGN.md, 3x3x3 family).
+// Interleaved A/B on MI355X over the C2 layers (tools/ab_bench.py, profiles/r02_ab_waves.txt): the four-wave form is slower
+// on every 3x3x3 layer that fills the chip (conv3d_2c 290 -> 301 us, 3c_b1b 144 -> 326 us: one tap per barrier and twice
+// the weight staging per MFMA cost more than the second resident workgroup hides) and ~7 % faster only on the smallest
+// 14x14 branch_2 layers, whose eight-wave launches are a few dozen workgroups.
 static bool prefer_four_waves(const ConvPlan& p8, const ConvPlan& p4, const step_conv_desc* d) {
-    (void)p8; (void)p4; (void)d;
-    return false;
+    (void)p4;
+    const long long wgs8 = p8.mtiles * ceil_div(ceil_div(d->Cout, 32), 2 * p8.NB);
+    return wgs8 < 64;
 }
 
-static bool prefer_four_waves_pw(const step_conv_desc* d) {
-    (void)d;
-    return false;
+// The streaming pointwise GEMM: four waves (128-pixel tiles, two resident workgroups) measured 6-9 % faster on the 28x28
+// layers (3b / 3c fused triples 27.2 -> 24.8 us, 46.6 -> 42.9 us) and 20-25 % faster where the eight-wave grid is below
+// half the chip (4b / 4f branch_3: 9.9 -> 7.3 us, 10.8 -> 8.4 us); equal or 1-4 % slower on the 14x14 fused triples.
+static bool prefer_four_waves_pw(const step_conv_desc* d, long long wgs8) {
+    const long long M = (long long)d->N * d->D * d->H * d->W;
+    return wgs8 < 128 || M >= 65536;
 }
 
 static ConvPlan conv_plan(const step_conv_desc* d) {
@@ -406,7 +414,8 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
         if (ov1 == 5 || (ov1 != 0 && d->Cin >= 128 && d->Cout >= 64 && mt256 * ceil_div(nblk32, 2) >= 32)) {
             pl.impl = 2;
             const int waves_env = getenv("STEP_CONV_WAVES") ? atoi(getenv("STEP_CONV_WAVES")) : 0;      // tuning aid / tests: 4 | 8
-            const bool four = waves_env == 4 || (waves_env != 8 && prefer_four_waves_pw(d));
+            const long long wgs8 = mt256 * ceil_div(nblk32, 2 * pick_nb_tap(nblk32, mt256));
+            const bool four = waves_env == 4 || (waves_env != 8 && prefer_four_waves_pw(d, wgs8));
             pl.wv = four ? 4 : 8;
             pl.mtiles = four ? ceil_div64((long long)d->N * d->D * d->H * d->W, 128) : mt256;
             pl.NB = pick_nb_tap(nblk32, pl.mtiles, four ? 512 : 256);
@@ -706,7 +715,7 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
 }
 
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 10; }
+int step_abi_version(void) { return 11; }
 
 }  // extern "C"
 

@@ -138,6 +138,34 @@ def conv_forward(x, w_packed, Cout, k, scale=None, shift=None, relu=True, res=No
     return out
 
 
+def pool3_conv1_forward(x, w_packed, Cout, scale=None, shift=None, relu=True, out=None):
+    """y = act(conv1x1x1(maxpool_tf(x, (3,3,3), (1,1,1))) * scale + shift) in one launch (an Inception block's branch_3,
+    models/i3dpt.py:151-155); x channels-last [N,D,H,W,Cin] (may be a channel slice), out an optional channel slice.
+    Returns None when the library declines the shape (the caller runs pool and conv as two launches)."""
+    L = _lib.lib()
+    N, D, H, W, Cin = x.shape
+    xcs = _chan_slice(x)
+    made = out is None
+    if made:
+        out = torch.empty((N, D, H, W, Cout), dtype=x.dtype, device=x.device)
+    d = _capi.ConvDesc(dtype=_dt(x), N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=xcs, x_coff=0,
+                       y_cstride=_chan_slice(out), y_coff=0, res_cstride=0, res_coff=0, relu=int(bool(relu)), split=0,
+                       y2_cstride=0, y2_coff=0)
+    prof = _NOPROF
+    if PROFILE is not None:
+        buf = ctypes.create_string_buffer(256)
+        if L.step_pool3_conv1_kernel_name(ctypes.byref(d), buf, 256) == 0:
+            pix = N * D * H * W
+            prof = _Prof(buf.value.decode(), 2.0 * pix * Cout * Cin, (pix * (Cin + Cout) + Cout * Cin) * _ES[x.dtype])
+    with prof:
+        st = L.step_pool3_conv1_forward(ctypes.byref(d), _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift),
+                                        _lib.dptr(out), _lib.stream_ptr(x.device))
+    if st == -4:                                                  # STEP_E_UNSUPPORTED
+        return None
+    _capi.check(st, "step_pool3_conv1_forward")
+    return out
+
+
 def conv_wgrad(x, gy, Cout, k, into=None):
     """Weight gradient of the stride-1 SAME conv: x channels-last [N,D,H,W,Cin] (any storage dtype, may be a channel
     slice), gy fp32 channels-last [N,D,H,W,Cout] (gradient w.r.t. the conv output before the affine epilogue).

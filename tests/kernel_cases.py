@@ -620,6 +620,82 @@ def case_conv_units_four_wave_form(bk, golden):
             os.environ["STEP_CONV_WAVES"] = saved
 
 
+POOLPW_CASES = [
+    # N, Cin, Cout, D, H, W
+    (1, 40, 64, 3, 7, 7),        # 7x7 planes -> 2 x 2 waves (boxes <= 64 pixels), ragged last slab (40 = 32 + 8)
+    (2, 64, 32, 5, 9, 13),       # one output block, ragged boxes in every direction
+    (1, 48, 160, 2, 6, 10),      # 5 output blocks -> two channel groups (the second one ragged)
+    (1, 32, 96, 4, 14, 14),      # 3 output blocks run as 4 (a duplicate block that is never stored)
+    (1, 16, 128, 1, 5, 28),      # a single plane (the pad planes on both sides win nothing but zeros), wide rows
+]
+
+
+def run_pool3_conv1(bk, x, w, scale, shift, dt, relu=True, x_pad=(0, 0), y_pad=(0, 0)):
+    N, Cin, D, H, W = x.shape
+    Cout = w.shape[0]
+    xb = np.zeros((N, D, H, W, x_pad[0] + Cin + x_pad[1]), np.float32)
+    xb[..., x_pad[0]:x_pad[0] + Cin] = cl(x)
+    xb[..., :x_pad[0]] = 77.0
+    xb[..., x_pad[0] + Cin:] = -55.0
+    xe = bk.dev(encode(xb, dt))
+    yb = bk.dev(np.zeros((N, D, H, W, y_pad[0] + Cout + y_pad[1]), NP_DT[dt]))
+    wp = pack_weight(bk, w, dt)
+    d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=xb.shape[-1], x_coff=x_pad[0],
+                       y_cstride=y_pad[0] + Cout + y_pad[1], y_coff=y_pad[0], res_cstride=0, res_coff=0, relu=int(relu), split=0,
+                       y2_cstride=0, y2_coff=0)
+    sc, sh = bk.dev(scale), bk.dev(shift)
+    rc = bk.lib.step_pool3_conv1_forward(ctypes.byref(d), xe.ptr, wp.ptr, sc.ptr, sh.ptr, yb.ptr, bk.stream)
+    assert rc == 0, rc
+    # the two-launch form on the same buffers: pool into a dense scratch tensor, then the 1x1x1 conv
+    pb = bk.dev(np.zeros((N, D, H, W, Cin), NP_DT[dt]))
+    assert bk.lib.step_maxpool3d_tf(dt, xe.ptr, N, D, H, W, Cin, xb.shape[-1], x_pad[0], 3, 3, 3, 1, 1, 1, pb.ptr, Cin, 0, bk.stream) == 0
+    y2 = bk.dev(np.zeros((N, D, H, W, y_pad[0] + Cout + y_pad[1]), NP_DT[dt]))
+    d2 = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=Cin, x_coff=0,
+                        y_cstride=y_pad[0] + Cout + y_pad[1], y_coff=y_pad[0], res_cstride=0, res_coff=0, relu=int(relu), split=0,
+                        y2_cstride=0, y2_coff=0)
+    assert bk.lib.step_conv_forward(ctypes.byref(d2), pb.ptr, wp.ptr, sc.ptr, sh.ptr, None, y2.ptr, None, bk.stream) == 0
+    y = decode(yb.get(), dt)
+    assert not y[..., :y_pad[0]].any() and not y[..., y_pad[0] + Cout:].any()
+    return uncl(y[..., y_pad[0]:y_pad[0] + Cout]), uncl(decode(y2.get(), dt)[..., y_pad[0]:y_pad[0] + Cout])
+
+
+def _pool3_conv1_case(bk, case, dts):
+    N, Cin, Cout, D, H, W = case
+    rs = np.random.RandomState(Cin * 5 + Cout)
+    x = rs.randn(N, Cin, D, H, W).astype(np.float32) - 0.6      # mostly negative: the zero pad wins along the borders
+    w = (rs.randn(Cout, Cin, 1, 1, 1) / np.sqrt(Cin)).astype(np.float32)
+    scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32)
+    shift = (0.2 * rs.randn(Cout)).astype(np.float32)
+    for dt in dts:
+        got, two = run_pool3_conv1(bk, x, w, scale, shift, dt, x_pad=(8, 8), y_pad=(16, 8))
+        pooled = R.maxpool_tf(torch.from_numpy(quantize(x, dt)), (3, 3, 3), (1, 1, 1)).numpy()
+        ref = ref_conv(pooled, w, scale, shift, dt)
+        err = np.abs(got - ref).max() / np.abs(ref).max()
+        assert err < tol(dt), (case, dt, err)
+        assert np.array_equal(got, two), (case, dt, float(np.abs(got - two).max()))     # same max, same K order: bit-identical
+
+
+def case_pool3_conv1_fused(bk, golden):
+    """step_pool3_conv1_forward (an Inception block's branch_3: 3x3x3 / 1 TF-SAME max pool -> 1x1x1 unit, one launch)
+    against the oracle's pool + conv and, bit for bit, against step_maxpool3d_tf + step_conv_forward."""
+    for case in POOLPW_CASES:
+        _pool3_conv1_case(bk, case, (F32, BF16))
+    _pool3_conv1_case(bk, POOLPW_CASES[0], (F16,))
+    # a conv that is not 1x1x1 is refused
+    d = _capi.ConvDesc(dtype=F32, N=1, D=2, H=4, W=4, Cin=16, Cout=32, kd=3, kh=3, kw=3, x_cstride=16, x_coff=0, y_cstride=32,
+                       y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+    z = bk.dev(np.zeros(16, np.float32))
+    assert bk.lib.step_pool3_conv1_forward(ctypes.byref(d), z.ptr, z.ptr, None, None, z.ptr, bk.stream) == -4
+
+
+def big_pool3_conv1(bk, golden):
+    """branch_3 at real Inception shapes (one clip of C2 / an AVA clip), 16-bit and fp32."""
+    for case in ((1, 192, 32, 16, 28, 28), (1, 480, 64, 8, 14, 14), (1, 528, 128, 8, 14, 14), (1, 256, 64, 6, 50, 50),
+                 (2, 832, 128, 3, 7, 7)):
+        _pool3_conv1_case(bk, case, (BF16, F16))
+    _pool3_conv1_case(bk, (1, 480, 64, 4, 14, 14), (F32,))
+
+
 def case_conv_residual_norelu_f16_and_bias_only(bk, golden):
     rs = np.random.RandomState(11)
     x = rs.randn(2, 32, 1, 7, 7).astype(np.float32)
@@ -951,4 +1027,4 @@ def big_adam_full_size(bk, golden):
         assert float(G.abs().max()) == 0.0
 
 
-GPU_ONLY = ["big_conv_shapes", "big_stem", "big_roi", "big_nms", "big_wgrad_full_size_properties", "big_adam_full_size"]
+GPU_ONLY = ["big_conv_shapes", "big_pool3_conv1", "big_stem", "big_roi", "big_nms", "big_wgrad_full_size_properties", "big_adam_full_size"]

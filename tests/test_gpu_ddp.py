@@ -41,7 +41,16 @@ def _worker(rank, world, port, q):
         dev = torch.device("cuda:0")
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     w = workloads.C4TrainStep(dev, batch=1, seed=123 + rank)
+    # run-to-run noise floor of ONE rank's gradient: the weight gradients meet in fp32 atomics, whose order changes from
+    # launch to launch (include/step_amd.h: "deterministic up to fp32 summation order"); two passes over the same clip
+    # with the same weights differ by that and nothing else
+    w.forward_backward()
+    local1, lnorms1 = _probe(w.opt.flat_grad, w.opt._entries)
+    w.opt.zero_grad()
     loss = w.forward_backward()
+    local2, lnorms2 = _probe(w.opt.flat_grad, w.opt._entries)
+    noise = float(np.linalg.norm(local2 - local1) / np.linalg.norm(local1))
+    noise_t = float((np.abs(lnorms2 - lnorms1) / np.maximum(lnorms1, 1e-30)).max())
     f = D.allreduce_flat(w.opt.flat_grad)
     sample, norms = _probe(w.opt.flat_grad * f, w.opt._entries)
     lsum = torch.tensor([float(loss)], device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -54,7 +63,7 @@ def _worker(rank, world, port, q):
     sample_b, norms_b = _probe(w.opt.flat_grad * w.scale, w.opt._entries)
     during, nb = w.reducer.issued_during_backward, len(w.reducer.buckets)
     if rank == 0:
-        q.put((sample, norms, float(lsum) / world, f, p0, sample_b, norms_b, during, nb, w.scale))
+        q.put((sample, norms, float(lsum) / world, f, p0, sample_b, norms_b, during, nb, w.scale, noise, noise_t))
     else:
         q.put(("p", p0))
     dist.barrier()
@@ -77,11 +86,17 @@ def test_two_rank_gradient_equals_single_process_on_the_concatenated_batch():
         assert p.exitcode == 0
     main = [g for g in got if g[0] is not None and not isinstance(g[0], str)][0]
     other = [g for g in got if isinstance(g[0], str)][0]
-    sample, norms, loss2, factor, p0, sample_b, norms_b, during, nb, scale_b = main
+    sample, norms, loss2, factor, p0, sample_b, norms_b, during, nb, scale_b, noise, noise_t = main
     assert factor == 0.5 and scale_b == 0.5
     assert nb >= 5 and during >= nb - 2, (during, nb)            # 178 MB arena in 32 MiB buckets; all but the front ones left during backward
+    # overlapped == single-shot up to the atomics' summation order (measured on MI355X: 1.6e-4 in relative L2 between
+    # two passes; `noise` is that floor measured on this very run).  A bucket that left before one of its weight
+    # gradients landed would be off by O(1) in that tensor's norm, so the per-tensor check is the one that guards the
+    # stream ordering.
     eb = np.linalg.norm(sample_b - sample) / np.linalg.norm(sample)
-    assert eb < 1e-4 and np.abs(norms_b - norms).max() < 1e-4 * norms.max(), eb
+    et = float((np.abs(norms_b - norms) / np.maximum(norms, 1e-6 * norms.max())).max())
+    assert noise < 1e-3 and noise_t < 2e-3, (noise, noise_t)
+    assert eb < max(5e-4, 5 * noise) and et < max(2e-3, 5 * noise_t), (eb, et, noise, noise_t)
     assert np.array_equal(p0, other[1])                          # replicas start from the same (broadcast) weights
     dev = torch.device("cuda:0")
     w = workloads.C4TrainStep(dev, batch=2, seed=123)
