@@ -103,6 +103,44 @@ def basenet_forward(images, sd, prefix="base_model", return_stages=False):
     return (out, stages) if return_stages else out
 
 
+I3D_STAGES = ["conv3d_1a_7x7", "maxPool3d_2a_3x3", "conv3d_2b_1x1", "conv3d_2c_3x3", "maxPool3d_3a_3x3", "mixed_3b", "mixed_3c",
+              "maxPool3d_4a_3x3", "mixed_4b", "mixed_4c", "mixed_4d", "mixed_4e", "mixed_4f"]
+
+
+def i3d_forward(inp, sd):
+    """The Kinetics classifier the backbone is cut from: inp [N,3,T,H,W] (NCDHW, T >= 16, H = W = 224 so that the
+    (2,7,7) average pool has a window) -> (softmax, logits) [N, num_classes].  models/i3dpt.py:236-262."""
+    x = inp
+    for (kind, _, args), name in zip(BACKBONE, I3D_STAGES):
+        if kind == "conv":
+            x = unit3d(x, sd, name, stride=args[3])
+        elif kind == "pool":
+            x = maxpool_tf(x, args[0], args[1])
+        else:
+            x = mixed(x, sd, name)
+    x = maxpool_tf(x, (2, 2, 2), (2, 2, 2))                 # maxPool3d_5a_2x2
+    x = mixed(x, sd, "mixed_5b")
+    x = mixed(x, sd, "mixed_5c")
+    x = F.avg_pool3d(x, (2, 7, 7), (1, 1, 1))
+    x = unit3d(x, sd, "conv3d_0c_1x1", bn=False, relu=False)    # dropout(p) is the identity in eval mode
+    logits = x.squeeze(3).squeeze(3).mean(2)
+    return F.softmax(logits, 1), logits
+
+
+def i3d_shapes(num_classes):
+    """state_dict key -> shape of the reference's I3D(num_classes) (models/i3dpt.py:175-234)."""
+    out = {}
+    for k, v in backbone_shapes("base_model").items():
+        idx, rest = k[len("base_model."):].split(".", 1)
+        out[I3D_STAGES[int(idx)] + "." + rest] = v
+    for k, v in head_i3d_shapes("h", 0).items():
+        idx, rest = k[2:].split(".", 1)
+        out[("mixed_5b", "mixed_5c")[int(idx)] + "." + rest] = v
+    out["conv3d_0c_1x1.conv3d.weight"] = (num_classes, 1024, 1, 1, 1)
+    out["conv3d_0c_1x1.conv3d.bias"] = (num_classes,)
+    return out
+
+
 def contextnet_forward(conv_feat, sd, prefix="i3d_conv_context"):
     """conv_feat [B,T,832,25,25] -> [B,1024,T,1,1].  models/two_branch.py:113-138."""
     x = conv_feat.permute(0, 2, 1, 3, 4)

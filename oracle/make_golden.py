@@ -595,8 +595,31 @@ def postprocess_main():
     np.savez_compressed(os.path.join(OUT, "postprocess_golden.npz"), **g)
 
 
+def i3d_main():
+    """The full Kinetics classifier I3D (models/i3dpt.py:175-262; never called by STEP's scripts): the
+    reference's module with closed-form weights on the smallest clip its (2,7,7) average pool accepts."""
+    torch.set_num_threads(8)
+    import_reference()
+    from models.i3dpt import I3D           # reference
+    from oracle import i3d_ref as R
+    net = I3D(num_classes=24, dropout_prob=0.5)
+    shapes = fill_module(net, "i3dcls.")
+    net.eval()
+    x = R.fill_tensor("golden.i3dcls.clip", (1, 3, 16, 224, 224), "image")
+    with torch.no_grad():
+        prob, logits = net(x)
+        ours = R.i3d_forward(x, R.fill_state_dict(shapes, "i3dcls."))
+    assert float((ours[1] - logits).abs().max()) < 1e-5 * float(logits.abs().max())
+    keys = sorted(shapes)
+    np.savez_compressed(os.path.join(OUT, "i3d_classifier_golden.npz"), prob=prob.numpy(), logits=logits.numpy(),
+                        keys=np.asarray(keys), shapes=np.asarray([str(tuple(shapes[k])) for k in keys]))
+    print("i3d classifier", tuple(logits.shape), float(logits.abs().max()))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "postprocess":
+    if len(sys.argv) > 1 and sys.argv[1] == "i3d":
+        i3d_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "postprocess":
         postprocess_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "tube_math":
         tube_math_main()
@@ -613,3 +636,4 @@ if __name__ == "__main__":
         variants_main()
         tube_math_main()
         postprocess_main()
+        i3d_main()

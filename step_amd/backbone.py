@@ -146,15 +146,37 @@ class ConvUnit:
     to input channels [lo, hi) of the weight (a conv over a channel concat becomes two accumulating
     launches)."""
 
-    def __init__(self, weight_fn, k, bn=None, bias_fn=None, perm=None, cin_slice=None, version_fn=None):
-        self.weight_fn, self.bias_fn, self.bn = weight_fn, bias_fn, bn
+    def __init__(self, owner, weight_fn, k, bn=None, bias_fn=None, perm=None, cin_slice=None, version_fn=None):
+        # The getters take the OWNING MODULE as their argument instead of closing over it: copy.deepcopy() copies a
+        # function by reference, so a closure would keep reading the ORIGINAL module's parameters from the copy's
+        # forward; `owner` is deep-copied through the memo and becomes the copy.
+        self.owner = owner
+        self._wf, self._bf, self._vf = weight_fn, bias_fn, version_fn
+        self.bias_fn = None if bias_fn is None else self._bias
+        self.bn = bn
         self.k = tuple(k)
         self.perm, self.cin_slice = perm, cin_slice
         # version_fn: key of the packed-weight cache when weight_fn() builds a NEW tensor on every call (a torch.cat of
         # several parameters): the temporary's (data_ptr, _version) says nothing about the parameters behind it
-        self.version_fn = version_fn
+        self.version_fn = None if version_fn is None else self._version
         self._packed = {}
         self._affine = None
+
+    def weight_fn(self):
+        return self._wf(self.owner)
+
+    def _bias(self):
+        return self._bf(self.owner)
+
+    def _version(self):
+        return self._vf(self.owner)
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = ConvUnit(copy.deepcopy(self.owner, memo), self._wf, self.k, copy.deepcopy(self.bn, memo), self._bf, self.perm,
+                       self.cin_slice, self._vf)
+        memo[id(self)] = new
+        return new                                               # (caches start empty: they hold device buffers of the original)
 
     @property
     def cout(self):
@@ -236,8 +258,18 @@ class ConvUnit:
         return y
 
 
+def _no_data_parallel(self):
+    """nn.DataParallel replicates a module by shallow-copying its __dict__ every forward: the replicas would share the
+    original's ConvUnit helpers (device-0 parameters, device-0 packed-weight caches) and the module-level stream / profiling
+    state across threads.  The supported multi-GPU mode is one process per GPU (step_amd.dist: clip sharding + RCCL
+    gradient all-reduce, which is what replaces train.py:142-148); fail loudly instead of computing on the wrong device."""
+    raise RuntimeError("step_amd modules cannot be replicated by nn.DataParallel; run one process per GPU "
+                       "(torch.distributed + step_amd.dist.shard_clips / BucketedReducer), see INTEGRATION.md")
+
+
 class Unit3D(nn.Module):
     """conv3d (+ frozen BN) + ReLU.  Keys: conv3d.weight[, conv3d.bias], batch3d.{weight,bias,running_*}."""
+    _replicate_for_data_parallel = _no_data_parallel
 
     def __init__(self, in_channels, out_channels, kernel_size=(1, 1, 1), stride=(1, 1, 1), use_bias=False, use_bn=True,
                  relu=True):
@@ -250,11 +282,11 @@ class Unit3D(nn.Module):
         if self.is_stem:
             assert self.stride == (2, 2, 2) and in_channels == 3
             self._stem_packed = {}
-            self._unit = ConvUnit(lambda: self.conv3d.weight, (7, 7, 7), bn=getattr(self, "batch3d", None))
+            self._unit = ConvUnit(self, lambda m: m.conv3d.weight, (7, 7, 7), bn=getattr(self, "batch3d", None))
         else:
             assert self.stride == (1, 1, 1)
-            self._unit = ConvUnit(lambda: self.conv3d.weight, self.kernel_size, bn=getattr(self, "batch3d", None),
-                                  bias_fn=(lambda: self.conv3d.bias) if use_bias else None)
+            self._unit = ConvUnit(self, lambda m: m.conv3d.weight, self.kernel_size, bn=getattr(self, "batch3d", None),
+                                  bias_fn=(lambda m: m.conv3d.bias) if use_bias else None)
 
     def forward(self, x, out=None):
         if self.is_stem:
@@ -550,6 +582,65 @@ def weights_init(m):
         nn.init.xavier_normal_(m.weight.data)
         if m.bias is not None:
             nn.init.constant_(m.bias.data, 0.0)
+
+
+class I3D_head(nn.Module):
+    """Weight container of the head's Mixed_5b / 5c pair (models/i3dpt.py:165-173)."""
+
+    def __init__(self):
+        super().__init__()
+        self.maxPool3d = MaxPoolTF((1, 3, 3), (1, 2, 2))
+        self.mixed_5b = Mixed(*MIXED_CFG["5b"])
+        self.mixed_5c = Mixed(*MIXED_CFG["5c"])
+
+
+class I3D(nn.Module):
+    """The Kinetics classifier the backbone is cut from (models/i3dpt.py:175-262): same constructor, attribute names /
+    state_dict keys and forward(inp [N,3,T,H,W]) -> (softmax, logits).  STEP's scripts only use it as a checkpoint
+    container (networks.py:113-132); forward runs the same HIP kernels as BaseNet, then maxPool3d_5a, Mixed_5b / 5c, the
+    (2,7,7) average pool (7x7 window kernel + the mean of neighbouring planes), dropout and the biased logits conv."""
+
+    def __init__(self, num_classes, dropout_prob=0, name="inception"):
+        super().__init__()
+        self.name = name
+        self.num_classes = num_classes
+        self.conv3d_1a_7x7 = Unit3D(3, 64, (7, 7, 7), (2, 2, 2))
+        self.maxPool3d_2a_3x3 = MaxPoolTF((1, 3, 3), (1, 2, 2))
+        self.conv3d_2b_1x1 = Unit3D(64, 64, (1, 1, 1))
+        self.conv3d_2c_3x3 = Unit3D(64, 192, (3, 3, 3))
+        self.maxPool3d_3a_3x3 = MaxPoolTF((1, 3, 3), (1, 2, 2))
+        self.mixed_3b = Mixed(*MIXED_CFG["3b"])
+        self.mixed_3c = Mixed(*MIXED_CFG["3c"])
+        self.maxPool3d_4a_3x3 = MaxPoolTF((3, 3, 3), (2, 2, 2))
+        self.mixed_4b = Mixed(*MIXED_CFG["4b"])
+        self.mixed_4c = Mixed(*MIXED_CFG["4c"])
+        self.mixed_4d = Mixed(*MIXED_CFG["4d"])
+        self.mixed_4e = Mixed(*MIXED_CFG["4e"])
+        self.mixed_4f = Mixed(*MIXED_CFG["4f"])
+        self.maxPool3d_5a_2x2 = MaxPoolTF((2, 2, 2), (2, 2, 2))
+        self.mixed_5b = Mixed(*MIXED_CFG["5b"])
+        self.mixed_5c = Mixed(*MIXED_CFG["5c"])
+        self.avg_pool = nn.AvgPool3d((2, 7, 7), (1, 1, 1))       # (parameter-free holder, as in the reference; forward uses the HIP pool)
+        self.dropout = nn.Dropout(dropout_prob)
+        self.conv3d_0c_1x1 = Unit3D(1024, num_classes, (1, 1, 1), use_bias=True, use_bn=False, relu=False)
+        self.softmax = nn.Softmax(1)
+
+    def forward(self, inp):
+        if inp.dim() != 5 or inp.shape[1] != 3:
+            raise RuntimeError("I3D expects [batch, 3, T, H, W]")
+        x = inp.permute(0, 2, 1, 3, 4).contiguous()             # the stem reads [N,T,3,H,W]
+        for name in I3D_STAGE_NAMES:
+            x = getattr(self, name)(x)
+        x = self.mixed_5c(self.mixed_5b(self.maxPool3d_5a_2x2(x)))
+        if x.shape[2] < 7 or x.shape[3] < 7 or x.shape[1] < 2:
+            raise RuntimeError("I3D: the (2,7,7) average pool needs at least 2 x 7 x 7 features (T >= 16, H, W >= 224)")
+        a = ops.avgpool_hw(x, 7, 7)                              # [N, D, H-6, W-6, 1024]
+        a = (a[:, :-1].float() + a[:, 1:].float()).mul_(0.5).to(x.dtype)
+        a = self.dropout(a)
+        out = self.conv3d_0c_1x1(a)                              # [N, D-1, H-6, W-6, classes]
+        out = out.permute(0, 4, 1, 2, 3)                         # logical NCDHW, as the reference's conv output
+        out = out.squeeze(3).squeeze(3).float().mean(2)
+        return self.softmax(out), out
 
 
 def as_channels_last_5d(t):

@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .backbone import (MIXED_CFG, ConvUnit, _ver, MaxPoolTF, Mixed, as_channels_last_5d, freeze_bn_affine, set_bn_eval,
+from .backbone import (MIXED_CFG, ConvUnit, _ver, _no_data_parallel, MaxPoolTF, Mixed, as_channels_last_5d, freeze_bn_affine, set_bn_eval,
                        weights_init)
 from .roi_layers import ROIAlign, ROIPool
 from .tube_math import encode_coef
@@ -137,15 +137,16 @@ class _AvgPoolFn(torch.autograd.Function):
 
 class _Bottleneck(nn.Module):
     """2-D bottleneck, no BN, no bias (models/two_branch.py:60-84); parameter holders only."""
+    _replicate_for_data_parallel = _no_data_parallel
 
     def __init__(self, inplanes, planes):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
         self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, padding=1, bias=False)
         self.conv3 = nn.Conv2d(planes, inplanes, kernel_size=1, bias=False)
-        self.u1 = ConvUnit(lambda: self.conv1.weight, (1, 1, 1))
-        self.u2 = ConvUnit(lambda: self.conv2.weight, (1, 3, 3))
-        self.u3 = ConvUnit(lambda: self.conv3.weight, (1, 1, 1))
+        self.u1 = ConvUnit(self, lambda m: m.conv1.weight, (1, 1, 1))
+        self.u2 = ConvUnit(self, lambda m: m.conv2.weight, (1, 3, 3))
+        self.u3 = ConvUnit(self, lambda m: m.conv3.weight, (1, 1, 1))
 
     def forward(self, x):
         o = self.u2(self.u1(x, relu=True), relu=True)
@@ -163,12 +164,12 @@ class _BottleneckResample(nn.Module):
         self.conv2 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
         self.conv3 = nn.Conv2d(planes, planes, kernel_size=3, padding=1, bias=False)
         self.conv4 = nn.Conv2d(planes, outplanes, kernel_size=1, bias=False)
-        self.u1a = ConvUnit(lambda: self.conv1.weight, (1, 1, 1), cin_slice=(0, in_a))
-        self.u1b = ConvUnit(lambda: self.conv1.weight, (1, 1, 1), cin_slice=(in_a, inplanes))
-        self.u2a = ConvUnit(lambda: self.conv2.weight, (1, 1, 1), cin_slice=(0, in_a))
-        self.u2b = ConvUnit(lambda: self.conv2.weight, (1, 1, 1), cin_slice=(in_a, inplanes))
-        self.u3 = ConvUnit(lambda: self.conv3.weight, (1, 3, 3))
-        self.u4 = ConvUnit(lambda: self.conv4.weight, (1, 1, 1))
+        self.u1a = ConvUnit(self, lambda m: m.conv1.weight, (1, 1, 1), cin_slice=(0, in_a))
+        self.u1b = ConvUnit(self, lambda m: m.conv1.weight, (1, 1, 1), cin_slice=(in_a, inplanes))
+        self.u2a = ConvUnit(self, lambda m: m.conv2.weight, (1, 1, 1), cin_slice=(0, in_a))
+        self.u2b = ConvUnit(self, lambda m: m.conv2.weight, (1, 1, 1), cin_slice=(in_a, inplanes))
+        self.u3 = ConvUnit(self, lambda m: m.conv3.weight, (1, 3, 3))
+        self.u4 = ConvUnit(self, lambda m: m.conv4.weight, (1, 1, 1))
 
     def forward(self, a, b):
         res = self.u1b(b, relu=False, res=self.u1a(a, relu=False))
@@ -214,12 +215,12 @@ class TwoBranchNet(nn.Module):
         self.downsample = nn.Conv3d(1024, self.fc_dim, kernel_size=1, stride=1, bias=True)
         self.dropout = nn.Dropout(self.dropout_prob)
         self.global_cls = nn.Conv3d(flat + (0 if self.no_context else 1024), self.num_classes, (1, 1, 1), bias=True)
-        self._u_down = ConvUnit(lambda: self.downsample.weight, (1, 1, 1), bias_fn=lambda: self.downsample.bias)
+        self._u_down = ConvUnit(self, lambda m: m.downsample.weight, (1, 1, 1), bias_fn=lambda m: m.downsample.bias)
         perm = _nhwc_flatten_perm(self.fc_dim, P2)
-        self._u_cls_feat = ConvUnit(lambda: self.global_cls.weight, (1, 1, 1), bias_fn=lambda: self.global_cls.bias,
+        self._u_cls_feat = ConvUnit(self, lambda m: m.global_cls.weight, (1, 1, 1), bias_fn=lambda m: m.global_cls.bias,
                                     cin_slice=(0, flat), perm=perm)
         if not self.no_context:
-            self._u_cls_ctx = ConvUnit(lambda: self.global_cls.weight, (1, 1, 1), cin_slice=(flat, flat + 1024))
+            self._u_cls_ctx = ConvUnit(self, lambda m: m.global_cls.weight, (1, 1, 1), cin_slice=(flat, flat + 1024))
 
         if not self.cls_only:
             self.local_conv = _LocalConv(_BottleneckResample(832, self.fc_dim, 1024, 256), _Bottleneck(1024, 256),
@@ -228,12 +229,12 @@ class TwoBranchNet(nn.Module):
             self.local_reg = nn.Linear(flat, 4)
             self.neighbor_reg1 = nn.Linear(flat, 4)     # tube t-1
             self.neighbor_reg2 = nn.Linear(flat, 4)     # tube t+1
-            self._u_down2 = ConvUnit(lambda: self.downsample2.weight, (1, 1, 1), bias_fn=lambda: self.downsample2.bias)
+            self._u_down2 = ConvUnit(self, lambda m: m.downsample2.weight, (1, 1, 1), bias_fn=lambda m: m.downsample2.bias)
             # the three regressors share their input: one GEMM with 12 output columns
             # (grad mode: a differentiable cat per call; the pack cache is keyed on the three PARAMETERS, not on the temporary)
-            self._u_reg = ConvUnit(lambda: torch.cat([self.local_reg.weight, self.neighbor_reg1.weight, self.neighbor_reg2.weight], 0),
-                                   (1, 1, 1), bias_fn=lambda: torch.cat([self.local_reg.bias, self.neighbor_reg1.bias, self.neighbor_reg2.bias], 0),
-                                   perm=perm, version_fn=lambda: _ver(self.local_reg.weight, self.neighbor_reg1.weight, self.neighbor_reg2.weight))
+            self._u_reg = ConvUnit(self, lambda m: torch.cat([m.local_reg.weight, m.neighbor_reg1.weight, m.neighbor_reg2.weight], 0),
+                                   (1, 1, 1), bias_fn=lambda m: torch.cat([m.local_reg.bias, m.neighbor_reg1.bias, m.neighbor_reg2.bias], 0),
+                                   perm=perm, version_fn=lambda m: _ver(m.local_reg.weight, m.neighbor_reg1.weight, m.neighbor_reg2.weight))
             self._reg_cache = None
         self._init_net()
         if self.freeze_stats:
@@ -271,7 +272,7 @@ class TwoBranchNet(nn.Module):
             with torch.no_grad():
                 w = torch.cat(ps[:3], 0)
                 b = torch.cat(ps[3:], 0)
-            unit = ConvUnit(lambda: w, (1, 1, 1), bias_fn=lambda: b, perm=self._u_reg.perm)
+            unit = ConvUnit((w, b), lambda o: o[0], (1, 1, 1), bias_fn=lambda o: o[1], perm=self._u_reg.perm)
             self._reg_cache = (ver, unit)
         return self._reg_cache[1]
 

@@ -105,6 +105,27 @@ def case_basenet_c1_16bit_error(dev, golden):
         assert e < bound, (dt, e)
 
 
+def case_i3d_classifier_golden(dev, golden):
+    """step_amd.I3D (the full Kinetics classifier, models/i3dpt.py:175-262): state_dict keys / shapes of the reference's
+    module, and forward on the golden clip against what the reference returned (fp32: 1e-3; bf16: the argmax and a loose bound)."""
+    g = golden("i3d_classifier_golden")
+    net = step_amd.I3D(num_classes=24, dropout_prob=0.5)
+    sd = net.state_dict()
+    assert sorted(sd) == [str(k) for k in g["keys"]]
+    assert [str(tuple(sd[k].shape)) for k in sorted(sd)] == [str(v) for v in g["shapes"]]
+    net.load_state_dict(R.fill_state_dict({k: tuple(v.shape) for k, v in sd.items()}, "i3dcls."))
+    net = net.to(dev).eval()
+    x = R.fill_tensor("golden.i3dcls.clip", (1, 3, 16, 224, 224), "image").to(dev)
+    with torch.no_grad():
+        prob, logits = net(x)
+    assert tuple(prob.shape) == (1, 24)
+    assert rel(np_(logits), g["logits"]) < 1e-3, rel(np_(logits), g["logits"])
+    assert float(np.abs(np_(prob) - g["prob"]).max()) < 1e-4
+    with torch.no_grad():
+        pb, lb = net(x.to(torch.bfloat16))
+    assert rel(np_(lb), g["logits"]) < 3e-2 and int(pb.argmax()) == int(g["prob"].argmax())
+
+
 def case_context_golden(dev, golden):
     g = golden("head_golden")
     net = fill(step_amd.ContextNet(cfg())).to(dev).eval()
@@ -525,8 +546,8 @@ def case_wgrad_into_and_targets(dev, golden):
             continue
         raise AssertionError("conv_wgrad(into=...) accepted a %s %s buffer" % (bad.dtype, tuple(bad.shape)))
     conv = torch.nn.Conv3d(8, 16, (1, 3, 3), bias=False).to(dev)
-    plain = backbone.ConvUnit(lambda: conv.weight, (1, 3, 3))
-    sliced = backbone.ConvUnit(lambda: conv.weight, (1, 3, 3), cin_slice=(0, 4))
+    plain = backbone.ConvUnit(conv, lambda m: m.weight, (1, 3, 3))
+    sliced = backbone.ConvUnit(conv, lambda m: m.weight, (1, 3, 3), cin_slice=(0, 4))
     assert backbone._wgrad_target(plain, plain.effective_weight()) is None          # no gradient buffer yet
     conv.weight.grad = torch.zeros_like(conv.weight)
     assert backbone._wgrad_target(plain, plain.effective_weight()) is conv.weight.grad
@@ -701,4 +722,4 @@ CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_g
              "case_flat_adam_matches_torch", "case_wgrad_into_and_targets", "case_twobranch_variants_golden",
              "case_reg_unit_pack_follows_weight_updates", "case_basenet_backward_matches_oracle_autograd",
              "case_contextnet_backward_matches_oracle_autograd", "case_postprocess_golden"]
-GPU_CASES = CPU_CASES + ["case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
+GPU_CASES = CPU_CASES + ["case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_i3d_classifier_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]

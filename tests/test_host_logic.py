@@ -165,3 +165,51 @@ def test_tube_math_matches_reference_helpers():
         assert at.shape == (n, 3, 4) and at.dtype == np.float32
         assert np.array_equal(at[:, 0], g["anchors_mode%s" % mode]) and np.array_equal(at[:, 2], at[:, 0])
     assert TM.anchor_tubes("0", T=9).shape == (1, 9, 4) and not TM.anchor_tubes("0", T=9).any()
+
+
+def test_deepcopy_owns_its_parameters_and_data_parallel_is_refused():
+    """copy.deepcopy(net): every ConvUnit of the copy must read the COPY's parameters (a closure over the original module
+    would keep computing with the original's weights); nn.DataParallel replication is refused loudly."""
+    import copy
+    from types import SimpleNamespace as NS
+
+    import torch
+
+    import step_amd
+    from step_amd import backbone
+
+    cfg = NS(base_net="i3d", kinetics_pretrain=None, freeze_stats=True, freeze_affine=True, fp16=False, fc_dim=256, pool_size=7,
+             dropout=0.0, num_classes=60, cls_thresh=0.0, reg_thresh=0.0, max_pos_num=5, neg_ratio=2, NUM_SAMPLE=-1,
+             topk=300, evaluate_topk=-1, T=3, iterative_mode="spatial", anchor_mode="1", temporal_mode="predict",
+             pool_mode="align", scale_norm=2, det_net="two_branch", no_context=False, cls_only=False)
+    nets = [step_amd.BaseNet(cfg)]
+    try:
+        nets.append(step_amd.TwoBranchNet(cfg))
+    except Exception:                                            # (cfg fields of the head differ: the backbone check stands alone)
+        pass
+    for net in nets:
+        c = copy.deepcopy(net)
+        n_units = 0
+        for (_, m), (_, mo) in zip(c.named_modules(), net.named_modules()):
+            for k, u in vars(m).items():
+                if isinstance(u, backbone.ConvUnit) and isinstance(u.owner, torch.nn.Module):
+                    n_units += 1
+                    assert u.owner is m, k
+                    w = u.weight_fn()
+                    mine = {id(p) for p in m.parameters()}
+                    theirs = {id(p) for p in mo.parameters()}
+                    if id(w) in mine or id(w) in theirs:         # (a torch.cat of parameters is a temporary)
+                        assert id(w) in mine and id(w) not in theirs, k
+                    if u.bn is not None:
+                        assert any(u.bn is sub for sub in m.modules())
+        assert n_units >= 10
+    # torch.nn.parallel.replicate() calls this hook on every submodule (it needs a GPU to get that far, so call it directly)
+    for m in nets[0].modules():
+        if isinstance(m, backbone.Unit3D):
+            try:
+                m._replicate_for_data_parallel()
+                raised = False
+            except RuntimeError as e:
+                raised = "one process per GPU" in str(e)
+            assert raised
+            break

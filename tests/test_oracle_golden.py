@@ -233,3 +233,22 @@ def test_postprocess_restatement_matches_the_reference_loop(golden, tag):
     if tag == "topm1":                                   # the reference's `[:args.topk]` with topk = -1 drops the last row
         full = P.postprocess(postprocess_fixture_history(g), evaluate_topk=-1, topk=-1)
         assert len(rows) == len(full) - 9
+
+
+def test_i3d_classifier_restatement_matches_the_reference_golden(golden):
+    """oracle/i3d_ref.i3d_forward (models/i3dpt.py:236-262) against what the reference's own I3D module returned for the
+    closed-form weights and clip (tests/golden/i3d_classifier_golden.npz, `python -m oracle.make_golden i3d`)."""
+    import torch
+
+    from oracle import i3d_ref as R
+
+    g = golden("i3d_classifier_golden")
+    shapes = R.i3d_shapes(24)
+    assert sorted(shapes) == [str(k) for k in g["keys"]]
+    assert [str(tuple(shapes[k])) for k in sorted(shapes)] == [str(v) for v in g["shapes"]]
+    x = R.fill_tensor("golden.i3dcls.clip", (1, 3, 16, 224, 224), "image")
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        prob, logits = R.i3d_forward(x, R.fill_state_dict(shapes, "i3dcls."))
+    assert float(np.abs(logits.numpy() - g["logits"]).max()) < 1e-4 * float(np.abs(g["logits"]).max())
+    assert float(np.abs(prob.numpy() - g["prob"]).max()) < 1e-5
