@@ -504,7 +504,11 @@ def wgrad_sync():
         _PENDING[0] = False
 
 
-FUSE_POOL_CONV = os.environ.get("STEP_FUSE_POOL_CONV", "1") != "0"   # branch_3 of an Inception block as one launch
+# branch_3 of an Inception block as one launch (step_pool3_conv1_forward).  Off by default: measured on MI355X (C2, bf16,
+# tools/ab_bench.py --set b3, profiles/r02_ab_b3.txt) the first version of the fused kernel is latency-bound -- one slab
+# of prefetch does not cover the halo's global-memory round trip (3.2 us per 64-byte slab against 0.4 us of work) -- and
+# loses to the two launches (350 us against 192 us per step); STEP_FUSE_POOL_CONV=1 selects it.
+FUSE_POOL_CONV = os.environ.get("STEP_FUSE_POOL_CONV", "0") == "1"
 BRANCH_STREAMS = True          # run the independent Inception branches on side streams (inference path)
 WGRAD_SIDE_STREAM = os.environ.get("STEP_WGRAD_STREAM", "1") != "0"   # training: weight gradient beside the data gradient
 _SIDE = {}

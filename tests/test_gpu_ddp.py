@@ -62,8 +62,15 @@ def _worker(rank, world, port, q):
     w.forward_backward(exchange=True)
     sample_b, norms_b = _probe(w.opt.flat_grad * w.scale, w.opt._entries)
     during, nb = w.reducer.issued_during_backward, len(w.reducer.buckets)
+    names = {}
+    for mi, m in enumerate(w.mods):
+        for k, p_ in m.named_parameters():
+            names[id(p_)] = "%d.%s" % (mi, k)
+    rel_t = np.abs(norms_b - norms) / np.maximum(norms, 1e-6 * norms.max())
+    worst = [(names.get(id(w.opt._entries[i][1]), "?"), w.reducer.bucket_of[id(w.opt._entries[i][1])], int(w.opt._entries[i][3]),
+              float(rel_t[i]), float(norms[i])) for i in np.argsort(-rel_t)[:6]]
     if rank == 0:
-        q.put((sample, norms, float(lsum) / world, f, p0, sample_b, norms_b, during, nb, w.scale, noise, noise_t))
+        q.put((sample, norms, float(lsum) / world, f, p0, sample_b, norms_b, during, nb, w.scale, noise, noise_t, worst))
     else:
         q.put(("p", p0))
     dist.barrier()
@@ -86,7 +93,7 @@ def test_two_rank_gradient_equals_single_process_on_the_concatenated_batch():
         assert p.exitcode == 0
     main = [g for g in got if g[0] is not None and not isinstance(g[0], str)][0]
     other = [g for g in got if isinstance(g[0], str)][0]
-    sample, norms, loss2, factor, p0, sample_b, norms_b, during, nb, scale_b, noise, noise_t = main
+    sample, norms, loss2, factor, p0, sample_b, norms_b, during, nb, scale_b, noise, noise_t, worst = main
     assert factor == 0.5 and scale_b == 0.5
     assert nb >= 5 and during >= nb - 2, (during, nb)            # 178 MB arena in 32 MiB buckets; all but the front ones left during backward
     # overlapped == single-shot up to the atomics' summation order (measured on MI355X: 1.6e-4 in relative L2 between
@@ -96,7 +103,7 @@ def test_two_rank_gradient_equals_single_process_on_the_concatenated_batch():
     eb = np.linalg.norm(sample_b - sample) / np.linalg.norm(sample)
     et = float((np.abs(norms_b - norms) / np.maximum(norms, 1e-6 * norms.max())).max())
     assert noise < 1e-3 and noise_t < 2e-3, (noise, noise_t)
-    assert eb < max(5e-4, 5 * noise) and et < max(2e-3, 5 * noise_t), (eb, et, noise, noise_t)
+    assert eb < max(5e-4, 5 * noise) and et < max(2e-3, 5 * noise_t), (eb, et, noise, noise_t, worst)
     assert np.array_equal(p0, other[1])                          # replicas start from the same (broadcast) weights
     dev = torch.device("cuda:0")
     w = workloads.C4TrainStep(dev, batch=2, seed=123)
