@@ -133,7 +133,7 @@ static inline unsigned flat_grid(long long total, int block) {
 }
 
 
-struct ConvPlan { bool ok, flat, wide, deep; int impl, NB, tps, mb, wv, twl, tiles_h, tiles_w, tiles_d, gtd, gth, gtw, ksplit, kchunk16, mbk, mpad, cpad; long long mtiles; };
+struct ConvPlan { bool ok, flat, wide, deep; int impl, NB, tps, mb, wv, ph, twl, tiles_h, tiles_w, tiles_d, gtd, gth, gtw, ksplit, kchunk16, mbk, mpad, cpad; long long mtiles; };
 
 static inline int conv_impl_override() {   // tuning aid: STEP_CONV_IMPL=igemm|tap|tap2 forces one implementation
     const char* e = getenv("STEP_CONV_IMPL");
@@ -146,6 +146,9 @@ static inline int conv_impl_override() {   // tuning aid: STEP_CONV_IMPL=igemm|t
 
 // launchers defined in the other translation units (explicitly instantiated for float, bf16_t, f16_t)
 template <typename T> int conv_tap_launch(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream);   // conv_tap_<dtype>.hip
+template <typename T> int conv_tap_ph_launch(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream);  // conv_tap_ph_<dtype>.hip (two-phase form)
+template <> int conv_tap_ph_launch<bf16_t>(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream);
+template <> int conv_tap_ph_launch<f16_t>(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream);
 template <typename T> int conv_pw_launch(int NB, int wv, const ConvParams& p, dim3 grid, step_stream_t stream);                        // conv_pw.hip
 template <typename T> int conv_splitk_launch(const ConvPlan& pl, const ConvParams& p, float* ws, step_stream_t stream);        // conv_pw.hip
 

@@ -399,7 +399,7 @@ static bool prefer_four_waves_pw(const step_conv_desc* d, long long wgs8) {
 
 static ConvPlan conv_plan(const step_conv_desc* d) {
     ConvPlan pl;
-    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1; pl.mb = 2; pl.wv = 8; pl.deep = false; pl.twl = 4; pl.tiles_d = d->D; pl.gtd = pl.gth = pl.gtw = 1; pl.ksplit = 0; pl.kchunk16 = 0; pl.mbk = 0; pl.mpad = 0; pl.cpad = 0;
+    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1; pl.mb = 2; pl.wv = 8; pl.ph = 0; pl.deep = false; pl.twl = 4; pl.tiles_d = d->D; pl.gtd = pl.gth = pl.gtw = 1; pl.ksplit = 0; pl.kchunk16 = 0; pl.mbk = 0; pl.mpad = 0; pl.cpad = 0;
     const int nblk32 = ceil_div(d->Cout, 32);
     const bool k1 = d->kd == 1 && d->kh == 1 && d->kw == 1;
     const bool k333 = d->kd == 3 && d->kh == 3 && d->kw == 3;
@@ -542,6 +542,12 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
         }
         pl.mtiles = mt256;
         pl.NB = pick_nb_tap(nblk32, pl.mtiles);
+        // the two-phase form (anti-phase wave groups, conv_tap_kernel.h): 16-bit storage, two taps per step
+        if (d->dtype != STEP_F32 && pl.tps == 2) {
+            const char* e = getenv("STEP_CONV_PHASED");             // tuning aid / tests: 0 | 1 | 2 (read per call)
+            pl.ph = e ? atoi(e) : 0;
+            if (pl.ph < 0 || pl.ph > 2) pl.ph = 0;
+        }
         if (have4 && ov != 1 && (waves_env == 4 || (waves_env != 8 && prefer_four_waves(pl, p4, d)))) return p4;
         return pl;
     }
@@ -706,8 +712,8 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
     else if (pl.impl == 2)
         snprintf(buf, (size_t)buflen, "void step::conv_pw_kernel<%s, %d, %d>(step::ConvParams)", t, pl.NB, pl.wv);
     else if (pl.impl == 1)
-        snprintf(buf, (size_t)buflen, "void step::conv_tap_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d>(step::ConvParams)", t,
-                 pl.twl, pl.NB, d->kd, d->kh, d->kw, pl.tps, pl.mb, pl.wv);
+        snprintf(buf, (size_t)buflen, "void step::conv_tap_kernel<%s, %d, %d, %d, %d, %d, %d, %d, %d, %d>(step::ConvParams)", t,
+                 pl.twl, pl.NB, d->kd, d->kh, d->kw, pl.tps, pl.mb, pl.wv, pl.wv == 8 ? pl.ph : 0);
     else
         snprintf(buf, (size_t)buflen, "void step::conv_igemm_kernel<%s, %d, %d, %d, %d, %d, %s, %d>(step::ConvParams)", t,
                  pl.flat ? 4 : (pl.wide ? 5 : 4), pl.NB, d->kd, d->kh, d->kw, pl.flat ? "true" : "false", pl.deep ? 128 : 32);

@@ -31,10 +31,24 @@ namespace step {
 // workgroups are resident per CU (<= 80 KiB of LDS each): they are not lock-stepped by each other's barriers, and one
 // workgroup's prologue / slab switch / epilogue (about a fifth of a workgroup's lifetime on conv3d_2c, all of it
 // exposed with a single resident workgroup) overlaps the other's matrix work.
-template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB, int WV>
-__global__ __launch_bounds__(WV * 64, (WV == 8 && NB == 1 && TWL == 0) ? 4 : 2)
+//
+// PH = 1 / 2 (16-bit storage, 8 waves, two taps per step): the TWO-PHASE form.  The matrix pipe is per SIMD and a single wave
+// issuing back-to-back keeps it busy (32 cycles per v_mfma_f32_32x32x16), but a wave is in-order: in the classic form both
+// waves of a SIMD read their fragments, wait, multiply and meet at the step's barrier at the same moments, so the pipe idles
+// whenever they wait (measured: matrix time and the LDS / barrier skeleton ADD instead of overlapping, MFMA busy 37 %).
+// Here a step is two phases separated by barriers -- L: all of a step's fragments LDS -> registers (20 ds_read_b128 at
+// NB = 3) plus the weight hand-over, C: the step's 8 * NB MFMAs back to back out of registers -- and the two wave groups
+// of the workgroup (one wave of each group per SIMD) run them in ANTI-PHASE: group 1 passes one extra barrier before a
+// slab's steps and group 0 one after them, so while one wave of a SIMD multiplies, its partner loads.  The groups are the
+// two channel halves of the tile (wn), so each group owns the weight ring of its half and stages it with its own 256
+// threads; the halo slab is shared and re-staged between slabs with the groups realigned.  No fragment double-buffering
+// (a wave's L and C phases alternate) -- same accumulation order as the classic form, bit-identical results.
+// PH = 1: group = wave / 4 (waves w and w + 4 share a SIMD), PH = 2: group = wave & 1.
+template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB, int WV, int PH = 0>
+__global__ __launch_bounds__(WV * 64, (WV == 8 && NB == 1 && TWL == 0 && PH == 0) ? 4 : 2)
 void conv_tap_kernel(ConvParams p) {
     static_assert(MB == 2 && (WV == 8 || WV == 4), "two accumulator rows per wave; 8 or 4 waves");
+    static_assert(PH == 0 || (WV == 8 && TPS == 2 && sizeof(T) == 2), "two-phase form: 8 waves, two taps per step, 16-bit storage");
     constexpr int NT = WV * 64;                 // threads
     constexpr int WM = WV / 2;                  // waves along the pixel axis (x 2 along channels)
     constexpr int MBP = MB / 2;                 // accumulator rows per wave per epilogue pass
@@ -119,7 +133,7 @@ void conv_tap_kernel(ConvParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> scalar branches
 #endif
     const int khalf = lane >> 5;
-    const int wm = wave % WM, wn = wave / WM;
+    const int wm = (PH == 2) ? (wave >> 1) : (wave % WM), wn = (PH == 2) ? (wave & 1) : (wave / WM);
 
     int gbx, gby;
     if (!grid_coords(p, gbx, gby)) return;
@@ -199,6 +213,126 @@ void conv_tap_kernel(ConvParams p) {
         }
     };
 
+    if constexpr (PH != 0) {
+        // ---- two-phase pipeline (see the header comment)
+        constexpr int HB = NB * KS * FRAGB;              // bytes of one tap's weights for ONE channel half
+        constexpr int HSTEP = TPS * HB;                  // ... of one step
+        constexpr int QH = HSTEP / 16 / 256;             // 16-byte vectors per thread per step (256 threads per group) = NB
+        static_assert(QH * 256 * 16 == HSTEP, "a step's half tile is a whole number of 256-thread rounds");
+        static_assert(3 * 2 * HSTEP == 3 * BSTEP || PADB, "the two half rings fit the classic weight region");
+        const int grp = wn;                              // wave group = channel half
+        const int gtid = (PH == 2) ? ((wave >> 1) * 64 + lane) : (tid & 255);     // thread index inside the group
+        unsigned char* const ldsBg = ldsB + grp * (3 * HSTEP);
+        const unsigned char* wthr[QH];
+#pragma unroll
+        for (int q = 0; q < QH; ++q) {
+            const int v = gtid + q * 256;
+            const int tp = v / (HB / 16), rem = v % (HB / 16);
+            const int f = rem / FRAGV, within = rem % FRAGV;
+            const int nbl = f / KS, ks = f % KS;
+            const int nbg = min(nb0 + grp * NB + nbl, p.nblk32 - 1);
+            wthr[q] = wg + (((size_t)nbg * taps_padded(NTAPS) + tp) * KC16 + ks) * FRAGB + within * 16;
+        }
+        const unsigned wtap = (unsigned)KC16 * FRAGB;
+        auto load_B = [&](unsigned woff, u32x4 (&r)[QH]) {
+#pragma unroll
+            for (int q = 0; q < QH; ++q) r[q] = *(const u32x4*)(wthr[q] + (size_t)woff);
+        };
+        auto store_B = [&](int bufoff, const u32x4 (&r)[QH]) {
+#pragma unroll
+            for (int q = 0; q < QH; ++q) *(u32x4*)(ldsBg + bufoff + (gtid + q * 256) * 16) = r[q];
+        };
+        u32x4 R0[QH], R1[QH];
+        frag_t fa[TPS][KS][MB], fb[TPS][KS][NB];
+        const unsigned char* const bwave = ldsBg + lane * (8 * ES);
+        int nshift = 0, tidx = 0, kw_c = 0, kh_c = 0;       // LDS byte shift of the next tap (as the classic form)
+        auto advance_tap = [&]() {
+            ++tidx;
+            if (tidx >= NTAPS) {
+                nshift = 0; kw_c = 0; kh_c = 0;
+                if (tidx == NTP) tidx = 0;
+                return;
+            }
+            ++kw_c; nshift += PITCH;
+            if (kw_c == KW) {
+                kw_c = 0; nshift += (HW_ - KW) * PITCH;
+                if (++kh_c == KH) { kh_c = 0; nshift += (HH_ - KH) * HW_ * PITCH; }
+            }
+        };
+        int slab3 = 0, sis3 = 0;
+        unsigned woff3 = 0;
+        auto adv_clamped = [&]() {
+            if (slab3 == nslab - 1 && sis3 == SPS - 1) return;
+            woff3 += (unsigned)TPS * wtap;
+            if (++sis3 == SPS) { sis3 = 0; ++slab3; woff3 = (unsigned)slab3 * KS * FRAGB; }
+        };
+        // prologue: halo slab 0, weights of steps 0 and 1 to LDS, steps 2 and 3 to the two register sets
+        stage_A(0);
+        load_B(0u, R0); adv_clamped();
+        load_B(woff3, R1); adv_clamped();
+        store_B(0, R0);
+        load_B(woff3, R0); adv_clamped();
+        store_B(HSTEP, R1);
+        load_B(woff3, R1); adv_clamped();
+        __syncthreads();
+        if (grp == 1) __syncthreads();                    // anti-phase: group 1 runs one phase behind group 0
+        int b0 = 0, b1 = HSTEP, b2 = 2 * HSTEP;            // ring buffers of step s, s+1, s+2
+        int s_ = 0, sis0 = 0, slab0 = 0;
+        auto step = [&](u32x4 (&R)[QH]) {
+            // ---- L: every fragment of the step, the hand-over of step s+2's weights and the request for step s+4's
+#pragma unroll
+            for (int tp = 0; tp < TPS; ++tp) {
+                const int shift = nshift;
+                advance_tap();
+#pragma unroll
+                for (int j = 0; j < KS; ++j) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) fa[tp][j][mb] = lds_read_bfrag<T>(abase[mb] + shift + j * 32);
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) fb[tp][j][i] = lds_read_bfrag<T>(bwave + b0 + tp * HB + (i * KS + j) * FRAGB);
+                }
+            }
+            store_B(b2, R);                                // (buffer b2 was last read in L of step s-1)
+            load_B(woff3, R);
+            adv_clamped();
+            __syncthreads();
+            // ---- C: the step's MFMAs, back to back out of registers, at raised priority (the partner wave is in its L phase)
+#ifndef STEP_EMUL
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+            for (int tp = 0; tp < TPS; ++tp)
+#pragma unroll
+                for (int j = 0; j < KS; ++j)
+#pragma unroll
+                    for (int i = 0; i < NB; ++i)
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) mma_k16(fa[tp][j][mb], fb[tp][j][i], acc[mb][i], T());
+#ifndef STEP_EMUL
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            __syncthreads();
+            const int t0 = b0; b0 = b1; b1 = b2; b2 = t0;
+            ++s_;
+            if (++sis0 == SPS) {
+                sis0 = 0; ++slab0;
+                if (s_ < S) {                              // slab switch: realign the groups, re-stage the halo, skew again
+                    if (grp == 0) __syncthreads();        // (group 1's last C phase of the slab)
+                    stage_A(slab0);
+                    __syncthreads();
+                    if (grp == 1) __syncthreads();
+                }
+            }
+        };
+#pragma unroll 1
+        while (s_ < S) {
+            step(R0);
+            if (s_ < S) step(R1);
+        }
+        if (grp == 0) __syncthreads();                    // realign before the epilogue reuses LDS
+    } else {
     // global -> registers: this thread's vectors of the B tile of a pipeline step.  Branch-free on
     // purpose (a predicated load makes the compiler drain vmcnt at the loop head): threads without a
     // vector re-load the last one, and channel blocks past Cout re-load the last real block -- their
@@ -359,6 +493,8 @@ void conv_tap_kernel(ConvParams p) {
         }
     }
 
+    }   // classic pipeline
+
     // ---- epilogue
     T* yg = (T*)p.y;
     const T* rg = (const T*)p.res;
@@ -481,8 +617,44 @@ static int launch_tap(const ConvParams& p, int NB, int tps, int wv, dim3 grid, s
 }
 
 
+// two-phase form (PH = 1 / 2): 16-bit storage only; instantiated in conv_tap_ph_{bf16,f16}.hip
+template <typename T, int TWL, int KD, int KH, int KW>
+static int launch_tap_ph(const ConvParams& p, int NB, int ph, dim3 grid, step_stream_t stream) {
+#define STEP_TAPPH(NB_, PH_) STEP_LAUNCH((conv_tap_kernel<T, TWL, NB_, KD, KH, KW, 2, 2, 8, PH_>), grid, dim3(512), stream, p)
+    if (ph == 2) {
+        switch (NB) {
+            case 1: STEP_TAPPH(1, 2); break;
+            case 2: STEP_TAPPH(2, 2); break;
+            default: STEP_TAPPH(3, 2); break;
+        }
+    } else {
+        switch (NB) {
+            case 1: STEP_TAPPH(1, 1); break;
+            case 2: STEP_TAPPH(2, 1); break;
+            default: STEP_TAPPH(3, 1); break;
+        }
+    }
+#undef STEP_TAPPH
+    return STEP_LAUNCH_CHECK();
+}
+
+template <typename T>
+int conv_tap_ph_launch_impl(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream) {
+    if (kd == 3) {
+        if (pl.twl == 0) return launch_tap_ph<T, 0, 3, 3, 3>(p, pl.NB, pl.ph, grid, stream);
+        if (pl.twl == 3) return launch_tap_ph<T, 3, 3, 3, 3>(p, pl.NB, pl.ph, grid, stream);
+        return pl.wide ? launch_tap_ph<T, 5, 3, 3, 3>(p, pl.NB, pl.ph, grid, stream) : launch_tap_ph<T, 4, 3, 3, 3>(p, pl.NB, pl.ph, grid, stream);
+    }
+    if (pl.twl == 0) return launch_tap_ph<T, 0, 1, 3, 3>(p, pl.NB, pl.ph, grid, stream);
+    if (pl.twl == 3) return launch_tap_ph<T, 3, 1, 3, 3>(p, pl.NB, pl.ph, grid, stream);
+    return pl.wide ? launch_tap_ph<T, 5, 1, 3, 3>(p, pl.NB, pl.ph, grid, stream) : launch_tap_ph<T, 4, 1, 3, 3>(p, pl.NB, pl.ph, grid, stream);
+}
+
 template <typename T>
 int conv_tap_launch(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream) {
+    if constexpr (sizeof(T) == 2) {
+        if (pl.ph != 0 && pl.wv == 8 && pl.tps == 2) return conv_tap_ph_launch<T>(pl, p, kd, grid, stream);
+    }
     if (kd == 3) {
         if (pl.twl == 0) return launch_tap<T, 0, 3, 3, 3>(p, pl.NB, pl.tps, pl.wv, grid, stream);
         if (pl.twl == 3) return launch_tap<T, 3, 3, 3, 3>(p, pl.NB, pl.tps, pl.wv, grid, stream);

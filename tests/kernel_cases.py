@@ -592,7 +592,7 @@ def case_conv_units_four_wave_form(bk, golden):
                            y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
         buf = ctypes.create_string_buffer(256)
         assert bk.lib.step_conv_kernel_name(ctypes.byref(d), buf, 256) == 0
-        assert buf.value.decode().endswith(", 2, 4>(step::ConvParams)"), buf.value      # ..., TPS, MB = 2, WV = 4>
+        assert buf.value.decode().endswith(", 2, 4, 0>(step::ConvParams)"), buf.value      # ..., TPS, MB = 2, WV = 4, PH = 0>
         extra = [(1, 64, 192, 3, 9, 17, (3, 3, 3)),     # NB = 3: 8x16 tiles, ragged in H and W, two slabs
                  (1, 96, 130, 5, 8, 8, (3, 3, 3)),      # 2 planes x 8x8, ragged plane pairs (5 = 2*2 + 1), 5 channel blocks
                  (2, 32, 64, 2, 6, 21, (1, 3, 3))]      # 2-D kernel, general box on a 6x21 map
@@ -694,6 +694,58 @@ def big_pool3_conv1(bk, golden):
                  (2, 832, 128, 3, 7, 7)):
         _pool3_conv1_case(bk, case, (BF16, F16))
     _pool3_conv1_case(bk, (1, 480, 64, 4, 14, 14), (F32,))
+
+
+def case_conv_units_two_phase_form(bk, golden):
+    """The TWO-PHASE form of conv_tap_kernel (anti-phase wave groups: a step is a load phase and a multiply phase separated
+    by barriers, the two channel-half groups of the workgroup run them alternately; STEP_CONV_PHASED=1|2 selects it wherever
+    the 8-wave tap kernel runs in 16-bit storage): same shapes as the classic form, checked against the fp32 reference AND
+    bit for bit against the classic form (the accumulation order is the same)."""
+    saved, saved_w = os.environ.get("STEP_CONV_PHASED"), os.environ.get("STEP_CONV_WAVES")
+    os.environ["STEP_CONV_WAVES"] = "8"              # (the planner sends grids this small to the four-wave form)
+    buf = ctypes.create_string_buffer(256)
+    extra = [(1, 96, 192, 3, 9, 17, (3, 3, 3)),      # NB = 3, three slabs (two halo re-stagings with the groups realigned), ragged tiles
+             (1, 40, 130, 5, 8, 8, (3, 3, 3)),       # 4 planes x 8x8, ragged last slab (40 = 32 + 8), 5 channel blocks (odd: a duplicate block)
+             (2, 32, 64, 2, 6, 21, (1, 3, 3))]       # 2-D kernel (10 padded taps: an ODD number of steps per slab), general box
+    cases = [c for c in CONV_CASES + extra if c[6] != (1, 1, 1)]
+    try:
+        os.environ.pop("STEP_CONV_PHASED", None)
+        classic = {}
+        for case in cases:
+            N, Cin, Cout, D, H, W, k = case
+            rs = np.random.RandomState(Cin * 7 + Cout)
+            x = rs.randn(N, Cin, D, H, W).astype(np.float32)
+            w = (rs.randn(Cout, Cin, *k) / np.sqrt(Cin * np.prod(k))).astype(np.float32)
+            scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32)
+            shift = (0.2 * rs.randn(Cout)).astype(np.float32)
+            classic[case] = (x, w, scale, shift, run_conv(bk, x, w, scale, shift, BF16, x_pad=(8, 8), y_pad=(16, 8)))
+        for ph in ("1", "2"):
+            os.environ["STEP_CONV_PHASED"] = ph
+            seen = 0
+            for case in cases:
+                N, Cin, Cout, D, H, W, k = case
+                x, w, scale, shift, y0 = classic[case]
+                d = _capi.ConvDesc(dtype=BF16, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2], x_cstride=Cin, x_coff=0,
+                                   y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+                assert bk.lib.step_conv_kernel_name(ctypes.byref(d), buf, 256) == 0
+                name = buf.value.decode()
+                if "conv_tap_kernel" in name:
+                    assert name.endswith(", 2, 2, 8, %s>(step::ConvParams)" % ph), name
+                    seen += 1
+                got = run_conv(bk, x, w, scale, shift, BF16, x_pad=(8, 8), y_pad=(16, 8))
+                ref = ref_conv(x, w, scale, shift, BF16)
+                err = np.abs(got - ref).max() / np.abs(ref).max()
+                assert err < tol(BF16), (case, ph, err)
+                assert np.array_equal(got, y0), (case, ph, float(np.abs(got - y0).max()))
+            assert seen >= 4, seen
+        os.environ["STEP_CONV_PHASED"] = "1"
+        _conv_case(bk, extra[0], (F16,))
+    finally:
+        for key, val in (("STEP_CONV_PHASED", saved), ("STEP_CONV_WAVES", saved_w)):
+            if val is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = val
 
 
 def case_conv_residual_norelu_f16_and_bias_only(bk, golden):
