@@ -276,6 +276,21 @@ STEP_API int step_adam_flat(float* param, float* grad, float* exp_avg, float* ex
 STEP_API int step_act_grad(int dtype, const void* y, int y_cstride, int gy_dtype, const void* gy, int gy_cstride, const float* scale,
                            long long M, int C, int relu, float* g32, void* g_act, step_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * One refinement step's tube bookkeeping (utils/utils.py:68-129 in temporal_mode "predict"), one launch:
+ *   pred_loc   [N,T,4]  = decode_coef(tubes[:, :, 1:5],                         local_loc)      (tube_utils.py:178-189)
+ *   pred_first [N,Tw,4] = decode_coef(tubes[:, first_off : first_off+Tw, 1:5],  first_loc)      (utils.py:75-79)
+ *   pred_last  [N,Tw,4] = decode_coef(tubes[:, last_off  : last_off +Tw, 1:5],  last_loc)
+ *   next_tubes [N,Tn,5] = the next step's proposals: extend ? cat(pred_first, pred_loc, pred_last) : pred_loc   (Tn = T + 2 Tw | T),
+ *                         through valid_tubes(width, height) (clamp; boxes under 3 px become the whole frame, tube_utils.py:59-92),
+ *                         with column 0 = clip_of[n] * Tn + frame (flatten_tubes(batch_idx=True), tube_utils.py:214-246).
+ * tubes [N,T,5] fp32 (column 0 ignored), local_loc [N,T,4], first_loc / last_loc [N,Tw,4] fp32, clip_of [N] int32.
+ * fp32 arithmetic in the reference's operation order. */
+STEP_API int step_tube_update(const float* tubes, int N, int T, const float* local_loc, const float* first_loc,
+                              const float* last_loc, int Tw, int first_off, int last_off, const int32_t* clip_of, int extend,
+                              float width, float height, float* pred_loc, float* pred_first, float* pred_last,
+                              float* next_tubes, step_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

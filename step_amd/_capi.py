@@ -4,7 +4,7 @@ import ctypes as C
 
 F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 vp, fp, ip, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # raw device addresses
 i, f, ll, sz = C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -48,6 +48,7 @@ SIGNATURES = {
     "step_avgpool_hw": (i, [i, vp, i, i, i, i, i, i, i, vp, vp]),
     "step_transpose_cs": (i, [vp, i, vp, i, i, i, ll, i, vp]),
     "step_act_grad": (i, [i, vp, i, i, vp, i, fp, ll, i, i, fp, vp, vp]),
+    "step_tube_update": (i, [fp, i, i, fp, fp, fp, i, i, i, ip, i, f, f, fp, fp, fp, fp, vp]),
     "step_adam_flat": (i, [fp, fp, fp, fp, ll, vp, fp, fp, i, C.c_double, C.c_double, C.c_double, i, f, i, vp]),
 }
 

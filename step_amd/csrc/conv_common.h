@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 namespace step {
 
@@ -46,6 +47,12 @@ __device__ __forceinline__ bool grid_coords(const ConvParams& p, int& bx, int& b
     by = (int)(L % (unsigned)p.gy);
     return true;
 }
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 template <typename T> struct Ld16;  // 16-byte LDS / global vector of T
 template <> struct Ld16<float> { typedef f32x4 type; };

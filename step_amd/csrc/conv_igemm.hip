@@ -543,10 +543,11 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
         pl.mtiles = mt256;
         pl.NB = pick_nb_tap(nblk32, pl.mtiles);
         // the two-phase form (anti-phase wave groups, conv_tap_kernel.h): 16-bit storage, two taps per step
-        if (d->dtype != STEP_F32 && pl.tps == 2) {
-            const char* e = getenv("STEP_CONV_PHASED");             // tuning aid / tests: 0 | 1 | 2 (read per call)
-            pl.ph = e ? atoi(e) : 0;
-            if (pl.ph < 0 || pl.ph > 2) pl.ph = 0;
+        // (measured on MI355X, C2 layers, interleaved A/B, profiles/r02_ab_phased.txt: every 3x3x3 layer faster, 829 -> 704 us
+        // per step in total; conv3d_2c 299 -> 259 us, the 14x14 branch_1 layers -19...-23 %)
+        if (d->dtype != STEP_F32 && pl.tps == 2 && k333) {
+            const char* e = getenv("STEP_CONV_PHASED");             // tuning aid / tests: 0 = the classic form (read per call)
+            pl.ph = (e && atoi(e) == 0) ? 0 : 1;
         }
         if (have4 && ov != 1 && (waves_env == 4 || (waves_env != 8 && prefer_four_waves(pl, p4, d)))) return p4;
         return pl;
@@ -721,7 +722,7 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
 }
 
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 11; }
+int step_abi_version(void) { return 12; }
 
 }  // extern "C"
 

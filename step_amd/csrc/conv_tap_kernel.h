@@ -106,7 +106,8 @@ void conv_tap_kernel(ConvParams p) {
 
     constexpr int EROWS = WM * MBP * 32;                                      // pixels per epilogue pass: 128 (WV = 8) or 64
     constexpr int EPI_BYTES = (ES == 2) ? EROWS * NBT * 32 * 4 + 1024 : 0;   // fp32 transpose buffer of the 16-bit epilogue + pixel table
-    constexpr int LDS_BYTES = (NPIX_MAX * PITCH + 3 * BSTEP) > EPI_BYTES ? (NPIX_MAX * PITCH + 3 * BSTEP) : EPI_BYTES;
+    constexpr int BBYTES = PH ? 2 * 2 * TPS * (NB * KS * FRAGB) : 3 * BSTEP;    // two-phase form: two groups x a ring of two half-step buffers
+    constexpr int LDS_BYTES = (NPIX_MAX * PITCH + BBYTES) > EPI_BYTES ? (NPIX_MAX * PITCH + BBYTES) : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     unsigned char* const ldsA = lds;
     unsigned char* const ldsB = lds + NPIX_MAX * PITCH;
@@ -153,7 +154,7 @@ void conv_tap_kernel(ConvParams p) {
     const unsigned char* wg = (const unsigned char*)p.w;
 
     // LDS address of this lane's two accumulator rows (before the tap shift), incl. its k half
-    const unsigned char* abase[MB];
+    const unsigned char* abase[MB];          // (not const-qualified pointers: the two-phase form launders them per slab)
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int m = wm * (MB * 32) + mb * 32 + (lane & 31);
@@ -214,15 +215,16 @@ void conv_tap_kernel(ConvParams p) {
     };
 
     if constexpr (PH != 0) {
-        // ---- two-phase pipeline (see the header comment)
+        // ---- two-phase pipeline (see the header comment).  A slab's steps are unrolled: tap shifts and ring-buffer offsets
+        // are immediates of the ds_reads (measured: the scalar / branch code of the rolled loop cost ~290 cycles per phase,
+        // as much as the 20 fragment reads themselves).
         constexpr int HB = NB * KS * FRAGB;              // bytes of one tap's weights for ONE channel half
         constexpr int HSTEP = TPS * HB;                  // ... of one step
         constexpr int QH = HSTEP / 16 / 256;             // 16-byte vectors per thread per step (256 threads per group) = NB
         static_assert(QH * 256 * 16 == HSTEP, "a step's half tile is a whole number of 256-thread rounds");
-        static_assert(3 * 2 * HSTEP == 3 * BSTEP || PADB, "the two half rings fit the classic weight region");
         const int grp = wn;                              // wave group = channel half
         const int gtid = (PH == 2) ? ((wave >> 1) * 64 + lane) : (tid & 255);     // thread index inside the group
-        unsigned char* const ldsBg = ldsB + grp * (3 * HSTEP);
+        unsigned char* const ldsBg = ldsB + grp * (2 * HSTEP);                     // per group: a ring of TWO step buffers
         const unsigned char* wthr[QH];
 #pragma unroll
         for (int q = 0; q < QH; ++q) {
@@ -233,7 +235,11 @@ void conv_tap_kernel(ConvParams p) {
             const int nbg = min(nb0 + grp * NB + nbl, p.nblk32 - 1);
             wthr[q] = wg + (((size_t)nbg * taps_padded(NTAPS) + tp) * KC16 + ks) * FRAGB + within * 16;
         }
-        const unsigned wtap = (unsigned)KC16 * FRAGB;
+        const unsigned wstep = (unsigned)TPS * KC16 * FRAGB;               // bytes between consecutive steps of a slab
+        auto woff_of = [&](int slab, int si) -> unsigned {                  // weight offset of a step; past the end: the last one
+            if (slab >= nslab) { slab = nslab - 1; si = SPS - 1; }
+            return (unsigned)slab * (KS * FRAGB) + (unsigned)si * wstep;
+        };
         auto load_B = [&](unsigned woff, u32x4 (&r)[QH]) {
 #pragma unroll
             for (int q = 0; q < QH; ++q) r[q] = *(const u32x4*)(wthr[q] + (size_t)woff);
@@ -242,94 +248,95 @@ void conv_tap_kernel(ConvParams p) {
 #pragma unroll
             for (int q = 0; q < QH; ++q) *(u32x4*)(ldsBg + bufoff + (gtid + q * 256) * 16) = r[q];
         };
-        u32x4 R0[QH], R1[QH];
+        u32x4 R0[QH], R1[QH];                                // weights in flight: R0 even steps, R1 odd steps
         frag_t fa[TPS][KS][MB], fb[TPS][KS][NB];
         const unsigned char* const bwave = ldsBg + lane * (8 * ES);
-        int nshift = 0, tidx = 0, kw_c = 0, kh_c = 0;       // LDS byte shift of the next tap (as the classic form)
-        auto advance_tap = [&]() {
-            ++tidx;
-            if (tidx >= NTAPS) {
-                nshift = 0; kw_c = 0; kh_c = 0;
-                if (tidx == NTP) tidx = 0;
-                return;
-            }
-            ++kw_c; nshift += PITCH;
-            if (kw_c == KW) {
-                kw_c = 0; nshift += (HW_ - KW) * PITCH;
-                if (++kh_c == KH) { kh_c = 0; nshift += (HH_ - KH) * HW_ * PITCH; }
-            }
-        };
-        int slab3 = 0, sis3 = 0;
-        unsigned woff3 = 0;
-        auto adv_clamped = [&]() {
-            if (slab3 == nslab - 1 && sis3 == SPS - 1) return;
-            woff3 += (unsigned)TPS * wtap;
-            if (++sis3 == SPS) { sis3 = 0; ++slab3; woff3 = (unsigned)slab3 * KS * FRAGB; }
-        };
-        // prologue: halo slab 0, weights of steps 0 and 1 to LDS, steps 2 and 3 to the two register sets
-        stage_A(0);
-        load_B(0u, R0); adv_clamped();
-        load_B(woff3, R1); adv_clamped();
-        store_B(0, R0);
-        load_B(woff3, R0); adv_clamped();
-        store_B(HSTEP, R1);
-        load_B(woff3, R1); adv_clamped();
-        __syncthreads();
-        if (grp == 1) __syncthreads();                    // anti-phase: group 1 runs one phase behind group 0
-        int b0 = 0, b1 = HSTEP, b2 = 2 * HSTEP;            // ring buffers of step s, s+1, s+2
-        int s_ = 0, sis0 = 0, slab0 = 0;
-        auto step = [&](u32x4 (&R)[QH]) {
-            // ---- L: every fragment of the step, the hand-over of step s+2's weights and the request for step s+4's
+        const int HHWB = HHW * PITCH, HWB = HW_ * PITCH;    // (compile-time constants for the power-of-two tiles)
+        int aoff[MB];                                        // LDS byte offsets of this lane's accumulator rows
 #pragma unroll
-            for (int tp = 0; tp < TPS; ++tp) {
-                const int shift = nshift;
-                advance_tap();
+        for (int mb = 0; mb < MB; ++mb) aoff[mb] = (int)(abase[mb] - lds);
+        // step g (global index) of parity q: fragments from ring buffer q; register set q^1 holds step g+1, written to ring
+        // buffer q^1 (last read in L of step g-1) and re-issued for step g+3
+        auto step = [&](auto sic, auto parc, int slab) {
+            constexpr int SI = decltype(sic)::value;               // step inside the slab
+            constexpr int Q = (decltype(parc)::value + SI) & 1;    // parity of the global step
+            u32x4 (&Rn)[QH] = Q ? R0 : R1;
+            // ---- L
+            {
 #pragma unroll
-                for (int j = 0; j < KS; ++j) {
+                for (int tp = 0; tp < TPS; ++tp) {
+                    const int tap = SI * TPS + tp;                 // (compile-time after unrolling; the padded tap reads shift 0)
+                    int shift = tap >= NTAPS ? 0 : (tap / (KH * KW)) * HHWB + ((tap / KW) % KH) * HWB + (tap % KW) * PITCH;
+#ifndef STEP_EMUL
+                    // run-time tile boxes: the shift is not an immediate.  Pin its use to this phase (volatile asm statements
+                    // keep their order with the barriers): left alone the compiler forms all 2 x 27 shifted fragment addresses
+                    // at the top of the slab (54 live VGPRs -> scratch spills)
+                    if (GEN) asm volatile("" : "+s"(shift));
+#endif
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) fa[tp][j][mb] = lds_read_bfrag<T>(abase[mb] + shift + j * 32);
+                    for (int j = 0; j < KS; ++j) {
 #pragma unroll
-                    for (int i = 0; i < NB; ++i) fb[tp][j][i] = lds_read_bfrag<T>(bwave + b0 + tp * HB + (i * KS + j) * FRAGB);
+                        for (int mb = 0; mb < MB; ++mb) fa[tp][j][mb] = lds_read_bfrag<T>(lds + aoff[mb] + shift + j * 32);
+#pragma unroll
+                        for (int i = 0; i < NB; ++i) fb[tp][j][i] = lds_read_bfrag<T>(bwave + Q * HSTEP + tp * HB + (i * KS + j) * FRAGB);
+                    }
                 }
             }
-            store_B(b2, R);                                // (buffer b2 was last read in L of step s-1)
-            load_B(woff3, R);
-            adv_clamped();
+            store_B((Q ^ 1) * HSTEP, Rn);
+#ifndef STEP_EMUL
+            __builtin_amdgcn_sched_barrier(0);             // the weight requests go BEHIND the fragment reads (see below)
+#endif
+            {
+                constexpr int S3 = SI + 3;
+                load_B(woff_of(slab + (S3 >= SPS ? 1 : 0), S3 >= SPS ? S3 - SPS : S3), Rn);
+            }
+#ifndef STEP_EMUL
+            // keep the weight requests at the END of this phase: left to itself the compiler hoists them (into fresh registers)
+            // to the head of the phase, where their issue delays the 20 ds_reads the partner wave's multiply phase is
+            // supposed to cover (measured on conv3d_2c: 261 -> 320 us)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             __syncthreads();
             // ---- C: the step's MFMAs, back to back out of registers, at raised priority (the partner wave is in its L phase)
 #ifndef STEP_EMUL
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #endif
+            {
 #pragma unroll
-            for (int tp = 0; tp < TPS; ++tp)
+                for (int tp = 0; tp < TPS; ++tp)
 #pragma unroll
-                for (int j = 0; j < KS; ++j)
+                    for (int j = 0; j < KS; ++j)
 #pragma unroll
-                    for (int i = 0; i < NB; ++i)
+                        for (int i = 0; i < NB; ++i)
 #pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) mma_k16(fa[tp][j][mb], fb[tp][j][i], acc[mb][i], T());
+                            for (int mb = 0; mb < MB; ++mb) mma_k16(fa[tp][j][mb], fb[tp][j][i], acc[mb][i], T());
+            }
 #ifndef STEP_EMUL
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
 #endif
             __syncthreads();
-            const int t0 = b0; b0 = b1; b1 = b2; b2 = t0;
-            ++s_;
-            if (++sis0 == SPS) {
-                sis0 = 0; ++slab0;
-                if (s_ < S) {                              // slab switch: realign the groups, re-stage the halo, skew again
-                    if (grp == 0) __syncthreads();        // (group 1's last C phase of the slab)
-                    stage_A(slab0);
-                    __syncthreads();
-                    if (grp == 1) __syncthreads();
-                }
-            }
         };
+        // prologue: halo slab 0; weights of step 0 to ring buffer 0, steps 1 and 2 in the register sets
+        stage_A(0);
+        load_B(woff_of(0, 0), R0);
+        load_B(woff_of(SPS > 1 ? 0 : 1, SPS > 1 ? 1 : 0), R1);
+        store_B(0, R0);
+        load_B(woff_of(SPS > 2 ? 0 : 1, SPS > 2 ? 2 : 2 - SPS), R0);
+        __syncthreads();
+        typedef std::integral_constant<int, 0> P0;
+        typedef std::integral_constant<int, 1> P1;
 #pragma unroll 1
-        while (s_ < S) {
-            step(R0);
-            if (s_ < S) step(R1);
+        for (int slab = 0; slab < nslab; ++slab) {
+            if (slab) {                                    // slab switch: realign the groups, re-stage the halo
+                if (grp == 0) __syncthreads();            // (group 1's last C phase of the previous slab)
+                stage_A(slab);
+                __syncthreads();
+            }
+            if (grp == 1) __syncthreads();                // anti-phase: group 1 runs one phase behind group 0
+            if ((SPS & 1) && (slab & 1)) static_for<SPS>([&](auto si) { step(si, P1(), slab); });
+            else static_for<SPS>([&](auto si) { step(si, P0(), slab); });
         }
         if (grp == 0) __syncthreads();                    // realign before the epilogue reuses LDS
     } else {
@@ -617,22 +624,16 @@ static int launch_tap(const ConvParams& p, int NB, int tps, int wv, dim3 grid, s
 }
 
 
-// two-phase form (PH = 1 / 2): 16-bit storage only; instantiated in conv_tap_ph_{bf16,f16}.hip
-template <typename T, int TWL, int KD, int KH, int KW>
-static int launch_tap_ph(const ConvParams& p, int NB, int ph, dim3 grid, step_stream_t stream) {
-#define STEP_TAPPH(NB_, PH_) STEP_LAUNCH((conv_tap_kernel<T, TWL, NB_, KD, KH, KW, 2, 2, 8, PH_>), grid, dim3(512), stream, p)
-    if (ph == 2) {
-        switch (NB) {
-            case 1: STEP_TAPPH(1, 2); break;
-            case 2: STEP_TAPPH(2, 2); break;
-            default: STEP_TAPPH(3, 2); break;
-        }
-    } else {
-        switch (NB) {
-            case 1: STEP_TAPPH(1, 1); break;
-            case 2: STEP_TAPPH(2, 1); break;
-            default: STEP_TAPPH(3, 1); break;
-        }
+// two-phase form (PH = 1): 16-bit storage, 3x3x3 windows; instantiated in conv_tap_ph_{bf16,f16}.hip
+// (1x3x3 windows have 5 steps per slab -- an odd count doubles the unrolled body and spills; PH = 2, the wave grouping
+// that pairs waves of DIFFERENT SIMDs, measured 20-30 % slower than the classic form and is not instantiated)
+template <typename T, int TWL>
+static int launch_tap_ph(const ConvParams& p, int NB, dim3 grid, step_stream_t stream) {
+#define STEP_TAPPH(NB_) STEP_LAUNCH((conv_tap_kernel<T, TWL, NB_, 3, 3, 3, 2, 2, 8, 1>), grid, dim3(512), stream, p)
+    switch (NB) {
+        case 1: STEP_TAPPH(1); break;
+        case 2: STEP_TAPPH(2); break;
+        default: STEP_TAPPH(3); break;
     }
 #undef STEP_TAPPH
     return STEP_LAUNCH_CHECK();
@@ -640,14 +641,10 @@ static int launch_tap_ph(const ConvParams& p, int NB, int ph, dim3 grid, step_st
 
 template <typename T>
 int conv_tap_ph_launch_impl(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream) {
-    if (kd == 3) {
-        if (pl.twl == 0) return launch_tap_ph<T, 0, 3, 3, 3>(p, pl.NB, pl.ph, grid, stream);
-        if (pl.twl == 3) return launch_tap_ph<T, 3, 3, 3, 3>(p, pl.NB, pl.ph, grid, stream);
-        return pl.wide ? launch_tap_ph<T, 5, 3, 3, 3>(p, pl.NB, pl.ph, grid, stream) : launch_tap_ph<T, 4, 3, 3, 3>(p, pl.NB, pl.ph, grid, stream);
-    }
-    if (pl.twl == 0) return launch_tap_ph<T, 0, 1, 3, 3>(p, pl.NB, pl.ph, grid, stream);
-    if (pl.twl == 3) return launch_tap_ph<T, 3, 1, 3, 3>(p, pl.NB, pl.ph, grid, stream);
-    return pl.wide ? launch_tap_ph<T, 5, 1, 3, 3>(p, pl.NB, pl.ph, grid, stream) : launch_tap_ph<T, 4, 1, 3, 3>(p, pl.NB, pl.ph, grid, stream);
+    if (kd != 3 || pl.ph != 1) return STEP_E_UNSUPPORTED;
+    if (pl.twl == 0) return launch_tap_ph<T, 0>(p, pl.NB, grid, stream);
+    if (pl.twl == 3) return launch_tap_ph<T, 3>(p, pl.NB, grid, stream);
+    return pl.wide ? launch_tap_ph<T, 5>(p, pl.NB, grid, stream) : launch_tap_ph<T, 4>(p, pl.NB, grid, stream);
 }
 
 template <typename T>

@@ -18,7 +18,10 @@ neighbour regressions extend the tube), "extrapolate" (linear, tube_utils.py:159
 import numpy as np
 import torch
 
+from . import ops
 from .tube_math import extrapolate_tubes, decode_coef, valid_tubes
+
+TUBE_KERNEL = True             # per-step tube bookkeeping as one HIP launch (False: the tensor-op restatement below)
 
 
 def _flat_tubes(tubes_list, device, dtype=torch.float32):
@@ -64,6 +67,7 @@ def inference_flat(args, conv_feat, context_feat, nets, exec_iter, flat, nums, c
     synchronisation, so the whole multi-step pipeline can be captured in a hipGraph (GraphedInference)."""
     dev = conv_feat.device
     history, trajectory = [], []
+    clip32 = None
     for i in range(1, exec_iter + 1):
         chunks = args.NUM_CHUNKS[i]
         T_start = int((args.NUM_CHUNKS[args.max_iter] - chunks) / 2) * args.T
@@ -79,19 +83,31 @@ def inference_flat(args, conv_feat, context_feat, nets, exec_iter, flat, nums, c
         prob, local_loc, first_loc, last_loc, _, _, _ = nets["det_net%d" % (i - 1)](pooled, context_feat=ctx)
 
         pred_prob = prob.view(-1, 1, args.num_classes).expand(-1, T_length, -1)
+        mode = getattr(args, "temporal_mode", "predict")
+        extend = i < args.max_iter and args.NUM_CHUNKS[i + 1] == args.NUM_CHUNKS[i] + 2
+        if mode == "predict" and TUBE_KERNEL and first_loc is not None and last_loc is not None and flat.shape[1] == T_length:
+            # decode x3 -> cat -> valid_tubes -> frame-index column: one launch (step_tube_update) instead of ~60 element-wise ones
+            if clip32 is None:
+                clip32 = clip_of.to(torch.int32)
+            pred_loc, pred_first, pred_last, flat = ops.tube_update(
+                flat, local_loc, first_loc, last_loc, clip32, chunk_idx[0] - half_T, chunk_idx[-1] - half_T, extend,
+                args.image_size[0], args.image_size[1])
+            history.append({"pred_prob": pred_prob.detach(), "pred_loc": pred_loc, "pred_first_loc": pred_first,
+                            "pred_last_loc": pred_last, "tubes_nums": list(nums)})
+            trajectory.append((flat[:, :, 1:], torch.argmax(prob, dim=-1)))
+            continue
         flat = flat.to(local_loc)
         pred_loc = decode_coef(flat.reshape(-1, 5)[:, 1:], local_loc.reshape(-1, 4)).view(local_loc.shape)
         lo, hi = chunk_idx[0] - half_T, chunk_idx[0] + half_T + 1
         lo2, hi2 = chunk_idx[-1] - half_T, chunk_idx[-1] + half_T + 1
         pred_first = decode_coef(flat[:, lo:hi].reshape(-1, 5)[:, 1:], first_loc.reshape(-1, 4)).view(first_loc.shape)
         pred_last = decode_coef(flat[:, lo2:hi2].reshape(-1, 5)[:, 1:], last_loc.reshape(-1, 4)).view(last_loc.shape)
-        mode = getattr(args, "temporal_mode", "predict")
         history.append({"pred_prob": pred_prob.detach(), "pred_loc": pred_loc.detach(),            # utils.py:81-85 (.data)
                         "pred_first_loc": pred_first.detach() if mode == "predict" else None,
                         "pred_last_loc": pred_last.detach() if mode == "predict" else None, "tubes_nums": list(nums)})
 
         # next step's proposals (utils.py:91-129), all clips at once
-        if i < args.max_iter and args.NUM_CHUNKS[i + 1] == args.NUM_CHUNKS[i] + 2:
+        if extend:
             if mode == "predict":
                 prop = torch.cat([pred_first, pred_loc, pred_last], dim=1)
             elif mode == "extrapolate":

@@ -463,3 +463,25 @@ def nms_batched(boxes, scores, counts, threshold):
     _capi.check(L.step_nms_batched(_lib.dptr(boxes), _lib.dptr(scores), _lib.dptr(counts), G, kmax, float(threshold),
                                    _lib.dptr(keep), _lib.dptr(scratch), _lib.stream_ptr(boxes.device)), "step_nms_batched")
     return keep
+
+
+def tube_update(flat, local_loc, first_loc, last_loc, clip_of, first_off, last_off, extend, width, height):
+    """One refinement step's tube bookkeeping (step_tube_update): returns (pred_loc, pred_first, pred_last, next_flat)."""
+    L = _lib.lib()
+    N, T, _ = flat.shape
+    Tw = first_loc.shape[1]
+    f32 = lambda t: t.detach().float().contiguous()
+    flat, local_loc, first_loc, last_loc = f32(flat), f32(local_loc), f32(first_loc), f32(last_loc)
+    if clip_of.dtype != torch.int32:
+        clip_of = clip_of.to(torch.int32)
+    Tn = T + 2 * Tw if extend else T
+    dev = flat.device
+    pl = torch.empty((N, T, 4), dtype=torch.float32, device=dev)
+    pf = torch.empty((N, Tw, 4), dtype=torch.float32, device=dev)
+    pla = torch.empty((N, Tw, 4), dtype=torch.float32, device=dev)
+    nxt = torch.empty((N, Tn, 5), dtype=torch.float32, device=dev)
+    _capi.check(L.step_tube_update(_lib.dptr(flat), N, T, _lib.dptr(local_loc), _lib.dptr(first_loc), _lib.dptr(last_loc), Tw,
+                                   int(first_off), int(last_off), _lib.dptr(clip_of.contiguous()), int(bool(extend)), float(width),
+                                   float(height), _lib.dptr(pl), _lib.dptr(pf), _lib.dptr(pla), _lib.dptr(nxt),
+                                   _lib.stream_ptr(dev)), "step_tube_update")
+    return pl, pf, pla, nxt

@@ -709,7 +709,7 @@ def case_conv_units_two_phase_form(bk, golden):
              (2, 32, 64, 2, 6, 21, (1, 3, 3))]       # 2-D kernel (10 padded taps: an ODD number of steps per slab), general box
     cases = [c for c in CONV_CASES + extra if c[6] != (1, 1, 1)]
     try:
-        os.environ.pop("STEP_CONV_PHASED", None)
+        os.environ["STEP_CONV_PHASED"] = "0"
         classic = {}
         for case in cases:
             N, Cin, Cout, D, H, W, k = case
@@ -719,7 +719,7 @@ def case_conv_units_two_phase_form(bk, golden):
             scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32)
             shift = (0.2 * rs.randn(Cout)).astype(np.float32)
             classic[case] = (x, w, scale, shift, run_conv(bk, x, w, scale, shift, BF16, x_pad=(8, 8), y_pad=(16, 8)))
-        for ph in ("1", "2"):
+        for ph in ("1",):
             os.environ["STEP_CONV_PHASED"] = ph
             seen = 0
             for case in cases:
@@ -729,7 +729,7 @@ def case_conv_units_two_phase_form(bk, golden):
                                    y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
                 assert bk.lib.step_conv_kernel_name(ctypes.byref(d), buf, 256) == 0
                 name = buf.value.decode()
-                if "conv_tap_kernel" in name:
+                if "conv_tap_kernel" in name and k == (3, 3, 3):
                     assert name.endswith(", 2, 2, 8, %s>(step::ConvParams)" % ph), name
                     seen += 1
                 got = run_conv(bk, x, w, scale, shift, BF16, x_pad=(8, 8), y_pad=(16, 8))
@@ -746,6 +746,42 @@ def case_conv_units_two_phase_form(bk, golden):
                 os.environ.pop(key, None)
             else:
                 os.environ[key] = val
+
+
+def case_tube_update(bk, golden):
+    """step_tube_update (one refinement step's decode x3 -> cat -> valid_tubes -> frame-index column, utils/utils.py:68-129)
+    against the torch restatement in step_amd.tube_math, whose pieces are pinned bit for bit by tube_math_golden.npz."""
+    from step_amd import tube_math as TM
+    rs = np.random.RandomState(21)
+    for N, T, Tw, extend in ((7, 3, 3, 1), (5, 9, 3, 0), (4, 9, 3, 1), (1, 3, 3, 0)):
+        xy = rs.uniform(-30, 380, (N, T, 2))
+        boxes = np.concatenate([xy, xy + rs.uniform(-2, 160, (N, T, 2))], 2).astype(np.float32)       # some degenerate, some outside
+        tubes = np.concatenate([rs.uniform(0, 50, (N, T, 1)).astype(np.float32), boxes], 2)
+        loc = (rs.randn(N, T, 4) * 0.2).astype(np.float32)
+        floc, lloc = (rs.randn(N, Tw, 4) * 0.2).astype(np.float32), (rs.randn(N, Tw, 4) * 0.2).astype(np.float32)
+        clip_of = np.sort(rs.randint(0, 3, N)).astype(np.int32)
+        first_off, last_off = 0, T - Tw
+        Tn = T + 2 * Tw if extend else T
+        d = [bk.dev(a) for a in (tubes, loc, floc, lloc, clip_of)]
+        o = [bk.dev(np.full(sh, 7.0, np.float32)) for sh in ((N, T, 4), (N, Tw, 4), (N, Tw, 4), (N, Tn, 5))]
+        rc = bk.lib.step_tube_update(d[0].ptr, N, T, d[1].ptr, d[2].ptr, d[3].ptr, Tw, first_off, last_off, d[4].ptr, extend, 400.0, 400.0,
+                                     o[0].ptr, o[1].ptr, o[2].ptr, o[3].ptr, bk.stream)
+        assert rc == 0, rc
+        t = torch.from_numpy
+        pl = TM.decode_coef(t(boxes).reshape(-1, 4), t(loc).reshape(-1, 4)).view(N, T, 4)
+        pf = TM.decode_coef(t(boxes[:, first_off:first_off + Tw]).reshape(-1, 4), t(floc).reshape(-1, 4)).view(N, Tw, 4)
+        pla = TM.decode_coef(t(boxes[:, last_off:last_off + Tw]).reshape(-1, 4), t(lloc).reshape(-1, 4)).view(N, Tw, 4)
+        prop = TM.valid_tubes(torch.cat([pf, pl, pla], 1) if extend else pl, 400, 400)
+        idx = t(clip_of).float().view(N, 1, 1) * Tn + torch.arange(Tn, dtype=torch.float32).view(1, Tn, 1)
+        nxt = torch.cat([idx, prop], 2)
+        for got, ref, what in zip(o, (pl, pf, pla, nxt), ("pred_loc", "pred_first", "pred_last", "next")):
+            g, r = got.get(), ref.numpy()
+            assert g.shape == r.shape
+            # exp() is the only operation whose last bit may differ between libraries
+            assert np.abs(g - r).max() <= 2e-6 * max(1.0, np.abs(r).max()), (what, N, T, extend, float(np.abs(g - r).max()))
+        assert np.array_equal(o[3].get()[..., 0], nxt.numpy()[..., 0])
+    assert bk.lib.step_tube_update(None, 0, 3, None, None, None, 3, 0, 0, None, 1, 400.0, 400.0, None, None, None, None, bk.stream) == 0
+    assert bk.lib.step_tube_update(None, 2, 3, None, None, None, 4, 0, 0, None, 1, 400.0, 400.0, None, None, None, None, bk.stream) == -2
 
 
 def case_conv_residual_norelu_f16_and_bias_only(bk, golden):

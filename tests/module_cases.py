@@ -41,6 +41,18 @@ def np_(t):
     return t.detach().float().cpu().contiguous().numpy()
 
 
+def record(name, value):
+    """Keep a measured error level next to the GPU run's other outputs (gpurun_out/test_metrics.json; ignored elsewhere)."""
+    import json
+    d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ""), "gpurun_out")
+    if not os.environ.get("GRAFT_REPO_ROOT") or not os.path.isdir(d):
+        return
+    f = os.path.join(d, "test_metrics.json")
+    m = json.load(open(f)) if os.path.exists(f) else {}
+    m[name] = value
+    json.dump(m, open(f, "w"), indent=1, sort_keys=True)
+
+
 def case_state_dict_contract(dev, golden):
     info = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
     nets = {"BaseNet": step_amd.BaseNet(cfg()), "ContextNet": step_amd.ContextNet(cfg()),
@@ -97,11 +109,13 @@ def case_basenet_c1_16bit_error(dev, golden):
     g = golden("i3d_c1_golden")
     net = fill(step_amd.BaseNet(cfg())).to(dev).eval()
     x = R.fill_tensor("golden.c1.images", (1, 8, 3, 112, 112), "image").to(dev)
-    for dt, bound in ((torch.bfloat16, 2e-2), (torch.float16, 4e-3)):
+    # measured on MI355X: bf16 5.0e-3 (BENCH_r01 smoke line), fp16 below 1e-3; the bounds sit just above the measured level
+    for dt, bound in ((torch.bfloat16, 8e-3), (torch.float16, 2e-3)):
         with torch.no_grad():
             y = net(x.to(dt))
         assert y.dtype == dt
         e = rel(np_(y), g["conv_feat"])
+        record("basenet_c1_rel_err_%s" % str(dt).split(".")[-1], e)
         assert e < bound, (dt, e)
 
 
@@ -718,7 +732,27 @@ def case_c2_full_size_properties(dev, golden):
         assert torch.equal(yp, y8[perm])
         yf = net(x[3:4])
         e = rel(np_(y1), np_(yf))
-        assert e < 2e-2, e
+        record("c2_full_size_bf16_vs_fp32", e)
+        assert e < 1e-2, e
+
+
+def case_c5_full_size_properties(dev, golden):
+    """BASELINE C5 at one GPU's share (4 x [64,3,400,400], fp16) -- the long-clip stress shape, too big for the oracle:
+    clip independence (a clip alone == the clip inside the batch of 4, BIT-EXACT, although the planner tiles the two
+    launches differently), finite outputs of the right shape, and the fp16 run within the 16-bit bound of the fp32 run."""
+    net = fill(step_amd.BaseNet(cfg())).to(dev).eval()
+    g = torch.Generator().manual_seed(321)
+    x = (torch.rand(4, 64, 3, 400, 400, generator=g) * 2 - 1).to(dev)
+    xh = x.to(torch.float16)
+    with torch.no_grad():
+        y4 = net(xh).clone()
+        assert tuple(y4.shape) == (4, 16, 832, 25, 25) and y4.dtype == torch.float16 and bool(torch.isfinite(y4.float()).all())
+        y1 = net(xh[2:3]).clone()
+        assert torch.equal(y4[2:3], y1), float((y4[2:3].float() - y1.float()).abs().max())
+        yf = net(x[2:3])
+        e = rel(np_(y1), np_(yf))
+        record("c5_full_size_fp16_vs_fp32", e)
+        assert e < 4e-3, e
 
 
 CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_golden", "case_context_golden",
@@ -726,4 +760,4 @@ CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_g
              "case_flat_adam_matches_torch", "case_wgrad_into_and_targets", "case_twobranch_variants_golden",
              "case_reg_unit_pack_follows_weight_updates", "case_basenet_backward_matches_oracle_autograd",
              "case_contextnet_backward_matches_oracle_autograd", "case_postprocess_golden"]
-GPU_CASES = CPU_CASES + ["case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_i3d_classifier_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
+GPU_CASES = CPU_CASES + ["case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_c5_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_i3d_classifier_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]

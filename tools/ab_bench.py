@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--set", default="c2")
     ap.add_argument("--only", default="")
+    ap.add_argument("--custom", action="append", default=[], help="name,Cin,Cout,k,D,H,W (repeatable; replaces the layer set)")
+    ap.add_argument("--nocheck", action="store_true", help="variants may compute different things (timing experiments)")
     ap.add_argument("--var", action="append", default=[], help="KEY=VAL[,KEY=VAL] environment of one variant (repeatable)")
     a = ap.parse_args()
     if a.set == "b3":
@@ -113,6 +115,11 @@ def main():
     st = _lib.stream_ptr()
     B = a.batch
     layers = C2 if a.set == "c2" else C3
+    if a.custom:
+        layers = []
+        for c in a.custom:
+            f = c.split(",")
+            layers.append((f[0],) + tuple(int(v) for v in f[1:]))
     only = set(x for x in a.only.split(",") if x)
     tot = [0.0] * len(variants)
     print("%-8s %s" % ("layer", "  ".join("%28s" % v for v in variants)))
@@ -153,7 +160,7 @@ def main():
                 ref = y.float().clone()
             else:
                 err = float((y.float() - ref).abs().max() / ref.abs().max().clamp_min(1e-20))
-                assert err < 2e-2, (name, v, err)            # every variant computes the same layer
+                assert a.nocheck or err < 2e-2, (name, v, err)            # every variant computes the same layer
         for _ in range(a.rounds):
             for vi, v in enumerate(variants):
                 setenv(v)
