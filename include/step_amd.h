@@ -190,6 +190,12 @@ STEP_API int step_pool3_conv1_kernel_name(const step_conv_desc* d, char* buf, in
 STEP_API int step_conv_wgrad(const step_conv_desc* d, const void* x, const float* dy, float* dw, int accumulate,
                              step_stream_t stream);
 
+/* The same weight gradient on the 16-bit matrix instructions (mixed-precision training): dy arrives in the activation type
+ * d->dtype (STEP_BF16 / STEP_F16; STEP_F32 -> STEP_E_UNSUPPORTED), laid out as above; products in 16 bits, fp32 accumulation,
+ * fp32 dw.  16x the matrix rate of step_conv_wgrad (whose fp32 instruction runs at 1/16 of the 16-bit one). */
+STEP_API int step_conv_wgrad16(const step_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
+                               step_stream_t stream);
+
 /* Diagnostic: the name (as rocprofv3 prints it) of the kernel instantiation step_conv_forward launches
  * for this descriptor -- lets bench.py attribute time and algorithmic work to profiler rows. */
 STEP_API int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen);

@@ -78,9 +78,21 @@ class _ConvUnitFn(torch.autograd.Function):
             # frozen affine, no residual (every backbone / Inception unit): only the conv's own gradients are wanted, so the
             # cast / ReLU mask / scale / cast chain is ONE HIP pass producing the wgrad operand (fp32) and the dgrad operand
             # (a residual input without an affine -- the Bottlenecks' third conv -- receives the same masked gradient as the conv)
-            fused = ops.act_grad(y, gy, scale, ctx.relu, want_f32=need_w, want_act=need_x or need_res) if (need_x or need_w or need_res) else (None, None)
+            # 16-bit activations: the weight gradient runs on the 16-bit matrix instructions too (step_conv_wgrad16: 16x the
+            # fp32 instruction's rate), reading the SAME 16-bit activation gradient as the data-gradient conv -- what
+            # mixed-precision training back-propagates; no fp32 copy of the gradient is written
+            w16 = WGRAD16 and need_w and x.dtype != torch.float32 and y.dtype == x.dtype
+            fused = ops.act_grad(y, gy, scale, ctx.relu, want_f32=need_w and not w16, want_act=need_x or need_res or w16) \
+                if (need_x or need_w or need_res) else (None, None)
             if fused is not None:
                 g32, gact = fused
+                if w16:
+                    g32 = gact
+
+                    def wgrad(x_, g_, cout_, k_, into=None):
+                        return ops.conv_wgrad16(x_, g_, cout_, k_, into=into)
+                else:
+                    wgrad = ops.conv_wgrad
                 target = _wgrad_target(ctx.unit, w_eff) if (need_w and WGRAD_INTO_GRAD and x.is_cuda and ops.PROFILE is None) else None
                 if target is not None:
                     # opt-in (wgrad_into_grad()): the weight gradient is ACCUMULATED straight into the parameter's .grad (the
@@ -91,9 +103,16 @@ class _ConvUnitFn(torch.autograd.Function):
                     side = _side_streams(x.device)[0]
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
-                        ops.conv_wgrad(x, g32, w_eff.shape[0], k, into=target)
+                        wgrad(x, g32, w_eff.shape[0], k, into=target)
                     x.record_stream(side)
                     g32.record_stream(side)
+                    if need_res and g32 is gact:
+                        # the side stream is still READING this buffer while it is handed to autograd as the residual's
+                        # gradient: with a use count of one autograd would accumulate the other branch's gradient into it
+                        # IN PLACE on the main stream (input_buffer.cpp) -- a write/read race that perturbed the Bottleneck
+                        # conv3 weight gradients by ~1 % (found by tests/test_gpu_ddp.py).  A second reference makes autograd
+                        # add out of place; the list is dropped in wgrad_sync().
+                        _KEEP.append(gact)
                     _PENDING[0] = True
                     if GRAD_READY is not None:                   # this parameter bypasses autograd's accumulate hook
                         GRAD_READY(ctx.unit.weight_fn(), side)
@@ -108,13 +127,13 @@ class _ConvUnitFn(torch.autograd.Function):
                     side = _side_streams(x.device)[0]
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
-                        gw = ops.conv_wgrad(x, g32, w_eff.shape[0], k).to(w_eff.dtype)
+                        gw = wgrad(x, g32, w_eff.shape[0], k).to(w_eff.dtype)
                     gx = _ConvUnitFn._dgrad(gact, w_eff, x.dtype, k)
                     main.wait_stream(side)
                     gw.record_stream(main)
                     return gx, gw, None, None, (gact if need_res else None), None, None
                 gx = _ConvUnitFn._dgrad(gact, w_eff, x.dtype, k) if need_x else None
-                gw = ops.conv_wgrad(x, g32, w_eff.shape[0], k).to(w_eff.dtype) if need_w else None
+                gw = wgrad(x, g32, w_eff.shape[0], k).to(w_eff.dtype) if need_w else None
                 return gx, gw, None, None, (gact if need_res else None), None, None
         g = gy.float()
         if ctx.relu:
@@ -461,9 +480,11 @@ class Mixed(nn.Module):
         return p
 
 
+WGRAD16 = os.environ.get("STEP_WGRAD16", "1") != "0"   # 16-bit activations: weight gradients on the 16-bit MFMA (step_conv_wgrad16)
 WGRAD_INTO_GRAD = False        # see wgrad_into_grad()
 GRAD_READY = None              # step_amd.dist.BucketedReducer.ready while a backward pass is being overlapped with the exchange
 _PENDING = [False]
+_KEEP = []                     # tensors the side stream reads that autograd must not modify in place (until wgrad_sync())
 
 
 def _wgrad_target(unit, w_eff):
@@ -502,6 +523,7 @@ def wgrad_sync():
         for dev_key, streams in list(_SIDE.items()):
             torch.cuda.current_stream(torch.device(dev_key[0], dev_key[1])).wait_stream(streams[0])
         _PENDING[0] = False
+    del _KEEP[:]
 
 
 # branch_3 of an Inception block as one launch (step_pool3_conv1_forward).  Off by default: measured on MI355X (C2, bf16,

@@ -16,7 +16,7 @@ namespace step {
 //   wavefront job = one (n, d) plane (or one chunk of pixels of a pointwise layer) x one tap x one
 //   (32*MB x 32*NB) tile of (co, ci); no barriers, four independent wavefronts per workgroup.
 struct WgradParams {
-    const void* x; const float* dy; float* dw;
+    const void* x; const void* dy; float* dw;      // dy: fp32, or the activation type in the 16-bit-MFMA form (W16)
     int N, D, H, W, Cin, Cout, kd, kh, kw;
     int x_cstride, x_coff, dy_cstride, dy_coff;
     int cot, cit;                 // tiles along Cout / Cin
@@ -25,8 +25,15 @@ struct WgradParams {
     long long jobs;               // ceil(total_rows / rows)
 };
 
-template <typename T, int MB, int NB>
+// W16 (16-bit storage only): dY arrives in the activation type too (what mixed-precision training back-propagates) and the
+// products run on v_mfma_f32_32x32x16_{bf16,f16} -- 16x the fp32 instruction's rate -- with fp32 accumulation; the eight
+// k values of a lane's fragment are still eight plain 2-byte loads of one channel at consecutive pixels (coalesced over the
+// 32 lanes of a row block: 64-byte runs), packed pairwise by the loads themselves.  Same jobs, same atomics.
+template <typename T, int MB, int NB, bool W16 = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+    static_assert(!W16 || sizeof(T) == 2, "the 16-bit-MFMA form needs 16-bit activations");
+    typedef typename std::conditional<W16, T, float>::type DY;
+    typedef typename std::conditional<W16, u16x8, f32x8>::type opfrag;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, khalf = lane >> 5;
     const long long job = (long long)blockIdx.x * 4 + wave;
     if (job >= p.jobs) return;                               // wave-uniform; the kernel has no barrier
@@ -60,10 +67,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
         const int n = (int)(plane / p.D), d = (int)(plane % p.D);
         const int id = d + kd_ - p.kd / 2, ih = h + kh_ - p.kh / 2;
         if (id < 0 || id >= p.D || ih < 0 || ih >= p.H) continue;        // this tap sees only zero padding from this row
-        const float* dyrow = p.dy + ((((size_t)n * p.D + d) * p.H + h) * p.W) * p.dy_cstride + p.dy_coff;
+        const DY* dyrow = (const DY*)p.dy + ((((size_t)n * p.D + d) * p.H + h) * p.W) * p.dy_cstride + p.dy_coff;
         const T* xrow = (const T*)p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W) * p.x_cstride + p.x_coff;
         for (int w0 = 0; w0 < p.W; w0 += 16) {
-            f32x8 a[MB], b[NB];
+            opfrag a[MB], b[NB];
+            auto ld_a = [&](size_t off) { if constexpr (W16) return dyrow[off].v; else return dyrow[off]; };
+            auto ld_b = [&](size_t off) { if constexpr (W16) return xrow[off].v; else return elem<T>::to_f32(xrow[off]); };
             // Channel masks are not needed: rows / columns of a ragged (co, ci) tile read a clamped channel and their
             // accumulators are never stored.  Pixel masks matter only on the first / last step of a row.
             const int sh = kw_ - p.kw / 2;
@@ -72,9 +81,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
                 for (int j = 0; j < 8; ++j) {
                     const int w = w0 + 8 * khalf + j;
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) a[mb][j] = dyrow[(size_t)w * p.dy_cstride + coc[mb]];
+                    for (int mb = 0; mb < MB; ++mb) a[mb][j] = ld_a((size_t)w * p.dy_cstride + coc[mb]);
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) b[nb][j] = elem<T>::to_f32(xrow[(size_t)(w + sh) * p.x_cstride + cic[nb]]);
+                    for (int nb = 0; nb < NB; ++nb) b[nb][j] = ld_b((size_t)(w + sh) * p.x_cstride + cic[nb]);
                 }
             } else {
 #pragma unroll
@@ -84,20 +93,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
                     const int wc = aok ? w : p.W - 1, iwc = bok ? iw : 0;
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb) {
-                        const float v = dyrow[(size_t)wc * p.dy_cstride + coc[mb]];
-                        a[mb][j] = aok ? v : 0.f;
+                        const auto v = ld_a((size_t)wc * p.dy_cstride + coc[mb]);
+                        a[mb][j] = aok ? v : (decltype(v))0;
                     }
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
-                        const float v = elem<T>::to_f32(xrow[(size_t)iwc * p.x_cstride + cic[nb]]);
-                        b[nb][j] = bok ? v : 0.f;
+                        const auto v = ld_b((size_t)iwc * p.x_cstride + cic[nb]);
+                        b[nb][j] = bok ? v : (decltype(v))0;
                     }
                 }
             }
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) mma_k16(a[mb], b[nb], acc[mb][nb], float());
+                for (int nb = 0; nb < NB; ++nb) mma_k16(a[mb], b[nb], acc[mb][nb], typename std::conditional<W16, T, float>::type());
         }
     }
 #pragma unroll
@@ -214,8 +223,9 @@ static int wgrad_min_pixels() {
     return x > 0 ? (x + 15) / 16 * 16 : 512;
 }
 
-int step_conv_wgrad(const step_conv_desc* d, const void* x, const float* dy, float* dw, int accumulate, step_stream_t stream) {
+static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* dy, bool w16, float* dw, int accumulate, step_stream_t stream) {
     if (!d) return STEP_E_NULL;
+    if (w16 && d->dtype != STEP_BF16 && d->dtype != STEP_F16) return STEP_E_UNSUPPORTED;
     if (d->N < 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return STEP_E_SHAPE;
     if (d->kd <= 0 || d->kh <= 0 || d->kw <= 0 || !(d->kd & 1) || !(d->kh & 1) || !(d->kw & 1)) return STEP_E_UNSUPPORTED;
     if (d->x_coff < 0 || d->x_coff + d->Cin > d->x_cstride || d->y_coff < 0 || d->y_coff + d->Cout > d->y_cstride) return STEP_E_SHAPE;
@@ -251,16 +261,18 @@ int step_conv_wgrad(const step_conv_desc* d, const void* x, const float* dy, flo
         auto launch = [&](long long jobs, int W, size_t pix0) {
             p.N = 1; p.D = (int)jobs; p.H = 1; p.W = W; p.jobs = jobs; p.rows = 1; p.total_rows = jobs;
             p.x = (const char*)x + pix0 * d->x_cstride * (d->dtype == STEP_F32 ? 4 : 2);
-            p.dy = dy + pix0 * d->y_cstride;
+            p.dy = (const char*)dy + pix0 * d->y_cstride * (w16 ? 2 : 4);
             const bool narrow = d->Cin <= 32;
             p.cot = ceil_div(d->Cout, 64); p.cit = ceil_div(d->Cin, narrow ? 32 : 64);
             dim3 grid((unsigned)ceil_div64(jobs, 4), (unsigned)(p.cot * p.cit));
 #define STEP_WG(T_) do { if (narrow) STEP_LAUNCH((conv_wgrad_kernel<T_, 2, 1>), grid, dim3(256), stream, p); \
                          else STEP_LAUNCH((conv_wgrad_kernel<T_, 2, 2>), grid, dim3(256), stream, p); } while (0)
+#define STEP_WG16(T_) do { if (narrow) STEP_LAUNCH((conv_wgrad_kernel<T_, 2, 1, true>), grid, dim3(256), stream, p); \
+                           else STEP_LAUNCH((conv_wgrad_kernel<T_, 2, 2, true>), grid, dim3(256), stream, p); } while (0)
             switch (d->dtype) {
                 case STEP_F32: STEP_WG(float); break;
-                case STEP_BF16: STEP_WG(bf16_t); break;
-                case STEP_F16: STEP_WG(f16_t); break;
+                case STEP_BF16: if (w16) STEP_WG16(bf16_t); else STEP_WG(bf16_t); break;
+                case STEP_F16: if (w16) STEP_WG16(f16_t); else STEP_WG(f16_t); break;
                 default: rc = STEP_E_DTYPE;
             }
         };
@@ -293,12 +305,21 @@ int step_conv_wgrad(const step_conv_desc* d, const void* x, const float* dy, flo
     dim3 grid((unsigned)ceil_div64(p.jobs, 4), (unsigned)gy);
     switch (d->dtype) {
         case STEP_F32: STEP_WG(float); break;
-        case STEP_BF16: STEP_WG(bf16_t); break;
-        case STEP_F16: STEP_WG(f16_t); break;
+        case STEP_BF16: if (w16) STEP_WG16(bf16_t); else STEP_WG(bf16_t); break;
+        case STEP_F16: if (w16) STEP_WG16(f16_t); else STEP_WG(f16_t); break;
         default: return STEP_E_DTYPE;
     }
 #undef STEP_WG
+#undef STEP_WG16
     return STEP_LAUNCH_CHECK();
+}
+
+int step_conv_wgrad(const step_conv_desc* d, const void* x, const float* dy, float* dw, int accumulate, step_stream_t stream) {
+    return conv_wgrad_impl(d, x, dy, false, dw, accumulate, stream);
+}
+
+int step_conv_wgrad16(const step_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, step_stream_t stream) {
+    return conv_wgrad_impl(d, x, dy, true, dw, accumulate, stream);
 }
 
 

@@ -190,12 +190,42 @@ def conv_wgrad(x, gy, Cout, k, into=None):
     if PROFILE is not None:
         pix = N * D * H * W
         # algorithmic: x and dy read once, dw written once (fp32); the kernel variant is chosen by Cin inside the library
-        prof = _Prof("void step::conv_wgrad_kernel<%s, 2, %d>(step::WgradParams)" % (_TNAME[x.dtype], 1 if Cin <= 32 else 2),
+        prof = _Prof("void step::conv_wgrad_kernel<%s, 2, %d, false>(step::WgradParams)" % (_TNAME[x.dtype], 1 if Cin <= 32 else 2),
                      2.0 * pix * Cout * Cin * k[0] * k[1] * k[2],
                      pix * (Cin * x.element_size() + Cout * 4) + 4.0 * Cout * Cin * k[0] * k[1] * k[2])
     with prof:
         _capi.check(L.step_conv_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(dw), int(into is not None),
                                       _lib.stream_ptr(x.device)), "step_conv_wgrad")
+    return dw
+
+
+def conv_wgrad16(x, gy, Cout, k, into=None):
+    """conv_wgrad on the 16-bit matrix instructions: x and gy both in the 16-bit activation dtype (gy dense channels-last
+    [N,D,H,W,Cout]); fp32 result / accumulation as conv_wgrad."""
+    L = _lib.lib()
+    N, D, H, W, Cin = x.shape
+    if gy.dtype != x.dtype or x.dtype == torch.float32:
+        raise RuntimeError("step_amd: conv_wgrad16 wants x and gy in the same 16-bit dtype")
+    if not gy.is_contiguous():
+        gy = gy.contiguous()
+    if into is not None:
+        if into.dtype != torch.float32 or not into.is_contiguous() or into.numel() != Cout * Cin * k[0] * k[1] * k[2]:
+            raise RuntimeError("step_amd: conv_wgrad16(into=...) wants a dense fp32 tensor of Cout*Cin*taps elements")
+        dw = into
+    else:
+        dw = torch.empty((Cout, Cin) + tuple(k), dtype=torch.float32, device=x.device)
+    d = _capi.ConvDesc(dtype=_dt(x), N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2],
+                       x_cstride=_chan_slice(x), x_coff=0, y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=0,
+                       split=0, y2_cstride=0, y2_coff=0)
+    prof = _NOPROF
+    if PROFILE is not None:
+        pix = N * D * H * W
+        prof = _Prof("void step::conv_wgrad_kernel<%s, 2, %d, true>(step::WgradParams)" % (_TNAME[x.dtype], 1 if Cin <= 32 else 2),
+                     2.0 * pix * Cout * Cin * k[0] * k[1] * k[2],
+                     pix * (Cin + Cout) * x.element_size() + 4.0 * Cout * Cin * k[0] * k[1] * k[2])
+    with prof:
+        _capi.check(L.step_conv_wgrad16(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(dw), int(into is not None),
+                                        _lib.stream_ptr(x.device)), "step_conv_wgrad16")
     return dw
 
 

@@ -890,6 +890,50 @@ def case_conv_wgrad(bk, golden):
     assert bk.lib.step_conv_wgrad(ctypes.byref(d), None, None, None, 0, bk.stream) < 0     # even kernels: unsupported / null
 
 
+def case_conv_wgrad16(bk, golden):
+    """step_conv_wgrad16 (weight gradient on the 16-bit matrix instructions: x AND dy in bf16 / fp16, fp32 accumulation)
+    against torch autograd on identically quantised operands: 16-bit x 16-bit products are exact in fp32, so only the summation
+    order differs (2e-5)."""
+    rs = np.random.RandomState(35)
+    cases = [(2, 24, 40, 3, 5, 19, (3, 3, 3)), (1, 72, 100, 2, 6, 7, (1, 3, 3)), (1, 40, 70, 1, 9, 130, (1, 1, 1))]
+    saved = os.environ.get("STEP_WGRAD_MINPIX")
+    try:
+        for minpix in ("64", None):
+            if minpix is None:
+                os.environ.pop("STEP_WGRAD_MINPIX", None)
+            else:
+                os.environ["STEP_WGRAD_MINPIX"] = minpix
+            for (N, Cin, Cout, D, H, W, k) in cases:
+                x = rs.randn(N, Cin, D, H, W).astype(np.float32)
+                gy = rs.randn(N, Cout, D, H, W).astype(np.float32)
+                for dt in (BF16, F16):
+                    w = torch.zeros(Cout, Cin, *k, requires_grad=True)
+                    F.conv3d(torch.from_numpy(quantize(x, dt)), w, padding=tuple(kk // 2 for kk in k)).backward(torch.from_numpy(quantize(gy, dt)))
+                    ref = w.grad.numpy()
+                    xpad = np.zeros((N, D, H, W, 8 + Cin), np.float32)
+                    xpad[..., 8:] = cl(x)
+                    xpad[..., :8] = 1e4
+                    xd = bk.dev(encode(xpad, dt))
+                    gd = bk.dev(encode(cl(gy), dt))
+                    dw = bk.dev(np.full((Cout, Cin) + k, 7.0, np.float32))
+                    d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2], x_cstride=8 + Cin, x_coff=8,
+                                       y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)
+                    assert bk.lib.step_conv_wgrad16(ctypes.byref(d), xd.ptr, gd.ptr, dw.ptr, 0, bk.stream) == 0
+                    err = np.abs(dw.get() - ref).max() / np.abs(ref).max()
+                    assert err < 2e-5, (N, Cin, Cout, k, dt, minpix, err)
+                    assert bk.lib.step_conv_wgrad16(ctypes.byref(d), xd.ptr, gd.ptr, dw.ptr, 1, bk.stream) == 0
+                    assert np.abs(dw.get() - 2 * ref).max() / np.abs(ref).max() < 4e-5
+    finally:
+        if saved is None:
+            os.environ.pop("STEP_WGRAD_MINPIX", None)
+        else:
+            os.environ["STEP_WGRAD_MINPIX"] = saved
+    d = _capi.ConvDesc(dtype=F32, N=1, D=1, H=4, W=4, Cin=8, Cout=8, kd=1, kh=1, kw=1, x_cstride=8, x_coff=0, y_cstride=8, y_coff=0,
+                       res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)
+    z = bk.dev(np.zeros(64, np.float32))
+    assert bk.lib.step_conv_wgrad16(ctypes.byref(d), z.ptr, z.ptr, z.ptr, 0, bk.stream) == -4       # fp32 storage: unsupported
+
+
 def case_stem_wgrad(bk, golden):
     rs = np.random.RandomState(44)
     N, T, H, W, Cout = 1, 6, 21, 70, 40                     # Ho = 10 (two row chunks), Wo = 35 (edge, interior and edge steps); Cout not a multiple of 32

@@ -70,6 +70,12 @@ def _worker(rank, world, port, q):
     worst = [(names.get(id(w.opt._entries[i][1]), "?"), w.reducer.bucket_of[id(w.opt._entries[i][1])], int(w.opt._entries[i][3]),
               float(rel_t[i]), float(norms[i])) for i in np.argsort(-rel_t)[:6]]
     if rank == 0:
+        import json, os
+        d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ""), "gpurun_out")
+        if os.environ.get("GRAFT_REPO_ROOT") and os.path.isdir(d):
+            full = [(names.get(id(w.opt._entries[i][1]), "?"), w.reducer.bucket_of[id(w.opt._entries[i][1])], int(w.opt._entries[i][3]),
+                     float(rel_t[i]), float(norms[i]), float(norms_b[i])) for i in np.argsort(-rel_t)[:24]]
+            json.dump({"worst": full, "buckets": w.reducer.buckets, "during": during}, open(os.path.join(d, "ddp_worst.json"), "w"), indent=1)
         q.put((sample, norms, float(lsum) / world, f, p0, sample_b, norms_b, during, nb, w.scale, noise, noise_t, worst))
     else:
         q.put(("p", p0))

@@ -3,8 +3,16 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -k "two_phase or conv_units or big_conv" > $O/gputests.log 2>&1; echo "rc=$?" >> $O/gputests.log
-L3="2c_3x3,3b_b1b,3b_b2b,3c_b1b,3c_b2b,4b_b1b,4c_b1b,4d_b1b,4e_b1b,4f_b1b,4f_b2b"
-timeout 600 python tools/ab_bench.py --rounds 5 --iters 10 --only $L3 --var "STEP_CONV_PHASED=" --var "STEP_CONV_PHASED=1" > $O/ab_phased.log 2>&1
-STEP_CONV_PHASED=1 timeout 300 python bench.py --steps 50 --warmup 10 > $O/bench_c2_ph1.json 2> $O/bench_c2_ph1.err
-tail -3 $O/gputests.log; cat $O/ab_phased.log | tail -14; cut -c1-120 $O/bench_c2_ph1.json
+timeout 600 python -m pytest tests/test_gpu_ddp.py -m gpu -q > $O/gputests_ddp.log 2>&1; echo "rc=$?" >> $O/gputests_ddp.log
+cd /tmp; export TMPDIR=/tmp
+prof() { # name, args...
+  n=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$n -- python $R/bench.py "$@" --no-cpu-baseline > $O/bench_${n}_prof.json 2> $O/bench_${n}_prof.err
+  python $R/tools/prof_summary.py $O/prof_$n $O/prof_${n}_summary.txt > /dev/null 2>&1
+  find $O/prof_$n -type f ! -name "*kernel_stats*" -delete 2>/dev/null
+}
+prof c2 --steps 50 --warmup 5
+prof c4_bf16 --config c4 --dtype bf16 --steps 10 --warmup 3
+prof c3 --config c3 --steps 20 --warmup 5
+cd $R
+tail -4 $O/gputests_ddp.log; head -24 $O/prof_c4_bf16_summary.txt | cut -c1-200
