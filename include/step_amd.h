@@ -196,6 +196,14 @@ STEP_API int step_conv_wgrad(const step_conv_desc* d, const void* x, const float
 STEP_API int step_conv_wgrad16(const step_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
                                step_stream_t stream);
 
+/* Same, with a caller-owned scratch buffer: 3x3 windows (kh = kw = 3) run as an LDS-tiled GEMM whose workgroups write their
+ * partial tiles to `ws` (step_conv_wgrad16_workspace_bytes(d) bytes, 16-byte aligned, no initialisation needed) and a second
+ * kernel sums them in a fixed order -- no atomics, bit-reproducible.  ws = NULL, a buffer that is too small or any other window:
+ * step_conv_wgrad16.  The library never allocates: the caller owns ws. */
+STEP_API size_t step_conv_wgrad16_workspace_bytes(const step_conv_desc* d);
+STEP_API int step_conv_wgrad16_ws(const step_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* ws,
+                                  size_t ws_bytes, step_stream_t stream);
+
 /* Diagnostic: the name (as rocprofv3 prints it) of the kernel instantiation step_conv_forward launches
  * for this descriptor -- lets bench.py attribute time and algorithmic work to profiler rows. */
 STEP_API int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen);

@@ -134,6 +134,53 @@ __device__ inline void mma_k16(const u16x8& a, const u16x8& b, f32x16& c, f16_t)
 }
 #endif
 
+// ---- 16x16 MFMA "k32 step" + the LDS transpose read that feeds it (weight-gradient kernels: the reduction axis is the PIXEL
+// axis of channels-last tensors).  D(16x16) += A(16x32) * B(32x16); lane l holds, for row / col (l & 15), the eight k values
+// 8 * (l >> 4) + {0..7}.  C/D: col = l & 15, row = 4 * (l >> 4) + reg.
+//   lds_tr8: ds_read_b64_tr_b16 x 2.  The 16 lanes of group g = l >> 4 each read 8 bytes of a PIXEL-major LDS image and
+//   the hardware transposes the 4 x 16 block inside the group: lane 4 r + q supplies (pixel r of the block, channels
+//   4 q .. 4 q + 3), lane i receives channel i of pixels 0..3 (measured, tools/ubench/tr_read.hip).  a0 / a1: THIS lane's
+//   addresses for block pixels 0-3 and 4-7, i.e. the address of pixel (r = (l & 15) >> 2) of each half plus (l & 3) * 8 --
+//   the pixels of a block need not be equidistant in LDS (a halo tile's rows are skewed against the output pixel order).
+#ifndef STEP_EMUL
+typedef short i16x4_hw __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u16x8 lds_tr8(const unsigned char* a0, const unsigned char* a1) {
+    typedef __attribute__((address_space(3))) i16x4_hw* lptr;
+    const i16x4_hw lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(const __attribute__((address_space(3))) unsigned char*)a0);
+    const i16x4_hw hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(const __attribute__((address_space(3))) unsigned char*)a1);
+    u16x8 r = {(unsigned short)lo[0], (unsigned short)lo[1], (unsigned short)lo[2], (unsigned short)lo[3],
+               (unsigned short)hi[0], (unsigned short)hi[1], (unsigned short)hi[2], (unsigned short)hi[3]};
+    return r;
+}
+__device__ __forceinline__ void mma16_k32(const u16x8& a, const u16x8& b, f32x4& c, bf16_t) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16_k32(const u16x8& a, const u16x8& b, f32x4& c, f16_t) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_hw, a), __builtin_bit_cast(f16x8_hw, b), c, 0, 0, 0);
+}
+#else
+__device__ inline u16x8 lds_tr8(const unsigned char* a0, const unsigned char* a1) {
+    u16x8 r;
+    for (int h = 0; h < 2; ++h) {
+        unsigned short mine[4], out[4];
+        __builtin_memcpy(mine, h ? a1 : a0, 8);
+        hipemu::tr16_b64(mine, out);
+        for (int j = 0; j < 4; ++j) r[h * 4 + j] = out[j];
+    }
+    return r;
+}
+__device__ inline void mma16_k32(const u16x8& a, const u16x8& b, f32x4& c, bf16_t) {
+    float fa[8], fb[8];
+    for (int j = 0; j < 8; ++j) { fa[j] = bf16_bits_to_f32(a[j]); fb[j] = bf16_bits_to_f32(b[j]); }
+    hipemu::mfma_16x16_k32(fa, fb, c);
+}
+__device__ inline void mma16_k32(const u16x8& a, const u16x8& b, f32x4& c, f16_t) {
+    float fa[8], fb[8];
+    for (int j = 0; j < 8; ++j) { fa[j] = f16_bits_to_f32(a[j]); fb[j] = f16_bits_to_f32(b[j]); }
+    hipemu::mfma_16x16_k32(fa, fb, c);
+}
+#endif
+
 // ---- LDS-DMA: each lane copies 16 B from its own global address to  lds_base + lane*16 ----------
 // (global_load_lds_dwordx4: the LDS destination is the wave-uniform base + lane x 16, the data never
 // passes through VGPRs; completion is tracked by vmcnt -- a following __syncthreads() drains it.)

@@ -120,6 +120,320 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
             }
 }
 
+// conv_wgrad16_row_kernel -- the 16-bit-MFMA weight gradient for kw = 3 windows (3x3x3 and 1x3x3).  The per-tap form
+// above is bound by its LOAD instructions once the matrix work is 16x cheaper (8 two-byte loads per fragment: 8 loads per
+// MFMA); here a wavefront job owns a whole ROW of taps (kd, kh, kw = 0..2) of its (co, ci) tile:
+//   * the dY fragments of a 16-pixel step are loaded once and used by the three taps;
+//   * per input-channel block the lane loads the TEN consecutive pixels w-1 .. w+8 of its channel once; the three shifted
+//     fragments are re-pairings of those ten values in registers (taps kw = 0 and 2 share the even pairing, kw = 1 takes
+//     one byte-align per pair)
+// -- 3 loads per MFMA instead of 8, and a third of the jobs / atomics passes per tile.  Accumulators: 3 taps x MB x NB tiles.
+template <typename T, int MB, int NB>
+__global__ __launch_bounds__(256) void conv_wgrad16_row_kernel(WgradParams p) {
+    static_assert(sizeof(T) == 2, "16-bit storage");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, khalf = lane >> 5;
+    const long long job = (long long)blockIdx.x * 4 + wave;
+    if (job >= p.jobs) return;                               // wave-uniform; the kernel has no barrier
+    int t = blockIdx.y;
+    const int cit_i = t % p.cit; t /= p.cit;
+    const int cot_i = t % p.cot;
+    const int krow = t / p.cot;                              // (kd, kh)
+    const int ntaps = p.kd * p.kh * 3;
+    const int kh_ = krow % p.kh, kd_ = krow / p.kh;
+    const int co0 = cot_i * 32 * MB, ci0 = cit_i * 32 * NB;
+    int coc[MB], cic[NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) { const int c = co0 + mb * 32 + m; coc[mb] = c < p.Cout ? c : p.Cout - 1; }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { const int c = ci0 + nb * 32 + m; cic[nb] = c < p.Cin ? c : p.Cin - 1; }
+
+    f32x16 acc[3][MB][NB];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[s][mb][nb][r] = 0.f;
+
+    const long long r_end = min((job + 1) * (long long)p.rows, p.total_rows);
+    for (long long rr = job * (long long)p.rows; rr < r_end; ++rr) {
+        const int h = (int)(rr % p.H);
+        const long long plane = rr / p.H;
+        const int n = (int)(plane / p.D), d = (int)(plane % p.D);
+        const int id = d + kd_ - p.kd / 2, ih = h + kh_ - p.kh / 2;
+        if (id < 0 || id >= p.D || ih < 0 || ih >= p.H) continue;        // this row of taps sees only zero padding from this row
+        const T* dyrow = (const T*)p.dy + ((((size_t)n * p.D + d) * p.H + h) * p.W) * p.dy_cstride + p.dy_coff;
+        const T* xrow = (const T*)p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W) * p.x_cstride + p.x_coff;
+        for (int w0 = 0; w0 < p.W; w0 += 16) {
+            const int wl = w0 + 8 * khalf;                   // this lane's first pixel
+            u16x8 a[MB];
+            unsigned short xv[NB][10];                       // pixels wl-1 .. wl+8 of the lane's input channel
+            if (w0 >= 1 && w0 + 17 <= p.W) {                 // interior step (wave-uniform): plain loads
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) a[mb][j] = dyrow[(size_t)(wl + j) * p.dy_cstride + coc[mb]].v;
+#pragma unroll
+                for (int j = 0; j < 10; ++j)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) xv[nb][j] = xrow[(size_t)(wl - 1 + j) * p.x_cstride + cic[nb]].v;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int w = wl + j;
+                    const bool ok = w < p.W;
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const unsigned short v = dyrow[(size_t)(ok ? w : p.W - 1) * p.dy_cstride + coc[mb]].v;
+                        a[mb][j] = ok ? v : (unsigned short)0;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    const int iw = wl - 1 + j;
+                    const bool ok = iw >= 0 && iw < p.W;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const unsigned short v = xrow[(size_t)(ok ? iw : 0) * p.x_cstride + cic[nb]].v;
+                        xv[nb][j] = ok ? v : (unsigned short)0;
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    u16x8 b;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) b[j] = xv[nb][j + s];         // x[w + s - 1]: tap kw = s
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) mma_k16(a[mb], b, acc[s][mb][nb], T());
+                }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int tap = (kd_ * p.kh + kh_) * 3 + s;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + mb * 32 + cd_row(r, lane), ci = ci0 + nb * 32 + (lane & 31);
+                    if (co < p.Cout && ci < p.Cin) atomicAdd(p.dw + ((size_t)co * p.Cin + ci) * ntaps + tap, acc[s][mb][nb][r]);
+                }
+    }
+}
+
+// conv_wgrad16_lds_kernel -- the 16-bit weight gradient as a tiled GEMM (kw = 3 windows: 3x3x3 and 1x3x3).
+// The two forms above load every MFMA operand element with its own 2- or 4-byte load and are bound by that (20-130 TFLOP/s).
+// Here a 384-thread workgroup stages, per chunk of output rows, the dY tile [P pixels][64 co] and the X halo tile
+// [(R+2) x (W+2) pixels][64 ci] of one input plane into LDS in their NATURAL pixel-major layout (16-byte vectors, pitch 144 B)
+// and reads the MFMA operands with ds_read_b64_tr_b16: the hardware transpose hands every lane the 8 consecutive pixels (k)
+// of one channel that v_mfma_f32_16x16x32 wants, and a tap shift is just another pixel address -- no transposed or shifted
+// copies (common.h: lds_tr8).  Six waves = 3 filter rows (kh) x 2 halves of the 64 input channels; each accumulates the three
+// kw taps of its row: 3 x (64 co x 32 ci) = 24 MFMAs per 32-pixel step from 20 transpose reads.  A workgroup walks several
+// (plane, row chunk) units with its accumulators in registers and ends in one pass of fp32 atomics.
+constexpr int WG16_P = 224;              // output pixels per chunk (7 k32 steps)
+constexpr int WG16_XP = 320;             // halo pixels per chunk
+constexpr int WG16_PITCH = 144;          // bytes per LDS pixel: 64 channels x 2 B + 16 B (keeps the transpose reads off a 128-B bank period)
+struct Wgrad16Params {
+    const void* x; const void* dy; float* dw;
+    int N, D, H, W, Cin, Cout, kd;
+    int x_cstride, x_coff, dy_cstride, dy_coff;
+    int cot, cit;                 // 64-channel tiles along Cout / Cin
+    int rows, cpp;                // output rows per chunk, chunks per plane
+    int upj;                      // (plane, chunk) units per workgroup
+    long long units;
+    float* ws;                    // partial tiles [gridDim.x][gridDim.y][6 waves][24 tiles][64 lanes][4] (NULL: fp32 atomics on dw)
+    unsigned wmagic, wmagic2;     // floor(k / W) = (k * wmagic) >> 22, floor(k / (W + 2)) = (k * wmagic2) >> 22 for k < 512
+};
+
+template <typename T>
+__global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) {
+    static_assert(sizeof(T) == 2, "16-bit storage");
+    constexpr int PITCH = WG16_PITCH;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(WG16_P + WG16_XP) * PITCH];
+    unsigned char* const dyI = lds;
+    unsigned char* const xI = lds + WG16_P * PITCH;
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifdef STEP_EMUL
+    const int wave = tid >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const int khw = wave % 3, cb = wave / 3;                  // filter row, 32-channel half of the ci tile
+    int t = blockIdx.y;
+    const int cit_i = t % p.cit; t /= p.cit;
+    const int cot_i = t % p.cot;
+    const int kd_ = t / p.cot;
+    const int co0 = cot_i * 64, ci0 = cit_i * 64;
+    const int W2 = p.W + 2;
+    const int g = lane >> 4, rr = (lane & 15) >> 2, q = lane & 3;
+
+    f32x4 acc[3][4][2];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int ma = 0; ma < 4; ++ma)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[s][ma][nb][r] = 0.f;
+
+    const T* xg = (const T*)p.x;
+    const T* dyg = (const T*)p.dy;
+    const long long u_beg = (long long)blockIdx.x * p.upj, u_end = min(u_beg + p.upj, p.units);
+    // A unit's two images go global -> registers -> LDS; the NEXT unit's vectors are requested before this unit's matrix
+    // work, so their round trip (2-3 us under load, against ~1 us of MFMAs per unit) flies under it.
+    constexpr int NV = ((WG16_P + WG16_XP) * 8 + 383) / 384;     // 16-byte vectors per thread per unit (12)
+    u32x4 stg[NV];
+    struct Unit { int n, d, id, r0, R, P, Ppad, XP; bool live; };
+    auto unit_of = [&](long long u) {
+        Unit q;
+        const long long plane = u / p.cpp;
+        const int chunk = (int)(u % p.cpp);
+        q.r0 = chunk * p.rows;
+        q.R = min(p.rows, p.H - q.r0);
+        q.n = (int)(plane / p.D); q.d = (int)(plane % p.D);
+        q.id = q.d + kd_ - p.kd / 2;
+        q.live = q.id >= 0 && q.id < p.D;                    // else: this plane of taps sees only zero padding
+        q.P = q.R * p.W; q.Ppad = (q.P + 31) & ~31; q.XP = (q.R + 2) * W2;
+        return q;
+    };
+    auto prefetch = [&](const Unit& q) {
+        const size_t gp0 = (((size_t)q.n * p.D + q.d) * p.H + q.r0) * p.W;
+        const size_t xp0 = ((size_t)q.n * p.D + q.id) * p.H;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * 384;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (v < q.Ppad * 8) {                            // dY [Ppad][64 co]: zero tail, zero past Cout
+                const int k = v >> 3, cv = v & 7;
+                if (k < q.P && co0 + cv * 8 < p.Cout) val = *(const u32x4*)(dyg + (gp0 + k) * p.dy_cstride + p.dy_coff + co0 + cv * 8);
+            } else {                                         // X halo [(R+2)(W+2)][64 ci]: zero border, zero past Cin
+                const int w = v - q.Ppad * 8;
+                const int px = w >> 3, cv = w & 7;
+                const int r_ = (int)(((unsigned)px * p.wmagic2) >> 22), c_ = px - r_ * W2;
+                const int ih = q.r0 + r_ - 1, iw = c_ - 1;
+                if (px < q.XP && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && ci0 + cv * 8 < p.Cin)
+                    val = *(const u32x4*)(xg + ((xp0 + ih) * p.W + iw) * p.x_cstride + p.x_coff + ci0 + cv * 8);
+            }
+            stg[i] = val;
+        }
+    };
+    auto to_lds = [&](const Unit& q) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * 384;
+            if (v < q.Ppad * 8) *(u32x4*)(dyI + (v >> 3) * PITCH + (v & 7) * 16) = stg[i];
+            else if (v - q.Ppad * 8 < q.XP * 8) *(u32x4*)(xI + ((v - q.Ppad * 8) >> 3) * PITCH + (v & 7) * 16) = stg[i];
+        }
+    };
+    Unit cur = unit_of(u_beg < u_end ? u_beg : 0);
+    if (u_beg < u_end && cur.live) prefetch(cur);
+    for (long long u = u_beg; u < u_end; ++u) {
+        __syncthreads();                                     // every wave is done with the previous unit's images
+        if (cur.live) to_lds(cur);
+        __syncthreads();
+        const Unit done = cur;
+        if (u + 1 < u_end) {
+            cur = unit_of(u + 1);
+            if (cur.live) prefetch(cur);
+        }
+        if (!done.live) continue;                            // (workgroup-uniform)
+        const int P = done.P, Ppad = done.Ppad;
+        // ---- 32 output pixels per step
+        for (int kb = 0; kb < Ppad; kb += 32) {
+            const unsigned char* pa[2];
+            const unsigned char* pb[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = kb + 8 * g + 4 * h + rr;       // this lane's pixel of the transpose block
+                const int kc = min(k, P - 1);                // (past the chunk: dY is zero there, X only has to be finite)
+                const int row = (int)(((unsigned)kc * p.wmagic) >> 22);
+                pa[h] = dyI + k * PITCH + q * 8;
+                pb[h] = xI + (kc + 2 * row + khw * W2) * PITCH + cb * 64 + q * 8;
+            }
+            u16x8 a[4];
+#pragma unroll
+            for (int ma = 0; ma < 4; ++ma) a[ma] = lds_tr8(pa[0] + ma * 32, pa[1] + ma * 32);
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const u16x8 b = lds_tr8(pb[0] + s * PITCH + nb * 32, pb[1] + s * PITCH + nb * 32);
+#pragma unroll
+                    for (int ma = 0; ma < 4; ++ma) mma16_k32(a[ma], b, acc[s][ma][nb], T());
+                }
+        }
+    }
+    if (p.ws) {
+        // partial tile of this workgroup, accumulator layout as is (16-byte stores, fully coalesced); wgrad16_reduce_kernel
+        // sums over the workgroups of the pixel axis in a fixed order -- no atomics, deterministic
+        f32x4* out = (f32x4*)p.ws + ((((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 6 + wave) * 24) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int ma = 0; ma < 4; ++ma)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) out[((s * 4 + ma) * 2 + nb) * 64] = acc[s][ma][nb];
+        return;
+    }
+    const int ntaps = p.kd * 9;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int tap = (kd_ * 3 + khw) * 3 + s;
+#pragma unroll
+        for (int ma = 0; ma < 4; ++ma)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + ma * 16 + 4 * g + r, ci = ci0 + cb * 32 + nb * 16 + (lane & 15);
+                    if (co < p.Cout && ci < p.Cin) atomicAdd(p.dw + ((size_t)co * p.Cin + ci) * ntaps + tap, acc[s][ma][nb][r]);
+                }
+    }
+}
+
+// sums the partial tiles of conv_wgrad16_lds_kernel over the pixel-axis workgroups: one thread per (tile, lane) 16-byte group
+__global__ void wgrad16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int gx, int gy, int cot, int cit, int Cout, int Cin,
+                                      int kd, int accumulate) {
+    const long long per_x = (long long)gy * 6 * 24 * 64;               // f32x4 groups of one pixel-axis workgroup
+    const int ntaps = kd * 9;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < per_x; idx += (long long)blockDim.x * gridDim.x) {
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int x = 0; x < gx; ++x) {
+            const f32x4 v = ((const f32x4*)ws)[(size_t)x * per_x + idx];
+            sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+        }
+        long long t = idx;
+        const int lane = (int)(t % 64); t /= 64;
+        const int tile = (int)(t % 24); t /= 24;
+        const int wave = (int)(t % 6); t /= 6;
+        const int y = (int)t;
+        const int nb = tile & 1, ma = (tile >> 1) & 3, s = tile >> 3;
+        const int khw = wave % 3, cb = wave / 3;
+        int yy = y;
+        const int cit_i = yy % cit; yy /= cit;
+        const int cot_i = yy % cot;
+        const int kd_ = yy / cot;
+        const int tap = (kd_ * 3 + khw) * 3 + s;
+        const int ci = cit_i * 64 + cb * 32 + nb * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = cot_i * 64 + ma * 16 + 4 * (lane >> 4) + r;
+            if (co < Cout && ci < Cin) {
+                float* o = dw + ((size_t)co * Cin + ci) * ntaps + tap;
+                *o = accumulate ? *o + sum[r] : sum[r];
+            }
+        }
+    }
+}
+
 // stem_wgrad_kernel -- weight gradient of the 7x7x7 stride-2 stem (Cin = 3) from the clip in its own [N,T,3,H,W]
 // layout.  Same scheme as conv_wgrad_kernel (fp32 MFMA, reduction over output pixels, lanes along channels), but
 // with only 3 input channels the B operand's 32 columns are the (kw, c) pairs of one (kd, kh) row of the filter
@@ -223,7 +537,38 @@ static int wgrad_min_pixels() {
     return x > 0 ? (x + 15) / 16 * 16 : 512;
 }
 
-static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* dy, bool w16, float* dw, int accumulate, step_stream_t stream) {
+// launch plan of the LDS-tiled 16-bit form; ok = false: the shape is left to the per-tap forms
+struct Wg16Plan { bool ok; int rows, cpp, upj, cot, cit; long long units, gx, gy; };
+static Wg16Plan wgrad16_plan(const step_conv_desc* d) {
+    Wg16Plan pl; pl.ok = false; pl.rows = pl.cpp = pl.upj = pl.cot = pl.cit = 0; pl.units = pl.gx = pl.gy = 0;
+    if (!d || (d->dtype != STEP_BF16 && d->dtype != STEP_F16)) return pl;
+    if (!(d->kh == 3 && d->kw == 3 && (d->kd == 1 || d->kd == 3))) return pl;
+    if (d->Cin % 8 || d->Cout % 8 || d->x_cstride % 8 || d->x_coff % 8 || d->y_cstride % 8 || d->y_coff % 8) return pl;
+    if (getenv("STEP_WGRAD16_LDS") && atoi(getenv("STEP_WGRAD16_LDS")) == 0) return pl;
+    if (d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0) return pl;
+    int R = 0;
+    for (int r = d->H; r >= 1; --r)
+        if (r * d->W <= WG16_P && (r + 2) * (d->W + 2) <= WG16_XP) { R = r; break; }
+    if (R <= 0) return pl;
+    pl.cot = ceil_div(d->Cout, 64); pl.cit = ceil_div(d->Cin, 64);
+    pl.cpp = ceil_div(d->H, R);
+    pl.rows = ceil_div(d->H, pl.cpp);                        // balanced chunks
+    pl.units = (long long)d->N * d->D * pl.cpp;
+    pl.gy = (long long)d->kd * pl.cot * pl.cit;
+    // ~512 workgroups per launch; each walks several (plane, chunk) units (the next one's loads under this one's matrix work)
+    long long want = 512 / (pl.gy > 0 ? pl.gy : 1);
+    if (want < 1) want = 1;
+    long long upj = ceil_div64(pl.units, want);
+    if (upj < 1) upj = 1;
+    if (upj > 0x3fffffff) upj = 0x3fffffff;
+    pl.upj = (int)upj;
+    pl.gx = ceil_div64(pl.units, pl.upj);
+    pl.ok = pl.gy <= 65535 && pl.gx <= 0x7fffffffLL;
+    return pl;
+}
+
+static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* dy, bool w16, float* dw, int accumulate, void* ws,
+                           size_t ws_bytes, step_stream_t stream) {
     if (!d) return STEP_E_NULL;
     if (w16 && d->dtype != STEP_BF16 && d->dtype != STEP_F16) return STEP_E_UNSUPPORTED;
     if (d->N < 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return STEP_E_SHAPE;
@@ -282,7 +627,9 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
     }
     const bool narrow = d->Cin <= 32;
     p.cot = ceil_div(d->Cout, 64); p.cit = ceil_div(d->Cin, narrow ? 32 : 64);
-    const long long gy = (long long)ntaps * p.cot * p.cit;
+    // (the tap-row form measured 1.3-2.6x SLOWER than the per-tap form -- 424 VGPRs, one wave per SIMD: kept for reference, off)
+    const bool rowform = w16 && d->kw == 3 && getenv("STEP_WGRAD16_ROW") && atoi(getenv("STEP_WGRAD16_ROW")) == 1;
+    const long long gy = (long long)(rowform ? ntaps / 3 : ntaps) * p.cot * p.cit;
     // (n, d, h) rows per wavefront job.  Two opposite pressures (PMC): the kernel hides its load latency only with
     // several wavefronts per SIMD (1.6 per SIMD -> matrix pipe 18 % busy), but every job ends in one set of fp32
     // atomics (a 64x64 tile = 4096 of them; the 14x14 layers spent their time in 81 M atomics with one job per
@@ -303,6 +650,37 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
     p.jobs = ceil_div64(p.total_rows, p.rows);
     if (gy > 65535) return STEP_E_UNSUPPORTED;
     dim3 grid((unsigned)ceil_div64(p.jobs, 4), (unsigned)gy);
+    // the LDS-tiled form (transpose reads): kh = kw = 3, channel counts in 16-byte vectors, rows that fit the chunk images
+    if (w16 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0) {
+        const Wg16Plan pl = wgrad16_plan(d);
+        if (pl.ok) {
+            Wgrad16Params q;
+            q.x = x; q.dy = dy; q.dw = dw;
+            q.N = d->N; q.D = d->D; q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.Cout = d->Cout; q.kd = d->kd;
+            q.x_cstride = d->x_cstride; q.x_coff = d->x_coff; q.dy_cstride = d->y_cstride; q.dy_coff = d->y_coff;
+            q.cot = pl.cot; q.cit = pl.cit; q.cpp = pl.cpp; q.rows = pl.rows; q.units = pl.units; q.upj = pl.upj;
+            q.wmagic = (unsigned)(((1u << 22) + d->W - 1) / d->W);
+            q.wmagic2 = (unsigned)(((1u << 22) + d->W + 1) / (d->W + 2));
+            const size_t need = (size_t)pl.gx * pl.gy * 6 * 24 * 64 * 16;
+            q.ws = (ws && ws_bytes >= need && ((uintptr_t)ws % 16) == 0) ? (float*)ws : nullptr;
+            dim3 grid16((unsigned)pl.gx, (unsigned)pl.gy);
+            if (d->dtype == STEP_BF16) STEP_LAUNCH((conv_wgrad16_lds_kernel<bf16_t>), grid16, dim3(384), stream, q);
+            else STEP_LAUNCH((conv_wgrad16_lds_kernel<f16_t>), grid16, dim3(384), stream, q);
+            if (q.ws) {
+                const long long groups = pl.gy * 6 * 24 * 64;
+                STEP_LAUNCH(wgrad16_reduce_kernel, dim3(flat_grid(groups, 256)), dim3(256), stream, (const float*)q.ws, dw, (int)pl.gx, (int)pl.gy,
+                            pl.cot, pl.cit, d->Cout, d->Cin, d->kd, 1);      // (dw was cleared above unless accumulate)
+            }
+            return STEP_LAUNCH_CHECK();
+        }
+    }
+    if (rowform) {
+#define STEP_WGROW(T_) do { if (narrow) STEP_LAUNCH((conv_wgrad16_row_kernel<T_, 2, 1>), grid, dim3(256), stream, p); \
+                            else STEP_LAUNCH((conv_wgrad16_row_kernel<T_, 2, 2>), grid, dim3(256), stream, p); } while (0)
+        if (d->dtype == STEP_BF16) STEP_WGROW(bf16_t); else STEP_WGROW(f16_t);
+#undef STEP_WGROW
+        return STEP_LAUNCH_CHECK();
+    }
     switch (d->dtype) {
         case STEP_F32: STEP_WG(float); break;
         case STEP_BF16: if (w16) STEP_WG16(bf16_t); else STEP_WG(bf16_t); break;
@@ -315,11 +693,21 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
 }
 
 int step_conv_wgrad(const step_conv_desc* d, const void* x, const float* dy, float* dw, int accumulate, step_stream_t stream) {
-    return conv_wgrad_impl(d, x, dy, false, dw, accumulate, stream);
+    return conv_wgrad_impl(d, x, dy, false, dw, accumulate, nullptr, 0, stream);
 }
 
 int step_conv_wgrad16(const step_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, step_stream_t stream) {
-    return conv_wgrad_impl(d, x, dy, true, dw, accumulate, stream);
+    return conv_wgrad_impl(d, x, dy, true, dw, accumulate, nullptr, 0, stream);
+}
+
+size_t step_conv_wgrad16_workspace_bytes(const step_conv_desc* d) {
+    const Wg16Plan pl = wgrad16_plan(d);
+    return pl.ok ? (size_t)pl.gx * pl.gy * 6 * 24 * 64 * 16 : 0;
+}
+
+int step_conv_wgrad16_ws(const step_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                         step_stream_t stream) {
+    return conv_wgrad_impl(d, x, dy, true, dw, accumulate, ws, ws_bytes, stream);
 }
 
 

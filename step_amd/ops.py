@@ -17,6 +17,7 @@ DT = {torch.float32: _capi.F32, torch.bfloat16: _capi.BF16, torch.float16: _capi
 # launch below is bracketed by two HIP events on the launch stream and a record
 # (kernel_name, algorithmic_flops, algorithmic_bytes, start_event, end_event) is appended.
 PROFILE = None
+WGRAD16_WS = os.environ.get("STEP_WGRAD16_WS", "1") != "0"   # partial-tile workspace instead of fp32 atomics (16-bit weight gradients)
 
 
 class _Prof:
@@ -223,9 +224,11 @@ def conv_wgrad16(x, gy, Cout, k, into=None):
         prof = _Prof("void step::conv_wgrad_kernel<%s, 2, %d, true>(step::WgradParams)" % (_TNAME[x.dtype], 1 if Cin <= 32 else 2),
                      2.0 * pix * Cout * Cin * k[0] * k[1] * k[2],
                      pix * (Cin + Cout) * x.element_size() + 4.0 * Cout * Cin * k[0] * k[1] * k[2])
+    wsb = L.step_conv_wgrad16_workspace_bytes(ctypes.byref(d)) if WGRAD16_WS else 0   # > 0: the LDS-tiled form with a two-stage sum
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
     with prof:
-        _capi.check(L.step_conv_wgrad16(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(dw), int(into is not None),
-                                        _lib.stream_ptr(x.device)), "step_conv_wgrad16")
+        _capi.check(L.step_conv_wgrad16_ws(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(dw), int(into is not None),
+                                           _lib.dptr(ws), wsb, _lib.stream_ptr(x.device)), "step_conv_wgrad16_ws")
     return dw
 
 

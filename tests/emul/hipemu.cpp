@@ -192,6 +192,36 @@ void mfma_32x32_k16(const float (&a)[8], const float (&b)[8], f32x16& c, bool f3
     exchange_end();
 }
 
+void mfma_16x16_k32(const float (&a)[8], const float (&b)[8], f32x4& c) {
+    float mine[16];
+    for (int j = 0; j < 8; ++j) { mine[j] = a[j]; mine[8 + j] = b[j]; }
+    char* s = exchange_begin(mine, 64);
+    int lane = (int)(t_threadIdx.x & 63);
+    int col = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (lane >> 4) + r;
+        float acc = c[r];
+        for (int g = 0; g < 4; ++g) {                       // k block g: the operands of lanes 16 g + row / col
+            const float* av = (const float*)(s + 256 * (16 * g + row));
+            const float* bv = (const float*)(s + 256 * (16 * g + col)) + 8;
+            for (int j = 0; j < 8; ++j) acc = fmaf(av[j], bv[j], acc);
+        }
+        c[r] = acc;
+    }
+    exchange_end();
+}
+
+void tr16_b64(const unsigned short (&mine)[4], unsigned short (&out)[4]) {
+    char* s = exchange_begin(mine, 8);
+    int lane = (int)(t_threadIdx.x & 63);
+    int g = lane >> 4, i = lane & 15;
+    for (int j = 0; j < 4; ++j) {
+        const unsigned short* src = (const unsigned short*)(s + 256 * (16 * g + 4 * j + i / 4));
+        out[j] = src[i % 4];
+    }
+    exchange_end();
+}
+
 void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     long long nblocks = (long long)grid.x * grid.y * grid.z;
     if (nblocks <= 0) return;

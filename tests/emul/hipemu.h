@@ -31,6 +31,12 @@ char* exchange_begin(const void* mine, int bytes);
 void exchange_end();
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 void mfma_32x32_k16(const float (&a)[8], const float (&b)[8], f32x16& c, bool f32_pairing);
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// v_mfma_f32_16x16x32_{bf16,f16}: lane l holds row/col (l & 15), k = 8 * (l >> 4) + 0..7; D: col = l & 15, row = 4 * (l >> 4) + reg
+void mfma_16x16_k32(const float (&a)[8], const float (&b)[8], f32x4& c);
+// ds_read_b64_tr_b16: every lane supplies the 4 x 16-bit elements at its own address; lane (16 g + i) receives, as element j,
+// element (i % 4) of the data of lane (16 g + 4 j + i / 4) (measured on gfx950, tools/ubench/tr_read.hip)
+void tr16_b64(const unsigned short (&mine)[4], unsigned short (&out)[4]);
 }  // namespace hipemu
 
 using hipemu::dim3;

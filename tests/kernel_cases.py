@@ -896,13 +896,18 @@ def case_conv_wgrad16(bk, golden):
     order differs (2e-5)."""
     rs = np.random.RandomState(35)
     cases = [(2, 24, 40, 3, 5, 19, (3, 3, 3)), (1, 72, 100, 2, 6, 7, (1, 3, 3)), (1, 40, 70, 1, 9, 130, (1, 1, 1))]
+    cases += [(1, 64, 72, 3, 20, 14, (3, 3, 3)),     # two row chunks per plane (20 rows of 14 > 224 pixels), a ragged second co tile
+              (2, 16, 32, 1, 3, 100, (3, 3, 3))]     # 100-pixel rows: one row per chunk, a single ci block
     saved = os.environ.get("STEP_WGRAD_MINPIX")
     try:
+        # "64" with STEP_WGRAD16_LDS=0: the per-tap 16-bit form with several row-range jobs per tile; None: the LDS-tiled form
         for minpix in ("64", None):
             if minpix is None:
                 os.environ.pop("STEP_WGRAD_MINPIX", None)
+                os.environ.pop("STEP_WGRAD16_LDS", None)
             else:
                 os.environ["STEP_WGRAD_MINPIX"] = minpix
+                os.environ["STEP_WGRAD16_LDS"] = "0"
             for (N, Cin, Cout, D, H, W, k) in cases:
                 x = rs.randn(N, Cin, D, H, W).astype(np.float32)
                 gy = rs.randn(N, Cout, D, H, W).astype(np.float32)
@@ -923,7 +928,23 @@ def case_conv_wgrad16(bk, golden):
                     assert err < 2e-5, (N, Cin, Cout, k, dt, minpix, err)
                     assert bk.lib.step_conv_wgrad16(ctypes.byref(d), xd.ptr, gd.ptr, dw.ptr, 1, bk.stream) == 0
                     assert np.abs(dw.get() - 2 * ref).max() / np.abs(ref).max() < 4e-5
+                    # the workspace form (LDS-tiled kernel + fixed-order sum of partial tiles): same result, and bit-reproducible
+                    nb = bk.lib.step_conv_wgrad16_workspace_bytes(ctypes.byref(d))
+                    if minpix is None and k[1] == 3 and Cin % 8 == 0 and Cout % 8 == 0:
+                        assert nb > 0 and nb % 16 == 0, (k, nb)
+                    if nb:
+                        outs = []
+                        for _ in range(2):
+                            ws = bk.dev(np.full(nb // 4, np.nan, np.float32))      # scratch needs no initialisation: poison it
+                            dw2 = bk.dev(np.full((Cout, Cin) + k, 7.0, np.float32))
+                            assert bk.lib.step_conv_wgrad16_ws(ctypes.byref(d), xd.ptr, gd.ptr, dw2.ptr, 0, ws.ptr, nb, bk.stream) == 0
+                            outs.append(dw2.get())
+                        assert np.abs(outs[0] - ref).max() / np.abs(ref).max() < 2e-5, (N, Cin, Cout, k, dt)
+                        assert np.array_equal(outs[0], outs[1])
+                        assert bk.lib.step_conv_wgrad16_ws(ctypes.byref(d), xd.ptr, gd.ptr, dw2.ptr, 1, ws.ptr, nb, bk.stream) == 0
+                        assert np.abs(dw2.get() - 2 * ref).max() / np.abs(ref).max() < 4e-5
     finally:
+        os.environ.pop("STEP_WGRAD16_LDS", None)
         if saved is None:
             os.environ.pop("STEP_WGRAD_MINPIX", None)
         else:
