@@ -1,0 +1,21 @@
+"""The reference's own call sites over the drop-in (build container only: skipped where /root/reference is absent).
+oracle/check_callers.py runs the reference's `utils.utils.inference` -- unchanged -- with `dropin/` ahead of the reference on
+sys.path (so `models` / `external.maskrcnn_benchmark.roi_layers` resolve to step_amd), kernels on the host interpreter, and
+compares its history with step_amd.driver.inference.  Runs in a subprocess: the check re-routes `models` / `utils` / `external`
+on sys.path, which must not leak into the other tests."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("STEP_REFERENCE", "/root/reference")
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "utils")), reason="reference tree not available")
+@pytest.mark.timeout(900)
+def test_reference_inference_runs_unchanged_over_the_dropin():
+    r = subprocess.run([sys.executable, "-m", "oracle.check_callers"], cwd=ROOT, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "== step_amd.driver.inference" in r.stdout
