@@ -239,6 +239,8 @@ __global__ __launch_bounds__(256) void conv_wgrad16_row_kernel(WgradParams p) {
 // (plane, row chunk) units with its accumulators in registers and ends in one pass of fp32 atomics.
 constexpr int WG16_P = 224;              // output pixels per chunk (7 k32 steps)
 constexpr int WG16_XP = 320;             // halo pixels per chunk
+constexpr int WG16_PW_P = 128;           // pointwise form: pixels per chunk
+constexpr int WG16_PW_XPITCH = 400;      // ... bytes per X pixel (192 channels x 2 B + 16 B)
 constexpr int WG16_PITCH = 144;          // bytes per LDS pixel: 64 channels x 2 B + 16 B (keeps the transpose reads off a 128-B bank period)
 struct Wgrad16Params {
     const void* x; const void* dy; float* dw;
@@ -252,31 +254,39 @@ struct Wgrad16Params {
     unsigned wmagic, wmagic2;     // floor(k / W) = (k * wmagic) >> 22, floor(k / (W + 2)) = (k * wmagic2) >> 22 for k < 512
 };
 
-template <typename T>
+// KW = 1 (pointwise convs / Linear layers): no halo; the unit is a chunk of 128 consecutive pixels of the flattened N*D*H*W
+// axis, the six waves take six 32-channel blocks of a 192-channel ci tile (X image pitch 400 B) and accumulate one tap.
+template <typename T, int KW>
 __global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) {
     static_assert(sizeof(T) == 2, "16-bit storage");
+    static_assert(KW == 3 || KW == 1, "3x3 windows or pointwise");
+    constexpr bool PW = KW == 1;
     constexpr int PITCH = WG16_PITCH;
+    constexpr int XPITCH = PW ? WG16_PW_XPITCH : WG16_PITCH;
+    constexpr int CIT = PW ? 192 : 64;                        // input channels per workgroup
+    constexpr int XCV = CIT / 8;                              // 16-byte vectors per X pixel
+    static_assert(WG16_PW_P * (PITCH + WG16_PW_XPITCH) <= (WG16_P + WG16_XP) * PITCH, "the pointwise images fit the same LDS array");
     __shared__ __attribute__((aligned(16))) unsigned char lds[(WG16_P + WG16_XP) * PITCH];
     unsigned char* const dyI = lds;
-    unsigned char* const xI = lds + WG16_P * PITCH;
+    unsigned char* const xI = lds + (PW ? WG16_PW_P : WG16_P) * PITCH;
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef STEP_EMUL
     const int wave = tid >> 6;
 #else
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
-    const int khw = wave % 3, cb = wave / 3;                  // filter row, 32-channel half of the ci tile
+    const int khw = PW ? 0 : wave % 3, cb = PW ? wave : wave / 3;   // filter row, 32-channel block of the ci tile
     int t = blockIdx.y;
     const int cit_i = t % p.cit; t /= p.cit;
     const int cot_i = t % p.cot;
     const int kd_ = t / p.cot;
-    const int co0 = cot_i * 64, ci0 = cit_i * 64;
+    const int co0 = cot_i * 64, ci0 = cit_i * CIT;
     const int W2 = p.W + 2;
     const int g = lane >> 4, rr = (lane & 15) >> 2, q = lane & 3;
 
-    f32x4 acc[3][4][2];
+    f32x4 acc[KW][4][2];
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < KW; ++s)
 #pragma unroll
         for (int ma = 0; ma < 4; ++ma)
 #pragma unroll
@@ -291,9 +301,17 @@ __global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) 
     // work, so their round trip (2-3 us under load, against ~1 us of MFMAs per unit) flies under it.
     constexpr int NV = ((WG16_P + WG16_XP) * 8 + 383) / 384;     // 16-byte vectors per thread per unit (12)
     u32x4 stg[NV];
-    struct Unit { int n, d, id, r0, R, P, Ppad, XP; bool live; };
+    struct Unit { int n, d, id, r0, R, P, Ppad, XP; long long k0; bool live; };
     auto unit_of = [&](long long u) {
         Unit q;
+        if (PW) {                                            // pixels [u * 128, +128) of the flat pixel axis
+            const long long M = (long long)p.N * p.D * p.H * p.W, k0 = u * WG16_PW_P;
+            q.n = q.d = q.id = q.R = 0; q.r0 = 0; q.live = true;
+            q.k0 = k0;
+            q.P = (int)min((long long)WG16_PW_P, M - k0); q.Ppad = (q.P + 31) & ~31; q.XP = q.P;
+            return q;
+        }
+        q.k0 = 0;
         const long long plane = u / p.cpp;
         const int chunk = (int)(u % p.cpp);
         q.r0 = chunk * p.rows;
@@ -305,7 +323,7 @@ __global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) 
         return q;
     };
     auto prefetch = [&](const Unit& q) {
-        const size_t gp0 = (((size_t)q.n * p.D + q.d) * p.H + q.r0) * p.W;
+        const size_t gp0 = PW ? (size_t)q.k0 : (((size_t)q.n * p.D + q.d) * p.H + q.r0) * p.W;
         const size_t xp0 = ((size_t)q.n * p.D + q.id) * p.H;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -314,6 +332,10 @@ __global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) 
             if (v < q.Ppad * 8) {                            // dY [Ppad][64 co]: zero tail, zero past Cout
                 const int k = v >> 3, cv = v & 7;
                 if (k < q.P && co0 + cv * 8 < p.Cout) val = *(const u32x4*)(dyg + (gp0 + k) * p.dy_cstride + p.dy_coff + co0 + cv * 8);
+            } else if (PW) {                                 // X [P][192 ci]: zero past the chunk / past Cin
+                const int w = v - q.Ppad * 8;
+                const int px = w / XCV, cv = w % XCV;
+                if (px < q.P && ci0 + cv * 8 < p.Cin) val = *(const u32x4*)(xg + (gp0 + px) * p.x_cstride + p.x_coff + ci0 + cv * 8);
             } else {                                         // X halo [(R+2)(W+2)][64 ci]: zero border, zero past Cin
                 const int w = v - q.Ppad * 8;
                 const int px = w >> 3, cv = w & 7;
@@ -330,7 +352,10 @@ __global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) 
         for (int i = 0; i < NV; ++i) {
             const int v = tid + i * 384;
             if (v < q.Ppad * 8) *(u32x4*)(dyI + (v >> 3) * PITCH + (v & 7) * 16) = stg[i];
-            else if (v - q.Ppad * 8 < q.XP * 8) *(u32x4*)(xI + ((v - q.Ppad * 8) >> 3) * PITCH + (v & 7) * 16) = stg[i];
+            else if (v - q.Ppad * 8 < q.XP * XCV) {
+                const int w = v - q.Ppad * 8;
+                *(u32x4*)(xI + (w / XCV) * XPITCH + (w % XCV) * 16) = stg[i];
+            }
         }
     };
     Unit cur = unit_of(u_beg < u_end ? u_beg : 0);
@@ -356,16 +381,16 @@ __global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) 
                 const int kc = min(k, P - 1);                // (past the chunk: dY is zero there, X only has to be finite)
                 const int row = (int)(((unsigned)kc * p.wmagic) >> 22);
                 pa[h] = dyI + k * PITCH + q * 8;
-                pb[h] = xI + (kc + 2 * row + khw * W2) * PITCH + cb * 64 + q * 8;
+                pb[h] = PW ? xI + kc * XPITCH + cb * 64 + q * 8 : xI + (kc + 2 * row + khw * W2) * PITCH + cb * 64 + q * 8;
             }
             u16x8 a[4];
 #pragma unroll
             for (int ma = 0; ma < 4; ++ma) a[ma] = lds_tr8(pa[0] + ma * 32, pa[1] + ma * 32);
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
+            for (int s = 0; s < KW; ++s)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
-                    const u16x8 b = lds_tr8(pb[0] + s * PITCH + nb * 32, pb[1] + s * PITCH + nb * 32);
+                    const u16x8 b = lds_tr8(pb[0] + s * XPITCH + nb * 32, pb[1] + s * XPITCH + nb * 32);
 #pragma unroll
                     for (int ma = 0; ma < 4; ++ma) mma16_k32(a[ma], b, acc[s][ma][nb], T());
                 }
@@ -374,19 +399,19 @@ __global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) 
     if (p.ws) {
         // partial tile of this workgroup, accumulator layout as is (16-byte stores, fully coalesced); wgrad16_reduce_kernel
         // sums over the workgroups of the pixel axis in a fixed order -- no atomics, deterministic
-        f32x4* out = (f32x4*)p.ws + ((((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 6 + wave) * 24) * 64 + lane;
+        f32x4* out = (f32x4*)p.ws + ((((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 6 + wave) * (KW * 8)) * 64 + lane;
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+        for (int s = 0; s < KW; ++s)
 #pragma unroll
             for (int ma = 0; ma < 4; ++ma)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) out[((s * 4 + ma) * 2 + nb) * 64] = acc[s][ma][nb];
         return;
     }
-    const int ntaps = p.kd * 9;
+    const int ntaps = PW ? 1 : p.kd * 9;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const int tap = (kd_ * 3 + khw) * 3 + s;
+    for (int s = 0; s < KW; ++s) {
+        const int tap = PW ? 0 : (kd_ * 3 + khw) * 3 + s;
 #pragma unroll
         for (int ma = 0; ma < 4; ++ma)
 #pragma unroll
@@ -401,9 +426,10 @@ __global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) 
 
 // sums the partial tiles of conv_wgrad16_lds_kernel over the pixel-axis workgroups: one thread per (tile, lane) 16-byte group
 __global__ void wgrad16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int gx, int gy, int cot, int cit, int Cout, int Cin,
-                                      int kd, int accumulate) {
-    const long long per_x = (long long)gy * 6 * 24 * 64;               // f32x4 groups of one pixel-axis workgroup
-    const int ntaps = kd * 9;
+                                      int kd, int accumulate, int pw) {
+    const int tpw = pw ? 8 : 24;                                        // accumulator tiles per wave
+    const long long per_x = (long long)gy * 6 * tpw * 64;              // f32x4 groups of one pixel-axis workgroup
+    const int ntaps = pw ? 1 : kd * 9;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < per_x; idx += (long long)blockDim.x * gridDim.x) {
         f32x4 sum = {0.f, 0.f, 0.f, 0.f};
         for (int x = 0; x < gx; ++x) {
@@ -412,17 +438,17 @@ __global__ void wgrad16_reduce_kernel(const float* __restrict__ ws, float* __res
         }
         long long t = idx;
         const int lane = (int)(t % 64); t /= 64;
-        const int tile = (int)(t % 24); t /= 24;
+        const int tile = (int)(t % tpw); t /= tpw;
         const int wave = (int)(t % 6); t /= 6;
         const int y = (int)t;
         const int nb = tile & 1, ma = (tile >> 1) & 3, s = tile >> 3;
-        const int khw = wave % 3, cb = wave / 3;
+        const int khw = pw ? 0 : wave % 3, cb = pw ? wave : wave / 3;
         int yy = y;
         const int cit_i = yy % cit; yy /= cit;
         const int cot_i = yy % cot;
         const int kd_ = yy / cot;
-        const int tap = (kd_ * 3 + khw) * 3 + s;
-        const int ci = cit_i * 64 + cb * 32 + nb * 16 + (lane & 15);
+        const int tap = pw ? 0 : (kd_ * 3 + khw) * 3 + s;
+        const int ci = cit_i * (pw ? 192 : 64) + cb * 32 + nb * 16 + (lane & 15);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = cot_i * 64 + ma * 16 + 4 * (lane >> 4) + r;
@@ -538,23 +564,36 @@ static int wgrad_min_pixels() {
 }
 
 // launch plan of the LDS-tiled 16-bit form; ok = false: the shape is left to the per-tap forms
-struct Wg16Plan { bool ok; int rows, cpp, upj, cot, cit; long long units, gx, gy; };
+struct Wg16Plan { bool ok, pw; int rows, cpp, upj, cot, cit; long long units, gx, gy; };
 static Wg16Plan wgrad16_plan(const step_conv_desc* d) {
-    Wg16Plan pl; pl.ok = false; pl.rows = pl.cpp = pl.upj = pl.cot = pl.cit = 0; pl.units = pl.gx = pl.gy = 0;
+    Wg16Plan pl; pl.ok = false; pl.pw = false; pl.rows = pl.cpp = pl.upj = pl.cot = pl.cit = 0; pl.units = pl.gx = pl.gy = 0;
     if (!d || (d->dtype != STEP_BF16 && d->dtype != STEP_F16)) return pl;
-    if (!(d->kh == 3 && d->kw == 3 && (d->kd == 1 || d->kd == 3))) return pl;
+    const bool pw = d->kd == 1 && d->kh == 1 && d->kw == 1;
+    pl.pw = pw;
+    if (!pw && !(d->kh == 3 && d->kw == 3 && (d->kd == 1 || d->kd == 3))) return pl;
     if (d->Cin % 8 || d->Cout % 8 || d->x_cstride % 8 || d->x_coff % 8 || d->y_cstride % 8 || d->y_coff % 8) return pl;
     if (getenv("STEP_WGRAD16_LDS") && atoi(getenv("STEP_WGRAD16_LDS")) == 0) return pl;
     if (d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0) return pl;
-    int R = 0;
-    for (int r = d->H; r >= 1; --r)
-        if (r * d->W <= WG16_P && (r + 2) * (d->W + 2) <= WG16_XP) { R = r; break; }
-    if (R <= 0) return pl;
-    pl.cot = ceil_div(d->Cout, 64); pl.cit = ceil_div(d->Cin, 64);
-    pl.cpp = ceil_div(d->H, R);
-    pl.rows = ceil_div(d->H, pl.cpp);                        // balanced chunks
-    pl.units = (long long)d->N * d->D * pl.cpp;
-    pl.gy = (long long)d->kd * pl.cot * pl.cit;
+    if (pw) {
+        const long long M = (long long)d->N * d->D * d->H * d->W;
+        // measured (tools/wgrad_bench.py, bf16): 480 -> 304 channels on 25x25x9: 56 -> 37 us; 256 -> 288 on 50x50x18: 74 -> 99 us; 64 -> 64
+        // on 100x100x18: 53 -> 154 us -- the six waves want six full 32-channel blocks: deep-Cin layers only
+        if (M < 4 * WG16_PW_P || d->Cin < 384) return pl;
+        pl.cot = ceil_div(d->Cout, 64); pl.cit = ceil_div(d->Cin, 192);
+        pl.cpp = 1; pl.rows = 1;
+        pl.units = ceil_div64(M, WG16_PW_P);
+        pl.gy = (long long)pl.cot * pl.cit;
+    } else {
+        int R = 0;
+        for (int r = d->H; r >= 1; --r)
+            if (r * d->W <= WG16_P && (r + 2) * (d->W + 2) <= WG16_XP) { R = r; break; }
+        if (R <= 0) return pl;
+        pl.cot = ceil_div(d->Cout, 64); pl.cit = ceil_div(d->Cin, 64);
+        pl.cpp = ceil_div(d->H, R);
+        pl.rows = ceil_div(d->H, pl.cpp);                    // balanced chunks
+        pl.units = (long long)d->N * d->D * pl.cpp;
+        pl.gy = (long long)d->kd * pl.cot * pl.cit;
+    }
     // ~512 workgroups per launch; each walks several (plane, chunk) units (the next one's loads under this one's matrix work)
     long long want = 512 / (pl.gy > 0 ? pl.gy : 1);
     if (want < 1) want = 1;
@@ -586,6 +625,35 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
     p.x = x; p.dy = dy; p.dw = dw;
     p.N = d->N; p.D = d->D; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.kd = d->kd; p.kh = d->kh; p.kw = d->kw;
     p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.dy_cstride = d->y_cstride; p.dy_coff = d->y_coff;
+    // the LDS-tiled form (transpose reads): 3x3 windows or pointwise, channel counts in 16-byte vectors (wgrad16_plan)
+    if (w16 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0) {
+        const Wg16Plan pl = wgrad16_plan(d);
+        if (pl.ok) {
+            Wgrad16Params q;
+            q.x = x; q.dy = dy; q.dw = dw;
+            q.N = d->N; q.D = d->D; q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.Cout = d->Cout; q.kd = d->kd;
+            q.x_cstride = d->x_cstride; q.x_coff = d->x_coff; q.dy_cstride = d->y_cstride; q.dy_coff = d->y_coff;
+            q.cot = pl.cot; q.cit = pl.cit; q.cpp = pl.cpp; q.rows = pl.rows; q.units = pl.units; q.upj = pl.upj;
+            q.wmagic = (unsigned)(((1u << 22) + d->W - 1) / d->W);
+            q.wmagic2 = (unsigned)(((1u << 22) + d->W + 1) / (d->W + 2));
+            const size_t need = (size_t)pl.gx * pl.gy * 6 * (pl.pw ? 8 : 24) * 64 * 16;
+            q.ws = (ws && ws_bytes >= need && ((uintptr_t)ws % 16) == 0) ? (float*)ws : nullptr;
+            dim3 grid16((unsigned)pl.gx, (unsigned)pl.gy);
+            if (pl.pw) {
+                if (d->dtype == STEP_BF16) STEP_LAUNCH((conv_wgrad16_lds_kernel<bf16_t, 1>), grid16, dim3(384), stream, q);
+                else STEP_LAUNCH((conv_wgrad16_lds_kernel<f16_t, 1>), grid16, dim3(384), stream, q);
+            } else {
+                if (d->dtype == STEP_BF16) STEP_LAUNCH((conv_wgrad16_lds_kernel<bf16_t, 3>), grid16, dim3(384), stream, q);
+                else STEP_LAUNCH((conv_wgrad16_lds_kernel<f16_t, 3>), grid16, dim3(384), stream, q);
+            }
+            if (q.ws) {
+                const long long groups = pl.gy * 6 * (pl.pw ? 8 : 24) * 64;
+                STEP_LAUNCH(wgrad16_reduce_kernel, dim3(flat_grid(groups, 256)), dim3(256), stream, (const float*)q.ws, dw, (int)pl.gx, (int)pl.gy,
+                            pl.cot, pl.cit, d->Cout, d->Cin, d->kd, 1, (int)pl.pw);      // (dw was cleared above unless accumulate)
+            }
+            return STEP_LAUNCH_CHECK();
+        }
+    }
     if (ntaps == 1) {
         // pointwise: no neighbourhood, so the pixel axis is cut into chunks of 1024 ("rows" of one long plane list)
         const long long M = (long long)d->N * d->D * d->H * d->W;
@@ -650,30 +718,6 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
     p.jobs = ceil_div64(p.total_rows, p.rows);
     if (gy > 65535) return STEP_E_UNSUPPORTED;
     dim3 grid((unsigned)ceil_div64(p.jobs, 4), (unsigned)gy);
-    // the LDS-tiled form (transpose reads): kh = kw = 3, channel counts in 16-byte vectors, rows that fit the chunk images
-    if (w16 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0) {
-        const Wg16Plan pl = wgrad16_plan(d);
-        if (pl.ok) {
-            Wgrad16Params q;
-            q.x = x; q.dy = dy; q.dw = dw;
-            q.N = d->N; q.D = d->D; q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.Cout = d->Cout; q.kd = d->kd;
-            q.x_cstride = d->x_cstride; q.x_coff = d->x_coff; q.dy_cstride = d->y_cstride; q.dy_coff = d->y_coff;
-            q.cot = pl.cot; q.cit = pl.cit; q.cpp = pl.cpp; q.rows = pl.rows; q.units = pl.units; q.upj = pl.upj;
-            q.wmagic = (unsigned)(((1u << 22) + d->W - 1) / d->W);
-            q.wmagic2 = (unsigned)(((1u << 22) + d->W + 1) / (d->W + 2));
-            const size_t need = (size_t)pl.gx * pl.gy * 6 * 24 * 64 * 16;
-            q.ws = (ws && ws_bytes >= need && ((uintptr_t)ws % 16) == 0) ? (float*)ws : nullptr;
-            dim3 grid16((unsigned)pl.gx, (unsigned)pl.gy);
-            if (d->dtype == STEP_BF16) STEP_LAUNCH((conv_wgrad16_lds_kernel<bf16_t>), grid16, dim3(384), stream, q);
-            else STEP_LAUNCH((conv_wgrad16_lds_kernel<f16_t>), grid16, dim3(384), stream, q);
-            if (q.ws) {
-                const long long groups = pl.gy * 6 * 24 * 64;
-                STEP_LAUNCH(wgrad16_reduce_kernel, dim3(flat_grid(groups, 256)), dim3(256), stream, (const float*)q.ws, dw, (int)pl.gx, (int)pl.gy,
-                            pl.cot, pl.cit, d->Cout, d->Cin, d->kd, 1);      // (dw was cleared above unless accumulate)
-            }
-            return STEP_LAUNCH_CHECK();
-        }
-    }
     if (rowform) {
 #define STEP_WGROW(T_) do { if (narrow) STEP_LAUNCH((conv_wgrad16_row_kernel<T_, 2, 1>), grid, dim3(256), stream, p); \
                             else STEP_LAUNCH((conv_wgrad16_row_kernel<T_, 2, 2>), grid, dim3(256), stream, p); } while (0)
@@ -702,7 +746,7 @@ int step_conv_wgrad16(const step_conv_desc* d, const void* x, const void* dy, fl
 
 size_t step_conv_wgrad16_workspace_bytes(const step_conv_desc* d) {
     const Wg16Plan pl = wgrad16_plan(d);
-    return pl.ok ? (size_t)pl.gx * pl.gy * 6 * 24 * 64 * 16 : 0;
+    return pl.ok ? (size_t)pl.gx * pl.gy * 6 * (pl.pw ? 8 : 24) * 64 * 16 : 0;
 }
 
 int step_conv_wgrad16_ws(const step_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,

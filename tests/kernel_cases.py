@@ -897,7 +897,8 @@ def case_conv_wgrad16(bk, golden):
     rs = np.random.RandomState(35)
     cases = [(2, 24, 40, 3, 5, 19, (3, 3, 3)), (1, 72, 100, 2, 6, 7, (1, 3, 3)), (1, 40, 70, 1, 9, 130, (1, 1, 1))]
     cases += [(1, 64, 72, 3, 20, 14, (3, 3, 3)),     # two row chunks per plane (20 rows of 14 > 224 pixels), a ragged second co tile
-              (2, 16, 32, 1, 3, 100, (3, 3, 3))]     # 100-pixel rows: one row per chunk, a single ci block
+              (2, 16, 32, 1, 3, 100, (3, 3, 3)),     # 100-pixel rows: one row per chunk, a single ci block
+              (1, 392, 72, 2, 9, 40, (1, 1, 1))]     # pointwise through the LDS-tiled form (Cin >= 384): 720 pixels = 5 chunks + a ragged one, three ci tiles of 192 (the last one ragged)
     saved = os.environ.get("STEP_WGRAD_MINPIX")
     try:
         # "64" with STEP_WGRAD16_LDS=0: the per-tap 16-bit form with several row-range jobs per tile; None: the LDS-tiled form
@@ -930,7 +931,7 @@ def case_conv_wgrad16(bk, golden):
                     assert np.abs(dw.get() - 2 * ref).max() / np.abs(ref).max() < 4e-5
                     # the workspace form (LDS-tiled kernel + fixed-order sum of partial tiles): same result, and bit-reproducible
                     nb = bk.lib.step_conv_wgrad16_workspace_bytes(ctypes.byref(d))
-                    if minpix is None and k[1] == 3 and Cin % 8 == 0 and Cout % 8 == 0:
+                    if minpix is None and (k[1] == 3 or (N * D * H * W >= 512 and Cin >= 384)) and Cin % 8 == 0 and Cout % 8 == 0:
                         assert nb > 0 and nb % 16 == 0, (k, nb)
                     if nb:
                         outs = []

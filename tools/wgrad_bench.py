@@ -11,7 +11,7 @@ from step_amd import ops  # noqa: E402
 # (name, N, Cin, Cout, k, D, H, W)
 LAYERS = [("2c@400", 1, 64, 192, 3, 18, 100, 100), ("3c_b1b@400", 1, 128, 192, 3, 18, 50, 50), ("4f_b1b@400", 1, 160, 320, 3, 9, 25, 25),
           ("3cf@400", 1, 256, 288, 1, 18, 50, 50), ("2c@224x8", 8, 64, 192, 3, 16, 56, 56), ("4f_b1b@224x8", 8, 160, 320, 3, 8, 14, 14),
-          ("3b_b2b@400", 1, 16, 32, 3, 18, 50, 50), ("4b_b1b@400", 1, 96, 208, 3, 9, 25, 25), ("5b_b1b@13", 1, 160, 320, 3, 9, 13, 13)]
+          ("3b_b2b@400", 1, 16, 32, 3, 18, 50, 50), ("4bf@400", 1, 480, 304, 1, 9, 25, 25), ("2b@400", 1, 64, 64, 1, 18, 100, 100), ("4b_b1b@400", 1, 96, 208, 3, 9, 25, 25), ("5b_b1b@13", 1, 160, 320, 3, 9, 13, 13)]
 
 
 def main():
