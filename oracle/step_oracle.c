@@ -22,7 +22,13 @@
  *       (ROIAlign.h:68); pinned indirectly as the exact adjoint of the
  *       forward (<fwd(x),g> == <x,bwd(g)>) -- tests/test_oracle_golden.py (test_roi_align_backward_is_adjoint).
  *   orc_roi_pool_forward/backward   : the reference has no CPU implementation
- *       (ROIPool.h:47,68): PARITY UNPINNED beyond hand-computed cases.
+ *       (ROIPool.h:47,68), so no reference output can pin it: PARITY UNPINNED
+ *       BY THE REFERENCE.  Cross-checked instead against an independent
+ *       implementation of the same published operator (torch's
+ *       adaptive_max_pool2d on the cropped RoI: values and argmax positions,
+ *       in-bounds integer RoIs) and, for the backward, as the exact scatter of
+ *       the argmax -- tests/test_oracle_golden.py
+ *       (test_roi_pool_restatement_against_an_independent_implementation).
  */
 #include <math.h>
 #include <float.h>

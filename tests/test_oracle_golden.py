@@ -252,3 +252,44 @@ def test_i3d_classifier_restatement_matches_the_reference_golden(golden):
         prob, logits = R.i3d_forward(x, R.fill_state_dict(shapes, "i3dcls."))
     assert float(np.abs(logits.numpy() - g["logits"]).max()) < 1e-4 * float(np.abs(g["logits"]).max())
     assert float(np.abs(prob.numpy() - g["prob"]).max()) < 1e-5
+
+
+def test_roi_pool_restatement_against_an_independent_implementation():
+    """The reference has no CPU ROIPool (ROIPool.h:47,68 raise on CPU tensors), so the C restatement of
+    cuda/ROIPool_cuda.cu:40-132 cannot be pinned by reference outputs.  Second-best pin: the algorithm it restates (Fast
+    R-CNN RoI max pooling: bin p covers [floor(p*s), ceil((p+1)*s)) of the RoI, s = roi_size / pooled_size) is what torch's
+    adaptive_max_pool2d computes on the cropped RoI (an independent implementation); for in-bounds RoIs with integer
+    corners at spatial_scale 1 -- where the float bin arithmetic has no rounding ambiguity (sizes that divide or are
+    dyadic multiples of 7 excluded from nothing: both sides use floor / ceil of the same rational) -- values AND argmax
+    positions must agree; the backward is then checked as the exact adjoint (scatter of the argmax)."""
+    import torch
+    import torch.nn.functional as F
+
+    import oracle
+
+    rs = np.random.RandomState(17)
+    B, C, H, W = 2, 5, 23, 31
+    x = rs.randn(B, C, H, W).astype(np.float32)
+    rois, crops = [], []
+    for _ in range(40):
+        b = rs.randint(0, B)
+        x1, y1 = rs.randint(0, W - 8), rs.randint(0, H - 8)
+        x2, y2 = rs.randint(x1 + 6, W), rs.randint(y1 + 6, H)          # at least 7 cells a side: no empty bins
+        rois.append([b, x1, y1, x2, y2])
+    rois = np.asarray(rois, np.float32)
+    out, arg = oracle.roi_pool_forward(x, rois, (7, 7), 1.0)
+    for k, (b, x1, y1, x2, y2) in enumerate(rois.astype(int)):
+        crop = torch.from_numpy(x[b:b + 1, :, y1:y2 + 1, x1:x2 + 1])
+        ref, idx = F.adaptive_max_pool2d(crop, (7, 7), return_indices=True)
+        assert np.array_equal(out[k], ref[0].numpy()), k
+        cw = x2 - x1 + 1
+        iy, ix = idx[0].numpy() // cw + y1, idx[0].numpy() % cw + x1      # crop index -> map position
+        assert np.array_equal(arg[k], (iy * W + ix).astype(np.int32)), k
+    g = rs.randn(*out.shape).astype(np.float32)
+    gin = oracle.roi_pool_backward(g, arg, rois, (7, 7), (B, C, H, W))
+    ref = np.zeros((B, C, H, W), np.float64)
+    for k in range(len(rois)):
+        b = int(rois[k, 0])
+        for c in range(C):
+            np.add.at(ref[b, c].reshape(-1), arg[k, c].reshape(-1), g[k, c].reshape(-1).astype(np.float64))
+    assert np.abs(gin - ref).max() < 1e-5
