@@ -179,6 +179,12 @@ STEP_API int step_conv_forward_ws(const step_conv_desc* d, const void* x, const 
  * caller runs the two launches instead). */
 STEP_API int step_pool3_conv1_forward(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale,
                                       const float* shift, void* y, step_stream_t stream);
+/* The same for the (1,3,3) window / (1,2,2) stride TF-"SAME" pool in front of a 1x1x1 unit -- maxPool3d_2a_3x3 -> conv3d_2b_1x1
+ * (models/i3dpt.py:193-201): x [N, D, Hi, Wi, x_cstride] is pooled to [N, D, ceil(Hi/2), ceil(Wi/2)] = d's N, D, H, W (the
+ * back-heavy TF pad of one row / column carries the VALUE 0), then the conv.  Bit-identical to step_maxpool3d_tf +
+ * step_conv_forward; the pooled tensor (51 MB written and read back per C2 batch) never reaches memory. */
+STEP_API int step_pool133s2_conv1_forward(const step_conv_desc* d, int Hi, int Wi, const void* x, const void* w_packed,
+                                          const float* scale, const float* shift, void* y, step_stream_t stream);
 /* Diagnostic, as step_conv_kernel_name. */
 STEP_API int step_pool3_conv1_kernel_name(const step_conv_desc* d, char* buf, int buflen);
 

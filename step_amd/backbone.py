@@ -468,7 +468,8 @@ class Mixed(nn.Module):
         """max pool 3x3x3 / 1 -> 1x1x1 unit into `out` (inference path).  One launch (step_pool3_conv1_forward: the pooled
         tensor never reaches memory); returns the pooled scratch tensor when the two-launch form had to be used, else None."""
         pool, unit = self.branch_3[0], self.branch_3[1]
-        if FUSE_POOL_CONV and pool.kernel_size == (3, 3, 3) and pool.stride == (1, 1, 1):
+        fuse = FUSE_POOL_CONV == "1"
+        if fuse and pool.kernel_size == (3, 3, 3) and pool.stride == (1, 1, 1):
             cu = unit._unit
             scale, shift = cu.affine()
             if shift is not None:
@@ -526,11 +527,15 @@ def wgrad_sync():
     del _KEEP[:]
 
 
-# branch_3 of an Inception block as one launch (step_pool3_conv1_forward).  Off by default: measured on MI355X (C2, bf16,
-# tools/ab_bench.py --set b3, profiles/r02_ab_b3.txt) the first version of the fused kernel is latency-bound -- one slab
-# of prefetch does not cover the halo's global-memory round trip (3.2 us per 64-byte slab against 0.4 us of work) -- and
-# loses to the two launches (350 us against 192 us per step); STEP_FUSE_POOL_CONV=1 selects it.
-FUSE_POOL_CONV = os.environ.get("STEP_FUSE_POOL_CONV", "0") == "1"
+# Pool -> 1x1x1 unit pairs as one launch (step_pool3_conv1_forward for an Inception block's branch_3,
+# step_pool133s2_conv1_forward for maxPool3d_2a -> conv3d_2b): bit-identical to the two launches and 0.5 GB less traffic per
+# C2 step, but measured SLOWER on MI355X in both versions of the kernel (tools/ab_bench.py --set b3, bf16, us per step over the
+# seven branch_3 layers: two launches 193, fused with one slab of prefetch 350, with a three-slab register ring 328; C2
+# 5450 clips/s unfused, 5385 with the 28x28 layers fused, 4960 with everything fused).  The per-slab pool pass (up to 54
+# dependent LDS reads per thread between two barriers) is the cost, not the halo latency the ring was built to hide.
+# Opt-in: STEP_FUSE_POOL_CONV=1.
+FUSE_POOL_CONV = os.environ.get("STEP_FUSE_POOL_CONV", "0")
+FUSE_POOL_CONV_MIN_PIXELS = 0
 BRANCH_STREAMS = True          # run the independent Inception branches on side streams (inference path)
 WGRAD_SIDE_STREAM = os.environ.get("STEP_WGRAD_STREAM", "1") != "0"   # training: weight gradient beside the data gradient
 _SIDE = {}
@@ -700,7 +705,28 @@ class BaseNet(nn.Module):
     def forward(self, x):
         if x.dim() != 5 or x.shape[2] != 3:
             raise RuntimeError("BaseNet expects [batch, T, 3, H, W]")
-        y = self.base_model(x.contiguous())
+        y = x.contiguous()
+        stages = list(self.base_model)
+        i = 0
+        while i < len(stages):
+            st = stages[i]
+            nxt = stages[i + 1] if i + 1 < len(stages) else None
+            # (measured: C2 5397 / 5418 clips/s fused against 5402 / 5396 unfused: opt-in, see FUSE_POOL_CONV)
+            if (FUSE_POOL_CONV == "1" and isinstance(st, MaxPoolTF) and st.kernel_size == (1, 3, 3) and st.stride == (1, 2, 2)
+                    and isinstance(nxt, Unit3D) and nxt.kernel_size == (1, 1, 1) and not nxt.is_stem
+                    and not (torch.is_grad_enabled() and (y.requires_grad or any(p.requires_grad for p in nxt.parameters())))):
+                # maxPool3d_2a_3x3 -> conv3d_2b_1x1 as one launch (inference path): the pooled tensor never reaches memory
+                cu = nxt._unit
+                scale, shift = cu.affine()
+                if shift is not None:
+                    shift = shift.detach().contiguous()
+                z = ops.pool133s2_conv1_forward(y, cu.packed(y.dtype), cu.cout, scale, shift, nxt.relu)
+                if z is not None:
+                    y = z
+                    i += 2
+                    continue
+            y = st(y)
+            i += 1
         return y.permute(0, 1, 4, 2, 3)
 
     def train(self, mode=True):

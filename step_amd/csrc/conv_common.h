@@ -21,6 +21,7 @@ struct ConvParams {
     const void* x; const void* w; const float* scale; const float* shift; const void* res; void* y; void* y2;
     int split, y2_cstride, y2_coff;
     int N, D, H, W, Cin, Cout;
+    int Hi, Wi;    // input extent where it differs from the output's (the strided-pool form of pool_pw_kernel); else unused
     int x_cstride, x_coff, y_cstride, y_coff, r_cstride, r_coff;
     int relu;
     int tiles_h, tiles_w, tiles_d;

@@ -16,6 +16,9 @@
 //   gemm  : wave w multiplies 32 pixels of the A tile with the slab's weights -- B fragments straight from the packed
 //           weights in global memory (a few KiB per slab, L2-resident, requested before the pool pass) -- into its fp32
 //           accumulators.
+// S2 = true: the same with the (1,3,3) / (1,2,2) pool of maxPool3d_2a_3x3 in front of conv3d_2b_1x1 (models/i3dpt.py:193-201):
+// planes are independent, the halo of a TD x TH x TW output box is TD x (2 TH + 1) x (2 TW + 1) input pixels, the TF pad is
+// back-heavy (window of output (h, w) = input rows 2h .. 2h+2: no front pad), every (plane, h, w, vector) is its own pool column.
 // Two barriers per slab; with ~45 KiB of LDS three workgroups share a CU, so one workgroup's pool pass (LDS-bound) runs under
 // another's loads.  WN = 2 (boxes of <= 64 pixels, e.g. one 7 x 7 quadrant plane of a 14 x 14 map): the four waves are
 // 2 (pixels) x 2 (channel halves) instead of 4 x 1.
@@ -27,7 +30,10 @@ namespace step {
 constexpr int PPW_NPIX = 512;            // halo pixels of a box (32 KiB of LDS)
 constexpr int PPW_PK = 2;                // pool columns per thread: TH*TW*4 <= 512
 
-template <typename T, int NBW, int WN>
+// DEPTH = slabs of the halo in flight (register sets): 1 measured latency-bound (3.2 us per slab against 0.4 us of work);
+// with DEPTH sets the loads of slab s + DEPTH are issued while slab s is processed.  The slab loop is unrolled by DEPTH and
+// branch-free: slabs past the end stage zeros (a zero pooled tile against finite weights adds nothing).
+template <typename T, int NBW, int WN, bool S2 = false, int DEPTH = 3>
 __global__ __launch_bounds__(256, 2) void pool_pw_kernel(ConvParams p) {
     static_assert(WN == 1 || WN == 2, "4 x 1 or 2 x 2 waves");
     constexpr int NT = 256;
@@ -62,7 +68,8 @@ __global__ __launch_bounds__(256, 2) void pool_pw_kernel(ConvParams p) {
     if (!grid_coords(p, gbx, gby)) return;
     const int TD = p.gtd, TH = p.gth, TW = p.gtw;
     const int TPX = TD * TH * TW;
-    const int HH_ = TH + 2, HW_ = TW + 2, PD = TD + 2;
+    const int HH_ = S2 ? 2 * TH + 1 : TH + 2, HW_ = S2 ? 2 * TW + 1 : TW + 2, PD = S2 ? TD : TD + 2;
+    const int Hin = S2 ? p.Hi : p.H, Win = S2 ? p.Wi : p.W;      // input extent (S2: the pool halves H and W)
     const int HHW = HH_ * HW_;
     const int NVEC = PD * HHW * 4;
     int t = gbx;
@@ -89,30 +96,32 @@ __global__ __launch_bounds__(256, 2) void pool_pw_kernel(ConvParams p) {
             const int pix = v >> 2;
             const int plane = pix / HHW, rem = pix % HHW;
             const int r = rem / HW_, cc = rem % HW_;
-            const int id = d0 + plane - 1, ih = h0 + r - 1, iw = w0 + cc - 1;
-            if (id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
-                const size_t gpix = (((size_t)n * p.D + id) * p.H + ih) * p.W + iw;
+            const int id = S2 ? d0 + plane : d0 + plane - 1, ih = S2 ? 2 * h0 + r : h0 + r - 1, iw = S2 ? 2 * w0 + cc : w0 + cc - 1;
+            if (id >= 0 && id < p.D && ih >= 0 && ih < Hin && iw >= 0 && iw < Win) {
+                const size_t gpix = (((size_t)n * p.D + id) * Hin + ih) * Win + iw;
                 goff[it] = (unsigned)(gpix * p.x_cstride + p.x_coff);
                 gmask[it] = 0xffffffffu;
             }
         }
     }
-    u32x4 stage[ITER];
+    u32x4 stage[DEPTH][ITER];
     // branch-free loads (a predicated load makes the compiler drain vmcnt): positions outside the image re-read pixel 0 of
     // the tensor, channels past Cin re-read channel 0; both are masked when the vector is written to LDS
-    auto load_slab = [&](int slab) {
+    auto load_slab = [&](int slab, auto setc) {
+        constexpr int SET = decltype(setc)::value;
         const int c = slab * CKT + slotc;
         const int ce = (slab < nslab && c < p.Cin) ? c : 0;
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) stage[it] = *(const u32x4*)(xg + ((size_t)goff[it] + ce) * ES);
+        for (int it = 0; it < ITER; ++it) stage[SET][it] = *(const u32x4*)(xg + ((size_t)goff[it] + ce) * ES);
     };
-    auto store_slab = [&](int slab) {
+    auto store_slab = [&](int slab, auto setc) {
+        constexpr int SET = decltype(setc)::value;
         const unsigned cm = (slab * CKT + slotc < p.Cin) ? 0xffffffffu : 0u;
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int v = tid + it * NT;
             if (v < NVEC) {
-                const u32x4 mv = stage[it] & (gmask[it] & cm);
+                const u32x4 mv = stage[SET][it] & (gmask[it] & cm);
                 *(raw*)(halo + v * 16) = VecMax<T>::enc(__builtin_bit_cast(raw, mv));
             }
         }
@@ -120,14 +129,21 @@ __global__ __launch_bounds__(256, 2) void pool_pw_kernel(ConvParams p) {
 
     // ---- pool columns of this thread: (h, w, slot) -> LDS offsets of the window's first vector / of the A-tile row
     int hoff[PPW_PK], aoff[PPW_PK];
-    const int ncol = TH * TW * 4;
+    const int ncol = (S2 ? TD : 1) * TH * TW * 4;              // S2: every plane of the box is its own set of columns
 #pragma unroll
     for (int k = 0; k < PPW_PK; ++k) {
         const int item = tid + k * NT;
         const int hw = item >> 2, slot = item & 3;
-        const int h = hw / TW, w = hw % TW;
-        hoff[k] = item < ncol ? (h * HW_ + w) * HP + slot * 16 : -1;
-        aoff[k] = (h * TW + w) * AP + slot * 16;
+        if (S2) {
+            const int w = hw % TW, q = hw / TW;
+            const int h = q % TH, d = q / TH;
+            hoff[k] = item < ncol ? ((d * HH_ + 2 * h) * HW_ + 2 * w) * HP + slot * 16 : -1;
+            aoff[k] = hw * AP + slot * 16;                      // tile pixel index = (d * TH + h) * TW + w = hw
+        } else {
+            const int h = hw / TW, w = hw % TW;
+            hoff[k] = item < ncol ? (h * HW_ + w) * HP + slot * 16 : -1;
+            aoff[k] = (h * TW + w) * AP + slot * 16;
+        }
     }
     const int planeB = HHW * HP, rowB = HW_ * HP, aplaneB = TH * TW * AP;
     const raw klow = VecMax<T>::lowest();
@@ -138,6 +154,19 @@ __global__ __launch_bounds__(256, 2) void pool_pw_kernel(ConvParams p) {
             raw m1 = klow, m2 = klow;
             const unsigned char* b = halo + hoff[k];
             unsigned char* a = ldsA + aoff[k];
+            if (S2) {                                        // one plane, one 3 x 3 window
+                raw m = *(const raw*)b;
+                m = VecMax<T>::max(m, *(const raw*)(b + HP));
+                m = VecMax<T>::max(m, *(const raw*)(b + 2 * HP));
+                m = VecMax<T>::max(m, *(const raw*)(b + rowB));
+                m = VecMax<T>::max(m, *(const raw*)(b + rowB + HP));
+                m = VecMax<T>::max(m, *(const raw*)(b + rowB + 2 * HP));
+                m = VecMax<T>::max(m, *(const raw*)(b + 2 * rowB));
+                m = VecMax<T>::max(m, *(const raw*)(b + 2 * rowB + HP));
+                m = VecMax<T>::max(m, *(const raw*)(b + 2 * rowB + 2 * HP));
+                *(raw*)a = VecMax<T>::dec(m);
+                continue;
+            }
             for (int pd = 0; pd < PD; ++pd) {
                 raw m = *(const raw*)b;
                 m = VecMax<T>::max(m, *(const raw*)(b + HP));
@@ -172,16 +201,17 @@ __global__ __launch_bounds__(256, 2) void pool_pw_kernel(ConvParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    load_slab(0);
-    for (int s = 0; s < nslab; ++s) {
-        store_slab(s);
+    static_for<DEPTH>([&](auto sc) { load_slab(decltype(sc)::value, sc); });
+    auto process = [&](int s, auto setc) {
+        store_slab(s, setc);                              // (slabs past the end: zeros)
         __syncthreads();                                  // halo slab visible; every wave is done with the previous A tile
         frag_t fb[NBW][KS];
+        const int sb = min(s, nslab - 1);                 // (past the end: finite weights against a zero tile)
 #pragma unroll
         for (int i = 0; i < NBW; ++i)
 #pragma unroll
-            for (int j = 0; j < KS; ++j) fb[i][j] = load_b_frag<T>(wthr[i] + (size_t)(s * KS + j) * 512);
-        load_slab(s + 1);                                 // (past the end: a harmless re-read)
+            for (int j = 0; j < KS; ++j) fb[i][j] = load_b_frag<T>(wthr[i] + (size_t)(sb * KS + j) * 512);
+        load_slab(s + DEPTH, setc);                       // (past the end: a harmless re-read)
         pool_pass();
         __syncthreads();                                  // A tile complete; the halo may be overwritten
 #pragma unroll
@@ -190,7 +220,9 @@ __global__ __launch_bounds__(256, 2) void pool_pw_kernel(ConvParams p) {
 #pragma unroll
             for (int i = 0; i < NBW; ++i) mma_k16(fa, fb[i][j], acc[i], T());
         }
-    }
+    };
+#pragma unroll 1
+    for (int s0 = 0; s0 < nslab; s0 += DEPTH) static_for<DEPTH>([&](auto sc) { process(s0 + decltype(sc)::value, sc); });
 
     // ---- epilogue: affine + ReLU, channels-last store
     T* yg = (T*)p.y;
@@ -261,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void pool_pw_kernel(ConvParams p) {
 // do not finish sooner than 512.
 struct PoolPwPlan { bool ok; int td, th, tw, nbw, wn, groups; long long tiles; };
 
-static PoolPwPlan pool_pw_plan(const step_conv_desc* d) {
+static PoolPwPlan pool_pw_plan(const step_conv_desc* d, bool s2 = false) {
     PoolPwPlan best; best.ok = false; best.td = best.th = best.tw = 1; best.nbw = 1; best.wn = 1; best.groups = 1; best.tiles = 0;
     const int nblk32 = ceil_div(d->Cout, 32);
     double best_cost = -1;
@@ -279,11 +311,11 @@ static PoolPwPlan pool_pw_plan(const step_conv_desc* d) {
                 for (int kw_ = 1; kw_ <= d->W; ++kw_) {
                     const int tw = ceil_div(d->W, kw_);
                     if (kw_ > 1 && tw == ceil_div(d->W, kw_ - 1)) continue;
-                    if (td * th * tw > cap || th * tw * 4 > PPW_PK * 256) continue;
-                    const int halo = (td + 2) * (th + 2) * (tw + 2);
+                    if (td * th * tw > cap || (s2 ? td : 1) * th * tw * 4 > PPW_PK * 256) continue;
+                    const int halo = s2 ? td * (2 * th + 1) * (2 * tw + 1) : (td + 2) * (th + 2) * (tw + 2);
                     if (halo > PPW_NPIX) continue;
                     const long long tiles = (long long)d->N * ceil_div(d->D, td) * ceil_div(d->H, th) * ceil_div(d->W, tw);
-                    const double per = halo * 8.0 + th * tw * 4.0 * (td + 2) * 9.0 + 4000.0;
+                    const double per = halo * 8.0 + (s2 ? td * th * tw * 4.0 * 9.0 : th * tw * 4.0 * (td + 2) * 9.0) + 4000.0;
                     const long long wgs = tiles * groups;
                     const double cost = (double)(wgs < 512 ? 512 : wgs) * per;
                     if (best_cost < 0 || cost < best_cost) {
@@ -296,9 +328,13 @@ static PoolPwPlan pool_pw_plan(const step_conv_desc* d) {
     return best;
 }
 
-template <typename T>
+template <typename T, bool S2>
 static int pool_pw_launch(const PoolPwPlan& pl, const ConvParams& p, dim3 grid, step_stream_t stream) {
-#define STEP_PPW(NBW_, WN_) STEP_LAUNCH((pool_pw_kernel<T, NBW_, WN_>), grid, dim3(256), stream, p)
+    // halo slabs in flight: 3, or 2 when that wastes less of a short K loop (the loop runs whole rounds of DEPTH slabs)
+    const int nslab = ceil_div(p.Cin, 64 / (int)sizeof(T));
+    const bool two = ceil_div(nslab, 2) * 2 < ceil_div(nslab, 3) * 3 || pl.nbw == 4;      // (four accumulator tiles + three sets spill)
+#define STEP_PPW(NBW_, WN_) do { if (two) STEP_LAUNCH((pool_pw_kernel<T, NBW_, WN_, S2, 2>), grid, dim3(256), stream, p); \
+                                 else STEP_LAUNCH((pool_pw_kernel<T, NBW_, WN_, S2, 3>), grid, dim3(256), stream, p); } while (0)
     if (pl.wn == 2) {
         if (pl.nbw == 1) STEP_PPW(1, 2); else STEP_PPW(2, 2);
     } else {
@@ -329,21 +365,25 @@ static int pool_conv_check(const step_conv_desc* d) {
     return STEP_OK;
 }
 
-int step_pool3_conv1_forward(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
-                             void* y, step_stream_t stream) {
+// d describes the 1x1x1 conv on the POOLED tensor; s2: the (1,3,3)/(1,2,2) pool in front of it reads x [N, D, Hi, Wi]
+static int pool_conv_forward_impl(const step_conv_desc* d, bool s2, int Hi, int Wi, const void* x, const void* w_packed, const float* scale,
+                                  const float* shift, void* y, step_stream_t stream) {
     const int chk = pool_conv_check(d);
     if (chk != STEP_OK) return chk;
+    if (s2 && (Hi <= 0 || Wi <= 0 || (Hi + 1) / 2 != d->H || (Wi + 1) / 2 != d->W)) return STEP_E_SHAPE;   // ceil(L / 2): step_pool_out_size(L, 3, 2)
+    if (s2 && ((unsigned long long)d->N * d->D * Hi * Wi + 1) * (unsigned long long)d->x_cstride >= 0xffffffffULL) return STEP_E_UNSUPPORTED;
     if (d->N == 0) return STEP_OK;
     if (!x || !w_packed || !y) return STEP_E_NULL;
     const int vec = d->dtype == STEP_F32 ? 4 : 8;
     if (d->Cin % vec || d->x_cstride % vec || d->x_coff % vec) return STEP_E_ALIGN;
     if (((uintptr_t)x % 16) || ((uintptr_t)w_packed % 16)) return STEP_E_ALIGN;
-    const PoolPwPlan pl = pool_pw_plan(d);
+    const PoolPwPlan pl = pool_pw_plan(d, s2);
     if (!pl.ok) return STEP_E_UNSUPPORTED;
     ConvParams p;
     p.x = x; p.w = w_packed; p.scale = scale; p.shift = shift; p.res = nullptr; p.y = y; p.y2 = nullptr;
     p.split = 0; p.y2_cstride = 0; p.y2_coff = 0;
     p.N = d->N; p.D = d->D; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
+    p.Hi = s2 ? Hi : d->H; p.Wi = s2 ? Wi : d->W;
     p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
     p.r_cstride = 0; p.r_coff = 0;
     p.relu = d->relu;
@@ -356,11 +396,28 @@ int step_pool3_conv1_forward(const step_conv_desc* d, const void* x, const void*
     p.gx = (int)pl.tiles; p.gy = pl.groups;
     const long long tot = pl.tiles * pl.groups;
     const dim3 grid((unsigned)((tot + 7) / 8 * 8));
-    switch (d->dtype) {
-        case STEP_F32: return pool_pw_launch<float>(pl, p, grid, stream);
-        case STEP_BF16: return pool_pw_launch<bf16_t>(pl, p, grid, stream);
-        default: return pool_pw_launch<f16_t>(pl, p, grid, stream);
+    if (s2) {
+        switch (d->dtype) {
+            case STEP_F32: return pool_pw_launch<float, true>(pl, p, grid, stream);
+            case STEP_BF16: return pool_pw_launch<bf16_t, true>(pl, p, grid, stream);
+            default: return pool_pw_launch<f16_t, true>(pl, p, grid, stream);
+        }
     }
+    switch (d->dtype) {
+        case STEP_F32: return pool_pw_launch<float, false>(pl, p, grid, stream);
+        case STEP_BF16: return pool_pw_launch<bf16_t, false>(pl, p, grid, stream);
+        default: return pool_pw_launch<f16_t, false>(pl, p, grid, stream);
+    }
+}
+
+int step_pool3_conv1_forward(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
+                             void* y, step_stream_t stream) {
+    return pool_conv_forward_impl(d, false, 0, 0, x, w_packed, scale, shift, y, stream);
+}
+
+int step_pool133s2_conv1_forward(const step_conv_desc* d, int Hi, int Wi, const void* x, const void* w_packed, const float* scale,
+                                 const float* shift, void* y, step_stream_t stream) {
+    return pool_conv_forward_impl(d, true, Hi, Wi, x, w_packed, scale, shift, y, stream);
 }
 
 int step_pool3_conv1_kernel_name(const step_conv_desc* d, char* buf, int buflen) {

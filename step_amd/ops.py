@@ -167,6 +167,31 @@ def pool3_conv1_forward(x, w_packed, Cout, scale=None, shift=None, relu=True, ou
     return out
 
 
+def pool133s2_conv1_forward(x, w_packed, Cout, scale=None, shift=None, relu=True):
+    """y = act(conv1x1x1(maxpool_tf(x, (1,3,3), (1,2,2))) * scale + shift) in one launch (maxPool3d_2a_3x3 -> conv3d_2b_1x1,
+    models/i3dpt.py:193-201); x channels-last [N,D,Hi,Wi,Cin].  Returns None when the library declines the shape."""
+    L = _lib.lib()
+    N, D, Hi, Wi, Cin = x.shape
+    Ho, Wo = L.step_pool_out_size(Hi, 3, 2), L.step_pool_out_size(Wi, 3, 2)
+    out = torch.empty((N, D, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+    d = _capi.ConvDesc(dtype=_dt(x), N=N, D=D, H=Ho, W=Wo, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=_chan_slice(x), x_coff=0,
+                       y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=int(bool(relu)), split=0, y2_cstride=0, y2_coff=0)
+    prof = _NOPROF
+    if PROFILE is not None:
+        buf = ctypes.create_string_buffer(256)
+        if L.step_pool3_conv1_kernel_name(ctypes.byref(d), buf, 256) == 0:
+            pix = N * D * Ho * Wo
+            name = buf.value.decode().replace(">(step::ConvParams)", ", true>(step::ConvParams)")
+            prof = _Prof(name, 2.0 * pix * Cout * Cin, (x.numel() + pix * Cout + Cout * Cin) * _ES[x.dtype])
+    with prof:
+        st = L.step_pool133s2_conv1_forward(ctypes.byref(d), Hi, Wi, _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift),
+                                            _lib.dptr(out), _lib.stream_ptr(x.device))
+    if st == -4:
+        return None
+    _capi.check(st, "step_pool133s2_conv1_forward")
+    return out
+
+
 def conv_wgrad(x, gy, Cout, k, into=None):
     """Weight gradient of the stride-1 SAME conv: x channels-last [N,D,H,W,Cin] (any storage dtype, may be a channel
     slice), gy fp32 channels-last [N,D,H,W,Cout] (gradient w.r.t. the conv output before the affine epilogue).

@@ -688,6 +688,41 @@ def case_pool3_conv1_fused(bk, golden):
     assert bk.lib.step_pool3_conv1_forward(ctypes.byref(d), z.ptr, z.ptr, None, None, z.ptr, bk.stream) == -4
 
 
+def case_pool133s2_conv1_fused(bk, golden):
+    """step_pool133s2_conv1_forward (maxPool3d_2a_3x3 -> conv3d_2b_1x1 as one launch: (1,3,3) / (1,2,2) TF-SAME pool, back-heavy
+    zero-VALUED pad, then the 1x1x1 unit) against the oracle and, bit for bit, against step_maxpool3d_tf + step_conv_forward."""
+    L = bk.lib
+    for (N, Cin, Cout, D, Hi, Wi) in ((1, 64, 64, 3, 16, 28), (2, 40, 32, 2, 9, 13), (1, 24, 160, 1, 7, 31)):   # even / odd extents (pad row / column), ragged slab, channel groups
+        rs = np.random.RandomState(Cin + Hi)
+        x = rs.randn(N, Cin, D, Hi, Wi).astype(np.float32) - 0.6
+        w = (rs.randn(Cout, Cin, 1, 1, 1) / np.sqrt(Cin)).astype(np.float32)
+        scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32)
+        shift = (0.2 * rs.randn(Cout)).astype(np.float32)
+        Ho, Wo = L.step_pool_out_size(Hi, 3, 2), L.step_pool_out_size(Wi, 3, 2)
+        for dt in (F32, BF16):
+            xe = bk.dev(encode(cl(x), dt))
+            wp = pack_weight(bk, w, dt)
+            sc, sh = bk.dev(scale), bk.dev(shift)
+            d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=Ho, W=Wo, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=Cin, x_coff=0, y_cstride=Cout,
+                               y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+            y = bk.dev(np.zeros((N, D, Ho, Wo, Cout), NP_DT[dt]))
+            assert L.step_pool133s2_conv1_forward(ctypes.byref(d), Hi, Wi, xe.ptr, wp.ptr, sc.ptr, sh.ptr, y.ptr, bk.stream) == 0
+            pb = bk.dev(np.zeros((N, D, Ho, Wo, Cin), NP_DT[dt]))
+            assert L.step_maxpool3d_tf(dt, xe.ptr, N, D, Hi, Wi, Cin, Cin, 0, 1, 3, 3, 1, 2, 2, pb.ptr, Cin, 0, bk.stream) == 0
+            y2 = bk.dev(np.zeros((N, D, Ho, Wo, Cout), NP_DT[dt]))
+            assert L.step_conv_forward(ctypes.byref(d), pb.ptr, wp.ptr, sc.ptr, sh.ptr, None, y2.ptr, None, bk.stream) == 0
+            got = uncl(decode(y.get(), dt))
+            pooled = R.maxpool_tf(torch.from_numpy(quantize(x, dt)), (1, 3, 3), (1, 2, 2)).numpy()
+            ref = ref_conv(pooled, w, scale, shift, dt)
+            err = np.abs(got - ref).max() / np.abs(ref).max()
+            assert err < tol(dt), (N, Cin, Cout, Hi, Wi, dt, err)
+            assert np.array_equal(y.get(), y2.get()), (N, Cin, Cout, Hi, Wi, dt)
+    d = _capi.ConvDesc(dtype=F32, N=1, D=1, H=5, W=5, Cin=16, Cout=32, kd=1, kh=1, kw=1, x_cstride=16, x_coff=0, y_cstride=32,
+                       y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+    z = bk.dev(np.zeros(16, np.float32))
+    assert L.step_pool133s2_conv1_forward(ctypes.byref(d), 12, 10, z.ptr, z.ptr, None, None, z.ptr, bk.stream) == -2     # ceil(12 / 2) != 5
+
+
 def big_pool3_conv1(bk, golden):
     """branch_3 at real Inception shapes (one clip of C2 / an AVA clip), 16-bit and fp32."""
     for case in ((1, 192, 32, 16, 28, 28), (1, 480, 64, 8, 14, 14), (1, 528, 128, 8, 14, 14), (1, 256, 64, 6, 50, 50),
