@@ -132,10 +132,14 @@ def conv_forward(x, w_packed, Cout, k, scale=None, shift=None, relu=True, res=No
                      (pix * (Cin + Cout) + Cout * Cin * k[0] * k[1] * k[2]) * _ES[x.dtype])
     wsb = L.step_conv_workspace_bytes(ctypes.byref(d))            # > 0 only for the split-K Linear layers of the heads
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
-    with prof:
+    def launch():
         _capi.check(L.step_conv_forward_ws(ctypes.byref(d), _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift),
                                            _lib.dptr(res), _lib.dptr(out), _lib.dptr(out2), _lib.dptr(ws), wsb,
                                            _lib.stream_ptr(x.device)), "step_conv_forward_ws")
+    if PROFILE is not None:
+        launch()           # untimed twin right in front of the timed launch (idempotent): the event pair then brackets a launch that
+    with prof:             # runs back to back with GPU work -- after an idle gap a short kernel is timed at ramped-down clocks (3x off)
+        launch()
     return out
 
 
@@ -301,9 +305,13 @@ def stem_forward(x, w_packed, Cout, scale, shift, out=None):
         _capi.check(L.step_stem_kernel_name(_dt(x), buf, 256), "step_stem_kernel_name")
         prof = _Prof(buf.value.decode(), 2.0 * pix * Cout * 1029,
                      (x.numel() + pix * Cout + Cout * 1029) * _ES[x.dtype])
-    with prof:
+    def launch():
         _capi.check(L.step_stem_forward(_dt(x), _lib.dptr(x), N, T, H, W, _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift),
                                         Cout, _lib.dptr(out), _chan_slice(out), 0, _lib.stream_ptr(x.device)), "step_stem_forward")
+    if PROFILE is not None:
+        launch()           # (untimed twin, see conv_forward)
+    with prof:
+        launch()
     return out
 
 
@@ -333,13 +341,17 @@ def maxpool_tf(x, k, s, out=None):
         ks = (tuple(k), tuple(s))
         sep = ks in (((3, 3, 3), (1, 1, 1)), ((1, 3, 3), (1, 2, 2)), ((3, 3, 3), (2, 2, 2))) and not os.environ.get("STEP_POOL_DIRECT")
         tn = _TNAME[x.dtype]
-        kn = ("maxpool_sep_kernel<%s, %d, %d, %d, %d, %d, %d>" % ((tn,) + ks[0] + ks[1]), ", int" * 7) if sep else \
+        kn = ("maxpool_sep_kernel<%s, %d, %d, %d, %d, %d, %d, 256>" % ((tn,) + ks[0] + ks[1]), ", int" * 7) if sep else \
             ("maxpool3d_tf_kernel<%s>" % tn, ", long long")
         prof = _Prof("void step::%s(%s const*, %s*, step::PoolParams%s)" % (kn[0], tn, tn, kn[1]),
                      0.0, (x.numel() + out.numel()) * _ES[x.dtype])
-    with prof:
+    def launch():
         _capi.check(L.step_maxpool3d_tf(_dt(x), _lib.dptr(x), N, D, H, W, C, _chan_slice(x), 0, k[0], k[1], k[2], s[0], s[1], s[2],
                                         _lib.dptr(out), _chan_slice(out), 0, _lib.stream_ptr(x.device)), "step_maxpool3d_tf")
+    if PROFILE is not None:
+        launch()           # (untimed twin, see conv_forward)
+    with prof:
+        launch()
     return out
 
 
