@@ -156,6 +156,22 @@ STEP_API int step_conv_pack_weight(const float* w, int Cout, int Cin, int kd, in
  * step_conv_pack_weight on the flipped / transposed / padded tensor, without materialising it. */
 STEP_API int step_conv_pack_weight_dgrad(const float* w, int Cout, int Cin, int kd, int kh, int kw, int dtype, int cin_pad,
                                          void* packed, step_stream_t stream);
+/* Every conv weight of a net re-packed by ONE launch (a training step changes all of them at once: ~290 separate pack
+ * launches per step otherwise).  `items` is a DEVICE array of n descriptors.  An item with dgrad = 0 is
+ * step_conv_pack_weight of the effective weight  w[:, cin_lo + perm_c[j]]  (j < Cin; perm_c NULL = identity) of the
+ * parameter w[Cout][w_cin][taps]; an item with dgrad = 1 is step_conv_pack_weight_dgrad of that effective weight
+ * (Cout = the FORWARD conv's output channels, Cin = its effective input channels, cin_pad >= Cout).  Results are bit-identical
+ * to the single-weight entries. */
+typedef struct step_pack_item {
+    const float* w;          /* the parameter, torch layout [Cout][w_cin][taps], fp32, device */
+    const int32_t* perm_c;   /* optional device int32 [Cin] */
+    void* packed;            /* destination (dtype of the call) */
+    int Cout, Cin, w_cin, cin_lo;
+    int kd, kh, kw;
+    int dgrad, cin_pad;      /* cin_pad: dgrad items only */
+    int reserved;
+} step_pack_item;
+STEP_API int step_conv_pack_weights(const step_pack_item* items, int n, int dtype, step_stream_t stream);
 STEP_API int step_conv_forward(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale,
                                const float* shift, const void* res, void* y, void* y2, step_stream_t stream);
 
@@ -229,6 +245,15 @@ STEP_API int step_stem_forward(int dtype, const void* x, int N, int T, int H, in
  * the affine epilogue).  The stem needs no data gradient (its input is the clip). */
 STEP_API int step_stem_wgrad(int dtype, const void* x, int N, int T, int H, int W, const float* dy, int Cout, float* dw,
                              int accumulate, step_stream_t stream);
+/* The same gradient on the 16-bit matrix instructions (bf16 / fp16 clip; dy in the SAME 16-bit type, channels-last contiguous --
+ * the activation gradient mixed-precision training back-propagates).  One workgroup per CU keeps all 49 x 21 filter columns of a
+ * 32-channel block in registers and reads x and dy once; the partial tiles go through the caller-owned scratch `ws`
+ * (step_stem_wgrad16_workspace_bytes; 16-byte aligned, no initialisation) and are summed in a fixed order: deterministic, no
+ * atomics.  Needs W % 8 == 0 and Cout % 8 == 0 (16-byte rows); the workspace query returns 0 and the call STEP_E_UNSUPPORTED
+ * for other shapes and for fp32, which stay with step_stem_wgrad. */
+STEP_API size_t step_stem_wgrad16_workspace_bytes(int dtype, int N, int T, int H, int W, int Cout);
+STEP_API int step_stem_wgrad16(int dtype, const void* x, int N, int T, int H, int W, const void* dy, int Cout, float* dw,
+                               int accumulate, void* ws, size_t ws_bytes, step_stream_t stream);
 /* Diagnostic, as step_conv_kernel_name: the kernel step_stem_forward launches for this dtype. */
 STEP_API int step_stem_kernel_name(int dtype, char* buf, int buflen);
 

@@ -4,7 +4,7 @@ import ctypes as C
 
 F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 vp, fp, ip, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # raw device addresses
 i, f, ll, sz = C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -15,6 +15,12 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "dtype", "N", "D", "H", "W", "Cin", "Cout", "kd", "kh", "kw", "x_cstride", "x_coff", "y_cstride", "y_coff",
         "res_cstride", "res_coff", "relu", "split", "y2_cstride", "y2_coff")]
+
+
+class PackItem(C.Structure):
+    """struct step_pack_item (include/step_amd.h)"""
+    _fields_ = [("w", C.c_void_p), ("perm_c", C.c_void_p), ("packed", C.c_void_p)] + [(n, C.c_int) for n in (
+        "Cout", "Cin", "w_cin", "cin_lo", "kd", "kh", "kw", "dgrad", "cin_pad", "reserved")]
 
 
 SIGNATURES = {
@@ -29,6 +35,7 @@ SIGNATURES = {
     "step_conv_packed_elems": (sz, [i, i, i, i, i]),
     "step_conv_pack_weight": (i, [fp, i, i, i, i, i, i, ip, vp, vp]),
     "step_conv_pack_weight_dgrad": (i, [fp, i, i, i, i, i, i, i, vp, vp]),
+    "step_conv_pack_weights": (i, [vp, i, i, vp]),
     "step_conv_forward": (i, [C.POINTER(ConvDesc), vp, vp, fp, fp, vp, vp, vp, vp]),
     "step_conv_workspace_bytes": (sz, [C.POINTER(ConvDesc)]),
     "step_conv_wgrad": (i, [C.POINTER(ConvDesc), vp, fp, fp, i, vp]),
@@ -45,6 +52,8 @@ SIGNATURES = {
     "step_stem_forward": (i, [i, vp, i, i, i, i, vp, fp, fp, i, vp, i, i, vp]),
     "step_stem_kernel_name": (i, [i, C.c_char_p, i]),
     "step_stem_wgrad": (i, [i, vp, i, i, i, i, fp, i, fp, i, vp]),
+    "step_stem_wgrad16_workspace_bytes": (sz, [i, i, i, i, i, i]),
+    "step_stem_wgrad16": (i, [i, vp, i, i, i, i, vp, i, fp, i, vp, sz, vp]),
     "step_pool_out_size": (i, [i, i, i]),
     "step_maxpool3d_tf": (i, [i, vp, i, i, i, i, i, i, i, i, i, i, i, i, i, vp, i, i, vp]),
     "step_maxpool3d_tf_backward": (i, [i, vp, i, i, i, i, i, i, i, i, i, i, i, i, i, fp, fp, vp]),

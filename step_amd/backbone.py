@@ -19,6 +19,7 @@ the pixel axis), the pools on step_maxpool3d_tf_backward.  No torch / MIOpen con
 called on either pass; torch does the element-wise mask / scale arithmetic around them.
 """
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -57,7 +58,7 @@ class _ConvUnitFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    def _dgrad(gin, w_eff, dtype, k):
+    def _dgrad(gin, w_eff, dtype, k, unit=None):
         # data gradient = the SAME fused HIP conv on the output gradient with the taps flipped and the channel roles
         # swapped (stride 1, SAME padding): no torch / MIOpen kernel on this leg; the flipped / transposed weight is
         # never materialised (step_conv_pack_weight_dgrad packs it straight from w)
@@ -65,7 +66,7 @@ class _ConvUnitFn(torch.autograd.Function):
         padc = (-gin.shape[-1]) % vec
         if padc:                                                 # e.g. the 60-class / 12-column Linear layers in 16-bit
             gin = torch.nn.functional.pad(gin, (0, padc))
-        wp = ops.pack_conv_weight_dgrad(w_eff, dtype, gin.shape[-1])
+        wp = unit.packed_dgrad(w_eff, dtype, gin.shape[-1]) if unit is not None else ops.pack_conv_weight_dgrad(w_eff, dtype, gin.shape[-1])
         return ops.conv_forward(gin, wp, w_eff.shape[1], k, None, None, False, None, None)
 
     @staticmethod
@@ -116,7 +117,7 @@ class _ConvUnitFn(torch.autograd.Function):
                     _PENDING[0] = True
                     if GRAD_READY is not None:                   # this parameter bypasses autograd's accumulate hook
                         GRAD_READY(ctx.unit.weight_fn(), side)
-                    gx = _ConvUnitFn._dgrad(gact, w_eff, x.dtype, k) if need_x else None
+                    gx = _ConvUnitFn._dgrad(gact, w_eff, x.dtype, k, ctx.unit) if need_x else None
                     return gx, None, None, None, (gact if need_res else None), None, None
                 if need_x and need_w and WGRAD_SIDE_STREAM and x.is_cuda and x.dtype == torch.float32 and ops.PROFILE is None:
                     # the two gradients are independent: the weight gradient (many of them latency-bound launches that fill a
@@ -128,11 +129,11 @@ class _ConvUnitFn(torch.autograd.Function):
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
                         gw = wgrad(x, g32, w_eff.shape[0], k).to(w_eff.dtype)
-                    gx = _ConvUnitFn._dgrad(gact, w_eff, x.dtype, k)
+                    gx = _ConvUnitFn._dgrad(gact, w_eff, x.dtype, k, ctx.unit)
                     main.wait_stream(side)
                     gw.record_stream(main)
                     return gx, gw, None, None, (gact if need_res else None), None, None
-                gx = _ConvUnitFn._dgrad(gact, w_eff, x.dtype, k) if need_x else None
+                gx = _ConvUnitFn._dgrad(gact, w_eff, x.dtype, k, ctx.unit) if need_x else None
                 gw = wgrad(x, g32, w_eff.shape[0], k).to(w_eff.dtype) if need_w else None
                 return gx, gw, None, None, (gact if need_res else None), None, None
         g = gy.float()
@@ -150,11 +151,61 @@ class _ConvUnitFn(torch.autograd.Function):
         gconv = g * scale.view(1, 1, 1, 1, -1) if scale is not None else g
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = _ConvUnitFn._dgrad(gconv.to(x.dtype).contiguous(), w_eff, x.dtype, k)
+            gx = _ConvUnitFn._dgrad(gconv.to(x.dtype).contiguous(), w_eff, x.dtype, k, ctx.unit)
         if ctx.needs_input_grad[1]:
             # weight gradient = the HIP wgrad kernel (fp32 MFMA over the pixel axis) on the same channels-last buffers
             gw = ops.conv_wgrad(x, gconv, w_eff.shape[0], k).to(w_eff.dtype)
         return gx, gw, gscale, gshift, gres, None, None
+
+
+BATCH_PACK = os.environ.get("STEP_BATCH_PACK", "1") != "0"
+_UNITS = weakref.WeakSet()     # every live ConvUnit: an optimizer step stales all their packed images at once
+_TABLES = {}                   # (dtype, device) -> (signature, device table, [(unit, cache key)]) of the last batched re-pack
+
+
+def _repack_all(dtype, device):
+    """Re-pack EVERY stale packed image (forward and data-gradient) of dtype / device held by a live ConvUnit with ONE launch
+    (step_conv_pack_weights) into the buffers the units already own.  A training step changes every weight, and the ~290
+    separate pack launches it caused cost more host time than GPU time.  Returns False when this call may not batch (the
+    caller then packs its own weight as before): on a side stream the launch would not be ordered before the other streams' reads
+    -- every side stream forks from the main one (wait_stream) after this point, so a launch on the main stream is."""
+    if device.type == "cuda":
+        cur = torch.cuda.current_stream(device)
+        if any(cur == s for s in _SIDE.get((device.type, device.index if device.index is not None else torch.cuda.current_device()), ())):
+            return False
+    entries, owners = [], []
+    for u in list(_UNITS):
+        if u.version_fn is not None or not u._packed:
+            continue
+        w = u.weight_fn()
+        if w.device != device or w.dtype != torch.float32 or not w.is_contiguous():
+            continue
+        ver = _ver(w)
+        wcin = w.shape[1]
+        lo, hi = u.cin_slice if u.cin_slice is not None else (0, wcin)
+        perm = None
+        if u.perm is not None:
+            perm = u._perm_dev.get(device)
+            if perm is None:
+                perm = u._perm_dev[device] = u.perm.to(device=device, dtype=torch.int32).contiguous()
+        for key, hit in u._packed.items():
+            if key[0] != dtype or key[1] != device or hit[0] == ver:
+                continue
+            cpad = key[2] if len(key) > 2 else 0
+            entries.append((w.data_ptr(), None if perm is None else perm.data_ptr(), hit[1].data_ptr(), w.shape[0], hi - lo, wcin,
+                            lo, u.k, len(key) > 2, cpad))
+            owners.append((u, key, ver, hit[1]))
+    if not entries:
+        return True
+    sig = tuple(e[:3] for e in entries)
+    cached = _TABLES.get((dtype, device))
+    if cached is None or cached[0] != sig:
+        cached = _TABLES[(dtype, device)] = (sig, ops.pack_table(entries, device))
+    with torch.no_grad():
+        ops.pack_conv_weights(cached[1], len(entries), dtype, device)
+    for u, key, ver, buf in owners:
+        u._packed[key] = (ver, buf)
+    return True
 
 
 class ConvUnit:
@@ -178,8 +229,10 @@ class ConvUnit:
         # version_fn: key of the packed-weight cache when weight_fn() builds a NEW tensor on every call (a torch.cat of
         # several parameters): the temporary's (data_ptr, _version) says nothing about the parameters behind it
         self.version_fn = None if version_fn is None else self._version
-        self._packed = {}
+        self._packed = {}          # (dtype, device) -> (version, forward image); (dtype, device, cin_pad) -> data-gradient image
+        self._perm_dev = {}
         self._affine = None
+        _UNITS.add(self)
 
     def weight_fn(self):
         return self._wf(self.owner)
@@ -223,9 +276,27 @@ class ConvUnit:
             key = (dtype, w.device)
             ver = _ver(w)
             hit = self._packed.get(key)
+        if hit is not None and hit[0] != ver and self.version_fn is None and BATCH_PACK and _repack_all(dtype, w.device):
+            hit = self._packed.get(key)                          # every stale image of the net, this one included, in one launch
         if hit is None or hit[0] != ver:
             with torch.no_grad():
                 hit = (ver, ops.pack_conv_weight(self.effective_weight(), dtype))
+            self._packed[key] = hit
+        return hit[1]
+
+    def packed_dgrad(self, w_eff, dtype, cin_pad):
+        """Packed weight of the data-gradient conv (cached like the forward image; re-packed with it after an optimizer step)."""
+        if self.version_fn is not None:
+            return ops.pack_conv_weight_dgrad(w_eff, dtype, cin_pad)
+        w = self.weight_fn()
+        key = (dtype, w.device, cin_pad)
+        ver = _ver(w)
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] != ver and BATCH_PACK and _repack_all(dtype, w.device):
+            hit = self._packed.get(key)
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                hit = (ver, ops.pack_conv_weight_dgrad(w_eff, dtype, cin_pad))
             self._packed[key] = hit
         return hit[1]
 
@@ -340,6 +411,15 @@ class _StemFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, w, scale, shift, y = ctx.saved_tensors
+        if WGRAD16 and ctx.needs_input_grad[1] and not (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]) and y.dtype != torch.float32 \
+                and x.dtype == y.dtype:
+            # frozen affine, 16-bit activations: ReLU mask x scale in ONE HIP pass (16-bit result), then the weight gradient on the
+            # 16-bit matrix instructions reading clip and gradient once (step_stem_wgrad16) -- as the other units' step_conv_wgrad16
+            fused = ops.act_grad(y, gy, scale, True, want_f32=False, want_act=True)
+            if fused is not None:
+                gw = ops.stem_wgrad16(x, fused[1], w.shape[0])
+                if gw is not None:
+                    return None, gw.to(w.dtype), None, None, None, None
         g = gy.float() * (y > 0).to(torch.float32)
         C = g.shape[-1]
         gw = gscale = gshift = None

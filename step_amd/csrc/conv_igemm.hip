@@ -267,28 +267,57 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 // DGRAD: pack the weight of the DATA-GRADIENT conv straight from the forward weight w [Cw][Cout][taps] (Cw = the forward
 // conv's output channels): effective weight [Cout][Cw][taps] with every tap axis flipped (= the linear tap index
 // reversed), input channels >= Cw (the caller's 16-byte padding) zero.
+// one element of the packed image (idx = its linear index): the effective weight is  w[:, cin_lo + perm[j]]  of the parameter
+// w [.][w_cin][taps]
+template <bool DGRAD>
+__device__ __forceinline__ float pack_value(const float* __restrict__ w, const int32_t* __restrict__ perm, long long idx, int Cout,
+                                            int Cin, int ntaps, int KC16, int Cw, int w_cin, int cin_lo) {
+    const int e = (int)(idx & 7);
+    const int lane = (int)((idx >> 3) & 63);
+    long long q = idx >> 9;
+    const int kc16 = (int)(q % KC16); q /= KC16;
+    const int ntp = taps_padded(ntaps);
+    const int tap = (int)(q % ntp);
+    const int nb = (int)(q / ntp);
+    const int co = nb * 32 + (lane & 31);
+    const int ci = kc16 * 16 + (lane >> 5) * 8 + e;
+    float v = 0.f;
+    if (DGRAD) {
+        if (co < Cout && ci < Cw && tap < ntaps) {
+            const int cs = cin_lo + (perm ? perm[co] : co);
+            v = w[((size_t)ci * w_cin + cs) * ntaps + (ntaps - 1 - tap)];
+        }
+    } else if (co < Cout && ci < Cin && tap < ntaps) {
+        const int cs = cin_lo + (perm ? perm[ci] : ci);
+        v = w[((size_t)co * w_cin + cs) * ntaps + tap];
+    }
+    return v;
+}
+
 template <typename T, bool DGRAD>
 __global__ void pack_weight_kernel(const float* __restrict__ w, const int32_t* __restrict__ perm, T* __restrict__ out,
                                    int Cout, int Cin, int ntaps, int KC16, long long total, int Cw) {
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)blockDim.x * gridDim.x) {
-        const int e = (int)(idx & 7);
-        const int lane = (int)((idx >> 3) & 63);
-        long long q = idx >> 9;
-        const int kc16 = (int)(q % KC16); q /= KC16;
-        const int ntp = taps_padded(ntaps);
-        const int tap = (int)(q % ntp);
-        const int nb = (int)(q / ntp);
-        const int co = nb * 32 + (lane & 31);
-        const int ci = kc16 * 16 + (lane >> 5) * 8 + e;
-        float v = 0.f;
-        if (DGRAD) {
-            if (co < Cout && ci < Cw && tap < ntaps) v = w[((size_t)ci * Cout + co) * ntaps + (ntaps - 1 - tap)];
-        } else if (co < Cout && ci < Cin && tap < ntaps) {
-            const int cs = perm ? perm[ci] : ci;
-            v = w[((size_t)co * Cin + cs) * ntaps + tap];
-        }
-        out[idx] = elem<T>::from_f32(v);
+         idx += (long long)blockDim.x * gridDim.x)
+        out[idx] = elem<T>::from_f32(pack_value<DGRAD>(w, perm, idx, Cout, Cin, ntaps, KC16, Cw, DGRAD ? Cout : Cin, 0));
+}
+
+// every weight of a net in one launch: blockIdx.y = the item, blockIdx.x strides over its packed image
+template <typename T>
+__global__ void pack_weights_kernel(const step_pack_item* __restrict__ items) {
+    const step_pack_item it = items[blockIdx.y];
+    const int ntaps = it.kd * it.kh * it.kw;
+    // the packed conv: forward Cout x Cin; data gradient (channel roles swapped) Cin x cin_pad
+    const int pc_out = it.dgrad ? it.Cin : it.Cout, pc_in = it.dgrad ? it.cin_pad : it.Cin;
+    const int KC16 = (pc_in + CK - 1) / CK * 2;
+    const long long total = (long long)((pc_out + 31) / 32) * taps_padded(ntaps) * KC16 * 512;
+    T* out = (T*)it.packed;
+    if (it.dgrad) {
+        for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)blockDim.x * gridDim.x)
+            out[idx] = elem<T>::from_f32(pack_value<true>(it.w, it.perm_c, idx, pc_out, pc_in, ntaps, KC16, it.Cout, it.w_cin, it.cin_lo));
+    } else {
+        for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)blockDim.x * gridDim.x)
+            out[idx] = elem<T>::from_f32(pack_value<false>(it.w, it.perm_c, idx, pc_out, pc_in, ntaps, KC16, 0, it.w_cin, it.cin_lo));
     }
 }
 
@@ -647,6 +676,23 @@ int step_conv_pack_weight_dgrad(const float* w, int Cout, int Cin, int kd, int k
 }
 
 
+int step_conv_pack_weights(const step_pack_item* items, int n, int dtype, step_stream_t stream) {
+    // the descriptors live on the device: shapes are validated by the caller's binding (step_amd/ops.py) -- here only what
+    // the launch itself needs
+    if (n < 0) return STEP_E_SHAPE;
+    if (n == 0) return STEP_OK;
+    if (!items) return STEP_E_NULL;
+    const dim3 grid(48, (unsigned)n);
+    switch (dtype) {
+        case STEP_F32: STEP_LAUNCH((pack_weights_kernel<float>), grid, dim3(256), stream, items); break;
+        case STEP_BF16: STEP_LAUNCH((pack_weights_kernel<bf16_t>), grid, dim3(256), stream, items); break;
+        case STEP_F16: STEP_LAUNCH((pack_weights_kernel<f16_t>), grid, dim3(256), stream, items); break;
+        default: return STEP_E_DTYPE;
+    }
+    return STEP_LAUNCH_CHECK();
+}
+
+
 size_t step_conv_workspace_bytes(const step_conv_desc* d) {
     if (!d || d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return 0;
     const step_conv_desc canon = canonical_desc(d);
@@ -722,7 +768,7 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
 }
 
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 15; }
+int step_abi_version(void) { return 16; }
 
 }  // extern "C"
 

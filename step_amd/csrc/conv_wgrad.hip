@@ -546,6 +546,222 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradParams p) {
 }
 
 
+// stem_wgrad16_kernel -- the stem's weight gradient on the 16-bit matrix instructions (16-bit clip, 16-bit activation gradient).
+// stem_wgrad_kernel gives every (kd, kh) filter row its own jobs, so the gradient tensor is read 49 times (9 GB for one
+// 36 x 400 x 400 clip: 2.4 ms); here a workgroup keeps ALL 49 x 21 filter columns of a 32-channel block in registers:
+//   seven waves = the seven kd planes, each holding five accumulators of the 32 x 32 product (rows = output channels, columns =
+//   the 147 (kh, kw, c) entries of its filter plane in blocks of 32: 92 % of the columns used, where one filter row per block
+//   would use 21 of 32); the reduction runs over the output pixels of a tile of SW16_R rows x P columns, 16 per matrix instruction.
+//   A operand (dy^T): the tile's gradient rows staged pixel-major in LDS, read with the transposing ds_read_b64_tr_b16.
+//   B operand (strided patches of the clip): the input rows a tile touches (7 planes x 2 R + 5 rows x 3 channels) staged with
+//   even and odd columns DE-INTERLEAVED, so that the eight pixels of a fragment -- input columns 2 p + kw - 2, stride 2 -- are
+//   eight consecutive elements of one phase (five aligned dwords + a byte funnel shift, lds_read8_shifted).
+//   The workgroup walks tiles (the next tile's loads are in flight under the current one's matrix work) and writes its partial
+//   [7][5][32 x 32] tiles once; stem_wgrad16_reduce_kernel sums them over the workgroups in a fixed order (no atomics).
+constexpr int SW16_R = 2, SW16_PMAX = 112, SW16_ROWS = 2 * SW16_R + 5, SW16_PH = SW16_PMAX + 8;
+constexpr int SW16_XROW = 3 * 2 * SW16_PH;                       // elements of one staged input row: 3 channels x 2 phases
+constexpr int SW16_XS = 7 * SW16_ROWS * SW16_XROW;               // elements of the staged clip tile
+constexpr int SW16_NT = 448;
+constexpr int SW16_NXV = (7 * SW16_ROWS * 3 * (SW16_PMAX / 4 + 2) + SW16_NT - 1) / SW16_NT;
+constexpr int SW16_NGV = (SW16_R * SW16_PMAX * 4 + SW16_NT - 1) / SW16_NT;
+
+struct StemWgrad16Params {
+    const void* x; const void* dy; float* ws;
+    int N, T, H, W, To, Ho, Wo, Cout;
+    int P, tiles_h, tiles_w;
+    long long tiles;
+};
+
+// Eight consecutive 16-bit elements starting at an ODD or even element of a 4-byte aligned LDS row: five aligned dwords and a
+// per-lane byte funnel shift (sh = 0 or 2).  A ds_read_b128 at a 2- or 4-byte aligned address is legal on gfx950 but measures
+// 6.6x slower than an aligned one (tools/ubench/lds_align.hip); 32-bit reads run at the full LDS rate.
+__device__ __forceinline__ u16x8 lds_read8_shifted(const unsigned char* p4, unsigned sh) {
+    const unsigned* q = (const unsigned*)p4;
+    const unsigned d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+#ifndef STEP_EMUL
+    const u32x4_ r = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh), __builtin_amdgcn_alignbyte(d3, d2, sh),
+                      __builtin_amdgcn_alignbyte(d4, d3, sh)};
+#else
+    auto ab = [](unsigned hi, unsigned lo, unsigned s_) { return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * s_)); };
+    const u32x4_ r = {ab(d1, d0, sh), ab(d2, d1, sh), ab(d3, d2, sh), ab(d4, d3, sh)};
+#endif
+    return __builtin_bit_cast(u16x8, r);
+}
+// The staging item tables (13 + 2 vectors per thread: plane / row / channel / column of each) are the same for every tile, and
+// the compiler would keep all of them in registers across the tile loop -- 256 VGPRs, single-buffered fragments, spills.  An
+// empty asm that "modifies" the item index makes them per-tile temporaries (a few hundred integer instructions per tile).
+#ifndef STEP_EMUL
+#define STEP_OPAQUE_V(v) asm volatile("" : "+v"(v))
+#else
+#define STEP_OPAQUE_V(v) ((void)0)
+#endif
+
+template <typename T>
+__global__ __launch_bounds__(SW16_NT) void stem_wgrad16_kernel(StemWgrad16Params p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[SW16_XS * 2 + SW16_R * SW16_PMAX * 64];
+    unsigned char* xs = lds;
+    unsigned char* gs = lds + SW16_XS * 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;          // wave = kd
+    const int khalf = lane >> 5;
+    const int co0 = blockIdx.y * 32;
+    // staging items are numbered for the widest tile (constant divisors); a narrower tile skips the items beyond its width
+    constexpr int VPRM = SW16_PMAX / 4 + 2;
+    constexpr int nxv = 7 * SW16_ROWS * 3 * VPRM, ngv = SW16_R * SW16_PMAX * 4;
+    const int P = p.P, VPR = P / 4 + 2;
+    const T* xg = (const T*)p.x;
+    const T* dyg = (const T*)p.dy;
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int nb = 0; nb < 5; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+    u16x8 xr[SW16_NXV], gr[SW16_NGV];
+    const u16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto load_tile = [&](long long tile) {
+        long long t = tile;
+        const int tw = (int)(t % p.tiles_w); t /= p.tiles_w;
+        const int th = (int)(t % p.tiles_h); t /= p.tiles_h;
+        const int od = (int)(t % p.To);
+        const int n = (int)(t / p.To);
+        const int oh0 = th * SW16_R, pw0 = tw * P;
+#pragma unroll
+        for (int q = 0; q < SW16_NXV; ++q) {
+            int v = tid + q * SW16_NT;
+            STEP_OPAQUE_V(v);                                                // (see STEP_OPAQUE_V)
+            u16x8 val = zero8;
+            if (v < nxv) {
+                const int j = v % VPRM;
+                int t2 = v / VPRM;
+                const int c = t2 % 3; t2 /= 3;
+                const int r = t2 % SW16_ROWS, kd = t2 / SW16_ROWS;
+                const int it = 2 * od + kd - 2, ih = 2 * oh0 - 2 + r, iw = 2 * pw0 - 8 + 8 * j;
+                if (j < VPR && it >= 0 && it < p.T && ih >= 0 && ih < p.H && iw >= 0 && iw + 8 <= p.W)
+                    val = *(const u16x8*)(xg + ((((size_t)n * p.T + it) * 3 + c) * p.H + ih) * p.W + iw);
+            }
+            xr[q] = val;
+        }
+#pragma unroll
+        for (int q = 0; q < SW16_NGV; ++q) {
+            int v = tid + q * SW16_NT;
+            STEP_OPAQUE_V(v);                                                // (see STEP_OPAQUE_V)
+            u16x8 val = zero8;
+            if (v < ngv) {
+                const int cq = v & 3, pix = v >> 2;
+                const int pp = pix % SW16_PMAX;
+                const int oh = oh0 + pix / SW16_PMAX, ow = pw0 + pp;
+                if (pp < P && oh < p.Ho && ow < p.Wo && co0 + 8 * cq + 8 <= p.Cout)
+                    val = *(const u16x8*)(dyg + ((((size_t)n * p.To + od) * p.Ho + oh) * p.Wo + ow) * p.Cout + co0 + 8 * cq);
+            }
+            gr[q] = val;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int q = 0; q < SW16_NXV; ++q) {
+            int v = tid + q * SW16_NT;
+            STEP_OPAQUE_V(v);                                                // (see STEP_OPAQUE_V)
+            if (v < nxv) {
+                const int j = v % VPRM, row = v / VPRM;                         // row = (kd * ROWS + r) * 3 + c
+                unsigned char* d = xs + ((size_t)row * 2 * SW16_PH + 4 * j) * 2;
+                const u16x4 ev = {xr[q][0], xr[q][2], xr[q][4], xr[q][6]}, odd = {xr[q][1], xr[q][3], xr[q][5], xr[q][7]};
+                *(u16x4*)d = ev;
+                *(u16x4*)(d + SW16_PH * 2) = odd;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < SW16_NGV; ++q) {
+            int v = tid + q * SW16_NT;
+            STEP_OPAQUE_V(v);                                                // (see STEP_OPAQUE_V)
+            if (v < ngv) *(u16x8*)(gs + (size_t)(v >> 2) * 64 + (v & 3) * 16) = gr[q];
+        }
+    };
+    // this lane's fragment addresses.  B: column n = 32 nb + (lane & 31) = (kh, kw, c) of filter plane kd; input column
+    // 2 (pw0 + p) + kw - 2 = staged element 2 p + kw + 6 -> phase kw & 1, index p + (kw >> 1) + 3; input row 2 ro + kh.
+    // (surplus columns n >= 147 compute garbage that is never stored.)  A: common.h lds_tr8 (16-lane group g: channels
+    // 16 (g & 1) .., pixels 8 (g >> 1) ..)
+    const unsigned char* bx[5];
+    unsigned bsh[5];                                                       // odd first element: shift the five dwords by 2 bytes
+#pragma unroll
+    for (int nb = 0; nb < 5; ++nb) {
+        const int n = min(nb * 32 + (lane & 31), 146);
+        const int kh_ = n / 21, kw_ = (n % 21) / 3, c_ = n % 3;
+        const int o = 8 * khalf + (kw_ >> 1) + 3;
+        bx[nb] = xs + ((((size_t)(wave * SW16_ROWS + kh_) * 3 + c_) * 2 + (kw_ & 1)) * SW16_PH + (o & ~1)) * 2;
+        bsh[nb] = (o & 1) * 2;
+    }
+    const int g = lane >> 4;
+    const unsigned char* ga = gs + (8 * (g >> 1) + ((lane & 15) >> 2)) * 64 + (g & 1) * 32 + (lane & 3) * 8;
+
+    long long tile = blockIdx.x;
+    if (tile < p.tiles) load_tile(tile);
+    for (; tile < p.tiles; tile += gridDim.x) {
+        __syncthreads();                                                  // the previous tile's fragment reads are done
+        store_tile();
+        __syncthreads();
+        if (tile + gridDim.x < p.tiles) load_tile(tile + gridDim.x);
+        // the two output rows of the tile alternate through two fragment sets: the reads of one are in flight under the
+        // matrix instructions of the other
+        u16x8 a0, a1, b0[5], b1[5];
+        auto frags = [&](int ro, int p0, u16x8& a, u16x8 (&b)[5]) {
+            const unsigned char* ap = ga + (size_t)(ro * SW16_PMAX + p0) * 64;
+            a = lds_tr8(ap, ap + 256);
+            const size_t boff = ((size_t)(2 * ro) * SW16_XROW + p0) * 2;
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb) b[nb] = lds_read8_shifted(bx[nb] + boff, bsh[nb]);
+        };
+        static_assert(SW16_R == 2, "the fragment pipeline below alternates two rows");
+        frags(0, 0, a0, b0);
+        for (int p0 = 0; p0 < P; p0 += 16) {
+            frags(1, p0, a1, b1);
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb) mma_k16(a0, b0[nb], acc[nb], T());
+            if (p0 + 16 < P) frags(0, p0 + 16, a0, b0);
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb) mma_k16(a1, b1[nb], acc[nb], T());
+        }
+    }
+    f32x4* out = (f32x4*)p.ws + ((((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 7 + wave) * 5) * 4 * 64 + lane;
+#pragma unroll
+    for (int nb = 0; nb < 5; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {acc[nb][4 * q], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]};
+            out[(nb * 4 + q) * 64] = v;
+        }
+}
+
+// sums the partial tiles over the gx workgroups of a channel block (fixed order) and scatters them into dw [Cout][3][7][7][7]
+__global__ void stem_wgrad16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int gx, int gy, int Cout, int accumulate) {
+    const long long per_x = (long long)gy * 35 * 4 * 64;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < per_x; idx += (long long)blockDim.x * gridDim.x) {
+        long long t = idx;
+        const int lane = (int)(t % 64); t /= 64;
+        const int q = (int)(t % 4); t /= 4;
+        const int nb = (int)(t % 5); t /= 5;
+        const int kd = (int)(t % 7);
+        const int by = (int)(t / 7);
+        const int n = nb * 32 + (lane & 31);
+        if (n >= 147) continue;
+        const int kh = n / 21, kw = (n % 21) / 3, c = n % 3;
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int x = 0; x < gx; ++x) {
+            const f32x4 v = ((const f32x4*)ws)[(size_t)x * per_x + idx];
+            sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = by * 32 + cd_row(4 * q + r, lane);
+            if (co < Cout) {
+                float* o = dw + ((((size_t)co * 3 + c) * 7 + kd) * 7 + kh) * 7 + kw;
+                *o = accumulate ? *o + sum[r] : sum[r];
+            }
+        }
+    }
+}
+
 }  // namespace step
 
 using namespace step;
@@ -779,6 +995,62 @@ int step_stem_wgrad(int dtype, const void* x, int N, int T, int H, int W, const 
         case STEP_F16: STEP_LAUNCH((stem_wgrad_kernel<f16_t>), grid, dim3(256), stream, p); break;
         default: return STEP_E_DTYPE;
     }
+    return STEP_LAUNCH_CHECK();
+}
+
+
+
+// launch plan of the 16-bit stem form: ok = false -> the caller keeps step_stem_wgrad
+struct Sw16Plan { bool ok; int P, tiles_h, tiles_w, gx, gy; long long tiles; };
+static Sw16Plan stem_wgrad16_plan(int dtype, int N, int T, int H, int W, int Cout) {
+    Sw16Plan pl; pl.ok = false; pl.P = pl.tiles_h = pl.tiles_w = pl.gx = pl.gy = 0; pl.tiles = 0;
+    if (dtype != STEP_BF16 && dtype != STEP_F16) return pl;
+    if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (W % 8) || (Cout % 8)) return pl;      // 16-byte rows of the clip / the gradient
+    const int To = (T + 5 - 7) / 2 + 1, Ho = (H + 5 - 7) / 2 + 1, Wo = (W + 5 - 7) / 2 + 1;
+    if (To <= 0 || Ho <= 0 || Wo <= 0) return pl;
+    pl.tiles_w = ceil_div(Wo, SW16_PMAX);
+    pl.P = ceil_div(ceil_div(Wo, pl.tiles_w), 16) * 16;
+    pl.tiles_h = ceil_div(Ho, SW16_R);
+    pl.tiles = (long long)N * To * pl.tiles_h * pl.tiles_w;
+    pl.gy = ceil_div(Cout, 32);
+    long long gx = 256 / pl.gy;                                   // one workgroup per CU
+    if (gx < 1) gx = 1;
+    if (gx > pl.tiles) gx = pl.tiles;
+    pl.gx = (int)gx;
+    pl.ok = true;
+    return pl;
+}
+
+size_t step_stem_wgrad16_workspace_bytes(int dtype, int N, int T, int H, int W, int Cout) {
+    const Sw16Plan pl = stem_wgrad16_plan(dtype, N, T, H, W, Cout);
+    return pl.ok ? (size_t)pl.gx * pl.gy * 35 * 4 * 64 * sizeof(f32x4) : 0;
+}
+
+int step_stem_wgrad16(int dtype, const void* x, int N, int T, int H, int W, const void* dy, int Cout, float* dw, int accumulate,
+                      void* ws, size_t ws_bytes, step_stream_t stream) {
+    if (N < 0 || T <= 0 || H <= 0 || W <= 0 || Cout <= 0) return STEP_E_SHAPE;
+    if (dtype != STEP_BF16 && dtype != STEP_F16) return STEP_E_DTYPE;
+    if (!dw) return STEP_E_NULL;
+    if (N == 0) {
+        if (!accumulate) return (int)hipMemsetAsync(dw, 0, (size_t)Cout * 3 * 343 * sizeof(float), (hipStream_t)stream);
+        return STEP_OK;
+    }
+    const Sw16Plan pl = stem_wgrad16_plan(dtype, N, T, H, W, Cout);
+    if (!pl.ok) return STEP_E_UNSUPPORTED;
+    if (!x || !dy || !ws) return STEP_E_NULL;
+    if (ws_bytes < step_stem_wgrad16_workspace_bytes(dtype, N, T, H, W, Cout) || (((uintptr_t)ws) & 15) || (((uintptr_t)x) & 15) ||
+        (((uintptr_t)dy) & 15))
+        return STEP_E_ALIGN;
+    StemWgrad16Params p;
+    p.x = x; p.dy = dy; p.ws = (float*)ws; p.N = N; p.T = T; p.H = H; p.W = W;
+    p.To = (T + 5 - 7) / 2 + 1; p.Ho = (H + 5 - 7) / 2 + 1; p.Wo = (W + 5 - 7) / 2 + 1;
+    p.Cout = Cout; p.P = pl.P; p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.tiles = pl.tiles;
+    const dim3 grid((unsigned)pl.gx, (unsigned)pl.gy);
+    if (dtype == STEP_BF16) STEP_LAUNCH((stem_wgrad16_kernel<bf16_t>), grid, dim3(SW16_NT), stream, p);
+    else STEP_LAUNCH((stem_wgrad16_kernel<f16_t>), grid, dim3(SW16_NT), stream, p);
+    const long long groups = (long long)pl.gy * 35 * 4 * 64;
+    STEP_LAUNCH(stem_wgrad16_reduce_kernel, dim3(flat_grid(groups, 256)), dim3(256), stream, (const float*)ws, dw, pl.gx, pl.gy, Cout,
+                accumulate);
     return STEP_LAUNCH_CHECK();
 }
 

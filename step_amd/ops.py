@@ -100,6 +100,27 @@ def pack_conv_weight_dgrad(w, dtype, cin_pad):
     return out
 
 
+def pack_table(entries, device):
+    """Device array of step_pack_item for pack_conv_weights.  entries: (w_ptr, perm_ptr | None, packed_ptr, Cout, Cin, w_cin,
+    cin_lo, (kd, kh, kw), dgrad, cin_pad) per weight; Cout / Cin are the FORWARD conv's (effective) channel counts."""
+    items = (_capi.PackItem * len(entries))()
+    for it, (w, perm, dst, cout, cin, wcin, lo, k, dgrad, cpad) in zip(items, entries):
+        if not (cout > 0 and cin > 0 and 0 <= lo and lo + cin <= wcin and min(k) > 0) or (dgrad and (cpad < cout or not all(v & 1 for v in k))):
+            raise ValueError("pack_table: bad item %r" % ((cout, cin, wcin, lo, k, dgrad, cpad),))
+        it.w, it.perm_c, it.packed = w, perm, dst
+        it.Cout, it.Cin, it.w_cin, it.cin_lo = cout, cin, wcin, lo
+        it.kd, it.kh, it.kw = k
+        it.dgrad, it.cin_pad = int(bool(dgrad)), cpad
+    host = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
+    return host.to(device)
+
+
+def pack_conv_weights(table, n, dtype, device):
+    """Every weight of a net re-packed by one launch (step_conv_pack_weights); `table` from pack_table()."""
+    L = _lib.lib()
+    _capi.check(L.step_conv_pack_weights(_lib.dptr(table), n, DT[dtype], _lib.stream_ptr(device)), "step_conv_pack_weights")
+
+
 def pack_stem_weight(w, dtype):
     L = _lib.lib()
     w = w.detach().contiguous().float()
@@ -323,6 +344,30 @@ def stem_wgrad(x, gy, Cout):
     dw = torch.empty((Cout, 3, 7, 7, 7), dtype=torch.float32, device=x.device)
     _capi.check(L.step_stem_wgrad(_dt(x), _lib.dptr(x), N, T, H, W, _lib.dptr(gy), Cout, _lib.dptr(dw), 0, _lib.stream_ptr(x.device)),
                 "step_stem_wgrad")
+    return dw
+
+
+def stem_wgrad16(x, gy, Cout):
+    """stem_wgrad on the 16-bit matrix instructions: x [N,T,3,H,W] and gy channels-last [N,To,Ho,Wo,Cout] in the same 16-bit dtype ->
+    fp32 [Cout,3,7,7,7]; None when the shape is outside the kernel's contract (the caller keeps stem_wgrad)."""
+    L = _lib.lib()
+    N, T, C, H, W = x.shape
+    if gy.dtype != x.dtype or x.dtype == torch.float32:
+        return None
+    wsb = L.step_stem_wgrad16_workspace_bytes(_dt(x), N, T, H, W, Cout)
+    if not wsb:
+        return None
+    x, gy = x.contiguous(), gy.contiguous()
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    dw = torch.empty((Cout, 3, 7, 7, 7), dtype=torch.float32, device=x.device)
+    prof = _NOPROF
+    if PROFILE is not None:
+        pix = gy.numel() // Cout
+        prof = _Prof("void step::stem_wgrad16_kernel<%s>(step::StemWgrad16Params)" % _TNAME[x.dtype], 2.0 * pix * Cout * 1029,
+                     (x.numel() + gy.numel()) * x.element_size())
+    with prof:
+        _capi.check(L.step_stem_wgrad16(_dt(x), _lib.dptr(x), N, T, H, W, _lib.dptr(gy), Cout, _lib.dptr(dw), 0, _lib.dptr(ws), wsb,
+                                        _lib.stream_ptr(x.device)), "step_stem_wgrad16")
     return dw
 
 

@@ -478,6 +478,53 @@ def case_pack_weight_dgrad(bk, golden):
     assert bk.lib.step_conv_pack_weight_dgrad(w.ptr, 4, 4, 1, 1, 1, F32, 3, w.ptr, bk.stream) < 0       # cin_pad < Cout
 
 
+def case_pack_weights_one_launch(bk, golden):
+    """step_conv_pack_weights (every weight of a net in one launch) == the single-weight entries on the effective weight
+    w[:, lo + perm[j]], forward and data-gradient images, bit for bit."""
+    import ctypes
+    from step_amd import _capi
+    rs = np.random.RandomState(23)
+    # (Cout, w_cin, k, (lo, hi) | None, permuted?, dgrad pad | None)
+    specs = ((40, 24, (3, 3, 3), None, False, None), (40, 24, (3, 3, 3), None, False, 0), (12, 72, (1, 1, 1), (8, 56), False, None),
+             (12, 72, (1, 1, 1), (8, 56), True, 4), (20, 33, (1, 3, 3), None, True, None), (20, 33, (1, 3, 3), (1, 33), False, 12),
+             (64, 16, (1, 1, 1), None, False, None), (7, 5, (3, 1, 1), None, False, 1))
+    for dt in (F32, BF16, F16):
+        items = (_capi.PackItem * len(specs))()
+        keep, want, outs = [], [], []
+        for j, (Cout, wcin, k, sl, permuted, dpad) in enumerate(specs):
+            w = rs.randn(Cout, wcin, *k).astype(np.float32)
+            lo, hi = sl if sl else (0, wcin)
+            cin = hi - lo
+            perm = rs.permutation(cin).astype(np.int32) if permuted else None
+            weff = w[:, lo:hi]
+            weff = np.ascontiguousarray(weff[:, perm] if perm is not None else weff)
+            wd, pd = bk.dev(w), bk.dev(perm)
+            if dpad is None:
+                n = bk.lib.step_conv_packed_elems(Cout, cin, *k)
+                a = bk.dev(np.zeros(n, NP_DT[dt]))
+                assert bk.lib.step_conv_pack_weight(bk.dev(weff).ptr, Cout, cin, k[0], k[1], k[2], dt, None, a.ptr, bk.stream) == 0
+            else:
+                n = bk.lib.step_conv_packed_elems(cin, Cout + dpad, *k)
+                a = bk.dev(np.zeros(n, NP_DT[dt]))
+                assert bk.lib.step_conv_pack_weight_dgrad(bk.dev(weff).ptr, Cout, cin, k[0], k[1], k[2], dt, Cout + dpad, a.ptr, bk.stream) == 0
+            b = bk.dev(np.full(n, 7, NP_DT[dt]))
+            it = items[j]
+            it.w, it.perm_c, it.packed = wd.ptr, pd.ptr, b.ptr
+            it.Cout, it.Cin, it.w_cin, it.cin_lo = Cout, cin, wcin, lo
+            it.kd, it.kh, it.kw = k
+            it.dgrad, it.cin_pad = (0, 0) if dpad is None else (1, Cout + dpad)
+            keep += [wd, pd]
+            want.append(a)
+            outs.append(b)
+        table = bk.dev(np.frombuffer(bytes(items), np.uint8).copy())
+        assert bk.lib.step_conv_pack_weights(table.ptr, len(specs), dt, bk.stream) == 0
+        for j, (a, b) in enumerate(zip(want, outs)):
+            assert np.array_equal(a.get(), b.get()), (dt, specs[j])
+    assert bk.lib.step_conv_pack_weights(None, 0, F32, bk.stream) == 0
+    assert bk.lib.step_conv_pack_weights(None, 2, F32, bk.stream) < 0
+    assert bk.lib.step_conv_pack_weights(table.ptr, 1, 9, bk.stream) < 0
+
+
 def case_act_grad(bk, golden):
     """g = gy * (y > 0) * scale[c] against the torch element-wise chain of the unit's backward (cast, mask, multiply, cast):
     bit-exact in fp32 and after the rounding to the 16-bit activation type; both outputs, either alone, no relu / no scale."""
@@ -1011,6 +1058,43 @@ def case_stem_wgrad(bk, golden):
         assert bk.lib.step_stem_wgrad(dt, xd.ptr, N, T, H, W, gd.ptr, Cout, dw.ptr, 0, bk.stream) == 0
         err = np.abs(dw.get() - ref).max() / np.abs(ref).max()
         assert err < 2e-5, (dt, err)
+
+
+def case_stem_wgrad16(bk, golden):
+    """step_stem_wgrad16 (16-bit clip and gradient, fp32 accumulation, workspace + fixed-order sum) against torch's conv3d
+    weight gradient of the same quantized operands: ragged row / column tiles, two column tiles, a partial channel block,
+    accumulate, run-to-run bit identity, and the shapes it hands back to step_stem_wgrad."""
+    rs = np.random.RandomState(45)
+    for (N, T, H, W, Cout) in ((2, 6, 22, 72, 40), (1, 4, 8, 240, 32), (1, 5, 13, 16, 64)):
+        x = rs.randn(N, T, 3, H, W).astype(np.float32)
+        To, Ho, Wo = (T - 2) // 2 + 1, (H - 2) // 2 + 1, (W - 2) // 2 + 1
+        gy = rs.randn(N, Cout, To, Ho, Wo).astype(np.float32)
+        for dt in (BF16, F16):
+            xq, gq = torch.from_numpy(quantize(x, dt)), torch.from_numpy(quantize(gy, dt))
+            w = torch.zeros(Cout, 3, 7, 7, 7, requires_grad=True, dtype=torch.float64)
+            y = F.conv3d(F.pad(xq.permute(0, 2, 1, 3, 4).double(), (2, 3, 2, 3, 2, 3)), w, stride=2)
+            assert tuple(y.shape[2:]) == (To, Ho, Wo)
+            y.backward(gq.double())
+            ref = w.grad.numpy()
+            xd, gd = bk.dev(encode(x, dt)), bk.dev(encode(np.ascontiguousarray(cl(gy)), dt))
+            wsb = bk.lib.step_stem_wgrad16_workspace_bytes(dt, N, T, H, W, Cout)
+            assert wsb > 0
+            ws = bk.dev(np.full(wsb // 4, 5.0, np.float32))
+            dw = bk.dev(np.full((Cout, 3, 7, 7, 7), -3.0, np.float32))
+            assert bk.lib.step_stem_wgrad16(dt, xd.ptr, N, T, H, W, gd.ptr, Cout, dw.ptr, 0, ws.ptr, wsb, bk.stream) == 0
+            got = dw.get().copy()
+            err = np.abs(got - ref).max() / np.abs(ref).max()
+            assert err < 2e-5, (N, T, H, W, Cout, dt, err)
+            assert bk.lib.step_stem_wgrad16(dt, xd.ptr, N, T, H, W, gd.ptr, Cout, dw.ptr, 1, ws.ptr, wsb, bk.stream) == 0
+            assert np.abs(dw.get() - 2 * got).max() <= 1e-6 * np.abs(got).max()
+            dw2 = bk.dev(np.zeros((Cout, 3, 7, 7, 7), np.float32))
+            assert bk.lib.step_stem_wgrad16(dt, xd.ptr, N, T, H, W, gd.ptr, Cout, dw2.ptr, 0, ws.ptr, wsb, bk.stream) == 0
+            assert np.array_equal(dw2.get(), got)                                   # deterministic: no atomics
+            assert bk.lib.step_stem_wgrad16(dt, xd.ptr, N, T, H, W, gd.ptr, Cout, dw2.ptr, 0, ws.ptr, wsb - 16, bk.stream) < 0
+    assert bk.lib.step_stem_wgrad16_workspace_bytes(F32, 1, 6, 22, 72, 64) == 0       # fp32, W % 8, Cout % 8: step_stem_wgrad's
+    assert bk.lib.step_stem_wgrad16_workspace_bytes(BF16, 1, 6, 22, 70, 64) == 0
+    assert bk.lib.step_stem_wgrad16_workspace_bytes(BF16, 1, 6, 22, 72, 60) == 0
+    assert bk.lib.step_stem_wgrad16(BF16, xd.ptr, 1, 6, 22, 70, gd.ptr, 64, dw.ptr, 0, ws.ptr, wsb, bk.stream) < 0
 
 
 def case_conv_split_two_destinations(bk, golden):

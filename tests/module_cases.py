@@ -710,6 +710,121 @@ def case_reg_unit_pack_follows_weight_updates(dev, golden):
         assert e < 1e-3, (k, e)
 
 
+def case_batched_repack_follows_weight_updates(dev, golden):
+    """After an optimizer step every packed weight image (forward and data-gradient, channel slices and permutations included)
+    is refreshed by ONE step_conv_pack_weights launch into the buffers the units already hold, bit-identical to packing each
+    effective weight on its own; units that were never used are left alone; STEP_BATCH_PACK=0 restores the per-weight path."""
+    from step_amd import backbone, ops
+    g = golden("head_golden")
+    pf = R.fill_tensor("golden.det.pooled3", (2, 3, 832, 7, 7), "feat").to(dev)
+    cx = R.fill_tensor("golden.det.ctx3", (2, 1024, 3, 1, 1), "feat").to(dev)
+    tubes, targets = torch.from_numpy(g["loss_tubes"]).to(dev), torch.from_numpy(g["loss_targets"]).to(dev)
+    net = fill(step_amd.TwoBranchNet(cfg()), "det0.").to(dev)
+    net.set_device(dev)
+    net.train()
+    mixed = backbone.Mixed(32, (16, 16, 24, 8, 16, 8)).to(dev).eval()
+    for p in mixed.parameters():
+        p.requires_grad_(p.dim() == 5)
+    xm = R.fill_tensor("golden.repack.x", (1, 4, 6, 6, 32), "feat").to(dev).requires_grad_(True)
+    calls = {"batched": 0, "single": 0, "single_d": 0}
+    orig = (ops.pack_conv_weights, ops.pack_conv_weight, ops.pack_conv_weight_dgrad)
+
+    def count(name, fn):
+        def f(*a, **k):
+            calls[name] += 1
+            return fn(*a, **k)
+        return f
+    ops.pack_conv_weights, ops.pack_conv_weight, ops.pack_conv_weight_dgrad = (count("batched", orig[0]), count("single", orig[1]),
+                                                                              count("single_d", orig[2]))
+    try:
+        def step():
+            o = net(pf, context_feat=cx, tubes=tubes, targets=targets)
+            (o[4].mean() + 5.0 * o[5].mean() + o[6].mean() + mixed(xm).square().mean()).backward()
+
+        def units():
+            return [u for u in list(backbone._UNITS) if u.version_fn is None and u._packed
+                    and any(u.owner is m for mod in (net, mixed) for m in mod.modules())]
+
+        def check():
+            n = 0
+            for u in units():
+                w = u.weight_fn()
+                for key, (ver, buf) in u._packed.items():
+                    assert ver == backbone._ver(w)
+                    want = orig[1](u.effective_weight(), key[0]) if len(key) == 2 else orig[2](u.effective_weight(), key[0], key[2])
+                    assert torch.equal(buf, want), (type(u.owner).__name__, key)
+                    n += 1
+            return n
+
+        step()
+        first = dict(calls)
+        assert first["batched"] == 0 and first["single"] > 5 and first["single_d"] > 5       # nothing to refresh yet
+        n_images = check()
+        ptrs = {(id(u), k): v[1].data_ptr() for u in units() for k, v in u._packed.items()}
+        for it in range(2):
+            with torch.no_grad():
+                for p in list(net.parameters()) + list(mixed.parameters()):
+                    if p.requires_grad:
+                        p.add_(0.03 * (it + 1))
+            before = dict(calls)
+            step()
+            # one launch refreshed every image; the fused units keyed on several parameters (version_fn) pack their own
+            assert calls["batched"] == before["batched"] + 1, calls
+            assert calls["single_d"] - before["single_d"] <= 2 and calls["single"] - before["single"] <= 2, (before, calls)
+            assert check() == n_images
+            assert ptrs == {(id(u), k): v[1].data_ptr() for u in units() for k, v in u._packed.items()}   # refreshed in place
+        # the per-weight path (STEP_BATCH_PACK=0)
+        backbone.BATCH_PACK = False
+        with torch.no_grad():
+            for p in mixed.parameters():
+                if p.requires_grad:
+                    p.add_(0.01)
+        before = dict(calls)
+        (mixed(xm).square().mean()).backward()
+        assert calls["batched"] == before["batched"] and calls["single"] > before["single"]
+        check()
+    finally:
+        backbone.BATCH_PACK = True
+        ops.pack_conv_weights, ops.pack_conv_weight, ops.pack_conv_weight_dgrad = orig
+
+
+def case_stem_backward_16bit(dev, golden):
+    """The stem's weight gradient with bf16 activations (frozen affine): ReLU mask x scale in one HIP pass and the 16-bit
+    matrix-instruction kernel (step_stem_wgrad16).  Against the same bf16 run through the fp32-MFMA kernel (STEP_WGRAD16=0) the
+    only difference is the bf16 rounding of the activation gradient (< 5e-3); both follow the fp32 run to the bf16 forward's own
+    error (quantized clip, ReLU decisions: a few per cent).  A clip width outside the 16-bit kernel's contract (W % 8) takes the
+    fp32-MFMA kernel."""
+    from step_amd import backbone, ops
+    for shape in ((2, 6, 3, 24, 40), (1, 5, 3, 18, 20)):
+        grads = {}
+        for tag, dt, w16 in (("f32", torch.float32, True), ("new", torch.bfloat16, True), ("old", torch.bfloat16, False)):
+            base = fill(step_amd.BaseNet(cfg())).to(dev)
+            base.train()
+            stem = base.base_model[0]
+            assert not stem.batch3d.weight.requires_grad
+            x = R.fill_tensor("golden.stem16.images", shape, "image").to(dev).to(dt)
+            used = []
+            orig, keep = ops.stem_wgrad16, backbone.WGRAD16
+
+            def spy(*a, **k):
+                r = orig(*a, **k)
+                used.append(r is not None)
+                return r
+            ops.stem_wgrad16, backbone.WGRAD16 = spy, w16
+            try:
+                y = stem(x)
+                wgt = R.fill_tensor("golden.stem16.w", tuple(y.shape), "feat").to(dev)
+                (y.float() * wgt).sum().backward()
+            finally:
+                ops.stem_wgrad16, backbone.WGRAD16 = orig, keep
+            assert used == ([shape[-1] % 8 == 0] if tag == "new" else []), (shape, tag, used)
+            grads[tag] = np_(stem.conv3d.weight.grad).astype(np.float64)
+        b = grads["f32"]
+        e_new, e_old = (float(np.linalg.norm(grads[k] - b) / np.linalg.norm(b)) for k in ("new", "old"))
+        e_no = float(np.linalg.norm(grads["new"] - grads["old"]) / np.linalg.norm(b))
+        assert np.isfinite(grads["new"]).all() and e_new < 6e-2 and e_new < 1.2 * e_old + 1e-3 and e_no < 5e-3, (shape, e_new, e_old, e_no)
+
+
 def case_c2_full_size_properties(dev, golden):
     """BASELINE C2 at its full size (8 x [32,3,224,224], bf16) -- too big for the oracle, so parity is checked through
     size-independent properties:
@@ -759,5 +874,6 @@ CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_g
              "case_twobranch_T3_and_losses_golden", "case_roinet_layouts", "case_training_step_matches_torch_autograd",
              "case_flat_adam_matches_torch", "case_wgrad_into_and_targets", "case_twobranch_variants_golden",
              "case_reg_unit_pack_follows_weight_updates", "case_basenet_backward_matches_oracle_autograd",
-             "case_contextnet_backward_matches_oracle_autograd", "case_postprocess_golden"]
+             "case_contextnet_backward_matches_oracle_autograd", "case_postprocess_golden",
+             "case_batched_repack_follows_weight_updates", "case_stem_backward_16bit"]
 GPU_CASES = CPU_CASES + ["case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_c5_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_i3d_classifier_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
