@@ -315,7 +315,13 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
                "flat gradient all-reduce, fused Adam, %d x [36,3,400,400] clip(s) per GPU" % CLIPS_PER_GPU
         metric = "clips_per_sec_train_T36_400"
     else:
-        w = workloads.C4TrainStep(dev, batch=CLIPS_PER_GPU, seed=123 + rank, dtype=tdt)
+        # one process: the whole step (forward, backward, re-pack, Adam) is captured in a HIP graph and replayed -- the eager step
+        # with 16-bit activations is bound by the host issuing ~1300 launches; several ranks: eager (the bucketed exchange)
+        # (fp32 is GPU-bound and measured SLOWER replayed than eager -- 54.6 vs 51.0 ms -- so only the 16-bit step is captured)
+        graphed = world == 1 and not a.no_graph and a.dtype != "f32"
+        w = workloads.C4TrainStep(dev, batch=CLIPS_PER_GPU, seed=123 + rank, dtype=tdt, capturable=graphed)
+        if graphed:
+            w.capture(warmup=max(a.warmup, 2))
         what = "C4: one training step (backbone + ContextNet + max_iter=3 heads on 3/3/9-frame tubes, BCE + smooth-L1 losses, gradient all-reduce, Adam), " \
                "%d x [36,3,400,400] clip(s) per GPU, 5 tubes/clip" % CLIPS_PER_GPU
         metric = "clips_per_sec_train_T36_400"
@@ -341,7 +347,7 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
     # gradient all-reduce: a collective issued by rank 0 alone would dead-lock against the others' final barrier)
     ops.PROFILE = []
     saved, backbone.BRANCH_STREAMS = backbone.BRANCH_STREAMS, False
-    (w.eager if a.config == "c3" else w.step)()
+    (w.eager if a.config == "c3" else getattr(w, "_eager_step", w.step))()
     torch.cuda.synchronize()
     backbone.BRANCH_STREAMS = saved
     REC, ops.PROFILE = ops.PROFILE, None
@@ -352,7 +358,8 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
                "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": what + ", inputs resident in HBM, random-init weights", "clips_per_gpu": CLIPS_PER_GPU, "T": 36, "HW": 400,
                           "parallelism": "clip-sharded replicas x%d (%s)" % (world, "no data-path collective" if a.config == "c3" else "one gradient all-reduce per step"),
-                          "launch": "hipGraph replay + eager post-processing" if (a.config == "c3" and not a.no_graph) else "eager"},
+                          "launch": "hipGraph replay + eager post-processing" if (a.config == "c3" and not a.no_graph) else
+                                    ("hipGraph replay (whole training step)" if getattr(w, "graph", None) is not None else "eager")},
                "ranks": {"world_size": world, "backend": (dist.get_backend() + " (RCCL over xGMI)" if dist.get_backend() == "nccl" else dist.get_backend()) if dist is not None else None,
                          "devices_visible": torch.cuda.device_count()}}
         rec = REC

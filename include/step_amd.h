@@ -309,6 +309,13 @@ STEP_API int step_clip_from_u8(const unsigned char* frames, int N, int T, int H,
 STEP_API int step_adam_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long long n,
                             const long long* seg_end, const float* seg_lr, const float* seg_wd, int n_seg, double beta1,
                             double beta2, double eps, int step, float grad_scale, int zero_grad, step_stream_t stream);
+/* The same update with the step counter ON THE DEVICE (torch.optim.Adam(capturable=True)): *step_dev (int64, device) is
+ * incremented by the call and the bias corrections are derived from it on the device (bias_corr: 2 floats of device scratch), so
+ * the launch can sit in a captured HIP graph and advance on every replay. */
+STEP_API int step_adam_flat_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                                const long long* seg_end, const float* seg_lr, const float* seg_wd, int n_seg, double beta1,
+                                double beta2, double eps, long long* step_dev, float* bias_corr, float grad_scale, int zero_grad,
+                                step_stream_t stream);
 
 /* Activation gradient of the fused conv unit (the backward of Unit3Dpy's BatchNorm3d(eval) + ReLU, models/i3dpt.py:100-111,
  * and of the Bottleneck ReLUs, two_branch.py:60-111, which autograd runs as separate element-wise kernels in the reference):

@@ -197,9 +197,16 @@ def _repack_all(dtype, device):
             owners.append((u, key, ver, hit[1]))
     if not entries:
         return True
+    order = sorted(range(len(entries)), key=lambda i: (entries[i][0], entries[i][8], entries[i][9], entries[i][2]))   # (the set's own order is not stable)
+    entries, owners = [entries[i] for i in order], [owners[i] for i in order]
     sig = tuple(e[:3] for e in entries)
     cached = _TABLES.get((dtype, device))
     if cached is None or cached[0] != sig:
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return False                                         # (a new table is a host -> device copy: not inside a graph capture)
+        if os.environ.get("STEP_PACK_DEBUG"):
+            old = set(cached[0]) if cached else set()
+            print("step_amd: pack table rebuilt (%s): %d items, %d new, %d gone" % (dtype, len(sig), len(set(sig) - old), len(old - set(sig))), flush=True)
         cached = _TABLES[(dtype, device)] = (sig, ops.pack_table(entries, device))
     with torch.no_grad():
         ops.pack_conv_weights(cached[1], len(entries), dtype, device)
@@ -261,7 +268,10 @@ class ConvUnit:
         if self.cin_slice is not None:
             w = w[:, self.cin_slice[0]:self.cin_slice[1]]
         if self.perm is not None:
-            w = w.index_select(1, self.perm.to(device=w.device, dtype=torch.long))
+            pl = self._perm_dev.get((w.device, "long"))          # (cached: a host tensor would be copied -- and waited for -- per call)
+            if pl is None:
+                pl = self._perm_dev[(w.device, "long")] = self.perm.to(device=w.device, dtype=torch.long)
+            w = w.index_select(1, pl)
         return w.reshape(w.shape[0], w.shape[1], *self.k)
 
     def packed(self, dtype):
@@ -530,6 +540,8 @@ class Mixed(nn.Module):
         # 256 CUs on the 28x28 / 14x14 maps, so they overlap instead of queueing behind each other.
         main = torch.cuda.current_stream(x.device)
         s1, s2 = _side_streams(x.device)
+        if BRANCH_STREAMS == 1:
+            s1 = s2                                        # tuning aid: both side branches on ONE side stream (one fork, one join)
         s2.wait_stream(main)
         with torch.cuda.stream(s2):                        # branch_3: pool -> 1x1x1 (one fused launch)
             p = self._branch_3(x, out[..., c2:])
@@ -539,7 +551,8 @@ class Mixed(nn.Module):
             self.branch_2[1](t[..., oc[1]:], out=out[..., c1:c2])
         self.branch_1[1](t[..., :oc[1]], out=out[..., c0:c1])   # main: the big 3x3x3
         main.wait_stream(s1)
-        main.wait_stream(s2)
+        if s2 is not s1:
+            main.wait_stream(s2)
         if p is not None:
             p.record_stream(main)
         return out
@@ -616,7 +629,7 @@ def wgrad_sync():
 # Opt-in: STEP_FUSE_POOL_CONV=1.
 FUSE_POOL_CONV = os.environ.get("STEP_FUSE_POOL_CONV", "0")
 FUSE_POOL_CONV_MIN_PIXELS = 0
-BRANCH_STREAMS = True          # run the independent Inception branches on side streams (inference path)
+BRANCH_STREAMS = int(os.environ.get("STEP_BRANCH_STREAMS", "2"))   # Inception branches on side streams (inference path): 2 side streams, 1, or 0 = off
 WGRAD_SIDE_STREAM = os.environ.get("STEP_WGRAD_STREAM", "1") != "0"   # training: weight gradient beside the data gradient
 _SIDE = {}
 

@@ -621,9 +621,9 @@ __global__ __launch_bounds__(SW16_NT) void stem_wgrad16_kernel(StemWgrad16Params
     u16x8 xr[SW16_NXV], gr[SW16_NGV];
     const u16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     auto load_tile = [&](long long tile) {
-        long long t = tile;
-        const int tw = (int)(t % p.tiles_w); t /= p.tiles_w;
+        long long t = tile;                                                // row tiles fastest: a workgroup's consecutive tiles share 5 of 9 input rows (L2)
         const int th = (int)(t % p.tiles_h); t /= p.tiles_h;
+        const int tw = (int)(t % p.tiles_w); t /= p.tiles_w;
         const int od = (int)(t % p.To);
         const int n = (int)(t / p.To);
         const int oh0 = th * SW16_R, pw0 = tw * P;
@@ -695,13 +695,16 @@ __global__ __launch_bounds__(SW16_NT) void stem_wgrad16_kernel(StemWgrad16Params
     const int g = lane >> 4;
     const unsigned char* ga = gs + (8 * (g >> 1) + ((lane & 15) >> 2)) * 64 + (g & 1) * 32 + (lane & 3) * 8;
 
-    long long tile = blockIdx.x;
-    if (tile < p.tiles) load_tile(tile);
-    for (; tile < p.tiles; tile += gridDim.x) {
+    // a contiguous strip of tiles per workgroup
+    const long long per = (p.tiles + gridDim.x - 1) / gridDim.x;
+    long long tile = (long long)blockIdx.x * per;
+    const long long tend = tile + per < p.tiles ? tile + per : p.tiles;
+    if (tile < tend) load_tile(tile);
+    for (; tile < tend; ++tile) {
         __syncthreads();                                                  // the previous tile's fragment reads are done
         store_tile();
         __syncthreads();
-        if (tile + gridDim.x < p.tiles) load_tile(tile + gridDim.x);
+        if (tile + 1 < tend) load_tile(tile + 1);
         // the two output rows of the tile alternate through two fragment sets: the reads of one are in flight under the
         // matrix instructions of the other
         u16x8 a0, a1, b0[5], b1[5];

@@ -25,8 +25,9 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, f
                                                         const long long* __restrict__ seg_end, const float* __restrict__ seg_lr,
                                                         const float* __restrict__ seg_wd, int n_seg, float beta2, float omb1,
                                                         float omb2, float eps, float bc1, float bc2_sqrt, float gscale,
-                                                        int zero_grad) {
+                                                        int zero_grad, const float* __restrict__ bc_dev) {
     __shared__ long long s_end[MAXSEG];                    // 4 KiB for the usual few hundred tensors: LDS does not limit occupancy
+    if (bc_dev) { bc1 = bc_dev[0]; bc2_sqrt = bc_dev[1]; } // step counter on the device (adam_bias_kernel): graph replays advance it
     for (int i = threadIdx.x; i < n_seg; i += blockDim.x) s_end[i] = seg_end[i];
     __syncthreads();
     for (long long vec = (long long)blockIdx.x * blockDim.x + threadIdx.x; vec < nvec; vec += (long long)blockDim.x * gridDim.x) {
@@ -54,6 +55,17 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, f
         *(f32x4*)(m + e) = M;
         *(f32x4*)(v + e) = V;
         if (zero_grad) *(f32x4*)(g + e) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// the step counter of a CAPTURED optimizer step lives on the device: a replayed graph cannot receive a new host scalar.  One
+// thread advances it and leaves the two bias corrections (double precision, as the host path) for adam_flat_kernel.
+__global__ void adam_bias_kernel(long long* step, float* bc, double beta1, double beta2) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long t = *step + 1;
+        *step = t;
+        bc[0] = (float)(1.0 - pow(beta1, (double)t));
+        bc[1] = (float)sqrt(1.0 - pow(beta2, (double)t));
     }
 }
 
@@ -119,17 +131,20 @@ using namespace step;
 
 extern "C" {
 
-int step_adam_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long long n, const long long* seg_end,
-                   const float* seg_lr, const float* seg_wd, int n_seg, double beta1, double beta2, double eps, int step_no,
-                   float grad_scale, int zero_grad, step_stream_t stream) {
-    if (n < 0 || (n & 3) || n_seg <= 0 || n_seg > ADAM_MAX_SEG || step_no < 1) return STEP_E_SHAPE;
+static int adam_flat_launch(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long long n, const long long* seg_end,
+                            const float* seg_lr, const float* seg_wd, int n_seg, double beta1, double beta2, double eps, int step_no,
+                            long long* step_dev, float* bc_dev, float grad_scale, int zero_grad, step_stream_t stream) {
+    if (n < 0 || (n & 3) || n_seg <= 0 || n_seg > ADAM_MAX_SEG || (!step_dev && step_no < 1)) return STEP_E_SHAPE;
     if (!(beta1 >= 0. && beta1 < 1.) || !(beta2 >= 0. && beta2 < 1.) || !(eps >= 0.)) return STEP_E_SHAPE;
-    if (n == 0) return STEP_OK;
+    if (step_dev && !bc_dev) return STEP_E_NULL;
+    if (step_dev) STEP_LAUNCH(adam_bias_kernel, dim3(1), dim3(64), stream, step_dev, bc_dev, beta1, beta2);   // (also for an empty arena: the step counts)
+    if (n == 0) return step_dev ? STEP_LAUNCH_CHECK() : STEP_OK;
     if (!param || !grad || !exp_avg || !exp_avg_sq || !seg_end || !seg_lr || !seg_wd) return STEP_E_NULL;
     if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq)) & 15) return STEP_E_ALIGN;
     // the scalars are Python doubles in torch: 1 - beta is taken in double (1.f - 0.999f is off by 1.3e-5 relative)
-    const float bc1 = (float)(1.0 - std::pow(beta1, (double)step_no));
-    const float bc2_sqrt = (float)std::sqrt(1.0 - std::pow(beta2, (double)step_no));
+    const float bc1 = step_dev ? 1.f : (float)(1.0 - std::pow(beta1, (double)step_no));
+    const float bc2_sqrt = step_dev ? 1.f : (float)std::sqrt(1.0 - std::pow(beta2, (double)step_no));
+    const float* bcd = step_dev ? bc_dev : nullptr;
     const long long nvec = n >> 2;
     long long blocks = (nvec + 255) / 256;
     static const int per_cu = [] { const char* e = getenv("STEP_ADAM_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 64; }();
@@ -137,12 +152,27 @@ int step_adam_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
     if (n_seg <= 512)
         STEP_LAUNCH((adam_flat_kernel<512>), dim3((unsigned)blocks), dim3(256), stream, param, grad, exp_avg, exp_avg_sq, nvec, seg_end,
                     seg_lr, seg_wd, n_seg, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, bc1, bc2_sqrt,
-                    grad_scale, zero_grad);
+                    grad_scale, zero_grad, bcd);
     else
         STEP_LAUNCH((adam_flat_kernel<ADAM_MAX_SEG>), dim3((unsigned)blocks), dim3(256), stream, param, grad, exp_avg, exp_avg_sq, nvec,
                     seg_end, seg_lr, seg_wd, n_seg, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, bc1,
-                    bc2_sqrt, grad_scale, zero_grad);
+                    bc2_sqrt, grad_scale, zero_grad, bcd);
     return STEP_LAUNCH_CHECK();
+}
+
+int step_adam_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long long n, const long long* seg_end,
+                   const float* seg_lr, const float* seg_wd, int n_seg, double beta1, double beta2, double eps, int step_no,
+                   float grad_scale, int zero_grad, step_stream_t stream) {
+    return adam_flat_launch(param, grad, exp_avg, exp_avg_sq, n, seg_end, seg_lr, seg_wd, n_seg, beta1, beta2, eps, step_no, nullptr, nullptr,
+                            grad_scale, zero_grad, stream);
+}
+
+int step_adam_flat_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long long n, const long long* seg_end,
+                       const float* seg_lr, const float* seg_wd, int n_seg, double beta1, double beta2, double eps, long long* step_dev,
+                       float* bias_corr, float grad_scale, int zero_grad, step_stream_t stream) {
+    if (!step_dev || !bias_corr) return STEP_E_NULL;
+    return adam_flat_launch(param, grad, exp_avg, exp_avg_sq, n, seg_end, seg_lr, seg_wd, n_seg, beta1, beta2, eps, 0, step_dev, bias_corr,
+                            grad_scale, zero_grad, stream);
 }
 
 int step_act_grad(int dtype, const void* y, int y_cstride, int gy_dtype, const void* gy, int gy_cstride, const float* scale, long long M, int C,

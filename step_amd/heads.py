@@ -24,6 +24,10 @@ from .backbone import (MIXED_CFG, ConvUnit, _ver, _no_data_parallel, MaxPoolTF, 
 from .roi_layers import ROIAlign, ROIPool
 from .tube_math import encode_coef
 
+import os
+
+SYNC_FREE_LOSSES = os.environ.get("STEP_REF_LOSS_BRANCHES", "0") != "1"    # see TwoBranchNet.forward (losses)
+
 
 class ROINet(nn.Module):
     """ROI pool | align over tubes: frames are flattened into the batch axis and each tube box is a
@@ -338,25 +342,42 @@ class TwoBranchNet(nn.Module):
             center_targets, first_targets, last_targets = targets[:, 1], targets[:, 0], targets[:, -1]
             center_tubes = tubes[:, chunk_idx[int(chunks / 2)]]
             first_tubes, last_tubes = tubes[:, chunk_idx[0]], tubes[:, chunk_idx[-1]]
+            # The reference branches on `if mask.sum():` (two_branch.py:289,301,318): three device->host round trips per head and
+            # step, each draining the launch queue, and impossible inside a captured HIP graph.  SYNC_FREE_LOSSES (default)
+            # computes the same values without looking at the mask on the host: an all-zero mask yields an exactly zero loss with
+            # zero gradients either way.  The one visible difference is the degenerate no-positive batch, where the reference
+            # returns a ONE-element zero loss_global_cls and this path N*classes zeros (same .mean()); STEP_REF_LOSS_BRANCHES=1
+            # restores the host branches.
+            free = SYNC_FREE_LOSSES or (global_class.is_cuda and torch.cuda.is_current_stream_capturing())
+
+            def positive(m):
+                return (m.sum() > 0) if free else bool(m.sum())
+
+            def mean_over(l, m):
+                s_ = torch.sum(m)
+                return torch.sum(l * m) / (torch.where(s_ > 0, s_, torch.ones_like(s_)) if free else s_)
             with torch.no_grad():
                 mask = center_targets[:, 4].reshape(-1, 1)
-            if mask.sum():
+            pos = positive(mask)
+            if free or pos:
                 loss_global_cls = F.binary_cross_entropy_with_logits(global_class, center_targets[:, 6:] * mask, reduction="none")
+                if free:
+                    loss_global_cls = loss_global_cls * pos.to(loss_global_cls.dtype)
             if not self.cls_only:
                 tgt = encode_coef(center_targets[:, :4].clone(), center_tubes.reshape(-1, 5)[:, 1:])
                 with torch.no_grad():
                     mask = center_targets[:, 5].reshape(-1, 1).repeat(1, 4)
-                if mask.sum():
+                if free or positive(mask):
                     l = F.smooth_l1_loss(center_pred, tgt, reduction="none")
-                    loss_local_loc = torch.sum(l * mask) / torch.sum(mask)
+                    loss_local_loc = mean_over(l, mask)
                 ntgt = encode_coef(torch.cat([first_targets[:, :4], last_targets[:, :4]], 0),
                                    torch.cat([first_tubes.reshape(-1, 5)[:, 1:], last_tubes.reshape(-1, 5)[:, 1:]], 0))
                 with torch.no_grad():
                     nmask = torch.cat([first_targets[:, 5].reshape(-1, 1).repeat(1, 4),
                                        last_targets[:, 5].reshape(-1, 1).repeat(1, 4)], 0)
-                if nmask.sum():
+                if free or positive(nmask):
                     l = F.smooth_l1_loss(torch.cat([first_pred, last_pred], 0), ntgt, reduction="none")
-                    loss_neighbor_loc = torch.sum(l * nmask) / torch.sum(nmask)
+                    loss_neighbor_loc = mean_over(l, nmask)
 
         return (torch.sigmoid(global_class), local_loc, first_loc, last_loc, loss_global_cls.reshape(-1),
                 loss_local_loc.reshape(-1), loss_neighbor_loc.reshape(-1))

@@ -23,7 +23,7 @@ class FlatAdam(torch.optim.Optimizer):
     """A torch.optim.Optimizer (the reference's schedulers subclass torch's _LRScheduler, which insists on one:
     utils/solver.py:96,141) whose whole state lives in four flat arenas."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
         # the base class normalises `params` into self.param_groups (fills lr / betas / eps / weight_decay defaults,
         # rejects duplicates) exactly as it does for torch.optim.Adam
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
@@ -65,7 +65,21 @@ class FlatAdam(torch.optim.Optimizer):
         self._seg_lr = torch.zeros(len(ends), dtype=torch.float32, device=dev)
         self._seg_wd = torch.zeros(len(ends), dtype=torch.float32, device=dev)
         self._tables = None
-        self.step_count = 0
+        # capturable (as torch.optim.Adam's flag): the step counter lives on the device and step() is free of host scalars, so a
+        # whole training step can be captured in a HIP graph and replayed (step_adam_flat_dev)
+        self.capturable = bool(capturable)
+        self._step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._bias_corr = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._step_host = 0
+
+    @property
+    def step_count(self):
+        return int(self._step_dev.item()) if self.capturable else self._step_host
+
+    @step_count.setter
+    def step_count(self, v):
+        self._step_host = int(v)
+        self._step_dev.fill_(int(v))
 
     # -- torch.optim.Optimizer surface ---------------------------------------------------------------------------
     def zero_grad(self, set_to_none=False):
@@ -107,14 +121,21 @@ class FlatAdam(torch.optim.Optimizer):
         wgrad_sync()                                             # weight gradients still in flight on the side stream
         self._gather_stray_grads()
         self._refresh_tables()
-        self.step_count += 1
         g0 = self.param_groups[0]
         L = _lib.lib()
-        _capi.check(L.step_adam_flat(_lib.dptr(self.flat_param), _lib.dptr(self.flat_grad), _lib.dptr(self.exp_avg),
-                                     _lib.dptr(self.exp_avg_sq), self.numel, _lib.dptr(self._seg_end), _lib.dptr(self._seg_lr),
-                                     _lib.dptr(self._seg_wd), len(self._entries), float(g0["betas"][0]), float(g0["betas"][1]),
-                                     float(g0["eps"]), self.step_count, float(grad_scale), int(bool(zero_grad)),
-                                     _lib.stream_ptr(self.device)), "step_adam_flat")
+        if self.capturable:
+            _capi.check(L.step_adam_flat_dev(_lib.dptr(self.flat_param), _lib.dptr(self.flat_grad), _lib.dptr(self.exp_avg),
+                                             _lib.dptr(self.exp_avg_sq), self.numel, _lib.dptr(self._seg_end), _lib.dptr(self._seg_lr),
+                                             _lib.dptr(self._seg_wd), len(self._entries), float(g0["betas"][0]), float(g0["betas"][1]),
+                                             float(g0["eps"]), _lib.dptr(self._step_dev), _lib.dptr(self._bias_corr), float(grad_scale),
+                                             int(bool(zero_grad)), _lib.stream_ptr(self.device)), "step_adam_flat_dev")
+        else:
+            self._step_host += 1
+            _capi.check(L.step_adam_flat(_lib.dptr(self.flat_param), _lib.dptr(self.flat_grad), _lib.dptr(self.exp_avg),
+                                         _lib.dptr(self.exp_avg_sq), self.numel, _lib.dptr(self._seg_end), _lib.dptr(self._seg_lr),
+                                         _lib.dptr(self._seg_wd), len(self._entries), float(g0["betas"][0]), float(g0["betas"][1]),
+                                         float(g0["eps"]), self._step_host, float(grad_scale), int(bool(zero_grad)),
+                                         _lib.stream_ptr(self.device)), "step_adam_flat")
         # the kernel wrote through raw pointers: bump the autograd version counters (the packed-weight caches of
         # backbone.py / heads.py are keyed on them)
         torch.autograd.graph.increment_version([p for _, p, _, _ in self._entries])

@@ -87,7 +87,7 @@ class C4TrainStep:
     selection between steps (utils/utils.py:135-423, host Python) is not part of the hot path: every step trains on the
     same `tubes_per_clip` anchor tubes, extended to the step's length."""
 
-    def __init__(self, dev, batch=1, tubes_per_clip=5, seed=123, max_iter=3, dtype=torch.float32):
+    def __init__(self, dev, batch=1, tubes_per_clip=5, seed=123, max_iter=3, dtype=torch.float32, capturable=False):
         # replicas: the same weights on every rank (same init seed, then rank 0's copy is broadcast once, as DDP does);
         # `seed` only varies the rank's clips
         self.args, self.base, self.ctx, self.nets = build_nets(dev, 123, heads=max_iter)
@@ -97,7 +97,8 @@ class C4TrainStep:
         for m in self.mods:
             m.train()
         self.params = [p for m in self.mods for p in m.parameters() if p.requires_grad]
-        self.opt = FlatAdam(self.params, lr=1e-5)
+        self.opt = FlatAdam(self.params, lr=1e-5, capturable=capturable)
+        self.graph = None
         # the gradient exchange runs bucket by bucket on a communication stream WHILE backward is still producing the
         # earlier layers' gradients (step_amd.dist.BucketedReducer); single-process runs issue nothing
         self.reducer = sdist.BucketedReducer(self.opt)
@@ -143,11 +144,48 @@ class C4TrainStep:
         self.scale = self.reducer.finish() if exchange else 1.0
         return loss
 
-    def step(self):
+    def _eager_step(self):
         loss = self.forward_backward(exchange=True)
         self.opt.step(grad_scale=self.scale, zero_grad=True)     # gradients are clean for the next backward
         self.loss = loss.detach()
         return self.loss
+
+    def step(self):
+        if self.graph is not None:
+            self.graph.replay()                                  # ~1300 launches, one submission
+            return self.loss
+        return self._eager_step()
+
+    def capture(self, warmup=3):
+        """Capture the WHOLE step (forward, backward with the side-stream weight gradients, weight re-pack, Adam) in one HIP graph;
+        step() then replays it.  The shapes of this step are static (fixed tubes per clip), every scalar that changes between
+        steps lives on the device (FlatAdam(capturable=True): step counter), and nothing on the path synchronises with the host --
+        with 16-bit activations the eager step is bound by the host issuing ~1300 launches, not by the GPU.  Single process
+        only: the bucketed gradient exchange of a multi-rank run stays eager.  Runs `warmup` eager steps first (caches, pack
+        tables, workspaces); the captured step itself is recorded, not executed."""
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            raise RuntimeError("C4TrainStep.capture: single-process only (the gradient exchange is not captured)")
+        if not self.opt.capturable:
+            raise RuntimeError("C4TrainStep.capture: build the workload with capturable=True (device-side Adam step counter)")
+        import gc
+        gc.collect()                                             # (torch.cuda.graph collects too: dead nets must not drop out of the re-pack table mid-capture)
+        dev = self.x.device
+        cur = torch.cuda.current_stream(dev)
+        s = torch.cuda.Stream(dev)
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._eager_step()
+        cur.wait_stream(s)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._eager_step()
+        # host-side caches now carry the version stamps of a step whose kernels only run on replay: make them stale again for
+        # any eager use of the modules after this point
+        torch.autograd.graph.increment_version(self.params)
+        self.graph = g
+        return self
 
 
 class C4SelectTrainStep(C4TrainStep):

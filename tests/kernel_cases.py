@@ -428,10 +428,13 @@ def case_adam_flat(bk, golden):
         tp.append(torch.nn.Parameter(torch.from_numpy(p0[off:off + sz_].copy())))
         off += sz_
     opt = torch.optim.Adam([{"params": [t], "lr": lr, "weight_decay": wd} for t, lr, wd in zip(tp, lrs, wds)], lr=1e-3)
-    P, M, V = bk.dev(p0), bk.dev(np.zeros(n, np.float32)), bk.dev(np.zeros(n, np.float32))
+    P, M, V = bk.dev(p0.copy()), bk.dev(np.zeros(n, np.float32)), bk.dev(np.zeros(n, np.float32))
     ends = bk.dev(np.cumsum(sizes).astype(np.int64))
     LR, WD = bk.dev(np.array(lrs, np.float32)), bk.dev(np.array(wds, np.float32))
     scale = 0.25
+    # the same trajectory with the step counter on the device (step_adam_flat_dev: what a captured training step replays)
+    P2, M2, V2 = bk.dev(p0.copy()), bk.dev(np.zeros(n, np.float32)), bk.dev(np.zeros(n, np.float32))    # (EmuBackend buffers alias their array)
+    cnt, bc = bk.dev(np.zeros(1, np.int64)), bk.dev(np.zeros(2, np.float32))
     for step_no in (1, 2, 3):
         g = (rs.randn(n) * (10.0 ** rs.uniform(-4, 1, n))).astype(np.float32)
         off = 0
@@ -439,7 +442,7 @@ def case_adam_flat(bk, golden):
             t.grad = torch.from_numpy(g[off:off + sz_] * np.float32(scale))
             off += sz_
         opt.step()
-        G = bk.dev(g)
+        G, G2 = bk.dev(g.copy()), bk.dev(g.copy())
         zero = int(step_no != 2)
         assert bk.lib.step_adam_flat(P.ptr, G.ptr, M.ptr, V.ptr, n, ends.ptr, LR.ptr, WD.ptr, len(sizes), 0.9, 0.999, 1e-8,
                                      step_no, scale, zero, bk.stream) == 0
@@ -450,7 +453,14 @@ def case_adam_flat(bk, golden):
         ga = np.abs(g * np.float32(scale)) + 1e-2                 # moments: a few ulp of the operands (m may cancel against g)
         assert np.all(np.abs(M.get() - refm) <= 1e-5 * np.abs(refm) + 1e-6 * ga), step_no
         assert np.all(np.abs(V.get() - refv) <= 1e-5 * np.abs(refv) + 1e-6 * ga * ga), step_no
+        assert bk.lib.step_adam_flat_dev(P2.ptr, G2.ptr, M2.ptr, V2.ptr, n, ends.ptr, LR.ptr, WD.ptr, len(sizes), 0.9, 0.999, 1e-8,
+                                         cnt.ptr, bc.ptr, scale, zero, bk.stream) == 0
+        assert int(cnt.get()[0]) == step_no
+        assert np.abs(P2.get() - P.get()).max() <= 2e-7 * np.abs(ref).max() and np.array_equal(M2.get(), M.get()) \
+            and np.array_equal(V2.get(), V.get()) and np.array_equal(G2.get(), G.get()), step_no
         assert np.array_equal(G.get(), np.zeros(n, np.float32) if zero else g)
+    assert bk.lib.step_adam_flat_dev(P2.ptr, G2.ptr, M2.ptr, V2.ptr, n, ends.ptr, LR.ptr, WD.ptr, len(sizes), 0.9, 0.999, 1e-8,
+                                     None, bc.ptr, scale, 0, bk.stream) < 0
     assert bk.lib.step_adam_flat(P.ptr, G.ptr, M.ptr, V.ptr, n + 2, ends.ptr, LR.ptr, WD.ptr, len(sizes), 0.9, 0.999, 1e-8, 1, 1.0,
                                  0, bk.stream) < 0                                        # n % 4
     assert bk.lib.step_adam_flat(P.ptr, G.ptr, M.ptr, V.ptr, n, ends.ptr, LR.ptr, WD.ptr, len(sizes), 0.9, 0.999, 1e-8, 0, 1.0,

@@ -825,6 +825,47 @@ def case_stem_backward_16bit(dev, golden):
         assert np.isfinite(grads["new"]).all() and e_new < 6e-2 and e_new < 1.2 * e_old + 1e-3 and e_no < 5e-3, (shape, e_new, e_old, e_no)
 
 
+def case_loss_masks_without_host_branches(dev, golden):
+    """The heads' losses without the reference's `if mask.sum():` host branches (heads.SYNC_FREE_LOSSES, the default) equal the
+    branching form bit for bit when positives exist; a batch without positives gives exactly zero losses and zero gradients in
+    both forms (the reference's one-element zero classification loss becomes N*classes zeros: same mean)."""
+    from step_amd import heads
+    g = golden("head_golden")
+    pf = R.fill_tensor("golden.det.pooled3", (2, 3, 832, 7, 7), "feat").to(dev)
+    cx = R.fill_tensor("golden.det.ctx3", (2, 1024, 3, 1, 1), "feat").to(dev)
+    tubes, targets = torch.from_numpy(g["loss_tubes"]).to(dev), torch.from_numpy(g["loss_targets"]).to(dev)
+    empty = targets.clone()
+    empty[:, :, 4:6] = 0
+    keep = heads.SYNC_FREE_LOSSES
+    out = {}
+    try:
+        for free in (True, False):
+            heads.SYNC_FREE_LOSSES = free
+            for tag, tg in (("pos", targets), ("none", empty)):
+                net = fill(step_amd.TwoBranchNet(cfg()), "det0.").to(dev)
+                net.set_device(dev)
+                net.train()
+                for m in net.modules():
+                    if isinstance(m, torch.nn.Dropout):
+                        m.p = 0.0
+                o = net(pf, context_feat=cx, tubes=tubes, targets=tg)
+                loss = o[4].mean() + 5.0 * o[5].mean() + o[6].mean()
+                gsum = 0.0
+                if loss.requires_grad:
+                    loss.backward()
+                    gsum = sum(float(p.grad.abs().sum()) for p in net.parameters() if p.grad is not None)
+                out[(free, tag)] = ([np_(o[i]) for i in (4, 5, 6)], gsum)
+    finally:
+        heads.SYNC_FREE_LOSSES = keep
+    for i in range(3):
+        assert np.array_equal(out[(True, "pos")][0][i], out[(False, "pos")][0][i]), i
+    assert out[(True, "pos")][1] > 0 and abs(out[(True, "pos")][1] - out[(False, "pos")][1]) <= 1e-5 * out[(False, "pos")][1]
+    for free in (True, False):
+        ls, gsum = out[(free, "none")]
+        assert all(float(np.abs(l).max()) == 0.0 for l in ls) and gsum == 0.0, (free, gsum)
+    assert out[(False, "none")][0][0].size == 1 and out[(True, "none")][0][0].size == out[(True, "pos")][0][0].size
+
+
 def case_c2_full_size_properties(dev, golden):
     """BASELINE C2 at its full size (8 x [32,3,224,224], bf16) -- too big for the oracle, so parity is checked through
     size-independent properties:
@@ -875,5 +916,6 @@ CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_g
              "case_flat_adam_matches_torch", "case_wgrad_into_and_targets", "case_twobranch_variants_golden",
              "case_reg_unit_pack_follows_weight_updates", "case_basenet_backward_matches_oracle_autograd",
              "case_contextnet_backward_matches_oracle_autograd", "case_postprocess_golden",
-             "case_batched_repack_follows_weight_updates", "case_stem_backward_16bit"]
+             "case_batched_repack_follows_weight_updates", "case_stem_backward_16bit",
+             "case_loss_masks_without_host_branches"]
 GPU_CASES = CPU_CASES + ["case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_c5_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_i3d_classifier_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
