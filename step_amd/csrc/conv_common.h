@@ -158,6 +158,13 @@ template <typename T> int conv_tap_ph_launch(const ConvPlan& pl, const ConvParam
 template <> int conv_tap_ph_launch<bf16_t>(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream);
 template <> int conv_tap_ph_launch<f16_t>(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream);
 template <typename T> int conv_pw_launch(int NB, int wv, const ConvParams& p, dim3 grid, step_stream_t stream);                        // conv_pw.hip
+template <typename T> int conv_pws_launch(int nbw, const ConvParams& p, dim3 grid, step_stream_t stream);                              // conv_pw.hip (weight-stationary stream, 16-bit)
+// conv_pws_kernel: nbw channel blocks per workgroup, KC16 16-channel chunks -> blocks per pass (<= 3: registers), 64-channel steps
+static inline void pws_shape(int nbw, int KC16, int& NB, int& S) {
+    NB = nbw >= 3 ? 3 : nbw;
+    if (nbw == 4) NB = 2;                                     // two even passes
+    S = (KC16 + 3) / 4;
+}
 template <typename T> int conv_splitk_launch(const ConvPlan& pl, const ConvParams& p, float* ws, step_stream_t stream);        // conv_pw.hip
 
 }  // namespace step

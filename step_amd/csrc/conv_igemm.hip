@@ -426,7 +426,7 @@ static bool prefer_four_waves_pw(const step_conv_desc* d, long long wgs8) {
     return wgs8 < 128 || M >= 65536;
 }
 
-static ConvPlan conv_plan(const step_conv_desc* d) {
+static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true) {
     ConvPlan pl;
     pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1; pl.mb = 2; pl.wv = 8; pl.ph = 0; pl.deep = false; pl.twl = 4; pl.tiles_d = d->D; pl.gtd = pl.gth = pl.gtw = 1; pl.ksplit = 0; pl.kchunk16 = 0; pl.mbk = 0; pl.mpad = 0; pl.cpad = 0;
     const int nblk32 = ceil_div(d->Cout, 32);
@@ -440,6 +440,36 @@ static ConvPlan conv_plan(const step_conv_desc* d) {
         // deep-K pointwise convs on enough pixels: the streaming 8-wave GEMM (STEP_CONV_IMPL=igemm forces the other)
         const long long mt256 = ceil_div64((long long)d->N * d->D * d->H * d->W, 256);
         const int ov1 = conv_impl_override();
+        {
+            // the weight-stationary stream (conv_pws_kernel): 16-bit, 16-byte channel vectors, the weights of a channel group
+            // (NB blocks x K) within 104 KiB of LDS.  STEP_CONV_PWS: 1 = wherever the contract allows, 0 = never.
+            const int pws_env = getenv("STEP_CONV_PWS") ? atoi(getenv("STEP_CONV_PWS")) : -1;     // (read per call: the tests switch it)
+            const int KC16 = ceil_div(d->Cin, CK) * 2;
+            const long long M = (long long)d->N * d->D * d->H * d->W;
+            const bool can = d->dtype != STEP_F32 && (d->Cin % 8) == 0 && (d->x_cstride % 8) == 0 && (d->x_coff % 8) == 0 && KC16 <= 16 &&
+                             (d->y_cstride % 8) == 0 && (d->y_coff % 8) == 0 && (d->Cout % 8) == 0 && d->res_cstride == 0 &&
+                             (d->split == 0 || ((d->split % 8) == 0 && (d->y2_cstride % 8) == 0 && (d->y2_coff % 8) == 0)) && M >= 1024;
+            // measured (tools/ab_bench.py, bf16): the only class it wins is K = 256 with many channel blocks on a large map -- the 3c
+            // fused triple 43.1 -> 37.4 us at 28x28 (batch 8), 65.2 -> 55.3 us at 50x50 (batch 4); equal within 3 % on conv3d_2b and
+            // the 3b triple, 5-12 % slower on the narrow branch_3 layers: the default covers that class only
+            const bool wins = KC16 > 12 && nblk32 >= 6 && M >= 65536;
+            if (allow_pws && can && pws_env != 0 && (pws_env == 1 || wins) && ov1 == -1) {
+                int nbmax = 152 / (ceil_div(KC16, 4) * 4);               // (LDS holds K padded to whole 64-channel steps)
+                if (nbmax > 16) nbmax = 16;
+                if (nbmax > nblk32) nbmax = nblk32;
+                const int groups = ceil_div(nblk32, nbmax);
+                pl.impl = 4;
+                pl.NB = ceil_div(nblk32, groups);                         // channel blocks per workgroup (balanced groups)
+                pl.wv = 8;
+                static const int pws_gx = getenv("STEP_PWS_GX") ? atoi(getenv("STEP_PWS_GX")) : 256;      // tuning aid
+                long long gx = pws_gx / groups;                            // one workgroup per CU
+                if (gx < 1) gx = 1;
+                const long long need = ceil_div64(ceil_div64(M, 32), 8);
+                if (gx > need) gx = need;
+                pl.mtiles = gx;
+                return pl;
+            }
+        }
         if (ov1 == 5 || (ov1 != 0 && d->Cin >= 128 && d->Cout >= 64 && mt256 * ceil_div(nblk32, 2) >= 32)) {
             pl.impl = 2;
             const int waves_env = getenv("STEP_CONV_WAVES") ? atoi(getenv("STEP_CONV_WAVES")) : 0;      // tuning aid / tests: 4 | 8
@@ -613,6 +643,11 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_
         const long long tot = pl.mtiles * groups;
         return dim3((unsigned)((tot + 7) / 8 * 8));
     };
+    if (pl.impl == 4) {
+        if (!p.res && p.vec_epi)
+            return conv_pws_launch<T>(pl.NB, p, dim3((unsigned)pl.mtiles, (unsigned)ceil_div(p.nblk32, pl.NB)), stream);
+        pl = conv_plan(d, false);                               // (an output pointer off the 16-byte grid: the general kernels)
+    }
     if (pl.impl == 2) {
         dim3 grid = grid1d(ceil_div(p.nblk32, 2 * pl.NB));
         return conv_pw_launch<T>(pl.NB, pl.wv, p, grid, stream);
@@ -756,6 +791,11 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
     const char* t = d->dtype == STEP_F32 ? "float" : (d->dtype == STEP_BF16 ? "step::bf16_t" : "step::f16_t");
     if (pl.impl == 3)
         snprintf(buf, (size_t)buflen, "void step::pw_splitk_kernel<%s, %d>(step::ConvParams, float*, int, int, int)", t, pl.mbk);
+    else if (pl.impl == 4) {
+        int nb, ksteps;
+        pws_shape(pl.NB, ceil_div(d->Cin, CK) * 2, nb, ksteps);
+        snprintf(buf, (size_t)buflen, "void step::conv_pws_kernel<%s, %d, %d>(step::ConvParams, int)", t, nb, ksteps);
+    }
     else if (pl.impl == 2)
         snprintf(buf, (size_t)buflen, "void step::conv_pw_kernel<%s, %d, %d>(step::ConvParams)", t, pl.NB, pl.wv);
     else if (pl.impl == 1)

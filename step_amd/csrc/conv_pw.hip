@@ -383,6 +383,153 @@ static int splitk_forward_t(const ConvPlan& pl, const ConvParams& p, float* ws, 
 }
 
 
+// ============================================================================================
+// conv_pws_kernel -- SHORT-K pointwise convs (K <= 256) as a weight-stationary stream (16-bit types).  The streaming GEMM
+// above stages both operands through LDS rings with a barrier per 32-channel step; with K = 64..256 (2-8 steps) its prologue,
+// first HBM round trip and epilogue are exposed once per 128/256-pixel workgroup: 2.3-3.5 TB/s of activation traffic on the
+// 28x28 / 56x56 maps.  Here:
+//   * a workgroup (8 waves, one per CU) loads the packed weights of its NBW output-channel blocks ONCE -- [NBW][K/16] 1 KiB
+//     fragments, <= 152 KiB -- and every wave then walks 32-pixel groups on its own: no barrier after the weight load;
+//   * the product is taken TRANSPOSED, D^T = W X^T: the weight fragment is the A operand (rows = output channels; the packed
+//     image already has that lane layout) and the activations are the B operand, whose fragment -- lane = pixel, 8 consecutive
+//     input channels -- is ONE 16-byte global load from the channels-last tensor: activations never pass through LDS;
+//   * a wave holds ALL K of its pixel group in registers (S steps of 64 channels: <= 64 VGPRs) and the next group's loads
+//     (another S steps) are in flight while it walks the channel blocks NB at a time (16 NB accumulator registers): up to
+//     16 KiB in flight per wave, every byte of the input loaded exactly once;
+//   * the accumulator holds, per lane, ONE pixel and groups of 4 consecutive output channels: the epilogue (scale, shift, ReLU,
+//     two destinations) stores 8-byte pieces straight from registers, no transpose through LDS.
+constexpr int PWS_LDSW = 152 * 1024;                        // weight image: up to 152 (block, 16-channel chunk) fragments
+constexpr int PWS_WV = 8;
+constexpr int PWS_MAXB = 16;                                // channel blocks per workgroup
+
+template <typename T, int NB, int S>
+__global__ __launch_bounds__(PWS_WV * 64) void conv_pws_kernel(ConvParams p, int NBW) {
+    static_assert(sizeof(T) == 2, "16-bit storage types");
+    typedef typename frag<T>::type frag_t;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[PWS_LDSW + 2 * PWS_MAXB * 32 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, khalf = lane >> 5;
+#ifdef STEP_EMUL
+    const int wave = tid >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const int KC16 = p.nchunks32 * 2;                         // <= 4 S
+    const int nbw0 = blockIdx.y * NBW;                        // the workgroup's channel blocks [nbw0, nbw0 + NBW)
+    const int nbwv = min(NBW, p.nblk32 - nbw0);
+    constexpr int KCP = 4 * S;                                // chunks per block in LDS: K padded to whole steps with ZERO weights,
+    {                                                         // so that the chunk loop below has no run-time bound (no branches)
+        const u32x4* src = (const u32x4*)((const unsigned char*)p.w + (size_t)nbw0 * KC16 * 1024);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int v = tid; v < nbwv * KCP * 64; v += PWS_WV * 64) {
+            const int blk = v / (KCP * 64), rem = v % (KCP * 64), kc = rem >> 6;
+            ((u32x4*)lds)[v] = kc < KC16 ? src[(blk * KC16 + kc) * 64 + (rem & 63)] : z;
+        }
+        float* sc = (float*)(lds + PWS_LDSW);
+        for (int i = tid; i < nbwv * 32; i += PWS_WV * 64) {
+            const int co = nbw0 * 32 + i;
+            sc[i] = (p.scale && co < p.Cout) ? p.scale[co] : 1.f;
+            sc[PWS_MAXB * 32 + i] = (p.shift && co < p.Cout) ? p.shift[co] : 0.f;
+        }
+    }
+    __syncthreads();
+    const float* scl = (const float*)(lds + PWS_LDSW);
+    const float* shl = scl + PWS_MAXB * 32;
+    const long long ngroups = (p.Mtot + 31) >> 5;
+    const long long gstride = (long long)gridDim.x * PWS_WV;
+    const T* xg = (const T*)p.x;
+
+    frag_t xa[2][S * 4];
+    auto load_group = [&](auto setc, long long g) {
+        constexpr int SET = decltype(setc)::value;
+        const long long gm = g * 32 + (lane & 31);
+        const bool ok = g < ngroups && gm < p.Mtot;
+        const T* xp = xg + (size_t)(ok ? gm : 0) * p.x_cstride + p.x_coff + 8 * khalf;
+#pragma unroll
+        for (int j = 0; j < S * 4; ++j) {
+            frag_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok && j * 16 + 8 * khalf < p.Cin) v = *(const frag_t*)(xp + j * 16);
+            xa[SET][j] = v;
+        }
+    };
+    auto group = [&](auto setc, long long g) {
+        constexpr int SET = decltype(setc)::value;
+        const long long gm = g * 32 + (lane & 31);
+        const bool ok = gm < p.Mtot;
+        for (int b0 = 0; b0 < nbwv; b0 += NB) {
+            f32x16 acc[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            const unsigned char* wb[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) wb[i] = lds + ((size_t)min(b0 + i, nbwv - 1) * KCP * 64 + lane) * 16;   // (a surplus block repeats the last one and is not stored)
+#pragma unroll
+            for (int j = 0; j < KCP; ++j)
+#pragma unroll
+                for (int i = 0; i < NB; ++i) mma_k16(lds_read_bfrag<T>(wb[i] + j * 1024), xa[SET][j], acc[i], T());
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c4 = (b0 + i) * 32 + 8 * q + 4 * khalf, co = nbw0 * 32 + c4;
+                    if (ok && b0 + i < nbwv && co < p.Cout) {
+                        const f32x4 s4 = *(const f32x4*)(scl + c4), h4 = *(const f32x4*)(shl + c4);
+                        u16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[i][4 * q + e] * s4[e] + h4[e];
+                            if (p.relu) v = fmaxf(v, 0.f);
+                            o[e] = elem<T>::bits16(v);
+                        }
+                        if (p.split > 0 && co >= p.split) *(u16x4*)((T*)p.y2 + (size_t)gm * p.y2_cstride + p.y2_coff + (co - p.split)) = o;
+                        else *(u16x4*)((T*)p.y + (size_t)gm * p.y_cstride + p.y_coff + co) = o;
+                    }
+                }
+            }
+        }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    long long g = (long long)blockIdx.x * PWS_WV + wave;
+    if (g >= ngroups) return;
+    load_group(I0(), g);
+    while (true) {
+        load_group(I1(), g + gstride);                        // (past the last group: no loads)
+        group(I0(), g);
+        g += gstride;
+        if (g >= ngroups) break;
+        load_group(I0(), g + gstride);
+        group(I1(), g);
+        g += gstride;
+        if (g >= ngroups) break;
+    }
+}
+
+template <typename T, int NB>
+static void conv_pws_launch_s(int S, const ConvParams& p, int nbw, dim3 grid, step_stream_t stream) {
+    switch (S) {
+        case 1: STEP_LAUNCH((conv_pws_kernel<T, NB, 1>), grid, dim3(PWS_WV * 64), stream, p, nbw); break;
+        case 2: STEP_LAUNCH((conv_pws_kernel<T, NB, 2>), grid, dim3(PWS_WV * 64), stream, p, nbw); break;
+        case 3: STEP_LAUNCH((conv_pws_kernel<T, NB, 3>), grid, dim3(PWS_WV * 64), stream, p, nbw); break;
+        default: STEP_LAUNCH((conv_pws_kernel<T, NB, 4>), grid, dim3(PWS_WV * 64), stream, p, nbw); break;
+    }
+}
+// nbw = channel blocks per workgroup (nbw * K/16 <= 152, K <= 256); blocks per pass and K steps: pws_shape
+template <typename T>
+int conv_pws_launch(int nbw, const ConvParams& p, dim3 grid, step_stream_t stream) {
+    int NB, S;
+    pws_shape(nbw, p.nchunks32 * 2, NB, S);
+    if (NB == 1) conv_pws_launch_s<T, 1>(S, p, nbw, grid, stream);
+    else if (NB == 2) conv_pws_launch_s<T, 2>(S, p, nbw, grid, stream);
+    else conv_pws_launch_s<T, 3>(S, p, nbw, grid, stream);
+    return STEP_LAUNCH_CHECK();
+}
+template <>
+int conv_pws_launch<float>(int, const ConvParams&, dim3, step_stream_t) { return STEP_E_UNSUPPORTED; }
+template int conv_pws_launch<bf16_t>(int, const ConvParams&, dim3, step_stream_t);
+template int conv_pws_launch<f16_t>(int, const ConvParams&, dim3, step_stream_t);
+
 template <typename T>
 int conv_pw_launch(int NB, int wv, const ConvParams& p, dim3 grid, step_stream_t stream) {
     if (wv == 4) {

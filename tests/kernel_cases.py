@@ -1136,6 +1136,67 @@ def case_conv_split_two_destinations(bk, golden):
     assert bk.lib.step_conv_forward(ctypes.byref(d), xe.ptr, wp.ptr, None, None, None, ya.ptr, yb.ptr, bk.stream) == -4
 
 
+def case_conv_pointwise_weight_stationary(bk, golden):
+    """conv_pws_kernel (the weight-stationary short-K pointwise stream, STEP_CONV_PWS=1) against the oracle and against the
+    default kernel: one to four 64-channel steps, a K tail that is not a multiple of 64 or 32, one to four passes over the
+    channel blocks with a partial last block, ragged pixel count, input and output channel slices, two destinations, no ReLU / no
+    affine; K > 256 stays with the default kernels."""
+    import os
+    rs = np.random.RandomState(31)
+    # (N, Cin, Cout, D, H, W, split, relu, affine, x_pad, y_pad)
+    cases = ((1, 64, 64, 2, 16, 33, 0, True, True, (0, 0), (0, 0)),
+             (1, 192, 176, 1, 20, 53, 64, True, True, (8, 16), (8, 8)),
+             (1, 528, 128, 1, 32, 33, 0, True, True, (0, 0), (0, 0)),
+             (1, 144, 40, 2, 8, 67, 0, False, False, (0, 8), (16, 0)),
+             (2, 32, 200, 1, 24, 23, 0, True, True, (0, 0), (0, 0)),
+             (1, 64, 296, 1, 16, 65, 96, True, True, (0, 0), (0, 0)),          # 10 blocks: four passes
+             (1, 256, 328, 1, 16, 65, 0, True, True, (0, 0), (0, 0)))          # 11 blocks x 16 chunks > 152: two workgroup-level channel groups
+    keep = os.environ.get("STEP_CONV_PWS")
+    try:
+        for (N, Cin, Cout, D, H, W, split, relu, affine, xp, yp) in cases:
+            x = rs.randn(N, Cin, D, H, W).astype(np.float32)
+            w = (rs.randn(Cout, Cin, 1, 1, 1) / np.sqrt(Cin)).astype(np.float32)
+            scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32) if affine else None
+            shift = (0.2 * rs.randn(Cout)).astype(np.float32) if affine else None
+            for dt in (BF16, F16):
+                ref = ref_conv(x, w, scale, shift, dt, relu=relu)
+                xb = np.full((N, D, H, W, xp[0] + Cin + xp[1]), 33.0, np.float32)
+                xb[..., xp[0]:xp[0] + Cin] = cl(x)
+                xe = bk.dev(encode(xb, dt))
+                wp = pack_weight(bk, w, dt)
+                ca = split if split else Cout
+                sc, sh = bk.dev(scale), bk.dev(shift)
+                outs = {}
+                for mode in ("1", "0"):
+                    os.environ["STEP_CONV_PWS"] = mode
+                    ya = bk.dev(np.zeros((N, D, H, W, yp[0] + ca + yp[1]), NP_DT[dt]))
+                    yb = bk.dev(np.zeros((N, D, H, W, 8 + (Cout - ca)), NP_DT[dt]))
+                    d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=xb.shape[-1], x_coff=xp[0],
+                                       y_cstride=yp[0] + ca + yp[1], y_coff=yp[0], res_cstride=0, res_coff=0, relu=int(relu), split=split,
+                                       y2_cstride=8 + (Cout - ca), y2_coff=8)
+                    name = ctypes.create_string_buffer(256)
+                    assert bk.lib.step_conv_kernel_name(ctypes.byref(d), name, 256) == 0
+                    assert (b"conv_pws_kernel" in name.value) == (mode == "1" and Cin <= 256), (mode, name.value)   # (K <= 256: the whole K of a pixel group lives in registers)
+                    assert bk.lib.step_conv_forward(ctypes.byref(d), xe.ptr, wp.ptr, sc.ptr, sh.ptr, None, ya.ptr, yb.ptr if split else None,
+                                                    bk.stream) == 0
+                    a = decode(ya.get(), dt)
+                    assert not a[..., :yp[0]].any() and not a[..., yp[0] + ca:].any()
+                    got = uncl(a[..., yp[0]:yp[0] + ca])
+                    if split:
+                        b = decode(yb.get(), dt)
+                        assert not b[..., :8].any()
+                        got = np.concatenate([got, uncl(b[..., 8:])], 1)
+                    outs[mode] = got
+                    assert np.abs(got - ref).max() / np.abs(ref).max() < tol(dt), (mode, Cin, Cout, dt)
+                # same operands, same fp32 accumulation order along K: the two kernels agree to the last bit
+                assert np.array_equal(outs["1"], outs["0"]), (Cin, Cout, dt)
+    finally:
+        if keep is None:
+            os.environ.pop("STEP_CONV_PWS", None)
+        else:
+            os.environ["STEP_CONV_PWS"] = keep
+
+
 def case_pack_weight_perm_folds_flatten_order(bk, golden):
     # Linear over an NCHW-flattened feature (c*HW+hw) evaluated on an NHWC-flattened one (hw*C+c)
     rs = np.random.RandomState(12)

@@ -41,8 +41,11 @@ def test_planner_dispatch(lib):
     # the heads' 2-D convs: N folds into D, plane-folded general boxes on 7x7 maps
     n, _ = name(lib, BF, 132, 256, 256, (1, 3, 3), 1, 7, 7)
     assert "conv_tap_kernel<step::bf16_t, 0, " in n and ", 1, 3, 3," in n
-    # deep pointwise layers stream through the 8-wave GEMM, shallow ones stay on the 4-wave kernel
-    assert "conv_pw_kernel" in name(lib, BF, 8, 256, 288, (1, 1, 1), 16, 28, 28)[0]
+    # deep pointwise layers stream through the 8-wave GEMM, shallow ones stay on the 4-wave kernel; K = 256 x many channel blocks
+    # on a large map (the 3c fused triple) takes the weight-stationary stream, fp32 and residual layers never do
+    assert "conv_pw_kernel" in name(lib, BF, 8, 480, 304, (1, 1, 1), 8, 14, 14)[0]
+    assert "conv_pws_kernel<step::bf16_t, 3, 4>" in name(lib, BF, 8, 256, 288, (1, 1, 1), 16, 28, 28)[0]
+    assert "conv_pw_kernel" in name(lib, F32, 8, 256, 288, (1, 1, 1), 16, 28, 28)[0]
     assert "conv_igemm_kernel" in name(lib, BF, 8, 64, 64, (1, 1, 1), 16, 56, 56)[0]
     # few rows x very deep K (Linear 12544 -> 60 on 132 rows): split-K with a caller-owned workspace, fp32 included
     for dt in (BF, F32):

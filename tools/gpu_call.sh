@@ -3,4 +3,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-for v in 2 1 0 2 1; do echo "STEP_BRANCH_STREAMS=$v"; STEP_BRANCH_STREAMS=$v timeout 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline 2>/dev/null | cut -c1-110; done
+timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tail -6 > $O/gputests.log; cat $O/gputests.log
+timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-330 $O/bench_default.json
+python -c "
+import json; d=json.load(open('$O/bench_default.json')); print(d['roofline']); print(d['cpu_baseline'])"
