@@ -360,6 +360,8 @@ static int pick_nb(int nblk32, long long mtiles) {
 static int pick_nb_tap(int nblk32, long long mtiles, int slots = 256) {
     const int forced = getenv("STEP_CONV_NB") ? atoi(getenv("STEP_CONV_NB")) : 0;     // tuning aid / tests (read per call)
     if (forced >= 1 && forced <= 3) return forced;
+    const int small = getenv("STEP_CONV_NB_SMALL") ? atoi(getenv("STEP_CONV_NB_SMALL")) : 0;  // tuning aid: depth for few-tile layers
+    if (small >= 1 && small <= 3 && mtiles <= 64) return small > (nblk32 + 1) / 2 ? (nblk32 + 1) / 2 : small;
     int best = 1;
     double best_cost = -1;
     for (int nb = 3; nb >= 1; --nb) {   // 2 fragment sets + 2*nb accumulators must fit 256 VGPRs: nb <= 3
