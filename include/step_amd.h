@@ -276,6 +276,15 @@ STEP_API int step_maxpool3d_tf(int dtype, const void* x, int N, int D, int H, in
 STEP_API int step_maxpool3d_tf_backward(int dtype, const void* x, int N, int D, int H, int W, int C, int x_cstride,
                                         int x_coff, int kd, int kh, int kw, int sd, int sh, int sw, const float* gy,
                                         float* gx, step_stream_t stream);
+/* The same gradient as two gathers instead of fp32 atomics: pass A writes one byte per output element (the window tap of the
+ * first maximum) into `arg_scratch` (N*Do*Ho*Wo*C bytes, device), pass B lets every input element collect the gradients of the
+ * windows it won, in a fixed order (bit-reproducible), and writes gx once -- in fp32 or in the activation type, from gy in fp32 or
+ * in the activation type (gy_dtype / gx_dtype: STEP_F32 or `dtype`), so a 16-bit net needs no fp32 staging, no clear and no
+ * conversion pass.  gy dense [N,Do,Ho,Wo,C], gx dense [N,D,H,W,C].  C (and the slice of x) must be whole 16-byte channel vectors of
+ * `dtype`, else STEP_E_UNSUPPORTED (the atomic entry above has no such limit). */
+STEP_API int step_maxpool3d_tf_backward_gather(int dtype, const void* x, int N, int D, int H, int W, int C, int x_cstride, int x_coff,
+                                               int kd, int kh, int kw, int sd, int sh, int sw, int gy_dtype, const void* gy, int gx_dtype,
+                                               void* gx, unsigned char* arg_scratch, step_stream_t stream);
 
 /* Average pool over a full (kh x kw) window, stride 1, no padding ("VALID"), kd = 1.
  * replaces nn.AvgPool3d((1,13,13),(1,1,1)) of ContextNet (models/two_branch.py:127,136).

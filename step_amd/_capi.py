@@ -4,7 +4,7 @@ import ctypes as C
 
 F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 vp, fp, ip, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # raw device addresses
 i, f, ll, sz = C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -57,6 +57,7 @@ SIGNATURES = {
     "step_pool_out_size": (i, [i, i, i]),
     "step_maxpool3d_tf": (i, [i, vp, i, i, i, i, i, i, i, i, i, i, i, i, i, vp, i, i, vp]),
     "step_maxpool3d_tf_backward": (i, [i, vp, i, i, i, i, i, i, i, i, i, i, i, i, i, fp, fp, vp]),
+    "step_maxpool3d_tf_backward_gather": (i, [i, vp, i, i, i, i, i, i, i, i, i, i, i, i, i, i, vp, i, vp, u8p, vp]),
     "step_clip_from_u8": (i, [vp, i, i, i, i, i, C.POINTER(C.c_float), C.POINTER(C.c_float), i, vp, vp]),
     "step_avgpool_hw": (i, [i, vp, i, i, i, i, i, i, i, vp, vp]),
     "step_transpose_cs": (i, [vp, i, vp, i, i, i, ll, i, vp]),

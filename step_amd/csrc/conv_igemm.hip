@@ -810,7 +810,7 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
 }
 
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 16; }
+int step_abi_version(void) { return 17; }
 
 }  // extern "C"
 

@@ -814,7 +814,8 @@ static Wg16Plan wgrad16_plan(const step_conv_desc* d) {
         pl.gy = (long long)d->kd * pl.cot * pl.cit;
     }
     // ~512 workgroups per launch; each walks several (plane, chunk) units (the next one's loads under this one's matrix work)
-    long long want = 512 / (pl.gy > 0 ? pl.gy : 1);
+    static const int wg_total = getenv("STEP_WGRAD16_WGS") ? atoi(getenv("STEP_WGRAD16_WGS")) : 512;      // tuning aid
+    long long want = wg_total / (pl.gy > 0 ? pl.gy : 1);
     if (want < 1) want = 1;
     long long upj = ceil_div64(pl.units, want);
     if (upj < 1) upj = 1;

@@ -386,6 +386,124 @@ __global__ void maxpool3d_tf_bwd_kernel(const T* __restrict__ x, const float* __
     }
 }
 
+// ---- max-pool backward as two gathers (no atomics, no clear, no fp32 staging) ------------------------------------------
+// maxpool3d_tf_bwd_kernel above scatters with fp32 atomics into a cleared fp32 tensor that the caller then converts: for a
+// 16-bit net ~24 bytes of traffic per input element and 2.3 ms of the 20 ms C4 step.  Same rule, gathered:
+//   pass A (maxpool_arg_kernel): one BYTE per output element = the tap (scan order (a * kh + b) * kw + c) of the FIRST maximum
+//     of its zero-padded window -- torch's `val > max` walk; a padding tap can win, and then no input owns the gradient;
+//   pass B (maxpool_bwd_gather_kernel): every input element visits the <= kd*kh*kw / (sd*sh*sw) windows that contain it and
+//     adds the gradients of those whose winning tap is its own position, in a fixed (od, oh, ow) order, and writes the result
+//     once in the activation type: ~4.5 bytes per element, bit-reproducible.
+// Lanes run along 16-byte channel vectors of x (8 channels for the 16-bit types, 4 for fp32).
+template <typename TG, int V>
+__device__ __forceinline__ void load_vec_f32(const TG* p, float (&f)[V]) {
+    if constexpr (sizeof(TG) == 4) {
+#pragma unroll
+        for (int q = 0; q < V / 4; ++q) {
+            const f32x4 v = *(const f32x4*)((const float*)p + 4 * q);
+            f[4 * q] = v[0]; f[4 * q + 1] = v[1]; f[4 * q + 2] = v[2]; f[4 * q + 3] = v[3];
+        }
+    } else {
+        static_assert(V == 8, "16-bit vectors carry 8 elements");
+        Vec16<TG, 8>::unpack(*(const typename Vec16<TG, 8>::raw*)p, f);
+    }
+}
+template <typename TO, int V>
+__device__ __forceinline__ void store_vec_f32(TO* p, const float (&f)[V]) {
+    if constexpr (sizeof(TO) == 4) {
+#pragma unroll
+        for (int q = 0; q < V / 4; ++q) {
+            const f32x4 v = {f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]};
+            *(f32x4*)((float*)p + 4 * q) = v;
+        }
+    } else {
+        static_assert(V == 8, "16-bit vectors carry 8 elements");
+        *(typename Vec16<TO, 8>::raw*)p = Vec16<TO, 8>::pack(f);
+    }
+}
+
+template <typename T>
+__global__ void maxpool_arg_kernel(const T* __restrict__ x, unsigned char* __restrict__ arg, PoolParams p, long long total) {
+    constexpr int V = elem<T>::VEC;
+    typedef typename Vec16<T, V>::raw raw;
+    const int CV = p.C / V;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)blockDim.x * gridDim.x) {
+        const int cv = (int)(idx % CV);
+        long long pix = idx / CV;
+        const int ow = (int)(pix % p.Wo); pix /= p.Wo;
+        const int oh = (int)(pix % p.Ho); pix /= p.Ho;
+        const int od = (int)(pix % p.Do);
+        const int n = (int)(pix / p.Do);
+        float best[V];
+        unsigned char win[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) { best[i] = -__builtin_inff(); win[i] = 0; }
+        for (int a = 0; a < p.kd; ++a) {
+            const int pd = od * p.sd + a;
+            if (pd >= p.Lpd) break;
+            const int id = pd - p.pfd;
+            for (int b = 0; b < p.kh; ++b) {
+                const int phh = oh * p.sh + b;
+                if (phh >= p.Lph) break;
+                const int ih = phh - p.pfh;
+                for (int c = 0; c < p.kw; ++c) {
+                    const int pw = ow * p.sw + c;
+                    if (pw >= p.Lpw) break;
+                    const int iw = pw - p.pfw;
+                    float f[V];
+#pragma unroll
+                    for (int i = 0; i < V; ++i) f[i] = 0.f;             // explicit TF padding: value 0
+                    if (id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                        Vec16<T, V>::unpack(*(const raw*)(x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.x_cstride + p.x_coff + cv * V), f);
+                    const unsigned char t = (unsigned char)((a * p.kh + b) * p.kw + c);
+#pragma unroll
+                    for (int i = 0; i < V; ++i)
+                        if (f[i] > best[i]) { best[i] = f[i]; win[i] = t; }
+                }
+            }
+        }
+        unsigned char* dst = arg + (size_t)idx * V;
+#pragma unroll
+        for (int i = 0; i < V; ++i) dst[i] = win[i];
+    }
+}
+
+template <typename T, typename TG, typename TO>
+__global__ void maxpool_bwd_gather_kernel(const unsigned char* __restrict__ arg, const TG* __restrict__ gy, TO* __restrict__ gx, PoolParams p,
+                                          long long total) {
+    constexpr int V = elem<T>::VEC;
+    const int CV = p.C / V;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)blockDim.x * gridDim.x) {
+        const int cv = (int)(idx % CV);
+        long long pix = idx / CV;
+        const int iw = (int)(pix % p.W); pix /= p.W;
+        const int ih = (int)(pix % p.H); pix /= p.H;
+        const int id = (int)(pix % p.D);
+        const int n = (int)(pix / p.D);
+        const int pd = id + p.pfd, ph = ih + p.pfh, pw = iw + p.pfw;       // padded coordinates
+        float sum[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) sum[i] = 0.f;
+        // windows that contain the position: o*s <= q <= o*s + k - 1
+        const int od0 = max(0, (pd - p.kd + p.sd) / p.sd), od1 = min(p.Do - 1, pd / p.sd);
+        const int oh0 = max(0, (ph - p.kh + p.sh) / p.sh), oh1 = min(p.Ho - 1, ph / p.sh);
+        const int ow0 = max(0, (pw - p.kw + p.sw) / p.sw), ow1 = min(p.Wo - 1, pw / p.sw);
+        for (int od = od0; od <= od1; ++od)
+            for (int oh = oh0; oh <= oh1; ++oh)
+                for (int ow = ow0; ow <= ow1; ++ow) {
+                    const unsigned char t = (unsigned char)(((pd - od * p.sd) * p.kh + (ph - oh * p.sh)) * p.kw + (pw - ow * p.sw));
+                    const size_t o = ((((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.C + cv * V;
+                    const unsigned char* wv = arg + o;
+                    float g[V];
+                    load_vec_f32<TG, V>(gy + o, g);
+#pragma unroll
+                    for (int i = 0; i < V; ++i)
+                        if (wv[i] == t) sum[i] += g[i];
+                }
+        store_vec_f32<TO, V>(gx + (size_t)idx * V, sum);
+    }
+}
+
 // Clip ingest: decoded frames arrive as uint8 [N,T,H,W,3] (what cv2 / the data loader hands over,
 // data/ava.py:298-338); the reference converts on the host -- ConvertFromInts(scale), SubtractMeans, DivideStds
 // (data/augmentations.py:68-111,600-612) -- and ships fp32 [T,3,H,W] over PCIe (4x the bytes).  Here the uint8 frames
@@ -556,6 +674,24 @@ static int transpose_t(const void* src, void* dst, int N, int C, long long S, in
     return STEP_LAUNCH_CHECK();
 }
 
+template <typename T, typename TG, typename TO>
+static void bwd_gather_launch(const unsigned char* arg, const void* gy, void* gx, const PoolParams& p, long long total, step_stream_t stream) {
+    STEP_LAUNCH((maxpool_bwd_gather_kernel<T, TG, TO>), dim3(flat_grid(total, 256)), dim3(256), stream, arg, (const TG*)gy, (TO*)gx, p, total);
+}
+template <typename T>
+static int bwd_gather_t(const void* x, int gy_dtype, const void* gy, int gx_dtype, void* gx, unsigned char* arg, const PoolParams& p,
+                        step_stream_t stream) {
+    constexpr int V = elem<T>::VEC;
+    const long long touts = (long long)p.N * p.Do * p.Ho * p.Wo * (p.C / V), tins = (long long)p.N * p.D * p.H * p.W * (p.C / V);
+    STEP_LAUNCH((maxpool_arg_kernel<T>), dim3(flat_grid(touts, 256)), dim3(256), stream, (const T*)x, arg, p, touts);
+    const bool gf = gy_dtype == STEP_F32, of = gx_dtype == STEP_F32;
+    if (gf && of) bwd_gather_launch<T, float, float>(arg, gy, gx, p, tins, stream);
+    else if (gf) bwd_gather_launch<T, float, T>(arg, gy, gx, p, tins, stream);
+    else if (of) bwd_gather_launch<T, T, float>(arg, gy, gx, p, tins, stream);
+    else bwd_gather_launch<T, T, T>(arg, gy, gx, p, tins, stream);
+    return STEP_LAUNCH_CHECK();
+}
+
 }  // namespace step
 
 using namespace step;
@@ -611,6 +747,33 @@ int step_maxpool3d_tf_backward(int dtype, const void* x, int N, int D, int H, in
         default: return STEP_E_DTYPE;
     }
     return STEP_LAUNCH_CHECK();
+}
+
+int step_maxpool3d_tf_backward_gather(int dtype, const void* x, int N, int D, int H, int W, int C, int x_cstride, int x_coff, int kd, int kh,
+                                      int kw, int sd, int sh, int sw, int gy_dtype, const void* gy, int gx_dtype, void* gx,
+                                      unsigned char* arg_scratch, step_stream_t stream) {
+    if (N < 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || kd <= 0 || kh <= 0 || kw <= 0 || sd <= 0 || sh <= 0 || sw <= 0)
+        return STEP_E_SHAPE;
+    if (x_coff < 0 || x_coff + C > x_cstride || kd * kh * kw > 255) return STEP_E_SHAPE;
+    if (dtype != STEP_F32 && dtype != STEP_BF16 && dtype != STEP_F16) return STEP_E_DTYPE;
+    if ((gy_dtype != STEP_F32 && gy_dtype != dtype) || (gx_dtype != STEP_F32 && gx_dtype != dtype)) return STEP_E_DTYPE;
+    const int V = dtype == STEP_F32 ? 4 : 8;
+    if (C % V || x_cstride % V || x_coff % V) return STEP_E_UNSUPPORTED;         // (the caller keeps step_maxpool3d_tf_backward)
+    if (N == 0) return STEP_OK;
+    if (!x || !gy || !gx || !arg_scratch) return STEP_E_NULL;
+    if ((((uintptr_t)x) | ((uintptr_t)gy) | ((uintptr_t)gx)) & 15) return STEP_E_ALIGN;
+    PoolParams p;
+    p.N = N; p.D = D; p.H = H; p.W = W; p.C = C; p.x_cstride = x_cstride; p.x_coff = x_coff;
+    p.Do = pool_out_size(D, kd, sd); p.Ho = pool_out_size(H, kh, sh); p.Wo = pool_out_size(W, kw, sw);
+    p.y_cstride = C; p.y_coff = 0;
+    p.kd = kd; p.kh = kh; p.kw = kw; p.sd = sd; p.sh = sh; p.sw = sw;
+    p.pfd = tf_pad_front(kd, sd); p.pfh = tf_pad_front(kh, sh); p.pfw = tf_pad_front(kw, sw);
+    p.Lpd = D + tf_pad_total(kd, sd); p.Lph = H + tf_pad_total(kh, sh); p.Lpw = W + tf_pad_total(kw, sw);
+    switch (dtype) {
+        case STEP_F32: return bwd_gather_t<float>(x, gy_dtype, gy, gx_dtype, gx, arg_scratch, p, stream);
+        case STEP_BF16: return bwd_gather_t<bf16_t>(x, gy_dtype, gy, gx_dtype, gx, arg_scratch, p, stream);
+        default: return bwd_gather_t<f16_t>(x, gy_dtype, gy, gx_dtype, gx, arg_scratch, p, stream);
+    }
 }
 
 int step_clip_from_u8(const unsigned char* frames, int N, int T, int H, int W, int scale, const float* mean3, const float* std3,

@@ -400,13 +400,28 @@ def maxpool_tf(x, k, s, out=None):
     return out
 
 
+POOL_BWD_GATHER = os.environ.get("STEP_POOL_BWD_GATHER", "1") != "0"
+
+
 def maxpool_tf_backward(x, gy, k, s):
-    """x channels-last [N,D,H,W,C] (the pool's input), gy [N,Do,Ho,Wo,C] -> fp32 gx [N,D,H,W,C]"""
+    """x channels-last [N,D,H,W,C] (the pool's input), gy [N,Do,Ho,Wo,C] -> gx [N,D,H,W,C] (in x's dtype from the gather form, fp32
+    from the atomic form that channel counts off the 16-byte grid fall back to)"""
     L = _lib.lib()
     N, D, H, W, C = x.shape
+    vec = 16 // x.element_size()
+    xcs = _chan_slice(x)
+    if POOL_BWD_GATHER and C % vec == 0 and xcs % vec == 0 and x.data_ptr() % 16 == 0 and gy.dtype in (torch.float32, x.dtype):
+        # two gathers, no atomics: gy as it arrives (fp32 or the activation type), gx written once in the activation type
+        gy = gy.contiguous()
+        gx = torch.empty((N, D, H, W, C), dtype=x.dtype, device=x.device)
+        arg = torch.empty(gy.numel(), dtype=torch.uint8, device=x.device)
+        _capi.check(L.step_maxpool3d_tf_backward_gather(_dt(x), _lib.dptr(x), N, D, H, W, C, xcs, 0, k[0], k[1], k[2], s[0], s[1], s[2],
+                                                        _dt(gy), _lib.dptr(gy), _dt(x), _lib.dptr(gx), _lib.dptr(arg),
+                                                        _lib.stream_ptr(x.device)), "step_maxpool3d_tf_backward_gather")
+        return gx
     gy = gy.float().contiguous()
     gx = torch.empty((N, D, H, W, C), dtype=torch.float32, device=x.device)
-    _capi.check(L.step_maxpool3d_tf_backward(_dt(x), _lib.dptr(x), N, D, H, W, C, _chan_slice(x), 0, k[0], k[1], k[2], s[0], s[1], s[2],
+    _capi.check(L.step_maxpool3d_tf_backward(_dt(x), _lib.dptr(x), N, D, H, W, C, xcs, 0, k[0], k[1], k[2], s[0], s[1], s[2],
                                              _lib.dptr(gy), _lib.dptr(gx), _lib.stream_ptr(x.device)), "step_maxpool3d_tf_backward")
     return gx
 

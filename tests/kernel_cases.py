@@ -363,6 +363,36 @@ def case_maxpool_backward(bk, golden):
         assert L.step_maxpool3d_tf_backward(0, xd.ptr, N, D, H, W, C, C, 0, k[0], k[1], k[2], s[0], s[1], s[2], gyd.ptr, gxd.ptr, bk.stream) == 0
         got = uncl(gxd.get())
         assert np.allclose(got, ref, rtol=1e-6, atol=1e-6), (k, s, np.abs(got - ref).max())
+        # the gather form (arg map + fixed-order gather): fp32 like the reference; bit-reproducible
+        Do, Ho, Wo = y.shape[2:]
+        arg = bk.dev(np.full(N * Do * Ho * Wo * C, 250, np.uint8))
+        g2 = bk.dev(np.full((N, D, H, W, C), 5.0, np.float32))
+        assert L.step_maxpool3d_tf_backward_gather(0, xd.ptr, N, D, H, W, C, C, 0, k[0], k[1], k[2], s[0], s[1], s[2], 0, gyd.ptr, 0, g2.ptr,
+                                                   arg.ptr, bk.stream) == 0
+        first = uncl(g2.get()).copy()
+        assert np.allclose(first, ref, rtol=1e-6, atol=1e-6), (k, s, np.abs(first - ref).max())
+        assert L.step_maxpool3d_tf_backward_gather(0, xd.ptr, N, D, H, W, C, C, 0, k[0], k[1], k[2], s[0], s[1], s[2], 0, gyd.ptr, 0, g2.ptr,
+                                                   arg.ptr, bk.stream) == 0
+        assert np.array_equal(uncl(g2.get()), first)
+        # 16-bit activations: x, gy and gx in the activation type (and the mixed forms), against torch on the quantized operands
+        for dt in (BF16, F16):
+            xq = quantize(x, dt)
+            xt = torch.from_numpy(xq).requires_grad_(True)
+            yq = F.max_pool3d(F.pad(xt, pads), k, s, ceil_mode=True)
+            gq = quantize(gy, dt)
+            yq.backward(torch.from_numpy(gq))
+            refq = xt.grad.numpy()
+            xe = bk.dev(encode(cl(xq), dt))
+            for gdt, odt in ((dt, dt), (0, dt), (dt, 0)):
+                ge = bk.dev(np.ascontiguousarray(cl(gq)) if gdt == 0 else encode(np.ascontiguousarray(cl(gq)), dt))
+                go = bk.dev(np.full((N, D, H, W, C), 3, np.float32 if odt == 0 else NP_DT[dt]))
+                assert L.step_maxpool3d_tf_backward_gather(dt, xe.ptr, N, D, H, W, C, C, 0, k[0], k[1], k[2], s[0], s[1], s[2], gdt, ge.ptr, odt,
+                                                           go.ptr, arg.ptr, bk.stream) == 0
+                out = uncl(go.get() if odt == 0 else decode(go.get(), dt))
+                want = refq if odt == 0 else quantize(refq, dt)
+                assert np.allclose(out, want, rtol=2e-2 if odt else 1e-6, atol=1e-6), (k, s, dt, gdt, odt, np.abs(out - want).max())
+    assert L.step_maxpool3d_tf_backward_gather(1, xe.ptr, N, D, H, W, 12, 12, 0, 3, 3, 3, 1, 1, 1, 1, ge.ptr, 1, go.ptr, arg.ptr, bk.stream) == -4   # C % 8
+    assert L.step_maxpool3d_tf_backward_gather(1, xe.ptr, N, D, H, W, C, C, 0, 3, 3, 3, 1, 1, 1, 2, ge.ptr, 1, go.ptr, arg.ptr, bk.stream) < 0     # gy type
 
 
 def case_pool_golden(bk, golden):

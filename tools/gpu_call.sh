@@ -3,5 +3,6 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-timeout 400 python tools/ab_bench.py --var "STEP_CONV_NB_SMALL=" --var "STEP_CONV_NB_SMALL=2" --var "STEP_CONV_NB_SMALL=3" 2>&1 | grep -E "layer|4._b1b|4._b2b|total"
-for v in "" 2 3 "" 2; do echo "NB_SMALL=$v"; STEP_CONV_NB_SMALL=$v timeout 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline 2>/dev/null | cut -c1-110; done
+timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_modules.py tests/test_gpu_graph_step.py -q -m gpu -k "pool or backward or training or graph or chain" 2>&1 | tail -4
+for v in 1 0 1 0; do echo "GATHER=$v"; STEP_POOL_BWD_GATHER=$v timeout 300 python bench.py --config c4 --dtype bf16 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | cut -c60-150; done
+for v in 1 0; do echo "f32 GATHER=$v"; STEP_POOL_BWD_GATHER=$v timeout 300 python bench.py --config c4 --dtype f32 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | cut -c60-150; done
