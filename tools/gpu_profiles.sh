@@ -27,7 +27,7 @@ K5='void step::conv_tap_kernel<step::bf16_t, 0, 1, 3, 3, 3, 2, 2, 8, 1>(step::Co
 K6='void step::maxpool_sep_kernel<step::bf16_t, 3, 3, 3, 1, 1, 1, 256>(step::bf16_t const*, step::bf16_t*, step::PoolParams, int, int, int, int, int, int, int)'
 K7='void step::maxpool_sep_kernel<step::bf16_t, 1, 3, 3, 1, 2, 2, 256>(step::bf16_t const*, step::bf16_t*, step::PoolParams, int, int, int, int, int, int, int)'
 K8='void step::conv_pw_kernel<step::bf16_t, 1, 8>(step::ConvParams)'
-K9='void step::conv_pw_kernel<step::bf16_t, 2, 4>(step::ConvParams)'
+K9='void step::conv_pws_kernel<step::bf16_t, 3, 4>(step::ConvParams, int)'
 K10='void step::conv_pw_kernel<step::bf16_t, 3, 4>(step::ConvParams)'
 python tools/pmc_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/traffic_latest.json "$K1" "$K2" "$K3" "$K4" "$K5" "$K6" "$K7" "$K8" "$K9" "$K10" > $O/pmc_traffic.log 2>&1
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
