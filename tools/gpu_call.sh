@@ -3,4 +3,6 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-for c in c3 c5; do for v in 1 2 1 2; do echo "$c BRANCH_STREAMS=$v"; STEP_BRANCH_STREAMS=$v timeout 300 python bench.py --config $c --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | cut -c1-120; done; done
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 > $O/gputests.log; cat $O/gputests.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-120 $O/bench_default.json
