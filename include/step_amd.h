@@ -229,6 +229,11 @@ STEP_API int step_conv_wgrad16_ws(const step_conv_desc* d, const void* x, const 
 /* Diagnostic: the name (as rocprofv3 prints it) of the kernel instantiation step_conv_forward launches
  * for this descriptor -- lets bench.py attribute time and algorithmic work to profiler rows. */
 STEP_API int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen);
+/* Diagnostic: the launch plan of a descriptor as integers -- info[0..9] = implementation (0 tiled, 1 pipelined conv_tap, 2 streaming
+ * pointwise, 3 split-K, 4 weight-stationary pointwise), log2 tile width (0 = general box), accumulator depth NB, waves per
+ * workgroup, two-phase form, the general box (planes, rows, columns), its pixel assignment mode (1 = every 16-lane LDS read group is
+ * one run of 16 columns of one box row), pixel tiles.  n >= 10. */
+STEP_API int step_conv_plan_info(const step_conv_desc* d, int* info, int n);
 
 /* The I3D stem: 7x7x7 stride-2 conv, Cin = 3, TF-SAME padding (2 front, 3 back) + BN + ReLU
  * (models/i3dpt.py:186-191) reading the clip in the reference's own input layout

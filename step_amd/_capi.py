@@ -4,7 +4,7 @@ import ctypes as C
 
 F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 vp, fp, ip, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # raw device addresses
 i, f, ll, sz = C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -44,6 +44,7 @@ SIGNATURES = {
     "step_conv_wgrad16_ws": (i, [C.POINTER(ConvDesc), vp, vp, fp, i, vp, sz, vp]),
     "step_conv_forward_ws": (i, [C.POINTER(ConvDesc), vp, vp, fp, fp, vp, vp, vp, vp, sz, vp]),
     "step_conv_kernel_name": (i, [C.POINTER(ConvDesc), C.c_char_p, i]),
+    "step_conv_plan_info": (i, [C.POINTER(ConvDesc), C.POINTER(C.c_int), i]),
     "step_pool3_conv1_forward": (i, [C.POINTER(ConvDesc), vp, vp, fp, fp, vp, vp]),
     "step_pool133s2_conv1_forward": (i, [C.POINTER(ConvDesc), i, i, vp, vp, fp, fp, vp, vp]),
     "step_pool3_conv1_kernel_name": (i, [C.POINTER(ConvDesc), C.c_char_p, i]),

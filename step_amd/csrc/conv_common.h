@@ -26,6 +26,7 @@ struct ConvParams {
     int relu;
     int tiles_h, tiles_w, tiles_d;
     int gtd, gth, gtw;   // box of a general (TWL = 0) conv_tap tile, gtd*gth*gtw <= 256
+    int gmode;           // general box: 0 = accumulator rows walk the box linearly, 1 = every 16-lane LDS read group is one run of 16 columns of one box row
     int gx, gy;          // logical grid: gx pixel tiles x gy channel groups (launched as a 1-D grid, see grid_coords)
     int nchunks;   // ceil(Cin / 32)
     int nchunks32; // same (the packed-weight K extent is 2*nchunks32 k16 blocks)
@@ -141,7 +142,7 @@ static inline unsigned flat_grid(long long total, int block) {
 }
 
 
-struct ConvPlan { bool ok, flat, wide, deep; int impl, NB, tps, mb, wv, ph, twl, tiles_h, tiles_w, tiles_d, gtd, gth, gtw, ksplit, kchunk16, mbk, mpad, cpad; long long mtiles; };
+struct ConvPlan { bool ok, flat, wide, deep; int impl, NB, tps, mb, wv, ph, twl, tiles_h, tiles_w, tiles_d, gtd, gth, gtw, gmode, ksplit, kchunk16, mbk, mpad, cpad; long long mtiles; };
 
 static inline int conv_impl_override() {   // tuning aid: STEP_CONV_IMPL=igemm|tap|tap2 forces one implementation
     const char* e = getenv("STEP_CONV_IMPL");

@@ -428,9 +428,20 @@ static bool prefer_four_waves_pw(const step_conv_desc* d, long long wgs8) {
     return wgs8 < 128 || M >= 65536;
 }
 
+// general boxes: may every 16-lane LDS read group be one run of 16 columns of one box row (conv_tap_kernel.h, p.gmode)?  Only for
+// widths just below a multiple of 16 (the padded lanes cost no more than the linear packing leaves unused) and when the box rows
+// fit the tile's 16-lane slots.  STEP_CONV_GMODE=0 keeps the linear walk (tuning aid / tests, read per call).
+static int gen_gmode(int td, int th, int tw, int tile_px) {
+    const char* e = getenv("STEP_CONV_GMODE");
+    if (e && atoi(e) == 0) return 0;
+    const int spr = (tw + 15) / 16;
+    if ((tw & 15) < 12) return 0;
+    return td * th * spr <= tile_px / 16 ? 1 : 0;
+}
+
 static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true) {
     ConvPlan pl;
-    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1; pl.mb = 2; pl.wv = 8; pl.ph = 0; pl.deep = false; pl.twl = 4; pl.tiles_d = d->D; pl.gtd = pl.gth = pl.gtw = 1; pl.ksplit = 0; pl.kchunk16 = 0; pl.mbk = 0; pl.mpad = 0; pl.cpad = 0;
+    pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1; pl.mb = 2; pl.wv = 8; pl.ph = 0; pl.deep = false; pl.twl = 4; pl.tiles_d = d->D; pl.gtd = pl.gth = pl.gtw = 1; pl.gmode = 0; pl.ksplit = 0; pl.kchunk16 = 0; pl.mbk = 0; pl.mpad = 0; pl.cpad = 0;
     const int nblk32 = ceil_div(d->Cout, 32);
     const bool k1 = d->kd == 1 && d->kh == 1 && d->kw == 1;
     const bool k333 = d->kd == 3 && d->kh == 3 && d->kw == 3;
@@ -568,6 +579,7 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true) {
             }
         }
         p4.wv = 4; p4.twl = tw4; p4.wide = tw4 == 5; p4.gtd = g4d; p4.gth = g4h; p4.gtw = g4w;
+        p4.gmode = tw4 == 0 ? gen_gmode(g4d, g4h, g4w, 128) : 0;
         if (tw4 == 0) {
             p4.tiles_d = ceil_div(d->D, g4d); p4.tiles_h = ceil_div(d->H, g4h); p4.tiles_w = ceil_div(d->W, g4w);
         } else {
@@ -594,6 +606,7 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true) {
         pl.twl = twl;
         pl.wide = twl == 5;
         pl.gtd = gtd; pl.gth = gth; pl.gtw = gtw;
+        pl.gmode = twl == 0 ? gen_gmode(gtd, gth, gtw, 256) : 0;
         if (twl == 0) {
             pl.tiles_d = ceil_div(d->D, gtd); pl.tiles_h = ceil_div(d->H, gth); pl.tiles_w = ceil_div(d->W, gtw);
         } else {
@@ -639,7 +652,7 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_
         pl.impl = 0; pl.mtiles = ceil_div64(p.Mtot, 128); pl.NB = pick_nb(p.nblk32, pl.mtiles); pl.deep = d->Cin >= 256;
     }
     p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.tiles_d = pl.tiles_d;
-    p.gtd = pl.gtd; p.gth = pl.gth; p.gtw = pl.gtw;
+    p.gtd = pl.gtd; p.gth = pl.gth; p.gtw = pl.gtw; p.gmode = pl.gmode;
     auto grid1d = [&](int groups) {                   // logical (mtiles x groups) grid as a 1-D launch padded to 8
         p.gx = (int)pl.mtiles; p.gy = groups;
         const long long tot = pl.mtiles * groups;
@@ -767,7 +780,7 @@ int step_conv_forward_ws(const step_conv_desc* d, const void* x, const void* w_p
     p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
     p.r_cstride = d->res_cstride; p.r_coff = d->res_coff;
     p.relu = d->relu;
-    p.tiles_h = p.tiles_w = 0; p.tiles_d = d->D; p.gtd = p.gth = p.gtw = 1; p.gx = p.gy = 0;
+    p.tiles_h = p.tiles_w = 0; p.tiles_d = d->D; p.gtd = p.gth = p.gtw = 1; p.gmode = 0; p.gx = p.gy = 0;
     p.nchunks = ceil_div(d->Cin, CK);
     p.nchunks32 = p.nchunks;
     p.vec_epi = (d->y_cstride % 8 == 0) && (d->y_coff % 8 == 0) && (d->Cout % 8 == 0) && (((uintptr_t)y) % 16 == 0) &&
@@ -809,8 +822,18 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
     return STEP_OK;
 }
 
+int step_conv_plan_info(const step_conv_desc* d, int* info, int n) {
+    if (!d || !info || n < 10) return STEP_E_NULL;
+    const step_conv_desc canon = canonical_desc(d);
+    const ConvPlan pl = conv_plan(&canon);
+    if (!pl.ok) return STEP_E_UNSUPPORTED;
+    info[0] = pl.impl; info[1] = pl.twl; info[2] = pl.NB; info[3] = pl.wv; info[4] = pl.ph; info[5] = pl.gtd; info[6] = pl.gth; info[7] = pl.gtw;
+    info[8] = pl.gmode; info[9] = (int)(pl.mtiles > 0x7fffffff ? 0x7fffffff : pl.mtiles);
+    return STEP_OK;
+}
+
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 17; }
+int step_abi_version(void) { return 18; }
 
 }  // extern "C"
 

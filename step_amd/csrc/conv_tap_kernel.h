@@ -111,13 +111,40 @@ void conv_tap_kernel(ConvParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     unsigned char* const ldsA = lds;
     unsigned char* const ldsB = lds + NPIX_MAX * PITCH;
-    // tile pixel index m (accumulator row) -> box coordinates; rows past the box of a GEN tile alias pixel 0
-    auto tile_pix = [&](int m, int& td, int& th, int& tw) {
+    // tile pixel index m (accumulator row) -> box coordinates, and whether the row holds a pixel of the box at all.
+    // General boxes, linear mode: rows past the box alias pixel 0.  General boxes, p.gmode = 1 (box widths just below a multiple
+    // of 16: the 14- and 28-wide C2 maps, 13): the 16 lanes of every ds_read_b128 service group ({0-3,12-15,20-27} and
+    // {4-11,16-19,28-31} of a 32-row block) take 16 CONSECUTIVE columns of ONE box row -- consecutive halo indices, so the group is
+    // conflict-free whatever the row pitch (linear packing of 14-wide rows measured 27-34 % of the LDS cycles as bank conflicts);
+    // the lanes past the row's end (2 of 16 at width 14, 4 of 32 at width 28: no more padding than the linear packing of
+    // these boxes leaves anyway) keep walking the halo row -- in-bounds reads whose products are never stored.
+    auto tile_pix = [&](int m, int& td, int& th, int& tw) -> bool {
         if (GEN) {
+            if (p.gmode) {
+                const int pl_ = m & 31, blk = m >> 5;
+                // service group and position inside it: 0-3 -> (0, 0..3), 4-11 -> (1, 0..7), 12-15 -> (0, 4..7), 16-19 -> (1, 8..11),
+                // 20-27 -> (0, 8..15), 28-31 -> (1, 12..15)
+                int g, j;
+                if (pl_ < 4) { g = 0; j = pl_; }
+                else if (pl_ < 12) { g = 1; j = pl_ - 4; }
+                else if (pl_ < 16) { g = 0; j = pl_ - 8; }
+                else if (pl_ < 20) { g = 1; j = pl_ - 8; }
+                else if (pl_ < 28) { g = 0; j = pl_ - 12; }
+                else { g = 1; j = pl_ - 16; }
+                const int spr = (TW + 15) >> 4;                       // 16-column runs per box row
+                const int slot = blk * 2 + g;
+                const int row = slot / spr, col = (slot % spr) * 16 + j;
+                const bool ok = row < TD * TH && col < TW;
+                const int rc = row < TD * TH ? row : 0;
+                tw = col; th = rc % TH; td = rc / TH;
+                return ok;
+            }
             const int mc = m < TPX ? m : 0;
             tw = mc % TW; const int q = mc / TW; th = q % TH; td = q / TH;
+            return m < TPX;
         } else {
             td = m >> (TWL + THL); th = (m >> TWL) & (TH - 1); tw = m & (TW - 1);
+            return true;
         }
     };
 
@@ -517,9 +544,9 @@ void conv_tap_kernel(ConvParams p) {
         int* const pixtab = (int*)(lds + sizeof(lds) - 1024);
         if (tid < TPXM) {
             int tdl, thl, twl;
-            tile_pix(tid, tdl, thl, twl);
+            const bool inbox = tile_pix(tid, tdl, thl, twl);
             const int od = d0 + tdl, oh = h0 + thl, ow = w0 + tile_col(thl, twl);
-            const bool ok = (!GEN || tid < TPX) && od < p.D && oh < p.H && ow < p.W;
+            const bool ok = inbox && od < p.D && oh < p.H && ow < p.W;
             pixtab[tid] = ok ? (int)((((long long)n * p.D + od) * p.H + oh) * p.W + ow) : -1;
         }
         float sc[NB], sh[NB];
@@ -579,9 +606,9 @@ void conv_tap_kernel(ConvParams p) {
                 for (int r = 0; r < 16; ++r) {
                     const int mm = wm * (MB * 32) + mb * 32 + cd_row(r, lane);
                     int tdl, thl, twl;
-                    tile_pix(mm, tdl, thl, twl);
+                    const bool inbox = tile_pix(mm, tdl, thl, twl);
                     const int od = d0 + tdl, oh = h0 + thl, ow = w0 + tile_col(thl, twl);
-                    if ((!GEN || mm < TPX) && od < p.D && oh < p.H && ow < p.W) {
+                    if (inbox && od < p.D && oh < p.H && ow < p.W) {
                         const size_t opix = (((size_t)n * p.D + od) * p.H + oh) * p.W + ow;
                         float v = acc[mb][i][r] * sc + sh;
                         if (rg) v += elem<T>::to_f32(rg[opix * p.r_cstride + p.r_coff + co]);

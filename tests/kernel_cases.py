@@ -1166,6 +1166,50 @@ def case_conv_split_two_destinations(bk, golden):
     assert bk.lib.step_conv_forward(ctypes.byref(d), xe.ptr, wp.ptr, None, None, None, ya.ptr, yb.ptr, bk.stream) == -4
 
 
+def case_conv_general_box_row_groups(bk, golden):
+    """General boxes whose width is just below a multiple of 16 (the 14- and 28-wide C2 maps, 13): the accumulator rows are
+    assigned so that every 16-lane LDS read group is one run of columns of one box row (p.gmode = 1).  Same pixels, same
+    per-pixel accumulation order: bit-identical to the linear walk (STEP_CONV_GMODE=0) and within tolerance of the oracle;
+    the plan says which mode ran."""
+    import os
+    rs = np.random.RandomState(41)
+    # (N, Cin, Cout, D, H, W, k)
+    cases = ((1, 64, 64, 8, 14, 14, (3, 3, 3)), (1, 64, 40, 4, 9, 28, (3, 3, 3)), (1, 64, 64, 8, 12, 28, (3, 3, 3)),
+             (2, 64, 96, 6, 14, 14, (3, 3, 3)), (1, 64, 64, 2, 10, 30, (3, 3, 3)))
+    keep, keepw = os.environ.get("STEP_CONV_GMODE"), os.environ.get("STEP_CONV_WAVES")
+    os.environ["STEP_CONV_WAVES"] = "8"                       # (the 256-pixel tiles: boxes of 14 x 14, 2 x 4 x 28, ...)
+    grouped = 0
+    try:
+        for (N, Cin, Cout, D, H, W, k) in cases:
+            x = rs.randn(N, Cin, D, H, W).astype(np.float32)
+            w = (rs.randn(Cout, Cin, *k) / np.sqrt(Cin * k[0] * 9)).astype(np.float32)
+            scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32)
+            shift = (0.2 * rs.randn(Cout)).astype(np.float32)
+            for dt in (BF16, F32):
+                ref = ref_conv(x, w, scale, shift, dt)
+                outs = {}
+                for mode in ("1", "0"):
+                    os.environ["STEP_CONV_GMODE"] = mode
+                    d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2], x_cstride=Cin, x_coff=0,
+                                       y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+                    info = (ctypes.c_int * 10)()
+                    assert bk.lib.step_conv_plan_info(ctypes.byref(d), info, 10) == 0
+                    assert info[0] == 1, list(info)                                         # the pipelined kernel
+                    fits = info[5] * info[6] * ((info[7] + 15) // 16) <= 2 * info[3]         # box rows x 16-column runs <= 16-lane slots of the tile
+                    assert info[8] == int(mode == "1" and info[1] == 0 and (info[7] & 15) >= 12 and fits), (mode, list(info))
+                    grouped += info[8]
+                    outs[mode] = run_conv(bk, x, w, scale, shift, dt)
+                    assert np.abs(outs[mode] - ref).max() / np.abs(ref).max() < tol(dt), (mode, W, dt)
+                assert np.array_equal(outs["1"], outs["0"]), (W, dt)
+        assert grouped >= 4, grouped                                                      # (the mode really ran)
+    finally:
+        for k_, v_ in (("STEP_CONV_GMODE", keep), ("STEP_CONV_WAVES", keepw)):
+            if v_ is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v_
+
+
 def case_conv_pointwise_weight_stationary(bk, golden):
     """conv_pws_kernel (the weight-stationary short-K pointwise stream, STEP_CONV_PWS=1) against the oracle and against the
     default kernel: one to four 64-channel steps, a K tail that is not a multiple of 64 or 32, one to four passes over the

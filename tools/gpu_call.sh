@@ -2,8 +2,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
-cd /tmp; export TMPDIR=/tmp
-STEP_CONV_PHASED=0 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmcx_a0 -- python $R/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline > /dev/null 2> $O/pmcx_a0.err || tail -3 $O/pmcx_a0.err
 cd $R
-python tools/pmc_counters.py $O/pmc_3x3x3_classic_a.txt "classic=$O/pmcx_a0" -- "conv_tap_kernel<step::bf16_t, 3, 3, 3, 3, 3" "conv_tap_kernel<step::bf16_t, 0, 3, 3, 3, 3" "conv_tap_kernel<step::bf16_t, 0, 2, 3, 3, 3" "conv_tap_kernel<step::bf16_t, 0, 1, 3, 3, 3, 2, 2, 8" | cut -c1-170
-rm -rf $O/pmcx_*
+timeout 300 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "row_groups or conv_units or golden_units" 2>&1 | tail -2
+timeout 400 python tools/ab_bench.py --var "STEP_CONV_GMODE=0" --var "STEP_CONV_GMODE=1" 2>&1 | grep -E "layer|_3x3|b1b|b2b|total" > $O/ab_gmode.log; cat $O/ab_gmode.log
+for v in 0 1 0 1; do echo "GMODE=$v"; STEP_CONV_GMODE=$v timeout 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline 2>/dev/null | cut -c1-110; done
