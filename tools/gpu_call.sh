@@ -2,7 +2,14 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+run() { tag=$1; shift
+  timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmcy_${tag} -- python $R/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline > /dev/null 2> $O/pmcy_${tag}.err || tail -3 $O/pmcy_${tag}.err; }
+run a SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES
+run b SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA
+run c SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS
 cd $R
-timeout 300 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "row_groups or conv_units or golden_units" 2>&1 | tail -2
-timeout 400 python tools/ab_bench.py --var "STEP_CONV_GMODE=0" --var "STEP_CONV_GMODE=1" 2>&1 | grep -E "layer|_3x3|b1b|b2b|total" > $O/ab_gmode.log; cat $O/ab_gmode.log
-for v in 0 1 0 1; do echo "GMODE=$v"; STEP_CONV_GMODE=$v timeout 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline 2>/dev/null | cut -c1-110; done
+python tools/pmc_counters.py $O/pmc_others.txt "default:$O/pmcy_a,$O/pmcy_b,$O/pmcy_c" -- "stem_stream_kernel" "conv_pw_kernel" "conv_pws_kernel" "maxpool_sep_kernel" "conv_igemm_kernel" "2, 2, 4, 0>" > /dev/null
+sed -i 's/=/=/' $O/pmc_others.txt
+grep -E "^\[|BANK_CONFLICT|IDX_ACTIVE|BUSY_CU|MFMA_BUSY|MFMA busy" $O/pmc_others.txt | cut -c1-150
+rm -rf $O/pmcy_*

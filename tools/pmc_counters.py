@@ -24,7 +24,7 @@ def collect(dirs):
 def main():
     out = sys.argv[1]
     split = sys.argv.index("--")
-    groups = [a.split("=", 1) for a in sys.argv[2:split]]
+    groups = [a.split(":", 1) if ":" in a.split("=")[0] else a.split("=", 1) for a in sys.argv[2:split]]
     filters = sys.argv[split + 1:]
     lines = []
     for label, dirs in groups:
