@@ -90,7 +90,12 @@ class FlatAdam(torch.optim.Optimizer):
                 p.grad = self.flat_grad[o:o + n].view(p.shape)
 
     def _gather_stray_grads(self):
-        # a caller that replaced p.grad (set_to_none, grad = tensor): fold it back into the arena
+        # a caller that replaced p.grad (set_to_none, grad = tensor): fold it back into the arena.
+        # Known divergence from torch.optim.Adam (documented, not emulated): torch SKIPS a parameter whose .grad is None -- no
+        # moment decay, no step count -- while the one launch here treats it as a zero gradient at the shared step count (its
+        # moments decay and the parameter keeps moving along exp_avg).  The reference's loop never produces that case: every
+        # parameter of get_params() receives a gradient in every iteration (train.py:318-348), and zero_grad() here keeps the
+        # gradients as views of the arena instead of dropping them.
         base = self.flat_grad.data_ptr()
         for _, p, o, n in self._entries:
             g = p.grad
