@@ -103,7 +103,7 @@ constexpr int PP_MAXIN = 16;                        // max input tile edge
 
 template <typename T, int KD, int KH, int KW, int SD, int SH, int SW, int NT>
 __global__ __launch_bounds__(NT) void maxpool_sep_kernel(const T* __restrict__ x, T* __restrict__ y, PoolParams p,
-                                                          int TH, int TW, int tiles_h, int tiles_w, int cchunks, int dseg, int nseg) {
+                                                          int TH, int TW, int tiles_h, int tiles_w, int cchunks, int dseg, int nseg, int cc_outer) {
     constexpr int V = elem<T>::VEC;
     typedef typename Vec16<T, V>::raw raw;
     constexpr int SL = PP_SL, R = PP_R * 256 / NT;        // NT = 256: 4 items per thread per pass, NT = 1024: 1
@@ -115,11 +115,22 @@ __global__ __launch_bounds__(NT) void maxpool_sep_kernel(const T* __restrict__ x
     // are neighbours in (tile, D segment) order -- which share halos -- land on the same XCD (one L2)
     int t = blockIdx.x;
     if ((gridDim.x & 7) == 0) t = (t & 7) * (gridDim.x >> 3) + (t >> 3);
+    // channel chunk fastest: a chunk is 64 bytes -- half a 128-byte line -- so the two chunks of a line are neighbours in launch
+    // order on ONE XCD (the second one's loads hit that L2) instead of being fetched by two XCDs (STEP_POOL_CC_OUTER=1: the old order)
+    int cc;
+    if (cc_outer) {
+        const int tw_o = t % tiles_w; t /= tiles_w;
+        const int th_o = t % tiles_h; t /= tiles_h;
+        const int seg_o = t % nseg; t /= nseg;
+        cc = t % cchunks;
+        t = ((t / cchunks) * nseg + seg_o) * tiles_h * tiles_w + th_o * tiles_w + tw_o;
+    } else {
+        cc = t % cchunks; t /= cchunks;
+    }
     const int tw_i = t % tiles_w; t /= tiles_w;
     const int th_i = t % tiles_h; t /= tiles_h;
-    const int seg = t % nseg; t /= nseg;
-    const int cc = t % cchunks;
-    const int n = t / cchunks;
+    const int seg = t % nseg;
+    const int n = t / nseg;
     const int oh0 = th_i * TH, ow0 = tw_i * TW;
     const int c0 = cc * SL * V;
     const int IR = (TH - 1) * SH + KH, IC = (TW - 1) * SW + KW;      // input tile
@@ -640,9 +651,10 @@ static int maxpool_t(const void* x, void* y, const PoolParams& p, step_stream_t 
         const dim3 grid((unsigned)(blocks * nseg));
         static const int nt_e = getenv("STEP_POOL_NT") ? atoi(getenv("STEP_POOL_NT")) : 0;
         const bool wide = nt_e ? nt_e == 1024 : false;
+        static const int cc_outer = getenv("STEP_POOL_CC_OUTER") ? atoi(getenv("STEP_POOL_CC_OUTER")) : 0;     // tuning aid
 #define STEP_POOL_SEP(KD_, KH_, KW_, SD_, SH_, SW_) \
-        if (wide) STEP_LAUNCH((maxpool_sep_kernel<T, KD_, KH_, KW_, SD_, SH_, SW_, 1024>), grid, dim3(1024), stream, (const T*)x, (T*)y, p, TH, TW, tiles_h, tiles_w, cchunks, dseg, nseg); \
-        else STEP_LAUNCH((maxpool_sep_kernel<T, KD_, KH_, KW_, SD_, SH_, SW_, 256>), grid, dim3(256), stream, (const T*)x, (T*)y, p, TH, TW, tiles_h, tiles_w, cchunks, dseg, nseg)
+        if (wide) STEP_LAUNCH((maxpool_sep_kernel<T, KD_, KH_, KW_, SD_, SH_, SW_, 1024>), grid, dim3(1024), stream, (const T*)x, (T*)y, p, TH, TW, tiles_h, tiles_w, cchunks, dseg, nseg, cc_outer); \
+        else STEP_LAUNCH((maxpool_sep_kernel<T, KD_, KH_, KW_, SD_, SH_, SW_, 256>), grid, dim3(256), stream, (const T*)x, (T*)y, p, TH, TW, tiles_h, tiles_w, cchunks, dseg, nseg, cc_outer)
         if (ssig == 111) { STEP_POOL_SEP(3, 3, 3, 1, 1, 1); }
         else if (ksig == 133) { STEP_POOL_SEP(1, 3, 3, 1, 2, 2); }
         else { STEP_POOL_SEP(3, 3, 3, 2, 2, 2); }

@@ -386,7 +386,7 @@ def maxpool_tf(x, k, s, out=None):
         ks = (tuple(k), tuple(s))
         sep = ks in (((3, 3, 3), (1, 1, 1)), ((1, 3, 3), (1, 2, 2)), ((3, 3, 3), (2, 2, 2))) and not os.environ.get("STEP_POOL_DIRECT")
         tn = _TNAME[x.dtype]
-        kn = ("maxpool_sep_kernel<%s, %d, %d, %d, %d, %d, %d, 256>" % ((tn,) + ks[0] + ks[1]), ", int" * 7) if sep else \
+        kn = ("maxpool_sep_kernel<%s, %d, %d, %d, %d, %d, %d, 256>" % ((tn,) + ks[0] + ks[1]), ", int" * 8) if sep else \
             ("maxpool3d_tf_kernel<%s>" % tn, ", long long")
         prof = _Prof("void step::%s(%s const*, %s*, step::PoolParams%s)" % (kn[0], tn, tn, kn[1]),
                      0.0, (x.numel() + out.numel()) * _ES[x.dtype])
