@@ -252,6 +252,7 @@ struct Wgrad16Params {
     long long units;
     float* ws;                    // partial tiles [gridDim.x][gridDim.y][6 waves][24 tiles][64 lanes][4] (NULL: fp32 atomics on dw)
     unsigned wmagic, wmagic2;     // floor(k / W) = (k * wmagic) >> 22, floor(k / (W + 2)) = (k * wmagic2) >> 22 for k < 512
+    int noremap;                  // tuning aid: keep the plain launch order
 };
 
 // KW = 1 (pointwise convs / Linear layers): no halo; the unit is a chunk of 128 consecutive pixels of the flattened N*D*H*W
@@ -276,7 +277,19 @@ __global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
     const int khw = PW ? 0 : wave % 3, cb = PW ? wave : wave / 3;   // filter row, 32-channel block of the ci tile
-    int t = blockIdx.y;
+    // launch order -> XCD: all gridDim.y channel / plane groups of a pixel unit read the SAME two images.  Dispatched in (x fastest)
+    // order they are gridDim.x workgroups apart -- each fetches the images from HBM / the infinity cache again (9 x 92 MB for
+    // conv3d_2c).  Remap so that the groups of one unit are consecutive on ONE XCD (ids go round-robin over the 8 XCDs) and the
+    // second to last of them hit its L2.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if ((gridDim.x & 7) == 0 && !p.noremap) {
+        const long long L = (long long)blockIdx.x + (long long)gridDim.x * blockIdx.y;
+        const int xcd = (int)(L & 7);
+        const long long slot = L >> 3;
+        by = (int)(slot % gridDim.y);
+        bx = (int)(slot / gridDim.y) * 8 + xcd;
+    }
+    int t = by;
     const int cit_i = t % p.cit; t /= p.cit;
     const int cot_i = t % p.cot;
     const int kd_ = t / p.cot;
@@ -296,7 +309,7 @@ __global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) 
 
     const T* xg = (const T*)p.x;
     const T* dyg = (const T*)p.dy;
-    const long long u_beg = (long long)blockIdx.x * p.upj, u_end = min(u_beg + p.upj, p.units);
+    const long long u_beg = (long long)bx * p.upj, u_end = min(u_beg + p.upj, p.units);
     // A unit's two images go global -> registers -> LDS; the NEXT unit's vectors are requested before this unit's matrix
     // work, so their round trip (2-3 us under load, against ~1 us of MFMAs per unit) flies under it.
     constexpr int NV = ((WG16_P + WG16_XP) * 8 + 383) / 384;     // 16-byte vectors per thread per unit (12)
@@ -399,7 +412,7 @@ __global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) 
     if (p.ws) {
         // partial tile of this workgroup, accumulator layout as is (16-byte stores, fully coalesced); wgrad16_reduce_kernel
         // sums over the workgroups of the pixel axis in a fixed order -- no atomics, deterministic
-        f32x4* out = (f32x4*)p.ws + ((((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 6 + wave) * (KW * 8)) * 64 + lane;
+        f32x4* out = (f32x4*)p.ws + ((((size_t)bx * gridDim.y + by) * 6 + wave) * (KW * 8)) * 64 + lane;
 #pragma unroll
         for (int s = 0; s < KW; ++s)
 #pragma unroll
@@ -822,6 +835,7 @@ static Wg16Plan wgrad16_plan(const step_conv_desc* d) {
     if (upj > 0x3fffffff) upj = 0x3fffffff;
     pl.upj = (int)upj;
     pl.gx = ceil_div64(pl.units, pl.upj);
+    if (pl.gx >= 8) pl.gx = (pl.gx + 7) / 8 * 8;             // whole rounds over the 8 XCDs (the kernel's launch-order remap); surplus workgroups write zero tiles
     pl.ok = pl.gy <= 65535 && pl.gx <= 0x7fffffffLL;
     return pl;
 }
@@ -855,6 +869,7 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
             q.x_cstride = d->x_cstride; q.x_coff = d->x_coff; q.dy_cstride = d->y_cstride; q.dy_coff = d->y_coff;
             q.cot = pl.cot; q.cit = pl.cit; q.cpp = pl.cpp; q.rows = pl.rows; q.units = pl.units; q.upj = pl.upj;
             q.wmagic = (unsigned)(((1u << 22) + d->W - 1) / d->W);
+            { static const int nr = getenv("STEP_WGRAD16_NOREMAP") ? atoi(getenv("STEP_WGRAD16_NOREMAP")) : 0; q.noremap = nr; }
             q.wmagic2 = (unsigned)(((1u << 22) + d->W + 1) / (d->W + 2));
             const size_t need = (size_t)pl.gx * pl.gy * 6 * (pl.pw ? 8 : 24) * 64 * 16;
             q.ws = (ws && ws_bytes >= need && ((uintptr_t)ws % 16) == 0) ? (float*)ws : nullptr;
