@@ -35,6 +35,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     typedef typename std::conditional<W16, T, float>::type DY;
     typedef typename std::conditional<W16, u16x8, f32x8>::type opfrag;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, khalf = lane >> 5;
+    // (the launch-order remap of conv_wgrad16_lds_kernel -- the groups of a pixel job back to back on one XCD -- was measured
+    // here too and is NOT used: the jobs of a group end in fp32 atomics on the same dw tile, and bunching the groups changes which
+    // atomics collide: fp32 C4 step 49.7 -> 60.4 ms, 5b_b1b weight gradient 0.27 -> 0.80 ms)
     const long long job = (long long)blockIdx.x * 4 + wave;
     if (job >= p.jobs) return;                               // wave-uniform; the kernel has no barrier
     int t = blockIdx.y;
