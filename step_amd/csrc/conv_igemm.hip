@@ -668,7 +668,30 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_
         return conv_pw_launch<T>(pl.NB, pl.wv, p, grid, stream);
     }
     if (pl.impl == 1) {
-        dim3 grid = grid1d(ceil_div(p.nblk32, 2 * pl.NB));
+        // The last, partial round of one-workgroup-per-CU tiles: conv3d_2c at C2 is 1568 tiles = 6.125 rounds of 256, i.e. a
+        // seventh round that keeps 32 CUs busy and 224 idle for a full tile time (12 % of the launch).  When the layer is ONE
+        // channel group deep (NB > 1) those tail tiles are launched separately with NB = 1 -- NB times as many, shorter
+        // workgroups spread over the idle CUs.  Same pixels, same K order per output: bit-identical.  (STEP_CONV_TAIL=0: one launch.)
+        const int groups = ceil_div(p.nblk32, 2 * pl.NB);
+        const long long slots = getenv("STEP_CONV_SLOTS") ? atoi(getenv("STEP_CONV_SLOTS")) : 256;     // (test aid: the split at interpreter sizes; read per call)
+        const long long tail = pl.mtiles % slots;
+        const bool tail_ok = !(getenv("STEP_CONV_TAIL") && atoi(getenv("STEP_CONV_TAIL")) == 0);
+        const int tgroups = ceil_div(p.nblk32, 2);
+        const bool box_ok = pl.twl != 0 || (pl.gtd + d->kd - 1) * (pl.gth + d->kh - 1) * (pl.gtw + d->kw - 1) <= conv_gen_npix(8, 1);   // (the NB = 1 kernel reserves a smaller general-box halo)
+        if (tail_ok && box_ok && pl.wv == 8 && groups == 1 && pl.NB > 1 && pl.mtiles > slots && tail > 0 && tail * 4 <= slots && tail * tgroups <= slots) {
+            const long long all = pl.mtiles;
+            pl.mtiles = all - tail;
+            dim3 grid = grid1d(1);
+            int rc = conv_tap_launch<T>(pl, p, d->kd, grid, stream);
+            if (rc != STEP_OK) return rc;
+            ConvPlan pt = pl;
+            pt.NB = 1; pt.mtiles = tail;
+            p.tile0 = (int)(all - tail);
+            p.gx = (int)tail; p.gy = tgroups;
+            const dim3 gt((unsigned)((tail * tgroups + 7) / 8 * 8));
+            return conv_tap_launch<T>(pt, p, d->kd, gt, stream);
+        }
+        dim3 grid = grid1d(groups);
         return conv_tap_launch<T>(pl, p, d->kd, grid, stream);
     }
     dim3 grid = grid1d(ceil_div(p.nblk32, pl.NB));
@@ -780,7 +803,7 @@ int step_conv_forward_ws(const step_conv_desc* d, const void* x, const void* w_p
     p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
     p.r_cstride = d->res_cstride; p.r_coff = d->res_coff;
     p.relu = d->relu;
-    p.tiles_h = p.tiles_w = 0; p.tiles_d = d->D; p.gtd = p.gth = p.gtw = 1; p.gmode = 0; p.gx = p.gy = 0;
+    p.tiles_h = p.tiles_w = 0; p.tiles_d = d->D; p.gtd = p.gth = p.gtw = 1; p.gmode = 0; p.gx = p.gy = 0; p.tile0 = 0;
     p.nchunks = ceil_div(d->Cin, CK);
     p.nchunks32 = p.nchunks;
     p.vec_epi = (d->y_cstride % 8 == 0) && (d->y_coff % 8 == 0) && (d->Cout % 8 == 0) && (((uintptr_t)y) % 16 == 0) &&

@@ -387,7 +387,7 @@ static int pool_conv_forward_impl(const step_conv_desc* d, bool s2, int Hi, int 
     p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
     p.r_cstride = 0; p.r_coff = 0;
     p.relu = d->relu;
-    p.gtd = pl.td; p.gth = pl.th; p.gtw = pl.tw; p.gmode = 0;
+    p.gtd = pl.td; p.gth = pl.th; p.gtw = pl.tw; p.gmode = 0; p.tile0 = 0;
     p.tiles_d = ceil_div(d->D, pl.td); p.tiles_h = ceil_div(d->H, pl.th); p.tiles_w = ceil_div(d->W, pl.tw);
     p.nchunks = ceil_div(d->Cin, CK); p.nchunks32 = p.nchunks;
     p.vec_epi = (d->y_cstride % 8 == 0) && (d->y_coff % 8 == 0) && (d->Cout % 8 == 0) && (((uintptr_t)y) % 16 == 0);

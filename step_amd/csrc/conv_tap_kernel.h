@@ -165,7 +165,7 @@ void conv_tap_kernel(ConvParams p) {
 
     int gbx, gby;
     if (!grid_coords(p, gbx, gby)) return;
-    int t = gbx;
+    int t = gbx + p.tile0;
     const int tw_i = t % p.tiles_w; t /= p.tiles_w;
     const int th_i = t % p.tiles_h; t /= p.tiles_h;
     const int d0 = (t % p.tiles_d) * TD;

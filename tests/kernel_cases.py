@@ -1210,6 +1210,42 @@ def case_conv_general_box_row_groups(bk, golden):
                 os.environ[k_] = v_
 
 
+def case_conv_tail_round_split(bk, golden):
+    """A layer that is one channel group deep and whose pixel tiles end in a small partial round of one-workgroup-per-CU slots is
+    launched in two parts: the full rounds at NB = 3 and the tail tiles at NB = 1 (three times as many, shorter workgroups).
+    At interpreter size with STEP_CONV_SLOTS=4 (9 tiles: two rounds + one tile): same result, bit for bit, as the single launch."""
+    import os
+    rs = np.random.RandomState(43)
+    N, Cin, Cout, D, H, W = 1, 64, 192, 4, 24, 24
+    x = rs.randn(N, Cin, D, H, W).astype(np.float32)
+    w = (rs.randn(Cout, Cin, 3, 3, 3) / np.sqrt(Cin * 27)).astype(np.float32)
+    scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32)
+    shift = (0.2 * rs.randn(Cout)).astype(np.float32)
+    keys = ("STEP_CONV_SLOTS", "STEP_CONV_TAIL", "STEP_CONV_NB", "STEP_CONV_WAVES")
+    keep = {k_: os.environ.get(k_) for k_ in keys}
+    try:
+        os.environ.update({"STEP_CONV_SLOTS": "4", "STEP_CONV_NB": "3", "STEP_CONV_WAVES": "8"})
+        for dt in (BF16, F32):
+            d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=3, kh=3, kw=3, x_cstride=Cin, x_coff=0, y_cstride=Cout, y_coff=0,
+                               res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+            info = (ctypes.c_int * 10)()
+            assert bk.lib.step_conv_plan_info(ctypes.byref(d), info, 10) == 0
+            assert info[0] == 1 and info[2] == 3 and info[3] == 8 and info[9] == 9, list(info)     # 9 tiles, one channel group
+            ref = ref_conv(x, w, scale, shift, dt)
+            outs = {}
+            for mode in ("1", "0"):
+                os.environ["STEP_CONV_TAIL"] = mode
+                outs[mode] = run_conv(bk, x, w, scale, shift, dt)
+                assert np.abs(outs[mode] - ref).max() / np.abs(ref).max() < tol(dt), (mode, dt)
+            assert np.array_equal(outs["1"], outs["0"]), dt
+    finally:
+        for k_, v_ in keep.items():
+            if v_ is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v_
+
+
 def case_conv_pointwise_weight_stationary(bk, golden):
     """conv_pws_kernel (the weight-stationary short-K pointwise stream, STEP_CONV_PWS=1) against the oracle and against the
     default kernel: one to four 64-channel steps, a K tail that is not a multiple of 64 or 32, one to four passes over the
