@@ -1,7 +1,31 @@
 #!/bin/bash
+# one gpurun call: rocprofv3 kernel statistics of the bench configs and the two PMC traffic passes (outputs under gpurun_out/,
+# the summaries are then copied to profiles/ by hand)
 R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 4 --warmup 2 --no-graph --no-cpu-baseline > $O/pmc_$c.json 2> $O/pmc_$c.err
+done
 cd $R
-timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_modules.py -q -m gpu -k "tail_round or conv_units or c2_full_size or c5_full or big_conv" 2>&1 | tail -2
-timeout 400 python tools/ab_bench.py --var "STEP_CONV_TAIL=0" --var "STEP_CONV_TAIL=1" 2>&1 | grep -E "layer|2c_3x3|3c_b1b|3b_b1b|total"
-timeout 400 python tools/ab_bench.py --set c3 --batch 4 --var "STEP_CONV_TAIL=0" --var "STEP_CONV_TAIL=1" 2>&1 | grep -E "layer|3x3|b1b|total"
-for v in 0 1 0 1; do echo "TAIL=$v"; STEP_CONV_TAIL=$v timeout 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline 2>/dev/null | cut -c1-110; done
+K1='void step::conv_tap_kernel<step::bf16_t, 3, 3, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'
+K2='void step::stem_stream_kernel<step::bf16_t>(step::StemParams)'
+K3='void step::conv_tap_kernel<step::bf16_t, 0, 2, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'
+K4='void step::conv_tap_kernel<step::bf16_t, 0, 3, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'
+K5='void step::conv_tap_kernel<step::bf16_t, 0, 1, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'
+K6='void step::maxpool_sep_kernel<step::bf16_t, 3, 3, 3, 1, 1, 1, 256>(step::bf16_t const*, step::bf16_t*, step::PoolParams, int, int, int, int, int, int, int, int)'
+K7='void step::maxpool_sep_kernel<step::bf16_t, 1, 3, 3, 1, 2, 2, 256>(step::bf16_t const*, step::bf16_t*, step::PoolParams, int, int, int, int, int, int, int, int)'
+K8='void step::conv_pw_kernel<step::bf16_t, 1, 8>(step::ConvParams)'
+K9='void step::conv_pws_kernel<step::bf16_t, 3, 4>(step::ConvParams, int)'
+K10='void step::conv_pw_kernel<step::bf16_t, 3, 4>(step::ConvParams)'
+K11='void step::conv_tap_kernel<step::bf16_t, 3, 1, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'    # conv3d_2c's partial last round (C2)
+python tools/pmc_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/traffic_latest.json "$K1" "$K2" "$K3" "$K4" "$K5" "$K6" "$K7" "$K8" "$K9" "$K10" "$K11" > $O/pmc_traffic.log 2>&1
+python - <<P
+import json
+f='$O/traffic_latest.json'; j=json.load(open(f)); k=j['kernels']
+if '''$K11''' in k: k['''$K11''']['with']='''$K1'''
+json.dump(j, open(f,'w'), indent=1)
+P
+rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+head -22 $O/prof_c2_summary.txt | cut -c1-200; cat $O/bench_c2_prof.json | cut -c1-300; tail -3 $O/pmc_traffic.log | cut -c1-600

@@ -29,6 +29,13 @@ K7='void step::maxpool_sep_kernel<step::bf16_t, 1, 3, 3, 1, 2, 2, 256>(step::bf1
 K8='void step::conv_pw_kernel<step::bf16_t, 1, 8>(step::ConvParams)'
 K9='void step::conv_pws_kernel<step::bf16_t, 3, 4>(step::ConvParams, int)'
 K10='void step::conv_pw_kernel<step::bf16_t, 3, 4>(step::ConvParams)'
-python tools/pmc_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/traffic_latest.json "$K1" "$K2" "$K3" "$K4" "$K5" "$K6" "$K7" "$K8" "$K9" "$K10" > $O/pmc_traffic.log 2>&1
+K11='void step::conv_tap_kernel<step::bf16_t, 3, 1, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'    # conv3d_2c's partial last round (C2)
+python tools/pmc_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/traffic_latest.json "$K1" "$K2" "$K3" "$K4" "$K5" "$K6" "$K7" "$K8" "$K9" "$K10" "$K11" > $O/pmc_traffic.log 2>&1
+python - <<P
+import json
+f='$O/traffic_latest.json'; j=json.load(open(f)); k=j['kernels']
+if '''$K11''' in k: k['''$K11''']['with']='''$K1'''
+json.dump(j, open(f,'w'), indent=1)
+P
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 head -22 $O/prof_c2_summary.txt | cut -c1-200; cat $O/bench_c2_prof.json | cut -c1-300; tail -3 $O/pmc_traffic.log | cut -c1-600
