@@ -1,31 +1,7 @@
 #!/bin/bash
-# one gpurun call: rocprofv3 kernel statistics of the bench configs and the two PMC traffic passes (outputs under gpurun_out/,
-# the summaries are then copied to profiles/ by hand)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
-mkdir -p $O
-cd /tmp; export TMPDIR=/tmp
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 4 --warmup 2 --no-graph --no-cpu-baseline > $O/pmc_$c.json 2> $O/pmc_$c.err
-done
 cd $R
-K1='void step::conv_tap_kernel<step::bf16_t, 3, 3, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'
-K2='void step::stem_stream_kernel<step::bf16_t>(step::StemParams)'
-K3='void step::conv_tap_kernel<step::bf16_t, 0, 2, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'
-K4='void step::conv_tap_kernel<step::bf16_t, 0, 3, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'
-K5='void step::conv_tap_kernel<step::bf16_t, 0, 1, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'
-K6='void step::maxpool_sep_kernel<step::bf16_t, 3, 3, 3, 1, 1, 1, 256>(step::bf16_t const*, step::bf16_t*, step::PoolParams, int, int, int, int, int, int, int, int)'
-K7='void step::maxpool_sep_kernel<step::bf16_t, 1, 3, 3, 1, 2, 2, 256>(step::bf16_t const*, step::bf16_t*, step::PoolParams, int, int, int, int, int, int, int, int)'
-K8='void step::conv_pw_kernel<step::bf16_t, 1, 8>(step::ConvParams)'
-K9='void step::conv_pws_kernel<step::bf16_t, 3, 4>(step::ConvParams, int)'
-K10='void step::conv_pw_kernel<step::bf16_t, 3, 4>(step::ConvParams)'
-K11='void step::conv_tap_kernel<step::bf16_t, 3, 1, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'    # conv3d_2c's partial last round (C2)
-python tools/pmc_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/traffic_latest.json "$K1" "$K2" "$K3" "$K4" "$K5" "$K6" "$K7" "$K8" "$K9" "$K10" "$K11" > $O/pmc_traffic.log 2>&1
-python - <<P
-import json
-f='$O/traffic_latest.json'; j=json.load(open(f)); k=j['kernels']
-if '''$K11''' in k: k['''$K11''']['with']='''$K1'''
-json.dump(j, open(f,'w'), indent=1)
-P
-rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
-head -22 $O/prof_c2_summary.txt | cut -c1-200; cat $O/bench_c2_prof.json | cut -c1-300; tail -3 $O/pmc_traffic.log | cut -c1-600
+timeout 600 python bench.py --steps 50 --warmup 10 --no-cpu-baseline > $O/bench_c2.json 2> $O/bench_c2.err; tail -3 $O/bench_c2.err; python -c "
+import json; d=json.load(open('$O/bench_c2.json')); print(d['value'], d['ms_per_step']); r=d['roofline']; print(r['kernel'][:60], r['frac'], r['avg_launch_ms'], r['traffic']); 
+for k in r['next_kernels']: print(k['kernel'][:70], k['frac'], k['avg_launch_ms'], k['launches_per_step'], k['traffic'])"
