@@ -120,10 +120,19 @@ def roofline(net, x, dtype_name):
     backbone.BRANCH_STREAMS = saved
     rec, ops.PROFILE = ops.PROFILE, None
     agg = {}
-    for name, flops, nbytes, e0, e1 in rec:
+    # the three forwards issue the same launches in the same order: every launch position is timed three times and the MEDIAN is
+    # used (one slow outlier -- a clock ramp, a first touch -- would otherwise decide which class is 'dominant')
+    npos = len(rec) // 3
+    same = npos > 0 and len(rec) == 3 * npos and all(rec[i][0] == rec[i + npos][0] == rec[i + 2 * npos][0] for i in range(npos))
+    for i, (name, flops, nbytes, e0, e1) in enumerate(rec):
         a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+        if same:
+            t3 = sorted(rec[(i % npos) + k * npos][3].elapsed_time(rec[(i % npos) + k * npos][4]) for k in range(3))
+            t = t3[1]
+        else:
+            t = e0.elapsed_time(e1)
         a[0] += 1
-        a[1] += e0.elapsed_time(e1)
+        a[1] += t
         a[2] += flops
         a[3] += nbytes
     total_ms = sum(a[1] for a in agg.values())

@@ -19,6 +19,7 @@ struct StemParams {
     const void* x; const void* w; const float* scale; const float* shift; void* y;
     int N, T, H, W, To, Ho, Wo, Cout, y_cstride, y_coff;
     int tiles_h, tiles_w, nblk32;
+    int tile0;                 // stem_stream_kernel: first pixel tile of this launch (the layer may be launched in two parts)
 };
 
 template <typename T, int NB>
@@ -390,11 +391,11 @@ __device__ __forceinline__ u16x8 lds_read_frag_a4(const unsigned char* p) {
     return r;
 }
 
-template <typename T>
+template <typename T, int NB_ = 2>
 __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel(StemParams p) {
     static_assert(sizeof(T) == 2, "16-bit storage types only");
     constexpr int FRAME = STS_FRAME, PITCH = STS_PITCH;
-    constexpr int NB = 2, FRAGB = 1024;
+    constexpr int NB = NB_, FRAGB = 1024;          // 32-channel blocks per workgroup: 2, or 1 for the tiles of the partial last round
     constexpr int NBREG = 4 * FRAGB;                // one n-block's share of a weight buffer (up to 4 K-steps)
     constexpr int BBUF = NB * NBREG;                // 8 KiB
     constexpr int ITEMS = STP_ROWS * (STP_COLS / 4);   // 4-pixel items per frame
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
     // they share input halos and frames -- are consecutive on ONE XCD instead of round-robin over the eight L2s
     int t = blockIdx.x;
     if ((gridDim.x & 7) == 0) t = (t & 7) * (gridDim.x >> 3) + (t >> 3);
+    t += p.tile0;
     const int tw_i = t % p.tiles_w; t /= p.tiles_w;
     const int th_i = t % p.tiles_h; t /= p.tiles_h;
     const int od = t % p.To;
@@ -706,8 +708,28 @@ template <typename T>
 static int stem_stream_forward_t(StemParams p, step_stream_t stream) {
     p.w = (const T*)p.w + stem_stream_offset(p.Cout);
     p.tiles_h = ceil_div(p.Ho, 16); p.tiles_w = ceil_div(p.Wo, 16);
-    dim3 grid((unsigned)((long long)p.N * p.To * p.tiles_h * p.tiles_w), (unsigned)ceil_div(p.nblk32, 2));
-    STEP_LAUNCH((stem_stream_kernel<T>), grid, dim3(256), stream, p);
+    const long long tiles = (long long)p.N * p.To * p.tiles_h * p.tiles_w;
+    const int groups = ceil_div(p.nblk32, 2);
+    // the partial last round (as conv_forward_t does for conv3d_2c): three workgroups fit a CU, so 768 run at a time; C2's 6272
+    // tiles are 8.17 such rounds -- a ninth that fills a sixth of the chip.  With one channel group those tail tiles can run as a
+    // second launch at one 32-channel block per workgroup: twice as many, shorter workgroups; bit-identical (same K order per output).
+    // MEASURED SLOWER here (C2 stem 263 -> 268 us: with three resident workgroups per CU the rounds are not in step and the tail is
+    // already smeared out; the NB = 1 workgroups re-stage the same frames for half the matrix work), so it is opt-in:
+    // STEP_STEM_TAIL=1 (kept with its test as the record of the experiment).
+    const long long slots = getenv("STEP_CONV_SLOTS") ? atoi(getenv("STEP_CONV_SLOTS")) : 768;          // (test aid, read per call)
+    const bool tail_ok = getenv("STEP_STEM_TAIL") && atoi(getenv("STEP_STEM_TAIL")) == 1;
+    const long long tail = tiles % slots;
+    p.tile0 = 0;
+    if (tail_ok && groups == 1 && p.nblk32 == 2 && tiles > slots && tail > 0 && tail * 4 <= slots) {
+        dim3 grid((unsigned)(tiles - tail), 1);
+        STEP_LAUNCH((stem_stream_kernel<T, 2>), grid, dim3(256), stream, p);
+        p.tile0 = (int)(tiles - tail);
+        dim3 gt((unsigned)tail, 2);
+        STEP_LAUNCH((stem_stream_kernel<T, 1>), gt, dim3(256), stream, p);
+        return STEP_LAUNCH_CHECK();
+    }
+    dim3 grid((unsigned)tiles, (unsigned)groups);
+    STEP_LAUNCH((stem_stream_kernel<T, 2>), grid, dim3(256), stream, p);
     return STEP_LAUNCH_CHECK();
 }
 
@@ -763,7 +785,7 @@ int step_stem_forward(int dtype, const void* x, int N, int T, int H, int W, cons
     if (((uintptr_t)x % 16) || ((uintptr_t)w_packed % 16)) return STEP_E_ALIGN;
     StemParams p;
     p.x = x; p.w = w_packed; p.scale = scale; p.shift = shift; p.y = y;
-    p.N = N; p.T = T; p.H = H; p.W = W;
+    p.N = N; p.T = T; p.H = H; p.W = W; p.tile0 = 0;
     p.To = (T + 5 - 7) / 2 + 1; p.Ho = (H + 5 - 7) / 2 + 1; p.Wo = (W + 5 - 7) / 2 + 1;
     if (p.To <= 0 || p.Ho <= 0 || p.Wo <= 0) return STEP_E_SHAPE;
     p.Cout = Cout; p.y_cstride = y_cstride; p.y_coff = y_coff;

@@ -1339,6 +1339,36 @@ def _stem_case(bk, shape, dts, Cout):
         assert err < tol(dt), (shape, dt, err)
 
 
+def case_stem_tail_round_split(bk, golden):
+    """The stem's partial last round as a second launch with one 32-channel block per workgroup (stem_stream_kernel<T, 1>, tile
+    offset; opt-in STEP_STEM_TAIL=1 -- measured slower on the C2 stem): at interpreter size through STEP_CONV_SLOTS (24 tiles,
+    20 slots: 20 + 4) the result equals the single launch bit for bit and the oracle within tolerance."""
+    import os
+    N, T, H, W, Cout = 1, 8, 40, 72, 64                    # To = 4, 2 x 3 tiles of 16 x 16 per frame: 24 tiles
+    rs = np.random.RandomState(47)
+    x = rs.uniform(-1, 1, (N, T, 3, H, W)).astype(np.float32)
+    w = (rs.randn(Cout, 3, 7, 7, 7) / np.sqrt(1029)).astype(np.float32)
+    scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32)
+    shift = (0.2 * rs.randn(Cout)).astype(np.float32)
+    keep = {k_: os.environ.get(k_) for k_ in ("STEP_CONV_SLOTS", "STEP_STEM_TAIL")}
+    try:
+        os.environ["STEP_CONV_SLOTS"] = "20"
+        for dt in (BF16, F16):
+            ref = ref_stem(x, w, scale, shift, dt)
+            outs = {}
+            for mode in ("1", "0"):
+                os.environ["STEP_STEM_TAIL"] = mode
+                outs[mode] = run_stem(bk, x, w, scale, shift, dt)
+                assert np.abs(outs[mode] - ref).max() / np.abs(ref).max() < tol(dt), (mode, dt)
+            assert np.array_equal(outs["1"], outs["0"]), dt
+    finally:
+        for k_, v_ in keep.items():
+            if v_ is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v_
+
+
 def case_stem(bk, golden):
     _stem_case(bk, (1, 8, 32, 32), (F32, BF16), 64)
     _stem_case(bk, (2, 5, 18, 22), (F32, BF16), 40)     # odd T, W % 4 != 0 -> scalar staging path
