@@ -808,7 +808,8 @@ int step_stem_kernel_name(int dtype, char* buf, int buflen) {
     const char* t = dtype == STEP_F32 ? "float" : (dtype == STEP_BF16 ? "step::bf16_t" : "step::f16_t");
     if (dtype != STEP_F32 && dtype != STEP_BF16 && dtype != STEP_F16) return STEP_E_DTYPE;
     if (dtype == STEP_F32 || ov == 0) snprintf(buf, (size_t)buflen, "void step::stem_igemm_kernel<%s, 2>(step::StemParams)", t);
-    else snprintf(buf, (size_t)buflen, "void step::%s<%s>(step::StemParams)", ov == 1 ? "stem_tap_kernel" : "stem_stream_kernel", t);
+    else if (ov == 1) snprintf(buf, (size_t)buflen, "void step::stem_tap_kernel<%s>(step::StemParams)", t);
+    else snprintf(buf, (size_t)buflen, "void step::stem_stream_kernel<%s, 2>(step::StemParams)", t);
     return STEP_OK;
 }
 

@@ -2,8 +2,13 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --list-avail 2>/dev/null | grep -o "SQ_[A-Z_0-9]*" | sort -u | grep -E "WAIT|ACTIVE_INST|IFETCH|BARRIER|LEVEL_WAVES|THREAD_CYCLES" | tr '\n' ' ' > $O/pmc_avail2.txt; cat $O/pmc_avail2.txt; echo
+run() { tag=$1; shift
+  timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmcz_${tag} -- python $R/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline > /dev/null 2> $O/pmcz_${tag}.err || tail -3 $O/pmcz_${tag}.err; }
+run a SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS
+run b SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VMEM
 cd $R
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > $O/gputests.log; cat $O/gputests.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; python -c "
-import json; d=json.load(open('$O/bench_default.json')); print(d['value'], d['ms_per_step']); r=d['roofline']; print(r['kernel'][:70], r['frac'], r['avg_launch_ms']); print([(k['kernel'][11:45], k['frac']) for k in r['next_kernels']]); print(d['cpu_baseline']['value'], d['cpu_baseline']['cores'])"
+python tools/pmc_counters.py $O/pmc_waits.txt "default:$O/pmcz_a,$O/pmcz_b" -- "stem_stream_kernel" "conv_tap_kernel<step::bf16_t, 3, 3" "conv_tap_kernel<step::bf16_t, 0, 1, 3, 3, 3, 2, 2, 8" > /dev/null
+cat $O/pmc_waits.txt | cut -c1-130
+rm -rf $O/pmcz_*

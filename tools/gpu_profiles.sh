@@ -20,7 +20,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 K1='void step::conv_tap_kernel<step::bf16_t, 3, 3, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'
-K2='void step::stem_stream_kernel<step::bf16_t>(step::StemParams)'
+K2='void step::stem_stream_kernel<step::bf16_t, 2>(step::StemParams)'
 K3='void step::conv_tap_kernel<step::bf16_t, 0, 2, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'
 K4='void step::conv_tap_kernel<step::bf16_t, 0, 3, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'
 K5='void step::conv_tap_kernel<step::bf16_t, 0, 1, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'
