@@ -45,7 +45,7 @@ def main():
         out = run()
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / a.iters
-    kept = sum(int(o[1].numel()) for o in out)
+    kept = sum(int(d_["scores"].shape[0]) for it_ in out for d_ in it_)       # postprocess: iterations x clips x {boxes, scores, labels, tubes}
     print("C3 inference: batch %d x [36,3,400,400] %s, %d tubes/clip: %.2f ms/batch = %.1f clips/s  (detections kept: %d)"
           % (a.batch, a.dtype, a.tubes, el * 1e3, a.batch / el, kept))
     # the same pipeline captured in a hipGraph
