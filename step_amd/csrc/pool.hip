@@ -643,7 +643,9 @@ static int maxpool_t(const void* x, void* y, const PoolParams& p, step_stream_t 
         // so keep >= 4 output planes per segment (kd = 1: no dependence along D)
         static const int target = getenv("STEP_POOL_BLOCKS") ? atoi(getenv("STEP_POOL_BLOCKS")) : 1024;     // tuning aids
         static const int minseg_e = getenv("STEP_POOL_MINSEG") ? atoi(getenv("STEP_POOL_MINSEG")) : 4;
-        const int minseg = p.kd == 1 ? 1 : minseg_e;
+        // (single-tile maps -- the 14x14 stage -- are latency-bound chains of planes, not bandwidth-bound: shorter segments, measured
+        // 14.8 -> 13.8 us per pool; on the 28x28 maps the extra halo planes cost more than the parallelism gives: 25.9 -> 30.2 us)
+        const int minseg = p.kd == 1 ? 1 : ((tiles_h * tiles_w == 1 && !getenv("STEP_POOL_MINSEG")) ? 2 : minseg_e);
         int nseg = 1;
         while (blocks * nseg < target && p.Do / (nseg * 2) >= minseg) nseg *= 2;
         const int dseg = ceil_div(p.Do, nseg);
