@@ -391,6 +391,25 @@ def case_maxpool_backward(bk, golden):
                 out = uncl(go.get() if odt == 0 else decode(go.get(), dt))
                 want = refq if odt == 0 else quantize(refq, dt)
                 assert np.allclose(out, want, rtol=2e-2 if odt else 1e-6, atol=1e-6), (k, s, dt, gdt, odt, np.abs(out - want).max())
+    # the pool input as a channel slice [8, 16) of a 24-channel buffer (x_cstride / x_coff): same gradient as the dense tensor
+    k, s = POOLS[0]
+    xw = np.full((N, D, H, W, 24), 9.0, np.float32)
+    xw[..., 8:16] = cl(x)
+    pads = []
+    for kk, ss in zip(reversed(k), reversed(s)):
+        a = max(kk - ss, 0)
+        pads += [a // 2, a - a // 2]
+    xt = torch.from_numpy(x).requires_grad_(True)
+    y = F.max_pool3d(F.pad(xt, pads), k, s, ceil_mode=True)
+    gy2 = rs.randn(*y.shape).astype(np.float32)
+    y.backward(torch.from_numpy(gy2))
+    Do, Ho, Wo = y.shape[2:]
+    arg2 = bk.dev(np.zeros(N * Do * Ho * Wo * C, np.uint8))
+    gs = bk.dev(np.zeros((N, D, H, W, C), np.float32))
+    xwd, gyd2 = bk.dev(xw), bk.dev(np.ascontiguousarray(cl(gy2)))          # (named: the buffers must outlive the call)
+    assert L.step_maxpool3d_tf_backward_gather(0, xwd.ptr, N, D, H, W, C, 24, 8, k[0], k[1], k[2], s[0], s[1], s[2], 0, gyd2.ptr, 0, gs.ptr,
+                                               arg2.ptr, bk.stream) == 0
+    assert np.allclose(uncl(gs.get()), xt.grad.numpy(), rtol=1e-6, atol=1e-6)
     assert L.step_maxpool3d_tf_backward_gather(1, xe.ptr, N, D, H, W, 12, 12, 0, 3, 3, 3, 1, 1, 1, 1, ge.ptr, 1, go.ptr, arg.ptr, bk.stream) == -4   # C % 8
     assert L.step_maxpool3d_tf_backward_gather(1, xe.ptr, N, D, H, W, C, C, 0, 3, 3, 3, 1, 1, 1, 2, ge.ptr, 1, go.ptr, arg.ptr, bk.stream) < 0     # gy type
 
