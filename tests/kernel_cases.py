@@ -410,6 +410,7 @@ def case_maxpool_backward(bk, golden):
     assert L.step_maxpool3d_tf_backward_gather(0, xwd.ptr, N, D, H, W, C, 24, 8, k[0], k[1], k[2], s[0], s[1], s[2], 0, gyd2.ptr, 0, gs.ptr,
                                                arg2.ptr, bk.stream) == 0
     assert np.allclose(uncl(gs.get()), xt.grad.numpy(), rtol=1e-6, atol=1e-6)
+    assert L.step_maxpool3d_tf_backward_gather(0, None, 0, D, H, W, C, C, 0, 3, 3, 3, 1, 1, 1, 0, None, 0, None, None, bk.stream) == 0              # empty batch
     assert L.step_maxpool3d_tf_backward_gather(1, xe.ptr, N, D, H, W, 12, 12, 0, 3, 3, 3, 1, 1, 1, 1, ge.ptr, 1, go.ptr, arg.ptr, bk.stream) == -4   # C % 8
     assert L.step_maxpool3d_tf_backward_gather(1, xe.ptr, N, D, H, W, C, C, 0, 3, 3, 3, 1, 1, 1, 2, ge.ptr, 1, go.ptr, arg.ptr, bk.stream) < 0     # gy type
 
@@ -1150,6 +1151,10 @@ def case_stem_wgrad16(bk, golden):
             assert bk.lib.step_stem_wgrad16(dt, xd.ptr, N, T, H, W, gd.ptr, Cout, dw2.ptr, 0, ws.ptr, wsb, bk.stream) == 0
             assert np.array_equal(dw2.get(), got)                                   # deterministic: no atomics
             assert bk.lib.step_stem_wgrad16(dt, xd.ptr, N, T, H, W, gd.ptr, Cout, dw2.ptr, 0, ws.ptr, wsb - 16, bk.stream) < 0
+    # an empty batch: no launch, the gradient is cleared (or left alone when accumulating)
+    dz = bk.dev(np.full((64, 3, 7, 7, 7), 2.0, np.float32))
+    assert bk.lib.step_stem_wgrad16(BF16, None, 0, 6, 24, 72, None, 64, dz.ptr, 1, None, 0, bk.stream) == 0 and float(dz.get().min()) == 2.0
+    assert bk.lib.step_stem_wgrad16(BF16, None, 0, 6, 24, 72, None, 64, dz.ptr, 0, None, 0, bk.stream) == 0 and not dz.get().any()
     assert bk.lib.step_stem_wgrad16_workspace_bytes(F32, 1, 6, 22, 72, 64) == 0       # fp32, W % 8, Cout % 8: step_stem_wgrad's
     assert bk.lib.step_stem_wgrad16_workspace_bytes(BF16, 1, 6, 22, 70, 64) == 0
     assert bk.lib.step_stem_wgrad16_workspace_bytes(BF16, 1, 6, 22, 72, 60) == 0
