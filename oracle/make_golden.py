@@ -616,9 +616,43 @@ def i3d_main():
     print("i3d classifier", tuple(logits.shape), float(logits.abs().max()))
 
 
+def head_grad_main():
+    """Gradients of the reference's OWN TwoBranchNet under its own autograd (two_branch.py:215-333, train mode, frozen BN,
+    dropout 0): the loss of train.py:318-331 (cls + 5 reg + neighbour) on the head_golden inputs, back-propagated to every
+    trainable parameter.  Stored per parameter as its L2 norm and a strided sample (the tensors themselves are ~80 MB)."""
+    from oracle import i3d_ref as R
+    models, _, _, _ = import_reference()
+    hg = np.load(os.path.join(OUT, "head_golden.npz"))
+    det = models.TwoBranchNet(cfg())
+    fill_module(det, "det0.")
+    det.set_device("cpu")
+    det.train()
+    pf = R.fill_tensor("golden.det.pooled3", (2, 3, 832, 7, 7), "feat")
+    cx = R.fill_tensor("golden.det.ctx3", (2, 1024, 3, 1, 1), "feat")
+    o = det(pf, context_feat=cx, tubes=torch.from_numpy(hg["loss_tubes"]), targets=torch.from_numpy(hg["loss_targets"]))
+    loss = o[4].mean() + 5.0 * o[5].mean() + o[6].mean()
+    loss.backward()
+    g = {"loss": np.float64(loss.item())}
+    names = []
+    for k, p in det.named_parameters():
+        if not p.requires_grad:
+            continue
+        f = p.grad.detach().reshape(-1)
+        step = max(1, f.numel() // 512)
+        names.append(k)
+        g["norm." + k] = np.float64(f.double().norm().item())
+        g["step." + k] = np.int64(step)
+        g["sample." + k] = f[::step][:512].numpy().copy()
+    g["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "head_grad_golden.npz"), **g)
+    print("head_grad_golden ok: %d tensors, loss %.6f" % (len(names), loss.item()))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "i3d":
         i3d_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "head_grad":
+        head_grad_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "postprocess":
         postprocess_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "tube_math":
@@ -637,3 +671,4 @@ if __name__ == "__main__":
         tube_math_main()
         postprocess_main()
         i3d_main()
+        head_grad_main()

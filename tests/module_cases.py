@@ -395,6 +395,18 @@ def case_training_step_matches_torch_autograd(dev, golden):
         checked += 1
     info = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
     assert checked == len(info["TwoBranchNet_trainable"])
+    # ... and those of the REFERENCE's own TwoBranchNet under its own autograd (head_grad_golden.npz, recorded by
+    # `python -m oracle.make_golden head_grad`: per-parameter L2 norm and a strided 512-element sample)
+    rg = golden("head_grad_golden")
+    assert abs(float(np_(loss)) - float(rg["loss"])) < 1e-3 * abs(float(rg["loss"]))
+    params = dict(net.named_parameters())
+    for k in (str(n) for n in rg["names"]):
+        gr = params[k].grad.detach().reshape(-1)
+        a = np_(gr[::int(rg["step." + k])][:512]).astype(np.float64)
+        b = rg["sample." + k].astype(np.float64)
+        n_ = float(gr.double().norm())
+        assert abs(n_ - float(rg["norm." + k])) <= 5e-2 * float(rg["norm." + k]), (k, n_, float(rg["norm." + k]))
+        assert np.linalg.norm(a - b) <= 5e-2 * max(np.linalg.norm(b), 1e-30) + 1e-12, k
 
 
 def _grad_check(named_params, sd, tol, what):

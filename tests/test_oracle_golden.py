@@ -182,6 +182,30 @@ def test_heads(golden):
     assert rel_err(o[6].numpy(), g["loss_nbr"]) < 1e-4
 
 
+def test_head_gradients_of_the_restatement_match_the_reference_autograd(golden):
+    """a-19: the training step's parity anchor.  tests/golden/head_grad_golden.npz holds the gradients the REFERENCE's own
+    TwoBranchNet produced under its own autograd for the loss of train.py:318-331 (`python -m oracle.make_golden head_grad`);
+    the restatement (oracle/i3d_ref.twobranch_forward + torch autograd) -- which the HIP path's gradients are compared with on the
+    GPU -- reproduces them."""
+    hg, g = golden("head_golden"), golden("head_grad_golden")
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "batch3d" not in k and "running" not in k)
+          for k, v in R.fill_state_dict(R.twobranch_shapes(), "det0.").items()}
+    pf = R.fill_tensor("golden.det.pooled3", (2, 3, 832, 7, 7), "feat")
+    cx = R.fill_tensor("golden.det.ctx3", (2, 1024, 3, 1, 1), "feat")
+    o = R.twobranch_forward(pf, cx, sd, tubes=torch.from_numpy(hg["loss_tubes"]), targets=torch.from_numpy(hg["loss_targets"]))
+    loss = o[4].mean() + 5.0 * o[5].mean() + o[6].mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    names = [str(n) for n in g["names"]]
+    assert len(names) == 34
+    for k in names:
+        gr = sd[k].grad.reshape(-1)
+        step = int(g["step." + k])
+        assert abs(float(gr.double().norm()) - float(g["norm." + k])) <= 2e-4 * float(g["norm." + k]), k
+        a, b = gr[::step][:512].numpy().astype(np.float64), g["sample." + k].astype(np.float64)
+        assert np.linalg.norm(a - b) <= 2e-4 * max(np.linalg.norm(b), 1e-30), k
+
+
 @pytest.mark.parametrize("ntubes", [11, 34])
 def test_inference_history(golden, ntubes):
     g = golden("inference_golden")
