@@ -648,11 +648,45 @@ def head_grad_main():
     print("head_grad_golden ok: %d tensors, loss %.6f" % (len(names), loss.item()))
 
 
+def base_grad_main():
+    """Gradients of the reference's OWN BaseNet (models/networks.py:55-81 over models/i3dpt.py) under its own autograd, training
+    mode with frozen BN: a scalar (every output element times a signed weight) back-propagated to all 45 trainable tensors, at
+    the two sizes tests/module_cases.case_basenet_backward_matches_oracle_autograd uses (same seeded clip, same weight tensor).
+    Stored per parameter as L2 norm + strided 512-element sample."""
+    from oracle import i3d_ref as R
+    models, _, _, _ = import_reference()
+    g = {}
+    for tag, shape in (("gpu", (1, 8, 3, 112, 112)), ("emul", (1, 4, 3, 32, 32))):
+        net = models.BaseNet(cfg())
+        fill_module(net)
+        net.train()
+        x = torch.rand(*shape, generator=torch.Generator().manual_seed(10)) * 2 - 1
+        y = net(x)
+        wgt = R.fill_tensor("golden.bwd.base.w", tuple(y.shape), "image")
+        (y * wgt).sum().backward()
+        names = []
+        for k, p in net.named_parameters():
+            if not p.requires_grad:
+                continue
+            f = p.grad.detach().reshape(-1)
+            step = max(1, f.numel() // 512)
+            names.append(k)
+            g["%s.norm.%s" % (tag, k)] = np.float64(f.double().norm().item())
+            g["%s.step.%s" % (tag, k)] = np.int64(step)
+            g["%s.sample.%s" % (tag, k)] = f[::step][:512].numpy().copy()
+        g[tag + ".names"] = np.array(names)
+        g[tag + ".out_l2"] = np.float64(y.detach().double().norm().item())
+        print("base_grad_golden %s: %d tensors, |y| %.6f" % (tag, len(names), g[tag + ".out_l2"]))
+    np.savez_compressed(os.path.join(OUT, "base_grad_golden.npz"), **g)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "i3d":
         i3d_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "head_grad":
         head_grad_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "base_grad":
+        base_grad_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "postprocess":
         postprocess_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "tube_math":
@@ -672,3 +706,4 @@ if __name__ == "__main__":
         postprocess_main()
         i3d_main()
         head_grad_main()
+        base_grad_main()

@@ -447,6 +447,20 @@ def case_basenet_backward_matches_oracle_autograd(dev, golden):
     (yo * wgt).sum().backward()
     n = _grad_check(net.named_parameters(), sd, 1e-3, "BaseNet")
     assert n == 45
+    # ... and the gradients the REFERENCE's own BaseNet produced under its own autograd for the same clip and weighting
+    # (base_grad_golden.npz, `python -m oracle.make_golden base_grad`: L2 norm + strided 512-element sample per tensor)
+    rg, tag = golden("base_grad_golden"), ("gpu" if dev != "cpu" else "emul")
+    assert abs(float(y.detach().double().norm()) - float(rg[tag + ".out_l2"])) < 1e-4 * float(rg[tag + ".out_l2"])
+    params = dict(net.named_parameters())
+    names = [str(k_) for k_ in rg[tag + ".names"]]
+    assert len(names) == 45
+    for k in names:
+        gr = params[k].grad.detach().reshape(-1)
+        a = np_(gr[::int(rg["%s.step.%s" % (tag, k)])][:512]).astype(np.float64)
+        b = rg["%s.sample.%s" % (tag, k)].astype(np.float64)
+        nr = float(rg["%s.norm.%s" % (tag, k)])
+        assert abs(float(gr.double().norm()) - nr) <= 1e-3 * nr, k
+        assert np.linalg.norm(a - b) <= 1e-3 * max(np.linalg.norm(b), 1e-30), k
 
 
 def case_contextnet_backward_matches_oracle_autograd(dev, golden):

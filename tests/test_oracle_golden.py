@@ -206,6 +206,24 @@ def test_head_gradients_of_the_restatement_match_the_reference_autograd(golden):
         assert np.linalg.norm(a - b) <= 2e-4 * max(np.linalg.norm(b), 1e-30), k
 
 
+def test_backbone_gradients_of_the_restatement_match_the_reference_autograd(golden):
+    """a-19, backbone leg: base_grad_golden.npz = the gradients of the reference's own BaseNet under its own autograd
+    (`python -m oracle.make_golden base_grad`); the restatement's autograd reproduces them (the 32x32 clip of the interpreter run)."""
+    g = golden("base_grad_golden")
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "batch3d" not in k) for k, v in R.fill_state_dict(R.backbone_shapes()).items()}
+    x = torch.rand(1, 4, 3, 32, 32, generator=torch.Generator().manual_seed(10)) * 2 - 1
+    y = R.basenet_forward(x, sd)
+    assert abs(float(y.detach().double().norm()) - float(g["emul.out_l2"])) < 1e-5 * float(g["emul.out_l2"])
+    wgt = R.fill_tensor("golden.bwd.base.w", tuple(y.shape), "image")
+    (y * wgt).sum().backward()
+    for k in (str(n) for n in g["emul.names"]):
+        gr = sd[k].grad.reshape(-1)
+        nr = float(g["emul.norm." + k])
+        assert abs(float(gr.double().norm()) - nr) <= 2e-4 * nr, k
+        a, b = gr[::int(g["emul.step." + k])][:512].numpy().astype(np.float64), g["emul.sample." + k].astype(np.float64)
+        assert np.linalg.norm(a - b) <= 2e-4 * max(np.linalg.norm(b), 1e-30), k
+
+
 @pytest.mark.parametrize("ntubes", [11, 34])
 def test_inference_history(golden, ntubes):
     g = golden("inference_golden")
