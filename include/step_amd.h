@@ -16,7 +16,8 @@
  *     (reference: outputs are fresh ATen tensors, ROIAlign_cuda.cu:295,340; scratch THCudaMalloc,
  *     nms.cu:113).
  *   - every entry point is asynchronous on `stream`, re-entrant and stateless (nn.DataParallel
- *     calls replicas from one thread per GPU; the caller selects the device).
+ *     calls replicas from one thread per GPU; the caller selects the device).  The library reads no environment
+ *     variable; its only process-wide state is the table of planner options below (step_set_option).
  *   - return value: 0 ok; <0 bad argument (STEP_E_*); >0 a hipError_t from the launch.
  *     (reference: AT_ASSERTM / THCudaCheck throw -> Python RuntimeError; our Python layer raises
  *     RuntimeError on any non-zero status.)
@@ -54,6 +55,36 @@ enum {
 /* Library identity: returns "step_amd <version> gfx950"; abi is bumped on any signature change. */
 STEP_API const char* step_version(void);
 STEP_API int step_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Planner options.  The library reads NO environment variable: the launch planners' few tuning / test knobs are explicit
+ * integers set through this entry point (process-wide, relaxed atomics: safe to call from any thread; a launch sees either
+ * the old or the new value).  Every option has a default under which the planner decides by itself (its measured rules);
+ * no option changes WHAT an entry point computes beyond fp32 summation order where the option's line says so -- they exist
+ * so that tests can reach every kernel form at interpreter sizes and tools/ab_bench.py can time one form against another
+ * in one process.  step_set_option returns STEP_E_SHAPE for an unknown id or a value outside the option's range.
+ */
+enum {
+    STEP_OPT_CONV_IMPL = 0,    /* -1 auto | 0 tiled 4-wave kernel | 1 conv_tap, one tap per step | 2 conv_tap, two taps | 5 streaming pointwise GEMM for every 1x1x1 */
+    STEP_OPT_CONV_NB,          /*  0 auto | 1..3 accumulator depth of conv_tap / conv_pw */
+    STEP_OPT_CONV_WAVES,       /*  0 auto | 4 | 8 wavefronts per workgroup of conv_tap / conv_pw */
+    STEP_OPT_CONV_PHASED,      /*  1 (default) two-phase conv_tap for 16-bit 3x3x3 | 0 classic pipeline (bit-identical results) */
+    STEP_OPT_CONV_GEN,         /*  93 (default): a general tile box when it needs <= this percent of the best power-of-two tiling's tiles; 0 never */
+    STEP_OPT_CONV_GMODE,       /*  1 (default) conflict-free pixel assignment inside general boxes | 0 linear walk (bit-identical) */
+    STEP_OPT_CONV_PWS,         /* -1 auto | 0 never | 1 wherever its contract allows: the weight-stationary pointwise stream (bit-identical) */
+    STEP_OPT_CONV_SPLITK,      /*  1 (default) | 0: split-K form of few-row / deep-K pointwise layers (fixed-order sum either way) */
+    STEP_OPT_CONV_TAIL,        /*  1 (default) | 0: partial last round of a one-channel-group conv_tap launch at NB = 1 (bit-identical) */
+    STEP_OPT_CONV_SLOTS,       /*  0 (default: resident workgroups of the chip) | n: pretend the chip holds n workgroups (tests: the tail split at small sizes) */
+    STEP_OPT_POOL_DIRECT,      /*  0 (default) | 1: every max pool on the general 27-tap kernel (tests) */
+    STEP_OPT_WGRAD_MINPIX,     /*  0 (default: 512) | n: least pixels per wavefront job of step_conv_wgrad (fp32 summation order) */
+    STEP_OPT_WGRAD16_LDS,      /*  1 (default) | 0: 3x3 windows of step_conv_wgrad16_ws on the per-tap kernel instead of the LDS-tiled GEMM */
+    STEP_OPT_CONV_DESYNC,      /*  0 (default) | n: first-round conv_tap workgroups start up to n x 64 clocks apart (de-phases the CUs' store bursts) */
+    STEP_OPT_COUNT_
+};
+STEP_API int step_set_option(int option, int value);
+STEP_API int step_get_option(int option, int* value);
+STEP_API void step_reset_options(void);
+STEP_API const char* step_option_name(int option);   /* "conv_impl", ... ; NULL for an unknown id */
 
 /* ------------------------------------------------------------------------------------------
  * ROIAlign forward.     replaces _C.roi_align_forward   (csrc/ROIAlign.h:35-48,
@@ -183,26 +214,6 @@ STEP_API size_t step_conv_workspace_bytes(const step_conv_desc* d);
 STEP_API int step_conv_forward_ws(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale,
                                   const float* shift, const void* res, void* y, void* y2, void* ws, size_t ws_bytes,
                                   step_stream_t stream);
-
-/* The branch_3 path of an Inception block in one launch:
- *     y = act( conv1x1x1( maxpool3d_tf(x; window 3x3x3, stride 1) ) * scale[c] + shift[c] )
- * replaces MaxPool3dTFPadding((3,3,3),(1,1,1)) followed by Unit3Dpy(1x1x1) (models/i3dpt.py:151-155,160): the pooled
- * tensor is never written to memory.  d describes the 1x1x1 conv (kd = kh = kw = 1, split = 0; x / y geometry, channel
- * strides and offsets as in step_conv_forward); the pool has the TF-"SAME" semantics of step_maxpool3d_tf (positions
- * outside the tensor carry the VALUE 0 and take part in the max).  w_packed: step_conv_pack_weight of the conv's
- * [Cout,Cin,1,1,1] weight.  Results are bit-identical to step_maxpool3d_tf followed by step_conv_forward (a max has no
- * rounding and the K order of the accumulation is the same).  STEP_E_UNSUPPORTED for tensors of >= 2^32 elements (the
- * caller runs the two launches instead). */
-STEP_API int step_pool3_conv1_forward(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale,
-                                      const float* shift, void* y, step_stream_t stream);
-/* The same for the (1,3,3) window / (1,2,2) stride TF-"SAME" pool in front of a 1x1x1 unit -- maxPool3d_2a_3x3 -> conv3d_2b_1x1
- * (models/i3dpt.py:193-201): x [N, D, Hi, Wi, x_cstride] is pooled to [N, D, ceil(Hi/2), ceil(Wi/2)] = d's N, D, H, W (the
- * back-heavy TF pad of one row / column carries the VALUE 0), then the conv.  Bit-identical to step_maxpool3d_tf +
- * step_conv_forward; the pooled tensor (51 MB written and read back per C2 batch) never reaches memory. */
-STEP_API int step_pool133s2_conv1_forward(const step_conv_desc* d, int Hi, int Wi, const void* x, const void* w_packed,
-                                          const float* scale, const float* shift, void* y, step_stream_t stream);
-/* Diagnostic, as step_conv_kernel_name. */
-STEP_API int step_pool3_conv1_kernel_name(const step_conv_desc* d, char* buf, int buflen);
 
 /* Weight gradient of the same conv (training, train.py:257-348; replaces the cuDNN wgrad behind Conv3d/Conv2d/Linear
  * .backward):  dw[co][ci][kd][kh][kw] (fp32, torch's weight layout) (+)= sum_p dy[p][co] * x[p + tap][ci].

@@ -4,7 +4,7 @@ import ctypes as C
 
 F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 vp, fp, ip, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # raw device addresses
 i, f, ll, sz = C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -26,6 +26,10 @@ class PackItem(C.Structure):
 SIGNATURES = {
     "step_version": (C.c_char_p, []),
     "step_abi_version": (i, []),
+    "step_set_option": (i, [i, i]),
+    "step_get_option": (i, [i, C.POINTER(C.c_int)]),
+    "step_reset_options": (None, []),
+    "step_option_name": (C.c_char_p, [i]),
     "step_roi_align_forward": (i, [vp, i, i, fp, i, i, i, i, i, i, i, f, i, vp, vp]),
     "step_roi_align_backward": (i, [fp, i, fp, i, i, i, i, i, i, i, f, i, fp, vp]),
     "step_roi_pool_forward": (i, [vp, i, i, fp, i, i, i, i, i, i, i, f, vp, ip, vp]),
@@ -45,9 +49,6 @@ SIGNATURES = {
     "step_conv_forward_ws": (i, [C.POINTER(ConvDesc), vp, vp, fp, fp, vp, vp, vp, vp, sz, vp]),
     "step_conv_kernel_name": (i, [C.POINTER(ConvDesc), C.c_char_p, i]),
     "step_conv_plan_info": (i, [C.POINTER(ConvDesc), C.POINTER(C.c_int), i]),
-    "step_pool3_conv1_forward": (i, [C.POINTER(ConvDesc), vp, vp, fp, fp, vp, vp]),
-    "step_pool133s2_conv1_forward": (i, [C.POINTER(ConvDesc), i, i, vp, vp, fp, fp, vp, vp]),
-    "step_pool3_conv1_kernel_name": (i, [C.POINTER(ConvDesc), C.c_char_p, i]),
     "step_stem_packed_elems": (sz, [i]),
     "step_stem_pack_weight": (i, [fp, i, i, vp, vp]),
     "step_stem_forward": (i, [i, vp, i, i, i, i, vp, fp, fp, i, vp, i, i, vp]),
@@ -87,3 +88,38 @@ def check(status, what):
     if status != 0:
         msg = _ERR.get(status, "hipError_t %d" % status) if status < 0 else "hipError_t %d" % status
         raise RuntimeError("%s failed: %s" % (what, msg))
+
+
+# ---- planner options (include/step_amd.h: step_set_option) -----------------------------------------------------------
+OPTION_IDS = {name: k for k, name in enumerate((
+    "conv_impl", "conv_nb", "conv_waves", "conv_phased", "conv_gen", "conv_gmode", "conv_pws", "conv_splitk", "conv_tail",
+    "conv_slots", "pool_direct", "wgrad_minpix", "wgrad16_lds", "conv_desync"))}
+
+
+def set_option(lib, name, value):
+    check(lib.step_set_option(OPTION_IDS[name], int(value)), "step_set_option(%s, %r)" % (name, value))
+
+
+def get_option(lib, name):
+    v = C.c_int()
+    check(lib.step_get_option(OPTION_IDS[name], C.byref(v)), "step_get_option(%s)" % name)
+    return v.value
+
+
+class options:
+    """Context manager: `with options(lib, conv_waves=4, conv_nb=2): ...` sets planner options and restores the previous
+    values on exit (tests and tools/ab_bench.py; the product never changes an option)."""
+
+    def __init__(self, lib, **kw):
+        self.lib, self.kw = lib, kw
+
+    def __enter__(self):
+        self.prev = {k: get_option(self.lib, k) for k in self.kw}
+        for k, v in self.kw.items():
+            set_option(self.lib, k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            set_option(self.lib, k, v)
+        return False

@@ -158,7 +158,7 @@ class _ConvUnitFn(torch.autograd.Function):
         return gx, gw, gscale, gshift, gres, None, None
 
 
-BATCH_PACK = os.environ.get("STEP_BATCH_PACK", "1") != "0"
+BATCH_PACK = True        # one-launch re-pack of every stale weight image (False: each unit packs its own; module switch for tests)
 _UNITS = weakref.WeakSet()     # every live ConvUnit: an optimizer step stales all their packed images at once
 _TABLES = {}                   # (dtype, device) -> (signature, device table, [(unit, cache key)]) of the last batched re-pack
 
@@ -199,14 +199,11 @@ def _repack_all(dtype, device):
         return True
     order = sorted(range(len(entries)), key=lambda i: (entries[i][0], entries[i][8], entries[i][9], entries[i][2]))   # (the set's own order is not stable)
     entries, owners = [entries[i] for i in order], [owners[i] for i in order]
-    sig = tuple(e[:3] for e in entries)
+    sig = tuple(entries)      # the FULL descriptors: the caching allocator can hand the same three addresses to differently shaped weights of a rebuilt net
     cached = _TABLES.get((dtype, device))
     if cached is None or cached[0] != sig:
         if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
             return False                                         # (a new table is a host -> device copy: not inside a graph capture)
-        if os.environ.get("STEP_PACK_DEBUG"):
-            old = set(cached[0]) if cached else set()
-            print("step_amd: pack table rebuilt (%s): %d items, %d new, %d gone" % (dtype, len(sig), len(set(sig) - old), len(old - set(sig))), flush=True)
         cached = _TABLES[(dtype, device)] = (sig, ops.pack_table(entries, device))
     with torch.no_grad():
         ops.pack_conv_weights(cached[1], len(entries), dtype, device)
@@ -543,7 +540,7 @@ class Mixed(nn.Module):
         if BRANCH_STREAMS == 1:
             s1 = s2                                        # tuning aid: both side branches on ONE side stream (one fork, one join)
         s2.wait_stream(main)
-        with torch.cuda.stream(s2):                        # branch_3: pool -> 1x1x1 (one fused launch)
+        with torch.cuda.stream(s2):                        # branch_3: pool -> 1x1x1
             p = self._branch_3(x, out[..., c2:])
         self._fused(x, out[..., :c0], t)                   # main: fused 1x1x1 convs
         s1.wait_stream(main)
@@ -558,23 +555,17 @@ class Mixed(nn.Module):
         return out
 
     def _branch_3(self, x, out):
-        """max pool 3x3x3 / 1 -> 1x1x1 unit into `out` (inference path).  One launch (step_pool3_conv1_forward: the pooled
-        tensor never reaches memory); returns the pooled scratch tensor when the two-launch form had to be used, else None."""
+        """max pool 3x3x3 / 1 -> 1x1x1 unit into `out` (inference path): two launches; returns the pooled scratch tensor.
+        (One fused launch -- the pooled tensor never reaching memory -- was built twice and measured SLOWER both times: the seven
+        branch_3 layers of a C2 step 193 us as two launches, 350 / 328 us fused; the per-slab pool pass, up to 54 dependent LDS
+        reads per thread between two barriers, costs more than the saved traffic.  Removed in round 3)"""
         pool, unit = self.branch_3[0], self.branch_3[1]
-        fuse = FUSE_POOL_CONV == "1"
-        if fuse and pool.kernel_size == (3, 3, 3) and pool.stride == (1, 1, 1):
-            cu = unit._unit
-            scale, shift = cu.affine()
-            if shift is not None:
-                shift = shift.detach().contiguous()
-            if ops.pool3_conv1_forward(x, cu.packed(x.dtype), cu.cout, scale, shift, unit.relu, out) is not None:
-                return None
         p = pool(x)
         unit(p, out=out)
         return p
 
 
-WGRAD16 = os.environ.get("STEP_WGRAD16", "1") != "0"   # 16-bit activations: weight gradients on the 16-bit MFMA (step_conv_wgrad16)
+WGRAD16 = True           # 16-bit activations: weight gradients on the 16-bit MFMA (step_conv_wgrad16)
 WGRAD_INTO_GRAD = False        # see wgrad_into_grad()
 GRAD_READY = None              # step_amd.dist.BucketedReducer.ready while a backward pass is being overlapped with the exchange
 _PENDING = [False]
@@ -620,17 +611,8 @@ def wgrad_sync():
     del _KEEP[:]
 
 
-# Pool -> 1x1x1 unit pairs as one launch (step_pool3_conv1_forward for an Inception block's branch_3,
-# step_pool133s2_conv1_forward for maxPool3d_2a -> conv3d_2b): bit-identical to the two launches and 0.5 GB less traffic per
-# C2 step, but measured SLOWER on MI355X in both versions of the kernel (tools/ab_bench.py --set b3, bf16, us per step over the
-# seven branch_3 layers: two launches 193, fused with one slab of prefetch 350, with a three-slab register ring 328; C2
-# 5450 clips/s unfused, 5385 with the 28x28 layers fused, 4960 with everything fused).  The per-slab pool pass (up to 54
-# dependent LDS reads per thread between two barriers) is the cost, not the halo latency the ring was built to hide.
-# Opt-in: STEP_FUSE_POOL_CONV=1.
-FUSE_POOL_CONV = os.environ.get("STEP_FUSE_POOL_CONV", "0")
-FUSE_POOL_CONV_MIN_PIXELS = 0
-BRANCH_STREAMS = int(os.environ.get("STEP_BRANCH_STREAMS", "1"))   # Inception side branches (inference path): on 1 side stream (default; C2 5345 -> 5430 clips/s against 2: one fork / join per block), 2, or 0 = off (5240)
-WGRAD_SIDE_STREAM = os.environ.get("STEP_WGRAD_STREAM", "1") != "0"   # training: weight gradient beside the data gradient
+BRANCH_STREAMS = 1       # Inception side branches (inference path): on 1 side stream (default; C2 5345 -> 5430 clips/s against 2: one fork / join per block), 2, or 0 = off (5240)
+WGRAD_SIDE_STREAM = True # training: weight gradient beside the data gradient
 _SIDE = {}
 
 
@@ -799,27 +781,8 @@ class BaseNet(nn.Module):
         if x.dim() != 5 or x.shape[2] != 3:
             raise RuntimeError("BaseNet expects [batch, T, 3, H, W]")
         y = x.contiguous()
-        stages = list(self.base_model)
-        i = 0
-        while i < len(stages):
-            st = stages[i]
-            nxt = stages[i + 1] if i + 1 < len(stages) else None
-            # (measured: C2 5397 / 5418 clips/s fused against 5402 / 5396 unfused: opt-in, see FUSE_POOL_CONV)
-            if (FUSE_POOL_CONV == "1" and isinstance(st, MaxPoolTF) and st.kernel_size == (1, 3, 3) and st.stride == (1, 2, 2)
-                    and isinstance(nxt, Unit3D) and nxt.kernel_size == (1, 1, 1) and not nxt.is_stem
-                    and not (torch.is_grad_enabled() and (y.requires_grad or any(p.requires_grad for p in nxt.parameters())))):
-                # maxPool3d_2a_3x3 -> conv3d_2b_1x1 as one launch (inference path): the pooled tensor never reaches memory
-                cu = nxt._unit
-                scale, shift = cu.affine()
-                if shift is not None:
-                    shift = shift.detach().contiguous()
-                z = ops.pool133s2_conv1_forward(y, cu.packed(y.dtype), cu.cout, scale, shift, nxt.relu)
-                if z is not None:
-                    y = z
-                    i += 2
-                    continue
+        for st in self.base_model:
             y = st(y)
-            i += 1
         return y.permute(0, 1, 4, 2, 3)
 
     def train(self, mode=True):

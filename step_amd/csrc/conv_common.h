@@ -2,6 +2,7 @@
 // conv_wgrad.hip, stem.hip): kernel parameter blocks, the XCD-aware grid remap, LDS / fragment helpers, the launch
 // plan and the cross-unit launch entry points.
 #pragma once
+#include "options.h"
 #include "common.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -21,7 +22,6 @@ struct ConvParams {
     const void* x; const void* w; const float* scale; const float* shift; const void* res; void* y; void* y2;
     int split, y2_cstride, y2_coff;
     int N, D, H, W, Cin, Cout;
-    int Hi, Wi;    // input extent where it differs from the output's (the strided-pool form of pool_pw_kernel); else unused
     int x_cstride, x_coff, y_cstride, y_coff, r_cstride, r_coff;
     int relu;
     int tiles_h, tiles_w, tiles_d;
@@ -29,6 +29,8 @@ struct ConvParams {
     int gmode;           // general box: 0 = accumulator rows walk the box linearly, 1 = every 16-lane LDS read group is one run of 16 columns of one box row
     int gx, gy;          // logical grid: gx pixel tiles x gy channel groups (launched as a 1-D grid, see grid_coords)
     int tile0;           // conv_tap_kernel: first pixel tile of this launch (a layer may be launched in two parts, see conv_forward_t)
+    int desync;          // conv_tap_kernel: > 0: workgroups of the first round (blockIdx.x < desync_first) sleep hash(blockIdx.x) % desync x 64 clocks first
+    int desync_first;
     int nchunks;   // ceil(Cin / 32)
     int nchunks32; // same (the packed-weight K extent is 2*nchunks32 k16 blocks)
     int vec_epi;   // 16-byte output stores are legal (channel strides/offsets % 8 == 0, pointers 16-B aligned)
@@ -145,13 +147,8 @@ static inline unsigned flat_grid(long long total, int block) {
 
 struct ConvPlan { bool ok, flat, wide, deep; int impl, NB, tps, mb, wv, ph, twl, tiles_h, tiles_w, tiles_d, gtd, gth, gtw, gmode, ksplit, kchunk16, mbk, mpad, cpad; long long mtiles; };
 
-static inline int conv_impl_override() {   // tuning aid: STEP_CONV_IMPL=igemm|tap|tap2 forces one implementation
-    const char* e = getenv("STEP_CONV_IMPL");
-    if (!e) return -1;
-    if (e[0] == 'i') return 0;
-    if (e[0] == 'p') return 5;      // pw: force the streaming pointwise GEMM for every 1x1x1 conv
-    if (e[0] == 't') return (e[1] && e[2] && e[3] == '2') ? 2 : ((e[1] && e[2] && e[3] == '4') ? 4 : 1);
-    return -1;
+static inline int conv_impl_override() {   // STEP_OPT_CONV_IMPL: -1 auto, 0 tiled, 1 conv_tap (one tap per step), 2 conv_tap, 5 streaming pointwise
+    return opt(STEP_OPT_CONV_IMPL);
 }
 
 // launchers defined in the other translation units (explicitly instantiated for float, bf16_t, f16_t)

@@ -358,10 +358,8 @@ static int pick_nb(int nblk32, long long mtiles) {
 
 
 static int pick_nb_tap(int nblk32, long long mtiles, int slots = 256) {
-    const int forced = getenv("STEP_CONV_NB") ? atoi(getenv("STEP_CONV_NB")) : 0;     // tuning aid / tests (read per call)
+    const int forced = opt(STEP_OPT_CONV_NB);             // tests / A-B timing
     if (forced >= 1 && forced <= 3) return forced;
-    const int small = getenv("STEP_CONV_NB_SMALL") ? atoi(getenv("STEP_CONV_NB_SMALL")) : 0;  // tuning aid: depth for few-tile layers
-    if (small >= 1 && small <= 3 && mtiles <= 64) return small > (nblk32 + 1) / 2 ? (nblk32 + 1) / 2 : small;
     int best = 1;
     double best_cost = -1;
     for (int nb = 3; nb >= 1; --nb) {   // 2 fragment sets + 2*nb accumulators must fit 256 VGPRs: nb <= 3
@@ -430,10 +428,9 @@ static bool prefer_four_waves_pw(const step_conv_desc* d, long long wgs8) {
 
 // general boxes: may every 16-lane LDS read group be one run of 16 columns of one box row (conv_tap_kernel.h, p.gmode)?  Only for
 // widths just below a multiple of 16 (the padded lanes cost no more than the linear packing leaves unused) and when the box rows
-// fit the tile's 16-lane slots.  STEP_CONV_GMODE=0 keeps the linear walk (tuning aid / tests, read per call).
+// fit the tile's 16-lane slots.  STEP_OPT_CONV_GMODE = 0 keeps the linear walk (tests / A-B timing).
 static int gen_gmode(int td, int th, int tw, int tile_px) {
-    const char* e = getenv("STEP_CONV_GMODE");
-    if (e && atoi(e) == 0) return 0;
+    if (opt(STEP_OPT_CONV_GMODE) == 0) return 0;
     const int spr = (tw + 15) / 16;
     if ((tw & 15) < 12) return 0;
     return td * th * spr <= tile_px / 16 ? 1 : 0;
@@ -450,13 +447,13 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true) {
     if (k1) {
         pl.mtiles = ceil_div64((long long)d->N * d->D * d->H * d->W, 128);
         pl.NB = pick_nb(nblk32, pl.mtiles);
-        // deep-K pointwise convs on enough pixels: the streaming 8-wave GEMM (STEP_CONV_IMPL=igemm forces the other)
+        // deep-K pointwise convs on enough pixels: the streaming 8-wave GEMM (STEP_OPT_CONV_IMPL = 0 forces the other)
         const long long mt256 = ceil_div64((long long)d->N * d->D * d->H * d->W, 256);
         const int ov1 = conv_impl_override();
         {
             // the weight-stationary stream (conv_pws_kernel): 16-bit, 16-byte channel vectors, the weights of a channel group
-            // (NB blocks x K) within 104 KiB of LDS.  STEP_CONV_PWS: 1 = wherever the contract allows, 0 = never.
-            const int pws_env = getenv("STEP_CONV_PWS") ? atoi(getenv("STEP_CONV_PWS")) : -1;     // (read per call: the tests switch it)
+            // (NB blocks x K) within 104 KiB of LDS.  STEP_OPT_CONV_PWS: 1 = wherever the contract allows, 0 = never.
+            const int pws_env = opt(STEP_OPT_CONV_PWS);
             const int KC16 = ceil_div(d->Cin, CK) * 2;
             const long long M = (long long)d->N * d->D * d->H * d->W;
             const bool can = d->dtype != STEP_F32 && (d->Cin % 8) == 0 && (d->x_cstride % 8) == 0 && (d->x_coff % 8) == 0 && KC16 <= 16 &&
@@ -474,8 +471,7 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true) {
                 pl.impl = 4;
                 pl.NB = ceil_div(nblk32, groups);                         // channel blocks per workgroup (balanced groups)
                 pl.wv = 8;
-                static const int pws_gx = getenv("STEP_PWS_GX") ? atoi(getenv("STEP_PWS_GX")) : 256;      // tuning aid
-                long long gx = pws_gx / groups;                            // one workgroup per CU
+                long long gx = 256 / groups;                               // one workgroup per CU
                 if (gx < 1) gx = 1;
                 const long long need = ceil_div64(ceil_div64(M, 32), 8);
                 if (gx > need) gx = need;
@@ -485,7 +481,7 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true) {
         }
         if (ov1 == 5 || (ov1 != 0 && d->Cin >= 128 && d->Cout >= 64 && mt256 * ceil_div(nblk32, 2) >= 32)) {
             pl.impl = 2;
-            const int waves_env = getenv("STEP_CONV_WAVES") ? atoi(getenv("STEP_CONV_WAVES")) : 0;      // tuning aid / tests: 4 | 8
+            const int waves_env = opt(STEP_OPT_CONV_WAVES);      // tests / A-B timing: 4 | 8
             const long long wgs8 = mt256 * ceil_div(nblk32, 2 * pick_nb_tap(nblk32, mt256));
             const bool four = waves_env == 4 || (waves_env != 8 && prefer_four_waves_pw(d, wgs8));
             pl.wv = four ? 4 : 8;
@@ -494,8 +490,8 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true) {
             return pl;
         }
         // few rows x very deep K (the heads' Linear layers): split K over the chip (needs the workspace of
-        // step_conv_forward_ws; STEP_CONV_SPLITK=0 disables)
-        static const bool splitk_ok = !(getenv("STEP_CONV_SPLITK") && atoi(getenv("STEP_CONV_SPLITK")) == 0);
+        // step_conv_forward_ws; STEP_OPT_CONV_SPLITK = 0 disables)
+        const bool splitk_ok = opt(STEP_OPT_CONV_SPLITK) != 0;
         const long long M = (long long)d->N * d->D * d->H * d->W;
         if (splitk_ok && ov1 != 0 && d->Cin >= 2048 && (d->Cin % 8) == 0 && M <= 1024 && pl.mtiles * nblk32 < 64) {
             pl.impl = 3;
@@ -515,7 +511,6 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true) {
             return pl;
         }
         pl.deep = d->Cin >= 256;        // 128-channel slabs: 4x fewer barriers along a deep K
-        if (const char* e = getenv("STEP_CONV_DEEP")) pl.deep = (e[0] == '1');   // tuning aid
         return pl;
     }
     if (!k333 && !k133) { pl.ok = false; pl.mtiles = 0; pl.NB = 1; return pl; }
@@ -532,9 +527,9 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true) {
     // a general box when it needs at least 7 % fewer tiles than the best power-of-two shape (its staging index
     // arithmetic divides and its LDS reads are not conflict-free, ~5 % per tile).  Measured: C2 (28x28 / 14x14 maps,
     // 12.5 % fewer tiles) +1.2 % clips/s, the 400x400 backbone (50x50 / 25x25 / 100x100 maps, 28 % fewer tiles) +9 %.
-    // STEP_CONV_GEN=<percent> moves the threshold, 0 disables the general boxes.
+    // STEP_OPT_CONV_GEN = <percent> moves the threshold, 0 disables the general boxes.
     int gtd = 1, gth = 1, gtw = 1;
-    static const int gen_pct = getenv("STEP_CONV_GEN") ? atoi(getenv("STEP_CONV_GEN")) : 93;    // 0 disables
+    const int gen_pct = opt(STEP_OPT_CONV_GEN);
     const int twl_p2 = twl;
     const long long tbest_p2 = tbest;
     if (gen_pct > 0) {
@@ -553,7 +548,7 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true) {
     }
     const long long mt256 = (long long)d->N * tbest;
     // ---- the four-wave form (128-pixel tiles, two resident workgroups per CU; conv_tap_kernel.h): its own tile search
-    const int waves_env = getenv("STEP_CONV_WAVES") ? atoi(getenv("STEP_CONV_WAVES")) : 0;      // tuning aid / tests: 4 | 8 (read per call)
+    const int waves_env = opt(STEP_OPT_CONV_WAVES);      // tests / A-B timing: 4 | 8
     ConvPlan p4 = pl;
     bool have4 = false;
     {
@@ -601,7 +596,7 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true) {
     const bool use_tap = fits32 && (ov >= 1 || (ov != 0 && (d->Cin >= 64 || mt256 >= 32)));
     if (use_tap) {
         pl.impl = 1;
-        pl.tps = (ov == 1) ? 1 : 2;     // two taps per barrier measured 6-15 % faster than one (STEP_CONV_IMPL=tap forces one)
+        pl.tps = (ov == 1) ? 1 : 2;     // two taps per barrier measured 6-15 % faster than one (STEP_OPT_CONV_IMPL = 1 forces one)
         pl.mb = 2;                      // (the 4-wave MB = 4 form of the kernel template spills at NB >= 2 and is not instantiated)
         pl.twl = twl;
         pl.wide = twl == 5;
@@ -620,8 +615,7 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true) {
         // (measured on MI355X, C2 layers, interleaved A/B, profiles/r02_ab_phased.txt: every 3x3x3 layer faster, 829 -> 704 us
         // per step in total; conv3d_2c 299 -> 259 us, the 14x14 branch_1 layers -19...-23 %)
         if (d->dtype != STEP_F32 && pl.tps == 2 && k333) {
-            const char* e = getenv("STEP_CONV_PHASED");             // tuning aid / tests: 0 = the classic form (read per call)
-            pl.ph = (e && atoi(e) == 0) ? 0 : 1;
+            pl.ph = opt(STEP_OPT_CONV_PHASED) ? 1 : 0;            // tests / A-B timing: 0 = the classic form
         }
         if (have4 && ov != 1 && (waves_env == 4 || (waves_env != 8 && prefer_four_waves(pl, p4, d)))) return p4;
         return pl;
@@ -671,11 +665,11 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_
         // The last, partial round of one-workgroup-per-CU tiles: conv3d_2c at C2 is 1568 tiles = 6.125 rounds of 256, i.e. a
         // seventh round that keeps 32 CUs busy and 224 idle for a full tile time (12 % of the launch).  When the layer is ONE
         // channel group deep (NB > 1) those tail tiles are launched separately with NB = 1 -- NB times as many, shorter
-        // workgroups spread over the idle CUs.  Same pixels, same K order per output: bit-identical.  (STEP_CONV_TAIL=0: one launch.)
+        // workgroups spread over the idle CUs.  Same pixels, same K order per output: bit-identical.  (STEP_OPT_CONV_TAIL = 0: one launch.)
         const int groups = ceil_div(p.nblk32, 2 * pl.NB);
-        const long long slots = getenv("STEP_CONV_SLOTS") ? atoi(getenv("STEP_CONV_SLOTS")) : 256;     // (test aid: the split at interpreter sizes; read per call)
+        const long long slots = opt(STEP_OPT_CONV_SLOTS) > 0 ? opt(STEP_OPT_CONV_SLOTS) : 256;     // (tests: the split at interpreter sizes)
         const long long tail = pl.mtiles % slots;
-        const bool tail_ok = !(getenv("STEP_CONV_TAIL") && atoi(getenv("STEP_CONV_TAIL")) == 0);
+        const bool tail_ok = opt(STEP_OPT_CONV_TAIL) != 0;
         const int tgroups = ceil_div(p.nblk32, 2);
         const bool box_ok = pl.twl != 0 || (pl.gtd + d->kd - 1) * (pl.gth + d->kh - 1) * (pl.gtw + d->kw - 1) <= conv_gen_npix(8, 1);   // (the NB = 1 kernel reserves a smaller general-box halo)
         if (tail_ok && box_ok && pl.wv == 8 && groups == 1 && pl.NB > 1 && pl.mtiles > slots && tail > 0 && tail * 4 <= slots && tail * tgroups <= slots) {
@@ -804,6 +798,7 @@ int step_conv_forward_ws(const step_conv_desc* d, const void* x, const void* w_p
     p.r_cstride = d->res_cstride; p.r_coff = d->res_coff;
     p.relu = d->relu;
     p.tiles_h = p.tiles_w = 0; p.tiles_d = d->D; p.gtd = p.gth = p.gtw = 1; p.gmode = 0; p.gx = p.gy = 0; p.tile0 = 0;
+    p.desync = opt(STEP_OPT_CONV_DESYNC); p.desync_first = 256;
     p.nchunks = ceil_div(d->Cin, CK);
     p.nchunks32 = p.nchunks;
     p.vec_epi = (d->y_cstride % 8 == 0) && (d->y_coff % 8 == 0) && (d->Cout % 8 == 0) && (((uintptr_t)y) % 16 == 0) &&
@@ -856,7 +851,7 @@ int step_conv_plan_info(const step_conv_desc* d, int* info, int n) {
 }
 
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 18; }
+int step_abi_version(void) { return 19; }
 
 }  // extern "C"
 

@@ -165,6 +165,15 @@ void conv_tap_kernel(ConvParams p) {
 
     int gbx, gby;
     if (!grid_coords(p, gbx, gby)) return;
+#ifndef STEP_EMUL
+    // STEP_OPT_CONV_DESYNC: every tile of a layer takes the same time, so the CUs (one workgroup each) run in lock-step and all of them
+    // reach their epilogue -- a burst of output stores nothing else overlaps -- at the same moment, round after round.  Starting
+    // the first round's workgroups a pseudo-random few microseconds apart de-phases the CUs for the whole launch.
+    if (p.desync > 0 && blockIdx.x < (unsigned)p.desync_first) {
+        const unsigned nsleep = ((blockIdx.x * 2654435761u) >> 12) % (unsigned)p.desync;
+        for (unsigned i = 0; i < nsleep; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+#endif
     int t = gbx + p.tile0;
     const int tw_i = t % p.tiles_w; t /= p.tiles_w;
     const int th_i = t % p.tiles_h; t /= p.tiles_h;

@@ -123,116 +123,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
             }
 }
 
-// conv_wgrad16_row_kernel -- the 16-bit-MFMA weight gradient for kw = 3 windows (3x3x3 and 1x3x3).  The per-tap form
-// above is bound by its LOAD instructions once the matrix work is 16x cheaper (8 two-byte loads per fragment: 8 loads per
-// MFMA); here a wavefront job owns a whole ROW of taps (kd, kh, kw = 0..2) of its (co, ci) tile:
-//   * the dY fragments of a 16-pixel step are loaded once and used by the three taps;
-//   * per input-channel block the lane loads the TEN consecutive pixels w-1 .. w+8 of its channel once; the three shifted
-//     fragments are re-pairings of those ten values in registers (taps kw = 0 and 2 share the even pairing, kw = 1 takes
-//     one byte-align per pair)
-// -- 3 loads per MFMA instead of 8, and a third of the jobs / atomics passes per tile.  Accumulators: 3 taps x MB x NB tiles.
-template <typename T, int MB, int NB>
-__global__ __launch_bounds__(256) void conv_wgrad16_row_kernel(WgradParams p) {
-    static_assert(sizeof(T) == 2, "16-bit storage");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, khalf = lane >> 5;
-    const long long job = (long long)blockIdx.x * 4 + wave;
-    if (job >= p.jobs) return;                               // wave-uniform; the kernel has no barrier
-    int t = blockIdx.y;
-    const int cit_i = t % p.cit; t /= p.cit;
-    const int cot_i = t % p.cot;
-    const int krow = t / p.cot;                              // (kd, kh)
-    const int ntaps = p.kd * p.kh * 3;
-    const int kh_ = krow % p.kh, kd_ = krow / p.kh;
-    const int co0 = cot_i * 32 * MB, ci0 = cit_i * 32 * NB;
-    int coc[MB], cic[NB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) { const int c = co0 + mb * 32 + m; coc[mb] = c < p.Cout ? c : p.Cout - 1; }
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) { const int c = ci0 + nb * 32 + m; cic[nb] = c < p.Cin ? c : p.Cin - 1; }
-
-    f32x16 acc[3][MB][NB];
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[s][mb][nb][r] = 0.f;
-
-    const long long r_end = min((job + 1) * (long long)p.rows, p.total_rows);
-    for (long long rr = job * (long long)p.rows; rr < r_end; ++rr) {
-        const int h = (int)(rr % p.H);
-        const long long plane = rr / p.H;
-        const int n = (int)(plane / p.D), d = (int)(plane % p.D);
-        const int id = d + kd_ - p.kd / 2, ih = h + kh_ - p.kh / 2;
-        if (id < 0 || id >= p.D || ih < 0 || ih >= p.H) continue;        // this row of taps sees only zero padding from this row
-        const T* dyrow = (const T*)p.dy + ((((size_t)n * p.D + d) * p.H + h) * p.W) * p.dy_cstride + p.dy_coff;
-        const T* xrow = (const T*)p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W) * p.x_cstride + p.x_coff;
-        for (int w0 = 0; w0 < p.W; w0 += 16) {
-            const int wl = w0 + 8 * khalf;                   // this lane's first pixel
-            u16x8 a[MB];
-            unsigned short xv[NB][10];                       // pixels wl-1 .. wl+8 of the lane's input channel
-            if (w0 >= 1 && w0 + 17 <= p.W) {                 // interior step (wave-uniform): plain loads
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) a[mb][j] = dyrow[(size_t)(wl + j) * p.dy_cstride + coc[mb]].v;
-#pragma unroll
-                for (int j = 0; j < 10; ++j)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) xv[nb][j] = xrow[(size_t)(wl - 1 + j) * p.x_cstride + cic[nb]].v;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int w = wl + j;
-                    const bool ok = w < p.W;
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
-                        const unsigned short v = dyrow[(size_t)(ok ? w : p.W - 1) * p.dy_cstride + coc[mb]].v;
-                        a[mb][j] = ok ? v : (unsigned short)0;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 10; ++j) {
-                    const int iw = wl - 1 + j;
-                    const bool ok = iw >= 0 && iw < p.W;
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        const unsigned short v = xrow[(size_t)(ok ? iw : 0) * p.x_cstride + cic[nb]].v;
-                        xv[nb][j] = ok ? v : (unsigned short)0;
-                    }
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 3; ++s)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    u16x8 b;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) b[j] = xv[nb][j + s];         // x[w + s - 1]: tap kw = s
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) mma_k16(a[mb], b, acc[s][mb][nb], T());
-                }
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const int tap = (kd_ * p.kh + kh_) * 3 + s;
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + mb * 32 + cd_row(r, lane), ci = ci0 + nb * 32 + (lane & 31);
-                    if (co < p.Cout && ci < p.Cin) atomicAdd(p.dw + ((size_t)co * p.Cin + ci) * ntaps + tap, acc[s][mb][nb][r]);
-                }
-    }
-}
 
 // conv_wgrad16_lds_kernel -- the 16-bit weight gradient as a tiled GEMM (kw = 3 windows: 3x3x3 and 1x3x3).
-// The two forms above load every MFMA operand element with its own 2- or 4-byte load and are bound by that (20-130 TFLOP/s).
+// The form above loads every MFMA operand element with its own 2- or 4-byte load and is bound by that (20-130 TFLOP/s).
 // Here a 384-thread workgroup stages, per chunk of output rows, the dY tile [P pixels][64 co] and the X halo tile
 // [(R+2) x (W+2) pixels][64 ci] of one input plane into LDS in their NATURAL pixel-major layout (16-byte vectors, pitch 144 B)
 // and reads the MFMA operands with ds_read_b64_tr_b16: the hardware transpose hands every lane the 8 consecutive pixels (k)
@@ -255,7 +148,6 @@ struct Wgrad16Params {
     long long units;
     float* ws;                    // partial tiles [gridDim.x][gridDim.y][6 waves][24 tiles][64 lanes][4] (NULL: fp32 atomics on dw)
     unsigned wmagic, wmagic2;     // floor(k / W) = (k * wmagic) >> 22, floor(k / (W + 2)) = (k * wmagic2) >> 22 for k < 512
-    int noremap;                  // tuning aid: keep the plain launch order
 };
 
 // KW = 1 (pointwise convs / Linear layers): no halo; the unit is a chunk of 128 consecutive pixels of the flattened N*D*H*W
@@ -285,7 +177,7 @@ __global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) 
     // conv3d_2c).  Remap so that the groups of one unit are consecutive on ONE XCD (ids go round-robin over the 8 XCDs) and the
     // second to last of them hit its L2.
     int bx = blockIdx.x, by = blockIdx.y;
-    if ((gridDim.x & 7) == 0 && !p.noremap) {
+    if ((gridDim.x & 7) == 0) {
         const long long L = (long long)blockIdx.x + (long long)gridDim.x * blockIdx.y;
         const int xcd = (int)(L & 7);
         const long long slot = L >> 3;
@@ -793,8 +685,7 @@ extern "C" {
 // the head layers on 7x7 maps ran at 0.3-4 TFLOP/s with the fixed ~6000-job split.  Swept on the C4 step (143 wgrad
 // launches, ms in total): 16 px -> 37.4, 128 -> 24.0, 256 -> 21.5, 512 -> 22.1, 720 -> 22.7, 1440 -> 28.0, 5760 -> 43.5.
 static int wgrad_min_pixels() {
-    const char* e = getenv("STEP_WGRAD_MINPIX");               // read per call (tests exercise both regimes in one process)
-    const int x = e ? atoi(e) : 0;
+    const int x = opt(STEP_OPT_WGRAD_MINPIX);                  // (tests exercise both regimes in one process)
     return x > 0 ? (x + 15) / 16 * 16 : 512;
 }
 
@@ -807,7 +698,7 @@ static Wg16Plan wgrad16_plan(const step_conv_desc* d) {
     pl.pw = pw;
     if (!pw && !(d->kh == 3 && d->kw == 3 && (d->kd == 1 || d->kd == 3))) return pl;
     if (d->Cin % 8 || d->Cout % 8 || d->x_cstride % 8 || d->x_coff % 8 || d->y_cstride % 8 || d->y_coff % 8) return pl;
-    if (getenv("STEP_WGRAD16_LDS") && atoi(getenv("STEP_WGRAD16_LDS")) == 0) return pl;
+    if (opt(STEP_OPT_WGRAD16_LDS) == 0) return pl;
     if (d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0) return pl;
     if (pw) {
         const long long M = (long long)d->N * d->D * d->H * d->W;
@@ -830,7 +721,7 @@ static Wg16Plan wgrad16_plan(const step_conv_desc* d) {
         pl.gy = (long long)d->kd * pl.cot * pl.cit;
     }
     // ~512 workgroups per launch; each walks several (plane, chunk) units (the next one's loads under this one's matrix work)
-    static const int wg_total = getenv("STEP_WGRAD16_WGS") ? atoi(getenv("STEP_WGRAD16_WGS")) : 512;      // tuning aid
+    constexpr int wg_total = 512;
     long long want = wg_total / (pl.gy > 0 ? pl.gy : 1);
     if (want < 1) want = 1;
     long long upj = ceil_div64(pl.units, want);
@@ -872,7 +763,6 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
             q.x_cstride = d->x_cstride; q.x_coff = d->x_coff; q.dy_cstride = d->y_cstride; q.dy_coff = d->y_coff;
             q.cot = pl.cot; q.cit = pl.cit; q.cpp = pl.cpp; q.rows = pl.rows; q.units = pl.units; q.upj = pl.upj;
             q.wmagic = (unsigned)(((1u << 22) + d->W - 1) / d->W);
-            { static const int nr = getenv("STEP_WGRAD16_NOREMAP") ? atoi(getenv("STEP_WGRAD16_NOREMAP")) : 0; q.noremap = nr; }
             q.wmagic2 = (unsigned)(((1u << 22) + d->W + 1) / (d->W + 2));
             const size_t need = (size_t)pl.gx * pl.gy * 6 * (pl.pw ? 8 : 24) * 64 * 16;
             q.ws = (ws && ws_bytes >= need && ((uintptr_t)ws % 16) == 0) ? (float*)ws : nullptr;
@@ -897,7 +787,7 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
         const long long M = (long long)d->N * d->D * d->H * d->W;
         if (M > 0x7fffffffLL) return STEP_E_UNSUPPORTED;
         // pixels per wavefront job: ~6000 jobs per launch (see below), a multiple of the 16-pixel MFMA step
-        static const int wg_jobs_pw = getenv("STEP_WGRAD_JOBS") ? atoi(getenv("STEP_WGRAD_JOBS")) : 6144;
+        constexpr int wg_jobs_pw = 6144;
         const long long tiles = (long long)ceil_div(d->Cout, 64) * ceil_div(d->Cin, d->Cin <= 32 ? 32 : 64);
         long long want = wg_jobs_pw / (tiles > 0 ? tiles : 1);
         if (want < 1) want = 1;
@@ -933,14 +823,14 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
     }
     const bool narrow = d->Cin <= 32;
     p.cot = ceil_div(d->Cout, 64); p.cit = ceil_div(d->Cin, narrow ? 32 : 64);
-    // (the tap-row form measured 1.3-2.6x SLOWER than the per-tap form -- 424 VGPRs, one wave per SIMD: kept for reference, off)
-    const bool rowform = w16 && d->kw == 3 && getenv("STEP_WGRAD16_ROW") && atoi(getenv("STEP_WGRAD16_ROW")) == 1;
-    const long long gy = (long long)(rowform ? ntaps / 3 : ntaps) * p.cot * p.cit;
+    // (a tap-row form -- a job owns a row of three kw taps and re-pairs ten loaded pixels in registers -- measured 1.3-2.6x SLOWER
+    // than this per-tap form: 424 VGPRs, one wave per SIMD; removed)
+    const long long gy = (long long)ntaps * p.cot * p.cit;
     // (n, d, h) rows per wavefront job.  Two opposite pressures (PMC): the kernel hides its load latency only with
     // several wavefronts per SIMD (1.6 per SIMD -> matrix pipe 18 % busy), but every job ends in one set of fp32
     // atomics (a 64x64 tile = 4096 of them; the 14x14 layers spent their time in 81 M atomics with one job per
     // plane).  Aim at ~6000 wavefront jobs per launch, whatever the map size.
-    static const int wg_jobs = getenv("STEP_WGRAD_JOBS") ? atoi(getenv("STEP_WGRAD_JOBS")) : 6144;
+    constexpr int wg_jobs = 6144;
     p.total_rows = (long long)d->N * d->D * d->H;
     {
         long long want = wg_jobs / (gy > 0 ? gy : 1);
@@ -956,13 +846,6 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
     p.jobs = ceil_div64(p.total_rows, p.rows);
     if (gy > 65535) return STEP_E_UNSUPPORTED;
     dim3 grid((unsigned)ceil_div64(p.jobs, 4), (unsigned)gy);
-    if (rowform) {
-#define STEP_WGROW(T_) do { if (narrow) STEP_LAUNCH((conv_wgrad16_row_kernel<T_, 2, 1>), grid, dim3(256), stream, p); \
-                            else STEP_LAUNCH((conv_wgrad16_row_kernel<T_, 2, 2>), grid, dim3(256), stream, p); } while (0)
-        if (d->dtype == STEP_BF16) STEP_WGROW(bf16_t); else STEP_WGROW(f16_t);
-#undef STEP_WGROW
-        return STEP_LAUNCH_CHECK();
-    }
     switch (d->dtype) {
         case STEP_F32: STEP_WG(float); break;
         case STEP_BF16: if (w16) STEP_WG16(bf16_t); else STEP_WG(bf16_t); break;

@@ -147,7 +147,7 @@ static int adam_flat_launch(float* param, float* grad, float* exp_avg, float* ex
     const float* bcd = step_dev ? bc_dev : nullptr;
     const long long nvec = n >> 2;
     long long blocks = (nvec + 255) / 256;
-    static const int per_cu = [] { const char* e = getenv("STEP_ADAM_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 64; }();
+    constexpr int per_cu = 64;
     if (blocks > 256LL * per_cu) blocks = 256LL * per_cu; // 64 workgroups per CU (measured: 4.6 TB/s at 16, 5.5 TB/s at 64), grid-stride beyond
     if (n_seg <= 512)
         STEP_LAUNCH((adam_flat_kernel<512>), dim3((unsigned)blocks), dim3(256), stream, param, grad, exp_avg, exp_avg_sq, nvec, seg_end,

@@ -9,6 +9,7 @@
 // 16-byte vectors, so every tap is a fully coalesced row segment.
 #include "common.h"
 #include "pool_vec.h"
+#include "options.h"
 #include <stdlib.h>
 
 namespace step {
@@ -103,7 +104,7 @@ constexpr int PP_MAXIN = 16;                        // max input tile edge
 
 template <typename T, int KD, int KH, int KW, int SD, int SH, int SW, int NT>
 __global__ __launch_bounds__(NT) void maxpool_sep_kernel(const T* __restrict__ x, T* __restrict__ y, PoolParams p,
-                                                          int TH, int TW, int tiles_h, int tiles_w, int cchunks, int dseg, int nseg, int cc_outer) {
+                                                          int TH, int TW, int tiles_h, int tiles_w, int cchunks, int dseg, int nseg) {
     constexpr int V = elem<T>::VEC;
     typedef typename Vec16<T, V>::raw raw;
     constexpr int SL = PP_SL, R = PP_R * 256 / NT;        // NT = 256: 4 items per thread per pass, NT = 1024: 1
@@ -116,17 +117,8 @@ __global__ __launch_bounds__(NT) void maxpool_sep_kernel(const T* __restrict__ x
     int t = blockIdx.x;
     if ((gridDim.x & 7) == 0) t = (t & 7) * (gridDim.x >> 3) + (t >> 3);
     // channel chunk fastest: a chunk is 64 bytes -- half a 128-byte line -- so the two chunks of a line are neighbours in launch
-    // order on ONE XCD (the second one's loads hit that L2) instead of being fetched by two XCDs (STEP_POOL_CC_OUTER=1: the old order)
-    int cc;
-    if (cc_outer) {
-        const int tw_o = t % tiles_w; t /= tiles_w;
-        const int th_o = t % tiles_h; t /= tiles_h;
-        const int seg_o = t % nseg; t /= nseg;
-        cc = t % cchunks;
-        t = ((t / cchunks) * nseg + seg_o) * tiles_h * tiles_w + th_o * tiles_w + tw_o;
-    } else {
-        cc = t % cchunks; t /= cchunks;
-    }
+    // order on ONE XCD (the second one's loads hit that L2) instead of being fetched by two XCDs (measured: maxPool3d_2a 64 -> 45 us)
+    const int cc = t % cchunks; t /= cchunks;
     const int tw_i = t % tiles_w; t /= tiles_w;
     const int th_i = t % tiles_h; t /= tiles_h;
     const int seg = t % nseg;
@@ -260,103 +252,6 @@ __global__ __launch_bounds__(NT) void maxpool_sep_kernel(const T* __restrict__ x
     for (int pd = pbeg; pd < pend; ++pd) step(pd, rg);
 }
 
-// The same separable pool WITHOUT LDS and barriers: a thread owns RW consecutive outputs of one row and one 16-byte channel
-// vector and walks along D.  Per input plane it loads the KH x ((RW-1)*SW+KW) vectors its outputs touch (all loads of a plane
-// issued back to back: ~18 KB in flight per wave, so a few waves per CU cover the HBM latency that the LDS form exposes once
-// per plane and workgroup), reduces along W then H in registers and keeps the 2-D maxima of the previous planes as the LDS
-// form does.  Neighbouring threads re-read each other's rows / columns from L1 / L2 (4.5 loads per output element at stride 1,
-// 16 bytes each, against 26 in the direct kernel).  Same padding classes as maxpool_sep_kernel (explicit TF pad = 0, overhang
-// = lowest), same storage-type maxima: bit-identical results.
-template <typename T, int KD, int KH, int KW, int SD, int SH, int SW, int RW>
-__global__ __launch_bounds__(256) void maxpool_reg_kernel(const T* __restrict__ x, T* __restrict__ y, PoolParams p, int wruns, int cvecs,
-                                                          int dseg, int nseg, long long total) {
-    constexpr int V = elem<T>::VEC;
-    typedef typename Vec16<T, V>::raw raw;
-    constexpr int NC = (RW - 1) * SW + KW;
-    raw zero;
-#pragma unroll
-    for (int i = 0; i < V; ++i) zero[i] = 0;
-    const raw kzero = VecMax<T>::enc(zero), klow = VecMax<T>::lowest();
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    long long t = idx;
-    const int cv = (int)(t % cvecs); t /= cvecs;
-    const int wr = (int)(t % wruns); t /= wruns;
-    const int oh = (int)(t % p.Ho); t /= p.Ho;
-    const int seg = (int)(t % nseg);
-    const int n = (int)(t / nseg);
-    const int ow0 = wr * RW;
-    // column / row classes (the same for every plane): element offset inside a plane (>= 0), -1: explicit pad (0), -2: overhang (lowest)
-    int coff[NC], roff[KH];
-#pragma unroll
-    for (int j = 0; j < NC; ++j) {
-        const int pc = ow0 * SW + j, iw = pc - p.pfw;
-        coff[j] = pc >= p.Lpw ? -2 : ((iw >= 0 && iw < p.W) ? iw * p.x_cstride : -1);
-    }
-#pragma unroll
-    for (int b = 0; b < KH; ++b) {
-        const int pr = oh * SH + b, ih = pr - p.pfh;
-        roff[b] = pr >= p.Lph ? -2 : ((ih >= 0 && ih < p.H) ? ih * p.W * p.x_cstride : -1);
-    }
-    const size_t xplane = (size_t)p.H * p.W * p.x_cstride, yplane = (size_t)p.Ho * p.Wo * p.y_cstride;
-    const T* xn = x + (size_t)n * p.D * xplane + p.x_coff + cv * V;
-    T* yn = y + (size_t)n * p.Do * yplane + ((size_t)oh * p.Wo + ow0) * p.y_cstride + p.y_coff + cv * V;
-    const int obeg = seg * dseg, oend = min(obeg + dseg, p.Do);
-    const int pbeg = obeg * SD, pend = (oend - 1) * SD + KD;
-    raw m1[RW], m2[RW];
-#pragma unroll
-    for (int r = 0; r < RW; ++r) { m1[r] = klow; m2[r] = klow; }
-    for (int pd = pbeg; pd < pend; ++pd) {
-        const int d = pd - p.pfd;
-        const int cls = pd >= p.Lpd ? 2 : ((d >= 0 && d < p.D) ? 0 : 1);
-        raw m0[RW];
-        if (cls == 0) {
-            const T* xp = xn + (size_t)d * xplane;
-            raw v[KH][NC];
-#pragma unroll
-            for (int b = 0; b < KH; ++b)
-#pragma unroll
-                for (int j = 0; j < NC; ++j) {
-                    raw val = zero;
-                    if (roff[b] >= 0 && coff[j] >= 0) val = *(const raw*)(xp + roff[b] + coff[j]);
-                    v[b][j] = val;
-                }
-#pragma unroll
-            for (int r = 0; r < RW; ++r) m0[r] = klow;
-#pragma unroll
-            for (int b = 0; b < KH; ++b) {
-#pragma unroll
-                for (int j = 0; j < NC; ++j) {
-                    const bool low = roff[b] == -2 || coff[j] == -2;
-                    v[b][j] = low ? klow : VecMax<T>::enc(v[b][j]);      // (pads were loaded as 0: enc(0) = kzero)
-                }
-#pragma unroll
-                for (int r = 0; r < RW; ++r) {
-                    raw m = v[b][r * SW];
-#pragma unroll
-                    for (int k = 1; k < KW; ++k) m = VecMax<T>::max(m, v[b][r * SW + k]);
-                    m0[r] = VecMax<T>::max(m0[r], m);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < RW; ++r) m0[r] = cls == 1 ? kzero : klow;
-        }
-        const int w0p = pd - (KD - 1);
-        const bool emit = w0p >= pbeg && (w0p % SD) == 0;
-#pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            if (emit && ow0 + r < p.Wo) {
-                raw m = m0[r];
-                if (KD >= 2) m = VecMax<T>::max(m, m1[r]);
-                if (KD >= 3) m = VecMax<T>::max(m, m2[r]);
-                *(raw*)(yn + (size_t)(w0p / SD) * yplane + (size_t)r * p.y_cstride) = VecMax<T>::dec(m);
-            }
-            m2[r] = m1[r]; m1[r] = m0[r];
-        }
-    }
-}
-
 // Backward of the TF-SAME max pool (training): the gradient of an output goes to the FIRST maximum of its window in
 // (d, h, w) scan order -- torch's MaxPool3d rule (`val > max`), applied to the explicitly zero-padded tensor as
 // MaxPool3dTFPadding builds it (models/i3dpt.py:114-126): when a pad element wins, the gradient is dropped.
@@ -448,7 +343,7 @@ __global__ void maxpool_arg_kernel(const T* __restrict__ x, unsigned char* __res
         float best[V];
         unsigned char win[V];
 #pragma unroll
-        for (int i = 0; i < V; ++i) { best[i] = -__builtin_inff(); win[i] = 0; }
+        for (int i = 0; i < V; ++i) { best[i] = -__builtin_inff(); win[i] = 255; }    // 255: no tap compared greater (all NaN / -inf): nobody owns the gradient, as in the atomic form
         for (int a = 0; a < p.kd; ++a) {
             const int pd = od * p.sd + a;
             if (pd >= p.Lpd) break;
@@ -608,30 +503,7 @@ static int maxpool_t(const void* x, void* y, const PoolParams& p, step_stream_t 
     if (p.C % V || p.x_cstride % V || p.x_coff % V || p.y_cstride % V || p.y_coff % V) return STEP_E_ALIGN;
     const int ksig = p.kd * 100 + p.kh * 10 + p.kw, ssig = p.sd * 100 + p.sh * 10 + p.sw;
     const bool sep = (ksig == 333 && ssig == 111) || (ksig == 133 && ssig == 122) || (ksig == 333 && ssig == 222);
-    static const bool force_direct = getenv("STEP_POOL_DIRECT") != nullptr;        // tuning aid / A-B against the direct kernel
-    static const int reg_mode = getenv("STEP_POOL_REG") ? atoi(getenv("STEP_POOL_REG")) : 0;
-    if (sep && !force_direct && reg_mode > 0) {
-        // the register form (no LDS): threads = N x D segments x Ho x W runs x channel vectors
-        constexpr int RW = 4;
-        const int wruns = ceil_div(p.Wo, RW), cvecs = p.C / V;
-        const long long per_seg = (long long)p.N * p.Ho * wruns * cvecs;
-        if (per_seg == 0) return STEP_OK;
-        static const int target_w = getenv("STEP_POOL_REG_WAVES") ? atoi(getenv("STEP_POOL_REG_WAVES")) : 1024;   // ~4 waves per CU
-        const int minseg = p.kd == 1 ? 1 : 4;
-        int nseg = 1;
-        while (per_seg * nseg < (long long)target_w * 64 && p.Do / (nseg * 2) >= minseg) nseg *= 2;
-        const int dseg = ceil_div(p.Do, nseg);
-        nseg = ceil_div(p.Do, dseg);
-        const long long total = per_seg * nseg;
-        const dim3 grid((unsigned)ceil_div64(total, 256));
-#define STEP_POOL_REG(KD_, KH_, KW_, SD_, SH_, SW_) \
-        STEP_LAUNCH((maxpool_reg_kernel<T, KD_, KH_, KW_, SD_, SH_, SW_, RW>), grid, dim3(256), stream, (const T*)x, (T*)y, p, wruns, cvecs, dseg, nseg, total)
-        if (ssig == 111) { STEP_POOL_REG(3, 3, 3, 1, 1, 1); }
-        else if (ksig == 133) { STEP_POOL_REG(1, 3, 3, 1, 2, 2); }
-        else { STEP_POOL_REG(3, 3, 3, 2, 2, 2); }
-#undef STEP_POOL_REG
-        return STEP_LAUNCH_CHECK();
-    }
+    const bool force_direct = opt(STEP_OPT_POOL_DIRECT) != 0;        // tests: the general kernel on the separable shapes
     if (sep && !force_direct) {
         // balanced tiles: at most 14x14 outputs at stride 1, 7x7 at stride 2; 64 bytes of channels per workgroup
         const int maxt = p.sh == 1 ? 14 : 7;
@@ -641,22 +513,17 @@ static int maxpool_t(const void* x, void* y, const PoolParams& p, step_stream_t 
         if (blocks == 0) return STEP_OK;
         // split D until there are ~1000 workgroups; with kd = 3 every segment re-reads planes of its neighbours,
         // so keep >= 4 output planes per segment (kd = 1: no dependence along D)
-        static const int target = getenv("STEP_POOL_BLOCKS") ? atoi(getenv("STEP_POOL_BLOCKS")) : 1024;     // tuning aids
-        static const int minseg_e = getenv("STEP_POOL_MINSEG") ? atoi(getenv("STEP_POOL_MINSEG")) : 4;
+        constexpr int target = 1024;
         // (single-tile maps -- the 14x14 stage -- are latency-bound chains of planes, not bandwidth-bound: shorter segments, measured
         // 14.8 -> 13.8 us per pool; on the 28x28 maps the extra halo planes cost more than the parallelism gives: 25.9 -> 30.2 us)
-        const int minseg = p.kd == 1 ? 1 : ((tiles_h * tiles_w == 1 && !getenv("STEP_POOL_MINSEG")) ? 2 : minseg_e);
+        const int minseg = p.kd == 1 ? 1 : (tiles_h * tiles_w == 1 ? 2 : 4);
         int nseg = 1;
         while (blocks * nseg < target && p.Do / (nseg * 2) >= minseg) nseg *= 2;
         const int dseg = ceil_div(p.Do, nseg);
         nseg = ceil_div(p.Do, dseg);
         const dim3 grid((unsigned)(blocks * nseg));
-        static const int nt_e = getenv("STEP_POOL_NT") ? atoi(getenv("STEP_POOL_NT")) : 0;
-        const bool wide = nt_e ? nt_e == 1024 : false;
-        static const int cc_outer = getenv("STEP_POOL_CC_OUTER") ? atoi(getenv("STEP_POOL_CC_OUTER")) : 0;     // tuning aid
 #define STEP_POOL_SEP(KD_, KH_, KW_, SD_, SH_, SW_) \
-        if (wide) STEP_LAUNCH((maxpool_sep_kernel<T, KD_, KH_, KW_, SD_, SH_, SW_, 1024>), grid, dim3(1024), stream, (const T*)x, (T*)y, p, TH, TW, tiles_h, tiles_w, cchunks, dseg, nseg, cc_outer); \
-        else STEP_LAUNCH((maxpool_sep_kernel<T, KD_, KH_, KW_, SD_, SH_, SW_, 256>), grid, dim3(256), stream, (const T*)x, (T*)y, p, TH, TW, tiles_h, tiles_w, cchunks, dseg, nseg, cc_outer)
+        STEP_LAUNCH((maxpool_sep_kernel<T, KD_, KH_, KW_, SD_, SH_, SW_, 256>), grid, dim3(256), stream, (const T*)x, (T*)y, p, TH, TW, tiles_h, tiles_w, cchunks, dseg, nseg)
         if (ssig == 111) { STEP_POOL_SEP(3, 3, 3, 1, 1, 1); }
         else if (ksig == 133) { STEP_POOL_SEP(1, 3, 3, 1, 2, 2); }
         else { STEP_POOL_SEP(3, 3, 3, 2, 2, 2); }

@@ -1,5 +1,4 @@
-// step_amd/csrc/pool_vec.h -- 16-byte channel vectors and their element-wise max in the storage type (shared by the pool
-// kernels of pool.hip and the fused pool + pointwise-conv kernel of conv_poolpw.hip).
+// step_amd/csrc/pool_vec.h -- 16-byte channel vectors and their element-wise max in the storage type (the pool kernels of pool.hip).
 #pragma once
 #include "common.h"
 

@@ -145,218 +145,7 @@ __global__ __launch_bounds__(256) void stem_igemm_kernel(StemParams p) {
     }
 }
 
-// --------------------------------------------------------------------------------------------
-// stem_tap_kernel (16-bit types): the pipelined form of the stem.
-// 256 threads = 4 wavefronts own a 16x16-pixel x 64-channel output tile of one output frame; each
-// wave accumulates a 64-pixel x 64-channel block (2 x 2 MFMA tiles).  One pipeline step = one
-// (kd, kh) pair = 32 K values (8 kw taps x 4 channels), 49 steps.
-//   * input frames go through a 3-slot LDS ring ([37 rows][40 cols] pixels of 4 channels each): frame
-//     kd+2 is loaded into registers at the first step of frame kd and written to the slot frame kd-1
-//     left, so only 35 KB of LDS hold the 7-frame receptive field and 3 workgroups fit on a CU
-//     (their staging bubbles fill each other's matrix work);
-//   * weights: one register set + 3 LDS buffers, fragments: 2 register sets (as conv_tap_kernel);
-//   * epilogue: LDS transpose, 16-byte stores.
-constexpr int STP_ROWS = 37, STP_COLS = 40;
-
-template <typename T>
-__global__ __launch_bounds__(256) void stem_tap_kernel(StemParams p) {
-    static_assert(sizeof(T) == 2, "16-bit storage types only");
-    constexpr int PIXB = 8;                         // 4 channels x 2 B
-    constexpr int FRAME = STP_ROWS * STP_COLS * PIXB;   // 11840 B
-    constexpr int NB = 2, KS = 2, FRAGB = 1024;
-    constexpr int BTILE = NB * KS * FRAGB;          // 4 KiB per step
-    constexpr int S = 49;
-    constexpr int ITEMS = STP_ROWS * (STP_COLS / 4);   // 4-pixel items per frame
-    constexpr int FQ = (ITEMS + 255) / 256;         // items per thread per frame (2)
-    typedef u16x8 frag_t;
-
-    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * FRAME + 3 * BTILE];
-    unsigned char* const ldsA = lds;
-    unsigned char* const ldsB = lds + 3 * FRAME;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-#ifdef STEP_EMUL
-    const int wave = tid >> 6;
-#else
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#endif
-    const int khalf = lane >> 5;
-
-    int t = blockIdx.x;
-    const int tw_i = t % p.tiles_w; t /= p.tiles_w;
-    const int th_i = t % p.tiles_h; t /= p.tiles_h;
-    const int od = t % p.To;
-    const int n = t / p.To;
-    const int oh0 = th_i * 16, ow0 = tw_i * 16;
-    const int nb0 = blockIdx.y * NB;
-
-    const T* xg = (const T*)p.x;
-    const unsigned char* wg = (const unsigned char*)p.w;
-    const bool vec_ok = (p.W % 4) == 0;
-
-    // ---- frame staging: LDS col cl <-> input col 2*ow0 - 4 + cl, row r <-> input row 2*oh0 - 2 + r
-    struct Item { u16x4 c[3]; };
-    auto load_frame = [&](int f, Item (&it)[FQ]) {
-        const int ifr = 2 * od - 2 + f;
-#pragma unroll
-        for (int q = 0; q < FQ; ++q) {
-            const int item = tid + q * 256;
-            const int cq = item % (STP_COLS / 4), r = item / (STP_COLS / 4);
-            const int ih = 2 * oh0 - 2 + r, iw0 = 2 * ow0 - 4 + cq * 4;
-            const bool rowok = item < ITEMS && ifr >= 0 && ifr < p.T && ih >= 0 && ih < p.H;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                u16x4 v = {0, 0, 0, 0};
-                if (rowok) {
-                    const unsigned short* src = (const unsigned short*)xg + ((((size_t)n * p.T + ifr) * 3 + c) * p.H + ih) * p.W;
-                    if (vec_ok && iw0 >= 0 && iw0 + 3 < p.W) {
-                        v = *(const u16x4*)(src + iw0);
-                    } else {
-#pragma unroll
-                        for (int a = 0; a < 4; ++a)
-                            if (iw0 + a >= 0 && iw0 + a < p.W) v[a] = src[iw0 + a];
-                    }
-                }
-                it[q].c[c] = v;
-            }
-        }
-    };
-    auto store_frame = [&](int slot, const Item (&it)[FQ]) {
-#pragma unroll
-        for (int q = 0; q < FQ; ++q) {
-            const int item = tid + q * 256;
-            if (item < ITEMS) {
-                const int cq = item % (STP_COLS / 4), r = item / (STP_COLS / 4);
-                unsigned char* dst = ldsA + slot * FRAME + (r * STP_COLS + cq * 4) * PIXB;
-                const u16x8 lo = {it[q].c[0][0], it[q].c[1][0], it[q].c[2][0], 0, it[q].c[0][1], it[q].c[1][1], it[q].c[2][1], 0};
-                const u16x8 hi = {it[q].c[0][2], it[q].c[1][2], it[q].c[2][2], 0, it[q].c[0][3], it[q].c[1][3], it[q].c[2][3], 0};
-                *(u16x8*)dst = lo;
-                *(u16x8*)(dst + 16) = hi;
-            }
-        }
-    };
-
-    // ---- weights: thread tid owns one 16-byte vector of the 4 KiB step tile
-    const int bf = tid >> 6;                                   // fragment (nbl, j)
-    const unsigned char* wthr = wg + (((size_t)min(nb0 + (bf >> 1), p.nblk32 - 1) * 98 + (bf & 1)) * 64 + (tid & 63)) * 16;
-    auto load_B = [&](int s_) { return *(const u32x4*)(wthr + (size_t)s_ * 2 * FRAGB); };
-
-    // ---- this lane's A base: pixel (2*th, 2*tw + 2) of the slot, + its k half
-    const unsigned char* abase[2];
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-        const int th = wave * 4 + mb * 2 + ((lane & 31) >> 4), tw = lane & 15;
-        abase[mb] = ldsA + ((2 * th) * STP_COLS + 2 * tw + 2 + 2 * khalf) * PIXB;
-    }
-    const unsigned char* const bwave = ldsB + lane * 16;
-
-    f32x16 acc[2][NB];
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mb][i][r] = 0.f;
-
-    frag_t fa[2][KS][2], fb[2][KS][NB];
-    auto read_frags = [&](auto setc, int bufoff, int aoff) {
-        constexpr int SET = decltype(setc)::value;
-#pragma unroll
-        for (int j = 0; j < KS; ++j) {
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) fa[SET][j][mb] = *(const frag_t*)(abase[mb] + aoff + j * 32);
-#pragma unroll
-            for (int i = 0; i < NB; ++i) fb[SET][j][i] = *(const frag_t*)(bwave + bufoff + (i * KS + j) * FRAGB);
-        }
-    };
-    auto mma_all = [&](auto setc) {
-        constexpr int SET = decltype(setc)::value;
-#pragma unroll
-        for (int j = 0; j < KS; ++j)
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                mma_k16(fa[SET][j][0], fb[SET][j][i], acc[0][i], T());
-                mma_k16(fa[SET][j][1], fb[SET][j][i], acc[1][i], T());
-            }
-    };
-
-    // ---- prologue: frames 0 and 1, weight tiles 0 and 1, tile 2 in flight
-    Item fr[FQ];
-    load_frame(0, fr); store_frame(0, fr);
-    load_frame(1, fr); store_frame(1, fr);
-    u32x4 R = load_B(0);
-    *(u32x4*)(ldsB + tid * 16) = R;
-    R = load_B(1);
-    *(u32x4*)(ldsB + BTILE + tid * 16) = R;
-    R = load_B(2);
-    __syncthreads();
-    read_frags(std::integral_constant<int, 0>(), 0, 0);
-
-    int b1 = BTILE, b2 = 2 * BTILE;
-    int kd1 = 0, kh1 = 0;                              // coordinates of step s+1
-    auto step = [&](auto setc, int s_) {
-        constexpr int SET = decltype(setc)::value;
-        const int kh = kh1, kd = kd1;                  // this step
-        if (++kh1 == 7) { kh1 = 0; ++kd1; }
-        if (kh == 0 && kd + 2 < 7) load_frame(kd + 2, fr);          // in flight over three steps
-        if (s_ + 1 < S) read_frags(std::integral_constant<int, SET ^ 1>(), b1, (kd1 % 3) * FRAME + kh1 * (STP_COLS * PIXB));
-        mma_all(setc);
-        if (s_ + 2 < S) *(u32x4*)(ldsB + b2 + tid * 16) = R;
-        if (s_ + 3 < S) R = load_B(s_ + 3);
-        if (kh == 3 && kd + 2 < 7) store_frame((kd + 2) % 3, fr);   // the slot of frame kd-1 (last read 4+ steps ago)
-        __syncthreads();
-        const int nb = (b2 == 2 * BTILE) ? 0 : b2 + BTILE;
-        b1 = b2; b2 = nb;
-    };
-#pragma unroll 1
-    for (int s_ = 0; s_ < S; s_ += 2) {
-        step(std::integral_constant<int, 0>(), s_);
-        if (s_ + 1 < S) step(std::integral_constant<int, 1>(), s_ + 1);
-    }
-
-    // ---- epilogue: affine + ReLU, LDS transpose (fp32, 128 pixels at a time), 16-byte stores
-    T* yg = (T*)p.y;
-    constexpr int BN = NB * 32, G = BN / 8;
-    float* ot = (float*)lds;
-    float sc[NB], sh[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int co = min((nb0 + i) * 32 + (lane & 31), p.Cout - 1);
-        sc[i] = p.scale ? p.scale[co] : 1.f;
-        sh[i] = p.shift ? p.shift[co] : 0.f;
-    }
-    const bool vec_epi = (p.y_cstride % 8 == 0) && (p.y_coff % 8 == 0) && (p.Cout % 8 == 0) && (((uintptr_t)p.y) % 16 == 0);
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-        if (mb) __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ot[(wave * 32 + cd_row(r, lane)) * BN + i * 32 + (lane & 31)] = fmaxf(acc[mb][i][r] * sc[i] + sh[i], 0.f);
-        __syncthreads();
-        for (int idx = tid; idx < 128 * G; idx += 256) {
-            const int row = idx / G, g = idx % G;
-            // row = wave*32 + rr ; pixel: th = wave*4 + mb*2 + (rr >> 4), tw = rr & 15
-            const int oh = oh0 + (row >> 5) * 4 + mb * 2 + ((row & 31) >> 4), ow = ow0 + (row & 15);
-            const int co = nb0 * 32 + g * 8;
-            if (oh < p.Ho && ow < p.Wo && co < p.Cout) {
-                const size_t opix = (((size_t)n * p.To + od) * p.Ho + oh) * p.Wo + ow;
-                const float* src = ot + row * BN + g * 8;
-                if (vec_epi) {
-                    u16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = elem<T>::bits16(src[e]);
-                    *(u16x8*)(yg + opix * p.y_cstride + p.y_coff + co) = o;
-                } else {
-                    for (int e = 0; e < 8; ++e)
-                        if (co + e < p.Cout) yg[opix * p.y_cstride + p.y_coff + co + e] = elem<T>::from_f32(src[e]);
-                }
-            }
-        }
-    }
-}
+constexpr int STP_ROWS = 37, STP_COLS = 40;       // LDS frame of the stream stem: rows x columns of input pixels under a 16x16 output tile
 
 // --------------------------------------------------------------------------------------------
 // stem_stream_kernel (16-bit types): the stem with a dense K axis.
@@ -710,34 +499,12 @@ static int stem_stream_forward_t(StemParams p, step_stream_t stream) {
     p.tiles_h = ceil_div(p.Ho, 16); p.tiles_w = ceil_div(p.Wo, 16);
     const long long tiles = (long long)p.N * p.To * p.tiles_h * p.tiles_w;
     const int groups = ceil_div(p.nblk32, 2);
-    // the partial last round (as conv_forward_t does for conv3d_2c): three workgroups fit a CU, so 768 run at a time; C2's 6272
-    // tiles are 8.17 such rounds -- a ninth that fills a sixth of the chip.  With one channel group those tail tiles can run as a
-    // second launch at one 32-channel block per workgroup: twice as many, shorter workgroups; bit-identical (same K order per output).
-    // MEASURED SLOWER here (C2 stem 263 -> 268 us: with three resident workgroups per CU the rounds are not in step and the tail is
-    // already smeared out; the NB = 1 workgroups re-stage the same frames for half the matrix work), so it is opt-in:
-    // STEP_STEM_TAIL=1 (kept with its test as the record of the experiment).
-    const long long slots = getenv("STEP_CONV_SLOTS") ? atoi(getenv("STEP_CONV_SLOTS")) : 768;          // (test aid, read per call)
-    const bool tail_ok = getenv("STEP_STEM_TAIL") && atoi(getenv("STEP_STEM_TAIL")) == 1;
-    const long long tail = tiles % slots;
+    // (a separate NB = 1 launch for the partial last round, as conv_forward_t does for conv3d_2c, was built and measured SLOWER
+    // here -- 263 -> 268 us: with three resident workgroups per CU the rounds are not in step and the tail is already smeared
+    // out -- and removed again)
     p.tile0 = 0;
-    if (tail_ok && groups == 1 && p.nblk32 == 2 && tiles > slots && tail > 0 && tail * 4 <= slots) {
-        dim3 grid((unsigned)(tiles - tail), 1);
-        STEP_LAUNCH((stem_stream_kernel<T, 2>), grid, dim3(256), stream, p);
-        p.tile0 = (int)(tiles - tail);
-        dim3 gt((unsigned)tail, 2);
-        STEP_LAUNCH((stem_stream_kernel<T, 1>), gt, dim3(256), stream, p);
-        return STEP_LAUNCH_CHECK();
-    }
     dim3 grid((unsigned)tiles, (unsigned)groups);
     STEP_LAUNCH((stem_stream_kernel<T, 2>), grid, dim3(256), stream, p);
-    return STEP_LAUNCH_CHECK();
-}
-
-template <typename T>
-static int stem_tap_forward_t(StemParams p, step_stream_t stream) {
-    p.tiles_h = ceil_div(p.Ho, 16); p.tiles_w = ceil_div(p.Wo, 16);
-    dim3 grid((unsigned)((long long)p.N * p.To * p.tiles_h * p.tiles_w), (unsigned)ceil_div(p.nblk32, 2));
-    STEP_LAUNCH((stem_tap_kernel<T>), grid, dim3(256), stream, p);
     return STEP_LAUNCH_CHECK();
 }
 
@@ -794,9 +561,9 @@ int step_stem_forward(int dtype, const void* x, int N, int T, int H, int W, cons
     const int ov = conv_impl_override();
     switch (dtype) {
         case STEP_F32: return stem_forward_t<float>(p, stream);
-        // STEP_CONV_IMPL=igemm / tap select the two older stems (A/B measurements, tests); default = dense-K stream stem
-        case STEP_BF16: return ov == 0 ? stem_forward_t<bf16_t>(p, stream) : (ov == 1 ? stem_tap_forward_t<bf16_t>(p, stream) : stem_stream_forward_t<bf16_t>(p, stream));
-        case STEP_F16: return ov == 0 ? stem_forward_t<f16_t>(p, stream) : (ov == 1 ? stem_tap_forward_t<f16_t>(p, stream) : stem_stream_forward_t<f16_t>(p, stream));
+        // STEP_OPT_CONV_IMPL = 0 selects the tiled stem (the fp32 kernel) for the 16-bit types too (tests); default = dense-K stream stem
+        case STEP_BF16: return ov == 0 ? stem_forward_t<bf16_t>(p, stream) : stem_stream_forward_t<bf16_t>(p, stream);
+        case STEP_F16: return ov == 0 ? stem_forward_t<f16_t>(p, stream) : stem_stream_forward_t<f16_t>(p, stream);
     }
     return STEP_E_DTYPE;
 }
@@ -808,7 +575,6 @@ int step_stem_kernel_name(int dtype, char* buf, int buflen) {
     const char* t = dtype == STEP_F32 ? "float" : (dtype == STEP_BF16 ? "step::bf16_t" : "step::f16_t");
     if (dtype != STEP_F32 && dtype != STEP_BF16 && dtype != STEP_F16) return STEP_E_DTYPE;
     if (dtype == STEP_F32 || ov == 0) snprintf(buf, (size_t)buflen, "void step::stem_igemm_kernel<%s, 2>(step::StemParams)", t);
-    else if (ov == 1) snprintf(buf, (size_t)buflen, "void step::stem_tap_kernel<%s>(step::StemParams)", t);
     else snprintf(buf, (size_t)buflen, "void step::stem_stream_kernel<%s, 2>(step::StemParams)", t);
     return STEP_OK;
 }

@@ -26,7 +26,7 @@ from .tube_math import encode_coef
 
 import os
 
-SYNC_FREE_LOSSES = os.environ.get("STEP_REF_LOSS_BRANCHES", "0") != "1"    # see TwoBranchNet.forward (losses)
+SYNC_FREE_LOSSES = True    # (module switch; False = the reference's `if mask.sum():` branches) see TwoBranchNet.forward (losses)
 
 
 class ROINet(nn.Module):

@@ -17,7 +17,7 @@ DT = {torch.float32: _capi.F32, torch.bfloat16: _capi.BF16, torch.float16: _capi
 # launch below is bracketed by two HIP events on the launch stream and a record
 # (kernel_name, algorithmic_flops, algorithmic_bytes, start_event, end_event) is appended.
 PROFILE = None
-WGRAD16_WS = os.environ.get("STEP_WGRAD16_WS", "1") != "0"   # partial-tile workspace instead of fp32 atomics (16-bit weight gradients)
+WGRAD16_WS = True      # 16-bit weight gradients: partial-tile workspace + fixed-order sum instead of fp32 atomics (module switch for tests / A-B timing)
 
 
 class _Prof:
@@ -161,59 +161,6 @@ def conv_forward(x, w_packed, Cout, k, scale=None, shift=None, relu=True, res=No
         launch()           # untimed twin right in front of the timed launch (idempotent): the event pair then brackets a launch that
     with prof:             # runs back to back with GPU work -- after an idle gap a short kernel is timed at ramped-down clocks (3x off)
         launch()
-    return out
-
-
-def pool3_conv1_forward(x, w_packed, Cout, scale=None, shift=None, relu=True, out=None):
-    """y = act(conv1x1x1(maxpool_tf(x, (3,3,3), (1,1,1))) * scale + shift) in one launch (an Inception block's branch_3,
-    models/i3dpt.py:151-155); x channels-last [N,D,H,W,Cin] (may be a channel slice), out an optional channel slice.
-    Returns None when the library declines the shape (the caller runs pool and conv as two launches)."""
-    L = _lib.lib()
-    N, D, H, W, Cin = x.shape
-    xcs = _chan_slice(x)
-    made = out is None
-    if made:
-        out = torch.empty((N, D, H, W, Cout), dtype=x.dtype, device=x.device)
-    d = _capi.ConvDesc(dtype=_dt(x), N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=xcs, x_coff=0,
-                       y_cstride=_chan_slice(out), y_coff=0, res_cstride=0, res_coff=0, relu=int(bool(relu)), split=0,
-                       y2_cstride=0, y2_coff=0)
-    prof = _NOPROF
-    if PROFILE is not None:
-        buf = ctypes.create_string_buffer(256)
-        if L.step_pool3_conv1_kernel_name(ctypes.byref(d), buf, 256) == 0:
-            pix = N * D * H * W
-            prof = _Prof(buf.value.decode(), 2.0 * pix * Cout * Cin, (pix * (Cin + Cout) + Cout * Cin) * _ES[x.dtype])
-    with prof:
-        st = L.step_pool3_conv1_forward(ctypes.byref(d), _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift),
-                                        _lib.dptr(out), _lib.stream_ptr(x.device))
-    if st == -4:                                                  # STEP_E_UNSUPPORTED
-        return None
-    _capi.check(st, "step_pool3_conv1_forward")
-    return out
-
-
-def pool133s2_conv1_forward(x, w_packed, Cout, scale=None, shift=None, relu=True):
-    """y = act(conv1x1x1(maxpool_tf(x, (1,3,3), (1,2,2))) * scale + shift) in one launch (maxPool3d_2a_3x3 -> conv3d_2b_1x1,
-    models/i3dpt.py:193-201); x channels-last [N,D,Hi,Wi,Cin].  Returns None when the library declines the shape."""
-    L = _lib.lib()
-    N, D, Hi, Wi, Cin = x.shape
-    Ho, Wo = L.step_pool_out_size(Hi, 3, 2), L.step_pool_out_size(Wi, 3, 2)
-    out = torch.empty((N, D, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
-    d = _capi.ConvDesc(dtype=_dt(x), N=N, D=D, H=Ho, W=Wo, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=_chan_slice(x), x_coff=0,
-                       y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=int(bool(relu)), split=0, y2_cstride=0, y2_coff=0)
-    prof = _NOPROF
-    if PROFILE is not None:
-        buf = ctypes.create_string_buffer(256)
-        if L.step_pool3_conv1_kernel_name(ctypes.byref(d), buf, 256) == 0:
-            pix = N * D * Ho * Wo
-            name = buf.value.decode().replace(">(step::ConvParams)", ", true>(step::ConvParams)")
-            prof = _Prof(name, 2.0 * pix * Cout * Cin, (x.numel() + pix * Cout + Cout * Cin) * _ES[x.dtype])
-    with prof:
-        st = L.step_pool133s2_conv1_forward(ctypes.byref(d), Hi, Wi, _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift),
-                                            _lib.dptr(out), _lib.stream_ptr(x.device))
-    if st == -4:
-        return None
-    _capi.check(st, "step_pool133s2_conv1_forward")
     return out
 
 
@@ -384,9 +331,9 @@ def maxpool_tf(x, k, s, out=None):
     prof = _NOPROF
     if PROFILE is not None:
         ks = (tuple(k), tuple(s))
-        sep = ks in (((3, 3, 3), (1, 1, 1)), ((1, 3, 3), (1, 2, 2)), ((3, 3, 3), (2, 2, 2))) and not os.environ.get("STEP_POOL_DIRECT")
+        sep = ks in (((3, 3, 3), (1, 1, 1)), ((1, 3, 3), (1, 2, 2)), ((3, 3, 3), (2, 2, 2))) and not _capi.get_option(L, "pool_direct")
         tn = _TNAME[x.dtype]
-        kn = ("maxpool_sep_kernel<%s, %d, %d, %d, %d, %d, %d, 256>" % ((tn,) + ks[0] + ks[1]), ", int" * 8) if sep else \
+        kn = ("maxpool_sep_kernel<%s, %d, %d, %d, %d, %d, %d, 256>" % ((tn,) + ks[0] + ks[1]), ", int" * 7) if sep else \
             ("maxpool3d_tf_kernel<%s>" % tn, ", long long")
         prof = _Prof("void step::%s(%s const*, %s*, step::PoolParams%s)" % (kn[0], tn, tn, kn[1]),
                      0.0, (x.numel() + out.numel()) * _ES[x.dtype])
@@ -400,7 +347,7 @@ def maxpool_tf(x, k, s, out=None):
     return out
 
 
-POOL_BWD_GATHER = os.environ.get("STEP_POOL_BWD_GATHER", "1") != "0"
+POOL_BWD_GATHER = True      # max-pool backward as two gathers (False: the fp32-atomic scatter form; module switch for tests / A-B timing)
 
 
 def maxpool_tf_backward(x, gy, k, s):

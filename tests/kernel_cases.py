@@ -690,11 +690,9 @@ def case_conv_units(bk, golden):
 
 def case_conv_units_four_wave_form(bk, golden):
     """The same shapes through the FOUR-wave form of conv_tap_kernel (128-pixel tiles: 8x16, 2 planes x 8x8, general boxes
-    <= 128 pixels, one tap per barrier; STEP_CONV_WAVES=4 makes the planner choose it wherever the tap kernel runs), plus
+    <= 128 pixels, one tap per barrier; option conv_waves = 4 makes the planner choose it wherever the tap kernel runs), plus
     shapes that make each of its tile kinds ragged."""
-    saved = os.environ.get("STEP_CONV_WAVES")
-    os.environ["STEP_CONV_WAVES"] = "4"
-    try:
+    with _capi.options(bk.lib, conv_waves=4):
         d = _capi.ConvDesc(dtype=BF16, N=1, D=2, H=8, W=16, Cin=64, Cout=96, kd=3, kh=3, kw=3, x_cstride=64, x_coff=0, y_cstride=96,
                            y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
         buf = ctypes.create_string_buffer(256)
@@ -710,159 +708,39 @@ def case_conv_units_four_wave_form(bk, golden):
         # two-deep register ring
         pw = [(1, 136, 200, 1, 40, 52, (1, 1, 1)),      # ragged K (136 = 4*32 + 8), ragged last pixel tile, 7 channel blocks
               (2, 128, 128, 2, 25, 41, (1, 1, 1))]      # whole slabs, tail tile
-        for nb in ("1", "2", "3"):
-            os.environ["STEP_CONV_NB"] = nb
+        for nb in (1, 2, 3):
+          with _capi.options(bk.lib, conv_nb=nb):
             for case in pw:
                 N, Cin, Cout, D, H, W, k = case
                 d = _capi.ConvDesc(dtype=BF16, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=Cin, x_coff=0,
                                    y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
                 assert bk.lib.step_conv_kernel_name(ctypes.byref(d), buf, 256) == 0
-                assert ("conv_pw_kernel<step::bf16_t, %s, 4>" % nb) in buf.value.decode(), buf.value
+                assert ("conv_pw_kernel<step::bf16_t, %d, 4>" % nb) in buf.value.decode(), buf.value
                 _conv_case(bk, case, (F32, BF16))
-    finally:
-        os.environ.pop("STEP_CONV_NB", None)
-        if saved is None:
-            os.environ.pop("STEP_CONV_WAVES", None)
-        else:
-            os.environ["STEP_CONV_WAVES"] = saved
-
-
-POOLPW_CASES = [
-    # N, Cin, Cout, D, H, W
-    (1, 40, 64, 3, 7, 7),        # 7x7 planes -> 2 x 2 waves (boxes <= 64 pixels), ragged last slab (40 = 32 + 8)
-    (2, 64, 32, 5, 9, 13),       # one output block, ragged boxes in every direction
-    (1, 48, 160, 2, 6, 10),      # 5 output blocks -> two channel groups (the second one ragged)
-    (1, 32, 96, 4, 14, 14),      # 3 output blocks run as 4 (a duplicate block that is never stored)
-    (1, 16, 128, 1, 5, 28),      # a single plane (the pad planes on both sides win nothing but zeros), wide rows
-]
-
-
-def run_pool3_conv1(bk, x, w, scale, shift, dt, relu=True, x_pad=(0, 0), y_pad=(0, 0)):
-    N, Cin, D, H, W = x.shape
-    Cout = w.shape[0]
-    xb = np.zeros((N, D, H, W, x_pad[0] + Cin + x_pad[1]), np.float32)
-    xb[..., x_pad[0]:x_pad[0] + Cin] = cl(x)
-    xb[..., :x_pad[0]] = 77.0
-    xb[..., x_pad[0] + Cin:] = -55.0
-    xe = bk.dev(encode(xb, dt))
-    yb = bk.dev(np.zeros((N, D, H, W, y_pad[0] + Cout + y_pad[1]), NP_DT[dt]))
-    wp = pack_weight(bk, w, dt)
-    d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=xb.shape[-1], x_coff=x_pad[0],
-                       y_cstride=y_pad[0] + Cout + y_pad[1], y_coff=y_pad[0], res_cstride=0, res_coff=0, relu=int(relu), split=0,
-                       y2_cstride=0, y2_coff=0)
-    sc, sh = bk.dev(scale), bk.dev(shift)
-    rc = bk.lib.step_pool3_conv1_forward(ctypes.byref(d), xe.ptr, wp.ptr, sc.ptr, sh.ptr, yb.ptr, bk.stream)
-    assert rc == 0, rc
-    # the two-launch form on the same buffers: pool into a dense scratch tensor, then the 1x1x1 conv
-    pb = bk.dev(np.zeros((N, D, H, W, Cin), NP_DT[dt]))
-    assert bk.lib.step_maxpool3d_tf(dt, xe.ptr, N, D, H, W, Cin, xb.shape[-1], x_pad[0], 3, 3, 3, 1, 1, 1, pb.ptr, Cin, 0, bk.stream) == 0
-    y2 = bk.dev(np.zeros((N, D, H, W, y_pad[0] + Cout + y_pad[1]), NP_DT[dt]))
-    d2 = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=Cin, x_coff=0,
-                        y_cstride=y_pad[0] + Cout + y_pad[1], y_coff=y_pad[0], res_cstride=0, res_coff=0, relu=int(relu), split=0,
-                        y2_cstride=0, y2_coff=0)
-    assert bk.lib.step_conv_forward(ctypes.byref(d2), pb.ptr, wp.ptr, sc.ptr, sh.ptr, None, y2.ptr, None, bk.stream) == 0
-    y = decode(yb.get(), dt)
-    assert not y[..., :y_pad[0]].any() and not y[..., y_pad[0] + Cout:].any()
-    return uncl(y[..., y_pad[0]:y_pad[0] + Cout]), uncl(decode(y2.get(), dt)[..., y_pad[0]:y_pad[0] + Cout])
-
-
-def _pool3_conv1_case(bk, case, dts):
-    N, Cin, Cout, D, H, W = case
-    rs = np.random.RandomState(Cin * 5 + Cout)
-    x = rs.randn(N, Cin, D, H, W).astype(np.float32) - 0.6      # mostly negative: the zero pad wins along the borders
-    w = (rs.randn(Cout, Cin, 1, 1, 1) / np.sqrt(Cin)).astype(np.float32)
-    scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32)
-    shift = (0.2 * rs.randn(Cout)).astype(np.float32)
-    for dt in dts:
-        got, two = run_pool3_conv1(bk, x, w, scale, shift, dt, x_pad=(8, 8), y_pad=(16, 8))
-        pooled = R.maxpool_tf(torch.from_numpy(quantize(x, dt)), (3, 3, 3), (1, 1, 1)).numpy()
-        ref = ref_conv(pooled, w, scale, shift, dt)
-        err = np.abs(got - ref).max() / np.abs(ref).max()
-        assert err < tol(dt), (case, dt, err)
-        assert np.array_equal(got, two), (case, dt, float(np.abs(got - two).max()))     # same max, same K order: bit-identical
-
-
-def case_pool3_conv1_fused(bk, golden):
-    """step_pool3_conv1_forward (an Inception block's branch_3: 3x3x3 / 1 TF-SAME max pool -> 1x1x1 unit, one launch)
-    against the oracle's pool + conv and, bit for bit, against step_maxpool3d_tf + step_conv_forward."""
-    for case in POOLPW_CASES:
-        _pool3_conv1_case(bk, case, (F32, BF16))
-    _pool3_conv1_case(bk, POOLPW_CASES[0], (F16,))
-    # a conv that is not 1x1x1 is refused
-    d = _capi.ConvDesc(dtype=F32, N=1, D=2, H=4, W=4, Cin=16, Cout=32, kd=3, kh=3, kw=3, x_cstride=16, x_coff=0, y_cstride=32,
-                       y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
-    z = bk.dev(np.zeros(16, np.float32))
-    assert bk.lib.step_pool3_conv1_forward(ctypes.byref(d), z.ptr, z.ptr, None, None, z.ptr, bk.stream) == -4
-
-
-def case_pool133s2_conv1_fused(bk, golden):
-    """step_pool133s2_conv1_forward (maxPool3d_2a_3x3 -> conv3d_2b_1x1 as one launch: (1,3,3) / (1,2,2) TF-SAME pool, back-heavy
-    zero-VALUED pad, then the 1x1x1 unit) against the oracle and, bit for bit, against step_maxpool3d_tf + step_conv_forward."""
-    L = bk.lib
-    for (N, Cin, Cout, D, Hi, Wi) in ((1, 64, 64, 3, 16, 28), (2, 40, 32, 2, 9, 13), (1, 24, 160, 1, 7, 31)):   # even / odd extents (pad row / column), ragged slab, channel groups
-        rs = np.random.RandomState(Cin + Hi)
-        x = rs.randn(N, Cin, D, Hi, Wi).astype(np.float32) - 0.6
-        w = (rs.randn(Cout, Cin, 1, 1, 1) / np.sqrt(Cin)).astype(np.float32)
-        scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32)
-        shift = (0.2 * rs.randn(Cout)).astype(np.float32)
-        Ho, Wo = L.step_pool_out_size(Hi, 3, 2), L.step_pool_out_size(Wi, 3, 2)
-        for dt in (F32, BF16):
-            xe = bk.dev(encode(cl(x), dt))
-            wp = pack_weight(bk, w, dt)
-            sc, sh = bk.dev(scale), bk.dev(shift)
-            d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=Ho, W=Wo, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=Cin, x_coff=0, y_cstride=Cout,
-                               y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
-            y = bk.dev(np.zeros((N, D, Ho, Wo, Cout), NP_DT[dt]))
-            assert L.step_pool133s2_conv1_forward(ctypes.byref(d), Hi, Wi, xe.ptr, wp.ptr, sc.ptr, sh.ptr, y.ptr, bk.stream) == 0
-            pb = bk.dev(np.zeros((N, D, Ho, Wo, Cin), NP_DT[dt]))
-            assert L.step_maxpool3d_tf(dt, xe.ptr, N, D, Hi, Wi, Cin, Cin, 0, 1, 3, 3, 1, 2, 2, pb.ptr, Cin, 0, bk.stream) == 0
-            y2 = bk.dev(np.zeros((N, D, Ho, Wo, Cout), NP_DT[dt]))
-            assert L.step_conv_forward(ctypes.byref(d), pb.ptr, wp.ptr, sc.ptr, sh.ptr, None, y2.ptr, None, bk.stream) == 0
-            got = uncl(decode(y.get(), dt))
-            pooled = R.maxpool_tf(torch.from_numpy(quantize(x, dt)), (1, 3, 3), (1, 2, 2)).numpy()
-            ref = ref_conv(pooled, w, scale, shift, dt)
-            err = np.abs(got - ref).max() / np.abs(ref).max()
-            assert err < tol(dt), (N, Cin, Cout, Hi, Wi, dt, err)
-            assert np.array_equal(y.get(), y2.get()), (N, Cin, Cout, Hi, Wi, dt)
-    d = _capi.ConvDesc(dtype=F32, N=1, D=1, H=5, W=5, Cin=16, Cout=32, kd=1, kh=1, kw=1, x_cstride=16, x_coff=0, y_cstride=32,
-                       y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
-    z = bk.dev(np.zeros(16, np.float32))
-    assert L.step_pool133s2_conv1_forward(ctypes.byref(d), 12, 10, z.ptr, z.ptr, None, None, z.ptr, bk.stream) == -2     # ceil(12 / 2) != 5
-
-
-def big_pool3_conv1(bk, golden):
-    """branch_3 at real Inception shapes (one clip of C2 / an AVA clip), 16-bit and fp32."""
-    for case in ((1, 192, 32, 16, 28, 28), (1, 480, 64, 8, 14, 14), (1, 528, 128, 8, 14, 14), (1, 256, 64, 6, 50, 50),
-                 (2, 832, 128, 3, 7, 7)):
-        _pool3_conv1_case(bk, case, (BF16, F16))
-    _pool3_conv1_case(bk, (1, 480, 64, 4, 14, 14), (F32,))
 
 
 def case_conv_units_two_phase_form(bk, golden):
     """The TWO-PHASE form of conv_tap_kernel (anti-phase wave groups: a step is a load phase and a multiply phase separated
-    by barriers, the two channel-half groups of the workgroup run them alternately; STEP_CONV_PHASED=1|2 selects it wherever
+    by barriers, the two channel-half groups of the workgroup run them alternately; option conv_phased = 1, the default, selects it wherever
     the 8-wave tap kernel runs in 16-bit storage): same shapes as the classic form, checked against the fp32 reference AND
     bit for bit against the classic form (the accumulation order is the same)."""
-    saved, saved_w = os.environ.get("STEP_CONV_PHASED"), os.environ.get("STEP_CONV_WAVES")
-    os.environ["STEP_CONV_WAVES"] = "8"              # (the planner sends grids this small to the four-wave form)
     buf = ctypes.create_string_buffer(256)
     extra = [(1, 96, 192, 3, 9, 17, (3, 3, 3)),      # NB = 3, three slabs (two halo re-stagings with the groups realigned), ragged tiles
              (1, 40, 130, 5, 8, 8, (3, 3, 3)),       # 4 planes x 8x8, ragged last slab (40 = 32 + 8), 5 channel blocks (odd: a duplicate block)
              (2, 32, 64, 2, 6, 21, (1, 3, 3))]       # 2-D kernel (10 padded taps: an ODD number of steps per slab), general box
     cases = [c for c in CONV_CASES + extra if c[6] != (1, 1, 1)]
-    try:
-        os.environ["STEP_CONV_PHASED"] = "0"
+    with _capi.options(bk.lib, conv_waves=8):         # (the planner sends grids this small to the four-wave form)
         classic = {}
-        for case in cases:
-            N, Cin, Cout, D, H, W, k = case
-            rs = np.random.RandomState(Cin * 7 + Cout)
-            x = rs.randn(N, Cin, D, H, W).astype(np.float32)
-            w = (rs.randn(Cout, Cin, *k) / np.sqrt(Cin * np.prod(k))).astype(np.float32)
-            scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32)
-            shift = (0.2 * rs.randn(Cout)).astype(np.float32)
-            classic[case] = (x, w, scale, shift, run_conv(bk, x, w, scale, shift, BF16, x_pad=(8, 8), y_pad=(16, 8)))
-        for ph in ("1",):
-            os.environ["STEP_CONV_PHASED"] = ph
+        with _capi.options(bk.lib, conv_phased=0):
+            for case in cases:
+                N, Cin, Cout, D, H, W, k = case
+                rs = np.random.RandomState(Cin * 7 + Cout)
+                x = rs.randn(N, Cin, D, H, W).astype(np.float32)
+                w = (rs.randn(Cout, Cin, *k) / np.sqrt(Cin * np.prod(k))).astype(np.float32)
+                scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32)
+                shift = (0.2 * rs.randn(Cout)).astype(np.float32)
+                classic[case] = (x, w, scale, shift, run_conv(bk, x, w, scale, shift, BF16, x_pad=(8, 8), y_pad=(16, 8)))
+        with _capi.options(bk.lib, conv_phased=1):
             seen = 0
             for case in cases:
                 N, Cin, Cout, D, H, W, k = case
@@ -872,22 +750,15 @@ def case_conv_units_two_phase_form(bk, golden):
                 assert bk.lib.step_conv_kernel_name(ctypes.byref(d), buf, 256) == 0
                 name = buf.value.decode()
                 if "conv_tap_kernel" in name and k == (3, 3, 3):
-                    assert name.endswith(", 2, 2, 8, %s>(step::ConvParams)" % ph), name
+                    assert name.endswith(", 2, 2, 8, 1>(step::ConvParams)"), name
                     seen += 1
                 got = run_conv(bk, x, w, scale, shift, BF16, x_pad=(8, 8), y_pad=(16, 8))
                 ref = ref_conv(x, w, scale, shift, BF16)
                 err = np.abs(got - ref).max() / np.abs(ref).max()
-                assert err < tol(BF16), (case, ph, err)
-                assert np.array_equal(got, y0), (case, ph, float(np.abs(got - y0).max()))
+                assert err < tol(BF16), (case, err)
+                assert np.array_equal(got, y0), (case, float(np.abs(got - y0).max()))
             assert seen >= 4, seen
-        os.environ["STEP_CONV_PHASED"] = "1"
-        _conv_case(bk, extra[0], (F16,))
-    finally:
-        for key, val in (("STEP_CONV_PHASED", saved), ("STEP_CONV_WAVES", saved_w)):
-            if val is None:
-                os.environ.pop(key, None)
-            else:
-                os.environ[key] = val
+            _conv_case(bk, extra[0], (F16,))
 
 
 def case_tube_update(bk, golden):
@@ -970,7 +841,7 @@ def case_conv_splitk_few_rows_deep_k(bk, golden):
         for dt in (BF16, F16, F32):
             ref = ref_conv(x, w, None, shift, dt, relu=False, res=res)
             got = run_conv(bk, x, w, None, shift, dt, relu=False, res=res, y_pad=(4, 4), use_ws=True)
-            if not os.environ.get("STEP_CONV_IMPL"):                  # a forced implementation bypasses the planner
+            if _capi.get_option(bk.lib, "conv_impl") == -1:           # a forced implementation bypasses the planner
                 assert run_conv.last_ws_bytes > 0, "split-K path not taken"
             plain = run_conv(bk, x, w, None, shift, dt, relu=False, res=res, y_pad=(4, 4))
             for y in (got, plain):
@@ -988,16 +859,12 @@ def case_conv_wgrad(bk, golden):
     cases = [(2, 24, 40, 3, 5, 19, (3, 3, 3)),      # ragged channels (24 -> one 32-block), 19 pixels per row (16 + 3)
              (1, 72, 100, 2, 6, 7, (1, 3, 3)),      # 2-D kernel, two ci / co tiles
              (1, 40, 70, 1, 9, 130, (1, 1, 1))]     # pointwise: 1170 pixels = full chunks + a ragged tail launch
-    # STEP_WGRAD_MINPIX = pixels a wavefront job covers at least (default 512: these small maps become one or two jobs per
+    # option wgrad_minpix = pixels a wavefront job covers at least (default 512: these small maps become one or two jobs per
     # tile); 64 and 256 force several row-range jobs per tile -- jobs that cross planes and clips, ragged last jobs,
     # pointwise chunks of 64 / 256 pixels with a tail launch
-    saved = os.environ.get("STEP_WGRAD_MINPIX")
     try:
-        for minpix in ("64", "256", None):
-            if minpix is None:
-                os.environ.pop("STEP_WGRAD_MINPIX", None)
-            else:
-                os.environ["STEP_WGRAD_MINPIX"] = minpix
+        for minpix in (64, 256, 0):
+            _capi.set_option(bk.lib, "wgrad_minpix", minpix)
             for (N, Cin, Cout, D, H, W, k) in cases:
                 x = rs.randn(N, Cin, D, H, W).astype(np.float32)
                 gy = rs.randn(N, Cout, D, H, W).astype(np.float32)
@@ -1022,10 +889,7 @@ def case_conv_wgrad(bk, golden):
                     err2 = np.abs(dw.get() - 2 * ref).max() / np.abs(ref).max()
                     assert err2 < 4e-5, err2
     finally:
-        if saved is None:
-            os.environ.pop("STEP_WGRAD_MINPIX", None)
-        else:
-            os.environ["STEP_WGRAD_MINPIX"] = saved
+        _capi.set_option(bk.lib, "wgrad_minpix", 0)
 
     d = _capi.ConvDesc(dtype=F32, N=1, D=1, H=4, W=4, Cin=8, Cout=8, kd=1, kh=2, kw=2, x_cstride=8, x_coff=0, y_cstride=8, y_coff=0,
                        res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)
@@ -1041,16 +905,11 @@ def case_conv_wgrad16(bk, golden):
     cases += [(1, 64, 72, 3, 20, 14, (3, 3, 3)),     # two row chunks per plane (20 rows of 14 > 224 pixels), a ragged second co tile
               (2, 16, 32, 1, 3, 100, (3, 3, 3)),     # 100-pixel rows: one row per chunk, a single ci block
               (1, 392, 72, 2, 9, 40, (1, 1, 1))]     # pointwise through the LDS-tiled form (Cin >= 384): 720 pixels = 5 chunks + a ragged one, three ci tiles of 192 (the last one ragged)
-    saved = os.environ.get("STEP_WGRAD_MINPIX")
     try:
-        # "64" with STEP_WGRAD16_LDS=0: the per-tap 16-bit form with several row-range jobs per tile; None: the LDS-tiled form
-        for minpix in ("64", None):
-            if minpix is None:
-                os.environ.pop("STEP_WGRAD_MINPIX", None)
-                os.environ.pop("STEP_WGRAD16_LDS", None)
-            else:
-                os.environ["STEP_WGRAD_MINPIX"] = minpix
-                os.environ["STEP_WGRAD16_LDS"] = "0"
+        # 64 with wgrad16_lds = 0: the per-tap 16-bit form with several row-range jobs per tile; None: the LDS-tiled form
+        for minpix in (64, None):
+            _capi.set_option(bk.lib, "wgrad_minpix", minpix or 0)
+            _capi.set_option(bk.lib, "wgrad16_lds", 1 if minpix is None else 0)
             for (N, Cin, Cout, D, H, W, k) in cases:
                 x = rs.randn(N, Cin, D, H, W).astype(np.float32)
                 gy = rs.randn(N, Cout, D, H, W).astype(np.float32)
@@ -1087,11 +946,8 @@ def case_conv_wgrad16(bk, golden):
                         assert bk.lib.step_conv_wgrad16_ws(ctypes.byref(d), xd.ptr, gd.ptr, dw2.ptr, 1, ws.ptr, nb, bk.stream) == 0
                         assert np.abs(dw2.get() - 2 * ref).max() / np.abs(ref).max() < 4e-5
     finally:
-        os.environ.pop("STEP_WGRAD16_LDS", None)
-        if saved is None:
-            os.environ.pop("STEP_WGRAD_MINPIX", None)
-        else:
-            os.environ["STEP_WGRAD_MINPIX"] = saved
+        _capi.set_option(bk.lib, "wgrad_minpix", 0)
+        _capi.set_option(bk.lib, "wgrad16_lds", 1)
     d = _capi.ConvDesc(dtype=F32, N=1, D=1, H=4, W=4, Cin=8, Cout=8, kd=1, kh=1, kw=1, x_cstride=8, x_coff=0, y_cstride=8, y_coff=0,
                        res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)
     z = bk.dev(np.zeros(64, np.float32))
@@ -1193,15 +1049,13 @@ def case_conv_split_two_destinations(bk, golden):
 def case_conv_general_box_row_groups(bk, golden):
     """General boxes whose width is just below a multiple of 16 (the 14- and 28-wide C2 maps, 13): the accumulator rows are
     assigned so that every 16-lane LDS read group is one run of columns of one box row (p.gmode = 1).  Same pixels, same
-    per-pixel accumulation order: bit-identical to the linear walk (STEP_CONV_GMODE=0) and within tolerance of the oracle;
+    per-pixel accumulation order: bit-identical to the linear walk (option conv_gmode = 0) and within tolerance of the oracle;
     the plan says which mode ran."""
-    import os
     rs = np.random.RandomState(41)
     # (N, Cin, Cout, D, H, W, k)
     cases = ((1, 64, 64, 8, 14, 14, (3, 3, 3)), (1, 64, 40, 4, 9, 28, (3, 3, 3)), (1, 64, 64, 8, 12, 28, (3, 3, 3)),
              (2, 64, 96, 6, 14, 14, (3, 3, 3)), (1, 64, 64, 2, 10, 30, (3, 3, 3)))
-    keep, keepw = os.environ.get("STEP_CONV_GMODE"), os.environ.get("STEP_CONV_WAVES")
-    os.environ["STEP_CONV_WAVES"] = "8"                       # (the 256-pixel tiles: boxes of 14 x 14, 2 x 4 x 28, ...)
+    _capi.set_option(bk.lib, "conv_waves", 8)                 # (the 256-pixel tiles: boxes of 14 x 14, 2 x 4 x 28, ...)
     grouped = 0
     try:
         for (N, Cin, Cout, D, H, W, k) in cases:
@@ -1213,7 +1067,7 @@ def case_conv_general_box_row_groups(bk, golden):
                 ref = ref_conv(x, w, scale, shift, dt)
                 outs = {}
                 for mode in ("1", "0"):
-                    os.environ["STEP_CONV_GMODE"] = mode
+                    _capi.set_option(bk.lib, "conv_gmode", int(mode))
                     d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2], x_cstride=Cin, x_coff=0,
                                        y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
                     info = (ctypes.c_int * 10)()
@@ -1227,28 +1081,23 @@ def case_conv_general_box_row_groups(bk, golden):
                 assert np.array_equal(outs["1"], outs["0"]), (W, dt)
         assert grouped >= 4, grouped                                                      # (the mode really ran)
     finally:
-        for k_, v_ in (("STEP_CONV_GMODE", keep), ("STEP_CONV_WAVES", keepw)):
-            if v_ is None:
-                os.environ.pop(k_, None)
-            else:
-                os.environ[k_] = v_
+        _capi.set_option(bk.lib, "conv_gmode", 1)
+        _capi.set_option(bk.lib, "conv_waves", 0)
 
 
 def case_conv_tail_round_split(bk, golden):
     """A layer that is one channel group deep and whose pixel tiles end in a small partial round of one-workgroup-per-CU slots is
     launched in two parts: the full rounds at NB = 3 and the tail tiles at NB = 1 (three times as many, shorter workgroups).
-    At interpreter size with STEP_CONV_SLOTS=4 (9 tiles: two rounds + one tile): same result, bit for bit, as the single launch."""
-    import os
+    At interpreter size with option conv_slots = 4 (9 tiles: two rounds + one tile): same result, bit for bit, as the single launch."""
     rs = np.random.RandomState(43)
     N, Cin, Cout, D, H, W = 1, 64, 192, 4, 24, 24
     x = rs.randn(N, Cin, D, H, W).astype(np.float32)
     w = (rs.randn(Cout, Cin, 3, 3, 3) / np.sqrt(Cin * 27)).astype(np.float32)
     scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32)
     shift = (0.2 * rs.randn(Cout)).astype(np.float32)
-    keys = ("STEP_CONV_SLOTS", "STEP_CONV_TAIL", "STEP_CONV_NB", "STEP_CONV_WAVES")
-    keep = {k_: os.environ.get(k_) for k_ in keys}
     try:
-        os.environ.update({"STEP_CONV_SLOTS": "4", "STEP_CONV_NB": "3", "STEP_CONV_WAVES": "8"})
+        for k_, v_ in (("conv_slots", 4), ("conv_nb", 3), ("conv_waves", 8)):
+            _capi.set_option(bk.lib, k_, v_)
         for dt in (BF16, F32):
             d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=3, kh=3, kw=3, x_cstride=Cin, x_coff=0, y_cstride=Cout, y_coff=0,
                                res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
@@ -1258,24 +1107,20 @@ def case_conv_tail_round_split(bk, golden):
             ref = ref_conv(x, w, scale, shift, dt)
             outs = {}
             for mode in ("1", "0"):
-                os.environ["STEP_CONV_TAIL"] = mode
+                _capi.set_option(bk.lib, "conv_tail", int(mode))
                 outs[mode] = run_conv(bk, x, w, scale, shift, dt)
                 assert np.abs(outs[mode] - ref).max() / np.abs(ref).max() < tol(dt), (mode, dt)
             assert np.array_equal(outs["1"], outs["0"]), dt
     finally:
-        for k_, v_ in keep.items():
-            if v_ is None:
-                os.environ.pop(k_, None)
-            else:
-                os.environ[k_] = v_
+        for k_, v_ in (("conv_slots", 0), ("conv_nb", 0), ("conv_waves", 0), ("conv_tail", 1)):
+            _capi.set_option(bk.lib, k_, v_)
 
 
 def case_conv_pointwise_weight_stationary(bk, golden):
-    """conv_pws_kernel (the weight-stationary short-K pointwise stream, STEP_CONV_PWS=1) against the oracle and against the
+    """conv_pws_kernel (the weight-stationary short-K pointwise stream, option conv_pws = 1) against the oracle and against the
     default kernel: one to four 64-channel steps, a K tail that is not a multiple of 64 or 32, one to four passes over the
     channel blocks with a partial last block, ragged pixel count, input and output channel slices, two destinations, no ReLU / no
     affine; K > 256 stays with the default kernels."""
-    import os
     rs = np.random.RandomState(31)
     # (N, Cin, Cout, D, H, W, split, relu, affine, x_pad, y_pad)
     cases = ((1, 64, 64, 2, 16, 33, 0, True, True, (0, 0), (0, 0)),
@@ -1285,7 +1130,6 @@ def case_conv_pointwise_weight_stationary(bk, golden):
              (2, 32, 200, 1, 24, 23, 0, True, True, (0, 0), (0, 0)),
              (1, 64, 296, 1, 16, 65, 96, True, True, (0, 0), (0, 0)),          # 10 blocks: four passes
              (1, 256, 328, 1, 16, 65, 0, True, True, (0, 0), (0, 0)))          # 11 blocks x 16 chunks > 152: two workgroup-level channel groups
-    keep = os.environ.get("STEP_CONV_PWS")
     try:
         for (N, Cin, Cout, D, H, W, split, relu, affine, xp, yp) in cases:
             x = rs.randn(N, Cin, D, H, W).astype(np.float32)
@@ -1302,7 +1146,7 @@ def case_conv_pointwise_weight_stationary(bk, golden):
                 sc, sh = bk.dev(scale), bk.dev(shift)
                 outs = {}
                 for mode in ("1", "0"):
-                    os.environ["STEP_CONV_PWS"] = mode
+                    _capi.set_option(bk.lib, "conv_pws", int(mode))
                     ya = bk.dev(np.zeros((N, D, H, W, yp[0] + ca + yp[1]), NP_DT[dt]))
                     yb = bk.dev(np.zeros((N, D, H, W, 8 + (Cout - ca)), NP_DT[dt]))
                     d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=xb.shape[-1], x_coff=xp[0],
@@ -1325,10 +1169,7 @@ def case_conv_pointwise_weight_stationary(bk, golden):
                 # same operands, same fp32 accumulation order along K: the two kernels agree to the last bit
                 assert np.array_equal(outs["1"], outs["0"]), (Cin, Cout, dt)
     finally:
-        if keep is None:
-            os.environ.pop("STEP_CONV_PWS", None)
-        else:
-            os.environ["STEP_CONV_PWS"] = keep
+        _capi.set_option(bk.lib, "conv_pws", -1)
 
 
 def case_pack_weight_perm_folds_flatten_order(bk, golden):
@@ -1361,36 +1202,6 @@ def _stem_case(bk, shape, dts, Cout):
         assert got.shape == ref.shape
         err = np.abs(got - ref).max() / np.abs(ref).max()
         assert err < tol(dt), (shape, dt, err)
-
-
-def case_stem_tail_round_split(bk, golden):
-    """The stem's partial last round as a second launch with one 32-channel block per workgroup (stem_stream_kernel<T, 1>, tile
-    offset; opt-in STEP_STEM_TAIL=1 -- measured slower on the C2 stem): at interpreter size through STEP_CONV_SLOTS (24 tiles,
-    20 slots: 20 + 4) the result equals the single launch bit for bit and the oracle within tolerance."""
-    import os
-    N, T, H, W, Cout = 1, 8, 40, 72, 64                    # To = 4, 2 x 3 tiles of 16 x 16 per frame: 24 tiles
-    rs = np.random.RandomState(47)
-    x = rs.uniform(-1, 1, (N, T, 3, H, W)).astype(np.float32)
-    w = (rs.randn(Cout, 3, 7, 7, 7) / np.sqrt(1029)).astype(np.float32)
-    scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32)
-    shift = (0.2 * rs.randn(Cout)).astype(np.float32)
-    keep = {k_: os.environ.get(k_) for k_ in ("STEP_CONV_SLOTS", "STEP_STEM_TAIL")}
-    try:
-        os.environ["STEP_CONV_SLOTS"] = "20"
-        for dt in (BF16, F16):
-            ref = ref_stem(x, w, scale, shift, dt)
-            outs = {}
-            for mode in ("1", "0"):
-                os.environ["STEP_STEM_TAIL"] = mode
-                outs[mode] = run_stem(bk, x, w, scale, shift, dt)
-                assert np.abs(outs[mode] - ref).max() / np.abs(ref).max() < tol(dt), (mode, dt)
-            assert np.array_equal(outs["1"], outs["0"]), dt
-    finally:
-        for k_, v_ in keep.items():
-            if v_ is None:
-                os.environ.pop(k_, None)
-            else:
-                os.environ[k_] = v_
 
 
 def case_stem(bk, golden):
@@ -1456,8 +1267,8 @@ def big_nms(bk, golden):
 def big_wgrad_full_size_properties(bk, golden):
     """Weight gradients at the C4 layer sizes (AVA clip: conv3d_2c on 18x100x100, a 25x25 Inception conv, the heads' convs on
     7x7 maps), where no CPU oracle finishes in seconds -- size-independent properties instead:
-      * the job split does not matter: one-row jobs (STEP_WGRAD_MINPIX=16), the default and one job per tile
-        (STEP_WGRAD_MINPIX=10^6) agree to fp32 summation-order noise;
+      * the job split does not matter: one-row jobs (option wgrad_minpix = 16), the default and one job per tile
+        (wgrad_minpix = 10^6) agree to fp32 summation-order noise;
       * linearity in dy: wgrad(x, a + b) == wgrad(x, a) + wgrad(x, b);
       * a checksum against a dense contraction: sum over taps and input channels of dw[co] for an all-ones x equals the
         (border-clipped) tap counts times sum(dy[co]) -- evaluated in closed form."""
@@ -1472,25 +1283,17 @@ def big_wgrad_full_size_properties(bk, golden):
         d = _capi.ConvDesc(dtype=F32, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2], x_cstride=Cin, x_coff=0,
                            y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)
 
-        def wg(xbuf, dy, minpix=None):
-            saved = os.environ.get("STEP_WGRAD_MINPIX")
-            if minpix is not None:
-                os.environ["STEP_WGRAD_MINPIX"] = minpix
-            try:
+        def wg(xbuf, dy, minpix=0):
+            with _capi.options(bk.lib, wgrad_minpix=minpix):
                 dw = bk.dev(np.zeros((Cout, Cin) + k, np.float32))
                 assert bk.lib.step_conv_wgrad(ctypes.byref(d), xbuf.ptr, bk.dev(dy).ptr, dw.ptr, 0, bk.stream) == 0
                 return dw.get()
-            finally:
-                if saved is None:
-                    os.environ.pop("STEP_WGRAD_MINPIX", None)
-                else:
-                    os.environ["STEP_WGRAD_MINPIX"] = saved
 
         base = wg(xd, a)
         scale = np.abs(base).max()
         # one job per tile = one fp32 chain over every pixel of the map (180 000 terms for conv3d_2c): its rounding noise
         # grows with the chain length, hence the wider bound there
-        for mp, bound in (("16", 2e-5), ("1000000", 1e-4)):
+        for mp, bound in ((16, 2e-5), (1000000, 1e-4)):
             assert np.abs(wg(xd, a, mp) - base).max() < bound * scale, (Cin, Cout, k, mp)
         assert np.abs(wg(xd, a + b) - (base + wg(xd, b))).max() < 2e-5 * scale, (Cin, Cout, k)
         ones = bk.dev(np.ones((N, D, H, W, Cin), np.float32))
@@ -1535,4 +1338,4 @@ def big_adam_full_size(bk, golden):
         assert float(G.abs().max()) == 0.0
 
 
-GPU_ONLY = ["big_conv_shapes", "big_pool3_conv1", "big_stem", "big_roi", "big_nms", "big_wgrad_full_size_properties", "big_adam_full_size"]
+GPU_ONLY = ["big_conv_shapes", "big_stem", "big_roi", "big_nms", "big_wgrad_full_size_properties", "big_adam_full_size"]

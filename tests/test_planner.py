@@ -14,11 +14,8 @@ LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 def lib():
     if not os.path.exists(LIB):
         pytest.skip("libstep_amd.so not built (python -c 'import __graft_entry__ as g; g.build()')")
-    for k in ("STEP_CONV_IMPL", "STEP_CONV_GEN", "STEP_CONV_NB", "STEP_CONV_SPLITK"):
-        assert not os.environ.get(k), "planner test needs the default dispatch (unset %s)" % k
-    L = ctypes.CDLL(LIB)
-    L.step_conv_kernel_name.restype = ctypes.c_int
-    L.step_conv_workspace_bytes.restype = ctypes.c_size_t
+    L = _capi.declare(ctypes.CDLL(LIB))
+    L.step_reset_options()                  # the default dispatch
     return L
 
 
@@ -69,3 +66,26 @@ def test_abi_and_symbols(lib):
     for sym in sorted(declared):
         assert hasattr(lib, sym), "declared in the header but not exported: " + sym
     assert declared == set(_capi.SIGNATURES), (sorted(declared - set(_capi.SIGNATURES)), sorted(set(_capi.SIGNATURES) - declared))
+
+
+def test_options_api_and_no_environment(lib):
+    """step_set_option / step_get_option: names and ids agree with step_amd/_capi.py, range checks, the context manager restores,
+    an option really moves the planner -- and the library source reads no environment variable."""
+    import glob
+
+    for nm, k in _capi.OPTION_IDS.items():
+        assert lib.step_option_name(k).decode() == nm
+    assert lib.step_option_name(len(_capi.OPTION_IDS)) is None
+    assert lib.step_set_option(999, 1) == -2 and lib.step_set_option(_capi.OPTION_IDS["conv_waves"], 5) == -2
+    BF = _capi.BF16
+    base, _ = name(lib, BF, 8, 96, 208, (3, 3, 3), 8, 14, 14)
+    assert base.endswith(", 2, 2, 8, 1>(step::ConvParams)"), base
+    with _capi.options(lib, conv_phased=0, conv_waves=4):
+        assert _capi.get_option(lib, "conv_phased") == 0
+        n4, _ = name(lib, BF, 8, 96, 208, (3, 3, 3), 8, 14, 14)
+        assert n4.endswith(", 2, 4, 0>(step::ConvParams)"), n4
+    assert _capi.get_option(lib, "conv_phased") == 1 and _capi.get_option(lib, "conv_waves") == 0
+    assert name(lib, BF, 8, 96, 208, (3, 3, 3), 8, 14, 14)[0] == base
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in glob.glob(os.path.join(root, "step_amd", "csrc", "*.h*")):
+        assert "getenv" not in open(f).read(), f

@@ -1,10 +1,10 @@
 """tools/ab_bench.py -- interleaved A/B timing of planner variants per layer (GPU only, tuning aid).
 
 Every layer of the C2 backbone (the fused 1x1x1 triples as the net really launches them) is timed under several
-environment settings of the launch planner (STEP_CONV_WAVES=8|4, ...), interleaved in ONE process (round-robin over the
+planner options (step_set_option: conv_waves=8|4, ...), interleaved in ONE process (round-robin over the
 variants, median over rounds) as cdna_hip_programming.md 5.4 rule 24 asks.
 
-    python tools/ab_bench.py [--batch 8] [--rounds 7] [--iters 10] [--set c2|c3] [--var "STEP_CONV_WAVES=8" --var "STEP_CONV_WAVES=4"]
+    python tools/ab_bench.py [--batch 8] [--rounds 7] [--iters 10] [--set c2|c3] [--var "conv_waves=8" --var "conv_waves=4"]
 """
 import argparse
 import ctypes
@@ -37,64 +37,6 @@ C3 = [
 ]
 
 
-# branch_3 of the Inception blocks: (name, Cin, Cout, D, H, W) per clip at C2
-B3 = [("3b_b3", 192, 32, 16, 28, 28), ("3c_b3", 256, 64, 16, 28, 28), ("4b_b3", 480, 64, 8, 14, 14), ("4c_b3", 512, 64, 8, 14, 14),
-      ("4d_b3", 512, 64, 8, 14, 14), ("4e_b3", 512, 64, 8, 14, 14), ("4f_b3", 528, 128, 8, 14, 14)]
-
-
-def bench_b3(a):
-    """pool 3x3x3/1 + 1x1x1 unit: two launches against the fused step_pool3_conv1_forward, interleaved."""
-    L = _lib.lib()
-    dt, tdt = _capi.BF16, torch.bfloat16
-    dev = torch.device("cuda:0")
-    st = _lib.stream_ptr()
-    B = a.batch
-    tot = [0.0, 0.0]
-    print("%-8s %22s %22s" % ("layer", "pool + conv (2 launches)", "fused"))
-    for name, ci, co, D, H, W in B3:
-        x = torch.randn(B, D, H, W, ci, device=dev).to(tdt)
-        w = torch.randn(co, ci, 1, 1, 1, device=dev) * (1.0 / ci ** 0.5)
-        wp = torch.empty(L.step_conv_packed_elems(co, ci, 1, 1, 1), dtype=tdt, device=dev)
-        _capi.check(L.step_conv_pack_weight(_lib.dptr(w), co, ci, 1, 1, 1, dt, None, _lib.dptr(wp), st), "pack")
-        sc, sh = torch.ones(co, device=dev), torch.zeros(co, device=dev)
-        pbuf = torch.empty(B, D, H, W, ci, dtype=tdt, device=dev)
-        y = [torch.empty(B, D, H, W, co, dtype=tdt, device=dev) for _ in range(2)]
-        d = _capi.ConvDesc(dtype=dt, N=B, D=D, H=H, W=W, Cin=ci, Cout=co, kd=1, kh=1, kw=1, x_cstride=ci, x_coff=0,
-                           y_cstride=co, y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
-
-        def two():
-            _capi.check(L.step_maxpool3d_tf(dt, _lib.dptr(x), B, D, H, W, ci, ci, 0, 3, 3, 3, 1, 1, 1, _lib.dptr(pbuf), ci, 0, st), "pool")
-            _capi.check(L.step_conv_forward(ctypes.byref(d), _lib.dptr(pbuf), _lib.dptr(wp), _lib.dptr(sc), _lib.dptr(sh), None, _lib.dptr(y[0]), None, st), "conv")
-
-        def fused():
-            _capi.check(L.step_pool3_conv1_forward(ctypes.byref(d), _lib.dptr(x), _lib.dptr(wp), _lib.dptr(sc), _lib.dptr(sh), _lib.dptr(y[1]), st), "fused")
-
-        fns = (two, fused)
-        for f in fns:
-            f()
-        torch.cuda.synchronize()
-        assert torch.equal(y[0], y[1]), name
-        times = [[], []]
-        for _ in range(a.rounds):
-            for vi, f in enumerate(fns):
-                f()
-                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record()
-                for _ in range(a.iters):
-                    f()
-                e.record()
-                torch.cuda.synchronize()
-                times[vi].append(s.elapsed_time(e) / a.iters)
-        med = [statistics.median(t) for t in times]
-        mb = B * D * H * W * (ci + co) * 2 / 1e6
-        kn = ctypes.create_string_buffer(256)
-        L.step_pool3_conv1_kernel_name(ctypes.byref(d), kn, 256)
-        print("%-8s %12.1f us %20.1f us %6.0f GB/s  %s" % (name, med[0] * 1e3, med[1] * 1e3, mb / med[1], kn.value.decode()[11:].split("(")[0]))
-        tot[0] += med[0]
-        tot[1] += med[1]
-    print("%-8s %12.1f us %20.1f us" % ("total", tot[0] * 1e3, tot[1] * 1e3))
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
@@ -104,11 +46,9 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--custom", action="append", default=[], help="name,Cin,Cout,k,D,H,W (repeatable; replaces the layer set)")
     ap.add_argument("--nocheck", action="store_true", help="variants may compute different things (timing experiments)")
-    ap.add_argument("--var", action="append", default=[], help="KEY=VAL[,KEY=VAL] environment of one variant (repeatable)")
+    ap.add_argument("--var", action="append", default=[], help="option=VAL[,option=VAL] planner options of one variant, or `default` (repeatable)")
     a = ap.parse_args()
-    if a.set == "b3":
-        return bench_b3(a)
-    variants = a.var or ["STEP_CONV_WAVES=8", "STEP_CONV_WAVES=4"]
+    variants = a.var or ["conv_waves=8", "conv_waves=4"]
     L = _lib.lib()
     dt, tdt = _capi.BF16, torch.bfloat16
     dev = torch.device("cuda:0")
@@ -138,13 +78,12 @@ def main():
         def run():
             _capi.check(L.step_conv_forward(ctypes.byref(d), _lib.dptr(x), _lib.dptr(wp), _lib.dptr(sc), _lib.dptr(sh), None, _lib.dptr(y), None, st), name)
 
-        def setenv(v):
+        def setenv(v):                       # a variant = planner options (include/step_amd.h), everything else at its default
+            L.step_reset_options()
             for kv in v.split(","):
-                kk, vv = kv.split("=")
-                if vv == "":
-                    os.environ.pop(kk, None)
-                else:
-                    os.environ[kk] = vv
+                if kv and kv != "default":
+                    kk, vv = kv.split("=")
+                    _capi.set_option(L, kk, int(vv))
 
         times = [[] for _ in variants]
         names = []
@@ -178,6 +117,7 @@ def main():
             tot[vi] += med[vi]
         print("%-8s %s" % (name, "  ".join("%7.1f us %6.0f TF %-12s" % (m * 1e3, gf / m, n[-14:]) for m, n in zip(med, names))))
     print("%-8s %s" % ("total", "  ".join("%7.1f us %21s" % (t * 1e3, "") for t in tot)))
+    L.step_reset_options()
 
 
 if __name__ == "__main__":

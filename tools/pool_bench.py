@@ -1,6 +1,5 @@
 """tools/pool_bench.py -- the max pools of the C2 backbone (and the AVA-shaped maps with --set c3) one by one: us per launch and
-algorithmic GB/s (input + output bytes).  The kernel form is chosen by the library's environment switches (STEP_POOL_REG=1: the
-register form), read once per process -- run the script once per variant.  GPU only, tuning aid."""
+algorithmic GB/s (input + output bytes).  GPU only, tuning aid."""
 import argparse
 import os
 import sys

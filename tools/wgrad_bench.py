@@ -6,7 +6,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from step_amd import ops  # noqa: E402
+from step_amd import _capi, _lib, ops  # noqa: E402
 
 # (name, N, Cin, Cout, k, D, H, W)
 LAYERS = [("2c@400", 1, 64, 192, 3, 18, 100, 100), ("3c_b1b@400", 1, 128, 192, 3, 18, 50, 50), ("4f_b1b@400", 1, 160, 320, 3, 9, 25, 25),
@@ -37,7 +37,7 @@ def main():
                 g32 = gy16.float()
                 fn = lambda: ops.conv_wgrad(x, g32, co, (k, k, k))
             else:
-                os.environ["STEP_WGRAD16_LDS"] = "1" if row == "lds" else "0"
+                _capi.set_option(_lib.lib(), "wgrad16_lds", 1 if row == "lds" else 0)
                 fn = lambda: ops.conv_wgrad16(x, gy16, co, (k, k, k))
             out = fn()
             torch.cuda.synchronize()
