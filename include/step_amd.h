@@ -78,7 +78,6 @@ enum {
     STEP_OPT_POOL_DIRECT,      /*  0 (default) | 1: every max pool on the general 27-tap kernel (tests) */
     STEP_OPT_WGRAD_MINPIX,     /*  0 (default: 512) | n: least pixels per wavefront job of step_conv_wgrad (fp32 summation order) */
     STEP_OPT_WGRAD16_LDS,      /*  1 (default) | 0: 3x3 windows of step_conv_wgrad16_ws on the per-tap kernel instead of the LDS-tiled GEMM */
-    STEP_OPT_CONV_DESYNC,      /*  0 (default) | n: first-round conv_tap workgroups start up to n x 64 clocks apart (de-phases the CUs' store bursts) */
     STEP_OPT_COUNT_
 };
 STEP_API int step_set_option(int option, int value);

@@ -83,6 +83,50 @@ def main():
     print("reference utils.utils.inference over dropin/ models == step_amd.driver.inference: %d iterations, worst rel. difference %.2e" %
           (len(h_ref), worst))
 
+    # ---- the wrapper code of test.py:62-98 / train.py:129-148 / demo.py:62-96, line for line, over the drop-in: nets built from
+    # `models`, base_net / context_net wrapped in torch.nn.DataParallel UNCONDITIONALLY, checkpoints (whose keys carry the wrapper's
+    # "module." prefix, train.py:380-381) loaded THROUGH the wrapper, `.eval()` on every entry, then
+    # nets['base_net'](images) -> nets['context_net'](conv_feat) -> the reference's inference().  With no / one visible device
+    # DataParallel calls the module itself; tests/module_cases.py::case_data_parallel_replicas covers the replicated path.
+    from collections import OrderedDict
+    with emulated_kernels(), torch.no_grad():
+        nets = OrderedDict()
+        nets["base_net"] = models.BaseNet(args)
+        nets["roi_net"] = models.ROINet(args.pool_mode, args.pool_size)
+        for i in range(args.max_iter):
+            nets["det_net%d" % i] = models.TwoBranchNet(args)
+        nets["context_net"] = models.ContextNet(args)
+        checkpoint = {}
+        for key in ("base_net", "context_net"):
+            shapes = {k: tuple(v.shape) for k, v in nets[key].state_dict().items()}
+            checkpoint[key] = {"module." + k: v for k, v in R.fill_state_dict(shapes).items()}
+        for i in range(args.max_iter):
+            shapes = {k: tuple(v.shape) for k, v in nets["det_net%d" % i].state_dict().items()}
+            checkpoint["det_net%d" % i] = R.fill_state_dict(shapes, "det%d." % i)
+        nets["base_net"] = torch.nn.DataParallel(nets["base_net"])
+        nets["context_net"] = torch.nn.DataParallel(nets["context_net"])
+        for i in range(args.max_iter):
+            nets["det_net%d" % i].set_device("cpu")
+        nets["base_net"].load_state_dict(checkpoint["base_net"])
+        nets["context_net"].load_state_dict(checkpoint["context_net"])
+        for i in range(args.max_iter):
+            nets["det_net%d" % i].load_state_dict(checkpoint["det_net%d" % i])
+        for _, net in nets.items():
+            net.eval()
+        images = R.fill_tensor("golden.c1.images", (1, 8, 3, 112, 112), "image")
+        feat = nets["base_net"](images)                         # test.py:141
+        g = np.load(os.path.join(ROOT, "tests", "golden", "i3d_c1_golden.npz"))["conv_feat"]
+        e1 = float(np.abs(feat.float().numpy() - g).max() / np.abs(g).max())
+        assert tuple(feat.shape) == g.shape and e1 < 1e-4, e1
+        context_feat = nets["context_net"](conv_feat[:, :3])  # test.py:144 (three frames: the interpreter's budget)
+        gc = np.load(os.path.join(ROOT, "tests", "golden", "head_golden.npz"))
+        assert tuple(context_feat.shape) == (B, 1024, 3, 1, 1)
+        h2, _ = ref_utils.inference(args, conv_feat, context, nets, args.max_iter, [t.copy() for t in tubes])      # test.py:152
+        for a, b in zip(h2, h_ref):
+            assert torch.equal(a["pred_prob"], b["pred_prob"]) and torch.equal(a["pred_loc"], b["pred_loc"])
+    print("test.py's wrapper code (DataParallel(base_net) / DataParallel(context_net), module.-prefixed checkpoints, .eval()) over dropin/: "
+          "base_net C1 rel. error %.2e, inference history identical" % e1)
+
 
 if __name__ == "__main__":
     main()

@@ -188,7 +188,7 @@ def _repack_all(dtype, device):
             perm = u._perm_dev.get(device)
             if perm is None:
                 perm = u._perm_dev[device] = u.perm.to(device=device, dtype=torch.int32).contiguous()
-        for key, hit in u._packed.items():
+        for key, hit in list(u._packed.items()):             # (replicas on other devices add their images to the same dict)
             if key[0] != dtype or key[1] != device or hit[0] == ver:
                 continue
             cpad = key[2] if len(key) > 2 else 0
@@ -220,14 +220,16 @@ class ConvUnit:
     to input channels [lo, hi) of the weight (a conv over a channel concat becomes two accumulating
     launches)."""
 
-    def __init__(self, owner, weight_fn, k, bn=None, bias_fn=None, perm=None, cin_slice=None, version_fn=None):
+    def __init__(self, owner, weight_fn, k, bn_fn=None, bias_fn=None, perm=None, cin_slice=None, version_fn=None):
         # The getters take the OWNING MODULE as their argument instead of closing over it: copy.deepcopy() copies a
         # function by reference, so a closure would keep reading the ORIGINAL module's parameters from the copy's
         # forward; `owner` is deep-copied through the memo and becomes the copy.
         self.owner = owner
-        self._wf, self._bf, self._vf = weight_fn, bias_fn, version_fn
+        # (the BatchNorm module too is reached through the owner: nn.DataParallel re-points a replica's children AFTER it copied
+        # the module, so a stored reference would stay on the original)
+        self._wf, self._bf, self._vf, self._bnf = weight_fn, bias_fn, version_fn, bn_fn
         self.bias_fn = None if bias_fn is None else self._bias
-        self.bn = bn
+        self._src = None           # nn.DataParallel replica: the unit of the ORIGINAL module (versions and caches live there)
         self.k = tuple(k)
         self.perm, self.cin_slice = perm, cin_slice
         # version_fn: key of the packed-weight cache when weight_fn() builds a NEW tensor on every call (a torch.cat of
@@ -235,8 +237,33 @@ class ConvUnit:
         self.version_fn = None if version_fn is None else self._version
         self._packed = {}          # (dtype, device) -> (version, forward image); (dtype, device, cin_pad) -> data-gradient image
         self._perm_dev = {}
-        self._affine = None
+        self._affine = {}          # device -> (version, scale, shift)
         _UNITS.add(self)
+
+    @property
+    def bn(self):
+        return None if self._bnf is None else self._bnf(self.owner)
+
+    def replica_for(self, owner):
+        """The unit of an nn.DataParallel replica of the owning module (torch.nn.parallel.replicate copies a module's __dict__
+        every forward and hands the copy broadcast, non-leaf tensors of another device): same conv, getters bound to the REPLICA
+        (its device's tensors), versions taken from the ORIGINAL's parameters (a fresh broadcast copy says nothing about the
+        optimizer steps behind it) and caches shared with the original, keyed by device -- so a device's packed images survive
+        from one forward's replica to the next.  Not in the batched re-pack registry (each replica packs its own weight)."""
+        r = object.__new__(ConvUnit)
+        r.__dict__ = dict(self.__dict__)
+        r.owner = owner
+        r._src = self._src or self
+        r.bias_fn = None if r._bf is None else r._bias
+        r.version_fn = None if r._vf is None else r._version
+        return r
+
+    def _wver(self, w):
+        """cache version of the image packed from weight tensor w (this unit's device)"""
+        if self._src is None:
+            return _ver(w)
+        ws = self._src.weight_fn()
+        return ((ws.data_ptr(), ws._version, w.device),)
 
     def weight_fn(self):
         return self._wf(self.owner)
@@ -245,12 +272,14 @@ class ConvUnit:
         return self._bf(self.owner)
 
     def _version(self):
-        return self._vf(self.owner)
+        if self._src is None:
+            return self._vf(self.owner)
+        dev = self._vf(self.owner)[0][2]                         # replica: the original's versions on this replica's device
+        return tuple((a, b, dev) for a, b, _ in self._src._vf(self._src.owner))
 
     def __deepcopy__(self, memo):
         import copy
-        new = ConvUnit(copy.deepcopy(self.owner, memo), self._wf, self.k, copy.deepcopy(self.bn, memo), self._bf, self.perm,
-                       self.cin_slice, self._vf)
+        new = ConvUnit(copy.deepcopy(self.owner, memo), self._wf, self.k, self._bnf, self._bf, self.perm, self.cin_slice, self._vf)
         memo[id(self)] = new
         return new                                               # (caches start empty: they hold device buffers of the original)
 
@@ -281,9 +310,9 @@ class ConvUnit:
         else:
             w = self.weight_fn()
             key = (dtype, w.device)
-            ver = _ver(w)
+            ver = self._wver(w)
             hit = self._packed.get(key)
-        if hit is not None and hit[0] != ver and self.version_fn is None and BATCH_PACK and _repack_all(dtype, w.device):
+        if hit is not None and hit[0] != ver and self.version_fn is None and self._src is None and BATCH_PACK and _repack_all(dtype, w.device):
             hit = self._packed.get(key)                          # every stale image of the net, this one included, in one launch
         if hit is None or hit[0] != ver:
             with torch.no_grad():
@@ -297,9 +326,9 @@ class ConvUnit:
             return ops.pack_conv_weight_dgrad(w_eff, dtype, cin_pad)
         w = self.weight_fn()
         key = (dtype, w.device, cin_pad)
-        ver = _ver(w)
+        ver = self._wver(w)
         hit = self._packed.get(key)
-        if hit is not None and hit[0] != ver and BATCH_PACK and _repack_all(dtype, w.device):
+        if hit is not None and hit[0] != ver and self._src is None and BATCH_PACK and _repack_all(dtype, w.device):
             hit = self._packed.get(key)
         if hit is None or hit[0] != ver:
             with torch.no_grad():
@@ -322,12 +351,15 @@ class ConvUnit:
                                           "on the owning net so that BN modules are in eval mode")
             if differentiable and (bn.weight.requires_grad or bn.bias.requires_grad):
                 return self._bn_affine()
-            ver = _ver(bn.weight, bn.bias, bn.running_mean, bn.running_var)
-            if self._affine is None or self._affine[0] != ver:
+            dev = bn.weight.device
+            bv = bn if self._src is None else self._src.bn          # (replica: the original's versions, this device's values)
+            ver = tuple((a, b, dev) for a, b, _ in _ver(bv.weight, bv.bias, bv.running_mean, bv.running_var))
+            hit = self._affine.get(dev)
+            if hit is None or hit[0] != ver:
                 with torch.no_grad():
                     scale, shift = self._bn_affine()
-                self._affine = (ver, scale.contiguous(), shift.contiguous())
-            return self._affine[1], self._affine[2]
+                hit = self._affine[dev] = (ver, scale.contiguous(), shift.contiguous())
+            return hit[1], hit[2]
         if self.bias_fn is not None:
             b = self.bias_fn()
             return None, (b if b.dtype == torch.float32 else b.float())
@@ -355,18 +387,22 @@ class ConvUnit:
         return y
 
 
-def _no_data_parallel(self):
-    """nn.DataParallel replicates a module by shallow-copying its __dict__ every forward: the replicas would share the
-    original's ConvUnit helpers (device-0 parameters, device-0 packed-weight caches) and the module-level stream / profiling
-    state across threads.  The supported multi-GPU mode is one process per GPU (step_amd.dist: clip sharding + RCCL
-    gradient all-reduce, which is what replaces train.py:142-148); fail loudly instead of computing on the wrong device."""
-    raise RuntimeError("step_amd modules cannot be replicated by nn.DataParallel; run one process per GPU "
-                       "(torch.distributed + step_amd.dist.shard_clips / BucketedReducer), see INTEGRATION.md")
+def _replicate_with_units(self):
+    """nn.DataParallel support (train.py:142-144, test.py:82-84, demo.py:79-81 wrap base_net / context_net unconditionally).
+    torch.nn.parallel.replicate shallow-copies a module's __dict__ for every device on every forward; the helper objects a
+    step_amd module keeps next to its parameters (ConvUnit, _FusedPointwise) would otherwise stay bound to the ORIGINAL module
+    -- device-0 parameters, device-0 packed weights.  Each replica gets helpers bound to itself (ConvUnit.replica_for).
+    The fast multi-GPU mode remains one process per GPU (step_amd.dist); this makes the reference scripts run unchanged."""
+    replica = nn.Module._replicate_for_data_parallel(self)
+    for name, val in self.__dict__.items():
+        if isinstance(val, (ConvUnit, _FusedPointwise)):
+            replica.__dict__[name] = val.replica_for(replica)
+    return replica
 
 
 class Unit3D(nn.Module):
     """conv3d (+ frozen BN) + ReLU.  Keys: conv3d.weight[, conv3d.bias], batch3d.{weight,bias,running_*}."""
-    _replicate_for_data_parallel = _no_data_parallel
+    _replicate_for_data_parallel = _replicate_with_units
 
     def __init__(self, in_channels, out_channels, kernel_size=(1, 1, 1), stride=(1, 1, 1), use_bias=False, use_bn=True,
                  relu=True):
@@ -379,10 +415,10 @@ class Unit3D(nn.Module):
         if self.is_stem:
             assert self.stride == (2, 2, 2) and in_channels == 3
             self._stem_packed = {}
-            self._unit = ConvUnit(self, lambda m: m.conv3d.weight, (7, 7, 7), bn=getattr(self, "batch3d", None))
+            self._unit = ConvUnit(self, lambda m: m.conv3d.weight, (7, 7, 7), bn_fn=(lambda m: m.batch3d) if use_bn else None)
         else:
             assert self.stride == (1, 1, 1)
-            self._unit = ConvUnit(self, lambda m: m.conv3d.weight, self.kernel_size, bn=getattr(self, "batch3d", None),
+            self._unit = ConvUnit(self, lambda m: m.conv3d.weight, self.kernel_size, bn_fn=(lambda m: m.batch3d) if use_bn else None,
                                   bias_fn=(lambda m: m.conv3d.bias) if use_bias else None)
 
     def forward(self, x, out=None):
@@ -394,7 +430,7 @@ class Unit3D(nn.Module):
         """x is the clip in the reference layout [N,T,3,H,W]."""
         w = self.conv3d.weight
         key = (x.dtype, w.device)
-        ver = _ver(w)
+        ver = self._unit._wver(w)
         hit = self._stem_packed.get(key)
         if hit is None or hit[0] != ver:
             hit = (ver, ops.pack_stem_weight(w, x.dtype))
@@ -473,15 +509,27 @@ class _FusedPointwise:
     kernel's two-destination epilogue sends the first unit's channels to `out` and the rest to `out2`
     (the input is read once instead of three times; 2 launches fewer per block).  Inference only."""
 
-    def __init__(self, units):
-        self.units = units
-        self._cache = {}
+    def __init__(self, owner):
+        self.owner = owner               # the Mixed block: its children are read at call time (a DataParallel replica's are re-pointed after the copy)
+        self._src = None
+        self._cache = {}                 # (dtype, device) -> (version, packed, scale, shift, cout, split); shared with replicas
+
+    @staticmethod
+    def _units(m):
+        return (m.branch_0, m.branch_1[0], m.branch_2[0])
+
+    def replica_for(self, owner):
+        r = object.__new__(_FusedPointwise)
+        r.owner, r._src, r._cache = owner, self._src or self, self._cache
+        return r
 
     def __call__(self, x, out, out2):
-        us = self.units
-        key = (x.dtype, us[0].conv3d.weight.device)
-        ver = tuple(v for u in us for v in _ver(u.conv3d.weight, u.batch3d.weight, u.batch3d.bias, u.batch3d.running_mean,
-                                                u.batch3d.running_var))
+        us = self._units(self.owner)
+        dev = us[0].conv3d.weight.device
+        key = (x.dtype, dev)
+        vs = us if self._src is None else self._units(self._src.owner)     # (replica: the original's versions)
+        ver = tuple((a, b, dev) for u in vs for a, b, _ in _ver(u.conv3d.weight, u.batch3d.weight, u.batch3d.bias, u.batch3d.running_mean,
+                                                                u.batch3d.running_var))
         hit = self._cache.get(key)
         if hit is None or hit[0] != ver:
             with torch.no_grad():
@@ -497,6 +545,7 @@ class _FusedPointwise:
 
 class Mixed(nn.Module):
     """Inception block; the four branches write channel slices of one buffer (order b0,b1,b2,b3)."""
+    _replicate_for_data_parallel = _replicate_with_units
 
     def __init__(self, in_channels, oc):
         super().__init__()
@@ -506,7 +555,7 @@ class Mixed(nn.Module):
         self.branch_2 = nn.Sequential(Unit3D(in_channels, oc[3]), Unit3D(oc[3], oc[4], (3, 3, 3)))
         self.branch_3 = nn.Sequential(MaxPoolTF((3, 3, 3), (1, 1, 1)), Unit3D(in_channels, oc[5]))
         self.out_channels = oc[0] + oc[2] + oc[4] + oc[5]
-        self._fused = _FusedPointwise((self.branch_0, self.branch_1[0], self.branch_2[0]))
+        self._fused = _FusedPointwise(self)
 
     def forward(self, x, out=None):
         oc = self.oc

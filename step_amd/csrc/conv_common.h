@@ -29,8 +29,6 @@ struct ConvParams {
     int gmode;           // general box: 0 = accumulator rows walk the box linearly, 1 = every 16-lane LDS read group is one run of 16 columns of one box row
     int gx, gy;          // logical grid: gx pixel tiles x gy channel groups (launched as a 1-D grid, see grid_coords)
     int tile0;           // conv_tap_kernel: first pixel tile of this launch (a layer may be launched in two parts, see conv_forward_t)
-    int desync;          // conv_tap_kernel: > 0: workgroups of the first round (blockIdx.x < desync_first) sleep hash(blockIdx.x) % desync x 64 clocks first
-    int desync_first;
     int nchunks;   // ceil(Cin / 32)
     int nchunks32; // same (the packed-weight K extent is 2*nchunks32 k16 blocks)
     int vec_epi;   // 16-byte output stores are legal (channel strides/offsets % 8 == 0, pointers 16-B aligned)

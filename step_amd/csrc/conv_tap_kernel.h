@@ -165,15 +165,10 @@ void conv_tap_kernel(ConvParams p) {
 
     int gbx, gby;
     if (!grid_coords(p, gbx, gby)) return;
-#ifndef STEP_EMUL
-    // STEP_OPT_CONV_DESYNC: every tile of a layer takes the same time, so the CUs (one workgroup each) run in lock-step and all of them
-    // reach their epilogue -- a burst of output stores nothing else overlaps -- at the same moment, round after round.  Starting
-    // the first round's workgroups a pseudo-random few microseconds apart de-phases the CUs for the whole launch.
-    if (p.desync > 0 && blockIdx.x < (unsigned)p.desync_first) {
-        const unsigned nsleep = ((blockIdx.x * 2654435761u) >> 12) % (unsigned)p.desync;
-        for (unsigned i = 0; i < nsleep; ++i) __builtin_amdgcn_s_sleep(1);
-    }
-#endif
+    // (Measured and removed: starting the first round's workgroups a pseudo-random 0..27 us apart -- to de-phase the CUs, whose
+    // equal-length tiles bring every epilogue's store burst to the same moment -- only ADDS the delay: conv3d_2c 238.7 us ->
+    // 242 / 240 / 243 / 248 / 270 us at 64 ... 1024 x 64 clocks of spread (gpurun_out/ab_desync.log, round 3).  The epilogues do
+    // not contend with each other.)
     int t = gbx + p.tile0;
     const int tw_i = t % p.tiles_w; t /= p.tiles_w;
     const int th_i = t % p.tiles_h; t /= p.tiles_h;

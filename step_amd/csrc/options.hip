@@ -23,7 +23,6 @@ constexpr OptSpec SPEC[STEP_OPT_COUNT_] = {
     {"pool_direct", 0, 0, 1},
     {"wgrad_minpix", 0, 0, 1 << 24},
     {"wgrad16_lds", 1, 0, 1},
-    {"conv_desync", 0, 0, 4096},
 };
 std::atomic<int> g_delta[STEP_OPT_COUNT_];      // value - default: zero-initialised static storage IS the default table
 }  // namespace

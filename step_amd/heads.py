@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .backbone import (MIXED_CFG, ConvUnit, _ver, _no_data_parallel, MaxPoolTF, Mixed, as_channels_last_5d, freeze_bn_affine, set_bn_eval,
+from .backbone import (MIXED_CFG, ConvUnit, _ver, _replicate_with_units, MaxPoolTF, Mixed, as_channels_last_5d, freeze_bn_affine, set_bn_eval,
                        weights_init)
 from .roi_layers import ROIAlign, ROIPool
 from .tube_math import encode_coef
@@ -141,7 +141,7 @@ class _AvgPoolFn(torch.autograd.Function):
 
 class _Bottleneck(nn.Module):
     """2-D bottleneck, no BN, no bias (models/two_branch.py:60-84); parameter holders only."""
-    _replicate_for_data_parallel = _no_data_parallel
+    _replicate_for_data_parallel = _replicate_with_units
 
     def __init__(self, inplanes, planes):
         super().__init__()
@@ -160,6 +160,7 @@ class _Bottleneck(nn.Module):
 class _BottleneckResample(nn.Module):
     """models/two_branch.py:86-111.  Its input is the channel concat [a | b]; conv1 / conv2 run as two
     accumulating launches over the two sources instead of materialising the concat."""
+    _replicate_for_data_parallel = _replicate_with_units
 
     def __init__(self, in_a, in_b, outplanes, planes):
         super().__init__()
@@ -199,6 +200,7 @@ def _nhwc_flatten_perm(channels, hw):
 
 class TwoBranchNet(nn.Module):
     """Global (classification) + local (box regression) head, models/two_branch.py:164-374."""
+    _replicate_for_data_parallel = _replicate_with_units
 
     def __init__(self, cfg, cls_only=False):
         super().__init__()

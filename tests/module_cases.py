@@ -69,6 +69,115 @@ def case_state_dict_contract(dev, golden):
     assert all(not m.training for m in nets["BaseNet"].modules() if isinstance(m, torch.nn.BatchNorm3d))
 
 
+def _replicate_like_data_parallel(net, n=2):
+    """What torch.nn.parallel.replicate does on every nn.DataParallel forward (torch/nn/parallel/replicate.py: each module's
+    _replicate_for_data_parallel(), children re-pointed to the replicas, parameters handed over as NON-LEAF copies set as plain
+    attributes, buffers as copies) -- with the copies on the module's own device, so that it runs on the CPU interpreter and on a
+    one-GPU box (the real replicate() needs one CUDA device per replica)."""
+    modules = list(net.modules())
+    index = {m: i for i, m in enumerate(modules)}
+    copies = [[m._replicate_for_data_parallel() for m in modules] for _ in range(n)]
+    for row in copies:
+        for r in row:
+            r._former_parameters = {}
+    for i, m in enumerate(modules):
+        for key, child in m._modules.items():
+            for j in range(n):
+                copies[j][i]._modules[key] = None if child is None else copies[j][index[child]]
+        for key, p in m._parameters.items():
+            for j in range(n):
+                r = copies[j][i]
+                pc = None if p is None else (p.clone() if p.requires_grad else p.detach().clone())     # Broadcast.apply: differentiable
+                setattr(r, key, pc)
+                if pc is not None:
+                    r._former_parameters[key] = pc
+        for key, b in m._buffers.items():
+            for j in range(n):
+                setattr(copies[j][i], key, None if b is None else b.detach().clone())
+    return [c[0] for c in copies]
+
+
+class _TinyNet(torch.nn.Module):
+    """stem-free slice of the backbone: Unit3D 3x3x3 -> Mixed -> pool (every helper kind a BaseNet holds)"""
+
+    def __init__(self):
+        super().__init__()
+        self.a = backbone.Unit3D(8, 24, (3, 3, 3))
+        self.b = backbone.Mixed(24, [8, 12, 16, 4, 8, 8])
+        self.c = backbone.MaxPoolTF((1, 3, 3), (1, 2, 2))
+
+    def forward(self, x):
+        return self.c(self.b(self.a(x)))
+
+
+def case_data_parallel_replicas(dev, golden):
+    """nn.DataParallel compatibility (train.py:142-144, test.py:82-84, demo.py:79-81 wrap base_net / context_net): replicas made
+    the way torch.nn.parallel.replicate makes them compute on THEIR tensors (not the original's), reuse a device's packed weights
+    from one forward's replicas to the next, follow in-place weight updates of the original, and route gradients back to the
+    original's parameters."""
+    from step_amd import ops
+    net = fill(_TinyNet(), "dp.").to(dev).eval()
+    x = R.fill_tensor("dp.x", (2, 8, 3, 9, 10), "feat").permute(0, 2, 3, 4, 1).contiguous().to(dev)
+    packs = []
+    orig = ops.pack_conv_weight
+    ops.pack_conv_weight = lambda *a, **k: (packs.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            full = net(x)
+            n0 = len(packs)
+            for rnd in range(2):
+                reps = _replicate_like_data_parallel(net)
+                ys = [r(x[j:j + 1]) for j, r in enumerate(reps)]
+                assert torch.equal(torch.cat(ys), full), rnd
+                # helpers are bound to the replica, not shared with the original
+                assert reps[0].a._unit is not net.a._unit and reps[0].a._unit.owner is reps[0].a and reps[0].b._fused.owner is reps[0].b
+            assert len(packs) == n0, (n0, len(packs))                 # same device, same versions: every image came from the cache
+            # the replica's unit reads the replica's tensors (another device's copy under the real DataParallel), versions come from the original
+            u = reps[1].a._unit
+            assert u.weight_fn() is reps[1].a.conv3d.weight and u.weight_fn() is not net.a.conv3d.weight and u.bn is reps[1].a.batch3d
+            assert u._wver(u.weight_fn())[0][:2] == (net.a.conv3d.weight.data_ptr(), net.a.conv3d.weight._version)
+            # ... and an in-place update of the ORIGINAL (an optimizer step) reaches the next forward's replicas
+            net.a.conv3d.weight.mul_(1.5)
+            net.b.branch_1[1].conv3d.weight.add_(0.05)
+            full2 = net(x)
+            assert not torch.equal(full2, full)
+            reps = _replicate_like_data_parallel(net)
+            assert torch.equal(torch.cat([r(x[j:j + 1]) for j, r in enumerate(reps)]), full2)
+    finally:
+        ops.pack_conv_weight = orig
+    # gradients: the replica's output depends on the original's parameters through the broadcast copies
+    for p in net.parameters():                                        # (BN stays in eval mode, as BaseNet.train() keeps it)
+        p.grad = None
+    g = R.fill_tensor("dp.g", tuple(full.shape), "feat").to(dev)
+    (net(x) * g).sum().backward()
+    want = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    assert len(want) >= 6
+    for p in net.parameters():
+        p.grad = None
+    reps = _replicate_like_data_parallel(net)
+    sum((r(x[j:j + 1]) * g[j:j + 1]).sum() for j, r in enumerate(reps)).backward()
+    for k, p in net.named_parameters():
+        if k in want:
+            assert p.grad is not None and rel(np_(p.grad), np_(want[k])) < 1e-4, (k, None if p.grad is None else rel(np_(p.grad), np_(want[k])))
+    # torch's own wrapper: one visible device (or none) -> DataParallel calls the module itself; with a GPU also the real
+    # replicate() / parallel_apply() path on device ids [0, 0]
+    net.eval()
+    with torch.no_grad():
+        ref = net(x)
+        dp = torch.nn.DataParallel(net)
+        assert torch.equal(dp(x), ref)
+        if str(dev).startswith("cuda"):
+            try:
+                dp2 = torch.nn.DataParallel(net, device_ids=[0, 0])
+                y2 = dp2(x)
+            except Exception as e:                                    # (a torch build that refuses duplicate device ids)
+                y2 = None
+                record("data_parallel_dup_ids", "refused: %s" % type(e).__name__)
+            if y2 is not None:
+                assert torch.equal(y2, ref)
+                record("data_parallel_dup_ids", "ran")
+
+
 def case_mixed_golden(dev, golden):
     g = golden("ops_golden")
     mx = fill(backbone.Mixed(24, [8, 12, 16, 4, 8, 8]), "golden.mixed.").to(dev).eval()
@@ -946,5 +1055,5 @@ CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_g
              "case_reg_unit_pack_follows_weight_updates", "case_basenet_backward_matches_oracle_autograd",
              "case_contextnet_backward_matches_oracle_autograd", "case_postprocess_golden",
              "case_batched_repack_follows_weight_updates", "case_stem_backward_16bit",
-             "case_loss_masks_without_host_branches"]
+             "case_loss_masks_without_host_branches", "case_data_parallel_replicas"]
 GPU_CASES = CPU_CASES + ["case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_c5_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_i3d_classifier_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]

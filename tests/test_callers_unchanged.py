@@ -19,3 +19,4 @@ def test_reference_inference_runs_unchanged_over_the_dropin():
     r = subprocess.run([sys.executable, "-m", "oracle.check_callers"], cwd=ROOT, capture_output=True, text=True, timeout=850)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "== step_amd.driver.inference" in r.stdout
+    assert "DataParallel(base_net)" in r.stdout          # the wrapper lines of test.py:62-98 ran over the drop-in too
