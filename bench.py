@@ -203,6 +203,8 @@ def main():
     ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--branch-streams", type=int, default=None, choices=[0, 1, 2],
+                    help="tuning aid: side streams of the Inception blocks (step_amd.backbone.BRANCH_STREAMS; default: the module's)")
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
     global CLIPS_PER_GPU, T_IN, HW_IN, GFLOP_PER_CLIP, ACT_MB_PER_CLIP
@@ -238,6 +240,9 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
+    if a.branch_streams is not None:
+        from step_amd import backbone as _bb
+        _bb.BRANCH_STREAMS = a.branch_streams
     if a.config in ("c3", "c4"):
         return pipeline_bench(a, c, dev, tdt, rank, world, dist)
     net = build_net(dev)

@@ -197,6 +197,26 @@ __device__ inline void glds16(const void* gsrc_lane, void* lds_base_uniform) {
 
 __device__ __forceinline__ int cd_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// v_permlane32_swap_b32 (gfx950): the UPPER 32 lanes of x trade places with the LOWER 32 lanes of y -- afterwards lane l < 32 holds
+// (x[l], x[l + 32]) in (x, y) and lane l + 32 holds (y[l], y[l + 32]).  (lane semantics measured: tools/ubench/lane_swap.hip)
+#ifndef STEP_EMUL
+__device__ __forceinline__ void lane32_swap(unsigned& x, unsigned& y) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    x = r[0]; y = r[1];
+}
+#else
+__device__ inline void lane32_swap(unsigned& x, unsigned& y) {
+    const unsigned mine[2] = {x, y};
+    const int lane = (int)(threadIdx.x & 63);
+    char* s = hipemu::exchange_begin(mine, 8);
+    unsigned nx = x, ny = y;
+    if (lane >= 32) __builtin_memcpy(&nx, s + 256 * (lane - 32) + 4, 4);      // x.upper <- y.lower
+    else __builtin_memcpy(&ny, s + 256 * (lane + 32), 4);                      // y.lower <- x.upper
+    hipemu::exchange_end();
+    x = nx; y = ny;
+}
+#endif
+
 // ---- launch helper -------------------------------------------------------------------------
 #ifdef STEP_EMUL
 #define STEP_LAUNCH(kernel, grid, block, stream, ...) \

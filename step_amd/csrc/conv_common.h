@@ -34,7 +34,31 @@ struct ConvParams {
     int vec_epi;   // 16-byte output stores are legal (channel strides/offsets % 8 == 0, pointers 16-B aligned)
     int nblk32;    // ceil(Cout / 32)
     long long Mtot;  // N*D*H*W
+#ifdef STEP_PROBE
+    unsigned long long* probe;   // tools/timeline_probe.py build only: 16 timestamp / id slots per workgroup (see probe_mark)
+#endif
 };
+
+#ifdef STEP_PROBE
+// Timeline probe (make PROBE=1 -> libstep_amd_probe.so, never the product library): wave 0 of a workgroup stores the 100 MHz
+// real-time counter at phase boundaries and the hardware ids of the CU it runs on.
+extern unsigned long long* g_probe_buf;       // set by step_probe_set()
+__device__ __forceinline__ void probe_mark(unsigned long long* probe, int slot) {
+    if (probe && threadIdx.x == 0) probe[(size_t)blockIdx.x * 16 + slot] = __builtin_amdgcn_s_memrealtime();
+}
+__device__ __forceinline__ void probe_ids(unsigned long long* probe) {
+    if (probe && threadIdx.x == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID
+        const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
+        probe[(size_t)blockIdx.x * 16 + 15] = ((unsigned long long)xcc << 32) | hw;
+    }
+}
+#define STEP_PROBE_MARK(p, slot) probe_mark((p).probe, slot)
+#define STEP_PROBE_IDS(p) probe_ids((p).probe)
+#else
+#define STEP_PROBE_MARK(p, slot)
+#define STEP_PROBE_IDS(p)
+#endif
 
 // Launch order -> XCD.  Workgroup ids go round-robin over the 8 XCDs (each with its own L2), so with a plain 2-D grid
 // the channel groups of one pixel tile -- which read the SAME activations -- and spatially adjacent tiles -- which

@@ -701,6 +701,10 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_
 
 using namespace step;
 
+#ifdef STEP_PROBE
+unsigned long long* step::g_probe_buf = nullptr;
+#endif
+
 extern "C" {
 
 size_t step_conv_packed_elems(int Cout, int Cin, int kd, int kh, int kw) {
@@ -805,6 +809,9 @@ int step_conv_forward_ws(const step_conv_desc* d, const void* x, const void* w_p
                 (!split || ((split % 8 == 0) && (d->y2_cstride % 8 == 0) && (d->y2_coff % 8 == 0) && (((uintptr_t)y2) % 16 == 0)));
     p.nblk32 = ceil_div(d->Cout, 32);
     p.Mtot = (long long)d->N * d->D * d->H * d->W;
+#ifdef STEP_PROBE
+    p.probe = step::g_probe_buf;
+#endif
     switch (d->dtype) {
         case STEP_F32: return conv_forward_t<float>(d, p, ws, ws_bytes, stream);
         case STEP_BF16: return conv_forward_t<bf16_t>(d, p, ws, ws_bytes, stream);
@@ -849,6 +856,9 @@ int step_conv_plan_info(const step_conv_desc* d, int* info, int n) {
     return STEP_OK;
 }
 
+#ifdef STEP_PROBE
+__attribute__((visibility("default"))) void step_probe_set(void* buf) { step::g_probe_buf = (unsigned long long*)buf; }
+#endif
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
 int step_abi_version(void) { return 19; }
 

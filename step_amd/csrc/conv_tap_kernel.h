@@ -51,7 +51,6 @@ void conv_tap_kernel(ConvParams p) {
     static_assert(PH == 0 || (WV == 8 && TPS == 2 && sizeof(T) == 2), "two-phase form: 8 waves, two taps per step, 16-bit storage");
     constexpr int NT = WV * 64;                 // threads
     constexpr int WM = WV / 2;                  // waves along the pixel axis (x 2 along channels)
-    constexpr int MBP = MB / 2;                 // accumulator rows per wave per epilogue pass
     constexpr int TPXM = WM * MB * 32;          // pixels of a full tile: 256 (WV = 8) or 128 (WV = 4)
     // tile shapes: TWL = 4 -> 1 plane x 16 x 16, TWL = 5 -> 1 x 8 x 32, TWL = 3 -> 4 planes x 8 x 8 (small maps:
     // 7x7 ROI features would fill 19 % of a 16x16 tile; four planes of 8x8 fill 77 %), TWL = 0 -> a box of
@@ -104,13 +103,16 @@ void conv_tap_kernel(ConvParams p) {
     typedef typename Ld16<T>::type vec16;
     typedef typename frag<T>::type frag_t;
 
-    constexpr int EROWS = WM * MBP * 32;                                      // pixels per epilogue pass: 128 (WV = 8) or 64
-    constexpr int EPI_BYTES = (ES == 2) ? EROWS * NBT * 32 * 4 + 1024 : 0;   // fp32 transpose buffer of the 16-bit epilogue + pixel table
+    // 16-bit storage: the accumulators are kept TRANSPOSED (TR: the MFMA takes the weight fragment as its first operand, so a lane
+    // owns ONE pixel and, per register quad, four consecutive channels) -- the epilogue then needs no LDS transpose, see below
+    constexpr bool TR = (ES == 2);
+    constexpr int SS_BYTES = TR ? NBT * 32 * 2 * 4 : 0;                       // fp32 scale | shift of the tile's channels
     constexpr int BBYTES = PH ? 2 * 2 * TPS * (NB * KS * FRAGB) : 3 * BSTEP;    // two-phase form: two groups x a ring of two half-step buffers
-    constexpr int LDS_BYTES = (NPIX_MAX * PITCH + BBYTES) > EPI_BYTES ? (NPIX_MAX * PITCH + BBYTES) : EPI_BYTES;
+    constexpr int LDS_BYTES = NPIX_MAX * PITCH + BBYTES + SS_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     unsigned char* const ldsA = lds;
     unsigned char* const ldsB = lds + NPIX_MAX * PITCH;
+    float* const ldsS = (float*)(lds + NPIX_MAX * PITCH + BBYTES);
     // tile pixel index m (accumulator row) -> box coordinates, and whether the row holds a pixel of the box at all.
     // General boxes, linear mode: rows past the box alias pixel 0.  General boxes, p.gmode = 1 (box widths just below a multiple
     // of 16: the 14- and 28-wide C2 maps, 13): the 16 lanes of every ds_read_b128 service group ({0-3,12-15,20-27} and
@@ -169,6 +171,8 @@ void conv_tap_kernel(ConvParams p) {
     // equal-length tiles bring every epilogue's store burst to the same moment -- only ADDS the delay: conv3d_2c 238.7 us ->
     // 242 / 240 / 243 / 248 / 270 us at 64 ... 1024 x 64 clocks of spread (gpurun_out/ab_desync.log, round 3).  The epilogues do
     // not contend with each other.)
+    STEP_PROBE_IDS(p);
+    STEP_PROBE_MARK(p, 0);
     int t = gbx + p.tile0;
     const int tw_i = t % p.tiles_w; t /= p.tiles_w;
     const int th_i = t % p.tiles_h; t /= p.tiles_h;
@@ -207,6 +211,7 @@ void conv_tap_kernel(ConvParams p) {
     // run-time box dimensions in the general-tile instantiation -- which used to be redone for every slab.
     // (32-bit offsets: the planner sends tensors of >= 2^32 elements to conv_igemm_kernel.)
     unsigned goff[ITER];
+    auto build_goff = [&]() {
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int v = tid + it * NT;
@@ -223,6 +228,21 @@ void conv_tap_kernel(ConvParams p) {
             }
         }
     }
+    };
+    if constexpr (PH == 0) build_goff();                   // (the two-phase form requests its first weights before this index work)
+    // the tile's scale / shift: requested with the first loads, parked in LDS behind the halo stores (visible after the prologue's
+    // barrier; read in the epilogue)
+    float ss_sc = 1.f, ss_sh = 0.f;
+    auto ss_load = [&]() {
+        if (TR && tid < NBT * 32) {
+            const int co = min(nb0 * 32 + tid, p.Cout - 1);
+            if (p.scale) ss_sc = p.scale[co];
+            if (p.shift) ss_sh = p.shift[co];
+        }
+    };
+    auto ss_store = [&]() {
+        if (TR && tid < NBT * 32) { ldsS[tid] = ss_sc; ldsS[NBT * 32 + tid] = ss_sh; }
+    };
     auto stage_A = [&](int slab) {
         vec16 stage[ITER];
 #pragma unroll
@@ -341,7 +361,10 @@ void conv_tap_kernel(ConvParams p) {
 #pragma unroll
                         for (int i = 0; i < NB; ++i)
 #pragma unroll
-                            for (int mb = 0; mb < MB; ++mb) mma_k16(fa[tp][j][mb], fb[tp][j][i], acc[mb][i], T());
+                            for (int mb = 0; mb < MB; ++mb) {
+                                if constexpr (TR) mma_k16(fb[tp][j][i], fa[tp][j][mb], acc[mb][i], T());
+                                else mma_k16(fa[tp][j][mb], fb[tp][j][i], acc[mb][i], T());
+                            }
             }
 #ifndef STEP_EMUL
             __builtin_amdgcn_s_setprio(0);
@@ -349,13 +372,25 @@ void conv_tap_kernel(ConvParams p) {
 #endif
             __syncthreads();
         };
-        // prologue: halo slab 0; weights of step 0 to ring buffer 0, steps 1 and 2 in the register sets
-        stage_A(0);
+        // prologue: weights of steps 0 and 1 requested FIRST -- their addresses need nothing but the block index, and the ~400-900
+        // instructions of index arithmetic behind the halo table (general boxes divide) then run under their latency instead of in
+        // front of a second memory round trip (measured per workgroup: index tables 1.1-1.9 us, halo 0.5-1.6 us, weights + barrier
+        // 0.7-1.2 us, one after the other) -- then halo slab 0; step 0 to ring buffer 0, steps 1 and 2 stay in the register sets
         load_B(woff_of(0, 0), R0);
         load_B(woff_of(SPS > 1 ? 0 : 1, SPS > 1 ? 1 : 0), R1);
+#ifndef STEP_EMUL
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        ss_load();
+        build_goff();
+        STEP_PROBE_MARK(p, 5);
+        stage_A(0);
+        ss_store();
+        STEP_PROBE_MARK(p, 6);
         store_B(0, R0);
         load_B(woff_of(SPS > 2 ? 0 : 1, SPS > 2 ? 2 : 2 - SPS), R0);
         __syncthreads();
+        STEP_PROBE_MARK(p, 1);
         typedef std::integral_constant<int, 0> P0;
         typedef std::integral_constant<int, 1> P1;
 #pragma unroll 1
@@ -370,6 +405,7 @@ void conv_tap_kernel(ConvParams p) {
             else static_for<SPS>([&](auto si) { step(si, P0(), slab); });
         }
         if (grp == 0) __syncthreads();                    // realign before the epilogue reuses LDS
+        STEP_PROBE_MARK(p, 2);
     } else {
     // global -> registers: this thread's vectors of the B tile of a pipeline step.  Branch-free on
     // purpose (a predicated load makes the compiler drain vmcnt at the loop head): threads without a
@@ -434,7 +470,10 @@ void conv_tap_kernel(ConvParams p) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {   // channel blocks past Cout compute on a duplicate block and are never stored
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) mma_k16(fa[SET][j][mb], fb[SET][j][i], acc[mb][i], T());
+                for (int mb = 0; mb < MB; ++mb) {
+                    if constexpr (TR) mma_k16(fb[SET][j][i], fa[SET][j][mb], acc[mb][i], T());
+                    else mma_k16(fa[SET][j][mb], fb[SET][j][i], acc[mb][i], T());
+                }
             }
     };
     // LDS byte shift of the NEXT tap to prefetch, advanced incrementally (kw, kh, kd counters): computing it from the
@@ -466,7 +505,9 @@ void conv_tap_kernel(ConvParams p) {
         if (++sis3 == SPS) { sis3 = 0; ++slab3; woff3 = (unsigned)slab3 * KS * FRAGB; }
     };
 
+    ss_load();
     stage_A(0);
+    ss_store();
     load_B(0u, R0);
     adv_clamped();
     load_B(woff3, R1);
@@ -536,62 +577,89 @@ void conv_tap_kernel(ConvParams p) {
     // ---- epilogue
     T* yg = (T*)p.y;
     const T* rg = (const T*)p.res;
-    if (ES == 2 && p.vec_epi) {
-        // 16-bit outputs: transpose the accumulators through LDS (fp32, 128 pixels at a time) so that
-        // every lane stores 16 contiguous bytes (8 channels of one pixel): 8x fewer store instructions
-        // than the accumulator layout allows (2 B per lane, 64 B runs) and whole-line writes.
-        constexpr int BN = NBT * 32, G = BN / 8;
-        float* ot = (float*)lds;
-        // output pixel of every accumulator row, decoded ONCE per tile pixel (a general box divides by run-time
-        // extents; the store loop below visits each pixel G/… times) into a 1 KiB table behind the transpose buffer
-        static_assert(ES != 2 || sizeof(lds) >= EROWS * BN * 4 + 1024, "no room for the pixel table");
-        int* const pixtab = (int*)(lds + sizeof(lds) - 1024);
-        if (tid < TPXM) {
+    if constexpr (TR) {
+        // 16-bit outputs, transposed accumulators: lane l owns pixel (l & 31) of each of its MB row blocks and, in registers
+        // 4g .. 4g+3 of a 32x32 tile, the four consecutive channels 8g + 4 (l >> 5) + {0..3}.  After the affine / residual / ReLU
+        // the four values are two packed dwords; ONE v_permlane32_swap per dword pair (g even, g odd) gives the lower lane channels
+        // 8g' .. 8g'+7 and the upper lane 8g'+8 .. 8g'+15 of the same pixel: every lane stores 16 contiguous bytes straight from
+        // registers.  No LDS transpose, no barrier (the LDS form took 5.3 of conv3d_2c's 44 us per tile: two passes of 48
+        // ds_write_b32 + barrier + read-out, tools/timeline_probe.py).
+        long long opix[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
             int tdl, thl, twl;
-            const bool inbox = tile_pix(tid, tdl, thl, twl);
+            const bool inbox = tile_pix(wm * (MB * 32) + mb * 32 + (lane & 31), tdl, thl, twl);
             const int od = d0 + tdl, oh = h0 + thl, ow = w0 + tile_col(thl, twl);
-            const bool ok = inbox && od < p.D && oh < p.H && ow < p.W;
-            pixtab[tid] = ok ? (int)((((long long)n * p.D + od) * p.H + oh) * p.W + ow) : -1;
+            opix[mb] = (inbox && od < p.D && oh < p.H && ow < p.W) ? (((long long)n * p.D + od) * p.H + oh) * p.W + ow : -1;
         }
-        float sc[NB], sh[NB];
+        if (p.vec_epi) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int cl = (wn * NB + i) * 32;                       // first channel of the block inside the workgroup tile
+                f32x4 sc[4], sh[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    sc[g] = *(const f32x4*)(ldsS + cl + 8 * g + 4 * khalf);
+                    sh[g] = *(const f32x4*)(ldsS + NBT * 32 + cl + 8 * g + 4 * khalf);
+                }
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const bool okp = opix[mb] >= 0;
+                    const size_t obase = (size_t)(okp ? opix[mb] : 0);
+                    unsigned d[4][2];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[mb][i][4 * g + e] * sc[g][e] + sh[g][e];
+                        const int co = nb0 * 32 + cl + 8 * g + 4 * khalf;
+                        if (rg && okp && co < p.Cout) {
+                            const u16x4 rv = *(const u16x4*)(rg + obase * p.r_cstride + p.r_coff + co);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += elem<T>::from_bits16(rv[e]);
+                        }
+                        if (p.relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        d[g][0] = (unsigned)elem<T>::bits16(v[0]) | ((unsigned)elem<T>::bits16(v[1]) << 16);
+                        d[g][1] = (unsigned)elem<T>::bits16(v[2]) | ((unsigned)elem<T>::bits16(v[3]) << 16);
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {                        // register quads (2h, 2h + 1) -> one 16-byte run per lane
+                        lane32_swap(d[2 * h][0], d[2 * h + 1][0]);
+                        lane32_swap(d[2 * h][1], d[2 * h + 1][1]);
+                        const int co = nb0 * 32 + cl + 16 * h + 8 * khalf;
+                        if (okp && co < p.Cout) {
+                            const u32x4 o = {d[2 * h][0], d[2 * h][1], d[2 * h + 1][0], d[2 * h + 1][1]};
+                            *(u32x4*)(yg + obase * p.y_cstride + p.y_coff + co) = o;
+                        }
+                    }
+                }
+            }
+#ifdef STEP_PROBE
+            STEP_PROBE_MARK(p, 3);
+            __builtin_amdgcn_s_waitcnt(0);                    // every store acknowledged
+            STEP_PROBE_MARK(p, 4);
+#endif
+            return;
+        }
+        // channel counts / offsets off the 16-byte grid: element stores (same transposed ownership)
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int co = min((nb0 + wn * NB + i) * 32 + (lane & 31), p.Cout - 1);
-            sc[i] = p.scale ? p.scale[co] : 1.f;
-            sh[i] = p.shift ? p.shift[co] : 0.f;
-        }
+            const int cl = (wn * NB + i) * 32;
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {                  // two passes of EROWS pixels
-            if (ps) __syncthreads();                      // previous half has been read out
+            for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
-            for (int mbl = 0; mbl < MBP; ++mbl)
-#pragma unroll
-                for (int i = 0; i < NB; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        ot[((wm * MBP + mbl) * 32 + cd_row(r, lane)) * BN + (wn * NB + i) * 32 + (lane & 31)] =
-                            acc[ps * MBP + mbl][i][r] * sc[i] + sh[i];
-            __syncthreads();
-            for (int idx = tid; idx < EROWS * G; idx += NT) {
-                const int row = idx / G, g = idx % G;
-                // row = (wm*MBP + mbl)*32 + rr  ->  tile pixel wm*(MB*32) + (ps*MBP + mbl)*32 + rr
-                const int mm = ((row >> 5) / MBP) * (MB * 32) + (ps * MBP + (row >> 5) % MBP) * 32 + (row & 31);
-                const int px = pixtab[mm];
-                const int co = nb0 * 32 + g * 8;
-                if (px >= 0 && co < p.Cout) {
-                    const size_t opix = (size_t)px;
-                    const f32x4 lo = *(const f32x4*)(ot + row * BN + g * 8);
-                    const f32x4 hi = *(const f32x4*)(ot + row * BN + g * 8 + 4);
-                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    if (rg) {
-                        const u16x8 rv = *(const u16x8*)(rg + opix * p.r_cstride + p.r_coff + co);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += elem<T>::from_bits16(rv[e]);
+                for (int r = 0; r < 16; ++r) {
+                    const int co = nb0 * 32 + cl + cd_row(r, lane);
+                    if (opix[mb] >= 0 && co < p.Cout) {
+                        const size_t o = (size_t)opix[mb];
+                        float v = acc[mb][i][r] * ldsS[cl + cd_row(r, lane)] + ldsS[NBT * 32 + cl + cd_row(r, lane)];
+                        if (rg) v += elem<T>::to_f32(rg[o * p.r_cstride + p.r_coff + co]);
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        yg[o * p.y_cstride + p.y_coff + co] = elem<T>::from_f32(v);
                     }
-                    u16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = elem<T>::bits16(p.relu ? fmaxf(v[e], 0.f) : v[e]);
-                    *(u16x8*)(yg + opix * p.y_cstride + p.y_coff + co) = o;
                 }
             }
         }
