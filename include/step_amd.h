@@ -205,6 +205,21 @@ STEP_API int step_conv_pack_weights(const step_pack_item* items, int n, int dtyp
 STEP_API int step_conv_forward(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale,
                                const float* shift, const void* res, void* y, void* y2, step_stream_t stream);
 
+/* Several INDEPENDENT convs as one launch where the planner can give them one kernel instantiation -- today: two 16-bit 3x3x3
+ * layers on the two-phase conv_tap kernel with general tile boxes, i.e. an Inception block's branch_1 / branch_2 3x3x3 convs
+ * (models/i3dpt.py:141-150), which read different slices of the bottleneck buffer and write different slices of the block output.
+ * Alone neither fills the chip's last round and every launch boundary idles all CUs for a prologue + an epilogue; in one grid the
+ * narrow conv's workgroups run on the CUs the wide one leaves idle.  Results are bit-identical to n step_conv_forward calls (same
+ * tiles, same K order); groups the planner cannot merge are launched one after the other.  No member may use `split`; outputs must
+ * not overlap any member's input. */
+typedef struct step_conv_item {
+    const step_conv_desc* desc;
+    const void* x; const void* w_packed; const float* scale; const float* shift; const void* res; void* y;
+} step_conv_item;
+STEP_API int step_conv_forward_group(const step_conv_item* items, int n, step_stream_t stream);
+/* Diagnostic: the kernel name of the merged launch, or "" when step_conv_forward_group would launch the members separately. */
+STEP_API int step_conv_group_kernel_name(const step_conv_item* items, int n, char* buf, int buflen);
+
 /* Same, with a caller-owned scratch buffer.  Few-row / very-deep-K pointwise layers (the heads' Linear(12544 -> 60 / 12),
  * models/two_branch.py:196,209-211) are split along K over the whole chip when `ws` holds at least
  * step_conv_workspace_bytes(d) bytes (16-byte aligned; contents are scratch, no initialisation needed); with ws = NULL

@@ -4,7 +4,7 @@ import ctypes as C
 
 F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 vp, fp, ip, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # raw device addresses
 i, f, ll, sz = C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -21,6 +21,12 @@ class PackItem(C.Structure):
     """struct step_pack_item (include/step_amd.h)"""
     _fields_ = [("w", C.c_void_p), ("perm_c", C.c_void_p), ("packed", C.c_void_p)] + [(n, C.c_int) for n in (
         "Cout", "Cin", "w_cin", "cin_lo", "kd", "kh", "kw", "dgrad", "cin_pad", "reserved")]
+
+
+class ConvItem(C.Structure):
+    """struct step_conv_item (include/step_amd.h)"""
+    _fields_ = [("desc", C.POINTER(ConvDesc)), ("x", C.c_void_p), ("w_packed", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("res", C.c_void_p), ("y", C.c_void_p)]
 
 
 SIGNATURES = {
@@ -41,6 +47,8 @@ SIGNATURES = {
     "step_conv_pack_weight_dgrad": (i, [fp, i, i, i, i, i, i, i, vp, vp]),
     "step_conv_pack_weights": (i, [vp, i, i, vp]),
     "step_conv_forward": (i, [C.POINTER(ConvDesc), vp, vp, fp, fp, vp, vp, vp, vp]),
+    "step_conv_forward_group": (i, [C.POINTER(ConvItem), i, vp]),
+    "step_conv_group_kernel_name": (i, [C.POINTER(ConvItem), i, C.c_char_p, i]),
     "step_conv_workspace_bytes": (sz, [C.POINTER(ConvDesc)]),
     "step_conv_wgrad": (i, [C.POINTER(ConvDesc), vp, fp, fp, i, vp]),
     "step_conv_wgrad16": (i, [C.POINTER(ConvDesc), vp, vp, fp, i, vp]),
@@ -70,10 +78,12 @@ SIGNATURES = {
 }
 
 
-def declare(lib):
+def declare(lib, strict=True):
     """Attach argtypes/restype for every symbol of include/step_amd.h; raises AttributeError when the
-    library does not export one of them."""
+    library does not export one of them (strict=False: tools that load an OLDER build next to the current one)."""
     for name, (res, args) in SIGNATURES.items():
+        if not strict and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args

@@ -573,13 +573,20 @@ class Mixed(nn.Module):
             out = torch.empty((N, D, H, W, self.out_channels), dtype=x.dtype, device=x.device)
         c0, c1, c2 = oc[0], oc[0] + oc[2], oc[0] + oc[2] + oc[4]
         t = torch.empty((N, D, H, W, oc[1] + oc[3]), dtype=x.dtype, device=x.device)
-        if not (BRANCH_STREAMS and x.is_cuda):
-            # branch_0 and the two bottleneck 1x1x1 convs: one launch; the bottleneck outputs share one
-            # scratch buffer whose slices the 3x3x3 convs read
+        if BRANCH_STREAMS == 0 or not x.is_cuda:
+            # ONE stream, four launches: pool, the fused 1x1x1 triple, branch_3's 1x1x1, and the two 3x3x3 convs as ONE grid
+            # (ops.conv_forward_group: the narrow branch_2 conv runs on the CUs the wide branch_1 conv leaves idle).  Measured on
+            # the replayed C2 step (tools/graph_timeline.py): a cross-stream edge of the HIP graph costs ~6 us of whole-GPU idle
+            # (fork + join: 11-16 us per block), kernels that each fill the chip with one workgroup per CU hardly overlap, and a
+            # single-stream graph runs its kernels back to back with no gap -- 1469 us against 1477 / 1505 us with 1 / 2 side streams.
+            p = self._branch_3(x, out[..., c2:])
             self._fused(x, out[..., :c0], t)
-            self.branch_1[1](t[..., :oc[1]], out=out[..., c0:c1])
-            self.branch_2[1](t[..., oc[1]:], out=out[..., c1:c2])
-            self._branch_3(x, out[..., c2:])
+            u1, u2 = self.branch_1[1]._unit, self.branch_2[1]._unit
+            m = []
+            for u, xin, o in ((u1, t[..., :oc[1]], out[..., c0:c1]), (u2, t[..., oc[1]:], out[..., c1:c2])):
+                scale, shift = u.affine()
+                m.append((xin, u.packed(x.dtype), u.cout, u.k, scale, None if shift is None else shift.detach().contiguous(), True, o))
+            ops.conv_forward_group(m)
             return out
         # The branches are independent: run them on three HIP streams (fork/join with events -- under
         # hipGraph capture these become parallel graph branches).  Most of these launches do not fill
@@ -587,7 +594,7 @@ class Mixed(nn.Module):
         main = torch.cuda.current_stream(x.device)
         s1, s2 = _side_streams(x.device)
         if BRANCH_STREAMS == 1:
-            s1 = s2                                        # tuning aid: both side branches on ONE side stream (one fork, one join)
+            s1 = s2                                        # both side branches on ONE side stream (one fork, one join)
         s2.wait_stream(main)
         with torch.cuda.stream(s2):                        # branch_3: pool -> 1x1x1
             p = self._branch_3(x, out[..., c2:])
@@ -660,7 +667,7 @@ def wgrad_sync():
     del _KEEP[:]
 
 
-BRANCH_STREAMS = 1       # Inception side branches (inference path): on 1 side stream (default; C2 5345 -> 5430 clips/s against 2: one fork / join per block), 2, or 0 = off (5240)
+BRANCH_STREAMS = 0       # Inception blocks (inference path): 0 = one stream + the grouped 3x3x3 launch (default since round 3, see Mixed.forward); 1 / 2 = side branches on 1 / 2 side streams
 WGRAD_SIDE_STREAM = True # training: weight gradient beside the data gradient
 _SIDE = {}
 

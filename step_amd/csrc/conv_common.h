@@ -28,6 +28,8 @@ struct ConvParams {
     int gtd, gth, gtw;   // box of a general (TWL = 0) conv_tap tile, gtd*gth*gtw <= 256
     int gmode;           // general box: 0 = accumulator rows walk the box linearly, 1 = every 16-lane LDS read group is one run of 16 columns of one box row
     int gx, gy;          // logical grid: gx pixel tiles x gy channel groups (launched as a 1-D grid, see grid_coords)
+    int gbase, gcount;   // this problem's workgroups are blockIdx.x in [gbase, gbase + gcount) (gcount % 8 == 0 when remapped): the whole grid, or one
+                         // member's share of a grouped launch (step_conv_forward_group)
     int tile0;           // conv_tap_kernel: first pixel tile of this launch (a layer may be launched in two parts, see conv_forward_t)
     int nchunks;   // ceil(Cin / 32)
     int nchunks32; // same (the packed-weight K extent is 2*nchunks32 k16 blocks)
@@ -38,6 +40,11 @@ struct ConvParams {
     unsigned long long* probe;   // tools/timeline_probe.py build only: 16 timestamp / id slots per workgroup (see probe_mark)
 #endif
 };
+
+// Several independent convs launched as ONE grid (step_conv_forward_group): the members share the kernel instantiation, each has its own
+// parameter block and a contiguous share of blockIdx.x (p[k].gbase ascending, p[0].gbase == 0).
+constexpr int CONV_GROUP_MAX = 2;
+struct ConvGroupParams { ConvParams p[CONV_GROUP_MAX]; int n; };
 
 #ifdef STEP_PROBE
 // Timeline probe (make PROBE=1 -> libstep_amd_probe.so, never the product library): wave 0 of a workgroup stores the 100 MHz
@@ -67,7 +74,7 @@ __device__ __forceinline__ void probe_ids(unsigned long long* probe) {
 // a multiple of 8, and remapped: ids that are consecutive on one XCD walk the channel groups of a tile first, then
 // the neighbouring tiles.  Returns false for the padding workgroups (they exit before any barrier).
 __device__ __forceinline__ bool grid_coords(const ConvParams& p, int& bx, int& by) {
-    const unsigned id = blockIdx.x, G = gridDim.x;
+    const unsigned id = blockIdx.x - (unsigned)p.gbase, G = (unsigned)p.gcount;
     const unsigned L = (G & 7) ? id : (id & 7) * (G >> 3) + (id >> 3);
     if (L >= (unsigned)p.gx * (unsigned)p.gy) return false;
     bx = (int)(L / (unsigned)p.gy);
@@ -178,6 +185,9 @@ template <typename T> int conv_tap_launch(const ConvPlan& pl, const ConvParams& 
 template <typename T> int conv_tap_ph_launch(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream);  // conv_tap_ph_<dtype>.hip (two-phase form)
 template <> int conv_tap_ph_launch<bf16_t>(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream);
 template <> int conv_tap_ph_launch<f16_t>(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream);
+template <typename T> int conv_tap_group_launch(int NB, const ConvGroupParams& g, dim3 grid, step_stream_t stream);       // conv_tap_ph_<dtype>.hip
+template <> int conv_tap_group_launch<bf16_t>(int NB, const ConvGroupParams& g, dim3 grid, step_stream_t stream);
+template <> int conv_tap_group_launch<f16_t>(int NB, const ConvGroupParams& g, dim3 grid, step_stream_t stream);
 template <typename T> int conv_pw_launch(int NB, int wv, const ConvParams& p, dim3 grid, step_stream_t stream);                        // conv_pw.hip
 template <typename T> int conv_pws_launch(int nbw, const ConvParams& p, dim3 grid, step_stream_t stream);                              // conv_pw.hip (weight-stationary stream, 16-bit)
 // conv_pws_kernel: nbw channel blocks per workgroup, KC16 16-channel chunks -> blocks per pass (<= 3: registers), 64-channel steps

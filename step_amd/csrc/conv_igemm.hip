@@ -436,7 +436,7 @@ static int gen_gmode(int td, int th, int tw, int tile_px) {
     return td * th * spr <= tile_px / 16 ? 1 : 0;
 }
 
-static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true) {
+static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true, int force_waves = 0) {
     ConvPlan pl;
     pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1; pl.mb = 2; pl.wv = 8; pl.ph = 0; pl.deep = false; pl.twl = 4; pl.tiles_d = d->D; pl.gtd = pl.gth = pl.gtw = 1; pl.gmode = 0; pl.ksplit = 0; pl.kchunk16 = 0; pl.mbk = 0; pl.mpad = 0; pl.cpad = 0;
     const int nblk32 = ceil_div(d->Cout, 32);
@@ -548,7 +548,7 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true) {
     }
     const long long mt256 = (long long)d->N * tbest;
     // ---- the four-wave form (128-pixel tiles, two resident workgroups per CU; conv_tap_kernel.h): its own tile search
-    const int waves_env = opt(STEP_OPT_CONV_WAVES);      // tests / A-B timing: 4 | 8
+    const int waves_env = force_waves ? force_waves : opt(STEP_OPT_CONV_WAVES);      // tests / A-B timing: 4 | 8
     ConvPlan p4 = pl;
     bool have4 = false;
     {
@@ -650,7 +650,8 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_
     auto grid1d = [&](int groups) {                   // logical (mtiles x groups) grid as a 1-D launch padded to 8
         p.gx = (int)pl.mtiles; p.gy = groups;
         const long long tot = pl.mtiles * groups;
-        return dim3((unsigned)((tot + 7) / 8 * 8));
+        p.gbase = 0; p.gcount = (int)((tot + 7) / 8 * 8);
+        return dim3((unsigned)p.gcount);
     };
     if (pl.impl == 4) {
         if (!p.res && p.vec_epi)
@@ -682,7 +683,8 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_
             pt.NB = 1; pt.mtiles = tail;
             p.tile0 = (int)(all - tail);
             p.gx = (int)tail; p.gy = tgroups;
-            const dim3 gt((unsigned)((tail * tgroups + 7) / 8 * 8));
+            p.gcount = (int)((tail * tgroups + 7) / 8 * 8);
+            const dim3 gt((unsigned)p.gcount);
             return conv_tap_launch<T>(pt, p, d->kd, gt, stream);
         }
         dim3 grid = grid1d(groups);
@@ -776,8 +778,9 @@ int step_conv_forward(const step_conv_desc* d, const void* x, const void* w_pack
     return step_conv_forward_ws(d, x, w_packed, scale, shift, res, y, y2, nullptr, 0, stream);
 }
 
-int step_conv_forward_ws(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale,
-                         const float* shift, const void* res, void* y, void* y2, void* ws, size_t ws_bytes, step_stream_t stream) {
+// argument checks + the kernel parameter block of one conv; `canon` receives the canonical descriptor.  STEP_OK with p.N == 0: nothing to launch.
+static int conv_fill_params(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
+                            const void* res, void* y, void* y2, step_conv_desc& canon, ConvParams& p) {
     if (!d) return STEP_E_NULL;
     if (d->N < 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return STEP_E_SHAPE;
     const int split = (d->split > 0 && d->split < d->Cout) ? d->split : 0;
@@ -790,18 +793,18 @@ int step_conv_forward_ws(const step_conv_desc* d, const void* x, const void* w_p
         if (d->y2_coff < 0 || d->y2_coff + (d->Cout - split) > d->y2_cstride) return STEP_E_SHAPE;
     }
     if (res && (d->res_coff < 0 || d->res_coff + d->Cout > d->res_cstride)) return STEP_E_SHAPE;
+    p.N = d->N;
     if (d->N == 0) return STEP_OK;
     if (!x || !w_packed || !y) return STEP_E_NULL;
-    const step_conv_desc canon = canonical_desc(d);
+    canon = canonical_desc(d);
     d = &canon;
-    ConvParams p;
     p.x = x; p.w = w_packed; p.scale = scale; p.shift = shift; p.res = res; p.y = y; p.y2 = y2;
     p.split = split; p.y2_cstride = d->y2_cstride; p.y2_coff = d->y2_coff;
     p.N = d->N; p.D = d->D; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
     p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
     p.r_cstride = d->res_cstride; p.r_coff = d->res_coff;
     p.relu = d->relu;
-    p.tiles_h = p.tiles_w = 0; p.tiles_d = d->D; p.gtd = p.gth = p.gtw = 1; p.gmode = 0; p.gx = p.gy = 0; p.tile0 = 0;
+    p.tiles_h = p.tiles_w = 0; p.tiles_d = d->D; p.gtd = p.gth = p.gtw = 1; p.gmode = 0; p.gx = p.gy = 0; p.tile0 = 0; p.gbase = 0; p.gcount = 0;
     p.nchunks = ceil_div(d->Cin, CK);
     p.nchunks32 = p.nchunks;
     p.vec_epi = (d->y_cstride % 8 == 0) && (d->y_coff % 8 == 0) && (d->Cout % 8 == 0) && (((uintptr_t)y) % 16 == 0) &&
@@ -812,12 +815,115 @@ int step_conv_forward_ws(const step_conv_desc* d, const void* x, const void* w_p
 #ifdef STEP_PROBE
     p.probe = step::g_probe_buf;
 #endif
-    switch (d->dtype) {
-        case STEP_F32: return conv_forward_t<float>(d, p, ws, ws_bytes, stream);
-        case STEP_BF16: return conv_forward_t<bf16_t>(d, p, ws, ws_bytes, stream);
-        case STEP_F16: return conv_forward_t<f16_t>(d, p, ws, ws_bytes, stream);
+    return STEP_OK;
+}
+
+int step_conv_forward_ws(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale,
+                         const float* shift, const void* res, void* y, void* y2, void* ws, size_t ws_bytes, step_stream_t stream) {
+    step_conv_desc canon;
+    ConvParams p;
+    const int rc = conv_fill_params(d, x, w_packed, scale, shift, res, y, y2, canon, p);
+    if (rc != STEP_OK || p.N == 0) return rc;
+    switch (canon.dtype) {
+        case STEP_F32: return conv_forward_t<float>(&canon, p, ws, ws_bytes, stream);
+        case STEP_BF16: return conv_forward_t<bf16_t>(&canon, p, ws, ws_bytes, stream);
+        case STEP_F16: return conv_forward_t<f16_t>(&canon, p, ws, ws_bytes, stream);
     }
     return STEP_E_DTYPE;
+}
+
+// Can these convs share one grid?  All 16-bit 3x3x3 layers the planner sends to the two-phase conv_tap form on general boxes
+// (forced to 8 waves: a member that alone would take the four-wave form for its small grid is exactly what a group is for).
+static bool conv_group_plan(const step_conv_item* items, int n, step_conv_desc* canon, ConvParams* ps, ConvPlan* pls, int* NBc) {
+    if (n < 2 || n > CONV_GROUP_MAX) return false;
+    if (opt(STEP_OPT_CONV_IMPL) != -1 || opt(STEP_OPT_CONV_NB) != 0 || opt(STEP_OPT_CONV_WAVES) == 4 || opt(STEP_OPT_CONV_PHASED) == 0) return false;
+    int nb = 0;
+    for (int k = 0; k < n; ++k) {
+        const step_conv_desc* d = &canon[k];
+        if (d->dtype == STEP_F32 || d->dtype != canon[0].dtype) return false;
+        if (!(d->kd == 3 && d->kh == 3 && d->kw == 3) || ps[k].N == 0) return false;
+        constexpr int VEC = 8;
+        if (d->Cin % VEC || d->x_cstride % VEC || d->x_coff % VEC) return false;
+        if (((uintptr_t)ps[k].x % 16) || ((uintptr_t)ps[k].w % 16)) return false;
+        pls[k] = conv_plan(d, true, 8);
+        const ConvPlan& pl = pls[k];
+        if (!pl.ok || pl.impl != 1 || pl.ph != 1 || pl.wv != 8 || pl.tps != 2 || pl.twl != 0) return false;
+        if (pl.NB > nb) nb = pl.NB;
+    }
+    *NBc = nb;
+    return true;
+}
+
+int step_conv_forward_group(const step_conv_item* items, int n, step_stream_t stream) {
+    if (n < 0) return STEP_E_SHAPE;
+    if (n == 0) return STEP_OK;
+    if (!items) return STEP_E_NULL;
+    if (n <= CONV_GROUP_MAX) {
+        step_conv_desc canon[CONV_GROUP_MAX];
+        ConvParams ps[CONV_GROUP_MAX];
+        ConvPlan pls[CONV_GROUP_MAX];
+        bool ok = true;
+        for (int k = 0; k < n && ok; ++k) {
+            const step_conv_item& it = items[k];
+            const int rc = conv_fill_params(it.desc, it.x, it.w_packed, it.scale, it.shift, it.res, it.y, nullptr, canon[k], ps[k]);
+            if (rc != STEP_OK) return rc;
+            ok = ps[k].N != 0 && (!it.desc->split);
+        }
+        int NBc = 0;
+        if (ok && conv_group_plan(items, n, canon, ps, pls, &NBc)) {
+            ConvGroupParams g;
+            g.n = n;
+            // longest workgroups first (they are dispatched first): descending K depth
+            int order[CONV_GROUP_MAX];
+            for (int k = 0; k < n; ++k) order[k] = k;
+            if (n == 2 && (long long)canon[1].Cin * pls[1].NB > (long long)canon[0].Cin * pls[0].NB) { order[0] = 1; order[1] = 0; }
+            long long base = 0;
+            for (int j = 0; j < n; ++j) {
+                const int k = order[j];
+                ConvParams& p = g.p[j];
+                p = ps[k];
+                const ConvPlan& pl = pls[k];
+                p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.tiles_d = pl.tiles_d;
+                p.gtd = pl.gtd; p.gth = pl.gth; p.gtw = pl.gtw; p.gmode = pl.gmode;
+                const int groups = ceil_div(p.nblk32, 2 * NBc);
+                p.gx = (int)pl.mtiles; p.gy = groups;
+                const long long tot = (pl.mtiles * groups + 7) / 8 * 8;
+                p.gbase = (int)base; p.gcount = (int)tot;
+                base += tot;
+            }
+            for (int j = n; j < CONV_GROUP_MAX; ++j) g.p[j] = g.p[0];
+            if (base <= 0x7fffffffLL) {
+                const dim3 grid((unsigned)base);
+                return canon[0].dtype == STEP_BF16 ? conv_tap_group_launch<bf16_t>(NBc, g, grid, stream)
+                                                   : conv_tap_group_launch<f16_t>(NBc, g, grid, stream);
+            }
+        }
+    }
+    for (int k = 0; k < n; ++k) {                            // not groupable: one launch each (the same results)
+        const step_conv_item& it = items[k];
+        const int rc = step_conv_forward_ws(it.desc, it.x, it.w_packed, it.scale, it.shift, it.res, it.y, nullptr, nullptr, 0, stream);
+        if (rc != STEP_OK) return rc;
+    }
+    return STEP_OK;
+}
+
+int step_conv_group_kernel_name(const step_conv_item* items, int n, char* buf, int buflen) {
+    if (!items || !buf || buflen <= 0) return STEP_E_NULL;
+    buf[0] = 0;
+    if (n < 2 || n > CONV_GROUP_MAX) return STEP_OK;
+    step_conv_desc canon[CONV_GROUP_MAX];
+    ConvParams ps[CONV_GROUP_MAX];
+    ConvPlan pls[CONV_GROUP_MAX];
+    for (int k = 0; k < n; ++k) {
+        const step_conv_item& it = items[k];
+        if (conv_fill_params(it.desc, it.x, it.w_packed, it.scale, it.shift, it.res, it.y, nullptr, canon[k], ps[k]) != STEP_OK || ps[k].N == 0 || it.desc->split)
+            return STEP_OK;
+    }
+    int NBc = 0;
+    if (!conv_group_plan(items, n, canon, ps, pls, &NBc)) return STEP_OK;
+    const char* t = canon[0].dtype == STEP_BF16 ? "step::bf16_t" : "step::f16_t";
+    snprintf(buf, (size_t)buflen, "void step::conv_tap_group_kernel<%s, 0, %d, 3, 3, 3, 2, 2, 8, 1>(step::ConvGroupParams)", t, NBc);
+    return STEP_OK;
 }
 
 
@@ -860,7 +966,7 @@ int step_conv_plan_info(const step_conv_desc* d, int* info, int n) {
 __attribute__((visibility("default"))) void step_probe_set(void* buf) { step::g_probe_buf = (unsigned long long*)buf; }
 #endif
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 19; }
+int step_abi_version(void) { return 20; }
 
 }  // extern "C"
 

@@ -44,9 +44,8 @@ namespace step {
 // threads; the halo slab is shared and re-staged between slabs with the groups realigned.  No fragment double-buffering
 // (a wave's L and C phases alternate) -- same accumulation order as the classic form, bit-identical results.
 // PH = 1: group = wave / 4 (waves w and w + 4 share a SIMD), PH = 2: group = wave & 1.
-template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB, int WV, int PH = 0>
-__global__ __launch_bounds__(WV * 64, (WV == 8 && NB == 1 && TWL == 0 && PH == 0) ? 4 : 2)
-void conv_tap_kernel(ConvParams p) {
+template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB, int WV, int PH = 0, bool GRP = false>
+__device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
     static_assert(MB == 2 && (WV == 8 || WV == 4), "two accumulator rows per wave; 8 or 4 waves");
     static_assert(PH == 0 || (WV == 8 && TPS == 2 && sizeof(T) == 2), "two-phase form: 8 waves, two taps per step, 16-bit storage");
     constexpr int NT = WV * 64;                 // threads
@@ -274,6 +273,11 @@ void conv_tap_kernel(ConvParams p) {
         constexpr int QH = HSTEP / 16 / 256;             // 16-byte vectors per thread per step (256 threads per group) = NB
         static_assert(QH * 256 * 16 == HSTEP, "a step's half tile is a whole number of 256-thread rounds");
         const int grp = wn;                              // wave group = channel half
+        // grouped launches (GRP): a wave group whose channel blocks all lie past Cout -- a narrow member that takes its instantiation
+        // from a deeper partner, e.g. 48 channels at NB = 2 -- skips its fragment reads, weight stream and MFMAs and only keeps the
+        // barriers and its share of the halo staging.  (Plain launches multiply a duplicate block instead: the uniform branches
+        // cost 0.5-2 % on every layer, measured, and only odd block counts would gain.)
+        const bool act = GRP ? (nb0 + grp * NB < p.nblk32) : true;
         const int gtid = (PH == 2) ? ((wave >> 1) * 64 + lane) : (tid & 255);     // thread index inside the group
         unsigned char* const ldsBg = ldsB + grp * (2 * HSTEP);                     // per group: a ring of TWO step buffers
         const unsigned char* wthr[QH];
@@ -313,7 +317,7 @@ void conv_tap_kernel(ConvParams p) {
             constexpr int Q = (decltype(parc)::value + SI) & 1;    // parity of the global step
             u32x4 (&Rn)[QH] = Q ? R0 : R1;
             // ---- L
-            {
+            if (act) {
 #pragma unroll
                 for (int tp = 0; tp < TPS; ++tp) {
                     const int tap = SI * TPS + tp;                 // (compile-time after unrolling; the padded tap reads shift 0)
@@ -333,11 +337,11 @@ void conv_tap_kernel(ConvParams p) {
                     }
                 }
             }
-            store_B((Q ^ 1) * HSTEP, Rn);
+            if (act) store_B((Q ^ 1) * HSTEP, Rn);
 #ifndef STEP_EMUL
             __builtin_amdgcn_sched_barrier(0);             // the weight requests go BEHIND the fragment reads (see below)
 #endif
-            {
+            if (act) {
                 constexpr int S3 = SI + 3;
                 load_B(woff_of(slab + (S3 >= SPS ? 1 : 0), S3 >= SPS ? S3 - SPS : S3), Rn);
             }
@@ -353,7 +357,7 @@ void conv_tap_kernel(ConvParams p) {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #endif
-            {
+            if (act) {
 #pragma unroll
                 for (int tp = 0; tp < TPS; ++tp)
 #pragma unroll
@@ -376,8 +380,10 @@ void conv_tap_kernel(ConvParams p) {
         // instructions of index arithmetic behind the halo table (general boxes divide) then run under their latency instead of in
         // front of a second memory round trip (measured per workgroup: index tables 1.1-1.9 us, halo 0.5-1.6 us, weights + barrier
         // 0.7-1.2 us, one after the other) -- then halo slab 0; step 0 to ring buffer 0, steps 1 and 2 stay in the register sets
-        load_B(woff_of(0, 0), R0);
-        load_B(woff_of(SPS > 1 ? 0 : 1, SPS > 1 ? 1 : 0), R1);
+        if (act) {
+            load_B(woff_of(0, 0), R0);
+            load_B(woff_of(SPS > 1 ? 0 : 1, SPS > 1 ? 1 : 0), R1);
+        }
 #ifndef STEP_EMUL
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -387,8 +393,10 @@ void conv_tap_kernel(ConvParams p) {
         stage_A(0);
         ss_store();
         STEP_PROBE_MARK(p, 6);
-        store_B(0, R0);
-        load_B(woff_of(SPS > 2 ? 0 : 1, SPS > 2 ? 2 : 2 - SPS), R0);
+        if (act) {
+            store_B(0, R0);
+            load_B(woff_of(SPS > 2 ? 0 : 1, SPS > 2 ? 2 : 2 - SPS), R0);
+        }
         __syncthreads();
         STEP_PROBE_MARK(p, 1);
         typedef std::integral_constant<int, 0> P0;
@@ -406,6 +414,7 @@ void conv_tap_kernel(ConvParams p) {
         }
         if (grp == 0) __syncthreads();                    // realign before the epilogue reuses LDS
         STEP_PROBE_MARK(p, 2);
+        if (!act) return;                                  // (no barrier beyond this point in the 16-bit epilogue)
     } else {
     // global -> registers: this thread's vectors of the B tile of a pipeline step.  Branch-free on
     // purpose (a predicated load makes the compiler drain vmcnt at the loop head): threads without a
@@ -694,6 +703,22 @@ void conv_tap_kernel(ConvParams p) {
 }
 
 
+template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB, int WV, int PH = 0>
+__global__ __launch_bounds__(WV * 64, (WV == 8 && NB == 1 && TWL == 0 && PH == 0) ? 4 : 2)
+void conv_tap_kernel(ConvParams p) {
+    conv_tap_body<T, TWL, NB, KD, KH, KW, TPS, MB, WV, PH>(p);
+}
+
+// The same workgroups for up to CONV_GROUP_MAX independent problems in one grid (an Inception block's branch_1 and branch_2 3x3x3
+// convs: neither fills the chip's second round alone, and a launch boundary between them idles every CU for a prologue + an epilogue).
+template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB, int WV, int PH>
+__global__ __launch_bounds__(WV * 64, 2)
+void conv_tap_group_kernel(ConvGroupParams g) {
+    const int k = (g.n > 1 && blockIdx.x >= (unsigned)g.p[1].gbase) ? 1 : 0;
+    conv_tap_body<T, TWL, NB, KD, KH, KW, TPS, MB, WV, PH, true>(g.p[k]);
+}
+
+
 template <typename T, int TWL, int KD, int KH, int KW>
 static int launch_tap(const ConvParams& p, int NB, int tps, int wv, dim3 grid, step_stream_t stream) {
 #define STEP_TAP(NB_, TPS_, MB_) STEP_LAUNCH((conv_tap_kernel<T, TWL, NB_, KD, KH, KW, TPS_, MB_, 8>), grid, dim3(512), stream, p)
@@ -744,6 +769,19 @@ int conv_tap_ph_launch_impl(const ConvPlan& pl, const ConvParams& p, int kd, dim
     if (pl.twl == 0) return launch_tap_ph<T, 0>(p, pl.NB, grid, stream);
     if (pl.twl == 3) return launch_tap_ph<T, 3>(p, pl.NB, grid, stream);
     return pl.wide ? launch_tap_ph<T, 5>(p, pl.NB, grid, stream) : launch_tap_ph<T, 4>(p, pl.NB, grid, stream);
+}
+
+// grouped launch (general boxes, two-phase form): NB = the deepest member's accumulator depth
+template <typename T>
+int conv_tap_group_launch_impl(int NB, const ConvGroupParams& g, dim3 grid, step_stream_t stream) {
+#define STEP_TAPG(NB_) STEP_LAUNCH((conv_tap_group_kernel<T, 0, NB_, 3, 3, 3, 2, 2, 8, 1>), grid, dim3(512), stream, g)
+    switch (NB) {
+        case 1: STEP_TAPG(1); break;
+        case 2: STEP_TAPG(2); break;
+        default: STEP_TAPG(3); break;
+    }
+#undef STEP_TAPG
+    return STEP_LAUNCH_CHECK();
 }
 
 template <typename T>

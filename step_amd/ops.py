@@ -164,6 +164,44 @@ def conv_forward(x, w_packed, Cout, k, scale=None, shift=None, relu=True, res=No
     return out
 
 
+def conv_forward_group(members):
+    """Several INDEPENDENT convs as one launch where the library can merge them (step_conv_forward_group: today two 16-bit 3x3x3
+    layers of the two-phase conv_tap form -- an Inception block's branch_1 / branch_2 convs); otherwise they are launched one after
+    the other.  members: (x, w_packed, Cout, k, scale, shift, relu, out) per conv, `out` a channel slice to write into.  Same results
+    as conv_forward per member, bit for bit."""
+    L = _lib.lib()
+    n = len(members)
+    items = (_capi.ConvItem * n)()
+    descs, flops, nbytes = [], 0.0, 0
+    for it, (x, w_packed, Cout, k, scale, shift, relu, out) in zip(items, members):
+        N, D, H, W, Cin = x.shape
+        d = _capi.ConvDesc(dtype=_dt(x), N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2],
+                           x_cstride=_chan_slice(x), x_coff=0, y_cstride=_chan_slice(out), y_coff=0, res_cstride=0, res_coff=0,
+                           relu=int(bool(relu)), split=0, y2_cstride=0, y2_coff=0)
+        descs.append(d)
+        it.desc = ctypes.pointer(d)
+        it.x, it.w_packed, it.y = x.data_ptr(), w_packed.data_ptr(), out.data_ptr()
+        it.scale = None if scale is None else scale.data_ptr()
+        it.shift = None if shift is None else shift.data_ptr()
+        it.res = None
+        _lib.dptr(x), _lib.dptr(out)                                # (refuse non-device tensors: there is no CPU fallback)
+        pix = N * D * H * W
+        flops += 2.0 * pix * Cout * Cin * k[0] * k[1] * k[2]
+        nbytes += (pix * (Cin + Cout) + Cout * Cin * k[0] * k[1] * k[2]) * _ES[x.dtype]
+    stream = _lib.stream_ptr(members[0][0].device)
+    if PROFILE is not None:
+        buf = ctypes.create_string_buffer(256)
+        L.step_conv_group_kernel_name(items, n, buf, 256)
+        if not buf.value:                                            # not merged: per-member attribution
+            for (x, w_packed, Cout, k, scale, shift, relu, out) in members:
+                conv_forward(x, w_packed, Cout, k, scale, shift, relu, None, out)
+            return
+        with _Prof(buf.value.decode(), flops, nbytes):
+            _capi.check(L.step_conv_forward_group(items, n, stream), "step_conv_forward_group")
+        return
+    _capi.check(L.step_conv_forward_group(items, n, stream), "step_conv_forward_group")
+
+
 def conv_wgrad(x, gy, Cout, k, into=None):
     """Weight gradient of the stride-1 SAME conv: x channels-last [N,D,H,W,Cin] (any storage dtype, may be a channel
     slice), gy fp32 channels-last [N,D,H,W,Cout] (gradient w.r.t. the conv output before the affine epilogue).

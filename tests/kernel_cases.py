@@ -1085,6 +1085,58 @@ def case_conv_general_box_row_groups(bk, golden):
         _capi.set_option(bk.lib, "conv_waves", 0)
 
 
+def case_conv_group_matches_separate_launches(bk, golden):
+    """step_conv_forward_group: two independent 3x3x3 convs (an Inception block's branch_1 / branch_2 shapes: different inputs of one
+    scratch buffer, different depths, outputs = channel slices of one buffer) as ONE grid -- bit-identical to two step_conv_forward
+    calls; a narrow member inside a deeper instantiation leaves a wave group without channel blocks (it must skip, not store); fp32 /
+    pointwise members are launched separately with the same results."""
+    rs = np.random.RandomState(51)
+    N, D, H, W = 1, 8, 14, 14                                  # (general 8 x 2 x 14 boxes, 7 pixel tiles)
+    buf = ctypes.create_string_buffer(256)
+    for dt, (ci0, co0, ci1, co1), merged in ((BF16, (64, 200, 64, 40), True), (F16, (96, 64, 64, 64), True), (BF16, (64, 96, 64, 160), True),
+                                             (F32, (64, 96, 64, 40), False)):
+        t = rs.randn(N, ci0 + ci1, D, H, W).astype(np.float32)                    # the shared bottleneck buffer: member k reads its slice
+        ws = [(rs.randn(co, ci, 3, 3, 3) / np.sqrt(ci * 27)).astype(np.float32) for ci, co in ((ci0, co0), (ci1, co1))]
+        aff = [((1 + 0.1 * rs.randn(co)).astype(np.float32), (0.2 * rs.randn(co)).astype(np.float32)) for co in (co0, co1)]
+        te = bk.dev(encode(cl(t), dt))
+        ctot = 8 + co0 + co1 + 8
+        outs = []
+        for grouped in (True, False):
+            yb = bk.dev(np.zeros((N, D, H, W, ctot), NP_DT[dt]))
+            keep, items, descs = [], (_capi.ConvItem * 2)(), []
+            for k_, (ci, co, xoff, yoff) in enumerate(((ci0, co0, 0, 8), (ci1, co1, ci0, 8 + co0))):
+                d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=ci, Cout=co, kd=3, kh=3, kw=3, x_cstride=ci0 + ci1, x_coff=xoff,
+                                   y_cstride=ctot, y_coff=yoff, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+                wp = pack_weight(bk, ws[k_], dt)
+                sc, sh = bk.dev(aff[k_][0]), bk.dev(aff[k_][1])
+                keep += [d, wp, sc, sh]
+                descs.append(d)
+                it = items[k_]
+                it.desc = ctypes.pointer(d)
+                it.x, it.w_packed, it.scale, it.shift, it.res, it.y = (ctypes.cast(te.ptr, ctypes.c_void_p).value, ctypes.cast(wp.ptr, ctypes.c_void_p).value,
+                                                                       ctypes.cast(sc.ptr, ctypes.c_void_p).value, ctypes.cast(sh.ptr, ctypes.c_void_p).value, None,
+                                                                       ctypes.cast(yb.ptr, ctypes.c_void_p).value)
+            if grouped:
+                assert bk.lib.step_conv_group_kernel_name(items, 2, buf, 256) == 0
+                assert bool(buf.value) == merged, (dt, buf.value)
+                if merged:
+                    assert b"conv_tap_group_kernel" in buf.value
+                assert bk.lib.step_conv_forward_group(items, 2, bk.stream) == 0
+            else:
+                for k_ in range(2):
+                    it = items[k_]
+                    assert bk.lib.step_conv_forward(it.desc, it.x, it.w_packed, it.scale, it.shift, None, it.y, None, bk.stream) == 0
+            outs.append(yb.get())
+        assert np.array_equal(outs[0], outs[1]), (dt, ci0, co0, ci1, co1)
+        y = decode(outs[0], dt)
+        assert not y[..., :8].any() and not y[..., 8 + co0 + co1:].any()
+        for k_, (lo, hi, xlo, xhi) in enumerate(((8, 8 + co0, 0, ci0), (8 + co0, 8 + co0 + co1, ci0, ci0 + ci1))):
+            ref = ref_conv(t[:, xlo:xhi], ws[k_], aff[k_][0], aff[k_][1], dt)
+            got = uncl(y[..., lo:hi])
+            assert np.abs(got - ref).max() / np.abs(ref).max() < tol(dt), (dt, k_)
+    assert bk.lib.step_conv_forward_group(None, 0, bk.stream) == 0 and bk.lib.step_conv_forward_group(None, 1, bk.stream) == -3
+
+
 def case_conv_tail_round_split(bk, golden):
     """A layer that is one channel group deep and whose pixel tiles end in a small partial round of one-workgroup-per-CU slots is
     launched in two parts: the full rounds at NB = 3 and the tail tiles at NB = 1 (three times as many, shorter workgroups).

@@ -167,7 +167,7 @@ def test_tube_math_matches_reference_helpers():
     assert TM.anchor_tubes("0", T=9).shape == (1, 9, 4) and not TM.anchor_tubes("0", T=9).any()
 
 
-def test_deepcopy_owns_its_parameters_and_data_parallel_is_refused():
+def test_deepcopy_owns_its_parameters_and_data_parallel_replicas_own_their_helpers():
     """copy.deepcopy(net): every ConvUnit of the copy must read the COPY's parameters (a closure over the original module
     would keep computing with the original's weights); nn.DataParallel replication is refused loudly."""
     import copy
@@ -203,13 +203,12 @@ def test_deepcopy_owns_its_parameters_and_data_parallel_is_refused():
                     if u.bn is not None:
                         assert any(u.bn is sub for sub in m.modules())
         assert n_units >= 10
-    # torch.nn.parallel.replicate() calls this hook on every submodule (it needs a GPU to get that far, so call it directly)
+    # torch.nn.parallel.replicate() calls this hook on every submodule: the replica gets helpers of its own, bound to itself and
+    # versioned by the original (the replicated forward itself: tests/module_cases.py::case_data_parallel_replicas)
     for m in nets[0].modules():
-        if isinstance(m, backbone.Unit3D):
-            try:
-                m._replicate_for_data_parallel()
-                raised = False
-            except RuntimeError as e:
-                raised = "one process per GPU" in str(e)
-            assert raised
-            break
+        if isinstance(m, (backbone.Unit3D, backbone.Mixed)):
+            r = m._replicate_for_data_parallel()
+            for k, u in vars(m).items():
+                if isinstance(u, (backbone.ConvUnit, backbone._FusedPointwise)):
+                    ru = vars(r)[k]
+                    assert ru is not u and ru.owner is r and ru._src is u

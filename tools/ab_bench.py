@@ -50,6 +50,9 @@ def main():
     a = ap.parse_args()
     variants = a.var or ["conv_waves=8", "conv_waves=4"]
     L = _lib.lib()
+    LP = None                                             # `lib=prev` in a variant: tools/libstep_amd_prev.so (tools/build_prev.sh)
+    if any("lib=prev" in v for v in variants):
+        LP = _capi.declare(ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libstep_amd_prev.so")), strict=False)
     dt, tdt = _capi.BF16, torch.bfloat16
     dev = torch.device("cuda:0")
     st = _lib.stream_ptr()
@@ -75,15 +78,18 @@ def main():
         d = _capi.ConvDesc(dtype=dt, N=B, D=D, H=H, W=W, Cin=ci, Cout=co, kd=k, kh=k, kw=k, x_cstride=ci, x_coff=0,
                            y_cstride=co, y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
 
+        cur = [L]
+
         def run():
-            _capi.check(L.step_conv_forward(ctypes.byref(d), _lib.dptr(x), _lib.dptr(wp), _lib.dptr(sc), _lib.dptr(sh), None, _lib.dptr(y), None, st), name)
+            _capi.check(cur[0].step_conv_forward(ctypes.byref(d), _lib.dptr(x), _lib.dptr(wp), _lib.dptr(sc), _lib.dptr(sh), None, _lib.dptr(y), None, st), name)
 
         def setenv(v):                       # a variant = planner options (include/step_amd.h), everything else at its default
-            L.step_reset_options()
+            cur[0] = LP if "lib=prev" in v else L
+            cur[0].step_reset_options()
             for kv in v.split(","):
-                if kv and kv != "default":
+                if kv and kv not in ("default", "lib=prev"):
                     kk, vv = kv.split("=")
-                    _capi.set_option(L, kk, int(vv))
+                    _capi.set_option(cur[0], kk, int(vv))
 
         times = [[] for _ in variants]
         names = []
@@ -91,7 +97,7 @@ def main():
         for vi, v in enumerate(variants):
             setenv(v)
             kn = ctypes.create_string_buffer(256)
-            L.step_conv_kernel_name(ctypes.byref(d), kn, 256)
+            cur[0].step_conv_kernel_name(ctypes.byref(d), kn, 256)
             names.append(kn.value.decode()[11:].split("(")[0].replace("step::", "").replace("_kernel", ""))
             run()
             torch.cuda.synchronize()
