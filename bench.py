@@ -109,32 +109,48 @@ def cpu_baseline(net, seconds_budget=12.0):
 
 
 def roofline(net, x, dtype_name):
-    """Instrumented pass: HIP events around every launch (on the launch stream), 3 forwards."""
-    from step_amd import backbone, ops
-    ops.PROFILE = []
-    saved, backbone.BRANCH_STREAMS = backbone.BRANCH_STREAMS, False      # one stream: launches do not overlap, so an
-    with torch.no_grad():                                                 # event pair times exactly one kernel
-        for _ in range(3):
-            net(x)
+    """Per-launch durations of the REPLAYED step, measured live: HIP graphs of growing prefixes of the forward (launches 1..k, the
+    rest skipped by step_amd.ops.PROFILE_LIMIT) are captured and replayed, and launch k's duration is the difference of the best
+    replay times of prefix k and prefix k-1 -- the kernel in its real place of the sequence, at replay clocks, its inputs where the
+    previous kernel left them (L2 / MALL / HBM), no warm-up twin, no eager launch gaps.  The replayed step is a single-stream chain
+    (tools/graph_timeline.py: kernels start back to back), so the differences add up to the step time."""
+    from step_amd import ops
+    ops.PROFILE, ops.PROFILE_LIMIT = [], 1 << 30
+    with torch.no_grad():
+        net(x)
     torch.cuda.synchronize()
-    backbone.BRANCH_STREAMS = saved
-    rec, ops.PROFILE = ops.PROFILE, None
+    plan = ops.PROFILE
+    n = len(plan)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    times = [0.0]
+    try:
+        for k in range(1, n + 1):
+            ops.PROFILE, ops.PROFILE_LIMIT = [], k
+            g = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g):
+                net(x)
+            g.replay()
+            torch.cuda.synchronize()
+            best = float("inf")
+            for _ in range(4):
+                e0.record()
+                for _ in range(5):
+                    g.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / 5)
+            times.append(best)
+            del g
+    finally:
+        ops.PROFILE, ops.PROFILE_LIMIT = None, None
+    rec = [(name, flops, nbytes, max(times[k + 1] - times[k], 1e-4)) for k, (name, flops, nbytes, _, _) in enumerate(plan)]
     agg = {}
-    # the three forwards issue the same launches in the same order: every launch position is timed three times and the MEDIAN is
-    # used (one slow outlier -- a clock ramp, a first touch -- would otherwise decide which class is 'dominant')
-    npos = len(rec) // 3
-    same = npos > 0 and len(rec) == 3 * npos and all(rec[i][0] == rec[i + npos][0] == rec[i + 2 * npos][0] for i in range(npos))
-    for i, (name, flops, nbytes, e0, e1) in enumerate(rec):
+    for name, flops, nbytes, t in rec:
         a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
-        if same:
-            t3 = sorted(rec[(i % npos) + k * npos][3].elapsed_time(rec[(i % npos) + k * npos][4]) for k in range(3))
-            t = t3[1]
-        else:
-            t = e0.elapsed_time(e1)
-        a[0] += 1
-        a[1] += t
-        a[2] += flops
-        a[3] += nbytes
+        a[0] += 3                                   # (describe() below counts in units of three passes)
+        a[1] += 3 * t
+        a[2] += 3 * flops
+        a[3] += 3 * nbytes
     total_ms = sum(a[1] for a in agg.values())
     def describe(name, cnt, ms, flops, nbytes):
         avg_ms = ms / cnt
@@ -146,7 +162,8 @@ def roofline(net, x, dtype_name):
             try:
                 tj = json.load(open(tfile))
                 if name in tj.get("kernels", {}):
-                    traffic, tsrc = tj["kernels"][name].get("hbm_bytes_per_launch"), tj.get("source")
+                    traffic = tj["kernels"][name].get("hbm_bytes_per_launch")
+                    tsrc = "NOT measured in this run: profiles/traffic_latest.json (%s; taken at commit %s)" % (tj.get("source"), tj.get("commit", "?"))
                     # a one-group conv_tap layer is launched in two parts (full rounds at NB = 3, the partial last round at NB = 1,
                     # DESIGN.md 3.1): the timed call and its algorithmic bytes cover both, so does the traffic
                     tail = name.replace(", 3, 3, 3, 3, 2, 2, 8, 1>", ", 1, 3, 3, 3, 2, 2, 8, 1>") if ", 3, 3, 3, 3, 2, 2, 8, 1>" in name else None
@@ -168,14 +185,16 @@ def roofline(net, x, dtype_name):
                     "algorithmic_gflop_per_launch": round(flops / cnt / 1e9, 3),
                     "algorithmic_mb_per_launch": round(nbytes / cnt / 1e6, 3)})
         if tsrc:
-            out["traffic_source"] = tsrc
+            out["traffic_from"] = tsrc
         return out
 
     ranked = sorted(agg.items(), key=lambda kv: -kv[1][1])
     out = describe(ranked[0][0], *ranked[0][1])
     # the classes behind the dominant one (conv3d_2c and the stem are within a few per cent of each other: which of them leads
     # changes with the box), same accounting
-    out["next_kernels"] = [{k_: v_ for k_, v_ in describe(n_, *a_).items() if k_ != "traffic_source"} for n_, a_ in ranked[1:3]]
+    out["next_kernels"] = [{k_: v_ for k_, v_ in describe(n_, *a_).items() if k_ != "traffic_from"} for n_, a_ in ranked[1:3]]
+    out["method"] = ("durations = differences of the best replay times of HIP graphs of growing prefixes of the step (each launch in its place of "
+                     "the replayed sequence, no warm-up twin); 'dominant' = the kernel name with the largest summed time over the step")
     table = sorted(((n_, a[1] / 3, a[0] // 3, a[2] / max(a[1], 1e-9) / 1e9) for n_, a in agg.items()), key=lambda r: -r[1])   # TFLOP/s = flops / ms / 1e9
     return out, table, total_ms / 3
 

@@ -402,6 +402,37 @@ def fill_state_dict(shapes, tag=""):
     return sd
 
 
+def fill_state_dict_margin(shapes, tag=""):
+    """TwoBranchNet weights whose every ReLU pre-activation is far from zero (tests/golden/head_grad_margin_golden.npz).
+    With generic weights one of the ~300 k pre-activations of the head always lands within fp32 summation noise of 0, and a single
+    flipped mask moves the upstream gradients by ~1 %: gradient checks then need a 5e-2 tolerance.  Here the sign of a pre-activation
+    is STRUCTURAL:
+      * Unit3D (conv -> frozen BN -> ReLU, i3d_conv): small conv weights (x 0.05) and BN shifts of +-(1 .. 1.2) alternating per channel;
+      * Bottlenecks (conv -> ReLU, no BN / bias) on non-negative inputs: all weights of an output channel share one sign (alternating
+        per channel) in conv1 / conv2 (Bottleneck) and conv2 / conv3 (resample), so a pre-activation is +- a sum of non-negative terms;
+        the convs in front of a residual add (conv3 / conv4, the projection conv1) and `downsample` (weights and bias) are positive, so
+        the block outputs stay positive.  Magnitudes are divided by sqrt(fan_in) to keep activations O(1)."""
+    sd = fill_state_dict(shapes, tag)
+    for k, v in sd.items():
+        co = torch.arange(v.shape[0]) if v.dim() else None
+        alt = None if co is None else (1.0 - 2.0 * (co % 2).float())
+        if k.startswith("i3d_conv.") and k.endswith("conv3d.weight"):
+            v.mul_(0.05)
+        elif k.startswith("i3d_conv.") and k.endswith("batch3d.bias"):
+            v.copy_(alt * (1.0 + 4.0 * v.abs()))
+        elif k.startswith("i3d_conv.") and k.endswith("batch3d.running_mean"):
+            v.mul_(0.1)
+        elif k in ("downsample.weight", "downsample.bias"):
+            v.copy_(v.abs() + (0.1 if k.endswith("bias") else 0.0))
+        elif k.startswith("local_conv.") and k.endswith(".weight"):
+            fan_in = float(v[0].numel())
+            signed = (k.startswith("local_conv.0.") and k.split(".")[2] in ("conv2", "conv3")) or \
+                     (not k.startswith("local_conv.0.") and k.split(".")[2] in ("conv1", "conv2"))
+            w = (v.abs() + 0.02 * math.sqrt(6.0 / fan_in)) * (fan_in ** -0.5) * 2.0
+            v.copy_(w * alt.view(-1, *([1] * (v.dim() - 1))) if signed else w)
+    return sd
+
+
 def backbone_shapes(prefix="base_model"):
     """state_dict key -> shape for BaseNet (270 keys)."""
     out = {}

@@ -616,6 +616,57 @@ def i3d_main():
     print("i3d classifier", tuple(logits.shape), float(logits.abs().max()))
 
 
+def head_grad_margin_main():
+    """As head_grad_main, with the MARGIN weights of oracle.i3d_ref.fill_state_dict_margin: every ReLU pre-activation of the
+    reference's TwoBranchNet is at least `margin` (recorded, relative to the layer's rms) away from zero, so a reimplementation's
+    gradients must agree to fp32 noise -- no ReLU mask can flip -- and the test asserts 1e-3."""
+    from oracle import i3d_ref as R
+    models, _, _, _ = import_reference()
+    hg = np.load(os.path.join(OUT, "head_golden.npz"))
+    det = models.TwoBranchNet(cfg())
+    shapes = {k: tuple(v.shape) for k, v in det.state_dict().items()}
+    det.load_state_dict(R.fill_state_dict_margin(shapes, "det0."))
+    det.set_device("cpu")
+    det.train()
+    margins = []
+
+    def pre(_m, inp):
+        x = inp[0].detach()
+        margins.append(float(x.abs().min() / x.pow(2).mean().sqrt()))
+
+    def post_bn(_m, _i, out):
+        x = out.detach()
+        margins.append(float(x.abs().min() / x.pow(2).mean().sqrt()))
+
+    for m in det.modules():
+        if isinstance(m, torch.nn.ReLU):
+            m.register_forward_pre_hook(pre)
+        if isinstance(m, torch.nn.BatchNorm3d):
+            m.register_forward_hook(post_bn)
+    pf = R.fill_tensor("golden.det.pooled3", (2, 3, 832, 7, 7), "feat")
+    cx = R.fill_tensor("golden.det.ctx3", (2, 1024, 3, 1, 1), "feat")
+    o = det(pf, context_feat=cx, tubes=torch.from_numpy(hg["loss_tubes"]), targets=torch.from_numpy(hg["loss_targets"]))
+    loss = o[4].mean() + 5.0 * o[5].mean() + o[6].mean()
+    loss.backward()
+    assert len(margins) == 12 + 9, len(margins)                 # 12 units of mixed_5b / 5c, 3 ReLUs in each of the 3 bottlenecks
+    assert min(margins) >= 1e-3, margins
+    g = {"loss": np.float64(loss.item()), "margin": np.float64(min(margins)), "outputs": np.concatenate([t.detach().reshape(-1).numpy() for t in o[:4]])}
+    names = []
+    for k, p in det.named_parameters():
+        if not p.requires_grad:
+            continue
+        f = p.grad.detach().reshape(-1)
+        step = max(1, f.numel() // 512)
+        names.append(k)
+        g["norm." + k] = np.float64(f.double().norm().item())
+        g["step." + k] = np.int64(step)
+        g["sample." + k] = f[::step][:512].numpy().copy()
+    g["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "head_grad_margin_golden.npz"), **g)
+    print("head_grad_margin_golden ok: %d tensors, loss %.6f, least |pre-activation| / rms over the %d ReLU sites %.3e" % (
+        len(names), loss.item(), len(margins), min(margins)))
+
+
 def head_grad_main():
     """Gradients of the reference's OWN TwoBranchNet under its own autograd (two_branch.py:215-333, train mode, frozen BN,
     dropout 0): the loss of train.py:318-331 (cls + 5 reg + neighbour) on the head_golden inputs, back-propagated to every
@@ -683,6 +734,8 @@ def base_grad_main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "i3d":
         i3d_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "head_grad_margin":
+        head_grad_margin_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "head_grad":
         head_grad_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "base_grad":

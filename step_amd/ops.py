@@ -13,13 +13,14 @@ from . import _capi, _lib
 
 DT = {torch.float32: _capi.F32, torch.bfloat16: _capi.BF16, torch.float16: _capi.F16}
 
-# Optional per-launch instrumentation (bench.py's roofline leg): when PROFILE is a list, every kernel
-# launch below is bracketed by two HIP events on the launch stream and a record
-# (kernel_name, algorithmic_flops, algorithmic_bytes, start_event, end_event) is appended.
+# Optional per-launch instrumentation (bench.py's roofline legs).  PROFILE = a list: every instrumented launch appends
+# (kernel name, algorithmic FLOPs, algorithmic bytes, event0, event1).
+#   * PROFILE_LIMIT = None (eager legs of the C3 / C4 pipelines): HIP events bracket the launch on its launch stream;
+#   * PROFILE_LIMIT = k (the C2 leg): nothing is timed here -- the launch is recorded and EXECUTED only if it is among the first k of
+#     the forward, so that bench.py can capture HIP graphs of growing prefixes of the step and time a launch as the difference of two
+#     replays: in its real place of the replayed sequence, at replay clocks, its inputs wherever the previous kernel left them.
 PROFILE = None
-WGRAD16_WS = True      # 16-bit weight gradients: partial-tile workspace + fixed-order sum instead of fp32 atomics (module switch for tests / A-B timing)
-
-
+PROFILE_LIMIT = None
 class _Prof:
     __slots__ = ("name", "flops", "bytes", "e0")
 
@@ -47,6 +48,21 @@ class _NoProf:
 
 
 _NOPROF = _NoProf()
+
+
+def _run(launch, describe):
+    """Run one forward launch; under PROFILE record / time it (see the comment at PROFILE).  describe() -> (name, flops, bytes)."""
+    if PROFILE is None:
+        launch()
+        return
+    name, flops, nbytes = describe()
+    if PROFILE_LIMIT is not None:
+        PROFILE.append((name, flops, nbytes, None, None))
+        if len(PROFILE) <= PROFILE_LIMIT:
+            launch()
+        return
+    with _Prof(name, flops, nbytes):
+        launch()
 _ES = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2}
 _TNAME = {torch.float32: "float", torch.bfloat16: "step::bf16_t", torch.float16: "step::f16_t"}
 
@@ -144,23 +160,19 @@ def conv_forward(x, w_packed, Cout, k, scale=None, shift=None, relu=True, res=No
                        x_cstride=xcs, x_coff=0, y_cstride=ycs, y_coff=0,
                        res_cstride=(_chan_slice(res) if res is not None else 0), res_coff=0, relu=int(bool(relu)),
                        split=int(split), y2_cstride=(_chan_slice(out2) if out2 is not None else 0), y2_coff=0)
-    prof = _NOPROF
-    if PROFILE is not None:
+    def describe():
         buf = ctypes.create_string_buffer(256)
         L.step_conv_kernel_name(ctypes.byref(d), buf, 256)
         pix = N * D * H * W
-        prof = _Prof(buf.value.decode(), 2.0 * pix * Cout * Cin * k[0] * k[1] * k[2],
-                     (pix * (Cin + Cout) + Cout * Cin * k[0] * k[1] * k[2]) * _ES[x.dtype])
+        return (buf.value.decode(), 2.0 * pix * Cout * Cin * k[0] * k[1] * k[2],
+                (pix * (Cin + Cout) + Cout * Cin * k[0] * k[1] * k[2]) * _ES[x.dtype])
     wsb = L.step_conv_workspace_bytes(ctypes.byref(d))            # > 0 only for the split-K Linear layers of the heads
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
     def launch():
         _capi.check(L.step_conv_forward_ws(ctypes.byref(d), _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift),
                                            _lib.dptr(res), _lib.dptr(out), _lib.dptr(out2), _lib.dptr(ws), wsb,
                                            _lib.stream_ptr(x.device)), "step_conv_forward_ws")
-    if PROFILE is not None:
-        launch()           # untimed twin right in front of the timed launch (idempotent): the event pair then brackets a launch that
-    with prof:             # runs back to back with GPU work -- after an idle gap a short kernel is timed at ramped-down clocks (3x off)
-        launch()
+    _run(launch, describe)
     return out
 
 
@@ -196,10 +208,8 @@ def conv_forward_group(members):
             for (x, w_packed, Cout, k, scale, shift, relu, out) in members:
                 conv_forward(x, w_packed, Cout, k, scale, shift, relu, None, out)
             return
-        with _Prof(buf.value.decode(), flops, nbytes):
-            _capi.check(L.step_conv_forward_group(items, n, stream), "step_conv_forward_group")
-        return
-    _capi.check(L.step_conv_forward_group(items, n, stream), "step_conv_forward_group")
+    _run(lambda: _capi.check(L.step_conv_forward_group(items, n, stream), "step_conv_forward_group"),
+         lambda: (buf.value.decode(), flops, nbytes))
 
 
 def conv_wgrad(x, gy, Cout, k, into=None):
@@ -304,20 +314,15 @@ def stem_forward(x, w_packed, Cout, scale, shift, out=None):
     To, Ho, Wo = (T - 2) // 2 + 1, (H - 2) // 2 + 1, (W - 2) // 2 + 1
     if out is None:
         out = torch.empty((N, To, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
-    prof = _NOPROF
-    if PROFILE is not None:
+    def describe():
         pix = N * To * Ho * Wo
         buf = ctypes.create_string_buffer(256)
         _capi.check(L.step_stem_kernel_name(_dt(x), buf, 256), "step_stem_kernel_name")
-        prof = _Prof(buf.value.decode(), 2.0 * pix * Cout * 1029,
-                     (x.numel() + pix * Cout + Cout * 1029) * _ES[x.dtype])
+        return buf.value.decode(), 2.0 * pix * Cout * 1029, (x.numel() + pix * Cout + Cout * 1029) * _ES[x.dtype]
     def launch():
         _capi.check(L.step_stem_forward(_dt(x), _lib.dptr(x), N, T, H, W, _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift),
                                         Cout, _lib.dptr(out), _chan_slice(out), 0, _lib.stream_ptr(x.device)), "step_stem_forward")
-    if PROFILE is not None:
-        launch()           # (untimed twin, see conv_forward)
-    with prof:
-        launch()
+    _run(launch, describe)
     return out
 
 
@@ -366,22 +371,17 @@ def maxpool_tf(x, k, s, out=None):
     if out is None:
         out = torch.empty((N, L.step_pool_out_size(D, k[0], s[0]), L.step_pool_out_size(H, k[1], s[1]),
                            L.step_pool_out_size(W, k[2], s[2]), C), dtype=x.dtype, device=x.device)
-    prof = _NOPROF
-    if PROFILE is not None:
+    def describe():
         ks = (tuple(k), tuple(s))
         sep = ks in (((3, 3, 3), (1, 1, 1)), ((1, 3, 3), (1, 2, 2)), ((3, 3, 3), (2, 2, 2))) and not _capi.get_option(L, "pool_direct")
         tn = _TNAME[x.dtype]
         kn = ("maxpool_sep_kernel<%s, %d, %d, %d, %d, %d, %d, 256>" % ((tn,) + ks[0] + ks[1]), ", int" * 7) if sep else \
             ("maxpool3d_tf_kernel<%s>" % tn, ", long long")
-        prof = _Prof("void step::%s(%s const*, %s*, step::PoolParams%s)" % (kn[0], tn, tn, kn[1]),
-                     0.0, (x.numel() + out.numel()) * _ES[x.dtype])
+        return "void step::%s(%s const*, %s*, step::PoolParams%s)" % (kn[0], tn, tn, kn[1]), 0.0, (x.numel() + out.numel()) * _ES[x.dtype]
     def launch():
         _capi.check(L.step_maxpool3d_tf(_dt(x), _lib.dptr(x), N, D, H, W, C, _chan_slice(x), 0, k[0], k[1], k[2], s[0], s[1], s[2],
                                         _lib.dptr(out), _chan_slice(out), 0, _lib.stream_ptr(x.device)), "step_maxpool3d_tf")
-    if PROFILE is not None:
-        launch()           # (untimed twin, see conv_forward)
-    with prof:
-        launch()
+    _run(launch, describe)
     return out
 
 

@@ -230,6 +230,40 @@ def case_roi_pool_forward_backward(bk, golden):
         assert np.abs(got - refg).max() <= 1e-5
 
 
+def case_roi_pool_hand_derived_vectors(bk, golden):
+    """step_roi_pool_forward / _backward against the 12 cases derived by hand from the reference's CUDA kernel
+    (tests/golden/make_roipool_hand_vectors.py, ROIPool_cuda.cu:40-132): value, argmax and gradient scatter, both layouts, bit for bit;
+    the 16-bit storage types give the same argmax and the same (exactly representable) values."""
+    import json
+    vec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "roipool_hand_vectors.json")))
+    for v in vec:
+        x = np.array(v["feature"], np.float32)
+        rois = np.array(v["rois"], np.float32)
+        B, C, H, W = x.shape
+        K = rois.shape[0]
+        PH, PW = v["pooled"]
+        want, wantarg = np.array(v["out"], np.float32), np.array(v["argmax"], np.int32)
+        for layout in (NCHW, NHWC):
+            for dt in (F32, BF16, F16):
+                xx, r = bk.dev(encode(x if layout == NCHW else nhwc(x), dt)), bk.dev(rois)
+                oshape = (K, C, PH, PW) if layout == NCHW else (K, PH, PW, C)
+                out, arg = bk.dev(np.zeros(oshape, NP_DT[dt])), bk.dev(np.full(oshape, 7, np.int32))
+                assert bk.lib.step_roi_pool_forward(xx.ptr, dt, layout, r.ptr, K, B, C, H, W, PH, PW, v["spatial_scale"], out.ptr, arg.ptr,
+                                                    bk.stream) == 0
+                o, a = decode(out.get(), dt), arg.get()
+                if layout == NHWC:
+                    o, a = nchw(o), nchw(a)
+                assert np.array_equal(a, wantarg), (v["name"], layout, dt, v["decided_by"])
+                assert np.array_equal(o, want), (v["name"], layout, dt, v["decided_by"])          # (integers <= 178: exact in bf16 / fp16)
+            g = np.array(v["grad_out"], np.float32)
+            gg = bk.dev(g if layout == NCHW else nhwc(g))
+            argd = bk.dev(wantarg if layout == NCHW else nhwc(wantarg))
+            gi = bk.dev(np.full((B, C, H, W) if layout == NCHW else (B, H, W, C), 3.0, np.float32))           # the op zeroes it
+            assert bk.lib.step_roi_pool_backward(gg.ptr, argd.ptr, layout, r.ptr, K, B, C, H, W, PH, PW, gi.ptr, bk.stream) == 0
+            got = gi.get() if layout == NCHW else nchw(gi.get())
+            assert np.array_equal(got, np.array(v["grad_in"], np.float32)), (v["name"], layout)
+
+
 def case_roi_empty_and_bad_args(bk, golden):
     L = bk.lib
     x = bk.dev(np.zeros((1, 4, 4, 8), np.float32))

@@ -471,8 +471,60 @@ def case_e2e_c3_golden(dev, golden):
 
 
 def case_training_step_matches_torch_autograd(dev, golden):
-    """One TwoBranchNet training step (losses + backward): parameter gradients of the HIP-forward module
-    equal those of the torch-CPU oracle evaluated with autograd on the same weights/inputs."""
+    """One TwoBranchNet training step (losses + backward) on the MARGIN weights (oracle.i3d_ref.fill_state_dict_margin: every ReLU
+    pre-activation of the head is structurally >= 0.35 rms away from zero, so no mask can flip under a different summation order):
+    loss and every trainable parameter's gradient of the HIP module against (a) the torch-CPU restatement under autograd on the same
+    weights / inputs, all elements, and (b) the REFERENCE's own TwoBranchNet under its own autograd (head_grad_margin_golden.npz,
+    `python -m oracle.make_golden head_grad_margin`: per-parameter L2 norm and a strided 512-element sample) -- 1e-3."""
+    g = golden("head_golden")
+    rg = golden("head_grad_margin_golden")
+    net = step_amd.TwoBranchNet(cfg())
+    net.load_state_dict(R.fill_state_dict_margin({k: tuple(v.shape) for k, v in net.state_dict().items()}, "det0."))
+    net = net.to(dev)
+    net.set_device(dev)
+    net.train()
+    pf = R.fill_tensor("golden.det.pooled3", (2, 3, 832, 7, 7), "feat").to(dev)
+    cx = R.fill_tensor("golden.det.ctx3", (2, 1024, 3, 1, 1), "feat").to(dev)
+    tubes, targets = torch.from_numpy(g["loss_tubes"]).to(dev), torch.from_numpy(g["loss_targets"]).to(dev)
+    o = net(pf, context_feat=cx, tubes=tubes, targets=targets)
+    loss = o[4].mean() + 5.0 * o[5].mean() + o[6].mean()
+    loss.backward()
+    assert rel(np.concatenate([np_(t).reshape(-1) for t in o[:4]]), rg["outputs"]) < 1e-3
+    assert abs(float(np_(loss)) - float(rg["loss"])) < 1e-3 * abs(float(rg["loss"]))
+    # (a) the restatement with autograd, every element
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and "batch3d" not in k)
+          for k, v in net.state_dict().items()}
+    oo = R.twobranch_forward(pf.cpu(), cx.cpu(), sd, tubes=tubes.cpu(), targets=targets.cpu())
+    (oo[4].mean() + 5.0 * oo[5].mean() + oo[6].mean()).backward()
+    checked, worst = 0, 0.0
+    for k, p in net.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, k
+        a, b = np_(p.grad).astype(np.float64), sd[k].grad.numpy().astype(np.float64)
+        e = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+        worst = max(worst, e)
+        assert e < 1e-3, (k, e)
+        checked += 1
+    record("head_grad_margin_worst_rel_l2", worst)
+    info = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
+    assert checked == len(info["TwoBranchNet_trainable"])
+    # (b) the reference's own autograd
+    params = dict(net.named_parameters())
+    for k in (str(n) for n in rg["names"]):
+        gr = params[k].grad.detach().reshape(-1)
+        a = np_(gr[::int(rg["step." + k])][:512]).astype(np.float64)
+        b = rg["sample." + k].astype(np.float64)
+        n_ = float(gr.double().norm())
+        assert abs(n_ - float(rg["norm." + k])) <= 1e-3 * float(rg["norm." + k]), (k, n_, float(rg["norm." + k]))
+        assert np.linalg.norm(a - b) <= 1e-3 * max(np.linalg.norm(b), 1e-30) + 1e-12, k
+
+
+def case_training_step_generic_weights(dev, golden):
+    """The same step on the GENERIC filler weights against the reference's own autograd (head_grad_golden.npz).  With ~300 k ReLU
+    pre-activations of ordinary magnitude one always lies within fp32 summation noise of zero; ONE flipped mask element moves the
+    upstream gradients of this two-tube batch by 0.4-1.5 % in relative L2 (observed), with no flip the agreement is ~1e-6.  This case
+    therefore only bounds the damage (5e-2); the 1e-3 parity statement is case_training_step_matches_torch_autograd above."""
     g = golden("head_golden")
     net = fill(step_amd.TwoBranchNet(cfg()), "det0.").to(dev)
     net.set_device(dev)
@@ -483,29 +535,6 @@ def case_training_step_matches_torch_autograd(dev, golden):
     o = net(pf, context_feat=cx, tubes=tubes, targets=targets)
     loss = o[4].mean() + 5.0 * o[5].mean() + o[6].mean()
     loss.backward()
-    # oracle with autograd
-    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and "batch3d" not in k)
-          for k, v in net.state_dict().items()}
-    oo = R.twobranch_forward(pf.cpu(), cx.cpu(), sd, tubes=tubes.cpu(), targets=targets.cpu())
-    (oo[4].mean() + 5.0 * oo[5].mean() + oo[6].mean()).backward()
-    assert rel(np_(loss), float((oo[4].mean() + 5.0 * oo[5].mean() + oo[6].mean()).detach())) < 1e-3
-    checked = 0
-    for k, p in net.named_parameters():
-        if not p.requires_grad:
-            continue
-        assert p.grad is not None, k
-        # The gradient of this tiny batch is carried by few elements, and a pre-activation that is ~1e-7
-        # can land on either side of the ReLU depending on summation order (observed: ONE flipped mask
-        # element in 301k changes every upstream gradient by ~0.4-1.5 % in relative L2; with no flip the
-        # agreement is ~1e-6).  So the check is on the relative L2 error with room for a flip.
-        a, b = np_(p.grad).astype(np.float64), sd[k].grad.numpy().astype(np.float64)
-        e = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
-        assert e < 5e-2, (k, e)
-        checked += 1
-    info = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
-    assert checked == len(info["TwoBranchNet_trainable"])
-    # ... and those of the REFERENCE's own TwoBranchNet under its own autograd (head_grad_golden.npz, recorded by
-    # `python -m oracle.make_golden head_grad`: per-parameter L2 norm and a strided 512-element sample)
     rg = golden("head_grad_golden")
     assert abs(float(np_(loss)) - float(rg["loss"])) < 1e-3 * abs(float(rg["loss"]))
     params = dict(net.named_parameters())
@@ -1051,6 +1080,7 @@ def case_c5_full_size_properties(dev, golden):
 
 CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_golden", "case_context_golden",
              "case_twobranch_T3_and_losses_golden", "case_roinet_layouts", "case_training_step_matches_torch_autograd",
+             "case_training_step_generic_weights",
              "case_flat_adam_matches_torch", "case_wgrad_into_and_targets", "case_twobranch_variants_golden",
              "case_reg_unit_pack_follows_weight_updates", "case_basenet_backward_matches_oracle_autograd",
              "case_contextnet_backward_matches_oracle_autograd", "case_postprocess_golden",

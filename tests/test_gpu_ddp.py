@@ -121,3 +121,35 @@ def test_two_rank_gradient_equals_single_process_on_the_concatenated_batch():
     e = np.linalg.norm(sample - ref_sample) / np.linalg.norm(ref_sample)
     en = np.abs(norms - ref_norms).max() / ref_norms.max()
     assert e < 1e-2 and en < 1e-2, (e, en)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("config", ["c4", "c2"])
+def test_bench_launches_and_reduces_over_two_ranks(config):
+    """`python bench.py --gpus 2`: the launch path the driver's 1/2/4/8-GPU scaling run takes -- bench.py spawns its own ranks under
+    torch.distributed.run (127.0.0.1), every rank times its steps between barriers, the MAX over ranks is all-reduced, rank 0 prints
+    ONE JSON line whose value is the whole-job clips/s; C4 runs the training step with the bucketed overlapped gradient exchange.
+    On a one-GPU box the two ranks share the GPU (STEP_BENCH_SHARE_GPU=1) and rendezvous over gloo (RCCL refuses two ranks on one
+    device); with two GPUs visible it is the production path over RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    two = torch.cuda.device_count() >= 2
+    if not two:
+        env.update(STEP_BENCH_SHARE_GPU="1", STEP_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", config, "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=850, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                    # rank 0 alone prints
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["unit"] == "clips/s"
+    assert j["ranks"]["world_size"] == 2 and j["ranks"]["backend"].startswith("nccl" if two else "gloo")
+    assert np.isfinite(j["value"]) and j["value"] > 0 and np.isfinite(j["ms_per_step"]) and j["ms_per_step"] > 0
+    # whole-job value = clips of BOTH ranks over the slowest rank's time
+    clips = j["config"]["clips_per_gpu"]
+    assert abs(j["value"] - 2 * clips / (j["ms_per_step"] * 1e-3)) < 0.02 * j["value"], j

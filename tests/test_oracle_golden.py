@@ -206,6 +206,28 @@ def test_head_gradients_of_the_restatement_match_the_reference_autograd(golden):
         assert np.linalg.norm(a - b) <= 2e-4 * max(np.linalg.norm(b), 1e-30), k
 
 
+def test_head_gradients_with_relu_margins_match_the_reference_autograd(golden):
+    """The same anchor on the MARGIN weights (oracle.i3d_ref.fill_state_dict_margin; head_grad_margin_golden.npz from the reference's
+    own autograd, every ReLU pre-activation >= 0.35 rms away from zero): no mask can flip, so the restatement must agree to fp32
+    noise -- 1e-5 here, and the HIP path is held to 1e-3 against the same file (module_cases.case_training_step_matches_torch_autograd)."""
+    hg, g = golden("head_golden"), golden("head_grad_margin_golden")
+    assert float(g["margin"]) >= 1e-3
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "batch3d" not in k and "running" not in k)
+          for k, v in R.fill_state_dict_margin(R.twobranch_shapes(), "det0.").items()}
+    pf = R.fill_tensor("golden.det.pooled3", (2, 3, 832, 7, 7), "feat")
+    cx = R.fill_tensor("golden.det.ctx3", (2, 1024, 3, 1, 1), "feat")
+    o = R.twobranch_forward(pf, cx, sd, tubes=torch.from_numpy(hg["loss_tubes"]), targets=torch.from_numpy(hg["loss_targets"]))
+    loss = o[4].mean() + 5.0 * o[5].mean() + o[6].mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    for k in (str(n) for n in g["names"]):
+        gr = sd[k].grad.reshape(-1)
+        step = int(g["step." + k])
+        assert abs(float(gr.double().norm()) - float(g["norm." + k])) <= 1e-5 * float(g["norm." + k]), k
+        a, b = gr[::step][:512].numpy().astype(np.float64), g["sample." + k].astype(np.float64)
+        assert np.linalg.norm(a - b) <= 1e-5 * max(np.linalg.norm(b), 1e-30), k
+
+
 def test_backbone_gradients_of_the_restatement_match_the_reference_autograd(golden):
     """a-19, backbone leg: base_grad_golden.npz = the gradients of the reference's own BaseNet under its own autograd
     (`python -m oracle.make_golden base_grad`); the restatement's autograd reproduces them (the 32x32 clip of the interpreter run)."""
@@ -335,3 +357,20 @@ def test_roi_pool_restatement_against_an_independent_implementation():
         for c in range(C):
             np.add.at(ref[b, c].reshape(-1), arg[k, c].reshape(-1), g[k, c].reshape(-1).astype(np.float64))
     assert np.abs(gin - ref).max() < 1e-5
+
+
+def test_roi_pool_restatement_matches_the_hand_derived_vectors():
+    """ROIPool has no CPU implementation in the reference (ROIPool.h:47,68); the C restatement is pinned by 12 cases worked out by
+    hand from ROIPool_cuda.cu:40-132 (tests/golden/make_roipool_hand_vectors.py: bin tables with the deciding source line each) --
+    forward value, argmax and the backward scatter, bit for bit."""
+    import json
+    vec = json.load(open(os.path.join(GOLDEN, "roipool_hand_vectors.json")))
+    assert len(vec) >= 12
+    for v in vec:
+        x = np.array(v["feature"], np.float32)
+        rois = np.array(v["rois"], np.float32)
+        out, arg = oracle.roi_pool_forward(x, rois, tuple(v["pooled"]), v["spatial_scale"])
+        assert np.array_equal(out, np.array(v["out"], np.float32)), (v["name"], v["decided_by"])
+        assert np.array_equal(arg, np.array(v["argmax"], np.int32)), (v["name"], v["decided_by"])
+        gin = oracle.roi_pool_backward(np.array(v["grad_out"], np.float32), arg, rois, tuple(v["pooled"]), x.shape)
+        assert np.array_equal(gin, np.array(v["grad_in"], np.float32)), v["name"]

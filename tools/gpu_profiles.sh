@@ -15,26 +15,28 @@ prof c3 --config c3 --steps 20 --warmup 5 --no-cpu-baseline
 prof c4_bf16 --config c4 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline
 prof c4_f32 --config c4 --steps 10 --warmup 3 --no-cpu-baseline
 prof c5 --config c5 --steps 20 --warmup 5 --no-cpu-baseline
+export STEP_COMMIT=${STEP_COMMIT:-?}
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 4 --warmup 2 --no-graph --no-cpu-baseline > $O/pmc_$c.json 2> $O/pmc_$c.err
 done
 cd $R
-K1='void step::conv_tap_kernel<step::bf16_t, 3, 3, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'
-K2='void step::stem_stream_kernel<step::bf16_t, 2>(step::StemParams)'
-K3='void step::conv_tap_kernel<step::bf16_t, 0, 2, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'
-K4='void step::conv_tap_kernel<step::bf16_t, 0, 3, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'
-K5='void step::conv_tap_kernel<step::bf16_t, 0, 1, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'
-K6='void step::maxpool_sep_kernel<step::bf16_t, 3, 3, 3, 1, 1, 1, 256>(step::bf16_t const*, step::bf16_t*, step::PoolParams, int, int, int, int, int, int, int, int)'
-K7='void step::maxpool_sep_kernel<step::bf16_t, 1, 3, 3, 1, 2, 2, 256>(step::bf16_t const*, step::bf16_t*, step::PoolParams, int, int, int, int, int, int, int, int)'
-K8='void step::conv_pw_kernel<step::bf16_t, 1, 8>(step::ConvParams)'
-K9='void step::conv_pws_kernel<step::bf16_t, 3, 4>(step::ConvParams, int)'
-K10='void step::conv_pw_kernel<step::bf16_t, 3, 4>(step::ConvParams)'
-K11='void step::conv_tap_kernel<step::bf16_t, 3, 1, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'    # conv3d_2c's partial last round (C2)
-python tools/pmc_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/traffic_latest.json "$K1" "$K2" "$K3" "$K4" "$K5" "$K6" "$K7" "$K8" "$K9" "$K10" "$K11" > $O/pmc_traffic.log 2>&1
+# every step:: kernel of the C2 backbone that the PMC passes saw (names as rocprofv3 prints them)
+python - <<P
+import csv, glob, subprocess, sys
+names = set()
+for f in glob.glob('$O/pmc_FETCH_SIZE/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Kernel_Name"].startswith("void step::"):
+            names.add(r["Kernel_Name"])
+sys.exit(subprocess.call([sys.executable, "tools/pmc_traffic.py", "$O/pmc_FETCH_SIZE", "$O/pmc_WRITE_SIZE", "$O/traffic_latest.json"] + sorted(names),
+                         stdout=open("$O/pmc_traffic.log", "w"), stderr=subprocess.STDOUT))
+P
 python - <<P
 import json
 f='$O/traffic_latest.json'; j=json.load(open(f)); k=j['kernels']
-if '''$K11''' in k: k['''$K11''']['with']='''$K1'''
+K1='void step::conv_tap_kernel<step::bf16_t, 3, 3, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'
+K11='void step::conv_tap_kernel<step::bf16_t, 3, 1, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'   # conv3d_2c's partial last round (C2)
+if K11 in k: k[K11]['with']=K1
 json.dump(j, open(f,'w'), indent=1)
 P
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE

@@ -33,7 +33,14 @@ def main(fetch_dir, write_dir, out, *kernels):
         rd = f * 1024 * 2          # gfx950: FETCH_SIZE counts 64 B per 128-B request
         wr = w * 1024
         res[kernel] = {"hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr), "launches_sampled": [nf, nw]}
-    j = {"kernels": res,
+    commit = "?"
+    try:
+        import subprocess
+        commit = subprocess.check_output(["git", "-C", os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rev-parse", "--short", "HEAD"],
+                                         stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        commit = os.environ.get("STEP_COMMIT", "?")          # (the GPU box has no .git: tools/gpu_profiles.sh passes it in)
+    j = {"kernels": res, "commit": commit,
          "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); FETCH_SIZE x1024 x2 (gfx950 correction), WRITE_SIZE x1024"}
     json.dump(j, open(out, "w"), indent=1)
     print(json.dumps(j))
