@@ -21,6 +21,7 @@ DT = {torch.float32: _capi.F32, torch.bfloat16: _capi.BF16, torch.float16: _capi
 #     replays: in its real place of the replayed sequence, at replay clocks, its inputs wherever the previous kernel left them.
 PROFILE = None
 PROFILE_LIMIT = None
+WGRAD16_WS = True      # 16-bit weight gradients: partial-tile workspace + fixed-order sum instead of fp32 atomics (module switch for tests / A-B timing)
 class _Prof:
     __slots__ = ("name", "flops", "bytes", "e0")
 
