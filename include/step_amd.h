@@ -135,6 +135,10 @@ STEP_API int step_roi_pool_backward(const float* grad, const int32_t* argmax, in
 STEP_API size_t step_nms_scratch_bytes(int G, int kmax);
 STEP_API int step_nms_batched(const float* boxes, const float* scores, const int32_t* counts, int G, int kmax,
                               float threshold, uint8_t* keep, void* scratch, step_stream_t stream);
+/* The same for double-precision boxes / scores: the reference operator dispatches on the dtype (AT_DISPATCH_FLOATING_TYPES,
+ * cpu/nms_cpu.cpp:95), so fp64 inputs are compared in fp64 -- down-casting them would move borderline IoU >= threshold decisions. */
+STEP_API int step_nms_batched_f64(const double* boxes, const double* scores, const int32_t* counts, int G, int kmax,
+                                  float threshold, uint8_t* keep, void* scratch, step_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused convolution unit on channels-last activations:

@@ -131,6 +131,18 @@ def nms(boxes, scores, thr):
     return keep[:m].copy()
 
 
+def nms_f64(boxes, scores, thr):
+    """the same for double-precision boxes / scores (the reference dispatches on the dtype, cpu/nms_cpu.cpp:95)"""
+    boxes = np.ascontiguousarray(boxes, np.float64).reshape(-1, 4)
+    scores = np.ascontiguousarray(scores, np.float64).reshape(-1)
+    n = boxes.shape[0]
+    keep = np.empty((max(n, 1),), np.int64)
+    L = lib()
+    L.orc_nms_f64.restype = ctypes.c_int64
+    m = L.orc_nms_f64(_p(boxes, ctypes.c_double), _p(scores, ctypes.c_double), ctypes.c_int64(n), ctypes.c_float(thr), _p(keep, ctypes.c_int64))
+    return keep[:m].copy()
+
+
 def nms_batched(boxes, scores, counts, thr):
     """boxes [G,kmax,4], scores [G,kmax], counts [G] -> keep mask uint8 [G,kmax]"""
     boxes, scores = _f32(boxes), _f32(scores)

@@ -320,6 +320,58 @@ ORC_API int64_t orc_nms(const float* boxes, const float* scores, int64_t n, floa
     return m;
 }
 
+/* The same in double precision: the reference dispatches AT_DISPATCH_FLOATING_TYPES (cpu/nms_cpu.cpp:95), so fp64 boxes / scores are
+ * compared in fp64 (the threshold stays the float argument of nms_cpu_kernel, promoted in `ovr >= threshold`). */
+typedef struct { double s; int64_t i; } orc_skd_t;
+static int orc_skd_cmp(const void* a, const void* b)
+{
+    const orc_skd_t* x = (const orc_skd_t*)a; const orc_skd_t* y = (const orc_skd_t*)b;
+    const int nx = x->s != x->s, ny = y->s != y->s;
+    if (nx != ny) return nx ? -1 : 1;
+    if (x->s > y->s) return -1;
+    if (x->s < y->s) return 1;
+    return (x->i < y->i) ? -1 : (x->i > y->i);
+}
+ORC_API int64_t orc_nms_f64(const double* boxes, const double* scores, int64_t n, float threshold, int64_t* keep)
+{
+    if (n <= 0) return 0;
+    orc_skd_t* ord = (orc_skd_t*)malloc(sizeof(orc_skd_t) * (size_t)n);
+    double* area = (double*)malloc(sizeof(double) * (size_t)n);
+    uint8_t* sup = (uint8_t*)calloc((size_t)n, 1);
+    for (int64_t i = 0; i < n; i++) {
+        const double* b = boxes + 4 * i;
+        double w = b[2] - b[0]; w = w + 1.0;
+        double h = b[3] - b[1]; h = h + 1.0;
+        area[i] = w * h;
+        ord[i].s = scores[i]; ord[i].i = i;
+    }
+    qsort(ord, (size_t)n, sizeof(orc_skd_t), orc_skd_cmp);
+    for (int64_t _i = 0; _i < n; _i++) {
+        int64_t i = ord[_i].i;
+        if (sup[i]) continue;
+        const double* bi = boxes + 4 * i;
+        for (int64_t _j = _i + 1; _j < n; _j++) {
+            int64_t j = ord[_j].i;
+            if (sup[j]) continue;
+            const double* bj = boxes + 4 * j;
+            double xx1 = fmax(bi[0], bj[0]);
+            double yy1 = fmax(bi[1], bj[1]);
+            double xx2 = fmin(bi[2], bj[2]);
+            double yy2 = fmin(bi[3], bj[3]);
+            double w = xx2 - xx1; w = w + 1.0; w = fmax(0.0, w);
+            double h = yy2 - yy1; h = h + 1.0; h = fmax(0.0, h);
+            double inter = w * h;
+            double den = area[i] + area[j]; den = den - inter;
+            double ovr = inter / den;
+            if (ovr >= threshold) sup[j] = 1;
+        }
+    }
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; i++) if (!sup[i]) keep[m++] = i;
+    free(ord); free(area); free(sup);
+    return m;
+}
+
 /* Batched form used to check the tube-batched HIP nms: G independent groups,
  * group g has counts[g] boxes stored at boxes[g*kmax*4 ...], scores[g*kmax ...].
  * keep_mask[g*kmax + i] = 1 if box i of group g survives. */

@@ -42,6 +42,7 @@ SIGNATURES = {
     "step_roi_pool_backward": (i, [fp, ip, i, fp, i, i, i, i, i, i, i, fp, vp]),
     "step_nms_scratch_bytes": (sz, [i, i]),
     "step_nms_batched": (i, [fp, fp, ip, i, i, f, u8p, vp, vp]),
+    "step_nms_batched_f64": (i, [fp, fp, ip, i, i, f, u8p, vp, vp]),
     "step_conv_packed_elems": (sz, [i, i, i, i, i]),
     "step_conv_pack_weight": (i, [fp, i, i, i, i, i, i, ip, vp, vp]),
     "step_conv_pack_weight_dgrad": (i, [fp, i, i, i, i, i, i, i, vp, vp]),

@@ -22,6 +22,23 @@ namespace step {
 __device__ __forceinline__ float box_area(float x1, float y1, float x2, float y2) {
     return __fmul_rn(__fadd_rn(__fsub_rn(x2, x1), 1.f), __fadd_rn(__fsub_rn(y2, y1), 1.f));  // nms_cpu.cpp:46
 }
+// fp64 boxes (the reference dispatches AT_DISPATCH_FLOATING_TYPES, nms_cpu.cpp:95): the same operations in double, each rounded
+// separately (this file is compiled with fp contraction off); the threshold stays the operator's float argument, promoted in
+// `ovr >= threshold` as in nms_cpu_kernel<double>.
+__device__ __forceinline__ double box_area(double x1, double y1, double x2, double y2) {
+    const double w = (x2 - x1) + 1.0, h = (y2 - y1) + 1.0;
+    return w * h;
+}
+__device__ __forceinline__ bool iou_ge(double ix1, double iy1, double ix2, double iy2, double iarea, double jx1, double jy1,
+                                       double jx2, double jy2, double jarea, float thr) {
+    const double xx1 = fmax(ix1, jx1), yy1 = fmax(iy1, jy1);
+    const double xx2 = fmin(ix2, jx2), yy2 = fmin(iy2, jy2);
+    const double w = fmax(0.0, (xx2 - xx1) + 1.0);
+    const double h = fmax(0.0, (yy2 - yy1) + 1.0);
+    const double inter = w * h;
+    const double ovr = inter / ((iarea + jarea) - inter);
+    return ovr >= (double)thr;
+}
 
 // i = the kept (higher score) box, j = the candidate.  nms_cpu.cpp:73-84
 __device__ __forceinline__ bool iou_ge(float ix1, float iy1, float ix2, float iy2, float iarea, float jx1, float jy1,
@@ -38,30 +55,32 @@ __device__ __forceinline__ bool iou_ge(float ix1, float iy1, float ix2, float iy
 // Score order: descending, ties by lower index.  NaN scores sort FIRST (torch's sort, which the reference uses at
 // nms_cpu.cpp:50, treats NaN as the largest value); without this rule NaNs compare false both ways, ranks collide and
 // the rank -> lane lookup below would be undefined.
-__device__ __forceinline__ bool score_before(float sj, int j, float s, int i) {
+template <typename F>
+__device__ __forceinline__ bool score_before(F sj, int j, F s, int i) {
     const bool nj = sj != sj, ni = s != s;
     if (nj || ni) return nj && (!ni || j < i);
     return sj > s || (sj == s && j < i);
 }
 
 // One wavefront per group, n <= 64.
-__global__ void nms_wave_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+template <typename F>
+__global__ void nms_wave_kernel(const F* __restrict__ boxes, const F* __restrict__ scores,
                                 const int32_t* __restrict__ counts, int kmax, float thr, uint8_t* __restrict__ keep) {
     const int g = blockIdx.x;
     const int lane = threadIdx.x;  // blockDim.x == 64
     const int n = min(counts[g], kmax);
     const bool valid = lane < n;
-    float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, s = 0.f;
+    F x1 = 0, y1 = 0, x2 = 0, y2 = 0, s = 0;
     if (valid) {
-        const float* b = boxes + ((size_t)g * kmax + lane) * 4;
+        const F* b = boxes + ((size_t)g * kmax + lane) * 4;
         x1 = b[0]; y1 = b[1]; x2 = b[2]; y2 = b[3];
         s = scores[(size_t)g * kmax + lane];
     }
-    const float area = box_area(x1, y1, x2, y2);
+    const F area = box_area(x1, y1, x2, y2);
     // stable descending rank (ties: lower index first)
     int rank = 0;
     for (int j = 0; j < n; ++j) {
-        float sj = __shfl(s, j);
+        F sj = __shfl(s, j);
         rank += score_before(sj, j, s, lane) ? 1 : 0;
     }
     bool suppressed = false;
@@ -69,8 +88,8 @@ __global__ void nms_wave_kernel(const float* __restrict__ boxes, const float* __
         unsigned long long m = __ballot(valid && rank == r);
         int i = __builtin_ctzll(m);  // exactly one lane has rank r
         unsigned long long sm = __ballot(suppressed);
-        float bx1 = __shfl(x1, i), by1 = __shfl(y1, i), bx2 = __shfl(x2, i), by2 = __shfl(y2, i);
-        float barea = __shfl(area, i);
+        F bx1 = __shfl(x1, i), by1 = __shfl(y1, i), bx2 = __shfl(x2, i), by2 = __shfl(y2, i);
+        F barea = __shfl(area, i);
         if ((sm >> i) & 1ull) continue;  // wave-uniform
         if (valid && !suppressed && rank > r && iou_ge(bx1, by1, bx2, by2, barea, x1, y1, x2, y2, area, thr))
             suppressed = true;
@@ -79,20 +98,21 @@ __global__ void nms_wave_kernel(const float* __restrict__ boxes, const float* __
 }
 
 // One 256-thread workgroup per group, any n.  scratch: order int32[G*kmax], sup uint8[G*kmax].
-__global__ void nms_block_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+template <typename F>
+__global__ void nms_block_kernel(const F* __restrict__ boxes, const F* __restrict__ scores,
                                  const int32_t* __restrict__ counts, int kmax, float thr, uint8_t* __restrict__ keep,
                                  int32_t* order_all, uint8_t* sup_all) {
     const int g = blockIdx.x;
     const int n = min(counts[g], kmax);
-    const float* B = boxes + (size_t)g * kmax * 4;
-    const float* S = scores + (size_t)g * kmax;
+    const F* B = boxes + (size_t)g * kmax * 4;
+    const F* S = scores + (size_t)g * kmax;
     int32_t* order = order_all + (size_t)g * kmax;
     uint8_t* sup = sup_all + (size_t)g * kmax;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const float s = S[i];
+        const F s = S[i];
         int rank = 0;
         for (int j = 0; j < n; ++j) {
-            float sj = S[j];
+            F sj = S[j];
             rank += score_before(sj, j, s, i) ? 1 : 0;
         }
         order[rank] = i;
@@ -103,18 +123,35 @@ __global__ void nms_block_kernel(const float* __restrict__ boxes, const float* _
         const int i = order[r];
         const bool isup = sup[i] != 0;  // uniform: written before the last barrier
         if (!isup) {
-            const float ix1 = B[4 * i], iy1 = B[4 * i + 1], ix2 = B[4 * i + 2], iy2 = B[4 * i + 3];
-            const float iarea = box_area(ix1, iy1, ix2, iy2);
+            const F ix1 = B[4 * i], iy1 = B[4 * i + 1], ix2 = B[4 * i + 2], iy2 = B[4 * i + 3];
+            const F iarea = box_area(ix1, iy1, ix2, iy2);
             for (int q = r + 1 + threadIdx.x; q < n; q += blockDim.x) {
                 const int j = order[q];
                 if (sup[j]) continue;
-                const float jx1 = B[4 * j], jy1 = B[4 * j + 1], jx2 = B[4 * j + 2], jy2 = B[4 * j + 3];
+                const F jx1 = B[4 * j], jy1 = B[4 * j + 1], jx2 = B[4 * j + 2], jy2 = B[4 * j + 3];
                 if (iou_ge(ix1, iy1, ix2, iy2, iarea, jx1, jy1, jx2, jy2, box_area(jx1, jy1, jx2, jy2), thr)) sup[j] = 1;
             }
         }
         __syncthreads();
     }
     for (int i = threadIdx.x; i < kmax; i += blockDim.x) keep[(size_t)g * kmax + i] = (i < n && !sup[i]) ? 1 : 0;
+}
+
+template <typename F>
+static int nms_batched_t(const F* boxes, const F* scores, const int32_t* counts, int G, int kmax, float threshold, uint8_t* keep, void* scratch,
+                         step_stream_t stream) {
+    if (G < 0 || kmax < 0) return STEP_E_SHAPE;
+    if (G == 0 || kmax == 0) return STEP_OK;
+    if (!boxes || !scores || !counts || !keep) return STEP_E_NULL;
+    if (kmax <= 64) {
+        STEP_LAUNCH((nms_wave_kernel<F>), dim3(G), dim3(64), stream, boxes, scores, counts, kmax, threshold, keep);
+    } else {
+        if (!scratch) return STEP_E_NULL;
+        int32_t* order = (int32_t*)scratch;
+        uint8_t* sup = (uint8_t*)scratch + (size_t)G * kmax * 4;
+        STEP_LAUNCH((nms_block_kernel<F>), dim3(G), dim3(256), stream, boxes, scores, counts, kmax, threshold, keep, order, sup);
+    }
+    return STEP_LAUNCH_CHECK();
 }
 
 }  // namespace step
@@ -130,19 +167,12 @@ size_t step_nms_scratch_bytes(int G, int kmax) {
 
 int step_nms_batched(const float* boxes, const float* scores, const int32_t* counts, int G, int kmax, float threshold,
                      uint8_t* keep, void* scratch, step_stream_t stream) {
-    if (G < 0 || kmax < 0) return STEP_E_SHAPE;
-    if (G == 0 || kmax == 0) return STEP_OK;
-    if (!boxes || !scores || !counts || !keep) return STEP_E_NULL;
-    if (kmax <= 64) {
-        STEP_LAUNCH((nms_wave_kernel), dim3(G), dim3(64), stream, boxes, scores, counts, kmax, threshold, keep);
-    } else {
-        if (!scratch) return STEP_E_NULL;
-        int32_t* order = (int32_t*)scratch;
-        uint8_t* sup = (uint8_t*)scratch + (size_t)G * kmax * 4;
-        STEP_LAUNCH((nms_block_kernel), dim3(G), dim3(256), stream, boxes, scores, counts, kmax, threshold, keep, order,
-                    sup);
-    }
-    return STEP_LAUNCH_CHECK();
+    return nms_batched_t<float>(boxes, scores, counts, G, kmax, threshold, keep, scratch, stream);
+}
+
+int step_nms_batched_f64(const double* boxes, const double* scores, const int32_t* counts, int G, int kmax, float threshold,
+                         uint8_t* keep, void* scratch, step_stream_t stream) {
+    return nms_batched_t<double>(boxes, scores, counts, G, kmax, threshold, keep, scratch, stream);
 }
 
 }  // extern "C"

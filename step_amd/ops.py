@@ -566,18 +566,21 @@ def roi_pool_backward(grad, argmax, rois, ph, pw, B, C, H, W):
 
 
 def nms_batched(boxes, scores, counts, threshold):
-    """boxes [G,kmax,4] fp32, scores [G,kmax] fp32, counts [G] int32 (all on one device)
-    -> keep mask uint8 [G,kmax] on the same device (no host round trip)."""
+    """boxes [G,kmax,4], scores [G,kmax] (fp32, or fp64 for double inputs: the reference operator dispatches on the dtype,
+    cpu/nms_cpu.cpp:95), counts [G] int32 (all on one device) -> keep mask uint8 [G,kmax] on the same device (no host round trip)."""
     L = _lib.lib()
-    boxes, scores, counts = boxes.contiguous().float(), scores.contiguous().float(), counts.contiguous().to(torch.int32)
+    f64 = boxes.dtype == torch.float64
+    dt = torch.float64 if f64 else torch.float32
+    boxes, scores, counts = boxes.contiguous().to(dt), scores.contiguous().to(dt), counts.contiguous().to(torch.int32)
     G, kmax = scores.shape
     keep = torch.zeros((G, kmax), dtype=torch.uint8, device=boxes.device)
     if G == 0 or kmax == 0:
         return keep
     nb = L.step_nms_scratch_bytes(G, kmax)
     scratch = torch.empty(nb, dtype=torch.uint8, device=boxes.device) if nb else None
-    _capi.check(L.step_nms_batched(_lib.dptr(boxes), _lib.dptr(scores), _lib.dptr(counts), G, kmax, float(threshold),
-                                   _lib.dptr(keep), _lib.dptr(scratch), _lib.stream_ptr(boxes.device)), "step_nms_batched")
+    fn = L.step_nms_batched_f64 if f64 else L.step_nms_batched
+    _capi.check(fn(_lib.dptr(boxes), _lib.dptr(scores), _lib.dptr(counts), G, kmax, float(threshold),
+                   _lib.dptr(keep), _lib.dptr(scratch), _lib.stream_ptr(boxes.device)), "step_nms_batched")
     return keep
 
 

@@ -24,8 +24,11 @@ def nms(dets, scores, threshold):
     if dets.numel() == 0:
         return torch.empty((0,), dtype=torch.int64, device="cpu")
     dev = dets.device if dets.is_cuda else _device()
-    b = dets.detach().to(device=dev, dtype=torch.float32).reshape(1, -1, 4)
-    s = scores.detach().to(device=dev, dtype=torch.float32).reshape(1, -1)
+    # the reference dispatches on the box dtype (AT_DISPATCH_FLOATING_TYPES, cpu/nms_cpu.cpp:95): double stays double (bit-exact
+    # against nms_cpu_kernel<double>); 16-bit inputs are up-cast as apex's float_function does (roi_layers/nms.py:36-43)
+    dt = torch.float64 if dets.dtype == torch.float64 else torch.float32
+    b = dets.detach().to(device=dev, dtype=dt).reshape(1, -1, 4)
+    s = scores.detach().to(device=dev, dtype=dt).reshape(1, -1)
     counts = torch.tensor([b.shape[1]], dtype=torch.int32, device=dev)
     keep = ops.nms_batched(b, s, counts, threshold)
     return torch.nonzero(keep[0]).squeeze(1).to("cpu", torch.int64)

@@ -264,6 +264,41 @@ def case_roi_pool_hand_derived_vectors(bk, golden):
             assert np.array_equal(got, np.array(v["grad_in"], np.float32)), (v["name"], layout)
 
 
+def case_nms_fp64(bk, golden):
+    """step_nms_batched_f64 (double boxes / scores, as the reference dispatches them) against the fp64 restatement -- itself bit-identical
+    to the reference's nms_cpu_kernel<double> (tests/test_oracle_vs_reference.py) -- on boxes whose IoU sits so close to the threshold
+    that the fp32 arithmetic decides differently; wave (k <= 64) and block (k > 64) kernels."""
+    rs = np.random.RandomState(77)
+    flips = 0
+    for k in (34, 64, 150):
+        G = 6
+        xy = rs.uniform(0, 300, (G, k, 2))
+        boxes = np.concatenate([xy, xy + rs.uniform(20, 120, (G, k, 2))], 2)
+        # plant pairs whose IoU is the threshold +- 1e-9: box j = box i shifted so that inter / union = 0.4 to within double rounding
+        for g in range(G):
+            for i in range(0, k - 1, 7):
+                x1, y1, x2, y2 = boxes[g, i]
+                w, h = x2 - x1 + 1, y2 - y1 + 1
+                # overlap o along x with equal sizes: iou = o h / (2 w h - o h) = 0.4 -> o = 0.8 w / 1.4
+                o = 0.8 * w / 1.4 + rs.choice([-1e-9, 1e-9])
+                boxes[g, i + 1] = [x1 + (w - o), y1, x2 + (w - o), y2]
+        scores = rs.permutation(G * k).reshape(G, k).astype(np.float64) / (G * k)
+        counts = np.array([k, k - 3, 1, 0, k, k // 2], np.int32)
+        want = np.zeros((G, k), np.uint8)
+        for g in range(G):
+            n = counts[g]
+            want[g, oracle.nms_f64(boxes[g, :n], scores[g, :n], 0.4)] = 1
+            if n and not np.array_equal(oracle.nms_f64(boxes[g, :n], scores[g, :n], 0.4), oracle.nms(boxes[g, :n], scores[g, :n], 0.4)):
+                flips += 1
+        b, s_, c = bk.dev(boxes), bk.dev(scores), bk.dev(counts)
+        keep = bk.dev(np.full((G, k), 9, np.uint8))
+        nb = bk.lib.step_nms_scratch_bytes(G, k)
+        scratch = bk.dev(np.zeros(max(nb, 16), np.uint8))
+        assert bk.lib.step_nms_batched_f64(b.ptr, s_.ptr, c.ptr, G, k, 0.4, keep.ptr, scratch.ptr, bk.stream) == 0
+        assert np.array_equal(keep.get(), want), k
+    assert flips >= 1, "the planted near-threshold pairs should make fp32 and fp64 disagree somewhere"
+
+
 def case_roi_empty_and_bad_args(bk, golden):
     L = bk.lib
     x = bk.dev(np.zeros((1, 4, 4, 8), np.float32))

@@ -70,3 +70,16 @@ def test_reference_has_no_cpu_backward_or_roipool(refC):
         refC.roi_pool_forward(x, r, 1.0, 2, 2)
     with pytest.raises(RuntimeError):
         refC.roi_align_backward(torch.zeros(1, 1, 2, 2), r, 1.0, 2, 2, 1, 1, 4, 4, 0)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_nms_fp64_restatement_matches_the_reference_double_kernel(refC, seed):
+    """AT_DISPATCH_FLOATING_TYPES (cpu/nms_cpu.cpp:95): double boxes run nms_cpu_kernel<double>; oracle.nms_f64 is bit-identical."""
+    rs = np.random.RandomState(100 + seed)
+    for n in (1, 11, 34, 200):
+        xy = rs.uniform(0, 300, (n, 2))
+        boxes = np.concatenate([xy, xy + rs.uniform(5, 150, (n, 2))], 1)
+        scores = rs.permutation(n).astype(np.float64) / n
+        for thr in (0.3, 0.4, 0.7):
+            ref = refC.nms(torch.from_numpy(boxes), torch.from_numpy(scores), thr).numpy()
+            assert np.array_equal(oracle.nms_f64(boxes, scores, thr), ref)
