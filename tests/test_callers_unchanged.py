@@ -20,3 +20,13 @@ def test_reference_inference_runs_unchanged_over_the_dropin():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "== step_amd.driver.inference" in r.stdout
     assert "DataParallel(base_net)" in r.stdout          # the wrapper lines of test.py:62-98 ran over the drop-in too
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "external")), reason="reference tree not available")
+@pytest.mark.timeout(600)
+def test_option_b_reference_roi_layers_run_over_the_ctypes_shim():
+    """INTEGRATION.md Option B: the reference's own roi_layers Python (autograd Functions, modules, nms) imported unchanged, with
+    integration/_C.py in the place of its pybind extension (oracle/check_option_b.py)."""
+    r = subprocess.run([sys.executable, "-m", "oracle.check_option_b"], cwd=ROOT, capture_output=True, text=True, timeout=550)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "over integration/_C.py == oracle" in r.stdout
