@@ -131,6 +131,7 @@ class BucketedReducer:
         from . import backbone
         self.pending = [c for _, _, c in self.buckets]
         self.seen = set()
+        self._hooked = {}                                        # autograd hook firings per parameter in this armed pass
         self.next = len(self.buckets) - 1                        # next bucket to issue (descending)
         self.works = []
         self.side = []                                           # producer streams to wait for, per bucket
@@ -151,7 +152,16 @@ class BucketedReducer:
     def _autograd_ready(self, p):
         # (autograd runs this hook for EVERY leaf it reaches, also when the gradient that arrives is undefined -- which is
         # what the conv units return for a weight whose gradient they accumulated themselves and announced already)
-        if self._armed and id(p) not in self.seen:
+        if not self._armed:
+            return
+        n = self._hooked.get(id(p), 0) + 1
+        self._hooked[id(p)] = n
+        if n > 1:
+            # a second backward() (gradient accumulation, retain_graph) between begin() and finish(): the later gradient would be
+            # added locally after the parameter's bucket may already have been all-reduced, and the ranks would diverge silently
+            raise RuntimeError("BucketedReducer: a second backward pass reached the same parameter before finish() -- "
+                               "one backward per begin() (accumulate micro-batches with the exchange off, then begin() for the last one)")
+        if id(p) not in self.seen:
             self.ready(p, None)
 
     def ready(self, p, stream=None):

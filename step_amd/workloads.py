@@ -152,7 +152,11 @@ class C4TrainStep:
 
     def step(self):
         if self.graph is not None:
+            self.opt._refresh_tables()                           # lr / weight_decay of param_groups -> the device tables the captured Adam reads (schedulers keep working)
             self.graph.replay()                                  # ~1300 launches, one submission
+            # the replay re-packed the weights at its start and Adam changed them at its end: any eager use of the modules between
+            # replays (validation) must see its packed-weight caches as stale
+            torch.autograd.graph.increment_version(self.params)
             return self.loss
         return self._eager_step()
 

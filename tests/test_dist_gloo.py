@@ -111,6 +111,20 @@ def _worker(rank, world, port, q):
             during = red.issued_during_backward
             f = red.finish()
             outs.append(((opt.flat_grad * f).numpy().copy(), during, f))
+        # a second backward between begin() and finish() (gradient accumulation, retain_graph) must fail loudly: the later gradient
+        # would be added locally after its bucket has left (every rank runs this, so the collectives stay matched)
+        opt.zero_grad()
+        red.begin()
+        y = model(clips[idx])
+        l2 = ((y - target[idx]) ** 2).mean()
+        l2.backward(retain_graph=True)
+        try:
+            l2.backward()
+            second = "accepted"
+        except RuntimeError as e:
+            second = "refused" if "one backward per begin()" in str(e) else repr(e)
+        red.finish()
+        assert second == "refused", second
         red.close()
         offs = [(o, n) for _, _, o, n in opt._entries]
     el = D.timed_steps(lambda: None if rank == 0 else __import__("time").sleep(0.05), 2, sync=lambda: None)
