@@ -192,9 +192,10 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
     constexpr int NTILES = 21;                      // weight tiles: 3 per frame
     typedef u16x8 frag_t;
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * FRAME + 3 * BBUF];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * FRAME + 3 * BBUF + NB * 32 * 2 * 4];
     unsigned char* const ldsA = lds;
     unsigned char* const ldsB = lds + 3 * FRAME;
+    float* const ldsS = (float*)(lds + 3 * FRAME + 3 * BBUF);     // fp32 scale | shift of the workgroup's channels (read in the epilogue)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -344,20 +345,31 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
     auto mma_all = [&](auto setc) {
         constexpr int SET = decltype(setc)::value;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            mma_k16(fa[SET][0], fb[SET][i], acc[0][i], T());
-            mma_k16(fa[SET][1], fb[SET][i], acc[1][i], T());
+        for (int i = 0; i < NB; ++i) {          // weights as the FIRST operand: transposed accumulators (a lane owns one pixel), see the epilogue
+            mma_k16(fb[SET][i], fa[SET][0], acc[0][i], T());
+            mma_k16(fb[SET][i], fa[SET][1], acc[1][i], T());
         }
     };
 
     // ---- prologue: frames 0 and 1, weight tiles 0 and 1, tile 2 in flight
-    Item fr[FQ];
-    load_frame(0, fr); store_frame(0, fr);
-    load_frame(1, fr); store_frame(FRAME, fr);
+    // (every request first, then the LDS stores: one memory round trip instead of four -- frame 0, frame 1, weight tiles 0 and 1
+    // used to be loaded and parked one after the other)
+    Item fr[FQ], fr1[FQ];
     BReg R = load_B(0);
+    BReg R1 = load_B(1);
+    float ss_sc = 1.f, ss_sh = 0.f;
+    if (tid < NB * 32) {
+        const int co = min(nb0 * 32 + tid, p.Cout - 1);
+        if (p.scale) ss_sc = p.scale[co];
+        if (p.shift) ss_sh = p.shift[co];
+    }
+    load_frame(0, fr);
+    load_frame(1, fr1);
     store_B(0, R);
-    R = load_B(1);
-    store_B(1, R);
+    store_B(1, R1);
+    if (tid < NB * 32) { ldsS[tid] = ss_sc; ldsS[NB * 32 + tid] = ss_sh; }
+    store_frame(0, fr);
+    store_frame(FRAME, fr1);
     R = load_B(2);
     __syncthreads();
     read_frags(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), 0);
@@ -399,42 +411,47 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
     }
     frame_iter(std::integral_constant<int, 0>(), 6);
 
-    // ---- epilogue: affine + ReLU, LDS transpose (fp32, 128 pixels at a time), 16-byte stores
+    // ---- epilogue: affine + ReLU and 16-byte stores straight from registers.  The accumulators are transposed (lane l owns pixel
+    // (l & 31) of each of its two row blocks and, in registers 4g .. 4g+3, the channels 8g + 4 (l >> 5) + {0..3}); one
+    // v_permlane32_swap per packed dword pair hands every lane 8 consecutive channels of its pixel (conv_tap_kernel.h: the LDS
+    // transpose this replaces -- two passes of 32 ds_write_b32 + barrier + read-out -- cost a third of the epilogue there).
     T* yg = (T*)p.y;
-    constexpr int BN = NB * 32, G = BN / 8;
-    float* ot = (float*)lds;
-    float sc[NB], sh[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int co = min((nb0 + i) * 32 + (lane & 31), p.Cout - 1);
-        sc[i] = p.scale ? p.scale[co] : 1.f;
-        sh[i] = p.shift ? p.shift[co] : 0.f;
-    }
     const bool vec_epi = (p.y_cstride % 8 == 0) && (p.y_coff % 8 == 0) && (p.Cout % 8 == 0) && (((uintptr_t)p.y) % 16 == 0);
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
-        if (mb) __syncthreads();
+        const int oh = oh0 + wave * 4 + mb + 2 * ((lane & 31) >> 4), ow = ow0 + (lane & 15);
+        const bool okp = oh < p.Ho && ow < p.Wo;
+        const size_t opix = okp ? (((size_t)n * p.To + od) * p.Ho + oh) * p.Wo + ow : 0;
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
+        for (int i = 0; i < NB; ++i) {
+            unsigned d[4][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ot[(wave * 32 + cd_row(r, lane)) * BN + i * 32 + (lane & 31)] = fmaxf(acc[mb][i][r] * sc[i] + sh[i], 0.f);
-        __syncthreads();
-        for (int idx = tid; idx < 128 * G; idx += 256) {
-            const int row = idx / G, g = idx % G;
-            const int oh = oh0 + (row >> 5) * 4 + mb + 2 * ((row & 31) >> 4), ow = ow0 + (row & 15);
-            const int co = nb0 * 32 + g * 8;
-            if (oh < p.Ho && ow < p.Wo && co < p.Cout) {
-                const size_t opix = (((size_t)n * p.To + od) * p.Ho + oh) * p.Wo + ow;
-                const float* src = ot + row * BN + g * 8;
-                if (vec_epi) {
-                    u16x8 o;
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 sc = *(const f32x4*)(ldsS + i * 32 + 8 * g + 4 * khalf);
+                const f32x4 sh = *(const f32x4*)(ldsS + NB * 32 + i * 32 + 8 * g + 4 * khalf);
+                float v[4];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = elem<T>::bits16(src[e]);
-                    *(u16x8*)(yg + opix * p.y_cstride + p.y_coff + co) = o;
-                } else {
-                    for (int e = 0; e < 8; ++e)
-                        if (co + e < p.Cout) yg[opix * p.y_cstride + p.y_coff + co + e] = elem<T>::from_f32(src[e]);
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[mb][i][4 * g + e] * sc[e] + sh[e], 0.f);
+                if (!vec_epi) {                               // channel counts / offsets off the 16-byte grid: element stores
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int co = (nb0 + i) * 32 + 8 * g + 4 * khalf + e;
+                        if (okp && co < p.Cout) yg[opix * p.y_cstride + p.y_coff + co] = elem<T>::from_f32(v[e]);
+                    }
+                }
+                d[g][0] = (unsigned)elem<T>::bits16(v[0]) | ((unsigned)elem<T>::bits16(v[1]) << 16);
+                d[g][1] = (unsigned)elem<T>::bits16(v[2]) | ((unsigned)elem<T>::bits16(v[3]) << 16);
+            }
+            if (vec_epi) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    lane32_swap(d[2 * h][0], d[2 * h + 1][0]);
+                    lane32_swap(d[2 * h][1], d[2 * h + 1][1]);
+                    const int co = (nb0 + i) * 32 + 16 * h + 8 * khalf;
+                    if (okp && co < p.Cout) {
+                        const u32x4 o = {d[2 * h][0], d[2 * h][1], d[2 * h + 1][0], d[2 * h + 1][1]};
+                        *(u32x4*)(yg + opix * p.y_cstride + p.y_coff + co) = o;
+                    }
                 }
             }
         }

@@ -66,6 +66,47 @@ def main():
     only = set(x for x in a.only.split(",") if x)
     tot = [0.0] * len(variants)
     print("%-8s %s" % ("layer", "  ".join("%28s" % v for v in variants)))
+    if "stem" in only or a.set == "stem":
+        # conv3d_1a_7x7 (its own entry point): B clips [32,3,224,224] (c2) or [36,3,400,400] (c3)
+        T_, HW_ = (36, 400) if a.set == "c3" else (32, 224)
+        x = (torch.rand(B, T_, 3, HW_, HW_, device=dev) * 2 - 1).to(tdt)
+        w = torch.randn(64, 3, 7, 7, 7, device=dev) * (1.0 / 1029 ** 0.5)
+        sc, sh = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+        To, Ho = (T_ - 2) // 2 + 1, (HW_ - 2) // 2 + 1
+        y = torch.empty(B, To, Ho, Ho, 64, dtype=tdt, device=dev)
+        times, ref = [[] for _ in variants], None
+        libs = [(LP if "lib=prev" in v else L) for v in variants]
+        wps = []
+        for lib in libs:
+            wp = torch.empty(lib.step_stem_packed_elems(64), dtype=tdt, device=dev)
+            _capi.check(lib.step_stem_pack_weight(_lib.dptr(w), 64, dt, _lib.dptr(wp), st), "stem pack")
+            wps.append(wp)
+
+        def run_stem(vi):
+            _capi.check(libs[vi].step_stem_forward(dt, _lib.dptr(x), B, T_, HW_, HW_, _lib.dptr(wps[vi]), _lib.dptr(sc), _lib.dptr(sh), 64,
+                                                   _lib.dptr(y), 64, 0, st), "stem")
+        for vi in range(len(variants)):
+            run_stem(vi)
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = y.float().clone()
+            else:
+                assert a.nocheck or float((y.float() - ref).abs().max() / ref.abs().max()) < 2e-2
+        for _ in range(a.rounds):
+            for vi in range(len(variants)):
+                run_stem(vi)
+                s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_.record()
+                for _ in range(a.iters):
+                    run_stem(vi)
+                e_.record()
+                torch.cuda.synchronize()
+                times[vi].append(s_.elapsed_time(e_) / a.iters)
+        gf = 2.0 * B * To * Ho * Ho * 64 * 1029 / 1e9
+        med = [statistics.median(t) for t in times]
+        print("%-8s %s" % ("stem", "  ".join("%7.1f us %6.0f TF %-12s" % (m * 1e3, gf / m, "stem_stream") for m in med)))
+        if a.set == "stem":
+            return
     for name, ci, co, k, D, H, W in layers:
         if only and name not in only:
             continue
