@@ -98,6 +98,14 @@ STEP_API int step_roi_align_forward(const void* feat, int dtype, int layout, con
                                     int C, int H, int W, int pooled_h, int pooled_w, float spatial_scale,
                                     int sampling_ratio, void* out, step_stream_t stream);
 
+/* "3-D ROIAlign over tubes" without the caller's copy (utils/utils.py:41-48: `conv_feat[:, T_start:T_start+T_length].contiguous()`):
+ * feat points at frame T_start of clip 0 inside a channels-last buffer [B, T_all, H, W, C]; a roi's first column is the frame index
+ * b * T + t of the SLICE (flatten_tubes, utils/tube_utils.py:237-241) and is read as frame b * T_all + t of the buffer.  Same
+ * arithmetic as step_roi_align_forward (bit-identical to it on the copied slice); out [K, ph, pw, C]. */
+STEP_API int step_roi_align_tubes_forward(const void* feat, int dtype, const float* rois, int K, int B, int T_all, int T, int C,
+                                          int H, int W, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                                          void* out, step_stream_t stream);
+
 /* ROIAlign backward.    replaces _C.roi_align_backward  (csrc/ROIAlign.h:51-69,
  *                       cuda/ROIAlign_cuda.cu:201-278,326-370)
  * grad [K,C,ph,pw] / [K,ph,pw,C]  ->  grad_feat [B,C,H,W] / [B,H,W,C].  grad_feat is zeroed here
@@ -139,6 +147,19 @@ STEP_API int step_nms_batched(const float* boxes, const float* scores, const int
  * cpu/nms_cpu.cpp:95), so fp64 inputs are compared in fp64 -- down-casting them would move borderline IoU >= threshold decisions. */
 STEP_API int step_nms_batched_f64(const double* boxes, const double* scores, const int32_t* counts, int G, int kmax,
                                   float threshold, uint8_t* keep, void* scratch, step_stream_t stream);
+
+/* The evaluation loop of one refinement iteration (test.py:157-198; the same code in train.py:512-573, demo.py:123-174) in ONE
+ * launch: for every clip b and class c, the clip's tubes whose middle-frame score prob[tube][c] > conf_thresh (test.py:180), their
+ * middle-frame boxes through valid_tubes (utils/tube_utils.py:59-92: clamp to [0,width] x [0,height]; boxes under 3 px in either
+ * direction become the whole frame), greedy NMS among them with the semantics of step_nms_batched (the reference compacts the
+ * masked boxes first, order kept, so ties go to the lower tube).
+ *   prob  [N, >= NC] fp32, row stride prob_stride elements     loc [N, >= 4] fp32, row stride loc_stride (x1,y1,x2,y2 in pixels)
+ *   tube_start / tube_count [B] int32: clip b owns tubes tube_start[b] .. + tube_count[b] (<= kmax <= 64; more: STEP_E_UNSUPPORTED)
+ *   keep [B, NC, kmax] uint8: 1 at the ORIGINAL slot of every surviving tube      boxes_out [N,4] (optional): the clamped boxes
+ */
+STEP_API int step_detect_nms(const float* prob, long long prob_stride, int NC, const float* loc, long long loc_stride,
+                             const int32_t* tube_start, const int32_t* tube_count, int B, int kmax, float conf_thresh,
+                             float nms_thresh, float width, float height, uint8_t* keep, float* boxes_out, step_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused convolution unit on channels-last activations:

@@ -4,7 +4,7 @@ import ctypes as C
 
 F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 vp, fp, ip, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # raw device addresses
 i, f, ll, sz = C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -37,12 +37,14 @@ SIGNATURES = {
     "step_reset_options": (None, []),
     "step_option_name": (C.c_char_p, [i]),
     "step_roi_align_forward": (i, [vp, i, i, fp, i, i, i, i, i, i, i, f, i, vp, vp]),
+    "step_roi_align_tubes_forward": (i, [vp, i, fp, i, i, i, i, i, i, i, i, i, f, i, vp, vp]),
     "step_roi_align_backward": (i, [fp, i, fp, i, i, i, i, i, i, i, f, i, fp, vp]),
     "step_roi_pool_forward": (i, [vp, i, i, fp, i, i, i, i, i, i, i, f, vp, ip, vp]),
     "step_roi_pool_backward": (i, [fp, ip, i, fp, i, i, i, i, i, i, i, fp, vp]),
     "step_nms_scratch_bytes": (sz, [i, i]),
     "step_nms_batched": (i, [fp, fp, ip, i, i, f, u8p, vp, vp]),
     "step_nms_batched_f64": (i, [fp, fp, ip, i, i, f, u8p, vp, vp]),
+    "step_detect_nms": (i, [fp, ll, i, fp, ll, ip, ip, i, i, f, f, f, f, u8p, fp, vp]),
     "step_conv_packed_elems": (sz, [i, i, i, i, i]),
     "step_conv_pack_weight": (i, [fp, i, i, i, i, i, i, ip, vp, vp]),
     "step_conv_pack_weight_dgrad": (i, [fp, i, i, i, i, i, i, i, vp, vp]),

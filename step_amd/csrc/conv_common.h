@@ -185,9 +185,9 @@ template <typename T> int conv_tap_launch(const ConvPlan& pl, const ConvParams& 
 template <typename T> int conv_tap_ph_launch(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream);  // conv_tap_ph_<dtype>.hip (two-phase form)
 template <> int conv_tap_ph_launch<bf16_t>(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream);
 template <> int conv_tap_ph_launch<f16_t>(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream);
-template <typename T> int conv_tap_group_launch(int NB, const ConvGroupParams& g, dim3 grid, step_stream_t stream);       // conv_tap_ph_<dtype>.hip
-template <> int conv_tap_group_launch<bf16_t>(int NB, const ConvGroupParams& g, dim3 grid, step_stream_t stream);
-template <> int conv_tap_group_launch<f16_t>(int NB, const ConvGroupParams& g, dim3 grid, step_stream_t stream);
+template <typename T> int conv_tap_group_launch(int twl, int NB, const ConvGroupParams& g, dim3 grid, step_stream_t stream);       // conv_tap_ph_<dtype>.hip
+template <> int conv_tap_group_launch<bf16_t>(int twl, int NB, const ConvGroupParams& g, dim3 grid, step_stream_t stream);
+template <> int conv_tap_group_launch<f16_t>(int twl, int NB, const ConvGroupParams& g, dim3 grid, step_stream_t stream);
 template <typename T> int conv_pw_launch(int NB, int wv, const ConvParams& p, dim3 grid, step_stream_t stream);                        // conv_pw.hip
 template <typename T> int conv_pws_launch(int nbw, const ConvParams& p, dim3 grid, step_stream_t stream);                              // conv_pw.hip (weight-stationary stream, 16-bit)
 // conv_pws_kernel: nbw channel blocks per workgroup, KC16 16-channel chunks -> blocks per pass (<= 3: registers), 64-channel steps

@@ -493,7 +493,7 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true, int fo
         // step_conv_forward_ws; STEP_OPT_CONV_SPLITK = 0 disables)
         const bool splitk_ok = opt(STEP_OPT_CONV_SPLITK) != 0;
         const long long M = (long long)d->N * d->D * d->H * d->W;
-        if (splitk_ok && ov1 != 0 && d->Cin >= 2048 && (d->Cin % 8) == 0 && M <= 1024 && pl.mtiles * nblk32 < 64) {
+        if (splitk_ok && ov1 != 0 && d->Cin >= 512 && (d->Cin % 8) == 0 && M <= 1024 && pl.mtiles * nblk32 < 64) {     // (>= 512: the 1024-channel context half of global_cls on ~130 rows ran 37 us as two serial workgroups)
             pl.impl = 3;
             pl.mbk = M <= 32 ? 1 : (M <= 64 ? 2 : 4);
             const int KC16 = ceil_div(d->Cin, CK) * 2;
@@ -847,7 +847,7 @@ static bool conv_group_plan(const step_conv_item* items, int n, step_conv_desc* 
         if (((uintptr_t)ps[k].x % 16) || ((uintptr_t)ps[k].w % 16)) return false;
         pls[k] = conv_plan(d, true, 8);
         const ConvPlan& pl = pls[k];
-        if (!pl.ok || pl.impl != 1 || pl.ph != 1 || pl.wv != 8 || pl.tps != 2 || pl.twl != 0) return false;
+        if (!pl.ok || pl.impl != 1 || pl.ph != 1 || pl.wv != 8 || pl.tps != 2 || (pl.twl != 0 && pl.twl != 3) || pl.twl != pls[0].twl) return false;
         if (pl.NB > nb) nb = pl.NB;
     }
     *NBc = nb;
@@ -894,8 +894,8 @@ int step_conv_forward_group(const step_conv_item* items, int n, step_stream_t st
             for (int j = n; j < CONV_GROUP_MAX; ++j) g.p[j] = g.p[0];
             if (base <= 0x7fffffffLL) {
                 const dim3 grid((unsigned)base);
-                return canon[0].dtype == STEP_BF16 ? conv_tap_group_launch<bf16_t>(NBc, g, grid, stream)
-                                                   : conv_tap_group_launch<f16_t>(NBc, g, grid, stream);
+                return canon[0].dtype == STEP_BF16 ? conv_tap_group_launch<bf16_t>(pls[0].twl, NBc, g, grid, stream)
+                                                   : conv_tap_group_launch<f16_t>(pls[0].twl, NBc, g, grid, stream);
             }
         }
     }
@@ -922,7 +922,7 @@ int step_conv_group_kernel_name(const step_conv_item* items, int n, char* buf, i
     int NBc = 0;
     if (!conv_group_plan(items, n, canon, ps, pls, &NBc)) return STEP_OK;
     const char* t = canon[0].dtype == STEP_BF16 ? "step::bf16_t" : "step::f16_t";
-    snprintf(buf, (size_t)buflen, "void step::conv_tap_group_kernel<%s, 0, %d, 3, 3, 3, 2, 2, 8, 1>(step::ConvGroupParams)", t, NBc);
+    snprintf(buf, (size_t)buflen, "void step::conv_tap_group_kernel<%s, %d, %d, 3, 3, 3, 2, 2, 8, 1>(step::ConvGroupParams)", t, pls[0].twl, NBc);
     return STEP_OK;
 }
 
@@ -966,7 +966,7 @@ int step_conv_plan_info(const step_conv_desc* d, int* info, int n) {
 __attribute__((visibility("default"))) void step_probe_set(void* buf) { step::g_probe_buf = (unsigned long long*)buf; }
 #endif
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 20; }
+int step_abi_version(void) { return 21; }
 
 }  // extern "C"
 

@@ -771,10 +771,10 @@ int conv_tap_ph_launch_impl(const ConvPlan& pl, const ConvParams& p, int kd, dim
     return pl.wide ? launch_tap_ph<T, 5>(p, pl.NB, grid, stream) : launch_tap_ph<T, 4>(p, pl.NB, grid, stream);
 }
 
-// grouped launch (general boxes, two-phase form): NB = the deepest member's accumulator depth
-template <typename T>
-int conv_tap_group_launch_impl(int NB, const ConvGroupParams& g, dim3 grid, step_stream_t stream) {
-#define STEP_TAPG(NB_) STEP_LAUNCH((conv_tap_group_kernel<T, 0, NB_, 3, 3, 3, 2, 2, 8, 1>), grid, dim3(512), stream, g)
+// grouped launch (two-phase form; general boxes, or the 4-plane 8x8 tiles of the heads' 7x7 maps): NB = the deepest member's depth
+template <typename T, int TWL>
+static int conv_tap_group_launch_twl(int NB, const ConvGroupParams& g, dim3 grid, step_stream_t stream) {
+#define STEP_TAPG(NB_) STEP_LAUNCH((conv_tap_group_kernel<T, TWL, NB_, 3, 3, 3, 2, 2, 8, 1>), grid, dim3(512), stream, g)
     switch (NB) {
         case 1: STEP_TAPG(1); break;
         case 2: STEP_TAPG(2); break;
@@ -782,6 +782,12 @@ int conv_tap_group_launch_impl(int NB, const ConvGroupParams& g, dim3 grid, step
     }
 #undef STEP_TAPG
     return STEP_LAUNCH_CHECK();
+}
+template <typename T>
+int conv_tap_group_launch_impl(int twl, int NB, const ConvGroupParams& g, dim3 grid, step_stream_t stream) {
+    if (twl == 0) return conv_tap_group_launch_twl<T, 0>(NB, g, grid, stream);
+    if (twl == 3) return conv_tap_group_launch_twl<T, 3>(NB, g, grid, stream);
+    return STEP_E_UNSUPPORTED;
 }
 
 template <typename T>

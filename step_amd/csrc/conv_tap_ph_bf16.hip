@@ -4,7 +4,7 @@ namespace step {
 template <> int conv_tap_ph_launch<bf16_t>(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream) {
     return conv_tap_ph_launch_impl<bf16_t>(pl, p, kd, grid, stream);
 }
-template <> int conv_tap_group_launch<bf16_t>(int NB, const ConvGroupParams& g, dim3 grid, step_stream_t stream) {
-    return conv_tap_group_launch_impl<bf16_t>(NB, g, grid, stream);
+template <> int conv_tap_group_launch<bf16_t>(int twl, int NB, const ConvGroupParams& g, dim3 grid, step_stream_t stream) {
+    return conv_tap_group_launch_impl<bf16_t>(twl, NB, g, grid, stream);
 }
 }  // namespace step

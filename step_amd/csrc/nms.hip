@@ -97,6 +97,53 @@ __global__ void nms_wave_kernel(const F* __restrict__ boxes, const F* __restrict
     if (lane < kmax) keep[(size_t)g * kmax + lane] = (valid && !suppressed) ? 1 : 0;
 }
 
+// The evaluation loop of test.py:157-198 for one refinement iteration as ONE launch: wavefront (b, c) takes clip b's tubes (slot j =
+// lane), masks them with score > conf (test.py:180), clamps their middle-frame boxes the way valid_tubes does (tube_utils.py:59-92:
+// clip to [0, width] x [0, height], boxes under 3 px become the whole frame) and runs the greedy NMS among the masked ones -- the
+// reference compacts them first, keeping their order, so score ties still go to the lower original slot.  keep[b][c][j] marks the
+// survivors at their ORIGINAL slots.  n <= 64 tubes per clip.
+__global__ void detect_nms_wave_kernel(const float* __restrict__ prob, long long prob_stride, int NC, const float* __restrict__ loc,
+                                       long long loc_stride, const int32_t* __restrict__ tube_start, const int32_t* __restrict__ tube_count,
+                                       int kmax, float conf, float thr, float width, float height, uint8_t* __restrict__ keep,
+                                       float* __restrict__ boxes_out) {
+    const int b = blockIdx.x / NC, c = blockIdx.x % NC;
+    const int lane = threadIdx.x;
+    const int n = min(tube_count[b], kmax);
+    const long long tube = (long long)tube_start[b] + lane;
+    float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, s = 0.f;
+    bool valid = false;
+    if (lane < n) {
+        const float* bx = loc + tube * loc_stride;
+        x1 = fmaxf(0.f, bx[0]); y1 = fmaxf(0.f, bx[1]); x2 = fminf(width, bx[2]); y2 = fminf(height, bx[3]);
+        if (!((x1 < __fsub_rn(x2, 2.f)) && (y1 < __fsub_rn(y2, 2.f)))) { x1 = 0.f; y1 = 0.f; x2 = width; y2 = height; }
+        s = prob[tube * prob_stride + c];
+        valid = s > conf;
+        if (c == 0 && boxes_out) {
+            float* o = boxes_out + tube * 4;
+            o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2;
+        }
+    }
+    const float area = box_area(x1, y1, x2, y2);
+    const unsigned long long vm = __ballot(valid);
+    int rank = 0;                                              // descending score among the masked tubes, ties: lower slot first
+    for (int j = 0; j < n; ++j) {
+        const float sj = __shfl(s, j);
+        rank += (((vm >> j) & 1ull) && score_before(sj, j, s, lane)) ? 1 : 0;
+    }
+    const int nv = __builtin_popcountll(vm);
+    bool suppressed = false;
+    for (int r = 0; r < nv; ++r) {
+        const unsigned long long m = __ballot(valid && rank == r);
+        const int i = __builtin_ctzll(m);                    // exactly one masked lane has rank r
+        const unsigned long long sm = __ballot(suppressed);
+        const float bx1 = __shfl(x1, i), by1 = __shfl(y1, i), bx2 = __shfl(x2, i), by2 = __shfl(y2, i);
+        const float barea = __shfl(area, i);
+        if ((sm >> i) & 1ull) continue;                       // wave-uniform
+        if (valid && !suppressed && rank > r && iou_ge(bx1, by1, bx2, by2, barea, x1, y1, x2, y2, area, thr)) suppressed = true;
+    }
+    if (lane < kmax) keep[((size_t)b * NC + c) * kmax + lane] = (valid && !suppressed) ? 1 : 0;
+}
+
 // One 256-thread workgroup per group, any n.  scratch: order int32[G*kmax], sup uint8[G*kmax].
 template <typename F>
 __global__ void nms_block_kernel(const F* __restrict__ boxes, const F* __restrict__ scores,
@@ -173,6 +220,18 @@ int step_nms_batched(const float* boxes, const float* scores, const int32_t* cou
 int step_nms_batched_f64(const double* boxes, const double* scores, const int32_t* counts, int G, int kmax, float threshold,
                          uint8_t* keep, void* scratch, step_stream_t stream) {
     return nms_batched_t<double>(boxes, scores, counts, G, kmax, threshold, keep, scratch, stream);
+}
+
+int step_detect_nms(const float* prob, long long prob_stride, int NC, const float* loc, long long loc_stride, const int32_t* tube_start,
+                    const int32_t* tube_count, int B, int kmax, float conf_thresh, float nms_thresh, float width, float height,
+                    uint8_t* keep, float* boxes_out, step_stream_t stream) {
+    if (B < 0 || NC < 0 || kmax < 0 || prob_stride < NC || loc_stride < 4) return STEP_E_SHAPE;
+    if (kmax > 64) return STEP_E_UNSUPPORTED;                 // (more tubes per clip: mask + step_nms_batched, as before)
+    if (B == 0 || NC == 0 || kmax == 0) return STEP_OK;
+    if (!prob || !loc || !tube_start || !tube_count || !keep) return STEP_E_NULL;
+    STEP_LAUNCH((detect_nms_wave_kernel), dim3((unsigned)(B * NC)), dim3(64), stream, prob, prob_stride, NC, loc, loc_stride, tube_start,
+                tube_count, kmax, conf_thresh, nms_thresh, width, height, keep, boxes_out);
+    return STEP_LAUNCH_CHECK();
 }
 
 }  // extern "C"

@@ -121,13 +121,16 @@ template <> struct VecIO<f16_t, 8> : VecIO16<f16_t> {};
 template <typename T, int V>
 __global__ void roi_align_fwd_nhwc_kernel(const T* __restrict__ feat, const float* __restrict__ rois, int C, int H,
                                           int W, int ph, int pw, float scale, int sampling_ratio,
-                                          T* __restrict__ out) {
+                                          T* __restrict__ out, int tsl, int tall) {
     const int bin = blockIdx.x;
     const int n = bin / (ph * pw);
     const int p = (bin / pw) % ph;
     const int q = bin % pw;
     const RoiGeom g = roi_geom(rois + 5 * n, scale, ph, pw, sampling_ratio);
-    const T* base = feat + (size_t)g.batch * H * W * C;
+    // tube form (step_roi_align_tubes_forward): the roi's frame index counts the frames of a T-slice [t0, t0 + tsl) of every
+    // clip (b * tsl + t); the feature buffer holds tall frames per clip and `feat` points at frame t0 of clip 0
+    const int frame = tsl > 0 ? (g.batch / tsl) * tall + g.batch % tsl : g.batch;
+    const T* base = feat + (size_t)frame * H * W * C;
     for (int c = threadIdx.x * V; c < C; c += blockDim.x * V) {
         float acc[V];
 #pragma unroll
@@ -359,15 +362,15 @@ static inline unsigned flat_grid(long long total, int block) {
 
 template <typename T>
 static int roi_align_forward_t(const void* feat, int layout, const float* rois, int K, int C, int H, int W, int ph,
-                               int pw, float scale, int sr, void* out, step_stream_t stream) {
+                               int pw, float scale, int sr, void* out, step_stream_t stream, int tsl = 0, int tall = 0) {
     constexpr int V = elem<T>::VEC;
     if (layout == STEP_NHWC) {
         if (C % V == 0 && ((uintptr_t)feat % 16) == 0 && ((uintptr_t)out % 16) == 0) {
             STEP_LAUNCH((roi_align_fwd_nhwc_kernel<T, V>), dim3(K * ph * pw), dim3(lanes_for(C / V)), stream,
-                        (const T*)feat, rois, C, H, W, ph, pw, scale, sr, (T*)out);
+                        (const T*)feat, rois, C, H, W, ph, pw, scale, sr, (T*)out, tsl, tall);
         } else {
             STEP_LAUNCH((roi_align_fwd_nhwc_kernel<T, 1>), dim3(K * ph * pw), dim3(lanes_for(C)), stream,
-                        (const T*)feat, rois, C, H, W, ph, pw, scale, sr, (T*)out);
+                        (const T*)feat, rois, C, H, W, ph, pw, scale, sr, (T*)out, tsl, tall);
         }
     } else {
         long long total = (long long)K * C * ph * pw;
@@ -407,6 +410,19 @@ int step_roi_align_forward(const void* feat, int dtype, int layout, const float*
         case STEP_F32: return roi_align_forward_t<float>(feat, layout, rois, K, C, H, W, ph, pw, scale, sr, out, stream);
         case STEP_BF16: return roi_align_forward_t<bf16_t>(feat, layout, rois, K, C, H, W, ph, pw, scale, sr, out, stream);
         case STEP_F16: return roi_align_forward_t<f16_t>(feat, layout, rois, K, C, H, W, ph, pw, scale, sr, out, stream);
+    }
+    return STEP_E_DTYPE;
+}
+
+int step_roi_align_tubes_forward(const void* feat, int dtype, const float* rois, int K, int B, int T_all, int T, int C, int H, int W,
+                                 int ph, int pw, float scale, int sr, void* out, step_stream_t stream) {
+    if (K < 0 || B < 0 || C <= 0 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0 || T <= 0 || T_all < T) return STEP_E_SHAPE;
+    if (K == 0) return STEP_OK;
+    if (!feat || !rois || !out) return STEP_E_NULL;
+    switch (dtype) {
+        case STEP_F32: return roi_align_forward_t<float>(feat, STEP_NHWC, rois, K, C, H, W, ph, pw, scale, sr, out, stream, T, T_all);
+        case STEP_BF16: return roi_align_forward_t<bf16_t>(feat, STEP_NHWC, rois, K, C, H, W, ph, pw, scale, sr, out, stream, T, T_all);
+        case STEP_F16: return roi_align_forward_t<f16_t>(feat, STEP_NHWC, rois, K, C, H, W, ph, pw, scale, sr, out, stream, T, T_all);
     }
     return STEP_E_DTYPE;
 }

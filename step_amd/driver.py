@@ -143,60 +143,101 @@ def postprocess(args, history, conf_thresh=None, nms_thresh=None, evaluate_topk=
     `score > conf_thresh`, valid_tubes() the middle-frame boxes (its 400 x 400 default, as the reference calls it), greedy
     NMS, normalise by the frame size; then the reference's row order -- classes ascending, kept tubes in ascending original
     order -- or, with evaluate_topk > 0, its stable ascending score sort, reversed, cut at `[:args.topk]` (including what that
-    slice does for topk = -1).  All (clip, class) groups of an iteration go through ONE nms launch (the reference makes
-    60 x B serial CPU calls) and there is no Python loop over classes or boxes; one host synchronisation per iteration
-    fetches the row counts for the per-clip split.
+    slice does for topk = -1).  The score mask, valid_tubes and the NMS of all (clip, class) groups of an iteration are ONE launch
+    (step_detect_nms; the reference makes 60 x B serial CPU calls), there is no Python loop over classes or boxes, and ONE host
+    synchronisation for all iterations fetches the row counts for the per-clip split.
 
     Thresholds default to args.conf_thresh / nms_thresh / evaluate_topk / topk (config.py:62-65).
     Returns a list over iterations of lists over clips of dicts {boxes [m,4] fp32 normalised, scores [m], labels [m] (class
     index), tubes [m] (index of the tube inside its clip)} in the order the reference writes its CSV rows."""
-    from .roi_layers import nms_batched
+    from . import ops
 
     conf = float(getattr(args, "conf_thresh", 0.01) if conf_thresh is None else conf_thresh)
     thr = float(getattr(args, "nms_thresh", 0.4) if nms_thresh is None else nms_thresh)
     etopk = int(getattr(args, "evaluate_topk", -1) if evaluate_topk is None else evaluate_topk)
     topk = int(getattr(args, "topk", -1) if topk is None else topk)
     W, H = float(args.image_size[0]), float(args.image_size[1])
-    out = []
-    for it, h in enumerate(history):
-        if iterations is not None and it not in iterations:
-            continue
+    todo = [(it, h) for it, h in enumerate(history) if iterations is None or it in iterations]
+    out = [None] * len(todo)
+    # iterations that share a clip layout (they all do in inference()) go through ONE pass: a fused mask + clamp + NMS launch each
+    # (ops.detect_nms), then one nonzero over all of them and ONE host synchronisation for the row counts
+    fast, slow = [], []
+    for oi, (it, h) in enumerate(todo):
         nums = [int(v) for v in h["tubes_nums"]]
-        prob, loc = h["pred_prob"], h["pred_loc"]
-        dev = loc.device
-        B, NC = len(nums), prob.shape[-1]
-        if B == 0 or sum(nums) == 0:
-            e = torch.zeros(0, device=dev)
-            out.append([{"boxes": e.view(0, 4), "scores": e, "labels": e.long(), "tubes": e.long()} for _ in nums])
-            continue
-        boxes = valid_tubes(loc[:, int(loc.shape[1] / 2)].float().unsqueeze(1))[:, 0]                 # [N,4] (test.py:161,191)
-        scores = prob[:, int(prob.shape[1] / 2)].float()                                              # [N,NC] (:159)
-        idx, valid = _clip_groups(nums, dev)
-        kmax = idx.shape[1]
-        gs = scores[idx].permute(0, 2, 1)                                                             # [B,NC,kmax]
-        mask = (gs > conf) & valid.view(B, 1, kmax)                                                   # :180
-        # the reference compacts the masked boxes before nms (order kept): move them to the front of each group
-        order = torch.argsort((~mask).to(torch.int8), dim=2, stable=True)
-        gs = torch.gather(gs, 2, order)
-        gb = boxes[idx].view(B, 1, kmax, 4).expand(B, NC, kmax, 4)
-        gb = torch.gather(gb, 2, order.unsqueeze(-1).expand(B, NC, kmax, 4)).contiguous()
-        counts = mask.sum(2).to(torch.int32)
-        keep = nms_batched(gb.view(B * NC, kmax, 4), gs.reshape(B * NC, kmax), counts.view(-1), thr).view(B, NC, kmax).bool()
-        # rows in the reference's order: clip, class ascending, kept tube ascending == row-major order of `keep`
-        kb, kc, kj = torch.nonzero(keep, as_tuple=True)
-        rb = gb[kb, kc, kj] / torch.tensor([W, H, W, H], device=dev)                                  # :197-198
-        rs = gs[kb, kc, kj]
-        rt = order[kb, kc, kj]
-        per_clip = torch.bincount(kb, minlength=B).tolist()                                           # the one host sync
-        clips = []
-        for bx, sc, cl, tb in zip(rb.split(per_clip), rs.split(per_clip), kc.split(per_clip), rt.split(per_clip)):
-            if etopk > 0:                                                                             # :205-208
-                # list.sort(key=score) is stable and ascending, then reversed: descending with ties in REVERSED row order
-                sel = torch.flip(torch.argsort(sc, stable=True), dims=(0,))[:topk]
-                bx, sc, cl, tb = bx[sel], sc[sel], cl[sel], tb[sel]
-            clips.append({"boxes": bx, "scores": sc, "labels": cl, "tubes": tb})
-        out.append(clips)
+        if len(nums) == 0 or sum(nums) == 0:
+            e = torch.zeros(0, device=h["pred_loc"].device)
+            out[oi] = [{"boxes": e.view(0, 4), "scores": e, "labels": e.long(), "tubes": e.long()} for _ in nums]
+        elif max(nums) <= 64:
+            fast.append((oi, h, nums))
+        else:
+            slow.append((oi, h, nums))
+    groups = {}
+    for oi, h, nums in fast:
+        groups.setdefault((tuple(nums), h["pred_prob"].shape[-1], h["pred_loc"].device), []).append((oi, h))
+    for (nums, NC, dev), members in groups.items():
+        B, kmax, I = len(nums), max(nums), len(members)
+        n = torch.as_tensor(nums, device=dev, dtype=torch.int32)
+        start = (torch.cumsum(n, 0) - n).to(torch.int32)
+        keep = torch.empty((I, B, NC, kmax), dtype=torch.uint8, device=dev)
+        sc_all, bx_all = [], []
+        for k, (oi, h) in enumerate(members):
+            prob, loc = h["pred_prob"], h["pred_loc"]
+            scores = prob[:, int(prob.shape[1] / 2)].float()                                          # [N,NC] middle frame (test.py:159)
+            _, boxes = ops.detect_nms(scores, loc[:, int(loc.shape[1] / 2)].float(), start, n, kmax, conf, thr, 400.0, 400.0, keep[k])
+            sc_all.append(scores)                                                                     # (valid_tubes' 400 x 400 default, as the reference calls it: test.py:161,191)
+            bx_all.append(boxes)
+        # rows in the reference's order: iteration, clip, class ascending, kept tube ascending == row-major order of `keep`
+        ki, kb, kc, kj = torch.nonzero(keep, as_tuple=True)
+        tube = start.long()[kb] + kj + ki * sum(nums)
+        rb = torch.cat(bx_all)[tube] / torch.tensor([W, H, W, H], device=dev)                         # test.py:197-198
+        rs = torch.cat(sc_all)[tube, kc]
+        per = torch.bincount(ki * B + kb, minlength=I * B).tolist()                                   # the one host sync
+        pieces = list(zip(rb.split(per), rs.split(per), kc.split(per), kj.split(per)))
+        for k, (oi, h) in enumerate(members):
+            clips = []
+            for bx, sc, cl, tb in pieces[k * B:(k + 1) * B]:
+                if etopk > 0:                                                                         # test.py:205-208
+                    # list.sort(key=score) is stable and ascending, then reversed: descending with ties in REVERSED row order
+                    sel = torch.flip(torch.argsort(sc, stable=True), dims=(0,))[:topk]
+                    bx, sc, cl, tb = bx[sel], sc[sel], cl[sel], tb[sel]
+                clips.append({"boxes": bx, "scores": sc, "labels": cl, "tubes": tb})
+            out[oi] = clips
+    for oi, h, nums in slow:
+        out[oi] = _postprocess_general(h, nums, conf, thr, etopk, topk, W, H)
     return out
+
+
+def _postprocess_general(h, nums, conf, thr, etopk, topk, W, H):
+    """One iteration with tensor operations + step_nms_batched: more than 64 tubes per clip (anchor modes 3 / 4)."""
+    from .roi_layers import nms_batched
+    prob, loc = h["pred_prob"], h["pred_loc"]
+    dev = loc.device
+    B, NC = len(nums), prob.shape[-1]
+    boxes = valid_tubes(loc[:, int(loc.shape[1] / 2)].float().unsqueeze(1))[:, 0]                     # [N,4] (test.py:161,191)
+    scores = prob[:, int(prob.shape[1] / 2)].float()                                                  # [N,NC] (:159)
+    idx, valid = _clip_groups(nums, dev)
+    kmax = idx.shape[1]
+    gs = scores[idx].permute(0, 2, 1)                                                                 # [B,NC,kmax]
+    mask = (gs > conf) & valid.view(B, 1, kmax)                                                       # :180
+    # the reference compacts the masked boxes before nms (order kept): move them to the front of each group
+    order = torch.argsort((~mask).to(torch.int8), dim=2, stable=True)
+    gs = torch.gather(gs, 2, order)
+    gb = boxes[idx].view(B, 1, kmax, 4).expand(B, NC, kmax, 4)
+    gb = torch.gather(gb, 2, order.unsqueeze(-1).expand(B, NC, kmax, 4)).contiguous()
+    counts = mask.sum(2).to(torch.int32)
+    keep = nms_batched(gb.view(B * NC, kmax, 4), gs.reshape(B * NC, kmax), counts.view(-1), thr).view(B, NC, kmax).bool()
+    kb, kc, kj = torch.nonzero(keep, as_tuple=True)
+    rb = gb[kb, kc, kj] / torch.tensor([W, H, W, H], device=dev)                                      # :197-198
+    rs = gs[kb, kc, kj]
+    rt = order[kb, kc, kj]
+    per_clip = torch.bincount(kb, minlength=B).tolist()
+    clips = []
+    for bx, sc, cl, tb in zip(rb.split(per_clip), rs.split(per_clip), kc.split(per_clip), rt.split(per_clip)):
+        if etopk > 0:
+            sel = torch.flip(torch.argsort(sc, stable=True), dims=(0,))[:topk]
+            bx, sc, cl, tb = bx[sel], sc[sel], cl[sel], tb[sel]
+        clips.append({"boxes": bx, "scores": sc, "labels": cl, "tubes": tb})
+    return clips
 
 
 def detections_csv(dets, infos, label_dict=None):

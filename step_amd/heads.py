@@ -58,6 +58,10 @@ class ROINet(nn.Module):
             # slice as frame b*T_all + t of a strided [B*T_all, ...] view that starts at the slice
             fstride = v.stride(1)
             t_all = v.stride(0) // fstride
+            if self.pool_mode == "align" and not (torch.is_grad_enabled() and conv_feat.requires_grad):
+                # inference: the kernel maps the slice's frame index onto the buffer itself (step_roi_align_tubes_forward) -- seven
+                # element-wise launches on the tubes per refinement step otherwise
+                return ops.roi_align_tubes_forward(v, rois, self.pool_size, self.pool_size, 1.0 / 16.0, 0)
             feat4 = torch.as_strided(v, (B * t_all - (t_all - T), H, W, C), (fstride, W * C, C, 1)).permute(0, 3, 1, 2)
             idx = rois[:, 0]
             b = torch.floor(idx / T)
@@ -314,9 +318,10 @@ class TwoBranchNet(nn.Module):
         global_class = logits.reshape(N, Tl, self.num_classes).float().mean(1)
 
         # ---- local branch
-        zero = torch.zeros(1, device=global_class.device, dtype=global_class.dtype)      # fill kernel: capturable
-        local_loc, first_loc, last_loc = zero, zero.clone(), zero.clone()
-        if not self.cls_only:
+        if self.cls_only:                                          # (two_branch.py:246: three one-element zeros)
+            zero = torch.zeros(1, device=global_class.device, dtype=global_class.dtype)      # fill kernel: capturable
+            local_loc, first_loc, last_loc = zero, zero.clone(), zero.clone()
+        else:
             a = g.reshape(N * Tl, 1, W, H, C)                      # frames as batch, D = 1
             b = gc.reshape(N * Tl, 1, W, H, self.fc_dim)
             lf = self.local_conv(a, b)                             # [N*Tl,1,7,7,1024]
@@ -336,8 +341,11 @@ class TwoBranchNet(nn.Module):
 
         # ---- losses (two_branch.py:276-333)
         loss_global_cls = torch.zeros((), device=global_class.device)
-        loss_local_loc = torch.zeros((), device=global_class.device)
-        loss_neighbor_loc = torch.zeros((), device=global_class.device)
+        if targets is None:                                        # inference: ONE fill for the three zero losses (read-only placeholders)
+            loss_local_loc = loss_neighbor_loc = loss_global_cls
+        else:
+            loss_local_loc = torch.zeros((), device=global_class.device)
+            loss_neighbor_loc = torch.zeros((), device=global_class.device)
         if targets is not None:
             tubes = tubes.to(dev)
             targets = targets.to(dev)

@@ -507,6 +507,24 @@ def roi_align_forward(inp, rois, ph, pw, scale, sampling_ratio):
     return out
 
 
+def roi_align_tubes_forward(v, rois, ph, pw, scale, sampling_ratio):
+    """ROIAlign over a T-slice of a channels-last feature buffer without copying it: v = buf[:, t0:t0+T] as a [B, T, H, W, C] view of a
+    dense [B, T_all, H, W, C] buffer, rois [K,5] with first column b * T + t (frame of the slice).  step_roi_align_tubes_forward: no
+    slice copy and no index arithmetic on the tubes.  Returns logical [K, C, ph, pw] (channels-last physical)."""
+    L = _lib.lib()
+    B, T, H, W, C = v.shape
+    if not (v.stride(4) == 1 and v.stride(3) == C and v.stride(2) == W * C and v.stride(1) == H * W * C and v.stride(0) % v.stride(1) == 0):
+        raise RuntimeError("step_amd: roi_align_tubes_forward wants a frame slice of a dense channels-last buffer")
+    T_all = max(v.stride(0) // v.stride(1), T)
+    rois = _rois_f32(rois, v.device)
+    K = rois.shape[0]
+    out = torch.empty((K, ph, pw, C), dtype=v.dtype, device=v.device)
+    _capi.check(L.step_roi_align_tubes_forward(_lib.dptr(v), _dt(v), _lib.dptr(rois) if K else None, K, B, T_all, T, C, H, W, ph, pw,
+                                               float(scale), int(sampling_ratio), _lib.dptr(out) if K else None,
+                                               _lib.stream_ptr(v.device)), "step_roi_align_tubes_forward")
+    return out.permute(0, 3, 1, 2)
+
+
 def roi_align_backward(grad, rois, ph, pw, scale, sampling_ratio, B, C, H, W):
     L = _lib.lib()
     g = grad.float()
@@ -582,6 +600,23 @@ def nms_batched(boxes, scores, counts, threshold):
     _capi.check(fn(_lib.dptr(boxes), _lib.dptr(scores), _lib.dptr(counts), G, kmax, float(threshold),
                    _lib.dptr(keep), _lib.dptr(scratch), _lib.stream_ptr(boxes.device)), "step_nms_batched")
     return keep
+
+
+def detect_nms(prob, loc, tube_start, tube_count, kmax, conf_thresh, nms_thresh, width, height, keep=None):
+    """One refinement iteration's evaluation loop in one launch (step_detect_nms): prob [N,NC] and loc [N,4] fp32 (rows may be strided
+    views), tube_start / tube_count [B] int32 -> (keep [B,NC,kmax] uint8 at the tubes' original slots, clamped boxes [N,4])."""
+    L = _lib.lib()
+    if prob.dtype != torch.float32 or loc.dtype != torch.float32 or prob.stride(1) != 1 or loc.stride(1) != 1:
+        prob, loc = prob.float().contiguous(), loc.float().contiguous()
+    N, NC = prob.shape
+    B = tube_start.shape[0]
+    if keep is None:
+        keep = torch.empty((B, NC, kmax), dtype=torch.uint8, device=prob.device)
+    boxes = torch.empty((N, 4), dtype=torch.float32, device=prob.device)
+    _capi.check(L.step_detect_nms(_lib.dptr(prob), prob.stride(0), NC, _lib.dptr(loc), loc.stride(0), _lib.dptr(tube_start), _lib.dptr(tube_count),
+                                  B, kmax, float(conf_thresh), float(nms_thresh), float(width), float(height), _lib.dptr(keep), _lib.dptr(boxes),
+                                  _lib.stream_ptr(prob.device)), "step_detect_nms")
+    return keep, boxes
 
 
 def tube_update(flat, local_loc, first_loc, last_loc, clip_of, first_off, last_off, extend, width, height):

@@ -917,7 +917,7 @@ def case_conv_splitk_few_rows_deep_k(bk, golden):
                 err = np.abs(y - ref).max() / np.abs(ref).max()
                 assert err < tol(dt), (rows, Cin, Cout, dt, err)
     # shallow layers never ask for a workspace
-    d = _capi.ConvDesc(dtype=F32, N=5, D=1, H=1, W=1, Cin=1024, Cout=12, kd=1, kh=1, kw=1, x_cstride=1024, x_coff=0, y_cstride=12,
+    d = _capi.ConvDesc(dtype=F32, N=5, D=1, H=1, W=1, Cin=256, Cout=12, kd=1, kh=1, kw=1, x_cstride=256, x_coff=0, y_cstride=12,
                        y_coff=0, res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)
     assert bk.lib.step_conv_workspace_bytes(ctypes.byref(d)) == 0
 
@@ -1160,10 +1160,11 @@ def case_conv_group_matches_separate_launches(bk, golden):
     calls; a narrow member inside a deeper instantiation leaves a wave group without channel blocks (it must skip, not store); fp32 /
     pointwise members are launched separately with the same results."""
     rs = np.random.RandomState(51)
-    N, D, H, W = 1, 8, 14, 14                                  # (general 8 x 2 x 14 boxes, 7 pixel tiles)
     buf = ctypes.create_string_buffer(256)
-    for dt, (ci0, co0, ci1, co1), merged in ((BF16, (64, 200, 64, 40), True), (F16, (96, 64, 64, 64), True), (BF16, (64, 96, 64, 160), True),
-                                             (F32, (64, 96, 64, 40), False)):
+    G14, H7 = (1, 8, 14, 14), (6, 3, 7, 7)                     # general 8 x 2 x 14 boxes (7 pixel tiles) | the heads' maps: 4-plane 8x8 tiles
+    for dt, (N, D, H, W), (ci0, co0, ci1, co1), merged in ((BF16, G14, (64, 200, 64, 40), True), (F16, G14, (96, 64, 64, 64), True),
+                                                           (BF16, G14, (64, 96, 64, 160), True), (BF16, H7, (160, 320, 64, 128), True),
+                                                           (F32, G14, (64, 96, 64, 40), False)):
         t = rs.randn(N, ci0 + ci1, D, H, W).astype(np.float32)                    # the shared bottleneck buffer: member k reads its slice
         ws = [(rs.randn(co, ci, 3, 3, 3) / np.sqrt(ci * 27)).astype(np.float32) for ci, co in ((ci0, co0), (ci1, co1))]
         aff = [((1 + 0.1 * rs.randn(co)).astype(np.float32), (0.2 * rs.randn(co)).astype(np.float32)) for co in (co0, co1)]

@@ -426,6 +426,13 @@ def case_postprocess_golden(dev, golden):
         assert np.array_equal(np.concatenate(box), g[tag + "_box"]), tag
         assert np.array_equal(np.concatenate(score), g[tag + "_score"]), tag
         assert lines == [str(x) for x in g[tag + "_lines"]], tag
+    # the general path (more than 64 tubes per clip: mask / compaction as tensor operations + step_nms_batched) gives the same rows
+    from step_amd import driver
+    fastp = postprocess(cfg(conf_thresh=0.01, nms_thresh=0.4, evaluate_topk=-1, topk=-1), hist)
+    for it in range(3):
+        gen = driver._postprocess_general(hist[it], nums, 0.01, 0.4, -1, -1, 400.0, 400.0)
+        for a_, b_ in zip(gen, fastp[it]):
+            assert all(torch.equal(a_[k_], b_[k_]) for k_ in ("boxes", "scores", "labels", "tubes"))
     # one iteration only, and an empty clip in the batch
     only = postprocess(cfg(), hist, iterations=(2,))
     assert len(only) == 1
