@@ -407,6 +407,18 @@ STEP_API int step_tube_update(const float* tubes, int N, int T, const float* loc
                               float width, float height, float* pred_loc, float* pred_first, float* pred_last,
                               float* next_tubes, step_stream_t stream);
 
+/* Training sample selection, device front end (utils/utils.py:179-214 train_select, utils/tube_utils.py:59-92,269-351): from a
+ * previous step's predictions -- prob [N,T,NC], loc [N,T,4], first / last [N,Tw,4] (NULL outside temporal_mode "predict"), all fp32
+ * dense -- in one launch: mean_prob [N,NC] = the class scores averaged over the tube's frames (sequential fp32 sum / T, as numpy's
+ * mean does), vloc / vfirst / vlast = the tubes through valid_tubes(width, height), and iou [N,Gmax] = box IoU (no +1 convention; 0
+ * unless both overlap extents are positive; 0 for an all-zero padding box) of the tube's clamped middle-frame box with the
+ * ground-truth boxes gt_mid [B,Gmax,4] of its clip (clip_of [N] int32, gt_count [B] int32).  The draws from the random streams and
+ * the stable sorts that pick the training tubes stay on the host (step_amd/selection.py), fed by ONE small device-to-host copy. */
+STEP_API int step_select_prepare(const float* prob, const float* loc, const float* first, const float* last, int N, int T, int Tw,
+                                 int NC, const int32_t* clip_of, const float* gt_mid, const int32_t* gt_count, int Gmax,
+                                 float width, float height, float* mean_prob, float* vloc, float* vfirst, float* vlast,
+                                 float* iou, step_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

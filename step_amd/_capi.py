@@ -76,6 +76,7 @@ SIGNATURES = {
     "step_transpose_cs": (i, [vp, i, vp, i, i, i, ll, i, vp]),
     "step_act_grad": (i, [i, vp, i, i, vp, i, fp, ll, i, i, fp, vp, vp]),
     "step_tube_update": (i, [fp, i, i, fp, fp, fp, i, i, i, ip, i, f, f, fp, fp, fp, fp, vp]),
+    "step_select_prepare": (i, [fp, fp, fp, fp, i, i, i, i, ip, fp, ip, i, f, f, fp, fp, fp, fp, fp, vp]),
     "step_adam_flat": (i, [fp, fp, fp, fp, ll, vp, fp, fp, i, C.c_double, C.c_double, C.c_double, i, f, i, vp]),
     "step_adam_flat_dev": (i, [fp, fp, fp, fp, ll, vp, fp, fp, i, C.c_double, C.c_double, C.c_double, vp, fp, f, i, vp]),
 }

@@ -64,9 +64,76 @@ __global__ void tube_update_kernel(TubeParams p) {
     }
 }
 
+// ---- training sample selection, device front end -------------------------------------------------------------
+// What utils/utils.py:179-214 (train_select) and utils/tube_utils.py:269-351 compute per clip on the host from a previous step's
+// predictions, for EVERY refined tube in one launch: the class scores averaged over the tube's frames, the three predicted tubes
+// through valid_tubes, and the IoU of the tube's middle-frame box with each of its clip's ground-truth boxes.  fp32 arithmetic in
+// the reference's (numpy's) operation order: the mean is the sequential sum over frames divided by T; box_iou without the +1
+// convention, zero unless both overlap extents are positive; a pair with an all-zero (padding) tube gives 0.
+struct SelectParams {
+    const float* prob; const float* loc; const float* first; const float* last; const int32_t* clip_of; const float* gt; const int32_t* gt_count;
+    float* mean_prob; float* vloc; float* vfirst; float* vlast; float* iou;
+    int N, T, Tw, NC, Gmax;
+    float width, height;
+};
+
+__device__ __forceinline__ void valid_box(const float* b, float w, float h, float* o) {        // tube_utils.py:59-92
+    float x1 = fmaxf(0.0f, b[0]), y1 = fmaxf(0.0f, b[1]), x2 = fminf(w, b[2]), y2 = fminf(h, b[3]);
+    if (!((x1 < x2 - 2.0f) && (y1 < y2 - 2.0f))) { x1 = 0.0f; y1 = 0.0f; x2 = w; y2 = h; }
+    o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2;
+}
+
+__global__ void select_prepare_kernel(SelectParams p) {
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < p.NC; c += blockDim.x) {
+        float s = p.prob[((size_t)n * p.T) * p.NC + c];
+        for (int t = 1; t < p.T; ++t) s = s + p.prob[((size_t)n * p.T + t) * p.NC + c];
+        p.mean_prob[(size_t)n * p.NC + c] = s / (float)p.T;
+    }
+    for (int t = threadIdx.x; t < p.T; t += blockDim.x) valid_box(p.loc + ((size_t)n * p.T + t) * 4, p.width, p.height, p.vloc + ((size_t)n * p.T + t) * 4);
+    if (p.first)
+        for (int t = threadIdx.x; t < p.Tw; t += blockDim.x) {
+            valid_box(p.first + ((size_t)n * p.Tw + t) * 4, p.width, p.height, p.vfirst + ((size_t)n * p.Tw + t) * 4);
+            valid_box(p.last + ((size_t)n * p.Tw + t) * 4, p.width, p.height, p.vlast + ((size_t)n * p.Tw + t) * 4);
+        }
+    const int b = p.clip_of[n];
+    for (int g = threadIdx.x; g < p.Gmax; g += blockDim.x) {
+        float v = 0.0f;
+        if (g < p.gt_count[b]) {
+            float a[4];
+            valid_box(p.loc + ((size_t)n * p.T + p.T / 2) * 4, p.width, p.height, a);        // the candidate's middle frame (after valid_tubes)
+            const float* q = p.gt + ((size_t)b * p.Gmax + g) * 4;
+            const bool live = (((q[0] + q[1]) + q[2]) + q[3]) != 0.0f && (((a[0] + a[1]) + a[2]) + a[3]) != 0.0f;     // bool(np.sum(tube))
+            if (live) {
+                const float iw = fmaxf(fminf(q[2], a[2]) - fmaxf(q[0], a[0]), 0.0f);
+                const float ih = fmaxf(fminf(q[3], a[3]) - fmaxf(q[1], a[1]), 0.0f);
+                const float inter = (iw > 0.0f && ih > 0.0f) ? iw * ih : 0.0f;
+                const float uni = (q[2] - q[0]) * (q[3] - q[1]) + (a[2] - a[0]) * (a[3] - a[1]) - inter;
+                v = inter / uni;
+            }
+        }
+        p.iou[(size_t)n * p.Gmax + g] = v;
+    }
+}
+
 }  // namespace step
 
 using namespace step;
+
+extern "C" int step_select_prepare(const float* prob, const float* loc, const float* first, const float* last, int N, int T, int Tw, int NC,
+                                   const int32_t* clip_of, const float* gt_mid, const int32_t* gt_count, int Gmax, float width, float height,
+                                   float* mean_prob, float* vloc, float* vfirst, float* vlast, float* iou, step_stream_t stream) {
+    if (N < 0 || T <= 0 || NC <= 0 || Gmax < 0 || Tw < 0) return STEP_E_SHAPE;
+    if (N == 0) return STEP_OK;
+    if (!prob || !loc || !clip_of || !mean_prob || !vloc || (Gmax && (!gt_mid || !gt_count || !iou))) return STEP_E_NULL;
+    if ((first != nullptr) != (last != nullptr) || (first && (!vfirst || !vlast || Tw <= 0))) return STEP_E_NULL;
+    SelectParams p;
+    p.prob = prob; p.loc = loc; p.first = first; p.last = last; p.clip_of = clip_of; p.gt = gt_mid; p.gt_count = gt_count;
+    p.mean_prob = mean_prob; p.vloc = vloc; p.vfirst = vfirst; p.vlast = vlast; p.iou = iou;
+    p.N = N; p.T = T; p.Tw = Tw; p.NC = NC; p.Gmax = Gmax; p.width = width; p.height = height;
+    STEP_LAUNCH(select_prepare_kernel, dim3((unsigned)N), dim3(64), stream, p);
+    return STEP_LAUNCH_CHECK();
+}
 
 extern "C" int step_tube_update(const float* tubes, int N, int T, const float* local_loc, const float* first_loc, const float* last_loc,
                                 int Tw, int first_off, int last_off, const int32_t* clip_of, int extend, float width, float height,

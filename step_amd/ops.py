@@ -619,6 +619,28 @@ def detect_nms(prob, loc, tube_start, tube_count, kmax, conf_thresh, nms_thresh,
     return keep, boxes
 
 
+def select_prepare(prob, loc, first, last, clip_of, gt_mid, gt_count, width, height):
+    """step_select_prepare: prob [N,T,NC], loc [N,T,4], first / last [N,Tw,4] | None, clip_of [N] int32, gt_mid [B,Gmax,4], gt_count [B]
+    int32 (one device) -> (mean_prob [N,NC], vloc [N,T,4], vfirst, vlast ([N,Tw,4] | None), iou [N,Gmax]), fp32 on that device."""
+    L = _lib.lib()
+    f32 = lambda t: None if t is None else t.detach().float().contiguous()
+    prob, loc, first, last, gt_mid = f32(prob), f32(loc), f32(first), f32(last), f32(gt_mid)
+    N, T, NC = prob.shape
+    Tw = first.shape[1] if first is not None else 0
+    Gmax = gt_mid.shape[1]
+    dev = prob.device
+    mean_prob = torch.empty((N, NC), dtype=torch.float32, device=dev)
+    vloc = torch.empty((N, T, 4), dtype=torch.float32, device=dev)
+    vfirst = torch.empty((N, Tw, 4), dtype=torch.float32, device=dev) if first is not None else None
+    vlast = torch.empty((N, Tw, 4), dtype=torch.float32, device=dev) if first is not None else None
+    iou = torch.empty((N, Gmax), dtype=torch.float32, device=dev)
+    _capi.check(L.step_select_prepare(_lib.dptr(prob), _lib.dptr(loc), _lib.dptr(first), _lib.dptr(last), N, T, Tw, NC,
+                                      _lib.dptr(clip_of.to(torch.int32).contiguous()), _lib.dptr(gt_mid), _lib.dptr(gt_count.to(torch.int32).contiguous()),
+                                      Gmax, float(width), float(height), _lib.dptr(mean_prob), _lib.dptr(vloc), _lib.dptr(vfirst), _lib.dptr(vlast),
+                                      _lib.dptr(iou), _lib.stream_ptr(dev)), "step_select_prepare")
+    return mean_prob, vloc, vfirst, vlast, iou
+
+
 def tube_update(flat, local_loc, first_loc, last_loc, clip_of, first_off, last_off, extend, width, height):
     """One refinement step's tube bookkeeping (step_tube_update): returns (pred_loc, pred_first, pred_last, next_flat)."""
     L = _lib.lib()

@@ -54,11 +54,12 @@ def tube_iou(t1, t2):
     return acc.astype(np.float32)
 
 
-def select_proposals(gt_tubes, anchors, scores=None, cls_thresh=0.2, max_pos_num=5, sampling="random", neg_ratio=2):
+def select_proposals(gt_tubes, anchors, scores=None, cls_thresh=0.2, max_pos_num=5, sampling="random", neg_ratio=2, ious=None):
     """-> (positives [(gt, proposal)], negatives [(gt, proposal)], iou table) -- utils/utils.py:341-423.
     Positives: the best free proposal of every ground truth (highest-IoU ground truth first), then random ones among the
     proposals above cls_thresh; negatives: drawn from the rest, uniformly / by score / by softmax(score)."""
-    ious = tube_iou(np.asarray(gt_tubes)[:, :, :4], anchors)
+    if ious is None:                                                # (the device front end hands the table in: step_select_prepare)
+        ious = tube_iou(np.asarray(gt_tubes)[:, :, :4], anchors)
     G, A = ious.shape
     if scores is None:
         scores = ious.max(axis=0)
@@ -132,13 +133,18 @@ def _top_candidates(prob, topk, num_classes):
     return np.asarray(rows, np.int64), np.asarray(sc)
 
 
-def train_select(step, history, targets, tubes, args):
+def train_select(step, history, targets, tubes, args, device=None):
     """-> (selected_tubes, target_tubes), one array per clip -- utils/utils.py:135-339.
 
     step 1 trains on the initial proposals `tubes[b]`; later steps on the best-scoring refined tubes of the previous step
     (`history`: pred_prob [N,T,C], pred_loc [N,T,4], pred_first_loc / pred_last_loc [N,T,4], tubes_nums).  Every selected tube
     comes with one target row per loss frame [first neighbour, centre, last neighbour], each
-    [x1,y1,x2,y2, cls flag, reg flag, class labels...]."""
+    [x1,y1,x2,y2, cls flag, reg flag, class labels...].
+
+    device=True (default when the history lives on a ROCm device): the per-tube arithmetic -- class scores averaged over the frames,
+    valid_tubes of the three predicted tubes, the IoU table against the clip's ground truths -- is ONE launch (step_select_prepare) and
+    ONE device-to-host copy of its small results instead of four copies of the raw predictions and numpy passes over them; the
+    sorts and the draws from the random streams, which decide WHICH tubes are trained on, stay here.  Same selections, bit for bit."""
     if args.temporal_mode not in ("predict", "extrapolate", "mean"):
         raise NotImplementedError("temporal_mode %r" % (args.temporal_mode,))
     chunks, max_chunks = args.NUM_CHUNKS[step], args.NUM_CHUNKS[args.max_iter]
@@ -156,11 +162,16 @@ def train_select(step, history, targets, tubes, args):
     def host(x):
         return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
 
+    dev_path = None
     if step > 1:
-        prob, loc = host(history["pred_prob"]), host(history["pred_loc"])
-        first = host(history["pred_first_loc"]) if predict else None
-        last = host(history["pred_last_loc"]) if predict else None
         bounds = np.concatenate(([0], np.cumsum(history["tubes_nums"]))).astype(np.int64)
+        on_dev = hasattr(history["pred_prob"], "is_cuda") and history["pred_prob"].is_cuda
+        if device if device is not None else on_dev:
+            dev_path = _prepare_on_device(history, targets, mid, predict, W, H)
+        else:
+            prob, loc = host(history["pred_prob"]), host(history["pred_loc"])
+            first = host(history["pred_first_loc"]) if predict else None
+            last = host(history["pred_last_loc"]) if predict else None
 
     selected, wanted = [], []
     for b in range(len(targets)):
@@ -169,12 +180,21 @@ def train_select(step, history, targets, tubes, args):
             cand, cand_score, cand_first, cand_last = np.asarray(tubes[b]), None, None, None
         else:
             lo, hi = bounds[b], bounds[b + 1]
-            rows, cand_score = _top_candidates(prob[lo:hi].mean(axis=1), args.topk, nc)
-            cand = valid_tubes(loc[lo:hi][rows], W, H)
-            cand_first = valid_tubes(first[lo:hi][rows], W, H) if predict else None
-            cand_last = valid_tubes(last[lo:hi][rows], W, H) if predict else None
+            if dev_path is not None:
+                mean_prob, vloc, vfirst, vlast, iou_all = dev_path
+                rows, cand_score = _top_candidates(mean_prob[lo:hi], args.topk, nc)
+                cand = vloc[lo:hi][rows]
+                cand_first = vfirst[lo:hi][rows] if predict else None
+                cand_last = vlast[lo:hi][rows] if predict else None
+                table = np.ascontiguousarray(iou_all[lo:hi][rows][:, :gt.shape[0]].T)            # [G, candidates]
+            else:
+                rows, cand_score = _top_candidates(prob[lo:hi].mean(axis=1), args.topk, nc)
+                cand = valid_tubes(loc[lo:hi][rows], W, H)
+                cand_first = valid_tubes(first[lo:hi][rows], W, H) if predict else None
+                cand_last = valid_tubes(last[lo:hi][rows], W, H) if predict else None
         pos, neg, ious = select_proposals(gt[:, mid].reshape(gt.shape[0], 1, -1), cand[:, int(cand.shape[1] / 2)].reshape(cand.shape[0], 1, -1),
-                                          cand_score, cls_thresh, args.max_pos_num, args.selection_sampling, args.neg_ratio)
+                                          cand_score, cls_thresh, args.max_pos_num, args.selection_sampling, args.neg_ratio,
+                                          ious=table if (step > 1 and dev_path is not None) else None)
         pg = np.asarray([g for g, _ in pos], np.int64)
         pa = np.asarray([a for _, a in pos], np.int64)
         ng = np.asarray([g for g, _ in neg], np.int64)
@@ -209,3 +229,37 @@ def train_select(step, history, targets, tubes, args):
         selected.append(sel)
         wanted.append(np.concatenate((before, centre, after), axis=1))
     return selected, wanted
+
+
+def _prepare_on_device(history, targets, mid, predict, W, H):
+    """step_select_prepare over a step's predictions (device tensors) -> host arrays (mean_prob [N,NC], vloc [N,T,4], vfirst / vlast
+    [N,Tw,4] | None, iou [N,Gmax]) through one packed device-to-host copy."""
+    import torch
+
+    from . import ops
+    prob = history["pred_prob"]
+    dev = prob.device
+    nums = [int(v) for v in history["tubes_nums"]]
+    B = len(nums)
+    Gmax = max([np.asarray(t).shape[0] for t in targets] + [1])
+    gt = np.zeros((B, Gmax, 4), np.float32)
+    cnt = np.zeros((B,), np.int32)
+    for b, t in enumerate(targets):
+        t = np.asarray(t)
+        cnt[b] = t.shape[0]
+        gt[b, :t.shape[0]] = t[:, mid, :4]
+    clip_of = torch.as_tensor(np.repeat(np.arange(B), nums).astype(np.int32), device=dev)
+    outs = ops.select_prepare(prob, history["pred_loc"], history["pred_first_loc"] if predict else None,
+                              history["pred_last_loc"] if predict else None, clip_of, torch.from_numpy(gt).to(dev), torch.from_numpy(cnt).to(dev),
+                              float(W), float(H))
+    sizes = [o.numel() for o in outs if o is not None]
+    packed = torch.cat([o.reshape(-1) for o in outs if o is not None]).cpu().numpy()           # the one device-to-host copy
+    res, k, off = [], 0, 0
+    for o in outs:
+        if o is None:
+            res.append(None)
+            continue
+        res.append(packed[off:off + sizes[k]].reshape(tuple(o.shape)))
+        off += sizes[k]
+        k += 1
+    return res

@@ -782,6 +782,40 @@ def case_wgrad_into_grad_matches_autograd(dev, golden):
     assert not backbone._PENDING[0] and not backbone.WGRAD_INTO_GRAD
 
 
+def case_train_select_device_front_end(dev, golden):
+    """SURVEY 8 f-3 on the device: train_select with the previous step's predictions as DEVICE tensors -- class-score means,
+    valid_tubes and the IoU table from one step_select_prepare launch and one device-to-host copy -- against what the reference's own
+    train_select returned for the same inputs and the same `random` / `numpy.random` seeds (selection_golden.npz): same tubes, same
+    order, same target rows, bit for bit; all six recorded cases (sampling modes, top-k, score ties, an invalid box, three temporal
+    modes)."""
+    import random
+
+    from step_amd import selection as S
+    from step_amd.tube_math import generate_anchors
+    g = np.load(os.path.join(GOLDEN, "selection_golden.npz"))
+    for ci in range(6):
+        args = NS(T=3, NUM_CHUNKS={1: 1, 2: 1, 3: 3, 4: 3}, max_iter=3, num_classes=60, image_size=(400, 400),
+                  cls_thresh=[0.2, 0.35, 0.5], reg_thresh=[0.2, 0.35, 0.5], max_pos_num=int(g["c%d_max_pos_num" % ci]),
+                  neg_ratio=int(g["c%d_neg_ratio" % ci]), topk=int(g["c%d_topk" % ci]),
+                  selection_sampling=str(g["c%d_sampling" % ci]), temporal_mode=str(g["c%d_mode" % ci]))
+        seed = int(g["c%d_seed" % ci])
+        targets = [g["c%d_targets%d" % (ci, b)] for b in range(2)]
+        anchors = (generate_anchors() * 400.0).astype(np.float32)
+        tubes = [np.tile(anchors[:, None, :], (1, 3, 1)).astype(np.float32) for _ in range(2)]
+        hist = {k: torch.from_numpy(g["c%d_hist_%s" % (ci, k)]).to(dev) for k in ("pred_loc", "pred_first_loc", "pred_last_loc")}
+        hist["pred_prob"] = torch.from_numpy(np.tile(g["c%d_hist_pred_prob" % ci], (1, 3, 1))).to(dev)
+        hist["tubes_nums"] = [34, 20]
+        for step in (2, 3):
+            random.seed(seed * 10 + step)
+            np.random.seed(seed * 10 + step)
+            sel, tgt = S.train_select(step, hist, targets, tubes, args, device=True)
+            for b in range(2):
+                ref_sel, ref_tgt = g["c%d_s%d_sel%d" % (ci, step, b)], g["c%d_s%d_tgt%d" % (ci, step, b)]
+                assert sel[b].shape == ref_sel.shape and sel[b].dtype == ref_sel.dtype, (ci, step, b)
+                assert np.array_equal(sel[b], ref_sel), (ci, step, b)
+                assert np.array_equal(tgt[b], ref_tgt), (ci, step, b)
+
+
 def case_training_iteration_with_selection(dev, golden):
     """The whole iteration of train.py:257-348 on one AVA-shaped clip (step_amd.workloads.C4SelectTrainStep): no-grad
     inference, train_select between the steps, three heads, backward, fused Adam.  Checks what is size-independent: per step
@@ -1092,5 +1126,5 @@ CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_g
              "case_reg_unit_pack_follows_weight_updates", "case_basenet_backward_matches_oracle_autograd",
              "case_contextnet_backward_matches_oracle_autograd", "case_postprocess_golden",
              "case_batched_repack_follows_weight_updates", "case_stem_backward_16bit",
-             "case_loss_masks_without_host_branches", "case_data_parallel_replicas"]
+             "case_loss_masks_without_host_branches", "case_data_parallel_replicas", "case_train_select_device_front_end"]
 GPU_CASES = CPU_CASES + ["case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_c5_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_i3d_classifier_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
