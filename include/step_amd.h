@@ -78,6 +78,7 @@ enum {
     STEP_OPT_POOL_DIRECT,      /*  0 (default) | 1: every max pool on the general 27-tap kernel (tests) */
     STEP_OPT_WGRAD_MINPIX,     /*  0 (default: 512) | n: least pixels per wavefront job of step_conv_wgrad (fp32 summation order) */
     STEP_OPT_WGRAD16_LDS,      /*  1 (default) | 0: 3x3 windows of step_conv_wgrad16_ws on the per-tap kernel instead of the LDS-tiled GEMM */
+    STEP_OPT_ROI_BWD_GATHER,   /*  1 (default) ROIAlign backward as a fixed-order gather per feature cell (deterministic) | 0: the fp32-atomics scatter of ROIAlign_cuda.cu */
     STEP_OPT_COUNT_
 };
 STEP_API int step_set_option(int option, int value);
@@ -108,8 +109,9 @@ STEP_API int step_roi_align_tubes_forward(const void* feat, int dtype, const flo
 
 /* ROIAlign backward.    replaces _C.roi_align_backward  (csrc/ROIAlign.h:51-69,
  *                       cuda/ROIAlign_cuda.cu:201-278,326-370)
- * grad [K,C,ph,pw] / [K,ph,pw,C]  ->  grad_feat [B,C,H,W] / [B,H,W,C].  grad_feat is zeroed here
- * (ROIAlign_cuda.cu:340) and accumulated with fp32 atomics (fp32 only).
+ * grad [K,C,ph,pw] / [K,ph,pw,C]  ->  grad_feat [B,C,H,W] / [B,H,W,C] (fp32 only).  Default: every cell of grad_feat gathers
+ * its samples in a fixed order (the same products gtop * w / count as the reference's scatter; deterministic, no clear, no
+ * atomics); option roi_bwd_gather = 0: grad_feat is zeroed (ROIAlign_cuda.cu:340) and accumulated with fp32 atomics.
  */
 STEP_API int step_roi_align_backward(const float* grad, int layout, const float* rois, int K, int B, int C, int H,
                                      int W, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
@@ -262,6 +264,14 @@ STEP_API int step_conv_forward_ws(const step_conv_desc* d, const void* x, const 
 STEP_API int step_conv_wgrad(const step_conv_desc* d, const void* x, const float* dy, float* dw, int accumulate,
                              step_stream_t stream);
 
+/* The same with a caller-owned scratch buffer (step_conv_wgrad_workspace_bytes(d) bytes, 16-byte aligned, no initialisation needed):
+ * every wavefront job writes its partial tile to `ws` and a second kernel sums a tile's jobs in a FIXED order -- no atomics (a job
+ * used to end in 4096 of them), bit-reproducible run to run, and accumulate = 0 needs no clear.  ws = NULL or too small:
+ * step_conv_wgrad.  The library never allocates: the caller owns ws. */
+STEP_API size_t step_conv_wgrad_workspace_bytes(const step_conv_desc* d);
+STEP_API int step_conv_wgrad_ws(const step_conv_desc* d, const void* x, const float* dy, float* dw, int accumulate, void* ws,
+                                size_t ws_bytes, step_stream_t stream);
+
 /* The same weight gradient on the 16-bit matrix instructions (mixed-precision training): dy arrives in the activation type
  * d->dtype (STEP_BF16 / STEP_F16; STEP_F32 -> STEP_E_UNSUPPORTED), laid out as above; products in 16 bits, fp32 accumulation,
  * fp32 dw.  16x the matrix rate of step_conv_wgrad (whose fp32 instruction runs at 1/16 of the 16-bit one). */
@@ -270,7 +280,8 @@ STEP_API int step_conv_wgrad16(const step_conv_desc* d, const void* x, const voi
 
 /* Same, with a caller-owned scratch buffer: 3x3 windows (kh = kw = 3) run as an LDS-tiled GEMM whose workgroups write their
  * partial tiles to `ws` (step_conv_wgrad16_workspace_bytes(d) bytes, 16-byte aligned, no initialisation needed) and a second
- * kernel sums them in a fixed order -- no atomics, bit-reproducible.  ws = NULL, a buffer that is too small or any other window:
+ * kernel sums them in a fixed order -- no atomics, bit-reproducible; every other window / channel count runs the per-tap kernel with
+ * the partial-tile scheme of step_conv_wgrad_ws (the workspace query covers both).  ws = NULL or a buffer that is too small:
  * step_conv_wgrad16.  The library never allocates: the caller owns ws. */
 STEP_API size_t step_conv_wgrad16_workspace_bytes(const step_conv_desc* d);
 STEP_API int step_conv_wgrad16_ws(const step_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* ws,
@@ -300,6 +311,12 @@ STEP_API int step_stem_forward(int dtype, const void* x, int N, int T, int H, in
  * the affine epilogue).  The stem needs no data gradient (its input is the clip). */
 STEP_API int step_stem_wgrad(int dtype, const void* x, int N, int T, int H, int W, const float* dy, int Cout, float* dw,
                              int accumulate, step_stream_t stream);
+/* step_stem_wgrad with a caller-owned scratch (step_stem_wgrad_workspace_bytes; 16-byte aligned, no initialisation): every job
+ * writes its partial tile and one fixed-order sum writes dw -- no fp32 atomics, bit-reproducible.  ws == NULL: the atomics form;
+ * a scratch that is too short or misaligned is STEP_E_SHAPE. */
+STEP_API size_t step_stem_wgrad_workspace_bytes(int N, int T, int H, int W, int Cout);
+STEP_API int step_stem_wgrad_ws(int dtype, const void* x, int N, int T, int H, int W, const float* dy, int Cout, float* dw,
+                                int accumulate, void* ws, size_t ws_bytes, step_stream_t stream);
 /* The same gradient on the 16-bit matrix instructions (bf16 / fp16 clip; dy in the SAME 16-bit type, channels-last contiguous --
  * the activation gradient mixed-precision training back-propagates).  One workgroup per CU keeps all 49 x 21 filter columns of a
  * 32-channel block in registers and reads x and dy once; the partial tiles go through the caller-owned scratch `ws`

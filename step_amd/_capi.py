@@ -4,7 +4,7 @@ import ctypes as C
 
 F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 vp, fp, ip, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # raw device addresses
 i, f, ll, sz = C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -54,6 +54,8 @@ SIGNATURES = {
     "step_conv_group_kernel_name": (i, [C.POINTER(ConvItem), i, C.c_char_p, i]),
     "step_conv_workspace_bytes": (sz, [C.POINTER(ConvDesc)]),
     "step_conv_wgrad": (i, [C.POINTER(ConvDesc), vp, fp, fp, i, vp]),
+    "step_conv_wgrad_workspace_bytes": (sz, [C.POINTER(ConvDesc)]),
+    "step_conv_wgrad_ws": (i, [C.POINTER(ConvDesc), vp, fp, fp, i, vp, sz, vp]),
     "step_conv_wgrad16": (i, [C.POINTER(ConvDesc), vp, vp, fp, i, vp]),
     "step_conv_wgrad16_workspace_bytes": (sz, [C.POINTER(ConvDesc)]),
     "step_conv_wgrad16_ws": (i, [C.POINTER(ConvDesc), vp, vp, fp, i, vp, sz, vp]),
@@ -65,6 +67,8 @@ SIGNATURES = {
     "step_stem_forward": (i, [i, vp, i, i, i, i, vp, fp, fp, i, vp, i, i, vp]),
     "step_stem_kernel_name": (i, [i, C.c_char_p, i]),
     "step_stem_wgrad": (i, [i, vp, i, i, i, i, fp, i, fp, i, vp]),
+    "step_stem_wgrad_workspace_bytes": (sz, [i, i, i, i, i]),
+    "step_stem_wgrad_ws": (i, [i, vp, i, i, i, i, fp, i, fp, i, vp, sz, vp]),
     "step_stem_wgrad16_workspace_bytes": (sz, [i, i, i, i, i, i]),
     "step_stem_wgrad16": (i, [i, vp, i, i, i, i, vp, i, fp, i, vp, sz, vp]),
     "step_pool_out_size": (i, [i, i, i]),
@@ -107,7 +111,7 @@ def check(status, what):
 # ---- planner options (include/step_amd.h: step_set_option) -----------------------------------------------------------
 OPTION_IDS = {name: k for k, name in enumerate((
     "conv_impl", "conv_nb", "conv_waves", "conv_phased", "conv_gen", "conv_gmode", "conv_pws", "conv_splitk", "conv_tail",
-    "conv_slots", "pool_direct", "wgrad_minpix", "wgrad16_lds"))}
+    "conv_slots", "pool_direct", "wgrad_minpix", "wgrad16_lds", "roi_bwd_gather"))}
 
 
 def set_option(lib, name, value):

@@ -23,6 +23,7 @@ struct WgradParams {
     int rows;                     // (n, d, h) rows per wavefront job
     long long total_rows;         // N * D * H
     long long jobs;               // ceil(total_rows / rows)
+    float* ws;                    // partial tiles [job][blockIdx.y][MB*NB][16][64 lanes] (NULL: fp32 atomics on dw), see wgrad_reduce_kernel
 };
 
 // W16 (16-bit storage only): dY arrives in the activation type too (what mixed-precision training back-propagates) and the
@@ -112,6 +113,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
                 for (int nb = 0; nb < NB; ++nb) mma_k16(a[mb], b[nb], acc[mb][nb], typename std::conditional<W16, T, float>::type());
         }
     }
+    if (p.ws) {
+        // this job's partial tile, accumulator layout as is (a register = 256 contiguous bytes over the lanes); wgrad_reduce_kernel
+        // sums the jobs of a tile in a FIXED order: no atomics (every job used to end in 4096 of them, ~0.2 us per job at the rate the
+        // L2 sustains), bit-reproducible
+        float* out = p.ws + (((size_t)job * gridDim.y + blockIdx.y) * (MB * NB * 16)) * 64 + lane;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[((mb * NB + nb) * 16 + r) * 64] = acc[mb][nb][r];
+        return;
+    }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -121,6 +135,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
                 const int co = co0 + mb * 32 + cd_row(r, lane), ci = ci0 + nb * 32 + (lane & 31);
                 if (co < p.Cout && ci < p.Cin) atomicAdd(p.dw + ((size_t)co * p.Cin + ci) * ntaps + tap, acc[mb][nb][r]);
             }
+}
+
+// sums the partial tiles of conv_wgrad_kernel over the jobs of the pixel axis: one thread per (tile, register, lane), jobs in
+// ascending order; writes (or adds to) dw in torch's weight layout
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long jobs, int gy, int MB, int NB, int cot, int cit,
+                                    int Cout, int Cin, int ntaps, int accumulate) {
+    const int per_tile = MB * NB * 16 * 64;
+    const long long per_job = (long long)gy * per_tile;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < per_job; idx += (long long)blockDim.x * gridDim.x) {
+        float sum = 0.f;
+        for (long long j = 0; j < jobs; ++j) sum += ws[(size_t)j * per_job + idx];
+        int t = (int)(idx % per_tile);
+        int y = (int)(idx / per_tile);
+        const int lane = t & 63, r = (t >> 6) & 15, tile = t >> 10;
+        const int nb = tile % NB, mb = tile / NB;
+        const int cit_i = y % cit; y /= cit;
+        const int cot_i = y % cot;
+        const int tap = y / cot;
+        const int co = cot_i * 32 * MB + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), ci = cit_i * 32 * NB + nb * 32 + (lane & 31);
+        if (co < Cout && ci < Cin) {
+            float* o = dw + ((size_t)co * Cin + ci) * ntaps + tap;
+            *o = accumulate ? *o + sum : sum;
+        }
+    }
 }
 
 
@@ -374,6 +412,7 @@ __global__ void wgrad16_reduce_kernel(const float* __restrict__ ws, float* __res
 // (21 of 32 used): one wavefront job = one output plane (n, od) x one (kd, kh) x 64 output channels.
 struct StemWgradParams {
     const void* x; const float* dy; float* dw;
+    float* ws;                    // non-null: every job writes its partial tile here (stem_wgrad_reduce_kernel sums them in job order)
     int N, T, H, W, To, Ho, Wo, Cout, cot;
     int rows, hchunks;            // output rows per job, jobs per output plane
     long long jobs;
@@ -391,7 +430,13 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradParams p) {
     const long long plane = job / p.hchunks;
     const int n = (int)(plane / p.To), od = (int)(plane % p.To);
     const int it = 2 * od + kd_ - 2;
-    if (it < 0 || it >= p.T) return;
+    float* wst = p.ws ? p.ws + (((size_t)job * gridDim.y + blockIdx.y) * 32) * 64 + lane : nullptr;
+    if (it < 0 || it >= p.T) {
+        if (wst)                                                   // a job outside the clip still owns its (zero) partial tile
+#pragma unroll
+            for (int q = 0; q < 32; ++q) wst[q * 64] = 0.f;
+        return;
+    }
     const int co0 = cot_i * 64;
     const int kw_ = m / 3, c_ = m % 3;
     const bool nok = m < 21;
@@ -440,6 +485,13 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradParams p) {
             mma_k16(a[1], b, acc[1], float());
         }
     }
+    if (wst) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wst[(mb * 16 + r) * 64] = acc[mb][r];
+        return;
+    }
     const int nn = lane & 31;
     if (nn < 21) {
         const int kw2 = nn / 3, c2 = nn % 3;
@@ -450,6 +502,25 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradParams p) {
                 const int co = co0 + mb * 32 + cd_row(r, lane);
                 if (co < p.Cout) atomicAdd(p.dw + ((((size_t)co * 3 + c2) * 7 + kd_) * 7 + kh_) * 7 + kw2, acc[mb][r]);
             }
+    }
+}
+
+// sums the partial tiles of stem_wgrad_kernel over its jobs in job order: one thread per (filter-row tile, accumulator register, lane)
+__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long jobs, int gy, int cot, int Cout,
+                                         int accumulate) {
+    const long long per_job = (long long)gy * 32 * 64;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < per_job; idx += (long long)blockDim.x * gridDim.x) {
+        const int lane = (int)(idx % 64), q = (int)((idx / 64) % 32);
+        int t = (int)(idx / (64 * 32));
+        const int nn = lane & 31;
+        const int cot_i = t % cot; t /= cot;
+        const int kh_ = t % 7, kd_ = t / 7;
+        const int co = cot_i * 64 + (q >> 4) * 32 + cd_row(q & 15, lane);
+        if (nn >= 21 || co >= Cout) continue;
+        float sum = 0.f;
+        for (long long j = 0; j < jobs; ++j) sum += ws[(size_t)j * per_job + idx];
+        float* o = dw + ((((size_t)co * 3 + nn % 3) * 7 + kd_) * 7 + kh_) * 7 + nn / 3;
+        *o = accumulate ? *o + sum : sum;
     }
 }
 
@@ -734,6 +805,56 @@ static Wg16Plan wgrad16_plan(const step_conv_desc* d) {
     return pl;
 }
 
+// job split of the per-tap kernel (conv_wgrad_kernel): pointwise layers cut the flattened pixel axis into `chunk`-pixel jobs (+ one
+// ragged tail job), windows cut the (n, d, h) rows; gy = (tap, co tile, ci tile) workgroup rows; per_tile = floats of a job's tile
+struct WgJobs { bool pw; int chunk, tail, rows; long long full, jobs, gy; int cot, cit, nbw; size_t per_tile; };
+static WgJobs wgrad_jobs(const step_conv_desc* d) {
+    WgJobs j;
+    const int ntaps = d->kd * d->kh * d->kw;
+    const bool narrow = d->Cin <= 32;
+    j.nbw = narrow ? 1 : 2;
+    j.cot = ceil_div(d->Cout, 64); j.cit = ceil_div(d->Cin, narrow ? 32 : 64);
+    j.per_tile = (size_t)2 * j.nbw * 16 * 64;
+    j.pw = ntaps == 1;
+    j.chunk = j.tail = j.rows = 0; j.full = 0;
+    if (j.pw) {
+        // pointwise: no neighbourhood, so the pixel axis is cut into chunks ("rows" of one long plane list); ~6000 wavefront jobs per
+        // launch (see below), a multiple of the 16-pixel MFMA step
+        const long long M = (long long)d->N * d->D * d->H * d->W;
+        constexpr int wg_jobs_pw = 6144;
+        const long long tiles = (long long)j.cot * j.cit;
+        long long want = wg_jobs_pw / (tiles > 0 ? tiles : 1);
+        if (want < 1) want = 1;
+        long long ch = (ceil_div64(M, want) + 15) / 16 * 16;
+        if (ch < wgrad_min_pixels()) ch = wgrad_min_pixels();
+        if (ch > 65536) ch = 65536;
+        j.chunk = (int)ch;
+        j.full = M / j.chunk;                                   // (n, d, h) collapse into full chunks; the ragged tail is a second launch
+        j.tail = (int)(M % j.chunk);
+        j.jobs = j.full + (j.tail ? 1 : 0);
+        j.gy = tiles;
+        return j;
+    }
+    j.gy = (long long)ntaps * j.cot * j.cit;
+    // (n, d, h) rows per wavefront job.  Two opposite pressures (PMC): the kernel hides its load latency only with
+    // several wavefronts per SIMD (1.6 per SIMD -> matrix pipe 18 % busy), but every job ends in one pass over its 64x64 tile
+    // (4096 fp32 atomics, or 16 KiB of partial tile).  Aim at ~6000 wavefront jobs per launch, whatever the map size.
+    constexpr int wg_jobs = 6144;
+    const long long total_rows = (long long)d->N * d->D * d->H;
+    long long want = wg_jobs / (j.gy > 0 ? j.gy : 1);
+    if (want < 1) want = 1;
+    long long rows = ceil_div64(total_rows, want);
+    const long long rows_min = ceil_div64(wgrad_min_pixels(), d->W);      // small maps: fewer, longer jobs (see above)
+    if (rows < rows_min) rows = rows_min;
+    if (rows > total_rows) rows = total_rows;
+    if (rows < 1) rows = 1;
+    if (rows > 0x3fffffff) rows = 0x3fffffff;
+    j.rows = (int)rows;
+    j.jobs = ceil_div64(total_rows, j.rows);
+    return j;
+}
+static size_t wgrad_jobs_ws_bytes(const WgJobs& j) { return (size_t)j.jobs * (size_t)j.gy * j.per_tile * sizeof(float); }
+
 static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* dy, bool w16, float* dw, int accumulate, void* ws,
                            size_t ws_bytes, step_stream_t stream) {
     if (!d) return STEP_E_NULL;
@@ -743,14 +864,18 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
     if (d->x_coff < 0 || d->x_coff + d->Cin > d->x_cstride || d->y_coff < 0 || d->y_coff + d->Cout > d->y_cstride) return STEP_E_SHAPE;
     if (!dw) return STEP_E_NULL;
     const int ntaps = d->kd * d->kh * d->kw;
-    if (!accumulate) {
+    const bool lds_form = w16 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && wgrad16_plan(d).ok && d->N > 0;
+    const WgJobs jb = wgrad_jobs(d);
+    // the per-tap kernel with a workspace: partial tiles + a fixed-order sum write every element of dw themselves
+    const bool tap_ws = !lds_form && d->N > 0 && ws && ((uintptr_t)ws % 16) == 0 && ws_bytes >= wgrad_jobs_ws_bytes(jb) && jb.jobs > 0;
+    if (!accumulate && !tap_ws) {
         const int e = (int)hipMemsetAsync(dw, 0, (size_t)d->Cout * d->Cin * ntaps * sizeof(float), (hipStream_t)stream);
         if (e != 0) return e;
     }
     if (d->N == 0) return STEP_OK;
     if (!x || !dy) return STEP_E_NULL;
     WgradParams p;
-    p.x = x; p.dy = dy; p.dw = dw;
+    p.x = x; p.dy = dy; p.dw = dw; p.ws = tap_ws ? (float*)ws : nullptr;
     p.N = d->N; p.D = d->D; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.kd = d->kd; p.kh = d->kh; p.kw = d->kw;
     p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.dy_cstride = d->y_cstride; p.dy_coff = d->y_coff;
     // the LDS-tiled form (transpose reads): 3x3 windows or pointwise, channel counts in 16-byte vectors (wgrad16_plan)
@@ -783,21 +908,11 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
         }
     }
     if (ntaps == 1) {
-        // pointwise: no neighbourhood, so the pixel axis is cut into chunks of 1024 ("rows" of one long plane list)
         const long long M = (long long)d->N * d->D * d->H * d->W;
         if (M > 0x7fffffffLL) return STEP_E_UNSUPPORTED;
-        // pixels per wavefront job: ~6000 jobs per launch (see below), a multiple of the 16-pixel MFMA step
-        constexpr int wg_jobs_pw = 6144;
-        const long long tiles = (long long)ceil_div(d->Cout, 64) * ceil_div(d->Cin, d->Cin <= 32 ? 32 : 64);
-        long long want = wg_jobs_pw / (tiles > 0 ? tiles : 1);
-        if (want < 1) want = 1;
-        long long ch = (ceil_div64(M, want) + 15) / 16 * 16;
-        if (ch < wgrad_min_pixels()) ch = wgrad_min_pixels();
-        if (ch > 65536) ch = 65536;
-        const int chunk = (int)ch;
-        // (n, d, h) collapse into full chunks; the ragged tail is a second launch
-        const long long full = M / chunk;
-        const int tail = (int)(M % chunk);
+        const int chunk = jb.chunk;
+        const long long full = jb.full;
+        const int tail = jb.tail;
         int rc = STEP_OK;
         auto launch = [&](long long jobs, int W, size_t pix0) {
             p.N = 1; p.D = (int)jobs; p.H = 1; p.W = W; p.jobs = jobs; p.rows = 1; p.total_rows = jobs;
@@ -818,32 +933,23 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
             }
         };
         if (full) launch(full, chunk, 0);
-        if (rc == STEP_OK && tail) launch(1, tail, (size_t)full * chunk);
+        if (rc == STEP_OK && tail) {
+            if (tap_ws) p.ws = (float*)ws + (size_t)full * jb.gy * jb.per_tile;      // the tail job's tiles behind the full chunks'
+            launch(1, tail, (size_t)full * chunk);
+        }
+        if (rc == STEP_OK && tap_ws)
+            STEP_LAUNCH(wgrad_reduce_kernel, dim3(flat_grid(jb.gy * (long long)jb.per_tile, 256)), dim3(256), stream, (const float*)ws, dw, jb.jobs,
+                        (int)jb.gy, 2, jb.nbw, jb.cot, jb.cit, d->Cout, d->Cin, 1, accumulate);
         return rc != STEP_OK ? rc : STEP_LAUNCH_CHECK();
     }
     const bool narrow = d->Cin <= 32;
-    p.cot = ceil_div(d->Cout, 64); p.cit = ceil_div(d->Cin, narrow ? 32 : 64);
+    p.cot = jb.cot; p.cit = jb.cit;
     // (a tap-row form -- a job owns a row of three kw taps and re-pairs ten loaded pixels in registers -- measured 1.3-2.6x SLOWER
     // than this per-tap form: 424 VGPRs, one wave per SIMD; removed)
-    const long long gy = (long long)ntaps * p.cot * p.cit;
-    // (n, d, h) rows per wavefront job.  Two opposite pressures (PMC): the kernel hides its load latency only with
-    // several wavefronts per SIMD (1.6 per SIMD -> matrix pipe 18 % busy), but every job ends in one set of fp32
-    // atomics (a 64x64 tile = 4096 of them; the 14x14 layers spent their time in 81 M atomics with one job per
-    // plane).  Aim at ~6000 wavefront jobs per launch, whatever the map size.
-    constexpr int wg_jobs = 6144;
+    const long long gy = jb.gy;
     p.total_rows = (long long)d->N * d->D * d->H;
-    {
-        long long want = wg_jobs / (gy > 0 ? gy : 1);
-        if (want < 1) want = 1;
-        long long rows = ceil_div64(p.total_rows, want);
-        const long long rows_min = ceil_div64(wgrad_min_pixels(), d->W);      // small maps: fewer, longer jobs (see above)
-        if (rows < rows_min) rows = rows_min;
-        if (rows > p.total_rows) rows = p.total_rows;
-        if (rows < 1) rows = 1;
-        if (rows > 0x3fffffff) rows = 0x3fffffff;
-        p.rows = (int)rows;
-    }
-    p.jobs = ceil_div64(p.total_rows, p.rows);
+    p.rows = jb.rows;
+    p.jobs = jb.jobs;
     if (gy > 65535) return STEP_E_UNSUPPORTED;
     dim3 grid((unsigned)ceil_div64(p.jobs, 4), (unsigned)gy);
     switch (d->dtype) {
@@ -854,7 +960,22 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
     }
 #undef STEP_WG
 #undef STEP_WG16
+    if (tap_ws)
+        STEP_LAUNCH(wgrad_reduce_kernel, dim3(flat_grid(jb.gy * (long long)jb.per_tile, 256)), dim3(256), stream, (const float*)ws, dw, jb.jobs,
+                    (int)jb.gy, 2, jb.nbw, jb.cot, jb.cit, d->Cout, d->Cin, ntaps, accumulate);
     return STEP_LAUNCH_CHECK();
+}
+
+size_t step_conv_wgrad_workspace_bytes(const step_conv_desc* d) {
+    if (!d || d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->kd <= 0 || d->kh <= 0 || d->kw <= 0) return 0;
+    return wgrad_jobs_ws_bytes(wgrad_jobs(d));
+}
+
+int step_conv_wgrad_ws(const step_conv_desc* d, const void* x, const float* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                       step_stream_t stream) {
+    // a scratch that is given must be usable: a short or misaligned one is an error, not a silent return to atomics
+    if (ws && d && (ws_bytes < step_conv_wgrad_workspace_bytes(d) || ((uintptr_t)ws % 16) != 0)) return STEP_E_SHAPE;
+    return conv_wgrad_impl(d, x, dy, false, dw, accumulate, ws, ws_bytes, stream);
 }
 
 int step_conv_wgrad(const step_conv_desc* d, const void* x, const float* dy, float* dw, int accumulate, step_stream_t stream) {
@@ -866,8 +987,10 @@ int step_conv_wgrad16(const step_conv_desc* d, const void* x, const void* dy, fl
 }
 
 size_t step_conv_wgrad16_workspace_bytes(const step_conv_desc* d) {
+    if (!d || (d->dtype != STEP_BF16 && d->dtype != STEP_F16)) return 0;
     const Wg16Plan pl = wgrad16_plan(d);
-    return pl.ok ? (size_t)pl.gx * pl.gy * 6 * (pl.pw ? 8 : 24) * 64 * 16 : 0;
+    if (pl.ok) return (size_t)pl.gx * pl.gy * 6 * (pl.pw ? 8 : 24) * 64 * 16;
+    return step_conv_wgrad_workspace_bytes(d);                   // the per-tap 16-bit form: partial tiles of its wavefront jobs
 }
 
 int step_conv_wgrad16_ws(const step_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
@@ -876,23 +999,42 @@ int step_conv_wgrad16_ws(const step_conv_desc* d, const void* x, const void* dy,
 }
 
 
-int step_stem_wgrad(int dtype, const void* x, int N, int T, int H, int W, const float* dy, int Cout, float* dw, int accumulate,
-                    step_stream_t stream) {
+struct StemJobs { int To, Ho, Wo, cot, rows, hchunks; long long jobs; };
+static StemJobs stem_wgrad_jobs(int N, int T, int H, int W, int Cout) {
+    StemJobs j;
+    j.To = (T + 5 - 7) / 2 + 1; j.Ho = (H + 5 - 7) / 2 + 1; j.Wo = (W + 5 - 7) / 2 + 1;
+    j.cot = ceil_div(Cout, 64);
+    j.rows = 8; j.hchunks = ceil_div(j.Ho > 0 ? j.Ho : 1, j.rows);       // 8 output rows per wavefront job: enough jobs for one clip
+    j.jobs = (long long)N * (j.To > 0 ? j.To : 0) * j.hchunks;
+    return j;
+}
+
+size_t step_stem_wgrad_workspace_bytes(int N, int T, int H, int W, int Cout) {
+    if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+    const StemJobs j = stem_wgrad_jobs(N, T, H, W, Cout);
+    if (j.To <= 0 || j.Ho <= 0 || j.Wo <= 0) return 0;
+    return (size_t)j.jobs * 49 * j.cot * 32 * 64 * sizeof(float);
+}
+
+static int stem_wgrad_impl(int dtype, const void* x, int N, int T, int H, int W, const float* dy, int Cout, float* dw, int accumulate,
+                           void* ws, size_t ws_bytes, step_stream_t stream) {
     if (N < 0 || T <= 0 || H <= 0 || W <= 0 || Cout <= 0) return STEP_E_SHAPE;
     if (!dw) return STEP_E_NULL;
-    if (!accumulate) {
+    if (ws && N > 0 && (ws_bytes < step_stem_wgrad_workspace_bytes(N, T, H, W, Cout) || ((uintptr_t)ws % 16) != 0)) return STEP_E_SHAPE;
+    if (!accumulate && !(ws && N > 0)) {
         const int e = (int)hipMemsetAsync(dw, 0, (size_t)Cout * 3 * 343 * sizeof(float), (hipStream_t)stream);
         if (e != 0) return e;
     }
     if (N == 0) return STEP_OK;
     if (!x || !dy) return STEP_E_NULL;
     StemWgradParams p;
-    p.x = x; p.dy = dy; p.dw = dw; p.N = N; p.T = T; p.H = H; p.W = W;
-    p.To = (T + 5 - 7) / 2 + 1; p.Ho = (H + 5 - 7) / 2 + 1; p.Wo = (W + 5 - 7) / 2 + 1;
+    const StemJobs sj = stem_wgrad_jobs(N, T, H, W, Cout);
+    p.x = x; p.dy = dy; p.dw = dw; p.ws = (float*)ws; p.N = N; p.T = T; p.H = H; p.W = W;
+    p.To = sj.To; p.Ho = sj.Ho; p.Wo = sj.Wo;
     if (p.To <= 0 || p.Ho <= 0 || p.Wo <= 0) return STEP_E_SHAPE;
-    p.Cout = Cout; p.cot = ceil_div(Cout, 64);
-    p.rows = 8; p.hchunks = ceil_div(p.Ho, p.rows);       // 8 output rows per wavefront job: enough jobs for one clip
-    p.jobs = (long long)N * p.To * p.hchunks;
+    p.Cout = Cout; p.cot = sj.cot;
+    p.rows = sj.rows; p.hchunks = sj.hchunks;
+    p.jobs = sj.jobs;
     dim3 grid((unsigned)ceil_div64(p.jobs, 4), (unsigned)(49 * p.cot));
     switch (dtype) {
         case STEP_F32: STEP_LAUNCH((stem_wgrad_kernel<float>), grid, dim3(256), stream, p); break;
@@ -900,7 +1042,20 @@ int step_stem_wgrad(int dtype, const void* x, int N, int T, int H, int W, const 
         case STEP_F16: STEP_LAUNCH((stem_wgrad_kernel<f16_t>), grid, dim3(256), stream, p); break;
         default: return STEP_E_DTYPE;
     }
+    if (ws)
+        STEP_LAUNCH(stem_wgrad_reduce_kernel, dim3(flat_grid((long long)49 * p.cot * 32 * 64, 256)), dim3(256), stream, (const float*)ws, dw,
+                    p.jobs, 49 * p.cot, p.cot, Cout, accumulate);
     return STEP_LAUNCH_CHECK();
+}
+
+int step_stem_wgrad(int dtype, const void* x, int N, int T, int H, int W, const float* dy, int Cout, float* dw, int accumulate,
+                    step_stream_t stream) {
+    return stem_wgrad_impl(dtype, x, N, T, H, W, dy, Cout, dw, accumulate, nullptr, 0, stream);
+}
+
+int step_stem_wgrad_ws(int dtype, const void* x, int N, int T, int H, int W, const float* dy, int Cout, float* dw, int accumulate,
+                       void* ws, size_t ws_bytes, step_stream_t stream) {
+    return stem_wgrad_impl(dtype, x, N, T, H, W, dy, Cout, dw, accumulate, ws, ws_bytes, stream);
 }
 
 

@@ -17,6 +17,7 @@
 // Arithmetic follows the reference operation for operation (no FMA contraction in this file),
 // so fp32 results are bit-identical to cpu/ROIAlign_cpu.cpp.
 #include "common.h"
+#include "options.h"
 
 #pragma clang fp contract(off)
 
@@ -251,6 +252,83 @@ __global__ void roi_align_bwd_nchw_kernel(const float* __restrict__ grad, const 
     }
 }
 
+// ROIAlign backward as a GATHER: one output pixel (frame b, row Y, column X) sums, in a fixed order (rois ascending, then bin row,
+// sample row, bin column, sample column), every sample whose bilinear footprint touches it -- the same products gtop * w / count as
+// the scatter form above, no atomics, so the gradient is bit-reproducible run to run.  The footprint is separable: a sample row y
+// touches pixel row Y with weight hy (y_low == Y) and / or ly (y_high == Y) of bilinear_tap; likewise for columns.
+__device__ __forceinline__ float axis_weight(int size, float v, int P) {
+    if (v < -1.0f || v > (float)size) return 0.f;          // void sample (bilinear_tap's first test, per axis)
+    if (v <= 0) v = 0;
+    int lo = (int)v, hi;
+    if (lo >= size - 1) { hi = lo = size - 1; v = (float)lo; } else { hi = lo + 1; }
+    const float l = v - (float)lo, h = 1.f - l;
+    return (lo == P ? h : 0.f) + (hi == P && hi != lo ? l : 0.f);
+}
+
+template <int V>
+__global__ void roi_align_bwd_gather_nhwc_kernel(const float* __restrict__ grad, const float* __restrict__ rois, int K, int C, int H, int W,
+                                                 int ph, int pw, float scale, int sampling_ratio, float* __restrict__ gfeat) {
+    const int pix = blockIdx.x;
+    const int X = pix % W, Y = (pix / W) % H, b = pix / (W * H);
+    for (int c = threadIdx.x * V; c < C; c += blockDim.x * V) {
+        float acc[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] = 0.f;
+        for (int n = 0; n < K; ++n) {
+            if ((int)rois[5 * n] != b) continue;
+            const RoiGeom g = roi_geom(rois + 5 * n, scale, ph, pw, sampling_ratio);
+            // samples lie inside [start, start + max(extent, 1)]; a pixel more than one cell away on either axis gets nothing
+            if (g.start_h > (float)(Y + 1) || g.start_h + g.bin_h * (float)ph < (float)(Y - 1) ||
+                g.start_w > (float)(X + 1) || g.start_w + g.bin_w * (float)pw < (float)(X - 1)) continue;
+            for (int p = 0; p < ph; ++p)
+                for (int iy = 0; iy < g.grid_h; ++iy) {
+                    const float wy = axis_weight(H, sample_y(g, p, iy), Y);
+                    if (wy == 0.f) continue;
+                    // (a sample whose OTHER coordinate is void contributes nothing: its column weight below is 0)
+                    for (int q = 0; q < pw; ++q)
+                        for (int ix = 0; ix < g.grid_w; ++ix) {
+                            const float wx = axis_weight(W, sample_x(g, q, ix), X);
+                            if (wx == 0.f) continue;
+                            float gt[V];
+                            VecIO<float, V>::load(grad + ((size_t)(n * ph + p) * pw + q) * C + c, gt);
+                            const float w = wy * wx;
+#pragma unroll
+                            for (int i = 0; i < V; ++i) acc[i] += gt[i] * w / g.count;
+                        }
+                }
+        }
+        VecIO<float, V>::store(gfeat + (size_t)pix * C + c, acc);
+    }
+}
+
+__global__ void roi_align_bwd_gather_nchw_kernel(const float* __restrict__ grad, const float* __restrict__ rois, int K, long long total, int C,
+                                                 int H, int W, int ph, int pw, float scale, int sampling_ratio, float* __restrict__ gfeat) {
+    for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total; index += (long long)blockDim.x * gridDim.x) {
+        const int X = (int)(index % W), Y = (int)((index / W) % H);
+        const int c = (int)((index / W / H) % C), b = (int)(index / W / H / C);
+        float acc = 0.f;
+        for (int n = 0; n < K; ++n) {
+            if ((int)rois[5 * n] != b) continue;
+            const RoiGeom g = roi_geom(rois + 5 * n, scale, ph, pw, sampling_ratio);
+            if (g.start_h > (float)(Y + 1) || g.start_h + g.bin_h * (float)ph < (float)(Y - 1) ||
+                g.start_w > (float)(X + 1) || g.start_w + g.bin_w * (float)pw < (float)(X - 1)) continue;
+            const float* gr = grad + ((size_t)n * C + c) * ph * pw;
+            for (int p = 0; p < ph; ++p)
+                for (int iy = 0; iy < g.grid_h; ++iy) {
+                    const float wy = axis_weight(H, sample_y(g, p, iy), Y);
+                    if (wy == 0.f) continue;
+                    for (int q = 0; q < pw; ++q)
+                        for (int ix = 0; ix < g.grid_w; ++ix) {
+                            const float wx = axis_weight(W, sample_x(g, q, ix), X);
+                            if (wx == 0.f) continue;
+                            acc += gr[p * pw + q] * (wy * wx) / g.count;
+                        }
+                }
+        }
+        gfeat[index] = acc;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // ROIPool.  ROIPool_cuda.cu:40-132.
 struct PoolBin { int batch, hstart, hend, wstart, wend; };
@@ -433,6 +511,23 @@ int step_roi_align_backward(const float* grad, int layout, const float* rois, in
     if (layout != STEP_NCHW && layout != STEP_NHWC) return STEP_E_UNSUPPORTED;
     if (B == 0) return STEP_OK;
     if (!gfeat) return STEP_E_NULL;
+    if (K > 0 && opt(STEP_OPT_ROI_BWD_GATHER)) {
+        // the deterministic form: every element of grad_feat is written by its own gather (no clear, no atomics)
+        if (!grad || !rois) return STEP_E_NULL;
+        if (layout == STEP_NHWC) {
+            const bool v4 = (C % 4) == 0 && ((uintptr_t)grad % 16) == 0 && ((uintptr_t)gfeat % 16) == 0;
+            const int threads = v4 ? lanes_for(C / 4) : lanes_for(C);
+            if (v4) STEP_LAUNCH((roi_align_bwd_gather_nhwc_kernel<4>), dim3((unsigned)(B * H * W)), dim3(threads), stream, grad, rois, K, C, H, W, ph, pw,
+                                scale, sr, gfeat);
+            else STEP_LAUNCH((roi_align_bwd_gather_nhwc_kernel<1>), dim3((unsigned)(B * H * W)), dim3(threads), stream, grad, rois, K, C, H, W, ph, pw,
+                             scale, sr, gfeat);
+        } else {
+            const long long total = (long long)B * C * H * W;
+            STEP_LAUNCH((roi_align_bwd_gather_nchw_kernel), dim3(flat_grid(total, 256)), dim3(256), stream, grad, rois, K, total, C, H, W, ph, pw,
+                        scale, sr, gfeat);
+        }
+        return STEP_LAUNCH_CHECK();
+    }
     int rc = (int)hipMemsetAsync(gfeat, 0, sizeof(float) * (size_t)B * C * H * W, (hipStream_t)stream);
     if (rc) return rc;
     if (K == 0) return STEP_OK;

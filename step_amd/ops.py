@@ -21,6 +21,7 @@ DT = {torch.float32: _capi.F32, torch.bfloat16: _capi.BF16, torch.float16: _capi
 #     replays: in its real place of the replayed sequence, at replay clocks, its inputs wherever the previous kernel left them.
 PROFILE = None
 PROFILE_LIMIT = None
+WGRAD_WS = True        # fp32 weight gradients: partial-tile workspace + fixed-order sum instead of fp32 atomics (bit-reproducible; module switch for tests / A-B timing)
 WGRAD16_WS = True      # 16-bit weight gradients: partial-tile workspace + fixed-order sum instead of fp32 atomics (module switch for tests / A-B timing)
 class _Prof:
     __slots__ = ("name", "flops", "bytes", "e0")
@@ -240,9 +241,11 @@ def conv_wgrad(x, gy, Cout, k, into=None):
         prof = _Prof("void step::conv_wgrad_kernel<%s, 2, %d, false>(step::WgradParams)" % (_TNAME[x.dtype], 1 if Cin <= 32 else 2),
                      2.0 * pix * Cout * Cin * k[0] * k[1] * k[2],
                      pix * (Cin * x.element_size() + Cout * 4) + 4.0 * Cout * Cin * k[0] * k[1] * k[2])
+    wsb = L.step_conv_wgrad_workspace_bytes(ctypes.byref(d)) if WGRAD_WS else 0     # partial tiles + fixed-order sum: no atomics, deterministic
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
     with prof:
-        _capi.check(L.step_conv_wgrad(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(dw), int(into is not None),
-                                      _lib.stream_ptr(x.device)), "step_conv_wgrad")
+        _capi.check(L.step_conv_wgrad_ws(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), _lib.dptr(dw), int(into is not None),
+                                         _lib.dptr(ws), wsb, _lib.stream_ptr(x.device)), "step_conv_wgrad_ws")
     return dw
 
 
@@ -333,8 +336,10 @@ def stem_wgrad(x, gy, Cout):
     N, T, C, H, W = x.shape
     gy = gy.float().contiguous()
     dw = torch.empty((Cout, 3, 7, 7, 7), dtype=torch.float32, device=x.device)
-    _capi.check(L.step_stem_wgrad(_dt(x), _lib.dptr(x), N, T, H, W, _lib.dptr(gy), Cout, _lib.dptr(dw), 0, _lib.stream_ptr(x.device)),
-                "step_stem_wgrad")
+    wsb = L.step_stem_wgrad_workspace_bytes(N, T, H, W, Cout) if WGRAD_WS else 0
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
+    _capi.check(L.step_stem_wgrad_ws(_dt(x), _lib.dptr(x), N, T, H, W, _lib.dptr(gy), Cout, _lib.dptr(dw), 0, _lib.dptr(ws), wsb,
+                                     _lib.stream_ptr(x.device)), "step_stem_wgrad_ws")
     return dw
 
 

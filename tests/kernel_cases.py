@@ -191,20 +191,37 @@ def case_roi_align_forward_16bit(bk, golden):
 
 
 def case_roi_align_backward(bk, golden):
+    """step_roi_align_backward against the oracle's restatement of ROIAlign_cpu.cpp's backward: the default fixed-order gather
+    (bit-reproducible, every cell written -- frames without a roi come back zero) and the reference's atomics scatter (option
+    roi_bwd_gather = 0); rois that hang over every border, a degenerate one, adaptive and fixed sampling, vector and scalar
+    channel counts."""
     rs = np.random.RandomState(2)
-    B, C, H, W = 2, 8, 9, 12
-    rois = np.array([[0, 0, 0, 190, 140], [1, 33.3, 20.1, 120.7, 100.2], [1, -20, 100, 90, 250], [0, 50, 50, 50.5, 50.5]], np.float32)
-    K = rois.shape[0]
-    for layout in (NCHW, NHWC):
-        for sr in (0, 2):
-            g = rs.randn(K, C, 7, 7).astype(np.float32)
-            ref = oracle.roi_align_backward(g, rois, (7, 7), 1 / 16., sr, (B, C, H, W))
-            gi = bk.dev(np.full((B, C, H, W) if layout == NCHW else (B, H, W, C), 7.0, np.float32))   # op must zero it
-            gg, r = bk.dev(g if layout == NCHW else nhwc(g)), bk.dev(rois)
-            rc = bk.lib.step_roi_align_backward(gg.ptr, layout, r.ptr, K, B, C, H, W, 7, 7, 1 / 16., sr, gi.ptr, bk.stream)
-            assert rc == 0
-            got = gi.get() if layout == NCHW else nchw(gi.get())
-            assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())   # atomics: order differs
+    few = np.array([[0, 0, 0, 190, 140], [1, 33.3, 20.1, 120.7, 100.2], [1, -20, 100, 90, 250], [0, 50, 50, 50.5, 50.5]], np.float32)
+    many = np.concatenate([rs.randint(0, 2, (40, 1)).astype(np.float32), rs.uniform(-30, 150, (40, 2)).astype(np.float32),
+                           rs.uniform(60, 260, (40, 2)).astype(np.float32)], 1)
+    many[::7, 3:] = many[::7, 1:3] - 5.0                      # malformed (x2 < x1): forced to 1 x 1
+    for gather in (1, 0):
+        with _capi.options(bk.lib, roi_bwd_gather=gather):
+            for rois, B, C, H, W in ((few, 2, 8, 9, 12), (many, 3, 8, 9, 12), (many, 2, 5, 11, 7)):
+                K = rois.shape[0]
+                for layout in (NCHW, NHWC):
+                    for sr in (0, 2):
+                        g = rs.randn(K, C, 7, 7).astype(np.float32)
+                        ref = oracle.roi_align_backward(g, rois, (7, 7), 1 / 16., sr, (B, C, H, W))
+                        gg, r = bk.dev(g if layout == NCHW else nhwc(g)), bk.dev(rois)
+                        outs = []
+                        for _ in range(2):
+                            gi = bk.dev(np.full((B, C, H, W) if layout == NCHW else (B, H, W, C), 7.0, np.float32))   # the op owns every cell
+                            rc = bk.lib.step_roi_align_backward(gg.ptr, layout, r.ptr, K, B, C, H, W, 7, 7, 1 / 16., sr, gi.ptr, bk.stream)
+                            assert rc == 0
+                            outs.append(gi.get() if layout == NCHW else nchw(gi.get()))
+                        assert np.abs(outs[0] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (gather, layout, sr, B, C)   # summation order differs
+                        if B == 3:
+                            assert not outs[0][2].any()
+                        if gather:
+                            assert np.array_equal(outs[0], outs[1])
+    gi = bk.dev(np.full((2, 9, 12, 8), 7.0, np.float32))
+    assert bk.lib.step_roi_align_backward(None, NHWC, None, 0, 2, 8, 9, 12, 7, 7, 1 / 16., 2, gi.ptr, bk.stream) == 0 and not gi.get().any()
 
 
 def case_roi_pool_forward_backward(bk, golden):
@@ -957,6 +974,23 @@ def case_conv_wgrad(bk, golden):
                     assert bk.lib.step_conv_wgrad(ctypes.byref(d), xd.ptr, gd.ptr, dw.ptr, 1, bk.stream) == 0    # accumulate
                     err2 = np.abs(dw.get() - 2 * ref).max() / np.abs(ref).max()
                     assert err2 < 4e-5, err2
+                    # the workspace form: every job writes its partial tile, one fixed-order sum -- no atomics, so two runs
+                    # are bit-identical; the scratch needs no initialisation (poisoned here)
+                    nb = bk.lib.step_conv_wgrad_workspace_bytes(ctypes.byref(d))
+                    assert nb > 0 and nb % 16 == 0, (k, nb)
+                    outs = []
+                    for _ in range(2):
+                        ws = bk.dev(np.full(nb // 4, np.nan, np.float32))
+                        dw2 = bk.dev(np.full((Cout, Cin) + k, 7.0, np.float32))
+                        assert bk.lib.step_conv_wgrad_ws(ctypes.byref(d), xd.ptr, gd.ptr, dw2.ptr, 0, ws.ptr, nb, bk.stream) == 0
+                        outs.append(dw2.get())
+                    assert np.abs(outs[0] - ref).max() / np.abs(ref).max() < 2e-5, (N, Cin, Cout, k, dt, minpix)
+                    assert np.array_equal(outs[0], outs[1])
+                    assert bk.lib.step_conv_wgrad_ws(ctypes.byref(d), xd.ptr, gd.ptr, dw2.ptr, 1, ws.ptr, nb, bk.stream) == 0
+                    assert np.abs(dw2.get() - 2 * ref).max() / np.abs(ref).max() < 4e-5
+                    assert bk.lib.step_conv_wgrad_ws(ctypes.byref(d), xd.ptr, gd.ptr, dw2.ptr, 0, ws.ptr, nb - 16, bk.stream) < 0   # short scratch refused
+                    assert bk.lib.step_conv_wgrad_ws(ctypes.byref(d), xd.ptr, gd.ptr, dw2.ptr, 0, None, 0, bk.stream) == 0          # none: the atomics form
+                    assert np.abs(dw2.get() - ref).max() / np.abs(ref).max() < 2e-5
     finally:
         _capi.set_option(bk.lib, "wgrad_minpix", 0)
 
@@ -1043,6 +1077,21 @@ def case_stem_wgrad(bk, golden):
         assert bk.lib.step_stem_wgrad(dt, xd.ptr, N, T, H, W, gd.ptr, Cout, dw.ptr, 0, bk.stream) == 0
         err = np.abs(dw.get() - ref).max() / np.abs(ref).max()
         assert err < 2e-5, (dt, err)
+        # the workspace form: partial tiles + fixed-order sum (no atomics): same values, run-to-run bit identity, accumulate
+        nb = bk.lib.step_stem_wgrad_workspace_bytes(N, T, H, W, Cout)
+        assert nb > 0 and nb % 16 == 0
+        outs = []
+        for _ in range(2):
+            ws = bk.dev(np.full(nb // 4, np.nan, np.float32))
+            dw2 = bk.dev(np.full((Cout, 3, 7, 7, 7), -3.0, np.float32))
+            assert bk.lib.step_stem_wgrad_ws(dt, xd.ptr, N, T, H, W, gd.ptr, Cout, dw2.ptr, 0, ws.ptr, nb, bk.stream) == 0
+            outs.append(dw2.get())
+        assert np.abs(outs[0] - ref).max() / np.abs(ref).max() < 2e-5
+        assert np.array_equal(outs[0], outs[1])
+        assert bk.lib.step_stem_wgrad_ws(dt, xd.ptr, N, T, H, W, gd.ptr, Cout, dw2.ptr, 1, ws.ptr, nb, bk.stream) == 0
+        assert np.abs(dw2.get() - 2 * ref).max() / np.abs(ref).max() < 4e-5
+        assert bk.lib.step_stem_wgrad_ws(dt, xd.ptr, N, T, H, W, gd.ptr, Cout, dw2.ptr, 0, ws.ptr, nb - 16, bk.stream) < 0
+    assert bk.lib.step_stem_wgrad_workspace_bytes(0, T, H, W, Cout) == 0
 
 
 def case_stem_wgrad16(bk, golden):

@@ -41,9 +41,8 @@ def _worker(rank, world, port, q):
         dev = torch.device("cuda:0")
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     w = workloads.C4TrainStep(dev, batch=1, seed=123 + rank)
-    # run-to-run noise floor of ONE rank's gradient: the weight gradients meet in fp32 atomics, whose order changes from
-    # launch to launch (include/step_amd.h: "deterministic up to fp32 summation order"); two passes over the same clip
-    # with the same weights differ by that and nothing else
+    # run-to-run noise of ONE rank's gradient: none -- weight gradients, the stem's and ROIAlign's backward all sum in a fixed
+    # order (workspace + ordered sum / gather forms), so two passes over the same clip with the same weights agree bit for bit
     w.forward_backward()
     local1, lnorms1 = _probe(w.opt.flat_grad, w.opt._entries)
     w.opt.zero_grad()
@@ -102,14 +101,13 @@ def test_two_rank_gradient_equals_single_process_on_the_concatenated_batch():
     sample, norms, loss2, factor, p0, sample_b, norms_b, during, nb, scale_b, noise, noise_t, worst = main
     assert factor == 0.5 and scale_b == 0.5
     assert nb >= 5 and during >= nb - 2, (during, nb)            # 178 MB arena in 32 MiB buckets; all but the front ones left during backward
-    # overlapped == single-shot up to the atomics' summation order (measured on MI355X: 1.6e-4 in relative L2 between
-    # two passes; `noise` is that floor measured on this very run).  A bucket that left before one of its weight
-    # gradients landed would be off by O(1) in that tensor's norm, so the per-tensor check is the one that guards the
-    # stream ordering.
+    # the gradient is bit-reproducible (noise == 0), so overlapped == single-shot EXACTLY: the same local gradients, the same
+    # two-rank sums (a + b commutes).  A bucket that left before one of its weight gradients landed would be off by O(1) in
+    # that tensor's norm.
     eb = np.linalg.norm(sample_b - sample) / np.linalg.norm(sample)
     et = float((np.abs(norms_b - norms) / np.maximum(norms, 1e-6 * norms.max())).max())
-    assert noise < 1e-3 and noise_t < 2e-3, (noise, noise_t)
-    assert eb < max(5e-4, 5 * noise) and et < max(2e-3, 5 * noise_t), (eb, et, noise, noise_t, worst)
+    assert noise == 0.0 and noise_t == 0.0, (noise, noise_t)
+    assert eb == 0.0 and et == 0.0, (eb, et, worst)
     assert np.array_equal(p0, other[1])                          # replicas start from the same (broadcast) weights
     dev = torch.device("cuda:0")
     w = workloads.C4TrainStep(dev, batch=2, seed=123)
@@ -117,10 +115,15 @@ def test_two_rank_gradient_equals_single_process_on_the_concatenated_batch():
     loss1 = float(w.forward_backward())
     ref_sample, ref_norms = _probe(w.opt.flat_grad, w.opt._entries)
     assert abs(loss1 - loss2) < 1e-4 * abs(loss1), (loss1, loss2)
-    # fp32 atomics and batch-dependent tilings reorder sums; a pre-activation within ~1e-7 of zero may flip its ReLU
+    # batch-dependent tilings and job splits reorder fp32 sums (the two-clip batch is one launch, the ranks' clips are two);
+    # a pre-activation within ~1e-7 of zero may flip its ReLU
     e = np.linalg.norm(sample - ref_sample) / np.linalg.norm(ref_sample)
     en = np.abs(norms - ref_norms).max() / ref_norms.max()
-    assert e < 1e-2 and en < 1e-2, (e, en)
+    import json, os
+    d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ""), "gpurun_out")
+    if os.environ.get("GRAFT_REPO_ROOT") and os.path.isdir(d):
+        json.dump({"e": float(e), "en": float(en), "loss1": loss1, "loss2": loss2}, open(os.path.join(d, "ddp_vs_single.json"), "w"))
+    assert e < 1e-4 and en < 1e-5, (e, en)
 
 
 @pytest.mark.timeout(900)

@@ -1,6 +1,6 @@
 """The whole C4 training step captured in one HIP graph (step_amd.workloads.C4TrainStep.capture) against the same steps launched
-eagerly: same parameter trajectory (up to the fp32 summation order of the weight-gradient atomics), the device-side Adam step
-counter advances on every replay, the loss tensor is refreshed in place."""
+eagerly: the same parameter trajectory VALUE FOR VALUE (every gradient sums in a fixed order, so the replayed kernels reproduce
+the eager ones), the device-side Adam step counter advances on every replay, the loss tensor is refreshed in place."""
 import numpy as np
 import pytest
 import torch
@@ -37,11 +37,15 @@ def test_captured_training_step_follows_the_eager_steps(dtype):
         torch.cuda.empty_cache()
     (da, la, ma), (db, lb, mb) = runs["eager"], runs["graph"]
     assert np.isfinite(db).all() and np.abs(db).max() > 0
-    # Adam normalises every gradient: a parameter whose gradient is at the noise floor can move either way, so compare the
-    # update DIRECTION over the whole arena and the first moment (linear in the gradients)
-    cos = float((da * db).sum() / (np.linalg.norm(da) * np.linalg.norm(db)))
+    # same kernels, same inputs, fixed summation orders: the trajectories agree value for value (1e-5 leaves room for a library
+    # GEMM of the heads choosing another algorithm under capture; measured: bit-identical)
+    rel = float(np.linalg.norm(da - db) / np.linalg.norm(da))
     em = float(np.linalg.norm(ma - mb) / np.linalg.norm(ma))
-    tol_l = 2e-2 if dtype == torch.bfloat16 else 1e-3
-    assert cos > 0.995 and em < 2e-2, (cos, em)
-    assert np.all(np.abs(la - lb) <= tol_l * np.abs(la)), (la, lb)
+    import json, os
+    d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ""), "gpurun_out")
+    if os.environ.get("GRAFT_REPO_ROOT") and os.path.isdir(d):
+        json.dump({"rel": rel, "em": em, "identical": bool(np.array_equal(da, db)), "losses": [la.tolist(), lb.tolist()]},
+                  open(os.path.join(d, "graph_vs_eager_%s.json" % str(dtype).split(".")[-1]), "w"))
+    assert rel < 1e-5 and em < 1e-5, (rel, em)
+    assert np.all(np.abs(la - lb) <= 1e-6 * np.abs(la)), (la, lb)
     assert len(set(np.round(lb, 10))) > 1                       # the replays really advance the weights
