@@ -14,11 +14,13 @@
 #include "hipemu.h"
 #define STEP_WAVES_PER_SIMD(n)
 #define STEP_WAVES_PER_SIMD_MIN(n)
+#define STEP_SCHED_BARRIER()
 #else
 #include <hip/hip_runtime.h>
 // register budget: make the compiler fit n wavefronts per SIMD (512 / n VGPRs each)
 #define STEP_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #define STEP_WAVES_PER_SIMD_MIN(n) __attribute__((amdgpu_waves_per_eu(n)))
+#define STEP_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)      // nothing is scheduled across this point
 #endif
 
 #include "../../include/step_amd.h"

@@ -20,6 +20,9 @@ struct StemParams {
     int N, T, H, W, To, Ho, Wo, Cout, y_cstride, y_coff;
     int tiles_h, tiles_w, nblk32;
     int tile0;                 // stem_stream_kernel: first pixel tile of this launch (the layer may be launched in two parts)
+#ifdef STEP_PROBE
+    unsigned long long* probe;   // tools/timeline_probe.py build only (conv_common.h: probe_mark)
+#endif
 };
 
 template <typename T, int NB>
@@ -180,7 +183,10 @@ __device__ __forceinline__ u16x8 lds_read_frag_a4(const unsigned char* p) {
     return r;
 }
 
-template <typename T, int NB_ = 2>
+// VEC: W % 4 == 0 (whole 4-column quads, 8-byte loads).  A compile-time switch on purpose: with both staging paths inside one loop
+// the compiler's wait counts must hold for the element-wise path too (nothing in flight behind it), so every wait for a weight
+// tile became vmcnt(0) and drained the frame loads issued behind it.
+template <typename T, int NB_ = 2, bool VEC = true>
 __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel(StemParams p) {
     static_assert(sizeof(T) == 2, "16-bit storage types only");
     constexpr int FRAME = STS_FRAME, PITCH = STS_PITCH;
@@ -188,7 +194,12 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
     constexpr int NBREG = 4 * FRAGB;                // one n-block's share of a weight buffer (up to 4 K-steps)
     constexpr int BBUF = NB * NBREG;                // 8 KiB
     constexpr int ITEMS = STP_ROWS * (STP_COLS / 4);   // 4-pixel items per frame
-    constexpr int FQ = (ITEMS + 255) / 256;
+    // Staging is split by wave: waves 0-1 move the weight tiles, waves 2-3 the frames.  A wave's memory counter retires in order, so
+    // with every wave doing both a wait for a weight tile (one per four K-steps) also waited for the frame requested just before it
+    // -- the frame loads, which go to HBM, never had more than 8 K-steps to land whatever the source distance (measured: a second
+    // register set, two frames ahead, changed nothing).  Separate waves have separate counters: the frame waves wait once per frame.
+    constexpr int SL = 128;                         // lanes per staging role
+    constexpr int FQ = (ITEMS + SL - 1) / SL;       // 3 items per frame lane
     constexpr int NTILES = 21;                      // weight tiles: 3 per frame
     typedef u16x8 frag_t;
 
@@ -205,9 +216,13 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
     const int khalf = lane >> 5;
+    const bool isW = wave < 2;                      // wave-uniform staging role
+    const int stid = tid & (SL - 1);
 
     // XCD-aware launch order (see grid_coords in conv_common.h): tiles that are neighbours in (w, h, frame) order --
     // they share input halos and frames -- are consecutive on ONE XCD instead of round-robin over the eight L2s
+    STEP_PROBE_IDS(p);
+    STEP_PROBE_MARK(p, 0);
     int t = blockIdx.x;
     if ((gridDim.x & 7) == 0) t = (t & 7) * (gridDim.x >> 3) + (t >> 3);
     t += p.tile0;
@@ -220,7 +235,7 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
 
     const T* xg = (const T*)p.x;
     const unsigned char* wg = (const unsigned char*)p.w;
-    const bool vec_ok = (p.W % 4) == 0;
+    constexpr bool vec_ok = VEC;
 
     // ---- frame staging: LDS col cl <-> input col 2*ow0 - 4 + cl, row r <-> input row 2*oh0 - 2 + r
     struct Item { u16x4 c[3]; };
@@ -230,7 +245,7 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
     int qoff[FQ];
 #pragma unroll
     for (int q = 0; q < FQ; ++q) {
-        const int item = tid + q * 256;
+        const int item = stid + q * SL;
         const int cq = item % (STP_COLS / 4), r = item / (STP_COLS / 4);
         const int ih = 2 * oh0 - 2 + r, iw0 = 2 * ow0 - 4 + cq * 4;
         qoff[q] = (item < ITEMS && ih >= 0 && ih < p.H && iw0 >= 0 && iw0 + 3 < p.W) ? ih * p.W + iw0 : -1;
@@ -240,23 +255,20 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
         const int ifr = 2 * od - 2 + f;
         const bool frok = ifr >= 0 && ifr < p.T;                 // workgroup-uniform
         const unsigned short* fbase = (const unsigned short*)xg + ((size_t)n * p.T + (frok ? ifr : 0)) * 3 * plane_elems;
-        if (vec_ok) {
+        if constexpr (vec_ok) {
+            // raw loads from a clamped (always valid) address; the out-of-image quads are zeroed in store_frame, where the data
+            // is needed anyway -- a select on the loaded value HERE made the compiler wait for the loads (vmcnt(0)) before the
+            // frame's first MFMA: 2.6 us of exposed latency per frame (tools/timeline_probe.py --stem, round 3)
 #pragma unroll
             for (int q = 0; q < FQ; ++q) {
-                const bool ok = frok && qoff[q] >= 0;
-                const unsigned short* src = fbase + (ok ? qoff[q] : 0);
+                const unsigned short* src = fbase + (qoff[q] >= 0 ? qoff[q] : 0);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const u16x4 v = *(const u16x4*)(src + c * plane_elems);
-                    const u16x4 z = {0, 0, 0, 0};
-                    it[q].c[c] = ok ? v : z;
-                }
+                for (int c = 0; c < 3; ++c) it[q].c[c] = *(const u16x4*)(src + c * plane_elems);
             }
-            return;
-        }
+        } else {
 #pragma unroll
         for (int q = 0; q < FQ; ++q) {                           // W % 4 != 0: element-wise with bounds checks
-            const int item = tid + q * 256;
+            const int item = stid + q * SL;
             const int cq = item % (STP_COLS / 4), r = item / (STP_COLS / 4);
             const int ih = 2 * oh0 - 2 + r, iw0 = 2 * ow0 - 4 + cq * 4;
             const bool rowok = item < ITEMS && frok && ih >= 0 && ih < p.H;
@@ -272,17 +284,23 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
                 it[q].c[c] = v;
             }
         }
+        }
     };
-    auto store_frame = [&](int slotoff, const Item (&it)[FQ]) {
+    auto store_frame = [&](int slotoff, int f, const Item (&it)[FQ]) {
+        const int ifr = 2 * od - 2 + f;
+        const bool frok = ifr >= 0 && ifr < p.T;                 // workgroup-uniform
 #pragma unroll
         for (int q = 0; q < FQ; ++q) {
-            const int item = tid + q * 256;
+            const int item = stid + q * SL;
             if (item < ITEMS) {
                 const int cq = item % (STP_COLS / 4), r = item / (STP_COLS / 4);
                 unsigned char* dst = ldsA + slotoff + r * PITCH + cq * 24;
-                const u16x4 v0 = {it[q].c[0][0], it[q].c[1][0], it[q].c[2][0], it[q].c[0][1]};
-                const u16x4 v1 = {it[q].c[1][1], it[q].c[2][1], it[q].c[0][2], it[q].c[1][2]};
-                const u16x4 v2 = {it[q].c[2][2], it[q].c[0][3], it[q].c[1][3], it[q].c[2][3]};
+                const unsigned short keep = (!vec_ok || (frok && qoff[q] >= 0)) ? 0xffffu : 0u;    // (the element-wise path zeroed on load)
+                u16x4 v0 = {it[q].c[0][0], it[q].c[1][0], it[q].c[2][0], it[q].c[0][1]};
+                u16x4 v1 = {it[q].c[1][1], it[q].c[2][1], it[q].c[0][2], it[q].c[1][2]};
+                u16x4 v2 = {it[q].c[2][2], it[q].c[0][3], it[q].c[1][3], it[q].c[2][3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v0[e] &= keep; v1[e] &= keep; v2[e] &= keep; }
                 *(u16x4*)dst = v0;
                 *(u16x4*)(dst + 8) = v1;
                 *(u16x4*)(dst + 16) = v2;
@@ -290,24 +308,28 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
         }
     };
 
-    // ---- weights: thread tid moves one 16-byte vector per n-block of a tile (K-steps kstep0 .. kstep0+3;
+    // ---- weights: a weight lane moves two 16-byte vectors per n-block of a tile (K-steps kstep0 .. kstep0+3;
     //      the 3-K-step tiles carry one K-step of the next tile along, never read)
     const unsigned char* wthr[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-        wthr[i] = wg + ((size_t)min(nb0 + i, p.nblk32 - 1) * STS_KSTEPS) * FRAGB + tid * 16;
-    struct BReg { u32x4 v[NB]; };
+        wthr[i] = wg + ((size_t)min(nb0 + i, p.nblk32 - 1) * STS_KSTEPS) * FRAGB + stid * 16;
+    struct BReg { u32x4 v[NB][2]; };
     auto load_B = [&](int tile) {
         tile = min(tile, NTILES - 1);
         const int ks0 = (tile / 3) * 11 + (tile % 3) * 4;
         BReg r;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) r.v[i] = *(const u32x4*)(wthr[i] + (size_t)ks0 * FRAGB);
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) r.v[i][j] = *(const u32x4*)(wthr[i] + (size_t)ks0 * FRAGB + j * (SL * 16));
         return r;
     };
     auto store_B = [&](int buf, const BReg& r) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) *(u32x4*)(ldsB + buf * BBUF + i * NBREG + tid * 16) = r.v[i];
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) *(u32x4*)(ldsB + buf * BBUF + i * NBREG + j * (SL * 16) + stid * 16) = r.v[i][j];
     };
 
     // ---- this lane's A base: element stream of row 2*th at pixel 2*tw + 2
@@ -354,31 +376,48 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
     // ---- prologue: frames 0 and 1, weight tiles 0 and 1, tile 2 in flight
     // (every request first, then the LDS stores: one memory round trip instead of four -- frame 0, frame 1, weight tiles 0 and 1
     // used to be loaded and parked one after the other)
+    // The whole K loop exists twice, once per staging role (compile-time W): inside ONE loop the role tests merge control flow at
+    // every staging point, and the values requested in a branch then reach the loop-carried registers through copies that wait for
+    // the loads -- measured in the ISA, not guessed.  Both bodies execute the same barriers.
+    auto run_role = [&](auto rolec) {
+    constexpr bool W = decltype(rolec)::value;
     Item fr[FQ], fr1[FQ];
-    BReg R = load_B(0);
-    BReg R1 = load_B(1);
-    float ss_sc = 1.f, ss_sh = 0.f;
-    if (tid < NB * 32) {
-        const int co = min(nb0 * 32 + tid, p.Cout - 1);
-        if (p.scale) ss_sc = p.scale[co];
-        if (p.shift) ss_sh = p.shift[co];
+    Item frS[FQ];                                  // the frame in flight during the K loop
+    BReg R, R1;
+    if constexpr (W) {
+        float ss_sc = 1.f, ss_sh = 0.f;
+        R = load_B(0);
+        R1 = load_B(1);
+        if (tid < NB * 32) {
+            const int co = min(nb0 * 32 + tid, p.Cout - 1);
+            if (p.scale) ss_sc = p.scale[co];
+            if (p.shift) ss_sh = p.shift[co];
+        }
+        store_B(0, R);
+        store_B(1, R1);
+        if (tid < NB * 32) { ldsS[tid] = ss_sc; ldsS[NB * 32 + tid] = ss_sh; }
+        R = load_B(2);
+    } else {
+        load_frame(0, fr);
+        load_frame(1, fr1);
+        load_frame(2, frS);                        // stays in registers until frame 0's K-steps park it
+        store_frame(0, 0, fr);
+        store_frame(FRAME, 1, fr1);
     }
-    load_frame(0, fr);
-    load_frame(1, fr1);
-    store_B(0, R);
-    store_B(1, R1);
-    if (tid < NB * 32) { ldsS[tid] = ss_sc; ldsS[NB * 32 + tid] = ss_sh; }
-    store_frame(0, fr);
-    store_frame(FRAME, fr1);
-    R = load_B(2);
     __syncthreads();
+    STEP_PROBE_MARK(p, 1);
     read_frags(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), 0);
 
     int cur = 0, nxt = FRAME, nn = 2 * FRAME;          // slot byte offsets of frames kd, kd+1, kd+2
     // one frame = 11 K-steps; P = parity of the frame's first K-step (11 is odd, so it alternates)
-    auto frame_iter = [&](auto pc, int kd) {
+    // The frame waves park frame kd + 2 (requested one frame = 11 K-steps earlier) before the second barrier of frame kd and request
+    // frame kd + 3 into the same registers right behind it.
+    // LD / ST (compile time): frame kd + 3 exists and is requested / frame kd + 2 exists and is parked during this frame.  Not
+    // run-time tests: a conditional load in the loop forces the waits behind it to a full drain (the compiler's counts must hold
+    // for the path without the load).
+    auto frame_iter = [&](auto pc, auto ldc, auto stc, int kd) {
         constexpr int P = decltype(pc)::value;
-        if (kd + 2 < 7) load_frame(kd + 2, fr);                     // in flight until the second barrier
+        constexpr bool LD = decltype(ldc)::value, ST = decltype(stc)::value;
 #define STS_KSTEP(J)                                                                                                  \
         {                                                                                                             \
             if (J < 10) read_frags(std::integral_constant<int, (P + J + 1) & 1>(), std::integral_constant<int, (J + 1) % 11>(), cur); \
@@ -387,15 +426,21 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
         }
 #define STS_TILE_END(TI)                                                                                              \
         {                                                                                                             \
-            store_B((TI + 2) % 3, R);                  /* tile 3*kd + TI + 2 -> its home buffer */                  \
-            R = load_B(3 * kd + TI + 3);                                                                              \
+            if constexpr (W) {                                                                                        \
+                store_B((TI + 2) % 3, R);              /* tile 3*kd + TI + 2 -> its home buffer */                  \
+                R = load_B(3 * kd + TI + 3);                                                                          \
+            }                                                                                                         \
         }
         STS_KSTEP(0) STS_KSTEP(1) STS_KSTEP(2) STS_KSTEP(3)
         STS_TILE_END(0)
         __syncthreads();
         STS_KSTEP(4) STS_KSTEP(5) STS_KSTEP(6) STS_KSTEP(7)
         STS_TILE_END(1)
-        if (kd + 2 < 7) store_frame(nn, fr);           // the slot frame kd-1 left (last read before the previous frame's last barrier)
+        if constexpr (ST && !W) {
+            STEP_SCHED_BARRIER();                      // (the scheduler pulled the repacking of the frame up to the frame's first K-steps -- and the wait for its loads with it)
+            store_frame(nn, kd + 2, frS);              // the slot frame kd-1 left (last read before the previous frame's last barrier)
+            if constexpr (LD) load_frame(kd + 3, frS);
+        }
         __syncthreads();
         STS_KSTEP(8) STS_KSTEP(9) STS_KSTEP(10)
         STS_TILE_END(2)
@@ -405,11 +450,19 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
         const int tmp = cur; cur = nxt; nxt = nn; nn = tmp;
     };
 #pragma unroll 1
-    for (int kd = 0; kd < 6; kd += 2) {
-        frame_iter(std::integral_constant<int, 0>(), kd);
-        frame_iter(std::integral_constant<int, 1>(), kd + 1);
+    for (int kd = 0; kd < 4; kd += 2) {
+        frame_iter(std::integral_constant<int, 0>(), std::true_type(), std::true_type(), kd);
+        frame_iter(std::integral_constant<int, 1>(), std::true_type(), std::true_type(), kd + 1);
+        STEP_PROBE_MARK(p, 5 + kd / 2);                 // slots 5, 6: frames 0-1, 2-3 done
     }
-    frame_iter(std::integral_constant<int, 0>(), 6);
+    frame_iter(std::integral_constant<int, 0>(), std::false_type(), std::true_type(), 4);
+    frame_iter(std::integral_constant<int, 1>(), std::false_type(), std::false_type(), 5);
+    STEP_PROBE_MARK(p, 7);                              // frames 4-5 done
+    frame_iter(std::integral_constant<int, 0>(), std::false_type(), std::false_type(), 6);
+    };
+    if (isW) run_role(std::true_type());
+    else run_role(std::false_type());
+    STEP_PROBE_MARK(p, 2);
 
     // ---- epilogue: affine + ReLU and 16-byte stores straight from registers.  The accumulators are transposed (lane l owns pixel
     // (l & 31) of each of its two row blocks and, in registers 4g .. 4g+3, the channels 8g + 4 (l >> 5) + {0..3}); one
@@ -456,6 +509,11 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
             }
         }
     }
+#ifdef STEP_PROBE
+    STEP_PROBE_MARK(p, 3);
+    __builtin_amdgcn_s_waitcnt(0);                    // every store acknowledged
+    STEP_PROBE_MARK(p, 4);
+#endif
 }
 
 // torch [Cout][3][7][7][7] fp32 -> [nb32][77 K-steps][lane][8] (+ one zero K-step at the very end) for stem_stream_kernel
@@ -520,8 +578,12 @@ static int stem_stream_forward_t(StemParams p, step_stream_t stream) {
     // here -- 263 -> 268 us: with three resident workgroups per CU the rounds are not in step and the tail is already smeared
     // out -- and removed again)
     p.tile0 = 0;
+#ifdef STEP_PROBE
+    p.probe = g_probe_buf;
+#endif
     dim3 grid((unsigned)tiles, (unsigned)groups);
-    STEP_LAUNCH((stem_stream_kernel<T, 2>), grid, dim3(256), stream, p);
+    if (p.W % 4 == 0) STEP_LAUNCH((stem_stream_kernel<T, 2, true>), grid, dim3(256), stream, p);
+    else STEP_LAUNCH((stem_stream_kernel<T, 2, false>), grid, dim3(256), stream, p);
     return STEP_LAUNCH_CHECK();
 }
 
@@ -592,7 +654,7 @@ int step_stem_kernel_name(int dtype, char* buf, int buflen) {
     const char* t = dtype == STEP_F32 ? "float" : (dtype == STEP_BF16 ? "step::bf16_t" : "step::f16_t");
     if (dtype != STEP_F32 && dtype != STEP_BF16 && dtype != STEP_F16) return STEP_E_DTYPE;
     if (dtype == STEP_F32 || ov == 0) snprintf(buf, (size_t)buflen, "void step::stem_igemm_kernel<%s, 2>(step::StemParams)", t);
-    else snprintf(buf, (size_t)buflen, "void step::stem_stream_kernel<%s, 2>(step::StemParams)", t);
+    else snprintf(buf, (size_t)buflen, "void step::stem_stream_kernel<%s, 2, true>(step::StemParams)", t);
     return STEP_OK;
 }
 

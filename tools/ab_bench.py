@@ -50,9 +50,18 @@ def main():
     a = ap.parse_args()
     variants = a.var or ["conv_waves=8", "conv_waves=4"]
     L = _lib.lib()
-    LP = None                                             # `lib=prev` in a variant: tools/libstep_amd_prev.so (tools/build_prev.sh)
-    if any("lib=prev" in v for v in variants):
-        LP = _capi.declare(ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libstep_amd_prev.so")), strict=False)
+    # `lib=NAME` in a variant: tools/libstep_amd_NAME.so -- `prev` from tools/build_prev.sh, experiment builds from
+    # `make -C step_amd/csrc EXP=NAME EXPFLAGS=-D...`
+    LIBS = {}
+
+    def lib_of(v):
+        for kv in v.split(","):
+            if kv.startswith("lib="):
+                n = kv[4:]
+                if n not in LIBS:
+                    LIBS[n] = _capi.declare(ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libstep_amd_%s.so" % n)), strict=False)
+                return LIBS[n]
+        return L
     dt, tdt = _capi.BF16, torch.bfloat16
     dev = torch.device("cuda:0")
     st = _lib.stream_ptr()
@@ -75,7 +84,7 @@ def main():
         To, Ho = (T_ - 2) // 2 + 1, (HW_ - 2) // 2 + 1
         y = torch.empty(B, To, Ho, Ho, 64, dtype=tdt, device=dev)
         times, ref = [[] for _ in variants], None
-        libs = [(LP if "lib=prev" in v else L) for v in variants]
+        libs = [lib_of(v) for v in variants]
         wps = []
         for lib in libs:
             wp = torch.empty(lib.step_stem_packed_elems(64), dtype=tdt, device=dev)
@@ -125,10 +134,10 @@ def main():
             _capi.check(cur[0].step_conv_forward(ctypes.byref(d), _lib.dptr(x), _lib.dptr(wp), _lib.dptr(sc), _lib.dptr(sh), None, _lib.dptr(y), None, st), name)
 
         def setenv(v):                       # a variant = planner options (include/step_amd.h), everything else at its default
-            cur[0] = LP if "lib=prev" in v else L
+            cur[0] = lib_of(v)
             cur[0].step_reset_options()
             for kv in v.split(","):
-                if kv and kv not in ("default", "lib=prev"):
+                if kv and kv != "default" and not kv.startswith("lib="):
                     kk, vv = kv.split("=")
                     _capi.set_option(cur[0], kk, int(vv))
 
