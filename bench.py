@@ -224,6 +224,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--branch-streams", type=int, default=None, choices=[0, 1, 2],
                     help="tuning aid: side streams of the Inception blocks (step_amd.backbone.BRANCH_STREAMS; default: the module's)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="tuning aid: a planner option of the library (include/step_amd.h step_set_option), e.g. conv_group_pw=0; repeatable")
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
     global CLIPS_PER_GPU, T_IN, HW_IN, GFLOP_PER_CLIP, ACT_MB_PER_CLIP
@@ -262,6 +264,10 @@ def main():
     if a.branch_streams is not None:
         from step_amd import backbone as _bb
         _bb.BRANCH_STREAMS = a.branch_streams
+    for kv in a.opt:
+        from step_amd import _capi, _lib
+        k_, v_ = kv.split("=")
+        _capi.set_option(_lib.lib(), k_, int(v_))
     if a.config in ("c3", "c4"):
         return pipeline_bench(a, c, dev, tdt, rank, world, dist)
     net = build_net(dev)

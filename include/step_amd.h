@@ -78,6 +78,7 @@ enum {
     STEP_OPT_POOL_DIRECT,      /*  0 (default) | 1: every max pool on the general 27-tap kernel (tests) */
     STEP_OPT_WGRAD_MINPIX,     /*  0 (default: 512) | n: least pixels per wavefront job of step_conv_wgrad (fp32 summation order) */
     STEP_OPT_WGRAD16_LDS,      /*  1 (default) | 0: 3x3 windows of step_conv_wgrad16_ws on the per-tap kernel instead of the LDS-tiled GEMM */
+    STEP_OPT_CONV_GROUP_PW,    /*  2^20 (default: always) | n: step_conv_forward_group carries a pointwise item inside the 3x3x3 members' grid when they are at most n workgroups; 0 never (bit-identical) */
     STEP_OPT_ROI_BWD_GATHER,   /*  1 (default) ROIAlign backward as a fixed-order gather per feature cell (deterministic) | 0: the fp32-atomics scatter of ROIAlign_cuda.cu */
     STEP_OPT_COUNT_
 };
@@ -238,7 +239,11 @@ STEP_API int step_conv_forward(const step_conv_desc* d, const void* x, const voi
  * Alone neither fills the chip's last round and every launch boundary idles all CUs for a prologue + an epilogue; in one grid the
  * narrow conv's workgroups run on the CUs the wide one leaves idle.  Results are bit-identical to n step_conv_forward calls (same
  * tiles, same K order); groups the planner cannot merge are launched one after the other.  No member may use `split`; outputs must
- * not overlap any member's input. */
+ * not overlap any member's input.
+ * A third item may be a pointwise (1x1x1) conv -- the block's branch_3 conv on the pooled tensor: its workgroups are appended to the
+ * same grid and run on the CUs the 3x3x3 members leave idle or free first (the 14x14 maps: 168-256 one-per-CU workgroups of very
+ * different lengths) instead of as a 9-20 us launch of their own (option conv_group_pw: the workgroup limit, 0 = always separate;
+ * bit-identical). */
 typedef struct step_conv_item {
     const step_conv_desc* desc;
     const void* x; const void* w_packed; const float* scale; const float* shift; const void* res; void* y;

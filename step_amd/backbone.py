@@ -574,16 +574,18 @@ class Mixed(nn.Module):
         c0, c1, c2 = oc[0], oc[0] + oc[2], oc[0] + oc[2] + oc[4]
         t = torch.empty((N, D, H, W, oc[1] + oc[3]), dtype=x.dtype, device=x.device)
         if BRANCH_STREAMS == 0 or not x.is_cuda:
-            # ONE stream, four launches: pool, the fused 1x1x1 triple, branch_3's 1x1x1, and the two 3x3x3 convs as ONE grid
+            # ONE stream, three or four launches: pool, the fused 1x1x1 triple, and the two 3x3x3 convs + branch_3's 1x1x1 as ONE grid
             # (ops.conv_forward_group: the narrow branch_2 conv runs on the CUs the wide branch_1 conv leaves idle).  Measured on
             # the replayed C2 step (tools/graph_timeline.py): a cross-stream edge of the HIP graph costs ~6 us of whole-GPU idle
             # (fork + join: 11-16 us per block), kernels that each fill the chip with one workgroup per CU hardly overlap, and a
             # single-stream graph runs its kernels back to back with no gap -- 1469 us against 1477 / 1505 us with 1 / 2 side streams.
-            p = self._branch_3(x, out[..., c2:])
+            # branch_3's 1x1x1 conv on the pooled tensor travels as a third member: on the 14x14 maps the two 3x3x3 convs leave
+            # 32-88 CUs idle and the library appends its workgroups to their grid (elsewhere it is launched behind them)
+            p = self.branch_3[0](x)
             self._fused(x, out[..., :c0], t)
-            u1, u2 = self.branch_1[1]._unit, self.branch_2[1]._unit
+            u1, u2, u3 = self.branch_1[1]._unit, self.branch_2[1]._unit, self.branch_3[1]._unit
             m = []
-            for u, xin, o in ((u1, t[..., :oc[1]], out[..., c0:c1]), (u2, t[..., oc[1]:], out[..., c1:c2])):
+            for u, xin, o in ((u1, t[..., :oc[1]], out[..., c0:c1]), (u2, t[..., oc[1]:], out[..., c1:c2]), (u3, p, out[..., c2:])):
                 scale, shift = u.affine()
                 m.append((xin, u.packed(x.dtype), u.cout, u.k, scale, None if shift is None else shift.detach().contiguous(), True, o))
             ops.conv_forward_group(m)

@@ -44,7 +44,9 @@ struct ConvParams {
 // Several independent convs launched as ONE grid (step_conv_forward_group): the members share the kernel instantiation, each has its own
 // parameter block and a contiguous share of blockIdx.x (p[k].gbase ascending, p[0].gbase == 0).
 constexpr int CONV_GROUP_MAX = 2;
-struct ConvGroupParams { ConvParams p[CONV_GROUP_MAX]; int n; };
+// pw (conv_tap_group_pw_kernel only): a pointwise conv whose 256-thread workgroups follow the members' in the same grid (pw.gbase =
+// the members' total) -- a branch's 1x1x1 conv running on the CUs the 3x3x3 members leave idle
+struct ConvGroupParams { ConvParams p[CONV_GROUP_MAX]; int n; ConvParams pw; };
 
 #ifdef STEP_PROBE
 // Timeline probe (make PROBE=1 -> libstep_amd_probe.so, never the product library): wave 0 of a workgroup stores the 100 MHz
@@ -53,7 +55,16 @@ extern unsigned long long* g_probe_buf;       // set by step_probe_set()
 __device__ __forceinline__ void probe_mark(unsigned long long* probe, int slot) {
     if (probe && threadIdx.x == 0) probe[(size_t)blockIdx.x * 16 + slot] = __builtin_amdgcn_s_memrealtime();
 }
+// shader-clock reading (s_memtime counts shader cycles, s_memrealtime 100 MHz): slot 14 holds entry clock at first, then
+// probe_clock_end() turns it into the cycles this workgroup lived -- cycles / (slot 4 - slot 0) = the clock the CU really ran at
+__device__ __forceinline__ void probe_clock_begin(unsigned long long* probe) {
+    if (probe && threadIdx.x == 0) probe[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memtime();
+}
+__device__ __forceinline__ void probe_clock_end(unsigned long long* probe) {
+    if (probe && threadIdx.x == 0) probe[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memtime() - probe[(size_t)blockIdx.x * 16 + 14];
+}
 __device__ __forceinline__ void probe_ids(unsigned long long* probe) {
+    probe_clock_begin(probe);
     if (probe && threadIdx.x == 0) {
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID
         const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID

@@ -854,31 +854,74 @@ static bool conv_group_plan(const step_conv_item* items, int n, step_conv_desc* 
     return true;
 }
 
+// The members of a grouped launch: the 3x3x3 items that share one conv_tap instantiation and, optionally, ONE pointwise item the
+// planner sends to conv_pw_kernel<T, 1, 4> (plain epilogue).  tap[] / pw index into items; returns false when the items do not
+// group (the caller launches them one by one).
+struct GroupSel { int ntap, tap[CONV_GROUP_MAX], pw; };
+static bool conv_group_select(const step_conv_item* items, int n, GroupSel& sel) {
+    sel.ntap = 0; sel.pw = -1;
+    if (n < 2 || n > CONV_GROUP_MAX + 1) return false;
+    for (int k = 0; k < n; ++k) {
+        const step_conv_desc* d = items[k].desc;
+        if (!d) return false;
+        if (d->kd == 1 && d->kh == 1 && d->kw == 1) {
+            if (sel.pw >= 0) return false;
+            sel.pw = k;
+        } else {
+            if (sel.ntap == CONV_GROUP_MAX) return false;
+            sel.tap[sel.ntap++] = k;
+        }
+    }
+    return sel.ntap == CONV_GROUP_MAX || (sel.ntap >= 2 && sel.pw < 0);
+}
+
+// the pointwise member's parameter block, or false when the layer is not one the group kernel carries
+static bool conv_group_pw_params(const step_conv_item& it, int dtype, step_conv_desc& canon, ConvParams& p, long long base) {
+    if (conv_fill_params(it.desc, it.x, it.w_packed, it.scale, it.shift, it.res, it.y, nullptr, canon, p) != STEP_OK || p.N == 0) return false;
+    if (canon.dtype != dtype || it.desc->split || it.res) return false;
+    constexpr int VEC = 8;
+    if (canon.Cin % VEC || canon.x_cstride % VEC || canon.x_coff % VEC || ((uintptr_t)p.x % 16) || ((uintptr_t)p.w % 16)) return false;
+    const ConvPlan pl = conv_plan(&canon, false);
+    if (!pl.ok || pl.impl != 2 || pl.NB != 1 || pl.wv != 4) return false;
+    p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.tiles_d = pl.tiles_d;
+    p.gtd = pl.gtd; p.gth = pl.gth; p.gtw = pl.gtw; p.gmode = pl.gmode;
+    const int groups = ceil_div(p.nblk32, 2);
+    p.gx = (int)pl.mtiles; p.gy = groups;
+    const long long tot = (pl.mtiles * groups + 7) / 8 * 8;
+    if (base + tot > 0x7fffffffLL) return false;
+    p.gbase = (int)base; p.gcount = (int)tot;
+    return true;
+}
+
 int step_conv_forward_group(const step_conv_item* items, int n, step_stream_t stream) {
     if (n < 0) return STEP_E_SHAPE;
     if (n == 0) return STEP_OK;
     if (!items) return STEP_E_NULL;
-    if (n <= CONV_GROUP_MAX) {
+    GroupSel sel;
+    bool done[CONV_GROUP_MAX + 1] = {false, false, false};
+    if (conv_group_select(items, n, sel)) {
         step_conv_desc canon[CONV_GROUP_MAX];
         ConvParams ps[CONV_GROUP_MAX];
         ConvPlan pls[CONV_GROUP_MAX];
+        step_conv_item taps[CONV_GROUP_MAX];
         bool ok = true;
-        for (int k = 0; k < n && ok; ++k) {
-            const step_conv_item& it = items[k];
+        for (int k = 0; k < sel.ntap && ok; ++k) {
+            taps[k] = items[sel.tap[k]];
+            const step_conv_item& it = taps[k];
             const int rc = conv_fill_params(it.desc, it.x, it.w_packed, it.scale, it.shift, it.res, it.y, nullptr, canon[k], ps[k]);
             if (rc != STEP_OK) return rc;
             ok = ps[k].N != 0 && (!it.desc->split);
         }
         int NBc = 0;
-        if (ok && conv_group_plan(items, n, canon, ps, pls, &NBc)) {
+        if (ok && conv_group_plan(taps, sel.ntap, canon, ps, pls, &NBc)) {
             ConvGroupParams g;
-            g.n = n;
+            g.n = sel.ntap;
             // longest workgroups first (they are dispatched first): descending K depth
             int order[CONV_GROUP_MAX];
-            for (int k = 0; k < n; ++k) order[k] = k;
-            if (n == 2 && (long long)canon[1].Cin * pls[1].NB > (long long)canon[0].Cin * pls[0].NB) { order[0] = 1; order[1] = 0; }
+            for (int k = 0; k < sel.ntap; ++k) order[k] = k;
+            if (sel.ntap == 2 && (long long)canon[1].Cin * pls[1].NB > (long long)canon[0].Cin * pls[0].NB) { order[0] = 1; order[1] = 0; }
             long long base = 0;
-            for (int j = 0; j < n; ++j) {
+            for (int j = 0; j < sel.ntap; ++j) {
                 const int k = order[j];
                 ConvParams& p = g.p[j];
                 p = ps[k];
@@ -891,15 +934,30 @@ int step_conv_forward_group(const step_conv_item* items, int n, step_stream_t st
                 p.gbase = (int)base; p.gcount = (int)tot;
                 base += tot;
             }
-            for (int j = n; j < CONV_GROUP_MAX; ++j) g.p[j] = g.p[0];
-            if (base <= 0x7fffffffLL) {
-                const dim3 grid((unsigned)base);
-                return canon[0].dtype == STEP_BF16 ? conv_tap_group_launch<bf16_t>(pls[0].twl, NBc, g, grid, stream)
-                                                   : conv_tap_group_launch<f16_t>(pls[0].twl, NBc, g, grid, stream);
+            for (int j = sel.ntap; j < CONV_GROUP_MAX; ++j) g.p[j] = g.p[0];
+            g.pw = g.p[0];
+            g.pw.gbase = 0; g.pw.gcount = 0;                 // (gcount == 0: no pointwise member)
+            // the pointwise member rides along when the 3x3x3 members leave CUs idle (fewer one-per-CU workgroups than CUs):
+            // behind a launch that fills every CU its workgroups would only queue
+            bool with_pw = false;
+            if (sel.pw >= 0 && pls[0].twl == 0 && base <= opt(STEP_OPT_CONV_GROUP_PW)) {
+                step_conv_desc cpw;
+                with_pw = conv_group_pw_params(items[sel.pw], canon[0].dtype, cpw, g.pw, base);
+                if (!with_pw) { g.pw = g.p[0]; g.pw.gbase = 0; g.pw.gcount = 0; }
+            }
+            const long long total = base + (with_pw ? g.pw.gcount : 0);
+            if (total <= 0x7fffffffLL) {
+                const dim3 grid((unsigned)total);
+                const int rc = canon[0].dtype == STEP_BF16 ? conv_tap_group_launch<bf16_t>(pls[0].twl, NBc, g, grid, stream)
+                                                           : conv_tap_group_launch<f16_t>(pls[0].twl, NBc, g, grid, stream);
+                if (rc != STEP_OK) return rc;
+                for (int k = 0; k < sel.ntap; ++k) done[sel.tap[k]] = true;
+                if (with_pw) done[sel.pw] = true;
             }
         }
     }
-    for (int k = 0; k < n; ++k) {                            // not groupable: one launch each (the same results)
+    for (int k = 0; k < n; ++k) {                            // what did not group: one launch each (the same results)
+        if (k <= CONV_GROUP_MAX && done[k]) continue;
         const step_conv_item& it = items[k];
         const int rc = step_conv_forward_ws(it.desc, it.x, it.w_packed, it.scale, it.shift, it.res, it.y, nullptr, nullptr, 0, stream);
         if (rc != STEP_OK) return rc;
@@ -910,19 +968,31 @@ int step_conv_forward_group(const step_conv_item* items, int n, step_stream_t st
 int step_conv_group_kernel_name(const step_conv_item* items, int n, char* buf, int buflen) {
     if (!items || !buf || buflen <= 0) return STEP_E_NULL;
     buf[0] = 0;
-    if (n < 2 || n > CONV_GROUP_MAX) return STEP_OK;
+    GroupSel sel;
+    if (!conv_group_select(items, n, sel)) return STEP_OK;
     step_conv_desc canon[CONV_GROUP_MAX];
     ConvParams ps[CONV_GROUP_MAX];
     ConvPlan pls[CONV_GROUP_MAX];
-    for (int k = 0; k < n; ++k) {
-        const step_conv_item& it = items[k];
+    step_conv_item taps[CONV_GROUP_MAX];
+    for (int k = 0; k < sel.ntap; ++k) {
+        taps[k] = items[sel.tap[k]];
+        const step_conv_item& it = taps[k];
         if (conv_fill_params(it.desc, it.x, it.w_packed, it.scale, it.shift, it.res, it.y, nullptr, canon[k], ps[k]) != STEP_OK || ps[k].N == 0 || it.desc->split)
             return STEP_OK;
     }
     int NBc = 0;
-    if (!conv_group_plan(items, n, canon, ps, pls, &NBc)) return STEP_OK;
+    if (!conv_group_plan(taps, sel.ntap, canon, ps, pls, &NBc)) return STEP_OK;
+    long long base = 0;
+    for (int k = 0; k < sel.ntap; ++k) base += (pls[k].mtiles * ceil_div(ps[k].nblk32, 2 * NBc) + 7) / 8 * 8;
+    bool with_pw = false;
+    if (sel.pw >= 0 && pls[0].twl == 0 && base <= opt(STEP_OPT_CONV_GROUP_PW)) {
+        step_conv_desc cpw;
+        ConvParams ppw;
+        with_pw = conv_group_pw_params(items[sel.pw], canon[0].dtype, cpw, ppw, base);
+    }
     const char* t = canon[0].dtype == STEP_BF16 ? "step::bf16_t" : "step::f16_t";
-    snprintf(buf, (size_t)buflen, "void step::conv_tap_group_kernel<%s, %d, %d, 3, 3, 3, 2, 2, 8, 1>(step::ConvGroupParams)", t, pls[0].twl, NBc);
+    snprintf(buf, (size_t)buflen, "void step::conv_tap_group%s_kernel<%s, %d, %d, 3, 3, 3, 2, 2, 8, 1>(step::ConvGroupParams)", with_pw ? "_pw" : "", t,
+             pls[0].twl, NBc);
     return STEP_OK;
 }
 

@@ -3,6 +3,7 @@
 // translation unit, so the three build in parallel).
 #pragma once
 #include "conv_common.h"
+#include "conv_pw_kernel.h"
 
 namespace step {
 
@@ -352,6 +353,9 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
             __builtin_amdgcn_sched_barrier(0);
 #endif
             __syncthreads();
+#ifdef STEP_PROBE
+            if (slab == 0 && SI >= 1 && SI <= 4) STEP_PROBE_MARK(p, 7 + 2 * (SI - 1));          // slots 7, 9, 11, 13: L phase of step SI done (group 0)
+#endif
             // ---- C: the step's MFMAs, back to back out of registers, at raised priority (the partner wave is in its L phase)
 #ifndef STEP_EMUL
             __builtin_amdgcn_sched_barrier(0);
@@ -373,6 +377,9 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
 #ifndef STEP_EMUL
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifdef STEP_PROBE
+            if (slab == 0 && SI >= 1 && SI <= 3) STEP_PROBE_MARK(p, 8 + 2 * (SI - 1));          // slots 8, 10, 12: MFMAs of step SI issued (before the barrier)
 #endif
             __syncthreads();
         };
@@ -649,6 +656,7 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
 #ifdef STEP_PROBE
             STEP_PROBE_MARK(p, 3);
             __builtin_amdgcn_s_waitcnt(0);                    // every store acknowledged
+            probe_clock_end(p.probe);
             STEP_PROBE_MARK(p, 4);
 #endif
             return;
@@ -714,6 +722,21 @@ void conv_tap_kernel(ConvParams p) {
 template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB, int WV, int PH>
 __global__ __launch_bounds__(WV * 64, 2)
 void conv_tap_group_kernel(ConvGroupParams g) {
+    const int k = (g.n > 1 && blockIdx.x >= (unsigned)g.p[1].gbase) ? 1 : 0;
+    conv_tap_body<T, TWL, NB, KD, KH, KW, TPS, MB, WV, PH, true>(g.p[k]);
+}
+
+
+// The grouped launch plus ONE pointwise conv (conv_pw_body<T, 1, 4>: 128 pixels x 64 channels per 256-thread workgroup; waves 4-7 of
+// such a workgroup leave at once).  On the 14x14 maps the two 3x3x3 convs of an Inception block are 168-224 one-per-CU workgroups
+// of 23-52 us: the block's branch_3 1x1x1 conv (9-11 us as a launch of its own) runs beside them on the idle CUs.
+template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB, int WV, int PH>
+__global__ __launch_bounds__(WV * 64, 2)
+void conv_tap_group_pw_kernel(ConvGroupParams g) {
+    if (blockIdx.x >= (unsigned)g.pw.gbase) {
+        if (threadIdx.x < 256) conv_pw_body<T, 1, 4>(g.pw);
+        return;
+    }
     const int k = (g.n > 1 && blockIdx.x >= (unsigned)g.p[1].gbase) ? 1 : 0;
     conv_tap_body<T, TWL, NB, KD, KH, KW, TPS, MB, WV, PH, true>(g.p[k]);
 }
@@ -785,6 +808,17 @@ static int conv_tap_group_launch_twl(int NB, const ConvGroupParams& g, dim3 grid
 }
 template <typename T>
 int conv_tap_group_launch_impl(int twl, int NB, const ConvGroupParams& g, dim3 grid, step_stream_t stream) {
+    if (g.pw.gcount > 0) {                               // with a pointwise member (general boxes only: the planner asks for nothing else)
+        if (twl != 0) return STEP_E_UNSUPPORTED;
+#define STEP_TAPGP(NB_) STEP_LAUNCH((conv_tap_group_pw_kernel<T, 0, NB_, 3, 3, 3, 2, 2, 8, 1>), grid, dim3(512), stream, g)
+        switch (NB) {
+            case 1: STEP_TAPGP(1); break;
+            case 2: STEP_TAPGP(2); break;
+            default: STEP_TAPGP(3); break;
+        }
+#undef STEP_TAPGP
+        return STEP_LAUNCH_CHECK();
+    }
     if (twl == 0) return conv_tap_group_launch_twl<T, 0>(NB, g, grid, stream);
     if (twl == 3) return conv_tap_group_launch_twl<T, 3>(NB, g, grid, stream);
     return STEP_E_UNSUPPORTED;

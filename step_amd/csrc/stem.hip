@@ -512,6 +512,7 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
 #ifdef STEP_PROBE
     STEP_PROBE_MARK(p, 3);
     __builtin_amdgcn_s_waitcnt(0);                    // every store acknowledged
+    probe_clock_end(p.probe);
     STEP_PROBE_MARK(p, 4);
 #endif
 }

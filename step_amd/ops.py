@@ -180,8 +180,8 @@ def conv_forward(x, w_packed, Cout, k, scale=None, shift=None, relu=True, res=No
 
 def conv_forward_group(members):
     """Several INDEPENDENT convs as one launch where the library can merge them (step_conv_forward_group: today two 16-bit 3x3x3
-    layers of the two-phase conv_tap form -- an Inception block's branch_1 / branch_2 convs); otherwise they are launched one after
-    the other.  members: (x, w_packed, Cout, k, scale, shift, relu, out) per conv, `out` a channel slice to write into.  Same results
+    layers of the two-phase conv_tap form -- an Inception block's branch_1 / branch_2 convs -- plus, on small maps, one pointwise
+    conv riding on the CUs they leave idle); otherwise they are launched one after the other.  members: (x, w_packed, Cout, k, scale, shift, relu, out) per conv, `out` a channel slice to write into.  Same results
     as conv_forward per member, bit for bit."""
     L = _lib.lib()
     n = len(members)
@@ -208,6 +208,12 @@ def conv_forward_group(members):
         L.step_conv_group_kernel_name(items, n, buf, 256)
         if not buf.value:                                            # not merged: per-member attribution
             for (x, w_packed, Cout, k, scale, shift, relu, out) in members:
+                conv_forward(x, w_packed, Cout, k, scale, shift, relu, None, out)
+            return
+        pw = [m for m in members if tuple(m[3]) == (1, 1, 1)]
+        if pw and b"_pw_kernel" not in buf.value:                    # the pointwise member stays a launch of its own: attribute it separately
+            conv_forward_group([m for m in members if tuple(m[3]) != (1, 1, 1)])
+            for (x, w_packed, Cout, k, scale, shift, relu, out) in pw:
                 conv_forward(x, w_packed, Cout, k, scale, shift, relu, None, out)
             return
     _run(lambda: _capi.check(L.step_conv_forward_group(items, n, stream), "step_conv_forward_group"),

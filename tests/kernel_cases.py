@@ -1256,6 +1256,61 @@ def case_conv_group_matches_separate_launches(bk, golden):
     assert bk.lib.step_conv_forward_group(None, 0, bk.stream) == 0 and bk.lib.step_conv_forward_group(None, 1, bk.stream) == -3
 
 
+def case_conv_group_with_pointwise_member(bk, golden):
+    """step_conv_forward_group with a third, pointwise item (an Inception block's branch_3 conv on the pooled tensor): when the two
+    3x3x3 members are fewer workgroups than the chip has CUs its 256-thread workgroups ride in the same grid
+    (conv_tap_group_pw_kernel) -- bit-identical to three step_conv_forward calls, ragged pixel and channel counts included; with
+    option conv_group_pw = 0, with a residual or with a member the planner sends elsewhere it is launched behind them."""
+    rs = np.random.RandomState(53)
+    buf = ctypes.create_string_buffer(256)
+    N, D, H, W = 3, 8, 14, 14                                  # 4704 pixels: enough rows for the planner to stream the pointwise layers (conv_pw_kernel<T, 1, 4>)
+    for dt, (ci0, co0, ci1, co1), (cp, cop), order, rides in ((BF16, (64, 72, 64, 40), (128, 96), (0, 1, 2), True), (F16, (64, 64, 64, 64), (136, 72), (2, 0, 1), True),
+                                                              (BF16, (64, 40, 64, 72), (64, 128), (0, 2, 1), False)):    # (K = 64: the planner keeps the tiled kernel -- not carried)
+        t = rs.randn(N, ci0 + ci1, D, H, W).astype(np.float32)
+        pl = rs.randn(N, cp, D, H, W).astype(np.float32)                           # the pooled tensor: another buffer
+        shapes = ((ci0, co0, 3), (ci1, co1, 3), (cp, cop, 1))
+        ws = [(rs.randn(co, ci, k, k, k) / np.sqrt(ci * k ** 3)).astype(np.float32) for ci, co, k in shapes]
+        aff = [((1 + 0.1 * rs.randn(co)).astype(np.float32), (0.2 * rs.randn(co)).astype(np.float32)) for _, co, _ in shapes]
+        te, pe = bk.dev(encode(cl(t), dt)), bk.dev(encode(cl(pl), dt))
+        ctot = 8 + co0 + co1 + cop + 8
+        outs = {}
+        for mode in ("group", "group_nopw", "separate"):
+            yb = bk.dev(np.zeros((N, D, H, W, ctot), NP_DT[dt]))
+            keep, items = [], (_capi.ConvItem * 3)()
+            specs = ((ci0, co0, 3, te, ci0 + ci1, 0, 8), (ci1, co1, 3, te, ci0 + ci1, ci0, 8 + co0), (cp, cop, 1, pe, cp, 0, 8 + co0 + co1))
+            for slot, k_ in enumerate(order):
+                ci, co, kk, xb, xcs, xoff, yoff = specs[k_]
+                d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=ci, Cout=co, kd=kk, kh=kk, kw=kk, x_cstride=xcs, x_coff=xoff,
+                                   y_cstride=ctot, y_coff=yoff, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+                wp = pack_weight(bk, ws[k_], dt)
+                sc, sh = bk.dev(aff[k_][0]), bk.dev(aff[k_][1])
+                keep += [d, wp, sc, sh]
+                it = items[slot]
+                it.desc = ctypes.pointer(d)
+                it.x, it.w_packed, it.scale, it.shift, it.res, it.y = (ctypes.cast(xb.ptr, ctypes.c_void_p).value, ctypes.cast(wp.ptr, ctypes.c_void_p).value,
+                                                                       ctypes.cast(sc.ptr, ctypes.c_void_p).value, ctypes.cast(sh.ptr, ctypes.c_void_p).value, None,
+                                                                       ctypes.cast(yb.ptr, ctypes.c_void_p).value)
+            if mode == "separate":
+                for slot in range(3):
+                    it = items[slot]
+                    assert bk.lib.step_conv_forward(it.desc, it.x, it.w_packed, it.scale, it.shift, None, it.y, None, bk.stream) == 0
+            else:
+                with _capi.options(bk.lib, conv_group_pw=256 if mode == "group" else 0):
+                    assert bk.lib.step_conv_group_kernel_name(items, 3, buf, 256) == 0
+                    assert (b"conv_tap_group_pw_kernel" in buf.value) == (mode == "group" and rides), (mode, buf.value)
+                    assert b"conv_tap_group" in buf.value
+                    assert bk.lib.step_conv_forward_group(items, 3, bk.stream) == 0
+            outs[mode] = yb.get()
+        assert np.array_equal(outs["group"], outs["separate"]) and np.array_equal(outs["group_nopw"], outs["separate"]), (dt, cp, cop)
+        y = decode(outs["group"], dt)
+        assert not y[..., :8].any() and not y[..., ctot - 8:].any()
+        ref = ref_conv(pl, ws[2], aff[2][0], aff[2][1], dt)
+        got = uncl(y[..., 8 + co0 + co1:8 + co0 + co1 + cop])
+        assert np.abs(got - ref).max() / np.abs(ref).max() < tol(dt), dt
+    # two pointwise items, or a pointwise item beside ONE 3x3x3 conv: nothing to merge into -- separate launches, empty name
+    assert bk.lib.step_conv_group_kernel_name(items, 2, buf, 256) == 0
+
+
 def case_conv_tail_round_split(bk, golden):
     """A layer that is one channel group deep and whose pixel tiles end in a small partial round of one-workgroup-per-CU slots is
     launched in two parts: the full rounds at NB = 3 and the tail tiles at NB = 1 (three times as many, shorter workgroups).

@@ -64,8 +64,21 @@ def report(L, name, run, probe, stem=False):
         print("         K loop: frames 0-1 %.2f, 2-3 %.2f, 4-5 %.2f, 6 %.2f" % (
             (f[:, 5] - f[:, 1]).mean(), (f[:, 6] - f[:, 5]).mean(), (f[:, 7] - f[:, 6]).mean(), (f[:, 2] - f[:, 7]).mean()))
     else:
+        f14 = p[:, :15].astype(np.float64) * 0.01
+        ok = (f14[:, 7] > 0) & (f14[:, 13] > 0)
+        if ok.any():
+            g = f14[ok]
+            print("         steps 1-3 of slab 0, group 0: MFMA issue %.2f %.2f %.2f us | barrier + load phase + barrier %.2f %.2f %.2f us" % (
+                (g[:, 8] - g[:, 7]).mean(), (g[:, 10] - g[:, 9]).mean(), (g[:, 12] - g[:, 11]).mean(),
+                (g[:, 9] - g[:, 8]).mean(), (g[:, 11] - g[:, 10]).mean(), (g[:, 13] - g[:, 12]).mean()))
         print("         prologue: weight requests + index tables %.2f, halo load -> LDS %.2f, weights -> LDS + barrier %.2f" % (
             (f[:, 5] - f[:, 0]).mean(), (f[:, 6] - f[:, 5]).mean(), (f[:, 1] - f[:, 6]).mean()))
+    cyc = p[:, 14].astype(np.float64)
+    okc = (cyc > 0) & (cyc < 1e9) & (t[:, 4] > t[:, 0])
+    if okc.any():
+        ghz = cyc[okc] / ((t[okc, 4] - t[okc, 0]) * 1e3)
+        print("         shader clock over a workgroup's life (s_memtime / s_memrealtime): median %.2f GHz, p5 %.2f, p95 %.2f" % (
+            np.median(ghz), np.percentile(ghz, 5), np.percentile(ghz, 95)))
     # first / last start and end spread: how synchronised the CUs are
     firsts = np.array([t[ids[0], 0] for ids in per_cu.values()]) - t0
     ends = np.array([t[ids[-1], 4] for ids in per_cu.values()]) - t0
