@@ -108,6 +108,34 @@ def cpu_baseline(net, seconds_budget=12.0):
             "sample": "%d single-clip [1,32,3,224,224] fp32 forwards of oracle/i3d_ref.basenet_forward (torch CPU) after 1 warm-up, %.1f s" % (n, el)}
 
 
+def sustained_mfma(dev):
+    """What THIS box sustains with nothing but 16-bit matrix instructions on every CU (step_mfma_clock_probe, include/step_amd.h):
+    MI355X is power-managed, so the clock under matrix load is well below the 2.4 GHz the datasheet peak assumes.  Reported beside
+    `roofline` (whose `peak` stays the datasheet figure the contract names) so that `frac` can be read against the box at hand."""
+    import ctypes
+    from step_amd import _capi, _lib
+    L = _lib.lib()
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    iters = 20000
+    buf = torch.zeros(3 * cus, dtype=torch.int64, device=dev)
+    for _ in range(40):                                          # ~60 ms of continuous matrix load: the power manager needs tens of ms to settle; the LAST launch is read
+        _capi.check(L.step_mfma_clock_probe(ctypes.c_void_p(buf.data_ptr()), cus, iters, _lib.stream_ptr(dev)), "step_mfma_clock_probe")
+    torch.cuda.synchronize()
+    h = buf.cpu().numpy().reshape(cus, 3).astype("float64")
+    ok = h[:, 1] > 0
+    if not ok.any():
+        return None
+    ghz = sorted(h[ok, 0] / (h[ok, 1] * 10.0))
+    us = sorted(h[ok, 1] * 0.01)
+    clock, t = ghz[len(ghz) // 2], us[len(us) // 2]
+    tf = cus * 4 * 4 * 32768.0 * iters / (t * 1e-6) / 1e12      # 4 waves x 4 MFMAs x 32768 FLOP per iteration per workgroup
+    return {"clock_ghz_median": round(clock, 3), "clock_ghz_p5_p95": [round(ghz[len(ghz) // 20], 3), round(ghz[-1 - len(ghz) // 20], 3)],
+            "dense_bf16_tflops": round(tf, 1), "workgroups": cus,
+            "note": "one 256-thread workgroup per CU issuing v_mfma_f32_32x32x16_bf16 back to back on pseudo-random bf16 operands, nothing "
+                    "else, read after ~60 ms of that load; clock = s_memtime / s_memrealtime over the loop; the datasheet peak "
+                    "(2500 TFLOP/s) assumes 2.4 GHz"}
+
+
 def roofline(net, x, dtype_name):
     """Per-launch durations of the REPLAYED step, measured live: HIP graphs of growing prefixes of the forward (launches 1..k, the
     rest skipped by step_amd.ops.PROFILE_LIMIT) are captured and replayed, and launch k's duration is the difference of the best
@@ -339,6 +367,10 @@ def main():
         with torch.no_grad():
             rl, table, gpu_ms = roofline(net, x, a.dtype)
         out["roofline"] = rl
+        if a.dtype != "f32":
+            sm = sustained_mfma(dev)
+            if sm:
+                rl["sustained_on_this_box"] = dict(sm, frac_of_sustained=round(rl["achieved"] / sm["dense_bf16_tflops"], 4) if rl.get("bound") == "mfma" else None)
         out["kernel_time_ms_per_step"] = round(gpu_ms, 4)
         if a.verbose:
             for n_, ms, cnt, gfs in table:

@@ -56,6 +56,13 @@ enum {
 STEP_API const char* step_version(void);
 STEP_API int step_abi_version(void);
 
+/* Diagnostic (bench.py): `workgroups` x 256 threads each issue `iters` x 4 back-to-back v_mfma_f32_32x32x16_bf16 per wavefront on
+ * pseudo-random bf16 operands (the clock depends on how many operand bits toggle: near-constant operands run ~0.45 GHz higher) and
+ * nothing else; out[3 * wg + {0, 1, 2}] = shader cycles (s_memtime), 100 MHz ticks (s_memrealtime) of that loop, and a nonzero
+ * flag.  One workgroup per CU gives the clock and the dense 16-bit matrix rate the box SUSTAINS -- MI355X is power-managed: the
+ * boxes this was developed on settle at ~1.9 GHz = ~2.0 PFLOP/s, not the 2.4 GHz / 2.5 PFLOP/s of the datasheet roofline. */
+STEP_API int step_mfma_clock_probe(unsigned long long* out, int workgroups, int iters, step_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Planner options.  The library reads NO environment variable: the launch planners' few tuning / test knobs are explicit
  * integers set through this entry point (process-wide, relaxed atomics: safe to call from any thread; a launch sees either

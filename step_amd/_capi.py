@@ -41,6 +41,7 @@ SIGNATURES = {
     "step_roi_align_backward": (i, [fp, i, fp, i, i, i, i, i, i, i, f, i, fp, vp]),
     "step_roi_pool_forward": (i, [vp, i, i, fp, i, i, i, i, i, i, i, f, vp, ip, vp]),
     "step_roi_pool_backward": (i, [fp, ip, i, fp, i, i, i, i, i, i, i, fp, vp]),
+    "step_mfma_clock_probe": (i, [vp, i, i, vp]),
     "step_nms_scratch_bytes": (sz, [i, i]),
     "step_nms_batched": (i, [fp, fp, ip, i, i, f, u8p, vp, vp]),
     "step_nms_batched_f64": (i, [fp, fp, ip, i, i, f, u8p, vp, vp]),

@@ -1,0 +1,66 @@
+// step_amd/csrc/diag.hip -- step_mfma_clock_probe: what this GPU sustains when every CU does nothing but 16-bit matrix
+// instructions.  MI355X is power-managed: the datasheet's dense bf16 figure assumes 2.4 GHz, but with all 256 CUs issuing
+// v_mfma_f32_32x32x16_bf16 back to back the boxes of this pool settle near 1.9 GHz.  bench.py reports the
+// measured figure next to the datasheet roofline, so that a kernel's fraction can be read against what the box at hand can do.
+// s_memtime counts shader cycles, s_memrealtime a constant 100 MHz; their ratio over the loop is the clock of that CU.
+#include "common.h"
+
+namespace step {
+
+__global__ __launch_bounds__(256) void mfma_clock_probe_kernel(unsigned long long* __restrict__ out, int iters) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    u16x8 fa, fb;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        // pseudo-random bf16 operands in +-[0.25, 2): random sign and mantissa bits -- the power a matrix instruction draws depends on
+        // how many operand bits toggle (near-constant operands measured 2.3 GHz on a box that grants random ones 1.9)
+        unsigned h = (threadIdx.x * 8u + e) * 2654435761u + blockIdx.x * 40503u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        fa[e] = (unsigned short)((h & 0x807fu) | (0x3e80u + ((h >> 8) & 0x0180u)));
+        fb[e] = (unsigned short)(((h >> 16) & 0x807fu) | (0x3e80u + ((h >> 24) & 0x0180u)));
+    }
+#ifdef STEP_EMUL
+    const unsigned long long c0 = 0, t0 = 0;
+#else
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) mma_k16(fa, fb, acc[a], bf16_t());      // four independent accumulators: the pipe never waits
+    }
+#ifdef STEP_EMUL
+    const unsigned long long c1 = 0, t1 = 0;
+#else
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[a][r];
+    if (threadIdx.x == 0) {
+        out[3 * (size_t)blockIdx.x + 0] = c1 - c0;
+        out[3 * (size_t)blockIdx.x + 1] = t1 - t0;
+        out[3 * (size_t)blockIdx.x + 2] = (unsigned long long)(s != 123.456f);      // (keeps the matrix work alive)
+    }
+}
+
+}  // namespace step
+
+using namespace step;
+
+extern "C" {
+
+int step_mfma_clock_probe(unsigned long long* out, int workgroups, int iters, step_stream_t stream) {
+    if (workgroups < 0 || iters < 0) return STEP_E_SHAPE;
+    if (workgroups == 0) return STEP_OK;
+    if (!out) return STEP_E_NULL;
+    STEP_LAUNCH(mfma_clock_probe_kernel, dim3((unsigned)workgroups), dim3(256), stream, out, iters);
+    return STEP_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -1311,6 +1311,25 @@ def case_conv_group_with_pointwise_member(bk, golden):
     assert bk.lib.step_conv_group_kernel_name(items, 2, buf, 256) == 0
 
 
+def case_mfma_clock_probe(bk, golden):
+    """step_mfma_clock_probe (the diagnostic behind bench.py's `sustained_on_this_box`): every workgroup reports its loop; on the
+    interpreter the counters read 0, on the GPU the clock lies in the part's range and the matrix pipe issues one 32x32x16 per
+    32 cycles per SIMD."""
+    wgs, iters = 8, 300
+    out = bk.dev(np.zeros(3 * wgs, np.uint64))
+    assert bk.lib.step_mfma_clock_probe(out.ptr, wgs, iters, bk.stream) == 0
+    h = out.get().reshape(wgs, 3)
+    assert (h[:, 2] == 1).all()
+    if bk.name == "gfx950":
+        ghz = h[:, 0] / (h[:, 1] * 10.0)
+        assert (ghz > 0.5).all() and (ghz < 3.0).all(), ghz
+        assert (h[:, 0] >= 4 * iters * 32 * 0.9).all(), h[:, 0]            # 4 MFMAs x 32 cycles per iteration at least
+    else:
+        assert not h[:, :2].any()
+    assert bk.lib.step_mfma_clock_probe(None, 0, 10, bk.stream) == 0 and bk.lib.step_mfma_clock_probe(None, 1, 10, bk.stream) == -3
+    assert bk.lib.step_mfma_clock_probe(out.ptr, -1, 10, bk.stream) < 0
+
+
 def case_conv_tail_round_split(bk, golden):
     """A layer that is one channel group deep and whose pixel tiles end in a small partial round of one-workgroup-per-CU slots is
     launched in two parts: the full rounds at NB = 3 and the tail tiles at NB = 1 (three times as many, shorter workgroups).
