@@ -155,4 +155,4 @@ def test_bench_launches_and_reduces_over_two_ranks(config):
     assert np.isfinite(j["value"]) and j["value"] > 0 and np.isfinite(j["ms_per_step"]) and j["ms_per_step"] > 0
     # whole-job value = clips of BOTH ranks over the slowest rank's time
     clips = j["config"]["clips_per_gpu"]
-    assert abs(j["value"] - 2 * clips / (j["ms_per_step"] * 1e-3)) < 0.02 * j["value"], j
+    assert abs(j["value"] - 2 * clips / (j["ms_per_step"] * 1e-3)) < 0.02 * j["value"] + 0.006, j     # (+ the rounding of `value` to two decimals: two ranks sharing one GPU over gloo take seconds per C4 step)
