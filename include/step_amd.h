@@ -251,6 +251,17 @@ STEP_API int step_conv_forward(const step_conv_desc* d, const void* x, const voi
  * same grid and run on the CUs the 3x3x3 members leave idle or free first (the 14x14 maps: 168-256 one-per-CU workgroups of very
  * different lengths) instead of as a 9-20 us launch of their own (option conv_group_pw: the workgroup limit, 0 = always separate;
  * bit-identical). */
+/* step_conv_forward with its INPUT produced on the fly: y = conv3x3x3(relu(pre_scale * conv1x1x1(x, pre_w) + pre_shift)) -- the pair
+ * conv3d_2b_1x1 -> conv3d_2c_3x3 of the backbone (models/i3dpt.py:207-209) without the tensor between them.  x [N,D,H,W,pre_cin]
+ * (d->x_cstride / x_coff describe it), pre_w_packed = step_conv_pack_weight of the [d->Cin, pre_cin, 1,1,1] weight, d->Cin = its
+ * output channels.  The pointwise layer is evaluated per halo pixel while the 3x3x3 kernel stages its input tile (same K order and
+ * the same 16-bit rounding as the separate launch: results are bit-identical to step_conv_forward twice).  Today: 16-bit storage,
+ * pre_cin = d->Cin = 64, layers the planner sends to the two-phase conv_tap form; anything else returns STEP_E_UNSUPPORTED and the
+ * caller launches the two layers separately. */
+STEP_API int step_conv_forward_pre(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
+                                   const void* pre_w_packed, const float* pre_scale, const float* pre_shift, int pre_cin, void* y,
+                                   step_stream_t stream);
+
 typedef struct step_conv_item {
     const step_conv_desc* desc;
     const void* x; const void* w_packed; const float* scale; const float* shift; const void* res; void* y;

@@ -669,6 +669,33 @@ def wgrad_sync():
     del _KEEP[:]
 
 
+FUSE_POINTWISE_INPUT = True    # inference: a 64 -> 64 1x1x1 unit directly in front of a 3x3x3 unit runs inside that unit's launch (ops.conv_forward_pre)
+
+
+def _pointwise_then_3x3x3(a, b, x):
+    """Unit3D a (1x1x1, BN, ReLU) followed by Unit3D b (3x3x3): one launch when neither needs autograd and the library has the fused
+    form for the shapes (16-bit, 64 -> 64 pointwise); None otherwise -- the caller runs the units one after the other (same result,
+    bit for bit)."""
+    if not (isinstance(a, Unit3D) and isinstance(b, Unit3D)) or a.is_stem or b.is_stem or not x.is_cuda or x.dtype == torch.float32:
+        return None
+    ua, ub = a._unit, b._unit
+    if tuple(ua.k) != (1, 1, 1) or tuple(ub.k) != (3, 3, 3) or not a.relu or ua.cout != 64 or x.shape[-1] != 64:
+        return None
+    for u in (ua, ub):
+        w = u.weight_fn()
+        if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (u.bias_fn is not None and u.bias_fn().requires_grad)
+                                        or (u.bn is not None and (u.bn.weight.requires_grad or u.bn.bias.requires_grad))):
+            return None
+    sa, ha = ua.affine()
+    sb, hb = ub.affine()
+    if sa is None or ha is None:
+        return None
+    ha = ha.detach().contiguous()
+    if hb is not None:
+        hb = hb.detach().contiguous()
+    return ops.conv_forward_pre(x, ub.packed(x.dtype), ub.cout, ub.k, sb, hb, b.relu, (ua.packed(x.dtype), sa.detach().contiguous(), ha, ua.cout))
+
+
 BRANCH_STREAMS = 0       # Inception blocks (inference path): 0 = one stream + the grouped 3x3x3 launch (default since round 3, see Mixed.forward); 1 / 2 = side branches on 1 / 2 side streams
 WGRAD_SIDE_STREAM = True # training: weight gradient beside the data gradient
 _SIDE = {}
@@ -839,8 +866,18 @@ class BaseNet(nn.Module):
         if x.dim() != 5 or x.shape[2] != 3:
             raise RuntimeError("BaseNet expects [batch, T, 3, H, W]")
         y = x.contiguous()
-        for st in self.base_model:
+        stages = list(self.base_model)
+        i = 0
+        while i < len(stages):
+            st = stages[i]
+            if FUSE_POINTWISE_INPUT and i + 1 < len(stages):
+                z = _pointwise_then_3x3x3(st, stages[i + 1], y)          # conv3d_2b evaluated inside conv3d_2c's halo staging
+                if z is not None:
+                    y = z
+                    i += 2
+                    continue
             y = st(y)
+            i += 1
         return y.permute(0, 1, 4, 2, 3)
 
     def train(self, mode=True):

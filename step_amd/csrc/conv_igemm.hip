@@ -811,6 +811,7 @@ static int conv_fill_params(const step_conv_desc* d, const void* x, const void* 
                 (!res || ((d->res_cstride % 8 == 0) && (d->res_coff % 8 == 0) && (((uintptr_t)res) % 16 == 0))) &&
                 (!split || ((split % 8 == 0) && (d->y2_cstride % 8 == 0) && (d->y2_coff % 8 == 0) && (((uintptr_t)y2) % 16 == 0)));
     p.nblk32 = ceil_div(d->Cout, 32);
+    p.pre_w = nullptr; p.pre_scale = nullptr; p.pre_shift = nullptr;
     p.Mtot = (long long)d->N * d->D * d->H * d->W;
 #ifdef STEP_PROBE
     p.probe = step::g_probe_buf;
@@ -830,6 +831,25 @@ int step_conv_forward_ws(const step_conv_desc* d, const void* x, const void* w_p
         case STEP_F16: return conv_forward_t<f16_t>(&canon, p, ws, ws_bytes, stream);
     }
     return STEP_E_DTYPE;
+}
+
+int step_conv_forward_pre(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
+                          const void* pre_w_packed, const float* pre_scale, const float* pre_shift, int pre_cin, void* y, step_stream_t stream) {
+    step_conv_desc canon;
+    ConvParams p;
+    const int rc = conv_fill_params(d, x, w_packed, scale, shift, nullptr, y, nullptr, canon, p);
+    if (rc != STEP_OK) return rc;
+    if (!pre_w_packed) return STEP_E_NULL;
+    // the fused form exists for what the backbone needs: 64 -> 64 pointwise in front of a 16-bit 3x3x3 conv on the two-phase kernel
+    if (pre_cin != 64 || canon.Cin != 64 || canon.dtype == STEP_F32 || canon.split || !(canon.kd == 3 && canon.kh == 3 && canon.kw == 3))
+        return STEP_E_UNSUPPORTED;
+    if (((uintptr_t)pre_w_packed % 16) || (pre_scale && ((uintptr_t)pre_scale % 16)) || (pre_shift && ((uintptr_t)pre_shift % 16))) return STEP_E_ALIGN;
+    if (p.N == 0) return STEP_OK;
+    if ((unsigned long long)p.Mtot * (unsigned long long)canon.x_cstride >= 0xffffffffULL) return STEP_E_UNSUPPORTED;      // 32-bit element offsets
+    const ConvPlan pl = conv_plan(&canon);
+    if (!pl.ok || pl.impl != 1 || pl.ph != 1 || pl.wv != 8 || pl.tps != 2 || (pl.twl != 0 && pl.twl != 3)) return STEP_E_UNSUPPORTED;
+    p.pre_w = pre_w_packed; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
+    return canon.dtype == STEP_BF16 ? conv_forward_t<bf16_t>(&canon, p, nullptr, 0, stream) : conv_forward_t<f16_t>(&canon, p, nullptr, 0, stream);
 }
 
 // Can these convs share one grid?  All 16-bit 3x3x3 layers the planner sends to the two-phase conv_tap form on general boxes
@@ -1036,7 +1056,7 @@ int step_conv_plan_info(const step_conv_desc* d, int* info, int n) {
 __attribute__((visibility("default"))) void step_probe_set(void* buf) { step::g_probe_buf = (unsigned long long*)buf; }
 #endif
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 23; }
+int step_abi_version(void) { return 24; }
 
 }  // extern "C"
 

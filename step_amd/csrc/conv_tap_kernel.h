@@ -45,9 +45,16 @@ namespace step {
 // threads; the halo slab is shared and re-staged between slabs with the groups realigned.  No fragment double-buffering
 // (a wave's L and C phases alternate) -- same accumulation order as the classic form, bit-identical results.
 // PH = 1: group = wave / 4 (waves w and w + 4 share a SIMD), PH = 2: group = wave & 1.
-template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB, int WV, int PH = 0, bool GRP = false>
+// PRE (two-phase form only): the conv's input is produced on the fly -- a pointwise 64 -> 64 conv + affine + ReLU (conv3d_2b in
+// front of conv3d_2c, models/i3dpt.py:207-209) applied to every halo pixel while the halo is staged: the wave reads the raw pixels
+// (p.x: the tensor BEFORE the pointwise layer) straight from global memory in MFMA operand layout, multiplies them by the pointwise
+// weights of the slab's 32 channels (4 K-steps), and stores affine + ReLU + 16-bit rounding of the result into the halo slab --
+// exactly the values the separate layer would have written to memory (same K order, same rounding), zeros outside the image.
+// The intermediate tensor never exists: -2 x 51 MB of traffic and one launch per C2 step for +3 % matrix work in this kernel.
+template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB, int WV, int PH = 0, bool GRP = false, bool PRE = false>
 __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
     static_assert(MB == 2 && (WV == 8 || WV == 4), "two accumulator rows per wave; 8 or 4 waves");
+    static_assert(!PRE || (PH == 1 && sizeof(T) == 2), "the fused pointwise input exists for the two-phase 16-bit form");
     static_assert(PH == 0 || (WV == 8 && TPS == 2 && sizeof(T) == 2), "two-phase form: 8 waves, two taps per step, 16-bit storage");
     constexpr int NT = WV * 64;                 // threads
     constexpr int WM = WV / 2;                  // waves along the pixel axis (x 2 along channels)
@@ -108,11 +115,14 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
     constexpr bool TR = (ES == 2);
     constexpr int SS_BYTES = TR ? NBT * 32 * 2 * 4 : 0;                       // fp32 scale | shift of the tile's channels
     constexpr int BBYTES = PH ? 2 * 2 * TPS * (NB * KS * FRAGB) : 3 * BSTEP;    // two-phase form: two groups x a ring of two half-step buffers
-    constexpr int LDS_BYTES = NPIX_MAX * PITCH + BBYTES + SS_BYTES;
+    constexpr int STASH_BYTES = PRE ? NPIX_MAX * 64 : 0;                      // PRE: the second slab's 32 channels wait here (dense 64-byte pixels)
+    constexpr int LDS_BYTES = NPIX_MAX * PITCH + BBYTES + SS_BYTES + STASH_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     unsigned char* const ldsA = lds;
     unsigned char* const ldsB = lds + NPIX_MAX * PITCH;
     float* const ldsS = (float*)(lds + NPIX_MAX * PITCH + BBYTES);
+    unsigned char* const ldsP = lds + NPIX_MAX * PITCH + BBYTES + SS_BYTES;
     // tile pixel index m (accumulator row) -> box coordinates, and whether the row holds a pixel of the box at all.
     // General boxes, linear mode: rows past the box alias pixel 0.  General boxes, p.gmode = 1 (box widths just below a multiple
     // of 16: the 14- and 28-wide C2 maps, 13): the 16 lanes of every ds_read_b128 service group ({0-3,12-15,20-27} and
@@ -265,6 +275,88 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
         }
     };
 
+    // ---- PRE: per-wave table of the halo's 32-pixel blocks (block b = wave + bi * WV): element offset of lane's pixel or ~0u
+    constexpr int PBLK = (NPIX_MAX + 31) / 32, PBW = (PBLK + WV - 1) / WV;
+    unsigned poff[PRE ? PBW : 1];
+    auto build_poff = [&]() {
+#pragma unroll
+        for (int bi = 0; bi < (PRE ? PBW : 0); ++bi) {
+            const int pix = (wave + bi * WV) * 32 + (lane & 31);
+            poff[bi] = ~0u;
+            if (pix < NPIX) {
+                const int plane = pix / HHW, rem = pix % HHW;
+                const int r = rem / HW_, cc = rem % HW_;
+                const int id = d0 + plane - KD / 2, ih = h0 + r - KH / 2, iw = w0 + cc - KW / 2;
+                if (id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && cc < HWV)
+                    poff[bi] = (unsigned)(((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.x_cstride + p.x_coff);
+            }
+        }
+    };
+    // slab 0: ONE read of the raw pixels (operand-layout loads touch 32 cache lines per instruction: the expensive part) feeds both
+    // 32-channel slabs -- slab 0's values go to the halo slab, slab 1's wait in ldsP; slab 1: an LDS -> LDS copy
+    auto stage_pre = [&](int slab) {
+        if constexpr (PRE) {
+            if (slab != 0) {
+#pragma unroll 1
+                for (int v = tid; v < NPIX * 4; v += NT)
+                    *(u32x4*)(ldsA + (v >> 2) * PITCH + (v & 3) * 16) = *(const u32x4*)(ldsP + v * 16);
+                return;
+            }
+            constexpr int PKS = 4;                                           // K-steps of the pointwise layer: 64 input channels
+            frag_t fap[PBW][PKS];
+#pragma unroll
+            for (int bi = 0; bi < PBW; ++bi) {                               // every request first: one memory round trip
+                const T* src = xg + (poff[bi] != ~0u ? poff[bi] : 0u) + 8 * khalf;
+#pragma unroll
+                for (int s = 0; s < PKS; ++s) fap[bi][s] = *(const frag_t*)(src + 16 * s);
+            }
+#pragma unroll
+            for (int nbk = 0; nbk < 2; ++nbk) {
+                const unsigned char* pw = (const unsigned char*)p.pre_w + ((size_t)nbk * PKS) * FRAGB + lane * 16;   // n-block nbk (taps_padded(1) = 1)
+                frag_t fbp[PKS];
+#pragma unroll
+                for (int s = 0; s < PKS; ++s) fbp[s] = *(const frag_t*)(pw + s * FRAGB);
+                f32x4 sc[4], sh[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+                    sc[g] = p.pre_scale ? *(const f32x4*)(p.pre_scale + nbk * 32 + 8 * g + 4 * khalf) : one;
+                    sh[g] = p.pre_shift ? *(const f32x4*)(p.pre_shift + nbk * 32 + 8 * g + 4 * khalf) : zero;
+                }
+#pragma unroll
+                for (int bi = 0; bi < PBW; ++bi) {
+                    const int pix = (wave + bi * WV) * 32 + (lane & 31);
+                    if ((wave + bi * WV) * 32 >= NPIX) continue;             // (wave-uniform)
+                    f32x16 a;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < PKS; ++s) mma_k16(fbp[s], fap[bi][s], a, T());   // weights first: a lane owns its pixel's channels 8g + 4 khalf + {0..3}
+                    const bool inb = poff[bi] != ~0u;
+                    unsigned d[4][2];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] = fmaxf(a[4 * g + e] * sc[g][e] + sh[g][e], 0.f); v[e] = inb ? v[e] : 0.f; }
+                        d[g][0] = (unsigned)elem<T>::bits16(v[0]) | ((unsigned)elem<T>::bits16(v[1]) << 16);
+                        d[g][1] = (unsigned)elem<T>::bits16(v[2]) | ((unsigned)elem<T>::bits16(v[3]) << 16);
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        lane32_swap(d[2 * h][0], d[2 * h + 1][0]);
+                        lane32_swap(d[2 * h][1], d[2 * h + 1][1]);
+                        if (pix < NPIX) {
+                            const u32x4 o = {d[2 * h][0], d[2 * h][1], d[2 * h + 1][0], d[2 * h + 1][1]};
+                            unsigned char* dst = nbk == 0 ? ldsA + pix * PITCH : ldsP + pix * 64;
+                            *(u32x4*)(dst + (16 * h + 8 * khalf) * ES) = o;
+                        }
+                    }
+                }
+            }
+        }
+    };
+
     if constexpr (PH != 0) {
         // ---- two-phase pipeline (see the header comment).  A slab's steps are unrolled: tap shifts and ring-buffer offsets
         // are immediates of the ds_reads (measured: the scalar / branch code of the rolled loop cost ~290 cycles per phase,
@@ -395,9 +487,9 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
         __builtin_amdgcn_sched_barrier(0);
 #endif
         ss_load();
-        build_goff();
+        if constexpr (PRE) build_poff(); else build_goff();
         STEP_PROBE_MARK(p, 5);
-        stage_A(0);
+        if constexpr (PRE) stage_pre(0); else stage_A(0);
         ss_store();
         STEP_PROBE_MARK(p, 6);
         if (act) {
@@ -412,7 +504,7 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
         for (int slab = 0; slab < nslab; ++slab) {
             if (slab) {                                    // slab switch: realign the groups, re-stage the halo
                 if (grp == 0) __syncthreads();            // (group 1's last C phase of the previous slab)
-                stage_A(slab);
+                if constexpr (PRE) stage_pre(slab); else stage_A(slab);
                 __syncthreads();
             }
             if (grp == 1) __syncthreads();                // anti-phase: group 1 runs one phase behind group 0
@@ -727,6 +819,14 @@ void conv_tap_group_kernel(ConvGroupParams g) {
 }
 
 
+// conv_tap_kernel with the fused pointwise input (PRE, see conv_tap_body)
+template <typename T, int TWL, int NB>
+__global__ __launch_bounds__(512, 2)
+void conv_tap_pre_kernel(ConvParams p) {
+    conv_tap_body<T, TWL, NB, 3, 3, 3, 2, 2, 8, 1, false, true>(p);
+}
+
+
 // The grouped launch plus ONE pointwise conv (conv_pw_body<T, 1, 4>: 128 pixels x 64 channels per 256-thread workgroup; waves 4-7 of
 // such a workgroup leave at once).  On the 14x14 maps the two 3x3x3 convs of an Inception block are 168-224 one-per-CU workgroups
 // of 23-52 us: the block's branch_3 1x1x1 conv (9-11 us as a launch of its own) runs beside them on the idle CUs.
@@ -786,9 +886,26 @@ static int launch_tap_ph(const ConvParams& p, int NB, dim3 grid, step_stream_t s
     return STEP_LAUNCH_CHECK();
 }
 
+template <typename T, int TWL>
+static int launch_tap_pre(const ConvParams& p, int NB, dim3 grid, step_stream_t stream) {
+#define STEP_TAPPRE(NB_) STEP_LAUNCH((conv_tap_pre_kernel<T, TWL, NB_>), grid, dim3(512), stream, p)
+    switch (NB) {
+        case 1: STEP_TAPPRE(1); break;
+        case 2: STEP_TAPPRE(2); break;
+        default: STEP_TAPPRE(3); break;
+    }
+#undef STEP_TAPPRE
+    return STEP_LAUNCH_CHECK();
+}
+
 template <typename T>
 int conv_tap_ph_launch_impl(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream) {
     if (kd != 3 || pl.ph != 1) return STEP_E_UNSUPPORTED;
+    if (p.pre_w) {                                         // fused pointwise input: the general-box and the 4 x 8 x 8 tile forms
+        if (pl.twl == 0) return launch_tap_pre<T, 0>(p, pl.NB, grid, stream);
+        if (pl.twl == 3) return launch_tap_pre<T, 3>(p, pl.NB, grid, stream);
+        return STEP_E_UNSUPPORTED;
+    }
     if (pl.twl == 0) return launch_tap_ph<T, 0>(p, pl.NB, grid, stream);
     if (pl.twl == 3) return launch_tap_ph<T, 3>(p, pl.NB, grid, stream);
     return pl.wide ? launch_tap_ph<T, 5>(p, pl.NB, grid, stream) : launch_tap_ph<T, 4>(p, pl.NB, grid, stream);

@@ -178,6 +178,37 @@ def conv_forward(x, w_packed, Cout, k, scale=None, shift=None, relu=True, res=No
     return out
 
 
+def conv_forward_pre(x, w_packed, Cout, k, scale, shift, relu, pre, out=None):
+    """conv_forward whose input is a pointwise conv + affine + ReLU of x, evaluated on the fly (step_conv_forward_pre: conv3d_2b in
+    front of conv3d_2c; the tensor between them never exists).  pre = (packed pointwise weight, scale, shift, Cmid): x has the
+    pointwise layer's input channels, Cmid = its output channels = this conv's input channels.  Returns None when the library has
+    no fused form for the layer (the caller launches the two layers one after the other); bit-identical to that."""
+    L = _lib.lib()
+    pw, pscale, pshift, cmid = pre
+    N, D, H, W, Cpre = x.shape
+    if out is None:
+        out = torch.empty((N, D, H, W, Cout), dtype=x.dtype, device=x.device)
+    d = _capi.ConvDesc(dtype=_dt(x), N=N, D=D, H=H, W=W, Cin=cmid, Cout=Cout, kd=k[0], kh=k[1], kw=k[2],
+                       x_cstride=_chan_slice(x), x_coff=0, y_cstride=_chan_slice(out), y_coff=0, res_cstride=0, res_coff=0,
+                       relu=int(bool(relu)), split=0, y2_cstride=0, y2_coff=0)
+    info = (ctypes.c_int * 10)()
+    if Cpre != 64 or cmid != 64 or x.dtype == torch.float32 or tuple(k) != (3, 3, 3) or L.step_conv_plan_info(ctypes.byref(d), info, 10) != 0 \
+            or not (info[0] == 1 and info[4] == 1 and info[3] == 8 and info[1] in (0, 3)):
+        return None                                                      # (the same test step_conv_forward_pre makes: STEP_E_UNSUPPORTED)
+
+    def launch():
+        _capi.check(L.step_conv_forward_pre(ctypes.byref(d), _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift), _lib.dptr(pw),
+                                            _lib.dptr(pscale), _lib.dptr(pshift), int(Cpre), _lib.dptr(out), _lib.stream_ptr(x.device)),
+                    "step_conv_forward_pre")
+
+    def describe():
+        pix = N * D * H * W
+        return ("void step::conv_tap_pre_kernel<%s, %d, %d>(step::ConvParams)" % (_TNAME[x.dtype], info[1], info[2]),
+                2.0 * pix * (Cout * cmid * 27 + cmid * Cpre), (pix * (Cpre + Cout) + Cout * cmid * 27 + cmid * Cpre) * _ES[x.dtype])
+    _run(launch, describe)
+    return out
+
+
 def conv_forward_group(members):
     """Several INDEPENDENT convs as one launch where the library can merge them (step_conv_forward_group: today two 16-bit 3x3x3
     layers of the two-phase conv_tap form -- an Inception block's branch_1 / branch_2 convs -- plus, on small maps, one pointwise

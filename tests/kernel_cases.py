@@ -1311,6 +1311,52 @@ def case_conv_group_with_pointwise_member(bk, golden):
     assert bk.lib.step_conv_group_kernel_name(items, 2, buf, 256) == 0
 
 
+def case_conv_forward_pre_matches_two_launches(bk, golden):
+    """step_conv_forward_pre (conv3d_2b evaluated inside conv3d_2c's halo staging) against the two layers launched one after the
+    other: bit-identical outputs on the 4 x 8 x 8 tile form (with its NB = 1 tail launch) and on general boxes, image borders and
+    ragged tiles included; shapes outside the fused form's contract are refused with STEP_E_UNSUPPORTED."""
+    rs = np.random.RandomState(57)
+    info = (ctypes.c_int * 10)()
+    seen = set()
+    for dt, (N, D, H, W), Cout, opts in ((BF16, (1, 4, 24, 24), 192, dict(conv_slots=4, conv_nb=3, conv_waves=8)),
+                                         (F16, (3, 8, 14, 14), 200, {}), (BF16, (1, 5, 21, 19), 96, dict(conv_waves=8))):
+        x = rs.randn(N, 64, D, H, W).astype(np.float32)
+        wa = (rs.randn(64, 64, 1, 1, 1) / 8).astype(np.float32)
+        wb = (rs.randn(Cout, 64, 3, 3, 3) / np.sqrt(64 * 27)).astype(np.float32)
+        sa, ha = (1 + 0.1 * rs.randn(64)).astype(np.float32), (0.2 * rs.randn(64)).astype(np.float32)
+        sb, hb = (1 + 0.1 * rs.randn(Cout)).astype(np.float32), (0.2 * rs.randn(Cout)).astype(np.float32)
+        xe = bk.dev(encode(cl(x), dt))
+        wpa, wpb = pack_weight(bk, wa, dt), pack_weight(bk, wb, dt)
+        dsa, dha, dsb, dhb = bk.dev(sa), bk.dev(ha), bk.dev(sb), bk.dev(hb)
+        da = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=64, Cout=64, kd=1, kh=1, kw=1, x_cstride=64, x_coff=0, y_cstride=64, y_coff=0,
+                            res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+        db = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=64, Cout=Cout, kd=3, kh=3, kw=3, x_cstride=64, x_coff=0, y_cstride=Cout, y_coff=0,
+                            res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+        with _capi.options(bk.lib, **opts):
+            assert bk.lib.step_conv_plan_info(ctypes.byref(db), info, 10) == 0
+            mid = bk.dev(np.zeros((N, D, H, W, 64), NP_DT[dt]))
+            y2 = bk.dev(np.zeros((N, D, H, W, Cout), NP_DT[dt]))
+            assert bk.lib.step_conv_forward(ctypes.byref(da), xe.ptr, wpa.ptr, dsa.ptr, dha.ptr, None, mid.ptr, None, bk.stream) == 0
+            assert bk.lib.step_conv_forward(ctypes.byref(db), mid.ptr, wpb.ptr, dsb.ptr, dhb.ptr, None, y2.ptr, None, bk.stream) == 0
+            y1 = bk.dev(np.full((N, D, H, W, Cout), 7, NP_DT[dt]))
+            rc = bk.lib.step_conv_forward_pre(ctypes.byref(db), xe.ptr, wpb.ptr, dsb.ptr, dhb.ptr, wpa.ptr, dsa.ptr, dha.ptr, 64, y1.ptr, bk.stream)
+        fusable = info[0] == 1 and info[4] == 1 and info[3] == 8 and info[1] in (0, 3)
+        assert rc == (0 if fusable else -4), (rc, list(info))
+        if fusable:
+            seen.add(info[1])
+            assert np.array_equal(y1.get(), y2.get()), (dt, N, D, H, W, Cout, list(info))
+            ref = ref_conv(np.maximum(ref_conv(x, wa, sa, ha, dt), 0).astype(np.float32), wb, sb, hb, dt)
+            got = uncl(decode(y1.get(), dt))
+            assert np.abs(got - ref).max() / np.abs(ref).max() < 3 * tol(dt), dt
+    assert seen == {0, 3}, seen                                  # both tile forms were exercised
+    # outside the contract: a 32-channel pointwise layer, fp32 storage, a null pointwise weight
+    assert bk.lib.step_conv_forward_pre(ctypes.byref(db), xe.ptr, wpb.ptr, dsb.ptr, dhb.ptr, wpa.ptr, dsa.ptr, dha.ptr, 32, y1.ptr, bk.stream) == -4
+    assert bk.lib.step_conv_forward_pre(ctypes.byref(db), xe.ptr, wpb.ptr, dsb.ptr, dhb.ptr, None, dsa.ptr, dha.ptr, 64, y1.ptr, bk.stream) == -3
+    df = _capi.ConvDesc(dtype=F32, N=1, D=4, H=8, W=8, Cin=64, Cout=64, kd=3, kh=3, kw=3, x_cstride=64, x_coff=0, y_cstride=64, y_coff=0,
+                        res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+    assert bk.lib.step_conv_forward_pre(ctypes.byref(df), xe.ptr, wpb.ptr, dsb.ptr, dhb.ptr, wpa.ptr, dsa.ptr, dha.ptr, 64, y1.ptr, bk.stream) == -4
+
+
 def case_mfma_clock_probe(bk, golden):
     """step_mfma_clock_probe (the diagnostic behind bench.py's `sustained_on_this_box`): every workgroup reports its loop; on the
     interpreter the counters read 0, on the GPU the clock lies in the part's range and the matrix pipe issues one 32x32x16 per

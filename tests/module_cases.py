@@ -1098,6 +1098,16 @@ def case_c2_full_size_properties(dev, golden):
         e = rel(np_(y1), np_(yf))
         record("c2_full_size_bf16_vs_fp32", e)
         assert e < 1e-2, e
+        # conv3d_2b evaluated inside conv3d_2c's launch (backbone.FUSE_POINTWISE_INPUT, ops.conv_forward_pre) == the two units
+        # launched one after the other, BIT-EXACT (same K order, same 16-bit rounding of the tensor between them)
+        from step_amd import backbone as _bb
+        assert _bb.FUSE_POINTWISE_INPUT
+        try:
+            _bb.FUSE_POINTWISE_INPUT = False
+            y8u = net(xb)
+        finally:
+            _bb.FUSE_POINTWISE_INPUT = True
+        assert torch.equal(y8u, y8), float((y8u.float() - y8.float()).abs().max())
 
 
 def case_c5_full_size_properties(dev, golden):
