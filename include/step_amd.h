@@ -251,6 +251,15 @@ STEP_API int step_conv_forward(const step_conv_desc* d, const void* x, const voi
  * same grid and run on the CUs the 3x3x3 members leave idle or free first (the 14x14 maps: 168-256 one-per-CU workgroups of very
  * different lengths) instead of as a 9-20 us launch of their own (option conv_group_pw: the workgroup limit, 0 = always separate;
  * bit-identical). */
+/* An Inception block's max pool (3x3x3, stride 1, TF SAME: models/i3dpt.py:151-155) and a pointwise conv (the block's fused 1x1x1
+ * triple, `split` allowed) as ONE launch: both read the block input, neither fills the chip on small maps, and in one grid the
+ * workgroups of the two run side by side instead of one launch waiting for the other.  pool: x [N,D,H,W,C] -> pool_y (same shape);
+ * conv: step_conv_forward(d, cx, ...) semantics.  Results are bit-identical to step_maxpool3d_tf + step_conv_forward.  16-bit
+ * storage and pointwise layers the planner streams only; otherwise STEP_E_UNSUPPORTED (the caller launches the two separately). */
+STEP_API int step_pool_conv_forward(int dtype, const void* x, int N, int D, int H, int W, int C, int x_cstride, int x_coff, void* pool_y,
+                                    int py_cstride, int py_coff, const step_conv_desc* d, const void* cx, const void* w_packed,
+                                    const float* scale, const float* shift, void* y, void* y2, step_stream_t stream);
+
 /* step_conv_forward with its INPUT produced on the fly: y = conv3x3x3(relu(pre_scale * conv1x1x1(x, pre_w) + pre_shift)) -- the pair
  * conv3d_2b_1x1 -> conv3d_2c_3x3 of the backbone (models/i3dpt.py:207-209) without the tensor between them.  x [N,D,H,W,pre_cin]
  * (d->x_cstride / x_coff describe it), pre_w_packed = step_conv_pack_weight of the [d->Cin, pre_cin, 1,1,1] weight, d->Cin = its

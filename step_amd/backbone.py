@@ -523,7 +523,7 @@ class _FusedPointwise:
         r.owner, r._src, r._cache = owner, self._src or self, self._cache
         return r
 
-    def __call__(self, x, out, out2):
+    def __call__(self, x, out, out2, pool=False):
         us = self._units(self.owner)
         dev = us[0].conv3d.weight.device
         key = (x.dtype, dev)
@@ -540,7 +540,13 @@ class _FusedPointwise:
                 hit = (ver, ops.pack_conv_weight(w, x.dtype), scale, shift, w.shape[0], us[0].conv3d.weight.shape[0])
             self._cache[key] = hit
         _, packed, scale, shift, cout, split = hit
+        if pool:
+            # the block's 3x3x3 / 1 max pool rides in the same grid where the library has that form (the 14x14 maps): returns the pooled x
+            p = ops.pool_conv_forward(x, packed, cout, scale, shift, True, out, out2, split)
+            if p is not None:
+                return p
         ops.conv_forward(x, packed, cout, (1, 1, 1), scale, shift, True, None, out, out2, split)
+        return None
 
 
 class Mixed(nn.Module):
@@ -581,8 +587,10 @@ class Mixed(nn.Module):
             # single-stream graph runs its kernels back to back with no gap -- 1469 us against 1477 / 1505 us with 1 / 2 side streams.
             # branch_3's 1x1x1 conv on the pooled tensor travels as a third member: on the 14x14 maps the two 3x3x3 convs leave
             # 32-88 CUs idle and the library appends its workgroups to their grid (elsewhere it is launched behind them)
-            p = self.branch_3[0](x)
-            self._fused(x, out[..., :c0], t)
+            pool = self.branch_3[0]
+            p = self._fused(x, out[..., :c0], t, pool=POOL_WITH_POINTWISE and pool.kernel_size == (3, 3, 3) and pool.stride == (1, 1, 1))
+            if p is None:
+                p = pool(x)
             u1, u2, u3 = self.branch_1[1]._unit, self.branch_2[1]._unit, self.branch_3[1]._unit
             m = []
             for u, xin, o in ((u1, t[..., :oc[1]], out[..., c0:c1]), (u2, t[..., oc[1]:], out[..., c1:c2]), (u3, p, out[..., c2:])):
@@ -669,6 +677,7 @@ def wgrad_sync():
     del _KEEP[:]
 
 
+POOL_WITH_POINTWISE = True     # inference: an Inception block's max pool and its fused 1x1x1 triple as one launch where the library has the form
 FUSE_POINTWISE_INPUT = True    # inference: a 64 -> 64 1x1x1 unit directly in front of a 3x3x3 unit runs inside that unit's launch (ops.conv_forward_pre)
 
 

@@ -833,6 +833,37 @@ int step_conv_forward_ws(const step_conv_desc* d, const void* x, const void* w_p
     return STEP_E_DTYPE;
 }
 
+int step_pool_conv_forward(int dtype, const void* x, int N, int D, int H, int W, int C, int x_cstride, int x_coff, void* pool_y, int py_cstride,
+                           int py_coff, const step_conv_desc* d, const void* cx, const void* w_packed, const float* scale, const float* shift,
+                           void* y, void* y2, step_stream_t stream) {
+    if (N < 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return STEP_E_SHAPE;
+    if (x_coff < 0 || x_coff + C > x_cstride || py_coff < 0 || py_coff + C > py_cstride) return STEP_E_SHAPE;
+    step_conv_desc canon;
+    ConvParams p;
+    const int rc = conv_fill_params(d, cx, w_packed, scale, shift, nullptr, y, y2, canon, p);
+    if (rc != STEP_OK) return rc;
+    if (N == 0 && p.N == 0) return STEP_OK;
+    if (!x || !pool_y) return STEP_E_NULL;
+    // both halves on their combined form only: a 16-bit pointwise conv the planner streams (conv_pw_kernel), run here at NB = 1 with
+    // four waves -- other instantiations of the same kernel, the same K order per output: bit-identical to the separate launch
+    if (N == 0 || p.N == 0 || canon.dtype != dtype || dtype == STEP_F32 || !(canon.kd == 1 && canon.kh == 1 && canon.kw == 1)) return STEP_E_UNSUPPORTED;
+    constexpr int VEC = 8;
+    if (canon.Cin % VEC || canon.x_cstride % VEC || canon.x_coff % VEC || ((uintptr_t)p.x % 16) || ((uintptr_t)p.w % 16) || ((uintptr_t)x % 16) ||
+        ((uintptr_t)pool_y % 16))
+        return STEP_E_UNSUPPORTED;
+    // (layers the planner gives deeper accumulators -- the 28x28 triples -- keep their own launch: at NB = 1 they would re-read the
+    // input three times)
+    const ConvPlan pl = conv_plan(&canon, false);
+    if (!pl.ok || pl.impl != 2 || pl.NB != 1) return STEP_E_UNSUPPORTED;
+    p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.tiles_d = pl.tiles_d;
+    p.gtd = pl.gtd; p.gth = pl.gth; p.gtw = pl.gtw; p.gmode = pl.gmode;
+    const long long mtiles = ceil_div64(p.Mtot, 128);
+    const int groups = ceil_div(p.nblk32, 2);
+    p.gx = (int)mtiles; p.gy = groups;
+    const long long tot = (mtiles * groups + 7) / 8 * 8;
+    return pool333_pw_launch(dtype, x, N, D, H, W, C, x_cstride, x_coff, pool_y, py_cstride, py_coff, p, tot, stream);
+}
+
 int step_conv_forward_pre(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
                           const void* pre_w_packed, const float* pre_scale, const float* pre_shift, int pre_cin, void* y, step_stream_t stream) {
     step_conv_desc canon;
@@ -1056,7 +1087,7 @@ int step_conv_plan_info(const step_conv_desc* d, int* info, int n) {
 __attribute__((visibility("default"))) void step_probe_set(void* buf) { step::g_probe_buf = (unsigned long long*)buf; }
 #endif
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 24; }
+int step_abi_version(void) { return 25; }
 
 }  // extern "C"
 

@@ -8,6 +8,7 @@
 // (models/two_branch.py:127).  Both are pure HBM-bound streaming ops: lanes run along C in
 // 16-byte vectors, so every tap is a fully coalesced row segment.
 #include "common.h"
+#include "conv_pw_kernel.h"
 #include "pool_vec.h"
 #include "options.h"
 #include <stdlib.h>
@@ -102,9 +103,10 @@ constexpr int PP_SL = 4;                            // 16-byte vectors per pixel
 constexpr int PP_R = 4;                             // load items per thread per plane: 16*16*4 / 256
 constexpr int PP_MAXIN = 16;                        // max input tile edge
 
+// (body as a device function: `bid` of `nblk` workgroups -- pool333_pw_kernel carries these workgroups in front of a pointwise conv's)
 template <typename T, int KD, int KH, int KW, int SD, int SH, int SW, int NT>
-__global__ __launch_bounds__(NT) void maxpool_sep_kernel(const T* __restrict__ x, T* __restrict__ y, PoolParams p,
-                                                          int TH, int TW, int tiles_h, int tiles_w, int cchunks, int dseg, int nseg) {
+__device__ __forceinline__ void maxpool_sep_body(const T* __restrict__ x, T* __restrict__ y, const PoolParams& p,
+                                                 int TH, int TW, int tiles_h, int tiles_w, int cchunks, int dseg, int nseg, int bid, int nblk) {
     constexpr int V = elem<T>::VEC;
     typedef typename Vec16<T, V>::raw raw;
     constexpr int SL = PP_SL, R = PP_R * 256 / NT;        // NT = 256: 4 items per thread per pass, NT = 1024: 1
@@ -114,8 +116,8 @@ __global__ __launch_bounds__(NT) void maxpool_sep_kernel(const T* __restrict__ x
     const int tid = threadIdx.x;
     // launch order -> XCD: consecutive workgroup ids go round-robin over the 8 XCDs; remap so that ids that
     // are neighbours in (tile, D segment) order -- which share halos -- land on the same XCD (one L2)
-    int t = blockIdx.x;
-    if ((gridDim.x & 7) == 0) t = (t & 7) * (gridDim.x >> 3) + (t >> 3);
+    int t = bid;
+    if ((nblk & 7) == 0) t = (t & 7) * (nblk >> 3) + (t >> 3);
     // channel chunk fastest: a chunk is 64 bytes -- half a 128-byte line -- so the two chunks of a line are neighbours in launch
     // order on ONE XCD (the second one's loads hit that L2) instead of being fetched by two XCDs (measured: maxPool3d_2a 64 -> 45 us)
     const int cc = t % cchunks; t /= cchunks;
@@ -250,6 +252,23 @@ __global__ __launch_bounds__(NT) void maxpool_sep_kernel(const T* __restrict__ x
     raw rg[R];
     load_plane(pbeg, rg);
     for (int pd = pbeg; pd < pend; ++pd) step(pd, rg);
+}
+
+template <typename T, int KD, int KH, int KW, int SD, int SH, int SW, int NT>
+__global__ __launch_bounds__(NT) void maxpool_sep_kernel(const T* __restrict__ x, T* __restrict__ y, PoolParams p,
+                                                          int TH, int TW, int tiles_h, int tiles_w, int cchunks, int dseg, int nseg) {
+    maxpool_sep_body<T, KD, KH, KW, SD, SH, SW, NT>(x, y, p, TH, TW, tiles_h, tiles_w, cchunks, dseg, nseg, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The 3x3x3 / 1 pool of an Inception block AND the block's fused 1x1x1 convs in ONE grid: both read the block input, neither fills
+// the chip on the 14x14 maps (the pool is 512 latency-bound workgroups, the convs 245-490) and one used to wait for the other.  The
+// pool's workgroups come first, the 256-thread workgroups of conv_pw_body<T, 1, 4> behind them (cp.gbase = npool); 32 + 43 KB of LDS:
+// two workgroups of either kind per CU.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void pool333_pw_kernel(const T* __restrict__ x, T* __restrict__ y, PoolParams p, int TH, int TW, int tiles_h,
+                                                            int tiles_w, int cchunks, int dseg, int nseg, int npool, ConvParams cp) {
+    if ((int)blockIdx.x < npool) maxpool_sep_body<T, 3, 3, 3, 1, 1, 1, 256>(x, y, p, TH, TW, tiles_h, tiles_w, cchunks, dseg, nseg, (int)blockIdx.x, npool);
+    else conv_pw_body<T, 1, 4>(cp);
 }
 
 // Backward of the TF-SAME max pool (training): the gradient of an output goes to the FIRST maximum of its window in
@@ -491,10 +510,34 @@ __global__ void transpose_cs_kernel(const TS* __restrict__ src, TD* __restrict__
     }
 }
 
-static inline unsigned flat_grid(long long total, int block) {
+static inline unsigned pool_flat_grid(long long total, int block) {
     long long g = ceil_div64(total, block);
     if (g > 16384) g = 16384;
     return (unsigned)g;
+}
+
+// tiling of the separable pool: balanced tiles of at most 14x14 outputs at stride 1 (7x7 at stride 2), 64 bytes of channels per
+// workgroup, D cut into segments
+struct PoolSepPlan { int TH, TW, tiles_h, tiles_w, cchunks, dseg, nseg; long long blocks; };
+static PoolSepPlan pool_sep_plan(const PoolParams& p, int V) {
+    PoolSepPlan sp;
+    const int maxt = p.sh == 1 ? 14 : 7;
+    sp.tiles_h = ceil_div(p.Ho, maxt); sp.tiles_w = ceil_div(p.Wo, maxt); sp.cchunks = ceil_div(p.C, PP_SL * V);
+    sp.TH = ceil_div(p.Ho, sp.tiles_h); sp.TW = ceil_div(p.Wo, sp.tiles_w);
+    sp.blocks = (long long)p.N * sp.tiles_h * sp.tiles_w * sp.cchunks;
+    sp.dseg = p.Do; sp.nseg = 1;
+    if (sp.blocks == 0) return sp;
+    // split D until there are ~1000 workgroups; with kd = 3 every segment re-reads planes of its neighbours,
+    // so keep >= 4 output planes per segment (kd = 1: no dependence along D)
+    constexpr int target = 1024;
+    // (single-tile maps -- the 14x14 stage -- are latency-bound chains of planes, not bandwidth-bound: shorter segments, measured
+    // 14.8 -> 13.8 us per pool; on the 28x28 maps the extra halo planes cost more than the parallelism gives: 25.9 -> 30.2 us)
+    const int minseg = p.kd == 1 ? 1 : (sp.tiles_h * sp.tiles_w == 1 ? 2 : 4);
+    int nseg = 1;
+    while (sp.blocks * nseg < target && p.Do / (nseg * 2) >= minseg) nseg *= 2;
+    sp.dseg = ceil_div(p.Do, nseg);
+    sp.nseg = ceil_div(p.Do, sp.dseg);
+    return sp;
 }
 
 template <typename T>
@@ -505,23 +548,10 @@ static int maxpool_t(const void* x, void* y, const PoolParams& p, step_stream_t 
     const bool sep = (ksig == 333 && ssig == 111) || (ksig == 133 && ssig == 122) || (ksig == 333 && ssig == 222);
     const bool force_direct = opt(STEP_OPT_POOL_DIRECT) != 0;        // tests: the general kernel on the separable shapes
     if (sep && !force_direct) {
-        // balanced tiles: at most 14x14 outputs at stride 1, 7x7 at stride 2; 64 bytes of channels per workgroup
-        const int maxt = p.sh == 1 ? 14 : 7;
-        const int tiles_h = ceil_div(p.Ho, maxt), tiles_w = ceil_div(p.Wo, maxt), cchunks = ceil_div(p.C, PP_SL * V);
-        const int TH = ceil_div(p.Ho, tiles_h), TW = ceil_div(p.Wo, tiles_w);
-        const long long blocks = (long long)p.N * tiles_h * tiles_w * cchunks;
-        if (blocks == 0) return STEP_OK;
-        // split D until there are ~1000 workgroups; with kd = 3 every segment re-reads planes of its neighbours,
-        // so keep >= 4 output planes per segment (kd = 1: no dependence along D)
-        constexpr int target = 1024;
-        // (single-tile maps -- the 14x14 stage -- are latency-bound chains of planes, not bandwidth-bound: shorter segments, measured
-        // 14.8 -> 13.8 us per pool; on the 28x28 maps the extra halo planes cost more than the parallelism gives: 25.9 -> 30.2 us)
-        const int minseg = p.kd == 1 ? 1 : (tiles_h * tiles_w == 1 ? 2 : 4);
-        int nseg = 1;
-        while (blocks * nseg < target && p.Do / (nseg * 2) >= minseg) nseg *= 2;
-        const int dseg = ceil_div(p.Do, nseg);
-        nseg = ceil_div(p.Do, dseg);
-        const dim3 grid((unsigned)(blocks * nseg));
+        const PoolSepPlan sp = pool_sep_plan(p, V);
+        if (sp.blocks == 0) return STEP_OK;
+        const int TH = sp.TH, TW = sp.TW, tiles_h = sp.tiles_h, tiles_w = sp.tiles_w, cchunks = sp.cchunks, dseg = sp.dseg, nseg = sp.nseg;
+        const dim3 grid((unsigned)(sp.blocks * nseg));
 #define STEP_POOL_SEP(KD_, KH_, KW_, SD_, SH_, SW_) \
         STEP_LAUNCH((maxpool_sep_kernel<T, KD_, KH_, KW_, SD_, SH_, SW_, 256>), grid, dim3(256), stream, (const T*)x, (T*)y, p, TH, TW, tiles_h, tiles_w, cchunks, dseg, nseg)
         if (ssig == 111) { STEP_POOL_SEP(3, 3, 3, 1, 1, 1); }
@@ -532,7 +562,7 @@ static int maxpool_t(const void* x, void* y, const PoolParams& p, step_stream_t 
     }
     long long total = (long long)p.N * p.Do * p.Ho * p.Wo * (p.C / V);
     if (total == 0) return STEP_OK;
-    STEP_LAUNCH((maxpool3d_tf_kernel<T>), dim3(flat_grid(total, 256)), dim3(256), stream, (const T*)x, (T*)y, p, total);
+    STEP_LAUNCH((maxpool3d_tf_kernel<T>), dim3(pool_flat_grid(total, 256)), dim3(256), stream, (const T*)x, (T*)y, p, total);
     return STEP_LAUNCH_CHECK();
 }
 
@@ -542,7 +572,7 @@ static int avgpool_t(const void* x, void* y, int N, int D, int H, int W, int C, 
     if (C % V) return STEP_E_ALIGN;
     long long total = (long long)N * D * (H - kh + 1) * (W - kw + 1) * (C / V);
     if (total == 0) return STEP_OK;
-    STEP_LAUNCH((avgpool_hw_kernel<T>), dim3(flat_grid(total, 256)), dim3(256), stream, (const T*)x, (T*)y, N * D, H, W,
+    STEP_LAUNCH((avgpool_hw_kernel<T>), dim3(pool_flat_grid(total, 256)), dim3(256), stream, (const T*)x, (T*)y, N * D, H, W,
                 C, kh, kw, total);
     return STEP_LAUNCH_CHECK();
 }
@@ -557,19 +587,46 @@ static int transpose_t(const void* src, void* dst, int N, int C, long long S, in
 
 template <typename T, typename TG, typename TO>
 static void bwd_gather_launch(const unsigned char* arg, const void* gy, void* gx, const PoolParams& p, long long total, step_stream_t stream) {
-    STEP_LAUNCH((maxpool_bwd_gather_kernel<T, TG, TO>), dim3(flat_grid(total, 256)), dim3(256), stream, arg, (const TG*)gy, (TO*)gx, p, total);
+    STEP_LAUNCH((maxpool_bwd_gather_kernel<T, TG, TO>), dim3(pool_flat_grid(total, 256)), dim3(256), stream, arg, (const TG*)gy, (TO*)gx, p, total);
 }
 template <typename T>
 static int bwd_gather_t(const void* x, int gy_dtype, const void* gy, int gx_dtype, void* gx, unsigned char* arg, const PoolParams& p,
                         step_stream_t stream) {
     constexpr int V = elem<T>::VEC;
     const long long touts = (long long)p.N * p.Do * p.Ho * p.Wo * (p.C / V), tins = (long long)p.N * p.D * p.H * p.W * (p.C / V);
-    STEP_LAUNCH((maxpool_arg_kernel<T>), dim3(flat_grid(touts, 256)), dim3(256), stream, (const T*)x, arg, p, touts);
+    STEP_LAUNCH((maxpool_arg_kernel<T>), dim3(pool_flat_grid(touts, 256)), dim3(256), stream, (const T*)x, arg, p, touts);
     const bool gf = gy_dtype == STEP_F32, of = gx_dtype == STEP_F32;
     if (gf && of) bwd_gather_launch<T, float, float>(arg, gy, gx, p, tins, stream);
     else if (gf) bwd_gather_launch<T, float, T>(arg, gy, gx, p, tins, stream);
     else if (of) bwd_gather_launch<T, T, float>(arg, gy, gx, p, tins, stream);
     else bwd_gather_launch<T, T, T>(arg, gy, gx, p, tins, stream);
+    return STEP_LAUNCH_CHECK();
+}
+
+// the combined launch behind step_pool_conv_forward (conv_igemm.hip prepares the conv's parameter block): 16-bit storage only
+int pool333_pw_launch(int dtype, const void* x, int N, int D, int H, int W, int C, int x_cstride, int x_coff, void* y, int y_cstride, int y_coff,
+                      ConvParams cp, long long conv_blocks, step_stream_t stream) {
+    if (dtype != STEP_BF16 && dtype != STEP_F16) return STEP_E_UNSUPPORTED;
+    constexpr int V = 8;
+    if (C % V || x_cstride % V || x_coff % V || y_cstride % V || y_coff % V) return STEP_E_UNSUPPORTED;
+    PoolParams p;
+    p.N = N; p.D = D; p.H = H; p.W = W; p.C = C; p.x_cstride = x_cstride; p.x_coff = x_coff;
+    p.Do = pool_out_size(D, 3, 1); p.Ho = pool_out_size(H, 3, 1); p.Wo = pool_out_size(W, 3, 1);
+    p.y_cstride = y_cstride; p.y_coff = y_coff;
+    p.kd = p.kh = p.kw = 3; p.sd = p.sh = p.sw = 1;
+    p.pfd = p.pfh = p.pfw = tf_pad_front(3, 1);
+    p.Lpd = D + tf_pad_total(3, 1); p.Lph = H + tf_pad_total(3, 1); p.Lpw = W + tf_pad_total(3, 1);
+    const PoolSepPlan sp = pool_sep_plan(p, V);
+    const long long npool = sp.blocks * sp.nseg;
+    if (npool <= 0 || npool + conv_blocks > 0x7fffffffLL) return STEP_E_UNSUPPORTED;
+    cp.gbase = (int)npool; cp.gcount = (int)conv_blocks;
+    const dim3 grid((unsigned)(npool + conv_blocks));
+    if (dtype == STEP_BF16)
+        STEP_LAUNCH((pool333_pw_kernel<bf16_t>), grid, dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, p, sp.TH, sp.TW, sp.tiles_h, sp.tiles_w, sp.cchunks,
+                    sp.dseg, sp.nseg, (int)npool, cp);
+    else
+        STEP_LAUNCH((pool333_pw_kernel<f16_t>), grid, dim3(256), stream, (const f16_t*)x, (f16_t*)y, p, sp.TH, sp.TW, sp.tiles_h, sp.tiles_w, sp.cchunks,
+                    sp.dseg, sp.nseg, (int)npool, cp);
     return STEP_LAUNCH_CHECK();
 }
 
@@ -620,7 +677,7 @@ int step_maxpool3d_tf_backward(int dtype, const void* x, int N, int D, int H, in
     int rc = (int)hipMemsetAsync(gx, 0, sizeof(float) * (size_t)N * D * H * W * C, (hipStream_t)stream);
     if (rc != 0) return rc;
     const long long total = (long long)N * p.Do * p.Ho * p.Wo * C;
-    const dim3 grid(flat_grid(total, 256));
+    const dim3 grid(pool_flat_grid(total, 256));
     switch (dtype) {
         case STEP_F32: STEP_LAUNCH((maxpool3d_tf_bwd_kernel<float>), grid, dim3(256), stream, (const float*)x, gy, gx, p, total); break;
         case STEP_BF16: STEP_LAUNCH((maxpool3d_tf_bwd_kernel<bf16_t>), grid, dim3(256), stream, (const bf16_t*)x, gy, gx, p, total); break;
@@ -665,7 +722,7 @@ int step_clip_from_u8(const unsigned char* frames, int N, int T, int H, int W, i
     const float m0 = mean3 ? mean3[0] : 0.f, m1 = mean3 ? mean3[1] : 0.f, m2 = mean3 ? mean3[2] : 0.f;   // host pointers (3 floats)
     const float s0 = std3 ? std3[0] : 1.f, s1 = std3 ? std3[1] : 1.f, s2 = std3 ? std3[2] : 1.f;
     const long long fr = (long long)N * T, total = fr * H * W;
-    const dim3 grid(flat_grid(total, 256));
+    const dim3 grid(pool_flat_grid(total, 256));
     switch (dtype) {
         case STEP_F32: STEP_LAUNCH((clip_from_u8_kernel<float>), grid, dim3(256), stream, frames, (float*)clip, H * W, fr, scale, m0, m1, m2, s0, s1, s2, total); break;
         case STEP_BF16: STEP_LAUNCH((clip_from_u8_kernel<bf16_t>), grid, dim3(256), stream, frames, (bf16_t*)clip, H * W, fr, scale, m0, m1, m2, s0, s1, s2, total); break;

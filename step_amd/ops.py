@@ -178,6 +178,35 @@ def conv_forward(x, w_packed, Cout, k, scale=None, shift=None, relu=True, res=No
     return out
 
 
+def pool_conv_forward(x, w_packed, Cout, scale, shift, relu, out, out2=None, split=0):
+    """The 3x3x3 / 1 TF-SAME max pool of x AND a pointwise conv of x as one launch (step_pool_conv_forward: an Inception block's
+    branch_3 pool beside its fused 1x1x1 triple).  Returns the pooled tensor, or None when the library keeps the two apart for these
+    shapes (the caller then launches them one after the other; same results bit for bit)."""
+    L = _lib.lib()
+    N, D, H, W, Cin = x.shape
+    if x.dtype == torch.float32:
+        return None
+    d = _capi.ConvDesc(dtype=_dt(x), N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=_chan_slice(x), x_coff=0,
+                       y_cstride=_chan_slice(out), y_coff=0, res_cstride=0, res_coff=0, relu=int(bool(relu)), split=int(split),
+                       y2_cstride=(_chan_slice(out2) if out2 is not None else 0), y2_coff=0)
+    info = (ctypes.c_int * 10)()
+    if L.step_conv_plan_info(ctypes.byref(d), info, 10) != 0 or info[0] != 2 or info[2] != 1:
+        return None                                                      # (the test step_pool_conv_forward makes)
+    pooled = torch.empty((N, D, H, W, Cin), dtype=x.dtype, device=x.device)
+
+    def launch():
+        _capi.check(L.step_pool_conv_forward(_dt(x), _lib.dptr(x), N, D, H, W, Cin, _chan_slice(x), 0, _lib.dptr(pooled), Cin, 0, ctypes.byref(d),
+                                             _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift), _lib.dptr(out), _lib.dptr(out2),
+                                             _lib.stream_ptr(x.device)), "step_pool_conv_forward")
+
+    def describe():
+        pix = N * D * H * W
+        return ("void step::pool333_pw_kernel<%s>(%s const*, %s*, step::PoolParams, int, int, int, int, int, int, int, int, step::ConvParams)" % (
+            _TNAME[x.dtype], _TNAME[x.dtype], _TNAME[x.dtype]), 2.0 * pix * Cout * Cin, (pix * (3 * Cin + Cout) + Cout * Cin) * _ES[x.dtype])
+    _run(launch, describe)
+    return pooled
+
+
 def conv_forward_pre(x, w_packed, Cout, k, scale, shift, relu, pre, out=None):
     """conv_forward whose input is a pointwise conv + affine + ReLU of x, evaluated on the fly (step_conv_forward_pre: conv3d_2b in
     front of conv3d_2c; the tensor between them never exists).  pre = (packed pointwise weight, scale, shift, Cmid): x has the

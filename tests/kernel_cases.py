@@ -1357,6 +1357,51 @@ def case_conv_forward_pre_matches_two_launches(bk, golden):
     assert bk.lib.step_conv_forward_pre(ctypes.byref(df), xe.ptr, wpb.ptr, dsb.ptr, dhb.ptr, wpa.ptr, dsa.ptr, dha.ptr, 64, y1.ptr, bk.stream) == -4
 
 
+def case_pool_conv_forward_matches_two_launches(bk, golden):
+    """step_pool_conv_forward (an Inception block's 3x3x3 / 1 max pool + its fused pointwise triple in ONE grid) against
+    step_maxpool3d_tf + step_conv_forward: bit-identical pooled tensor and conv outputs (two destinations through `split`, ragged
+    pixel and channel counts); layers the planner does not stream at NB = 1 and fp32 are refused with STEP_E_UNSUPPORTED."""
+    rs = np.random.RandomState(59)
+    info = (ctypes.c_int * 10)()
+    ran = 0
+    for dt, (N, D, H, W), Cin, Cout, split in ((BF16, (8, 3, 14, 14), 136, 104, 40), (F16, (8, 3, 14, 14), 128, 96, 0), (BF16, (1, 3, 14, 14), 128, 96, 0)):
+        x = rs.randn(N, Cin, D, H, W).astype(np.float32)
+        w = (rs.randn(Cout, Cin, 1, 1, 1) / np.sqrt(Cin)).astype(np.float32)
+        sc, sh = (1 + 0.1 * rs.randn(Cout)).astype(np.float32), (0.2 * rs.randn(Cout)).astype(np.float32)
+        xe = bk.dev(encode(cl(x), dt))
+        wp, dsc, dsh = pack_weight(bk, w, dt), bk.dev(sc), bk.dev(sh)
+        c0 = split if split else Cout
+        d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=Cin, x_coff=0, y_cstride=c0 + 8, y_coff=8,
+                           res_cstride=0, res_coff=0, relu=1, split=split, y2_cstride=Cout - split if split else 0, y2_coff=0)
+        assert bk.lib.step_conv_plan_info(ctypes.byref(d), info, 10) == 0
+        outs = []
+        for fused in (True, False):
+            py = bk.dev(np.full((N, D, H, W, Cin), 3, NP_DT[dt]))
+            y = bk.dev(np.zeros((N, D, H, W, c0 + 8), NP_DT[dt]))
+            y2 = bk.dev(np.zeros((N, D, H, W, max(Cout - split, 1)), NP_DT[dt]))
+            if fused:
+                rc = bk.lib.step_pool_conv_forward(dt, xe.ptr, N, D, H, W, Cin, Cin, 0, py.ptr, Cin, 0, ctypes.byref(d), xe.ptr, wp.ptr, dsc.ptr, dsh.ptr,
+                                                   y.ptr, y2.ptr if split else None, bk.stream)
+                ok = info[0] == 2 and info[2] == 1
+                assert rc == (0 if ok else -4), (rc, list(info))
+                if not ok:
+                    break
+            else:
+                assert bk.lib.step_maxpool3d_tf(dt, xe.ptr, N, D, H, W, Cin, Cin, 0, 3, 3, 3, 1, 1, 1, py.ptr, Cin, 0, bk.stream) == 0
+                assert bk.lib.step_conv_forward(ctypes.byref(d), xe.ptr, wp.ptr, dsc.ptr, dsh.ptr, None, y.ptr, y2.ptr if split else None, bk.stream) == 0
+            outs.append((py.get(), y.get(), y2.get()))
+        if len(outs) == 2:
+            ran += 1
+            for a, b in zip(*outs):
+                assert np.array_equal(a, b), (dt, N, Cin, Cout, split)
+            assert not decode(outs[0][1], dt)[..., :8].any()
+    assert ran >= 2, ran
+    df = _capi.ConvDesc(dtype=F32, N=1, D=3, H=14, W=14, Cin=128, Cout=96, kd=1, kh=1, kw=1, x_cstride=128, x_coff=0, y_cstride=96, y_coff=0,
+                        res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+    assert bk.lib.step_pool_conv_forward(F32, xe.ptr, 1, 3, 14, 14, 128, 128, 0, py.ptr, 128, 0, ctypes.byref(df), xe.ptr, wp.ptr, dsc.ptr, dsh.ptr,
+                                         y.ptr, None, bk.stream) == -4
+
+
 def case_mfma_clock_probe(bk, golden):
     """step_mfma_clock_probe (the diagnostic behind bench.py's `sustained_on_this_box`): every workgroup reports its loop; on the
     interpreter the counters read 0, on the GPU the clock lies in the part's range and the matrix pipe issues one 32x32x16 per
