@@ -1382,7 +1382,7 @@ def case_pool_conv_forward_matches_two_launches(bk, golden):
             if fused:
                 rc = bk.lib.step_pool_conv_forward(dt, xe.ptr, N, D, H, W, Cin, Cin, 0, py.ptr, Cin, 0, ctypes.byref(d), xe.ptr, wp.ptr, dsc.ptr, dsh.ptr,
                                                    y.ptr, y2.ptr if split else None, bk.stream)
-                ok = info[0] == 2 and info[2] == 1
+                ok = info[0] == 2 and info[2] <= 2
                 assert rc == (0 if ok else -4), (rc, list(info))
                 if not ok:
                     break
