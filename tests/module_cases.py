@@ -1100,13 +1100,16 @@ def case_c2_full_size_properties(dev, golden):
         assert e < 1e-2, e
         # conv3d_2b evaluated inside conv3d_2c's launch (backbone.FUSE_POINTWISE_INPUT, ops.conv_forward_pre) == the two units
         # launched one after the other, BIT-EXACT (same K order, same 16-bit rounding of the tensor between them)
+        # ... and the 14x14 blocks' pool + fused 1x1x1 triple in one grid (backbone.POOL_WITH_POINTWISE, ops.pool_conv_forward) == two launches
         from step_amd import backbone as _bb
-        assert _bb.FUSE_POINTWISE_INPUT
+        assert _bb.FUSE_POINTWISE_INPUT and _bb.POOL_WITH_POINTWISE
         try:
             _bb.FUSE_POINTWISE_INPUT = False
+            _bb.POOL_WITH_POINTWISE = False
             y8u = net(xb)
         finally:
             _bb.FUSE_POINTWISE_INPUT = True
+            _bb.POOL_WITH_POINTWISE = True
         assert torch.equal(y8u, y8), float((y8u.float() - y8.float()).abs().max())
 
 
