@@ -34,9 +34,10 @@ P
 python - <<P
 import json
 f='$O/traffic_latest.json'; j=json.load(open(f)); k=j['kernels']
-K1='void step::conv_tap_kernel<step::bf16_t, 3, 3, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'
-K11='void step::conv_tap_kernel<step::bf16_t, 3, 1, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'   # conv3d_2c's partial last round (C2)
-if K11 in k: k[K11]['with']=K1
+# conv3d_2c's partial last round (C2) is a second launch of the same call: plain form and the form with conv3d_2b fused in
+for K1, K11 in (('void step::conv_tap_kernel<step::bf16_t, 3, 3, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)', 'void step::conv_tap_kernel<step::bf16_t, 3, 1, 3, 3, 3, 2, 2, 8, 1>(step::ConvParams)'),
+                ('void step::conv_tap_pre_kernel<step::bf16_t, 3, 3>(step::ConvParams)', 'void step::conv_tap_pre_kernel<step::bf16_t, 3, 1>(step::ConvParams)')):
+    if K11 in k: k[K11]['with']=K1
 json.dump(j, open(f,'w'), indent=1)
 P
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
