@@ -36,6 +36,9 @@ struct ConvParams {
     int vec_epi;   // 16-byte output stores are legal (channel strides/offsets % 8 == 0, pointers 16-B aligned)
     int nblk32;    // ceil(Cout / 32)
     long long Mtot;  // N*D*H*W
+    // general boxes: ceil(2^32 / d) for d = halo rows x halo columns and d = halo columns -- the halo index tables divide by these
+    // run-time extents once per staged vector; (x * m) >> 32 is exact for x < 2^16, d < 2^11
+    unsigned mag_hhw, mag_hw;
     // step_conv_forward_pre (conv_tap_pre_kernel): a pointwise conv + affine + ReLU applied to the halo while it is staged (64 -> 64
     // channels: conv3d_2b in front of conv3d_2c); pre_w = its packed weights, null otherwise
     const void* pre_w; const float* pre_scale; const float* pre_shift;

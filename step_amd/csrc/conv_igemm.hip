@@ -632,6 +632,13 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true, int fo
 }
 
 
+// reciprocals of a general box's halo extents for the kernels' index tables (conv_common.h: mag_hhw / mag_hw)
+static inline void conv_set_box_magic(ConvParams& p, int kh, int kw) {
+    const unsigned long long hw = (unsigned long long)(p.gtw + kw - 1), hhw = hw * (unsigned long long)(p.gth + kh - 1);
+    p.mag_hw = (unsigned)((0x100000000ULL + hw - 1) / hw);
+    p.mag_hhw = (unsigned)((0x100000000ULL + hhw - 1) / hhw);
+}
+
 template <typename T>
 static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_t ws_bytes, step_stream_t stream) {
     constexpr int VEC = elem<T>::VEC;
@@ -647,6 +654,7 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_
     }
     p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.tiles_d = pl.tiles_d;
     p.gtd = pl.gtd; p.gth = pl.gth; p.gtw = pl.gtw; p.gmode = pl.gmode;
+    conv_set_box_magic(p, d->kh, d->kw);
     auto grid1d = [&](int groups) {                   // logical (mtiles x groups) grid as a 1-D launch padded to 8
         p.gx = (int)pl.mtiles; p.gy = groups;
         const long long tot = pl.mtiles * groups;
@@ -812,6 +820,7 @@ static int conv_fill_params(const step_conv_desc* d, const void* x, const void* 
                 (!split || ((split % 8 == 0) && (d->y2_cstride % 8 == 0) && (d->y2_coff % 8 == 0) && (((uintptr_t)y2) % 16 == 0)));
     p.nblk32 = ceil_div(d->Cout, 32);
     p.pre_w = nullptr; p.pre_scale = nullptr; p.pre_shift = nullptr;
+    p.mag_hhw = p.mag_hw = 0;
     p.Mtot = (long long)d->N * d->D * d->H * d->W;
 #ifdef STEP_PROBE
     p.probe = step::g_probe_buf;
@@ -979,6 +988,7 @@ int step_conv_forward_group(const step_conv_item* items, int n, step_stream_t st
                 const ConvPlan& pl = pls[k];
                 p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.tiles_d = pl.tiles_d;
                 p.gtd = pl.gtd; p.gth = pl.gth; p.gtw = pl.gtw; p.gmode = pl.gmode;
+                conv_set_box_magic(p, canon[k].kh, canon[k].kw);
                 const int groups = ceil_div(p.nblk32, 2 * NBc);
                 p.gx = (int)pl.mtiles; p.gy = groups;
                 const long long tot = (pl.mtiles * groups + 7) / 8 * 8;

@@ -228,8 +228,11 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
         goff[it] = ~0u;
         if (v < NVEC) {
             const int pix = v / SLOTS, slot = v % SLOTS;
-            const int plane = pix / HHW, rem = pix % HHW;
-            const int r = rem / HW_, cc = rem % HW_;
+            int plane, rem, r, cc;
+            if constexpr (GEN) {                                   // run-time extents: multiply by the host's reciprocals (p.mag_*) instead of dividing
+                plane = (int)__umulhi((unsigned)pix, p.mag_hhw); rem = pix - plane * HHW;
+                r = (int)__umulhi((unsigned)rem, p.mag_hw); cc = rem - r * HW_;
+            } else { plane = pix / HHW; rem = pix % HHW; r = rem / HW_; cc = rem % HW_; }
             const int id = d0 + plane - KD / 2, ih = h0 + r - KH / 2, iw = w0 + cc - KW / 2;
             const bool inb = id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && cc < HWV;
             if (inb) {
@@ -284,8 +287,11 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
             const int pix = (wave + bi * WV) * 32 + (lane & 31);
             poff[bi] = ~0u;
             if (pix < NPIX) {
-                const int plane = pix / HHW, rem = pix % HHW;
-                const int r = rem / HW_, cc = rem % HW_;
+                int plane, rem, r, cc;
+                if constexpr (GEN) {
+                    plane = (int)__umulhi((unsigned)pix, p.mag_hhw); rem = pix - plane * HHW;
+                    r = (int)__umulhi((unsigned)rem, p.mag_hw); cc = rem - r * HW_;
+                } else { plane = pix / HHW; rem = pix % HHW; r = rem / HW_; cc = rem % HW_; }
                 const int id = d0 + plane - KD / 2, ih = h0 + r - KH / 2, iw = w0 + cc - KW / 2;
                 if (id >= 0 && id < p.D && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && cc < HWV)
                     poff[bi] = (unsigned)(((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.x_cstride + p.x_coff);

@@ -55,6 +55,7 @@ using hipemu::dim3;
 typedef void* hipStream_t;
 
 static inline void __syncthreads() { hipemu::block_barrier(); }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 
 template <typename T> static inline T __shfl(T v, int src) {
     char* s = hipemu::exchange_begin(&v, (int)sizeof(T));
