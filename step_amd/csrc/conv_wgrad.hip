@@ -755,9 +755,13 @@ extern "C" {
 // of a job.  So a job must cover some hundred pixels or the launch is bound by the atomics, however small the map:
 // the head layers on 7x7 maps ran at 0.3-4 TFLOP/s with the fixed ~6000-job split.  Swept on the C4 step (143 wgrad
 // launches, ms in total): 16 px -> 37.4, 128 -> 24.0, 256 -> 21.5, 512 -> 22.1, 720 -> 22.7, 1440 -> 28.0, 5760 -> 43.5.
-static int wgrad_min_pixels() {
+// With a workspace (partial tiles + fixed-order sum) a job ends in plain stores, not atomics, and parallelism wins again: swept on the
+// C4 step with the workspace forms (round 3, ms per step): fp32 MFMA 32 px -> 45.2, 64 -> 43.0, 128 -> 42.2, 256 -> 43.0, 512 -> 46.0,
+// 1024 -> 49.6; 16-bit per-tap form 64 -> 19.5, 128 -> 18.40, 256 -> 18.31, 512 -> 18.55.
+enum { WG_ATOMICS = 0, WG_WS_F32 = 1, WG_WS_16 = 2 };
+static int wgrad_min_pixels(int form) {
     const int x = opt(STEP_OPT_WGRAD_MINPIX);                  // (tests exercise both regimes in one process)
-    return x > 0 ? (x + 15) / 16 * 16 : 512;
+    return x > 0 ? (x + 15) / 16 * 16 : (form == WG_WS_F32 ? 128 : (form == WG_WS_16 ? 256 : 512));
 }
 
 // launch plan of the LDS-tiled 16-bit form; ok = false: the shape is left to the per-tap forms
@@ -808,7 +812,7 @@ static Wg16Plan wgrad16_plan(const step_conv_desc* d) {
 // job split of the per-tap kernel (conv_wgrad_kernel): pointwise layers cut the flattened pixel axis into `chunk`-pixel jobs (+ one
 // ragged tail job), windows cut the (n, d, h) rows; gy = (tap, co tile, ci tile) workgroup rows; per_tile = floats of a job's tile
 struct WgJobs { bool pw; int chunk, tail, rows; long long full, jobs, gy; int cot, cit, nbw; size_t per_tile; };
-static WgJobs wgrad_jobs(const step_conv_desc* d) {
+static WgJobs wgrad_jobs(const step_conv_desc* d, int form) {
     WgJobs j;
     const int ntaps = d->kd * d->kh * d->kw;
     const bool narrow = d->Cin <= 32;
@@ -826,7 +830,7 @@ static WgJobs wgrad_jobs(const step_conv_desc* d) {
         long long want = wg_jobs_pw / (tiles > 0 ? tiles : 1);
         if (want < 1) want = 1;
         long long ch = (ceil_div64(M, want) + 15) / 16 * 16;
-        if (ch < wgrad_min_pixels()) ch = wgrad_min_pixels();
+        if (ch < wgrad_min_pixels(form)) ch = wgrad_min_pixels(form);
         if (ch > 65536) ch = 65536;
         j.chunk = (int)ch;
         j.full = M / j.chunk;                                   // (n, d, h) collapse into full chunks; the ragged tail is a second launch
@@ -844,7 +848,7 @@ static WgJobs wgrad_jobs(const step_conv_desc* d) {
     long long want = wg_jobs / (j.gy > 0 ? j.gy : 1);
     if (want < 1) want = 1;
     long long rows = ceil_div64(total_rows, want);
-    const long long rows_min = ceil_div64(wgrad_min_pixels(), d->W);      // small maps: fewer, longer jobs (see above)
+    const long long rows_min = ceil_div64(wgrad_min_pixels(form), d->W);      // small maps: fewer, longer jobs (see above)
     if (rows < rows_min) rows = rows_min;
     if (rows > total_rows) rows = total_rows;
     if (rows < 1) rows = 1;
@@ -865,9 +869,11 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
     if (!dw) return STEP_E_NULL;
     const int ntaps = d->kd * d->kh * d->kw;
     const bool lds_form = w16 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && wgrad16_plan(d).ok && d->N > 0;
-    const WgJobs jb = wgrad_jobs(d);
-    // the per-tap kernel with a workspace: partial tiles + a fixed-order sum write every element of dw themselves
-    const bool tap_ws = !lds_form && d->N > 0 && ws && ((uintptr_t)ws % 16) == 0 && ws_bytes >= wgrad_jobs_ws_bytes(jb) && jb.jobs > 0;
+    // the per-tap kernel with a workspace: partial tiles + a fixed-order sum write every element of dw themselves; its jobs are
+    // shorter than the atomics form's (wgrad_min_pixels)
+    const WgJobs jws = wgrad_jobs(d, w16 ? WG_WS_16 : WG_WS_F32);
+    const bool tap_ws = !lds_form && d->N > 0 && ws && ((uintptr_t)ws % 16) == 0 && ws_bytes >= wgrad_jobs_ws_bytes(jws) && jws.jobs > 0;
+    const WgJobs jb = tap_ws ? jws : wgrad_jobs(d, WG_ATOMICS);
     if (!accumulate && !tap_ws) {
         const int e = (int)hipMemsetAsync(dw, 0, (size_t)d->Cout * d->Cin * ntaps * sizeof(float), (hipStream_t)stream);
         if (e != 0) return e;
@@ -968,7 +974,7 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
 
 size_t step_conv_wgrad_workspace_bytes(const step_conv_desc* d) {
     if (!d || d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->kd <= 0 || d->kh <= 0 || d->kw <= 0) return 0;
-    return wgrad_jobs_ws_bytes(wgrad_jobs(d));
+    return wgrad_jobs_ws_bytes(wgrad_jobs(d, WG_WS_F32));
 }
 
 int step_conv_wgrad_ws(const step_conv_desc* d, const void* x, const float* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
@@ -990,7 +996,8 @@ size_t step_conv_wgrad16_workspace_bytes(const step_conv_desc* d) {
     if (!d || (d->dtype != STEP_BF16 && d->dtype != STEP_F16)) return 0;
     const Wg16Plan pl = wgrad16_plan(d);
     if (pl.ok) return (size_t)pl.gx * pl.gy * 6 * (pl.pw ? 8 : 24) * 64 * 16;
-    return step_conv_wgrad_workspace_bytes(d);                   // the per-tap 16-bit form: partial tiles of its wavefront jobs
+    if (d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->kd <= 0 || d->kh <= 0 || d->kw <= 0) return 0;
+    return wgrad_jobs_ws_bytes(wgrad_jobs(d, WG_WS_16));         // the per-tap 16-bit form: partial tiles of its wavefront jobs
 }
 
 int step_conv_wgrad16_ws(const step_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
