@@ -83,7 +83,7 @@ enum {
     STEP_OPT_CONV_TAIL,        /*  1 (default) | 0: partial last round of a one-channel-group conv_tap launch at NB = 1 (bit-identical) */
     STEP_OPT_CONV_SLOTS,       /*  0 (default: resident workgroups of the chip) | n: pretend the chip holds n workgroups (tests: the tail split at small sizes) */
     STEP_OPT_POOL_DIRECT,      /*  0 (default) | 1: every max pool on the general 27-tap kernel (tests) */
-    STEP_OPT_WGRAD_MINPIX,     /*  0 (default: 512 for the atomics forms, 128 (fp32 MFMA) / 256 (16-bit) with a workspace) | n: least pixels per wavefront job of the per-tap weight gradient (fp32 summation order) */
+    STEP_OPT_WGRAD_MINPIX,     /*  0 (default: 512 for the atomics forms, 64 (fp32 MFMA) / 256 (16-bit) with a workspace) | n: least pixels per wavefront job of the per-tap weight gradient (fp32 summation order) */
     STEP_OPT_WGRAD16_LDS,      /*  1 (default) | 0: 3x3 windows of step_conv_wgrad16_ws on the per-tap kernel instead of the LDS-tiled GEMM */
     STEP_OPT_CONV_GROUP_PW,    /*  2^20 (default: always) | n: step_conv_forward_group carries a pointwise item inside the 3x3x3 members' grid when they are at most n workgroups; 0 never (bit-identical) */
     STEP_OPT_ROI_BWD_GATHER,   /*  1 (default) ROIAlign backward as a fixed-order gather per feature cell (deterministic) | 0: the fp32-atomics scatter of ROIAlign_cuda.cu */

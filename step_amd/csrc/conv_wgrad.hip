@@ -23,7 +23,7 @@ struct WgradParams {
     int rows;                     // (n, d, h) rows per wavefront job
     long long total_rows;         // N * D * H
     long long jobs;               // ceil(total_rows / rows)
-    float* ws;                    // partial tiles [job][blockIdx.y][MB*NB][16][64 lanes] (NULL: fp32 atomics on dw), see wgrad_reduce_kernel
+    float* ws;                    // partial tiles [blockIdx.x][blockIdx.y][MB*NB][16][64 lanes]: the four jobs of a workgroup already summed (NULL: fp32 atomics on dw), see wgrad_reduce_kernel
 };
 
 // W16 (16-bit storage only): dY arrives in the activation type too (what mixed-precision training back-propagates) and the
@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     // here too and is NOT used: the jobs of a group end in fp32 atomics on the same dw tile, and bunching the groups changes which
     // atomics collide: fp32 C4 step 49.7 -> 60.4 ms, 5b_b1b weight gradient 0.27 -> 0.80 ms)
     const long long job = (long long)blockIdx.x * 4 + wave;
-    if (job >= p.jobs) return;                               // wave-uniform; the kernel has no barrier
+    const bool valid = job < p.jobs;                         // wave-uniform
+    if (!valid && !p.ws) return;                             // (workspace form: the wave still takes part in the workgroup's sum, with zeros)
     int t = blockIdx.y;
     const int cit_i = t % p.cit; t /= p.cit;
     const int cot_i = t % p.cot;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 
-    const long long r_end = min((job + 1) * (long long)p.rows, p.total_rows);
+    const long long r_end = valid ? min((job + 1) * (long long)p.rows, p.total_rows) : 0;
     for (long long rr = job * (long long)p.rows; rr < r_end; ++rr) {
         const int h = (int)(rr % p.H);
         const long long plane = rr / p.H;
@@ -114,16 +115,53 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
         }
     }
     if (p.ws) {
-        // this job's partial tile, accumulator layout as is (a register = 256 contiguous bytes over the lanes); wgrad_reduce_kernel
-        // sums the jobs of a tile in a FIXED order: no atomics (every job used to end in 4096 of them, ~0.2 us per job at the rate the
-        // L2 sustains), bit-reproducible
-        float* out = p.ws + (((size_t)job * gridDim.y + blockIdx.y) * (MB * NB * 16)) * 64 + lane;
+        // The workgroup's four jobs are summed through LDS first -- (w0 + w2) + (w1 + w3), a fixed order -- and ONE partial tile per
+        // workgroup goes to the workspace, accumulator layout as is (a register = 256 contiguous bytes over the lanes);
+        // wgrad_reduce_kernel sums the workgroups of a tile in ascending order: no atomics (every job used to end in 4096 of them,
+        // ~0.2 us per job at the rate the L2 sustains), bit-reproducible.  (One tile per JOB: 4x the workspace traffic -- with 128-pixel
+        // jobs the 143 reduce launches of a C4 step read 4.9 ms worth of partial tiles.)
+        constexpr int TILE = MB * NB * 16 * 64;
+        __shared__ float red[2 * TILE];
+        if (wave >= 2) {
+            float* o = red + (wave - 2) * TILE + lane;
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+                for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) out[((mb * NB + nb) * 16 + r) * 64] = acc[mb][nb][r];
+                    for (int r = 0; r < 16; ++r) o[((mb * NB + nb) * 16 + r) * 64] = acc[mb][nb][r];
+        }
+        __syncthreads();
+        if (wave < 2) {
+            const float* o = red + wave * TILE + lane;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mb][nb][r] += o[((mb * NB + nb) * 16 + r) * 64];
+        }
+        __syncthreads();
+        if (wave == 1) {
+            float* o = red + lane;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[((mb * NB + nb) * 16 + r) * 64] = acc[mb][nb][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const float* o = red + lane;
+            float* out = p.ws + (((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (MB * NB * 16)) * 64 + lane;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) out[((mb * NB + nb) * 16 + r) * 64] = acc[mb][nb][r] + o[((mb * NB + nb) * 16 + r) * 64];
+        }
         return;
     }
 #pragma unroll
@@ -757,11 +795,12 @@ extern "C" {
 // launches, ms in total): 16 px -> 37.4, 128 -> 24.0, 256 -> 21.5, 512 -> 22.1, 720 -> 22.7, 1440 -> 28.0, 5760 -> 43.5.
 // With a workspace (partial tiles + fixed-order sum) a job ends in plain stores, not atomics, and parallelism wins again: swept on the
 // C4 step with the workspace forms (round 3, ms per step): fp32 MFMA 32 px -> 45.2, 64 -> 43.0, 128 -> 42.2, 256 -> 43.0, 512 -> 46.0,
-// 1024 -> 49.6; 16-bit per-tap form 64 -> 19.5, 128 -> 18.40, 256 -> 18.31, 512 -> 18.55.
+// 1024 -> 49.6; 16-bit per-tap form 64 -> 19.5, 128 -> 18.40, 256 -> 18.31, 512 -> 18.55.  Once a workgroup sums its four jobs
+// before writing (one partial tile per workgroup): fp32 32 px -> 41.1, 64 -> 41.1, 96 -> 41.4, 128 -> 41.7; 16-bit 64...256 all 18.0.
 enum { WG_ATOMICS = 0, WG_WS_F32 = 1, WG_WS_16 = 2 };
 static int wgrad_min_pixels(int form) {
     const int x = opt(STEP_OPT_WGRAD_MINPIX);                  // (tests exercise both regimes in one process)
-    return x > 0 ? (x + 15) / 16 * 16 : (form == WG_WS_F32 ? 128 : (form == WG_WS_16 ? 256 : 512));
+    return x > 0 ? (x + 15) / 16 * 16 : (form == WG_WS_F32 ? 64 : (form == WG_WS_16 ? 256 : 512));
 }
 
 // launch plan of the LDS-tiled 16-bit form; ok = false: the shape is left to the per-tap forms
@@ -857,7 +896,9 @@ static WgJobs wgrad_jobs(const step_conv_desc* d, int form) {
     j.jobs = ceil_div64(total_rows, j.rows);
     return j;
 }
-static size_t wgrad_jobs_ws_bytes(const WgJobs& j) { return (size_t)j.jobs * (size_t)j.gy * j.per_tile * sizeof(float); }
+// one partial tile per WORKGROUP (four jobs): pointwise layers launch their full chunks and the ragged tail separately
+static long long wgrad_ws_blocks(const WgJobs& j) { return j.pw ? ceil_div64(j.full, 4) + (j.tail ? 1 : 0) : ceil_div64(j.jobs, 4); }
+static size_t wgrad_jobs_ws_bytes(const WgJobs& j) { return (size_t)wgrad_ws_blocks(j) * (size_t)j.gy * j.per_tile * sizeof(float); }
 
 static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* dy, bool w16, float* dw, int accumulate, void* ws,
                            size_t ws_bytes, step_stream_t stream) {
@@ -940,11 +981,11 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
         };
         if (full) launch(full, chunk, 0);
         if (rc == STEP_OK && tail) {
-            if (tap_ws) p.ws = (float*)ws + (size_t)full * jb.gy * jb.per_tile;      // the tail job's tiles behind the full chunks'
+            if (tap_ws) p.ws = (float*)ws + (size_t)ceil_div64(full, 4) * jb.gy * jb.per_tile;      // the tail job's tiles behind the full chunks
             launch(1, tail, (size_t)full * chunk);
         }
         if (rc == STEP_OK && tap_ws)
-            STEP_LAUNCH(wgrad_reduce_kernel, dim3(flat_grid(jb.gy * (long long)jb.per_tile, 256)), dim3(256), stream, (const float*)ws, dw, jb.jobs,
+            STEP_LAUNCH(wgrad_reduce_kernel, dim3(flat_grid(jb.gy * (long long)jb.per_tile, 256)), dim3(256), stream, (const float*)ws, dw, wgrad_ws_blocks(jb),
                         (int)jb.gy, 2, jb.nbw, jb.cot, jb.cit, d->Cout, d->Cin, 1, accumulate);
         return rc != STEP_OK ? rc : STEP_LAUNCH_CHECK();
     }
@@ -967,7 +1008,7 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
 #undef STEP_WG
 #undef STEP_WG16
     if (tap_ws)
-        STEP_LAUNCH(wgrad_reduce_kernel, dim3(flat_grid(jb.gy * (long long)jb.per_tile, 256)), dim3(256), stream, (const float*)ws, dw, jb.jobs,
+        STEP_LAUNCH(wgrad_reduce_kernel, dim3(flat_grid(jb.gy * (long long)jb.per_tile, 256)), dim3(256), stream, (const float*)ws, dw, wgrad_ws_blocks(jb),
                     (int)jb.gy, 2, jb.nbw, jb.cot, jb.cit, d->Cout, d->Cin, ntaps, accumulate);
     return STEP_LAUNCH_CHECK();
 }
