@@ -450,24 +450,55 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
         what = "C4: one training step (backbone + ContextNet + max_iter=3 heads on 3/3/9-frame tubes, BCE + smooth-L1 losses, gradient all-reduce, Adam), " \
                "%d x [36,3,400,400] clip(s) per GPU, 5 tubes/clip" % CLIPS_PER_GPU
         metric = "clips_per_sec_train_T36_400"
-    for _ in range(max(a.warmup, 2)):
-        w.step()
-    torch.cuda.synchronize()
+    # C3 with a captured graph: TWO batches in flight (see main(): the same idea) -- a second workload object on the same networks,
+    # its own clips / captured graph / stream; batch k + 1 is launched before batch k is post-processed (its one host sync waits for
+    # its own stream only).  Every step is still one batch through the whole pipeline, post-processing included.
+    nfl = a.in_flight if (a.config == "c3" and not a.no_graph) else 1
+    ws, streams = [w], [torch.cuda.current_stream()]
+    for i in range(1, nfl):
+        si = torch.cuda.Stream()
+        with torch.cuda.stream(si):
+            ws.append(workloads.C3Inference(dev, tdt, batch=CLIPS_PER_GPU, tubes=11, seed=123 + rank, share=w))
+            torch.cuda.synchronize()
+        streams.append(si)
+
+    def run(k_steps, n):
+        if n == 1:
+            for _ in range(k_steps):
+                w.step()
+            return
+        pending = None
+        for k in range(k_steps):
+            i = k % n
+            with torch.cuda.stream(streams[i]):
+                h = ws[i].launch()
+            if pending is not None:
+                with torch.cuda.stream(streams[pending[0]]):
+                    ws[pending[0]].finish(pending[1])
+            pending = (i, h)
+        with torch.cuda.stream(streams[pending[0]]):
+            ws[pending[0]].finish(pending[1])
+
+    def timed(n):
+        run(max(a.warmup, 2), n)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(a.steps, n)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    el = timed(nfl)
+    el_one = timed(1) if nfl > 1 else el
     if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        w.step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        t = torch.tensor([el, el_one], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        el, el_one = float(t[0].item()), float(t[1].item())
     # dominant kernel of one eager, single-stream, instrumented step -- run by EVERY rank (the C4 step contains the
     # gradient all-reduce: a collective issued by rank 0 alone would dead-lock against the others' final barrier)
     ops.PROFILE = []
@@ -483,10 +514,15 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
                "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": what + ", inputs resident in HBM, random-init weights", "clips_per_gpu": CLIPS_PER_GPU, "T": 36, "HW": 400,
                           "parallelism": "clip-sharded replicas x%d (%s)" % (world, "no data-path collective" if a.config == "c3" else "one gradient all-reduce per step"),
-                          "launch": "hipGraph replay + eager post-processing" if (a.config == "c3" and not a.no_graph) else
+                          "batches_in_flight": nfl,
+                          "launch": ("hipGraph replay + eager post-processing" + (", %d batches in flight (own clips / graph / stream each; batch k + 1 launched before batch k is post-processed)" % nfl if nfl > 1 else ""))
+                                    if (a.config == "c3" and not a.no_graph) else
                                     ("hipGraph replay (whole training step)" if getattr(w, "graph", None) is not None else "eager")},
                "ranks": {"world_size": world, "backend": (dist.get_backend() + " (RCCL over xGMI)" if dist.get_backend() == "nccl" else dist.get_backend()) if dist is not None else None,
                          "devices_visible": torch.cuda.device_count()}}
+        if nfl > 1:
+            out["one_batch_in_flight"] = {"value": round(world * CLIPS_PER_GPU * a.steps / el_one, 2), "ms_per_step": round(el_one / a.steps * 1e3, 4),
+                                          "note": "the same K steps one after the other on one stream (the loop of rounds 1-2)"}
         rec = REC
         agg = {}
         for name, flops, nbytes, e0, e1 in rec:

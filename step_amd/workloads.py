@@ -48,9 +48,13 @@ def build_nets(dev, seed=123, heads=3):
 class C3Inference:
     """B clips [36,3,400,400], `tubes` initial tubes per clip, 3 refinement steps, batched per-class NMS (test.py:140-218)."""
 
-    def __init__(self, dev, dtype, batch=4, tubes=11, seed=123, graph=True):
-        self.args, self.base, self.ctx, self.nets = build_nets(dev, seed)
-        g = torch.Generator().manual_seed(seed)
+    def __init__(self, dev, dtype, batch=4, tubes=11, seed=123, graph=True, share=None):
+        # share = another C3Inference: the same networks (weights, packed-weight caches) on other clips -- a second batch in flight
+        if share is not None:
+            self.args, self.base, self.ctx, self.nets = share.args, share.base, share.ctx, share.nets
+        else:
+            self.args, self.base, self.ctx, self.nets = build_nets(dev, seed)
+        g = torch.Generator().manual_seed(seed + (1000 if share is not None else 0))
         self.x = (torch.rand(batch, 36, 3, 400, 400, generator=g) * 2 - 1).to(dev).to(dtype)
         anchors = generate_anchors()[:tubes] * 400.0
         self.tubes = [np.tile(anchors[:, None, :], (1, 3, 1)).astype(np.float32) for _ in range(batch)]
@@ -67,8 +71,18 @@ class C3Inference:
     def step(self):
         if self.graphed is None:
             return self.eager()
+        return self.finish(self.launch())
+
+    def launch(self):
+        """Enqueue the captured backbone + context + three refinement steps on the CURRENT stream; returns the history (static buffers
+        the next launch() of this object overwrites).  launch() / finish() apart let a caller keep a second batch in flight."""
         with torch.no_grad():
             hist, _, _ = self.graphed(self.x)
+        return hist
+
+    def finish(self, hist):
+        """Post-processing of a launched batch (thresholds, per-class NMS, the one device-to-host copy): synchronises the current stream only."""
+        with torch.no_grad():
             return postprocess(self.args, hist)
 
 

@@ -49,3 +49,44 @@ def test_captured_training_step_follows_the_eager_steps(dtype):
     assert rel < 1e-5 and em < 1e-5, (rel, em)
     assert np.all(np.abs(la - lb) <= 1e-6 * np.abs(la)), (la, lb)
     assert len(set(np.round(lb, 10))) > 1                       # the replays really advance the weights
+
+
+def test_two_inference_batches_in_flight_equal_one_at_a_time():
+    """workloads.C3Inference.launch() / finish(): batch k + 1 (a second workload object on the SAME networks, own clips, own captured
+    graph, own stream) is launched before batch k is post-processed -- the detections of both equal the ones each produces alone."""
+    from step_amd import workloads
+
+    dev = torch.device("cuda:0")
+    a = workloads.C3Inference(dev, torch.bfloat16, batch=1, tubes=5, seed=123)
+    sb = torch.cuda.Stream()
+    with torch.cuda.stream(sb):
+        b = workloads.C3Inference(dev, torch.bfloat16, batch=1, tubes=5, seed=123, share=a)
+        torch.cuda.synchronize()
+    assert b.base is a.base and not torch.equal(a.x, b.x)
+    alone = [a.step(), None]
+    with torch.cuda.stream(sb):
+        alone[1] = b.step()
+    torch.cuda.synchronize()
+    sa = torch.cuda.current_stream()
+    got = [None, None]
+    for _ in range(3):                                          # a few rounds of the pipelined loop
+        ha = a.launch()
+        with torch.cuda.stream(sb):
+            hb = b.launch()
+        got[0] = a.finish(ha)
+        with torch.cuda.stream(sb):
+            got[1] = b.finish(hb)
+    torch.cuda.synchronize()
+    del sa
+
+    def same(p, q):
+        if isinstance(p, torch.Tensor):
+            return torch.equal(p, q)
+        if isinstance(p, np.ndarray):
+            return np.array_equal(p, q)
+        if isinstance(p, (list, tuple)):
+            return len(p) == len(q) and all(same(x, y) for x, y in zip(p, q))
+        if isinstance(p, dict):
+            return p.keys() == q.keys() and all(same(p[k], q[k]) for k in p)
+        return p == q
+    assert same(got[0], alone[0]) and same(got[1], alone[1])
