@@ -136,6 +136,32 @@ def sustained_mfma(dev):
                     "(2500 TFLOP/s) assumes 2.4 GHz"}
 
 
+def sustained_hbm(dev):
+    """What THIS box moves with a plain streaming copy (step_hbm_stream_probe): 1 GiB read + 1 GiB written per launch, far beyond the
+    256 MB last-level cache; best of 5 launches after a warm-up, HIP events on the launch stream.  The HBM-bound kernels (pools,
+    pointwise convs, ROIAlign) are read against this next to the 8 TB/s of the datasheet."""
+    from step_amd import _capi, _lib
+    import ctypes
+    L = _lib.lib()
+    nbytes = 1 << 30
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 255)
+    dst = torch.empty_like(src)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    best = None
+    for k in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _capi.check(L.step_hbm_stream_probe(ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), nbytes, cus * 16, _lib.stream_ptr(dev)), "step_hbm_stream_probe")
+        e1.record()
+        torch.cuda.synchronize()
+        if k:
+            ms = e0.elapsed_time(e1)
+            best = ms if best is None else min(best, ms)
+    del src, dst
+    return {"copy_GBs": round(2 * nbytes / (best * 1e-3) / 1e9, 1), "bytes_read_plus_written": 2 * nbytes,
+            "note": "step_hbm_stream_probe: grid-stride 16 B / lane non-temporal copy, 16 workgroups per CU, best of 5"}
+
+
 def roofline(net, x, dtype_name):
     """Per-launch durations of the REPLAYED step, measured live: HIP graphs of growing prefixes of the forward (launches 1..k, the
     rest skipped by step_amd.ops.PROFILE_LIMIT) are captured and replayed, and launch k's duration is the difference of the best
@@ -409,6 +435,10 @@ def main():
             sm = sustained_mfma(dev)
             if sm:
                 rl["sustained_on_this_box"] = dict(sm, frac_of_sustained=round(rl["achieved"] / sm["dense_bf16_tflops"], 4) if rl.get("bound") == "mfma" else None)
+        sh = sustained_hbm(dev)
+        rl.setdefault("sustained_on_this_box", {})["hbm"] = dict(sh, frac_of_sustained=round(rl["achieved"] / sh["copy_GBs"], 4) if rl.get("bound") == "hbm" else None)
+        if "backbone_roofline" in out:
+            out["backbone_roofline"]["hbm_frac_of_sustained_copy"] = round(out["backbone_roofline"]["hbm_frac"] * PEAK_HBM_GBS / sh["copy_GBs"], 4)
         out["kernel_time_ms_per_step"] = round(gpu_ms, 4)
         if out["config"].get("batches_in_flight", 1) > 1:
             out["kernel_time_note"] = ("sum of the per-launch durations of ONE step replayed alone (= one_batch_in_flight.ms_per_step); with %d batches "

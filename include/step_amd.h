@@ -63,6 +63,12 @@ STEP_API int step_abi_version(void);
  * boxes this was developed on settle at ~1.9 GHz = ~2.0 PFLOP/s, not the 2.4 GHz / 2.5 PFLOP/s of the datasheet roofline. */
 STEP_API int step_mfma_clock_probe(unsigned long long* out, int workgroups, int iters, step_stream_t stream);
 
+/* The other measured ceiling: a plain streaming copy of `bytes` (multiple of 16; src, dst 16-byte aligned, not overlapping) by
+ * `workgroups` 256-thread workgroups, 16 B per lane, grid-stride.  2 * bytes / its duration on buffers well beyond the 256 MB
+ * last-level cache is the HBM rate one launch reaches on this box -- what the pools / pointwise convs / ROIAlign are read against
+ * (the datasheet's 8 TB/s is not reachable by any copy). */
+STEP_API int step_hbm_stream_probe(const void* src, void* dst, size_t bytes, int workgroups, step_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Planner options.  The library reads NO environment variable: the launch planners' few tuning / test knobs are explicit
  * integers set through this entry point (process-wide, relaxed atomics: safe to call from any thread; a launch sees either

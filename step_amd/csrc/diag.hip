@@ -49,6 +49,19 @@ __global__ __launch_bounds__(256) void mfma_clock_probe_kernel(unsigned long lon
     }
 }
 
+// step_hbm_stream_probe: the plain streaming copy (16 B per lane, grid-stride, non-temporal) against which the HBM-bound kernels
+// (pools, pointwise convs, ROIAlign) are read: what one launch moves per second on this box when it does nothing else.
+__global__ __launch_bounds__(256) void hbm_stream_probe_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) {
+#ifdef STEP_EMUL
+        dst[i] = src[i];
+#else
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+#endif
+    }
+}
+
 }  // namespace step
 
 using namespace step;
@@ -60,6 +73,15 @@ int step_mfma_clock_probe(unsigned long long* out, int workgroups, int iters, st
     if (workgroups == 0) return STEP_OK;
     if (!out) return STEP_E_NULL;
     STEP_LAUNCH(mfma_clock_probe_kernel, dim3((unsigned)workgroups), dim3(256), stream, out, iters);
+    return STEP_LAUNCH_CHECK();
+}
+
+int step_hbm_stream_probe(const void* src, void* dst, size_t bytes, int workgroups, step_stream_t stream) {
+    if (workgroups < 0 || (bytes & 15)) return STEP_E_SHAPE;
+    if (bytes == 0 || workgroups == 0) return STEP_OK;
+    if (!src || !dst) return STEP_E_NULL;
+    if (((uintptr_t)src | (uintptr_t)dst) & 15) return STEP_E_ALIGN;
+    STEP_LAUNCH(hbm_stream_probe_kernel, dim3((unsigned)workgroups), dim3(256), stream, (const u32x4*)src, (u32x4*)dst, bytes / 16);
     return STEP_LAUNCH_CHECK();
 }
 

@@ -1421,6 +1421,23 @@ def case_mfma_clock_probe(bk, golden):
     assert bk.lib.step_mfma_clock_probe(out.ptr, -1, 10, bk.stream) < 0
 
 
+def case_hbm_stream_probe(bk, golden):
+    """step_hbm_stream_probe (bench.py's measured HBM ceiling): the copy is exact for any workgroup count, incl. fewer lanes than
+    vectors and a ragged last pass; argument checks."""
+    rs = np.random.RandomState(5)
+    src = rs.randint(0, 1 << 30, size=4 * 1237).astype(np.int32)          # 1237 16-byte vectors
+    a = bk.dev(src)
+    for wgs in (1, 3, 64):
+        b = bk.dev(np.zeros_like(src))
+        assert bk.lib.step_hbm_stream_probe(a.ptr, b.ptr, src.nbytes, wgs, bk.stream) == 0
+        assert np.array_equal(b.get(), src)
+    b = bk.dev(np.zeros_like(src))
+    assert bk.lib.step_hbm_stream_probe(a.ptr, b.ptr, 0, 4, bk.stream) == 0 and not b.get().any()
+    assert bk.lib.step_hbm_stream_probe(a.ptr, b.ptr, 24, 4, bk.stream) == -2
+    assert bk.lib.step_hbm_stream_probe(None, b.ptr, 32, 4, bk.stream) == -3
+    assert bk.lib.step_hbm_stream_probe(getattr(a.ptr, "value", a.ptr) + 4, b.ptr, 32, 4, bk.stream) == -5
+
+
 def case_conv_tail_round_split(bk, golden):
     """A layer that is one channel group deep and whose pixel tiles end in a small partial round of one-workgroup-per-CU slots is
     launched in two parts: the full rounds at NB = 3 and the tail tiles at NB = 1 (three times as many, shorter workgroups).
