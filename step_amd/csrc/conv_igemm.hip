@@ -459,10 +459,11 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true, int fo
             const bool can = d->dtype != STEP_F32 && (d->Cin % 8) == 0 && (d->x_cstride % 8) == 0 && (d->x_coff % 8) == 0 && KC16 <= 16 &&
                              (d->y_cstride % 8) == 0 && (d->y_coff % 8) == 0 && (d->Cout % 8) == 0 && d->res_cstride == 0 &&
                              (d->split == 0 || ((d->split % 8) == 0 && (d->y2_cstride % 8) == 0 && (d->y2_coff % 8) == 0)) && M >= 1024;
-            // measured (tools/ab_bench.py, bf16): the only class it wins is K = 256 with many channel blocks on a large map -- the 3c
-            // fused triple 43.1 -> 37.4 us at 28x28 (batch 8), 65.2 -> 55.3 us at 50x50 (batch 4); equal within 3 % on conv3d_2b and
-            // the 3b triple, 5-12 % slower on the narrow branch_3 layers: the default covers that class only
-            const bool wins = KC16 > 12 && nblk32 >= 6 && M >= 65536;
+            // measured (tools/ab_bench.py, bf16): it wins with K = 192 .. 256 and many channel blocks on a large map -- the 3c fused
+            // triple 43.1 -> 37.4 us at 28x28 (batch 8), 65.2 -> 55.3 us at 50x50 (batch 4), and with the 16-byte register epilogue
+            // (round 3) 34.2 / 48.7 us; the 3b triple (K = 192) 26.1 -> 24.3 us since that epilogue; equal or slower on conv3d_2b
+            // and the narrow branch_3 layers: the default covers that class only
+            const bool wins = KC16 >= 12 && nblk32 >= 6 && M >= 65536;
             if (allow_pws && can && pws_env != 0 && (pws_env == 1 || wins) && ov1 == -1) {
                 int nbmax = 152 / (ceil_div(KC16, 4) * 4);               // (LDS holds K padded to whole 64-channel steps)
                 if (nbmax > 16) nbmax = 16;

@@ -133,7 +133,8 @@ static int splitk_forward_t(const ConvPlan& pl, const ConvParams& p, float* ws, 
 //     (another S steps) are in flight while it walks the channel blocks NB at a time (16 NB accumulator registers): up to
 //     16 KiB in flight per wave, every byte of the input loaded exactly once;
 //   * the accumulator holds, per lane, ONE pixel and groups of 4 consecutive output channels: the epilogue (scale, shift, ReLU,
-//     two destinations) stores 8-byte pieces straight from registers, no transpose through LDS.
+//     two destinations) pairs lanes l / l + 32 with v_permlane32_swap and stores 16-byte pieces (8 channels) straight from
+//     registers, no transpose through LDS.
 constexpr int PWS_LDSW = 152 * 1024;                        // weight image: up to 152 (block, 16-channel chunk) fragments
 constexpr int PWS_WV = 8;
 constexpr int PWS_MAXB = 16;                                // channel blocks per workgroup
@@ -204,22 +205,34 @@ __global__ __launch_bounds__(PWS_WV * 64) void conv_pws_kernel(ConvParams p, int
             for (int j = 0; j < KCP; ++j)
 #pragma unroll
                 for (int i = 0; i < NB; ++i) mma_k16(lds_read_bfrag<T>(wb[i] + j * 1024), xa[SET][j], acc[i], T());
+            // epilogue (the planner sends only layers whose channel counts / offsets / pitches are multiples of 8 here): one
+            // v_permlane32_swap per packed dword pair (register quads 2h, 2h + 1) hands the lower lane channels 16h .. 16h+7 and the
+            // upper lane 16h+8 .. 16h+15 of its pixel (conv_tap_kernel.h, epilogue): 16-byte stores straight from registers
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
+                unsigned d[4][2];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int c4 = (b0 + i) * 32 + 8 * q + 4 * khalf, co = nbw0 * 32 + c4;
-                    if (ok && b0 + i < nbwv && co < p.Cout) {
-                        const f32x4 s4 = *(const f32x4*)(scl + c4), h4 = *(const f32x4*)(shl + c4);
-                        u16x4 o;
+                    const int c4 = (b0 + i) * 32 + 8 * q + 4 * khalf;
+                    const f32x4 s4 = *(const f32x4*)(scl + c4), h4 = *(const f32x4*)(shl + c4);
+                    float v[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float v = acc[i][4 * q + e] * s4[e] + h4[e];
-                            if (p.relu) v = fmaxf(v, 0.f);
-                            o[e] = elem<T>::bits16(v);
-                        }
-                        if (p.split > 0 && co >= p.split) *(u16x4*)((T*)p.y2 + (size_t)gm * p.y2_cstride + p.y2_coff + (co - p.split)) = o;
-                        else *(u16x4*)((T*)p.y + (size_t)gm * p.y_cstride + p.y_coff + co) = o;
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[i][4 * q + e] * s4[e] + h4[e];
+                        if (p.relu) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    d[q][0] = (unsigned)elem<T>::bits16(v[0]) | ((unsigned)elem<T>::bits16(v[1]) << 16);
+                    d[q][1] = (unsigned)elem<T>::bits16(v[2]) | ((unsigned)elem<T>::bits16(v[3]) << 16);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    lane32_swap(d[2 * h][0], d[2 * h + 1][0]);
+                    lane32_swap(d[2 * h][1], d[2 * h + 1][1]);
+                    const int co = nbw0 * 32 + (b0 + i) * 32 + 16 * h + 8 * khalf;
+                    if (ok && b0 + i < nbwv && co < p.Cout) {
+                        const u32x4 o = {d[2 * h][0], d[2 * h][1], d[2 * h + 1][0], d[2 * h + 1][1]};
+                        if (p.split > 0 && co >= p.split) *(u32x4*)((T*)p.y2 + (size_t)gm * p.y2_cstride + p.y2_coff + (co - p.split)) = o;
+                        else *(u32x4*)((T*)p.y + (size_t)gm * p.y_cstride + p.y_coff + co) = o;
                     }
                 }
             }

@@ -10,7 +10,11 @@ prof() { n=$1; shift
   python $R/tools/prof_summary.py $O/prof_$n $O/prof_${n}_summary.txt > /dev/null 2>&1
   cp $(find $O/prof_$n -name "*kernel_stats.csv" | head -1) $O/prof_${n}_kernel_stats.csv 2>/dev/null
   rm -rf $O/prof_$n; }
-prof c2 --steps 100 --warmup 10
+# per-kernel durations are defined one batch at a time (what bench.py's roofline measures: prefix replays of ONE captured step);
+# the default command keeps two batches in flight, where launches of the two batches share the CUs and a trace's per-launch
+# durations are no longer per-kernel costs -- both traces are kept
+prof c2 --steps 100 --warmup 10 --in-flight 1
+prof c2_two --steps 100 --warmup 10
 prof c3 --config c3 --steps 20 --warmup 5 --no-cpu-baseline
 prof c4_bf16 --config c4 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline
 prof c4_f32 --config c4 --steps 10 --warmup 3 --no-cpu-baseline
