@@ -210,7 +210,7 @@ def roofline(net, x, dtype_name):
         avg_ms = ms / cnt
         hbm_time = (nbytes / cnt) / (PEAK_HBM_GBS * 1e9)
         mfma_time = (flops / cnt) / (PEAK[dtype_name] * 1e12)
-        traffic, tsrc = None, None
+        traffic, tsrc, covers = None, None, None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tfile):
             try:
@@ -226,6 +226,7 @@ def roofline(net, x, dtype_name):
                     if tail and tail != name and tail in tj["kernels"] and tj["kernels"][tail].get("with") == name:
                         traffic += tj["kernels"][tail].get("hbm_bytes_per_launch", 0)
                         tsrc += "; + the NB = 1 launch of the layer's last partial round"
+                        covers = [name, tail]
             except Exception:
                 pass
         if mfma_time >= hbm_time:      # matrix-bound kernel: algorithmic FLOP/s against the dense MFMA peak
@@ -242,6 +243,9 @@ def roofline(net, x, dtype_name):
                     "algorithmic_mb_per_launch": round(nbytes / cnt / 1e6, 3)})
         if tsrc:
             out["traffic_from"] = tsrc
+        if covers:
+            out["call_covers"] = {"launches": covers, "note": "avg_launch_ms / achieved are those of the layer CALL = both launches back to back (in a "
+                                  "kernel trace: the sum of the two kernels' average durations)"}
         return out
 
     ranked = sorted(agg.items(), key=lambda kv: -kv[1][1])

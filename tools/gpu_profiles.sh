@@ -13,7 +13,7 @@ prof() { n=$1; shift
 # per-kernel durations are defined one batch at a time (what bench.py's roofline measures: prefix replays of ONE captured step);
 # the default command keeps two batches in flight, where launches of the two batches share the CUs and a trace's per-launch
 # durations are no longer per-kernel costs -- both traces are kept
-prof c2 --steps 100 --warmup 10 --in-flight 1
+prof c2 --steps 100 --warmup 10 --in-flight 1 --no-cpu-baseline
 prof c2_two --steps 100 --warmup 10
 prof c3 --config c3 --steps 20 --warmup 5 --no-cpu-baseline
 prof c4_bf16 --config c4 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline
