@@ -79,17 +79,27 @@ def roi_pool_backward(grad, input, rois, argmax, spatial_scale, pooled_height, p
     return gin
 
 
+_NMS_COUNTS = {}
+
+
 def nms(dets, scores, threshold):                                                                        # csrc/nms.h:34-36
     if dets.numel() == 0:
         return torch.empty((0,), dtype=torch.int64)                                                      # nms.h:41-42
-    dev = dets.device if (dets.is_cuda or not torch.cuda.is_available()) else torch.device("cuda", torch.cuda.current_device())
     f64 = dets.dtype == torch.float64                                                                    # AT_DISPATCH_FLOATING_TYPES, nms_cpu.cpp:95
     dt = torch.float64 if f64 else torch.float32
-    d, s = dets.to(device=dev, dtype=dt).contiguous(), scores.to(device=dev, dtype=dt).contiguous()
-    n = d.shape[0]
-    cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+    n = dets.shape[0]
+    if dets.is_cuda or not torch.cuda.is_available():
+        dev = dets.device
+        d, s = dets.to(dtype=dt).contiguous(), scores.to(device=dev, dtype=dt).contiguous()
+    else:                                                                                                # CPU tensors (test.py:158-160): one upload [4n | n]
+        dev = torch.device("cuda", torch.cuda.current_device())
+        buf = torch.cat([dets.to(dt).reshape(-1), scores.to(device="cpu", dtype=dt).reshape(-1)]).to(dev)
+        d, s = buf[:4 * n], buf[4 * n:]
+    cnt = _NMS_COUNTS.get((dev, n))
+    if cnt is None:
+        cnt = _NMS_COUNTS[(dev, n)] = torch.tensor([n], dtype=torch.int32, device=dev)
     keep = torch.zeros((1, n), dtype=torch.uint8, device=dev)
     scratch = torch.empty(max(_L.step_nms_scratch_bytes(1, n), 16), dtype=torch.uint8, device=dev)
     fn = _L.step_nms_batched_f64 if f64 else _L.step_nms_batched
     _chk(fn(_p(d), _p(s), _p(cnt), 1, n, threshold, _p(keep), _p(scratch), _s(d)), "nms")
-    return torch.nonzero(keep[0]).squeeze(1).to("cpu", torch.int64)                                      # ascending original indices (nms_cpu.cpp:88)
+    return torch.nonzero(keep[0].cpu()).squeeze(1)                                                       # ascending original indices (nms_cpu.cpp:88); the mask comes down in one copy

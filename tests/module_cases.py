@@ -9,6 +9,7 @@ from types import SimpleNamespace as NS
 import numpy as np
 import torch
 
+import oracle
 import step_amd
 from oracle import i3d_ref as R
 from step_amd import backbone, heads
@@ -1132,6 +1133,33 @@ def case_c5_full_size_properties(dev, golden):
         assert e < 4e-3, e
 
 
+def case_nms_operator_api(dev, golden):
+    """`step_amd.roi_layers.nms` (reference: roi_layers/nms.py:38, csrc/nms.h:34-52) as the reference's callers use it: CPU tensors
+    (test.py:158-160), GPU tensors, double boxes (nms_cpu.cpp:95 dispatch), 16-bit boxes (apex float_function), empty input --
+    the kept ORIGINAL indices, ascending, int64 on the CPU, bit-exact against the reference operator's restatement."""
+    from step_amd.roi_layers import nms
+    rs = np.random.RandomState(77)
+    for k in (1, 7, 40, 333):
+        c = rs.rand(k, 2) * 200
+        wh = rs.rand(k, 2) * 80 + 4
+        boxes = np.concatenate([c, c + wh], 1)
+        boxes[k // 2] = boxes[0]                                    # an exact duplicate: IoU = 1 >= thr
+        scores = rs.rand(k)
+        scores[k // 3] = scores[0]                                  # a score tie (stable order decides)
+        b32, s32 = boxes.astype(np.float32), scores.astype(np.float32)
+        want = oracle.nms(b32, s32, 0.4)
+        for place in ("cpu", dev):
+            got = nms(torch.from_numpy(b32).to(place), torch.from_numpy(s32).to(place), 0.4)
+            assert got.device.type == "cpu" and got.dtype == torch.int64 and np.array_equal(got.numpy(), want), (k, place)
+        got64 = nms(torch.from_numpy(boxes), torch.from_numpy(scores), 0.4)
+        assert np.array_equal(got64.numpy(), oracle.nms_f64(boxes, scores, 0.4)), k
+        bh = torch.from_numpy(b32).half()
+        goth = nms(bh.to(dev), torch.from_numpy(s32).to(dev), 0.4)
+        assert np.array_equal(goth.numpy(), oracle.nms(bh.float().numpy(), s32, 0.4)), k
+    e = nms(torch.zeros(0, 4), torch.zeros(0), 0.4)
+    assert e.numel() == 0 and e.dtype == torch.int64
+
+
 CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_golden", "case_context_golden",
              "case_twobranch_T3_and_losses_golden", "case_roinet_layouts", "case_training_step_matches_torch_autograd",
              "case_training_step_generic_weights",
@@ -1140,4 +1168,4 @@ CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_g
              "case_contextnet_backward_matches_oracle_autograd", "case_postprocess_golden",
              "case_batched_repack_follows_weight_updates", "case_stem_backward_16bit",
              "case_loss_masks_without_host_branches", "case_data_parallel_replicas", "case_train_select_device_front_end"]
-GPU_CASES = CPU_CASES + ["case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_c5_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_i3d_classifier_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
+GPU_CASES = CPU_CASES + ["case_nms_operator_api", "case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_c5_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_i3d_classifier_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
