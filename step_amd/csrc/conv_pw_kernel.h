@@ -18,8 +18,17 @@ namespace step {
 // latency-bound with one: every workgroup's prologue, its first HBM round trip and its epilogue are exposed).
 // The body is a device function so that other grids can carry pointwise workgroups (conv_tap_group_pw_kernel: a branch's 1x1x1 conv
 // on the CUs a grouped 3x3x3 launch leaves idle); blocks are addressed through p.gbase / p.gcount (grid_coords), never blockIdx alone.
+// EXT: the LDS comes from the caller (`arena`, conv_pw_lds_bytes<T, NB, WV>() bytes, 16-byte aligned) instead of a static array of this
+// function -- a kernel that carries workgroups of several bodies declares ONE arena of the largest size (static arrays of all the
+// bodies a kernel can reach are allocated side by side and would cap the occupancy of every workgroup by their SUM).
+// DRX > 0 overrides the depth of the global -> register ring (see DR below).
 template <typename T, int NB, int WV>
-__device__ __forceinline__ void conv_pw_body(const ConvParams& p) {
+constexpr int conv_pw_lds_bytes() {
+    constexpr int NT = WV * 64, ATILE = (WV / 2) * 64 * 80, BVEC = 2 * NB * (64 / (int)sizeof(T) / 16) * 512 * (int)sizeof(T) / 16;
+    return 3 * ATILE + 3 * ((BVEC + NT - 1) / NT) * NT * 16;
+}
+template <typename T, int NB, int WV, bool EXT = false, int DRX = 0>
+__device__ __forceinline__ void conv_pw_body(const ConvParams& p, unsigned char* arena = nullptr) {
     static_assert(WV == 8 || WV == 4, "8 or 4 waves");
     constexpr int NT = WV * 64, WM = WV / 2, TPX = WM * 64, EROWS = WM * 32;
     constexpr int ES = (int)sizeof(T);
@@ -35,7 +44,14 @@ __device__ __forceinline__ void conv_pw_body(const ConvParams& p) {
     typedef typename frag<T>::type frag_t;
 
     constexpr int BSTRIDE = Q * NT * 16;                    // weight buffer pitch: every thread stores all its Q vectors (no predicate)
-    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * ATILE + 3 * BSTRIDE];
+    static_assert(conv_pw_lds_bytes<T, NB, WV>() == 3 * ATILE + 3 * BSTRIDE, "conv_pw_lds_bytes");
+    unsigned char* lds;
+    if constexpr (EXT) {
+        lds = arena;
+    } else {
+        __shared__ __attribute__((aligned(16))) unsigned char own[3 * ATILE + 3 * BSTRIDE];
+        lds = own;
+    }
     unsigned char* const ldsA = lds;
     unsigned char* const ldsB = lds + 3 * ATILE;
 
@@ -89,7 +105,7 @@ __device__ __forceinline__ void conv_pw_body(const ConvParams& p) {
     // single step and the K loop ran latency-bound)
     // (four-wave NB = 3: 3 weight vectors per thread per step -- four register sets would spill; two suffice when a second
     // resident workgroup covers the latency)
-    constexpr int DR = (WV == 4 && NB == 3) ? 2 : 4;
+    constexpr int DR = DRX > 0 ? DRX : ((WV == 4 && NB == 3) ? 2 : 4);
     u32x4 RA[DR][2], RB[DR][Q];
     // FULL = whole slabs (Cin % CKT == 0) and a whole 256-pixel tile: no channel / pixel masks anywhere in the loop
     // (workgroup-uniform; the vector ALU work per step drops by two thirds)

@@ -104,14 +104,25 @@ constexpr int PP_R = 4;                             // load items per thread per
 constexpr int PP_MAXIN = 16;                        // max input tile edge
 
 // (body as a device function: `bid` of `nblk` workgroups -- pool333_pw_kernel carries these workgroups in front of a pointwise conv's)
-template <typename T, int KD, int KH, int KW, int SD, int SH, int SW, int NT>
+// (EXT: the two LDS images live in the caller's arena -- PP_LDS_BYTES, 16-byte aligned -- see conv_pw_body)
+constexpr int PP_LDS_BYTES = 2 * PP_MAXIN * PP_MAXIN * PP_SL * 16;
+template <typename T, int KD, int KH, int KW, int SD, int SH, int SW, int NT, bool EXT = false>
 __device__ __forceinline__ void maxpool_sep_body(const T* __restrict__ x, T* __restrict__ y, const PoolParams& p,
-                                                 int TH, int TW, int tiles_h, int tiles_w, int cchunks, int dseg, int nseg, int bid, int nblk) {
+                                                 int TH, int TW, int tiles_h, int tiles_w, int cchunks, int dseg, int nseg, int bid, int nblk,
+                                                 unsigned char* arena = nullptr) {
     constexpr int V = elem<T>::VEC;
     typedef typename Vec16<T, V>::raw raw;
+    static_assert(sizeof(raw) == 16, "16-byte vectors");
     constexpr int SL = PP_SL, R = PP_R * 256 / NT;        // NT = 256: 4 items per thread per pass, NT = 1024: 1
-    __shared__ __attribute__((aligned(16))) raw lds_raw[PP_MAXIN * PP_MAXIN * SL];
-    __shared__ __attribute__((aligned(16))) raw lds_w[PP_MAXIN * PP_MAXIN * SL];
+    raw *lds_raw, *lds_w;
+    if constexpr (EXT) {
+        lds_raw = (raw*)arena;
+        lds_w = (raw*)arena + PP_MAXIN * PP_MAXIN * SL;
+    } else {
+        __shared__ __attribute__((aligned(16))) raw own_raw[PP_MAXIN * PP_MAXIN * SL];
+        __shared__ __attribute__((aligned(16))) raw own_w[PP_MAXIN * PP_MAXIN * SL];
+        lds_raw = own_raw; lds_w = own_w;
+    }
 
     const int tid = threadIdx.x;
     // launch order -> XCD: consecutive workgroup ids go round-robin over the 8 XCDs; remap so that ids that
@@ -262,13 +273,17 @@ __global__ __launch_bounds__(NT) void maxpool_sep_kernel(const T* __restrict__ x
 
 // The 3x3x3 / 1 pool of an Inception block AND the block's fused 1x1x1 convs in ONE grid: both read the block input, neither fills
 // the chip on the 14x14 maps (the pool is 512 latency-bound workgroups, the convs 245-490) and one used to wait for the other.  The
-// pool's workgroups come first, the 256-thread workgroups of conv_pw_body<T, 1, 4> behind them (cp.gbase = npool); 32 + 43 KB of LDS:
-// two workgroups of either kind per CU.
+// pool's workgroups come first, the 256-thread workgroups of conv_pw_body<T, 1, 4> behind them (cp.gbase = npool).  Occupancy: the two
+// bodies' LDS images share ONE 43 KB arena (as static arrays of the two functions they added up to 75 KB) and the pointwise body runs
+// a two-deep global -> register ring here (154 instead of 182 VGPRs): THREE workgroups of either kind per CU instead of two --
+// C2 +0.4-1.0 %, C3 +1-2 % (same box, libraries swapped; the ring depth changes no arithmetic).
 template <typename T>
-__global__ __launch_bounds__(256, 2) void pool333_pw_kernel(const T* __restrict__ x, T* __restrict__ y, PoolParams p, int TH, int TW, int tiles_h,
+__global__ __launch_bounds__(256, 3) void pool333_pw_kernel(const T* __restrict__ x, T* __restrict__ y, PoolParams p, int TH, int TW, int tiles_h,
                                                             int tiles_w, int cchunks, int dseg, int nseg, int npool, ConvParams cp) {
-    if ((int)blockIdx.x < npool) maxpool_sep_body<T, 3, 3, 3, 1, 1, 1, 256>(x, y, p, TH, TW, tiles_h, tiles_w, cchunks, dseg, nseg, (int)blockIdx.x, npool);
-    else conv_pw_body<T, 1, 4>(cp);
+    constexpr int ARENA = PP_LDS_BYTES > conv_pw_lds_bytes<T, 1, 4>() ? PP_LDS_BYTES : conv_pw_lds_bytes<T, 1, 4>();
+    __shared__ __attribute__((aligned(16))) unsigned char arena[ARENA];     // ONE arena for whichever body this workgroup runs
+    if ((int)blockIdx.x < npool) maxpool_sep_body<T, 3, 3, 3, 1, 1, 1, 256, true>(x, y, p, TH, TW, tiles_h, tiles_w, cchunks, dseg, nseg, (int)blockIdx.x, npool, arena);
+    else conv_pw_body<T, 1, 4, true, 2>(cp, arena);
 }
 
 // Backward of the TF-SAME max pool (training): the gradient of an output goes to the FIRST maximum of its window in
