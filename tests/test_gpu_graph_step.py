@@ -90,3 +90,45 @@ def test_two_inference_batches_in_flight_equal_one_at_a_time():
             return p.keys() == q.keys() and all(same(p[k], q[k]) for k in p)
         return p == q
     assert same(got[0], alone[0]) and same(got[1], alone[1])
+
+
+def test_two_backbone_batches_in_flight_equal_one_at_a_time():
+    """bench.py's default loop for the forward-only configs: ONE network, one captured step per batch on its own stream, replayed
+    round-robin so that consecutive batches overlap on the chip.  The features of both batches equal the eager ones bit for bit
+    (scratch buffers are per call, i.e. per graph; packed weights are shared and read-only)."""
+    from types import SimpleNamespace as NS
+
+    import step_amd
+    from oracle import i3d_ref as R
+
+    dev = torch.device("cuda:0")
+    cfg = NS(base_net="i3d", kinetics_pretrain=None, freeze_stats=True, freeze_affine=True, fp16=False)
+    net = step_amd.BaseNet(cfg)
+    net.load_state_dict(R.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}))
+    net = net.to(dev).eval()
+    g = torch.Generator().manual_seed(5)
+    xs = [(torch.rand(2, 32, 3, 224, 224, generator=g) * 2 - 1).to(dev).bfloat16() for _ in range(2)]
+    with torch.no_grad():
+        want = [net(x).clone() for x in xs]
+    torch.cuda.synchronize()
+    assert not torch.equal(want[0], want[1])
+    flights = []
+    for x in xs:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.no_grad():
+            for _ in range(2):
+                net(x)
+            s.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=s):
+                y = net(x)
+        flights.append((s, graph, y))
+    torch.cuda.synchronize()
+    for k in range(12):                                         # round-robin replays: batch k + 1 starts while batch k drains
+        s, graph, _ = flights[k % 2]
+        with torch.cuda.stream(s):
+            graph.replay()
+    torch.cuda.synchronize()
+    for (s, graph, y), w in zip(flights, want):
+        assert torch.equal(y, w)
