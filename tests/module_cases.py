@@ -1137,7 +1137,19 @@ def case_nms_operator_api(dev, golden):
     """`step_amd.roi_layers.nms` (reference: roi_layers/nms.py:38, csrc/nms.h:34-52) as the reference's callers use it: CPU tensors
     (test.py:158-160), GPU tensors, double boxes (nms_cpu.cpp:95 dispatch), 16-bit boxes (apex float_function), empty input --
     the kept ORIGINAL indices, ascending, int64 on the CPU, bit-exact against the reference operator's restatement."""
+    import importlib
     from step_amd.roi_layers import nms
+    mod = importlib.import_module("step_amd.roi_layers.nms")
+    saved = mod._device
+    if dev == "cpu":                                                # interpreter build: "the device" of the upload path is the host (test-side patch)
+        mod._device = lambda: torch.device("cpu")
+    try:
+        _nms_operator_api(dev, nms)
+    finally:
+        mod._device = saved
+
+
+def _nms_operator_api(dev, nms):
     rs = np.random.RandomState(77)
     for k in (1, 7, 40, 333):
         c = rs.rand(k, 2) * 200
@@ -1167,5 +1179,5 @@ CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_g
              "case_reg_unit_pack_follows_weight_updates", "case_basenet_backward_matches_oracle_autograd",
              "case_contextnet_backward_matches_oracle_autograd", "case_postprocess_golden",
              "case_batched_repack_follows_weight_updates", "case_stem_backward_16bit",
-             "case_loss_masks_without_host_branches", "case_data_parallel_replicas", "case_train_select_device_front_end"]
-GPU_CASES = CPU_CASES + ["case_nms_operator_api", "case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_c5_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_i3d_classifier_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
+             "case_loss_masks_without_host_branches", "case_data_parallel_replicas", "case_train_select_device_front_end", "case_nms_operator_api"]
+GPU_CASES = CPU_CASES + ["case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_c5_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_i3d_classifier_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
