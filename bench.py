@@ -73,20 +73,7 @@ def cpu_baseline(net, seconds_budget=12.0):
     g = torch.Generator().manual_seed(123)
     x = torch.rand(1, 32, 3, 224, 224, generator=g) * 2 - 1     # the CPU sample is always a C2-shaped clip
     with torch.no_grad():
-        # torch's CPU conv3d does not scale to hundreds of threads: probe a few thread counts on a
-        # quarter-length clip and keep the fastest for the timed sample
-        best, best_t = None, None
-        for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
-            torch.set_num_threads(th)
-            R.basenet_forward(x[:, :8], sd)
-            t0 = time.perf_counter()
-            R.basenet_forward(x[:, :8], sd)
-            dt = time.perf_counter() - t0
-            if best_t is None or dt < best_t:
-                best, best_t = th, dt
-            if dt > 6.0:
-                break
-        torch.set_num_threads(best)
+        best, table = _cpu_threads(lambda: R.basenet_forward(x[:, :8], sd), ncpu)    # probe on a quarter-length clip
         R.basenet_forward(x, sd)                                 # warm-up
         n, t0 = 0, time.perf_counter()
         while True:
@@ -95,17 +82,182 @@ def cpu_baseline(net, seconds_budget=12.0):
             el = time.perf_counter() - t0
             if el > seconds_budget or n >= 64:
                 break
-    model = None
+    model = _cpu_model()
+    # cores = the threads the timed sample actually ran on (the fastest of the probed thread counts); host_cores = what the box has
+    return {"value": round(n / el, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "host_cores": ncpu, "cpu_model": model, "kind": "port", "threads_probe_s": table,
+            "sample": "%d single-clip [1,32,3,224,224] fp32 forwards of oracle/i3d_ref.basenet_forward (torch CPU) after 1 warm-up, %.1f s" % (n, el)}
+
+
+def _cpu_threads(probe, ncpu):
+    """torch's CPU conv3d does not scale to hundreds of threads: time `probe()` at a few thread counts and keep the fastest."""
+    best, best_t, table = None, None, {}
+    for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
+        torch.set_num_threads(th)
+        probe()
+        t0 = time.perf_counter()
+        probe()
+        dt = time.perf_counter() - t0
+        table[th] = round(dt, 3)
+        if best_t is None or dt < best_t:
+            best, best_t = th, dt
+        if dt > 6.0:
+            break
+    torch.set_num_threads(best)
+    return best, table
+
+
+def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
             if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
+                return line.split(":", 1)[1].strip()
     except OSError:
         pass
-    # cores = the threads the timed sample actually ran on (the fastest of the probed thread counts); host_cores = what the box has
-    return {"value": round(n / el, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "host_cores": ncpu, "cpu_model": model, "kind": "port",
-            "sample": "%d single-clip [1,32,3,224,224] fp32 forwards of oracle/i3d_ref.basenet_forward (torch CPU) after 1 warm-up, %.1f s" % (n, el)}
+    return None
+
+
+def cpu_pipeline_baseline(config, w, tubes, seconds_budget=15.0):
+    """cpu_baseline of --config c3 / c4: the torch-CPU fp32 restatement (oracle/i3d_ref.py; test infrastructure, used here only as the
+    timed CPU leg) of the same pipeline on ONE AVA-shaped clip with the workload's weights -- c3: BaseNet + ContextNet + the 3-step
+    inference() + the per-class post-processing loop; c4: forward + backward of BaseNet + ContextNet + the three heads' losses under
+    torch autograd (no optimizer step: the restatement has none).  Bounded sample, host cores of this box."""
+    import numpy as np
+    from oracle import i3d_ref as R
+    from oracle import postprocess_ref as PR
+    ncpu = os.cpu_count() or 1
+    f = lambda m: {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    sd_b, sd_c = f(w.base), f(w.ctx)
+    nets_sd = {k: f(v) for k, v in w.nets.items() if k.startswith("det_net")}
+    g = torch.Generator().manual_seed(123)
+    x = torch.rand(1, 36, 3, 400, 400, generator=g) * 2 - 1
+    from step_amd.tube_math import generate_anchors
+    anchors = generate_anchors()[:tubes] * 400.0
+    tl = [np.tile(anchors[:, None, :], (1, 3, 1)).astype(np.float32)]
+    if config == "c3":
+        def once():
+            with torch.no_grad():
+                cf = R.basenet_forward(x, sd_b)
+                cx = R.contextnet_forward(cf, sd_c)
+                hist = R.inference(cf, cx, nets_sd, tl)
+                return PR.postprocess(hist)
+        what = "BaseNet + ContextNet + 3-step inference() + post-processing on 1 x [36,3,400,400] clip, %d tubes" % tubes
+    else:
+        K = tubes
+        params = []
+        for sd in [sd_b, sd_c] + list(nets_sd.values()):
+            for k, v in sd.items():
+                if v.dtype.is_floating_point and "batch3d" not in k and "running" not in k:
+                    v.requires_grad_(True)
+                    params.append(v)
+        at = torch.from_numpy(anchors.astype(np.float32))
+        tgt = torch.zeros(K, 3, 66)
+        tgt[:, :, :4] = at.view(K, 1, 4) + 4.0
+        tgt[:, :, 4] = 1; tgt[:, :, 5] = 1; tgt[:, :, 6 + 7] = 1
+        import oracle
+
+        class RoiAlignCPU(torch.autograd.Function):               # the C restatement's forward / backward pair under torch autograd
+            @staticmethod
+            def forward(ctx_, feat, rois):
+                ctx_.shape, ctx_.rois = tuple(feat.shape), rois.numpy()
+                return torch.from_numpy(oracle.roi_align_forward(feat.detach().numpy(), ctx_.rois, (7, 7), 1 / 16., 0))
+
+            @staticmethod
+            def backward(ctx_, g_):
+                return torch.from_numpy(oracle.roi_align_backward(g_.contiguous().numpy(), ctx_.rois, (7, 7), 1 / 16., 0, ctx_.shape)), None
+
+        def once():
+            for p_ in params:
+                p_.grad = None
+            cf = R.basenet_forward(x, sd_b)
+            cx = R.contextnet_forward(cf, sd_c)
+            loss = 0.0
+            for it in range(3):
+                Tl = 3 * w.args.NUM_CHUNKS[it + 1]
+                t0 = (9 - Tl) // 2
+                fr = (t0 + torch.arange(Tl, dtype=torch.float32)).view(1, Tl, 1).expand(K, Tl, 1)
+                flat = torch.cat([fr, at.view(K, 1, 4).expand(K, Tl, 4)], 2).contiguous()
+                pooled = RoiAlignCPU.apply(cf.reshape(-1, *cf.shape[2:]).contiguous(), flat.reshape(-1, 5).contiguous())
+                pooled = pooled.view(K, Tl, *pooled.shape[1:])
+                o = R.twobranch_forward(pooled, cx.expand(K, -1, -1, -1, -1)[:, :, t0:t0 + Tl], nets_sd["det_net%d" % it], tubes=flat, targets=tgt)
+                loss = loss + o[4].mean() + 5 * o[5].mean() + o[6].mean()
+            loss.backward()
+            return float(loss.detach())
+        what = "forward + backward (torch autograd) of BaseNet + ContextNet + 3 heads' losses on 1 x [36,3,400,400] clip, %d tubes" % tubes
+    small = x[:, :12]
+    best, table = _cpu_threads(lambda: _nograd(R.basenet_forward, small, sd_b), ncpu)
+    once()                                                       # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        once()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 16:
+            break
+    return {"value": round(n / el, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "host_cores": ncpu, "cpu_model": _cpu_model(),
+            "kind": "port", "threads_probe_s": table,
+            "sample": "%d x (%s) of oracle/i3d_ref.py (torch CPU fp32) after 1 warm-up, %.1f s" % (n, what, el)}
+
+
+def _nograd(fn, *a):
+    with torch.no_grad():
+        return fn(*a)
+
+
+class ClockSampler:
+    """Best-effort shader-clock reading while a loop runs: a thread polls the amdgpu sysfs nodes of the device (hwmon freq1_input in
+    Hz, else the starred line of pp_dpm_sclk) every 20 ms.  None when the box exposes neither (nothing else is affected)."""
+
+    def __init__(self, index=0):
+        import glob
+        self.paths = []
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk")) or glob.glob(os.path.join(c, "hwmon/hwmon*/freq1_input"))]
+        if cards:
+            c = cards[min(index, len(cards) - 1)]
+            self.paths = glob.glob(os.path.join(c, "hwmon/hwmon*/freq1_input")) + [os.path.join(c, "pp_dpm_sclk")]
+        self.samples, self._stop, self._th = [], False, None
+
+    def _read(self):
+        for p_ in self.paths:
+            try:
+                txt = open(p_).read()
+            except OSError:
+                continue
+            if p_.endswith("freq1_input"):
+                v = float(txt.strip()) / 1e9
+                if v > 0:
+                    return v
+            else:
+                for line in txt.splitlines():
+                    if "*" in line:
+                        return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip()) / 1e3
+        return None
+
+    def __enter__(self):
+        import threading
+        def loop():
+            while not self._stop:
+                try:
+                    v = self._read()
+                except Exception:
+                    v = None
+                if v:
+                    self.samples.append(v)
+                time.sleep(0.02)
+        if self.paths:
+            self._th = threading.Thread(target=loop, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._th is not None:
+            self._th.join(timeout=1.0)
+        return False
+
+    def median(self):
+        s_ = sorted(self.samples)
+        return round(s_[len(s_) // 2], 3) if s_ else None
 
 
 def sustained_mfma(dev):
@@ -289,13 +441,17 @@ def main():
                     help="tuning aid: side streams of the Inception blocks (step_amd.backbone.BRANCH_STREAMS; default: the module's)")
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
                     help="c2 / c5: independent batches kept in flight on separate HIP streams (each step is still one batch; default 2)")
+    ap.add_argument("--clips", type=int, default=None, help="clips per GPU (default: the config's: c2 8, c5 4, c3 4, c4 1)")
+    ap.add_argument("--tubes", type=int, default=None, help="c3 / c4: tubes per clip (default: c3 11, c4 5)")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0,
+                    help="c2 / c5: length of the second, sustained loop of the same captured step reported under 'sustained' (0 = skip)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="tuning aid: a planner option of the library (include/step_amd.h step_set_option), e.g. conv_group_pw=0; repeatable")
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
     global CLIPS_PER_GPU, T_IN, HW_IN, GFLOP_PER_CLIP, ACT_MB_PER_CLIP
     c = CONFIGS[a.config]
-    CLIPS_PER_GPU, T_IN, HW_IN, GFLOP_PER_CLIP, ACT_MB_PER_CLIP = c["clips"], c["T"], c["HW"], c["gflop"], c["act_mb"]
+    CLIPS_PER_GPU, T_IN, HW_IN, GFLOP_PER_CLIP, ACT_MB_PER_CLIP = a.clips or c["clips"], c["T"], c["HW"], c["gflop"], c["act_mb"]
     a.dtype = a.dtype or c["dtype"]
 
     rank = int(os.environ.get("RANK", "0"))
@@ -405,10 +561,22 @@ def main():
         nfl = len(flights) if graph is not None else 1
         el = timed(nfl)
         el_one = timed(1) if nfl > 1 else el                   # the same K steps one batch at a time (reported beside the headline)
+        # A second, SUSTAINED loop of the same captured step(s): the contract's K steps can be a few tens of milliseconds, shorter than
+        # the power manager's settling time, so a throttling cliff could hide behind them.  Same launches, >= --sustained-seconds long.
+        sus = None
+        if a.sustained_seconds > 0:
+            keep_steps, keep_warm = a.steps, a.warmup
+            a.steps, a.warmup = max(a.steps, int(a.sustained_seconds * 1.1 / (el / keep_steps)) + 1), 0
+            with ClockSampler(local_dev) as cs:
+                el_s = timed(nfl)
+            sus = (a.steps, el_s, cs.median(), len(cs.samples))
+            a.steps, a.warmup = keep_steps, keep_warm
     if dist is not None:
-        t = torch.tensor([el, el_one], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        t = torch.tensor([el, el_one, sus[1] if sus else 0.0], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el, el_one = float(t[0].item()), float(t[1].item())
+        if sus:
+            sus = (sus[0], float(t[2].item())) + sus[2:]
 
     out = None
     if rank == 0:
@@ -427,6 +595,12 @@ def main():
                                        "note": "the same K steps replayed one after the other on one stream (the loop of rounds 1-2)"},
                "ranks": {"world_size": world, "backend": (dist.get_backend() + " (RCCL over xGMI)" if dist.get_backend() == "nccl" else dist.get_backend()) if dist is not None else None,
                          "devices_visible": ndev}}
+        if sus:
+            out["sustained"] = {"seconds": round(sus[1], 3), "steps": sus[0], "value": round(world * CLIPS_PER_GPU * sus[0] / sus[1], 2),
+                                "ms_per_step": round(sus[1] / sus[0] * 1e3, 4), "clock_ghz": sus[2], "clock_samples": sus[3],
+                                "note": "the same loop (same captured steps, same batches in flight) run for >= %.1f s right after the timed K steps; "
+                                        "clock_ghz = median shader clock from the amdgpu sysfs node sampled every 20 ms during it (null: not exposed "
+                                        "on this box); `value` / `ms_per_step` above stay on the contract's K steps" % a.sustained_seconds}
         per_gpu = val / world
         out["backbone_roofline"] = {
             "hbm_frac": round(per_gpu * (ACT_MB_PER_CLIP + W_MB / CLIPS_PER_GPU) * 1e6 / (PEAK_HBM_GBS * 1e9), 4),
@@ -464,10 +638,11 @@ def main():
 def pipeline_bench(a, c, dev, tdt, rank, world, dist):
     """--config c3 / c4: the whole-pipeline workloads (not the headline metric; same timing contract)."""
     from step_amd import backbone, ops, workloads
+    tubes = a.tubes or (11 if a.config == "c3" else 5)
     if a.config == "c3":
-        w = workloads.C3Inference(dev, tdt, batch=CLIPS_PER_GPU, tubes=11, seed=123 + rank, graph=not a.no_graph)
-        what = "C3: full two_branch inference (I3D backbone + ContextNet + 3 refinement steps with ROIAlign over 11 tubes/clip + " \
-               "batched per-class NMS), %d x [36,3,400,400] clips per GPU" % CLIPS_PER_GPU
+        w = workloads.C3Inference(dev, tdt, batch=CLIPS_PER_GPU, tubes=tubes, seed=123 + rank, graph=not a.no_graph)
+        what = "C3: full two_branch inference (I3D backbone + ContextNet + 3 refinement steps with ROIAlign over %d tubes/clip + " \
+               "batched per-class NMS), %d x [36,3,400,400] clips per GPU" % (tubes, CLIPS_PER_GPU)
         metric = "clips_per_sec_inference_T36_400"
     elif os.environ.get("STEP_BENCH_SELECT", "0") == "1":
         # the reference's whole iteration: eval inference over the first two steps + train_select between the steps
@@ -481,11 +656,11 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
         # with 16-bit activations is bound by the host issuing ~1300 launches; several ranks: eager (the bucketed exchange)
         # (fp32 is GPU-bound and measured SLOWER replayed than eager -- 54.6 vs 51.0 ms -- so only the 16-bit step is captured)
         graphed = world == 1 and not a.no_graph and a.dtype != "f32"
-        w = workloads.C4TrainStep(dev, batch=CLIPS_PER_GPU, seed=123 + rank, dtype=tdt, capturable=graphed)
+        w = workloads.C4TrainStep(dev, batch=CLIPS_PER_GPU, tubes_per_clip=tubes, seed=123 + rank, dtype=tdt, capturable=graphed)
         if graphed:
             w.capture(warmup=max(a.warmup, 2))
         what = "C4: one training step (backbone + ContextNet + max_iter=3 heads on 3/3/9-frame tubes, BCE + smooth-L1 losses, gradient all-reduce, Adam), " \
-               "%d x [36,3,400,400] clip(s) per GPU, 5 tubes/clip" % CLIPS_PER_GPU
+               "%d x [36,3,400,400] clip(s) per GPU, %d tubes/clip" % (CLIPS_PER_GPU, tubes)
         metric = "clips_per_sec_train_T36_400"
     # C3 with a captured graph: TWO batches in flight (see main(): the same idea) -- a second workload object on the same networks,
     # its own clips / captured graph / stream; batch k + 1 is launched before batch k is post-processed (its one host sync waits for
@@ -495,7 +670,7 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
     for i in range(1, nfl):
         si = torch.cuda.Stream()
         with torch.cuda.stream(si):
-            ws.append(workloads.C3Inference(dev, tdt, batch=CLIPS_PER_GPU, tubes=11, seed=123 + rank, share=w))
+            ws.append(workloads.C3Inference(dev, tdt, batch=CLIPS_PER_GPU, tubes=tubes, seed=123 + rank, share=w))
             torch.cuda.synchronize()
         streams.append(si)
 
@@ -549,7 +724,7 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
         out = {"metric": metric, "value": round(val, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": max(a.warmup, 2),
                "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": what + ", inputs resident in HBM, random-init weights", "clips_per_gpu": CLIPS_PER_GPU, "T": 36, "HW": 400,
+               "config": {"workload": what + ", inputs resident in HBM, random-init weights", "clips_per_gpu": CLIPS_PER_GPU, "tubes_per_clip": tubes, "T": 36, "HW": 400,
                           "parallelism": "clip-sharded replicas x%d (%s)" % (world, "no data-path collective" if a.config == "c3" else "one gradient all-reduce per step"),
                           "batches_in_flight": nfl,
                           "launch": ("hipGraph replay + eager post-processing" + (", %d batches in flight (own clips / graph / stream each; batch k + 1 launched before batch k is post-processed)" % nfl if nfl > 1 else ""))
@@ -570,11 +745,23 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
             mf = flops / (PEAK[a.dtype] * 1e12) >= nbytes / (PEAK_HBM_GBS * 1e9)
             ach = (flops / (ms * 1e-3) / 1e12) if mf else (nbytes / (ms * 1e-3) / 1e9)
             peak = PEAK[a.dtype] if mf else PEAK_HBM_GBS
+            traffic, tsrc = None, None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+                hit = tj.get("kernels_" + a.config, {}).get(name)
+                if hit:
+                    traffic = hit.get("hbm_bytes_per_launch")
+                    tsrc = "NOT measured in this run: profiles/traffic_latest.json kernels_%s (%s; taken at commit %s)" % (a.config, tj.get("source"), tj.get("commit_" + a.config, tj.get("commit", "?")))
+            except Exception:
+                pass
             out["roofline"] = {"kernel": name, "bound": "mfma" if mf else "hbm", "achieved": round(ach, 2), "peak": peak,
-                               "unit": "TFLOP/s" if mf else "GB/s", "frac": round(ach / peak, 4), "traffic": None,
+                               "unit": "TFLOP/s" if mf else "GB/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_from": tsrc,
+                               "algorithmic_gflop_per_launch": round(flops / cnt / 1e9, 3), "algorithmic_mb_per_launch": round(nbytes / cnt / 1e6, 3),
                                "launches_per_step": cnt, "avg_launch_ms": round(ms / cnt, 4),
                                "share_of_instrumented_kernel_time": round(ms / sum(v[1] for v in agg.values()), 3),
                                "note": "instrumented launches of step_amd.ops: conv / stem / pool forward, the data-gradient convs and conv weight gradients (torch glue kernels are not in this table)"}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_pipeline_baseline(a.config, w, tubes)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
