@@ -92,7 +92,6 @@ enum {
     STEP_OPT_WGRAD_MINPIX,     /*  0 (default: 512 for the atomics forms, 64 (fp32 MFMA) / 256 (16-bit) with a workspace) | n: least pixels per wavefront job of the per-tap weight gradient (fp32 summation order) */
     STEP_OPT_WGRAD16_LDS,      /*  1 (default) | 0: 3x3 windows of step_conv_wgrad16_ws on the per-tap kernel instead of the LDS-tiled GEMM */
     STEP_OPT_CONV_GROUP_PW,    /*  2^20 (default: always) | n: step_conv_forward_group carries a pointwise item inside the 3x3x3 members' grid when they are at most n workgroups; 0 never (bit-identical) */
-    STEP_OPT_ROI_BWD_GATHER,   /*  1 (default) ROIAlign backward as a fixed-order gather per feature cell (deterministic) | 0: the fp32-atomics scatter of ROIAlign_cuda.cu */
     STEP_OPT_COUNT_
 };
 STEP_API int step_set_option(int option, int value);
@@ -123,13 +122,21 @@ STEP_API int step_roi_align_tubes_forward(const void* feat, int dtype, const flo
 
 /* ROIAlign backward.    replaces _C.roi_align_backward  (csrc/ROIAlign.h:51-69,
  *                       cuda/ROIAlign_cuda.cu:201-278,326-370)
- * grad [K,C,ph,pw] / [K,ph,pw,C]  ->  grad_feat [B,C,H,W] / [B,H,W,C] (fp32 only).  Default: every cell of grad_feat gathers
- * its samples in a fixed order (the same products gtop * w / count as the reference's scatter; deterministic, no clear, no
- * atomics); option roi_bwd_gather = 0: grad_feat is zeroed (ROIAlign_cuda.cu:340) and accumulated with fp32 atomics.
+ * grad [K,C,ph,pw] / [K,ph,pw,C]  ->  grad_feat [B,C,H,W] / [B,H,W,C] (fp32 only).
+ * `mode` is a PER-CALL argument (it changes the fp32 summation order, i.e. results in the last bits, so it is not a process-wide
+ * planner option: two threads of one process -- nn.DataParallel replicas -- cannot flip each other's determinism):
+ *   STEP_ROI_BWD_GATHER  every cell of grad_feat gathers its samples in a fixed order, rois ascending (the same products
+ *                        gtop * w / count as the reference's scatter): bit-reproducible, no clear, no atomics.  Every cell walks the
+ *                        K roi headers (batch index first), so its cost grows with K x cells; the channels-last form evaluates a
+ *                        roi's weights once per cell for all channels, the NCHW form once per (cell, channel).
+ *   STEP_ROI_BWD_ATOMIC  the reference's algorithm: grad_feat is zeroed (ROIAlign_cuda.cu:340) and every sample adds its four
+ *                        products with fp32 atomics (ROIAlign_cuda.cu:201-278); summation order varies from run to run.
  */
+#define STEP_ROI_BWD_GATHER 0
+#define STEP_ROI_BWD_ATOMIC 1
 STEP_API int step_roi_align_backward(const float* grad, int layout, const float* rois, int K, int B, int C, int H,
                                      int W, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
-                                     float* grad_feat, step_stream_t stream);
+                                     int mode, float* grad_feat, step_stream_t stream);
 
 /* ROIPool forward.      replaces _C.roi_pool_forward    (csrc/ROIPool.h:35-48,
  *                       cuda/ROIPool_cuda.cu:40-101,134-180)
@@ -434,6 +441,21 @@ STEP_API int step_adam_flat(float* param, float* grad, float* exp_avg, float* ex
 STEP_API int step_adam_flat_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long long n,
                                 const long long* seg_end, const float* seg_lr, const float* seg_wd, int n_seg, double beta1,
                                 double beta2, double eps, long long* step_dev, float* bias_corr, float grad_scale, int zero_grad,
+                                step_stream_t stream);
+/* Mixed-precision training with dynamic loss scaling (train.py:136-139 apex amp O1, :342-345 `with amp.scale_loss(loss, optimizer)`),
+ * as one call with every decision on the device (capturable): amp_state = 4 device floats {scale, growth_tracker, found_inf, unused}.
+ * The caller multiplied the loss by amp_state[0] before backward, so `grad` holds scale x the gradients.  The call
+ *   1. scans the gradient arena for inf / nan (found_inf = 1),
+ *   2. runs step_adam_flat_dev with grad_scale / scale -- or, when found_inf is set, SKIPS the step as apex's patched
+ *      optimizer.step() / torch.amp.GradScaler.step() do: parameters, moments and the step count stay as they are (zero_grad
+ *      still clears the gradients),
+ *   3. updates the scale like DynamicLossScaler / GradScaler.update(): overflow -> scale *= backoff_factor, tracker = 0; else
+ *      tracker += 1 and after growth_interval clean steps scale *= growth_factor; found_inf = 0.
+ * apex's defaults: initial scale 2^16, growth 2, backoff 0.5, interval 2000. */
+STEP_API int step_adam_flat_amp(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                                const long long* seg_end, const float* seg_lr, const float* seg_wd, int n_seg, double beta1,
+                                double beta2, double eps, long long* step_dev, float* bias_corr, float grad_scale, int zero_grad,
+                                float* amp_state, float growth_factor, float backoff_factor, int growth_interval,
                                 step_stream_t stream);
 
 /* Activation gradient of the fused conv unit (the backward of Unit3Dpy's BatchNorm3d(eval) + ReLU, models/i3dpt.py:100-111,

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _L = ctypes.CDLL(os.environ.get("STEP_AMD_LIB") or os.path.join(os.path.dirname(_HERE), "step_amd", "libstep_amd.so"))
 _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 _L.step_roi_align_forward.argtypes = [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]
-_L.step_roi_align_backward.argtypes = [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]
+_L.step_roi_align_backward.argtypes = [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp]
 _L.step_roi_pool_forward.argtypes = [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]
 _L.step_roi_pool_backward.argtypes = [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]
 _L.step_nms_scratch_bytes.restype = ctypes.c_size_t
@@ -27,6 +27,10 @@ _L.step_nms_batched.argtypes = [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]
 _L.step_nms_batched_f64.argtypes = [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]
 _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 _NCHW = 0
+# ROIAlign backward mode (a per-call argument of the C ABI): 0 = fixed-order gather (bit-reproducible; every cell walks the K roi
+# headers), 1 = the algorithm of cuda/ROIAlign_cuda.cu:201-278 (zero + fp32 atomics).  The shim stands in for the reference's own
+# CUDA operator on torch-contiguous maps with hundreds of rois, so it runs that algorithm unless STEP_ROI_BWD_DETERMINISTIC=1.
+_ROI_BWD_MODE = 0 if os.environ.get("STEP_ROI_BWD_DETERMINISTIC") == "1" else 1
 
 
 def _p(t):
@@ -56,7 +60,7 @@ def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, b
     grad, rois = grad.contiguous().float(), rois.contiguous().float()
     gin = torch.empty((batch_size, channels, height, width), dtype=torch.float32, device=grad.device)     # zeroed by the op
     _chk(_L.step_roi_align_backward(_p(grad), _NCHW, _p(rois), rois.shape[0], batch_size, channels, height, width, pooled_height,
-                                    pooled_width, spatial_scale, sampling_ratio, _p(gin), _s(grad)), "roi_align_backward")
+                                    pooled_width, spatial_scale, sampling_ratio, _ROI_BWD_MODE, _p(gin), _s(grad)), "roi_align_backward")
     return gin
 
 

@@ -4,7 +4,7 @@ ROIAlign / ROIPool / NMS.  Drop-in for the reference's `models` package and
 from .backbone import BaseNet, I3D, I3D_head, build_base_i3d, weights_init  # noqa: F401
 from .heads import ContextNet, ROINet, TwoBranchNet  # noqa: F401
 from . import dist  # noqa: F401
-from .optim import FlatAdam  # noqa: F401
+from .optim import FlatAdam, LossScaler  # noqa: F401
 
 __all__ = ["BaseNet", "ROINet", "TwoBranchNet", "ContextNet", "I3D", "I3D_head"]
 __version__ = "0.1.0"

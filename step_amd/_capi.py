@@ -4,7 +4,8 @@ import ctypes as C
 
 F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
-ABI_VERSION = 26
+ROI_BWD_GATHER, ROI_BWD_ATOMIC = 0, 1
+ABI_VERSION = 27
 
 vp, fp, ip, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # raw device addresses
 i, f, ll, sz = C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -38,7 +39,7 @@ SIGNATURES = {
     "step_option_name": (C.c_char_p, [i]),
     "step_roi_align_forward": (i, [vp, i, i, fp, i, i, i, i, i, i, i, f, i, vp, vp]),
     "step_roi_align_tubes_forward": (i, [vp, i, fp, i, i, i, i, i, i, i, i, i, f, i, vp, vp]),
-    "step_roi_align_backward": (i, [fp, i, fp, i, i, i, i, i, i, i, f, i, fp, vp]),
+    "step_roi_align_backward": (i, [fp, i, fp, i, i, i, i, i, i, i, f, i, i, fp, vp]),
     "step_roi_pool_forward": (i, [vp, i, i, fp, i, i, i, i, i, i, i, f, vp, ip, vp]),
     "step_roi_pool_backward": (i, [fp, ip, i, fp, i, i, i, i, i, i, i, fp, vp]),
     "step_mfma_clock_probe": (i, [vp, i, i, vp]),
@@ -87,6 +88,7 @@ SIGNATURES = {
     "step_select_prepare": (i, [fp, fp, fp, fp, i, i, i, i, ip, fp, ip, i, f, f, fp, fp, fp, fp, fp, vp]),
     "step_adam_flat": (i, [fp, fp, fp, fp, ll, vp, fp, fp, i, C.c_double, C.c_double, C.c_double, i, f, i, vp]),
     "step_adam_flat_dev": (i, [fp, fp, fp, fp, ll, vp, fp, fp, i, C.c_double, C.c_double, C.c_double, vp, fp, f, i, vp]),
+    "step_adam_flat_amp": (i, [fp, fp, fp, fp, ll, vp, fp, fp, i, C.c_double, C.c_double, C.c_double, vp, fp, f, i, fp, f, f, i, vp]),
 }
 
 
@@ -115,7 +117,7 @@ def check(status, what):
 # ---- planner options (include/step_amd.h: step_set_option) -----------------------------------------------------------
 OPTION_IDS = {name: k for k, name in enumerate((
     "conv_impl", "conv_nb", "conv_waves", "conv_phased", "conv_gen", "conv_gmode", "conv_pws", "conv_splitk", "conv_tail",
-    "conv_slots", "pool_direct", "wgrad_minpix", "wgrad16_lds", "conv_group_pw", "roi_bwd_gather"))}
+    "conv_slots", "pool_direct", "wgrad_minpix", "wgrad16_lds", "conv_group_pw"))}
 
 
 def set_option(lib, name, value):

@@ -115,7 +115,10 @@ __global__ void detect_nms_wave_kernel(const float* __restrict__ prob, long long
     if (lane < n) {
         const float* bx = loc + tube * loc_stride;
         x1 = fmaxf(0.f, bx[0]); y1 = fmaxf(0.f, bx[1]); x2 = fminf(width, bx[2]); y2 = fminf(height, bx[3]);
-        if (!((x1 < __fsub_rn(x2, 2.f)) && (y1 < __fsub_rn(y2, 2.f)))) { x1 = 0.f; y1 = 0.f; x2 = width; y2 = height; }
+        // np.maximum / np.minimum PROPAGATE a NaN (fmaxf / fminf drop it), and a NaN coordinate then fails the `<` test of
+        // valid_tubes: the reference turns a box with any NaN coordinate into the whole frame
+        const bool nan_in = (bx[0] != bx[0]) || (bx[1] != bx[1]) || (bx[2] != bx[2]) || (bx[3] != bx[3]);
+        if (nan_in || !((x1 < __fsub_rn(x2, 2.f)) && (y1 < __fsub_rn(y2, 2.f)))) { x1 = 0.f; y1 = 0.f; x2 = width; y2 = height; }
         s = prob[tube * prob_stride + c];
         valid = s > conf;
         if (c == 0 && boxes_out) {

@@ -25,9 +25,14 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, f
                                                         const long long* __restrict__ seg_end, const float* __restrict__ seg_lr,
                                                         const float* __restrict__ seg_wd, int n_seg, float beta2, float omb1,
                                                         float omb2, float eps, float bc1, float bc2_sqrt, float gscale,
-                                                        int zero_grad, const float* __restrict__ bc_dev) {
+                                                        int zero_grad, const float* __restrict__ bc_dev, const float* __restrict__ amp) {
     __shared__ long long s_end[MAXSEG];                    // 4 KiB for the usual few hundred tensors: LDS does not limit occupancy
     if (bc_dev) { bc1 = bc_dev[0]; bc2_sqrt = bc_dev[1]; } // step counter on the device (adam_bias_kernel): graph replays advance it
+    // dynamic loss scaling (step_adam_flat_amp): amp = {scale, growth_tracker, found_inf, -}.  The gradients carry the factor `scale`;
+    // a step whose gradients held an inf / nan is SKIPPED (apex amp O1's patched optimizer.step, torch.amp.GradScaler.step) -- no
+    // moment decay, no parameter change; the gradient arena is still cleared when the caller asked for it.
+    bool skip = false;
+    if (amp) { skip = amp[2] != 0.f; gscale = gscale * (1.f / amp[0]); }
     for (int i = threadIdx.x; i < n_seg; i += blockDim.x) s_end[i] = seg_end[i];
     __syncthreads();
     for (long long vec = (long long)blockIdx.x * blockDim.x + threadIdx.x; vec < nvec; vec += (long long)blockDim.x * gridDim.x) {
@@ -36,6 +41,10 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, f
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
             if (s_end[mid] > e) hi = mid; else lo = mid + 1;
+        }
+        if (skip) {
+            if (zero_grad) *(f32x4*)(g + e) = f32x4{0.f, 0.f, 0.f, 0.f};
+            continue;
         }
         const float lr = seg_lr[lo], wd = seg_wd[lo];
         const float step_size = lr / bc1;
@@ -60,12 +69,40 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, f
 
 // the step counter of a CAPTURED optimizer step lives on the device: a replayed graph cannot receive a new host scalar.  One
 // thread advances it and leaves the two bias corrections (double precision, as the host path) for adam_flat_kernel.
-__global__ void adam_bias_kernel(long long* step, float* bc, double beta1, double beta2) {
+__global__ void adam_bias_kernel(long long* step, float* bc, double beta1, double beta2, const float* amp) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (amp && amp[2] != 0.f) return;                  // skipped step (overflowed gradients): the step count does not advance
         const long long t = *step + 1;
         *step = t;
         bc[0] = (float)(1.0 - pow(beta1, (double)t));
         bc[1] = (float)sqrt(1.0 - pow(beta2, (double)t));
+    }
+}
+
+// ---- dynamic loss scaling (mixed-precision training: train.py:136-139 `amp.initialize(opt_level="O1")`, :342-345 `amp.scale_loss`) ----
+// amp_state = {scale, growth_tracker, found_inf, unused}: the state of apex's DynamicLossScaler / torch.amp.GradScaler, on the device so
+// that a captured training step needs no host decision.  grad_scan raises found_inf when any gradient is inf / nan (the overflow check
+// apex runs while unscaling); loss_scale_update is GradScaler.update(): overflow -> scale *= backoff, tracker = 0; else tracker += 1 and
+// at growth_interval clean steps scale *= growth, tracker = 0; found_inf is cleared for the next step.
+__global__ __launch_bounds__(256) void grad_scan_kernel(const float* __restrict__ g, long long nvec, float* __restrict__ amp) {
+    bool bad = false;
+    for (long long vec = (long long)blockIdx.x * blockDim.x + threadIdx.x; vec < nvec; vec += (long long)blockDim.x * gridDim.x) {
+        const u32x4 v = *(const u32x4*)(g + vec * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bad |= (v[j] & 0x7f800000u) == 0x7f800000u;     // exponent all ones: inf or nan
+    }
+    if (bad) amp[2] = 1.f;                                  // (every writer stores the same value)
+}
+
+__global__ void loss_scale_update_kernel(float* amp, float growth, float backoff, int interval) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (amp[2] != 0.f) { amp[0] = amp[0] * backoff; amp[1] = 0.f; }
+        else {
+            const float t = amp[1] + 1.f;
+            if (t >= (float)interval) { amp[0] = amp[0] * growth; amp[1] = 0.f; }
+            else amp[1] = t;
+        }
+        amp[2] = 0.f;
     }
 }
 
@@ -133,11 +170,12 @@ extern "C" {
 
 static int adam_flat_launch(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long long n, const long long* seg_end,
                             const float* seg_lr, const float* seg_wd, int n_seg, double beta1, double beta2, double eps, int step_no,
-                            long long* step_dev, float* bc_dev, float grad_scale, int zero_grad, step_stream_t stream) {
+                            long long* step_dev, float* bc_dev, float grad_scale, int zero_grad, step_stream_t stream,
+                            const float* amp = nullptr) {
     if (n < 0 || (n & 3) || n_seg <= 0 || n_seg > ADAM_MAX_SEG || (!step_dev && step_no < 1)) return STEP_E_SHAPE;
     if (!(beta1 >= 0. && beta1 < 1.) || !(beta2 >= 0. && beta2 < 1.) || !(eps >= 0.)) return STEP_E_SHAPE;
     if (step_dev && !bc_dev) return STEP_E_NULL;
-    if (step_dev) STEP_LAUNCH(adam_bias_kernel, dim3(1), dim3(64), stream, step_dev, bc_dev, beta1, beta2);   // (also for an empty arena: the step counts)
+    if (step_dev) STEP_LAUNCH(adam_bias_kernel, dim3(1), dim3(64), stream, step_dev, bc_dev, beta1, beta2, amp);   // (also for an empty arena: the step counts)
     if (n == 0) return step_dev ? STEP_LAUNCH_CHECK() : STEP_OK;
     if (!param || !grad || !exp_avg || !exp_avg_sq || !seg_end || !seg_lr || !seg_wd) return STEP_E_NULL;
     if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq)) & 15) return STEP_E_ALIGN;
@@ -152,11 +190,11 @@ static int adam_flat_launch(float* param, float* grad, float* exp_avg, float* ex
     if (n_seg <= 512)
         STEP_LAUNCH((adam_flat_kernel<512>), dim3((unsigned)blocks), dim3(256), stream, param, grad, exp_avg, exp_avg_sq, nvec, seg_end,
                     seg_lr, seg_wd, n_seg, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, bc1, bc2_sqrt,
-                    grad_scale, zero_grad, bcd);
+                    grad_scale, zero_grad, bcd, amp);
     else
         STEP_LAUNCH((adam_flat_kernel<ADAM_MAX_SEG>), dim3((unsigned)blocks), dim3(256), stream, param, grad, exp_avg, exp_avg_sq, nvec,
                     seg_end, seg_lr, seg_wd, n_seg, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, bc1,
-                    bc2_sqrt, grad_scale, zero_grad, bcd);
+                    bc2_sqrt, grad_scale, zero_grad, bcd, amp);
     return STEP_LAUNCH_CHECK();
 }
 
@@ -173,6 +211,27 @@ int step_adam_flat_dev(float* param, float* grad, float* exp_avg, float* exp_avg
     if (!step_dev || !bias_corr) return STEP_E_NULL;
     return adam_flat_launch(param, grad, exp_avg, exp_avg_sq, n, seg_end, seg_lr, seg_wd, n_seg, beta1, beta2, eps, 0, step_dev, bias_corr,
                             grad_scale, zero_grad, stream);
+}
+
+int step_adam_flat_amp(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long long n, const long long* seg_end,
+                       const float* seg_lr, const float* seg_wd, int n_seg, double beta1, double beta2, double eps, long long* step_dev,
+                       float* bias_corr, float grad_scale, int zero_grad, float* amp_state, float growth_factor, float backoff_factor,
+                       int growth_interval, step_stream_t stream) {
+    if (!step_dev || !bias_corr || !amp_state) return STEP_E_NULL;
+    if (n < 0 || (n & 3) || growth_interval < 1 || !(growth_factor >= 1.f) || !(backoff_factor > 0.f && backoff_factor <= 1.f)) return STEP_E_SHAPE;
+    if (n > 0) {
+        if (!grad) return STEP_E_NULL;
+        if ((uintptr_t)grad & 15) return STEP_E_ALIGN;
+        const long long nvec = n >> 2;
+        long long blocks = (nvec + 255) / 256;
+        if (blocks > 256LL * 32) blocks = 256LL * 32;
+        STEP_LAUNCH(grad_scan_kernel, dim3((unsigned)blocks), dim3(256), stream, grad, nvec, amp_state);
+    }
+    const int rc = adam_flat_launch(param, grad, exp_avg, exp_avg_sq, n, seg_end, seg_lr, seg_wd, n_seg, beta1, beta2, eps, 0, step_dev, bias_corr,
+                                    grad_scale, zero_grad, stream, amp_state);
+    if (rc) return rc;
+    STEP_LAUNCH(loss_scale_update_kernel, dim3(1), dim3(64), stream, amp_state, growth_factor, backoff_factor, growth_interval);
+    return STEP_LAUNCH_CHECK();
 }
 
 int step_act_grad(int dtype, const void* y, int y_cstride, int gy_dtype, const void* gy, int gy_cstride, const float* scale, long long M, int C,

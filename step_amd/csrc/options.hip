@@ -24,7 +24,6 @@ constexpr OptSpec SPEC[STEP_OPT_COUNT_] = {
     {"wgrad_minpix", 0, 0, 1 << 24},
     {"wgrad16_lds", 1, 0, 1},
     {"conv_group_pw", 1 << 20, 0, 1 << 20},
-    {"roi_bwd_gather", 1, 0, 1},
 };
 std::atomic<int> g_delta[STEP_OPT_COUNT_];      // value - default: zero-initialised static storage IS the default table
 }  // namespace

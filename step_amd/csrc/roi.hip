@@ -536,12 +536,13 @@ int step_roi_align_tubes_forward(const void* feat, int dtype, const float* rois,
 }
 
 int step_roi_align_backward(const float* grad, int layout, const float* rois, int K, int B, int C, int H, int W,
-                            int ph, int pw, float scale, int sr, float* gfeat, step_stream_t stream) {
+                            int ph, int pw, float scale, int sr, int mode, float* gfeat, step_stream_t stream) {
     if (K < 0 || B < 0 || C <= 0 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0) return STEP_E_SHAPE;
     if (layout != STEP_NCHW && layout != STEP_NHWC) return STEP_E_UNSUPPORTED;
+    if (mode != STEP_ROI_BWD_GATHER && mode != STEP_ROI_BWD_ATOMIC) return STEP_E_UNSUPPORTED;
     if (B == 0) return STEP_OK;
     if (!gfeat) return STEP_E_NULL;
-    if (K > 0 && opt(STEP_OPT_ROI_BWD_GATHER)) {
+    if (K > 0 && mode == STEP_ROI_BWD_GATHER) {
         // the deterministic form: every element of grad_feat is written by its own gather (no clear, no atomics)
         if (!grad || !rois) return STEP_E_NULL;
         if (layout == STEP_NHWC) {

@@ -79,7 +79,9 @@ struct SelectParams {
 
 __device__ __forceinline__ void valid_box(const float* b, float w, float h, float* o) {        // tube_utils.py:59-92
     float x1 = fmaxf(0.0f, b[0]), y1 = fmaxf(0.0f, b[1]), x2 = fminf(w, b[2]), y2 = fminf(h, b[3]);
-    if (!((x1 < x2 - 2.0f) && (y1 < y2 - 2.0f))) { x1 = 0.0f; y1 = 0.0f; x2 = w; y2 = h; }
+    // (np.maximum / np.minimum propagate NaN where fmaxf / fminf drop it: a NaN coordinate fails the reference's `<` test)
+    const bool nan_in = (b[0] != b[0]) || (b[1] != b[1]) || (b[2] != b[2]) || (b[3] != b[3]);
+    if (nan_in || !((x1 < x2 - 2.0f) && (y1 < y2 - 2.0f))) { x1 = 0.0f; y1 = 0.0f; x2 = w; y2 = h; }
     o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2;
 }
 

@@ -340,10 +340,11 @@ class TwoBranchNet(nn.Module):
             last_pred = last_loc[:, half_T].reshape(N, -1)
 
         # ---- losses (two_branch.py:276-333)
-        loss_global_cls = torch.zeros((), device=global_class.device)
-        if targets is None:                                        # inference: ONE fill for the three zero losses (read-only placeholders)
-            loss_local_loc = loss_neighbor_loc = loss_global_cls
+        if targets is None:                                        # inference: ONE fill, three separate one-element views (a caller that
+            z3 = torch.zeros(3, device=global_class.device)        # accumulates a returned loss in place touches only that one)
+            loss_global_cls, loss_local_loc, loss_neighbor_loc = z3[0], z3[1], z3[2]
         else:
+            loss_global_cls = torch.zeros((), device=global_class.device)
             loss_local_loc = torch.zeros((), device=global_class.device)
             loss_neighbor_loc = torch.zeros((), device=global_class.device)
         if targets is not None:

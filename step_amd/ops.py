@@ -599,7 +599,9 @@ def roi_align_tubes_forward(v, rois, ph, pw, scale, sampling_ratio):
     return out.permute(0, 3, 1, 2)
 
 
-def roi_align_backward(grad, rois, ph, pw, scale, sampling_ratio, B, C, H, W):
+def roi_align_backward(grad, rois, ph, pw, scale, sampling_ratio, B, C, H, W, deterministic=True):
+    """deterministic=True: the fixed-order gather (bit-reproducible); False: the reference's fp32-atomics scatter
+    (ROIAlign_cuda.cu:201-278).  A per-call argument of the C ABI (STEP_ROI_BWD_GATHER / _ATOMIC), not process state."""
     L = _lib.lib()
     g = grad.float()
     if g.is_contiguous():
@@ -614,7 +616,8 @@ def roi_align_backward(grad, rois, ph, pw, scale, sampling_ratio, B, C, H, W):
     rois = _rois_f32(rois, g.device)
     K = rois.shape[0]
     _capi.check(L.step_roi_align_backward(_lib.dptr(g) if K else None, layout, _lib.dptr(rois) if K else None, K, B, C, H, W,
-                                          ph, pw, float(scale), int(sampling_ratio), _lib.dptr(gin), _lib.stream_ptr(g.device)),
+                                          ph, pw, float(scale), int(sampling_ratio),
+                                          _capi.ROI_BWD_GATHER if deterministic else _capi.ROI_BWD_ATOMIC, _lib.dptr(gin), _lib.stream_ptr(g.device)),
                 "step_roi_align_backward")
     return gin.to(grad.dtype)
 

@@ -19,6 +19,39 @@ from . import _capi, _lib
 _ALIGN = 64          # elements (256 B): every tensor starts on its own cache line; segment ends stay multiples of 4
 
 
+class LossScaler:
+    """Dynamic loss scaling of mixed-precision (fp16) training -- what `amp.initialize(..., opt_level="O1")` + `with amp.scale_loss(loss,
+    optimizer) as scaled_loss: scaled_loss.backward()` do in the reference (train.py:136-139,342-345) -- with the whole state on the device:
+    `state` = {scale, growth_tracker, found_inf, -}.  Defaults are apex's DynamicLossScaler (2^16, x2 after 2000 clean steps, /2 on overflow),
+    the same rule as torch.amp.GradScaler.  Use:
+
+        scaler = LossScaler(device)
+        scaler.scale_loss(loss).backward()          # a device multiply: nothing here reads the scale on the host
+        opt.step(scaler=scaler, zero_grad=True)     # overflow scan + unscale + skip-or-step + scale update: step_adam_flat_amp
+
+    The optimizer must be FlatAdam(capturable=True): a skipped step must not advance the step count, and only the device knows."""
+
+    def __init__(self, device, init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        self.state = torch.tensor([float(init_scale), 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
+
+    def scale_loss(self, loss):
+        return loss * self.state[0].to(loss.dtype)
+
+    @property
+    def scale(self):
+        return float(self.state[0].item())
+
+    def state_dict(self):
+        s = self.state.tolist()
+        return {"scale": s[0], "growth_tracker": int(s[1]), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval}
+
+    def load_state_dict(self, sd):
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(sd["growth_factor"]), float(sd["backoff_factor"]), int(sd["growth_interval"])
+        self.state.copy_(torch.tensor([float(sd["scale"]), float(sd["growth_tracker"]), 0.0, 0.0]))
+
+
 class FlatAdam(torch.optim.Optimizer):
     """A torch.optim.Optimizer (the reference's schedulers subclass torch's _LRScheduler, which insists on one:
     utils/solver.py:96,141) whose whole state lives in four flat arenas."""
@@ -115,9 +148,11 @@ class FlatAdam(torch.optim.Optimizer):
             self._tables = (lr, wd)
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0, zero_grad=False):
+    def step(self, closure=None, grad_scale=1.0, zero_grad=False, scaler=None):
         """optimizer.step() (train.py:348): one kernel launch.  grad_scale multiplies every gradient on the way in
-        (1/world_size after a SUM all-reduce, 1/loss_scale); zero_grad=True clears the gradient arena in the same pass."""
+        (1/world_size after a SUM all-reduce, 1/loss_scale); zero_grad=True clears the gradient arena in the same pass.
+        scaler = a LossScaler whose scale the loss was multiplied by: the gradients are scanned for inf / nan, unscaled, and the
+        step is skipped on overflow (apex O1 / GradScaler semantics), all on the device (step_adam_flat_amp)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -128,7 +163,17 @@ class FlatAdam(torch.optim.Optimizer):
         self._refresh_tables()
         g0 = self.param_groups[0]
         L = _lib.lib()
-        if self.capturable:
+        if scaler is not None:
+            if not self.capturable:
+                raise RuntimeError("FlatAdam.step(scaler=...): build the optimizer with capturable=True (a skipped step must not count, "
+                                   "and only the device knows whether it was skipped)")
+            _capi.check(L.step_adam_flat_amp(_lib.dptr(self.flat_param), _lib.dptr(self.flat_grad), _lib.dptr(self.exp_avg),
+                                             _lib.dptr(self.exp_avg_sq), self.numel, _lib.dptr(self._seg_end), _lib.dptr(self._seg_lr),
+                                             _lib.dptr(self._seg_wd), len(self._entries), float(g0["betas"][0]), float(g0["betas"][1]),
+                                             float(g0["eps"]), _lib.dptr(self._step_dev), _lib.dptr(self._bias_corr), float(grad_scale),
+                                             int(bool(zero_grad)), _lib.dptr(scaler.state), scaler.growth_factor, scaler.backoff_factor,
+                                             scaler.growth_interval, _lib.stream_ptr(self.device)), "step_adam_flat_amp")
+        elif self.capturable:
             _capi.check(L.step_adam_flat_dev(_lib.dptr(self.flat_param), _lib.dptr(self.flat_grad), _lib.dptr(self.exp_avg),
                                              _lib.dptr(self.exp_avg_sq), self.numel, _lib.dptr(self._seg_end), _lib.dptr(self._seg_lr),
                                              _lib.dptr(self._seg_wd), len(self._entries), float(g0["betas"][0]), float(g0["betas"][1]),

@@ -16,8 +16,9 @@ from .. import ops
 
 class _ROIAlignFn(Function):
     @staticmethod
-    def forward(ctx, input, roi, output_size, spatial_scale, sampling_ratio):
+    def forward(ctx, input, roi, output_size, spatial_scale, sampling_ratio, deterministic=True):
         ctx.save_for_backward(roi)
+        ctx.deterministic = bool(deterministic)
         ctx.geom = (_pair(output_size), float(spatial_scale), int(sampling_ratio), tuple(input.shape))
         ph, pw = ctx.geom[0]
         return ops.roi_align_forward(input, roi, ph, pw, spatial_scale, sampling_ratio)
@@ -27,22 +28,27 @@ class _ROIAlignFn(Function):
     def backward(ctx, grad_output):
         (roi,) = ctx.saved_tensors
         (ph, pw), scale, sr, (B, C, H, W) = ctx.geom
-        grad_input = ops.roi_align_backward(grad_output, roi, ph, pw, scale, sr, B, C, H, W)
-        return grad_input, None, None, None, None
+        grad_input = ops.roi_align_backward(grad_output, roi, ph, pw, scale, sr, B, C, H, W, deterministic=ctx.deterministic)
+        return grad_input, None, None, None, None, None
 
 
-roi_align = _ROIAlignFn.apply
+def roi_align(input, rois, output_size, spatial_scale, sampling_ratio, deterministic=True):
+    """The reference's five arguments (roi_layers/roi_align.py:73) plus `deterministic`: which backward THIS call's autograd node
+    runs -- the fixed-order gather (default, bit-reproducible) or the reference's fp32-atomics scatter.  Chosen per call and
+    carried by the node, never read from process state."""
+    return _ROIAlignFn.apply(input, rois, output_size, spatial_scale, sampling_ratio, deterministic)
 
 
 class ROIAlign(nn.Module):
-    def __init__(self, output_size, spatial_scale, sampling_ratio):
+    def __init__(self, output_size, spatial_scale, sampling_ratio, deterministic=True):
         super().__init__()
         self.output_size = output_size
         self.spatial_scale = spatial_scale
         self.sampling_ratio = sampling_ratio
+        self.deterministic = deterministic          # backward mode of this module's calls (see roi_align)
 
     def forward(self, input, rois):
-        return roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio)
+        return roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio, self.deterministic)
 
     def __repr__(self):
         return "%s(output_size=%s, spatial_scale=%s, sampling_ratio=%s)" % (

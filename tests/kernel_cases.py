@@ -192,8 +192,8 @@ def case_roi_align_forward_16bit(bk, golden):
 
 def case_roi_align_backward(bk, golden):
     """step_roi_align_backward against the oracle's restatement of ROIAlign_cpu.cpp's backward: the default fixed-order gather
-    (bit-reproducible, every cell written -- frames without a roi come back zero) and the reference's atomics scatter (option
-    roi_bwd_gather = 0); rois that hang over every border, a degenerate one, adaptive and fixed sampling, vector and scalar
+    (bit-reproducible, every cell written -- frames without a roi come back zero) and the reference's atomics scatter, chosen PER
+    CALL (the `mode` argument; an unknown mode is refused); rois that hang over every border, a degenerate one, adaptive and fixed sampling, vector and scalar
     channel counts."""
     rs = np.random.RandomState(2)
     few = np.array([[0, 0, 0, 190, 140], [1, 33.3, 20.1, 120.7, 100.2], [1, -20, 100, 90, 250], [0, 50, 50, 50.5, 50.5]], np.float32)
@@ -201,7 +201,8 @@ def case_roi_align_backward(bk, golden):
                            rs.uniform(60, 260, (40, 2)).astype(np.float32)], 1)
     many[::7, 3:] = many[::7, 1:3] - 5.0                      # malformed (x2 < x1): forced to 1 x 1
     for gather in (1, 0):
-        with _capi.options(bk.lib, roi_bwd_gather=gather):
+        mode = _capi.ROI_BWD_GATHER if gather else _capi.ROI_BWD_ATOMIC
+        if True:
             for rois, B, C, H, W in ((few, 2, 8, 9, 12), (many, 3, 8, 9, 12), (many, 2, 5, 11, 7)):
                 K = rois.shape[0]
                 for layout in (NCHW, NHWC):
@@ -212,7 +213,7 @@ def case_roi_align_backward(bk, golden):
                         outs = []
                         for _ in range(2):
                             gi = bk.dev(np.full((B, C, H, W) if layout == NCHW else (B, H, W, C), 7.0, np.float32))   # the op owns every cell
-                            rc = bk.lib.step_roi_align_backward(gg.ptr, layout, r.ptr, K, B, C, H, W, 7, 7, 1 / 16., sr, gi.ptr, bk.stream)
+                            rc = bk.lib.step_roi_align_backward(gg.ptr, layout, r.ptr, K, B, C, H, W, 7, 7, 1 / 16., sr, mode, gi.ptr, bk.stream)
                             assert rc == 0
                             outs.append(gi.get() if layout == NCHW else nchw(gi.get()))
                         assert np.abs(outs[0] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (gather, layout, sr, B, C)   # summation order differs
@@ -221,7 +222,8 @@ def case_roi_align_backward(bk, golden):
                         if gather:
                             assert np.array_equal(outs[0], outs[1])
     gi = bk.dev(np.full((2, 9, 12, 8), 7.0, np.float32))
-    assert bk.lib.step_roi_align_backward(None, NHWC, None, 0, 2, 8, 9, 12, 7, 7, 1 / 16., 2, gi.ptr, bk.stream) == 0 and not gi.get().any()
+    assert bk.lib.step_roi_align_backward(None, NHWC, None, 0, 2, 8, 9, 12, 7, 7, 1 / 16., 2, _capi.ROI_BWD_ATOMIC, gi.ptr, bk.stream) == 0 and not gi.get().any()
+    assert bk.lib.step_roi_align_backward(None, NHWC, None, 0, 2, 8, 9, 12, 7, 7, 1 / 16., 2, 2, gi.ptr, bk.stream) == -4       # unknown mode
 
 
 def case_roi_pool_forward_backward(bk, golden):
@@ -603,6 +605,62 @@ def case_adam_flat(bk, golden):
                                  0, bk.stream) < 0                                        # steps count from 1
     assert bk.lib.step_adam_flat(P.ptr, G.ptr, M.ptr, V.ptr, 0, ends.ptr, LR.ptr, WD.ptr, len(sizes), 0.9, 0.999, 1e-8, 1, 1.0,
                                  0, bk.stream) == 0                                       # empty arena: no launch
+
+
+def case_adam_flat_amp(bk, golden):
+    """step_adam_flat_amp -- dynamic loss scaling on the device (train.py:136-139,342-345: apex amp O1) -- against torch's own pair
+    torch.optim.Adam + torch.amp.GradScaler semantics restated on the host: clean steps equal step_adam_flat_dev with grad_scale / scale bit for
+    bit and count towards the growth interval; a step whose gradients hold an inf or a nan changes NOTHING but the scale (halved), the
+    tracker (reset) and -- when asked -- the cleared gradients; the step count does not advance on a skipped step."""
+    rs = np.random.RandomState(5)
+    sizes = [64, 8, 256]
+    n = sum(sizes)
+    p0 = rs.randn(n).astype(np.float32)
+    ends = bk.dev(np.cumsum(sizes).astype(np.int64))
+    LR, WD = bk.dev(np.array([1e-3, 2e-3, 5e-4], np.float32)), bk.dev(np.array([0.0, 1e-2, 0.0], np.float32))
+    P, M, V = bk.dev(p0.copy()), bk.dev(np.zeros(n, np.float32)), bk.dev(np.zeros(n, np.float32))
+    P2, M2, V2 = bk.dev(p0.copy()), bk.dev(np.zeros(n, np.float32)), bk.dev(np.zeros(n, np.float32))
+    cnt, bc = bk.dev(np.zeros(1, np.int64)), bk.dev(np.zeros(2, np.float32))
+    cnt2, bc2 = bk.dev(np.zeros(1, np.int64)), bk.dev(np.zeros(2, np.float32))
+    amp = bk.dev(np.array([1024.0, 0.0, 0.0, 0.0], np.float32))
+    scale, tracker, steps = 1024.0, 0, 0
+    interval = 3
+    plan = ["ok", "ok", "inf", "ok", "ok", "ok", "nan", "ok"]          # growth after 3 clean steps in a row; two overflows
+    for k, kind in enumerate(plan):
+        g = (rs.randn(n) * 0.1).astype(np.float32)
+        gs = (g * np.float32(scale)).astype(np.float32)                 # what backward of the scaled loss leaves in the arena
+        if kind == "inf":
+            gs[17] = np.inf
+        elif kind == "nan":
+            gs[n - 3] = np.nan
+        G = bk.dev(gs.copy())
+        before = (P.get().copy(), M.get().copy(), V.get().copy())
+        zero = int(k % 2 == 0)
+        assert bk.lib.step_adam_flat_amp(P.ptr, G.ptr, M.ptr, V.ptr, n, ends.ptr, LR.ptr, WD.ptr, len(sizes), 0.9, 0.999, 1e-8, cnt.ptr, bc.ptr,
+                                         0.5, zero, amp.ptr, 2.0, 0.5, interval, bk.stream) == 0
+        if kind == "ok":
+            G2 = bk.dev(gs.copy())
+            assert bk.lib.step_adam_flat_dev(P2.ptr, G2.ptr, M2.ptr, V2.ptr, n, ends.ptr, LR.ptr, WD.ptr, len(sizes), 0.9, 0.999, 1e-8, cnt2.ptr,
+                                             bc2.ptr, 0.5 * (1.0 / scale), zero, bk.stream) == 0
+            assert np.array_equal(P.get(), P2.get()) and np.array_equal(M.get(), M2.get()) and np.array_equal(V.get(), V2.get()), k
+            steps += 1
+            tracker += 1
+            if tracker == interval:
+                scale, tracker = scale * 2.0, 0
+        else:
+            assert all(np.array_equal(a, b) for a, b in zip(before, (P.get(), M.get(), V.get()))), k      # skipped: nothing moved
+            scale, tracker = scale * 0.5, 0
+        assert int(cnt.get()[0]) == steps, (k, cnt.get(), steps)
+        st = amp.get()
+        assert st[0] == np.float32(scale) and st[1] == np.float32(tracker) and st[2] == 0.0, (k, st, scale, tracker)
+        if zero:
+            assert not G.get().any(), k
+        else:
+            assert np.array_equal(G.get(), gs, equal_nan=True), k
+    assert bk.lib.step_adam_flat_amp(P.ptr, None, M.ptr, V.ptr, n, ends.ptr, LR.ptr, WD.ptr, len(sizes), 0.9, 0.999, 1e-8, cnt.ptr, bc.ptr,
+                                     1.0, 0, amp.ptr, 2.0, 0.5, interval, bk.stream) < 0
+    assert bk.lib.step_adam_flat_amp(P.ptr, P.ptr, M.ptr, V.ptr, n, ends.ptr, LR.ptr, WD.ptr, len(sizes), 0.9, 0.999, 1e-8, cnt.ptr, bc.ptr,
+                                     1.0, 0, None, 2.0, 0.5, interval, bk.stream) < 0
 
 
 def case_pack_weight_dgrad(bk, golden):

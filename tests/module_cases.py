@@ -434,6 +434,17 @@ def case_postprocess_golden(dev, golden):
         gen = driver._postprocess_general(hist[it], nums, 0.01, 0.4, -1, -1, 400.0, 400.0)
         for a_, b_ in zip(gen, fastp[it]):
             assert all(torch.equal(a_[k_], b_[k_]) for k_ in ("boxes", "scores", "labels", "tubes"))
+    # NaN predictions: np.maximum / torch.clamp PROPAGATE a NaN and valid_tubes' `<` test then fails, so the reference turns a box with
+    # any NaN coordinate into the whole frame -- the fused launch (fmaxf / fminf drop NaNs) must do the same as the tensor path
+    hn = {"pred_prob": hist[0]["pred_prob"], "pred_loc": hist[0]["pred_loc"].clone(), "tubes_nums": nums}
+    mid = hn["pred_loc"].shape[1] // 2
+    for row, col in ((1, 0), (4, 3), (7, 1), (nums[0] + 2, 2)):
+        hn["pred_loc"][row, mid, col] = float("nan")
+    gen = driver._postprocess_general(hn, nums, 0.01, 0.4, -1, -1, 400.0, 400.0)
+    fast = postprocess(cfg(conf_thresh=0.01, nms_thresh=0.4, evaluate_topk=-1, topk=-1), [hn])[0]
+    for a_, b_ in zip(gen, fast):
+        assert all(torch.equal(a_[k_], b_[k_]) for k_ in ("boxes", "scores", "labels", "tubes"))
+        assert not bool(torch.isnan(b_["boxes"]).any())
     # one iteration only, and an empty clip in the batch
     only = postprocess(cfg(), hist, iterations=(2,))
     assert len(only) == 1
@@ -875,6 +886,64 @@ def case_training_step_16bit_storage(dev, golden):
     assert worst < 0.15, worst
 
 
+def case_fp16_training_step_loss_scaling(dev, golden):
+    """The reference's only 16-bit training mode (train.py:136-139 apex amp O1 with dynamic loss scaling, :342-345 amp.scale_loss): fp16
+    activations, fp32 master weights, the loss multiplied by the scale on the device (step_amd.LossScaler), FlatAdam.step(scaler=...)
+    = overflow scan + unscale + skip-or-step + scale update in one call.  (1) a step with scale 2^12 moves the parameters like the
+    step without scaling (the scale is a power of two: the fp32 gradients agree up to the fp16 rounding of the activation gradients);
+    (2) a scale that overflows the fp16 gradients is SKIPPED: parameters, moments and step count untouched, gradients cleared, scale
+    halved -- and the next step at a sane scale goes through."""
+    g = golden("head_golden")
+    pf = R.fill_tensor("golden.det.pooled3", (2, 3, 832, 7, 7), "feat").to(dev).half()
+    cx = R.fill_tensor("golden.det.ctx3", (2, 1024, 3, 1, 1), "feat").to(dev).half()
+    tubes, targets = torch.from_numpy(g["loss_tubes"]).to(dev), torch.from_numpy(g["loss_targets"]).to(dev)
+
+    def build():
+        net = fill(step_amd.TwoBranchNet(cfg()), "det0.").to(dev)
+        net.set_device(dev)
+        net.train()
+        opt = step_amd.FlatAdam([p for p in net.parameters() if p.requires_grad], lr=1e-4, capturable=True)
+        return net, opt
+
+    def loss_of(net):
+        o = net(pf, context_feat=cx, tubes=tubes, targets=targets)
+        return o[4].mean() + 5.0 * o[5].mean() + o[6].mean()
+    net0, opt0 = build()
+    loss_of(net0).backward()
+    g0 = opt0.flat_grad.clone()
+    opt0.step(zero_grad=True)
+    net1, opt1 = build()
+    sc = step_amd.LossScaler(torch.device(dev), init_scale=2.0 ** 12, growth_interval=2)
+    sc.scale_loss(loss_of(net1)).backward()
+    g1 = opt1.flat_grad.clone()
+    assert bool(torch.isfinite(g1).all())
+    assert float((g1 / 4096.0 - g0).double().norm() / g0.double().norm()) < 2e-2
+    p_before = opt1.flat_param.clone()
+    opt1.step(scaler=sc, zero_grad=True)
+    assert opt1.step_count == 1 and sc.scale == 4096.0 and float(sc.state[1]) == 1.0 and not bool(opt1.flat_grad.any())
+    d0, d1 = (opt0.flat_param - p_before).double(), (opt1.flat_param - p_before).double()
+    assert float((d1 - d0).norm() / d0.norm()) < 5e-2, float((d1 - d0).norm() / d0.norm())      # Adam's first step is sign-like: a few flipped tiny gradients
+    # (2) overflow: a scale no fp16 gradient survives
+    sc.state[0] = 2.0 ** 40
+    p_before, m_before = opt1.flat_param.clone(), opt1.exp_avg.clone()
+    sc.scale_loss(loss_of(net1)).backward()
+    assert not bool(torch.isfinite(opt1.flat_grad).all())
+    opt1.step(scaler=sc, zero_grad=True)
+    assert opt1.step_count == 1 and torch.equal(opt1.flat_param, p_before) and torch.equal(opt1.exp_avg, m_before)
+    assert sc.scale == 2.0 ** 39 and float(sc.state[1]) == 0.0 and not bool(opt1.flat_grad.any())
+    sc.state[0] = 2.0 ** 10
+    sc.scale_loss(loss_of(net1)).backward()
+    opt1.step(scaler=sc, zero_grad=True)
+    assert opt1.step_count == 2 and not torch.equal(opt1.flat_param, p_before) and bool(torch.isfinite(opt1.flat_param).all())
+    sc.scale_loss(loss_of(net1)).backward()
+    opt1.step(scaler=sc, zero_grad=True)
+    assert opt1.step_count == 3 and sc.scale == 2.0 ** 11 and float(sc.state[1]) == 0.0          # two clean steps in a row: growth
+    sd = sc.state_dict()
+    sc2 = step_amd.LossScaler(torch.device(dev))
+    sc2.load_state_dict(sd)
+    assert sc2.scale == sc.scale and sc2.growth_interval == 2
+
+
 def case_reg_unit_pack_follows_weight_updates(dev, golden):
     """The fused regressor unit (three Linear layers as one GEMM) in GRAD mode: its weight_fn is a fresh torch.cat per call, so
     the packed-weight cache must be keyed on the three parameters -- a temporary's (data_ptr, _version) can repeat after an
@@ -1180,4 +1249,4 @@ CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_g
              "case_contextnet_backward_matches_oracle_autograd", "case_postprocess_golden",
              "case_batched_repack_follows_weight_updates", "case_stem_backward_16bit",
              "case_loss_masks_without_host_branches", "case_data_parallel_replicas", "case_train_select_device_front_end", "case_nms_operator_api"]
-GPU_CASES = CPU_CASES + ["case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_c5_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_i3d_classifier_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
+GPU_CASES = CPU_CASES + ["case_fp16_training_step_loss_scaling", "case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_c5_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_i3d_classifier_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
