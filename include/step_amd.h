@@ -344,12 +344,13 @@ STEP_API int step_conv_plan_info(const step_conv_desc* d, int* info, int n);
 /* The I3D stem: 7x7x7 stride-2 conv, Cin = 3, TF-SAME padding (2 front, 3 back) + BN + ReLU
  * (models/i3dpt.py:186-191) reading the clip in the reference's own input layout
  *   x [N, T, 3, H, W] (what BaseNet.forward receives, models/networks.py:69-77)
- * and writing channels-last y [N, To, Ho, Wo, Cout] with To = ceil(T/2) etc. */
+ * and writing channels-last y [N, To, Ho, Wo, Cout] with To = ceil(T/2) etc.  relu = 0: the affine output without the ReLU (the
+ * batch-statistics BatchNorm of --freeze_stats False follows as its own pass, step_bn_train_forward). */
 STEP_API size_t step_stem_packed_elems(int Cout);
 STEP_API int step_stem_pack_weight(const float* w /*[Cout,3,7,7,7]*/, int Cout, int dtype, void* packed,
                                    step_stream_t stream);
 STEP_API int step_stem_forward(int dtype, const void* x, int N, int T, int H, int W, const void* w_packed,
-                               const float* scale, const float* shift, int Cout, void* y, int y_cstride,
+                               const float* scale, const float* shift, int relu, int Cout, void* y, int y_cstride,
                                int y_coff, step_stream_t stream);
 /* Weight gradient of the stem: dw[Cout][3][7][7][7] (fp32, torch layout) (+)= sum over output pixels of
  * dy[n,to,ho,wo,co] * x_padded[...]; x as in step_stem_forward, dy fp32 contiguous [N,To,Ho,Wo,Cout] (gradient before
@@ -457,6 +458,26 @@ STEP_API int step_adam_flat_amp(float* param, float* grad, float* exp_avg, float
                                 double beta2, double eps, long long* step_dev, float* bias_corr, float grad_scale, int zero_grad,
                                 float* amp_state, float growth_factor, float backoff_factor, int growth_interval,
                                 step_stream_t stream);
+
+/* Batch-statistics BatchNorm3d (+ ReLU) of a conv unit: the TRAINING-mode BatchNorm of --freeze_stats False (models/networks.py:85-99
+ * leaves the layers in train mode; models/i3dpt.py:95-110, models/two_branch.py:160,372).  Eval-mode BN is folded into the conv
+ * epilogues and never comes here.
+ * forward:  z [M, C] channels-last (the raw conv output; z_cstride elements between pixels, 0 = C) ->
+ *             y = relu?(gamma * (z - mean_B) / sqrt(var_B + eps) + beta)      mean_B / var_B (biased) over the M pixels of THIS batch
+ *           save_mean / save_invstd [C] fp32 (for backward); running_mean / running_var (may be NULL) move by `momentum` towards the
+ *           batch mean / UNBIASED variance, as torch.nn.BatchNorm3d(momentum=0.1) does.  gamma / beta NULL = 1 / 0.
+ * backward: gy [M, C] (fp32 or `dtype`), y the forward's output (read for the ReLU mask only) ->
+ *             gz [M, C] dense `dtype` (gradient w.r.t. the conv output), ggamma / gbeta [C] fp32 (may be NULL)
+ * Fixed-order reductions (chunk partials in a caller-owned workspace, merged in double precision): bit-reproducible, no atomics.
+ * ws: step_bn_train_workspace_bytes(M, C) bytes, 16-byte aligned.  C and the strides must be multiples of 4. */
+STEP_API size_t step_bn_train_workspace_bytes(long long M, int C);
+STEP_API int step_bn_train_forward(int dtype, const void* z, int z_cstride, long long M, int C, const float* gamma, const float* beta,
+                                   float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
+                                   float* save_invstd, int relu, void* y, int y_cstride, void* ws, size_t ws_bytes, step_stream_t stream);
+STEP_API int step_bn_train_backward(int dtype, const void* z, int z_cstride, const void* y, int y_cstride, int gy_dtype, const void* gy,
+                                    int gy_cstride, long long M, int C, int relu, const float* gamma, const float* save_mean,
+                                    const float* save_invstd, void* gz, float* ggamma, float* gbeta, void* ws, size_t ws_bytes,
+                                    step_stream_t stream);
 
 /* Activation gradient of the fused conv unit (the backward of Unit3Dpy's BatchNorm3d(eval) + ReLU, models/i3dpt.py:100-111,
  * and of the Bottleneck ReLUs, two_branch.py:60-111, which autograd runs as separate element-wise kernels in the reference):

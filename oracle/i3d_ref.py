@@ -59,15 +59,18 @@ def _pad3d(x, pads):
     return F.pad(x, (wf, wb, hf, hb, df, db), value=0.0)
 
 
-def unit3d(x, sd, prefix, stride=(1, 1, 1), bn=True, relu=True):
-    """conv (+bias) -> BN(eval) -> ReLU on NCDHW.  models/i3dpt.py:43-111."""
+def unit3d(x, sd, prefix, stride=(1, 1, 1), bn=True, relu=True, train_bn=False):
+    """conv (+bias) -> BN -> ReLU on NCDHW.  models/i3dpt.py:43-111.  BN in eval mode (the reference's --freeze_stats True,
+    networks.py:85-99) unless train_bn: then batch statistics, and the running statistics in `sd` move by momentum 0.1 IN PLACE."""
     w = sd[prefix + ".conv3d.weight"]
     b = sd.get(prefix + ".conv3d.bias")
     x = _pad3d(x, tf_same_pad(tuple(w.shape[2:]), stride))
     y = F.conv3d(x, w, b, stride=stride)
     if bn:
         y = F.batch_norm(y, sd[prefix + ".batch3d.running_mean"], sd[prefix + ".batch3d.running_var"],
-                         sd[prefix + ".batch3d.weight"], sd[prefix + ".batch3d.bias"], False, 0.0, BN_EPS)
+                         sd[prefix + ".batch3d.weight"], sd[prefix + ".batch3d.bias"], bool(train_bn), 0.1 if train_bn else 0.0, BN_EPS)
+        if train_bn and prefix + ".batch3d.num_batches_tracked" in sd:
+            sd[prefix + ".batch3d.num_batches_tracked"] += 1
     return F.relu(y) if relu else y
 
 
@@ -77,27 +80,28 @@ def maxpool_tf(x, kernel, stride):
     return F.max_pool3d(_pad3d(x, tf_same_pad(kernel, stride)), kernel, stride, ceil_mode=True)
 
 
-def mixed(x, sd, prefix):
+def mixed(x, sd, prefix, train_bn=False):
     """Inception block, concat order b0,b1,b2,b3.  models/i3dpt.py:129-163."""
-    b0 = unit3d(x, sd, prefix + ".branch_0")
-    b1 = unit3d(unit3d(x, sd, prefix + ".branch_1.0"), sd, prefix + ".branch_1.1")
-    b2 = unit3d(unit3d(x, sd, prefix + ".branch_2.0"), sd, prefix + ".branch_2.1")
-    b3 = unit3d(maxpool_tf(x, (3, 3, 3), (1, 1, 1)), sd, prefix + ".branch_3.1")
+    t = train_bn
+    b0 = unit3d(x, sd, prefix + ".branch_0", train_bn=t)
+    b1 = unit3d(unit3d(x, sd, prefix + ".branch_1.0", train_bn=t), sd, prefix + ".branch_1.1", train_bn=t)
+    b2 = unit3d(unit3d(x, sd, prefix + ".branch_2.0", train_bn=t), sd, prefix + ".branch_2.1", train_bn=t)
+    b3 = unit3d(maxpool_tf(x, (3, 3, 3), (1, 1, 1)), sd, prefix + ".branch_3.1", train_bn=t)
     return torch.cat((b0, b1, b2, b3), 1)
 
 
-def basenet_forward(images, sd, prefix="base_model", return_stages=False):
-    """images [N,T,3,H,W] -> conv_feat [N,T',832,H',W'].  models/networks.py:69-83."""
+def basenet_forward(images, sd, prefix="base_model", return_stages=False, train_bn=False):
+    """images [N,T,3,H,W] -> conv_feat [N,T',832,H',W'].  models/networks.py:69-83.  train_bn: see unit3d."""
     x = images.permute(0, 2, 1, 3, 4)
     stages = []
     for kind, idx, args in BACKBONE:
         p = "%s.%d" % (prefix, idx)
         if kind == "conv":
-            x = unit3d(x, sd, p, stride=args[3])
+            x = unit3d(x, sd, p, stride=args[3], train_bn=train_bn)
         elif kind == "pool":
             x = maxpool_tf(x, args[0], args[1])
         else:
-            x = mixed(x, sd, p)
+            x = mixed(x, sd, p, train_bn=train_bn)
         stages.append(x)
     out = x.permute(0, 2, 1, 3, 4)
     return (out, stages) if return_stages else out

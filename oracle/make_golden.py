@@ -731,8 +731,57 @@ def base_grad_main():
     np.savez_compressed(os.path.join(OUT, "base_grad_golden.npz"), **g)
 
 
+def bn_train_main():
+    """--freeze_stats False: the reference's OWN BaseNet with its BatchNorm layers in TRAINING mode (models/networks.py:85-99 only forces
+    eval when freeze_stats; models/i3dpt.py:95-110) and trainable BN affine (--freeze_affine False), two clips per batch so that the batch
+    statistics span clips.  One forward + backward under the reference's autograd: output (digest + sample), every BN layer's running
+    statistics after the step, gradients of all 135 trainable tensors (45 conv weights + 45 x (gamma, beta)) as L2 norm + strided sample.
+    Three sizes: 'emul' [2,4,3,48,48] (the interpreter's), 'gpu' [2,8,3,48,48] and 'c1' [2,8,3,112,112].  Conditioning, measured by
+    running the restatement in fp32 and in fp64 (worst relative L2 over the 135 gradients): 48x48 clips 4e-5; a 32x32 clip 1.5e-2 (its
+    last maps are 1x2x2: a 3x3x3 pool makes them constant per clip and the batch variance of the following conv a difference of nearly
+    equal numbers); the C1-sized clip 6e-3 (the signed loss weights make the BN bias gradients sums with heavy cancellation, and a few
+    ReLU masks flip between fp32 and fp64) -- so gradients are pinned at 1e-3 on the 48x48 clips and output / running statistics also
+    at C1 size."""
+    from oracle import i3d_ref as R
+    models, _, _, _ = import_reference()
+    g = {}
+    for tag, shape in (("gpu", (2, 8, 3, 48, 48)), ("emul", (2, 4, 3, 48, 48)), ("c1", (2, 8, 3, 112, 112))):
+        net = models.BaseNet(cfg(freeze_stats=False, freeze_affine=False))
+        fill_module(net)
+        net.train()
+        assert all(m.training for m in net.modules() if isinstance(m, torch.nn.BatchNorm3d))
+        x = torch.rand(*shape, generator=torch.Generator().manual_seed(11)) * 2 - 1
+        y = net(x)
+        wgt = R.fill_tensor("golden.bn_train.w", tuple(y.shape), "image")
+        (y * wgt).sum().backward()
+        f = y.detach().reshape(-1)
+        step = max(1, f.numel() // 4096)
+        g[tag + ".out_l2"] = np.float64(f.double().norm().item())
+        g[tag + ".out_step"] = np.int64(step)
+        g[tag + ".out_sample"] = f[::step][:4096].numpy().copy()
+        sd = net.state_dict()
+        rkeys = [k for k in sd if k.endswith("running_mean") or k.endswith("running_var")]
+        g[tag + ".running_keys"] = np.array(rkeys)
+        g[tag + ".running"] = np.concatenate([sd[k].numpy().reshape(-1) for k in rkeys]).astype(np.float32)
+        g[tag + ".tracked"] = np.array([int(sd[k]) for k in sd if k.endswith("num_batches_tracked")], np.int64)
+        names = []
+        for k, p in net.named_parameters():
+            assert p.requires_grad and p.grad is not None, k
+            fg = p.grad.detach().reshape(-1)
+            st = max(1, fg.numel() // 512)
+            names.append(k)
+            g["%s.norm.%s" % (tag, k)] = np.float64(fg.double().norm().item())
+            g["%s.step.%s" % (tag, k)] = np.int64(st)
+            g["%s.sample.%s" % (tag, k)] = fg[::st][:512].numpy().copy()
+        g[tag + ".names"] = np.array(names)
+        print("bn_train_golden %s: %d tensors, |y| %.6f, %d running-stat values" % (tag, len(names), g[tag + ".out_l2"], g[tag + ".running"].size))
+    np.savez_compressed(os.path.join(OUT, "bn_train_golden.npz"), **g)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "i3d":
+    if len(sys.argv) > 1 and sys.argv[1] == "bn_train":
+        bn_train_main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "i3d":
         i3d_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "head_grad_margin":
         head_grad_margin_main()
@@ -758,5 +807,6 @@ if __name__ == "__main__":
         tube_math_main()
         postprocess_main()
         i3d_main()
+        bn_train_main()
         head_grad_main()
         base_grad_main()

@@ -69,7 +69,7 @@ SIGNATURES = {
     "step_conv_plan_info": (i, [C.POINTER(ConvDesc), C.POINTER(C.c_int), i]),
     "step_stem_packed_elems": (sz, [i]),
     "step_stem_pack_weight": (i, [fp, i, i, vp, vp]),
-    "step_stem_forward": (i, [i, vp, i, i, i, i, vp, fp, fp, i, vp, i, i, vp]),
+    "step_stem_forward": (i, [i, vp, i, i, i, i, vp, fp, fp, i, i, vp, i, i, vp]),
     "step_stem_kernel_name": (i, [i, C.c_char_p, i]),
     "step_stem_wgrad": (i, [i, vp, i, i, i, i, fp, i, fp, i, vp]),
     "step_stem_wgrad_workspace_bytes": (sz, [i, i, i, i, i]),
@@ -84,6 +84,9 @@ SIGNATURES = {
     "step_avgpool_hw": (i, [i, vp, i, i, i, i, i, i, i, vp, vp]),
     "step_transpose_cs": (i, [vp, i, vp, i, i, i, ll, i, vp]),
     "step_act_grad": (i, [i, vp, i, i, vp, i, fp, ll, i, i, fp, vp, vp]),
+    "step_bn_train_workspace_bytes": (sz, [ll, i]),
+    "step_bn_train_forward": (i, [i, vp, i, ll, i, fp, fp, f, f, fp, fp, fp, fp, i, vp, i, vp, sz, vp]),
+    "step_bn_train_backward": (i, [i, vp, i, vp, i, i, vp, i, ll, i, i, fp, fp, fp, vp, fp, fp, vp, sz, vp]),
     "step_tube_update": (i, [fp, i, i, fp, fp, fp, i, i, i, ip, i, f, f, fp, fp, fp, fp, vp]),
     "step_select_prepare": (i, [fp, fp, fp, fp, i, i, i, i, ip, fp, ip, i, f, f, fp, fp, fp, fp, fp, vp]),
     "step_adam_flat": (i, [fp, fp, fp, fp, ll, vp, fp, fp, i, C.c_double, C.c_double, C.c_double, i, f, i, vp]),

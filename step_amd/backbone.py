@@ -50,8 +50,9 @@ class _ConvUnitFn(torch.autograd.Function):
     differentiable view ops so autograd routes its gradient back to the parameter."""
 
     @staticmethod
-    def forward(ctx, x, w_eff, scale, shift, res, unit, relu):
-        y = unit._launch(x.detach(), relu, None if res is None else res.detach(), None)
+    def forward(ctx, x, w_eff, scale, shift, res, unit, relu, raw=False):
+        # raw: the conv alone, no affine / ReLU (the unit's BatchNorm runs on batch statistics as its own autograd node, _BatchNormTrainFn)
+        y = unit._launch(x.detach(), relu, None if res is None else res.detach(), None, raw=raw)
         ctx.save_for_backward(x, w_eff, scale, shift, y, res)
         ctx.relu = relu
         ctx.unit = unit
@@ -118,7 +119,7 @@ class _ConvUnitFn(torch.autograd.Function):
                     if GRAD_READY is not None:                   # this parameter bypasses autograd's accumulate hook
                         GRAD_READY(ctx.unit.weight_fn(), side)
                     gx = _ConvUnitFn._dgrad(gact, w_eff, x.dtype, k, ctx.unit) if need_x else None
-                    return gx, None, None, None, (gact if need_res else None), None, None
+                    return gx, None, None, None, (gact if need_res else None), None, None, None
                 if need_x and need_w and WGRAD_SIDE_STREAM and x.is_cuda and x.dtype == torch.float32 and ops.PROFILE is None:
                     # the two gradients are independent: the weight gradient (many of them latency-bound launches that fill a
                     # fraction of the chip) runs on a side stream beside the data-gradient conv.  Measured on the C4 step:
@@ -132,10 +133,10 @@ class _ConvUnitFn(torch.autograd.Function):
                     gx = _ConvUnitFn._dgrad(gact, w_eff, x.dtype, k, ctx.unit)
                     main.wait_stream(side)
                     gw.record_stream(main)
-                    return gx, gw, None, None, (gact if need_res else None), None, None
+                    return gx, gw, None, None, (gact if need_res else None), None, None, None
                 gx = _ConvUnitFn._dgrad(gact, w_eff, x.dtype, k, ctx.unit) if need_x else None
                 gw = wgrad(x, g32, w_eff.shape[0], k).to(w_eff.dtype) if need_w else None
-                return gx, gw, None, None, (gact if need_res else None), None, None
+                return gx, gw, None, None, (gact if need_res else None), None, None, None
         g = gy.float()
         if ctx.relu:
             g = g * (y > 0).to(g.dtype)
@@ -155,7 +156,38 @@ class _ConvUnitFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             # weight gradient = the HIP wgrad kernel (fp32 MFMA over the pixel axis) on the same channels-last buffers
             gw = ops.conv_wgrad(x, gconv, w_eff.shape[0], k).to(w_eff.dtype)
-        return gx, gw, gscale, gshift, gres, None, None
+        return gx, gw, gscale, gshift, gres, None, None, None
+
+
+class _BatchNormTrainFn(torch.autograd.Function):
+    """nn.BatchNorm3d in TRAINING mode (+ the unit's ReLU) on a raw conv output z (channels-last): batch statistics, running-statistics
+    update, backward through the statistics -- step_bn_train_forward / _backward (csrc/bn.hip).  models/i3dpt.py:95-110 with
+    --freeze_stats False (models/networks.py:85-99)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, bn, relu):
+        if bn.momentum is None:
+            raise NotImplementedError("step_amd: BatchNorm(momentum=None) (cumulative average) -- the reference builds its layers with the default 0.1")
+        track = bn.track_running_stats and bn.running_mean is not None
+        y, mean, invstd = ops.bn_train_forward(z.detach(), None if gamma is None else gamma.detach(), None if beta is None else beta.detach(),
+                                               bn.running_mean if track else None, bn.running_var if track else None, bn.eps, bn.momentum, relu)
+        if track and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        ctx.save_for_backward(z, y, gamma, mean, invstd)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        z, y, gamma, mean, invstd = ctx.saved_tensors
+        gz, gg, gb = ops.bn_train_backward(z, y, gy, gamma, mean, invstd, ctx.relu)
+        return (gz if ctx.needs_input_grad[0] else None, gg.to(gamma.dtype) if (gamma is not None and ctx.needs_input_grad[1]) else None,
+                gb if ctx.needs_input_grad[2] else None, None, None)
+
+
+def batchnorm_train(z, bn, relu):
+    """y = relu?(BatchNorm3d_training(z)) for a channels-last raw conv output; updates bn's running statistics."""
+    return _BatchNormTrainFn.apply(z, bn.weight, bn.bias, bn, relu)
 
 
 BATCH_PACK = True        # one-launch re-pack of every stale weight image (False: each unit packs its own; module switch for tests)
@@ -345,10 +377,8 @@ class ConvUnit:
         """fp32 (scale, shift) of the epilogue: folded eval-mode BN, or (None, bias), or (None, None)."""
         if self.bn is not None:
             bn = self.bn
-            if bn.training:
-                raise NotImplementedError("step_amd: batch-statistics BatchNorm is not on the hot path "
-                                          "(the reference always runs with freeze_stats=True); call .eval()/.train() "
-                                          "on the owning net so that BN modules are in eval mode")
+            if bn.training:                                      # (callers test bn_training first: ConvUnit.__call__, Mixed.forward, Unit3D._forward_stem)
+                raise RuntimeError("step_amd: ConvUnit.affine() folds EVAL-mode BatchNorm; a layer in training mode goes through batchnorm_train")
             if differentiable and (bn.weight.requires_grad or bn.bias.requires_grad):
                 return self._bn_affine()
             dev = bn.weight.device
@@ -365,14 +395,34 @@ class ConvUnit:
             return None, (b if b.dtype == torch.float32 else b.float())
         return None, None
 
-    def _launch(self, x, relu, res, out):
-        scale, shift = self.affine()
+    @property
+    def bn_training(self):
+        """The unit's BatchNorm normalises with batch statistics (nn.BatchNorm3d in training mode: --freeze_stats False)."""
+        bn = self.bn
+        return bn is not None and bn.training
+
+    def _launch(self, x, relu, res, out, raw=False):
+        scale, shift = (None, None) if raw else self.affine()
         if shift is not None:
             shift = shift.detach().contiguous()
         return ops.conv_forward(x, self.packed(x.dtype), self.cout, self.k, scale, shift, relu, res, out)
 
     def __call__(self, x, relu=True, res=None, out=None):
         w = self.weight_fn()
+        if self.bn_training:
+            # --freeze_stats False (models/networks.py:85-99 leaves BatchNorm in training mode): conv without an epilogue, then the
+            # batch-statistics BatchNorm + ReLU as its own pass / autograd node (the statistics need the whole conv output first)
+            if res is not None:
+                raise NotImplementedError("step_amd: a residual input on a unit with batch-statistics BatchNorm")
+            if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+                z = _ConvUnitFn.apply(x, self.effective_weight(), None, None, None, self, False, True)
+            else:
+                z = self._launch(x, False, None, None, raw=True)
+            y = batchnorm_train(z, self.bn, relu)
+            if out is not None:
+                out.copy_(y)
+                return out
+            return y
         need_grad = torch.is_grad_enabled() and (
             x.requires_grad or w.requires_grad or (res is not None and res.requires_grad)
             or (self.bias_fn is not None and self.bias_fn().requires_grad)
@@ -437,6 +487,16 @@ class Unit3D(nn.Module):
             self._stem_packed[key] = hit
         bn = getattr(self, "batch3d", None)
         bn_grad = bn is not None and (bn.weight.requires_grad or bn.bias.requires_grad)
+        if self._unit.bn_training:                                     # --freeze_stats False: raw stem conv, then batch-statistics BN + ReLU
+            if torch.is_grad_enabled() and w.requires_grad:
+                z = _StemFn.apply(x, w, None, None, self, hit[1], False)
+            else:
+                z = ops.stem_forward(x, hit[1], w.shape[0], None, None, None, relu=False)
+            y = batchnorm_train(z, bn, self.relu)
+            if out is not None:
+                out.copy_(y)
+                return out
+            return y
         if torch.is_grad_enabled() and (w.requires_grad or bn_grad):
             scale, shift = self._unit.affine(differentiable=True)      # --freeze_affine False: the BN affine trains too
             return _StemFn.apply(x, w, scale, shift, self, hit[1])
@@ -446,14 +506,25 @@ class Unit3D(nn.Module):
 
 class _StemFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, scale, shift, unit, packed):
-        y = ops.stem_forward(x.detach(), packed, w.shape[0], scale.detach().contiguous(), shift.detach().contiguous())
+    def forward(ctx, x, w, scale, shift, unit, packed, relu=True):
+        det = lambda t: None if t is None else t.detach().contiguous()
+        y = ops.stem_forward(x.detach(), packed, w.shape[0], det(scale), det(shift), None, relu=relu)
         ctx.save_for_backward(x, w, scale, shift, y)
+        ctx.relu = relu
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w, scale, shift, y = ctx.saved_tensors
+        if not ctx.relu and scale is None:                             # the raw conv (batch-statistics BN follows): gy IS the conv's gradient
+            gw = None
+            if ctx.needs_input_grad[1]:
+                if WGRAD16 and x.dtype != torch.float32 and gy.dtype == x.dtype:
+                    gw = ops.stem_wgrad16(x, gy.contiguous(), w.shape[0])
+                if gw is None:
+                    gw = ops.stem_wgrad(x.contiguous(), gy.float(), w.shape[0])
+                gw = gw.to(w.dtype)
+            return None, gw, None, None, None, None, None
         if WGRAD16 and ctx.needs_input_grad[1] and not (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]) and y.dtype != torch.float32 \
                 and x.dtype == y.dtype:
             # frozen affine, 16-bit activations: ReLU mask x scale in ONE HIP pass (16-bit result), then the weight gradient on the
@@ -462,7 +533,7 @@ class _StemFn(torch.autograd.Function):
             if fused is not None:
                 gw = ops.stem_wgrad16(x, fused[1], w.shape[0])
                 if gw is not None:
-                    return None, gw.to(w.dtype), None, None, None, None
+                    return None, gw.to(w.dtype), None, None, None, None, None
         g = gy.float() * (y > 0).to(torch.float32)
         C = g.shape[-1]
         gw = gscale = gshift = None
@@ -472,7 +543,7 @@ class _StemFn(torch.autograd.Function):
             gscale = (g * (y.float() - shift.view(1, 1, 1, 1, -1)) / scale.view(1, 1, 1, 1, -1)).reshape(-1, C).sum(0)
         if ctx.needs_input_grad[1]:
             gw = ops.stem_wgrad(x.contiguous(), g * scale.view(1, 1, 1, 1, -1), w.shape[0]).to(w.dtype)   # HIP (the clip itself needs no gradient)
-        return None, gw, gscale, gshift, None, None
+        return None, gw, gscale, gshift, None, None, None
 
 
 class MaxPoolTF(nn.Module):
@@ -567,7 +638,8 @@ class Mixed(nn.Module):
         oc = self.oc
         N, D, H, W, _ = x.shape
         grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if grad:
+        bn_train = any(u._unit.bn_training for u in (self.branch_0, self.branch_1[0], self.branch_1[1], self.branch_2[0], self.branch_2[1], self.branch_3[1]))
+        if grad or bn_train:
             # autograd path: branches return fresh tensors, concatenated by torch (bookkeeping only)
             y = torch.cat([self.branch_0(x), self.branch_1[1](self.branch_1[0](x)), self.branch_2[1](self.branch_2[0](x)),
                            self.branch_3[1](self.branch_3[0](x))], dim=-1)
@@ -688,6 +760,8 @@ def _pointwise_then_3x3x3(a, b, x):
     if not (isinstance(a, Unit3D) and isinstance(b, Unit3D)) or a.is_stem or b.is_stem or not x.is_cuda or x.dtype == torch.float32:
         return None
     ua, ub = a._unit, b._unit
+    if ua.bn_training or ub.bn_training:
+        return None
     if tuple(ua.k) != (1, 1, 1) or tuple(ub.k) != (3, 3, 3) or not a.relu or ua.cout != 64 or x.shape[-1] != 64:
         return None
     for u in (ua, ub):

@@ -20,6 +20,7 @@ struct StemParams {
     int N, T, H, W, To, Ho, Wo, Cout, y_cstride, y_coff;
     int tiles_h, tiles_w, nblk32;
     int tile0;                 // stem_stream_kernel: first pixel tile of this launch (the layer may be launched in two parts)
+    int relu;                  // 1: ReLU after the affine (Unit3Dpy); 0: the raw affine output (batch-statistics BatchNorm follows, bn.hip)
 #ifdef STEP_PROBE
     unsigned long long* probe;   // tools/timeline_probe.py build only (conv_common.h: probe_mark)
 #endif
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(256) void stem_igemm_kernel(StemParams p) {
                 const int mm = wave * 32 + cd_row(r, lane);
                 const int oh = oh0 + (mm >> 4), ow = ow0 + (mm & 15);
                 if (oh < p.Ho && ow < p.Wo) {
-                    float v = fmaxf(acc[i][r] * sc + sh, 0.f);
+                    float v = acc[i][r] * sc + sh;
+                    if (p.relu) v = fmaxf(v, 0.f);
                     const size_t opix = (((size_t)n * p.To + od) * p.Ho + oh) * p.Wo + ow;
                     yg[opix * p.y_cstride + p.y_coff + co] = elem<T>::from_f32(v);
                 }
@@ -484,7 +486,10 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
                 const f32x4 sh = *(const f32x4*)(ldsS + NB * 32 + i * 32 + 8 * g + 4 * khalf);
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[mb][i][4 * g + e] * sc[e] + sh[e], 0.f);
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[mb][i][4 * g + e] * sc[e] + sh[e];
+                    if (p.relu) v[e] = fmaxf(v[e], 0.f);
+                }
                 if (!vec_epi) {                               // channel counts / offsets off the 16-byte grid: element stores
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -624,7 +629,7 @@ int step_stem_pack_weight(const float* w, int Cout, int dtype, void* packed, ste
 }
 
 int step_stem_forward(int dtype, const void* x, int N, int T, int H, int W, const void* w_packed, const float* scale,
-                      const float* shift, int Cout, void* y, int y_cstride, int y_coff, step_stream_t stream) {
+                      const float* shift, int relu, int Cout, void* y, int y_cstride, int y_coff, step_stream_t stream) {
     if (N < 0 || T <= 0 || H <= 0 || W <= 0 || Cout <= 0) return STEP_E_SHAPE;
     if (y_coff < 0 || y_coff + Cout > y_cstride) return STEP_E_SHAPE;
     if (N == 0) return STEP_OK;
@@ -632,7 +637,7 @@ int step_stem_forward(int dtype, const void* x, int N, int T, int H, int W, cons
     if (((uintptr_t)x % 16) || ((uintptr_t)w_packed % 16)) return STEP_E_ALIGN;
     StemParams p;
     p.x = x; p.w = w_packed; p.scale = scale; p.shift = shift; p.y = y;
-    p.N = N; p.T = T; p.H = H; p.W = W; p.tile0 = 0;
+    p.N = N; p.T = T; p.H = H; p.W = W; p.tile0 = 0; p.relu = relu != 0;
     p.To = (T + 5 - 7) / 2 + 1; p.Ho = (H + 5 - 7) / 2 + 1; p.Wo = (W + 5 - 7) / 2 + 1;
     if (p.To <= 0 || p.Ho <= 0 || p.Wo <= 0) return STEP_E_SHAPE;
     p.Cout = Cout; p.y_cstride = y_cstride; p.y_coff = y_coff;

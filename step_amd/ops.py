@@ -378,7 +378,59 @@ def act_grad(y, gy, scale, relu, want_f32=True, want_act=False):
     return (g32 if want_f32 or same else None), (g32 if same else gact)
 
 
-def stem_forward(x, w_packed, Cout, scale, shift, out=None):
+def bn_train_forward(z, gamma, beta, running_mean, running_var, eps, momentum, relu, out=None):
+    """Batch-statistics BatchNorm (+ ReLU) of a raw conv output z (channels-last, possibly a channel slice): step_bn_train_forward.
+    Updates running_mean / running_var in place (None: no update).  Returns (y, save_mean, save_invstd)."""
+    L = _lib.lib()
+    C = z.shape[-1]
+    M = z.numel() // C
+    zcs = _chan_slice(z)
+    if out is None:
+        out = torch.empty(z.shape, dtype=z.dtype, device=z.device)
+    f32 = lambda t: None if t is None else (t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous())
+    g_, b_ = f32(gamma), f32(beta)
+    for t in (running_mean, running_var):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            raise RuntimeError("step_amd: BatchNorm running statistics must be contiguous fp32 tensors")
+    save_mean = torch.empty(C, dtype=torch.float32, device=z.device)
+    save_invstd = torch.empty(C, dtype=torch.float32, device=z.device)
+    wsb = L.step_bn_train_workspace_bytes(M, C)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=z.device)
+    _capi.check(L.step_bn_train_forward(_dt(z), _lib.dptr(z), zcs, M, C, _lib.dptr(g_), _lib.dptr(b_), float(eps), float(momentum),
+                                        _lib.dptr(running_mean), _lib.dptr(running_var), _lib.dptr(save_mean), _lib.dptr(save_invstd),
+                                        int(bool(relu)), _lib.dptr(out), _chan_slice(out), _lib.dptr(ws), wsb, _lib.stream_ptr(z.device)),
+                "step_bn_train_forward")
+    return out, save_mean, save_invstd
+
+
+def bn_train_backward(z, y, gy, gamma, save_mean, save_invstd, relu):
+    """-> (gz dense in z.dtype, ggamma, gbeta fp32 [C])   step_bn_train_backward"""
+    L = _lib.lib()
+    C = z.shape[-1]
+    M = z.numel() // C
+    if gy.dtype not in (torch.float32, z.dtype):
+        gy = gy.float()
+    if gy.stride(-1) != 1:
+        gy = gy.contiguous()
+    try:
+        gcs = _chan_slice(gy)
+    except RuntimeError:
+        gy = gy.contiguous()
+        gcs = C
+    gz = torch.empty(z.shape, dtype=z.dtype, device=z.device)
+    ggamma = torch.empty(C, dtype=torch.float32, device=z.device)
+    gbeta = torch.empty(C, dtype=torch.float32, device=z.device)
+    g_ = None if gamma is None else (gamma if (gamma.dtype == torch.float32 and gamma.is_contiguous()) else gamma.float().contiguous())
+    wsb = L.step_bn_train_workspace_bytes(M, C)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=z.device)
+    _capi.check(L.step_bn_train_backward(_dt(z), _lib.dptr(z), _chan_slice(z), _lib.dptr(y), _chan_slice(y), DT[gy.dtype], _lib.dptr(gy), gcs, M, C,
+                                         int(bool(relu)), _lib.dptr(g_), _lib.dptr(save_mean), _lib.dptr(save_invstd), _lib.dptr(gz),
+                                         _lib.dptr(ggamma), _lib.dptr(gbeta), _lib.dptr(ws), wsb, _lib.stream_ptr(z.device)),
+                "step_bn_train_backward")
+    return gz, ggamma, gbeta
+
+
+def stem_forward(x, w_packed, Cout, scale, shift, out=None, relu=True):
     """x: [N,T,3,H,W] contiguous (the reference's input layout) -> channels-last [N,To,Ho,Wo,Cout]"""
     L = _lib.lib()
     N, T, C, H, W = x.shape
@@ -394,7 +446,7 @@ def stem_forward(x, w_packed, Cout, scale, shift, out=None):
         return buf.value.decode(), 2.0 * pix * Cout * 1029, (x.numel() + pix * Cout + Cout * 1029) * _ES[x.dtype]
     def launch():
         _capi.check(L.step_stem_forward(_dt(x), _lib.dptr(x), N, T, H, W, _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift),
-                                        Cout, _lib.dptr(out), _chan_slice(out), 0, _lib.stream_ptr(x.device)), "step_stem_forward")
+                                        int(bool(relu)), Cout, _lib.dptr(out), _chan_slice(out), 0, _lib.stream_ptr(x.device)), "step_stem_forward")
     _run(launch, describe)
     return out
 

@@ -151,7 +151,7 @@ def run_stem(bk, x_ntchw, w, scale, shift, dt):
     To, Ho, Wo = (T - 2) // 2 + 1, (H - 2) // 2 + 1, (W - 2) // 2 + 1
     y = bk.dev(np.zeros((N, To, Ho, Wo, Cout), NP_DT[dt]))
     xe, sc, sh = bk.dev(encode(x_ntchw, dt)), bk.dev(scale), bk.dev(shift)
-    rc = bk.lib.step_stem_forward(dt, xe.ptr, N, T, H, W, wp.ptr, sc.ptr, sh.ptr, Cout, y.ptr, Cout, 0, bk.stream)
+    rc = bk.lib.step_stem_forward(dt, xe.ptr, N, T, H, W, wp.ptr, sc.ptr, sh.ptr, 1, Cout, y.ptr, Cout, 0, bk.stream)
     assert rc == 0, rc
     return uncl(decode(y.get(), dt))
 
@@ -221,6 +221,24 @@ def case_roi_align_backward(bk, golden):
                             assert not outs[0][2].any()
                         if gather:
                             assert np.array_equal(outs[0], outs[1])
+    # the gather's per-cell roi list: more rois than one 64-header scan round (order must stay ascending across rounds), and more rois
+    # on one cell than the list holds (520 whole-frame rois on frame 0 > 512: that cell walks every header instead)
+    spread = np.concatenate([rs.randint(0, 3, (150, 1)).astype(np.float32), rs.uniform(-10, 100, (150, 2)).astype(np.float32),
+                             rs.uniform(60, 200, (150, 2)).astype(np.float32)], 1)
+    crowd = np.tile(np.array([[0, 0, 0, 190, 140]], np.float32), (520, 1))
+    crowd[::3, 1:] += rs.uniform(-3, 3, (len(crowd[::3]), 4)).astype(np.float32)
+    for rois, B, C, H, W in ((spread, 3, 8, 9, 12), (crowd, 1, 4, 9, 12)):
+        K = rois.shape[0]
+        g = rs.randn(K, C, 7, 7).astype(np.float32)
+        ref = oracle.roi_align_backward(g, rois, (7, 7), 1 / 16., 0, (B, C, H, W))
+        gg, r = bk.dev(nhwc(g)), bk.dev(rois)
+        outs = []
+        for _ in range(2):
+            gi = bk.dev(np.full((B, H, W, C), 7.0, np.float32))
+            assert bk.lib.step_roi_align_backward(gg.ptr, NHWC, r.ptr, K, B, C, H, W, 7, 7, 1 / 16., 0, _capi.ROI_BWD_GATHER, gi.ptr, bk.stream) == 0
+            outs.append(nchw(gi.get()))
+        assert np.abs(outs[0] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), K
+        assert np.array_equal(outs[0], outs[1])
     gi = bk.dev(np.full((2, 9, 12, 8), 7.0, np.float32))
     assert bk.lib.step_roi_align_backward(None, NHWC, None, 0, 2, 8, 9, 12, 7, 7, 1 / 16., 2, _capi.ROI_BWD_ATOMIC, gi.ptr, bk.stream) == 0 and not gi.get().any()
     assert bk.lib.step_roi_align_backward(None, NHWC, None, 0, 2, 8, 9, 12, 7, 7, 1 / 16., 2, 2, gi.ptr, bk.stream) == -4       # unknown mode
@@ -661,6 +679,62 @@ def case_adam_flat_amp(bk, golden):
                                      1.0, 0, amp.ptr, 2.0, 0.5, interval, bk.stream) < 0
     assert bk.lib.step_adam_flat_amp(P.ptr, P.ptr, M.ptr, V.ptr, n, ends.ptr, LR.ptr, WD.ptr, len(sizes), 0.9, 0.999, 1e-8, cnt.ptr, bc.ptr,
                                      1.0, 0, None, 2.0, 0.5, interval, bk.stream) < 0
+
+
+def case_bn_train(bk, golden):
+    """step_bn_train_forward / _backward (batch-statistics BatchNorm + ReLU of --freeze_stats False, models/i3dpt.py:95-110) against
+    torch's own F.batch_norm(training=True) + relu under autograd on the same (storage-rounded) input: output, saved statistics, the
+    running-statistics update (momentum 0.1, unbiased variance), gz / ggamma / gbeta; channel-slice strides, several chunks with a
+    ragged tail, a large |mean| / std ratio (shifted sums), ReLU on and off, fp32 and 16-bit gradients; bit-reproducible."""
+    rs = np.random.RandomState(9)
+    for dt, M, C, zcs, relu, gdt in ((F32, 5000, 24, 24, 1, F32), (F32, 300, 8, 16, 0, F32), (BF16, 4500, 16, 24, 1, BF16), (F16, 2100, 8, 8, 1, F32)):
+        z = (rs.randn(M, C) * rs.uniform(0.5, 2.0, C) + rs.uniform(-30, 30, C)).astype(np.float32)
+        gamma, beta = rs.uniform(0.5, 1.5, C).astype(np.float32), rs.uniform(-1, 1, C).astype(np.float32)
+        rm0, rv0 = rs.randn(C).astype(np.float32), rs.uniform(0.5, 2, C).astype(np.float32)
+        gy = rs.randn(M, C).astype(np.float32)
+        zq, gq = quantize(z, dt), quantize(gy, gdt)
+        zt = torch.from_numpy(zq).requires_grad_(True)
+        gt, bt = torch.from_numpy(gamma).requires_grad_(True), torch.from_numpy(beta).requires_grad_(True)
+        rm, rv = torch.from_numpy(rm0.copy()), torch.from_numpy(rv0.copy())
+        yr = F.batch_norm(zt.t().reshape(1, C, M), rm, rv, gt, bt, True, 0.1, 1e-5).reshape(C, M).t()
+        yr = F.relu(yr) if relu else yr
+        (yr * torch.from_numpy(gq)).sum().backward()        # (the kernel masks with the STORED output; rounding never moves a positive y to <= 0)
+        zbuf = np.zeros((M, zcs), np.float32)
+        zbuf[:, :C] = zq
+        Z = bk.dev(encode(zbuf, dt))
+        Y = bk.dev(np.zeros((M, zcs), NP_DT[dt]))
+        G, Bt = bk.dev(gamma), bk.dev(beta)
+        RM, RV = bk.dev(rm0.copy()), bk.dev(rv0.copy())
+        SM, SI = bk.dev(np.zeros(C, np.float32)), bk.dev(np.zeros(C, np.float32))
+        wsb = bk.lib.step_bn_train_workspace_bytes(M, C)
+        WS = bk.dev(np.zeros(wsb // 4 + 4, np.float32))
+        assert bk.lib.step_bn_train_forward(dt, Z.ptr, zcs, M, C, G.ptr, Bt.ptr, 1e-5, 0.1, RM.ptr, RV.ptr, SM.ptr, SI.ptr, relu, Y.ptr, zcs, WS.ptr, wsb,
+                                            bk.stream) == 0
+        y = decode(Y.get(), dt)[:, :C]
+        t_ = tol(dt)
+        assert np.abs(y - yr.detach().numpy()).max() <= t_ * max(1.0, np.abs(yr.detach().numpy()).max()) + 2e-5, (dt, M, C)
+        mean = zq.astype(np.float64).mean(0)
+        var = zq.astype(np.float64).var(0)
+        assert np.abs(SM.get() - mean).max() <= 1e-6 * np.abs(mean).max() + 1e-6
+        assert np.abs(SI.get() - 1 / np.sqrt(var + 1e-5)).max() <= 2e-6 * (1 / np.sqrt(var + 1e-5)).max()
+        assert np.abs(RM.get() - rm.numpy()).max() <= 1e-6 * max(1.0, np.abs(rm.numpy()).max())
+        assert np.abs(RV.get() - rv.numpy()).max() <= 2e-6 * max(1.0, np.abs(rv.numpy()).max())
+        GY = bk.dev(encode(gq, gdt))
+        GZ = bk.dev(np.zeros((M, C), NP_DT[dt]))
+        GG, GB = bk.dev(np.zeros(C, np.float32)), bk.dev(np.zeros(C, np.float32))
+        outs = []
+        for _ in range(2):
+            assert bk.lib.step_bn_train_backward(dt, Z.ptr, zcs, Y.ptr, zcs, gdt, GY.ptr, C, M, C, relu, G.ptr, SM.ptr, SI.ptr, GZ.ptr, GG.ptr, GB.ptr,
+                                                 WS.ptr, wsb, bk.stream) == 0
+            outs.append((GZ.get().copy(), GG.get().copy(), GB.get().copy()))
+        assert all(np.array_equal(a, b) for a, b in zip(*outs))
+        gz = decode(outs[0][0], dt)
+        ref_gz = zt.grad.numpy()
+        assert np.abs(gz - ref_gz).max() <= max(t_, 2e-5) * max(1e-3, np.abs(ref_gz).max()) * (4 if dt != F32 else 1), (dt, M, C, np.abs(gz - ref_gz).max(), np.abs(ref_gz).max())
+        assert np.abs(outs[0][1] - gt.grad.numpy()).max() <= (2e-2 if dt != F32 else 2e-4) * max(1.0, np.abs(gt.grad.numpy()).max()), (dt, M)
+        assert np.abs(outs[0][2] - bt.grad.numpy()).max() <= (2e-2 if dt != F32 else 2e-4) * max(1.0, np.abs(bt.grad.numpy()).max()), (dt, M)
+    assert bk.lib.step_bn_train_forward(F32, Z.ptr, 6, 10, 6, None, None, 1e-5, 0.1, None, None, SM.ptr, SI.ptr, 1, Y.ptr, 6, WS.ptr, wsb, bk.stream) == -4   # C % 4
+    assert bk.lib.step_bn_train_forward(F32, Z.ptr, 8, 0, 8, None, None, 1e-5, 0.1, None, None, SM.ptr, SI.ptr, 1, Y.ptr, 8, WS.ptr, wsb, bk.stream) == 0     # empty batch
 
 
 def case_pack_weight_dgrad(bk, golden):

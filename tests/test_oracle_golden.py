@@ -246,6 +246,32 @@ def test_backbone_gradients_of_the_restatement_match_the_reference_autograd(gold
         assert np.linalg.norm(a - b) <= 2e-4 * max(np.linalg.norm(b), 1e-30), k
 
 
+def test_batch_statistics_bn_restatement_matches_the_reference(golden):
+    """--freeze_stats False: bn_train_golden.npz = the reference's OWN BaseNet with its BatchNorm layers in training mode and trainable BN
+    affine, forward + backward on a two-clip batch (`python -m oracle.make_golden bn_train`).  The restatement with train_bn=True
+    reproduces the output, every running statistic after the step and all 135 gradients (the interpreter-sized clip)."""
+    g = golden("bn_train_golden")
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in R.fill_state_dict(R.backbone_shapes()).items()}
+    x = torch.rand(2, 4, 3, 48, 48, generator=torch.Generator().manual_seed(11)) * 2 - 1
+    y = R.basenet_forward(x, sd, train_bn=True)
+    assert abs(float(y.detach().double().norm()) - float(g["emul.out_l2"])) < 1e-5 * float(g["emul.out_l2"])
+    f = y.detach().reshape(-1)[::int(g["emul.out_step"])][:4096].numpy()
+    assert rel_err(f, g["emul.out_sample"]) < 1e-5
+    run = np.concatenate([sd[str(k)].detach().numpy().reshape(-1) for k in g["emul.running_keys"]])
+    assert rel_err(run, g["emul.running"]) < 1e-5
+    assert all(int(sd[k]) == 1 for k in sd if k.endswith("num_batches_tracked")) and bool((g["emul.tracked"] == 1).all())
+    wgt = R.fill_tensor("golden.bn_train.w", tuple(y.shape), "image")
+    (y * wgt).sum().backward()
+    names = [str(n) for n in g["emul.names"]]
+    assert len(names) == 135
+    for k in names:
+        gr = sd[k].grad.reshape(-1)
+        nr = float(g["emul.norm." + k])
+        assert abs(float(gr.double().norm()) - nr) <= 2e-4 * nr + 1e-12, k
+        a, b = gr[::int(g["emul.step." + k])][:512].numpy().astype(np.float64), g["emul.sample." + k].astype(np.float64)
+        assert np.linalg.norm(a - b) <= 2e-4 * max(np.linalg.norm(b), 1e-30) + 1e-12, k
+
+
 @pytest.mark.parametrize("ntubes", [11, 34])
 def test_inference_history(golden, ntubes):
     g = golden("inference_golden")

@@ -92,7 +92,7 @@ def main():
             wps.append(wp)
 
         def run_stem(vi):
-            _capi.check(libs[vi].step_stem_forward(dt, _lib.dptr(x), B, T_, HW_, HW_, _lib.dptr(wps[vi]), _lib.dptr(sc), _lib.dptr(sh), 64,
+            _capi.check(libs[vi].step_stem_forward(dt, _lib.dptr(x), B, T_, HW_, HW_, _lib.dptr(wps[vi]), _lib.dptr(sc), _lib.dptr(sh), 1, 64,
                                                    _lib.dptr(y), 64, 0, st), "stem")
         for vi in range(len(variants)):
             run_stem(vi)

@@ -70,7 +70,7 @@ def main():
     sc = torch.ones(64, device=dev)
     sh = torch.zeros(64, device=dev)
     y = torch.empty(B, 16, 112, 112, 64, dtype=tdt, device=dev)
-    ms = time_it(lambda: _capi.check(L.step_stem_forward(dt, _lib.dptr(x), B, 32, 224, 224, _lib.dptr(wp), _lib.dptr(sc), _lib.dptr(sh), 64, _lib.dptr(y), 64, 0, st), "stem"), a.iters)
+    ms = time_it(lambda: _capi.check(L.step_stem_forward(dt, _lib.dptr(x), B, 32, 224, 224, _lib.dptr(wp), _lib.dptr(sc), _lib.dptr(sh), 1, 64, _lib.dptr(y), 64, 0, st), "stem"), a.iters)
     gf = 2 * B * 16 * 112 * 112 * 64 * 1029 / 1e9
     print("%-8s %8.3f ms %8.1f TFLOP/s (useful)" % ("stem", ms, gf / ms))
     tot_ms += ms

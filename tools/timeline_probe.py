@@ -122,7 +122,7 @@ def main():
 
         def run():
             _capi.check(L.step_stem_forward(dt, ctypes.c_void_p(x.data_ptr()), B, T_, HW, HW, ctypes.c_void_p(wp.data_ptr()),
-                                            ctypes.c_void_p(sc.data_ptr()), ctypes.c_void_p(sh.data_ptr()), 64,
+                                            ctypes.c_void_p(sc.data_ptr()), ctypes.c_void_p(sh.data_ptr()), 1, 64,
                                             ctypes.c_void_p(y.data_ptr()), 64, 0, st), "stem")
         report(L, "stem", run, probe, stem=True)
         return
