@@ -352,6 +352,17 @@ STEP_API int step_stem_pack_weight(const float* w /*[Cout,3,7,7,7]*/, int Cout, 
 STEP_API int step_stem_forward(int dtype, const void* x, int N, int T, int H, int W, const void* w_packed,
                                const float* scale, const float* shift, int relu, int Cout, void* y, int y_cstride,
                                int y_coff, step_stream_t stream);
+/* The stem AND maxPool3d_2a_3x3 behind it (models/i3dpt.py:186-196: Unit3Dpy 7x7x7 / 2, then MaxPool3dTFPadding (1,3,3) / (1,2,2)) as one
+ * call: every 16x16 stem tile is max-pooled while it is still on the chip, y is the POOLED tensor [N, To, Hp, Wp, Cout] (Hp / Wp =
+ * step_pool_out_size(Ho / Wo, 3, 2)) and the un-pooled stem output -- the largest tensor of the backbone -- never reaches memory.
+ * Pooled pixels on tile seams lack one row / column of the neighbouring tile: tiles leave their first row and column in `ws` and a
+ * second, small launch completes the seams.  Bit-identical to step_stem_forward (relu = 1) + step_maxpool3d_tf.  16-bit dtypes,
+ * W % 4 == 0, Cout == 64, y 16-byte aligned with y_cstride / y_coff multiples of 8; otherwise STEP_E_UNSUPPORTED (the caller runs the
+ * two layers one after the other).  ws: step_stem_pool_workspace_bytes() bytes (0 = unsupported), 16-byte aligned. */
+STEP_API size_t step_stem_pool_workspace_bytes(int dtype, int N, int T, int H, int W, int Cout);
+STEP_API int step_stem_pool_forward(int dtype, const void* x, int N, int T, int H, int W, const void* w_packed, const float* scale,
+                                    const float* shift, int Cout, void* y, int y_cstride, int y_coff, void* ws, size_t ws_bytes,
+                                    step_stream_t stream);
 /* Weight gradient of the stem: dw[Cout][3][7][7][7] (fp32, torch layout) (+)= sum over output pixels of
  * dy[n,to,ho,wo,co] * x_padded[...]; x as in step_stem_forward, dy fp32 contiguous [N,To,Ho,Wo,Cout] (gradient before
  * the affine epilogue).  The stem needs no data gradient (its input is the clip). */

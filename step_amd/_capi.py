@@ -70,6 +70,8 @@ SIGNATURES = {
     "step_stem_packed_elems": (sz, [i]),
     "step_stem_pack_weight": (i, [fp, i, i, vp, vp]),
     "step_stem_forward": (i, [i, vp, i, i, i, i, vp, fp, fp, i, i, vp, i, i, vp]),
+    "step_stem_pool_workspace_bytes": (sz, [i, i, i, i, i, i]),
+    "step_stem_pool_forward": (i, [i, vp, i, i, i, i, vp, fp, fp, i, vp, i, i, vp, sz, vp]),
     "step_stem_kernel_name": (i, [i, C.c_char_p, i]),
     "step_stem_wgrad": (i, [i, vp, i, i, i, i, fp, i, fp, i, vp]),
     "step_stem_wgrad_workspace_bytes": (sz, [i, i, i, i, i]),

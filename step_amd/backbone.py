@@ -476,15 +476,20 @@ class Unit3D(nn.Module):
             return self._forward_stem(x, out)
         return self._unit(x, relu=self.relu, out=out)
 
-    def _forward_stem(self, x, out):
-        """x is the clip in the reference layout [N,T,3,H,W]."""
+    def stem_packed(self, dtype):
         w = self.conv3d.weight
-        key = (x.dtype, w.device)
+        key = (dtype, w.device)
         ver = self._unit._wver(w)
         hit = self._stem_packed.get(key)
         if hit is None or hit[0] != ver:
-            hit = (ver, ops.pack_stem_weight(w, x.dtype))
+            hit = (ver, ops.pack_stem_weight(w, dtype))
             self._stem_packed[key] = hit
+        return hit[1]
+
+    def _forward_stem(self, x, out):
+        """x is the clip in the reference layout [N,T,3,H,W]."""
+        w = self.conv3d.weight
+        hit = (None, self.stem_packed(x.dtype))
         bn = getattr(self, "batch3d", None)
         bn_grad = bn is not None and (bn.weight.requires_grad or bn.bias.requires_grad)
         if self._unit.bn_training:                                     # --freeze_stats False: raw stem conv, then batch-statistics BN + ReLU
@@ -750,7 +755,23 @@ def wgrad_sync():
 
 
 POOL_WITH_POINTWISE = True     # inference: an Inception block's max pool and its fused 1x1x1 triple as one launch where the library has the form
+FUSE_STEM_POOL = True          # inference: maxPool3d_2a is taken on the stem's tiles while they are on the chip (ops.stem_pool_forward)
 FUSE_POINTWISE_INPUT = True    # inference: a 64 -> 64 1x1x1 unit directly in front of a 3x3x3 unit runs inside that unit's launch (ops.conv_forward_pre)
+
+
+def _stem_then_pool(a, b, x):
+    """Unit3D a (the 7x7x7 stem, eval-mode BN, ReLU) followed by MaxPoolTF b ((1,3,3) / (1,2,2)): one call when neither needs autograd
+    and the library has the fused form (16-bit clips); None otherwise -- the caller runs them one after the other (bit-identical)."""
+    if not (isinstance(a, Unit3D) and a.is_stem and isinstance(b, MaxPoolTF)) or not x.is_cuda or x.dtype == torch.float32:
+        return None
+    if b.kernel_size != (1, 3, 3) or b.stride != (1, 2, 2) or not a.relu or a._unit.bn_training or a._unit.bn is None:
+        return None
+    w = a.conv3d.weight
+    bn = a.batch3d
+    if torch.is_grad_enabled() and (w.requires_grad or bn.weight.requires_grad or bn.bias.requires_grad or x.requires_grad):
+        return None
+    scale, shift = a._unit.affine()
+    return ops.stem_pool_forward(x, a.stem_packed(x.dtype), w.shape[0], scale, shift)
 
 
 def _pointwise_then_3x3x3(a, b, x):
@@ -953,6 +974,12 @@ class BaseNet(nn.Module):
         i = 0
         while i < len(stages):
             st = stages[i]
+            if FUSE_STEM_POOL and i == 0 and i + 1 < len(stages):
+                z = _stem_then_pool(st, stages[i + 1], y)                # maxPool3d_2a on the stem's tiles
+                if z is not None:
+                    y = z
+                    i += 2
+                    continue
             if FUSE_POINTWISE_INPUT and i + 1 < len(stages):
                 z = _pointwise_then_3x3x3(st, stages[i + 1], y)          # conv3d_2b evaluated inside conv3d_2c's halo staging
                 if z is not None:

@@ -21,6 +21,11 @@ struct StemParams {
     int tiles_h, tiles_w, nblk32;
     int tile0;                 // stem_stream_kernel: first pixel tile of this launch (the layer may be launched in two parts)
     int relu;                  // 1: ReLU after the affine (Unit3Dpy); 0: the raw affine output (batch-statistics BatchNorm follows, bn.hip)
+    // stem_stream_kernel<.., POOL = true> (step_stem_pool_forward): maxPool3d_2a -- (1,3,3) / (1,2,2), TF padding (0,1) -- taken on the
+    // tile while it is still on the chip; y is then the POOLED tensor [N, To, Hp, Wp, C] and the un-pooled stem output never exists
+    int Hp, Wp;
+    void* rowbuf;              // [N*To][tiles_h][Wo][C]: the first row of every tile (what the tile above still needs), raw stem values
+    void* colbuf;              // [N*To][tiles_w][Ho][C]: the first column of every tile
 #ifdef STEP_PROBE
     unsigned long long* probe;   // tools/timeline_probe.py build only (conv_common.h: probe_mark)
 #endif
@@ -188,7 +193,18 @@ __device__ __forceinline__ u16x8 lds_read_frag_a4(const unsigned char* p) {
 // VEC: W % 4 == 0 (whole 4-column quads, 8-byte loads).  A compile-time switch on purpose: with both staging paths inside one loop
 // the compiler's wait counts must hold for the element-wise path too (nothing in flight behind it), so every wait for a weight
 // tile became vmcnt(0) and drained the frame loads issued behind it.
-template <typename T, int NB_ = 2, bool VEC = true>
+// POOL: see StemParams::Hp.  A pooled pixel (ph, pw) is the max over stem rows 2ph .. 2ph+2 and columns 2pw .. 2pw+2; a 16x16 tile
+// holds everything for 7 of its 8 pooled rows / columns and two of the three rows / columns of the eighth.  The tile writes the max
+// over what it HAS to y and its own first row and first column (raw values) to rowbuf / colbuf; stem_pool_fix_kernel then completes
+// the pooled pixels on tile seams from those.  Values are post-ReLU (>= +0), so the zero padding of the reference's ConstantPad3d is
+// neutral, out-of-image pixels of partial tiles enter as 0, and 16-bit patterns order like signed integers (one v_pk_max_i16 per pair).
+constexpr int STS_TPITCH = 144;                     // bytes per pixel of the epilogue's LDS tile: 64 channels x 2 B + 16 B (16 lanes x 16 B at one channel offset spread over all banks)
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ u32x4 pk_max_nonneg16(const u32x4& a, const u32x4& b) {
+    return __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8_t, a), __builtin_bit_cast(s16x8_t, b)));
+}
+
+template <typename T, int NB_ = 2, bool VEC = true, bool POOL = false>
 __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel(StemParams p) {
     static_assert(sizeof(T) == 2, "16-bit storage types only");
     constexpr int FRAME = STS_FRAME, PITCH = STS_PITCH;
@@ -205,6 +221,7 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
     constexpr int NTILES = 21;                      // weight tiles: 3 per frame
     typedef u16x8 frag_t;
 
+    static_assert(!POOL || (NB == 2 && 256 * STS_TPITCH <= 3 * FRAME + 3 * BBUF), "the pooled epilogue's tile lives in the frame / weight rings");
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * FRAME + 3 * BBUF + NB * 32 * 2 * 4];
     unsigned char* const ldsA = lds;
     unsigned char* const ldsB = lds + 3 * FRAME;
@@ -490,7 +507,7 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
                     v[e] = acc[mb][i][4 * g + e] * sc[e] + sh[e];
                     if (p.relu) v[e] = fmaxf(v[e], 0.f);
                 }
-                if (!vec_epi) {                               // channel counts / offsets off the 16-byte grid: element stores
+                if (!vec_epi && !POOL) {                      // channel counts / offsets off the 16-byte grid: element stores
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int co = (nb0 + i) * 32 + 8 * g + 4 * khalf + e;
@@ -500,7 +517,18 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
                 d[g][0] = (unsigned)elem<T>::bits16(v[0]) | ((unsigned)elem<T>::bits16(v[1]) << 16);
                 d[g][1] = (unsigned)elem<T>::bits16(v[2]) | ((unsigned)elem<T>::bits16(v[3]) << 16);
             }
-            if (vec_epi) {
+            if constexpr (POOL) {
+                // the tile goes to LDS (the rings are free: the K loop ended in a barrier), pixel-major at a 144-byte pitch
+                const int tpix = (wave * 4 + mb + 2 * ((lane & 31) >> 4)) * 16 + (lane & 15);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    lane32_swap(d[2 * h][0], d[2 * h + 1][0]);
+                    lane32_swap(d[2 * h][1], d[2 * h + 1][1]);
+                    u32x4 o = {d[2 * h][0], d[2 * h][1], d[2 * h + 1][0], d[2 * h + 1][1]};
+                    if (!okp) o = u32x4{0u, 0u, 0u, 0u};
+                    *(u32x4*)(lds + tpix * STS_TPITCH + (i * 32 + 16 * h + 8 * khalf) * 2) = o;
+                }
+            } else if (vec_epi) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     lane32_swap(d[2 * h][0], d[2 * h + 1][0]);
@@ -514,12 +542,96 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
             }
         }
     }
+    if constexpr (POOL) {
+        __syncthreads();
+        const size_t plane = (size_t)n * p.To + od;
+        // 8 x 8 pooled pixels x 8 channel vectors = 512 items, two per thread; vector fastest (8 lanes = one pixel's 128 bytes)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int item = tid + 256 * k;
+            const int v = item & 7, q = (item >> 3) & 7, j = item >> 6;
+            const unsigned char* base = lds + ((2 * j) * 16 + 2 * q) * STS_TPITCH + v * 16;
+            u32x4 m = *(const u32x4*)base;
+#pragma unroll
+            for (int dr = 0; dr < 3; ++dr)
+#pragma unroll
+                for (int dc = 0; dc < 3; ++dc) {
+                    if (dr == 0 && dc == 0) continue;
+                    if (2 * j + dr < 16 && 2 * q + dc < 16) m = pk_max_nonneg16(m, *(const u32x4*)(base + (dr * 16 + dc) * STS_TPITCH));
+                }
+            const int ph = (oh0 >> 1) + j, pw = (ow0 >> 1) + q;
+            if (ph < p.Hp && pw < p.Wp)
+                *(u32x4*)(yg + ((plane * p.Hp + ph) * p.Wp + pw) * p.y_cstride + p.y_coff + v * 8) = m;
+        }
+        // the tile's first row -> rowbuf, first column -> colbuf (raw values; a tile in the first tile row / column has no reader)
+        {
+            const int v = tid & 7, e = (tid >> 3) & 15;
+            unsigned short* rb = (unsigned short*)p.rowbuf;
+            unsigned short* cb = (unsigned short*)p.colbuf;
+            if (tid < 128) {
+                if (th_i > 0 && ow0 + e < p.Wo)
+                    *(u32x4*)(rb + ((plane * p.tiles_h + th_i) * p.Wo + ow0 + e) * (size_t)p.Cout + v * 8) = *(const u32x4*)(lds + e * STS_TPITCH + v * 16);
+            } else {
+                if (tw_i > 0 && oh0 + e < p.Ho)
+                    *(u32x4*)(cb + ((plane * p.tiles_w + tw_i) * p.Ho + oh0 + e) * (size_t)p.Cout + v * 8) = *(const u32x4*)(lds + (e * 16) * STS_TPITCH + v * 16);
+            }
+        }
+    }
 #ifdef STEP_PROBE
     STEP_PROBE_MARK(p, 3);
     __builtin_amdgcn_s_waitcnt(0);                    // every store acknowledged
     probe_clock_end(p.probe);
     STEP_PROBE_MARK(p, 4);
 #endif
+}
+
+// Completes the pooled pixels on tile seams of stem_stream_kernel<.., POOL> (see there): one thread per (plane, seam pixel, 8-channel
+// vector).  Row seams: pooled row 8t - 1 lacks stem row 16t = the first row of tile row t (rowbuf); the pixels that are ALSO on a column
+// seam take the two colbuf rows they lack here too, so that exactly one thread updates any pooled pixel.  Column seams: pooled column
+// 8s - 1 lacks stem column 16s (colbuf), rows 2ph .. 2ph+2 -- all inside one tile row unless ph is a seam row (handled above).
+__global__ __launch_bounds__(256) void stem_pool_fix_kernel(StemParams p) {
+    const int nbr = p.tiles_h - 1, nbc = p.tiles_w - 1;
+    const long long per_plane = ((long long)nbr * p.Wp + (long long)nbc * p.Hp) * (p.Cout / 8);
+    const long long total = per_plane * p.N * p.To;
+    const int V = p.Cout / 8;
+    unsigned short* yg = (unsigned short*)p.y;
+    const unsigned short* rb = (const unsigned short*)p.rowbuf;
+    const unsigned short* cb = (const unsigned short*)p.colbuf;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)blockDim.x * gridDim.x) {
+        const long long plane = idx / per_plane;
+        long long it = idx % per_plane;
+        const int v = (int)(it % V);
+        it /= V;
+        int ph, pw;
+        bool row_item;
+        if (it < (long long)nbr * p.Wp) { row_item = true; ph = 8 * ((int)(it / p.Wp) + 1) - 1; pw = (int)(it % p.Wp); }
+        else { it -= (long long)nbr * p.Wp; row_item = false; pw = 8 * ((int)(it / p.Hp) + 1) - 1; ph = (int)(it % p.Hp); }
+        if (ph >= p.Hp || pw >= p.Wp) continue;
+        const bool ph_seam = ((ph + 1) & 7) == 0 && ((ph + 1) >> 3) <= nbr;
+        const bool pw_seam = ((pw + 1) & 7) == 0 && ((pw + 1) >> 3) <= nbc;
+        if (!row_item && ph_seam) continue;                       // a corner: the row pass owns it
+        unsigned short* yp = yg + ((plane * p.Hp + ph) * p.Wp + pw) * (size_t)p.y_cstride + p.y_coff + v * 8;
+        u32x4 m = *(const u32x4*)yp;
+        if (row_item) {
+            const int t = (ph + 1) >> 3;
+            for (int dc = 0; dc < 3; ++dc) {
+                const int c = 2 * pw + dc;
+                if (c < p.Wo) m = pk_max_nonneg16(m, *(const u32x4*)(rb + ((plane * p.tiles_h + t) * p.Wo + c) * (size_t)p.Cout + v * 8));
+            }
+            if (pw_seam) {
+                const int s = (pw + 1) >> 3;
+                for (int dr = 0; dr < 2; ++dr)
+                    m = pk_max_nonneg16(m, *(const u32x4*)(cb + ((plane * p.tiles_w + s) * p.Ho + 2 * ph + dr) * (size_t)p.Cout + v * 8));
+            }
+        } else {
+            const int s = (pw + 1) >> 3;
+            for (int dr = 0; dr < 3; ++dr) {
+                const int r = 2 * ph + dr;
+                if (r < p.Ho) m = pk_max_nonneg16(m, *(const u32x4*)(cb + ((plane * p.tiles_w + s) * p.Ho + r) * (size_t)p.Cout + v * 8));
+            }
+        }
+        *(u32x4*)yp = m;
+    }
 }
 
 // torch [Cout][3][7][7][7] fp32 -> [nb32][77 K-steps][lane][8] (+ one zero K-step at the very end) for stem_stream_kernel
@@ -653,6 +765,56 @@ int step_stem_forward(int dtype, const void* x, int N, int T, int H, int W, cons
     return STEP_E_DTYPE;
 }
 
+
+static bool stem_pool_supported(int dtype, int N, int T, int H, int W, int Cout) {
+    return (dtype == STEP_BF16 || dtype == STEP_F16) && N > 0 && T > 0 && H > 0 && W > 0 && (W % 4) == 0 && Cout == 64 && conv_impl_override() != 0;
+}
+
+size_t step_stem_pool_workspace_bytes(int dtype, int N, int T, int H, int W, int Cout) {
+    if (!stem_pool_supported(dtype, N, T, H, W, Cout)) return 0;
+    const int To = (T - 2) / 2 + 1, Ho = (H - 2) / 2 + 1, Wo = (W - 2) / 2 + 1;
+    const size_t planes = (size_t)N * To;
+    return planes * ((size_t)ceil_div(Ho, 16) * Wo + (size_t)ceil_div(Wo, 16) * Ho) * Cout * 2 + 32;
+}
+
+int step_stem_pool_forward(int dtype, const void* x, int N, int T, int H, int W, const void* w_packed, const float* scale, const float* shift,
+                           int Cout, void* y, int y_cstride, int y_coff, void* ws, size_t ws_bytes, step_stream_t stream) {
+    if (N < 0 || T <= 0 || H <= 0 || W <= 0 || Cout <= 0) return STEP_E_SHAPE;
+    if (y_coff < 0 || y_coff + Cout > y_cstride) return STEP_E_SHAPE;
+    if (N == 0) return STEP_OK;
+    if (!stem_pool_supported(dtype, N, T, H, W, Cout)) return STEP_E_UNSUPPORTED;
+    if (!x || !w_packed || !y || !ws) return STEP_E_NULL;
+    if (((uintptr_t)x % 16) || ((uintptr_t)w_packed % 16) || ((uintptr_t)y % 16) || ((uintptr_t)ws % 16) || (y_cstride % 8) || (y_coff % 8)) return STEP_E_ALIGN;
+    if (ws_bytes < step_stem_pool_workspace_bytes(dtype, N, T, H, W, Cout)) return STEP_E_SHAPE;
+    StemParams p;
+    p.x = x; p.scale = scale; p.shift = shift; p.y = y;
+    p.N = N; p.T = T; p.H = H; p.W = W; p.tile0 = 0; p.relu = 1;
+    p.To = (T + 5 - 7) / 2 + 1; p.Ho = (H + 5 - 7) / 2 + 1; p.Wo = (W + 5 - 7) / 2 + 1;
+    if (p.To <= 0 || p.Ho <= 0 || p.Wo <= 0) return STEP_E_SHAPE;
+    p.Cout = Cout; p.y_cstride = y_cstride; p.y_coff = y_coff;
+    p.nblk32 = ceil_div(Cout, 32);
+    p.tiles_h = ceil_div(p.Ho, 16); p.tiles_w = ceil_div(p.Wo, 16);
+    p.Hp = step_pool_out_size(p.Ho, 3, 2); p.Wp = step_pool_out_size(p.Wo, 3, 2);
+    p.rowbuf = ws;
+    p.colbuf = (unsigned char*)ws + (((size_t)N * p.To * p.tiles_h * p.Wo * Cout * 2 + 15) / 16) * 16;
+#ifdef STEP_PROBE
+    p.probe = g_probe_buf;
+#endif
+    const long long tiles = (long long)p.N * p.To * p.tiles_h * p.tiles_w;
+    dim3 grid((unsigned)tiles, 1);
+    if (dtype == STEP_BF16) {
+        p.w = (const bf16_t*)w_packed + stem_stream_offset(Cout);
+        STEP_LAUNCH((stem_stream_kernel<bf16_t, 2, true, true>), grid, dim3(256), stream, p);
+    } else {
+        p.w = (const f16_t*)w_packed + stem_stream_offset(Cout);
+        STEP_LAUNCH((stem_stream_kernel<f16_t, 2, true, true>), grid, dim3(256), stream, p);
+    }
+    if (p.tiles_h > 1 || p.tiles_w > 1) {
+        const long long items = ((long long)(p.tiles_h - 1) * p.Wp + (long long)(p.tiles_w - 1) * p.Hp) * (Cout / 8) * p.N * p.To;
+        STEP_LAUNCH(stem_pool_fix_kernel, dim3(flat_grid(items, 256)), dim3(256), stream, p);
+    }
+    return STEP_LAUNCH_CHECK();
+}
 
 int step_stem_kernel_name(int dtype, char* buf, int buflen) {
     if (!buf || buflen <= 0) return STEP_E_NULL;

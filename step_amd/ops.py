@@ -451,6 +451,34 @@ def stem_forward(x, w_packed, Cout, scale, shift, out=None, relu=True):
     return out
 
 
+def stem_pool_forward(x, w_packed, Cout, scale, shift):
+    """The stem and the (1,3,3) / (1,2,2) max pool behind it as one call (step_stem_pool_forward): x [N,T,3,H,W] -> the POOLED
+    channels-last tensor [N,To,Hp,Wp,Cout]; the un-pooled stem output never exists.  None when the library has no fused form for the
+    shape / dtype (the caller runs the two layers one after the other; bit-identical)."""
+    L = _lib.lib()
+    N, T, C, H, W = x.shape
+    if C != 3 or not x.is_contiguous() or x.dtype == torch.float32:
+        return None
+    wsb = L.step_stem_pool_workspace_bytes(_dt(x), N, T, H, W, Cout)
+    if not wsb:
+        return None
+    To, Ho, Wo = (T - 2) // 2 + 1, (H - 2) // 2 + 1, (W - 2) // 2 + 1
+    Hp, Wp = L.step_pool_out_size(Ho, 3, 2), L.step_pool_out_size(Wo, 3, 2)
+    out = torch.empty((N, To, Hp, Wp, Cout), dtype=x.dtype, device=x.device)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+
+    def describe():
+        pix = N * To * Ho * Wo
+        return ("void step::stem_stream_kernel<%s, 2, true, true>(step::StemParams)" % _TNAME[x.dtype], 2.0 * pix * Cout * 1029,
+                (x.numel() + out.numel() + Cout * 1029) * _ES[x.dtype])
+
+    def launch():
+        _capi.check(L.step_stem_pool_forward(_dt(x), _lib.dptr(x), N, T, H, W, _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift), Cout,
+                                             _lib.dptr(out), Cout, 0, _lib.dptr(ws), wsb, _lib.stream_ptr(x.device)), "step_stem_pool_forward")
+    _run(launch, describe)
+    return out
+
+
 def stem_wgrad(x, gy, Cout):
     """x [N,T,3,H,W] (the clip), gy fp32 channels-last [N,To,Ho,Wo,Cout] -> fp32 [Cout,3,7,7,7]"""
     L = _lib.lib()

@@ -1189,6 +1189,46 @@ def case_conv_wgrad16(bk, golden):
     assert bk.lib.step_conv_wgrad16(ctypes.byref(d), z.ptr, z.ptr, z.ptr, 0, bk.stream) == -4       # fp32 storage: unsupported
 
 
+def case_stem_pool_fused(bk, golden):
+    """step_stem_pool_forward (the stem with maxPool3d_2a taken on its tiles, models/i3dpt.py:186-196) is BIT-IDENTICAL to step_stem_forward
+    followed by step_maxpool3d_tf (1,3,3) / (1,2,2): maps of several tiles in both directions with partial last tiles (seams completed by
+    the second launch, corners by exactly one thread), odd sizes (ceil-mode windows that hang over the padded border), a single-tile map
+    (no seam launch), a channel-slice destination; unsupported shapes are refused so that the caller falls back."""
+    rs = np.random.RandomState(21)
+    Cout = 64
+    w = (rs.randn(Cout, 3, 7, 7, 7) / np.sqrt(1029)).astype(np.float32)
+    scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32)
+    shift = (0.2 * rs.randn(Cout)).astype(np.float32)
+    for (N, T, H, W), dt, ycs, yoff in (((1, 4, 72, 80), BF16, 64, 0), ((2, 2, 50, 52), F16, 64, 0), ((1, 2, 20, 24), BF16, 80, 8), ((1, 2, 34, 68), BF16, 64, 0)):
+        x = rs.uniform(-1, 1, (N, T, 3, H, W)).astype(np.float32)
+        To, Ho, Wo = (T - 2) // 2 + 1, (H - 2) // 2 + 1, (W - 2) // 2 + 1
+        Hp, Wp = bk.lib.step_pool_out_size(Ho, 3, 2), bk.lib.step_pool_out_size(Wo, 3, 2)
+        wp = bk.dev(np.zeros(bk.lib.step_stem_packed_elems(Cout), NP_DT[dt]))
+        wd = bk.dev(np.ascontiguousarray(w, np.float32))
+        assert bk.lib.step_stem_pack_weight(wd.ptr, Cout, dt, wp.ptr, bk.stream) == 0
+        xe, sc, sh = bk.dev(encode(x, dt)), bk.dev(scale), bk.dev(shift)
+        y = bk.dev(np.zeros((N, To, Ho, Wo, Cout), NP_DT[dt]))
+        assert bk.lib.step_stem_forward(dt, xe.ptr, N, T, H, W, wp.ptr, sc.ptr, sh.ptr, 1, Cout, y.ptr, Cout, 0, bk.stream) == 0
+        ref = bk.dev(np.zeros((N, To, Hp, Wp, Cout), NP_DT[dt]))
+        assert bk.lib.step_maxpool3d_tf(dt, y.ptr, N, To, Ho, Wo, Cout, Cout, 0, 1, 3, 3, 1, 2, 2, ref.ptr, Cout, 0, bk.stream) == 0
+        wsb = bk.lib.step_stem_pool_workspace_bytes(dt, N, T, H, W, Cout)
+        assert wsb > 0 and wsb % 16 == 0
+        ws = bk.dev(np.full(wsb // 2, 0x7f7f, np.uint16))                      # a huge positive pattern: a seam read from a slot no tile wrote would win the max
+        out = bk.dev(np.full((N, To, Hp, Wp, ycs), 0x3c00 if dt == F16 else 0x3f80, NP_DT[dt] if dt == F16 else np.uint16).view(NP_DT[dt]))
+        before = out.get().copy()
+        assert bk.lib.step_stem_pool_forward(dt, xe.ptr, N, T, H, W, wp.ptr, sc.ptr, sh.ptr, Cout, out.ptr, ycs, yoff, ws.ptr, wsb, bk.stream) == 0
+        got = out.get()
+        assert np.array_equal(got[..., yoff:yoff + Cout].view(np.uint16), ref.get().view(np.uint16)), (N, T, H, W)
+        if ycs > Cout:                                                          # the rest of the wider buffer is untouched
+            keep = np.ones(ycs, bool)
+            keep[yoff:yoff + Cout] = False
+            assert np.array_equal(got[..., keep].view(np.uint16), before[..., keep].view(np.uint16))
+        assert bk.lib.step_stem_pool_forward(dt, xe.ptr, N, T, H, W, wp.ptr, sc.ptr, sh.ptr, Cout, out.ptr, ycs, yoff, ws.ptr, wsb - 16, bk.stream) < 0
+    assert bk.lib.step_stem_pool_workspace_bytes(F32, 1, 4, 72, 80, 64) == 0 and bk.lib.step_stem_pool_workspace_bytes(BF16, 1, 4, 72, 82, 64) == 0 \
+        and bk.lib.step_stem_pool_workspace_bytes(BF16, 1, 4, 72, 80, 32) == 0
+    assert bk.lib.step_stem_pool_forward(F32, xe.ptr, 1, 4, 72, 80, wp.ptr, sc.ptr, sh.ptr, 64, out.ptr, 64, 0, ws.ptr, wsb, bk.stream) == -4
+
+
 def case_stem_wgrad(bk, golden):
     rs = np.random.RandomState(44)
     N, T, H, W, Cout = 1, 6, 21, 70, 40                     # Ho = 10 (two row chunks), Wo = 35 (edge, interior and edge steps); Cout not a multiple of 32

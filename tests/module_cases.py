@@ -1274,15 +1274,19 @@ def case_c2_full_size_properties(dev, golden):
         # conv3d_2b evaluated inside conv3d_2c's launch (backbone.FUSE_POINTWISE_INPUT, ops.conv_forward_pre) == the two units
         # launched one after the other, BIT-EXACT (same K order, same 16-bit rounding of the tensor between them)
         # ... and the 14x14 blocks' pool + fused 1x1x1 triple in one grid (backbone.POOL_WITH_POINTWISE, ops.pool_conv_forward) == two launches
+        # ... and maxPool3d_2a taken on the stem's tiles (backbone.FUSE_STEM_POOL, ops.stem_pool_forward: 7 x 7 tiles per frame, seams
+        # completed by the second launch) == the stem and the pool as two launches
         from step_amd import backbone as _bb
-        assert _bb.FUSE_POINTWISE_INPUT and _bb.POOL_WITH_POINTWISE
+        assert _bb.FUSE_POINTWISE_INPUT and _bb.POOL_WITH_POINTWISE and _bb.FUSE_STEM_POOL
         try:
             _bb.FUSE_POINTWISE_INPUT = False
             _bb.POOL_WITH_POINTWISE = False
+            _bb.FUSE_STEM_POOL = False
             y8u = net(xb)
         finally:
             _bb.FUSE_POINTWISE_INPUT = True
             _bb.POOL_WITH_POINTWISE = True
+            _bb.FUSE_STEM_POOL = True
         assert torch.equal(y8u, y8), float((y8u.float() - y8.float()).abs().max())
 
 
