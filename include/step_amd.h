@@ -470,6 +470,27 @@ STEP_API int step_adam_flat_amp(float* param, float* grad, float* exp_avg, float
                                 float* amp_state, float growth_factor, float backoff_factor, int growth_interval,
                                 step_stream_t stream);
 
+/* The tail of TwoBranchNet.forward (models/two_branch.py:246-342) behind its last two GEMMs, as ONE launch (and one for its backward):
+ * the class logits averaged over a tube's frames and their sigmoid, the box regressions (local_loc = columns 0..3 of the fused
+ * 12-column regressor, first_loc / last_loc = local_loc + columns 4..7 / 8..11 on the first / last chunk), and -- with targets -- the
+ * three losses: BCE-with-logits against the centre frame's labels x mask (:281-299) and the masked-mean smooth-L1 of the centre /
+ * first / last predictions against their encode_coef targets (:301-333, utils/tube_utils.py:127-157).  ~60 element-wise kernels per head
+ * and step in the reference's formulation (and as many in backward).
+ *   logits [N * Tl rows, >= NC], reg [N * Tl rows, >= 12] (NULL: cls_only) in `dtype`, row strides in elements
+ *   tubes [N, Tl, 5] fp32, targets [N, 3, 6 + NC] fp32 (rows: first, centre, last frame; [4] class mask, [5] box mask, [6:] labels) --
+ *   both NULL for inference (the three losses are then written as zeros)
+ *   prob [N, NC], local_loc [N, Tl, 4], first_loc / last_loc [N, T, 4], loss_cls [N, NC] ([1] without targets), loss_loc [1], loss_nbr [1]: fp32
+ * An all-zero mask yields exactly zero losses and gradients (the reference's `if mask.sum():` branches, taken on the device).
+ * backward: g_loss_* = the gradients of the three loss outputs (NULL = zero) -> g_logits [N * Tl, NC], g_reg [N * Tl, 12] dense, `dtype`.
+ * One 256-thread workgroup, fixed-order sums (bit-reproducible). */
+STEP_API int step_head_outputs(int dtype, const void* logits, int logits_stride, const void* reg, int reg_stride, int N, int Tl, int T,
+                               int NC, const float* tubes, const float* targets, float* prob, float* local_loc, float* first_loc,
+                               float* last_loc, float* loss_cls, float* loss_loc, float* loss_nbr, step_stream_t stream);
+STEP_API int step_head_outputs_backward(int dtype, const void* logits, int logits_stride, const void* reg, int reg_stride, int N, int Tl,
+                                        int T, int NC, const float* tubes, const float* targets, const float* g_loss_cls,
+                                        const float* g_loss_loc, const float* g_loss_nbr, void* g_logits, void* g_reg,
+                                        step_stream_t stream);
+
 /* Batch-statistics BatchNorm3d (+ ReLU) of a conv unit: the TRAINING-mode BatchNorm of --freeze_stats False (models/networks.py:85-99
  * leaves the layers in train mode; models/i3dpt.py:95-110, models/two_branch.py:160,372).  Eval-mode BN is folded into the conv
  * epilogues and never comes here.

@@ -89,6 +89,8 @@ SIGNATURES = {
     "step_bn_train_workspace_bytes": (sz, [ll, i]),
     "step_bn_train_forward": (i, [i, vp, i, ll, i, fp, fp, f, f, fp, fp, fp, fp, i, vp, i, vp, sz, vp]),
     "step_bn_train_backward": (i, [i, vp, i, vp, i, i, vp, i, ll, i, i, fp, fp, fp, vp, fp, fp, vp, sz, vp]),
+    "step_head_outputs": (i, [i, vp, i, vp, i, i, i, i, i, fp, fp, fp, fp, fp, fp, fp, fp, fp, vp]),
+    "step_head_outputs_backward": (i, [i, vp, i, vp, i, i, i, i, i, fp, fp, fp, fp, fp, vp, vp, vp]),
     "step_tube_update": (i, [fp, i, i, fp, fp, fp, i, i, i, ip, i, f, f, fp, fp, fp, fp, vp]),
     "step_select_prepare": (i, [fp, fp, fp, fp, i, i, i, i, ip, fp, ip, i, f, f, fp, fp, fp, fp, fp, vp]),
     "step_adam_flat": (i, [fp, fp, fp, fp, ll, vp, fp, fp, i, C.c_double, C.c_double, C.c_double, i, f, i, vp]),

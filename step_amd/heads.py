@@ -27,6 +27,28 @@ from .tube_math import encode_coef
 import os
 
 SYNC_FREE_LOSSES = True    # (module switch; False = the reference's `if mask.sum():` branches) see TwoBranchNet.forward (losses)
+FUSED_HEAD_OUTPUTS = True  # everything behind the head's last two GEMMs (frame mean, sigmoid, box sums, the three losses) as ONE launch, forward and backward (ops.head_outputs); False: the element-wise torch formulation below
+
+
+class _HeadOutputsFn(torch.autograd.Function):
+    """models/two_branch.py:246-342 behind the last two GEMMs as one launch (step_head_outputs), backward as one more
+    (step_head_outputs_backward): the reference's formulation is ~60 element-wise kernels per head and step, and as many in backward.
+    Gradients flow from the three losses to the logits and the regressor columns; the probabilities and boxes are outputs only."""
+
+    @staticmethod
+    def forward(ctx, logits, reg, tubes, targets, N, Tl, T, NC):
+        prob, ll, fl, la, lc, lo, ln, tubes32, targets32 = ops.head_outputs(logits.detach(), reg.detach(), N, Tl, T, NC, tubes, targets)
+        ctx.save_for_backward(logits, reg, tubes32, targets32)
+        ctx.dims = (N, Tl, T, NC)
+        ctx.mark_non_differentiable(prob, ll, fl, la)
+        return prob, ll, fl, la, lc, lo, ln
+
+    @staticmethod
+    def backward(ctx, gp, gll, gfl, gla, g_cls, g_loc, g_nbr):
+        logits, reg, tubes32, targets32 = ctx.saved_tensors
+        N, Tl, T, NC = ctx.dims
+        g_logits, g_reg = ops.head_outputs_backward(logits.detach(), reg.detach(), N, Tl, T, NC, tubes32, targets32, g_cls, g_loc, g_nbr)
+        return g_logits, g_reg, None, None, None, None, None, None
 
 
 class ROINet(nn.Module):
@@ -315,7 +337,8 @@ class TwoBranchNet(nn.Module):
             logits = self._u_cls_ctx(ctx, relu=False, res=self._u_cls_feat(flat, relu=False))
         else:
             logits = self._u_cls_feat(flat, relu=False)
-        global_class = logits.reshape(N, Tl, self.num_classes).float().mean(1)
+        fused_tail = FUSED_HEAD_OUTPUTS and SYNC_FREE_LOSSES and not self.cls_only
+        global_class = None if fused_tail else logits.reshape(N, Tl, self.num_classes).float().mean(1)
 
         # ---- local branch
         if self.cls_only:                                          # (two_branch.py:246: three one-element zeros)
@@ -329,6 +352,18 @@ class TwoBranchNet(nn.Module):
             if self.training and self.dropout_prob > 0:
                 lf = self.dropout(lf)
             reg = self._reg_unit()(lf.reshape(N * Tl, 1, 1, 1, self.fc_dim * P2), relu=False)
+            if fused_tail:
+                # frame mean + sigmoid + box sums + the three losses: one launch (and one in backward), heads._HeadOutputsFn
+                if targets is not None:
+                    tubes, targets = tubes.to(dev), targets.to(dev)
+                    need = torch.is_grad_enabled() and (logits.requires_grad or reg.requires_grad)
+                    if need:
+                        o = _HeadOutputsFn.apply(logits, reg, tubes, targets, N, Tl, self.T, self.num_classes)
+                    else:
+                        o = ops.head_outputs(logits, reg, N, Tl, self.T, self.num_classes, tubes, targets)[:7]
+                else:
+                    o = ops.head_outputs(logits, reg, N, Tl, self.T, self.num_classes)[:7]
+                return (o[0], o[1], o[2], o[3], o[4].reshape(-1), o[5].reshape(-1), o[6].reshape(-1))
             reg = reg.reshape(N, Tl, 12).float()
             local_loc = reg[..., 0:4].contiguous()
             lo, hi = chunk_idx[0] - half_T, chunk_idx[0] + half_T + 1

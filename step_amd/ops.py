@@ -798,6 +798,48 @@ def select_prepare(prob, loc, first, last, clip_of, gt_mid, gt_count, width, hei
     return mean_prob, vloc, vfirst, vlast, iou
 
 
+def head_outputs(logits, reg, N, Tl, T, NC, tubes=None, targets=None):
+    """step_head_outputs: logits [N*Tl, ..., NC], reg [N*Tl, ..., 12] | None (2-D views of the GEMM outputs, activation dtype) ->
+    (prob [N,NC], local_loc [N,Tl,4], first_loc, last_loc [N,T,4], loss_cls [N*NC | 1], loss_loc [1], loss_nbr [1]) fp32."""
+    L = _lib.lib()
+    dev = logits.device
+    lg = logits.reshape(N * Tl, -1)
+    rg = None if reg is None else reg.reshape(N * Tl, -1)
+    if lg.stride(1) != 1 or (rg is not None and rg.stride(1) != 1):
+        lg, rg = lg.contiguous(), (None if rg is None else rg.contiguous())
+    f32 = lambda t: None if t is None else t.detach().float().contiguous()
+    tubes, targets = f32(tubes), f32(targets)
+    train = targets is not None
+    prob = torch.empty((N, NC), dtype=torch.float32, device=dev)
+    ll = torch.empty((N, Tl, 4), dtype=torch.float32, device=dev) if rg is not None else None
+    fl = torch.empty((N, T, 4), dtype=torch.float32, device=dev) if rg is not None else None
+    la = torch.empty((N, T, 4), dtype=torch.float32, device=dev) if rg is not None else None
+    losses = torch.empty((N * NC if train else 1) + 2, dtype=torch.float32, device=dev)
+    ncls = N * NC if train else 1
+    _capi.check(L.step_head_outputs(_dt(lg), _lib.dptr(lg), lg.stride(0), _lib.dptr(rg), 0 if rg is None else rg.stride(0), N, Tl, T, NC,
+                                    _lib.dptr(tubes), _lib.dptr(targets), _lib.dptr(prob), _lib.dptr(ll), _lib.dptr(fl), _lib.dptr(la),
+                                    _lib.dptr(losses), _lib.dptr(losses[ncls:]), _lib.dptr(losses[ncls + 1:]), _lib.stream_ptr(dev)),
+                "step_head_outputs")
+    return prob, ll, fl, la, losses[:ncls], losses[ncls:ncls + 1], losses[ncls + 1:ncls + 2], tubes, targets
+
+
+def head_outputs_backward(logits, reg, N, Tl, T, NC, tubes, targets, g_cls, g_loc, g_nbr):
+    """step_head_outputs_backward -> (g_logits, g_reg) shaped like logits / reg, in their dtype."""
+    L = _lib.lib()
+    lg = logits.reshape(N * Tl, -1)
+    rg = None if reg is None else reg.reshape(N * Tl, -1)
+    if lg.stride(1) != 1 or (rg is not None and rg.stride(1) != 1):
+        lg, rg = lg.contiguous(), (None if rg is None else rg.contiguous())
+    f32 = lambda t: None if t is None else t.detach().float().contiguous()
+    g_logits = torch.empty((N * Tl, NC), dtype=logits.dtype, device=logits.device)
+    g_reg = torch.empty((N * Tl, 12), dtype=reg.dtype, device=reg.device) if rg is not None else None
+    g_cls, g_loc, g_nbr = f32(g_cls), f32(g_loc), f32(g_nbr)
+    _capi.check(L.step_head_outputs_backward(_dt(lg), _lib.dptr(lg), lg.stride(0), _lib.dptr(rg), 0 if rg is None else rg.stride(0), N, Tl, T, NC,
+                                             _lib.dptr(tubes), _lib.dptr(targets), _lib.dptr(g_cls), _lib.dptr(g_loc), _lib.dptr(g_nbr),
+                                             _lib.dptr(g_logits), _lib.dptr(g_reg), _lib.stream_ptr(logits.device)), "step_head_outputs_backward")
+    return g_logits.reshape(logits.shape), (None if g_reg is None else g_reg.reshape(reg.shape))
+
+
 def tube_update(flat, local_loc, first_loc, last_loc, clip_of, first_off, last_off, extend, width, height):
     """One refinement step's tube bookkeeping (step_tube_update): returns (pred_loc, pred_first, pred_last, next_flat)."""
     L = _lib.lib()

@@ -681,6 +681,96 @@ def case_adam_flat_amp(bk, golden):
                                      1.0, 0, None, 2.0, 0.5, interval, bk.stream) < 0
 
 
+def case_head_outputs(bk, golden):
+    """step_head_outputs / _backward (everything behind TwoBranchNet's last two GEMMs, models/two_branch.py:246-342, as one launch each)
+    against the element-wise torch formulation under autograd: frame-mean logits, sigmoid, local / first / last boxes, BCE-with-logits
+    x class mask, masked-mean smooth-L1 of the centre / first / last predictions against encode_coef targets; one chunk (Tl = 3: centre,
+    first and last frame coincide) and three (Tl = 9); partly and entirely zero masks (zero losses AND zero gradients, the reference's
+    `if mask.sum():`); large regression errors (the linear branch of smooth-L1); inference mode (no targets); 16-bit inputs."""
+    from step_amd.tube_math import encode_coef
+    rs = np.random.RandomState(17)
+    NC, T = 60, 3
+    for dt, N, Tl, zero_cls, zero_box in ((F32, 7, 3, False, False), (F32, 5, 9, False, False), (F32, 4, 9, True, False), (F32, 4, 3, False, True),
+                                          (BF16, 6, 9, False, False), (F16, 3, 3, False, False), (F32, 300, 3, False, False)):
+        chunks = Tl // T
+        cidx = [j * T + T // 2 for j in range(chunks)]
+        logits = quantize((rs.randn(N * Tl, NC) * 2).astype(np.float32), dt)
+        reg = quantize((rs.randn(N * Tl, 12) * rs.choice([0.2, 3.0], (N * Tl, 1))).astype(np.float32), dt)
+        xy = rs.uniform(0, 250, (N, Tl, 2))
+        tubes = np.concatenate([np.zeros((N, Tl, 1)), xy, xy + rs.uniform(20, 140, (N, Tl, 2))], 2).astype(np.float32)
+        targets = np.zeros((N, 3, 6 + NC), np.float32)
+        gxy = rs.uniform(0, 250, (N, 3, 2))
+        targets[:, :, :4] = np.concatenate([gxy, gxy + rs.uniform(20, 140, (N, 3, 2))], 2)
+        targets[:, :, 4] = (rs.rand(N, 3) < 0.7)
+        targets[:, :, 5] = (rs.rand(N, 3) < 0.7)
+        targets[:, :, 6:] = (rs.rand(N, 3, NC) < 0.1)
+        if zero_cls:
+            targets[:, :, 4] = 0
+        if zero_box:
+            targets[:, :, 5] = 0
+        # ---- the reference formulation (as heads.py's element-wise path, SYNC_FREE_LOSSES)
+        lt, rt = torch.from_numpy(logits).requires_grad_(True), torch.from_numpy(reg).requires_grad_(True)
+        tb, tg = torch.from_numpy(tubes), torch.from_numpy(targets)
+        gc = lt.reshape(N, Tl, NC).mean(1)
+        r3 = rt.reshape(N, Tl, 12)
+        ll = r3[..., 0:4]
+        lo, lo2 = cidx[0] - T // 2, cidx[-1] - T // 2
+        fl = ll[:, lo:lo + T] + r3[:, lo:lo + T, 4:8]
+        la = ll[:, lo2:lo2 + T] + r3[:, lo2:lo2 + T, 8:12]
+        ct, ft, ltg = tg[:, 1], tg[:, 0], tg[:, -1]
+        m = ct[:, 4].reshape(-1, 1)
+        pos = (m.sum() > 0).float()
+        l_cls = F.binary_cross_entropy_with_logits(gc, ct[:, 6:] * m, reduction="none") * pos
+
+        def mean_over(l, mk):
+            s_ = mk.sum()
+            return (l * mk).sum() / (s_ if float(s_) > 0 else 1.0)
+        l_loc = mean_over(F.smooth_l1_loss(ll[:, cidx[chunks // 2]], encode_coef(ct[:, :4], tb[:, cidx[chunks // 2], 1:]), reduction="none"),
+                          ct[:, 5].reshape(-1, 1).repeat(1, 4))
+        ntgt = encode_coef(torch.cat([ft[:, :4], ltg[:, :4]], 0), torch.cat([tb[:, cidx[0], 1:], tb[:, cidx[-1], 1:]], 0))
+        l_nbr = mean_over(F.smooth_l1_loss(torch.cat([fl[:, T // 2], la[:, T // 2]], 0), ntgt, reduction="none"),
+                          torch.cat([ft[:, 5].reshape(-1, 1).repeat(1, 4), ltg[:, 5].reshape(-1, 1).repeat(1, 4)], 0))
+        wc = torch.from_numpy(rs.randn(N, NC).astype(np.float32))
+        (l_cls * wc).sum().add(1.7 * l_loc).add(-0.6 * l_nbr).backward()
+        # ---- the kernels
+        L_, R_ = bk.dev(encode(logits, dt)), bk.dev(encode(reg, dt))
+        TB, TG = bk.dev(tubes), bk.dev(targets)
+        prob, oll, ofl, ola = bk.dev(np.zeros((N, NC), np.float32)), bk.dev(np.zeros((N, Tl, 4), np.float32)), bk.dev(np.zeros((N, T, 4), np.float32)), bk.dev(np.zeros((N, T, 4), np.float32))
+        lc, lo_, ln = bk.dev(np.zeros((N, NC), np.float32)), bk.dev(np.zeros(1, np.float32)), bk.dev(np.zeros(1, np.float32))
+        assert bk.lib.step_head_outputs(dt, L_.ptr, NC, R_.ptr, 12, N, Tl, T, NC, TB.ptr, TG.ptr, prob.ptr, oll.ptr, ofl.ptr, ola.ptr, lc.ptr, lo_.ptr, ln.ptr,
+                                        bk.stream) == 0
+        close = lambda a, b, t_=2e-6: np.abs(a - b).max() <= t_ * max(1.0, np.abs(b).max())
+        assert close(prob.get(), torch.sigmoid(gc).detach().numpy()) and close(oll.get(), ll.detach().numpy(), 0) and close(ofl.get(), fl.detach().numpy())
+        assert close(ola.get(), la.detach().numpy()) and close(lc.get(), l_cls.detach().numpy(), 5e-6)
+        assert abs(float(lo_.get()[0]) - float(l_loc.detach())) <= 5e-6 * max(1.0, abs(float(l_loc.detach()))) and abs(float(ln.get()[0]) - float(l_nbr.detach())) <= 5e-6 * max(1.0, abs(float(l_nbr.detach())))
+        if zero_cls:
+            assert not lc.get().any()
+        if zero_box:
+            assert float(lo_.get()[0]) == 0.0 and float(ln.get()[0]) == 0.0
+        GL, GR = bk.dev(np.full((N * Tl, NC), 7, NP_DT[dt])), bk.dev(np.full((N * Tl, 12), 7, NP_DT[dt]))
+        gcl, glo, gnb = bk.dev(wc.numpy()), bk.dev(np.array([1.7], np.float32)), bk.dev(np.array([-0.6], np.float32))
+        outs = []
+        for _ in range(2):
+            assert bk.lib.step_head_outputs_backward(dt, L_.ptr, NC, R_.ptr, 12, N, Tl, T, NC, TB.ptr, TG.ptr, gcl.ptr, glo.ptr, gnb.ptr, GL.ptr, GR.ptr,
+                                                     bk.stream) == 0
+            outs.append((GL.get().copy(), GR.get().copy()))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        gl_, gr_ = decode(outs[0][0], dt), decode(outs[0][1], dt)
+        t_ = 2e-6 if dt == F32 else tol(dt)
+        assert np.abs(gl_ - lt.grad.numpy()).max() <= t_ * max(1e-6, np.abs(lt.grad.numpy()).max()) + 1e-9, (dt, N, Tl)
+        assert np.abs(gr_ - rt.grad.numpy()).max() <= t_ * max(1e-6, np.abs(rt.grad.numpy()).max()) + 1e-9, (dt, N, Tl)
+        if zero_cls:
+            assert not gl_.any()
+        if zero_box:
+            assert not gr_.any()
+    # inference: no targets, no tubes -- probabilities and boxes, three zero losses
+    z3 = bk.dev(np.full(3, 5.0, np.float32))
+    assert bk.lib.step_head_outputs(dt, L_.ptr, NC, R_.ptr, 12, N, Tl, T, NC, None, None, prob.ptr, oll.ptr, ofl.ptr, ola.ptr, z3.ptr, z3.ptr + 4 if isinstance(z3.ptr, int) else ctypes.c_void_p(z3.ptr.value + 4),
+                                    z3.ptr + 8 if isinstance(z3.ptr, int) else ctypes.c_void_p(z3.ptr.value + 8), bk.stream) == 0
+    assert not z3.get().any() and close(prob.get(), torch.sigmoid(gc).detach().numpy())
+    assert bk.lib.step_head_outputs(dt, L_.ptr, NC, R_.ptr, 12, N, 4, T, NC, None, None, prob.ptr, oll.ptr, ofl.ptr, ola.ptr, z3.ptr, z3.ptr, z3.ptr, bk.stream) == -2   # Tl % T
+
+
 def case_bn_train(bk, golden):
     """step_bn_train_forward / _backward (batch-statistics BatchNorm + ReLU of --freeze_stats False, models/i3dpt.py:95-110) against
     torch's own F.batch_norm(training=True) + relu under autograd on the same (storage-rounded) input: output, saved statistics, the

@@ -1207,9 +1207,11 @@ def case_stem_backward_16bit(dev, golden):
 
 
 def case_loss_masks_without_host_branches(dev, golden):
-    """The heads' losses without the reference's `if mask.sum():` host branches (heads.SYNC_FREE_LOSSES, the default) equal the
-    branching form bit for bit when positives exist; a batch without positives gives exactly zero losses and zero gradients in
-    both forms (the reference's one-element zero classification loss becomes N*classes zeros: same mean)."""
+    """The heads' losses without the reference's `if mask.sum():` host branches (heads.SYNC_FREE_LOSSES, the default: the fused tail
+    heads._HeadOutputsFn -- one launch forward, one backward -- and, with FUSED_HEAD_OUTPUTS off, its element-wise torch form) against
+    the branching form: the element-wise free form equals it bit for bit when positives exist, the fused launch within 2e-6 (its sums
+    run in a different, fixed order); a batch without positives gives exactly zero losses and zero gradients in all three forms (the
+    reference's one-element zero classification loss becomes N*classes zeros: same mean)."""
     from step_amd import heads
     g = golden("head_golden")
     pf = R.fill_tensor("golden.det.pooled3", (2, 3, 832, 7, 7), "feat").to(dev)
@@ -1217,12 +1219,16 @@ def case_loss_masks_without_host_branches(dev, golden):
     tubes, targets = torch.from_numpy(g["loss_tubes"]).to(dev), torch.from_numpy(g["loss_targets"]).to(dev)
     empty = targets.clone()
     empty[:, :, 4:6] = 0
-    keep = heads.SYNC_FREE_LOSSES
+    keep, keepf = heads.SYNC_FREE_LOSSES, heads.FUSED_HEAD_OUTPUTS
     out = {}
     try:
-        for free in (True, False):
-            heads.SYNC_FREE_LOSSES = free
+        for free in (True, "torch", False):
+            heads.SYNC_FREE_LOSSES = bool(free)
+            heads.FUSED_HEAD_OUTPUTS = free is True
             for tag, tg in (("pos", targets), ("none", empty)):
+                if free == "torch" and tag == "none" and dev == "cpu":
+                    out[(free, tag)] = out[(True, tag)]                 # (interpreter time; the GPU run covers it)
+                    continue
                 net = fill(step_amd.TwoBranchNet(cfg()), "det0.").to(dev)
                 net.set_device(dev)
                 net.train()
@@ -1237,11 +1243,13 @@ def case_loss_masks_without_host_branches(dev, golden):
                     gsum = sum(float(p.grad.abs().sum()) for p in net.parameters() if p.grad is not None)
                 out[(free, tag)] = ([np_(o[i]) for i in (4, 5, 6)], gsum)
     finally:
-        heads.SYNC_FREE_LOSSES = keep
+        heads.SYNC_FREE_LOSSES, heads.FUSED_HEAD_OUTPUTS = keep, keepf
     for i in range(3):
-        assert np.array_equal(out[(True, "pos")][0][i], out[(False, "pos")][0][i]), i
-    assert out[(True, "pos")][1] > 0 and abs(out[(True, "pos")][1] - out[(False, "pos")][1]) <= 1e-5 * out[(False, "pos")][1]
-    for free in (True, False):
+        assert np.array_equal(out[("torch", "pos")][0][i], out[(False, "pos")][0][i]), i
+        assert np.abs(out[(True, "pos")][0][i] - out[(False, "pos")][0][i]).max() <= 2e-6 * max(1.0, np.abs(out[(False, "pos")][0][i]).max()), i
+    for free in (True, "torch"):
+        assert out[(free, "pos")][1] > 0 and abs(out[(free, "pos")][1] - out[(False, "pos")][1]) <= 1e-5 * out[(False, "pos")][1]
+    for free in (True, "torch", False):
         ls, gsum = out[(free, "none")]
         assert all(float(np.abs(l).max()) == 0.0 for l in ls) and gsum == 0.0, (free, gsum)
     assert out[(False, "none")][0][0].size == 1 and out[(True, "none")][0][0].size == out[(True, "pos")][0][0].size
