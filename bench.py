@@ -215,10 +215,36 @@ class ClockSampler:
         if cards:
             c = cards[min(index, len(cards) - 1)]
             self.paths = glob.glob(os.path.join(c, "hwmon/hwmon*/freq1_input")) + [os.path.join(c, "pp_dpm_sclk")]
-        self.samples, self._stop, self._th = [], False, None
+        self.samples, self.smi_samples, self._stop, self._th = [], [], False, None
+
+    def _smi(self):
+        """`amd-smi metric --clock --json` (one call takes ~1 s): mean of the gfx engine clocks it lists, in GHz"""
+        import re
+        import subprocess
+        try:
+            txt = subprocess.run(["amd-smi", "metric", "--clock", "--json"], capture_output=True, text=True, timeout=10).stdout
+            j = json.loads(txt)
+            vals = []
+
+            def walk(o, under_gfx=False):
+                if isinstance(o, dict):
+                    for k_, v_ in o.items():
+                        g_ = under_gfx or k_.lower().startswith("gfx")
+                        if g_ and k_ in ("clk", "cur_clk") and isinstance(v_, dict) and isinstance(v_.get("value"), (int, float)):
+                            vals.append(float(v_["value"]))
+                        else:
+                            walk(v_, g_)
+                elif isinstance(o, list):
+                    for v_ in o:
+                        walk(v_, under_gfx)
+            walk(j[0] if isinstance(j, list) and j else j)
+            vals = [v_ for v_ in vals if v_ > 0]
+            return sum(vals) / len(vals) / 1e3 if vals else None
+        except Exception:
+            return None
 
     def _read(self):
-        for p_ in self.paths:
+        for p_ in sorted(self.paths, key=lambda q: not q.endswith("pp_dpm_sclk")):     # the DPM table's starred line first
             try:
                 txt = open(p_).read()
             except OSError:
@@ -244,9 +270,18 @@ class ClockSampler:
                 if v:
                     self.samples.append(v)
                 time.sleep(0.02)
+        def smi_loop():
+            while not self._stop:
+                v = self._smi()
+                if v:
+                    self.smi_samples.append(v)
+                else:
+                    break
         if self.paths:
             self._th = threading.Thread(target=loop, daemon=True)
             self._th.start()
+        self._th2 = threading.Thread(target=smi_loop, daemon=True)
+        self._th2.start()
         return self
 
     def __exit__(self, *exc):
@@ -257,6 +292,10 @@ class ClockSampler:
 
     def median(self):
         s_ = sorted(self.samples)
+        return round(s_[len(s_) // 2], 3) if s_ else None
+
+    def smi_median(self):
+        s_ = sorted(self.smi_samples)
         return round(s_[len(s_) // 2], 3) if s_ else None
 
 
@@ -569,7 +608,7 @@ def main():
             a.steps, a.warmup = max(a.steps, int(a.sustained_seconds * 1.1 / (el / keep_steps)) + 1), 0
             with ClockSampler(local_dev) as cs:
                 el_s = timed(nfl)
-            sus = (a.steps, el_s, cs.median(), len(cs.samples))
+            sus = (a.steps, el_s, cs.median(), len(cs.samples), cs.smi_median(), len(cs.smi_samples))
             a.steps, a.warmup = keep_steps, keep_warm
     if dist is not None:
         t = torch.tensor([el, el_one, sus[1] if sus else 0.0], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
@@ -597,10 +636,11 @@ def main():
                          "devices_visible": ndev}}
         if sus:
             out["sustained"] = {"seconds": round(sus[1], 3), "steps": sus[0], "value": round(world * CLIPS_PER_GPU * sus[0] / sus[1], 2),
-                                "ms_per_step": round(sus[1] / sus[0] * 1e3, 4), "clock_ghz": sus[2], "clock_samples": sus[3],
+                                "ms_per_step": round(sus[1] / sus[0] * 1e3, 4), "clock_ghz": sus[4] if sus[4] else sus[2], "clock_samples": sus[5] if sus[4] else sus[3],
+                                "clock_ghz_sysfs": sus[2], "clock_ghz_amd_smi": sus[4],
                                 "note": "the same loop (same captured steps, same batches in flight) run for >= %.1f s right after the timed K steps; "
-                                        "clock_ghz = median shader clock from the amdgpu sysfs node sampled every 20 ms during it (null: not exposed "
-                                        "on this box); `value` / `ms_per_step` above stay on the contract's K steps" % a.sustained_seconds}
+                                        "clock_ghz = median gfx clock during it from `amd-smi metric --clock` (polled back to back) or, failing that, the amdgpu "
+                                        "sysfs node (pp_dpm_sclk / hwmon freq1_input, every 20 ms); null: neither is exposed on this box; `value` / `ms_per_step` above stay on the contract's K steps" % a.sustained_seconds}
         per_gpu = val / world
         out["backbone_roofline"] = {
             "hbm_frac": round(per_gpu * (ACT_MB_PER_CLIP + W_MB / CLIPS_PER_GPU) * 1e6 / (PEAK_HBM_GBS * 1e9), 4),

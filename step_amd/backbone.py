@@ -625,6 +625,104 @@ class _FusedPointwise:
         return None
 
 
+def _unit_wgrad(unit, w_eff, x, g, k):
+    """Weight gradient of one conv unit from its input x and the gradient g of its conv output (both channels-last, g possibly a channel
+    slice): inside wgrad_into_grad() accumulated straight into the parameter's .grad on the side stream (returns None), else returned."""
+    w16 = WGRAD16 and x.dtype != torch.float32 and g.dtype == x.dtype
+    fn = ops.conv_wgrad16 if w16 else ops.conv_wgrad
+    cout = w_eff.shape[0]
+    target = _wgrad_target(unit, w_eff) if (WGRAD_INTO_GRAD and x.is_cuda and ops.PROFILE is None) else None
+    if target is None:
+        return fn(x, g, cout, k).to(w_eff.dtype)
+    main = torch.cuda.current_stream(x.device)
+    side = _side_streams(x.device)[0]
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        fn(x, g, cout, k, into=target)
+    x.record_stream(side)
+    g.record_stream(side)
+    _PENDING[0] = True
+    if GRAD_READY is not None:                                   # this parameter bypasses autograd's accumulate hook
+        GRAD_READY(unit.weight_fn(), side)
+    return None
+
+
+class _MixedTrainFn(torch.autograd.Function):
+    """One autograd node for a whole Inception block in training (eval-mode BN with a frozen affine: every shipped configuration).
+    Forward: the block's six units write channel slices of one output buffer and one bottleneck buffer (no torch.cat), the two 3x3x3
+    convs and branch_3's 1x1x1 conv as one grouped launch -- 5 launches.  Backward, hand-scheduled instead of six per-unit nodes plus
+    autograd's concat / accumulate glue:
+        1 pass   ReLU mask x BN scale over the whole concat gradient (one act_grad instead of four)
+        1 launch the two 3x3x3 data gradients (grouped), into one bottleneck-gradient buffer
+        1 pass   ReLU mask x scale over that buffer (instead of two)
+        the pooled branch: 1x1x1 data gradient, max-pool backward (2 launches)
+        the block-input gradient: branch_0's, branch_1.0's and branch_2.0's 1x1x1 data gradients ACCUMULATE into the pool's result
+        through the conv's residual input -- no torch add, no clear
+        6 weight gradients, reading their activation-gradient slices in place
+    The same kernels and the same operands as the per-unit nodes (the sums into the block-input gradient run in a fixed order:
+    pool, branch_0, branch_1.0, branch_2.0)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, w1a, w1b, w2a, w2b, w3, block):
+        xd = x.detach()
+        out, t, p = block._forward_sliced(xd)
+        ctx.block = block
+        ctx.save_for_backward(x, t, p, out, w0, w1a, w1b, w2a, w2b, w3)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, t, p, out, w0, w1a, w1b, w2a, w2b, w3 = ctx.saved_tensors
+        m = ctx.block
+        oc = m.oc
+        c0, c1, c2 = oc[0], oc[0] + oc[2], oc[0] + oc[2] + oc[4]
+        u0, u1a, u1b, u2a, u2b, u3 = m._train_units()
+        need_x = ctx.needs_input_grad[0]
+        need_w = ctx.needs_input_grad[1:7]
+        # 1. the whole concat gradient through the four final ReLUs / BN scales in one pass
+        r = ops.act_grad(out, gy, m._train_scales(out.device)[0], True, want_f32=False, want_act=True)
+        if r is None:                                            # (a gradient that is not channels-last, e.g. through BaseNet's output permute)
+            r = ops.act_grad(out, gy.contiguous(), m._train_scales(out.device)[0], True, want_f32=False, want_act=True)
+        gact = r[1]
+        g0, g1, g2, g3 = gact[..., :c0], gact[..., c0:c1], gact[..., c1:c2], gact[..., c2:]
+        gws = [None] * 6
+        if need_w[0]:
+            gws[0] = _unit_wgrad(u0, w0, x, g0, (1, 1, 1))
+        if need_w[2]:
+            gws[2] = _unit_wgrad(u1b, w1b, t[..., :oc[1]], g1, (3, 3, 3))
+        if need_w[4]:
+            gws[4] = _unit_wgrad(u2b, w2b, t[..., oc[1]:], g2, (3, 3, 3))
+        if need_w[5]:
+            gws[5] = _unit_wgrad(u3, w3, p, g3, (1, 1, 1))
+        # 2. the two 3x3x3 data gradients into one bottleneck-gradient buffer (one grouped launch where the library merges them)
+        gt = torch.empty(t.shape, dtype=t.dtype, device=t.device)
+        dt_ = out.dtype
+        ops.conv_forward_group([
+            (g1, u1b.packed_dgrad(w1b, dt_, oc[2]), oc[1], (3, 3, 3), None, None, False, gt[..., :oc[1]]),
+            (g2, u2b.packed_dgrad(w2b, dt_, oc[4]), oc[3], (3, 3, 3), None, None, False, gt[..., oc[1]:])])
+        # 3. through the two bottleneck ReLUs / BN scales in one pass
+        _, gta = ops.act_grad(t, gt, m._train_scales(out.device)[1], True, want_f32=False, want_act=True)
+        if need_w[1]:
+            gws[1] = _unit_wgrad(u1a, w1a, x, gta[..., :oc[1]], (1, 1, 1))
+        if need_w[3]:
+            gws[3] = _unit_wgrad(u2a, w2a, x, gta[..., oc[1]:], (1, 1, 1))
+        gx = None
+        if need_x:
+            cin = x.shape[-1]
+            # 4. the pooled branch, then the three pointwise data gradients accumulate into its result (the conv's residual input)
+            gp = ops.conv_forward(g3, u3.packed_dgrad(w3, dt_, oc[5]), cin, (1, 1, 1), None, None, False, None, None)
+            gx = ops.maxpool_tf_backward(x, gp, (3, 3, 3), (1, 1, 1))
+            if gx.dtype != x.dtype:
+                gx = gx.to(x.dtype)
+            ops.conv_forward(g0, u0.packed_dgrad(w0, dt_, oc[0]), cin, (1, 1, 1), None, None, False, gx, gx)
+            ops.conv_forward(gta[..., :oc[1]], u1a.packed_dgrad(w1a, dt_, oc[1]), cin, (1, 1, 1), None, None, False, gx, gx)
+            ops.conv_forward(gta[..., oc[1]:], u2a.packed_dgrad(w2a, dt_, oc[3]), cin, (1, 1, 1), None, None, False, gx, gx)
+        return (gx,) + tuple(gws) + (None,)
+
+
+MIXED_TRAIN_FN = True     # training: an Inception block is ONE autograd node with a hand-scheduled backward (_MixedTrainFn); False: six per-unit nodes + torch.cat
+
+
 class Mixed(nn.Module):
     """Inception block; the four branches write channel slices of one buffer (order b0,b1,b2,b3)."""
     _replicate_for_data_parallel = _replicate_with_units
@@ -639,11 +737,71 @@ class Mixed(nn.Module):
         self.out_channels = oc[0] + oc[2] + oc[4] + oc[5]
         self._fused = _FusedPointwise(self)
 
+    def _train_units(self):
+        return (self.branch_0._unit, self.branch_1[0]._unit, self.branch_1[1]._unit, self.branch_2[0]._unit, self.branch_2[1]._unit,
+                self.branch_3[1]._unit)
+
+    def _train_scales(self, device):
+        """(folded BN scales of [b0 | b1b | b2b | b3], of [b1a | b2a]) concatenated in buffer order, cached on the BN tensors' versions"""
+        u0, u1a, u1b, u2a, u2b, u3 = self._train_units()
+        ver = tuple(v for u in (u0, u1a, u1b, u2a, u2b, u3) for v in _ver(u.bn.weight, u.bn.running_var)) + (device,)
+        hit = self.__dict__.get("_scales_cache")
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                so = torch.cat([u.affine()[0] for u in (u0, u1b, u2b, u3)]).contiguous()
+                st = torch.cat([u.affine()[0] for u in (u1a, u2a)]).contiguous()
+            hit = (ver, so, st)
+            self.__dict__["_scales_cache"] = hit
+        return hit[1], hit[2]
+
+    def _forward_sliced(self, x):
+        """The six units writing channel slices of one output buffer and one bottleneck buffer, every unit with its OWN packed weight
+        (the batched re-pack after an optimizer step covers them): b0, b1a, b2a, the pool, then [b1b, b2b, b3] as one grouped launch.
+        Returns (out, bottleneck buffer, pooled input)."""
+        oc = self.oc
+        N, D, H, W, _ = x.shape
+        c0, c1, c2 = oc[0], oc[0] + oc[2], oc[0] + oc[2] + oc[4]
+        out = torch.empty((N, D, H, W, self.out_channels), dtype=x.dtype, device=x.device)
+        t = torch.empty((N, D, H, W, oc[1] + oc[3]), dtype=x.dtype, device=x.device)
+        u0, u1a, u1b, u2a, u2b, u3 = self._train_units()
+        u0._launch(x, True, None, out[..., :c0])
+        u1a._launch(x, True, None, t[..., :oc[1]])
+        u2a._launch(x, True, None, t[..., oc[1]:])
+        p = ops.maxpool_tf(x, (3, 3, 3), (1, 1, 1))
+        m = []
+        for u, xin, o in ((u1b, t[..., :oc[1]], out[..., c0:c1]), (u2b, t[..., oc[1]:], out[..., c1:c2]), (u3, p, out[..., c2:])):
+            scale, shift = u.affine()
+            m.append((xin, u.packed(x.dtype), u.cout, u.k, scale, None if shift is None else shift.detach().contiguous(), True, o))
+        ops.conv_forward_group(m)
+        return out, t, p
+
+    def _train_fn_ok(self, x):
+        """_MixedTrainFn's contract: eval-mode BN with a frozen affine on all six units, plain fp32 parameters, channel counts on the
+        kernels' 16-byte grid, not a DataParallel replica."""
+        if not MIXED_TRAIN_FN or x.dim() != 5:
+            return False
+        vec = 16 // x.element_size()
+        for u in self._train_units():
+            bn = u.bn
+            if bn is None or bn.training or bn.weight.requires_grad or bn.bias.requires_grad or u._src is not None:
+                return False
+            w = u.weight_fn()
+            if w.dtype != torch.float32 or not w.is_contiguous() or w.shape[0] % vec or w.shape[1] % vec:
+                return False
+        return True
+
     def forward(self, x, out=None):
         oc = self.oc
         N, D, H, W, _ = x.shape
         grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
         bn_train = any(u._unit.bn_training for u in (self.branch_0, self.branch_1[0], self.branch_1[1], self.branch_2[0], self.branch_2[1], self.branch_3[1]))
+        if grad and not bn_train and self._train_fn_ok(x):
+            u0, u1a, u1b, u2a, u2b, u3 = self._train_units()
+            y = _MixedTrainFn.apply(x, u0.weight_fn(), u1a.weight_fn(), u1b.weight_fn(), u2a.weight_fn(), u2b.weight_fn(), u3.weight_fn(), self)
+            if out is not None:
+                out.copy_(y)
+                return out
+            return y
         if grad or bn_train:
             # autograd path: branches return fresh tensors, concatenated by torch (bookkeeping only)
             y = torch.cat([self.branch_0(x), self.branch_1[1](self.branch_1[0](x)), self.branch_2[1](self.branch_2[0](x)),

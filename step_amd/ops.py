@@ -283,6 +283,18 @@ def conv_forward_group(members):
          lambda: (buf.value.decode(), flops, nbytes))
 
 
+def _grad_slice(gy, vec):
+    """Channel stride of a gradient that is a channel slice of a dense channels-last buffer the weight-gradient kernels can read in place
+    (stride and start on the kernels' vector grid), else None (the caller densifies)."""
+    try:
+        cs = _chan_slice(gy)
+    except RuntimeError:
+        return None
+    if cs % vec or gy.data_ptr() % 16:
+        return None
+    return cs
+
+
 def conv_wgrad(x, gy, Cout, k, into=None):
     """Weight gradient of the stride-1 SAME conv: x channels-last [N,D,H,W,Cin] (any storage dtype, may be a channel
     slice), gy fp32 channels-last [N,D,H,W,Cout] (gradient w.r.t. the conv output before the affine epilogue).
@@ -292,8 +304,9 @@ def conv_wgrad(x, gy, Cout, k, into=None):
     N, D, H, W, Cin = x.shape
     if gy.dtype != torch.float32:
         gy = gy.float()
-    if not gy.is_contiguous():
-        gy = gy.contiguous()
+    gcs = _grad_slice(gy, 4)
+    if gcs is None:
+        gy, gcs = gy.contiguous(), Cout
     if into is not None:
         if into.dtype != torch.float32 or not into.is_contiguous() or into.numel() != Cout * Cin * k[0] * k[1] * k[2]:
             raise RuntimeError("step_amd: conv_wgrad(into=...) wants a dense fp32 tensor of Cout*Cin*taps elements")
@@ -301,7 +314,7 @@ def conv_wgrad(x, gy, Cout, k, into=None):
     else:
         dw = torch.empty((Cout, Cin) + tuple(k), dtype=torch.float32, device=x.device)
     d = _capi.ConvDesc(dtype=_dt(x), N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2],
-                       x_cstride=_chan_slice(x), x_coff=0, y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=0,
+                       x_cstride=_chan_slice(x), x_coff=0, y_cstride=gcs, y_coff=0, res_cstride=0, res_coff=0, relu=0,
                        split=0, y2_cstride=0, y2_coff=0)
     prof = _NOPROF
     if PROFILE is not None:
@@ -325,8 +338,9 @@ def conv_wgrad16(x, gy, Cout, k, into=None):
     N, D, H, W, Cin = x.shape
     if gy.dtype != x.dtype or x.dtype == torch.float32:
         raise RuntimeError("step_amd: conv_wgrad16 wants x and gy in the same 16-bit dtype")
-    if not gy.is_contiguous():
-        gy = gy.contiguous()
+    gcs = _grad_slice(gy, 8)
+    if gcs is None:
+        gy, gcs = gy.contiguous(), Cout
     if into is not None:
         if into.dtype != torch.float32 or not into.is_contiguous() or into.numel() != Cout * Cin * k[0] * k[1] * k[2]:
             raise RuntimeError("step_amd: conv_wgrad16(into=...) wants a dense fp32 tensor of Cout*Cin*taps elements")
@@ -334,7 +348,7 @@ def conv_wgrad16(x, gy, Cout, k, into=None):
     else:
         dw = torch.empty((Cout, Cin) + tuple(k), dtype=torch.float32, device=x.device)
     d = _capi.ConvDesc(dtype=_dt(x), N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2],
-                       x_cstride=_chan_slice(x), x_coff=0, y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=0,
+                       x_cstride=_chan_slice(x), x_coff=0, y_cstride=gcs, y_coff=0, res_cstride=0, res_coff=0, relu=0,
                        split=0, y2_cstride=0, y2_coff=0)
     prof = _NOPROF
     if PROFILE is not None:
