@@ -352,6 +352,22 @@ STEP_API int step_stem_pack_weight(const float* w /*[Cout,3,7,7,7]*/, int Cout, 
 STEP_API int step_stem_forward(int dtype, const void* x, int N, int T, int H, int W, const void* w_packed,
                                const float* scale, const float* shift, int relu, int Cout, void* y, int y_cstride,
                                int y_coff, step_stream_t stream);
+/* Weight gradients whose fixed-order sum is DEFERRED: step_conv_wgrad_partial launches only the kernel that writes the partial tiles
+ * into `ws` (as step_conv_wgrad_ws / step_conv_wgrad16_ws with dy16 = 0 / 1 would) and fills *item -- a host-side descriptor of the sum
+ * that is still to run; step_wgrad_reduce_group then runs up to STEP_WGRAD_REDUCE_MAX such sums as ONE launch (an Inception block's six
+ * weight gradients: one reduce launch instead of six).  item->kind == 0: nothing is pending (the form accumulated into dw itself).
+ * ws must stay alive and untouched until the group launch has run.  Same arithmetic and summation order as the _ws entry points
+ * (bit-identical results). */
+#define STEP_WGRAD_REDUCE_MAX 8
+typedef struct step_wgrad_reduce_item {
+    const float* ws; float* dw;
+    long long jobs;
+    int kind, gy, nbw, cot, cit, Cout, Cin, taps, accumulate, pw;
+} step_wgrad_reduce_item;
+STEP_API int step_conv_wgrad_partial(const step_conv_desc* d, const void* x, const void* dy, int dy16, float* dw, int accumulate, void* ws,
+                                     size_t ws_bytes, step_wgrad_reduce_item* item, step_stream_t stream);
+STEP_API int step_wgrad_reduce_group(const step_wgrad_reduce_item* items, int n, step_stream_t stream);
+
 /* The stem AND maxPool3d_2a_3x3 behind it (models/i3dpt.py:186-196: Unit3Dpy 7x7x7 / 2, then MaxPool3dTFPadding (1,3,3) / (1,2,2)) as one
  * call: every 16x16 stem tile is max-pooled while it is still on the chip, y is the POOLED tensor [N, To, Hp, Wp, Cout] (Hp / Wp =
  * step_pool_out_size(Ho / Wo, 3, 2)) and the un-pooled stem output -- the largest tensor of the backbone -- never reaches memory.

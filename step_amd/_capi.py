@@ -30,6 +30,14 @@ class ConvItem(C.Structure):
                 ("res", C.c_void_p), ("y", C.c_void_p)]
 
 
+class WgradReduceItem(C.Structure):
+    """struct step_wgrad_reduce_item (include/step_amd.h)"""
+    _fields_ = [("ws", C.c_void_p), ("dw", C.c_void_p), ("jobs", C.c_longlong)] + [(n, C.c_int) for n in (
+        "kind", "gy", "nbw", "cot", "cit", "Cout", "Cin", "taps", "accumulate", "pw")]
+
+
+WGRAD_REDUCE_MAX = 8
+
 SIGNATURES = {
     "step_version": (C.c_char_p, []),
     "step_abi_version": (i, []),
@@ -64,6 +72,8 @@ SIGNATURES = {
     "step_conv_wgrad16": (i, [C.POINTER(ConvDesc), vp, vp, fp, i, vp]),
     "step_conv_wgrad16_workspace_bytes": (sz, [C.POINTER(ConvDesc)]),
     "step_conv_wgrad16_ws": (i, [C.POINTER(ConvDesc), vp, vp, fp, i, vp, sz, vp]),
+    "step_conv_wgrad_partial": (i, [C.POINTER(ConvDesc), vp, vp, i, fp, i, vp, sz, C.POINTER(WgradReduceItem), vp]),
+    "step_wgrad_reduce_group": (i, [C.POINTER(WgradReduceItem), i, vp]),
     "step_conv_forward_ws": (i, [C.POINTER(ConvDesc), vp, vp, fp, fp, vp, vp, vp, vp, sz, vp]),
     "step_conv_kernel_name": (i, [C.POINTER(ConvDesc), C.c_char_p, i]),
     "step_conv_plan_info": (i, [C.POINTER(ConvDesc), C.POINTER(C.c_int), i]),

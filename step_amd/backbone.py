@@ -98,16 +98,13 @@ class _ConvUnitFn(torch.autograd.Function):
                 target = _wgrad_target(ctx.unit, w_eff) if (need_w and WGRAD_INTO_GRAD and x.is_cuda and ops.PROFILE is None) else None
                 if target is not None:
                     # opt-in (wgrad_into_grad()): the weight gradient is ACCUMULATED straight into the parameter's .grad (the
-                    # FlatAdam arena) by the kernel's own atomics, on a side stream that nobody waits for until
-                    # wgrad_sync() -- no clear, no autograd add, and the latency-bound weight-gradient launches overlap the
-                    # rest of the backward pass instead of sitting in its critical path
-                    main = torch.cuda.current_stream(x.device)
-                    side = _side_streams(x.device)[0]
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side):
-                        wgrad(x, g32, w_eff.shape[0], k, into=target)
-                    x.record_stream(side)
-                    g32.record_stream(side)
+                    # FlatAdam arena) on a side stream that nobody waits for until wgrad_sync() -- no clear, no autograd add, and the
+                    # latency-bound weight-gradient launches overlap the rest of the backward pass instead of sitting in its
+                    # critical path.  The fixed-order sums of the partial tiles queue up and run eight layers per launch
+                    # (_PEND_Q; the parameters are announced to the gradient exchange when their sum has been launched).
+                    _unit_wgrad(ctx.unit, w_eff, x, g32, k, _PEND_Q)
+                    if len(_PEND_Q) >= 8:
+                        _flush_wgrads(_PEND_Q, x.device)
                     if need_res and g32 is gact:
                         # the side stream is still READING this buffer while it is handed to autograd as the residual's
                         # gradient: with a use count of one autograd would accumulate the other branch's gradient into it
@@ -115,9 +112,6 @@ class _ConvUnitFn(torch.autograd.Function):
                         # conv3 weight gradients by ~1 % (found by tests/test_gpu_ddp.py).  A second reference makes autograd
                         # add out of place; the list is dropped in wgrad_sync().
                         _KEEP.append(gact)
-                    _PENDING[0] = True
-                    if GRAD_READY is not None:                   # this parameter bypasses autograd's accumulate hook
-                        GRAD_READY(ctx.unit.weight_fn(), side)
                     gx = _ConvUnitFn._dgrad(gact, w_eff, x.dtype, k, ctx.unit) if need_x else None
                     return gx, None, None, None, (gact if need_res else None), None, None, None
                 if need_x and need_w and WGRAD_SIDE_STREAM and x.is_cuda and x.dtype == torch.float32 and ops.PROFILE is None:
@@ -625,26 +619,60 @@ class _FusedPointwise:
         return None
 
 
-def _unit_wgrad(unit, w_eff, x, g, k):
+def _unit_wgrad(unit, w_eff, x, g, k, pend=None):
     """Weight gradient of one conv unit from its input x and the gradient g of its conv output (both channels-last, g possibly a channel
-    slice): inside wgrad_into_grad() accumulated straight into the parameter's .grad on the side stream (returns None), else returned."""
+    slice): inside wgrad_into_grad() accumulated straight into the parameter's .grad on the side stream (returns None), else returned.
+    pend (a list): the fixed-order sum of the partial tiles is deferred and described there -- _flush_wgrads() runs the sums of a whole
+    block as one launch (and only then announces the parameters to the gradient exchange)."""
     w16 = WGRAD16 and x.dtype != torch.float32 and g.dtype == x.dtype
+    if not w16 and g.dtype != torch.float32:
+        g = g.float()
     fn = ops.conv_wgrad16 if w16 else ops.conv_wgrad
     cout = w_eff.shape[0]
     target = _wgrad_target(unit, w_eff) if (WGRAD_INTO_GRAD and x.is_cuda and ops.PROFILE is None) else None
+    defer = pend is not None and ops.PROFILE is None and (ops.WGRAD16_WS if w16 else ops.WGRAD_WS)
     if target is None:
+        if defer:
+            dw, item, ws = ops.conv_wgrad_partial(x, g, cout, k)
+            pend.append((item, ws, None, None, x.device))
+            assert dw.dtype == w_eff.dtype                       # (fp32 master weights: a cast here would read the gradient before its sum has run)
+            return dw
         return fn(x, g, cout, k).to(w_eff.dtype)
     main = torch.cuda.current_stream(x.device)
     side = _side_streams(x.device)[0]
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        fn(x, g, cout, k, into=target)
+        if defer:
+            _, item, ws = ops.conv_wgrad_partial(x, g, cout, k, into=target)
+            pend.append((item, ws, unit, side, x.device))
+        else:
+            fn(x, g, cout, k, into=target)
     x.record_stream(side)
     g.record_stream(side)
     _PENDING[0] = True
-    if GRAD_READY is not None:                                   # this parameter bypasses autograd's accumulate hook
+    if GRAD_READY is not None and not defer:                     # this parameter bypasses autograd's accumulate hook
         GRAD_READY(unit.weight_fn(), side)
     return None
+
+
+def _flush_wgrads(pend, device):
+    """The deferred sums collected by _unit_wgrad(pend=...), one launch (per eight layers), on the stream their partial tiles were
+    written on; then the gradient exchange hears about the parameters."""
+    if not pend:
+        return
+    side = next((e[3] for e in pend if e[3] is not None), None)
+    items = [e[0] for e in pend]
+    if side is not None:
+        with torch.cuda.stream(side):
+            ops.wgrad_reduce_group(items, device)
+        for _, ws, unit, _, _ in pend:
+            if ws is not None:
+                ws.record_stream(side)
+            if GRAD_READY is not None and unit is not None:
+                GRAD_READY(unit.weight_fn(), side)
+    else:
+        ops.wgrad_reduce_group(items, device)
+    del pend[:]
 
 
 class _MixedTrainFn(torch.autograd.Function):
@@ -686,14 +714,15 @@ class _MixedTrainFn(torch.autograd.Function):
         gact = r[1]
         g0, g1, g2, g3 = gact[..., :c0], gact[..., c0:c1], gact[..., c1:c2], gact[..., c2:]
         gws = [None] * 6
+        pend = []                                                # the six fixed-order sums of partial tiles run as ONE launch at the end
         if need_w[0]:
-            gws[0] = _unit_wgrad(u0, w0, x, g0, (1, 1, 1))
+            gws[0] = _unit_wgrad(u0, w0, x, g0, (1, 1, 1), pend)
         if need_w[2]:
-            gws[2] = _unit_wgrad(u1b, w1b, t[..., :oc[1]], g1, (3, 3, 3))
+            gws[2] = _unit_wgrad(u1b, w1b, t[..., :oc[1]], g1, (3, 3, 3), pend)
         if need_w[4]:
-            gws[4] = _unit_wgrad(u2b, w2b, t[..., oc[1]:], g2, (3, 3, 3))
+            gws[4] = _unit_wgrad(u2b, w2b, t[..., oc[1]:], g2, (3, 3, 3), pend)
         if need_w[5]:
-            gws[5] = _unit_wgrad(u3, w3, p, g3, (1, 1, 1))
+            gws[5] = _unit_wgrad(u3, w3, p, g3, (1, 1, 1), pend)
         # 2. the two 3x3x3 data gradients into one bottleneck-gradient buffer (one grouped launch where the library merges them)
         gt = torch.empty(t.shape, dtype=t.dtype, device=t.device)
         dt_ = out.dtype
@@ -703,9 +732,10 @@ class _MixedTrainFn(torch.autograd.Function):
         # 3. through the two bottleneck ReLUs / BN scales in one pass
         _, gta = ops.act_grad(t, gt, m._train_scales(out.device)[1], True, want_f32=False, want_act=True)
         if need_w[1]:
-            gws[1] = _unit_wgrad(u1a, w1a, x, gta[..., :oc[1]], (1, 1, 1))
+            gws[1] = _unit_wgrad(u1a, w1a, x, gta[..., :oc[1]], (1, 1, 1), pend)
         if need_w[3]:
-            gws[3] = _unit_wgrad(u2a, w2a, x, gta[..., oc[1]:], (1, 1, 1))
+            gws[3] = _unit_wgrad(u2a, w2a, x, gta[..., oc[1]:], (1, 1, 1), pend)
+        _flush_wgrads(pend, x.device)
         gx = None
         if need_x:
             cin = x.shape[-1]
@@ -870,6 +900,7 @@ WGRAD16 = True           # 16-bit activations: weight gradients on the 16-bit MF
 WGRAD_INTO_GRAD = False        # see wgrad_into_grad()
 GRAD_READY = None              # step_amd.dist.BucketedReducer.ready while a backward pass is being overlapped with the exchange
 _PENDING = [False]
+_PEND_Q = []                   # deferred weight-gradient sums of the per-unit nodes (flushed eight at a time and in wgrad_sync())
 _KEEP = []                     # tensors the side stream reads that autograd must not modify in place (until wgrad_sync())
 
 
@@ -905,6 +936,8 @@ class wgrad_into_grad:
 
 def wgrad_sync():
     """Order every weight gradient launched on the side stream before what the current stream does next."""
+    if _PEND_Q:
+        _flush_wgrads(_PEND_Q, _PEND_Q[0][4])
     if _PENDING[0] and torch.cuda.is_available():
         for dev_key, streams in list(_SIDE.items()):
             torch.cuda.current_stream(torch.device(dev_key[0], dev_key[1])).wait_stream(streams[0])

@@ -177,11 +177,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 
 // sums the partial tiles of conv_wgrad_kernel over the jobs of the pixel axis: one thread per (tile, register, lane), jobs in
 // ascending order; writes (or adds to) dw in torch's weight layout
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long jobs, int gy, int MB, int NB, int cot, int cit,
-                                    int Cout, int Cin, int ntaps, int accumulate) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ ws, float* __restrict__ dw, long long jobs, int gy, int MB, int NB, int cot,
+                                                  int cit, int Cout, int Cin, int ntaps, int accumulate, unsigned bx, unsigned nbx) {
     const int per_tile = MB * NB * 16 * 64;
     const long long per_job = (long long)gy * per_tile;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < per_job; idx += (long long)blockDim.x * gridDim.x) {
+    for (long long idx = (long long)bx * blockDim.x + threadIdx.x; idx < per_job; idx += (long long)blockDim.x * nbx) {
         float sum = 0.f;
         for (long long j = 0; j < jobs; ++j) sum += ws[(size_t)j * per_job + idx];
         int t = (int)(idx % per_tile);
@@ -197,6 +197,10 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
             *o = accumulate ? *o + sum : sum;
         }
     }
+}
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long jobs, int gy, int MB, int NB, int cot, int cit,
+                                    int Cout, int Cin, int ntaps, int accumulate) {
+    wgrad_reduce_body(ws, dw, jobs, gy, MB, NB, cot, cit, Cout, Cin, ntaps, accumulate, blockIdx.x, gridDim.x);
 }
 
 
@@ -409,12 +413,12 @@ __global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) 
 }
 
 // sums the partial tiles of conv_wgrad16_lds_kernel over the pixel-axis workgroups: one thread per (tile, lane) 16-byte group
-__global__ void wgrad16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int gx, int gy, int cot, int cit, int Cout, int Cin,
-                                      int kd, int accumulate, int pw) {
+__device__ __forceinline__ void wgrad16_reduce_body(const float* __restrict__ ws, float* __restrict__ dw, int gx, int gy, int cot, int cit, int Cout,
+                                                    int Cin, int kd, int accumulate, int pw, unsigned bx, unsigned nbx) {
     const int tpw = pw ? 8 : 24;                                        // accumulator tiles per wave
     const long long per_x = (long long)gy * 6 * tpw * 64;              // f32x4 groups of one pixel-axis workgroup
     const int ntaps = pw ? 1 : kd * 9;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < per_x; idx += (long long)blockDim.x * gridDim.x) {
+    for (long long idx = (long long)bx * blockDim.x + threadIdx.x; idx < per_x; idx += (long long)blockDim.x * nbx) {
         f32x4 sum = {0.f, 0.f, 0.f, 0.f};
         for (int x = 0; x < gx; ++x) {
             const f32x4 v = ((const f32x4*)ws)[(size_t)x * per_x + idx];
@@ -442,6 +446,18 @@ __global__ void wgrad16_reduce_kernel(const float* __restrict__ ws, float* __res
             }
         }
     }
+}
+__global__ void wgrad16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int gx, int gy, int cot, int cit, int Cout, int Cin,
+                                      int kd, int accumulate, int pw) {
+    wgrad16_reduce_body(ws, dw, gx, gy, cot, cit, Cout, Cin, kd, accumulate, pw, blockIdx.x, gridDim.x);
+}
+
+// the fixed-order sums of several layers' partial tiles as ONE launch (step_wgrad_reduce_group): blockIdx.y = the layer
+struct WgradReduceGroup { step_wgrad_reduce_item it[STEP_WGRAD_REDUCE_MAX]; };
+__global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(WgradReduceGroup g) {
+    const step_wgrad_reduce_item& it = g.it[blockIdx.y];
+    if (it.kind == 1) wgrad_reduce_body(it.ws, it.dw, it.jobs, it.gy, 2, it.nbw, it.cot, it.cit, it.Cout, it.Cin, it.taps, it.accumulate, blockIdx.x, gridDim.x);
+    else if (it.kind == 2) wgrad16_reduce_body(it.ws, it.dw, (int)it.jobs, it.gy, it.cot, it.cit, it.Cout, it.Cin, it.taps, it.accumulate, it.pw, blockIdx.x, gridDim.x);
 }
 
 // stem_wgrad_kernel -- weight gradient of the 7x7x7 stride-2 stem (Cin = 3) from the clip in its own [N,T,3,H,W]
@@ -900,8 +916,13 @@ static WgJobs wgrad_jobs(const step_conv_desc* d, int form) {
 static long long wgrad_ws_blocks(const WgJobs& j) { return j.pw ? ceil_div64(j.full, 4) + (j.tail ? 1 : 0) : ceil_div64(j.jobs, 4); }
 static size_t wgrad_jobs_ws_bytes(const WgJobs& j) { return (size_t)wgrad_ws_blocks(j) * (size_t)j.gy * j.per_tile * sizeof(float); }
 
+// defer != NULL: the fixed-order sum of the partial tiles is NOT launched; *defer describes it (step_wgrad_reduce_group runs several
+// layers' sums as one launch).  kind 0: nothing is pending (the atomics forms, an empty batch).
+static void reduce_item_none(step_wgrad_reduce_item* it) { if (it) { *it = step_wgrad_reduce_item(); } }
+
 static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* dy, bool w16, float* dw, int accumulate, void* ws,
-                           size_t ws_bytes, step_stream_t stream) {
+                           size_t ws_bytes, step_stream_t stream, step_wgrad_reduce_item* defer = nullptr) {
+    reduce_item_none(defer);
     if (!d) return STEP_E_NULL;
     if (w16 && d->dtype != STEP_BF16 && d->dtype != STEP_F16) return STEP_E_UNSUPPORTED;
     if (d->N < 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return STEP_E_SHAPE;
@@ -946,7 +967,10 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
                 if (d->dtype == STEP_BF16) STEP_LAUNCH((conv_wgrad16_lds_kernel<bf16_t, 3>), grid16, dim3(384), stream, q);
                 else STEP_LAUNCH((conv_wgrad16_lds_kernel<f16_t, 3>), grid16, dim3(384), stream, q);
             }
-            if (q.ws) {
+            if (q.ws && defer) {
+                defer->kind = 2; defer->ws = q.ws; defer->dw = dw; defer->jobs = pl.gx; defer->gy = (int)pl.gy; defer->cot = pl.cot; defer->cit = pl.cit;
+                defer->Cout = d->Cout; defer->Cin = d->Cin; defer->taps = d->kd; defer->accumulate = 1; defer->pw = (int)pl.pw;
+            } else if (q.ws) {
                 const long long groups = pl.gy * 6 * (pl.pw ? 8 : 24) * 64;
                 STEP_LAUNCH(wgrad16_reduce_kernel, dim3(flat_grid(groups, 256)), dim3(256), stream, (const float*)q.ws, dw, (int)pl.gx, (int)pl.gy,
                             pl.cot, pl.cit, d->Cout, d->Cin, d->kd, 1, (int)pl.pw);      // (dw was cleared above unless accumulate)
@@ -984,7 +1008,10 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
             if (tap_ws) p.ws = (float*)ws + (size_t)ceil_div64(full, 4) * jb.gy * jb.per_tile;      // the tail job's tiles behind the full chunks
             launch(1, tail, (size_t)full * chunk);
         }
-        if (rc == STEP_OK && tap_ws)
+        if (rc == STEP_OK && tap_ws && defer) {
+            defer->kind = 1; defer->ws = (const float*)ws; defer->dw = dw; defer->jobs = wgrad_ws_blocks(jb); defer->gy = (int)jb.gy; defer->nbw = jb.nbw;
+            defer->cot = jb.cot; defer->cit = jb.cit; defer->Cout = d->Cout; defer->Cin = d->Cin; defer->taps = 1; defer->accumulate = accumulate; defer->pw = 1;
+        } else if (rc == STEP_OK && tap_ws)
             STEP_LAUNCH(wgrad_reduce_kernel, dim3(flat_grid(jb.gy * (long long)jb.per_tile, 256)), dim3(256), stream, (const float*)ws, dw, wgrad_ws_blocks(jb),
                         (int)jb.gy, 2, jb.nbw, jb.cot, jb.cit, d->Cout, d->Cin, 1, accumulate);
         return rc != STEP_OK ? rc : STEP_LAUNCH_CHECK();
@@ -1007,7 +1034,10 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
     }
 #undef STEP_WG
 #undef STEP_WG16
-    if (tap_ws)
+    if (tap_ws && defer) {
+        defer->kind = 1; defer->ws = (const float*)ws; defer->dw = dw; defer->jobs = wgrad_ws_blocks(jb); defer->gy = (int)jb.gy; defer->nbw = jb.nbw;
+        defer->cot = jb.cot; defer->cit = jb.cit; defer->Cout = d->Cout; defer->Cin = d->Cin; defer->taps = ntaps; defer->accumulate = accumulate; defer->pw = 0;
+    } else if (tap_ws)
         STEP_LAUNCH(wgrad_reduce_kernel, dim3(flat_grid(jb.gy * (long long)jb.per_tile, 256)), dim3(256), stream, (const float*)ws, dw, wgrad_ws_blocks(jb),
                     (int)jb.gy, 2, jb.nbw, jb.cot, jb.cit, d->Cout, d->Cin, ntaps, accumulate);
     return STEP_LAUNCH_CHECK();
@@ -1044,6 +1074,36 @@ size_t step_conv_wgrad16_workspace_bytes(const step_conv_desc* d) {
 int step_conv_wgrad16_ws(const step_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate, void* ws, size_t ws_bytes,
                          step_stream_t stream) {
     return conv_wgrad_impl(d, x, dy, true, dw, accumulate, ws, ws_bytes, stream);
+}
+
+
+int step_conv_wgrad_partial(const step_conv_desc* d, const void* x, const void* dy, int dy16, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                            step_wgrad_reduce_item* item, step_stream_t stream) {
+    if (!item) return STEP_E_NULL;
+    if (ws && d && ((uintptr_t)ws % 16) != 0) return STEP_E_SHAPE;
+    if (ws && d && ws_bytes < (dy16 ? step_conv_wgrad16_workspace_bytes(d) : step_conv_wgrad_workspace_bytes(d))) return STEP_E_SHAPE;
+    return conv_wgrad_impl(d, x, dy, dy16 != 0, dw, accumulate, ws, ws_bytes, stream, item);
+}
+
+int step_wgrad_reduce_group(const step_wgrad_reduce_item* items, int n, step_stream_t stream) {
+    if (n < 0 || n > STEP_WGRAD_REDUCE_MAX) return STEP_E_SHAPE;
+    if (n == 0) return STEP_OK;
+    if (!items) return STEP_E_NULL;
+    WgradReduceGroup g;
+    int m = 0;
+    long long most = 0;
+    for (int i = 0; i < n; ++i) {
+        const step_wgrad_reduce_item& it = items[i];
+        if (it.kind == 0) continue;
+        if ((it.kind != 1 && it.kind != 2) || !it.ws || !it.dw) return STEP_E_SHAPE;
+        const long long work = it.kind == 1 ? (long long)it.gy * (2 * it.nbw * 16 * 64) : (long long)it.gy * 6 * (it.pw ? 8 : 24) * 64;
+        if (work > most) most = work;
+        g.it[m++] = it;
+    }
+    if (m == 0) return STEP_OK;
+    for (int i = m; i < STEP_WGRAD_REDUCE_MAX; ++i) g.it[i] = step_wgrad_reduce_item();
+    STEP_LAUNCH(wgrad_reduce_group_kernel, dim3(flat_grid(most, 256), (unsigned)m), dim3(256), stream, g);
+    return STEP_LAUNCH_CHECK();
 }
 
 

@@ -364,6 +364,45 @@ def conv_wgrad16(x, gy, Cout, k, into=None):
     return dw
 
 
+def conv_wgrad_partial(x, gy, Cout, k, into=None):
+    """conv_wgrad / conv_wgrad16 (chosen by gy's dtype) with the fixed-order sum of the partial tiles DEFERRED: launches the kernel that
+    writes the partial tiles and returns (dw, item, ws) -- pass the items of several layers to wgrad_reduce_group (one launch) and keep
+    `ws` alive until then.  item.kind == 0: nothing is pending."""
+    L = _lib.lib()
+    N, D, H, W, Cin = x.shape
+    w16 = gy.dtype == x.dtype and x.dtype != torch.float32
+    if not w16 and gy.dtype != torch.float32:
+        gy = gy.float()
+    gcs = _grad_slice(gy, 8 if w16 else 4)
+    if gcs is None:
+        gy, gcs = gy.contiguous(), Cout
+    if into is not None:
+        if into.dtype != torch.float32 or not into.is_contiguous() or into.numel() != Cout * Cin * k[0] * k[1] * k[2]:
+            raise RuntimeError("step_amd: conv_wgrad_partial(into=...) wants a dense fp32 tensor of Cout*Cin*taps elements")
+        dw = into
+    else:
+        dw = torch.empty((Cout, Cin) + tuple(k), dtype=torch.float32, device=x.device)
+    d = _capi.ConvDesc(dtype=_dt(x), N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2],
+                       x_cstride=_chan_slice(x), x_coff=0, y_cstride=gcs, y_coff=0, res_cstride=0, res_coff=0, relu=0,
+                       split=0, y2_cstride=0, y2_coff=0)
+    wsb = (L.step_conv_wgrad16_workspace_bytes if w16 else L.step_conv_wgrad_workspace_bytes)(ctypes.byref(d))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
+    item = _capi.WgradReduceItem()
+    _capi.check(L.step_conv_wgrad_partial(ctypes.byref(d), _lib.dptr(x), _lib.dptr(gy), int(w16), _lib.dptr(dw), int(into is not None), _lib.dptr(ws), wsb,
+                                          ctypes.byref(item), _lib.stream_ptr(x.device)), "step_conv_wgrad_partial")
+    return dw, item, ws
+
+
+def wgrad_reduce_group(items, device):
+    """The deferred sums of conv_wgrad_partial, up to 8 per launch (step_wgrad_reduce_group)."""
+    L = _lib.lib()
+    live = [it for it in items if it.kind != 0]
+    for i in range(0, len(live), _capi.WGRAD_REDUCE_MAX):
+        chunk = live[i:i + _capi.WGRAD_REDUCE_MAX]
+        arr = (_capi.WgradReduceItem * len(chunk))(*chunk)
+        _capi.check(L.step_wgrad_reduce_group(arr, len(chunk), _lib.stream_ptr(device)), "step_wgrad_reduce_group")
+
+
 def act_grad(y, gy, scale, relu, want_f32=True, want_act=False):
     """Activation gradient of the fused conv unit: g = gy * (y > 0) * scale[c] in one pass (step_act_grad).
     y / gy channels-last (possibly channel slices); returns (g fp32 or None, g in y.dtype or None), dense.

@@ -1279,6 +1279,50 @@ def case_conv_wgrad16(bk, golden):
     assert bk.lib.step_conv_wgrad16(ctypes.byref(d), z.ptr, z.ptr, z.ptr, 0, bk.stream) == -4       # fp32 storage: unsupported
 
 
+def case_wgrad_partial_and_grouped_reduce(bk, golden):
+    """step_conv_wgrad_partial + step_wgrad_reduce_group (the fixed-order sums of several layers' partial tiles as ONE launch: an
+    Inception block's six weight gradients) give BIT-IDENTICAL gradients to step_conv_wgrad_ws / step_conv_wgrad16_ws layer by layer:
+    a 3x3x3 and a deep pointwise layer on the LDS-tiled 16-bit form, a shallow pointwise one on the per-tap 16-bit form, an fp32 layer,
+    accumulate on and off, the gradient read in place as a channel SLICE of a wider buffer (what _MixedTrainFn hands over)."""
+    rs = np.random.RandomState(36)
+    layers = [(BF16, True, 1, 64, 72, 3, 20, 14, (3, 3, 3), 0), (BF16, True, 1, 392, 72, 2, 9, 40, (1, 1, 1), 1), (BF16, True, 2, 40, 24, 1, 9, 30, (1, 1, 1), 0),
+              (F32, False, 1, 24, 40, 2, 6, 7, (3, 3, 3), 1), (F16, True, 1, 16, 32, 1, 3, 100, (3, 3, 3), 0)]
+    items = (_capi.WgradReduceItem * len(layers))()
+    keep, expect, got = [], [], []
+    for li, (dt, w16, N, Cin, Cout, D, H, W, k, acc) in enumerate(layers):
+        x = rs.randn(N, D, H, W, Cin).astype(np.float32)
+        wide = rs.randn(N, D, H, W, Cout + 16).astype(np.float32)              # the gradient is channels [8, 8 + Cout) of this buffer
+        gdt = dt if w16 else F32
+        xd, gwide = bk.dev(encode(x, dt)), bk.dev(encode(wide, gdt))
+        gdense = bk.dev(encode(np.ascontiguousarray(wide[..., 8:8 + Cout]), gdt))
+        es = 2 if w16 else 4
+        gslice_ptr = (gwide.ptr + 8 * es) if isinstance(gwide.ptr, int) else ctypes.c_void_p(gwide.ptr.value + 8 * es)
+        init = rs.randn(Cout, Cin, *k).astype(np.float32)
+        d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2], x_cstride=Cin, x_coff=0,
+                           y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)
+        nb = (bk.lib.step_conv_wgrad16_workspace_bytes if w16 else bk.lib.step_conv_wgrad_workspace_bytes)(ctypes.byref(d))
+        assert nb > 0
+        ws = bk.dev(np.full(nb // 4, np.nan, np.float32))
+        dw = bk.dev(init.copy())
+        fn = bk.lib.step_conv_wgrad16_ws if w16 else bk.lib.step_conv_wgrad_ws
+        assert fn(ctypes.byref(d), xd.ptr, gdense.ptr, dw.ptr, acc, ws.ptr, nb, bk.stream) == 0
+        expect.append(dw.get().copy())
+        ds = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2], x_cstride=Cin, x_coff=0,
+                            y_cstride=Cout + 16, y_coff=0, res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)
+        ws2 = bk.dev(np.full(nb // 4, np.nan, np.float32))
+        dw2 = bk.dev(init.copy())
+        assert bk.lib.step_conv_wgrad_partial(ctypes.byref(ds), xd.ptr, gslice_ptr, int(w16), dw2.ptr, acc, ws2.ptr, nb, ctypes.byref(items[li]), bk.stream) == 0
+        assert items[li].kind in (1, 2)
+        keep.append((ws2, xd, gwide))
+        got.append(dw2)
+    assert bk.lib.step_wgrad_reduce_group(items, len(layers), bk.stream) == 0
+    for li in range(len(layers)):
+        assert np.array_equal(got[li].get(), expect[li]), layers[li]
+    assert bk.lib.step_wgrad_reduce_group(items, 9, bk.stream) == -2 and bk.lib.step_wgrad_reduce_group(items, 0, bk.stream) == 0
+    none = _capi.WgradReduceItem()
+    assert bk.lib.step_wgrad_reduce_group(ctypes.byref(none), 1, bk.stream) == 0          # kind 0: nothing pending
+
+
 def case_stem_pool_fused(bk, golden):
     """step_stem_pool_forward (the stem with maxPool3d_2a taken on its tiles, models/i3dpt.py:186-196) is BIT-IDENTICAL to step_stem_forward
     followed by step_maxpool3d_tf (1,3,3) / (1,2,2): maps of several tiles in both directions with partial last tiles (seams completed by
