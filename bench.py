@@ -639,8 +639,10 @@ def main():
                                 "ms_per_step": round(sus[1] / sus[0] * 1e3, 4), "clock_ghz": sus[4] if sus[4] else sus[2], "clock_samples": sus[5] if sus[4] else sus[3],
                                 "clock_ghz_sysfs": sus[2], "clock_ghz_amd_smi": sus[4],
                                 "note": "the same loop (same captured steps, same batches in flight) run for >= %.1f s right after the timed K steps; "
-                                        "clock_ghz = median gfx clock during it from `amd-smi metric --clock` (polled back to back) or, failing that, the amdgpu "
-                                        "sysfs node (pp_dpm_sclk / hwmon freq1_input, every 20 ms); null: neither is exposed on this box; `value` / `ms_per_step` above stay on the contract's K steps" % a.sustained_seconds}
+                                        "clock_ghz = median gfx clock during it AS THE DRIVER REPORTS IT (`amd-smi metric --clock`, polled back to back; failing "
+                                        "that the amdgpu sysfs node) -- the DPM state, not the effective clock: inside these kernels s_memtime / s_memrealtime "
+                                        "measure 1.3-1.6 GHz (tools/timeline_probe.py) and roofline.sustained_on_this_box gives the rate under bare MFMA load; "
+                                        "null: not exposed on this box; `value` / `ms_per_step` above stay on the contract's K steps" % a.sustained_seconds}
         per_gpu = val / world
         out["backbone_roofline"] = {
             "hbm_frac": round(per_gpu * (ACT_MB_PER_CLIP + W_MB / CLIPS_PER_GPU) * 1e6 / (PEAK_HBM_GBS * 1e9), 4),

@@ -645,6 +645,8 @@ def _unit_wgrad(unit, w_eff, x, g, k, pend=None):
         if defer:
             _, item, ws = ops.conv_wgrad_partial(x, g, cout, k, into=target)
             pend.append((item, ws, unit, side, x.device))
+            if GRAD_DEFER is not None:
+                GRAD_DEFER(unit.weight_fn())
         else:
             fn(x, g, cout, k, into=target)
     x.record_stream(side)
@@ -899,6 +901,7 @@ class Mixed(nn.Module):
 WGRAD16 = True           # 16-bit activations: weight gradients on the 16-bit MFMA (step_conv_wgrad16)
 WGRAD_INTO_GRAD = False        # see wgrad_into_grad()
 GRAD_READY = None              # step_amd.dist.BucketedReducer.ready while a backward pass is being overlapped with the exchange
+GRAD_DEFER = None              # ... its defer(): this parameter's gradient will be announced by _flush_wgrads, not by autograd's hook
 _PENDING = [False]
 _PEND_Q = []                   # deferred weight-gradient sums of the per-unit nodes (flushed eight at a time and in wgrad_sync())
 _KEEP = []                     # tensors the side stream reads that autograd must not modify in place (until wgrad_sync())

@@ -96,7 +96,9 @@ class BucketedReducer:
         opt.step(grad_scale=scale, zero_grad=True)
     """
 
-    def __init__(self, opt, bucket_bytes=32 << 20):
+    def __init__(self, opt, bucket_bytes=32 << 20, single_rank=False):
+        # single_rank: issue the collectives even in a ONE-rank process group (they are identities there) -- lets the whole
+        # RCCL path (communicator on this device, communication stream, bucket order, stream waits) run on a one-GPU box
         self.opt = opt
         self.flat = opt.flat_grad
         entries = opt._entries                                  # (group, param, offset, numel), ascending offsets
@@ -111,7 +113,7 @@ class BucketedReducer:
             if end - lo >= cap or k + 1 == len(entries):
                 self.buckets.append((lo, end, cnt))
                 lo, cnt = end, 0
-        self.active = dist.is_initialized() and dist.get_world_size() > 1
+        self.active = dist.is_initialized() and (dist.get_world_size() > 1 or bool(single_rank))
         self.cuda = self.flat.is_cuda
         self.comm = torch.cuda.Stream(self.flat.device) if self.cuda else None
         self._hooks = [p.register_post_accumulate_grad_hook(self._autograd_ready) for _, p, _, _ in entries]
@@ -125,12 +127,14 @@ class BucketedReducer:
         from . import backbone
         if backbone.GRAD_READY is self.ready:
             backbone.GRAD_READY = None
+            backbone.GRAD_DEFER = None
 
     def begin(self, weight=None):
         """Arm for one backward pass.  weight: optional per-rank scalar as in allreduce_flat()."""
         from . import backbone
         self.pending = [c for _, _, c in self.buckets]
         self.seen = set()
+        self.deferred = set()                                    # parameters whose gradient a conv unit will announce itself, later (see defer())
         self._hooked = {}                                        # autograd hook firings per parameter in this armed pass
         self.next = len(self.buckets) - 1                        # next bucket to issue (descending)
         self.works = []
@@ -147,6 +151,7 @@ class BucketedReducer:
                 self.weight = float(weight)
                 self.factor = 1.0 / float(wsum.item())
         backbone.GRAD_READY = self.ready
+        backbone.GRAD_DEFER = self.defer
         self._armed = True
 
     def _autograd_ready(self, p):
@@ -156,6 +161,8 @@ class BucketedReducer:
             return
         n = self._hooked.get(id(p), 0) + 1
         self._hooked[id(p)] = n
+        if id(p) in self.deferred:
+            return                                               # the unit that accumulates this gradient announces it when its last kernel has been launched
         if n > 1:
             # a second backward() (gradient accumulation, retain_graph) between begin() and finish(): the later gradient would be
             # added locally after the parameter's bucket may already have been all-reduced, and the ranks would diverge silently
@@ -163,6 +170,13 @@ class BucketedReducer:
                                "one backward per begin() (accumulate micro-batches with the exchange off, then begin() for the last one)")
         if id(p) not in self.seen:
             self.ready(p, None)
+
+    def defer(self, p):
+        """A conv unit accumulates `p`'s gradient itself and its last kernel (the grouped fixed-order sum of partial tiles,
+        backbone._flush_wgrads) is launched LATER than the unit's autograd node returns: autograd's hook, which fires for the leaf even
+        though no gradient arrives through it, must not count the parameter -- the unit calls ready() when the sum has been launched."""
+        if self._armed:
+            self.deferred.add(id(p))
 
     def ready(self, p, stream=None):
         """`p`'s gradient for this step is complete (as far as the host is concerned: the producing kernel has been
@@ -207,10 +221,13 @@ class BucketedReducer:
         """Issue the buckets backward did not complete (same order on every rank), wait for all of them, return the
         factor that turns the sums into the average (for FlatAdam.step(grad_scale=...))."""
         from . import backbone
+        if self.cuda:
+            # queued weight-gradient sums are launched (and announce their parameters: buckets may still leave here); late
+            # side-stream accumulations are ordered before the main stream
+            backbone.wgrad_sync()
         self._armed = False
         backbone.GRAD_READY = None
-        if self.cuda:
-            backbone.wgrad_sync()                                # late side-stream accumulations -> ordered before the main stream
+        backbone.GRAD_DEFER = None
         while self.next >= 0:
             self._issue(self.next)
             self.next -= 1

@@ -126,6 +126,56 @@ def test_two_rank_gradient_equals_single_process_on_the_concatenated_batch():
     assert e < 1e-4 and en < 1e-5, (e, en)
 
 
+def _rccl_single_rank_worker(port, q):
+    import torch.distributed as dist
+    from step_amd import dist as D, workloads
+
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)    # "nccl" IS RCCL on ROCm
+    assert dist.get_backend() == "nccl"
+    w = workloads.C4TrainStep(dev, batch=1, seed=123, dtype=torch.bfloat16)
+    w.forward_backward()                                          # no exchange: the reference gradient
+    ref = w.opt.flat_grad.clone()
+    w.opt.zero_grad()
+    w.reducer.close()
+    w.reducer = D.BucketedReducer(w.opt, single_rank=True)        # every bucket goes through RCCL on the communication stream
+    assert w.reducer.active
+    w.forward_backward(exchange=True)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(w.opt.flat_grad, ref))
+    during, nb, scale = w.reducer.issued_during_backward, len(w.reducer.buckets), w.scale
+    # ... and two whole optimisation steps (bucketed exchange + fused Adam) stay finite
+    w._eager_step()
+    w._eager_step()
+    torch.cuda.synchronize()
+    finite = bool(torch.isfinite(w.opt.flat_param).all())
+    t = torch.ones(8, device=dev)
+    dist.all_reduce(t)
+    q.put((same, during, nb, scale, finite, float(t.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_bucketed_exchange_over_rccl_with_one_rank():
+    """The RCCL leg on a one-GPU box: a ONE-rank `nccl` process group (RCCL accepts a single-rank communicator) with
+    init_process_group(device_id=...), and a full C4 training step whose gradient buckets are all-reduced by RCCL on the communication
+    stream while backward is still running (BucketedReducer(single_rank=True)): the communicator set-up, the stream waits, the bucket
+    issue order and the in-place collectives on views of FlatAdam's arena all execute on RCCL; a one-rank SUM is the identity, so the
+    exchanged gradient must equal the un-exchanged one bit for bit.  (Two ranks need two devices: the round-end scaling run.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    p = ctx.Process(target=_rccl_single_rank_worker, args=(_free_port(), q))
+    p.start()
+    got = q.get()
+    p.join(180)
+    assert p.exitcode == 0
+    same, during, nb, scale, finite, tsum = got
+    assert same and finite and scale == 1.0 and tsum == 8.0
+    assert nb >= 5 and during >= nb - 2, (during, nb)
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("config", ["c4", "c2"])
 def test_bench_launches_and_reduces_over_two_ranks(config):
