@@ -196,17 +196,26 @@ def pool_conv_forward(x, w_packed, Cout, scale, shift, relu, out, out2=None, spl
     if L.step_conv_plan_info(ctypes.byref(d), info, 10) != 0 or info[0] != 2 or info[2] > POOL_CONV_MAX_NB:
         return None                                                      # (the test step_pool_conv_forward makes)
     pooled = torch.empty((N, D, H, W, Cin), dtype=x.dtype, device=x.device)
+    refused = []
 
     def launch():
-        _capi.check(L.step_pool_conv_forward(_dt(x), _lib.dptr(x), N, D, H, W, Cin, _chan_slice(x), 0, _lib.dptr(pooled), Cin, 0, ctypes.byref(d),
-                                             _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift), _lib.dptr(out), _lib.dptr(out2),
-                                             _lib.stream_ptr(x.device)), "step_pool_conv_forward")
+        rc = L.step_pool_conv_forward(_dt(x), _lib.dptr(x), N, D, H, W, Cin, _chan_slice(x), 0, _lib.dptr(pooled), Cin, 0, ctypes.byref(d),
+                                      _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift), _lib.dptr(out), _lib.dptr(out2),
+                                      _lib.stream_ptr(x.device))
+        if rc in (-4, -5):          # STEP_E_UNSUPPORTED / STEP_E_ALIGN: the library's own contract checks (alignment, 32-bit offsets, ...) are
+            refused.append(rc)      # stricter than the plan test above -- the caller then launches pool and conv one after the other
+            return
+        _capi.check(rc, "step_pool_conv_forward")
 
     def describe():
         pix = N * D * H * W
         return ("void step::pool333_pw_kernel<%s>(%s const*, %s*, step::PoolParams, int, int, int, int, int, int, int, int, step::ConvParams)" % (
             _TNAME[x.dtype], _TNAME[x.dtype], _TNAME[x.dtype]), 2.0 * pix * Cout * Cin, (pix * (3 * Cin + Cout) + Cout * Cin) * _ES[x.dtype])
     _run(launch, describe)
+    if refused:
+        if PROFILE is not None and PROFILE and PROFILE[-1][0].startswith("void step::pool333_pw_kernel"):
+            PROFILE.pop()
+        return None
     return pooled
 
 
@@ -228,16 +237,25 @@ def conv_forward_pre(x, w_packed, Cout, k, scale, shift, relu, pre, out=None):
             or not (info[0] == 1 and info[4] == 1 and info[3] == 8 and info[1] in (0, 3)):
         return None                                                      # (the same test step_conv_forward_pre makes: STEP_E_UNSUPPORTED)
 
+    refused = []
+
     def launch():
-        _capi.check(L.step_conv_forward_pre(ctypes.byref(d), _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift), _lib.dptr(pw),
-                                            _lib.dptr(pscale), _lib.dptr(pshift), int(Cpre), _lib.dptr(out), _lib.stream_ptr(x.device)),
-                    "step_conv_forward_pre")
+        rc = L.step_conv_forward_pre(ctypes.byref(d), _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift), _lib.dptr(pw),
+                                     _lib.dptr(pscale), _lib.dptr(pshift), int(Cpre), _lib.dptr(out), _lib.stream_ptr(x.device))
+        if rc in (-4, -5):          # the library's stricter contract (alignment of x / scale tables, x_coff, 32-bit offsets): fall back to two launches
+            refused.append(rc)
+            return
+        _capi.check(rc, "step_conv_forward_pre")
 
     def describe():
         pix = N * D * H * W
         return ("void step::conv_tap_pre_kernel<%s, %d, %d>(step::ConvParams)" % (_TNAME[x.dtype], info[1], info[2]),
                 2.0 * pix * (Cout * cmid * 27 + cmid * Cpre), (pix * (Cpre + Cout) + Cout * cmid * 27 + cmid * Cpre) * _ES[x.dtype])
     _run(launch, describe)
+    if refused:
+        if PROFILE is not None and PROFILE and PROFILE[-1][0].startswith("void step::conv_tap_pre_kernel"):
+            PROFILE.pop()
+        return None
     return out
 
 
@@ -247,6 +265,28 @@ def conv_forward_group(members):
     conv riding on the CUs they leave idle); otherwise they are launched one after the other.  members: (x, w_packed, Cout, k, scale, shift, relu, out) per conv, `out` a channel slice to write into.  Same results
     as conv_forward per member, bit for bit."""
     L = _lib.lib()
+    # a member whose plan needs a caller-owned workspace (the split-K form of few-row / deep-K pointwise layers) goes through
+    # conv_forward, which allocates it: inside the group call it would silently run on the tiled kernel instead -- a valid result, but
+    # summed in another order than the same layer launched alone (bit-identity of the two forms is part of this function's contract)
+    solo = []
+    for m_ in members:
+        x, w_packed, Cout, k, scale, shift, relu, out = m_
+        if tuple(k) == (1, 1, 1):
+            N, D, H, W, Cin = x.shape
+            d = _capi.ConvDesc(dtype=_dt(x), N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=_chan_slice(x), x_coff=0,
+                               y_cstride=_chan_slice(out), y_coff=0, res_cstride=0, res_coff=0, relu=int(bool(relu)), split=0, y2_cstride=0, y2_coff=0)
+            if L.step_conv_workspace_bytes(ctypes.byref(d)):
+                solo.append(m_)
+    if solo:
+        members = [m_ for m_ in members if not any(m_ is s_ for s_ in solo)]
+        for (x, w_packed, Cout, k, scale, shift, relu, out) in solo:
+            conv_forward(x, w_packed, Cout, k, scale, shift, relu, None, out)
+        if not members:
+            return
+        if len(members) == 1:
+            x, w_packed, Cout, k, scale, shift, relu, out = members[0]
+            conv_forward(x, w_packed, Cout, k, scale, shift, relu, None, out)
+            return
     n = len(members)
     items = (_capi.ConvItem * n)()
     descs, flops, nbytes = [], 0.0, 0
