@@ -232,8 +232,8 @@ struct Wgrad16Params {
 
 // KW = 1 (pointwise convs / Linear layers): no halo; the unit is a chunk of 128 consecutive pixels of the flattened N*D*H*W
 // axis, the six waves take six 32-channel blocks of a 192-channel ci tile (X image pitch 400 B) and accumulate one tap.
-template <typename T, int KW>
-__global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) {
+template <typename T, int KW, bool PF>
+__device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
     static_assert(sizeof(T) == 2, "16-bit storage");
     static_assert(KW == 3 || KW == 1, "3x3 windows or pointwise");
     constexpr bool PW = KW == 1;
@@ -310,11 +310,13 @@ __global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) 
         q.P = q.R * p.W; q.Ppad = (q.P + 31) & ~31; q.XP = (q.R + 2) * W2;
         return q;
     };
-    auto prefetch = [&](const Unit& q) {
+    // (i0, i1: the slice of the thread's NV vectors this call moves -- the form without cross-unit prefetch stages a unit in two halves,
+    // so that only half the staging registers are live at a time)
+    auto prefetch = [&](const Unit& q, int i0 = 0, int i1 = NV) {
         const size_t gp0 = PW ? (size_t)q.k0 : (((size_t)q.n * p.D + q.d) * p.H + q.r0) * p.W;
         const size_t xp0 = ((size_t)q.n * p.D + q.id) * p.H;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
+        for (int i = i0; i < i1; ++i) {
             const int v = tid + i * 384;
             u32x4 val = {0u, 0u, 0u, 0u};
             if (v < q.Ppad * 8) {                            // dY [Ppad][64 co]: zero tail, zero past Cout
@@ -335,9 +337,9 @@ __global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) 
             stg[i] = val;
         }
     };
-    auto to_lds = [&](const Unit& q) {
+    auto to_lds = [&](const Unit& q, int i0 = 0, int i1 = NV) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
+        for (int i = i0; i < i1; ++i) {
             const int v = tid + i * 384;
             if (v < q.Ppad * 8) *(u32x4*)(dyI + (v >> 3) * PITCH + (v & 7) * 16) = stg[i];
             else if (v - q.Ppad * 8 < q.XP * XCV) {
@@ -347,13 +349,23 @@ __global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) 
         }
     };
     Unit cur = unit_of(u_beg < u_end ? u_beg : 0);
-    if (u_beg < u_end && cur.live) prefetch(cur);
+    if (PF && u_beg < u_end && cur.live) prefetch(cur);
     for (long long u = u_beg; u < u_end; ++u) {
+        if (!PF) {                                           // no cross-unit prefetch: the staging registers die before the matrix phase (fewer
+            cur = unit_of(u);                                // VGPRs -> two resident workgroups per CU, whose staging and matrix phases interleave)
+            if (cur.live) prefetch(cur, 0, KW == 3 ? NV / 2 : NV);
+        }
         __syncthreads();                                     // every wave is done with the previous unit's images
-        if (cur.live) to_lds(cur);
+        if (!PF && KW == 3) {
+            if (cur.live) {
+                to_lds(cur, 0, NV / 2);
+                prefetch(cur, NV / 2, NV);
+                to_lds(cur, NV / 2, NV);
+            }
+        } else if (cur.live) to_lds(cur);
         __syncthreads();
         const Unit done = cur;
-        if (u + 1 < u_end) {
+        if (PF && u + 1 < u_end) {
             cur = unit_of(u + 1);
             if (cur.live) prefetch(cur);
         }
@@ -411,6 +423,16 @@ __global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) 
                 }
     }
 }
+
+template <typename T, int KW>
+__global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) { conv_wgrad16_lds_body<T, KW, true>(p); }
+// The same without the cross-unit register prefetch, held to 168 VGPRs: TWO workgroups per CU, whose staging and matrix phases interleave
+// (and 12 waves spread evenly over the 4 SIMDs instead of 6).  Measured (tools/wgrad_bench.py, bf16, 8 AVA clips, same process):
+// pointwise 480 -> 304 on 25x25x9x8: 137 -> 96 us, 832 -> 624 on 1080 7x7 maps: 914 -> 572 us (140 VGPRs, no spill) -- the product
+// form for KW = 1; the 3x3 windows spill at 168 VGPRs and measured 15-25 % SLOWER than the prefetching form even with the staging
+// split in two halves (profiles/r04_wgrad16_variants.txt): they keep one prefetching workgroup per CU.
+template <typename T, int KW>
+__global__ __launch_bounds__(384) STEP_WAVES_PER_SIMD(3) void conv_wgrad16_lds2_kernel(Wgrad16Params p) { conv_wgrad16_lds_body<T, KW, false>(p); }
 
 // sums the partial tiles of conv_wgrad16_lds_kernel over the pixel-axis workgroups: one thread per (tile, lane) 16-byte group
 __device__ __forceinline__ void wgrad16_reduce_body(const float* __restrict__ ws, float* __restrict__ dw, int gx, int gy, int cot, int cit, int Cout,
@@ -834,7 +856,10 @@ static Wg16Plan wgrad16_plan(const step_conv_desc* d) {
         const long long M = (long long)d->N * d->D * d->H * d->W;
         // measured (tools/wgrad_bench.py, bf16): 480 -> 304 channels on 25x25x9: 56 -> 37 us; 256 -> 288 on 50x50x18: 74 -> 99 us; 64 -> 64
         // on 100x100x18: 53 -> 154 us -- the six waves want six full 32-channel blocks: deep-Cin layers only
-        if (M < 4 * WG16_PW_P || d->Cin < 384) return pl;
+#ifndef WG16_PW_MINCIN
+#define WG16_PW_MINCIN 384
+#endif
+        if (M < 4 * WG16_PW_P || d->Cin < WG16_PW_MINCIN) return pl;
         pl.cot = ceil_div(d->Cout, 64); pl.cit = ceil_div(d->Cin, 192);
         pl.cpp = 1; pl.rows = 1;
         pl.units = ceil_div64(M, WG16_PW_P);
@@ -960,13 +985,19 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
             const size_t need = (size_t)pl.gx * pl.gy * 6 * (pl.pw ? 8 : 24) * 64 * 16;
             q.ws = (ws && ws_bytes >= need && ((uintptr_t)ws % 16) == 0) ? (float*)ws : nullptr;
             dim3 grid16((unsigned)pl.gx, (unsigned)pl.gy);
+#ifdef WG16_NOPF            /* experiment builds (make EXP=... EXPFLAGS=-DWG16_NOPF): the two-workgroup form for the 3x3 windows too */
+#define WG16_K3 conv_wgrad16_lds2_kernel
+#else
+#define WG16_K3 conv_wgrad16_lds_kernel
+#endif
             if (pl.pw) {
-                if (d->dtype == STEP_BF16) STEP_LAUNCH((conv_wgrad16_lds_kernel<bf16_t, 1>), grid16, dim3(384), stream, q);
-                else STEP_LAUNCH((conv_wgrad16_lds_kernel<f16_t, 1>), grid16, dim3(384), stream, q);
+                if (d->dtype == STEP_BF16) STEP_LAUNCH((conv_wgrad16_lds2_kernel<bf16_t, 1>), grid16, dim3(384), stream, q);
+                else STEP_LAUNCH((conv_wgrad16_lds2_kernel<f16_t, 1>), grid16, dim3(384), stream, q);
             } else {
-                if (d->dtype == STEP_BF16) STEP_LAUNCH((conv_wgrad16_lds_kernel<bf16_t, 3>), grid16, dim3(384), stream, q);
-                else STEP_LAUNCH((conv_wgrad16_lds_kernel<f16_t, 3>), grid16, dim3(384), stream, q);
+                if (d->dtype == STEP_BF16) STEP_LAUNCH((WG16_K3<bf16_t, 3>), grid16, dim3(384), stream, q);
+                else STEP_LAUNCH((WG16_K3<f16_t, 3>), grid16, dim3(384), stream, q);
             }
+#undef WG16_K3
             if (q.ws && defer) {
                 defer->kind = 2; defer->ws = q.ws; defer->dw = dw; defer->jobs = pl.gx; defer->gy = (int)pl.gy; defer->cot = pl.cot; defer->cit = pl.cit;
                 defer->Cout = d->Cout; defer->Cin = d->Cin; defer->taps = d->kd; defer->accumulate = 1; defer->pw = (int)pl.pw;
