@@ -17,6 +17,7 @@ prof() { n=$1; shift
   rm -rf $O/prof_$n; }
 prof c4_bf16 --config c4 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline
 prof c4_bf16_b8 --config c4 --dtype bf16 --clips 8 --tubes 15 --steps 6 --warmup 2 --no-cpu-baseline
+prof c3 --config c3 --steps 20 --warmup 5 --no-cpu-baseline --in-flight 1
 cd $R
 python - <<P
 import json,glob
