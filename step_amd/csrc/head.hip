@@ -92,7 +92,9 @@ __global__ __launch_bounds__(256) void head_outputs_kernel(HeadParams p) {
         for (int n = tid; n < p.N; n += 256) m += p.targets[(size_t)n * p.tstride + (p.tstride / 3) + 4];
         pos = block_sum(m, red) > 0.f ? 1.f : 0.f;                          // `if mask.sum():` (two_branch.py:289)
     }
-    for (int i = tid; i < p.N * p.NC; i += 256) {
+    // (inference launches several workgroups over the element-wise parts; training -- whose losses are block sums -- exactly one)
+    const int gtid = blockIdx.x * 256 + tid, gstep = gridDim.x * 256;
+    for (int i = gtid; i < p.N * p.NC; i += gstep) {
         const int n = i / p.NC, c = i % p.NC;
         const float x = mean_logit<T>(p, n, c);
         p.prob[i] = 1.0f / (1.0f + expf(-x));
@@ -103,11 +105,11 @@ __global__ __launch_bounds__(256) void head_outputs_kernel(HeadParams p) {
         }
     }
     if (p.reg) {
-        for (int i = tid; i < p.N * p.Tl * 4; i += 256) {
+        for (int i = gtid; i < p.N * p.Tl * 4; i += gstep) {
             const int k = i & 3, row = i >> 2;
             p.local_loc[i] = ld<T>(p.reg, (size_t)row * p.rcs + k);
         }
-        for (int i = tid; i < p.N * p.T * 4; i += 256) {
+        for (int i = gtid; i < p.N * p.T * 4; i += gstep) {
             const int k = i & 3, t = (i >> 2) % p.T, n = (i >> 2) / p.T;
             const size_t r1 = (size_t)(n * p.Tl + p.lo + t), r2 = (size_t)(n * p.Tl + p.lo2 + t);
             p.first_loc[i] = ld<T>(p.reg, r1 * p.rcs + k) + ld<T>(p.reg, r1 * p.rcs + 4 + k);
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void head_outputs_kernel(HeadParams p) {
             }
         }
     }
-    if (!train && tid < 3) {                                                 // inference: three separate zero losses (two_branch.py:276-278)
+    if (!train && gtid < 3) {                                                // inference: three separate zero losses (two_branch.py:276-278)
         if (tid == 0) p.loss_cls[0] = 0.f;
         if (tid == 1) p.loss_loc[0] = 0.f;
         if (tid == 2) p.loss_nbr[0] = 0.f;
@@ -210,10 +212,12 @@ int step_head_outputs(int dtype, const void* logits, int logits_stride, const vo
     if (N > 0 && (!logits || !prob || (reg && (!local_loc || !first_loc || !last_loc)) || (targets && reg && !tubes))) return STEP_E_NULL;
     p.prob = prob; p.local_loc = local_loc; p.first_loc = first_loc; p.last_loc = last_loc;
     p.loss_cls = loss_cls; p.loss_loc = loss_loc; p.loss_nbr = loss_nbr;
+    const long long work = (long long)N * (NC > Tl * 4 ? NC : Tl * 4);
+    const dim3 grid(targets ? 1u : (unsigned)(work <= 256 ? 1 : (work + 255) / 256 > 64 ? 64 : (work + 255) / 256));
     switch (dtype) {
-        case STEP_F32: STEP_LAUNCH((head_outputs_kernel<float>), dim3(1), dim3(256), stream, p); break;
-        case STEP_BF16: STEP_LAUNCH((head_outputs_kernel<bf16_t>), dim3(1), dim3(256), stream, p); break;
-        default: STEP_LAUNCH((head_outputs_kernel<f16_t>), dim3(1), dim3(256), stream, p); break;
+        case STEP_F32: STEP_LAUNCH((head_outputs_kernel<float>), grid, dim3(256), stream, p); break;
+        case STEP_BF16: STEP_LAUNCH((head_outputs_kernel<bf16_t>), grid, dim3(256), stream, p); break;
+        default: STEP_LAUNCH((head_outputs_kernel<f16_t>), grid, dim3(256), stream, p); break;
     }
     return STEP_LAUNCH_CHECK();
 }

@@ -137,6 +137,9 @@ def _clip_groups(nums, device):
     return idx, valid
 
 
+_POST_CONST = {}
+
+
 def postprocess(args, history, conf_thresh=None, nms_thresh=None, evaluate_topk=None, topk=None, iterations=None):
     """The evaluation loop of test.py:157-210 (the same code is inlined in train.py:512-573 and demo.py:123-174) as batched
     tensor operations: for EVERY refinement iteration and every clip, per class: mask the middle-frame scores with
@@ -176,8 +179,16 @@ def postprocess(args, history, conf_thresh=None, nms_thresh=None, evaluate_topk=
         groups.setdefault((tuple(nums), h["pred_prob"].shape[-1], h["pred_loc"].device), []).append((oi, h))
     for (nums, NC, dev), members in groups.items():
         B, kmax, I = len(nums), max(nums), len(members)
-        n = torch.as_tensor(nums, device=dev, dtype=torch.int32)
-        start = (torch.cumsum(n, 0) - n).to(torch.int32)
+        # per-layout constants live on the device (a host -> device copy from pageable memory per call stalls the host; the layout of a
+        # serving loop never changes)
+        ck = (nums, dev, W, H)
+        hit = _POST_CONST.get(ck)
+        if hit is None:
+            n = torch.as_tensor(nums, device=dev, dtype=torch.int32)
+            hit = _POST_CONST[ck] = (n, (torch.cumsum(n, 0) - n).to(torch.int32), torch.tensor([W, H, W, H], device=dev))
+            if len(_POST_CONST) > 64:
+                _POST_CONST.pop(next(iter(_POST_CONST)))
+        n, start, whwh = hit
         keep = torch.empty((I, B, NC, kmax), dtype=torch.uint8, device=dev)
         sc_all, bx_all = [], []
         for k, (oi, h) in enumerate(members):
@@ -189,7 +200,7 @@ def postprocess(args, history, conf_thresh=None, nms_thresh=None, evaluate_topk=
         # rows in the reference's order: iteration, clip, class ascending, kept tube ascending == row-major order of `keep`
         ki, kb, kc, kj = torch.nonzero(keep, as_tuple=True)
         tube = start.long()[kb] + kj + ki * sum(nums)
-        rb = torch.cat(bx_all)[tube] / torch.tensor([W, H, W, H], device=dev)                         # test.py:197-198
+        rb = torch.cat(bx_all)[tube] / whwh                                                           # test.py:197-198
         rs = torch.cat(sc_all)[tube, kc]
         per = torch.bincount(ki * B + kb, minlength=I * B).tolist()                                   # the one host sync
         pieces = list(zip(rb.split(per), rs.split(per), kc.split(per), kj.split(per)))
