@@ -875,16 +875,40 @@ static Wg16Plan wgrad16_plan(const step_conv_desc* d) {
         pl.units = (long long)d->N * d->D * pl.cpp;
         pl.gy = (long long)d->kd * pl.cot * pl.cit;
     }
-    // ~512 workgroups per launch; each walks several (plane, chunk) units (the next one's loads under this one's matrix work)
-    constexpr int wg_total = 512;
-    long long want = wg_total / (pl.gy > 0 ? pl.gy : 1);
-    if (want < 1) want = 1;
-    long long upj = ceil_div64(pl.units, want);
-    if (upj < 1) upj = 1;
-    if (upj > 0x3fffffff) upj = 0x3fffffff;
-    pl.upj = (int)upj;
-    pl.gx = ceil_div64(pl.units, pl.upj);
-    if (pl.gx >= 8) pl.gx = (pl.gx + 7) / 8 * 8;             // whole rounds over the 8 XCDs (the kernel's launch-order remap); surplus workgroups write zero tiles
+    // How many workgroups along the pixel axis (each walks `upj` (plane, chunk) units, the next one's loads under this one's matrix
+    // work).  The 3x3 form holds ONE workgroup per CU, the pointwise form two: a grid just over a whole number of rounds leaves most
+    // of the chip idle for a whole workgroup time (measured with fixed targets of 256 / 512 / 1024 workgroups, 8 AVA clips:
+    // 3c_b1b 1.57 / 1.24 / 0.90 ms, 4f_b1b 0.35 / 0.46 / 0.44 ms, 5c on 1080 7x7 maps 0.99 / 0.89 / 0.60 ms -- the winner is whichever
+    // lands just under a multiple of 256).  So the count is chosen per layer: time ~ rounds x units per workgroup, plus the partial
+    // tiles every pixel-axis workgroup writes and the sum reads back (~150 KB each way per workgroup: ~1 % of a unit's time each).
+#ifdef WG16_TOTAL           /* experiment builds: a fixed target, as rounds 2-3 had (512) */
+    {
+        long long want = WG16_TOTAL / (pl.gy > 0 ? pl.gy : 1);
+        if (want < 1) want = 1;
+        long long upj = ceil_div64(pl.units, want);
+        if (upj < 1) upj = 1;
+        pl.upj = (int)(upj > 0x3fffffff ? 0x3fffffff : upj);
+        pl.gx = ceil_div64(pl.units, pl.upj);
+        if (pl.gx >= 8) pl.gx = (pl.gx + 7) / 8 * 8;
+    }
+#else
+    {
+        const long long slots = 256LL * (pw ? 2 : 1);
+        double best = -1.0;
+        long long best_gx = 1, best_upj = pl.units;
+        const long long gx_max = pl.units < 2048 / (pl.gy > 0 ? pl.gy : 1) + 8 ? pl.units : 2048 / (pl.gy > 0 ? pl.gy : 1) + 8;
+        for (long long cand = 1; cand <= (gx_max > 1 ? gx_max : 1); cand = cand < 8 ? cand + 1 : cand + 8) {
+            const long long upj = ceil_div64(pl.units, cand);
+            long long gx = ceil_div64(pl.units, upj);
+            if (gx >= 8) gx = (gx + 7) / 8 * 8;              // whole rounds over the 8 XCDs (the kernel's launch-order remap); surplus workgroups write zero tiles
+            const long long wgs = gx * pl.gy;
+            const double cost = (double)ceil_div64(wgs, slots) * (double)upj + 0.012 * (double)wgs / (double)slots * 256.0 + 0.25;   // (+ a launch's fixed part)
+            if (best < 0.0 || cost < best) { best = cost; best_gx = gx; best_upj = upj; }
+        }
+        pl.upj = (int)(best_upj > 0x3fffffff ? 0x3fffffff : best_upj);
+        pl.gx = best_gx;
+    }
+#endif
     pl.ok = pl.gy <= 65535 && pl.gx <= 0x7fffffffLL;
     return pl;
 }

@@ -362,6 +362,10 @@ __device__ __forceinline__ void store_vec_f32(TO* p, const float (&f)[V]) {
     }
 }
 
+// (Measured and removed, round 4: an XCD-aware launch order for the two gather passes -- every XCD a contiguous eighth of each
+// grid-stride round, so that the workgroups sharing rows and planes share one L2 -- was SLOWER on the large maps (8 AVA clips: 3b
+// 0.87 -> 1.04 ms, 3c 1.15 -> 1.29 ms, the heads' 7x7 maps 0.55 -> 0.77 ms per backward; 25x25 maps -5 %): the round-robin order
+// spreads the simultaneous requests over all L2 channels, the contiguous order concentrates them.  tools/pool_bwd_bench.py.)
 template <typename T>
 __global__ void maxpool_arg_kernel(const T* __restrict__ x, unsigned char* __restrict__ arg, PoolParams p, long long total) {
     constexpr int V = elem<T>::VEC;
