@@ -358,6 +358,8 @@ STEP_API int step_stem_forward(int dtype, const void* x, int N, int T, int H, in
  * weight gradients: one reduce launch instead of six).  item->kind == 0: nothing is pending (the form accumulated into dw itself).
  * ws must stay alive and untouched until the group launch has run.  Same arithmetic and summation order as the _ws entry points
  * (bit-identical results). */
+/* Diagnostic, as step_conv_kernel_name: the (main) kernel a weight-gradient call launches for this descriptor (dy16: the 16-bit entry). */
+STEP_API int step_conv_wgrad_kernel_name(const step_conv_desc* d, int dy16, char* buf, int buflen);
 #define STEP_WGRAD_REDUCE_MAX 8
 typedef struct step_wgrad_reduce_item {
     const float* ws; float* dw;

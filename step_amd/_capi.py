@@ -72,6 +72,7 @@ SIGNATURES = {
     "step_conv_wgrad16": (i, [C.POINTER(ConvDesc), vp, vp, fp, i, vp]),
     "step_conv_wgrad16_workspace_bytes": (sz, [C.POINTER(ConvDesc)]),
     "step_conv_wgrad16_ws": (i, [C.POINTER(ConvDesc), vp, vp, fp, i, vp, sz, vp]),
+    "step_conv_wgrad_kernel_name": (i, [C.POINTER(ConvDesc), i, C.c_char_p, i]),
     "step_conv_wgrad_partial": (i, [C.POINTER(ConvDesc), vp, vp, i, fp, i, vp, sz, C.POINTER(WgradReduceItem), vp]),
     "step_wgrad_reduce_group": (i, [C.POINTER(WgradReduceItem), i, vp]),
     "step_conv_forward_ws": (i, [C.POINTER(ConvDesc), vp, vp, fp, fp, vp, vp, vp, vp, sz, vp]),

@@ -1132,6 +1132,17 @@ int step_conv_wgrad16_ws(const step_conv_desc* d, const void* x, const void* dy,
 }
 
 
+int step_conv_wgrad_kernel_name(const step_conv_desc* d, int dy16, char* buf, int buflen) {
+    if (!d || !buf || buflen <= 0) return STEP_E_NULL;
+    const char* t = d->dtype == STEP_F32 ? "float" : (d->dtype == STEP_BF16 ? "step::bf16_t" : "step::f16_t");
+    if (dy16 && wgrad16_plan(d).ok) {
+        const bool pw = d->kd == 1 && d->kh == 1 && d->kw == 1;
+        snprintf(buf, (size_t)buflen, "void step::%s<%s, %d>(step::Wgrad16Params)", pw ? "conv_wgrad16_lds2_kernel" : "conv_wgrad16_lds_kernel", t, pw ? 1 : 3);
+    } else
+        snprintf(buf, (size_t)buflen, "void step::conv_wgrad_kernel<%s, 2, %d, %s>(step::WgradParams)", t, d->Cin <= 32 ? 1 : 2, dy16 ? "true" : "false");
+    return STEP_OK;
+}
+
 int step_conv_wgrad_partial(const step_conv_desc* d, const void* x, const void* dy, int dy16, float* dw, int accumulate, void* ws, size_t ws_bytes,
                             step_wgrad_reduce_item* item, step_stream_t stream) {
     if (!item) return STEP_E_NULL;

@@ -270,6 +270,7 @@ __device__ __forceinline__ float axis_weight(int size, float v, int P) {
 // here is workgroup-uniform -- it depends on blockIdx and the roi list only -- so the barriers inside the roi loop are legal), then
 // every lane walks the non-zero pairs.  (Each lane evaluating the weights itself: 205 us per call in the C4 step, VALU-bound.)
 constexpr int RBG_MAXS = 128;                       // samples per axis the LDS tables hold (pooled size x sampling grid); larger: per-lane path
+constexpr int RBG_RB = 8;                           // rois per round of the listed walk: their weight tables are built together (two barriers per round, not per roi)
 constexpr int RBG_LIST = 512;                       // rois per cell the LDS candidate list holds; a cell that more rois touch walks all K headers
 // a roi can reach the cell (frame b, row Y, column X): samples lie inside [start, start + max(extent, 1)]; a pixel more than one cell
 // away on either axis gets nothing
@@ -282,8 +283,10 @@ __device__ __forceinline__ bool roi_touches(const float* r, int b, int Y, int X,
 template <int V>
 __global__ void roi_align_bwd_gather_nhwc_kernel(const float* __restrict__ grad, const float* __restrict__ rois, int K, int C, int H, int W,
                                                  int ph, int pw, float scale, int sampling_ratio, float* __restrict__ gfeat) {
-    __shared__ float wy_s[RBG_MAXS], wx_s[RBG_MAXS];
+    __shared__ float wy_s[RBG_RB][RBG_MAXS], wx_s[RBG_RB][RBG_MAXS];
+    __shared__ int rng_s[RBG_RB][4];                  // per roi of the round: first / last sample row, first / last sample column with a non-zero weight
     __shared__ int list_s[RBG_LIST];
+    __shared__ float box_s[RBG_LIST][5];              // the listed rois' rows: the rounds below read their geometry from LDS, not through a chain of global loads
     __shared__ int nlist_s;
     const int pix = blockIdx.x;
     const int X = pix % W, Y = (pix / W) % H, b = pix / (W * H);
@@ -293,13 +296,23 @@ __global__ void roi_align_bwd_gather_nhwc_kernel(const float* __restrict__ grad,
     // every cell walking all K headers one after the other was 2.8 ms per call there (profiles/r04: 9 % of the C4 step at 8 clips).
     if (tid < 64) {
         int cnt = 0;
-        for (int base = 0; base < K; base += 64) {
+#pragma unroll 4
+        for (int base = 0; base < K; base += 64) {    // (unrolled: the header loads of four rounds are in flight together)
             const int n = base + tid;
-            const bool hit = n < K && roi_touches(rois + 5 * n, b, Y, X, scale, ph, pw, sampling_ratio);
+            float r5[5] = {-1.f, 0.f, 0.f, 0.f, 0.f};
+            if (n < K) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) r5[j] = rois[5 * n + j];
+            }
+            const bool hit = n < K && roi_touches(r5, b, Y, X, scale, ph, pw, sampling_ratio);
             const unsigned long long m = __ballot(hit);
             if (hit) {
                 const int pos = cnt + __builtin_popcountll(m & ((1ull << tid) - 1ull));
-                if (pos < RBG_LIST) list_s[pos] = n;
+                if (pos < RBG_LIST) {
+                    list_s[pos] = n;
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) box_s[pos][j] = r5[j];
+                }
             }
             cnt += __builtin_popcountll(m);
         }
@@ -316,27 +329,88 @@ __global__ void roi_align_bwd_gather_nhwc_kernel(const float* __restrict__ grad,
     for (int k = 0; k < MAXCV; ++k)
 #pragma unroll
         for (int i = 0; i < V; ++i) acc[k][i] = 0.f;
-    for (int w_ = 0; w_ < nwalk; ++w_) {
-        const int n = listed ? list_s[w_] : w_;
-        if (!listed && !roi_touches(rois + 5 * n, b, Y, X, scale, ph, pw, sampling_ratio)) continue;
+    // Listed walk, RBG_RB rois per round.  A sample row's weight for cell row Y is a function of the sample coordinate alone, and the
+    // coordinates grow with the sample index: the samples that reach this cell are a CONTIGUOUS index range per axis (2-3 of the 7 x
+    // grid samples).  The round's first phase writes every roi's two weight tables and finds the ranges (LDS min / max: order-
+    // independent), the second walks range x range instead of all (7 grid)^2 table entries -- same products, same order (rois
+    // ascending, then sample row, then sample column).
+    for (int w0 = 0; listed && w0 < nlist; w0 += RBG_RB) {
+        const int nr = min(RBG_RB, nlist - w0);
+        if (tid < RBG_RB * 4) rng_s[tid >> 2][tid & 3] = (tid & 1) ? -1 : 0x7fffffff;
+        __syncthreads();
+        bool small = true;                            // (workgroup-uniform: every roi of the round fits the tables)
+        for (int r = 0; r < nr; ++r) {
+            const RoiGeom g = roi_geom(box_s[w0 + r], scale, ph, pw, sampling_ratio);
+            const int SY = ph * g.grid_h, SX = pw * g.grid_w;
+            if (SY > RBG_MAXS || SX > RBG_MAXS) { small = false; continue; }
+            for (int i = tid; i < SY + SX; i += nthr) {
+                if (i < SY) {
+                    const float w = axis_weight(H, sample_y(g, i / g.grid_h, i % g.grid_h), Y);
+                    wy_s[r][i] = w;
+                    if (w != 0.f) { atomicMin(&rng_s[r][0], i); atomicMax(&rng_s[r][1], i); }
+                } else {
+                    const int j = i - SY;
+                    const float w = axis_weight(W, sample_x(g, j / g.grid_w, j % g.grid_w), X);
+                    wx_s[r][j] = w;
+                    if (w != 0.f) { atomicMin(&rng_s[r][2], j); atomicMax(&rng_s[r][3], j); }
+                }
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < nr; ++r) {
+            const int n = list_s[w0 + r];
+            const RoiGeom g = roi_geom(box_s[w0 + r], scale, ph, pw, sampling_ratio);
+            const int SY = ph * g.grid_h, SX = pw * g.grid_w;
+            const bool tables = SY <= RBG_MAXS && SX <= RBG_MAXS;
+            const int y0 = tables ? rng_s[r][0] : 0, y1 = tables ? rng_s[r][1] : SY - 1;
+            const int x0 = tables ? rng_s[r][2] : 0, x1 = tables ? rng_s[r][3] : SX - 1;
+            for (int sy = y0; sy <= y1; ++sy) {
+                const int p = sy / g.grid_h;
+                const float wy = tables ? wy_s[r][sy] : axis_weight(H, sample_y(g, p, sy % g.grid_h), Y);
+                if (wy == 0.f) continue;
+                for (int sx = x0; sx <= x1; ++sx) {
+                    const int q = sx / g.grid_w;
+                    const float wx = tables ? wx_s[r][sx] : axis_weight(W, sample_x(g, q, sx % g.grid_w), X);
+                    if (wx == 0.f) continue;
+                    const float w = wy * wx;
+#pragma unroll
+                    for (int k = 0; k < MAXCV; ++k) {
+                        const int c = cbase + (tid + k * nthr) * V;
+                        if (c < C) {
+                            float gt[V];
+                            VecIO<float, V>::load(grad + ((size_t)(n * ph + p) * pw + q) * C + c, gt);
+#pragma unroll
+                            for (int i = 0; i < V; ++i) acc[k][i] += gt[i] * w / g.count;
+                        }
+                    }
+                }
+            }
+        }
+        (void)small;
+        __syncthreads();                              // the tables are rewritten in the next round
+    }
+    // a cell that more rois touch than the list holds: every header, one roi per barrier pair (round 3's walk)
+    for (int w_ = 0; !listed && w_ < nwalk; ++w_) {
+        const int n = w_;
+        if (!roi_touches(rois + 5 * n, b, Y, X, scale, ph, pw, sampling_ratio)) continue;
         const RoiGeom g = roi_geom(rois + 5 * n, scale, ph, pw, sampling_ratio);
         const int SY = ph * g.grid_h, SX = pw * g.grid_w;
         const bool tables = SY <= RBG_MAXS && SX <= RBG_MAXS;
         if (tables) {
             for (int i = tid; i < SY + SX; i += nthr) {
-                if (i < SY) wy_s[i] = axis_weight(H, sample_y(g, i / g.grid_h, i % g.grid_h), Y);
-                else wx_s[i - SY] = axis_weight(W, sample_x(g, (i - SY) / g.grid_w, (i - SY) % g.grid_w), X);
+                if (i < SY) wy_s[0][i] = axis_weight(H, sample_y(g, i / g.grid_h, i % g.grid_h), Y);
+                else wx_s[0][i - SY] = axis_weight(W, sample_x(g, (i - SY) / g.grid_w, (i - SY) % g.grid_w), X);
             }
             __syncthreads();
         }
         for (int p = 0; p < ph; ++p)
             for (int iy = 0; iy < g.grid_h; ++iy) {
-                const float wy = tables ? wy_s[p * g.grid_h + iy] : axis_weight(H, sample_y(g, p, iy), Y);
+                const float wy = tables ? wy_s[0][p * g.grid_h + iy] : axis_weight(H, sample_y(g, p, iy), Y);
                 if (wy == 0.f) continue;
                 // (a sample whose OTHER coordinate is void contributes nothing: its column weight below is 0)
                 for (int q = 0; q < pw; ++q)
                     for (int ix = 0; ix < g.grid_w; ++ix) {
-                        const float wx = tables ? wx_s[q * g.grid_w + ix] : axis_weight(W, sample_x(g, q, ix), X);
+                        const float wx = tables ? wx_s[0][q * g.grid_w + ix] : axis_weight(W, sample_x(g, q, ix), X);
                         if (wx == 0.f) continue;
                         const float w = wy * wx;
 #pragma unroll

@@ -360,8 +360,9 @@ def conv_wgrad(x, gy, Cout, k, into=None):
     if PROFILE is not None:
         pix = N * D * H * W
         # algorithmic: x and dy read once, dw written once (fp32); the kernel variant is chosen by Cin inside the library
-        prof = _Prof("void step::conv_wgrad_kernel<%s, 2, %d, false>(step::WgradParams)" % (_TNAME[x.dtype], 1 if Cin <= 32 else 2),
-                     2.0 * pix * Cout * Cin * k[0] * k[1] * k[2],
+        nbuf = ctypes.create_string_buffer(256)
+        L.step_conv_wgrad_kernel_name(ctypes.byref(d), 0, nbuf, 256)
+        prof = _Prof(nbuf.value.decode(), 2.0 * pix * Cout * Cin * k[0] * k[1] * k[2],
                      pix * (Cin * x.element_size() + Cout * 4) + 4.0 * Cout * Cin * k[0] * k[1] * k[2])
     wsb = L.step_conv_wgrad_workspace_bytes(ctypes.byref(d)) if WGRAD_WS else 0     # partial tiles + fixed-order sum: no atomics, deterministic
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None
@@ -393,8 +394,9 @@ def conv_wgrad16(x, gy, Cout, k, into=None):
     prof = _NOPROF
     if PROFILE is not None:
         pix = N * D * H * W
-        prof = _Prof("void step::conv_wgrad_kernel<%s, 2, %d, true>(step::WgradParams)" % (_TNAME[x.dtype], 1 if Cin <= 32 else 2),
-                     2.0 * pix * Cout * Cin * k[0] * k[1] * k[2],
+        nbuf = ctypes.create_string_buffer(256)
+        L.step_conv_wgrad_kernel_name(ctypes.byref(d), 1, nbuf, 256)
+        prof = _Prof(nbuf.value.decode(), 2.0 * pix * Cout * Cin * k[0] * k[1] * k[2],
                      pix * (Cin + Cout) * x.element_size() + 4.0 * Cout * Cin * k[0] * k[1] * k[2])
     wsb = L.step_conv_wgrad16_workspace_bytes(ctypes.byref(d)) if WGRAD16_WS else 0   # > 0: the LDS-tiled form with a two-stage sum
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device) if wsb else None

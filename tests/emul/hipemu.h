@@ -81,6 +81,16 @@ static inline unsigned long long __ballot(int pred) {
     hipemu::exchange_end();
     return m;
 }
+static inline int atomicMin(int* p, int v) {          // (LDS min / max of the kernels: the fibers of a block run on one OS thread, but stay atomic anyway)
+    int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v < old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
+static inline int atomicMax(int* p, int v) {
+    int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v > old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
 static inline float atomicAdd(float* p, float v) {
     // blocks may run on different OS threads
     unsigned int* ip = (unsigned int*)p;

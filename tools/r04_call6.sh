@@ -1,0 +1,18 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+cd $R
+timeout 900 python -m pytest tests -x -q -m gpu -k "kernel or ddp or graph" 2>&1 | grep -E "passed|failed" 
+for cfg in "1 5" "8 15" "8 5"; do set -- $cfg
+  timeout 500 python bench.py --config c4 --dtype bf16 --clips $1 --tubes $2 --steps 10 --warmup 3 --no-cpu-baseline > $O/r04d_c4_bf16_b$1_t$2.json 2> $O/r04d_c4_bf16_b$1_t$2.err
+done
+timeout 300 python bench.py --config c3 --no-cpu-baseline --steps 30 --warmup 5 > $O/r04d_c3.json 2> $O/r04d_c3.err
+python - <<P
+import json,glob
+for f in sorted(glob.glob('$O/r04d_*.json')):
+    try:
+        j=json.loads(open(f).read().strip().splitlines()[-1]); r=j.get('roofline',{})
+        print(f.split('/')[-1], j['value'], j['ms_per_step'], (j.get('one_batch_in_flight') or {}).get('value'), r.get('kernel','')[:60], r.get('frac'), r.get('traffic'))
+    except Exception as e:
+        print(f, 'ERR', e)
+P
