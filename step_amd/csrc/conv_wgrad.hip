@@ -215,6 +215,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 // (plane, row chunk) units with its accumulators in registers and ends in one pass of fp32 atomics.
 constexpr int WG16_P = 224;              // output pixels per chunk (7 k32 steps)
 constexpr int WG16_XP = 320;             // halo pixels per chunk
+constexpr int WG16_XP_WIDE = 416;        // ... of the wide-map instantiation: 100-wide maps take two rows per chunk, 56-wide ones four (92 KB of LDS,
+                                         // 14 staged vectors per thread: 5 % slower than the 320 form when both give the same rows, so chosen per layer)
 constexpr int WG16_PW_P = 128;           // pointwise form: pixels per chunk
 constexpr int WG16_PW_XPITCH = 400;      // ... bytes per X pixel (192 channels x 2 B + 16 B)
 constexpr int WG16_PITCH = 144;          // bytes per LDS pixel: 64 channels x 2 B + 16 B (keeps the transpose reads off a 128-B bank period)
@@ -232,7 +234,7 @@ struct Wgrad16Params {
 
 // KW = 1 (pointwise convs / Linear layers): no halo; the unit is a chunk of 128 consecutive pixels of the flattened N*D*H*W
 // axis, the six waves take six 32-channel blocks of a 192-channel ci tile (X image pitch 400 B) and accumulate one tap.
-template <typename T, int KW, bool PF>
+template <typename T, int KW, bool PF, int XPMAX = WG16_XP>
 __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
     static_assert(sizeof(T) == 2, "16-bit storage");
     static_assert(KW == 3 || KW == 1, "3x3 windows or pointwise");
@@ -241,8 +243,8 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
     constexpr int XPITCH = PW ? WG16_PW_XPITCH : WG16_PITCH;
     constexpr int CIT = PW ? 192 : 64;                        // input channels per workgroup
     constexpr int XCV = CIT / 8;                              // 16-byte vectors per X pixel
-    static_assert(WG16_PW_P * (PITCH + WG16_PW_XPITCH) <= (WG16_P + WG16_XP) * PITCH, "the pointwise images fit the same LDS array");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[(WG16_P + WG16_XP) * PITCH];
+    constexpr int LDSB = PW ? WG16_PW_P * (PITCH + WG16_PW_XPITCH) : (WG16_P + XPMAX) * PITCH;    // 68 KiB (two workgroups per CU) | 76.5 / 90 KiB
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDSB];
     unsigned char* const dyI = lds;
     unsigned char* const xI = lds + (PW ? WG16_PW_P : WG16_P) * PITCH;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -287,7 +289,7 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
     const long long u_beg = (long long)bx * p.upj, u_end = min(u_beg + p.upj, p.units);
     // A unit's two images go global -> registers -> LDS; the NEXT unit's vectors are requested before this unit's matrix
     // work, so their round trip (2-3 us under load, against ~1 us of MFMAs per unit) flies under it.
-    constexpr int NV = ((WG16_P + WG16_XP) * 8 + 383) / 384;     // 16-byte vectors per thread per unit (12)
+    constexpr int NV = PW ? (WG16_PW_P * (8 + XCV) + 383) / 384 : ((WG16_P + XPMAX) * 8 + 383) / 384;     // 16-byte vectors per thread per unit (11 | 12 / 14)
     u32x4 stg[NV];
     struct Unit { int n, d, id, r0, R, P, Ppad, XP; long long k0; bool live; };
     auto unit_of = [&](long long u) {
@@ -312,7 +314,7 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
     };
     // (i0, i1: the slice of the thread's NV vectors this call moves -- the form without cross-unit prefetch stages a unit in two halves,
     // so that only half the staging registers are live at a time)
-    auto prefetch = [&](const Unit& q, int i0 = 0, int i1 = NV) {
+    auto prefetch = [&](const Unit& q, int i0, int i1) {
         const size_t gp0 = PW ? (size_t)q.k0 : (((size_t)q.n * p.D + q.d) * p.H + q.r0) * p.W;
         const size_t xp0 = ((size_t)q.n * p.D + q.id) * p.H;
 #pragma unroll
@@ -337,7 +339,7 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
             stg[i] = val;
         }
     };
-    auto to_lds = [&](const Unit& q, int i0 = 0, int i1 = NV) {
+    auto to_lds = [&](const Unit& q, int i0, int i1) {
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
             const int v = tid + i * 384;
@@ -349,7 +351,7 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
         }
     };
     Unit cur = unit_of(u_beg < u_end ? u_beg : 0);
-    if (PF && u_beg < u_end && cur.live) prefetch(cur);
+    if (PF && u_beg < u_end && cur.live) prefetch(cur, 0, NV);
     for (long long u = u_beg; u < u_end; ++u) {
         if (!PF) {                                           // no cross-unit prefetch: the staging registers die before the matrix phase (fewer
             cur = unit_of(u);                                // VGPRs -> two resident workgroups per CU, whose staging and matrix phases interleave)
@@ -362,12 +364,12 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
                 prefetch(cur, NV / 2, NV);
                 to_lds(cur, NV / 2, NV);
             }
-        } else if (cur.live) to_lds(cur);
+        } else if (cur.live) to_lds(cur, 0, NV);
         __syncthreads();
         const Unit done = cur;
         if (PF && u + 1 < u_end) {
             cur = unit_of(u + 1);
-            if (cur.live) prefetch(cur);
+            if (cur.live) prefetch(cur, 0, NV);
         }
         if (!done.live) continue;                            // (workgroup-uniform)
         const int P = done.P, Ppad = done.Ppad;
@@ -426,6 +428,8 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
 
 template <typename T, int KW>
 __global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) { conv_wgrad16_lds_body<T, KW, true>(p); }
+template <typename T, int KW>
+__global__ __launch_bounds__(384) void conv_wgrad16_lds_wide_kernel(Wgrad16Params p) { conv_wgrad16_lds_body<T, KW, true, WG16_XP_WIDE>(p); }
 // The same without the cross-unit register prefetch, held to 168 VGPRs: TWO workgroups per CU, whose staging and matrix phases interleave
 // (and 12 waves spread evenly over the 4 SIMDs instead of 6).  Measured (tools/wgrad_bench.py, bf16, 8 AVA clips, same process):
 // pointwise 480 -> 304 on 25x25x9x8: 137 -> 96 us, 832 -> 624 on 1080 7x7 maps: 914 -> 572 us (140 VGPRs, no spill) -- the product
@@ -842,9 +846,9 @@ static int wgrad_min_pixels(int form) {
 }
 
 // launch plan of the LDS-tiled 16-bit form; ok = false: the shape is left to the per-tap forms
-struct Wg16Plan { bool ok, pw; int rows, cpp, upj, cot, cit; long long units, gx, gy; };
+struct Wg16Plan { bool ok = false, pw = false, wide = false; int rows, cpp, upj, cot, cit; long long units, gx, gy; };
 static Wg16Plan wgrad16_plan(const step_conv_desc* d) {
-    Wg16Plan pl; pl.ok = false; pl.pw = false; pl.rows = pl.cpp = pl.upj = pl.cot = pl.cit = 0; pl.units = pl.gx = pl.gy = 0;
+    Wg16Plan pl; pl.ok = false; pl.pw = false; pl.wide = false; pl.rows = pl.cpp = pl.upj = pl.cot = pl.cit = 0; pl.units = pl.gx = pl.gy = 0;
     if (!d || (d->dtype != STEP_BF16 && d->dtype != STEP_F16)) return pl;
     const bool pw = d->kd == 1 && d->kh == 1 && d->kw == 1;
     pl.pw = pw;
@@ -865,9 +869,14 @@ static Wg16Plan wgrad16_plan(const step_conv_desc* d) {
         pl.units = ceil_div64(M, WG16_PW_P);
         pl.gy = (long long)pl.cot * pl.cit;
     } else {
-        int R = 0;
-        for (int r = d->H; r >= 1; --r)
-            if (r * d->W <= WG16_P && (r + 2) * (d->W + 2) <= WG16_XP) { R = r; break; }
+        int R = 0, Rw = 0;
+        for (int r = d->H; r >= 1; --r) {
+            if (!R && r * d->W <= WG16_P && (r + 2) * (d->W + 2) <= WG16_XP) R = r;
+            if (!Rw && r * d->W <= WG16_P && (r + 2) * (d->W + 2) <= WG16_XP_WIDE) Rw = r;
+        }
+        // the wide-halo instantiation only where it cuts the chunks per plane (measured, bf16, 8 clips: conv3d_2c on 100x100 2.61 -> 1.80 ms,
+        // on 56x56 0.53 -> 0.48 ms; the 50- and 25-wide layers keep the same rows and would lose 5 % to its longer staging loops)
+        if (Rw > 0 && (R <= 0 || ceil_div(d->H, Rw) < ceil_div(d->H, R))) { R = Rw; pl.wide = true; }
         if (R <= 0) return pl;
         pl.cot = ceil_div(d->Cout, 64); pl.cit = ceil_div(d->Cin, 64);
         pl.cpp = ceil_div(d->H, R);
@@ -1018,7 +1027,10 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
                 if (d->dtype == STEP_BF16) STEP_LAUNCH((conv_wgrad16_lds2_kernel<bf16_t, 1>), grid16, dim3(384), stream, q);
                 else STEP_LAUNCH((conv_wgrad16_lds2_kernel<f16_t, 1>), grid16, dim3(384), stream, q);
             } else {
-                if (d->dtype == STEP_BF16) STEP_LAUNCH((WG16_K3<bf16_t, 3>), grid16, dim3(384), stream, q);
+                if (pl.wide) {
+                    if (d->dtype == STEP_BF16) STEP_LAUNCH((conv_wgrad16_lds_wide_kernel<bf16_t, 3>), grid16, dim3(384), stream, q);
+                    else STEP_LAUNCH((conv_wgrad16_lds_wide_kernel<f16_t, 3>), grid16, dim3(384), stream, q);
+                } else if (d->dtype == STEP_BF16) STEP_LAUNCH((WG16_K3<bf16_t, 3>), grid16, dim3(384), stream, q);
                 else STEP_LAUNCH((WG16_K3<f16_t, 3>), grid16, dim3(384), stream, q);
             }
 #undef WG16_K3
@@ -1135,9 +1147,11 @@ int step_conv_wgrad16_ws(const step_conv_desc* d, const void* x, const void* dy,
 int step_conv_wgrad_kernel_name(const step_conv_desc* d, int dy16, char* buf, int buflen) {
     if (!d || !buf || buflen <= 0) return STEP_E_NULL;
     const char* t = d->dtype == STEP_F32 ? "float" : (d->dtype == STEP_BF16 ? "step::bf16_t" : "step::f16_t");
-    if (dy16 && wgrad16_plan(d).ok) {
+    const Wg16Plan pl = dy16 ? wgrad16_plan(d) : Wg16Plan();
+    if (dy16 && pl.ok) {
         const bool pw = d->kd == 1 && d->kh == 1 && d->kw == 1;
-        snprintf(buf, (size_t)buflen, "void step::%s<%s, %d>(step::Wgrad16Params)", pw ? "conv_wgrad16_lds2_kernel" : "conv_wgrad16_lds_kernel", t, pw ? 1 : 3);
+        snprintf(buf, (size_t)buflen, "void step::%s<%s, %d>(step::Wgrad16Params)",
+                 pw ? "conv_wgrad16_lds2_kernel" : (pl.wide ? "conv_wgrad16_lds_wide_kernel" : "conv_wgrad16_lds_kernel"), t, pw ? 1 : 3);
     } else
         snprintf(buf, (size_t)buflen, "void step::conv_wgrad_kernel<%s, 2, %d, %s>(step::WgradParams)", t, d->Cin <= 32 ? 1 : 2, dy16 ? "true" : "false");
     return STEP_OK;

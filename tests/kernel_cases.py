@@ -1228,7 +1228,8 @@ def case_conv_wgrad16(bk, golden):
     rs = np.random.RandomState(35)
     cases = [(2, 24, 40, 3, 5, 19, (3, 3, 3)), (1, 72, 100, 2, 6, 7, (1, 3, 3)), (1, 40, 70, 1, 9, 130, (1, 1, 1))]
     cases += [(1, 64, 72, 3, 20, 14, (3, 3, 3)),     # two row chunks per plane (20 rows of 14 > 224 pixels), a ragged second co tile
-              (2, 16, 32, 1, 3, 100, (3, 3, 3)),     # 100-pixel rows: one row per chunk, a single ci block
+              (2, 16, 32, 1, 3, 100, (3, 3, 3)),     # 100-pixel rows: the wide-halo instantiation (two rows per chunk, then a ragged one), a single ci block
+              (1, 24, 16, 2, 7, 56, (3, 3, 3)),      # 56-pixel rows: wide halo too (chunks of four and three rows instead of 3 + 2 + 2)
               (1, 392, 72, 2, 9, 40, (1, 1, 1))]     # pointwise through the LDS-tiled form (Cin >= 384): 720 pixels = 5 chunks + a ragged one, three ci tiles of 192 (the last one ragged)
     try:
         # 64 with wgrad16_lds = 0: the per-tap 16-bit form with several row-range jobs per tile; None: the LDS-tiled form
