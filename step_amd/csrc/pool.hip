@@ -448,6 +448,246 @@ __global__ void maxpool_bwd_gather_kernel(const unsigned char* __restrict__ arg,
     }
 }
 
+// ---- (3,3,3) / (1,1,1) max-pool backward in ONE launch (the branch_3 pool of every Inception block, i3dpt.py:151-155) ------------
+// The two gathers above walk 27 taps per output and 27 windows per input through L1: 0.8 TB/s of operand traffic, 7 of the 55 ms
+// of a C4 step at 8 clips x 15 tubes.  The first maximum of a zero-padded 3x3x3 window in scan order is SEPARABLE -- the first
+// plane whose plane maximum is the window maximum, in it the first row whose row maximum is, in it the first column -- and so is
+// the route of the gradient back: an output hands its gradient to a plane (3 candidates), the plane position to a row (3), the row
+// position to a column (3).  Nine compares forth and nine back instead of 27 + 27, on tiles held in LDS, every x / gy element read
+// from memory once (plus the tile halo) and no byte map in memory.
+// A 512-thread workgroup owns a TH x TW tile of the map x CVC 16-byte channel vectors and walks the planes of one sample; a thread
+// owns one position of the (TH+2) x (TW+2) grid of outputs that touch the tile and keeps its three-plane windows (plane maxima,
+// winning planes, gradients) in registers.  Per input plane t, four barriers:
+//   X tile (TH+4 x TW+4, zero outside the map) -> LDS | rows: first maximum of 3 columns -> (value, c) | columns: first maximum of
+//   3 rows -> plane maximum M_t (registers) and b | depth: a(t-1) from M_{t-2..t} | plane q = t-2: G1 = sum over the 3 outputs of
+//   the column whose a points at q -> LDS | G2[row] = sum over the 3 positions whose b points at the row -> LDS | gx[row][col] =
+//   sum over the 3 positions whose c points at the column -> memory.
+// Sums are fp32 in this fixed nested order (planes, then rows, then columns, each ascending); the gather form adds the same terms
+// in (od, oh, ow) order, so the two agree to fp32 rounding, not bit for bit (torch's own backward adds them with atomics).
+// "No winner" (every tap NaN or -inf) is tag 3 at each level and owns nothing, like the byte map's 255.
+constexpr int PB_THREADS = 512;
+constexpr int PB_XSLOTS = 768;          // (TH+4) x (TW+4) x CVC 16-byte slots of the input tile
+
+template <typename T> __device__ __forceinline__ unsigned short exact_bits16(float f);      // f is representable in T: no rounding involved
+template <> __device__ __forceinline__ unsigned short exact_bits16<bf16_t>(float f) { return (unsigned short)(__builtin_bit_cast(unsigned, f) >> 16); }
+template <> __device__ __forceinline__ unsigned short exact_bits16<f16_t>(float f) { return elem<f16_t>::bits16(f); }
+
+// first maximum of three 16-byte vectors in order: `val > best` from -inf, as torch walks a window (NaN never wins); tag 3: none
+template <typename T>
+__device__ __forceinline__ void first_max3(const u16x8& v0, const u16x8& v1, const u16x8& v2, float (&best)[8], unsigned (&win)[8]) {
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { best[i] = -__builtin_inff(); win[i] = 3; }
+    Vec16<T, 8>::unpack(v0, f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (f[i] > best[i]) { best[i] = f[i]; win[i] = 0; }
+    Vec16<T, 8>::unpack(v1, f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (f[i] > best[i]) { best[i] = f[i]; win[i] = 1; }
+    Vec16<T, 8>::unpack(v2, f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (f[i] > best[i]) { best[i] = f[i]; win[i] = 2; }
+}
+__device__ __forceinline__ unsigned long long pack_tags(const unsigned (&w)[8]) {
+    const unsigned lo = w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24), hi = w[4] | (w[5] << 8) | (w[6] << 16) | (w[7] << 24);
+    return (unsigned long long)lo | ((unsigned long long)hi << 32);
+}
+__device__ __forceinline__ unsigned tag_of(unsigned long long w, int i) { return (unsigned)(w >> (8 * i)) & 0xffu; }
+
+template <typename T, typename TG, typename TO>
+__global__ __launch_bounds__(PB_THREADS) void maxpool333_bwd_kernel(const T* __restrict__ x, const TG* __restrict__ gy, TO* __restrict__ gx, PoolParams p,
+                                                                    int TH, int TW, int tiles_h, int tiles_w, int CVC, int cchunks) {
+    static_assert(sizeof(T) == 2, "16-bit activations");
+    typedef u16x8 raw;
+    // XS [0, 12 K) and RM [16 K, 28 K) live during the forward half of a plane step, G1S [0, 16 K) and G2S [16 K, 32 K) during the
+    // backward half; each buffer's last reader is a barrier ahead of the next writer of its bytes (see the phase list above)
+    __shared__ __attribute__((aligned(16))) unsigned char U[32768];
+    __shared__ unsigned long long CR[3][PB_THREADS], BR[3][PB_THREADS];
+    raw* const XS = (raw*)U;
+    raw* const RM = (raw*)(U + 16384);
+    float* const G1S = (float*)U;
+    float* const G2S = (float*)(U + 16384);
+    const int tid = threadIdx.x;
+    const int CV = p.C / 8;
+    long long bid = blockIdx.x;
+    const int cc = (int)(bid % cchunks); bid /= cchunks;
+    const int twi = (int)(bid % tiles_w); bid /= tiles_w;
+    const int thi = (int)(bid % tiles_h);
+    const int n = (int)(bid / tiles_h);
+    const int h0 = thi * TH, w0 = twi * TW, cv0 = cc * CVC;
+    const int PW = TW + 2, PH = TH + 2, XW = TW + 4, XH = TH + 4;
+    const int nX = XH * XW * CVC, nR = XH * PW * CVC, nP = PH * PW * CVC;
+    // input-tile items (two per thread): offset inside a plane, or -1 outside the map (zero padding)
+    long long xoff[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid + k * PB_THREADS;
+        xoff[k] = -1;
+        if (i < nX) {
+            const int cvi = i % CVC, pos = i / CVC, h = h0 - 2 + pos / XW, w = w0 - 2 + pos % XW;
+            if (h >= 0 && h < p.H && w >= 0 && w < p.W && cv0 + cvi < CV) xoff[k] = ((long long)h * p.W + w) * p.x_cstride + p.x_coff + (cv0 + cvi) * 8;
+        }
+    }
+    // this thread's output position (ph, pw) of the (TH+2) x (TW+2) grid, and the tile position it writes
+    const bool pthread = tid < nP;
+    const int pcvi = tid % CVC, ppos = tid / CVC, ph = ppos / PW, pw = ppos % PW;
+    long long goff = -1, ooff = -1;
+    if (pthread && cv0 + pcvi < CV) {
+        const int oh = h0 - 1 + ph, ow = w0 - 1 + pw;
+        if (oh >= 0 && oh < p.H && ow >= 0 && ow < p.W) goff = ((long long)oh * p.W + ow) * p.C + (cv0 + pcvi) * 8;
+        if (ph < TH && pw < TW && h0 + ph < p.H && w0 + pw < p.W) ooff = ((long long)(h0 + ph) * p.W + (w0 + pw)) * p.C + (cv0 + pcvi) * 8;
+    }
+    const bool g2thread = pthread && ph < TH, g3thread = g2thread && pw < TW;
+    const long long xplane = (long long)p.H * p.W * p.x_cstride, gplane = (long long)p.H * p.W * p.C;
+    const T* const xn = x + (long long)n * p.D * xplane;
+    const TG* const gyn = gy + (long long)n * p.D * gplane;
+    TO* const gxn = gx + (long long)n * p.D * gplane;
+    const raw zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    raw xpre[2] = {zero, zero};
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (xoff[k] >= 0) xpre[k] = *(const raw*)(xn + xoff[k]);                 // plane 0
+    raw M0 = zero, M1 = zero, M2 = zero;                                           // plane maxima of planes t-2, t-1, t (plane -1: the zero pad)
+    unsigned long long a0 = 0x0303030303030303ull, a1 = a0, a2 = a0;               // winning planes of outputs t-3, t-2, t-1 (3: none / no such output)
+    float g0[8], g1[8], g2[8], gpre[8];                                            // gradients of outputs t-3, t-2, t-1; the next one in flight
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g0[i] = g1[i] = g2[i] = gpre[i] = 0.f;
+    if (goff >= 0) load_vec_f32<TG, 8>(gyn + goff, gpre);                          // output plane 0
+    for (int t = 0; t <= p.D + 1; ++t) {
+        M0 = M1; M1 = M2;
+        if (t < p.D) {
+            // ---- forward half: plane t -> row maxima -> plane maximum of this thread's position
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (tid + k * PB_THREADS < nX) XS[tid + k * PB_THREADS] = xpre[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                xpre[k] = zero;
+                if (t + 1 < p.D && xoff[k] >= 0) xpre[k] = *(const raw*)(xn + (long long)(t + 1) * xplane + xoff[k]);      // next plane: in flight during the passes
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = tid + k * PB_THREADS;
+                if (i < nR) {
+                    const int cvi = i % CVC, pos = i / CVC, xh = pos / PW, rw = pos % PW;
+                    const raw* src = XS + (xh * XW + rw) * CVC + cvi;
+                    float best[8]; unsigned win[8];
+                    first_max3<T>(src[0], src[CVC], src[2 * CVC], best, win);
+                    raw m;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) m[e] = exact_bits16<T>(best[e]);
+                    RM[i] = m;
+                    if (xh >= 2 && xh < TH + 2) CR[t % 3][((xh - 2) * PW + rw) * CVC + cvi] = pack_tags(win);
+                }
+            }
+            __syncthreads();
+            if (pthread) {
+                const raw* src = RM + (ph * PW + pw) * CVC + pcvi;
+                float best[8]; unsigned win[8];
+                first_max3<T>(src[0], src[PW * CVC], src[2 * PW * CVC], best, win);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) M2[e] = exact_bits16<T>(best[e]);
+                BR[t % 3][tid] = pack_tags(win);
+            }
+        } else {
+            M2 = zero;                                                             // planes D, D + 1: the zero pad behind the sample
+        }
+        // ---- depth: the winning plane of output t - 1 (planes t-2, t-1, t)
+        a0 = a1; a1 = a2; a2 = 0x0303030303030303ull;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { g0[i] = g1[i]; g1[i] = g2[i]; g2[i] = 0.f; }
+        if (t >= 1 && t - 1 < p.D) {
+            float best[8]; unsigned win[8];
+            first_max3<T>(M0, M1, M2, best, win);
+            a2 = pack_tags(win);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) g2[i] = gpre[i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gpre[i] = 0.f;
+            if (t < p.D && goff >= 0) load_vec_f32<TG, 8>(gyn + (long long)t * gplane + goff, gpre);       // output plane t, used in the next step
+        }
+        const int q = t - 2;
+        if (q < 0 || q >= p.D) continue;                  // (uniform: every thread of the workgroup takes the same branch)
+        // ---- backward half for input plane q: outputs q-1, q, q+1 own it through a = 2, 1, 0
+        if (pthread) {
+            float s[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s[i] = tag_of(a0, i) == 2 ? g0[i] : 0.f;
+                s[i] += tag_of(a1, i) == 1 ? g1[i] : 0.f;
+                s[i] += tag_of(a2, i) == 0 ? g2[i] : 0.f;
+            }
+            *(f32x4*)(G1S + (size_t)tid * 8) = f32x4{s[0], s[1], s[2], s[3]};
+            *(f32x4*)(G1S + (size_t)tid * 8 + 4) = f32x4{s[4], s[5], s[6], s[7]};
+        }
+        __syncthreads();
+        if (g2thread) {                                   // row ph of the tile: positions ph, ph+1, ph+2 of the output grid reach it through b = 2, 1, 0
+            float s[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int o = tid + j * PW * CVC;
+                const unsigned long long b = BR[q % 3][o];
+                const f32x4 lo = *(const f32x4*)(G1S + (size_t)o * 8), hi = *(const f32x4*)(G1S + (size_t)o * 8 + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s[i] += tag_of(b, i) == (unsigned)(2 - j) ? lo[i] : 0.f;
+                    s[i + 4] += tag_of(b, i + 4) == (unsigned)(2 - j) ? hi[i] : 0.f;
+                }
+            }
+            *(f32x4*)(G2S + (size_t)tid * 8) = f32x4{s[0], s[1], s[2], s[3]};
+            *(f32x4*)(G2S + (size_t)tid * 8 + 4) = f32x4{s[4], s[5], s[6], s[7]};
+        }
+        __syncthreads();
+        if (g3thread && ooff >= 0) {                      // column pw: positions pw, pw+1, pw+2 of the row reach it through c = 2, 1, 0
+            float s[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int o = tid + j * CVC;
+                const unsigned long long c = CR[q % 3][o];
+                const f32x4 lo = *(const f32x4*)(G2S + (size_t)o * 8), hi = *(const f32x4*)(G2S + (size_t)o * 8 + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s[i] += tag_of(c, i) == (unsigned)(2 - j) ? lo[i] : 0.f;
+                    s[i + 4] += tag_of(c, i + 4) == (unsigned)(2 - j) ? hi[i] : 0.f;
+                }
+            }
+            store_vec_f32<TO, 8>(gxn + (long long)q * gplane + ooff, s);
+        }
+        // (the next step's first barrier stands between these reads of G2S / CR and the row pass that overwrites RM;
+        //  its XS writes overlap G1S, whose readers are behind the barrier above)
+    }
+}
+
+struct PoolBwdPlan { int TH, TW, tiles_h, tiles_w, CVC, cchunks; long long blocks; };
+static PoolBwdPlan pool333_bwd_plan(const PoolParams& p) {
+    PoolBwdPlan pl;
+    const int CV = p.C / 8;
+    auto shape = [&](int maxt) {
+        pl.tiles_h = ceil_div(p.H, maxt); pl.tiles_w = ceil_div(p.W, maxt);
+        pl.TH = ceil_div(p.H, pl.tiles_h); pl.TW = ceil_div(p.W, pl.tiles_w);
+        int cvc = PB_THREADS / ((pl.TH + 2) * (pl.TW + 2));
+        while (cvc > 1 && (pl.TH + 4) * (pl.TW + 4) * cvc > PB_XSLOTS) --cvc;
+        if (cvc > 4) cvc = 4;                              // 64 contiguous bytes per pixel are enough; more chunks = more workgroups
+        if (cvc > CV) cvc = CV;
+        pl.CVC = cvc; pl.cchunks = ceil_div(CV, cvc);
+        pl.blocks = (long long)p.N * pl.tiles_h * pl.tiles_w * pl.cchunks;
+    };
+    shape(14);
+    if (pl.blocks < 512 && (p.H > 7 || p.W > 7)) shape(7);       // small batches: smaller tiles rather than idle CUs
+    return pl;
+}
+
+template <typename T, typename TG, typename TO>
+static void bwd333_launch(const void* x, const void* gy, void* gx, const PoolParams& p, const PoolBwdPlan& pl, step_stream_t stream) {
+    STEP_LAUNCH((maxpool333_bwd_kernel<T, TG, TO>), dim3((unsigned)pl.blocks), dim3(PB_THREADS), stream, (const T*)x, (const TG*)gy, (TO*)gx, p,
+                pl.TH, pl.TW, pl.tiles_h, pl.tiles_w, pl.CVC, pl.cchunks);
+}
+
 // Clip ingest: decoded frames arrive as uint8 [N,T,H,W,3] (what cv2 / the data loader hands over,
 // data/ava.py:298-338); the reference converts on the host -- ConvertFromInts(scale), SubtractMeans, DivideStds
 // (data/augmentations.py:68-111,600-612) -- and ships fp32 [T,3,H,W] over PCIe (4x the bytes).  Here the uint8 frames
@@ -612,9 +852,22 @@ template <typename T>
 static int bwd_gather_t(const void* x, int gy_dtype, const void* gy, int gx_dtype, void* gx, unsigned char* arg, const PoolParams& p,
                         step_stream_t stream) {
     constexpr int V = elem<T>::VEC;
+    const bool gf = gy_dtype == STEP_F32, of = gx_dtype == STEP_F32;
+    if constexpr (sizeof(T) == 2) {
+        // the Inception blocks' (3,3,3) / (1,1,1) pool: one LDS-tiled launch, no byte map (STEP_OPT_POOL_DIRECT = 1 keeps the two gathers: tests)
+        if (p.kd == 3 && p.kh == 3 && p.kw == 3 && p.sd == 1 && p.sh == 1 && p.sw == 1 && opt(STEP_OPT_POOL_DIRECT) == 0) {
+            const PoolBwdPlan pl = pool333_bwd_plan(p);
+            if (pl.blocks > 0 && pl.blocks <= 0x7fffffffLL && (pl.TH + 2) * (pl.TW + 2) * pl.CVC <= PB_THREADS && (pl.TH + 4) * (pl.TW + 4) * pl.CVC <= PB_XSLOTS) {
+                if (gf && of) bwd333_launch<T, float, float>(x, gy, gx, p, pl, stream);
+                else if (gf) bwd333_launch<T, float, T>(x, gy, gx, p, pl, stream);
+                else if (of) bwd333_launch<T, T, float>(x, gy, gx, p, pl, stream);
+                else bwd333_launch<T, T, T>(x, gy, gx, p, pl, stream);
+                return STEP_LAUNCH_CHECK();
+            }
+        }
+    }
     const long long touts = (long long)p.N * p.Do * p.Ho * p.Wo * (p.C / V), tins = (long long)p.N * p.D * p.H * p.W * (p.C / V);
     STEP_LAUNCH((maxpool_arg_kernel<T>), dim3(pool_flat_grid(touts, 256)), dim3(256), stream, (const T*)x, arg, p, touts);
-    const bool gf = gy_dtype == STEP_F32, of = gx_dtype == STEP_F32;
     if (gf && of) bwd_gather_launch<T, float, float>(arg, gy, gx, p, tins, stream);
     else if (gf) bwd_gather_launch<T, float, T>(arg, gy, gx, p, tins, stream);
     else if (of) bwd_gather_launch<T, T, float>(arg, gy, gx, p, tins, stream);

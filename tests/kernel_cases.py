@@ -497,6 +497,36 @@ def case_maxpool_backward(bk, golden):
                 out = uncl(go.get() if odt == 0 else decode(go.get(), dt))
                 want = refq if odt == 0 else quantize(refq, dt)
                 assert np.allclose(out, want, rtol=2e-2 if odt else 1e-6, atol=1e-6), (k, s, dt, gdt, odt, np.abs(out - want).max())
+    # the one-launch (3,3,3) / (1,1,1) form (16-bit activations): several tiles per map with ragged last ones, a ragged last channel
+    # chunk, one- and two-plane samples, windows with no winner (NaN / -inf everywhere) and NaNs beside real values; against torch
+    # and against the two-gather form (pool_direct = 1), which adds the same terms in another order
+    for (n2, c2, d2, h2, w2) in ((2, 24, 4, 17, 30), (1, 8, 1, 15, 9), (3, 40, 2, 7, 7), (1, 16, 3, 31, 3)):
+        xb = rs.randn(n2, c2, d2, h2, w2).astype(np.float32)
+        xb[0, :, :, :h2 // 2] = np.maximum(xb[0, :, :, :h2 // 2], 0)              # ties with the pad and with each other
+        xb[0, 0, :, :3, :3] = -np.inf
+        xb[0, 1, :, :4, :4] = np.nan
+        xb[0, 2, 0, 1, 1] = np.nan
+        gb = rs.randn(n2, c2, d2, h2, w2).astype(np.float32)
+        for dt in (BF16, F16):
+            xq, gq = quantize(xb, dt), quantize(gb, dt)
+            xt = torch.from_numpy(np.nan_to_num(xq, nan=-np.inf)).requires_grad_(True)       # torch's pool PROPAGATES NaN; the walk `val > max` skips it
+            F.max_pool3d(F.pad(xt, [1, 1, 1, 1, 1, 1]), 3, 1).backward(torch.from_numpy(gq))
+            refq = xt.grad.numpy()
+            xe, ge = bk.dev(encode(cl(xq), dt)), bk.dev(encode(np.ascontiguousarray(cl(gq)), dt))
+            outs = []
+            for direct in (0, 1):
+                _capi.set_option(L, "pool_direct", direct)
+                try:
+                    go = bk.dev(np.full((n2, d2, h2, w2, c2), 3, np.float32))
+                    argb = bk.dev(np.zeros(n2 * d2 * h2 * w2 * c2, np.uint8))
+                    assert L.step_maxpool3d_tf_backward_gather(dt, xe.ptr, n2, d2, h2, w2, c2, c2, 0, 3, 3, 3, 1, 1, 1, dt, ge.ptr, 0, go.ptr, argb.ptr, bk.stream) == 0
+                    outs.append(uncl(go.get()).copy())
+                finally:
+                    _capi.set_option(L, "pool_direct", 0)
+            assert np.allclose(outs[0], outs[1], rtol=1e-6, atol=1e-6), ((n2, c2, d2, h2, w2), dt, np.abs(outs[0] - outs[1]).max())
+            # (channels 0 and 1 hold windows with no winner: torch hands those to the window's first element, both forms here to nobody)
+            assert np.allclose(outs[0][:, 2:], refq[:, 2:], rtol=1e-6, atol=1e-6), ((n2, c2, d2, h2, w2), dt, np.abs(outs[0][:, 2:] - refq[:, 2:]).max())
+            assert np.all(outs[0][np.isnan(xq)] == 0)
     # the pool input as a channel slice [8, 16) of a 24-channel buffer (x_cstride / x_coff): same gradient as the dense tensor
     k, s = POOLS[0]
     xw = np.full((N, D, H, W, 24), 9.0, np.float32)
