@@ -950,6 +950,25 @@ def case_act_grad(bk, golden):
                     assert bk.lib.step_act_grad(dt, yd.ptr, 0, g_dt, gd.ptr, 0, sd.ptr if sd else None, M, C, relu, o32.ptr, oT.ptr, bk.stream) == 0
                     assert np.array_equal(o32.get(), ref), (dt, g_dt, relu)
                     assert np.array_equal(decode(oT.get(), dt), quantize(ref, dt)), (dt, g_dt, relu)
+    # 16-bit, 16-byte vectors per lane with the (pixel, channel) pair carried along the grid-stride walk: enough vectors for several
+    # trips (the emulator build caps the grid at two workgroups; on the GPU the walk starts at 2 M vectors), y and gy as channel
+    # slices of wider buffers; C = 12 keeps the 4-wide form
+    for (M2, C2, wide) in ((700, 24, 40), (2100, 8, 24), (300, 12, 12)) + (((1 << 18) + 3, 72, 80),) * (bk.name == "gfx950"):
+        yw, gw = rs.randn(M2, wide).astype(np.float32), rs.randn(M2, wide).astype(np.float32)
+        yw[::3] = 0.0
+        sc2 = (1 + 0.3 * rs.randn(C2)).astype(np.float32)
+        for dt in (BF16, F16):
+            yq, gq = quantize(yw, dt), quantize(gw, dt)
+            esz = 2
+            yd2, gd2, sd2 = bk.dev(encode(yq, dt)), bk.dev(encode(gq, dt)), bk.dev(sc2)
+            yo, go = wide - C2 - (wide - C2) % 8, 0 if wide == C2 else 8
+            ref = (gq[:, go:go + C2] * sc2[None, :]).astype(np.float32) * (yq[:, yo:yo + C2] > 0)
+            o32b = bk.dev(np.full((M2, C2), 9.0, np.float32))
+            oTb = bk.dev(encode(np.full((M2, C2), 9.0, np.float32), dt))
+            offp = lambda p_, nbytes: ctypes.c_void_p((p_.value if isinstance(p_, ctypes.c_void_p) else int(p_)) + nbytes)
+            assert bk.lib.step_act_grad(dt, offp(yd2.ptr, yo * esz), wide, dt, offp(gd2.ptr, go * esz), wide, sd2.ptr, M2, C2, 1, o32b.ptr, oTb.ptr, bk.stream) == 0
+            assert np.array_equal(o32b.get(), ref.astype(np.float32)), (M2, C2, dt)
+            assert np.array_equal(decode(oTb.get(), dt), quantize(ref.astype(np.float32), dt)), (M2, C2, dt)
     yd, gd = bk.dev(y), bk.dev(gy)
     o32 = bk.dev(np.zeros((M, C), np.float32))
     assert bk.lib.step_act_grad(F32, yd.ptr, 0, F32, gd.ptr, 0, None, M, C, 1, o32.ptr, None, bk.stream) == 0      # fp32 output only
