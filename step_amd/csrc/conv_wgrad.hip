@@ -181,9 +181,27 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ ws, 
                                                   int cit, int Cout, int Cin, int ntaps, int accumulate, unsigned bx, unsigned nbx) {
     const int per_tile = MB * NB * 16 * 64;
     const long long per_job = (long long)gy * per_tile;
-    for (long long idx = (long long)bx * blockDim.x + threadIdx.x; idx < per_job; idx += (long long)blockDim.x * nbx) {
+    // (256 threads = 64 consecutive elements x 4 subgroups of the jobs, partial sums added in subgroup order through LDS: see wgrad16_reduce_body)
+    __shared__ float part1[256];
+    const int ln = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long chunks = (per_job + 63) / 64;
+    for (long long ch = bx; ch < chunks; ch += nbx) {
+        const long long idx = ch * 64 + ln;
         float sum = 0.f;
-        for (long long j = 0; j < jobs; ++j) sum += ws[(size_t)j * per_job + idx];
+        if (idx < per_job) {
+            long long j = w;
+            for (; j + 12 < jobs; j += 16) {
+                const float v0 = ws[(size_t)j * per_job + idx], v1 = ws[(size_t)(j + 4) * per_job + idx];
+                const float v2 = ws[(size_t)(j + 8) * per_job + idx], v3 = ws[(size_t)(j + 12) * per_job + idx];
+                sum = (((sum + v0) + v1) + v2) + v3;
+            }
+            for (; j < jobs; j += 4) sum += ws[(size_t)j * per_job + idx];
+        }
+        part1[threadIdx.x] = sum;
+        __syncthreads();
+        if (w != 0 || idx >= per_job) { __syncthreads(); continue; }
+        sum = ((sum + part1[64 + ln]) + part1[128 + ln]) + part1[192 + ln];
+        __syncthreads();
         int t = (int)(idx % per_tile);
         int y = (int)(idx / per_tile);
         const int lane = t & 63, r = (t >> 6) & 15, tile = t >> 10;
@@ -438,39 +456,244 @@ __global__ __launch_bounds__(384) void conv_wgrad16_lds_wide_kernel(Wgrad16Param
 template <typename T, int KW>
 __global__ __launch_bounds__(384) STEP_WAVES_PER_SIMD(3) void conv_wgrad16_lds2_kernel(Wgrad16Params p) { conv_wgrad16_lds_body<T, KW, false>(p); }
 
+
+// conv_wgrad16_pws_kernel -- pointwise (1x1x1 / Linear) weight gradient as a PIXEL STREAM (round 4).
+// dW[Cout, Cin] = dY[M, Cout]^T X[M, Cin] is a GEMM whose K axis is the pixel axis: M = 10^4..10^6, Cout x Cin small.  Most of these
+// layers are HBM-bound (2 x 128 x 256 / ((128 + 256) x 2 B) = 85 FLOP per operand byte at the largest tile), so the job is to read
+// every operand byte once at the memory rate: the forms above cut Cout x Cin into 64 x 192 (or 64 x 64) tiles, re-read both operands
+// once per tile of the other and stage a unit at a time without overlap -- 1/3 to 1/5 of the copy rate on the backbone's layers
+// (the vendor GEMM is 2-5x slower still on these shapes: tools/gemm_probe.py).
+// Here a 512-thread workgroup owns up to 128 x 256 of dW (8 waves as 2 x 4, 64 x 64 accumulators each: 64 VGPRs) and walks a slice of
+// the pixel axis in 32-pixel stages: two stages of global loads in flight in registers (48 B per thread each), a double-buffered LDS
+// image (pixel-major, pitch = 144 mod 256 bytes so that the rows of a transpose-read block fall on distinct banks), ONE barrier per
+// stage, fragments by ds_read_b64_tr_b16, 16 MFMAs (16x16x32) per wave and stage.  Two workgroups per CU (<= 128 VGPRs, 2 x 66 KB).
+// Slices end in a dense fp32 [Cout, Cin] image per slice (the reduce is a coalesced sum of images) or, without a workspace, in atomics.
+constexpr int PWS_P = 32;
+constexpr int PWS_APITCH = 400;          // 128 output channels x 2 B + 144
+constexpr int PWS_BPITCH = 656;          // 256 input channels x 2 B + 144
+constexpr int PWS_STAGE = PWS_P * (PWS_APITCH + PWS_BPITCH);
+struct WgradPwsParams {
+    const void* x; const void* dy; float* dw; float* ws;
+    long long M, ppj;             // pixels; pixels per slice (a multiple of 32)
+    int Cin, Cout, x_cstride, x_coff, dy_cstride, dy_coff;
+    int cot, cit, co_t, ci_t;     // tiles along Cout / Cin and their extents (co_t: a multiple of 32 <= 128, ci_t: a multiple of 64 <= 256)
+};
+
+template <typename T>
+__global__ __launch_bounds__(512) STEP_WAVES_PER_SIMD_MIN(4) void conv_wgrad16_pws_kernel(WgradPwsParams p) {
+    static_assert(sizeof(T) == 2, "16-bit storage");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PWS_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifdef STEP_EMUL
+    const int wave = tid >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const int wm = wave & 1, wn = wave >> 1;
+    // launch order -> XCD as in conv_wgrad16_lds_kernel: the tiles of one pixel slice consecutive on ONE XCD (they read the same pixels)
+    int bx = blockIdx.x, by = blockIdx.y;
+    if ((gridDim.x & 7) == 0) {
+        const long long L = (long long)blockIdx.x + (long long)gridDim.x * blockIdx.y;
+        const int xcd = (int)(L & 7);
+        const long long slot = L >> 3;
+        by = (int)(slot % gridDim.y);
+        bx = (int)(slot / gridDim.y) * 8 + xcd;
+    }
+    const int cit_i = by % p.cit, cot_i = by / p.cit;
+    const int co0 = cot_i * p.co_t, ci0 = cit_i * p.ci_t;
+    const int cow = p.co_t >> 1, ciw = p.ci_t >> 2;           // channels per wave along Cout / Cin (multiples of 16)
+    const int nma = cow >> 4, nnb = ciw >> 4;                  // 16-channel blocks per wave (1..4 each)
+    const int g = lane >> 4, rr = (lane & 15) >> 2, q = lane & 3;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ma = 0; ma < 4; ++ma)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[ma][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const long long k_beg = (long long)bx * p.ppj, k_end = min(k_beg + p.ppj, p.M);
+    const int S = k_beg < k_end ? (int)((k_end - k_beg + PWS_P - 1) / PWS_P) : 0;
+    // staging: thread -> (pixel, 16-byte vector) of dY (one vector per stage) and of X (two); 32-bit element offsets from the slice's
+    // first pixel (a slice is at most 2^31 elements of either operand: the planner checks)
+    const int len = (int)(k_end > k_beg ? k_end - k_beg : 0);
+    const T* const ag = (const T*)p.dy + k_beg * p.dy_cstride + p.dy_coff + co0;
+    const T* const bgp = (const T*)p.x + k_beg * p.x_cstride + p.x_coff + ci0;
+    const int apx = tid >> 4, acv = tid & 15;
+    const bool a_in = acv * 8 < p.co_t, a_ld = a_in && co0 + acv * 8 < p.Cout;
+    const unsigned aoff = (unsigned)apx * (unsigned)p.dy_cstride + (unsigned)acv * 8u;
+    const int bpx0 = tid >> 5, bcv = tid & 31;                 // second vector: 16 pixels further
+    const bool b_in = bcv * 8 < p.ci_t, b_ld = b_in && ci0 + bcv * 8 < p.Cin;
+    const unsigned boff = (unsigned)bpx0 * (unsigned)p.x_cstride + (unsigned)bcv * 8u;
+    struct Stage { u32x4 a, b0, b1; };
+    auto load = [&](int s) {
+        Stage st;
+        st.a = st.b0 = st.b1 = u32x4{0u, 0u, 0u, 0u};
+        const int r0 = s * PWS_P;                              // first pixel of the stage, relative to the slice
+        if (a_ld && r0 + apx < len) st.a = *(const u32x4*)(ag + ((unsigned)r0 * (unsigned)p.dy_cstride + aoff));
+        if (b_ld && r0 + bpx0 < len) st.b0 = *(const u32x4*)(bgp + ((unsigned)r0 * (unsigned)p.x_cstride + boff));
+        if (b_ld && r0 + bpx0 + 16 < len) st.b1 = *(const u32x4*)(bgp + ((unsigned)(r0 + 16) * (unsigned)p.x_cstride + boff));
+        return st;
+    };
+    auto store = [&](const Stage& st, int buf) {
+        unsigned char* A = lds + buf * PWS_STAGE;
+        unsigned char* B = A + PWS_P * PWS_APITCH;
+        if (a_in) *(u32x4*)(A + apx * PWS_APITCH + acv * 16) = st.a;
+        if (b_in) {
+            *(u32x4*)(B + bpx0 * PWS_BPITCH + bcv * 16) = st.b0;
+            *(u32x4*)(B + (bpx0 + 16) * PWS_BPITCH + bcv * 16) = st.b1;
+        }
+    };
+    auto compute = [&](int buf) {
+        const unsigned char* A = lds + buf * PWS_STAGE + wm * cow * 2 + q * 8;
+        const unsigned char* B = lds + buf * PWS_STAGE + PWS_P * PWS_APITCH + wn * ciw * 2 + q * 8;
+        const int k0 = 8 * g + rr, k1 = k0 + 4;                // this lane's pixels of the two transpose blocks
+        // (always the full 4 x 4 blocks: a narrower tile's surplus blocks multiply whatever the LDS rows hold behind its channels into
+        //  accumulators that are never written out -- branch-free, and these layers are bound by their operand traffic, not by this)
+        u16x8 a[4];
+#pragma unroll
+        for (int ma = 0; ma < 4; ++ma) a[ma] = lds_tr8(A + k0 * PWS_APITCH + ma * 32, A + k1 * PWS_APITCH + ma * 32);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const u16x8 b = lds_tr8(B + k0 * PWS_BPITCH + nb * 32, B + k1 * PWS_BPITCH + nb * 32);
+#pragma unroll
+            for (int ma = 0; ma < 4; ++ma) mma16_k32(a[ma], b, acc[ma][nb], T());
+        }
+    };
+    Stage s0 = load(0), s1 = load(1);
+    for (int s = 0; s < S; s += 2) {
+        store(s0, 0);
+        s0 = load(s + 2);
+        __syncthreads();
+        compute(0);
+        if (s + 1 < S) {                                        // (workgroup-uniform)
+            store(s1, 1);
+            s1 = load(s + 3);
+            __syncthreads();
+            compute(1);
+        }
+    }
+    float* const out = p.ws ? p.ws + (size_t)bx * p.Cout * p.Cin : p.dw;
+#pragma unroll
+    for (int ma = 0; ma < 4; ++ma)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+            if (ma < nma && nb < nnb) {
+                const int ci = ci0 + wn * ciw + nb * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + wm * cow + ma * 16 + 4 * g + r;
+                    if (co < p.Cout && ci < p.Cin) {
+                        if (p.ws) out[(size_t)co * p.Cin + ci] = acc[ma][nb][r];
+                        else atomicAdd(out + (size_t)co * p.Cin + ci, acc[ma][nb][r]);
+                    }
+                }
+            }
+}
+
+// fixed-order sum of the slices' dense [Cout, Cin] images.  A small layer has few elements and hundreds of slices: one thread per element
+// walking all slices is a chain of dependent-latency loads on a handful of workgroups (measured: 100 us of a 160 us call).  So a 256-thread
+// workgroup takes 16 consecutive 16-byte vectors x 16 slice subgroups (subgroup g adds slices g, g + 16, ... in ascending order, four loads
+// in flight), and the 16 partial sums are added in subgroup order through LDS: the same association on every run.
+__device__ __forceinline__ void wgradpws_reduce_body(const float* __restrict__ ws, float* __restrict__ dw, long long slices, long long n4, int accumulate,
+                                                     unsigned bx, unsigned nbx) {
+    __shared__ f32x4 part[256];
+    const int t = threadIdx.x, vi = t & 15, sg = t >> 4;
+    const long long chunks = (n4 + 15) / 16;
+    for (long long ch = bx; ch < chunks; ch += nbx) {
+        const long long i = ch * 16 + vi;
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        if (i < n4) {
+            long long sl = sg;
+            for (; sl + 48 < slices; sl += 64) {
+                const f32x4 v0 = ((const f32x4*)ws)[sl * n4 + i], v1 = ((const f32x4*)ws)[(sl + 16) * n4 + i];
+                const f32x4 v2 = ((const f32x4*)ws)[(sl + 32) * n4 + i], v3 = ((const f32x4*)ws)[(sl + 48) * n4 + i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum[e] = (((sum[e] + v0[e]) + v1[e]) + v2[e]) + v3[e];
+            }
+            for (; sl < slices; sl += 16) {
+                const f32x4 v = ((const f32x4*)ws)[sl * n4 + i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum[e] += v[e];
+            }
+        }
+        part[t] = sum;
+        __syncthreads();
+        if (sg == 0 && i < n4) {
+            f32x4 tot = accumulate ? ((const f32x4*)dw)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const f32x4 v = part[k * 16 + vi];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tot[e] += v[e];
+            }
+            ((f32x4*)dw)[i] = tot;
+        }
+        __syncthreads();
+    }
+}
+__global__ void wgradpws_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long slices, long long n4, int accumulate) {
+    wgradpws_reduce_body(ws, dw, slices, n4, accumulate, blockIdx.x, gridDim.x);
+}
+
 // sums the partial tiles of conv_wgrad16_lds_kernel over the pixel-axis workgroups: one thread per (tile, lane) 16-byte group
 __device__ __forceinline__ void wgrad16_reduce_body(const float* __restrict__ ws, float* __restrict__ dw, int gx, int gy, int cot, int cit, int Cout,
                                                     int Cin, int kd, int accumulate, int pw, unsigned bx, unsigned nbx) {
     const int tpw = pw ? 8 : 24;                                        // accumulator tiles per wave
     const long long per_x = (long long)gy * 6 * tpw * 64;              // f32x4 groups of one pixel-axis workgroup
     const int ntaps = pw ? 1 : kd * 9;
-    for (long long idx = (long long)bx * blockDim.x + threadIdx.x; idx < per_x; idx += (long long)blockDim.x * nbx) {
+    // 256 threads = 64 consecutive 16-byte groups x 4 subgroups of the pixel-axis workgroups (subgroup w adds x = w, w + 4, ... in ascending
+    // order, four loads in flight; the four partial sums are added in subgroup order through LDS): one thread walking all gx partial tiles
+    // was a chain of dependent-latency loads -- 60 us per grouped launch at one clip per GPU
+    __shared__ f32x4 part[256];
+    const int ln = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long chunks = (per_x + 63) / 64;
+    for (long long ch = bx; ch < chunks; ch += nbx) {
+        const long long idx = ch * 64 + ln;
         f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-        for (int x = 0; x < gx; ++x) {
-            const f32x4 v = ((const f32x4*)ws)[(size_t)x * per_x + idx];
-            sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
-        }
-        long long t = idx;
-        const int lane = (int)(t % 64); t /= 64;
-        const int tile = (int)(t % tpw); t /= tpw;
-        const int wave = (int)(t % 6); t /= 6;
-        const int y = (int)t;
-        const int nb = tile & 1, ma = (tile >> 1) & 3, s = tile >> 3;
-        const int khw = pw ? 0 : wave % 3, cb = pw ? wave : wave / 3;
-        int yy = y;
-        const int cit_i = yy % cit; yy /= cit;
-        const int cot_i = yy % cot;
-        const int kd_ = yy / cot;
-        const int tap = pw ? 0 : (kd_ * 3 + khw) * 3 + s;
-        const int ci = cit_i * (pw ? 192 : 64) + cb * 32 + nb * 16 + (lane & 15);
+        if (idx < per_x) {
+            int x = w;
+            for (; x + 12 < gx; x += 16) {
+                const f32x4 v0 = ((const f32x4*)ws)[(size_t)x * per_x + idx], v1 = ((const f32x4*)ws)[(size_t)(x + 4) * per_x + idx];
+                const f32x4 v2 = ((const f32x4*)ws)[(size_t)(x + 8) * per_x + idx], v3 = ((const f32x4*)ws)[(size_t)(x + 12) * per_x + idx];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = cot_i * 64 + ma * 16 + 4 * (lane >> 4) + r;
-            if (co < Cout && ci < Cin) {
-                float* o = dw + ((size_t)co * Cin + ci) * ntaps + tap;
-                *o = accumulate ? *o + sum[r] : sum[r];
+                for (int e = 0; e < 4; ++e) sum[e] = (((sum[e] + v0[e]) + v1[e]) + v2[e]) + v3[e];
+            }
+            for (; x < gx; x += 4) {
+                const f32x4 v = ((const f32x4*)ws)[(size_t)x * per_x + idx];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum[e] += v[e];
             }
         }
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        if (w == 0 && idx < per_x) {
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const f32x4 v = part[k * 64 + ln];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum[e] += v[e];
+            }
+            long long t = idx;
+            const int lane = (int)(t % 64); t /= 64;
+            const int tile = (int)(t % tpw); t /= tpw;
+            const int wave = (int)(t % 6); t /= 6;
+            const int y = (int)t;
+            const int nb = tile & 1, ma = (tile >> 1) & 3, s = tile >> 3;
+            const int khw = pw ? 0 : wave % 3, cb = pw ? wave : wave / 3;
+            int yy = y;
+            const int cit_i = yy % cit; yy /= cit;
+            const int cot_i = yy % cot;
+            const int kd_ = yy / cot;
+            const int tap = pw ? 0 : (kd_ * 3 + khw) * 3 + s;
+            const int ci = cit_i * (pw ? 192 : 64) + cb * 32 + nb * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = cot_i * 64 + ma * 16 + 4 * (lane >> 4) + r;
+                if (co < Cout && ci < Cin) {
+                    float* o = dw + ((size_t)co * Cin + ci) * ntaps + tap;
+                    *o = accumulate ? *o + sum[r] : sum[r];
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 __global__ void wgrad16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int gx, int gy, int cot, int cit, int Cout, int Cin,
@@ -484,6 +707,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(WgradReduceGrou
     const step_wgrad_reduce_item& it = g.it[blockIdx.y];
     if (it.kind == 1) wgrad_reduce_body(it.ws, it.dw, it.jobs, it.gy, 2, it.nbw, it.cot, it.cit, it.Cout, it.Cin, it.taps, it.accumulate, blockIdx.x, gridDim.x);
     else if (it.kind == 2) wgrad16_reduce_body(it.ws, it.dw, (int)it.jobs, it.gy, it.cot, it.cit, it.Cout, it.Cin, it.taps, it.accumulate, it.pw, blockIdx.x, gridDim.x);
+    else if (it.kind == 3) wgradpws_reduce_body(it.ws, it.dw, it.jobs, (long long)it.Cout * it.Cin / 4, it.accumulate, blockIdx.x, gridDim.x);
 }
 
 // stem_wgrad_kernel -- weight gradient of the 7x7x7 stride-2 stem (Cin = 3) from the clip in its own [N,T,3,H,W]
@@ -854,7 +1078,7 @@ static Wg16Plan wgrad16_plan(const step_conv_desc* d) {
     pl.pw = pw;
     if (!pw && !(d->kh == 3 && d->kw == 3 && (d->kd == 1 || d->kd == 3))) return pl;
     if (d->Cin % 8 || d->Cout % 8 || d->x_cstride % 8 || d->x_coff % 8 || d->y_cstride % 8 || d->y_coff % 8) return pl;
-    if (opt(STEP_OPT_WGRAD16_LDS) == 0) return pl;
+    if (opt(STEP_OPT_WGRAD16_LDS) == 0) return pl;             // (1 and 2 differ only for the pointwise layers: wgradpws_plan)
     if (d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0) return pl;
     if (pw) {
         const long long M = (long long)d->N * d->D * d->H * d->W;
@@ -976,6 +1200,49 @@ static size_t wgrad_jobs_ws_bytes(const WgJobs& j) { return (size_t)wgrad_ws_blo
 
 // defer != NULL: the fixed-order sum of the partial tiles is NOT launched; *defer describes it (step_wgrad_reduce_group runs several
 // layers' sums as one launch).  kind 0: nothing is pending (the atomics forms, an empty batch).
+
+// the pixel-stream form of the pointwise weight gradient (conv_wgrad16_pws_kernel): tiles, slices
+struct WgPwsPlan { bool ok = false; int cot = 0, cit = 0, co_t = 0, ci_t = 0; long long gx = 0, gy = 0, ppj = 0; };
+static WgPwsPlan wgradpws_plan(const step_conv_desc* d) {
+    WgPwsPlan pl;
+    if (!d || (d->dtype != STEP_BF16 && d->dtype != STEP_F16)) return pl;
+    if (!(d->kd == 1 && d->kh == 1 && d->kw == 1)) return pl;
+    if (d->Cin % 8 || d->Cout % 8 || d->x_cstride % 8 || d->x_coff % 8 || d->y_cstride % 8 || d->y_coff % 8) return pl;
+    if (opt(STEP_OPT_WGRAD16_LDS) != 1) return pl;             // 2: the pointwise layers on the forms of the start of round 4 (A/B, tests); 0: per-tap everywhere
+    if (d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0) return pl;
+    const long long M = (long long)d->N * d->D * d->H * d->W;
+#ifndef WGPWS_MINPIX
+#define WGPWS_MINPIX 2048
+#endif
+    if (M < WGPWS_MINPIX) return pl;
+    pl.cot = ceil_div(d->Cout, 128); pl.co_t = (ceil_div(d->Cout, pl.cot) + 31) / 32 * 32;
+    pl.cit = ceil_div(d->Cin, 256); pl.ci_t = (ceil_div(d->Cin, pl.cit) + 63) / 64 * 64;
+    pl.gy = (long long)pl.cot * pl.cit;
+    const long long stages = ceil_div64(M, PWS_P);
+    // slices: time ~ rounds of the chip (two workgroups per CU) x (stages per slice + the slice's image, written here and read back by the
+    // sum, in units of a stage's operand bytes)
+    const double img = 2.0 * pl.co_t * pl.ci_t * 4.0 / (double)(PWS_P * (pl.co_t + pl.ci_t) * 2);
+    const long long slots = 512;
+    double best = -1.0;
+    long long best_gx = 1;
+    const long long gx_max = stages / 4 > 1 ? stages / 4 : 1;
+    for (long long cand = 1; cand <= gx_max && cand * pl.gy <= 4096; cand = cand < 8 ? cand + 1 : cand + 8) {
+        const long long spj = ceil_div64(stages, cand);
+        long long gx = ceil_div64(stages, spj);
+        if (gx >= 8) gx = (gx + 7) / 8 * 8;
+        const double cost = (double)ceil_div64(gx * pl.gy, slots) * ((double)spj + img) + 2.0;
+        if (best < 0.0 || cost < best) { best = cost; best_gx = gx; }
+    }
+    pl.gx = best_gx;
+    pl.ppj = ceil_div64(stages, ceil_div64(stages, best_gx) > 0 ? best_gx : 1) * PWS_P;
+    {   // whole stages per slice, every pixel covered
+        const long long spj = ceil_div64(stages, pl.gx);
+        pl.ppj = spj * PWS_P;
+    }
+    pl.ok = pl.gy <= 65535 && pl.gx <= 0x7fffffffLL && pl.gx > 0;
+    return pl;
+}
+
 static void reduce_item_none(step_wgrad_reduce_item* it) { if (it) { *it = step_wgrad_reduce_item(); } }
 
 static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* dy, bool w16, float* dw, int accumulate, void* ws,
@@ -988,7 +1255,8 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
     if (d->x_coff < 0 || d->x_coff + d->Cin > d->x_cstride || d->y_coff < 0 || d->y_coff + d->Cout > d->y_cstride) return STEP_E_SHAPE;
     if (!dw) return STEP_E_NULL;
     const int ntaps = d->kd * d->kh * d->kw;
-    const bool lds_form = w16 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && wgrad16_plan(d).ok && d->N > 0;
+    const bool pws_form = w16 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && d->N > 0 && wgradpws_plan(d).ok;
+    const bool lds_form = pws_form || (w16 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && wgrad16_plan(d).ok && d->N > 0);
     // the per-tap kernel with a workspace: partial tiles + a fixed-order sum write every element of dw themselves; its jobs are
     // shorter than the atomics form's (wgrad_min_pixels)
     const WgJobs jws = wgrad_jobs(d, w16 ? WG_WS_16 : WG_WS_F32);
@@ -1004,6 +1272,27 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
     p.x = x; p.dy = dy; p.dw = dw; p.ws = tap_ws ? (float*)ws : nullptr;
     p.N = d->N; p.D = d->D; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.kd = d->kd; p.kh = d->kh; p.kw = d->kw;
     p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.dy_cstride = d->y_cstride; p.dy_coff = d->y_coff;
+    // pointwise layers: the pixel-stream form (wgradpws_plan)
+    if (pws_form) {
+        const WgPwsPlan pp = wgradpws_plan(d);
+        WgradPwsParams q;
+        q.x = x; q.dy = dy; q.dw = dw;
+        q.M = (long long)d->N * d->D * d->H * d->W; q.ppj = pp.ppj;
+        q.Cin = d->Cin; q.Cout = d->Cout; q.x_cstride = d->x_cstride; q.x_coff = d->x_coff; q.dy_cstride = d->y_cstride; q.dy_coff = d->y_coff;
+        q.cot = pp.cot; q.cit = pp.cit; q.co_t = pp.co_t; q.ci_t = pp.ci_t;
+        const size_t need = (size_t)pp.gx * d->Cout * d->Cin * sizeof(float);
+        q.ws = (ws && ws_bytes >= need && ((uintptr_t)ws % 16) == 0 && ((uintptr_t)dw % 16) == 0) ? (float*)ws : nullptr;
+        const dim3 gridp((unsigned)pp.gx, (unsigned)pp.gy);
+        if (d->dtype == STEP_BF16) STEP_LAUNCH((conv_wgrad16_pws_kernel<bf16_t>), gridp, dim3(512), stream, q);
+        else STEP_LAUNCH((conv_wgrad16_pws_kernel<f16_t>), gridp, dim3(512), stream, q);
+        if (q.ws && defer) {
+            defer->kind = 3; defer->ws = q.ws; defer->dw = dw; defer->jobs = pp.gx; defer->Cout = d->Cout; defer->Cin = d->Cin; defer->taps = 1; defer->accumulate = 1;
+        } else if (q.ws) {
+            const long long n4 = (long long)d->Cout * d->Cin / 4;
+            STEP_LAUNCH(wgradpws_reduce_kernel, dim3(flat_grid((n4 + 15) / 16 * 256, 256)), dim3(256), stream, (const float*)q.ws, dw, pp.gx, n4, 1);   // (dw was cleared above unless accumulate)
+        }
+        return STEP_LAUNCH_CHECK();
+    }
     // the LDS-tiled form (transpose reads): 3x3 windows or pointwise, channel counts in 16-byte vectors (wgrad16_plan)
     if (w16 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0) {
         const Wg16Plan pl = wgrad16_plan(d);
@@ -1039,7 +1328,7 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
                 defer->Cout = d->Cout; defer->Cin = d->Cin; defer->taps = d->kd; defer->accumulate = 1; defer->pw = (int)pl.pw;
             } else if (q.ws) {
                 const long long groups = pl.gy * 6 * (pl.pw ? 8 : 24) * 64;
-                STEP_LAUNCH(wgrad16_reduce_kernel, dim3(flat_grid(groups, 256)), dim3(256), stream, (const float*)q.ws, dw, (int)pl.gx, (int)pl.gy,
+                STEP_LAUNCH(wgrad16_reduce_kernel, dim3(flat_grid(groups * 4, 256)), dim3(256), stream, (const float*)q.ws, dw, (int)pl.gx, (int)pl.gy,
                             pl.cot, pl.cit, d->Cout, d->Cin, d->kd, 1, (int)pl.pw);      // (dw was cleared above unless accumulate)
             }
             return STEP_LAUNCH_CHECK();
@@ -1079,7 +1368,7 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
             defer->kind = 1; defer->ws = (const float*)ws; defer->dw = dw; defer->jobs = wgrad_ws_blocks(jb); defer->gy = (int)jb.gy; defer->nbw = jb.nbw;
             defer->cot = jb.cot; defer->cit = jb.cit; defer->Cout = d->Cout; defer->Cin = d->Cin; defer->taps = 1; defer->accumulate = accumulate; defer->pw = 1;
         } else if (rc == STEP_OK && tap_ws)
-            STEP_LAUNCH(wgrad_reduce_kernel, dim3(flat_grid(jb.gy * (long long)jb.per_tile, 256)), dim3(256), stream, (const float*)ws, dw, wgrad_ws_blocks(jb),
+            STEP_LAUNCH(wgrad_reduce_kernel, dim3(flat_grid(jb.gy * (long long)jb.per_tile * 4, 256)), dim3(256), stream, (const float*)ws, dw, wgrad_ws_blocks(jb),
                         (int)jb.gy, 2, jb.nbw, jb.cot, jb.cit, d->Cout, d->Cin, 1, accumulate);
         return rc != STEP_OK ? rc : STEP_LAUNCH_CHECK();
     }
@@ -1105,7 +1394,7 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
         defer->kind = 1; defer->ws = (const float*)ws; defer->dw = dw; defer->jobs = wgrad_ws_blocks(jb); defer->gy = (int)jb.gy; defer->nbw = jb.nbw;
         defer->cot = jb.cot; defer->cit = jb.cit; defer->Cout = d->Cout; defer->Cin = d->Cin; defer->taps = ntaps; defer->accumulate = accumulate; defer->pw = 0;
     } else if (tap_ws)
-        STEP_LAUNCH(wgrad_reduce_kernel, dim3(flat_grid(jb.gy * (long long)jb.per_tile, 256)), dim3(256), stream, (const float*)ws, dw, wgrad_ws_blocks(jb),
+        STEP_LAUNCH(wgrad_reduce_kernel, dim3(flat_grid(jb.gy * (long long)jb.per_tile * 4, 256)), dim3(256), stream, (const float*)ws, dw, wgrad_ws_blocks(jb),
                     (int)jb.gy, 2, jb.nbw, jb.cot, jb.cit, d->Cout, d->Cin, ntaps, accumulate);
     return STEP_LAUNCH_CHECK();
 }
@@ -1132,6 +1421,8 @@ int step_conv_wgrad16(const step_conv_desc* d, const void* x, const void* dy, fl
 
 size_t step_conv_wgrad16_workspace_bytes(const step_conv_desc* d) {
     if (!d || (d->dtype != STEP_BF16 && d->dtype != STEP_F16)) return 0;
+    const WgPwsPlan pp = wgradpws_plan(d);
+    if (pp.ok) return (size_t)pp.gx * d->Cout * d->Cin * sizeof(float);
     const Wg16Plan pl = wgrad16_plan(d);
     if (pl.ok) return (size_t)pl.gx * pl.gy * 6 * (pl.pw ? 8 : 24) * 64 * 16;
     if (d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->kd <= 0 || d->kh <= 0 || d->kw <= 0) return 0;
@@ -1148,7 +1439,8 @@ int step_conv_wgrad_kernel_name(const step_conv_desc* d, int dy16, char* buf, in
     if (!d || !buf || buflen <= 0) return STEP_E_NULL;
     const char* t = d->dtype == STEP_F32 ? "float" : (d->dtype == STEP_BF16 ? "step::bf16_t" : "step::f16_t");
     const Wg16Plan pl = dy16 ? wgrad16_plan(d) : Wg16Plan();
-    if (dy16 && pl.ok) {
+    if (dy16 && wgradpws_plan(d).ok) snprintf(buf, (size_t)buflen, "void step::conv_wgrad16_pws_kernel<%s>(step::WgradPwsParams)", t);
+    else if (dy16 && pl.ok) {
         const bool pw = d->kd == 1 && d->kh == 1 && d->kw == 1;
         snprintf(buf, (size_t)buflen, "void step::%s<%s, %d>(step::Wgrad16Params)",
                  pw ? "conv_wgrad16_lds2_kernel" : (pl.wide ? "conv_wgrad16_lds_wide_kernel" : "conv_wgrad16_lds_kernel"), t, pw ? 1 : 3);
@@ -1175,8 +1467,9 @@ int step_wgrad_reduce_group(const step_wgrad_reduce_item* items, int n, step_str
     for (int i = 0; i < n; ++i) {
         const step_wgrad_reduce_item& it = items[i];
         if (it.kind == 0) continue;
-        if ((it.kind != 1 && it.kind != 2) || !it.ws || !it.dw) return STEP_E_SHAPE;
-        const long long work = it.kind == 1 ? (long long)it.gy * (2 * it.nbw * 16 * 64) : (long long)it.gy * 6 * (it.pw ? 8 : 24) * 64;
+        if ((it.kind != 1 && it.kind != 2 && it.kind != 3) || !it.ws || !it.dw) return STEP_E_SHAPE;
+        const long long work = it.kind == 1 ? (long long)it.gy * (2 * it.nbw * 16 * 64) * 4
+                             : (it.kind == 2 ? (long long)it.gy * 6 * (it.pw ? 8 : 24) * 64 * 4 : ((long long)it.Cout * it.Cin / 4 + 15) / 16 * 256);
         if (work > most) most = work;
         g.it[m++] = it;
     }

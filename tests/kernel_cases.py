@@ -1279,7 +1279,9 @@ def case_conv_wgrad16(bk, golden):
     cases += [(1, 64, 72, 3, 20, 14, (3, 3, 3)),     # two row chunks per plane (20 rows of 14 > 224 pixels), a ragged second co tile
               (2, 16, 32, 1, 3, 100, (3, 3, 3)),     # 100-pixel rows: the wide-halo instantiation (two rows per chunk, then a ragged one), a single ci block
               (1, 24, 16, 2, 7, 56, (3, 3, 3)),      # 56-pixel rows: wide halo too (chunks of four and three rows instead of 3 + 2 + 2)
-              (1, 392, 72, 2, 9, 40, (1, 1, 1))]     # pointwise through the LDS-tiled form (Cin >= 384): 720 pixels = 5 chunks + a ragged one, three ci tiles of 192 (the last one ragged)
+              (1, 392, 72, 2, 9, 40, (1, 1, 1)),     # pointwise through the LDS-tiled form (Cin >= 384, < 2048 pixels): 720 pixels = 5 chunks + a ragged one, three ci tiles of 192 (the last one ragged)
+              (1, 72, 40, 2, 36, 40, (1, 1, 1)),     # pointwise as a pixel stream (>= 2048 pixels): one 64 x 128 tile with ragged channels, 90 stages
+              (1, 392, 136, 1, 30, 70, (1, 1, 1))]   # ... 2 x 2 tiles of 96 x 256 (both axes ragged), 2100 pixels = 65 stages + 20 pixels
     try:
         # 64 with wgrad16_lds = 0: the per-tap 16-bit form with several row-range jobs per tile; None: the LDS-tiled form
         for minpix in (64, None):
@@ -1307,7 +1309,7 @@ def case_conv_wgrad16(bk, golden):
                     assert np.abs(dw.get() - 2 * ref).max() / np.abs(ref).max() < 4e-5
                     # the workspace form (LDS-tiled kernel + fixed-order sum of partial tiles): same result, and bit-reproducible
                     nb = bk.lib.step_conv_wgrad16_workspace_bytes(ctypes.byref(d))
-                    if minpix is None and (k[1] == 3 or (N * D * H * W >= 512 and Cin >= 384)) and Cin % 8 == 0 and Cout % 8 == 0:
+                    if minpix is None and (k[1] == 3 or N * D * H * W >= 2048 or (N * D * H * W >= 512 and Cin >= 384)) and Cin % 8 == 0 and Cout % 8 == 0:
                         assert nb > 0 and nb % 16 == 0, (k, nb)
                     if nb:
                         outs = []
@@ -1336,7 +1338,8 @@ def case_wgrad_partial_and_grouped_reduce(bk, golden):
     accumulate on and off, the gradient read in place as a channel SLICE of a wider buffer (what _MixedTrainFn hands over)."""
     rs = np.random.RandomState(36)
     layers = [(BF16, True, 1, 64, 72, 3, 20, 14, (3, 3, 3), 0), (BF16, True, 1, 392, 72, 2, 9, 40, (1, 1, 1), 1), (BF16, True, 2, 40, 24, 1, 9, 30, (1, 1, 1), 0),
-              (F32, False, 1, 24, 40, 2, 6, 7, (3, 3, 3), 1), (F16, True, 1, 16, 32, 1, 3, 100, (3, 3, 3), 0)]
+              (F32, False, 1, 24, 40, 2, 6, 7, (3, 3, 3), 1), (F16, True, 1, 16, 32, 1, 3, 100, (3, 3, 3), 0),
+              (BF16, True, 1, 72, 40, 2, 36, 40, (1, 1, 1), 1)]              # a pointwise layer on the pixel-stream form (dense per-slice images)
     items = (_capi.WgradReduceItem * len(layers))()
     keep, expect, got = [], [], []
     for li, (dt, w16, N, Cin, Cout, D, H, W, k, acc) in enumerate(layers):
@@ -1362,7 +1365,7 @@ def case_wgrad_partial_and_grouped_reduce(bk, golden):
         ws2 = bk.dev(np.full(nb // 4, np.nan, np.float32))
         dw2 = bk.dev(init.copy())
         assert bk.lib.step_conv_wgrad_partial(ctypes.byref(ds), xd.ptr, gslice_ptr, int(w16), dw2.ptr, acc, ws2.ptr, nb, ctypes.byref(items[li]), bk.stream) == 0
-        assert items[li].kind in (1, 2)
+        assert items[li].kind in (1, 2, 3)
         keep.append((ws2, xd, gwide))
         got.append(dw2)
     assert bk.lib.step_wgrad_reduce_group(items, len(layers), bk.stream) == 0

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", default="", help="comma-separated substrings of layer names")
     ap.add_argument("--lds-only", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="time the calls replayed from a captured HIP graph (no host time between launches)")
     ap.add_argument("--libs", default="", help="comma-separated experiment builds (tools/libstep_amd_NAME.so, `make EXP=NAME EXPFLAGS=...`) timed beside the product library")
     a = ap.parse_args()
     tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
@@ -72,10 +73,26 @@ def main():
                 err = float((out - ref).abs().max() / ref.abs().max())
                 assert err < 1e-3, (name, row, err)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(a.iters):
-                fn()
-            e1.record()
+            if a.graph:
+                gr = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    fn()
+                    with torch.cuda.graph(gr, stream=side):
+                        for _ in range(a.iters):
+                            fn()
+                torch.cuda.current_stream().wait_stream(side)
+                gr.replay()
+                torch.cuda.synchronize()
+                e0.record()
+                gr.replay()
+                e1.record()
+            else:
+                e0.record()
+                for _ in range(a.iters):
+                    fn()
+                e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / a.iters
             cells.append("%10.3f ms %7.1f TFLOP/s" % (ms, gf / ms))
