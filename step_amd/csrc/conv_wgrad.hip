@@ -252,26 +252,33 @@ struct Wgrad16Params {
 
 // KW = 1 (pointwise convs / Linear layers): no halo; the unit is a chunk of 128 consecutive pixels of the flattened N*D*H*W
 // axis, the six waves take six 32-channel blocks of a 192-channel ci tile (X image pitch 400 B) and accumulate one tap.
-template <typename T, int KW, bool PF, int XPMAX = WG16_XP>
+template <typename T, int KW, bool PF, int XPMAX = WG16_XP, int NW = 6, bool DB = false>
 __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
     static_assert(sizeof(T) == 2, "16-bit storage");
     static_assert(KW == 3 || KW == 1, "3x3 windows or pointwise");
     constexpr bool PW = KW == 1;
+    static_assert(NW == 6 || (NW == 12 && KW == 3), "six waves, or twelve for the 3x3 windows");
+    constexpr int THREADS = NW * 64;
+    constexpr int MA = NW == 12 ? 2 : 4;                      // 16-channel blocks of the co tile per wave (twelve waves: two halves of the 64)
     constexpr int PITCH = WG16_PITCH;
     constexpr int XPITCH = PW ? WG16_PW_XPITCH : WG16_PITCH;
     constexpr int CIT = PW ? 192 : 64;                        // input channels per workgroup
     constexpr int XCV = CIT / 8;                              // 16-byte vectors per X pixel
     constexpr int LDSB = PW ? WG16_PW_P * (PITCH + WG16_PW_XPITCH) : (WG16_P + XPMAX) * PITCH;    // 68 KiB (two workgroups per CU) | 76.5 / 90 KiB
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDSB];
-    unsigned char* const dyI = lds;
-    unsigned char* const xI = lds + (PW ? WG16_PW_P : WG16_P) * PITCH;
+    // DB: two images -- unit u + 1 is written while slower waves still multiply unit u, and one barrier per unit instead of two
+    static_assert(!DB || (PF && LDSB * 2 <= 160 * 1024), "the double-buffered form prefetches across units and fits the LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[DB ? 2 * LDSB : LDSB];
+    unsigned char* dyI = lds;
+    unsigned char* xI = lds + (PW ? WG16_PW_P : WG16_P) * PITCH;
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef STEP_EMUL
     const int wave = tid >> 6;
 #else
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
-    const int khw = PW ? 0 : wave % 3, cb = PW ? wave : wave / 3;   // filter row, 32-channel block of the ci tile
+    const int khw = PW ? 0 : wave % 3;                                          // filter row
+    const int wrest = PW ? wave : wave / 3;
+    const int cb = NW == 12 ? (wrest & 1) : wrest, coh = NW == 12 ? (wrest >> 1) : 0;   // 32-channel block of the ci tile; half of the co tile
     // launch order -> XCD: all gridDim.y channel / plane groups of a pixel unit read the SAME two images.  Dispatched in (x fastest)
     // order they are gridDim.x workgroups apart -- each fetches the images from HBM / the infinity cache again (9 x 92 MB for
     // conv3d_2c).  Remap so that the groups of one unit are consecutive on ONE XCD (ids go round-robin over the 8 XCDs) and the
@@ -292,11 +299,11 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
     const int W2 = p.W + 2;
     const int g = lane >> 4, rr = (lane & 15) >> 2, q = lane & 3;
 
-    f32x4 acc[KW][4][2];
+    f32x4 acc[KW][MA][2];
 #pragma unroll
     for (int s = 0; s < KW; ++s)
 #pragma unroll
-        for (int ma = 0; ma < 4; ++ma)
+        for (int ma = 0; ma < MA; ++ma)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -307,7 +314,7 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
     const long long u_beg = (long long)bx * p.upj, u_end = min(u_beg + p.upj, p.units);
     // A unit's two images go global -> registers -> LDS; the NEXT unit's vectors are requested before this unit's matrix
     // work, so their round trip (2-3 us under load, against ~1 us of MFMAs per unit) flies under it.
-    constexpr int NV = PW ? (WG16_PW_P * (8 + XCV) + 383) / 384 : ((WG16_P + XPMAX) * 8 + 383) / 384;     // 16-byte vectors per thread per unit (11 | 12 / 14)
+    constexpr int NV = PW ? (WG16_PW_P * (8 + XCV) + THREADS - 1) / THREADS : ((WG16_P + XPMAX) * 8 + THREADS - 1) / THREADS;     // 16-byte vectors per thread per unit (11 | 12 / 14)
     u32x4 stg[NV];
     struct Unit { int n, d, id, r0, R, P, Ppad, XP; long long k0; bool live; };
     auto unit_of = [&](long long u) {
@@ -337,7 +344,7 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
         const size_t xp0 = ((size_t)q.n * p.D + q.id) * p.H;
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
-            const int v = tid + i * 384;
+            const int v = tid + i * THREADS;
             u32x4 val = {0u, 0u, 0u, 0u};
             if (v < q.Ppad * 8) {                            // dY [Ppad][64 co]: zero tail, zero past Cout
                 const int k = v >> 3, cv = v & 7;
@@ -360,7 +367,7 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
     auto to_lds = [&](const Unit& q, int i0, int i1) {
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
-            const int v = tid + i * 384;
+            const int v = tid + i * THREADS;
             if (v < q.Ppad * 8) *(u32x4*)(dyI + (v >> 3) * PITCH + (v & 7) * 16) = stg[i];
             else if (v - q.Ppad * 8 < q.XP * XCV) {
                 const int w = v - q.Ppad * 8;
@@ -375,7 +382,11 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
             cur = unit_of(u);                                // VGPRs -> two resident workgroups per CU, whose staging and matrix phases interleave)
             if (cur.live) prefetch(cur, 0, KW == 3 ? NV / 2 : NV);
         }
-        __syncthreads();                                     // every wave is done with the previous unit's images
+        if (DB) {                                            // this unit's images: the last reader of them (unit u - 2) is a barrier behind
+            dyI = lds + (size_t)((u - u_beg) & 1) * LDSB;
+            xI = dyI + (PW ? WG16_PW_P : WG16_P) * PITCH;
+        } else
+            __syncthreads();                                 // every wave is done with the previous unit's images
         if (!PF && KW == 3) {
             if (cur.live) {
                 to_lds(cur, 0, NV / 2);
@@ -403,29 +414,29 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
                 pa[h] = dyI + k * PITCH + q * 8;
                 pb[h] = PW ? xI + kc * XPITCH + cb * 64 + q * 8 : xI + (kc + 2 * row + khw * W2) * PITCH + cb * 64 + q * 8;
             }
-            u16x8 a[4];
+            u16x8 a[MA];
 #pragma unroll
-            for (int ma = 0; ma < 4; ++ma) a[ma] = lds_tr8(pa[0] + ma * 32, pa[1] + ma * 32);
+            for (int ma = 0; ma < MA; ++ma) a[ma] = lds_tr8(pa[0] + (coh * MA + ma) * 32, pa[1] + (coh * MA + ma) * 32);
 #pragma unroll
             for (int s = 0; s < KW; ++s)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
                     const u16x8 b = lds_tr8(pb[0] + s * XPITCH + nb * 32, pb[1] + s * XPITCH + nb * 32);
 #pragma unroll
-                    for (int ma = 0; ma < 4; ++ma) mma16_k32(a[ma], b, acc[s][ma][nb], T());
+                    for (int ma = 0; ma < MA; ++ma) mma16_k32(a[ma], b, acc[s][ma][nb], T());
                 }
         }
     }
     if (p.ws) {
         // partial tile of this workgroup, accumulator layout as is (16-byte stores, fully coalesced); wgrad16_reduce_kernel
         // sums over the workgroups of the pixel axis in a fixed order -- no atomics, deterministic
-        f32x4* out = (f32x4*)p.ws + ((((size_t)bx * gridDim.y + by) * 6 + wave) * (KW * 8)) * 64 + lane;
+        f32x4* out = (f32x4*)p.ws + ((((size_t)bx * gridDim.y + by) * NW + wave) * (KW * MA * 2)) * 64 + lane;
 #pragma unroll
         for (int s = 0; s < KW; ++s)
 #pragma unroll
-            for (int ma = 0; ma < 4; ++ma)
+            for (int ma = 0; ma < MA; ++ma)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) out[((s * 4 + ma) * 2 + nb) * 64] = acc[s][ma][nb];
+                for (int nb = 0; nb < 2; ++nb) out[((s * MA + ma) * 2 + nb) * 64] = acc[s][ma][nb];
         return;
     }
     const int ntaps = PW ? 1 : p.kd * 9;
@@ -433,12 +444,12 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
     for (int s = 0; s < KW; ++s) {
         const int tap = PW ? 0 : (kd_ * 3 + khw) * 3 + s;
 #pragma unroll
-        for (int ma = 0; ma < 4; ++ma)
+        for (int ma = 0; ma < MA; ++ma)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int co = co0 + ma * 16 + 4 * g + r, ci = ci0 + cb * 32 + nb * 16 + (lane & 15);
+                    const int co = co0 + (coh * MA + ma) * 16 + 4 * g + r, ci = ci0 + cb * 32 + nb * 16 + (lane & 15);
                     if (co < p.Cout && ci < p.Cin) atomicAdd(p.dw + ((size_t)co * p.Cin + ci) * ntaps + tap, acc[s][ma][nb][r]);
                 }
     }
@@ -446,6 +457,19 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
 
 template <typename T, int KW>
 __global__ __launch_bounds__(384) void conv_wgrad16_lds_kernel(Wgrad16Params p) { conv_wgrad16_lds_body<T, KW, true>(p); }
+// twelve waves (3 filter rows x 2 halves of the ci tile x 2 halves of the co tile, 12 accumulator tiles each): three waves per SIMD
+// instead of 1.5, every SIMD equally loaded
+// (measured, bf16, 8 AVA clips, same process: 3c_b1b 0.883 -> 0.669 ms = 714 TFLOP/s, 3b_b1b 0.582 -> 0.454, 4f_b1b 0.335 -> 0.270, 5c on 1080
+// 7x7 maps 0.468 -> 0.387, the heads' 1x3x3 convs 0.262 -> 0.196; 142 VGPRs, no spill: the product form of the 3x3 windows.  The six-wave
+// kernels remain for experiment builds, -DWG16_NW6.)
+template <typename T, int KW>
+#ifdef WG16_DB
+__global__ __launch_bounds__(768) STEP_WAVES_PER_SIMD(3) void conv_wgrad16_lds12_kernel(Wgrad16Params p) { conv_wgrad16_lds_body<T, KW, true, WG16_XP, 12, true>(p); }
+#else
+__global__ __launch_bounds__(768) STEP_WAVES_PER_SIMD(3) void conv_wgrad16_lds12_kernel(Wgrad16Params p) { conv_wgrad16_lds_body<T, KW, true, WG16_XP, 12>(p); }
+#endif
+template <typename T, int KW>
+__global__ __launch_bounds__(768) STEP_WAVES_PER_SIMD(3) void conv_wgrad16_lds12_wide_kernel(Wgrad16Params p) { conv_wgrad16_lds_body<T, KW, true, WG16_XP_WIDE, 12>(p); }
 template <typename T, int KW>
 __global__ __launch_bounds__(384) void conv_wgrad16_lds_wide_kernel(Wgrad16Params p) { conv_wgrad16_lds_body<T, KW, true, WG16_XP_WIDE>(p); }
 // The same without the cross-unit register prefetch, held to 168 VGPRs: TWO workgroups per CU, whose staging and matrix phases interleave
@@ -636,9 +660,11 @@ __global__ void wgradpws_reduce_kernel(const float* __restrict__ ws, float* __re
 // sums the partial tiles of conv_wgrad16_lds_kernel over the pixel-axis workgroups: one thread per (tile, lane) 16-byte group
 __device__ __forceinline__ void wgrad16_reduce_body(const float* __restrict__ ws, float* __restrict__ dw, int gx, int gy, int cot, int cit, int Cout,
                                                     int Cin, int kd, int accumulate, int pw, unsigned bx, unsigned nbx) {
-    const int tpw = pw ? 8 : 24;                                        // accumulator tiles per wave
-    const long long per_x = (long long)gy * 6 * tpw * 64;              // f32x4 groups of one pixel-axis workgroup
-    const int ntaps = pw ? 1 : kd * 9;
+    // pw: 0 = 3x3 windows, six waves x 24 tiles | 1 = pointwise, six waves x 8 tiles | 2 = 3x3 windows, twelve waves x 12 tiles
+    const int tpw = pw == 1 ? 8 : (pw == 2 ? 12 : 24);                  // accumulator tiles per wave
+    const int nw = pw == 2 ? 12 : 6;
+    const long long per_x = (long long)gy * nw * tpw * 64;             // f32x4 groups of one pixel-axis workgroup
+    const int ntaps = pw == 1 ? 1 : kd * 9;
     // 256 threads = 64 consecutive 16-byte groups x 4 subgroups of the pixel-axis workgroups (subgroup w adds x = w, w + 4, ... in ascending
     // order, four loads in flight; the four partial sums are added in subgroup order through LDS): one thread walking all gx partial tiles
     // was a chain of dependent-latency loads -- 60 us per grouped launch at one clip per GPU
@@ -674,16 +700,18 @@ __device__ __forceinline__ void wgrad16_reduce_body(const float* __restrict__ ws
             long long t = idx;
             const int lane = (int)(t % 64); t /= 64;
             const int tile = (int)(t % tpw); t /= tpw;
-            const int wave = (int)(t % 6); t /= 6;
+            const int wave = (int)(t % nw); t /= nw;
             const int y = (int)t;
-            const int nb = tile & 1, ma = (tile >> 1) & 3, s = tile >> 3;
-            const int khw = pw ? 0 : wave % 3, cb = pw ? wave : wave / 3;
+            const int nb = tile & 1;
+            const int khw = pw == 1 ? 0 : wave % 3, wrest = pw == 1 ? wave : wave / 3;
+            const int cb = pw == 2 ? (wrest & 1) : wrest;
+            const int ma = pw == 2 ? (wrest >> 1) * 2 + ((tile >> 1) & 1) : (tile >> 1) & 3, s = pw == 2 ? tile >> 2 : tile >> 3;
             int yy = y;
             const int cit_i = yy % cit; yy /= cit;
             const int cot_i = yy % cot;
             const int kd_ = yy / cot;
-            const int tap = pw ? 0 : (kd_ * 3 + khw) * 3 + s;
-            const int ci = cit_i * (pw ? 192 : 64) + cb * 32 + nb * 16 + (lane & 15);
+            const int tap = pw == 1 ? 0 : (kd_ * 3 + khw) * 3 + s;
+            const int ci = cit_i * (pw == 1 ? 192 : 64) + cb * 32 + nb * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = cot_i * 64 + ma * 16 + 4 * (lane >> 4) + r;
@@ -1070,7 +1098,7 @@ static int wgrad_min_pixels(int form) {
 }
 
 // launch plan of the LDS-tiled 16-bit form; ok = false: the shape is left to the per-tap forms
-struct Wg16Plan { bool ok = false, pw = false, wide = false; int rows, cpp, upj, cot, cit; long long units, gx, gy; };
+struct Wg16Plan { bool ok = false, pw = false, wide = false, nw12 = false; int rows, cpp, upj, cot, cit; long long units, gx, gy; };
 static Wg16Plan wgrad16_plan(const step_conv_desc* d) {
     Wg16Plan pl; pl.ok = false; pl.pw = false; pl.wide = false; pl.rows = pl.cpp = pl.upj = pl.cot = pl.cit = 0; pl.units = pl.gx = pl.gy = 0;
     if (!d || (d->dtype != STEP_BF16 && d->dtype != STEP_F16)) return pl;
@@ -1101,6 +1129,9 @@ static Wg16Plan wgrad16_plan(const step_conv_desc* d) {
         // the wide-halo instantiation only where it cuts the chunks per plane (measured, bf16, 8 clips: conv3d_2c on 100x100 2.61 -> 1.80 ms,
         // on 56x56 0.53 -> 0.48 ms; the 50- and 25-wide layers keep the same rows and would lose 5 % to its longer staging loops)
         if (Rw > 0 && (R <= 0 || ceil_div(d->H, Rw) < ceil_div(d->H, R))) { R = Rw; pl.wide = true; }
+#ifndef WG16_NW6
+        pl.nw12 = true;
+#endif
         if (R <= 0) return pl;
         pl.cot = ceil_div(d->Cout, 64); pl.cit = ceil_div(d->Cin, 64);
         pl.cpp = ceil_div(d->H, R);
@@ -1316,20 +1347,26 @@ static int conv_wgrad_impl(const step_conv_desc* d, const void* x, const void* d
                 if (d->dtype == STEP_BF16) STEP_LAUNCH((conv_wgrad16_lds2_kernel<bf16_t, 1>), grid16, dim3(384), stream, q);
                 else STEP_LAUNCH((conv_wgrad16_lds2_kernel<f16_t, 1>), grid16, dim3(384), stream, q);
             } else {
-                if (pl.wide) {
+                if (pl.wide && pl.nw12) {
+                    if (d->dtype == STEP_BF16) STEP_LAUNCH((conv_wgrad16_lds12_wide_kernel<bf16_t, 3>), grid16, dim3(768), stream, q);
+                    else STEP_LAUNCH((conv_wgrad16_lds12_wide_kernel<f16_t, 3>), grid16, dim3(768), stream, q);
+                } else if (pl.wide) {
                     if (d->dtype == STEP_BF16) STEP_LAUNCH((conv_wgrad16_lds_wide_kernel<bf16_t, 3>), grid16, dim3(384), stream, q);
                     else STEP_LAUNCH((conv_wgrad16_lds_wide_kernel<f16_t, 3>), grid16, dim3(384), stream, q);
+                } else if (pl.nw12) {
+                    if (d->dtype == STEP_BF16) STEP_LAUNCH((conv_wgrad16_lds12_kernel<bf16_t, 3>), grid16, dim3(768), stream, q);
+                    else STEP_LAUNCH((conv_wgrad16_lds12_kernel<f16_t, 3>), grid16, dim3(768), stream, q);
                 } else if (d->dtype == STEP_BF16) STEP_LAUNCH((WG16_K3<bf16_t, 3>), grid16, dim3(384), stream, q);
                 else STEP_LAUNCH((WG16_K3<f16_t, 3>), grid16, dim3(384), stream, q);
             }
 #undef WG16_K3
             if (q.ws && defer) {
                 defer->kind = 2; defer->ws = q.ws; defer->dw = dw; defer->jobs = pl.gx; defer->gy = (int)pl.gy; defer->cot = pl.cot; defer->cit = pl.cit;
-                defer->Cout = d->Cout; defer->Cin = d->Cin; defer->taps = d->kd; defer->accumulate = 1; defer->pw = (int)pl.pw;
+                defer->Cout = d->Cout; defer->Cin = d->Cin; defer->taps = d->kd; defer->accumulate = 1; defer->pw = pl.nw12 ? 2 : (int)pl.pw;
             } else if (q.ws) {
                 const long long groups = pl.gy * 6 * (pl.pw ? 8 : 24) * 64;
                 STEP_LAUNCH(wgrad16_reduce_kernel, dim3(flat_grid(groups * 4, 256)), dim3(256), stream, (const float*)q.ws, dw, (int)pl.gx, (int)pl.gy,
-                            pl.cot, pl.cit, d->Cout, d->Cin, d->kd, 1, (int)pl.pw);      // (dw was cleared above unless accumulate)
+                            pl.cot, pl.cit, d->Cout, d->Cin, d->kd, 1, pl.nw12 ? 2 : (int)pl.pw);      // (dw was cleared above unless accumulate)
             }
             return STEP_LAUNCH_CHECK();
         }
@@ -1443,7 +1480,8 @@ int step_conv_wgrad_kernel_name(const step_conv_desc* d, int dy16, char* buf, in
     else if (dy16 && pl.ok) {
         const bool pw = d->kd == 1 && d->kh == 1 && d->kw == 1;
         snprintf(buf, (size_t)buflen, "void step::%s<%s, %d>(step::Wgrad16Params)",
-                 pw ? "conv_wgrad16_lds2_kernel" : (pl.wide ? "conv_wgrad16_lds_wide_kernel" : "conv_wgrad16_lds_kernel"), t, pw ? 1 : 3);
+                 pw ? "conv_wgrad16_lds2_kernel" : (pl.nw12 ? (pl.wide ? "conv_wgrad16_lds12_wide_kernel" : "conv_wgrad16_lds12_kernel")
+                                                             : (pl.wide ? "conv_wgrad16_lds_wide_kernel" : "conv_wgrad16_lds_kernel")), t, pw ? 1 : 3);
     } else
         snprintf(buf, (size_t)buflen, "void step::conv_wgrad_kernel<%s, 2, %d, %s>(step::WgradParams)", t, d->Cin <= 32 ? 1 : 2, dy16 ? "true" : "false");
     return STEP_OK;
@@ -1469,7 +1507,7 @@ int step_wgrad_reduce_group(const step_wgrad_reduce_item* items, int n, step_str
         if (it.kind == 0) continue;
         if ((it.kind != 1 && it.kind != 2 && it.kind != 3) || !it.ws || !it.dw) return STEP_E_SHAPE;
         const long long work = it.kind == 1 ? (long long)it.gy * (2 * it.nbw * 16 * 64) * 4
-                             : (it.kind == 2 ? (long long)it.gy * 6 * (it.pw ? 8 : 24) * 64 * 4 : ((long long)it.Cout * it.Cin / 4 + 15) / 16 * 256);
+                             : (it.kind == 2 ? (long long)it.gy * 6 * (it.pw == 1 ? 8 : 24) * 64 * 4 : ((long long)it.Cout * it.Cin / 4 + 15) / 16 * 256);
         if (work > most) most = work;
         g.it[m++] = it;
     }
