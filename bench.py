@@ -790,10 +790,18 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
             traffic, tsrc = None, None
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-                hit = tj.get("kernels_" + a.config, {}).get(name)
-                if hit:
-                    traffic = hit.get("hbm_bytes_per_launch")
-                    tsrc = "NOT measured in this run: profiles/traffic_latest.json kernels_%s (%s; taken at commit %s)" % (a.config, tj.get("source"), tj.get("commit_" + a.config, tj.get("commit", "?")))
+                # per-launch traffic depends on the workload: only a table taken at THIS run's clips / tubes is quoted
+                for key in [k for k in tj if k.startswith("kernels_" + a.config)]:
+                    wl = tj.get("workload_" + key[len("kernels_"):], {})
+                    if wl.get("clips") != CLIPS_PER_GPU or wl.get("tubes") != tubes:
+                        continue
+                    hit = tj[key].get(name)
+                    if hit:
+                        traffic = hit.get("hbm_bytes_per_launch")
+                        tsrc = "NOT measured in this run: profiles/traffic_latest.json %s (%s; %s; taken at commit %s)" % (
+                            key, tj.get("note_" + key[len("kernels_"):], ""), tj.get("source"), tj.get("commit_" + key[len("kernels_"):], tj.get("commit", "?")))
+                if traffic is None:
+                    tsrc = "no PMC table for this kernel at %d clips x %d tubes in profiles/traffic_latest.json" % (CLIPS_PER_GPU, tubes)
             except Exception:
                 pass
             out["roofline"] = {"kernel": name, "bound": "mfma" if mf else "hbm", "achieved": round(ach, 2), "peak": peak,
