@@ -663,6 +663,10 @@ __global__ __launch_bounds__(PB_THREADS) void maxpool333_bwd_kernel(const T* __r
     }
 }
 
+// (Measured and NOT kept, round 4: the same separable, LDS-tiled treatment for the (1,3,3) / (1,2,2) pools (maxPool3d_2a / 3a: planes are
+// independent, an input belongs to at most 2 x 2 windows).  Five barriers per 8 x 8-output tile with a third to a half of the 512 threads
+// busy per phase: 2a 0.869 -> 0.888 ms, 3a 0.587 -> 0.727 ms at 8 AVA clips -- the two gathers already run these at 2.3-2.6 TB/s because
+// every input visits only 4 windows.  tools/pool_bwd_bench.py.)
 struct PoolBwdPlan { int TH, TW, tiles_h, tiles_w, CVC, cchunks; long long blocks; };
 static PoolBwdPlan pool333_bwd_plan(const PoolParams& p) {
     PoolBwdPlan pl;

@@ -527,6 +527,34 @@ def case_maxpool_backward(bk, golden):
             # (channels 0 and 1 hold windows with no winner: torch hands those to the window's first element, both forms here to nobody)
             assert np.allclose(outs[0][:, 2:], refq[:, 2:], rtol=1e-6, atol=1e-6), ((n2, c2, d2, h2, w2), dt, np.abs(outs[0][:, 2:] - refq[:, 2:]).max())
             assert np.all(outs[0][np.isnan(xq)] == 0)
+    # (1,3,3) / (1,2,2) (maxPool3d_2a / 3a) on 16-bit activations at larger sizes: even and odd map sizes (the TF pad row / column behind
+    # the map, the ceil-mode overhang), an all-negative channel whose windows the pad wins, a NaN
+    for (n2, c2, d2, h2, w2) in ((2, 32, 2, 21, 40), (1, 16, 1, 16, 16), (1, 24, 3, 33, 9), (1, 8, 2, 40, 70)):
+        xb = rs.randn(n2, c2, d2, h2, w2).astype(np.float32)
+        xb[0, :, :, :h2 // 2] = np.maximum(xb[0, :, :, :h2 // 2], 0)
+        xb[0, 0] = -np.abs(xb[0, 0])                                                # all-negative channel: the pad behind the map wins its windows
+        xb[0, 1, 0, 1, 1] = np.nan
+        pads2 = [0, 1, 0, 1, 0, 0]
+        for dt in (BF16, F16):
+            xq = quantize(xb, dt)
+            xt = torch.from_numpy(np.nan_to_num(xq, nan=-np.inf)).requires_grad_(True)
+            yq = F.max_pool3d(F.pad(xt, pads2), (1, 3, 3), (1, 2, 2), ceil_mode=True)
+            gq = quantize(rs.randn(*yq.shape).astype(np.float32), dt)
+            yq.backward(torch.from_numpy(gq))
+            refq = xt.grad.numpy()
+            xe, ge = bk.dev(encode(cl(xq), dt)), bk.dev(encode(np.ascontiguousarray(cl(gq)), dt))
+            outs = []
+            for direct in (0, 1):
+                _capi.set_option(L, "pool_direct", direct)
+                try:
+                    go = bk.dev(np.full((n2, d2, h2, w2, c2), 3, np.float32))
+                    argb = bk.dev(np.zeros(int(np.prod(yq.shape)), np.uint8))
+                    assert L.step_maxpool3d_tf_backward_gather(dt, xe.ptr, n2, d2, h2, w2, c2, c2, 0, 1, 3, 3, 1, 2, 2, dt, ge.ptr, 0, go.ptr, argb.ptr, bk.stream) == 0
+                    outs.append(uncl(go.get()).copy())
+                finally:
+                    _capi.set_option(L, "pool_direct", 0)
+            assert np.allclose(outs[0], outs[1], rtol=1e-6, atol=1e-6), ((n2, c2, d2, h2, w2), dt, np.abs(outs[0] - outs[1]).max())
+            assert np.allclose(outs[0], refq, rtol=1e-6, atol=1e-6), ((n2, c2, d2, h2, w2), dt, np.abs(outs[0] - refq).max())
     # the pool input as a channel slice [8, 16) of a 24-channel buffer (x_cstride / x_coff): same gradient as the dense tensor
     k, s = POOLS[0]
     xw = np.full((N, D, H, W, 24), 9.0, np.float32)
