@@ -1145,6 +1145,9 @@ static Wg16Plan wgrad16_plan(const step_conv_desc* d) {
     // 3c_b1b 1.57 / 1.24 / 0.90 ms, 4f_b1b 0.35 / 0.46 / 0.44 ms, 5c on 1080 7x7 maps 0.99 / 0.89 / 0.60 ms -- the winner is whichever
     // lands just under a multiple of 256).  So the count is chosen per layer: time ~ rounds x units per workgroup, plus the partial
     // tiles every pixel-axis workgroup writes and the sum reads back (~150 KB each way per workgroup: ~1 % of a unit's time each).
+#ifndef WG16_WGCOST
+#define WG16_WGCOST 0.012       /* a workgroup's partial tiles (written here, read back by the sum), in units of a unit's time */
+#endif
 #ifdef WG16_TOTAL           /* experiment builds: a fixed target, as rounds 2-3 had (512) */
     {
         long long want = WG16_TOTAL / (pl.gy > 0 ? pl.gy : 1);
@@ -1166,7 +1169,7 @@ static Wg16Plan wgrad16_plan(const step_conv_desc* d) {
             long long gx = ceil_div64(pl.units, upj);
             if (gx >= 8) gx = (gx + 7) / 8 * 8;              // whole rounds over the 8 XCDs (the kernel's launch-order remap); surplus workgroups write zero tiles
             const long long wgs = gx * pl.gy;
-            const double cost = (double)ceil_div64(wgs, slots) * (double)upj + 0.012 * (double)wgs / (double)slots * 256.0 + 0.25;   // (+ a launch's fixed part)
+            const double cost = (double)ceil_div64(wgs, slots) * (double)upj + WG16_WGCOST * (double)wgs / (double)slots * 256.0 + 0.25;   // (+ a launch's fixed part)
             if (best < 0.0 || cost < best) { best = cost; best_gx = gx; best_upj = upj; }
         }
         pl.upj = (int)(best_upj > 0x3fffffff ? 0x3fffffff : best_upj);
@@ -1270,7 +1273,9 @@ static WgPwsPlan wgradpws_plan(const step_conv_desc* d) {
         const long long spj = ceil_div64(stages, pl.gx);
         pl.ppj = spj * PWS_P;
     }
-    pl.ok = pl.gy <= 65535 && pl.gx <= 0x7fffffffLL && pl.gx > 0;
+    // the kernel addresses a slice's operands with 32-bit element offsets from the slice's first pixel
+    const long long span = (pl.ppj + PWS_P) * (long long)(d->x_cstride > d->y_cstride ? d->x_cstride : d->y_cstride);
+    pl.ok = pl.gy <= 65535 && pl.gx <= 0x7fffffffLL && pl.gx > 0 && span < 0x7fffffffLL;
     return pl;
 }
 

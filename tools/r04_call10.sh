@@ -5,7 +5,8 @@ O=$R/gpurun_out
 cd $R
 rm -f $O/r04h_*.json
 for cfg in "1 5" "1 15" "8 5" "8 15"; do set -- $cfg
-  timeout 500 python bench.py --config c4 --dtype bf16 --clips $1 --tubes $2 --steps 10 --warmup 3 > $O/r04h_c4_bf16_b$1_t$2.json 2> $O/r04h_c4_bf16_b$1_t$2.err
+  nocpu="--no-cpu-baseline"; [ "$1 $2" = "1 5" ] && nocpu=""          # (the CPU leg is one clip either way: timed once)
+  timeout 500 python bench.py --config c4 --dtype bf16 --clips $1 --tubes $2 --steps 10 --warmup 3 $nocpu > $O/r04h_c4_bf16_b$1_t$2.json 2> $O/r04h_c4_bf16_b$1_t$2.err
 done
 timeout 500 python bench.py --config c4 --steps 10 --warmup 3 --no-cpu-baseline > $O/r04h_c4_f32_b1_t5.json 2> $O/r04h_c4_f32_b1_t5.err
 timeout 300 python bench.py --config c3 --steps 30 --warmup 5 > $O/r04h_c3.json 2> $O/r04h_c3.err
