@@ -280,6 +280,9 @@ __device__ __forceinline__ bool roi_touches(const float* r, int b, int Y, int X,
     return !(g.start_h > (float)(Y + 1) || g.start_h + g.bin_h * (float)ph < (float)(Y - 1) ||
              g.start_w > (float)(X + 1) || g.start_w + g.bin_w * (float)pw < (float)(X - 1));
 }
+// (Measured and not kept, round 4: one workgroup per ROW of cells -- the header scan and candidate list shared by the row's cells, the
+// cells walked one after the other -- 1.70 -> 2.57 ms at K = 1080, 0.56 -> 0.95 at K = 360: the scan is not what bounds the call, and
+// 25 cells in sequence per workgroup cost more latency than 24 saved scans.  tools/roi_bwd_bench.py.)
 template <int V>
 __global__ void roi_align_bwd_gather_nhwc_kernel(const float* __restrict__ grad, const float* __restrict__ rois, int K, int C, int H, int W,
                                                  int ph, int pw, float scale, int sampling_ratio, float* __restrict__ gfeat) {
