@@ -90,7 +90,7 @@ enum {
     STEP_OPT_CONV_SLOTS,       /*  0 (default: resident workgroups of the chip) | n: pretend the chip holds n workgroups (tests: the tail split at small sizes) */
     STEP_OPT_POOL_DIRECT,      /*  0 (default) | 1: every max pool on the general 27-tap kernel (tests) */
     STEP_OPT_WGRAD_MINPIX,     /*  0 (default: 512 for the atomics forms, 64 (fp32 MFMA) / 256 (16-bit) with a workspace) | n: least pixels per wavefront job of the per-tap weight gradient (fp32 summation order) */
-    STEP_OPT_WGRAD16_LDS,      /*  1 (default) | 0: 3x3 windows of step_conv_wgrad16_ws on the per-tap kernel instead of the LDS-tiled GEMM */
+    STEP_OPT_WGRAD16_LDS,      /*  1 (default): 3x3 windows on the LDS-tiled GEMM, pointwise layers on the pixel stream | 2: pointwise layers on the forms of early round 4 (LDS tiles / per tap) | 0: everything on the per-tap kernel (fp32 summation order differs between the three) */
     STEP_OPT_CONV_GROUP_PW,    /*  2^20 (default: always) | n: step_conv_forward_group carries a pointwise item inside the 3x3x3 members' grid when they are at most n workgroups; 0 never (bit-identical) */
     STEP_OPT_COUNT_
 };
@@ -428,7 +428,11 @@ STEP_API int step_maxpool3d_tf_backward(int dtype, const void* x, int N, int D, 
  * windows it won, in a fixed order (bit-reproducible), and writes gx once -- in fp32 or in the activation type, from gy in fp32 or
  * in the activation type (gy_dtype / gx_dtype: STEP_F32 or `dtype`), so a 16-bit net needs no fp32 staging, no clear and no
  * conversion pass.  gy dense [N,Do,Ho,Wo,C], gx dense [N,D,H,W,C].  C (and the slice of x) must be whole 16-byte channel vectors of
- * `dtype`, else STEP_E_UNSUPPORTED (the atomic entry above has no such limit). */
+ * `dtype`, else STEP_E_UNSUPPORTED (the atomic entry above has no such limit).
+ * Round 4: for 16-bit activations the (3,3,3) / (1,1,1) window (the Inception blocks' pool) runs as ONE launch that finds the first
+ * maximum separably on LDS tiles and routes the gradient back the same way; it does not touch arg_scratch (still required non-NULL)
+ * and adds the same terms in a different fixed order (planes, rows, columns) -- equal to the two-gather form up to fp32 rounding,
+ * bit-reproducible run to run; STEP_OPT_POOL_DIRECT = 1 keeps the two gathers. */
 STEP_API int step_maxpool3d_tf_backward_gather(int dtype, const void* x, int N, int D, int H, int W, int C, int x_cstride, int x_coff,
                                                int kd, int kh, int kw, int sd, int sh, int sw, int gy_dtype, const void* gy, int gx_dtype,
                                                void* gx, unsigned char* arg_scratch, step_stream_t stream);
