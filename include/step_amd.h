@@ -361,10 +361,12 @@ STEP_API int step_stem_forward(int dtype, const void* x, int N, int T, int H, in
 /* Diagnostic, as step_conv_kernel_name: the (main) kernel a weight-gradient call launches for this descriptor (dy16: the 16-bit entry). */
 STEP_API int step_conv_wgrad_kernel_name(const step_conv_desc* d, int dy16, char* buf, int buflen);
 #define STEP_WGRAD_REDUCE_MAX 8
-typedef struct step_wgrad_reduce_item {
+typedef struct step_wgrad_reduce_item {     /* filled by step_conv_wgrad_partial; opaque to the caller apart from kind == 0 (nothing pending) */
     const float* ws; float* dw;
-    long long jobs;
-    int kind, gy, nbw, cot, cit, Cout, Cin, taps, accumulate, pw;
+    long long jobs;                          /* partial results along the pixel axis */
+    int kind;                                /* 0 none | 1 per-tap kernel's tiles | 2 LDS-tiled kernel's tiles | 3 dense [Cout, Cin] slice images (pointwise pixel stream) */
+    int gy, nbw, cot, cit, Cout, Cin, taps, accumulate;
+    int pw;                                  /* kind 2: 0 = 3x3 windows, six waves | 1 = pointwise | 2 = 3x3 windows, twelve waves (tile order inside a workgroup's block) */
 } step_wgrad_reduce_item;
 STEP_API int step_conv_wgrad_partial(const step_conv_desc* d, const void* x, const void* dy, int dy16, float* dw, int accumulate, void* ws,
                                      size_t ws_bytes, step_wgrad_reduce_item* item, step_stream_t stream);
