@@ -446,8 +446,8 @@ def roofline(net, x, dtype_name):
     out["next_kernels"] = [{k_: v_ for k_, v_ in describe(n_, *a_).items() if k_ != "traffic_from"} for n_, a_ in ranked[1:3]]
     out["method"] = ("durations = differences of the best replay times of HIP graphs of growing prefixes of the step (each launch in its place of "
                      "the replayed sequence, no warm-up twin); 'dominant' = the kernel name with the largest summed time over the step")
-    out["profile"] = ("rocprofv3 --kernel-trace --stats of `bench.py --in-flight 1`: profiles/r03_c2_kernel_stats.txt (one batch at a time, as these "
-                      "durations); of the default command: profiles/r03_c2_kernel_stats_two_in_flight.txt -- there launches of the two batches in "
+    out["profile"] = ("rocprofv3 --kernel-trace --stats of `bench.py --in-flight 1`: profiles/r04_c2_kernel_stats.txt (one batch at a time, as these "
+                      "durations); of the default command: profiles/r04_c2_kernel_stats_two_in_flight.txt -- there launches of the two batches in "
                       "flight share the CUs, so a trace's per-launch durations are longer than the kernels' own cost while the step is shorter")
     table = sorted(((n_, a[1] / 3, a[0] // 3, a[2] / max(a[1], 1e-9) / 1e9) for n_, a in agg.items()), key=lambda r: -r[1])   # TFLOP/s = flops / ms / 1e9
     return out, table, total_ms / 3
