@@ -1268,11 +1268,7 @@ static WgPwsPlan wgradpws_plan(const step_conv_desc* d) {
         if (best < 0.0 || cost < best) { best = cost; best_gx = gx; }
     }
     pl.gx = best_gx;
-    pl.ppj = ceil_div64(stages, ceil_div64(stages, best_gx) > 0 ? best_gx : 1) * PWS_P;
-    {   // whole stages per slice, every pixel covered
-        const long long spj = ceil_div64(stages, pl.gx);
-        pl.ppj = spj * PWS_P;
-    }
+    pl.ppj = ceil_div64(stages, pl.gx) * PWS_P;               // whole stages per slice, every pixel covered (surplus slices write zero images)
     // the kernel addresses a slice's operands with 32-bit element offsets from the slice's first pixel
     const long long span = (pl.ppj + PWS_P) * (long long)(d->x_cstride > d->y_cstride ? d->x_cstride : d->y_cstride);
     pl.ok = pl.gy <= 65535 && pl.gx <= 0x7fffffffLL && pl.gx > 0 && span < 0x7fffffffLL;
