@@ -658,6 +658,9 @@ __global__ void wgradpws_reduce_kernel(const float* __restrict__ ws, float* __re
 }
 
 // sums the partial tiles of conv_wgrad16_lds_kernel over the pixel-axis workgroups: one thread per (tile, lane) 16-byte group
+// (Measured and not kept, round 4: the sum organised by OUTPUT -- a workgroup per 16 co x 16 ci block assembling [co][ci][27 taps] in LDS and
+// writing whole rows instead of 4-byte stores 108 bytes apart: 3c_b1b at one clip 0.131 -> 0.145 ms, 16 -> 32 channels 0.038 -> 0.082 ms,
+// the one-clip step 13.4 -> 13.7 ms.  The scattered stores are merged by the L2; a block-per-workgroup walk has too few workgroups.)
 __device__ __forceinline__ void wgrad16_reduce_body(const float* __restrict__ ws, float* __restrict__ dw, int gx, int gy, int cot, int cit, int Cout,
                                                     int Cin, int kd, int accumulate, int pw, unsigned bx, unsigned nbx) {
     // pw: 0 = 3x3 windows, six waves x 24 tiles | 1 = pointwise, six waves x 8 tiles | 2 = 3x3 windows, twelve waves x 12 tiles
