@@ -225,7 +225,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 // conv_wgrad16_lds_kernel -- the 16-bit weight gradient as a tiled GEMM (kw = 3 windows: 3x3x3 and 1x3x3).
 // The form above loads every MFMA operand element with its own 2- or 4-byte load and is bound by that (20-130 TFLOP/s).
 // Here a 384-thread workgroup stages, per chunk of output rows, the dY tile [P pixels][64 co] and the X halo tile
-// [(R+2) x (W+2) pixels][64 ci] of one input plane into LDS in their NATURAL pixel-major layout (16-byte vectors, pitch 144 B)
+// [(R+2) x (W+2) pixels][64 ci] of one input plane into LDS in their NATURAL pixel-major layout (16-byte vectors, pitch 160 B)
 // and reads the MFMA operands with ds_read_b64_tr_b16: the hardware transpose hands every lane the 8 consecutive pixels (k)
 // of one channel that v_mfma_f32_16x16x32 wants, and a tap shift is just another pixel address -- no transposed or shifted
 // copies (common.h: lds_tr8).  Six waves = 3 filter rows (kh) x 2 halves of the 64 input channels; each accumulates the three
@@ -233,11 +233,18 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 // (plane, row chunk) units with its accumulators in registers and ends in one pass of fp32 atomics.
 constexpr int WG16_P = 224;              // output pixels per chunk (7 k32 steps)
 constexpr int WG16_XP = 320;             // halo pixels per chunk
-constexpr int WG16_XP_WIDE = 416;        // ... of the wide-map instantiation: 100-wide maps take two rows per chunk, 56-wide ones four (92 KB of LDS,
+constexpr int WG16_XP_WIDE = 416;        // ... of the wide-map instantiation: 100-wide maps take two rows per chunk, 56-wide ones four (100 KB of LDS,
                                          // 14 staged vectors per thread: 5 % slower than the 320 form when both give the same rows, so chosen per layer)
 constexpr int WG16_PW_P = 128;           // pointwise form: pixels per chunk
-constexpr int WG16_PW_XPITCH = 400;      // ... bytes per X pixel (192 channels x 2 B + 16 B)
-constexpr int WG16_PITCH = 144;          // bytes per LDS pixel: 64 channels x 2 B + 16 B (keeps the transpose reads off a 128-B bank period)
+// LDS pitches and the pixel order of the transpose reads (round 4, from the SQ counters: 40-43 % of these kernels' LDS cycles were bank
+// conflicts, profiles/r04_pmc_c4.txt).  A ds_read_b64_tr_b16 moves 8 bytes per lane: 32 lanes fill the 64 banks once, and a half-wave
+// (two 16-lane groups) reads 8 pixel rows x 32 bytes.  With the natural order -- group g takes rows 8g .. 8g + 7, four per read -- the
+// half-wave's rows are k .. k+3 and k+8 .. k+11, and rows 8 apart share banks at ANY 16-byte-aligned pitch.  The MFMA does not care
+// in which order the 32 pixels of a step meet, as long as both operands use the same one: group g now takes rows 16 (g >> 1) + 4 (g & 1)
+// + {0..3} (+8 for its second read), so a half-wave reads 8 CONSECUTIVE rows, and a pitch of 160 bytes modulo 256 (40 dwords: 40 k mod 64
+// runs through all eight multiples of 8) puts them on disjoint banks.
+constexpr int WG16_PW_XPITCH = 416;      // ... bytes per X pixel (192 channels x 2 B + 32 B)
+constexpr int WG16_PITCH = 160;          // bytes per LDS pixel: 64 channels x 2 B + 32 B
 struct Wgrad16Params {
     const void* x; const void* dy; float* dw;
     int N, D, H, W, Cin, Cout, kd;
@@ -264,9 +271,9 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
     constexpr int XPITCH = PW ? WG16_PW_XPITCH : WG16_PITCH;
     constexpr int CIT = PW ? 192 : 64;                        // input channels per workgroup
     constexpr int XCV = CIT / 8;                              // 16-byte vectors per X pixel
-    constexpr int LDSB = PW ? WG16_PW_P * (PITCH + WG16_PW_XPITCH) : (WG16_P + XPMAX) * PITCH;    // 68 KiB (two workgroups per CU) | 76.5 / 90 KiB
+    constexpr int LDSB = PW ? WG16_PW_P * (PITCH + WG16_PW_XPITCH) : (WG16_P + XPMAX) * PITCH;    // 72 KiB (two workgroups per CU) | 85 / 100 KiB
     // DB: two images -- unit u + 1 is written while slower waves still multiply unit u, and one barrier per unit instead of two
-    static_assert(!DB || (PF && LDSB * 2 <= 160 * 1024), "the double-buffered form prefetches across units and fits the LDS");
+    static_assert(!DB || PF, "the double-buffered form prefetches across units");     // (2 x 87 KB no longer fits the LDS at the 160-byte pitch: experiment builds only, with a smaller WG16_P)
     __shared__ __attribute__((aligned(16))) unsigned char lds[DB ? 2 * LDSB : LDSB];
     unsigned char* dyI = lds;
     unsigned char* xI = lds + (PW ? WG16_PW_P : WG16_P) * PITCH;
@@ -339,6 +346,10 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
     };
     // (i0, i1: the slice of the thread's NV vectors this call moves -- the form without cross-unit prefetch stages a unit in two halves,
     // so that only half the staging registers are live at a time)
+    // (staging order: the 16 lanes of a ds_write_b128 pass write rows r and r + 1, which share eight banks at this pitch; pairing rows r and
+    //  r + 4 instead removes those conflicts (SQ_LDS_BANK_CONFLICT 40 -> 22-32 % of the LDS cycles with it, 40 -> ~35 % without) but measured
+    //  SLOWER -- 5c_b1b 0.385 -> 0.416 ms, the heads' 1x3x3 convs 0.197 -> 0.213 -- and is not kept: the kernel is not bound by its LDS cycles)
+    auto srow = [](int u) { return u >> 3; };
     auto prefetch = [&](const Unit& q, int i0, int i1) {
         const size_t gp0 = PW ? (size_t)q.k0 : (((size_t)q.n * p.D + q.d) * p.H + q.r0) * p.W;
         const size_t xp0 = ((size_t)q.n * p.D + q.id) * p.H;
@@ -347,7 +358,7 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
             const int v = tid + i * THREADS;
             u32x4 val = {0u, 0u, 0u, 0u};
             if (v < q.Ppad * 8) {                            // dY [Ppad][64 co]: zero tail, zero past Cout
-                const int k = v >> 3, cv = v & 7;
+                const int k = srow(v), cv = v & 7;
                 if (k < q.P && co0 + cv * 8 < p.Cout) val = *(const u32x4*)(dyg + (gp0 + k) * p.dy_cstride + p.dy_coff + co0 + cv * 8);
             } else if (PW) {                                 // X [P][192 ci]: zero past the chunk / past Cin
                 const int w = v - q.Ppad * 8;
@@ -355,7 +366,7 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
                 if (px < q.P && ci0 + cv * 8 < p.Cin) val = *(const u32x4*)(xg + (gp0 + px) * p.x_cstride + p.x_coff + ci0 + cv * 8);
             } else {                                         // X halo [(R+2)(W+2)][64 ci]: zero border, zero past Cin
                 const int w = v - q.Ppad * 8;
-                const int px = w >> 3, cv = w & 7;
+                const int px = srow(w), cv = w & 7;
                 const int r_ = (int)(((unsigned)px * p.wmagic2) >> 22), c_ = px - r_ * W2;
                 const int ih = q.r0 + r_ - 1, iw = c_ - 1;
                 if (px < q.XP && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && ci0 + cv * 8 < p.Cin)
@@ -368,10 +379,13 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
             const int v = tid + i * THREADS;
-            if (v < q.Ppad * 8) *(u32x4*)(dyI + (v >> 3) * PITCH + (v & 7) * 16) = stg[i];
-            else if (v - q.Ppad * 8 < q.XP * XCV) {
+            if (v < q.Ppad * 8) *(u32x4*)(dyI + srow(v) * PITCH + (v & 7) * 16) = stg[i];
+            else if (PW) {
                 const int w = v - q.Ppad * 8;
-                *(u32x4*)(xI + (w / XCV) * XPITCH + (w % XCV) * 16) = stg[i];
+                if (w < q.XP * XCV) *(u32x4*)(xI + (w / XCV) * XPITCH + (w % XCV) * 16) = stg[i];
+            } else {
+                const int w = v - q.Ppad * 8;                // (whole 8-row blocks: the rows past XP of the last one carry zeros)
+                if (w < ((q.XP + 7) & ~7) * 8) *(u32x4*)(xI + srow(w) * PITCH + (w & 7) * 16) = stg[i];
             }
         }
     };
@@ -408,7 +422,7 @@ __device__ __forceinline__ void conv_wgrad16_lds_body(const Wgrad16Params& p) {
             const unsigned char* pb[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int k = kb + 8 * g + 4 * h + rr;       // this lane's pixel of the transpose block
+                const int k = kb + 16 * (g >> 1) + 4 * (g & 1) + 8 * h + rr;       // this lane's pixel of the transpose block (order: see WG16_PITCH)
                 const int kc = min(k, P - 1);                // (past the chunk: dY is zero there, X only has to be finite)
                 const int row = (int)(((unsigned)kc * p.wmagic) >> 22);
                 pa[h] = dyI + k * PITCH + q * 8;
@@ -489,12 +503,12 @@ __global__ __launch_bounds__(384) STEP_WAVES_PER_SIMD(3) void conv_wgrad16_lds2_
 // (the vendor GEMM is 2-5x slower still on these shapes: tools/gemm_probe.py).
 // Here a 512-thread workgroup owns up to 128 x 256 of dW (8 waves as 2 x 4, 64 x 64 accumulators each: 64 VGPRs) and walks a slice of
 // the pixel axis in 32-pixel stages: two stages of global loads in flight in registers (48 B per thread each), a double-buffered LDS
-// image (pixel-major, pitch = 144 mod 256 bytes so that the rows of a transpose-read block fall on distinct banks), ONE barrier per
+// image (pixel-major; pitch and pixel order of the transpose reads: see WG16_PITCH), ONE barrier per
 // stage, fragments by ds_read_b64_tr_b16, 16 MFMAs (16x16x32) per wave and stage.  Two workgroups per CU (<= 128 VGPRs, 2 x 66 KB).
 // Slices end in a dense fp32 [Cout, Cin] image per slice (the reduce is a coalesced sum of images) or, without a workspace, in atomics.
 constexpr int PWS_P = 32;
-constexpr int PWS_APITCH = 400;          // 128 output channels x 2 B + 144
-constexpr int PWS_BPITCH = 656;          // 256 input channels x 2 B + 144
+constexpr int PWS_APITCH = 416;          // 128 output channels x 2 B + 160 (pitch = 160 mod 256 and the pixel order of WG16_PITCH: conflict-free half-waves)
+constexpr int PWS_BPITCH = 672;          // 256 input channels x 2 B + 160
 constexpr int PWS_STAGE = PWS_P * (PWS_APITCH + PWS_BPITCH);
 struct WgradPwsParams {
     const void* x; const void* dy; float* dw; float* ws;
@@ -568,7 +582,7 @@ __global__ __launch_bounds__(512) STEP_WAVES_PER_SIMD_MIN(4) void conv_wgrad16_p
     auto compute = [&](int buf) {
         const unsigned char* A = lds + buf * PWS_STAGE + wm * cow * 2 + q * 8;
         const unsigned char* B = lds + buf * PWS_STAGE + PWS_P * PWS_APITCH + wn * ciw * 2 + q * 8;
-        const int k0 = 8 * g + rr, k1 = k0 + 4;                // this lane's pixels of the two transpose blocks
+        const int k0 = 16 * (g >> 1) + 4 * (g & 1) + rr, k1 = k0 + 8;      // this lane's pixels of the two transpose blocks
         // (always the full 4 x 4 blocks: a narrower tile's surplus blocks multiply whatever the LDS rows hold behind its channels into
         //  accumulators that are never written out -- branch-free, and these layers are bound by their operand traffic, not by this)
         u16x8 a[4];

@@ -618,8 +618,8 @@ __global__ __launch_bounds__(PB_THREADS) void maxpool333_bwd_kernel(const T* __r
                 s[i] += tag_of(a1, i) == 1 ? g1[i] : 0.f;
                 s[i] += tag_of(a2, i) == 0 ? g2[i] : 0.f;
             }
-            *(f32x4*)(G1S + (size_t)tid * 8) = f32x4{s[0], s[1], s[2], s[3]};
-            *(f32x4*)(G1S + (size_t)tid * 8 + 4) = f32x4{s[4], s[5], s[6], s[7]};
+            *(f32x4*)(G1S + (size_t)tid * 4) = f32x4{s[0], s[1], s[2], s[3]};               // (low / high channel halves in separate planes: a lane's
+            *(f32x4*)(G1S + PB_THREADS * 4 + (size_t)tid * 4) = f32x4{s[4], s[5], s[6], s[7]};   //  16 bytes next to its neighbour's, no bank conflicts)
         }
         __syncthreads();
         if (g2thread) {                                   // row ph of the tile: positions ph, ph+1, ph+2 of the output grid reach it through b = 2, 1, 0
@@ -630,15 +630,15 @@ __global__ __launch_bounds__(PB_THREADS) void maxpool333_bwd_kernel(const T* __r
             for (int j = 0; j < 3; ++j) {
                 const int o = tid + j * PW * CVC;
                 const unsigned long long b = BR[q % 3][o];
-                const f32x4 lo = *(const f32x4*)(G1S + (size_t)o * 8), hi = *(const f32x4*)(G1S + (size_t)o * 8 + 4);
+                const f32x4 lo = *(const f32x4*)(G1S + (size_t)o * 4), hi = *(const f32x4*)(G1S + PB_THREADS * 4 + (size_t)o * 4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     s[i] += tag_of(b, i) == (unsigned)(2 - j) ? lo[i] : 0.f;
                     s[i + 4] += tag_of(b, i + 4) == (unsigned)(2 - j) ? hi[i] : 0.f;
                 }
             }
-            *(f32x4*)(G2S + (size_t)tid * 8) = f32x4{s[0], s[1], s[2], s[3]};
-            *(f32x4*)(G2S + (size_t)tid * 8 + 4) = f32x4{s[4], s[5], s[6], s[7]};
+            *(f32x4*)(G2S + (size_t)tid * 4) = f32x4{s[0], s[1], s[2], s[3]};
+            *(f32x4*)(G2S + PB_THREADS * 4 + (size_t)tid * 4) = f32x4{s[4], s[5], s[6], s[7]};
         }
         __syncthreads();
         if (g3thread && ooff >= 0) {                      // column pw: positions pw, pw+1, pw+2 of the row reach it through c = 2, 1, 0
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(PB_THREADS) void maxpool333_bwd_kernel(const T* __r
             for (int j = 0; j < 3; ++j) {
                 const int o = tid + j * CVC;
                 const unsigned long long c = CR[q % 3][o];
-                const f32x4 lo = *(const f32x4*)(G2S + (size_t)o * 8), hi = *(const f32x4*)(G2S + (size_t)o * 8 + 4);
+                const f32x4 lo = *(const f32x4*)(G2S + (size_t)o * 4), hi = *(const f32x4*)(G2S + PB_THREADS * 4 + (size_t)o * 4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     s[i] += tag_of(c, i) == (unsigned)(2 - j) ? lo[i] : 0.f;
