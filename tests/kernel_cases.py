@@ -468,7 +468,8 @@ def case_maxpool_backward(bk, golden):
         gxd = bk.dev(np.full((N, D, H, W, C), 5.0, np.float32))
         assert L.step_maxpool3d_tf_backward(0, xd.ptr, N, D, H, W, C, C, 0, k[0], k[1], k[2], s[0], s[1], s[2], gyd.ptr, gxd.ptr, bk.stream) == 0
         got = uncl(gxd.get())
-        assert np.allclose(got, ref, rtol=1e-6, atol=1e-6), (k, s, np.abs(got - ref).max())
+        # (fp32 atomics: the order in which up to 27 windows' gradients meet differs from run to run -- a few ulps of the sum)
+        assert np.allclose(got, ref, rtol=2e-5, atol=2e-5), (k, s, np.abs(got - ref).max())
         # the gather form (arg map + fixed-order gather): fp32 like the reference; bit-reproducible
         Do, Ho, Wo = y.shape[2:]
         arg = bk.dev(np.full(N * Do * Ho * Wo * C, 250, np.uint8))
