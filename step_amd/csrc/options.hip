@@ -22,7 +22,7 @@ constexpr OptSpec SPEC[STEP_OPT_COUNT_] = {
     {"conv_slots", 0, 0, 1 << 20},
     {"pool_direct", 0, 0, 1},
     {"wgrad_minpix", 0, 0, 1 << 24},
-    {"wgrad16_lds", 1, 0, 1},
+    {"wgrad16_lds", 1, 0, 2},
     {"conv_group_pw", 1 << 20, 0, 1 << 20},
 };
 std::atomic<int> g_delta[STEP_OPT_COUNT_];      // value - default: zero-initialised static storage IS the default table

@@ -1313,9 +1313,10 @@ def case_conv_wgrad16(bk, golden):
               (1, 392, 136, 1, 30, 70, (1, 1, 1))]   # ... 2 x 2 tiles of 96 x 256 (both axes ragged), 2100 pixels = 65 stages + 20 pixels
     try:
         # 64 with wgrad16_lds = 0: the per-tap 16-bit form with several row-range jobs per tile; None: the LDS-tiled form
-        for minpix in (64, None):
+        # (wgrad16_lds = 2: the pointwise layers on the LDS-tiled / per-tap forms instead of the pixel stream)
+        for minpix, ldsopt in ((64, 0), (None, 1), (None, 2)):
             _capi.set_option(bk.lib, "wgrad_minpix", minpix or 0)
-            _capi.set_option(bk.lib, "wgrad16_lds", 1 if minpix is None else 0)
+            _capi.set_option(bk.lib, "wgrad16_lds", ldsopt)
             for (N, Cin, Cout, D, H, W, k) in cases:
                 x = rs.randn(N, Cin, D, H, W).astype(np.float32)
                 gy = rs.randn(N, Cout, D, H, W).astype(np.float32)

@@ -53,6 +53,46 @@ def test_planner_dispatch(lib):
     assert "conv_igemm_kernel" in n
 
 
+def wgrad_name(L, dt, N, Cin, Cout, k, D, H, W, xcs=None):
+    d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2], x_cstride=xcs or Cin, x_coff=0, y_cstride=Cout,
+                       y_coff=0, res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)
+    buf = ctypes.create_string_buffer(256)
+    assert L.step_conv_wgrad_kernel_name(ctypes.byref(d), 1, buf, 256) == 0
+    return buf.value.decode(), L.step_conv_wgrad16_workspace_bytes(ctypes.byref(d))
+
+
+def test_weight_gradient_planner(lib):
+    """Which 16-bit weight-gradient form a layer of the training step gets (round 4), and the workspace each form asks for."""
+    BF = _capi.BF16
+    # 3x3x3 windows: the twelve-wave LDS-tiled kernel; 100-wide maps (one clip or eight) the wide-halo instantiation
+    n, ws = wgrad_name(lib, BF, 8, 128, 192, (3, 3, 3), 18, 50, 50)
+    assert "conv_wgrad16_lds12_kernel<step::bf16_t, 3>" in n and ws > 0 and ws % (144 * 64 * 16) == 0      # whole workgroup blocks of partial tiles
+    n, _ = wgrad_name(lib, BF, 1, 64, 192, (3, 3, 3), 18, 100, 100)
+    assert "conv_wgrad16_lds12_wide_kernel" in n
+    n, _ = wgrad_name(lib, BF, 8, 64, 192, (3, 3, 3), 16, 56, 56)
+    assert "conv_wgrad16_lds12_wide_kernel" in n                                # four rows per chunk instead of three
+    n, _ = wgrad_name(lib, BF, 120, 256, 256, (1, 3, 3), 9, 7, 7)
+    assert "conv_wgrad16_lds12_kernel" in n
+    # pointwise layers with >= 2048 pixels: the pixel stream, dense [Cout, Cin] fp32 images per slice
+    for (N, Cin, Cout, D, H, W) in ((8, 192, 96, 18, 50, 50), (1, 480, 304, 9, 25, 25), (1080, 832, 624, 1, 7, 7), (1, 64, 64, 18, 100, 100)):
+        n, ws = wgrad_name(lib, BF, N, Cin, Cout, (1, 1, 1), D, H, W)
+        assert "conv_wgrad16_pws_kernel<step::bf16_t>" in n, (N, Cin, Cout, n)
+        assert ws > 0 and ws % (Cout * Cin * 4) == 0 and ws // (Cout * Cin * 4) <= 4096, (N, Cin, Cout, ws)
+    # a channel-sliced input keeps the form; fewer pixels fall back to the tiled / per-tap kernels; odd channel counts to the per-tap one
+    assert "conv_wgrad16_pws_kernel" in wgrad_name(lib, BF, 8, 192, 96, (1, 1, 1), 18, 50, 50, xcs=256)[0]
+    assert "conv_wgrad16_lds2_kernel<step::bf16_t, 1>" in wgrad_name(lib, BF, 1, 480, 304, (1, 1, 1), 4, 13, 13)[0]
+    assert "conv_wgrad_kernel<step::bf16_t, 2, 2, true>" in wgrad_name(lib, BF, 1, 192, 96, (1, 1, 1), 3, 13, 13)[0]
+    assert "conv_wgrad_kernel" in wgrad_name(lib, BF, 8, 192, 81, (1, 1, 1), 18, 50, 50)[0]
+    # option 2 keeps the pointwise layers on the earlier forms (A/B, tests)
+    _capi.set_option(lib, "wgrad16_lds", 2)
+    try:
+        assert "conv_wgrad_kernel" in wgrad_name(lib, BF, 8, 192, 96, (1, 1, 1), 18, 50, 50)[0]
+        assert "conv_wgrad16_lds2_kernel" in wgrad_name(lib, BF, 1080, 832, 624, (1, 1, 1), 1, 7, 7)[0]
+        assert "conv_wgrad16_lds12_kernel" in wgrad_name(lib, BF, 8, 128, 192, (3, 3, 3), 18, 50, 50)[0]
+    finally:
+        _capi.set_option(lib, "wgrad16_lds", 1)
+
+
 def test_abi_and_symbols(lib):
     """Every entry point include/step_amd.h declares is exported by the library and bound in step_amd/_capi.py (and nothing
     is bound that the header does not declare); no compute call is made."""
