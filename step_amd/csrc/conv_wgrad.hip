@@ -229,7 +229,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 // and reads the MFMA operands with ds_read_b64_tr_b16: the hardware transpose hands every lane the 8 consecutive pixels (k)
 // of one channel that v_mfma_f32_16x16x32 wants, and a tap shift is just another pixel address -- no transposed or shifted
 // copies (common.h: lds_tr8).  Six waves = 3 filter rows (kh) x 2 halves of the 64 input channels; each accumulates the three
-// kw taps of its row: 3 x (64 co x 32 ci) = 24 MFMAs per 32-pixel step from 20 transpose reads.  A workgroup walks several
+// kw taps of its row: 3 x (64 co x 32 ci) = 24 MFMAs per 32-pixel step from 20 transpose reads (NW = 6; the product form of the 3x3
+// windows since round 4 is NW = 12: the co tile split over a second pair of waves, conv_wgrad16_lds12_kernel below).  A workgroup walks several
 // (plane, row chunk) units with its accumulators in registers and ends in one pass of fp32 atomics.
 constexpr int WG16_P = 224;              // output pixels per chunk (7 k32 steps)
 constexpr int WG16_XP = 320;             // halo pixels per chunk
