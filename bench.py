@@ -453,6 +453,93 @@ def roofline(net, x, dtype_name):
     return out, table, total_ms / 3
 
 
+def fed_loop(a, net, flights, x, dev, tdt, dist, resident_s_per_step):
+    """--feed u8: the loop a fed node runs (reference: data/ava.py:298-368 hands [T,3,H,W] fp32 frames to the DataLoader every iteration,
+    data/augmentations.py:68-84 converts from uint8 on the HOST; SURVEY 8e names input feeding as the scaling limiter).  Here the wire
+    format is uint8 [N,T,H,W,3] (4x fewer PCIe bytes than fp32): per batch in flight a PINNED host buffer, a device staging buffer, one
+    hipMemcpyAsync on a COPY stream, step_clip_from_u8 (scale 2: x*2/255-1, the reference's ConvertFromInts) into the captured step's
+    static input on the batch's compute stream, then the captured step.  The copy of batch k + nfl waits only for batch k's conversion
+    (not for its backbone), so transfers run under the other batches' compute.  The host buffers hold synthetic frames that are not
+    rewritten between steps (there is no decoder on this path); everything behind them is what a fed loop does."""
+    from step_amd import ops
+    nfl = len(flights)
+    N, T, _, H, W = x.shape
+    g = torch.Generator().manual_seed(777)
+    hosts, stages, xs, streams, graphs = [], [], [], [], []
+    for i, fl in enumerate(flights):
+        hosts.append(torch.randint(0, 256, (N, T, H, W, 3), dtype=torch.uint8, generator=g).pin_memory())
+        stages.append(torch.empty((N, T, H, W, 3), dtype=torch.uint8, device=dev))
+        xs.append(x if i == 0 else fl[2])                      # the captured graphs' static inputs
+        streams.append(fl[0]); graphs.append(fl[1])
+    copy_stream = torch.cuda.Stream()
+    ev_copied = [torch.cuda.Event() for _ in range(nfl)]
+    ev_conv = [torch.cuda.Event() for _ in range(nfl)]
+    nbytes = hosts[0].numel()
+
+    def step(k):
+        i = k % nfl
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(ev_conv[i])                 # the staging buffer is free once batch k - nfl has been converted
+            stages[i].copy_(hosts[i], non_blocking=True)
+            ev_copied[i].record(copy_stream)
+        with torch.cuda.stream(streams[i]):
+            streams[i].wait_event(ev_copied[i])
+            ops.clip_from_u8(stages[i], scale=2, out=xs[i])
+            ev_conv[i].record(streams[i])
+            graphs[i].replay()
+
+    def copies_only(k):
+        i = k % nfl
+        with torch.cuda.stream(copy_stream):
+            stages[i].copy_(hosts[i], non_blocking=True)
+
+    def run(fn, steps, warm):
+        for k in range(warm):
+            fn(k)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            fn(k)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    for i in range(nfl):                                        # events start signalled
+        ev_conv[i].record(streams[i])
+    torch.cuda.synchronize()
+    steps = max(a.steps, int(1.0 / max(resident_s_per_step, 1e-5)) + 1)       # ~1 s of the fed loop
+    el_f = run(step, steps, max(a.warmup, 2 * nfl))
+    el_c = run(copies_only, steps, 4)
+    if dist is not None:
+        t = torch.tensor([el_f, el_c], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el_f, el_c = float(t[0].item()), float(t[1].item())
+    world = dist.get_world_size() if dist is not None else 1
+    fed_rate = world * N * steps / el_f
+    res_rate = world * N / resident_s_per_step
+    h2d = nbytes * steps / el_c / 1e9
+    need = nbytes / N * (res_rate / world) / 1e9              # GB/s of uint8 frames one rank consumes at the resident rate
+    if fed_rate >= 0.97 * res_rate:
+        limit = "compute: the fed loop runs at the resident-input rate (transfers and the conversion hide under the other batch's compute)"
+    elif h2d < 1.1 * need:
+        limit = "the host->device link: the copy-only loop moves %.1f GB/s per rank, the resident rate would consume %.1f GB/s" % (h2d, need)
+    else:
+        limit = "neither link nor compute alone: copy-only %.1f GB/s exceeds the %.1f GB/s the fed rate consumes -- the copy's dependency on the previous conversion / the conversion launch serialise" % (h2d, nbytes / N * (fed_rate / world) / 1e9)
+    return {"value": round(fed_rate, 2), "unit": "clips/s", "ms_per_step": round(el_f / steps * 1e3, 4), "steps": steps,
+            "resident_value": round(res_rate, 2), "fed_over_resident": round(fed_rate / res_rate, 4),
+            "wire_format": "uint8 [N,T,H,W,3], %.2f MB per clip (fp32 [T,3,H,W] as the reference feeds it: %.2f MB)" % (nbytes / N / 1e6, 4 * nbytes / N / 1e6),
+            "h2d_GBs_in_fed_loop": round(nbytes * steps / el_f / 1e9, 2), "h2d_GBs_copy_only": round(h2d, 2),
+            "u8_GBs_needed_at_resident_rate": round(need, 2), "bottleneck": limit,
+            "eight_ranks": "8 ranks at this rate pull %.0f GB/s of uint8 frames from the host (fp32 frames: %.0f GB/s)" % (8 * nbytes / N * (fed_rate / world) / 1e9, 32 * nbytes / N * (fed_rate / world) / 1e9),
+            "note": "pinned host buffers (synthetic frames, not rewritten between steps) -> hipMemcpyAsync on a copy stream -> step_clip_from_u8 (x*2/255-1) into "
+                    "the captured step's input -> captured step; %d batches in flight; copy k+%d waits for conversion k only" % (nfl, nfl)}
+
+
 def spawn_ranks(n):
     import socket
     import subprocess
@@ -484,6 +571,14 @@ def main():
     ap.add_argument("--tubes", type=int, default=None, help="c3 / c4: tubes per clip (default: c3 11, c4 5)")
     ap.add_argument("--sustained-seconds", type=float, default=2.0,
                     help="c2 / c5: length of the second, sustained loop of the same captured step reported under 'sustained' (0 = skip)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="c4 on ONE GPU: initialise a one-rank RCCL process group and issue the bucketed gradient all-reduces all the same "
+                         "(identities there) -- the multi-rank program, captured in the step's HIP graph, on a one-GPU box")
+    ap.add_argument("--c4-graph", default="auto", choices=["auto", "one", "split"],
+                    help="c4: how the step is captured (workloads.C4TrainStep.capture): one graph incl. the RCCL collectives, or fwd/bwd + eager exchange + update")
+    ap.add_argument("--feed", default="none", choices=["none", "u8"],
+                    help="c2 / c5: additionally time the FED loop -- pinned host uint8 frames -> H2D on a copy stream -> step_clip_from_u8 -> the "
+                         "captured step, double-buffered against the batches in flight; reported under 'fed' (value stays the resident-input loop)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="tuning aid: a planner option of the library (include/step_amd.h step_set_option), e.g. conv_group_pw=0; repeatable")
     ap.add_argument("--verbose", action="store_true")
@@ -519,6 +614,14 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    elif a.force_exchange:
+        import socket
+        import torch.distributed as dist
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
 
     tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
     if a.branch_streams is not None:
@@ -598,18 +701,28 @@ def main():
             return time.perf_counter() - t0
 
         nfl = len(flights) if graph is not None else 1
-        el = timed(nfl)
-        el_one = timed(1) if nfl > 1 else el                   # the same K steps one batch at a time (reported beside the headline)
-        # A second, SUSTAINED loop of the same captured step(s): the contract's K steps can be a few tens of milliseconds, shorter than
-        # the power manager's settling time, so a throttling cliff could hide behind them.  Same launches, >= --sustained-seconds long.
+        # The SUSTAINED loop runs FIRST: the contract's K steps can be a few tens of milliseconds, shorter than the
+        # power manager's settling time -- on the driver's box the 24 ms window read 8 % under the same captured steps replayed for 2 s
+        # right after it (the window sat on the clock ramp).  So: >= --sustained-seconds of the same loop first (reported under
+        # 'sustained', and it leaves the DPM state where a serving loop keeps it), THEN the contract's W warm-up + K timed steps
+        # (`value`), then the same K steps one batch at a time.
         sus = None
         if a.sustained_seconds > 0:
             keep_steps, keep_warm = a.steps, a.warmup
-            a.steps, a.warmup = max(a.steps, int(a.sustained_seconds * 1.1 / (el / keep_steps)) + 1), 0
+            a.steps, a.warmup = 10, 5
+            pilot = timed(nfl) / 10                                  # s per step, to size the loop
+            if dist is not None:
+                tp = torch.tensor([pilot], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+                dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+                pilot = float(tp.item())
+            a.steps, a.warmup = max(keep_steps, int(a.sustained_seconds * 1.1 / pilot) + 1), 0
             with ClockSampler(local_dev) as cs:
                 el_s = timed(nfl)
             sus = (a.steps, el_s, cs.median(), len(cs.samples), cs.smi_median(), len(cs.smi_samples))
             a.steps, a.warmup = keep_steps, keep_warm
+        el = timed(nfl)
+        el_one = timed(1) if nfl > 1 else el                   # the same K steps one batch at a time (reported beside the headline)
+        fed = fed_loop(a, net, flights, x, dev, tdt, dist, el / a.steps) if (a.feed == "u8" and graph is not None) else None
     if dist is not None:
         t = torch.tensor([el, el_one, sus[1] if sus else 0.0], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -638,11 +751,13 @@ def main():
             out["sustained"] = {"seconds": round(sus[1], 3), "steps": sus[0], "value": round(world * CLIPS_PER_GPU * sus[0] / sus[1], 2),
                                 "ms_per_step": round(sus[1] / sus[0] * 1e3, 4), "clock_ghz": sus[4] if sus[4] else sus[2], "clock_samples": sus[5] if sus[4] else sus[3],
                                 "clock_ghz_sysfs": sus[2], "clock_ghz_amd_smi": sus[4],
-                                "note": "the same loop (same captured steps, same batches in flight) run for >= %.1f s right after the timed K steps; "
+                                "note": "the same loop (same captured steps, same batches in flight) run for >= %.1f s right BEFORE the timed K steps (it also settles the DPM state the contract window then starts from); "
                                         "clock_ghz = median gfx clock during it AS THE DRIVER REPORTS IT (`amd-smi metric --clock`, polled back to back; failing "
                                         "that the amdgpu sysfs node) -- the DPM state, not the effective clock: inside these kernels s_memtime / s_memrealtime "
                                         "measure 1.3-1.6 GHz (tools/timeline_probe.py) and roofline.sustained_on_this_box gives the rate under bare MFMA load; "
                                         "null: not exposed on this box; `value` / `ms_per_step` above stay on the contract's K steps" % a.sustained_seconds}
+        if fed is not None:
+            out["fed"] = fed
         per_gpu = val / world
         out["backbone_roofline"] = {
             "hbm_frac": round(per_gpu * (ACT_MB_PER_CLIP + W_MB / CLIPS_PER_GPU) * 1e6 / (PEAK_HBM_GBS * 1e9), 4),
@@ -697,10 +812,13 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
         # one process: the whole step (forward, backward, re-pack, Adam) is captured in a HIP graph and replayed -- the eager step
         # with 16-bit activations is bound by the host issuing ~1300 launches; several ranks: eager (the bucketed exchange)
         # (fp32 is GPU-bound and measured SLOWER replayed than eager -- 54.6 vs 51.0 ms -- so only the 16-bit step is captured)
-        graphed = world == 1 and not a.no_graph and a.dtype != "f32"
-        w = workloads.C4TrainStep(dev, batch=CLIPS_PER_GPU, tubes_per_clip=tubes, seed=123 + rank, dtype=tdt, capturable=graphed)
+        # several ranks: the SAME captured program -- the bucket all-reduces on the communication stream are recorded in the graph
+        # (RCCL), or, where they cannot be (gloo), forward/backward and the update are two graphs around one eager flat all-reduce
+        graphed = not a.no_graph and a.dtype != "f32"
+        w = workloads.C4TrainStep(dev, batch=CLIPS_PER_GPU, tubes_per_clip=tubes, seed=123 + rank, dtype=tdt, capturable=graphed,
+                                  force_exchange=a.force_exchange)
         if graphed:
-            w.capture(warmup=max(a.warmup, 2))
+            w.capture(warmup=max(a.warmup, 2), mode=a.c4_graph)
         what = "C4: one training step (backbone + ContextNet + max_iter=3 heads on 3/3/9-frame tubes, BCE + smooth-L1 losses, gradient all-reduce, Adam), " \
                "%d x [36,3,400,400] clip(s) per GPU, %d tubes/clip" % (CLIPS_PER_GPU, tubes)
         metric = "clips_per_sec_train_T36_400"
@@ -771,7 +889,11 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
                           "batches_in_flight": nfl,
                           "launch": ("hipGraph replay + eager post-processing" + (", %d batches in flight (own clips / graph / stream each; batch k + 1 launched before batch k is post-processed)" % nfl if nfl > 1 else ""))
                                     if (a.config == "c3" and not a.no_graph) else
-                                    ("hipGraph replay (whole training step)" if getattr(w, "graph", None) is not None else "eager")},
+                                    ({"one": "hipGraph replay (whole training step%s)" % (", the bucketed RCCL gradient all-reduces recorded in the graph" if getattr(w.reducer, "active", False) else ""),
+                                      "split": "two hipGraphs (forward + backward | re-pack + Adam) around one eager flat gradient all-reduce"}[w.graph_mode]
+                                     if getattr(w, "graph", None) is not None else "eager"),
+                          "gradient_exchange": ("bucketed all-reduce, %d buckets, %s" % (len(w.reducer.buckets), "one-rank RCCL group (forced)" if world == 1 else "%d ranks" % world))
+                                               if getattr(getattr(w, "reducer", None), "active", False) else None},
                "ranks": {"world_size": world, "backend": (dist.get_backend() + " (RCCL over xGMI)" if dist.get_backend() == "nccl" else dist.get_backend()) if dist is not None else None,
                          "devices_visible": torch.cuda.device_count()}}
         if nfl > 1:

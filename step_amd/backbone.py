@@ -662,18 +662,23 @@ def _flush_wgrads(pend, device):
     written on; then the gradient exchange hears about the parameters."""
     if not pend:
         return
-    side = next((e[3] for e in pend if e[3] is not None), None)
-    items = [e[0] for e in pend]
-    if side is not None:
+    # One launch PER STREAM the partial tiles were written on (None = the current stream, whose dw autograd reads next: its sum must be
+    # ordered on that stream, not on the side stream of a neighbour that happens to have a dense fp32 .grad).
+    parts = {}
+    for e in pend:
+        parts.setdefault((e[4], e[3]), []).append(e)
+    for (dev, side), es in parts.items():
+        items = [e[0] for e in es]
+        if side is None:
+            ops.wgrad_reduce_group(items, dev if dev is not None else device)
+            continue
         with torch.cuda.stream(side):
-            ops.wgrad_reduce_group(items, device)
-        for _, ws, unit, _, _ in pend:
+            ops.wgrad_reduce_group(items, dev if dev is not None else device)
+        for _, ws, unit, _, _ in es:
             if ws is not None:
                 ws.record_stream(side)
             if GRAD_READY is not None and unit is not None:
                 GRAD_READY(unit.weight_fn(), side)
-    else:
-        ops.wgrad_reduce_group(items, device)
     del pend[:]
 
 
@@ -928,12 +933,18 @@ class wgrad_into_grad:
 
     def __enter__(self):
         global WGRAD_INTO_GRAD
+        if not WGRAD_INTO_GRAD:
+            wgrad_sync()                                         # nothing of an earlier backward may ride into this step's sums
         self.prev, WGRAD_INTO_GRAD = WGRAD_INTO_GRAD, True
         return self
 
     def __exit__(self, *exc):
         global WGRAD_INTO_GRAD
         WGRAD_INTO_GRAD = self.prev
+        if exc and exc[0] is not None:
+            # backward raised mid-way: the queued partial sums describe a gradient nobody will use -- drop them instead of adding them
+            # to the arena at the next flush (their workspaces die with the list); the side stream is still joined
+            del _PEND_Q[:]
         wgrad_sync()
         return False
 

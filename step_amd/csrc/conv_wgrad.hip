@@ -199,9 +199,10 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ ws, 
         }
         part1[threadIdx.x] = sum;
         __syncthreads();
-        if (w != 0 || idx >= per_job) { __syncthreads(); continue; }
-        sum = ((sum + part1[64 + ln]) + part1[128 + ln]) + part1[192 + ln];
+        const bool mine = w == 0 && idx < per_job;               // one unconditional barrier pair, the work predicated (no barrier inside a branch)
+        if (mine) sum = ((sum + part1[64 + ln]) + part1[128 + ln]) + part1[192 + ln];
         __syncthreads();
+        if (!mine) continue;
         int t = (int)(idx % per_tile);
         int y = (int)(idx / per_tile);
         const int lane = t & 63, r = (t >> 6) & 15, tile = t >> 10;
@@ -1514,17 +1515,37 @@ int step_conv_wgrad_partial(const step_conv_desc* d, const void* x, const void* 
     return conv_wgrad_impl(d, x, dy, dy16 != 0, dw, accumulate, ws, ws_bytes, stream, item);
 }
 
+static int wgrad_reduce_group_launch(const WgradReduceGroup& g, int m, long long most, step_stream_t stream) {
+    STEP_LAUNCH(wgrad_reduce_group_kernel, dim3(flat_grid(most, 256), (unsigned)m), dim3(256), stream, g);
+    return STEP_LAUNCH_CHECK();
+}
+
 int step_wgrad_reduce_group(const step_wgrad_reduce_item* items, int n, step_stream_t stream) {
     if (n < 0 || n > STEP_WGRAD_REDUCE_MAX) return STEP_E_SHAPE;
     if (n == 0) return STEP_OK;
     if (!items) return STEP_E_NULL;
+    for (int i = 0; i < n; ++i) {
+        const step_wgrad_reduce_item& it = items[i];
+        if (it.kind == 0) continue;
+        if ((it.kind != 1 && it.kind != 2 && it.kind != 3) || !it.ws || !it.dw) return STEP_E_SHAPE;
+    }
+    // The members of one launch run CONCURRENTLY (blockIdx.y) and each ends in a plain read-modify-write of its dw: two sums into the
+    // same gradient (a unit used twice in one graph, leftovers of an earlier backward) must not share a launch.  A repeated dw closes the
+    // launch; the stream then orders the two sums as separate launches did before the grouping.
     WgradReduceGroup g;
     int m = 0;
     long long most = 0;
     for (int i = 0; i < n; ++i) {
         const step_wgrad_reduce_item& it = items[i];
         if (it.kind == 0) continue;
-        if ((it.kind != 1 && it.kind != 2 && it.kind != 3) || !it.ws || !it.dw) return STEP_E_SHAPE;
+        bool dup = false;
+        for (int q = 0; q < m; ++q) dup = dup || g.it[q].dw == it.dw;
+        if (dup) {
+            for (int q = m; q < STEP_WGRAD_REDUCE_MAX; ++q) g.it[q] = step_wgrad_reduce_item();
+            const int rc = wgrad_reduce_group_launch(g, m, most, stream);
+            if (rc != STEP_OK) return rc;
+            m = 0; most = 0;
+        }
         const long long work = it.kind == 1 ? (long long)it.gy * (2 * it.nbw * 16 * 64) * 4
                              : (it.kind == 2 ? (long long)it.gy * 6 * (it.pw == 1 ? 8 : 24) * 64 * 4 : ((long long)it.Cout * it.Cin / 4 + 15) / 16 * 256);
         if (work > most) most = work;
@@ -1532,8 +1553,7 @@ int step_wgrad_reduce_group(const step_wgrad_reduce_item* items, int n, step_str
     }
     if (m == 0) return STEP_OK;
     for (int i = m; i < STEP_WGRAD_REDUCE_MAX; ++i) g.it[i] = step_wgrad_reduce_item();
-    STEP_LAUNCH(wgrad_reduce_group_kernel, dim3(flat_grid(most, 256), (unsigned)m), dim3(256), stream, g);
-    return STEP_LAUNCH_CHECK();
+    return wgrad_reduce_group_launch(g, m, most, stream);
 }
 
 

@@ -661,14 +661,20 @@ def maxpool_tf_backward(x, gy, k, s):
     return gx
 
 
-def clip_from_u8(frames, dtype=torch.float32, scale=2, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0)):
+def clip_from_u8(frames, dtype=torch.float32, scale=2, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), out=None):
     """uint8 frames [N,T,H,W,3] on the device -> normalised clip [N,T,3,H,W] (the reference's ConvertFromInts(scale) +
-    SubtractMeans + DivideStds, data/augmentations.py:68-111, done after the PCIe transfer instead of before it)."""
+    SubtractMeans + DivideStds, data/augmentations.py:68-111, done after the PCIe transfer instead of before it).
+    out: a contiguous [N,T,3,H,W] tensor to write (e.g. the static input of a captured step); its dtype wins."""
     L = _lib.lib()
     if frames.dtype != torch.uint8 or frames.dim() != 5 or frames.shape[-1] != 3 or not frames.is_contiguous():
         raise RuntimeError("step_amd: clip_from_u8 expects contiguous uint8 frames [N,T,H,W,3]")
     N, T, H, W, _ = frames.shape
-    out = torch.empty((N, T, 3, H, W), dtype=dtype, device=frames.device)
+    if out is None:
+        out = torch.empty((N, T, 3, H, W), dtype=dtype, device=frames.device)
+    else:
+        if tuple(out.shape) != (N, T, 3, H, W) or not out.is_contiguous() or out.device != frames.device:
+            raise RuntimeError("step_amd: clip_from_u8(out=...) wants a contiguous [N,T,3,H,W] tensor on the frames' device")
+        dtype = out.dtype
     m = (ctypes.c_float * 3)(*[float(v) for v in mean])
     sd = (ctypes.c_float * 3)(*[float(v) for v in std])
     code = {torch.float32: _capi.F32, torch.bfloat16: _capi.BF16, torch.float16: _capi.F16}[dtype]
@@ -893,6 +899,20 @@ def select_prepare(prob, loc, first, last, clip_of, gt_mid, gt_count, width, hei
     return mean_prob, vloc, vfirst, vlast, iou
 
 
+def _check_head_targets(name, dev, N, Tl, NC, tubes, targets):
+    """The kernel hard-codes tubes [N,Tl,5] and targets [N,3,6+NC] (row 2 = 'last'): anything else would be read out of bounds and give
+    wrong losses silently, where the torch chain it replaces (two_branch.py:294-333) would have raised."""
+    if targets is not None:
+        if tuple(targets.shape) != (N, 3, 6 + NC):
+            raise RuntimeError("step_amd: %s wants targets [N=%d, 3, 6+NC=%d], got %s" % (name, N, 6 + NC, tuple(targets.shape)))
+        if tubes is None or tuple(tubes.shape) != (N, Tl, 5):
+            raise RuntimeError("step_amd: %s wants tubes [N=%d, Tl=%d, 5], got %s" % (name, N, Tl, None if tubes is None else tuple(tubes.shape)))
+        if targets.device != dev or tubes.device != dev:
+            raise RuntimeError("step_amd: %s wants tubes and targets on %s" % (name, dev))
+    elif tubes is not None and tuple(tubes.shape) != (N, Tl, 5):
+        raise RuntimeError("step_amd: %s wants tubes [N=%d, Tl=%d, 5], got %s" % (name, N, Tl, tuple(tubes.shape)))
+
+
 def head_outputs(logits, reg, N, Tl, T, NC, tubes=None, targets=None):
     """step_head_outputs: logits [N*Tl, ..., NC], reg [N*Tl, ..., 12] | None (2-D views of the GEMM outputs, activation dtype) ->
     (prob [N,NC], local_loc [N,Tl,4], first_loc, last_loc [N,T,4], loss_cls [N*NC | 1], loss_loc [1], loss_nbr [1]) fp32."""
@@ -903,6 +923,9 @@ def head_outputs(logits, reg, N, Tl, T, NC, tubes=None, targets=None):
     if lg.stride(1) != 1 or (rg is not None and rg.stride(1) != 1):
         lg, rg = lg.contiguous(), (None if rg is None else rg.contiguous())
     f32 = lambda t: None if t is None else t.detach().float().contiguous()
+    _check_head_targets("head_outputs", dev, N, Tl, NC, tubes, targets)
+    if lg.shape[1] < NC or (rg is not None and rg.shape[1] < 12):
+        raise RuntimeError("step_amd: head_outputs wants >= NC logit columns and >= 12 regression columns per row")
     tubes, targets = f32(tubes), f32(targets)
     train = targets is not None
     prob = torch.empty((N, NC), dtype=torch.float32, device=dev)
@@ -926,6 +949,9 @@ def head_outputs_backward(logits, reg, N, Tl, T, NC, tubes, targets, g_cls, g_lo
     if lg.stride(1) != 1 or (rg is not None and rg.stride(1) != 1):
         lg, rg = lg.contiguous(), (None if rg is None else rg.contiguous())
     f32 = lambda t: None if t is None else t.detach().float().contiguous()
+    _check_head_targets("head_outputs_backward", logits.device, N, Tl, NC, tubes, targets)
+    if targets is None:
+        raise RuntimeError("step_amd: head_outputs_backward wants the targets of the forward call")
     g_logits = torch.empty((N * Tl, NC), dtype=logits.dtype, device=logits.device)
     g_reg = torch.empty((N * Tl, 12), dtype=reg.dtype, device=reg.device) if rg is not None else None
     g_cls, g_loc, g_nbr = f32(g_cls), f32(g_loc), f32(g_nbr)

@@ -101,7 +101,7 @@ class C4TrainStep:
     selection between steps (utils/utils.py:135-423, host Python) is not part of the hot path: every step trains on the
     same `tubes_per_clip` anchor tubes, extended to the step's length."""
 
-    def __init__(self, dev, batch=1, tubes_per_clip=5, seed=123, max_iter=3, dtype=torch.float32, capturable=False):
+    def __init__(self, dev, batch=1, tubes_per_clip=5, seed=123, max_iter=3, dtype=torch.float32, capturable=False, force_exchange=False):
         # replicas: the same weights on every rank (same init seed, then rank 0's copy is broadcast once, as DDP does);
         # `seed` only varies the rank's clips
         self.args, self.base, self.ctx, self.nets = build_nets(dev, 123, heads=max_iter)
@@ -113,9 +113,12 @@ class C4TrainStep:
         self.params = [p for m in self.mods for p in m.parameters() if p.requires_grad]
         self.opt = FlatAdam(self.params, lr=1e-5, capturable=capturable)
         self.graph = None
+        self.graph_mode = None                                   # "one" | "split" after capture()
+        self._g_update = None
         # the gradient exchange runs bucket by bucket on a communication stream WHILE backward is still producing the
         # earlier layers' gradients (step_amd.dist.BucketedReducer); single-process runs issue nothing
-        self.reducer = sdist.BucketedReducer(self.opt)
+        # (force_exchange: in a ONE-rank process group the collectives are issued all the same -- the multi-rank program on a one-GPU box)
+        self.reducer = sdist.BucketedReducer(self.opt, single_rank=bool(force_exchange))
         # fp32 master weights either way; a 16-bit clip makes every activation / data gradient 16-bit (fp32 accumulate),
         # weight gradients stay fp32
         self.x = ava_clips(seed, batch).to(dev).to(dtype)
@@ -167,26 +170,17 @@ class C4TrainStep:
     def step(self):
         if self.graph is not None:
             self.opt._refresh_tables()                           # lr / weight_decay of param_groups -> the device tables the captured Adam reads (schedulers keep working)
-            self.graph.replay()                                  # ~1300 launches, one submission
+            self.graph.replay()                                  # ~800 launches (+ the bucket all-reduces of a multi-rank step), one submission
+            if self._g_update is not None:                       # "split" form: forward / backward replayed, the exchange eager, the update replayed
+                sdist.allreduce_flat(self.opt.flat_grad)
+                self._g_update.replay()
             # the replay re-packed the weights at its start and Adam changed them at its end: any eager use of the modules between
             # replays (validation) must see its packed-weight caches as stale
             torch.autograd.graph.increment_version(self.params)
             return self.loss
         return self._eager_step()
 
-    def capture(self, warmup=3):
-        """Capture the WHOLE step (forward, backward with the side-stream weight gradients, weight re-pack, Adam) in one HIP graph;
-        step() then replays it.  The shapes of this step are static (fixed tubes per clip), every scalar that changes between
-        steps lives on the device (FlatAdam(capturable=True): step counter), and nothing on the path synchronises with the host --
-        with 16-bit activations the eager step is bound by the host issuing ~1300 launches, not by the GPU.  Single process
-        only: the bucketed gradient exchange of a multi-rank run stays eager.  Runs `warmup` eager steps first (caches, pack
-        tables, workspaces); the captured step itself is recorded, not executed."""
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            raise RuntimeError("C4TrainStep.capture: single-process only (the gradient exchange is not captured)")
-        if not self.opt.capturable:
-            raise RuntimeError("C4TrainStep.capture: build the workload with capturable=True (device-side Adam step counter)")
-        import gc
-        gc.collect()                                             # (torch.cuda.graph collects too: dead nets must not drop out of the re-pack table mid-capture)
+    def _warm(self, warmup):
         dev = self.x.device
         cur = torch.cuda.current_stream(dev)
         s = torch.cuda.Stream(dev)
@@ -196,13 +190,71 @@ class C4TrainStep:
                 self._eager_step()
         cur.wait_stream(s)
         torch.cuda.synchronize(dev)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._eager_step()
+
+    def capture(self, warmup=3, mode="auto"):
+        """Capture the WHOLE step (forward, backward with the side-stream weight gradients, the gradient exchange, weight re-pack, Adam)
+        in one HIP graph; step() then replays it.  The shapes of this step are static (fixed tubes per clip), every scalar that
+        changes between steps lives on the device (FlatAdam(capturable=True): step counter), and nothing on the path synchronises with
+        the host -- with 16-bit activations the eager step is bound by the host issuing ~800 launches, not by the GPU.
+
+        With a process group (the reference's step is one optimizer.step() per iteration over all devices, train.py:142-148,257-348) the
+        N > 1 step is the SAME program as the N = 1 step: mode "one" records the bucket all-reduces on the communication stream
+        inside the graph (RCCL collectives are stream-ordered and capturable; ProcessGroupNCCL issues them on its own stream, forked
+        from and joined to the capturing stream by events, and keeps captured work off its watchdog) -- the overlap of the exchange with
+        backward is part of the replayed graph.  Mode "split" is the fallback where the collectives cannot be recorded (a gloo group;
+        an RCCL build that refuses capture): graph 1 = forward + backward into the gradient arena, the exchange eager as ONE flat
+        all-reduce, graph 2 = re-pack + Adam.  "auto" = "one" on nccl, falling back to "split" if the capture raises.
+        Runs `warmup` eager steps first (caches, pack tables, workspaces, the communicator); the captured step itself is recorded,
+        not executed."""
+        if not self.opt.capturable:
+            raise RuntimeError("C4TrainStep.capture: build the workload with capturable=True (device-side Adam step counter)")
+        import gc
+        dd = torch.distributed
+        grouped = self.reducer.active
+        backend = dd.get_backend() if (dd.is_available() and dd.is_initialized()) else None
+        if mode == "auto":
+            mode = "one" if (not grouped or backend == "nccl") else "split"
+        if mode not in ("one", "split"):
+            raise ValueError("C4TrainStep.capture: mode is 'auto', 'one' or 'split'")
+        if mode == "one" and grouped and backend != "nccl":
+            raise RuntimeError("C4TrainStep.capture(mode='one'): only RCCL ('nccl') collectives can be recorded in a HIP graph; use mode='split'")
+        gc.collect()                                             # (torch.cuda.graph collects too: dead nets must not drop out of the re-pack table mid-capture)
+        self._warm(warmup)
+        dev = self.x.device
+        # with a live process group its watchdog / heartbeat threads may touch the runtime while this thread records: only THIS thread's
+        # calls are checked against the capture
+        kw = {"capture_error_mode": "thread_local"} if grouped else {}
+        if mode == "one":
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, **kw):
+                    self._eager_step()
+                self.graph, self.graph_mode, self._g_update = g, "one", None
+            except RuntimeError as e:
+                if not grouped:
+                    raise
+                import warnings
+                warnings.warn("C4TrainStep.capture: recording the gradient exchange failed (%s); falling back to the split form" % (str(e).splitlines()[0],))
+                torch.cuda.synchronize(dev)
+                self.reducer._armed = False
+                from . import backbone as _bb
+                _bb.GRAD_READY = _bb.GRAD_DEFER = None
+                _bb.wgrad_sync()
+                self.opt.zero_grad()
+                mode = "split"
+        if mode == "split":
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, **kw):
+                loss = self.forward_backward(exchange=False)
+                self.loss = loss.detach()
+            world = dd.get_world_size() if (dd.is_available() and dd.is_initialized()) else 1
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, **kw):
+                self.opt.step(grad_scale=1.0 / world, zero_grad=True)
+            self.graph, self._g_update, self.graph_mode = g1, g2, "split"
         # host-side caches now carry the version stamps of a step whose kernels only run on replay: make them stale again for
         # any eager use of the modules after this point
         torch.autograd.graph.increment_version(self.params)
-        self.graph = g
         return self
 
 

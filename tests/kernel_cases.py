@@ -1404,6 +1404,27 @@ def case_wgrad_partial_and_grouped_reduce(bk, golden):
     assert bk.lib.step_wgrad_reduce_group(items, 9, bk.stream) == -2 and bk.lib.step_wgrad_reduce_group(items, 0, bk.stream) == 0
     none = _capi.WgradReduceItem()
     assert bk.lib.step_wgrad_reduce_group(ctypes.byref(none), 1, bk.stream) == 0          # kind 0: nothing pending
+    # the SAME gradient twice in one group (a unit used twice in a graph; leftovers of an earlier backward): the members of one launch run
+    # concurrently and each ends in a plain read-modify-write, so the entry point must order them as separate launches -- the result
+    # equals two accumulating single-layer calls
+    dt, N, Cin, Cout, D, H, W, k = BF16, 1, 64, 72, 2, 10, 14, (3, 3, 3)
+    d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2], x_cstride=Cin, x_coff=0,
+                       y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)
+    nb = bk.lib.step_conv_wgrad16_workspace_bytes(ctypes.byref(d))
+    xs = [bk.dev(encode(rs.randn(N, D, H, W, Cin).astype(np.float32), dt)) for _ in range(2)]
+    gs = [bk.dev(encode(rs.randn(N, D, H, W, Cout).astype(np.float32), dt)) for _ in range(2)]
+    init = rs.randn(Cout, Cin, *k).astype(np.float32)
+    dwa, dwb = bk.dev(init.copy()), bk.dev(init.copy())
+    wsa = [bk.dev(np.full(nb // 4, np.nan, np.float32)) for _ in range(2)]
+    for i in range(2):
+        assert bk.lib.step_conv_wgrad16_ws(ctypes.byref(d), xs[i].ptr, gs[i].ptr, dwa.ptr, 1, wsa[i].ptr, nb, bk.stream) == 0
+    two = (_capi.WgradReduceItem * 2)()
+    wsb = [bk.dev(np.full(nb // 4, np.nan, np.float32)) for _ in range(2)]
+    for i in range(2):
+        assert bk.lib.step_conv_wgrad_partial(ctypes.byref(d), xs[i].ptr, gs[i].ptr, 1, dwb.ptr, 1, wsb[i].ptr, nb, ctypes.byref(two[i]), bk.stream) == 0
+    assert two[0].dw == two[1].dw
+    assert bk.lib.step_wgrad_reduce_group(two, 2, bk.stream) == 0
+    assert np.array_equal(dwb.get(), dwa.get())
 
 
 def case_stem_pool_fused(bk, golden):

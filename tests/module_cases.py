@@ -1255,17 +1255,36 @@ def case_loss_masks_without_host_branches(dev, golden):
     assert out[(False, "none")][0][0].size == 1 and out[(True, "none")][0][0].size == out[(True, "pos")][0][0].size
 
 
+def _full_size_oracle(golden, tag, name, shape):
+    """The oracle's fp32 conv_feat of the pinned full-size clip (seconds on the host), itself checked here against the digest the
+    imported reference left in tests/golden/full_size_golden.npz."""
+    g = golden("full_size_golden")
+    xo = R.fill_tensor(name, shape, "image")
+    with torch.no_grad():
+        yo = R.basenet_forward(xo, R.fill_state_dict(R.backbone_shapes())).contiguous()
+    f = yo.reshape(-1)
+    st = int(g[tag + ".out_stats"][3])
+    assert rel(f[::st][:4096].numpy(), g[tag + ".out_sample"]) < 1e-5
+    return xo, yo.numpy()
+
+
 def case_c2_full_size_properties(dev, golden):
-    """BASELINE C2 at its full size (8 x [32,3,224,224], bf16) -- too big for the oracle, so parity is checked through
-    size-independent properties:
+    """BASELINE C2 at its full size (8 x [32,3,224,224], bf16), the config the bench number is quoted on:
+      * ORACLE PARITY AT THIS SIZE: clip 3 of the batch is the pinned clip `golden.c2.images`; the fp32 HIP run of it is held to the
+        oracle's full [1,8,832,14,14] tensor at 1e-3 (north_star's bound), and the bf16 / fp16 errors are measured AGAINST THE ORACLE
+        (not against the HIP fp32 run), recorded and bounded; the oracle itself is pinned at this shape by full_size_golden.npz
+        (digests of the imported reference, models/networks.py:69-83);
       * clip independence: every tensor on the path is per clip, so a clip's features must not depend on which batch
         it travels in (the launch planner picks other tile shapes / channel groupings for other batch sizes; the K
         order of every accumulation is the same) -> the batch-of-8 result equals the clip computed alone, BIT-EXACT;
       * permutation equivariance of the batch axis (bit-exact);
-      * the fp32 run of the same clip agrees with the bf16 run within the 16-bit bound of the C1 golden test."""
+      * the fusion toggles leave the batch bit-identical."""
     net = fill(step_amd.BaseNet(cfg())).to(dev).eval()
     g = torch.Generator().manual_seed(123)
-    x = (torch.rand(8, 32, 3, 224, 224, generator=g) * 2 - 1).to(dev)
+    x = torch.rand(8, 32, 3, 224, 224, generator=g) * 2 - 1
+    xo, yo = _full_size_oracle(golden, "c2", "golden.c2.images", (1, 32, 3, 224, 224))
+    x[3:4] = xo
+    x = x.to(dev)
     xb = x.to(torch.bfloat16)
     with torch.no_grad():
         y8 = net(xb).clone()
@@ -1276,6 +1295,15 @@ def case_c2_full_size_properties(dev, golden):
         yp = net(xb[perm])
         assert torch.equal(yp, y8[perm])
         yf = net(x[3:4])
+        ef = rel(np_(yf), yo)
+        record("c2_full_size_fp32_vs_oracle", ef)
+        assert ef < 1e-3, ef                                       # north_star: within 1e-3 rel of the reference CPU path (measured ~1e-6)
+        eb = rel(np_(y1), yo)
+        record("c2_full_size_bf16_vs_oracle", eb)
+        assert eb < 1e-2, eb                                       # one bf16 rounding per layer over 45 layers (C1: 5.0e-3 of 8e-3)
+        eh = rel(np_(net(x[3:4].half())), yo)
+        record("c2_full_size_fp16_vs_oracle", eh)
+        assert eh < 2e-3, eh
         e = rel(np_(y1), np_(yf))
         record("c2_full_size_bf16_vs_fp32", e)
         assert e < 1e-2, e
@@ -1299,12 +1327,16 @@ def case_c2_full_size_properties(dev, golden):
 
 
 def case_c5_full_size_properties(dev, golden):
-    """BASELINE C5 at one GPU's share (4 x [64,3,400,400], fp16) -- the long-clip stress shape, too big for the oracle:
-    clip independence (a clip alone == the clip inside the batch of 4, BIT-EXACT, although the planner tiles the two
-    launches differently), finite outputs of the right shape, and the fp16 run within the 16-bit bound of the fp32 run."""
+    """BASELINE C5 at one GPU's share (4 x [64,3,400,400], fp16) -- the long-clip stress shape: ORACLE PARITY AT THIS SIZE (clip 2 is the
+    pinned clip `golden.c5.images`: fp32 HIP within 1e-3 of the oracle's full [1,16,832,25,25] tensor, the fp16 error against the oracle
+    recorded and bounded; the oracle pinned by full_size_golden.npz), clip independence (a clip alone == the clip inside the batch of 4,
+    BIT-EXACT, although the planner tiles the two launches differently), finite outputs of the right shape."""
     net = fill(step_amd.BaseNet(cfg())).to(dev).eval()
     g = torch.Generator().manual_seed(321)
-    x = (torch.rand(4, 64, 3, 400, 400, generator=g) * 2 - 1).to(dev)
+    x = torch.rand(4, 64, 3, 400, 400, generator=g) * 2 - 1
+    xo, yo = _full_size_oracle(golden, "c5", "golden.c5.images", (1, 64, 3, 400, 400))
+    x[2:3] = xo
+    x = x.to(dev)
     xh = x.to(torch.float16)
     with torch.no_grad():
         y4 = net(xh).clone()
@@ -1312,6 +1344,12 @@ def case_c5_full_size_properties(dev, golden):
         y1 = net(xh[2:3]).clone()
         assert torch.equal(y4[2:3], y1), float((y4[2:3].float() - y1.float()).abs().max())
         yf = net(x[2:3])
+        ef = rel(np_(yf), yo)
+        record("c5_full_size_fp32_vs_oracle", ef)
+        assert ef < 1e-3, ef
+        eh = rel(np_(y1), yo)
+        record("c5_full_size_fp16_vs_oracle", eh)
+        assert eh < 4e-3, eh
         e = rel(np_(y1), np_(yf))
         record("c5_full_size_fp16_vs_fp32", e)
         assert e < 4e-3, e

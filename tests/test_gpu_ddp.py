@@ -176,6 +176,72 @@ def test_bucketed_exchange_over_rccl_with_one_rank():
     assert nb >= 5 and during >= nb - 2, (during, nb)
 
 
+def _rccl_captured_step_worker(port, q):
+    import numpy as np
+    import torch.distributed as dist
+    from step_amd import workloads
+
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    steps, warm = 4, 2
+    out = {}
+    for mode in ("eager", "one", "split"):
+        torch.manual_seed(7)
+        w = workloads.C4TrainStep(dev, batch=1, seed=123, dtype=torch.bfloat16, capturable=(mode != "eager"), force_exchange=True)
+        assert w.reducer.active
+        p0 = w.opt.flat_param.clone()
+        if mode == "eager":
+            for _ in range(steps):
+                w.step()
+        else:
+            w.capture(warmup=warm, mode=mode)
+            assert w.graph is not None
+            out["mode_" + mode] = w.graph_mode
+            for _ in range(steps - warm):
+                w.step()
+            assert w.opt.step_count == steps
+        torch.cuda.synchronize()
+        out[mode] = (w.opt.flat_param - p0).double().cpu().numpy()
+        out["loss_" + mode] = float(w.loss)
+        w.reducer.close()
+        del w
+        torch.cuda.empty_cache()
+    res = {"one_mode": out["mode_one"], "split_mode": out["mode_split"],
+           "one_identical": bool(np.array_equal(out["eager"], out["one"])), "split_identical": bool(np.array_equal(out["eager"], out["split"])),
+           "one_rel": float(np.linalg.norm(out["eager"] - out["one"]) / np.linalg.norm(out["eager"])),
+           "split_rel": float(np.linalg.norm(out["eager"] - out["split"]) / np.linalg.norm(out["eager"])),
+           "moved": float(np.abs(out["eager"]).max()), "losses": [out["loss_eager"], out["loss_one"], out["loss_split"]]}
+    q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_captured_step_with_the_gradient_exchange_recorded_in_the_graph():
+    """The multi-rank training step is the SAME replayed program as the one-rank step (the reference runs one
+    optimizer.step() per iteration over all devices, train.py:142-148,257-348): C4TrainStep.capture() with a process group records the
+    bucketed RCCL all-reduces on the communication stream INSIDE the step's HIP graph (mode "one"), or brackets one eager flat
+    all-reduce with two graphs (mode "split").  On the one-GPU box the group has one rank and the exchange is forced
+    (force_exchange=True: every bucket really goes through RCCL, a one-rank SUM is the identity), so both captured forms must
+    reproduce the eager exchanged steps' parameter trajectory BIT FOR BIT."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    p = ctx.Process(target=_rccl_captured_step_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get()
+    p.join(240)
+    assert p.exitcode == 0
+    import json, os
+    d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ""), "gpurun_out")
+    if os.environ.get("GRAFT_REPO_ROOT") and os.path.isdir(d):
+        json.dump(res, open(os.path.join(d, "captured_exchange.json"), "w"))
+    assert res["moved"] > 0
+    assert res["split_mode"] == "split" and res["split_identical"], res
+    assert res["one_mode"] in ("one", "split"), res               # ("split" only if this RCCL build refused the capture: recorded in captured_exchange.json)
+    assert res["one_identical"], res
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("config", ["c4", "c2"])
 def test_bench_launches_and_reduces_over_two_ranks(config):

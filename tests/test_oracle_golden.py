@@ -131,6 +131,31 @@ def test_backbone_c1(golden):
         assert rel_err(s.reshape(-1)[::step][:256].numpy(), g["stage%d_sample" % i]) < 1e-5, i
 
 
+FULL_SIZE_CLIPS = {"c2": ("golden.c2.images", (1, 32, 3, 224, 224)), "c5": ("golden.c5.images", (1, 64, 3, 400, 400))}
+
+
+@pytest.mark.parametrize("tag", ["c2", "c5"])
+def test_backbone_full_size(golden, tag):
+    """The restatement at the shapes the bench numbers are quoted on (BASELINE C2: T=32, 224^2; C5: T=64, 400^2), one clip each, against
+    digests of the imported reference's BaseNet at that shape (oracle/make_golden.py full_size; models/networks.py:69-83)."""
+    g = golden("full_size_golden")
+    name, shape = FULL_SIZE_CLIPS[tag]
+    sd = R.fill_state_dict(R.backbone_shapes())
+    x = R.fill_tensor(name, shape, "image")
+    with torch.no_grad():
+        y, stages = R.basenet_forward(x, sd, return_stages=True)
+    assert list(y.shape) == list(g[tag + ".out_shape"])
+    f = y.contiguous().reshape(-1)
+    st = int(g[tag + ".out_stats"][3])
+    assert rel_err(f[::st][:4096].numpy(), g[tag + ".out_sample"]) < 1e-5
+    assert abs(float(f.double().norm()) - g[tag + ".out_stats"][2]) < 1e-5 * g[tag + ".out_stats"][2]
+    for i, s in enumerate(stages):
+        assert list(s.shape) == list(g["%s.stage%d_shape" % (tag, i)])
+        step = int(g["%s.stage%d_stats" % (tag, i)][3])
+        assert rel_err(s.reshape(-1)[::step][:256].numpy(), g["%s.stage%d_sample" % (tag, i)]) < 1e-5, i
+        assert abs(float(s.double().norm()) - g["%s.stage%d_stats" % (tag, i)][2]) < 1e-5 * g["%s.stage%d_stats" % (tag, i)][2], i
+
+
 def test_single_ops(golden):
     g = golden("ops_golden")
     xin = R.fill_tensor("golden.pool.in", (2, 5, 6, 9, 11), "image")
