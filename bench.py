@@ -471,7 +471,10 @@ def fed_loop(a, net, flights, x, dev, tdt, dist, resident_s_per_step):
         stages.append(torch.empty((N, T, H, W, 3), dtype=torch.uint8, device=dev))
         xs.append(x if i == 0 else fl[2])                      # the captured graphs' static inputs
         streams.append(fl[0]); graphs.append(fl[1])
-    copy_stream = torch.cuda.Stream()
+    # a HIGH-PRIORITY stream: HIP maps streams onto a handful of hardware queues, and a normal-priority copy stream can land in the
+    # queue of a compute stream -- its copies then wait behind that stream's whole captured step (measured, tools/feed_probe.py: the
+    # fed loop at 4.5 k clips/s with a normal copy stream, 6.45 k with a high-priority one, 7.05 k resident; copy alone 56 GB/s)
+    copy_stream = torch.cuda.Stream(priority=-1)
     ev_copied = [torch.cuda.Event() for _ in range(nfl)]
     ev_conv = [torch.cuda.Event() for _ in range(nfl)]
     nbytes = hosts[0].numel()
@@ -529,7 +532,8 @@ def fed_loop(a, net, flights, x, dev, tdt, dist, resident_s_per_step):
     elif h2d < 1.1 * need:
         limit = "the host->device link: the copy-only loop moves %.1f GB/s per rank, the resident rate would consume %.1f GB/s" % (h2d, need)
     else:
-        limit = "neither link nor compute alone: copy-only %.1f GB/s exceeds the %.1f GB/s the fed rate consumes -- the copy's dependency on the previous conversion / the conversion launch serialise" % (h2d, nbytes / N * (fed_rate / world) / 1e9)
+        limit = ("compute + the conversion pass: the link has room (copy-only %.1f GB/s against the %.1f GB/s the fed rate consumes); what the fed loop adds to every "
+                 "step is step_clip_from_u8 on the compute stream (reads the uint8 batch, writes the 16-bit clip) and the copy's HBM writes under the backbone" % (h2d, nbytes / N * (fed_rate / world) / 1e9))
     return {"value": round(fed_rate, 2), "unit": "clips/s", "ms_per_step": round(el_f / steps * 1e3, 4), "steps": steps,
             "resident_value": round(res_rate, 2), "fed_over_resident": round(fed_rate / res_rate, 4),
             "wire_format": "uint8 [N,T,H,W,3], %.2f MB per clip (fp32 [T,3,H,W] as the reference feeds it: %.2f MB)" % (nbytes / N / 1e6, 4 * nbytes / N / 1e6),
@@ -537,7 +541,7 @@ def fed_loop(a, net, flights, x, dev, tdt, dist, resident_s_per_step):
             "u8_GBs_needed_at_resident_rate": round(need, 2), "bottleneck": limit,
             "eight_ranks": "8 ranks at this rate pull %.0f GB/s of uint8 frames from the host (fp32 frames: %.0f GB/s)" % (8 * nbytes / N * (fed_rate / world) / 1e9, 32 * nbytes / N * (fed_rate / world) / 1e9),
             "note": "pinned host buffers (synthetic frames, not rewritten between steps) -> hipMemcpyAsync on a copy stream -> step_clip_from_u8 (x*2/255-1) into "
-                    "the captured step's input -> captured step; %d batches in flight; copy k+%d waits for conversion k only" % (nfl, nfl)}
+                    "the captured step's input -> captured step; %d batches in flight; copy k+%d waits for conversion k only; the copy stream is a high-priority stream (own hardware queue)" % (nfl, nfl)}
 
 
 def spawn_ranks(n):

@@ -669,16 +669,24 @@ def clip_from_u8(frames, dtype=torch.float32, scale=2, mean=(0.0, 0.0, 0.0), std
     if frames.dtype != torch.uint8 or frames.dim() != 5 or frames.shape[-1] != 3 or not frames.is_contiguous():
         raise RuntimeError("step_amd: clip_from_u8 expects contiguous uint8 frames [N,T,H,W,3]")
     N, T, H, W, _ = frames.shape
+    host = not frames.is_cuda
+    if host:
+        # ZERO-COPY ingest: page-locked host memory is mapped into the device's address space (hipHostMalloc), so the kernel can read
+        # the frames over the host link itself -- the transfer and the conversion are one pass, no staging buffer, no copy engine,
+        # no cross-stream event.  Only pinned tensors, and only with an explicit device-side `out`.
+        if not frames.is_pinned() or out is None or not out.is_cuda:
+            raise RuntimeError("step_amd: clip_from_u8 on host frames wants PINNED memory and a device tensor `out` (no CPU fallback)")
     if out is None:
         out = torch.empty((N, T, 3, H, W), dtype=dtype, device=frames.device)
     else:
-        if tuple(out.shape) != (N, T, 3, H, W) or not out.is_contiguous() or out.device != frames.device:
+        if tuple(out.shape) != (N, T, 3, H, W) or not out.is_contiguous() or (not host and out.device != frames.device):
             raise RuntimeError("step_amd: clip_from_u8(out=...) wants a contiguous [N,T,3,H,W] tensor on the frames' device")
         dtype = out.dtype
     m = (ctypes.c_float * 3)(*[float(v) for v in mean])
     sd = (ctypes.c_float * 3)(*[float(v) for v in std])
     code = {torch.float32: _capi.F32, torch.bfloat16: _capi.BF16, torch.float16: _capi.F16}[dtype]
-    _capi.check(L.step_clip_from_u8(_lib.dptr(frames), N, T, H, W, int(scale), m, sd, code, _lib.dptr(out), _lib.stream_ptr(frames.device)),
+    src = ctypes.c_void_p(frames.data_ptr()) if host else _lib.dptr(frames)
+    _capi.check(L.step_clip_from_u8(src, N, T, H, W, int(scale), m, sd, code, _lib.dptr(out), _lib.stream_ptr(out.device)),
                 "step_clip_from_u8")
     return out
 

@@ -177,6 +177,15 @@ def test_bucketed_exchange_over_rccl_with_one_rank():
 
 
 def _rccl_captured_step_worker(port, q):
+    try:
+        _rccl_captured_step_body(port, q)
+    except BaseException:                                         # the parent must hear about it (a dead worker would leave it waiting)
+        import traceback
+        q.put({"error": traceback.format_exc()[-3000:]})
+        raise
+
+
+def _rccl_captured_step_body(port, q):
     import numpy as np
     import torch.distributed as dist
     from step_amd import workloads
@@ -226,11 +235,16 @@ def test_captured_step_with_the_gradient_exchange_recorded_in_the_graph():
     (force_exchange=True: every bucket really goes through RCCL, a one-rank SUM is the identity), so both captured forms must
     reproduce the eager exchanged steps' parameter trajectory BIT FOR BIT."""
     ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
+    q = ctx.Queue()
     p = ctx.Process(target=_rccl_captured_step_worker, args=(_free_port(), q))
     p.start()
-    res = q.get()
-    p.join(240)
+    try:
+        res = q.get(timeout=600)
+    finally:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert "error" not in res, res["error"]
     assert p.exitcode == 0
     import json, os
     d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ""), "gpurun_out")

@@ -79,7 +79,7 @@ def main():
         g_ = torch.Generator().manual_seed(999 + rank)
         host = [torch.randint(0, 256, (N, T, H, W, 3), dtype=torch.uint8, generator=g_).pin_memory() for _ in range(2)]
         stage = [torch.empty((N, T, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
-        copy_stream = torch.cuda.Stream()
+        copy_stream = torch.cuda.Stream(priority=-1)             # own hardware queue: never behind the captured step (tools/feed_probe.py)
         copied = [torch.cuda.Event() for _ in range(2)]
         main_stream = torch.cuda.current_stream()
 
