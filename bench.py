@@ -470,7 +470,9 @@ def fed_loop(a, net, flights, x, dev, tdt, dist, resident_s_per_step):
         hosts.append(torch.randint(0, 256, (N, T, H, W, 3), dtype=torch.uint8, generator=g).pin_memory())
         stages.append(torch.empty((N, T, H, W, 3), dtype=torch.uint8, device=dev))
         xs.append(x if i == 0 else fl[2])                      # the captured graphs' static inputs
-        streams.append(fl[0]); graphs.append(fl[1])
+        # every batch in flight on a stream of its own (the resident loop replays batch 0 on the default stream: measured, the fed loop
+        # on the default stream + a second one does not overlap its copies -- 4.6 k clips/s -- whatever the copy stream's priority)
+        streams.append(torch.cuda.Stream()); graphs.append(fl[1])
     # a HIGH-PRIORITY stream: HIP maps streams onto a handful of hardware queues, and a normal-priority copy stream can land in the
     # queue of a compute stream -- its copies then wait behind that stream's whole captured step (measured, tools/feed_probe.py: the
     # fed loop at 4.5 k clips/s with a normal copy stream, 6.45 k with a high-priority one, 7.05 k resident; copy alone 56 GB/s)

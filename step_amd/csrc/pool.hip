@@ -717,6 +717,44 @@ __global__ void clip_from_u8_kernel(const unsigned char* __restrict__ src, T* __
     }
 }
 
+// The same conversion, 16 consecutive pixels of one frame per thread (H*W % 16 == 0, 16-byte aligned buffers): three 16-byte loads of the
+// interleaved bytes, per plane 16 * sizeof(T) contiguous bytes stored as 16-byte vectors -- a wave reads 3 KB and writes 1-2 KB per plane,
+// all contiguous (the per-pixel form issues byte loads and 2-byte stores).  The same fp32 operations in the same order per element:
+// bit-identical (kernel case).
+template <typename T>
+__global__ __launch_bounds__(256) void clip_from_u8_vec_kernel(const unsigned char* __restrict__ src, T* __restrict__ dst, int HW, int scale,
+                                                               float m0, float m1, float m2, float s0, float s1, float s2, long long total16) {
+    const int per_frame = HW >> 4;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total16; idx += (long long)blockDim.x * gridDim.x) {
+        const long long f = idx / per_frame;
+        const int pix = (int)(idx % per_frame) << 4;
+        const u32x4* s4 = (const u32x4*)(src + (f * HW + pix) * 3);
+        const u32x4 q0 = s4[0], q1 = s4[1], q2 = s4[2];
+        const unsigned w[12] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3], q2[0], q2[1], q2[2], q2[3]};
+        const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            T o[16];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int b = 3 * p + c;
+                float v = (float)((w[b >> 2] >> (8 * (b & 3))) & 0xffu);
+                if (scale == 1) v = __fdiv_rn(v, 255.f);
+                else if (scale == 2) v = __fsub_rn(__fdiv_rn(__fmul_rn(v, 2.f), 255.f), 1.f);
+                v = __fdiv_rn(__fsub_rn(v, mean[c]), stdv[c]);
+                o[p] = elem<T>::from_f32(v);
+            }
+            u32x4* d4 = (u32x4*)(dst + (f * 3 + c) * HW + pix);
+#pragma unroll
+            for (int v_ = 0; v_ < (int)sizeof(T); ++v_) {       // sizeof(T) 16-byte vectors per 16 elements
+                u32x4 ov;
+                __builtin_memcpy(&ov, (const char*)o + 16 * v_, 16);
+                d4[v_] = ov;
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ void avgpool_hw_kernel(const T* __restrict__ x, T* __restrict__ y, int ND, int H, int W, int C, int kh,
                                   int kw, long long total) {
@@ -998,6 +1036,17 @@ int step_clip_from_u8(const unsigned char* frames, int N, int T, int H, int W, i
     const float m0 = mean3 ? mean3[0] : 0.f, m1 = mean3 ? mean3[1] : 0.f, m2 = mean3 ? mean3[2] : 0.f;   // host pointers (3 floats)
     const float s0 = std3 ? std3[0] : 1.f, s1 = std3 ? std3[1] : 1.f, s2 = std3 ? std3[2] : 1.f;
     const long long fr = (long long)N * T, total = fr * H * W;
+    if (dtype != STEP_F32 && dtype != STEP_BF16 && dtype != STEP_F16) return STEP_E_DTYPE;
+    if ((H * W) % 16 == 0 && ((size_t)frames & 15) == 0 && ((size_t)clip & 15) == 0 && opt(STEP_OPT_CLIP_VEC) != 0) {
+        const long long total16 = total / 16;
+        const dim3 g16(pool_flat_grid(total16, 256));
+        switch (dtype) {
+            case STEP_F32: STEP_LAUNCH((clip_from_u8_vec_kernel<float>), g16, dim3(256), stream, frames, (float*)clip, H * W, scale, m0, m1, m2, s0, s1, s2, total16); break;
+            case STEP_BF16: STEP_LAUNCH((clip_from_u8_vec_kernel<bf16_t>), g16, dim3(256), stream, frames, (bf16_t*)clip, H * W, scale, m0, m1, m2, s0, s1, s2, total16); break;
+            default: STEP_LAUNCH((clip_from_u8_vec_kernel<f16_t>), g16, dim3(256), stream, frames, (f16_t*)clip, H * W, scale, m0, m1, m2, s0, s1, s2, total16); break;
+        }
+        return STEP_LAUNCH_CHECK();
+    }
     const dim3 grid(pool_flat_grid(total, 256));
     switch (dtype) {
         case STEP_F32: STEP_LAUNCH((clip_from_u8_kernel<float>), grid, dim3(256), stream, frames, (float*)clip, H * W, fr, scale, m0, m1, m2, s0, s1, s2, total); break;

@@ -625,6 +625,32 @@ def case_clip_from_u8(bk, golden):
     ref2 = np.transpose(fr.astype(np.float32) * 2 / 255 - 1., (0, 1, 4, 2, 3))
     assert np.array_equal(outb.get(), to_bf16_bits(ref2))
     assert bk.lib.step_clip_from_u8(None, N, T, H, W, 3, None, None, F32, out.ptr, bk.stream) < 0
+    # the 16-pixels-per-thread form (H * W % 16 == 0: every network resolution) against numpy AND against the per-pixel kernel, every
+    # dtype and scale mode, a frame count that leaves the last workgroup partial
+    N, T, H, W = 2, 5, 12, 20
+    fr = rs.randint(0, 256, (N, T, H, W, 3)).astype(np.uint8)
+    fr[1, 4, 11, 16:20] = ((0, 255, 128), (255, 0, 1), (254, 127, 129), (1, 2, 3))
+    src = bk.dev(fr)
+    m = (ctypes.c_float * 3)(*mean.tolist())
+    sd = (ctypes.c_float * 3)(*std.tolist())
+    for scale in (0, 1, 2):
+        ref = fr.astype(np.float32)
+        if scale == 1:
+            ref = ref / np.float32(255.)
+        elif scale == 2:
+            ref = ref * np.float32(2) / np.float32(255) - np.float32(1.)
+        ref = ((ref.astype(np.float32) - mean) / std).astype(np.float32)
+        ref = np.ascontiguousarray(np.transpose(ref, (0, 1, 4, 2, 3)))
+        for dt, z in ((F32, np.float32), (BF16, np.uint16), (F16, np.uint16)):
+            got = {}
+            for vec in (1, 0):
+                with _capi.options(bk.lib, clip_vec=vec):
+                    o = bk.dev(np.zeros((N, T, 3, H, W), z))
+                    assert bk.lib.step_clip_from_u8(src.ptr, N, T, H, W, scale, m, sd, dt, o.ptr, bk.stream) == 0
+                    got[vec] = o.get()
+            assert np.array_equal(got[1], got[0]), (scale, dt)
+            want = ref if dt == F32 else (to_bf16_bits(ref) if dt == BF16 else ref.astype(np.float16).view(np.uint16))
+            assert np.array_equal(got[1], want), (scale, dt)
 
 
 def case_adam_flat(bk, golden):

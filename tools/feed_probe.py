@@ -85,6 +85,26 @@ def main():
             with torch.cuda.stream(cs):
                 stages[k % 2].copy_(hosts[k % 2], non_blocking=True)
         out["copy_only_GBs_prio%d" % prio] = round(nbytes * loop(copies) / 1e9, 1)
+    # flight 0 on the DEFAULT stream (what bench.py's resident loop does), high-priority copy stream
+    cs = torch.cuda.Stream(priority=-1)
+    dstreams = [torch.cuda.current_stream(), flights[1][0]]
+    ev_c = [torch.cuda.Event() for _ in range(2)]
+    ev_v = [torch.cuda.Event() for _ in range(2)]
+    for i in range(2):
+        ev_v[i].record(dstreams[i])
+
+    def staged_default(k):
+        i = k % 2
+        with torch.cuda.stream(cs):
+            cs.wait_event(ev_v[i])
+            stages[i].copy_(hosts[i], non_blocking=True)
+            ev_c[i].record(cs)
+        with torch.cuda.stream(dstreams[i]):
+            dstreams[i].wait_event(ev_c[i])
+            ops.clip_from_u8(stages[i], scale=2, out=flights[i][2])
+            ev_v[i].record(dstreams[i])
+            flights[i][1].replay()
+    out["staged_prio-1_2_flight0_on_default_stream"] = round(N * loop(staged_default), 1)
     # conversion on its own stream per flight (so the copy -> convert chain never sits in the compute stream's queue)
     for nfl in (2, 3)[:max(0, nfl_max - 1)]:
         cs = torch.cuda.Stream(priority=-1)
