@@ -367,7 +367,11 @@ static int pick_nb_tap(int nblk32, long long mtiles, int slots = 256) {
         const long long wgs = groups * mtiles;
         // `slots` resident workgroups on the chip (256 eight-wave ones, 512 four-wave ones): rounds of that many;
         // per-workgroup time ~ 2*nb MFMA units + fixed part
-        const double cost = (double)ceil_div64(wgs, slots) * (2.0 * nb + 1.5) - 0.01 * nb;
+        // (STEP_OPT_CONV_NB_RULE = 1: the CHIP TIME of the launch -- workgroups x per-workgroup time, no rounding to rounds: with two
+        // batches in flight the CUs a one-round launch leaves idle run the other batch, so fewer, deeper workgroups -- more MFMAs per
+        // fragment read -- are what counts, not the length of the round)
+        const double cost = opt(STEP_OPT_CONV_NB_RULE) == 1 ? (double)wgs * (2.0 * nb + 1.5) - 0.01 * nb
+                                                            : (double)ceil_div64(wgs, slots) * (2.0 * nb + 1.5) - 0.01 * nb;
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nb; }
     }
     return best;

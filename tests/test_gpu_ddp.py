@@ -286,3 +286,37 @@ def test_bench_launches_and_reduces_over_two_ranks(config):
     # whole-job value = clips of BOTH ranks over the slowest rank's time
     clips = j["config"]["clips_per_gpu"]
     assert abs(j["value"] - 2 * clips / (j["ms_per_step"] * 1e-3)) < 0.02 * j["value"] + 0.006, j     # (+ the rounding of `value` to two decimals: two ranks sharing one GPU over gloo take seconds per C4 step)
+
+
+@pytest.mark.timeout(900)
+def test_train_step_amd_launcher_two_ranks():
+    """train_step_amd.py (the torchrun entry INTEGRATION.md names as the replacement of train.py:142-148) with TWO ranks: process group,
+    clip shards, weight broadcast, the captured step and the gradient exchange, the learning-rate schedule through param_groups, the fed
+    (uint8, pinned, copy stream) input path.  Two GPUs: RCCL with the all-reduces recorded in the graph; the one-GPU box: the ranks share the
+    GPU over gloo, where the step is two graphs around one eager flat all-reduce -- the same program text either way.  Both ranks start
+    from rank 0's weights and apply the same averaged gradient, so the run must finish with a finite loss and the Adam step count of
+    warm-up + iterations; a one-rank run of the same command is the N = 1 form."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    two = torch.cuda.device_count() >= 2
+    for world in (2, 1):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(root, "train_step_amd.py"), "--iters", "4", "--warmup-iters", "2", "--log-every", "2",
+               "--lr-decay-every", "2", "--feed", "u8"] + ([] if (two or world == 1) else ["--backend", "gloo"])
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=root)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+        summ = [ln for ln in lines if ln.get("summary")]
+        assert len(summ) == 1, r.stdout[-2000:]
+        s = summ[0]
+        assert s["world_size"] == world and s["global_batch"] == world and s["clips_per_rank"] == 1 and s["feed"] == "u8"
+        assert s["adam_steps"] == 6 and np.isfinite(s["final_loss"]) and s["final_loss"] > 0 and s["ms_per_iter"] > 0
+        assert s["launch"].startswith("hipGraph replay") and (("split" in s["launch"]) == (world == 2 and not two))
+        assert (s["gradient_exchange"] is not None) == (world == 2)
+        logs = [ln for ln in lines if "iter" in ln]
+        assert [ln["iter"] for ln in logs] == [2, 4] and abs(logs[1]["lr"] - 0.1 * logs[0]["lr"]) < 1e-12     # the schedule reached the captured Adam's tables

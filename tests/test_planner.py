@@ -53,6 +53,24 @@ def test_planner_dispatch(lib):
     assert "conv_igemm_kernel" in n
 
 
+def test_planner_nb_rule(lib):
+    """conv_nb_rule (round 5 A/B, tools/plan_ab.py): 0 = the accumulator depth that needs the fewest ROUNDS of the chip (the default: the
+    14x14 layers take NB = 1, one round of 224-280 workgroups), 1 = the depth with the least chip time (workgroups x per-workgroup time):
+    the 14x14 layers go deeper, conv3d_2c and the 28x28 layers keep their depth."""
+    BF = _capi.BF16
+    nb = lambda n: int(n.split("conv_tap_kernel<step::bf16_t, ")[1].split(",")[1])
+    n4d0, _ = name(lib, BF, 8, 128, 256, (3, 3, 3), 8, 14, 14)
+    n2c0, _ = name(lib, BF, 8, 64, 192, (3, 3, 3), 16, 56, 56)
+    n3c0, _ = name(lib, BF, 8, 128, 192, (3, 3, 3), 16, 28, 28)
+    assert nb(n4d0) == 1 and nb(n2c0) == 3 and nb(n3c0) == 3
+    with _capi.options(lib, conv_nb_rule=1):
+        assert nb(name(lib, BF, 8, 128, 256, (3, 3, 3), 8, 14, 14)[0]) == 2
+        assert nb(name(lib, BF, 8, 160, 320, (3, 3, 3), 8, 14, 14)[0]) == 3
+        assert name(lib, BF, 8, 64, 192, (3, 3, 3), 16, 56, 56)[0] == n2c0
+        assert name(lib, BF, 8, 128, 192, (3, 3, 3), 16, 28, 28)[0] == n3c0
+    assert name(lib, BF, 8, 128, 256, (3, 3, 3), 8, 14, 14)[0] == n4d0
+
+
 def wgrad_name(L, dt, N, Cin, Cout, k, D, H, W, xcs=None):
     d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2], x_cstride=xcs or Cin, x_coff=0, y_cstride=Cout,
                        y_coff=0, res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)

@@ -48,12 +48,15 @@ def main():
     ap.add_argument("--graph", default="auto", choices=["auto", "one", "split"])
     ap.add_argument("--feed", default="none", choices=["none", "u8"])
     ap.add_argument("--log-every", type=int, default=10)
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
+                    help="process-group backend (default: nccl = RCCL; gloo only to exercise the multi-rank program with ranks SHARING one GPU, "
+                         "which RCCL refuses -- the exchange is then one eager flat all-reduce between two captured graphs)")
     a = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("train_step_amd.py needs a ROCm device (there is no CPU fallback)")
 
     from step_amd import dist as sdist, ops, workloads
-    rank, world = sdist.init()
+    rank, world = sdist.init(a.backend)
     local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
