@@ -412,12 +412,17 @@ def roofline(net, x, dtype_name):
                     # a one-group conv_tap layer is launched in two parts (full rounds at NB = 3, the partial last round at NB = 1,
                     # DESIGN.md 3.1): the timed call and its algorithmic bytes cover both, so does the traffic
                     tail = name.replace(", 3, 3, 3, 3, 2, 2, 8, 1>", ", 1, 3, 3, 3, 2, 2, 8, 1>") if ", 3, 3, 3, 3, 2, 2, 8, 1>" in name else None
-                    if "conv_tap_pre_kernel<" in name and name.endswith(", 3>(step::ConvParams)"):      # (the form with conv3d_2b fused in)
+                    if ("conv_tap_pre_kernel<" in name or "conv_tap_pre_pool_kernel<" in name) and name.endswith(", 3>(step::ConvParams)"):      # (the forms with conv3d_2b fused in / and maxPool3d_3a)
                         tail = name.replace(", 3>(step::ConvParams)", ", 1>(step::ConvParams)")
                     if tail and tail != name and tail in tj["kernels"] and tj["kernels"][tail].get("with") == name:
                         traffic += tj["kernels"][tail].get("hbm_bytes_per_launch", 0)
                         tsrc += "; + the NB = 1 launch of the layer's last partial round"
                         covers = [name, tail]
+                        fixk = "step::pool_seam_fix_kernel(step::PoolFixParams)"
+                        if "conv_tap_pre_pool_kernel<" in name and fixk in tj["kernels"]:
+                            traffic += tj["kernels"][fixk].get("hbm_bytes_per_launch", 0)
+                            tsrc += "; + the seam pass of the fused max pool"
+                            covers.append(fixk)
             except Exception:
                 pass
         if mfma_time >= hbm_time:      # matrix-bound kernel: algorithmic FLOP/s against the dense MFMA peak

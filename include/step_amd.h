@@ -286,6 +286,20 @@ STEP_API int step_conv_forward_pre(const step_conv_desc* d, const void* x, const
                                    const void* pre_w_packed, const float* pre_scale, const float* pre_shift, int pre_cin, void* y,
                                    step_stream_t stream);
 
+/* ... and with the (1,3,3) / (1,2,2) max pool BEHIND it taken on the conv's tiles while they are on the chip: the triple
+ * conv3d_2b_1x1 -> conv3d_2c_3x3 -> maxPool3d_3a_3x3 (models/i3dpt.py:207-212: Unit3Dpy, Unit3Dpy, MaxPool3dTFPadding) as one call.
+ * y_pooled [N, D, Hp, Wp, Cout] with Hp = step_pool_out_size(H, 3, 2) (d->y_cstride / y_coff describe IT); the un-pooled conv
+ * output never exists.  Two launches of the conv kernel at most (full rounds + the partial last round) plus one that completes the
+ * pooled pixels on tile seams from `ws` (caller-owned, step_conv_pre_pool_workspace_bytes(d) bytes, 16-byte aligned: the tiles'
+ * first rows and columns).  Bit-identical to step_conv_forward_pre followed by step_maxpool3d_tf.  Supported where
+ * step_conv_forward_pre is AND the planner tiles the map 4 planes x 8 x 8 (sides the 8-pixel tiles cover best: 56 x 56 at T=32,
+ * 224^2), d->relu = 1 (the pooled epilogue orders 16-bit patterns as integers: values >= +0), channel strides / offsets on the
+ * 16-byte grid; otherwise the workspace size is 0 and the call returns STEP_E_UNSUPPORTED (the caller keeps the two calls). */
+STEP_API size_t step_conv_pre_pool_workspace_bytes(const step_conv_desc* d);
+STEP_API int step_conv_forward_pre_pool(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
+                                        const void* pre_w_packed, const float* pre_scale, const float* pre_shift, int pre_cin, void* y_pooled,
+                                        void* ws, size_t ws_bytes, step_stream_t stream);
+
 typedef struct step_conv_item {
     const step_conv_desc* desc;
     const void* x; const void* w_packed; const float* scale; const float* shift; const void* res; void* y;

@@ -962,6 +962,7 @@ def wgrad_sync():
 
 POOL_WITH_POINTWISE = True     # inference: an Inception block's max pool and its fused 1x1x1 triple as one launch where the library has the form
 FUSE_STEM_POOL = True          # inference: maxPool3d_2a is taken on the stem's tiles while they are on the chip (ops.stem_pool_forward)
+FUSE_CONV_POOL = True          # inference: maxPool3d_3a is taken on conv3d_2c's tiles while they are on the chip (ops.conv_forward_pre_pool; needs FUSE_POINTWISE_INPUT)
 FUSE_POINTWISE_INPUT = True    # inference: a 64 -> 64 1x1x1 unit directly in front of a 3x3x3 unit runs inside that unit's launch (ops.conv_forward_pre)
 
 
@@ -980,10 +981,11 @@ def _stem_then_pool(a, b, x):
     return ops.stem_pool_forward(x, a.stem_packed(x.dtype), w.shape[0], scale, shift)
 
 
-def _pointwise_then_3x3x3(a, b, x):
+def _pointwise_then_3x3x3(a, b, x, pool=None):
     """Unit3D a (1x1x1, BN, ReLU) followed by Unit3D b (3x3x3): one launch when neither needs autograd and the library has the fused
     form for the shapes (16-bit, 64 -> 64 pointwise); None otherwise -- the caller runs the units one after the other (same result,
-    bit for bit)."""
+    bit for bit).  pool: the MaxPoolTF (1,3,3) / (1,2,2) behind b -- then the pool is taken on b's tiles too (ops.conv_forward_pre_pool)
+    and the POOLED tensor is returned, or None when that form does not exist for the shape."""
     if not (isinstance(a, Unit3D) and isinstance(b, Unit3D)) or a.is_stem or b.is_stem or not x.is_cuda or x.dtype == torch.float32:
         return None
     ua, ub = a._unit, b._unit
@@ -1003,7 +1005,12 @@ def _pointwise_then_3x3x3(a, b, x):
     ha = ha.detach().contiguous()
     if hb is not None:
         hb = hb.detach().contiguous()
-    return ops.conv_forward_pre(x, ub.packed(x.dtype), ub.cout, ub.k, sb, hb, b.relu, (ua.packed(x.dtype), sa.detach().contiguous(), ha, ua.cout))
+    pre = (ua.packed(x.dtype), sa.detach().contiguous(), ha, ua.cout)
+    if pool is not None:
+        if not isinstance(pool, MaxPoolTF) or pool.kernel_size != (1, 3, 3) or pool.stride != (1, 2, 2) or not b.relu or sb is None or hb is None:
+            return None
+        return ops.conv_forward_pre_pool(x, ub.packed(x.dtype), ub.cout, ub.k, sb, hb, b.relu, pre)
+    return ops.conv_forward_pre(x, ub.packed(x.dtype), ub.cout, ub.k, sb, hb, b.relu, pre)
 
 
 BRANCH_STREAMS = 0       # Inception blocks (inference path): 0 = one stream + the grouped 3x3x3 launch (default since round 3, see Mixed.forward); 1 / 2 = side branches on 1 / 2 side streams
@@ -1185,6 +1192,12 @@ class BaseNet(nn.Module):
                 if z is not None:
                     y = z
                     i += 2
+                    continue
+            if FUSE_POINTWISE_INPUT and FUSE_CONV_POOL and i + 2 < len(stages):
+                z = _pointwise_then_3x3x3(st, stages[i + 1], y, pool=stages[i + 2])    # ... and maxPool3d_3a on conv3d_2c's tiles
+                if z is not None:
+                    y = z
+                    i += 3
                     continue
             if FUSE_POINTWISE_INPUT and i + 1 < len(stages):
                 z = _pointwise_then_3x3x3(st, stages[i + 1], y)          # conv3d_2b evaluated inside conv3d_2c's halo staging

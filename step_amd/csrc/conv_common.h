@@ -42,6 +42,9 @@ struct ConvParams {
     // step_conv_forward_pre (conv_tap_pre_kernel): a pointwise conv + affine + ReLU applied to the halo while it is staged (64 -> 64
     // channels: conv3d_2b in front of conv3d_2c); pre_w = its packed weights, null otherwise
     const void* pre_w; const float* pre_scale; const float* pre_shift;
+    // step_conv_forward_pre_pool (conv_tap_pre_pool_kernel): a (1,3,3) / (1,2,2) max pool taken on the tile; y is then the pooled tensor
+    // [N, D, Hp, Wp, C]; pool_row / pool_col receive the tiles' first rows / columns for pool_seam_fix_kernel (null: no pooling)
+    void* pool_row; void* pool_col; int Hp, Wp;
 #ifdef STEP_PROBE
     unsigned long long* probe;   // tools/timeline_probe.py build only: 16 timestamp / id slots per workgroup (see probe_mark)
 #endif

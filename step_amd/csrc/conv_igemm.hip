@@ -825,6 +825,7 @@ static int conv_fill_params(const step_conv_desc* d, const void* x, const void* 
                 (!split || ((split % 8 == 0) && (d->y2_cstride % 8 == 0) && (d->y2_coff % 8 == 0) && (((uintptr_t)y2) % 16 == 0)));
     p.nblk32 = ceil_div(d->Cout, 32);
     p.pre_w = nullptr; p.pre_scale = nullptr; p.pre_shift = nullptr;
+    p.pool_row = nullptr; p.pool_col = nullptr; p.Hp = p.Wp = 0;
     p.mag_hhw = p.mag_hw = 0;
     p.Mtot = (long long)d->N * d->D * d->H * d->W;
 #ifdef STEP_PROBE
@@ -895,6 +896,119 @@ int step_conv_forward_pre(const step_conv_desc* d, const void* x, const void* w_
     if (!pl.ok || pl.impl != 1 || pl.ph != 1 || pl.wv != 8 || pl.tps != 2 || (pl.twl != 0 && pl.twl != 3)) return STEP_E_UNSUPPORTED;
     p.pre_w = pre_w_packed; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
     return canon.dtype == STEP_BF16 ? conv_forward_t<bf16_t>(&canon, p, nullptr, 0, stream) : conv_forward_t<f16_t>(&canon, p, nullptr, 0, stream);
+}
+
+// ---- conv3d_2b -> conv3d_2c -> maxPool3d_3a as one call (step_conv_forward_pre_pool) ---------------------------------------------------
+// Completes the pooled pixels on tile seams of conv_tap_pre_pool_kernel (see the POOL epilogue of conv_tap_body): one thread per (plane,
+// seam pixel, 8-channel vector).  PT = pooled pixels per tile side (4: 8 x 8 tiles).  Row seams: pooled row PT*t - 1 lacks conv row
+// 2*PT*t = the first row of tile row t (pool_row); the pixels that are ALSO on a column seam take the two pool_col rows they lack here
+// too, so that exactly one thread updates any pooled pixel.  Column seams: pooled column PT*s - 1 lacks conv column 2*PT*s (pool_col),
+// rows 2ph .. 2ph+2 -- all inside one tile row unless ph is a seam row (handled by the row pass).  Same structure as
+// stem_pool_fix_kernel (stem.hip, PT = 8).
+struct PoolFixParams { void* y; const void* rowbuf; const void* colbuf; long long planes; int H, W, Hp, Wp, tiles_h, tiles_w, C, y_cstride, y_coff, PT; };
+typedef short s16x8_fix __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ u32x4 pk_max_nonneg16_fix(const u32x4& a, const u32x4& b) {
+    return __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8_fix, a), __builtin_bit_cast(s16x8_fix, b)));
+}
+__global__ __launch_bounds__(256) void pool_seam_fix_kernel(PoolFixParams p) {
+    const int nbr = p.tiles_h - 1, nbc = p.tiles_w - 1, PT = p.PT;
+    const int V = p.C / 8;
+    const long long per_plane = ((long long)nbr * p.Wp + (long long)nbc * p.Hp) * V;
+    const long long total = per_plane * p.planes;
+    unsigned short* yg = (unsigned short*)p.y;
+    const unsigned short* rb = (const unsigned short*)p.rowbuf;
+    const unsigned short* cb = (const unsigned short*)p.colbuf;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)blockDim.x * gridDim.x) {
+        const long long plane = idx / per_plane;
+        long long it = idx % per_plane;
+        const int v = (int)(it % V);
+        it /= V;
+        int ph, pw;
+        bool row_item;
+        if (it < (long long)nbr * p.Wp) { row_item = true; ph = PT * ((int)(it / p.Wp) + 1) - 1; pw = (int)(it % p.Wp); }
+        else { it -= (long long)nbr * p.Wp; row_item = false; pw = PT * ((int)(it / p.Hp) + 1) - 1; ph = (int)(it % p.Hp); }
+        if (ph >= p.Hp || pw >= p.Wp) continue;
+        const bool ph_seam = ((ph + 1) % PT) == 0 && ((ph + 1) / PT) <= nbr;
+        const bool pw_seam = ((pw + 1) % PT) == 0 && ((pw + 1) / PT) <= nbc;
+        if (!row_item && ph_seam) continue;                       // a corner: the row pass owns it
+        unsigned short* yp = yg + ((plane * p.Hp + ph) * p.Wp + pw) * (size_t)p.y_cstride + p.y_coff + v * 8;
+        u32x4 m = *(const u32x4*)yp;
+        if (row_item) {
+            const int t = (ph + 1) / PT;
+            for (int dc = 0; dc < 3; ++dc) {
+                const int c = 2 * pw + dc;
+                if (c < p.W) m = pk_max_nonneg16_fix(m, *(const u32x4*)(rb + ((plane * p.tiles_h + t) * p.W + c) * (size_t)p.C + v * 8));
+            }
+            if (pw_seam) {
+                const int s_ = (pw + 1) / PT;
+                for (int dr = 0; dr < 2; ++dr)
+                    m = pk_max_nonneg16_fix(m, *(const u32x4*)(cb + ((plane * p.tiles_w + s_) * p.H + 2 * ph + dr) * (size_t)p.C + v * 8));
+            }
+        } else {
+            const int s_ = (pw + 1) / PT;
+            for (int dr = 0; dr < 3; ++dr) {
+                const int r = 2 * ph + dr;
+                if (r < p.H) m = pk_max_nonneg16_fix(m, *(const u32x4*)(cb + ((plane * p.tiles_w + s_) * p.H + r) * (size_t)p.C + v * 8));
+            }
+        }
+        *(u32x4*)yp = m;
+    }
+}
+
+
+// supported: what step_conv_forward_pre takes, planned onto the 4-plane 8x8 tile (maps whose sides the planner tiles by 8: 56 x 56 at C2),
+// ReLU on (the pooled epilogue orders 16-bit patterns as integers: values must be >= +0), 16-byte output vectors, no residual
+static bool conv_pre_pool_plan(const step_conv_desc* d, step_conv_desc& canon, ConvPlan& pl) {
+    if (!d || d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0) return false;
+    canon = canonical_desc(d);
+    if (canon.Cin != 64 || canon.dtype == STEP_F32 || canon.split || !(canon.kd == 3 && canon.kh == 3 && canon.kw == 3) || !canon.relu) return false;
+    if (canon.Cout % 8 || canon.y_cstride % 8 || canon.y_coff % 8) return false;
+    if ((unsigned long long)canon.N * canon.D * canon.H * canon.W * (unsigned long long)canon.x_cstride >= 0xffffffffULL) return false;
+    pl = conv_plan(&canon);
+    return pl.ok && pl.impl == 1 && pl.ph == 1 && pl.wv == 8 && pl.tps == 2 && pl.twl == 3;
+}
+
+size_t step_conv_pre_pool_workspace_bytes(const step_conv_desc* d) {
+    step_conv_desc canon;
+    ConvPlan pl;
+    if (!conv_pre_pool_plan(d, canon, pl)) return 0;
+    const size_t planes = (size_t)canon.N * canon.D;
+    return planes * ((size_t)pl.tiles_h * canon.W + (size_t)pl.tiles_w * canon.H) * canon.Cout * 2;
+}
+
+int step_conv_forward_pre_pool(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
+                               const void* pre_w_packed, const float* pre_scale, const float* pre_shift, int pre_cin, void* y_pooled,
+                               void* ws, size_t ws_bytes, step_stream_t stream) {
+    step_conv_desc canon;
+    ConvParams p;
+    const int rc = conv_fill_params(d, x, w_packed, scale, shift, nullptr, y_pooled, nullptr, canon, p);
+    if (rc != STEP_OK) return rc;
+    if (!pre_w_packed) return STEP_E_NULL;
+    if (p.N == 0) return STEP_OK;
+    ConvPlan pl;
+    if (pre_cin != 64 || !conv_pre_pool_plan(d, canon, pl) || !p.vec_epi) return STEP_E_UNSUPPORTED;
+    if (((uintptr_t)pre_w_packed % 16) || (pre_scale && ((uintptr_t)pre_scale % 16)) || (pre_shift && ((uintptr_t)pre_shift % 16))) return STEP_E_ALIGN;
+    const size_t need = step_conv_pre_pool_workspace_bytes(d);
+    if (!ws || ws_bytes < need || ((uintptr_t)ws % 16)) return STEP_E_SHAPE;
+    p.pre_w = pre_w_packed; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
+    const size_t planes = (size_t)canon.N * canon.D;
+    p.pool_row = ws;
+    p.pool_col = (unsigned char*)ws + planes * (size_t)pl.tiles_h * canon.W * canon.Cout * 2;
+    p.Hp = step_pool_out_size(canon.H, 3, 2); p.Wp = step_pool_out_size(canon.W, 3, 2);      // (1,3,3) / (1,2,2), TF padding (0,1), ceil mode
+    const int rc2 = canon.dtype == STEP_BF16 ? conv_forward_t<bf16_t>(&canon, p, nullptr, 0, stream) : conv_forward_t<f16_t>(&canon, p, nullptr, 0, stream);
+    if (rc2 != STEP_OK) return rc2;
+    if (pl.tiles_h > 1 || pl.tiles_w > 1) {
+        PoolFixParams f;
+        f.y = y_pooled; f.rowbuf = p.pool_row; f.colbuf = p.pool_col; f.planes = (long long)planes;
+        f.H = canon.H; f.W = canon.W; f.Hp = p.Hp; f.Wp = p.Wp; f.tiles_h = pl.tiles_h; f.tiles_w = pl.tiles_w; f.C = canon.Cout;
+        f.y_cstride = canon.y_cstride; f.y_coff = canon.y_coff; f.PT = 4;
+        const long long items = (long long)planes * ((long long)(pl.tiles_h - 1) * p.Wp + (long long)(pl.tiles_w - 1) * p.Hp) * (canon.Cout / 8);
+        if (items > 0) {
+            STEP_LAUNCH(pool_seam_fix_kernel, dim3(flat_grid(items, 256)), dim3(256), stream, f);
+            return STEP_LAUNCH_CHECK();
+        }
+    }
+    return STEP_OK;
 }
 
 // Can these convs share one grid?  All 16-bit 3x3x3 layers the planner sends to the two-phase conv_tap form on general boxes
@@ -1102,7 +1216,7 @@ int step_conv_plan_info(const step_conv_desc* d, int* info, int n) {
 __attribute__((visibility("default"))) void step_probe_set(void* buf) { step::g_probe_buf = (unsigned long long*)buf; }
 #endif
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 28; }
+int step_abi_version(void) { return 29; }
 
 }  // extern "C"
 

@@ -51,8 +51,11 @@ namespace step {
 // weights of the slab's 32 channels (4 K-steps), and stores affine + ReLU + 16-bit rounding of the result into the halo slab --
 // exactly the values the separate layer would have written to memory (same K order, same rounding), zeros outside the image.
 // The intermediate tensor never exists: -2 x 51 MB of traffic and one launch per C2 step for +3 % matrix work in this kernel.
-template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB, int WV, int PH = 0, bool GRP = false, bool PRE = false>
+typedef short s16x8_pool __attribute__((ext_vector_type(8)));
+
+template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB, int WV, int PH = 0, bool GRP = false, bool PRE = false, bool POOL = false>
 __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
+    static_assert(!POOL || (TWL == 3 && WV == 8 && PH == 1 && !GRP && sizeof(T) == 2 && KD == 3), "the pooled epilogue exists for the 4-plane 8x8 tile of the two-phase 16-bit form");
     static_assert(MB == 2 && (WV == 8 || WV == 4), "two accumulator rows per wave; 8 or 4 waves");
     static_assert(!PRE || (PH == 1 && sizeof(T) == 2), "the fused pointwise input exists for the two-phase 16-bit form");
     static_assert(PH == 0 || (WV == 8 && TPS == 2 && sizeof(T) == 2), "two-phase form: 8 waves, two taps per step, 16-bit storage");
@@ -118,6 +121,7 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
     constexpr int STASH_BYTES = PRE ? NPIX_MAX * 64 : 0;                      // PRE: the second slab's 32 channels wait here (dense 64-byte pixels)
     constexpr int LDS_BYTES = NPIX_MAX * PITCH + BBYTES + SS_BYTES + STASH_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(!POOL || TPXM * (NBT * 64 + 16) <= NPIX_MAX * PITCH + BBYTES, "the pooled epilogue's tile lives in the halo / weight rings, below the scale table");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     unsigned char* const ldsA = lds;
     unsigned char* const ldsB = lds + NPIX_MAX * PITCH;
@@ -706,6 +710,100 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
             const int od = d0 + tdl, oh = h0 + thl, ow = w0 + tile_col(thl, twl);
             opix[mb] = (inbox && od < p.D && oh < p.H && ow < p.W) ? (((long long)n * p.D + od) * p.H + oh) * p.W + ow : -1;
         }
+        if constexpr (POOL) {
+            // POOL (step_conv_forward_pre_pool: maxPool3d_3a -- (1,3,3) / (1,2,2), TF padding (0,1) -- taken on conv3d_2c's tile while it is
+            // on the chip): y is the POOLED tensor [N, D, Hp, Wp, C]; the un-pooled output never exists.  Same scheme as the stem's pooled
+            // epilogue (stem.hip): the 4 planes x 8 x 8 tile goes to LDS pixel-major (the rings are free: the K loop ended in a barrier); a
+            // pooled pixel (ph, pw) is the max over rows 2ph .. 2ph+2 and columns 2pw .. 2pw+2, so a tile plane holds everything for 3 of its
+            // 4 pooled rows / columns and two of the three rows / columns of the fourth.  The tile writes the max over what it HAS to y and
+            // its own first row and first column (raw values) to pool_row / pool_col; pool_seam_fix_kernel completes the pooled pixels on tile
+            // seams from those.  Values are post-ReLU (>= +0): the zero padding of the reference's ConstantPad3d is neutral, out-of-image
+            // pixels of partial tiles enter as 0, and 16-bit patterns order like signed integers (one v_pk_max_i16 per pair).
+            constexpr int TP = NBT * 64 + 16;                            // bytes per tile pixel (+16: 16 lanes x 16 B at one channel offset spread over all banks)
+            int tpix[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                int tdl, thl, twl;
+                tile_pix(wm * (MB * 32) + mb * 32 + (lane & 31), tdl, thl, twl);
+                tpix[mb] = (tdl * 8 + thl) * 8 + tile_col(thl, twl);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int cl = (wn * NB + i) * 32;
+                f32x4 sc[4], sh[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    sc[g] = *(const f32x4*)(ldsS + cl + 8 * g + 4 * khalf);
+                    sh[g] = *(const f32x4*)(ldsS + NBT * 32 + cl + 8 * g + 4 * khalf);
+                }
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const bool okp = opix[mb] >= 0;
+                    unsigned d[4][2];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[mb][i][4 * g + e] * sc[g][e] + sh[g][e], 0.f);      // (the host admits relu = 1 only)
+                        d[g][0] = (unsigned)elem<T>::bits16(v[0]) | ((unsigned)elem<T>::bits16(v[1]) << 16);
+                        d[g][1] = (unsigned)elem<T>::bits16(v[2]) | ((unsigned)elem<T>::bits16(v[3]) << 16);
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        lane32_swap(d[2 * h][0], d[2 * h + 1][0]);
+                        lane32_swap(d[2 * h][1], d[2 * h + 1][1]);
+                        u32x4 o = {d[2 * h][0], d[2 * h][1], d[2 * h + 1][0], d[2 * h + 1][1]};
+                        if (!okp) o = u32x4{0u, 0u, 0u, 0u};
+                        *(u32x4*)(lds + tpix[mb] * TP + (cl + 16 * h + 8 * khalf) * 2) = o;
+                    }
+                }
+            }
+            __syncthreads();
+            constexpr int CV = NBT * 4;                                  // 8-channel vectors of the workgroup's channels
+            unsigned short* yp_ = (unsigned short*)p.y;
+            // 4 planes x 4 x 4 pooled pixels x CV vectors = NB items per thread; vector fastest (a pixel's channels are contiguous)
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int item = tid + NT * k;
+                const int v = item % CV, pq = item / CV;
+                const int j = pq & 3, i2 = (pq >> 2) & 3, pl_ = pq >> 4;
+                const unsigned char* base = lds + ((pl_ * 8 + 2 * i2) * 8 + 2 * j) * TP + v * 16;
+                u32x4 m = *(const u32x4*)base;
+#pragma unroll
+                for (int dr = 0; dr < 3; ++dr)
+#pragma unroll
+                    for (int dc = 0; dc < 3; ++dc) {
+                        if (dr == 0 && dc == 0) continue;
+                        if (2 * i2 + dr < 8 && 2 * j + dc < 8) {
+                            const u32x4 o = *(const u32x4*)(base + (dr * 8 + dc) * TP);
+                            m = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8_pool, m), __builtin_bit_cast(s16x8_pool, o)));
+                        }
+                    }
+                const int od = d0 + pl_, ph = (h0 >> 1) + i2, pw = (w0 >> 1) + j, co = nb0 * 32 + v * 8;
+                if (od < p.D && ph < p.Hp && pw < p.Wp && co < p.Cout)
+                    *(u32x4*)(yp_ + ((((size_t)n * p.D + od) * p.Hp + ph) * p.Wp + pw) * p.y_cstride + p.y_coff + co) = m;
+            }
+            // the tile's first row -> pool_row, first column -> pool_col (raw values; tiles of the first tile row / column have no reader)
+            unsigned short* rb = (unsigned short*)p.pool_row;
+            unsigned short* cb = (unsigned short*)p.pool_col;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int item = tid + NT * k;                           // 2 x 4 planes x 8 pixels x CV vectors = NB x 512
+                const int v = item % CV, q = item / CV;
+                const int e = q & 7, pl_ = (q >> 3) & 3, col_item = q >> 5;
+                const int od = d0 + pl_, co = nb0 * 32 + v * 8;
+                if (od >= p.D || co >= p.Cout) continue;
+                const size_t plane = (size_t)n * p.D + od;
+                if (!col_item) {
+                    if (th_i > 0 && w0 + e < p.W)
+                        *(u32x4*)(rb + ((plane * p.tiles_h + th_i) * p.W + w0 + e) * (size_t)p.Cout + co) = *(const u32x4*)(lds + ((pl_ * 8) * 8 + e) * TP + v * 16);
+                } else {
+                    if (tw_i > 0 && h0 + e < p.H)
+                        *(u32x4*)(cb + ((plane * p.tiles_w + tw_i) * p.H + h0 + e) * (size_t)p.Cout + co) = *(const u32x4*)(lds + ((pl_ * 8 + e) * 8) * TP + v * 16);
+                }
+            }
+            return;
+        }
         if (p.vec_epi) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
@@ -833,6 +931,14 @@ void conv_tap_pre_kernel(ConvParams p) {
 }
 
 
+// ... and with maxPool3d_3a taken on the tile (POOL, see the epilogue of conv_tap_body): the 4-plane 8x8 tile only
+template <typename T, int NB>
+__global__ __launch_bounds__(512, 2)
+void conv_tap_pre_pool_kernel(ConvParams p) {
+    conv_tap_body<T, 3, NB, 3, 3, 3, 2, 2, 8, 1, false, true, true>(p);
+}
+
+
 // The grouped launch plus ONE pointwise conv (conv_pw_body<T, 1, 4>: 128 pixels x 64 channels per 256-thread workgroup; waves 4-7 of
 // such a workgroup leave at once).  On the 14x14 maps the two 3x3x3 convs of an Inception block are 168-224 one-per-CU workgroups
 // of 23-52 us: the block's branch_3 1x1x1 conv (9-11 us as a launch of its own) runs beside them on the idle CUs.
@@ -905,8 +1011,22 @@ static int launch_tap_pre(const ConvParams& p, int NB, dim3 grid, step_stream_t 
 }
 
 template <typename T>
+static int launch_tap_pre_pool(const ConvParams& p, int NB, dim3 grid, step_stream_t stream) {
+    switch (NB) {
+        case 1: STEP_LAUNCH((conv_tap_pre_pool_kernel<T, 1>), grid, dim3(512), stream, p); break;
+        case 2: STEP_LAUNCH((conv_tap_pre_pool_kernel<T, 2>), grid, dim3(512), stream, p); break;
+        default: STEP_LAUNCH((conv_tap_pre_pool_kernel<T, 3>), grid, dim3(512), stream, p); break;
+    }
+    return STEP_LAUNCH_CHECK();
+}
+
+template <typename T>
 int conv_tap_ph_launch_impl(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream) {
     if (kd != 3 || pl.ph != 1) return STEP_E_UNSUPPORTED;
+    if (p.pre_w && p.pool_row) {                           // ... with the (1,3,3) / (1,2,2) max pool on the tile: the 4 x 8 x 8 tile form only
+        if (pl.twl != 3) return STEP_E_UNSUPPORTED;
+        return launch_tap_pre_pool<T>(p, pl.NB, grid, stream);
+    }
     if (p.pre_w) {                                         // fused pointwise input: the general-box and the 4 x 8 x 8 tile forms
         if (pl.twl == 0) return launch_tap_pre<T, 0>(p, pl.NB, grid, stream);
         if (pl.twl == 3) return launch_tap_pre<T, 3>(p, pl.NB, grid, stream);

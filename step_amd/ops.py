@@ -259,6 +259,49 @@ def conv_forward_pre(x, w_packed, Cout, k, scale, shift, relu, pre, out=None):
     return out
 
 
+def conv_forward_pre_pool(x, w_packed, Cout, k, scale, shift, relu, pre):
+    """conv_forward_pre with the (1,3,3) / (1,2,2) max pool behind it taken on the conv's tiles (step_conv_forward_pre_pool: conv3d_2b ->
+    conv3d_2c -> maxPool3d_3a as one call; neither the tensor between the convs nor the un-pooled conv output exists).  Returns the
+    POOLED channels-last tensor [N,D,Hp,Wp,Cout], or None when the library has no fused form for the layer (the caller keeps
+    conv_forward_pre + the pool; bit-identical)."""
+    L = _lib.lib()
+    pw, pscale, pshift, cmid = pre
+    N, D, H, W, Cpre = x.shape
+    if Cpre != 64 or cmid != 64 or x.dtype == torch.float32 or tuple(k) != (3, 3, 3) or not relu:
+        return None
+    Hp, Wp = L.step_pool_out_size(H, 3, 2), L.step_pool_out_size(W, 3, 2)
+    d = _capi.ConvDesc(dtype=_dt(x), N=N, D=D, H=H, W=W, Cin=cmid, Cout=Cout, kd=3, kh=3, kw=3,
+                       x_cstride=_chan_slice(x), x_coff=0, y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0,
+                       relu=1, split=0, y2_cstride=0, y2_coff=0)
+    wsb = L.step_conv_pre_pool_workspace_bytes(ctypes.byref(d))
+    if not wsb:
+        return None
+    out = torch.empty((N, D, Hp, Wp, Cout), dtype=x.dtype, device=x.device)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    info = (ctypes.c_int * 10)()
+    L.step_conv_plan_info(ctypes.byref(d), info, 10)
+    refused = []
+
+    def launch():
+        rc = L.step_conv_forward_pre_pool(ctypes.byref(d), _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift), _lib.dptr(pw),
+                                          _lib.dptr(pscale), _lib.dptr(pshift), int(Cpre), _lib.dptr(out), _lib.dptr(ws), wsb, _lib.stream_ptr(x.device))
+        if rc in (-4, -5):          # the library's stricter contract (alignment, 32-bit offsets): the caller falls back
+            refused.append(rc)
+            return
+        _capi.check(rc, "step_conv_forward_pre_pool")
+
+    def describe():
+        pix = N * D * H * W
+        return ("void step::conv_tap_pre_pool_kernel<%s, %d>(step::ConvParams)" % (_TNAME[x.dtype], info[2]),
+                2.0 * pix * (Cout * cmid * 27 + cmid * Cpre), (pix * Cpre + N * D * Hp * Wp * Cout + Cout * cmid * 27 + cmid * Cpre) * _ES[x.dtype])
+    _run(launch, describe)
+    if refused:
+        if PROFILE is not None and PROFILE and PROFILE[-1][0].startswith("void step::conv_tap_pre_pool_kernel"):
+            PROFILE.pop()
+        return None
+    return out
+
+
 def conv_forward_group(members):
     """Several INDEPENDENT convs as one launch where the library can merge them (step_conv_forward_group: today two 16-bit 3x3x3
     layers of the two-phase conv_tap form -- an Inception block's branch_1 / branch_2 convs -- plus, on small maps, one pointwise

@@ -1793,6 +1793,67 @@ def case_conv_forward_pre_matches_two_launches(bk, golden):
     assert bk.lib.step_conv_forward_pre(ctypes.byref(df), xe.ptr, wpb.ptr, dsb.ptr, dhb.ptr, wpa.ptr, dsa.ptr, dha.ptr, 64, y1.ptr, bk.stream) == -4
 
 
+def case_conv_forward_pre_pool_matches_separate_calls(bk, golden):
+    """step_conv_forward_pre_pool (conv3d_2b -> conv3d_2c -> maxPool3d_3a as one call: the (1,3,3) / (1,2,2) max pool taken on the conv's
+    4-plane 8x8 tiles, seams completed by pool_seam_fix_kernel) against step_conv_forward_pre + step_maxpool3d_tf: BIT-IDENTICAL pooled
+    tensors -- several tiles in both directions (row seams, column seams, corners), the NB = 1 launch of the partial last round, partial
+    tiles and partial plane groups, odd map sides (the ceil-mode window that hangs over the zero pad), the pooled tensor as a channel
+    slice of a wider buffer; layers the planner does not tile 4 x 8 x 8, no ReLU and fp32 are refused (workspace size 0, -4)."""
+    rs = np.random.RandomState(61)
+    info = (ctypes.c_int * 10)()
+    ran = 0
+    for dt, (N, D, H, W), Cout, opts, ycs, yco in ((BF16, (1, 4, 24, 24), 192, dict(conv_slots=4, conv_nb=3, conv_waves=8), 192, 0),
+                                                   (F16, (1, 7, 21, 24), 72, dict(conv_gen=0, conv_waves=8), 88, 8),
+                                                   (BF16, (1, 8, 16, 8), 64, dict(conv_gen=0, conv_waves=8), 64, 0)):
+        x = rs.randn(N, 64, D, H, W).astype(np.float32)
+        wa = (rs.randn(64, 64, 1, 1, 1) / 8).astype(np.float32)
+        wb = (rs.randn(Cout, 64, 3, 3, 3) / np.sqrt(64 * 27)).astype(np.float32)
+        sa, ha = (1 + 0.1 * rs.randn(64)).astype(np.float32), (0.2 * rs.randn(64)).astype(np.float32)
+        sb, hb = (1 + 0.1 * rs.randn(Cout)).astype(np.float32), (0.2 * rs.randn(Cout)).astype(np.float32)
+        xe = bk.dev(encode(cl(x), dt))
+        wpa, wpb = pack_weight(bk, wa, dt), pack_weight(bk, wb, dt)
+        dsa, dha, dsb, dhb = bk.dev(sa), bk.dev(ha), bk.dev(sb), bk.dev(hb)
+        Hp, Wp = bk.lib.step_pool_out_size(H, 3, 2), bk.lib.step_pool_out_size(W, 3, 2)
+        db = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=64, Cout=Cout, kd=3, kh=3, kw=3, x_cstride=64, x_coff=0, y_cstride=Cout, y_coff=0,
+                            res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+        dp = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=64, Cout=Cout, kd=3, kh=3, kw=3, x_cstride=64, x_coff=0, y_cstride=ycs, y_coff=yco,
+                            res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+        with _capi.options(bk.lib, **opts):
+            assert bk.lib.step_conv_plan_info(ctypes.byref(db), info, 10) == 0
+            assert info[0] == 1 and info[1] == 3 and info[4] == 1, list(info)         # conv_tap, the 4 x 8 x 8 tile, two-phase
+            full = bk.dev(np.zeros((N, D, H, W, Cout), NP_DT[dt]))
+            assert bk.lib.step_conv_forward_pre(ctypes.byref(db), xe.ptr, wpb.ptr, dsb.ptr, dhb.ptr, wpa.ptr, dsa.ptr, dha.ptr, 64, full.ptr, bk.stream) == 0
+            want = bk.dev(np.full((N, D, Hp, Wp, ycs), 3, NP_DT[dt]))
+            assert bk.lib.step_maxpool3d_tf(dt, full.ptr, N, D, H, W, Cout, Cout, 0, 1, 3, 3, 1, 2, 2, want.ptr, ycs, yco, bk.stream) == 0
+            nb = bk.lib.step_conv_pre_pool_workspace_bytes(ctypes.byref(dp))
+            assert nb > 0 and nb % 16 == 0
+            ws = bk.dev(np.full(nb // 2, 0x7f7f, np.uint16))                      # garbage: every byte the fix kernel reads must have been written
+            got = bk.dev(np.full((N, D, Hp, Wp, ycs), 3, NP_DT[dt]))
+            assert bk.lib.step_conv_forward_pre_pool(ctypes.byref(dp), xe.ptr, wpb.ptr, dsb.ptr, dhb.ptr, wpa.ptr, dsa.ptr, dha.ptr, 64, got.ptr,
+                                                     ws.ptr, nb, bk.stream) == 0
+            assert bk.lib.step_conv_forward_pre_pool(ctypes.byref(dp), xe.ptr, wpb.ptr, dsb.ptr, dhb.ptr, wpa.ptr, dsa.ptr, dha.ptr, 64, got.ptr,
+                                                     ws.ptr, nb - 16, bk.stream) == -2
+        g_, w_ = got.get(), want.get()
+        assert np.array_equal(g_, w_), (dt, N, D, H, W, Cout, int((g_ != w_).sum()), np.argwhere(g_ != w_)[:4].tolist())
+        assert (decode(g_[..., yco:yco + Cout], dt) >= 0).all()
+        ran += 1
+    assert ran == 3
+    # outside the contract: a general-box layer (the 14 x 14 map), no ReLU, fp32
+    d14 = _capi.ConvDesc(dtype=BF16, N=3, D=8, H=14, W=14, Cin=64, Cout=64, kd=3, kh=3, kw=3, x_cstride=64, x_coff=0, y_cstride=64, y_coff=0,
+                         res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+    assert bk.lib.step_conv_plan_info(ctypes.byref(d14), info, 10) == 0
+    if info[1] != 3:
+        assert bk.lib.step_conv_pre_pool_workspace_bytes(ctypes.byref(d14)) == 0
+    dn = _capi.ConvDesc(dtype=BF16, N=1, D=4, H=24, W=24, Cin=64, Cout=192, kd=3, kh=3, kw=3, x_cstride=64, x_coff=0, y_cstride=192, y_coff=0,
+                        res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)
+    df = _capi.ConvDesc(dtype=F32, N=1, D=4, H=24, W=24, Cin=64, Cout=192, kd=3, kh=3, kw=3, x_cstride=64, x_coff=0, y_cstride=192, y_coff=0,
+                        res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+    for dbad in (dn, df):
+        assert bk.lib.step_conv_pre_pool_workspace_bytes(ctypes.byref(dbad)) == 0
+        assert bk.lib.step_conv_forward_pre_pool(ctypes.byref(dbad), xe.ptr, wpb.ptr, dsb.ptr, dhb.ptr, wpa.ptr, dsa.ptr, dha.ptr, 64, got.ptr,
+                                                 ws.ptr, nb, bk.stream) == -4
+
+
 def case_pool_conv_forward_matches_two_launches(bk, golden):
     """step_pool_conv_forward (an Inception block's 3x3x3 / 1 max pool + its fused pointwise triple in ONE grid) against
     step_maxpool3d_tf + step_conv_forward: bit-identical pooled tensor and conv outputs (two destinations through `split`, ragged

@@ -229,6 +229,37 @@ def case_basenet_c1_16bit_error(dev, golden):
         assert e < bound, (dt, e)
 
 
+def case_conv_pool_fusion_in_basenet(dev, golden):
+    """backbone.FUSE_CONV_POOL: maxPool3d_3a taken on conv3d_2c's tiles (ops.conv_forward_pre_pool, models/i3dpt.py:207-212) inside
+    BaseNet.forward -- a clip whose 24 x 24 stage-2 maps the planner tiles 4 x 8 x 8 (as the 56 x 56 maps of C2): the fused call is
+    really taken (ops.PROFILE sees its kernel and no stand-alone (1,3,3) pool behind conv3d_2c) and the network output is BIT-IDENTICAL
+    to the run with the fusion off."""
+    from step_amd import backbone as _bb
+    from step_amd import ops as _ops
+    net = fill(step_amd.BaseNet(cfg())).to(dev).eval()
+    # (stage-2 maps 40 x 40 x 16 planes: 100 tiles of 4 x 8 x 8 -- enough for the 8-wave two-phase form the fusion lives in; on the
+    # interpreter a smaller clip with the 8-wave form forced)
+    shape = (1, 32, 3, 160, 160) if dev != "cpu" else (1, 16, 3, 96, 96)
+    x = R.fill_tensor("golden.fuse.images", shape, "image").to(dev).to(torch.bfloat16)
+    assert _bb.FUSE_CONV_POOL and _bb.FUSE_POINTWISE_INPUT
+    with torch.no_grad():
+        _ops.PROFILE, _ops.PROFILE_LIMIT = [], 1 << 30              # (record the launches, time nothing)
+        try:
+            y1 = net(x).clone()
+            names = [r[0] for r in _ops.PROFILE]
+        finally:
+            _ops.PROFILE, _ops.PROFILE_LIMIT = None, None
+        assert any("conv_tap_pre_pool_kernel" in n for n in names), names
+        assert sum("maxpool_sep_kernel" in n and " 1, 3, 3, 1, 2, 2" in n for n in names) == 0, names     # 2a rides in the stem, 3a in conv3d_2c
+        try:
+            _bb.FUSE_CONV_POOL = False
+            y0 = net(x)
+        finally:
+            _bb.FUSE_CONV_POOL = True
+    assert tuple(y1.shape) == ((1, 8, 832, 10, 10) if dev != "cpu" else (1, 4, 832, 6, 6))
+    assert torch.equal(y1, y0), float((y1.float() - y0.float()).abs().max())
+
+
 def case_i3d_classifier_golden(dev, golden):
     """step_amd.I3D (the full Kinetics classifier, models/i3dpt.py:175-262): state_dict keys / shapes of the reference's
     module, and forward on the golden clip against what the reference returned (fp32: 1e-3; bf16: the argmax and a loose bound)."""
@@ -1313,8 +1344,12 @@ def case_c2_full_size_properties(dev, golden):
         # ... and maxPool3d_2a taken on the stem's tiles (backbone.FUSE_STEM_POOL, ops.stem_pool_forward: 7 x 7 tiles per frame, seams
         # completed by the second launch) == the stem and the pool as two launches
         from step_amd import backbone as _bb
-        assert _bb.FUSE_POINTWISE_INPUT and _bb.POOL_WITH_POINTWISE and _bb.FUSE_STEM_POOL
+        # ... and maxPool3d_3a taken on conv3d_2c's tiles (backbone.FUSE_CONV_POOL, ops.conv_forward_pre_pool: 49 tiles of 8 x 8 per plane,
+        # seams completed by pool_seam_fix_kernel) == conv3d_2c and the pool as two calls
+        assert _bb.FUSE_POINTWISE_INPUT and _bb.POOL_WITH_POINTWISE and _bb.FUSE_STEM_POOL and _bb.FUSE_CONV_POOL
         try:
+            _bb.FUSE_CONV_POOL = False
+            y8p = net(xb)
             _bb.FUSE_POINTWISE_INPUT = False
             _bb.POOL_WITH_POINTWISE = False
             _bb.FUSE_STEM_POOL = False
@@ -1323,6 +1358,8 @@ def case_c2_full_size_properties(dev, golden):
             _bb.FUSE_POINTWISE_INPUT = True
             _bb.POOL_WITH_POINTWISE = True
             _bb.FUSE_STEM_POOL = True
+            _bb.FUSE_CONV_POOL = True
+        assert torch.equal(y8p, y8), float((y8p.float() - y8.float()).abs().max())
         assert torch.equal(y8u, y8), float((y8u.float() - y8.float()).abs().max())
 
 
@@ -1402,4 +1439,4 @@ CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_g
              "case_contextnet_backward_matches_oracle_autograd", "case_basenet_batch_statistics_bn_golden", "case_postprocess_golden",
              "case_batched_repack_follows_weight_updates", "case_stem_backward_16bit",
              "case_loss_masks_without_host_branches", "case_data_parallel_replicas", "case_train_select_device_front_end", "case_nms_operator_api"]
-GPU_CASES = CPU_CASES + ["case_fp16_training_step_loss_scaling", "case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_c5_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_i3d_classifier_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
+GPU_CASES = CPU_CASES + ["case_conv_pool_fusion_in_basenet", "case_fp16_training_step_loss_scaling", "case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_c5_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_i3d_classifier_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
