@@ -418,11 +418,6 @@ def roofline(net, x, dtype_name):
                         traffic += tj["kernels"][tail].get("hbm_bytes_per_launch", 0)
                         tsrc += "; + the NB = 1 launch of the layer's last partial round"
                         covers = [name, tail]
-                        fixk = "step::pool_seam_fix_kernel(step::PoolFixParams)"
-                        if "conv_tap_pre_pool_kernel<" in name and fixk in tj["kernels"]:
-                            traffic += tj["kernels"][fixk].get("hbm_bytes_per_launch", 0)
-                            tsrc += "; + the seam pass of the fused max pool"
-                            covers.append(fixk)
             except Exception:
                 pass
         if mfma_time >= hbm_time:      # matrix-bound kernel: algorithmic FLOP/s against the dense MFMA peak
@@ -461,42 +456,77 @@ def roofline(net, x, dtype_name):
 def fed_loop(a, net, flights, x, dev, tdt, dist, resident_s_per_step):
     """--feed u8: the loop a fed node runs (reference: data/ava.py:298-368 hands [T,3,H,W] fp32 frames to the DataLoader every iteration,
     data/augmentations.py:68-84 converts from uint8 on the HOST; SURVEY 8e names input feeding as the scaling limiter).  Here the wire
-    format is uint8 [N,T,H,W,3] (4x fewer PCIe bytes than fp32): per batch in flight a PINNED host buffer, a device staging buffer, one
-    hipMemcpyAsync on a COPY stream, step_clip_from_u8 (scale 2: x*2/255-1, the reference's ConvertFromInts) into the captured step's
-    static input on the batch's compute stream, then the captured step.  The copy of batch k + nfl waits only for batch k's conversion
-    (not for its backbone), so transfers run under the other batches' compute.  The host buffers hold synthetic frames that are not
+    format is uint8 [N,T,H,W,3] (4x fewer PCIe bytes than fp32): per batch in flight a PINNED host buffer, a device staging buffer and one
+    hipMemcpyAsync on a high-priority COPY stream; then either
+      "u8_stem"    the backbone reads the staged uint8 frames itself (BaseNet.stem_u8 / after_stem, step_stem_pool_forward_u8: the
+                   normalisation happens in the stem's frame staging) -- two captured graphs per batch, stem | rest, so that the copy of
+                   batch k + nfl may start as soon as batch k's STEM has run; or
+      "convert"    step_clip_from_u8 (scale 2: x*2/255-1, the reference's ConvertFromInts) writes the captured step's static 16-bit input,
+                   then the resident loop's captured step; copy k + nfl waits for conversion k.
+    Both are timed; `value` of the block is the faster one (the product form).  The host buffers hold synthetic frames that are not
     rewritten between steps (there is no decoder on this path); everything behind them is what a fed loop does."""
     from step_amd import ops
     nfl = len(flights)
     N, T, _, H, W = x.shape
     g = torch.Generator().manual_seed(777)
-    hosts, stages, xs, streams, graphs = [], [], [], [], []
-    for i, fl in enumerate(flights):
-        hosts.append(torch.randint(0, 256, (N, T, H, W, 3), dtype=torch.uint8, generator=g).pin_memory())
-        stages.append(torch.empty((N, T, H, W, 3), dtype=torch.uint8, device=dev))
-        xs.append(x if i == 0 else fl[2])                      # the captured graphs' static inputs
-        # every batch in flight on a stream of its own (the resident loop replays batch 0 on the default stream: measured, the fed loop
-        # on the default stream + a second one does not overlap its copies -- 4.6 k clips/s -- whatever the copy stream's priority)
-        streams.append(torch.cuda.Stream()); graphs.append(fl[1])
-    # a HIGH-PRIORITY stream: HIP maps streams onto a handful of hardware queues, and a normal-priority copy stream can land in the
-    # queue of a compute stream -- its copies then wait behind that stream's whole captured step (measured, tools/feed_probe.py: the
-    # fed loop at 4.5 k clips/s with a normal copy stream, 6.45 k with a high-priority one, 7.05 k resident; copy alone 56 GB/s)
+    hosts = [torch.randint(0, 256, (N, T, H, W, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(nfl)]
+    stages = [torch.empty((N, T, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(nfl)]
+    xs = [x if i == 0 else flights[i][2] for i in range(nfl)]      # the resident graphs' static inputs
+    graphs = [fl[1] for fl in flights]
+    # every batch in flight on a stream of its own, the copies on a HIGH-PRIORITY stream: HIP maps streams onto a handful of hardware
+    # queues, and a copy stream that shares a queue with a compute stream waits behind that stream's whole captured step (measured,
+    # tools/feed_probe.py: 4.5 k clips/s fed with an aliased copy stream, 6.8 k with streams of their own, 7.2 k resident)
+    streams = [torch.cuda.Stream() for _ in range(nfl)]
     copy_stream = torch.cuda.Stream(priority=-1)
     ev_copied = [torch.cuda.Event() for _ in range(nfl)]
-    ev_conv = [torch.cuda.Event() for _ in range(nfl)]
+    ev_free = [torch.cuda.Event() for _ in range(nfl)]             # the staging buffer may be overwritten
     nbytes = hosts[0].numel()
+    # the uint8-stem form: two graphs per batch in flight
+    u8g = []
+    from step_amd import backbone as _bb
+    keep_u8, _bb.FUSE_STEM_U8 = _bb.FUSE_STEM_U8, True            # (opt-in form of the library; measured here beside the default)
+    with torch.no_grad():
+        for i in range(nfl):
+            with torch.cuda.stream(streams[i]):
+                z = net.stem_u8(stages[i], tdt)
+                if z is None:
+                    u8g = None
+                    break
+                net.after_stem(z)
+                torch.cuda.synchronize()
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, stream=streams[i]):
+                    z = net.stem_u8(stages[i], tdt)
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb, stream=streams[i]):
+                    y = net.after_stem(z)
+                u8g.append((ga, gb, z, y))
+    _bb.FUSE_STEM_U8 = keep_u8
+    torch.cuda.synchronize()
 
-    def step(k):
-        i = k % nfl
+    def copy_in(i):
         with torch.cuda.stream(copy_stream):
-            copy_stream.wait_event(ev_conv[i])                 # the staging buffer is free once batch k - nfl has been converted
+            copy_stream.wait_event(ev_free[i])
             stages[i].copy_(hosts[i], non_blocking=True)
             ev_copied[i].record(copy_stream)
+
+    def step_convert(k):
+        i = k % nfl
+        copy_in(i)
         with torch.cuda.stream(streams[i]):
             streams[i].wait_event(ev_copied[i])
             ops.clip_from_u8(stages[i], scale=2, out=xs[i])
-            ev_conv[i].record(streams[i])
+            ev_free[i].record(streams[i])
             graphs[i].replay()
+
+    def step_u8(k):
+        i = k % nfl
+        copy_in(i)
+        with torch.cuda.stream(streams[i]):
+            streams[i].wait_event(ev_copied[i])
+            u8g[i][0].replay()
+            ev_free[i].record(streams[i])
+            u8g[i][1].replay()
 
     def copies_only(k):
         i = k % nfl
@@ -504,6 +534,9 @@ def fed_loop(a, net, flights, x, dev, tdt, dist, resident_s_per_step):
             stages[i].copy_(hosts[i], non_blocking=True)
 
     def run(fn, steps, warm):
+        for i in range(nfl):                                    # events start signalled
+            ev_free[i].record(streams[i])
+        torch.cuda.synchronize()
         for k in range(warm):
             fn(k)
         torch.cuda.synchronize()
@@ -519,36 +552,41 @@ def fed_loop(a, net, flights, x, dev, tdt, dist, resident_s_per_step):
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
-    for i in range(nfl):                                        # events start signalled
-        ev_conv[i].record(streams[i])
-    torch.cuda.synchronize()
-    steps = max(a.steps, int(1.0 / max(resident_s_per_step, 1e-5)) + 1)       # ~1 s of the fed loop
-    el_f = run(step, steps, max(a.warmup, 2 * nfl))
+    steps = max(a.steps, int(1.0 / max(resident_s_per_step, 1e-5)) + 1)       # ~1 s per fed loop
+    el_conv = run(step_convert, steps, max(a.warmup, 2 * nfl))
+    el_u8 = run(step_u8, steps, max(a.warmup, 2 * nfl)) if u8g else None
     el_c = run(copies_only, steps, 4)
     if dist is not None:
-        t = torch.tensor([el_f, el_c], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        t = torch.tensor([el_conv, el_u8 if el_u8 is not None else 0.0, el_c], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el_f, el_c = float(t[0].item()), float(t[1].item())
+        el_conv, el_c = float(t[0].item()), float(t[2].item())
+        el_u8 = float(t[1].item()) if el_u8 is not None else None
     world = dist.get_world_size() if dist is not None else 1
-    fed_rate = world * N * steps / el_f
+    rate = lambda el: world * N * steps / el
+    form = "u8_stem" if (el_u8 is not None and el_u8 <= el_conv) else "convert"
+    el_f = el_u8 if form == "u8_stem" else el_conv
+    fed_rate = rate(el_f)
     res_rate = world * N / resident_s_per_step
     h2d = nbytes * steps / el_c / 1e9
     need = nbytes / N * (res_rate / world) / 1e9              # GB/s of uint8 frames one rank consumes at the resident rate
     if fed_rate >= 0.97 * res_rate:
-        limit = "compute: the fed loop runs at the resident-input rate (transfers and the conversion hide under the other batch's compute)"
+        limit = "compute: the fed loop runs at the resident-input rate (transfers hide under the other batch's compute)"
     elif h2d < 1.1 * need:
         limit = "the host->device link: the copy-only loop moves %.1f GB/s per rank, the resident rate would consume %.1f GB/s" % (h2d, need)
     else:
-        limit = ("compute + the conversion pass: the link has room (copy-only %.1f GB/s against the %.1f GB/s the fed rate consumes); what the fed loop adds to every "
-                 "step is step_clip_from_u8 on the compute stream (reads the uint8 batch, writes the 16-bit clip) and the copy's HBM writes under the backbone" % (h2d, nbytes / N * (fed_rate / world) / 1e9))
-    return {"value": round(fed_rate, 2), "unit": "clips/s", "ms_per_step": round(el_f / steps * 1e3, 4), "steps": steps,
+        limit = ("compute + what feeding adds to a step: the link has room (copy-only %.1f GB/s against the %.1f GB/s the fed rate consumes); the fed step carries the "
+                 "copy's HBM writes under the backbone and %s" % (h2d, nbytes / N * (fed_rate / world) / 1e9,
+                 "the table look-ups of the uint8 frame staging in the stem" if form == "u8_stem" else "step_clip_from_u8 on the compute stream (reads the uint8 batch, writes the 16-bit clip)"))
+    return {"value": round(fed_rate, 2), "unit": "clips/s", "ms_per_step": round(el_f / steps * 1e3, 4), "steps": steps, "form": form,
+            "forms": {"u8_stem": round(rate(el_u8), 2) if el_u8 is not None else None, "convert": round(rate(el_conv), 2)},
             "resident_value": round(res_rate, 2), "fed_over_resident": round(fed_rate / res_rate, 4),
             "wire_format": "uint8 [N,T,H,W,3], %.2f MB per clip (fp32 [T,3,H,W] as the reference feeds it: %.2f MB)" % (nbytes / N / 1e6, 4 * nbytes / N / 1e6),
             "h2d_GBs_in_fed_loop": round(nbytes * steps / el_f / 1e9, 2), "h2d_GBs_copy_only": round(h2d, 2),
             "u8_GBs_needed_at_resident_rate": round(need, 2), "bottleneck": limit,
             "eight_ranks": "8 ranks at this rate pull %.0f GB/s of uint8 frames from the host (fp32 frames: %.0f GB/s)" % (8 * nbytes / N * (fed_rate / world) / 1e9, 32 * nbytes / N * (fed_rate / world) / 1e9),
-            "note": "pinned host buffers (synthetic frames, not rewritten between steps) -> hipMemcpyAsync on a copy stream -> step_clip_from_u8 (x*2/255-1) into "
-                    "the captured step's input -> captured step; %d batches in flight; copy k+%d waits for conversion k only; the copy stream is a high-priority stream (own hardware queue)" % (nfl, nfl)}
+            "note": "pinned host buffers (synthetic frames, not rewritten between steps) -> hipMemcpyAsync on a high-priority copy stream -> u8_stem: the stem stages the uint8 "
+                    "frames itself (two captured graphs per batch: stem | rest; copy k+%d waits for stem k) | convert: step_clip_from_u8 (x*2/255-1) into the captured step's input "
+                    "(copy k+%d waits for conversion k); %d batches in flight, each on a stream of its own" % (nfl, nfl, nfl)}
 
 
 def spawn_ranks(n):

@@ -299,6 +299,13 @@ STEP_API size_t step_conv_pre_pool_workspace_bytes(const step_conv_desc* d);
 STEP_API int step_conv_forward_pre_pool(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
                                         const void* pre_w_packed, const float* pre_scale, const float* pre_shift, int pre_cin, void* y_pooled,
                                         void* ws, size_t ws_bytes, step_stream_t stream);
+/* The same call in its two parts, for callers that account the launches separately (bench.py's per-kernel roofline): _tiles = the conv
+ * launches (pooled tiles + the tiles' first rows / columns into ws), _finish = the seam pass over y_pooled.  _tiles then _finish on one
+ * stream == step_conv_forward_pre_pool. */
+STEP_API int step_conv_forward_pre_pool_tiles(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
+                                              const void* pre_w_packed, const float* pre_scale, const float* pre_shift, int pre_cin, void* y_pooled,
+                                              void* ws, size_t ws_bytes, step_stream_t stream);
+STEP_API int step_conv_pre_pool_finish(const step_conv_desc* d, void* y_pooled, void* ws, size_t ws_bytes, step_stream_t stream);
 
 typedef struct step_conv_item {
     const step_conv_desc* desc;
@@ -399,6 +406,15 @@ STEP_API size_t step_stem_pool_workspace_bytes(int dtype, int N, int T, int H, i
 STEP_API int step_stem_pool_forward(int dtype, const void* x, int N, int T, int H, int W, const void* w_packed, const float* scale,
                                     const float* shift, int Cout, void* y, int y_cstride, int y_coff, void* ws, size_t ws_bytes,
                                     step_stream_t stream);
+/* The same call reading the decoder's uint8 frames [N,T,H,W,3] directly (device memory, 4-byte aligned): step_clip_from_u8's
+ * normalisation -- scale 0 / 1 / 2, then (v - mean[c]) / std[c], data/augmentations.py:68-111 -- and the rounding to `dtype` happen
+ * while the stem stages its frames (a 3 x 256-entry table built per workgroup with the same fp32 operations), so the normalised
+ * clip never exists: half the input bytes and one pass less on a FED node.  Bit-identical to step_clip_from_u8 (into `dtype`) +
+ * step_stem_pool_forward.  mean3 / std3: HOST pointers to 3 floats (NULL = 0 / 1).  Same support and workspace as
+ * step_stem_pool_forward. */
+STEP_API int step_stem_pool_forward_u8(int dtype, const unsigned char* frames, int N, int T, int H, int W, int scale_mode, const float* mean3,
+                                       const float* std3, const void* w_packed, const float* scale, const float* shift, int Cout, void* y,
+                                       int y_cstride, int y_coff, void* ws, size_t ws_bytes, step_stream_t stream);
 /* Weight gradient of the stem: dw[Cout][3][7][7][7] (fp32, torch layout) (+)= sum over output pixels of
  * dy[n,to,ho,wo,co] * x_padded[...]; x as in step_stem_forward, dy fp32 contiguous [N,To,Ho,Wo,Cout] (gradient before
  * the affine epilogue).  The stem needs no data gradient (its input is the clip). */

@@ -962,13 +962,17 @@ def wgrad_sync():
 
 POOL_WITH_POINTWISE = True     # inference: an Inception block's max pool and its fused 1x1x1 triple as one launch where the library has the form
 FUSE_STEM_POOL = True          # inference: maxPool3d_2a is taken on the stem's tiles while they are on the chip (ops.stem_pool_forward)
+FUSE_STEM_U8 = False           # BaseNet.forward_u8: True = the stem stages uint8 frames itself (ops.stem_pool_forward_u8, bit-identical); False (default) = one conversion
+                               # pass in front -- MEASURED: the table look-ups in the stem's frame staging cost more than the pass they save (fed C2 6.75 k against 6.96 k clips/s)
 FUSE_CONV_POOL = True          # inference: maxPool3d_3a is taken on conv3d_2c's tiles while they are on the chip (ops.conv_forward_pre_pool; needs FUSE_POINTWISE_INPUT)
 FUSE_POINTWISE_INPUT = True    # inference: a 64 -> 64 1x1x1 unit directly in front of a 3x3x3 unit runs inside that unit's launch (ops.conv_forward_pre)
 
 
-def _stem_then_pool(a, b, x):
+def _stem_then_pool(a, b, x, u8=None):
     """Unit3D a (the 7x7x7 stem, eval-mode BN, ReLU) followed by MaxPoolTF b ((1,3,3) / (1,2,2)): one call when neither needs autograd
-    and the library has the fused form (16-bit clips); None otherwise -- the caller runs them one after the other (bit-identical)."""
+    and the library has the fused form (16-bit clips); None otherwise -- the caller runs them one after the other (bit-identical).
+    u8 = (dtype, scale_mode, mean, std): x is uint8 frames [N,T,H,W,3] and the normalisation happens in the stem's staging
+    (ops.stem_pool_forward_u8)."""
     if not (isinstance(a, Unit3D) and a.is_stem and isinstance(b, MaxPoolTF)) or not x.is_cuda or x.dtype == torch.float32:
         return None
     if b.kernel_size != (1, 3, 3) or b.stride != (1, 2, 2) or not a.relu or a._unit.bn_training or a._unit.bn is None:
@@ -978,6 +982,9 @@ def _stem_then_pool(a, b, x):
     if torch.is_grad_enabled() and (w.requires_grad or bn.weight.requires_grad or bn.bias.requires_grad or x.requires_grad):
         return None
     scale, shift = a._unit.affine()
+    if u8 is not None:
+        dtype, mode, mean, std = u8
+        return ops.stem_pool_forward_u8(x, dtype, a.stem_packed(dtype), w.shape[0], scale, shift, mode, mean, std)
     return ops.stem_pool_forward(x, a.stem_packed(x.dtype), w.shape[0], scale, shift)
 
 
@@ -1179,12 +1186,38 @@ class BaseNet(nn.Module):
             raise NotImplementedError
         self.base_model = build_base_i3d(self.kinetics_pretrain, self.freeze_affine)
 
+    def forward_u8(self, frames, dtype=torch.bfloat16, scale=2, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0)):
+        """forward() on the decoder's uint8 frames [batch, T, H, W, 3] (what a fed node receives over PCIe: 4x fewer bytes than the fp32
+        clip of data/ava.py:298-368): the reference's ConvertFromInts(scale) / SubtractMeans / DivideStds (data/augmentations.py:68-111)
+        and the rounding to `dtype` happen inside the stem's frame staging where the library has that form (inference, 16-bit, W % 4 == 0),
+        else as one conversion pass (ops.clip_from_u8) in front of forward().  Bit-identical to forward(clip_from_u8(frames, dtype))."""
+        z = self.stem_u8(frames, dtype, scale, mean, std)
+        if z is not None:
+            return self.after_stem(z)
+        return self.forward(ops.clip_from_u8(frames.contiguous(), dtype, scale, mean, std))
+
+    def stem_u8(self, frames, dtype=torch.bfloat16, scale=2, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0)):
+        """The first two stages (conv3d_1a_7x7 + maxPool3d_2a) from uint8 frames: the pooled channels-last tensor [N,To,Hp,Wp,64], or None
+        when the library has no such form for the call (then forward_u8 converts first).  A fed loop captures this and after_stem() as two
+        graphs: the frames' staging buffer is free again as soon as THIS part has run."""
+        if frames.dim() != 5 or frames.shape[-1] != 3 or frames.dtype != torch.uint8:
+            raise RuntimeError("BaseNet.forward_u8 expects uint8 frames [batch, T, H, W, 3]")
+        stages = list(self.base_model)
+        if FUSE_STEM_POOL and FUSE_STEM_U8 and len(stages) > 1 and frames.is_cuda and dtype != torch.float32:
+            return _stem_then_pool(stages[0], stages[1], frames.contiguous(), u8=(dtype, scale, mean, std))
+        return None
+
+    def after_stem(self, z):
+        """Stages 2.. on the pooled stem output of stem_u8(); returns what forward() returns."""
+        return self._stages_from(z, 2)
+
     def forward(self, x):
         if x.dim() != 5 or x.shape[2] != 3:
             raise RuntimeError("BaseNet expects [batch, T, 3, H, W]")
-        y = x.contiguous()
+        return self._stages_from(x.contiguous(), 0)
+
+    def _stages_from(self, y, i):
         stages = list(self.base_model)
-        i = 0
         while i < len(stages):
             st = stages[i]
             if FUSE_STEM_POOL and i == 0 and i + 1 < len(stages):

@@ -905,6 +905,8 @@ int step_conv_forward_pre(const step_conv_desc* d, const void* x, const void* w_
 // too, so that exactly one thread updates any pooled pixel.  Column seams: pooled column PT*s - 1 lacks conv column 2*PT*s (pool_col),
 // rows 2ph .. 2ph+2 -- all inside one tile row unless ph is a seam row (handled by the row pass).  Same structure as
 // stem_pool_fix_kernel (stem.hip, PT = 8).
+}  // extern "C"
+namespace step {
 struct PoolFixParams { void* y; const void* rowbuf; const void* colbuf; long long planes; int H, W, Hp, Wp, tiles_h, tiles_w, C, y_cstride, y_coff, PT; };
 typedef short s16x8_fix __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ u32x4 pk_max_nonneg16_fix(const u32x4& a, const u32x4& b) {
@@ -956,6 +958,9 @@ __global__ __launch_bounds__(256) void pool_seam_fix_kernel(PoolFixParams p) {
 }
 
 
+}  // namespace step
+extern "C" {
+
 // supported: what step_conv_forward_pre takes, planned onto the 4-plane 8x8 tile (maps whose sides the planner tiles by 8: 56 x 56 at C2),
 // ReLU on (the pooled epilogue orders 16-bit patterns as integers: values must be >= +0), 16-byte output vectors, no residual
 static bool conv_pre_pool_plan(const step_conv_desc* d, step_conv_desc& canon, ConvPlan& pl) {
@@ -976,18 +981,21 @@ size_t step_conv_pre_pool_workspace_bytes(const step_conv_desc* d) {
     return planes * ((size_t)pl.tiles_h * canon.W + (size_t)pl.tiles_w * canon.H) * canon.Cout * 2;
 }
 
-int step_conv_forward_pre_pool(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
-                               const void* pre_w_packed, const float* pre_scale, const float* pre_shift, int pre_cin, void* y_pooled,
-                               void* ws, size_t ws_bytes, step_stream_t stream) {
+// parts: 1 = the conv launches (tiles + their first rows / columns), 2 = the seam pass, 3 = both
+static int conv_forward_pre_pool_impl(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
+                                      const void* pre_w_packed, const float* pre_scale, const float* pre_shift, int pre_cin, void* y_pooled,
+                                      void* ws, size_t ws_bytes, int parts, step_stream_t stream) {
     step_conv_desc canon;
     ConvParams p;
-    const int rc = conv_fill_params(d, x, w_packed, scale, shift, nullptr, y_pooled, nullptr, canon, p);
+    const bool conv = (parts & 1) != 0;
+    // (the seam pass needs the descriptor, the pooled tensor and the workspace only)
+    const int rc = conv_fill_params(d, conv ? x : y_pooled, conv ? w_packed : y_pooled, scale, shift, nullptr, y_pooled, nullptr, canon, p);
     if (rc != STEP_OK) return rc;
-    if (!pre_w_packed) return STEP_E_NULL;
+    if (conv && !pre_w_packed) return STEP_E_NULL;
     if (p.N == 0) return STEP_OK;
     ConvPlan pl;
-    if (pre_cin != 64 || !conv_pre_pool_plan(d, canon, pl) || !p.vec_epi) return STEP_E_UNSUPPORTED;
-    if (((uintptr_t)pre_w_packed % 16) || (pre_scale && ((uintptr_t)pre_scale % 16)) || (pre_shift && ((uintptr_t)pre_shift % 16))) return STEP_E_ALIGN;
+    if ((conv && pre_cin != 64) || !conv_pre_pool_plan(d, canon, pl) || !p.vec_epi) return STEP_E_UNSUPPORTED;
+    if (conv && (((uintptr_t)pre_w_packed % 16) || (pre_scale && ((uintptr_t)pre_scale % 16)) || (pre_shift && ((uintptr_t)pre_shift % 16)))) return STEP_E_ALIGN;
     const size_t need = step_conv_pre_pool_workspace_bytes(d);
     if (!ws || ws_bytes < need || ((uintptr_t)ws % 16)) return STEP_E_SHAPE;
     p.pre_w = pre_w_packed; p.pre_scale = pre_scale; p.pre_shift = pre_shift;
@@ -995,9 +1003,11 @@ int step_conv_forward_pre_pool(const step_conv_desc* d, const void* x, const voi
     p.pool_row = ws;
     p.pool_col = (unsigned char*)ws + planes * (size_t)pl.tiles_h * canon.W * canon.Cout * 2;
     p.Hp = step_pool_out_size(canon.H, 3, 2); p.Wp = step_pool_out_size(canon.W, 3, 2);      // (1,3,3) / (1,2,2), TF padding (0,1), ceil mode
-    const int rc2 = canon.dtype == STEP_BF16 ? conv_forward_t<bf16_t>(&canon, p, nullptr, 0, stream) : conv_forward_t<f16_t>(&canon, p, nullptr, 0, stream);
-    if (rc2 != STEP_OK) return rc2;
-    if (pl.tiles_h > 1 || pl.tiles_w > 1) {
+    if (conv) {
+        const int rc2 = canon.dtype == STEP_BF16 ? conv_forward_t<bf16_t>(&canon, p, nullptr, 0, stream) : conv_forward_t<f16_t>(&canon, p, nullptr, 0, stream);
+        if (rc2 != STEP_OK) return rc2;
+    }
+    if ((parts & 2) && (pl.tiles_h > 1 || pl.tiles_w > 1)) {
         PoolFixParams f;
         f.y = y_pooled; f.rowbuf = p.pool_row; f.colbuf = p.pool_col; f.planes = (long long)planes;
         f.H = canon.H; f.W = canon.W; f.Hp = p.Hp; f.Wp = p.Wp; f.tiles_h = pl.tiles_h; f.tiles_w = pl.tiles_w; f.C = canon.Cout;
@@ -1009,6 +1019,22 @@ int step_conv_forward_pre_pool(const step_conv_desc* d, const void* x, const voi
         }
     }
     return STEP_OK;
+}
+
+int step_conv_forward_pre_pool(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
+                               const void* pre_w_packed, const float* pre_scale, const float* pre_shift, int pre_cin, void* y_pooled,
+                               void* ws, size_t ws_bytes, step_stream_t stream) {
+    return conv_forward_pre_pool_impl(d, x, w_packed, scale, shift, pre_w_packed, pre_scale, pre_shift, pre_cin, y_pooled, ws, ws_bytes, 3, stream);
+}
+
+int step_conv_forward_pre_pool_tiles(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,
+                                     const void* pre_w_packed, const float* pre_scale, const float* pre_shift, int pre_cin, void* y_pooled,
+                                     void* ws, size_t ws_bytes, step_stream_t stream) {
+    return conv_forward_pre_pool_impl(d, x, w_packed, scale, shift, pre_w_packed, pre_scale, pre_shift, pre_cin, y_pooled, ws, ws_bytes, 1, stream);
+}
+
+int step_conv_pre_pool_finish(const step_conv_desc* d, void* y_pooled, void* ws, size_t ws_bytes, step_stream_t stream) {
+    return conv_forward_pre_pool_impl(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 64, y_pooled, ws, ws_bytes, 2, stream);
 }
 
 // Can these convs share one grid?  All 16-bit 3x3x3 layers the planner sends to the two-phase conv_tap form on general boxes
@@ -1216,7 +1242,7 @@ int step_conv_plan_info(const step_conv_desc* d, int* info, int n) {
 __attribute__((visibility("default"))) void step_probe_set(void* buf) { step::g_probe_buf = (unsigned long long*)buf; }
 #endif
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 29; }
+int step_abi_version(void) { return 31; }
 
 }  // extern "C"
 

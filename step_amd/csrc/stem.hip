@@ -26,6 +26,10 @@ struct StemParams {
     int Hp, Wp;
     void* rowbuf;              // [N*To][tiles_h][Wo][C]: the first row of every tile (what the tile above still needs), raw stem values
     void* colbuf;              // [N*To][tiles_w][Ho][C]: the first column of every tile
+    // stem_stream_kernel<.., U8 = true> (step_stem_pool_forward_u8): x is the decoder's uint8 frames [N,T,H,W,3]; the normalisation of
+    // step_clip_from_u8 -- ConvertFromInts(scale) / SubtractMeans / DivideStds, data/augmentations.py:68-111 -- and the rounding to the
+    // storage type happen in the frame staging through a 3 x 256-entry table built in the prologue with the same fp32 operations
+    int u8_scale; float u8_mean[3], u8_std[3];
 #ifdef STEP_PROBE
     unsigned long long* probe;   // tools/timeline_probe.py build only (conv_common.h: probe_mark)
 #endif
@@ -204,9 +208,10 @@ __device__ __forceinline__ u32x4 pk_max_nonneg16(const u32x4& a, const u32x4& b)
     return __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8_t, a), __builtin_bit_cast(s16x8_t, b)));
 }
 
-template <typename T, int NB_ = 2, bool VEC = true, bool POOL = false>
+template <typename T, int NB_ = 2, bool VEC = true, bool POOL = false, bool U8 = false>
 __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel(StemParams p) {
     static_assert(sizeof(T) == 2, "16-bit storage types only");
+    static_assert(!U8 || VEC, "uint8 frames: whole 4-column quads only");
     constexpr int FRAME = STS_FRAME, PITCH = STS_PITCH;
     constexpr int NB = NB_, FRAGB = 1024;          // 32-channel blocks per workgroup: 2, or 1 for the tiles of the partial last round
     constexpr int NBREG = 4 * FRAGB;                // one n-block's share of a weight buffer (up to 4 K-steps)
@@ -222,10 +227,11 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
     typedef u16x8 frag_t;
 
     static_assert(!POOL || (NB == 2 && 256 * STS_TPITCH <= 3 * FRAME + 3 * BBUF), "the pooled epilogue's tile lives in the frame / weight rings");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * FRAME + 3 * BBUF + NB * 32 * 2 * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * FRAME + 3 * BBUF + NB * 32 * 2 * 4 + (U8 ? 3 * 256 * 2 : 0)];
     unsigned char* const ldsA = lds;
     unsigned char* const ldsB = lds + 3 * FRAME;
     float* const ldsS = (float*)(lds + 3 * FRAME + 3 * BBUF);     // fp32 scale | shift of the workgroup's channels (read in the epilogue)
+    unsigned short* const ldsL = (unsigned short*)(lds + 3 * FRAME + 3 * BBUF + NB * 32 * 2 * 4);    // U8: [channel][byte value] -> storage bits
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -257,7 +263,9 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
     constexpr bool vec_ok = VEC;
 
     // ---- frame staging: LDS col cl <-> input col 2*ow0 - 4 + cl, row r <-> input row 2*oh0 - 2 + r
-    struct Item { u16x4 c[3]; };
+    struct ItemP { u16x4 c[3]; };                  // planar 16-bit clip: 4 columns of each channel plane
+    struct ItemB { unsigned w[3]; };               // uint8 frames: the 12 interleaved bytes of 4 pixels
+    typedef typename std::conditional<U8, ItemB, ItemP>::type Item;
     // per-thread item table (frame-invariant): element offset of the item's 4 columns inside a channel plane, or -1
     // when the quad lies outside the image.  With W % 4 == 0 a quad is entirely inside or entirely outside (the tile
     // origin 2*ow0 - 4 is a multiple of 4), so the frame loop needs no division, no branch and no partial quad.
@@ -274,7 +282,15 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
         const int ifr = 2 * od - 2 + f;
         const bool frok = ifr >= 0 && ifr < p.T;                 // workgroup-uniform
         const unsigned short* fbase = (const unsigned short*)xg + ((size_t)n * p.T + (frok ? ifr : 0)) * 3 * plane_elems;
-        if constexpr (vec_ok) {
+        if constexpr (U8) {
+            // [H,W,3] bytes: the quad's 12 bytes are contiguous and 4-byte aligned (W % 4 == 0, quad origins are multiples of 4 pixels)
+            const unsigned char* fb8 = (const unsigned char*)p.x + ((size_t)n * p.T + (frok ? ifr : 0)) * 3 * plane_elems;
+#pragma unroll
+            for (int q = 0; q < FQ; ++q) {
+                const unsigned* src = (const unsigned*)(fb8 + (size_t)(qoff[q] >= 0 ? qoff[q] : 0) * 3);
+                it[q].w[0] = src[0]; it[q].w[1] = src[1]; it[q].w[2] = src[2];
+            }
+        } else if constexpr (vec_ok) {
             // raw loads from a clamped (always valid) address; the out-of-image quads are zeroed in store_frame, where the data
             // is needed anyway -- a select on the loaded value HERE made the compiler wait for the loads (vmcnt(0)) before the
             // frame's first MFMA: 2.6 us of exposed latency per frame (tools/timeline_probe.py --stem, round 3)
@@ -315,9 +331,18 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
                 const int cq = item % (STP_COLS / 4), r = item / (STP_COLS / 4);
                 unsigned char* dst = ldsA + slotoff + r * PITCH + cq * 24;
                 const unsigned short keep = (!vec_ok || (frok && qoff[q] >= 0)) ? 0xffffu : 0u;    // (the element-wise path zeroed on load)
-                u16x4 v0 = {it[q].c[0][0], it[q].c[1][0], it[q].c[2][0], it[q].c[0][1]};
-                u16x4 v1 = {it[q].c[1][1], it[q].c[2][1], it[q].c[0][2], it[q].c[1][2]};
-                u16x4 v2 = {it[q].c[2][2], it[q].c[0][3], it[q].c[1][3], it[q].c[2][3]};
+                u16x4 v0, v1, v2;
+                if constexpr (U8) {
+                    // the LDS element stream [column][3 channels] IS the byte order of the frame: element e <- table[e % 3][byte e]
+                    unsigned short val[12];
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) val[e] = ldsL[(e % 3) * 256 + ((it[q].w[e >> 2] >> (8 * (e & 3))) & 0xffu)];
+                    v0 = u16x4{val[0], val[1], val[2], val[3]}; v1 = u16x4{val[4], val[5], val[6], val[7]}; v2 = u16x4{val[8], val[9], val[10], val[11]};
+                } else {
+                    v0 = u16x4{it[q].c[0][0], it[q].c[1][0], it[q].c[2][0], it[q].c[0][1]};
+                    v1 = u16x4{it[q].c[1][1], it[q].c[2][1], it[q].c[0][2], it[q].c[1][2]};
+                    v2 = u16x4{it[q].c[2][2], it[q].c[0][3], it[q].c[1][3], it[q].c[2][3]};
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v0[e] &= keep; v1[e] &= keep; v2[e] &= keep; }
                 *(u16x4*)dst = v0;
@@ -398,6 +423,19 @@ __global__ __launch_bounds__(256) STEP_WAVES_PER_SIMD(3) void stem_stream_kernel
     // The whole K loop exists twice, once per staging role (compile-time W): inside ONE loop the role tests merge control flow at
     // every staging point, and the values requested in a branch then reach the loop-carried registers through copies that wait for
     // the loads -- measured in the ISA, not guessed.  Both bodies execute the same barriers.
+    if constexpr (U8) {
+        // the normalisation table, 3 entries per thread: the fp32 operations of clip_from_u8_kernel in the same order (no FMA contraction),
+        // then the storage rounding -- exactly the element the two-launch path would have read from the converted clip
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float v = (float)tid;
+            if (p.u8_scale == 1) v = __fdiv_rn(v, 255.f);
+            else if (p.u8_scale == 2) v = __fsub_rn(__fdiv_rn(__fmul_rn(v, 2.f), 255.f), 1.f);
+            v = __fdiv_rn(__fsub_rn(v, p.u8_mean[k]), p.u8_std[k]);
+            ldsL[k * 256 + tid] = elem<T>::bits16(v);
+        }
+        __syncthreads();
+    }
     auto run_role = [&](auto rolec) {
     constexpr bool W = decltype(rolec)::value;
     Item fr[FQ], fr1[FQ];
@@ -808,6 +846,48 @@ int step_stem_pool_forward(int dtype, const void* x, int N, int T, int H, int W,
     } else {
         p.w = (const f16_t*)w_packed + stem_stream_offset(Cout);
         STEP_LAUNCH((stem_stream_kernel<f16_t, 2, true, true>), grid, dim3(256), stream, p);
+    }
+    if (p.tiles_h > 1 || p.tiles_w > 1) {
+        const long long items = ((long long)(p.tiles_h - 1) * p.Wp + (long long)(p.tiles_w - 1) * p.Hp) * (Cout / 8) * p.N * p.To;
+        STEP_LAUNCH(stem_pool_fix_kernel, dim3(flat_grid(items, 256)), dim3(256), stream, p);
+    }
+    return STEP_LAUNCH_CHECK();
+}
+
+int step_stem_pool_forward_u8(int dtype, const unsigned char* frames, int N, int T, int H, int W, int u8_scale, const float* mean3, const float* std3,
+                              const void* w_packed, const float* scale, const float* shift, int Cout, void* y, int y_cstride, int y_coff,
+                              void* ws, size_t ws_bytes, step_stream_t stream) {
+    if (N < 0 || T <= 0 || H <= 0 || W <= 0 || Cout <= 0 || u8_scale < 0 || u8_scale > 2) return STEP_E_SHAPE;
+    if (y_coff < 0 || y_coff + Cout > y_cstride) return STEP_E_SHAPE;
+    if (N == 0) return STEP_OK;
+    if (!stem_pool_supported(dtype, N, T, H, W, Cout)) return STEP_E_UNSUPPORTED;
+    if (!frames || !w_packed || !y || !ws) return STEP_E_NULL;
+    if (((uintptr_t)frames % 4) || ((uintptr_t)w_packed % 16) || ((uintptr_t)y % 16) || ((uintptr_t)ws % 16) || (y_cstride % 8) || (y_coff % 8)) return STEP_E_ALIGN;
+    if (ws_bytes < step_stem_pool_workspace_bytes(dtype, N, T, H, W, Cout)) return STEP_E_SHAPE;
+    StemParams p;
+    p.x = frames; p.scale = scale; p.shift = shift; p.y = y;
+    p.N = N; p.T = T; p.H = H; p.W = W; p.tile0 = 0; p.relu = 1;
+    p.To = (T + 5 - 7) / 2 + 1; p.Ho = (H + 5 - 7) / 2 + 1; p.Wo = (W + 5 - 7) / 2 + 1;
+    if (p.To <= 0 || p.Ho <= 0 || p.Wo <= 0) return STEP_E_SHAPE;
+    p.Cout = Cout; p.y_cstride = y_cstride; p.y_coff = y_coff;
+    p.nblk32 = ceil_div(Cout, 32);
+    p.tiles_h = ceil_div(p.Ho, 16); p.tiles_w = ceil_div(p.Wo, 16);
+    p.Hp = step_pool_out_size(p.Ho, 3, 2); p.Wp = step_pool_out_size(p.Wo, 3, 2);
+    p.rowbuf = ws;
+    p.colbuf = (unsigned char*)ws + (((size_t)N * p.To * p.tiles_h * p.Wo * Cout * 2 + 15) / 16) * 16;
+    p.u8_scale = u8_scale;
+    for (int c = 0; c < 3; ++c) { p.u8_mean[c] = mean3 ? mean3[c] : 0.f; p.u8_std[c] = std3 ? std3[c] : 1.f; }     // host pointers (3 floats)
+#ifdef STEP_PROBE
+    p.probe = g_probe_buf;
+#endif
+    const long long tiles = (long long)p.N * p.To * p.tiles_h * p.tiles_w;
+    dim3 grid((unsigned)tiles, 1);
+    if (dtype == STEP_BF16) {
+        p.w = (const bf16_t*)w_packed + stem_stream_offset(Cout);
+        STEP_LAUNCH((stem_stream_kernel<bf16_t, 2, true, true, true>), grid, dim3(256), stream, p);
+    } else {
+        p.w = (const f16_t*)w_packed + stem_stream_offset(Cout);
+        STEP_LAUNCH((stem_stream_kernel<f16_t, 2, true, true, true>), grid, dim3(256), stream, p);
     }
     if (p.tiles_h > 1 || p.tiles_w > 1) {
         const long long items = ((long long)(p.tiles_h - 1) * p.Wp + (long long)(p.tiles_w - 1) * p.Hp) * (Cout / 8) * p.N * p.To;

@@ -283,12 +283,22 @@ def conv_forward_pre_pool(x, w_packed, Cout, k, scale, shift, relu, pre):
     refused = []
 
     def launch():
-        rc = L.step_conv_forward_pre_pool(ctypes.byref(d), _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift), _lib.dptr(pw),
-                                          _lib.dptr(pscale), _lib.dptr(pshift), int(Cpre), _lib.dptr(out), _lib.dptr(ws), wsb, _lib.stream_ptr(x.device))
+        # (the call in its two parts so that the instrumented legs time the conv launches and the seam pass separately)
+        rc = L.step_conv_forward_pre_pool_tiles(ctypes.byref(d), _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift), _lib.dptr(pw),
+                                                _lib.dptr(pscale), _lib.dptr(pshift), int(Cpre), _lib.dptr(out), _lib.dptr(ws), wsb, _lib.stream_ptr(x.device))
         if rc in (-4, -5):          # the library's stricter contract (alignment, 32-bit offsets): the caller falls back
             refused.append(rc)
             return
-        _capi.check(rc, "step_conv_forward_pre_pool")
+        _capi.check(rc, "step_conv_forward_pre_pool_tiles")
+
+    def finish():
+        _capi.check(L.step_conv_pre_pool_finish(ctypes.byref(d), _lib.dptr(out), _lib.dptr(ws), wsb, _lib.stream_ptr(x.device)), "step_conv_pre_pool_finish")
+
+    def describe_finish():
+        th, tw = -(-H // 8), -(-W // 8)
+        seam = N * D * ((th - 1) * Wp + (tw - 1) * Hp) * Cout
+        rows = N * D * (th * W + tw * H) * Cout
+        return ("step::pool_seam_fix_kernel(step::PoolFixParams)", 0.0, (2 * seam + rows) * _ES[x.dtype])
 
     def describe():
         pix = N * D * H * W
@@ -299,6 +309,7 @@ def conv_forward_pre_pool(x, w_packed, Cout, k, scale, shift, relu, pre):
         if PROFILE is not None and PROFILE and PROFILE[-1][0].startswith("void step::conv_tap_pre_pool_kernel"):
             PROFILE.pop()
         return None
+    _run(finish, describe_finish)
     return out
 
 
@@ -613,6 +624,39 @@ def stem_pool_forward(x, w_packed, Cout, scale, shift):
     def launch():
         _capi.check(L.step_stem_pool_forward(_dt(x), _lib.dptr(x), N, T, H, W, _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift), Cout,
                                              _lib.dptr(out), Cout, 0, _lib.dptr(ws), wsb, _lib.stream_ptr(x.device)), "step_stem_pool_forward")
+    _run(launch, describe)
+    return out
+
+
+def stem_pool_forward_u8(frames, dtype, w_packed, Cout, scale, shift, u8_scale=2, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0)):
+    """stem_pool_forward reading uint8 frames [N,T,H,W,3] directly (step_stem_pool_forward_u8): clip_from_u8's normalisation and the
+    rounding to `dtype` happen in the stem's frame staging -- the normalised clip never exists.  Returns the pooled channels-last tensor
+    [N,To,Hp,Wp,Cout] or None when the library has no fused form (the caller converts with clip_from_u8 first; bit-identical)."""
+    L = _lib.lib()
+    if frames.dtype != torch.uint8 or frames.dim() != 5 or frames.shape[-1] != 3 or not frames.is_contiguous() or not frames.is_cuda \
+            or dtype not in (torch.bfloat16, torch.float16):
+        return None
+    N, T, H, W, _ = frames.shape
+    code = _capi.BF16 if dtype == torch.bfloat16 else _capi.F16
+    wsb = L.step_stem_pool_workspace_bytes(code, N, T, H, W, Cout)
+    if not wsb:
+        return None
+    To, Ho, Wo = (T - 2) // 2 + 1, (H - 2) // 2 + 1, (W - 2) // 2 + 1
+    Hp, Wp = L.step_pool_out_size(Ho, 3, 2), L.step_pool_out_size(Wo, 3, 2)
+    out = torch.empty((N, To, Hp, Wp, Cout), dtype=dtype, device=frames.device)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=frames.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    sd = (ctypes.c_float * 3)(*[float(v) for v in std])
+
+    def describe():
+        pix = N * To * Ho * Wo
+        return ("void step::stem_stream_kernel<%s, 2, true, true, true>(step::StemParams)" % _TNAME[dtype], 2.0 * pix * Cout * 1029,
+                frames.numel() + (out.numel() + Cout * 1029) * _ES[dtype])
+
+    def launch():
+        _capi.check(L.step_stem_pool_forward_u8(code, _lib.dptr(frames), N, T, H, W, int(u8_scale), m, sd, _lib.dptr(w_packed), _lib.dptr(scale),
+                                                _lib.dptr(shift), Cout, _lib.dptr(out), Cout, 0, _lib.dptr(ws), wsb, _lib.stream_ptr(frames.device)),
+                    "step_stem_pool_forward_u8")
     _run(launch, describe)
     return out
 

@@ -1493,6 +1493,49 @@ def case_stem_pool_fused(bk, golden):
     assert bk.lib.step_stem_pool_forward(F32, xe.ptr, 1, 4, 72, 80, wp.ptr, sc.ptr, sh.ptr, 64, out.ptr, 64, 0, ws.ptr, wsb, bk.stream) == -4
 
 
+def case_stem_pool_forward_u8(bk, golden):
+    """step_stem_pool_forward_u8 (the stem stages the decoder's uint8 frames [N,T,H,W,3] itself: normalisation + storage rounding through a
+    table built in the prologue) is BIT-IDENTICAL to step_clip_from_u8 (into the storage type) + step_stem_pool_forward: all three scale
+    modes, per-channel mean / std, both 16-bit types, maps of several tiles with partial tiles and image borders (out-of-image quads are
+    zeros AFTER normalisation, as the padded clip's), byte extremes 0 / 255 on the border; misaligned frames are refused."""
+    rs = np.random.RandomState(23)
+    Cout = 64
+    w = (rs.randn(Cout, 3, 7, 7, 7) / np.sqrt(1029)).astype(np.float32)
+    scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32)
+    shift = (0.2 * rs.randn(Cout)).astype(np.float32)
+    mean, std = np.array([0.1, -0.2, 0.3], np.float32), np.array([1.0, 0.5, 2.0], np.float32)
+    for (N, T, H, W), dt, mode, norm in (((1, 4, 40, 72), BF16, 2, False), ((2, 3, 34, 36), F16, 1, True), ((1, 2, 20, 24), BF16, 0, True)):
+        fr = rs.randint(0, 256, (N, T, H, W, 3)).astype(np.uint8)
+        fr[:, :, 0, :4] = 0
+        fr[:, :, -1, -4:] = 255
+        To, Ho, Wo = (T - 2) // 2 + 1, (H - 2) // 2 + 1, (W - 2) // 2 + 1
+        Hp, Wp = bk.lib.step_pool_out_size(Ho, 3, 2), bk.lib.step_pool_out_size(Wo, 3, 2)
+        wp = bk.dev(np.zeros(bk.lib.step_stem_packed_elems(Cout), NP_DT[dt]))
+        wd = bk.dev(np.ascontiguousarray(w, np.float32))
+        assert bk.lib.step_stem_pack_weight(wd.ptr, Cout, dt, wp.ptr, bk.stream) == 0
+        sc, sh, frd = bk.dev(scale), bk.dev(shift), bk.dev(fr)
+        m = (ctypes.c_float * 3)(*mean.tolist()) if norm else None
+        sd = (ctypes.c_float * 3)(*std.tolist()) if norm else None
+        clip = bk.dev(np.zeros((N, T, 3, H, W), NP_DT[dt]))
+        assert bk.lib.step_clip_from_u8(frd.ptr, N, T, H, W, mode, m, sd, dt, clip.ptr, bk.stream) == 0
+        wsb = bk.lib.step_stem_pool_workspace_bytes(dt, N, T, H, W, Cout)
+        assert wsb > 0
+        ws = bk.dev(np.full(wsb // 2, 0x7f7f, np.uint16))
+        want = bk.dev(np.zeros((N, To, Hp, Wp, Cout), NP_DT[dt]))
+        assert bk.lib.step_stem_pool_forward(dt, clip.ptr, N, T, H, W, wp.ptr, sc.ptr, sh.ptr, Cout, want.ptr, Cout, 0, ws.ptr, wsb, bk.stream) == 0
+        ws2 = bk.dev(np.full(wsb // 2, 0x7f7f, np.uint16))
+        got = bk.dev(np.zeros((N, To, Hp, Wp, Cout), NP_DT[dt]))
+        assert bk.lib.step_stem_pool_forward_u8(dt, frd.ptr, N, T, H, W, mode, m, sd, wp.ptr, sc.ptr, sh.ptr, Cout, got.ptr, Cout, 0, ws2.ptr, wsb,
+                                                bk.stream) == 0
+        g_, w_ = got.get().view(np.uint16), want.get().view(np.uint16)
+        assert np.array_equal(g_, w_), ((N, T, H, W), dt, mode, int((g_ != w_).sum()))
+        assert np.abs(decode(got.get(), dt)).max() > 0
+    assert bk.lib.step_stem_pool_forward_u8(F32, frd.ptr, N, T, H, W, 2, None, None, wp.ptr, sc.ptr, sh.ptr, Cout, got.ptr, Cout, 0, ws2.ptr, wsb, bk.stream) == -4
+    assert bk.lib.step_stem_pool_forward_u8(dt, frd.ptr, N, T, H, W, 3, None, None, wp.ptr, sc.ptr, sh.ptr, Cout, got.ptr, Cout, 0, ws2.ptr, wsb, bk.stream) == -2
+    off1 = (frd.ptr + 1) if isinstance(frd.ptr, int) else ctypes.c_void_p(frd.ptr.value + 1)
+    assert bk.lib.step_stem_pool_forward_u8(dt, off1, N, T, H, W, 2, None, None, wp.ptr, sc.ptr, sh.ptr, Cout, got.ptr, Cout, 0, ws2.ptr, wsb, bk.stream) == -5
+
+
 def case_stem_wgrad(bk, golden):
     rs = np.random.RandomState(44)
     N, T, H, W, Cout = 1, 6, 21, 70, 40                     # Ho = 10 (two row chunks), Wo = 35 (edge, interior and edge steps); Cout not a multiple of 32
@@ -1833,7 +1876,14 @@ def case_conv_forward_pre_pool_matches_separate_calls(bk, golden):
                                                      ws.ptr, nb, bk.stream) == 0
             assert bk.lib.step_conv_forward_pre_pool(ctypes.byref(dp), xe.ptr, wpb.ptr, dsb.ptr, dhb.ptr, wpa.ptr, dsa.ptr, dha.ptr, 64, got.ptr,
                                                      ws.ptr, nb - 16, bk.stream) == -2
+            # ... and in its two parts (conv launches, then the seam pass): the same bits
+            got2 = bk.dev(np.full((N, D, Hp, Wp, ycs), 3, NP_DT[dt]))
+            ws2 = bk.dev(np.full(nb // 2, 0x7f7f, np.uint16))
+            assert bk.lib.step_conv_forward_pre_pool_tiles(ctypes.byref(dp), xe.ptr, wpb.ptr, dsb.ptr, dhb.ptr, wpa.ptr, dsa.ptr, dha.ptr, 64, got2.ptr,
+                                                           ws2.ptr, nb, bk.stream) == 0
+            assert bk.lib.step_conv_pre_pool_finish(ctypes.byref(dp), got2.ptr, ws2.ptr, nb, bk.stream) == 0
         g_, w_ = got.get(), want.get()
+        assert np.array_equal(got2.get(), g_)
         assert np.array_equal(g_, w_), (dt, N, D, H, W, Cout, int((g_ != w_).sum()), np.argwhere(g_ != w_)[:4].tolist())
         assert (decode(g_[..., yco:yco + Cout], dt) >= 0).all()
         ran += 1

@@ -260,6 +260,43 @@ def case_conv_pool_fusion_in_basenet(dev, golden):
     assert torch.equal(y1, y0), float((y1.float() - y0.float()).abs().max())
 
 
+def case_basenet_forward_u8(dev, golden):
+    """BaseNet.forward_u8 (uint8 frames [N,T,H,W,3]: the reference's ConvertFromInts / SubtractMeans / DivideStds, data/augmentations.py:68-111,
+    inside the stem's frame staging, ops.stem_pool_forward_u8) is BIT-IDENTICAL to forward(clip_from_u8(frames)) -- default normalisation
+    and a per-channel mean / std, bf16 and fp16 -- and really takes the uint8 stem (ops.PROFILE); fp32 falls back to the conversion pass."""
+    from step_amd import backbone as _bb
+    from step_amd import ops as _ops
+    net = fill(step_amd.BaseNet(cfg())).to(dev).eval()
+    g = torch.Generator().manual_seed(5)
+    fr = torch.randint(0, 256, (2, 16, 64, 80, 3), dtype=torch.uint8, generator=g).to(dev)
+    keep_flag = _bb.FUSE_STEM_U8
+    with torch.no_grad():
+        y_conv = net.forward_u8(fr, torch.bfloat16)               # the default form: conversion pass + forward
+        assert torch.equal(y_conv, net(_ops.clip_from_u8(fr, torch.bfloat16)))
+    _bb.FUSE_STEM_U8 = True                                       # opt-in form: the stem stages the uint8 frames itself
+    try:
+        _basenet_forward_u8(dev, net, fr, _ops)
+    finally:
+        _bb.FUSE_STEM_U8 = keep_flag
+
+
+def _basenet_forward_u8(dev, net, fr, _ops):
+    with torch.no_grad():
+        for dt, kw in ((torch.bfloat16, {}), (torch.float16, dict(scale=1, mean=(0.4, 0.45, 0.5), std=(0.25, 0.2, 0.3)))):
+            want = net(_ops.clip_from_u8(fr, dt, kw.get("scale", 2), kw.get("mean", (0.0, 0.0, 0.0)), kw.get("std", (1.0, 1.0, 1.0))))
+            _ops.PROFILE, _ops.PROFILE_LIMIT = [], 1 << 30
+            try:
+                got = net.forward_u8(fr, dt, **kw)
+                names = [r[0] for r in _ops.PROFILE]
+            finally:
+                _ops.PROFILE, _ops.PROFILE_LIMIT = None, None
+            if dev != "cpu":                                       # (the fused forms live behind is_cuda checks: on the interpreter forward_u8 is the conversion pass + forward)
+                assert any("stem_stream_kernel" in n and "true, true, true>" in n for n in names), names[:3]
+            assert got.dtype == dt and torch.equal(got, want), (dt, float((got.float() - want.float()).abs().max()))
+        y32 = net.forward_u8(fr[:1, :8], torch.float32)
+        assert y32.dtype == torch.float32 and rel(np_(y32), np_(net(_ops.clip_from_u8(fr[:1, :8], torch.float32)))) == 0.0
+
+
 def case_i3d_classifier_golden(dev, golden):
     """step_amd.I3D (the full Kinetics classifier, models/i3dpt.py:175-262): state_dict keys / shapes of the reference's
     module, and forward on the golden clip against what the reference returned (fp32: 1e-3; bf16: the argmax and a loose bound)."""
@@ -1439,4 +1476,4 @@ CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_g
              "case_contextnet_backward_matches_oracle_autograd", "case_basenet_batch_statistics_bn_golden", "case_postprocess_golden",
              "case_batched_repack_follows_weight_updates", "case_stem_backward_16bit",
              "case_loss_masks_without_host_branches", "case_data_parallel_replicas", "case_train_select_device_front_end", "case_nms_operator_api"]
-GPU_CASES = CPU_CASES + ["case_conv_pool_fusion_in_basenet", "case_fp16_training_step_loss_scaling", "case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_c5_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_i3d_classifier_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
+GPU_CASES = CPU_CASES + ["case_basenet_forward_u8", "case_conv_pool_fusion_in_basenet", "case_fp16_training_step_loss_scaling", "case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_c5_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_i3d_classifier_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
