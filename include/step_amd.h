@@ -94,6 +94,9 @@ enum {
     STEP_OPT_CONV_GROUP_PW,    /*  2^20 (default: always) | n: step_conv_forward_group carries a pointwise item inside the 3x3x3 members' grid when they are at most n workgroups; 0 never (bit-identical) */
     STEP_OPT_CLIP_VEC,         /*  1 (default): step_clip_from_u8 converts 16 pixels per thread with 16-byte accesses where H*W % 16 == 0 | 0: the per-pixel kernel (bit-identical) */
     STEP_OPT_CONV_NB_RULE,     /*  0 (default): conv_tap's accumulator depth minimises ROUNDS of the chip (the latency of one launch) | 1: minimises workgroups x per-workgroup time (the chip time of the launch: what counts with several batches in flight); same K order per output either way (bit-identical) */
+    STEP_OPT_THROUGHPUT,       /*  0 (default): launch shapes tuned for the LATENCY of one batch | 1: for several independent batches in flight on separate streams (a serving loop) --
+                                    a block's pointwise conv is launched on its own instead of riding in the 3x3x3 members' grid (the other batch fills the idle CUs; measured
+                                    C2 +1.3 % at two in flight, -2.2 % one batch at a time).  Same bits either way */
     STEP_OPT_COUNT_
 };
 STEP_API int step_set_option(int option, int value);

@@ -5,7 +5,7 @@ import ctypes as C
 F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
 ROI_BWD_GATHER, ROI_BWD_ATOMIC = 0, 1
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 vp, fp, ip, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # raw device addresses
 i, f, ll, sz = C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -140,7 +140,7 @@ def check(status, what):
 # ---- planner options (include/step_amd.h: step_set_option) -----------------------------------------------------------
 OPTION_IDS = {name: k for k, name in enumerate((
     "conv_impl", "conv_nb", "conv_waves", "conv_phased", "conv_gen", "conv_gmode", "conv_pws", "conv_splitk", "conv_tail",
-    "conv_slots", "pool_direct", "wgrad_minpix", "wgrad16_lds", "conv_group_pw", "clip_vec", "conv_nb_rule"))}
+    "conv_slots", "pool_direct", "wgrad_minpix", "wgrad16_lds", "conv_group_pw", "clip_vec", "conv_nb_rule", "throughput"))}
 
 
 def set_option(lib, name, value):

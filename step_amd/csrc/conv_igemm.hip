@@ -1146,7 +1146,7 @@ int step_conv_forward_group(const step_conv_item* items, int n, step_stream_t st
             // the pointwise member rides along when the 3x3x3 members leave CUs idle (fewer one-per-CU workgroups than CUs):
             // behind a launch that fills every CU its workgroups would only queue
             bool with_pw = false;
-            if (sel.pw >= 0 && pls[0].twl == 0 && base <= opt(STEP_OPT_CONV_GROUP_PW)) {
+            if (sel.pw >= 0 && pls[0].twl == 0 && base <= opt(STEP_OPT_CONV_GROUP_PW) && opt(STEP_OPT_THROUGHPUT) == 0) {
                 step_conv_desc cpw;
                 with_pw = conv_group_pw_params(items[sel.pw], canon[0].dtype, cpw, g.pw, base);
                 if (!with_pw) { g.pw = g.p[0]; g.pw.gbase = 0; g.pw.gcount = 0; }
@@ -1191,7 +1191,7 @@ int step_conv_group_kernel_name(const step_conv_item* items, int n, char* buf, i
     long long base = 0;
     for (int k = 0; k < sel.ntap; ++k) base += (pls[k].mtiles * ceil_div(ps[k].nblk32, 2 * NBc) + 7) / 8 * 8;
     bool with_pw = false;
-    if (sel.pw >= 0 && pls[0].twl == 0 && base <= opt(STEP_OPT_CONV_GROUP_PW)) {
+    if (sel.pw >= 0 && pls[0].twl == 0 && base <= opt(STEP_OPT_CONV_GROUP_PW) && opt(STEP_OPT_THROUGHPUT) == 0) {
         step_conv_desc cpw;
         ConvParams ppw;
         with_pw = conv_group_pw_params(items[sel.pw], canon[0].dtype, cpw, ppw, base);
@@ -1242,7 +1242,7 @@ int step_conv_plan_info(const step_conv_desc* d, int* info, int n) {
 __attribute__((visibility("default"))) void step_probe_set(void* buf) { step::g_probe_buf = (unsigned long long*)buf; }
 #endif
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 31; }
+int step_abi_version(void) { return 32; }
 
 }  // extern "C"
 

@@ -1753,7 +1753,7 @@ def case_conv_group_with_pointwise_member(bk, golden):
         te, pe = bk.dev(encode(cl(t), dt)), bk.dev(encode(cl(pl), dt))
         ctot = 8 + co0 + co1 + cop + 8
         outs = {}
-        for mode in ("group", "group_nopw", "separate"):
+        for mode in ("group", "group_nopw", "group_throughput", "separate"):
             yb = bk.dev(np.zeros((N, D, H, W, ctot), NP_DT[dt]))
             keep, items = [], (_capi.ConvItem * 3)()
             specs = ((ci0, co0, 3, te, ci0 + ci1, 0, 8), (ci1, co1, 3, te, ci0 + ci1, ci0, 8 + co0), (cp, cop, 1, pe, cp, 0, 8 + co0 + co1))
@@ -1774,13 +1774,15 @@ def case_conv_group_with_pointwise_member(bk, golden):
                     it = items[slot]
                     assert bk.lib.step_conv_forward(it.desc, it.x, it.w_packed, it.scale, it.shift, None, it.y, None, bk.stream) == 0
             else:
-                with _capi.options(bk.lib, conv_group_pw=256 if mode == "group" else 0):
+                # (the `throughput` profile -- several batches in flight -- launches the pointwise member on its own as conv_group_pw = 0 does)
+                with _capi.options(bk.lib, **(dict(throughput=1) if mode == "group_throughput" else dict(conv_group_pw=256 if mode == "group" else 0))):
                     assert bk.lib.step_conv_group_kernel_name(items, 3, buf, 256) == 0
                     assert (b"conv_tap_group_pw_kernel" in buf.value) == (mode == "group" and rides), (mode, buf.value)
                     assert b"conv_tap_group" in buf.value
                     assert bk.lib.step_conv_forward_group(items, 3, bk.stream) == 0
             outs[mode] = yb.get()
         assert np.array_equal(outs["group"], outs["separate"]) and np.array_equal(outs["group_nopw"], outs["separate"]), (dt, cp, cop)
+        assert np.array_equal(outs["group_throughput"], outs["separate"]), (dt, cp, cop)
         y = decode(outs["group"], dt)
         assert not y[..., :8].any() and not y[..., ctot - 8:].any()
         ref = ref_conv(pl, ws[2], aff[2][0], aff[2][1], dt)
