@@ -221,6 +221,15 @@ class C4TrainStep:
         gc.collect()                                             # (torch.cuda.graph collects too: dead nets must not drop out of the re-pack table mid-capture)
         self._warm(warmup)
         dev = self.x.device
+        if grouped and backend == "nccl":
+            # The process group's watchdog thread polls the completion events of the collectives the warm-up steps issued (every ~100 ms).
+            # If it still holds some when the capture begins, it queries them while the group's internal stream is capturing -- HIP answers
+            # hipErrorCapturedEvent and the watchdog takes the process down (seen once in four runs of `bench.py --config c4 --force-exchange`).
+            # Let it finish its list first: everything is complete after the synchronize, a few polling intervals empty the list.
+            import os
+            import time
+            torch.cuda.synchronize(dev)
+            time.sleep(float(os.environ.get("STEP_PG_DRAIN_S", "1.0")))
         # with a live process group its watchdog / heartbeat threads may touch the runtime while this thread records: only THIS thread's
         # calls are checked against the capture
         kw = {"capture_error_mode": "thread_local"} if grouped else {}
