@@ -45,6 +45,7 @@ struct ConvParams {
     // step_conv_forward_pre_pool (conv_tap_pre_pool_kernel): a (1,3,3) / (1,2,2) max pool taken on the tile; y is then the pooled tensor
     // [N, D, Hp, Wp, C]; pool_row / pool_col receive the tiles' first rows / columns for pool_seam_fix_kernel (null: no pooling)
     void* pool_row; void* pool_col; int Hp, Wp;
+    int pool_p2;   // the launch was planned with general boxes off (the 4 x 8 x 8 tile although the planner alone would take a box)
 #ifdef STEP_PROBE
     unsigned long long* probe;   // tools/timeline_probe.py build only: 16 timestamp / id slots per workgroup (see probe_mark)
 #endif

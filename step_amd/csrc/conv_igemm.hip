@@ -440,7 +440,7 @@ static int gen_gmode(int td, int th, int tw, int tile_px) {
     return td * th * spr <= tile_px / 16 ? 1 : 0;
 }
 
-static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true, int force_waves = 0) {
+static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true, int force_waves = 0, bool no_gen = false) {
     ConvPlan pl;
     pl.ok = true; pl.wide = false; pl.tiles_h = pl.tiles_w = 0; pl.impl = 0; pl.tps = 1; pl.mb = 2; pl.wv = 8; pl.ph = 0; pl.deep = false; pl.twl = 4; pl.tiles_d = d->D; pl.gtd = pl.gth = pl.gtw = 1; pl.gmode = 0; pl.ksplit = 0; pl.kchunk16 = 0; pl.mbk = 0; pl.mpad = 0; pl.cpad = 0;
     const int nblk32 = ceil_div(d->Cout, 32);
@@ -534,7 +534,7 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true, int fo
     // 12.5 % fewer tiles) +1.2 % clips/s, the 400x400 backbone (50x50 / 25x25 / 100x100 maps, 28 % fewer tiles) +9 %.
     // STEP_OPT_CONV_GEN = <percent> moves the threshold, 0 disables the general boxes.
     int gtd = 1, gth = 1, gtw = 1;
-    const int gen_pct = opt(STEP_OPT_CONV_GEN);
+    const int gen_pct = no_gen ? 0 : opt(STEP_OPT_CONV_GEN);    // (no_gen: the caller wants a power-of-two tile -- the pooled epilogue of step_conv_forward_pre_pool)
     const int twl_p2 = twl;
     const long long tbest_p2 = tbest;
     if (gen_pct > 0) {
@@ -649,7 +649,7 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_
     constexpr int VEC = elem<T>::VEC;
     if (d->Cin % VEC || d->x_cstride % VEC || d->x_coff % VEC) return STEP_E_ALIGN;
     if (((uintptr_t)p.x % 16) || ((uintptr_t)p.w % 16)) return STEP_E_ALIGN;
-    ConvPlan pl = conv_plan(d);
+    ConvPlan pl = conv_plan(d, true, 0, p.pool_row != nullptr && p.pool_p2);
     if (!pl.ok) return STEP_E_UNSUPPORTED;
     if (pl.impl == 3) {
         const size_t need = (size_t)pl.ksplit * pl.mpad * pl.cpad * sizeof(float);
@@ -825,7 +825,7 @@ static int conv_fill_params(const step_conv_desc* d, const void* x, const void* 
                 (!split || ((split % 8 == 0) && (d->y2_cstride % 8 == 0) && (d->y2_coff % 8 == 0) && (((uintptr_t)y2) % 16 == 0)));
     p.nblk32 = ceil_div(d->Cout, 32);
     p.pre_w = nullptr; p.pre_scale = nullptr; p.pre_shift = nullptr;
-    p.pool_row = nullptr; p.pool_col = nullptr; p.Hp = p.Wp = 0;
+    p.pool_row = nullptr; p.pool_col = nullptr; p.Hp = p.Wp = 0; p.pool_p2 = 0;
     p.mag_hhw = p.mag_hw = 0;
     p.Mtot = (long long)d->N * d->D * d->H * d->W;
 #ifdef STEP_PROBE
@@ -963,20 +963,29 @@ extern "C" {
 
 // supported: what step_conv_forward_pre takes, planned onto the 4-plane 8x8 tile (maps whose sides the planner tiles by 8: 56 x 56 at C2),
 // ReLU on (the pooled epilogue orders 16-bit patterns as integers: values must be >= +0), 16-byte output vectors, no residual
-static bool conv_pre_pool_plan(const step_conv_desc* d, step_conv_desc& canon, ConvPlan& pl) {
+static bool conv_pre_pool_plan(const step_conv_desc* d, step_conv_desc& canon, ConvPlan& pl, bool& p2) {
     if (!d || d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0) return false;
     canon = canonical_desc(d);
     if (canon.Cin != 64 || canon.dtype == STEP_F32 || canon.split || !(canon.kd == 3 && canon.kh == 3 && canon.kw == 3) || !canon.relu) return false;
     if (canon.Cout % 8 || canon.y_cstride % 8 || canon.y_coff % 8) return false;
     if ((unsigned long long)canon.N * canon.D * canon.H * canon.W * (unsigned long long)canon.x_cstride >= 0xffffffffULL) return false;
     pl = conv_plan(&canon);
-    return pl.ok && pl.impl == 1 && pl.ph == 1 && pl.wv == 8 && pl.tps == 2 && pl.twl == 3;
+    p2 = false;
+    if (pl.ok && pl.impl == 1 && pl.ph == 1 && pl.wv == 8 && pl.tps == 2 && pl.twl == 3) return true;
+    // The planner prefers a general box (e.g. the 100 x 100 x 18-plane maps of AVA clips: 720 boxes of 2 x 5 x 25 against 845 tiles of
+    // 4 x 8 x 8).  With the pool riding in the epilogue the 4 x 8 x 8 tiling wins all the same: measured at that shape, 4 clips, bf16
+    // (tools/prepool_ab.py): general box + stand-alone pool 570.6 us, 4 x 8 x 8 + stand-alone pool 599.1, 4 x 8 x 8 fused 521.2.  Taken
+    // when it needs at most 25 % more tiles than the planner's own choice.
+    const ConvPlan q = conv_plan(&canon, true, 0, true);
+    if (pl.ok && q.ok && q.impl == 1 && q.ph == 1 && q.wv == 8 && q.tps == 2 && q.twl == 3 && q.mtiles * 4 <= pl.mtiles * 5) { pl = q; p2 = true; return true; }
+    return false;
 }
 
 size_t step_conv_pre_pool_workspace_bytes(const step_conv_desc* d) {
     step_conv_desc canon;
     ConvPlan pl;
-    if (!conv_pre_pool_plan(d, canon, pl)) return 0;
+    bool p2;
+    if (!conv_pre_pool_plan(d, canon, pl, p2)) return 0;
     const size_t planes = (size_t)canon.N * canon.D;
     return planes * ((size_t)pl.tiles_h * canon.W + (size_t)pl.tiles_w * canon.H) * canon.Cout * 2;
 }
@@ -994,7 +1003,9 @@ static int conv_forward_pre_pool_impl(const step_conv_desc* d, const void* x, co
     if (conv && !pre_w_packed) return STEP_E_NULL;
     if (p.N == 0) return STEP_OK;
     ConvPlan pl;
-    if ((conv && pre_cin != 64) || !conv_pre_pool_plan(d, canon, pl) || !p.vec_epi) return STEP_E_UNSUPPORTED;
+    bool p2 = false;
+    if ((conv && pre_cin != 64) || !conv_pre_pool_plan(d, canon, pl, p2) || !p.vec_epi) return STEP_E_UNSUPPORTED;
+    p.pool_p2 = p2 ? 1 : 0;
     if (conv && (((uintptr_t)pre_w_packed % 16) || (pre_scale && ((uintptr_t)pre_scale % 16)) || (pre_shift && ((uintptr_t)pre_shift % 16)))) return STEP_E_ALIGN;
     const size_t need = step_conv_pre_pool_workspace_bytes(d);
     if (!ws || ws_bytes < need || ((uintptr_t)ws % 16)) return STEP_E_SHAPE;

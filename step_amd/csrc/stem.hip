@@ -902,7 +902,7 @@ int step_stem_kernel_name(int dtype, char* buf, int buflen) {
     const char* t = dtype == STEP_F32 ? "float" : (dtype == STEP_BF16 ? "step::bf16_t" : "step::f16_t");
     if (dtype != STEP_F32 && dtype != STEP_BF16 && dtype != STEP_F16) return STEP_E_DTYPE;
     if (dtype == STEP_F32 || ov == 0) snprintf(buf, (size_t)buflen, "void step::stem_igemm_kernel<%s, 2>(step::StemParams)", t);
-    else snprintf(buf, (size_t)buflen, "void step::stem_stream_kernel<%s, 2, true>(step::StemParams)", t);
+    else snprintf(buf, (size_t)buflen, "void step::stem_stream_kernel<%s, 2, true, false, false>(step::StemParams)", t);
     return STEP_OK;
 }
 

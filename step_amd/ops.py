@@ -618,7 +618,7 @@ def stem_pool_forward(x, w_packed, Cout, scale, shift):
 
     def describe():
         pix = N * To * Ho * Wo
-        return ("void step::stem_stream_kernel<%s, 2, true, true>(step::StemParams)" % _TNAME[x.dtype], 2.0 * pix * Cout * 1029,
+        return ("void step::stem_stream_kernel<%s, 2, true, true, false>(step::StemParams)" % _TNAME[x.dtype], 2.0 * pix * Cout * 1029,
                 (x.numel() + out.numel() + Cout * 1029) * _ES[x.dtype])
 
     def launch():

@@ -2240,4 +2240,36 @@ def big_adam_full_size(bk, golden):
         assert float(G.abs().max()) == 0.0
 
 
-GPU_ONLY = ["big_conv_shapes", "big_stem", "big_roi", "big_nms", "big_wgrad_full_size_properties", "big_adam_full_size"]
+def big_pre_pool_ava(bk, golden):
+    """step_conv_forward_pre_pool at the AVA shape (100 x 100 x 18-plane maps): the planner alone takes a general box there, the pooled call
+    re-plans onto 4 x 8 x 8 tiles (845 against 720, within its 25 % allowance; tools/prepool_ab.py: 521 against 571 us) with partial tiles on
+    both sides (100 = 12.5 x 8) and a partial plane group (18 = 4.5 x 4) -- BIT-IDENTICAL to step_conv_forward_pre + step_maxpool3d_tf."""
+    rs = np.random.RandomState(63)
+    dt, (N, D, H, W), Cout = BF16, (2, 18, 100, 100), 192
+    info = (ctypes.c_int * 10)()
+    x = rs.randn(N, 64, D, H, W).astype(np.float32)
+    wa = (rs.randn(64, 64, 1, 1, 1) / 8).astype(np.float32)
+    wb = (rs.randn(Cout, 64, 3, 3, 3) / np.sqrt(64 * 27)).astype(np.float32)
+    sa, ha = (1 + 0.1 * rs.randn(64)).astype(np.float32), (0.2 * rs.randn(64)).astype(np.float32)
+    sb, hb = (1 + 0.1 * rs.randn(Cout)).astype(np.float32), (0.2 * rs.randn(Cout)).astype(np.float32)
+    xe = bk.dev(encode(cl(x), dt))
+    wpa, wpb = pack_weight(bk, wa, dt), pack_weight(bk, wb, dt)
+    dsa, dha, dsb, dhb = bk.dev(sa), bk.dev(ha), bk.dev(sb), bk.dev(hb)
+    Hp, Wp = bk.lib.step_pool_out_size(H, 3, 2), bk.lib.step_pool_out_size(W, 3, 2)
+    db = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=64, Cout=Cout, kd=3, kh=3, kw=3, x_cstride=64, x_coff=0, y_cstride=Cout, y_coff=0,
+                        res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+    assert bk.lib.step_conv_plan_info(ctypes.byref(db), info, 10) == 0 and info[1] == 0          # the planner's own choice: a general box
+    full = bk.dev(np.zeros((N, D, H, W, Cout), NP_DT[dt]))
+    assert bk.lib.step_conv_forward_pre(ctypes.byref(db), xe.ptr, wpb.ptr, dsb.ptr, dhb.ptr, wpa.ptr, dsa.ptr, dha.ptr, 64, full.ptr, bk.stream) == 0
+    want = bk.dev(np.zeros((N, D, Hp, Wp, Cout), NP_DT[dt]))
+    assert bk.lib.step_maxpool3d_tf(dt, full.ptr, N, D, H, W, Cout, Cout, 0, 1, 3, 3, 1, 2, 2, want.ptr, Cout, 0, bk.stream) == 0
+    nb = bk.lib.step_conv_pre_pool_workspace_bytes(ctypes.byref(db))
+    assert nb > 0
+    ws = bk.dev(np.full(nb // 2, 0x7f7f, np.uint16))
+    got = bk.dev(np.full((N, D, Hp, Wp, Cout), 3, NP_DT[dt]))
+    assert bk.lib.step_conv_forward_pre_pool(ctypes.byref(db), xe.ptr, wpb.ptr, dsb.ptr, dhb.ptr, wpa.ptr, dsa.ptr, dha.ptr, 64, got.ptr, ws.ptr, nb, bk.stream) == 0
+    g_, w_ = got.get(), want.get()
+    assert np.array_equal(g_, w_), int((g_ != w_).sum())
+
+
+GPU_ONLY = ["big_pre_pool_ava", "big_conv_shapes", "big_stem", "big_roi", "big_nms", "big_wgrad_full_size_properties", "big_adam_full_size"]

@@ -71,6 +71,27 @@ def test_planner_nb_rule(lib):
     assert name(lib, BF, 8, 128, 256, (3, 3, 3), 8, 14, 14)[0] == n4d0
 
 
+def test_planner_pooled_conv_replans_onto_tiles(lib):
+    """step_conv_forward_pre_pool exists where the map is (or may be) tiled 4 x 8 x 8: C2's 56 x 56 maps by the planner's own choice; the
+    100 x 100 x 18-plane maps of AVA clips by re-planning (the planner alone prefers 720 general boxes to 845 tiles: within the pooled call's
+    25 % allowance, and faster with the pool in the epilogue, tools/prepool_ab.py); not the 14 x 14 maps, not without ReLU, not fp32."""
+    BF = _capi.BF16
+
+    def desc(N, D, H, W, Cout=192, relu=1, dt=BF):
+        return _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=64, Cout=Cout, kd=3, kh=3, kw=3, x_cstride=64, x_coff=0, y_cstride=Cout, y_coff=0,
+                              res_cstride=0, res_coff=0, relu=relu, split=0, y2_cstride=0, y2_coff=0)
+    info = (ctypes.c_int * 10)()
+    d = desc(8, 16, 56, 56)
+    assert lib.step_conv_plan_info(ctypes.byref(d), info, 10) == 0 and info[1] == 3
+    assert lib.step_conv_pre_pool_workspace_bytes(ctypes.byref(d)) == 8 * 16 * (7 * 56 + 7 * 56) * 192 * 2
+    d = desc(4, 18, 100, 100)
+    assert lib.step_conv_plan_info(ctypes.byref(d), info, 10) == 0 and info[1] == 0 and info[9] == 4 * 720
+    assert lib.step_conv_pre_pool_workspace_bytes(ctypes.byref(d)) == 4 * 18 * (13 * 100 + 13 * 100) * 192 * 2
+    assert lib.step_conv_pre_pool_workspace_bytes(ctypes.byref(desc(8, 8, 14, 14))) == 0
+    assert lib.step_conv_pre_pool_workspace_bytes(ctypes.byref(desc(8, 16, 56, 56, relu=0))) == 0
+    assert lib.step_conv_pre_pool_workspace_bytes(ctypes.byref(desc(8, 16, 56, 56, dt=_capi.F32))) == 0
+
+
 def wgrad_name(L, dt, N, Cin, Cout, k, D, H, W, xcs=None):
     d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=k[0], kh=k[1], kw=k[2], x_cstride=xcs or Cin, x_coff=0, y_cstride=Cout,
                        y_coff=0, res_cstride=0, res_coff=0, relu=0, split=0, y2_cstride=0, y2_coff=0)
