@@ -132,3 +132,28 @@ def test_two_backbone_batches_in_flight_equal_one_at_a_time():
     torch.cuda.synchronize()
     for (s, graph, y), w in zip(flights, want):
         assert torch.equal(y, w)
+
+
+@pytest.mark.timeout(600)
+def test_bench_fed_loop_reports_both_forms():
+    """`bench.py --feed u8`: the contract line keeps the resident-input `value`; the `fed` block carries the fed rate (pinned host uint8 frames ->
+    copy stream -> the captured step), both forms of it (conversion pass | the stem staging uint8 itself), the copy-only link rate and the
+    named bottleneck; the multi-batch steps were captured under the library's throughput profile with identical bits (asserted in the run)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--feed", "u8", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--sustained-seconds", "0.3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=560, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["metric"] == "clips_per_sec_T32_224" and j["config"]["batches_in_flight"] == 2 and "throughput" in j["config"]["launch"]
+    f = j["fed"]
+    assert f["form"] in ("u8_stem", "convert") and f["forms"]["convert"] > 0 and f["forms"]["u8_stem"] > 0
+    assert f["value"] == max(f["forms"].values()) and 0.5 < f["fed_over_resident"] < 1.1
+    assert f["h2d_GBs_copy_only"] > 10 and f["bottleneck"] and "uint8" in f["wire_format"]
+    assert j["roofline"]["frac"] > 0 and j["sustained"]["value"] > 0
