@@ -154,6 +154,6 @@ def test_bench_fed_loop_reports_both_forms():
     assert j["metric"] == "clips_per_sec_T32_224" and j["config"]["batches_in_flight"] == 2 and "throughput" in j["config"]["launch"]
     f = j["fed"]
     assert f["form"] in ("u8_stem", "convert") and f["forms"]["convert"] > 0 and f["forms"]["u8_stem"] > 0
-    assert f["value"] == max(f["forms"].values()) and 0.5 < f["fed_over_resident"] < 1.1
+    assert f["value"] == max(f["forms"].values()) and 0.5 < f["fed_over_resident"] < 1.6          # (the 5-step resident window of this test is cold: the ratio is only sanity-checked)
     assert f["h2d_GBs_copy_only"] > 10 and f["bottleneck"] and "uint8" in f["wire_format"]
     assert j["roofline"]["frac"] > 0 and j["sustained"]["value"] > 0
