@@ -965,7 +965,9 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
                                     ({"one": "hipGraph replay (whole training step%s)" % (", the bucketed RCCL gradient all-reduces recorded in the graph" if getattr(w.reducer, "active", False) else ""),
                                       "split": "two hipGraphs (forward + backward | re-pack + Adam) around one eager flat gradient all-reduce"}[w.graph_mode]
                                      if getattr(w, "graph", None) is not None else "eager"),
-                          "gradient_exchange": ("bucketed all-reduce, %d buckets, %s" % (len(w.reducer.buckets), "one-rank RCCL group (forced)" if world == 1 else "%d ranks" % world))
+                          "gradient_exchange": (("one flat all-reduce of the gradient arena between the two graphs, %s" if getattr(w, "graph_mode", None) == "split" else
+                                                 "bucketed all-reduce, %d buckets, overlapped with backward, %%s" % len(w.reducer.buckets)) %
+                                                ("one-rank RCCL group (forced)" if world == 1 else "%d ranks" % world))
                                                if getattr(getattr(w, "reducer", None), "active", False) else None},
                "ranks": {"world_size": world, "backend": (dist.get_backend() + " (RCCL over xGMI)" if dist.get_backend() == "nccl" else dist.get_backend()) if dist is not None else None,
                          "devices_visible": torch.cuda.device_count()}}
