@@ -22,12 +22,19 @@ def main():
     def patched(members):
         if mode["v"] == "all":
             return orig(members)
-        keep = [m for m in members if not (tuple(m[3]) == (3, 3, 3) and m[0].shape[-1] <= 32 and (mode["v"] == "no_b2b" or m[0].shape[2] >= 28))]
+        small = [m for m in members if tuple(m[3]) == (3, 3, 3) and m[0].shape[-1] <= 32 and (mode["v"] != "no_b2b_28" and mode["v"] != "sep_b2b_28" or m[0].shape[2] >= 28)]
+        keep = [m for m in members if not any(m is s_ for s_ in small)]
+        if mode["v"].startswith("sep"):                        # the small-Cin members as launches of their own (their own plan: the two-workgroups-per-CU NB = 1 form)
+            for (x_, w_, co_, k_, sc_, sh_, relu_, out_) in small:
+                ops.conv_forward(x_, w_, co_, k_, sc_, sh_, relu_, None, out_)
+        if len(keep) == 1:
+            x_, w_, co_, k_, sc_, sh_, relu_, out_ = keep[0]
+            return ops.conv_forward(x_, w_, co_, k_, sc_, sh_, relu_, None, out_)
         return orig(keep) if keep else None
     ops.conv_forward_group = patched
     caps = {}
     with torch.no_grad():
-        for v in ("all", "no_b2b_28", "no_b2b"):
+        for v in ("all", "no_b2b_28", "sep_b2b_28", "sep_b2b"):
             mode["v"] = v
             gs = []
             for b in range(2):
