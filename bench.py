@@ -38,6 +38,7 @@ CONFIGS = {"c2": dict(clips=8, T=32, HW=224, dtype="bf16", gflop=109.29, act_mb=
            "c4": dict(clips=1, T=36, HW=400, dtype="f32", gflop=3 * (392.05 + 14.46), act_mb=2187.7, name="C4")}
 PEAK = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}          # dense MFMA TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+PROFILE_ROUND = "r06"                                           # the profiles/ files of the round this bench.py ships with
 # algorithmic work of BaseNet at C2 per clip: 109.29 GFLOP, 304.9 MB activations + 15.0 MB weights/batch
 GFLOP_PER_CLIP = 109.29
 ACT_MB_PER_CLIP, W_MB = 304.9, 15.0
@@ -299,6 +300,39 @@ class ClockSampler:
         return round(s_[len(s_) // 2], 3) if s_ else None
 
 
+class EffClock:
+    """Effective shader clock DURING a loop: step_clock_sample (one wavefront per workgroup that compares s_memtime with the 100 MHz
+    s_memrealtime over ~50 us of s_sleep) launched on a high-priority side stream every `every` steps of the loop it accompanies.
+    Unlike the DPM state the driver reports (ClockSampler), this is the clock the CUs really ran at while the loop's kernels
+    executed around the sampler wave.  median / p5 / p95 over all samples, GHz."""
+
+    def __init__(self, dev, slots=64, wgs=8, ticks=5000):
+        import ctypes
+        from step_amd import _capi, _lib
+        self.L, self._capi, self._lib, self.ct = _lib.lib(), _capi, _lib, ctypes
+        self.dev, self.slots, self.wgs, self.ticks = dev, slots, wgs, ticks
+        self.buf = torch.zeros(slots * wgs * 2, dtype=torch.int64, device=dev)
+        self.stream = torch.cuda.Stream(priority=-1)
+        self.n = 0
+
+    def sample(self):
+        if self.n >= self.slots:
+            return
+        off = self.n * self.wgs * 2 * 8
+        with torch.cuda.stream(self.stream):
+            self._capi.check(self.L.step_clock_sample(self.ct.c_void_p(self.buf.data_ptr() + off), self.wgs, self.ticks, self._lib.stream_ptr(self.dev)), "step_clock_sample")
+        self.n += 1
+
+    def result(self):
+        torch.cuda.synchronize()
+        h = self.buf.cpu().numpy().reshape(-1, 2)[: self.n * self.wgs].astype("float64")
+        ok = h[:, 1] > 0
+        if not ok.any():
+            return None
+        g = sorted(h[ok, 0] / (h[ok, 1] * 10.0))
+        return {"ghz_median": round(g[len(g) // 2], 3), "ghz_p5": round(g[len(g) // 20], 3), "ghz_p95": round(g[-1 - len(g) // 20], 3), "samples": len(g)}
+
+
 def sustained_mfma(dev):
     """What THIS box sustains with nothing but 16-bit matrix instructions on every CU (step_mfma_clock_probe, include/step_amd.h):
     MI355X is power-managed, so the clock under matrix load is well below the 2.4 GHz the datasheet peak assumes.  Reported beside
@@ -368,6 +402,7 @@ def roofline(net, x, dtype_name):
     n = len(plan)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     times = [0.0]
+    eff = EffClock(x.device, slots=max(n, 1))
     try:
         for k in range(1, n + 1):
             ops.PROFILE, ops.PROFILE_LIMIT = [], k
@@ -377,7 +412,9 @@ def roofline(net, x, dtype_name):
             g.replay()
             torch.cuda.synchronize()
             best = float("inf")
-            for _ in range(4):
+            for r_ in range(4):
+                if r_ == 3:
+                    eff.sample()                   # (beside the last round of this prefix's replays)
                 e0.record()
                 for _ in range(5):
                     g.replay()
@@ -446,11 +483,22 @@ def roofline(net, x, dtype_name):
     out["next_kernels"] = [{k_: v_ for k_, v_ in describe(n_, *a_).items() if k_ != "traffic_from"} for n_, a_ in ranked[1:3]]
     out["method"] = ("durations = differences of the best replay times of HIP graphs of growing prefixes of the step (each launch in its place of "
                      "the replayed sequence, no warm-up twin); 'dominant' = the kernel name with the largest summed time over the step")
-    out["profile"] = ("rocprofv3 --kernel-trace --stats of `bench.py --in-flight 1`: profiles/r04_c2_kernel_stats.txt (one batch at a time, as these "
-                      "durations); of the default command: profiles/r04_c2_kernel_stats_two_in_flight.txt -- there launches of the two batches in "
-                      "flight share the CUs, so a trace's per-launch durations are longer than the kernels' own cost while the step is shorter")
+    out["profile"] = ("rocprofv3 --kernel-trace --stats of `bench.py --in-flight 1`: profiles/%s_c2_kernel_stats.txt (one batch at a time, as these "
+                      "durations); of the default command: profiles/%s_c2_kernel_stats_two_in_flight.txt -- there launches of the two batches in "
+                      "flight share the CUs, so a trace's per-launch durations are longer than the kernels' own cost while the step is shorter" % (PROFILE_ROUND, PROFILE_ROUND))
+    out["clock_during_prefix_replays"] = eff.result()
     table = sorted(((n_, a[1] / 3, a[0] // 3, a[2] / max(a[1], 1e-9) / 1e9) for n_, a in agg.items()), key=lambda r: -r[1])   # TFLOP/s = flops / ms / 1e9
-    return out, table, total_ms / 3
+    # the step launch by launch, in launch order (the driver's record must be able to say WHICH launch is slow on its box)
+    seq = []
+    for name, flops, nbytes, t in rec:
+        short = name.split("(")[0].replace("step::", "")
+        row = {"kernel": short, "us": round(t * 1e3, 1)}
+        if flops / (PEAK[dtype_name] * 1e12) >= nbytes / (PEAK_HBM_GBS * 1e9):
+            row["tflops"] = round(flops / (t * 1e-3) / 1e12, 1)
+        else:
+            row["gbs"] = round(nbytes / (t * 1e-3) / 1e9, 1)
+        seq.append(row)
+    return out, table, total_ms / 3, seq
 
 
 def fed_loop(a, net, flights, x, dev, tdt, dist, resident_s_per_step):
@@ -589,6 +637,72 @@ def fed_loop(a, net, flights, x, dev, tdt, dist, resident_s_per_step):
                     "(copy k+%d waits for conversion k); %d batches in flight, each on a stream of its own" % (nfl, nfl, nfl)}
 
 
+def fp16_leg(a, net, x, dev, nfl, thr_profile):
+    """The C2 loop with fp16 storage: BASELINE names bf16, so bf16 stays the headline, but bf16 storage costs one
+    8-bit-mantissa rounding per layer (6.7e-3 against the oracle over the 45 layers at full size) while fp16 -- same MFMA rate, same
+    bytes -- is inside north_star's 1e-3 (tests/module_cases.py case_c2_full_size_properties asserts < 1e-3 against the oracle's full tensor).
+    Same captured-step loop as `value`: nfl batches in flight, ~0.5 s of the loop first, then the contract's K steps; and the same K steps one at a
+    time.  rel_err_vs_fp32 is measured here on the batch's own input: max |y16 - y32| / max |y32| against this library's fp32 path (itself
+    2e-6 from the oracle at this size)."""
+    from step_amd import _capi as _cp, _lib as _lb
+    x16 = x.to(torch.float16)
+    y32 = net(x.float())
+    y16 = net(x16)
+    torch.cuda.synchronize()
+    rel = float((y16.float() - y32).abs().max() / y32.abs().max())
+    relb = float((net(x).float() - y32).abs().max() / y32.abs().max())
+    del y32
+    g = torch.Generator(device="cpu").manual_seed(4242)
+    fl = []
+    with _cp.options(_lb.lib(), **({"throughput": 1} if thr_profile else {})):
+        for i in range(nfl):
+            xi = x16 if i == 0 else (torch.rand(x.shape, generator=g) * 2 - 1).to(dev).to(torch.float16)
+            si = torch.cuda.current_stream() if i == 0 else torch.cuda.Stream()
+            with torch.cuda.stream(si):
+                for _ in range(2):
+                    net(xi)
+                torch.cuda.synchronize()
+            gi = torch.cuda.CUDAGraph()
+            if i == 0:                                               # (captured on the capture's own side stream, replayed on the default stream)
+                with torch.cuda.graph(gi):
+                    yi = net(xi)
+            else:
+                with torch.cuda.stream(si), torch.cuda.graph(gi, stream=si):
+                    yi = net(xi)
+            fl.append((si, gi, xi, yi))
+    g1 = torch.cuda.CUDAGraph()                                    # default planner profile, one batch at a time
+    with torch.cuda.graph(g1):
+        y1 = net(x16)
+    torch.cuda.synchronize()
+
+    def loop(steps, n):
+        for k in range(steps):
+            if n == 1:
+                g1.replay()
+            else:
+                f = fl[k % n]
+                with torch.cuda.stream(f[0]):
+                    f[1].replay()
+
+    def timed(steps, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loop(steps, n)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    pilot = timed(10, nfl) / 10
+    timed(int(0.5 / max(pilot, 1e-5)) + 1, nfl)
+    el = timed(a.steps, nfl)
+    timed(int(0.3 / max(pilot, 1e-5)) + 1, 1)
+    el1 = timed(a.steps, 1)
+    n = x.shape[0]
+    return {"value": round(n * a.steps / el, 2), "unit": "clips/s", "ms_per_step": round(el / a.steps * 1e3, 4), "batches_in_flight": nfl,
+            "one_batch_in_flight": {"value": round(n * a.steps / el1, 2), "ms_per_step": round(el1 / a.steps * 1e3, 4)},
+            "rel_err_vs_fp32": float("%.3e" % rel), "bf16_rel_err_vs_fp32": float("%.3e" % relb),
+            "rel_err_vs_oracle": "asserted < 1e-3 on the oracle's full [1,8,832,14,14] tensor in tests/module_cases.py case_c2_full_size_properties (measured 9.3e-4; bf16 6.7e-3)",
+            "note": "the same loop as `value` with fp16 storage (fp32 accumulate): same MFMA rate and bytes as bf16, inside north_star's 1e-3; bf16 stays the headline because BASELINE names it"}
+
+
 def spawn_ranks(n):
     import socket
     import subprocess
@@ -630,6 +744,7 @@ def main():
                          "captured step, double-buffered against the batches in flight; reported under 'fed' (value stays the resident-input loop)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="tuning aid: a planner option of the library (include/step_amd.h step_set_option), e.g. conv_group_pw=0; repeatable")
+    ap.add_argument("--no-fp16-leg", action="store_true", help="c2: skip the fp16 leg (the same loop with fp16 storage, reported under 'fp16')")
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
     global CLIPS_PER_GPU, T_IN, HW_IN, GFLOP_PER_CLIP, ACT_MB_PER_CLIP
@@ -660,6 +775,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("STEP_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only for the shared-GPU test
         if backend == "nccl":
+            from step_amd import dist as _sd
+            _sd.enable_flight_recorder()                         # (C4TrainStep.capture's deterministic watchdog drain reads it)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
@@ -670,6 +787,8 @@ def main():
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
         sk.close()
+        from step_amd import dist as _sd
+        _sd.enable_flight_recorder()
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
 
     tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
@@ -691,6 +810,7 @@ def main():
         torch.cuda.synchronize()
         assert tuple(y.shape) == (CLIPS_PER_GPU, T_IN // 4, 832, -(-HW_IN // 16), -(-HW_IN // 16)) and bool(torch.isfinite(y.float()).all())
         graph = None
+        thr_profile = False
         flights = []                                             # (stream, graph) per batch in flight
         if not a.no_graph:
             s = torch.cuda.Stream()
@@ -746,9 +866,13 @@ def main():
                 torch.cuda.synchronize()
                 assert torch.equal(y, flights[0][3]), "the throughput profile changed the result"
 
+        _timed_hook = [None]
+
         def timed(nfl):
             """W warm-up steps, then K steps between barrier + synchronize on both sides; nfl batches in flight (round-robin)."""
             def step(k):
+                if _timed_hook[0] is not None:
+                    _timed_hook[0](k)
                 if graph is None:
                     net(x)
                 elif nfl == 1:
@@ -788,13 +912,32 @@ def main():
                 dist.all_reduce(tp, op=dist.ReduceOp.MAX)
                 pilot = float(tp.item())
             a.steps, a.warmup = max(keep_steps, int(a.sustained_seconds * 1.1 / pilot) + 1), 0
+            ec_s = EffClock(dev)
+            every_s = max(1, a.steps // ec_s.slots)
+            _timed_hook[0] = lambda k: ec_s.sample() if k % every_s == 0 else None
             with ClockSampler(local_dev) as cs:
                 el_s = timed(nfl)
-            sus = (a.steps, el_s, cs.median(), len(cs.samples), cs.smi_median(), len(cs.smi_samples))
+            _timed_hook[0] = None
+            sus = (a.steps, el_s, cs.median(), len(cs.samples), cs.smi_median(), len(cs.smi_samples), ec_s.result())
             a.steps, a.warmup = keep_steps, keep_warm
         el = timed(nfl)
+        # the one-batch-at-a-time window: first ~0.5 s of that loop (the DPM state after two batches in flight is not the state a
+        # one-batch loop settles in; the driver's round-5 box read 1.45 ms here against 1.23 ms on every other box),
+        # with the EFFECTIVE clock sampled beside it, then the same K steps
+        one_clock = None
+        if nfl > 1:
+            keep_steps, keep_warm = a.steps, a.warmup
+            a.steps, a.warmup = max(keep_steps, int(0.5 / max(el / keep_steps, 1e-5)) + 1), 0
+            ec = EffClock(dev)
+            every = max(1, a.steps // ec.slots)
+            _timed_hook[0] = lambda k: ec.sample() if k % every == 0 else None
+            timed(1)
+            _timed_hook[0] = None
+            one_clock = ec.result()
+            a.steps, a.warmup = keep_steps, keep_warm
         el_one = timed(1) if nfl > 1 else el                   # the same K steps one batch at a time (reported beside the headline)
         fed = fed_loop(a, net, flights, x, dev, tdt, dist, el / a.steps) if (a.feed == "u8" and graph is not None) else None
+        fp16 = fp16_leg(a, net, x, dev, nfl, thr_profile) if (a.config == "c2" and a.dtype == "bf16" and graph is not None and world == 1 and not a.no_fp16_leg) else None
     if dist is not None:
         t = torch.tensor([el, el_one, sus[1] if sus else 0.0], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -816,14 +959,17 @@ def main():
                                                                     "hipGraph replay, %d batches in flight (one captured step per batch, %d HIP streams, round-robin%s)" % (
                                                                         nfl, nfl, "; steps captured under the library's `throughput` planner profile, bit-identical to the default" if thr_profile else "")),
                           "batches_in_flight": nfl},
-               "one_batch_in_flight": {"value": round(clips / el_one, 2), "ms_per_step": round(el_one / a.steps * 1e3, 4),
-                                       "note": "the same K steps replayed one after the other on one stream (the loop of rounds 1-2)"},
+               "one_batch_in_flight": {"value": round(clips / el_one, 2), "ms_per_step": round(el_one / a.steps * 1e3, 4), "clock_effective": one_clock,
+                                       "note": "the same K steps replayed one after the other on one stream (the loop of rounds 1-2), after ~0.5 s of that same loop; "
+                                               "clock_effective = step_clock_sample beside that 0.5 s loop (s_memtime / s_memrealtime, GHz)"},
+               "planner_profile": {"value": "throughput" if thr_profile else "default", "one_batch_in_flight": "default", "roofline": "default",
+                                   "note": "planner option `throughput` (include/step_amd.h) under which the steps of each loop were captured; results bit-identical (asserted in this run)"},
                "ranks": {"world_size": world, "backend": (dist.get_backend() + " (RCCL over xGMI)" if dist.get_backend() == "nccl" else dist.get_backend()) if dist is not None else None,
                          "devices_visible": ndev}}
         if sus:
             out["sustained"] = {"seconds": round(sus[1], 3), "steps": sus[0], "value": round(world * CLIPS_PER_GPU * sus[0] / sus[1], 2),
                                 "ms_per_step": round(sus[1] / sus[0] * 1e3, 4), "clock_ghz": sus[4] if sus[4] else sus[2], "clock_samples": sus[5] if sus[4] else sus[3],
-                                "clock_ghz_sysfs": sus[2], "clock_ghz_amd_smi": sus[4],
+                                "clock_ghz_sysfs": sus[2], "clock_ghz_amd_smi": sus[4], "clock_effective": sus[6],
                                 "note": "the same loop (same captured steps, same batches in flight) run for >= %.1f s right BEFORE the timed K steps (it also settles the DPM state the contract window then starts from); "
                                         "clock_ghz = median gfx clock during it AS THE DRIVER REPORTS IT (`amd-smi metric --clock`, polled back to back; failing "
                                         "that the amdgpu sysfs node) -- the DPM state, not the effective clock: inside these kernels s_memtime / s_memrealtime "
@@ -831,6 +977,8 @@ def main():
                                         "null: not exposed on this box; `value` / `ms_per_step` above stay on the contract's K steps" % a.sustained_seconds}
         if fed is not None:
             out["fed"] = fed
+        if fp16 is not None:
+            out["fp16"] = fp16
         per_gpu = val / world
         out["backbone_roofline"] = {
             "hbm_frac": round(per_gpu * (ACT_MB_PER_CLIP + W_MB / CLIPS_PER_GPU) * 1e6 / (PEAK_HBM_GBS * 1e9), 4),
@@ -840,8 +988,12 @@ def main():
     # roofline of the dominant kernel (every rank could, rank 0 reports)
     if rank == 0:
         with torch.no_grad():
-            rl, table, gpu_ms = roofline(net, x, a.dtype)
+            rl, table, gpu_ms, seq = roofline(net, x, a.dtype)
         out["roofline"] = rl
+        out["kernel_table"] = seq
+        out["clock_ghz"] = {"two_in_flight_sustained": (out.get("sustained") or {}).get("clock_effective"), "one_batch_loop": one_clock,
+                            "prefix_graph_replays": rl.pop("clock_during_prefix_replays", None),
+                            "note": "EFFECTIVE shader clock (step_clock_sample: s_memtime / s_memrealtime of a sampler wave beside the loop), not the DPM state"}
         if a.dtype != "f32":
             sm = sustained_mfma(dev)
             if sm:

@@ -63,6 +63,12 @@ STEP_API int step_abi_version(void);
  * boxes this was developed on settle at ~1.9 GHz = ~2.0 PFLOP/s, not the 2.4 GHz / 2.5 PFLOP/s of the datasheet roofline. */
 STEP_API int step_mfma_clock_probe(unsigned long long* out, int workgroups, int iters, step_stream_t stream);
 
+/* Diagnostic (bench.py): the EFFECTIVE shader clock while other work runs.  `workgroups` single-wavefront workgroups each read the shader
+ * cycle counter and the 100 MHz real-time counter, sleep (s_sleep, no memory traffic) until `ticks_100mhz` ticks have passed and read both
+ * again: out[2 * wg + {0, 1}] = shader cycles, 100 MHz ticks; cycles / (ticks * 10) = GHz.  Launched on a side stream beside a loop it
+ * takes one wave slot; the driver's DPM state (sysfs / amd-smi) is NOT this number. */
+STEP_API int step_clock_sample(unsigned long long* out, int workgroups, int ticks_100mhz, step_stream_t stream);
+
 /* The other measured ceiling: a plain streaming copy of `bytes` (multiple of 16; src, dst 16-byte aligned, not overlapping) by
  * `workgroups` 256-thread workgroups, 16 B per lane, grid-stride.  2 * bytes / its duration on buffers well beyond the 256 MB
  * last-level cache is the HBM rate one launch reaches on this box -- what the pools / pointwise convs / ROIAlign are read against
@@ -97,6 +103,9 @@ enum {
     STEP_OPT_THROUGHPUT,       /*  0 (default): launch shapes tuned for the LATENCY of one batch | 1: for several independent batches in flight on separate streams (a serving loop) --
                                     a block's pointwise conv is launched on its own instead of riding in the 3x3x3 members' grid (the other batch fills the idle CUs; measured
                                     C2 +1.3 % at two in flight, -2.2 % one batch at a time).  Same bits either way */
+    STEP_OPT_CONV_PERSIST,     /*  1 (default): one-channel-group conv_tap launches of more than one round of the chip run as a PERSISTENT tile loop, one workgroup per CU
+                                    (no relaunch gap, the weight ring never drains, the next tile's halo is requested before the current tile's epilogue) where the
+                                    library has that form (the fused conv3d_2b -> conv3d_2c -> maxPool3d_3a call) | 0: one workgroup per tile (bit-identical) */
     STEP_OPT_COUNT_
 };
 STEP_API int step_set_option(int option, int value);
@@ -366,6 +375,10 @@ STEP_API int step_conv_kernel_name(const step_conv_desc* d, char* buf, int bufle
  * workgroup, two-phase form, the general box (planes, rows, columns), its pixel assignment mode (1 = every 16-lane LDS read group is
  * one run of 16 columns of one box row), pixel tiles.  n >= 10. */
 STEP_API int step_conv_plan_info(const step_conv_desc* d, int* info, int n);
+/* ... and the plan step_conv_forward_pre_pool REALLY uses for d (it re-plans a general-box layer onto the 4 x 8 x 8 tiles when those are
+ * at most 25 % more): info[0..9] as above, info[10..11] = tile rows / tile columns per plane (what the seam pass walks).  n >= 12;
+ * STEP_E_UNSUPPORTED where the fused call has no form for d. */
+STEP_API int step_conv_pre_pool_plan_info(const step_conv_desc* d, int* info, int n);
 
 /* The I3D stem: 7x7x7 stride-2 conv, Cin = 3, TF-SAME padding (2 front, 3 back) + BN + ReLU
  * (models/i3dpt.py:186-191) reading the clip in the reference's own input layout

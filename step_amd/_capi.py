@@ -5,7 +5,7 @@ import ctypes as C
 F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
 ROI_BWD_GATHER, ROI_BWD_ATOMIC = 0, 1
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 vp, fp, ip, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # raw device addresses
 i, f, ll, sz = C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -52,6 +52,7 @@ SIGNATURES = {
     "step_roi_pool_backward": (i, [fp, ip, i, fp, i, i, i, i, i, i, i, fp, vp]),
     "step_mfma_clock_probe": (i, [vp, i, i, vp]),
     "step_hbm_stream_probe": (i, [vp, vp, sz, i, vp]),
+    "step_clock_sample": (i, [vp, i, i, vp]),
     "step_nms_scratch_bytes": (sz, [i, i]),
     "step_nms_batched": (i, [fp, fp, ip, i, i, f, u8p, vp, vp]),
     "step_nms_batched_f64": (i, [fp, fp, ip, i, i, f, u8p, vp, vp]),
@@ -82,6 +83,7 @@ SIGNATURES = {
     "step_conv_forward_ws": (i, [C.POINTER(ConvDesc), vp, vp, fp, fp, vp, vp, vp, vp, sz, vp]),
     "step_conv_kernel_name": (i, [C.POINTER(ConvDesc), C.c_char_p, i]),
     "step_conv_plan_info": (i, [C.POINTER(ConvDesc), C.POINTER(C.c_int), i]),
+    "step_conv_pre_pool_plan_info": (i, [C.POINTER(ConvDesc), C.POINTER(C.c_int), i]),
     "step_stem_packed_elems": (sz, [i]),
     "step_stem_pack_weight": (i, [fp, i, i, vp, vp]),
     "step_stem_forward": (i, [i, vp, i, i, i, i, vp, fp, fp, i, i, vp, i, i, vp]),
@@ -140,7 +142,7 @@ def check(status, what):
 # ---- planner options (include/step_amd.h: step_set_option) -----------------------------------------------------------
 OPTION_IDS = {name: k for k, name in enumerate((
     "conv_impl", "conv_nb", "conv_waves", "conv_phased", "conv_gen", "conv_gmode", "conv_pws", "conv_splitk", "conv_tail",
-    "conv_slots", "pool_direct", "wgrad_minpix", "wgrad16_lds", "conv_group_pw", "clip_vec", "conv_nb_rule", "throughput"))}
+    "conv_slots", "pool_direct", "wgrad_minpix", "wgrad16_lds", "conv_group_pw", "clip_vec", "conv_nb_rule", "throughput", "conv_persist"))}
 
 
 def set_option(lib, name, value):

@@ -943,8 +943,13 @@ class wgrad_into_grad:
         WGRAD_INTO_GRAD = self.prev
         if exc and exc[0] is not None:
             # backward raised mid-way: the queued partial sums describe a gradient nobody will use -- drop them instead of adding them
-            # to the arena at the next flush (their workspaces die with the list); the side stream is still joined
+            # to the arena at the next flush (their workspaces die with the list); the side stream is still joined.  The gradients of
+            # this step are UNDEFINED after a failed backward (some weight gradients are in the arena, the dropped ones are not): the
+            # announcement hooks are cleared so that a BucketedReducer armed for this step does not wait for parameters that will never
+            # report (its next begin() re-arms it), and the caller must zero the arena (opt.zero_grad()) before the next backward.
+            global GRAD_READY, GRAD_DEFER
             del _PEND_Q[:]
+            GRAD_READY = GRAD_DEFER = None
         wgrad_sync()
         return False
 

@@ -31,6 +31,7 @@ struct ConvParams {
     int gbase, gcount;   // this problem's workgroups are blockIdx.x in [gbase, gbase + gcount) (gcount % 8 == 0 when remapped): the whole grid, or one
                          // member's share of a grouped launch (step_conv_forward_group)
     int tile0;           // conv_tap_kernel: first pixel tile of this launch (a layer may be launched in two parts, see conv_forward_t)
+    int gpersist;        // > 0: launch the PERSISTENT form with this many workgroups (each walks virtual ids id, id + gpersist, ... < gcount); 0: one workgroup per id
     int nchunks;   // ceil(Cin / 32)
     int nchunks32; // same (the packed-weight K extent is 2*nchunks32 k16 blocks)
     int vec_epi;   // 16-byte output stores are legal (channel strides/offsets % 8 == 0, pointers 16-B aligned)
@@ -98,13 +99,16 @@ __device__ __forceinline__ void probe_ids(unsigned long long* probe) {
 // 3c fused 1x1x1: FETCH 178 MB against 51 MB of input, three channel groups).  The grid is therefore 1-D, padded to
 // a multiple of 8, and remapped: ids that are consecutive on one XCD walk the channel groups of a tile first, then
 // the neighbouring tiles.  Returns false for the padding workgroups (they exit before any barrier).
-__device__ __forceinline__ bool grid_coords(const ConvParams& p, int& bx, int& by) {
-    const unsigned id = blockIdx.x - (unsigned)p.gbase, G = (unsigned)p.gcount;
+__device__ __forceinline__ bool grid_coords_of(const ConvParams& p, unsigned id, int& bx, int& by) {      // id in [0, p.gcount)
+    const unsigned G = (unsigned)p.gcount;
     const unsigned L = (G & 7) ? id : (id & 7) * (G >> 3) + (id >> 3);
     if (L >= (unsigned)p.gx * (unsigned)p.gy) return false;
     bx = (int)(L / (unsigned)p.gy);
     by = (int)(L % (unsigned)p.gy);
     return true;
+}
+__device__ __forceinline__ bool grid_coords(const ConvParams& p, int& bx, int& by) {
+    return grid_coords_of(p, blockIdx.x - (unsigned)p.gbase, bx, by);
 }
 
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})

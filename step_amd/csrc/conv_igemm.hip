@@ -664,6 +664,12 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_
         p.gx = (int)pl.mtiles; p.gy = groups;
         const long long tot = pl.mtiles * groups;
         p.gbase = 0; p.gcount = (int)((tot + 7) / 8 * 8);
+        // the persistent tile loop (conv_tap_kernel.h, PERSIST): one channel group, more than one round of the chip's one-per-CU slots --
+        // today the fused conv3d_2b -> 2c -> pool call (STEP_OPT_CONV_PERSIST = 0: one workgroup per tile; bit-identical)
+        p.gpersist = 0;
+        const long long slots_ = opt(STEP_OPT_CONV_SLOTS) > 0 ? opt(STEP_OPT_CONV_SLOTS) : 256;
+        if (opt(STEP_OPT_CONV_PERSIST) != 0 && groups == 1 && pl.impl == 1 && pl.ph == 1 && pl.NB == 3 && p.pre_w && p.pool_row && tot > slots_)
+            p.gpersist = (int)(slots_ / 8 * 8 > 0 ? slots_ / 8 * 8 : 8);
         return dim3((unsigned)p.gcount);
     };
     if (pl.impl == 4) {
@@ -694,6 +700,7 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_
             if (rc != STEP_OK) return rc;
             ConvPlan pt = pl;
             pt.NB = 1; pt.mtiles = tail;
+            p.gpersist = 0;
             p.tile0 = (int)(all - tail);
             p.gx = (int)tail; p.gy = tgroups;
             p.gcount = (int)((tail * tgroups + 7) / 8 * 8);
@@ -817,7 +824,7 @@ static int conv_fill_params(const step_conv_desc* d, const void* x, const void* 
     p.x_cstride = d->x_cstride; p.x_coff = d->x_coff; p.y_cstride = d->y_cstride; p.y_coff = d->y_coff;
     p.r_cstride = d->res_cstride; p.r_coff = d->res_coff;
     p.relu = d->relu;
-    p.tiles_h = p.tiles_w = 0; p.tiles_d = d->D; p.gtd = p.gth = p.gtw = 1; p.gmode = 0; p.gx = p.gy = 0; p.tile0 = 0; p.gbase = 0; p.gcount = 0;
+    p.tiles_h = p.tiles_w = 0; p.tiles_d = d->D; p.gtd = p.gth = p.gtw = 1; p.gmode = 0; p.gx = p.gy = 0; p.tile0 = 0; p.gbase = 0; p.gcount = 0; p.gpersist = 0;
     p.nchunks = ceil_div(d->Cin, CK);
     p.nchunks32 = p.nchunks;
     p.vec_epi = (d->y_cstride % 8 == 0) && (d->y_coff % 8 == 0) && (d->Cout % 8 == 0) && (((uintptr_t)y) % 16 == 0) &&
@@ -1249,11 +1256,23 @@ int step_conv_plan_info(const step_conv_desc* d, int* info, int n) {
     return STEP_OK;
 }
 
+int step_conv_pre_pool_plan_info(const step_conv_desc* d, int* info, int n) {
+    if (!d || !info || n < 12) return STEP_E_NULL;
+    step_conv_desc canon;
+    ConvPlan pl;
+    bool p2 = false;
+    if (!conv_pre_pool_plan(d, canon, pl, p2)) return STEP_E_UNSUPPORTED;
+    info[0] = pl.impl; info[1] = pl.twl; info[2] = pl.NB; info[3] = pl.wv; info[4] = pl.ph; info[5] = pl.gtd; info[6] = pl.gth; info[7] = pl.gtw;
+    info[8] = pl.gmode; info[9] = (int)(pl.mtiles > 0x7fffffff ? 0x7fffffff : pl.mtiles);
+    info[10] = pl.tiles_h; info[11] = pl.tiles_w;
+    return STEP_OK;
+}
+
 #ifdef STEP_PROBE
 __attribute__((visibility("default"))) void step_probe_set(void* buf) { step::g_probe_buf = (unsigned long long*)buf; }
 #endif
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 32; }
+int step_abi_version(void) { return 33; }
 
 }  // extern "C"
 

@@ -52,9 +52,22 @@ namespace step {
 // exactly the values the separate layer would have written to memory (same K order, same rounding), zeros outside the image.
 // The intermediate tensor never exists: -2 x 51 MB of traffic and one launch per C2 step for +3 % matrix work in this kernel.
 typedef short s16x8_pool __attribute__((ext_vector_type(8)));
+#define NTAPS_EVEN_STEPS(KD, KH, KW, TPS) (((taps_padded((KD) * (KH) * (KW)) / (TPS)) & 1) == 0)
 
-template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB, int WV, int PH = 0, bool GRP = false, bool PRE = false, bool POOL = false>
+// PERSIST (round 6; two-phase form, one channel group: p.gy == 1): the workgroup is a PERSISTENT tile loop -- the grid is p.gpersist workgroups
+// (one per CU) and workgroup w runs the virtual block ids w, w + gridDim.x, ... of the p.gcount ids the ordinary launch would have had (same
+// XCD-aware remap: consecutive tiles of one workgroup stay on its XCD's share of the map).  What the loop buys over one workgroup per tile:
+//   * no relaunch gap between a CU's tiles (measured 2.0 us of a 42 us conv3d_2c workgroup, tools/timeline_probe.py);
+//   * the weight ring never drains: the last three steps of a tile request the first three steps' weights of the next one (the same
+//     weights: one channel group), so a tile starts with ring buffer 0 filled and both register sets in flight -- the prologue's weight
+//     round trip (0.7-1.2 us) and the scale / shift fetch happen once per workgroup;
+//   * the next tile's halo is REQUESTED before the current tile's epilogue (index tables + global loads, raw pixels of the fused pointwise
+//     input for PRE) and lands while the epilogue's conversions, LDS passes and stores run; the fragment registers of the K loop are dead there.
+// The accumulation order of every output is unchanged: bit-identical to the one-tile-per-workgroup launch.
+template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB, int WV, int PH = 0, bool GRP = false, bool PRE = false, bool POOL = false, bool PERSIST = false>
 __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
+    static_assert(!PERSIST || (PH == 1 && !GRP && (NTAPS_EVEN_STEPS(KD, KH, KW, TPS))), "the persistent tile loop exists for the two-phase form with an even number of steps per slab");
+    static_assert(!(PERSIST && POOL) || PRE, "persistent + pooled epilogue: the pooled tile lives in halo + stash (PRE)");
     static_assert(!POOL || (TWL == 3 && WV == 8 && PH == 1 && !GRP && sizeof(T) == 2 && KD == 3), "the pooled epilogue exists for the 4-plane 8x8 tile of the two-phase 16-bit form");
     static_assert(MB == 2 && (WV == 8 || WV == 4), "two accumulator rows per wave; 8 or 4 waves");
     static_assert(!PRE || (PH == 1 && sizeof(T) == 2), "the fused pointwise input exists for the two-phase 16-bit form");
@@ -121,12 +134,15 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
     constexpr int STASH_BYTES = PRE ? NPIX_MAX * 64 : 0;                      // PRE: the second slab's 32 channels wait here (dense 64-byte pixels)
     constexpr int LDS_BYTES = NPIX_MAX * PITCH + BBYTES + SS_BYTES + STASH_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static_assert(!POOL || TPXM * (NBT * 64 + 16) <= NPIX_MAX * PITCH + BBYTES, "the pooled epilogue's tile lives in the halo / weight rings, below the scale table");
+    // layout: halo | weight rings | scale table | stash.  PERSIST: halo | stash | scale table | weight rings -- the pooled epilogue's tile then
+    // covers halo + stash only and the rings (which already hold the NEXT tile's first step) survive it
+    static_assert(!POOL || PERSIST || TPXM * (NBT * 64 + 16) <= NPIX_MAX * PITCH + BBYTES, "the pooled epilogue's tile lives in the halo / weight rings, below the scale table");
+    static_assert(!POOL || !PERSIST || TPXM * (NBT * 64 + 16) <= NPIX_MAX * PITCH + STASH_BYTES, "persistent form: the pooled tile lives in halo + stash");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     unsigned char* const ldsA = lds;
-    unsigned char* const ldsB = lds + NPIX_MAX * PITCH;
-    float* const ldsS = (float*)(lds + NPIX_MAX * PITCH + BBYTES);
-    unsigned char* const ldsP = lds + NPIX_MAX * PITCH + BBYTES + SS_BYTES;
+    unsigned char* const ldsB = lds + NPIX_MAX * PITCH + (PERSIST ? STASH_BYTES + SS_BYTES : 0);
+    float* const ldsS = (float*)(lds + NPIX_MAX * PITCH + (PERSIST ? STASH_BYTES : BBYTES));
+    unsigned char* const ldsP = lds + NPIX_MAX * PITCH + (PERSIST ? 0 : BBYTES + SS_BYTES);
     // tile pixel index m (accumulator row) -> box coordinates, and whether the row holds a pixel of the box at all.
     // General boxes, linear mode: rows past the box alias pixel 0.  General boxes, p.gmode = 1 (box widths just below a multiple
     // of 16: the 14- and 28-wide C2 maps, 13): the 16 lanes of every ds_read_b128 service group ({0-3,12-15,20-27} and
@@ -169,30 +185,57 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
         if (TWL == 3) return (((th & 3) == 1) || ((th & 3) == 2)) ? (j ^ 4) : j;
         return j;
     };
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    // (not const: the persistent tile loop re-derives them from an opaque copy of the thread index once per tile -- see relaunder())
+    int tid = threadIdx.x;
+    int lane = tid & 63;
 #ifdef STEP_EMUL
-    const int wave = tid >> 6;
+    int wave = tid >> 6;
 #else
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> scalar branches
+    int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> scalar branches
 #endif
-    const int khalf = lane >> 5;
-    const int wm = (PH == 2) ? (wave >> 1) : (wave % WM), wn = (PH == 2) ? (wave & 1) : (wave / WM);
+    int khalf = lane >> 5;
+    int wm = (PH == 2) ? (wave >> 1) : (wave % WM), wn = (PH == 2) ? (wave & 1) : (wave / WM);
+    // PERSIST: everything the epilogue and the halo staging derive from the thread index (LDS / global addresses, pixel tables, pooling
+    // item decode: ~150 values) is the same for every tile, so the compiler hoists it out of the tile loop and keeps it alive across the K
+    // loop, whose 222 VGPRs leave no room: 133 spilled registers, and every scratch reload is an s_waitcnt vmcnt(0) that also drains the
+    // halo requests in flight.  Passing the index through an empty asm statement once per tile makes those values per-tile values again
+    // (what a freshly launched workgroup computes anyway); the K loop's own tables (aoff, wthr, bwave) were derived before and stay put.
+    auto relaunder = [&]() {
+#ifndef STEP_EMUL
+        asm volatile("" : "+v"(tid));
+        asm volatile("" : "+s"(wave));
+#endif
+        lane = tid & 63; khalf = lane >> 5;
+        wm = (PH == 2) ? (wave >> 1) : (wave % WM); wn = (PH == 2) ? (wave & 1) : (wave / WM);
+    };
 
     int gbx, gby;
-    if (!grid_coords(p, gbx, gby)) return;
+    unsigned vid = blockIdx.x - (unsigned)p.gbase;          // PERSIST: the virtual block id this workgroup is working on
+    if constexpr (PERSIST) {
+        while (vid < (unsigned)p.gcount && !grid_coords_of(p, vid, gbx, gby)) vid += gridDim.x;     // (padding ids of the remapped grid)
+        if (vid >= (unsigned)p.gcount) return;
+    } else {
+        if (!grid_coords(p, gbx, gby)) return;
+    }
     // (Measured and removed: starting the first round's workgroups a pseudo-random 0..27 us apart -- to de-phase the CUs, whose
     // equal-length tiles bring every epilogue's store burst to the same moment -- only ADDS the delay: conv3d_2c 238.7 us ->
     // 242 / 240 / 243 / 248 / 270 us at 64 ... 1024 x 64 clocks of spread (gpurun_out/ab_desync.log, round 3).  The epilogues do
     // not contend with each other.)
     STEP_PROBE_IDS(p);
     STEP_PROBE_MARK(p, 0);
-    int t = gbx + p.tile0;
-    const int tw_i = t % p.tiles_w; t /= p.tiles_w;
-    const int th_i = t % p.tiles_h; t /= p.tiles_h;
-    const int d0 = (t % p.tiles_d) * TD;
-    const int n = t / p.tiles_d;
-    const int h0 = th_i * TH, w0 = tw_i * TW;
+    struct TileC { int tw_i, th_i, d0, n, h0, w0; };
+    auto tile_of = [&](int bx) {
+        TileC c;
+        int t = bx + p.tile0;
+        c.tw_i = t % p.tiles_w; t /= p.tiles_w;
+        c.th_i = t % p.tiles_h; t /= p.tiles_h;
+        c.d0 = (t % p.tiles_d) * TD;
+        c.n = t / p.tiles_d;
+        c.h0 = c.th_i * TH; c.w0 = c.tw_i * TW;
+        return c;
+    };
+    TileC tc = tile_of(gbx);                                 // the tile being computed (PERSIST: replaced at the end of the tile loop's body)
+    int tw_i = tc.tw_i, th_i = tc.th_i, d0 = tc.d0, n = tc.n, h0 = tc.h0, w0 = tc.w0;
     const int HHW = HH_ * HW_;
     const int nb0 = gby * NBT;
     const int KC16 = p.nchunks32 * 2;
@@ -225,7 +268,8 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
     // run-time box dimensions in the general-tile instantiation -- which used to be redone for every slab.
     // (32-bit offsets: the planner sends tensors of >= 2^32 elements to conv_igemm_kernel.)
     unsigned goff[ITER];
-    auto build_goff = [&]() {
+    auto build_goff = [&](const TileC& c) {
+    const int d0 = c.d0, h0 = c.h0, w0 = c.w0, n = c.n;
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int v = tid + it * NT;
@@ -246,7 +290,7 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
         }
     }
     };
-    if constexpr (PH == 0) build_goff();                   // (the two-phase form requests its first weights before this index work)
+    if constexpr (PH == 0) build_goff(tc);                 // (the two-phase form requests its first weights before this index work)
     // the tile's scale / shift: requested with the first loads, parked in LDS behind the halo stores (visible after the prologue's
     // barrier; read in the epilogue)
     float ss_sc = 1.f, ss_sh = 0.f;
@@ -260,8 +304,9 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
     auto ss_store = [&]() {
         if (TR && tid < NBT * 32) { ldsS[tid] = ss_sc; ldsS[NBT * 32 + tid] = ss_sh; }
     };
-    auto stage_A = [&](int slab) {
-        vec16 stage[ITER];
+    vec16 stage[ITER];
+    auto stage_A = [&](int slab, int part = 3) {             // part 1: global -> registers, 2: registers -> LDS, 3: both
+        if (part & 1) {
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int v = tid + it * NT;
@@ -272,6 +317,8 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
             if (goff[it] != ~0u && c < p.Cin) val = *(const vec16*)(xg + (size_t)goff[it] + slab * CKT);
             stage[it] = val;
         }
+        }
+        if (part & 2) {
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int v = tid + it * NT;
@@ -280,12 +327,14 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
                 *(vec16*)(ldsA + pix * PITCH + (slot << 4)) = stage[it];
             }
         }
+        }
     };
 
     // ---- PRE: per-wave table of the halo's 32-pixel blocks (block b = wave + bi * WV): element offset of lane's pixel or ~0u
     constexpr int PBLK = (NPIX_MAX + 31) / 32, PBW = (PBLK + WV - 1) / WV;
     unsigned poff[PRE ? PBW : 1];
-    auto build_poff = [&]() {
+    auto build_poff = [&](const TileC& c) {
+        const int d0 = c.d0, h0 = c.h0, w0 = c.w0, n = c.n;
 #pragma unroll
         for (int bi = 0; bi < (PRE ? PBW : 0); ++bi) {
             const int pix = (wave + bi * WV) * 32 + (lane & 31);
@@ -304,7 +353,19 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
     };
     // slab 0: ONE read of the raw pixels (operand-layout loads touch 32 cache lines per instruction: the expensive part) feeds both
     // 32-channel slabs -- slab 0's values go to the halo slab, slab 1's wait in ldsP; slab 1: an LDS -> LDS copy
-    auto stage_pre = [&](int slab) {
+    constexpr int PKS = 4;                                                   // K-steps of the pointwise layer: 64 input channels
+    frag_t fap[PRE ? PBW : 1][PKS];                                          // the raw pixels of the halo's blocks, MFMA operand layout
+    auto pre_issue = [&]() {                                                 // every request first: one memory round trip
+        if constexpr (PRE) {
+#pragma unroll
+            for (int bi = 0; bi < PBW; ++bi) {
+                const T* src = xg + (poff[bi] != ~0u ? poff[bi] : 0u) + 8 * khalf;
+#pragma unroll
+                for (int s = 0; s < PKS; ++s) fap[bi][s] = *(const frag_t*)(src + 16 * s);
+            }
+        }
+    };
+    auto stage_pre = [&](int slab, bool issue = true) {
         if constexpr (PRE) {
             if (slab != 0) {
 #pragma unroll 1
@@ -312,14 +373,7 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
                     *(u32x4*)(ldsA + (v >> 2) * PITCH + (v & 3) * 16) = *(const u32x4*)(ldsP + v * 16);
                 return;
             }
-            constexpr int PKS = 4;                                           // K-steps of the pointwise layer: 64 input channels
-            frag_t fap[PBW][PKS];
-#pragma unroll
-            for (int bi = 0; bi < PBW; ++bi) {                               // every request first: one memory round trip
-                const T* src = xg + (poff[bi] != ~0u ? poff[bi] : 0u) + 8 * khalf;
-#pragma unroll
-                for (int s = 0; s < PKS; ++s) fap[bi][s] = *(const frag_t*)(src + 16 * s);
-            }
+            if (issue) pre_issue();                                          // (PERSIST: requested before the previous tile's epilogue)
 #pragma unroll
             for (int nbk = 0; nbk < 2; ++nbk) {
                 const unsigned char* pw = (const unsigned char*)p.pre_w + ((size_t)nbk * PKS) * FRAGB + lane * 16;   // n-block nbk (taps_padded(1) = 1)
@@ -367,6 +421,227 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
         }
     };
 
+    // the tile's epilogue (reads acc and the current tile's coordinates n, d0, h0, w0, th_i, tw_i; PERSIST calls it once per tile)
+    // (mid(): called once when the accumulators are dead or about to be -- POOL: behind the barrier that follows the tile's trip to LDS, otherwise
+    // at the start; the persistent loop requests the next tile's halo there)
+    auto epilogue = [&](auto&& mid) {
+    T* yg = (T*)p.y;
+    if constexpr (!POOL) mid();
+    const T* rg = (const T*)p.res;
+    if constexpr (TR) {
+        // 16-bit outputs, transposed accumulators: lane l owns pixel (l & 31) of each of its MB row blocks and, in registers
+        // 4g .. 4g+3 of a 32x32 tile, the four consecutive channels 8g + 4 (l >> 5) + {0..3}.  After the affine / residual / ReLU
+        // the four values are two packed dwords; ONE v_permlane32_swap per dword pair (g even, g odd) gives the lower lane channels
+        // 8g' .. 8g'+7 and the upper lane 8g'+8 .. 8g'+15 of the same pixel: every lane stores 16 contiguous bytes straight from
+        // registers.  No LDS transpose, no barrier (the LDS form took 5.3 of conv3d_2c's 44 us per tile: two passes of 48
+        // ds_write_b32 + barrier + read-out, tools/timeline_probe.py).
+        long long opix[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            int tdl, thl, twl;
+            const bool inbox = tile_pix(wm * (MB * 32) + mb * 32 + (lane & 31), tdl, thl, twl);
+            const int od = d0 + tdl, oh = h0 + thl, ow = w0 + tile_col(thl, twl);
+            opix[mb] = (inbox && od < p.D && oh < p.H && ow < p.W) ? (((long long)n * p.D + od) * p.H + oh) * p.W + ow : -1;
+        }
+        if constexpr (POOL) {
+            // POOL (step_conv_forward_pre_pool: maxPool3d_3a -- (1,3,3) / (1,2,2), TF padding (0,1) -- taken on conv3d_2c's tile while it is
+            // on the chip): y is the POOLED tensor [N, D, Hp, Wp, C]; the un-pooled output never exists.  Same scheme as the stem's pooled
+            // epilogue (stem.hip): the 4 planes x 8 x 8 tile goes to LDS pixel-major (the rings are free: the K loop ended in a barrier); a
+            // pooled pixel (ph, pw) is the max over rows 2ph .. 2ph+2 and columns 2pw .. 2pw+2, so a tile plane holds everything for 3 of its
+            // 4 pooled rows / columns and two of the three rows / columns of the fourth.  The tile writes the max over what it HAS to y and
+            // its own first row and first column (raw values) to pool_row / pool_col; pool_seam_fix_kernel completes the pooled pixels on tile
+            // seams from those.  Values are post-ReLU (>= +0): the zero padding of the reference's ConstantPad3d is neutral, out-of-image
+            // pixels of partial tiles enter as 0, and 16-bit patterns order like signed integers (one v_pk_max_i16 per pair).
+            constexpr int TP = NBT * 64 + 16;                            // bytes per tile pixel (+16: 16 lanes x 16 B at one channel offset spread over all banks)
+            int tpix[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                int tdl, thl, twl;
+                tile_pix(wm * (MB * 32) + mb * 32 + (lane & 31), tdl, thl, twl);
+                tpix[mb] = (tdl * 8 + thl) * 8 + tile_col(thl, twl);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int cl = (wn * NB + i) * 32;
+                f32x4 sc[4], sh[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    sc[g] = *(const f32x4*)(ldsS + cl + 8 * g + 4 * khalf);
+                    sh[g] = *(const f32x4*)(ldsS + NBT * 32 + cl + 8 * g + 4 * khalf);
+                }
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const bool okp = opix[mb] >= 0;
+                    unsigned d[4][2];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[mb][i][4 * g + e] * sc[g][e] + sh[g][e], 0.f);      // (the host admits relu = 1 only)
+                        d[g][0] = (unsigned)elem<T>::bits16(v[0]) | ((unsigned)elem<T>::bits16(v[1]) << 16);
+                        d[g][1] = (unsigned)elem<T>::bits16(v[2]) | ((unsigned)elem<T>::bits16(v[3]) << 16);
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        lane32_swap(d[2 * h][0], d[2 * h + 1][0]);
+                        lane32_swap(d[2 * h][1], d[2 * h + 1][1]);
+                        u32x4 o = {d[2 * h][0], d[2 * h][1], d[2 * h + 1][0], d[2 * h + 1][1]};
+                        if (!okp) o = u32x4{0u, 0u, 0u, 0u};
+                        *(u32x4*)(lds + tpix[mb] * TP + (cl + 16 * h + 8 * khalf) * 2) = o;
+                    }
+                }
+            }
+            __syncthreads();
+            mid();
+            constexpr int CV = NBT * 4;                                  // 8-channel vectors of the workgroup's channels
+            unsigned short* yp_ = (unsigned short*)p.y;
+            // 4 planes x 4 x 4 pooled pixels x CV vectors = NB items per thread; vector fastest (a pixel's channels are contiguous)
+            // (PERSIST: one item at a time -- unrolled, the scheduler hoists all 9 * NB window reads to the top, ~110 live registers beside the
+            // halo requests mid() has just put in flight, and the allocator spills those)
+#pragma unroll (PERSIST ? 1 : NB)
+            for (int k = 0; k < NB; ++k) {
+                const int item = tid + NT * k;
+                const int v = item % CV, pq = item / CV;
+                const int j = pq & 3, i2 = (pq >> 2) & 3, pl_ = pq >> 4;
+                const unsigned char* base = lds + ((pl_ * 8 + 2 * i2) * 8 + 2 * j) * TP + v * 16;
+                u32x4 m = *(const u32x4*)base;
+#pragma unroll
+                for (int dr = 0; dr < 3; ++dr)
+#pragma unroll
+                    for (int dc = 0; dc < 3; ++dc) {
+                        if (dr == 0 && dc == 0) continue;
+                        if (2 * i2 + dr < 8 && 2 * j + dc < 8) {
+                            const u32x4 o = *(const u32x4*)(base + (dr * 8 + dc) * TP);
+                            m = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8_pool, m), __builtin_bit_cast(s16x8_pool, o)));
+                        }
+                    }
+                const int od = d0 + pl_, ph = (h0 >> 1) + i2, pw = (w0 >> 1) + j, co = nb0 * 32 + v * 8;
+                if (od < p.D && ph < p.Hp && pw < p.Wp && co < p.Cout)
+                    *(u32x4*)(yp_ + ((((size_t)n * p.D + od) * p.Hp + ph) * p.Wp + pw) * p.y_cstride + p.y_coff + co) = m;
+            }
+            // the tile's first row -> pool_row, first column -> pool_col (raw values; tiles of the first tile row / column have no reader)
+            unsigned short* rb = (unsigned short*)p.pool_row;
+            unsigned short* cb = (unsigned short*)p.pool_col;
+#pragma unroll (PERSIST ? 1 : NB)
+            for (int k = 0; k < NB; ++k) {
+                const int item = tid + NT * k;                           // 2 x 4 planes x 8 pixels x CV vectors = NB x 512
+                const int v = item % CV, q = item / CV;
+                const int e = q & 7, pl_ = (q >> 3) & 3, col_item = q >> 5;
+                const int od = d0 + pl_, co = nb0 * 32 + v * 8;
+                if (od >= p.D || co >= p.Cout) continue;
+                const size_t plane = (size_t)n * p.D + od;
+                if (!col_item) {
+                    if (th_i > 0 && w0 + e < p.W)
+                        *(u32x4*)(rb + ((plane * p.tiles_h + th_i) * p.W + w0 + e) * (size_t)p.Cout + co) = *(const u32x4*)(lds + ((pl_ * 8) * 8 + e) * TP + v * 16);
+                } else {
+                    if (tw_i > 0 && h0 + e < p.H)
+                        *(u32x4*)(cb + ((plane * p.tiles_w + tw_i) * p.H + h0 + e) * (size_t)p.Cout + co) = *(const u32x4*)(lds + ((pl_ * 8 + e) * 8) * TP + v * 16);
+                }
+            }
+            return;
+        }
+        if (p.vec_epi) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int cl = (wn * NB + i) * 32;                       // first channel of the block inside the workgroup tile
+                f32x4 sc[4], sh[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    sc[g] = *(const f32x4*)(ldsS + cl + 8 * g + 4 * khalf);
+                    sh[g] = *(const f32x4*)(ldsS + NBT * 32 + cl + 8 * g + 4 * khalf);
+                }
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const bool okp = opix[mb] >= 0;
+                    const size_t obase = (size_t)(okp ? opix[mb] : 0);
+                    unsigned d[4][2];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[mb][i][4 * g + e] * sc[g][e] + sh[g][e];
+                        const int co = nb0 * 32 + cl + 8 * g + 4 * khalf;
+                        if (rg && okp && co < p.Cout) {
+                            const u16x4 rv = *(const u16x4*)(rg + obase * p.r_cstride + p.r_coff + co);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += elem<T>::from_bits16(rv[e]);
+                        }
+                        if (p.relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        d[g][0] = (unsigned)elem<T>::bits16(v[0]) | ((unsigned)elem<T>::bits16(v[1]) << 16);
+                        d[g][1] = (unsigned)elem<T>::bits16(v[2]) | ((unsigned)elem<T>::bits16(v[3]) << 16);
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {                        // register quads (2h, 2h + 1) -> one 16-byte run per lane
+                        lane32_swap(d[2 * h][0], d[2 * h + 1][0]);
+                        lane32_swap(d[2 * h][1], d[2 * h + 1][1]);
+                        const int co = nb0 * 32 + cl + 16 * h + 8 * khalf;
+                        if (okp && co < p.Cout) {
+                            const u32x4 o = {d[2 * h][0], d[2 * h][1], d[2 * h + 1][0], d[2 * h + 1][1]};
+                            *(u32x4*)(yg + obase * p.y_cstride + p.y_coff + co) = o;
+                        }
+                    }
+                }
+            }
+#ifdef STEP_PROBE
+            STEP_PROBE_MARK(p, 3);
+            __builtin_amdgcn_s_waitcnt(0);                    // every store acknowledged
+            probe_clock_end(p.probe);
+            STEP_PROBE_MARK(p, 4);
+#endif
+            return;
+        }
+        // channel counts / offsets off the 16-byte grid: element stores (same transposed ownership)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int cl = (wn * NB + i) * 32;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = nb0 * 32 + cl + cd_row(r, lane);
+                    if (opix[mb] >= 0 && co < p.Cout) {
+                        const size_t o = (size_t)opix[mb];
+                        float v = acc[mb][i][r] * ldsS[cl + cd_row(r, lane)] + ldsS[NBT * 32 + cl + cd_row(r, lane)];
+                        if (rg) v += elem<T>::to_f32(rg[o * p.r_cstride + p.r_coff + co]);
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        yg[o * p.y_cstride + p.y_coff + co] = elem<T>::from_f32(v);
+                    }
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int nbg = nb0 + wn * NB + i;
+        const int co = nbg * 32 + (lane & 31);
+        if (nbg < p.nblk32 && co < p.Cout) {
+            const float sc = p.scale ? p.scale[co] : 1.f;
+            const float sh = p.shift ? p.shift[co] : 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mm = wm * (MB * 32) + mb * 32 + cd_row(r, lane);
+                    int tdl, thl, twl;
+                    const bool inbox = tile_pix(mm, tdl, thl, twl);
+                    const int od = d0 + tdl, oh = h0 + thl, ow = w0 + tile_col(thl, twl);
+                    if (inbox && od < p.D && oh < p.H && ow < p.W) {
+                        const size_t opix = (((size_t)n * p.D + od) * p.H + oh) * p.W + ow;
+                        float v = acc[mb][i][r] * sc + sh;
+                        if (rg) v += elem<T>::to_f32(rg[opix * p.r_cstride + p.r_coff + co]);
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        yg[opix * p.y_cstride + p.y_coff + co] = elem<T>::from_f32(v);
+                    }
+                }
+            }
+        }
+    }
+    };
+
     if constexpr (PH != 0) {
         // ---- two-phase pipeline (see the header comment).  A slab's steps are unrolled: tap shifts and ring-buffer offsets
         // are immediates of the ds_reads (measured: the scalar / branch code of the rolled loop cost ~290 cycles per phase,
@@ -394,8 +669,8 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
             wthr[q] = wg + (((size_t)nbg * taps_padded(NTAPS) + tp) * KC16 + ks) * FRAGB + within * 16;
         }
         const unsigned wstep = (unsigned)TPS * KC16 * FRAGB;               // bytes between consecutive steps of a slab
-        auto woff_of = [&](int slab, int si) -> unsigned {                  // weight offset of a step; past the end: the last one
-            if (slab >= nslab) { slab = nslab - 1; si = SPS - 1; }
+        auto woff_of = [&](int slab, int si) -> unsigned {                  // weight offset of a step; past the end: the last one (PERSIST: the next tile's first steps)
+            if (slab >= nslab) { if constexpr (PERSIST) slab -= nslab; else { slab = nslab - 1; si = SPS - 1; } }
             return (unsigned)slab * (KS * FRAGB) + (unsigned)si * wstep;
         };
         auto load_B = [&](unsigned woff, u32x4 (&r)[QH]) {
@@ -423,7 +698,12 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
             if (act) {
 #pragma unroll
                 for (int tp = 0; tp < TPS; ++tp) {
-                    const int tap = SI * TPS + tp;                 // (compile-time after unrolling; the padded tap reads shift 0)
+                    const int tap = SI * TPS + tp;                 // (compile-time after unrolling)
+                    // the zero tap that pads an odd tap count: no fragment reads and (below) no MFMAs -- its products are exact zeros,
+                    // 1 / 28 of the loop's matrix work and LDS reads (round 6; the classic form still multiplies it)
+#ifndef STEP_EXP_KEEP_PAD_TAP                                       // (experiment builds: make EXP=padtap EXPFLAGS=-DSTEP_EXP_KEEP_PAD_TAP, tools/step_ab.py)
+                    if (tap >= NTAPS) continue;
+#endif
                     int shift = tap >= NTAPS ? 0 : (tap / (KH * KW)) * HHWB + ((tap / KW) % KH) * HWB + (tap % KW) * PITCH;
 #ifndef STEP_EMUL
                     // run-time tile boxes: the shift is not an immediate.  Pin its use to this phase (volatile asm statements
@@ -465,7 +745,10 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
 #endif
             if (act) {
 #pragma unroll
-                for (int tp = 0; tp < TPS; ++tp)
+                for (int tp = 0; tp < TPS; ++tp) {
+#ifndef STEP_EXP_KEEP_PAD_TAP
+                    if (SI * TPS + tp >= NTAPS) continue;          // (the padding tap: see the L phase)
+#endif
 #pragma unroll
                     for (int j = 0; j < KS; ++j)
 #pragma unroll
@@ -475,6 +758,7 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
                                 if constexpr (TR) mma_k16(fb[tp][j][i], fa[tp][j][mb], acc[mb][i], T());
                                 else mma_k16(fa[tp][j][mb], fb[tp][j][i], acc[mb][i], T());
                             }
+                }
             }
 #ifndef STEP_EMUL
             __builtin_amdgcn_s_setprio(0);
@@ -497,19 +781,37 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
         __builtin_amdgcn_sched_barrier(0);
 #endif
         ss_load();
-        if constexpr (PRE) build_poff(); else build_goff();
+        if constexpr (PRE) build_poff(tc); else build_goff(tc);
         STEP_PROBE_MARK(p, 5);
-        if constexpr (PRE) stage_pre(0); else stage_A(0);
+        if constexpr (PERSIST) {
+            // the first tile's halo is only REQUESTED here; every tile's staging is finished at the top of the tile loop (one copy of that
+            // code, and the accumulators -- cleared there -- are not alive while it runs)
+            if constexpr (PRE) pre_issue(); else stage_A(0, 1);
+        } else {
+            if constexpr (PRE) stage_pre(0); else stage_A(0);
+        }
         ss_store();
         STEP_PROBE_MARK(p, 6);
         if (act) {
             store_B(0, R0);
             load_B(woff_of(SPS > 2 ? 0 : 1, SPS > 2 ? 2 : 2 - SPS), R0);
         }
-        __syncthreads();
+        if constexpr (!PERSIST) __syncthreads();
         STEP_PROBE_MARK(p, 1);
         typedef std::integral_constant<int, 0> P0;
         typedef std::integral_constant<int, 1> P1;
+#pragma unroll 1
+        for (;;) {                                         // PERSIST: the workgroup's tile loop (otherwise a single pass)
+        if constexpr (PERSIST) {
+            if constexpr (PRE) stage_pre(0, false); else stage_A(0, 2);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mb][i][r] = 0.f;
+            __syncthreads();
+        }
 #pragma unroll 1
         for (int slab = 0; slab < nslab; ++slab) {
             if (slab) {                                    // slab switch: realign the groups, re-stage the halo
@@ -523,6 +825,51 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
         }
         if (grp == 0) __syncthreads();                    // realign before the epilogue reuses LDS
         STEP_PROBE_MARK(p, 2);
+        if constexpr (!PERSIST) {
+            break;
+        } else {
+            // the workgroup's next tile.  Ring buffer 0 already holds its step 0 and the register sets its steps 1 and 2 (the last
+            // steps' requests wrapped around: same channel group, same weights).  Its halo is requested from inside the epilogue (mid():
+            // index table + global loads into registers the K loop's fragments occupied) and lands while the epilogue pools and stores.
+            relaunder();
+            unsigned nv = vid + gridDim.x;
+            int nbx = 0, nby = 0;
+            while (nv < (unsigned)p.gcount && !grid_coords_of(p, nv, nbx, nby)) nv += gridDim.x;
+            const bool more = nv < (unsigned)p.gcount;
+            TileC nt = tc;
+            if (more) nt = tile_of(nbx);
+            epilogue([&]() {
+                if (more) {
+                    if constexpr (PRE) { build_poff(nt); pre_issue(); } else { build_goff(nt); stage_A(0, 1); }
+                } else {
+                    // (no next tile: give the request registers a value all the same.  Left alone, "unchanged" means the PREVIOUS tile's
+                    // requests stay alive from the top of the loop across the whole K loop to this point -- the allocator then spills them,
+                    // and a spilled request is a load followed at once by s_waitcnt vmcnt(0) + scratch store: measured in the ISA, 4 of 12)
+                    if constexpr (PRE) {
+#pragma unroll
+                        for (int bi = 0; bi < PBW; ++bi) {
+                            poff[bi] = ~0u;
+#pragma unroll
+                            for (int s_ = 0; s_ < PKS; ++s_)
+#pragma unroll
+                                for (int e = 0; e < (int)(sizeof(frag_t) / sizeof(fap[0][0][0])); ++e) fap[bi][s_][e] = 0;
+                        }
+                    } else {
+#pragma unroll
+                        for (int it = 0; it < ITER; ++it) {
+                            goff[it] = ~0u;
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) stage[it][e] = 0;
+                        }
+                    }
+                }
+            });
+            if (!more) return;
+            if constexpr (POOL) __syncthreads();          // (the pooled tile's readers are done: halo + stash may be overwritten)
+            tc = nt; vid = nv;
+            tw_i = tc.tw_i; th_i = tc.th_i; d0 = tc.d0; n = tc.n; h0 = tc.h0; w0 = tc.w0;
+        }
+        }
         if (!act) return;                                  // (no barrier beyond this point in the 16-bit epilogue)
     } else {
     // global -> registers: this thread's vectors of the B tile of a pipeline step.  Branch-free on
@@ -692,218 +1039,7 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
 
     }   // classic pipeline
 
-    // ---- epilogue
-    T* yg = (T*)p.y;
-    const T* rg = (const T*)p.res;
-    if constexpr (TR) {
-        // 16-bit outputs, transposed accumulators: lane l owns pixel (l & 31) of each of its MB row blocks and, in registers
-        // 4g .. 4g+3 of a 32x32 tile, the four consecutive channels 8g + 4 (l >> 5) + {0..3}.  After the affine / residual / ReLU
-        // the four values are two packed dwords; ONE v_permlane32_swap per dword pair (g even, g odd) gives the lower lane channels
-        // 8g' .. 8g'+7 and the upper lane 8g'+8 .. 8g'+15 of the same pixel: every lane stores 16 contiguous bytes straight from
-        // registers.  No LDS transpose, no barrier (the LDS form took 5.3 of conv3d_2c's 44 us per tile: two passes of 48
-        // ds_write_b32 + barrier + read-out, tools/timeline_probe.py).
-        long long opix[MB];
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            int tdl, thl, twl;
-            const bool inbox = tile_pix(wm * (MB * 32) + mb * 32 + (lane & 31), tdl, thl, twl);
-            const int od = d0 + tdl, oh = h0 + thl, ow = w0 + tile_col(thl, twl);
-            opix[mb] = (inbox && od < p.D && oh < p.H && ow < p.W) ? (((long long)n * p.D + od) * p.H + oh) * p.W + ow : -1;
-        }
-        if constexpr (POOL) {
-            // POOL (step_conv_forward_pre_pool: maxPool3d_3a -- (1,3,3) / (1,2,2), TF padding (0,1) -- taken on conv3d_2c's tile while it is
-            // on the chip): y is the POOLED tensor [N, D, Hp, Wp, C]; the un-pooled output never exists.  Same scheme as the stem's pooled
-            // epilogue (stem.hip): the 4 planes x 8 x 8 tile goes to LDS pixel-major (the rings are free: the K loop ended in a barrier); a
-            // pooled pixel (ph, pw) is the max over rows 2ph .. 2ph+2 and columns 2pw .. 2pw+2, so a tile plane holds everything for 3 of its
-            // 4 pooled rows / columns and two of the three rows / columns of the fourth.  The tile writes the max over what it HAS to y and
-            // its own first row and first column (raw values) to pool_row / pool_col; pool_seam_fix_kernel completes the pooled pixels on tile
-            // seams from those.  Values are post-ReLU (>= +0): the zero padding of the reference's ConstantPad3d is neutral, out-of-image
-            // pixels of partial tiles enter as 0, and 16-bit patterns order like signed integers (one v_pk_max_i16 per pair).
-            constexpr int TP = NBT * 64 + 16;                            // bytes per tile pixel (+16: 16 lanes x 16 B at one channel offset spread over all banks)
-            int tpix[MB];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                int tdl, thl, twl;
-                tile_pix(wm * (MB * 32) + mb * 32 + (lane & 31), tdl, thl, twl);
-                tpix[mb] = (tdl * 8 + thl) * 8 + tile_col(thl, twl);
-            }
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int cl = (wn * NB + i) * 32;
-                f32x4 sc[4], sh[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    sc[g] = *(const f32x4*)(ldsS + cl + 8 * g + 4 * khalf);
-                    sh[g] = *(const f32x4*)(ldsS + NBT * 32 + cl + 8 * g + 4 * khalf);
-                }
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const bool okp = opix[mb] >= 0;
-                    unsigned d[4][2];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[mb][i][4 * g + e] * sc[g][e] + sh[g][e], 0.f);      // (the host admits relu = 1 only)
-                        d[g][0] = (unsigned)elem<T>::bits16(v[0]) | ((unsigned)elem<T>::bits16(v[1]) << 16);
-                        d[g][1] = (unsigned)elem<T>::bits16(v[2]) | ((unsigned)elem<T>::bits16(v[3]) << 16);
-                    }
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        lane32_swap(d[2 * h][0], d[2 * h + 1][0]);
-                        lane32_swap(d[2 * h][1], d[2 * h + 1][1]);
-                        u32x4 o = {d[2 * h][0], d[2 * h][1], d[2 * h + 1][0], d[2 * h + 1][1]};
-                        if (!okp) o = u32x4{0u, 0u, 0u, 0u};
-                        *(u32x4*)(lds + tpix[mb] * TP + (cl + 16 * h + 8 * khalf) * 2) = o;
-                    }
-                }
-            }
-            __syncthreads();
-            constexpr int CV = NBT * 4;                                  // 8-channel vectors of the workgroup's channels
-            unsigned short* yp_ = (unsigned short*)p.y;
-            // 4 planes x 4 x 4 pooled pixels x CV vectors = NB items per thread; vector fastest (a pixel's channels are contiguous)
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                const int item = tid + NT * k;
-                const int v = item % CV, pq = item / CV;
-                const int j = pq & 3, i2 = (pq >> 2) & 3, pl_ = pq >> 4;
-                const unsigned char* base = lds + ((pl_ * 8 + 2 * i2) * 8 + 2 * j) * TP + v * 16;
-                u32x4 m = *(const u32x4*)base;
-#pragma unroll
-                for (int dr = 0; dr < 3; ++dr)
-#pragma unroll
-                    for (int dc = 0; dc < 3; ++dc) {
-                        if (dr == 0 && dc == 0) continue;
-                        if (2 * i2 + dr < 8 && 2 * j + dc < 8) {
-                            const u32x4 o = *(const u32x4*)(base + (dr * 8 + dc) * TP);
-                            m = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8_pool, m), __builtin_bit_cast(s16x8_pool, o)));
-                        }
-                    }
-                const int od = d0 + pl_, ph = (h0 >> 1) + i2, pw = (w0 >> 1) + j, co = nb0 * 32 + v * 8;
-                if (od < p.D && ph < p.Hp && pw < p.Wp && co < p.Cout)
-                    *(u32x4*)(yp_ + ((((size_t)n * p.D + od) * p.Hp + ph) * p.Wp + pw) * p.y_cstride + p.y_coff + co) = m;
-            }
-            // the tile's first row -> pool_row, first column -> pool_col (raw values; tiles of the first tile row / column have no reader)
-            unsigned short* rb = (unsigned short*)p.pool_row;
-            unsigned short* cb = (unsigned short*)p.pool_col;
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                const int item = tid + NT * k;                           // 2 x 4 planes x 8 pixels x CV vectors = NB x 512
-                const int v = item % CV, q = item / CV;
-                const int e = q & 7, pl_ = (q >> 3) & 3, col_item = q >> 5;
-                const int od = d0 + pl_, co = nb0 * 32 + v * 8;
-                if (od >= p.D || co >= p.Cout) continue;
-                const size_t plane = (size_t)n * p.D + od;
-                if (!col_item) {
-                    if (th_i > 0 && w0 + e < p.W)
-                        *(u32x4*)(rb + ((plane * p.tiles_h + th_i) * p.W + w0 + e) * (size_t)p.Cout + co) = *(const u32x4*)(lds + ((pl_ * 8) * 8 + e) * TP + v * 16);
-                } else {
-                    if (tw_i > 0 && h0 + e < p.H)
-                        *(u32x4*)(cb + ((plane * p.tiles_w + tw_i) * p.H + h0 + e) * (size_t)p.Cout + co) = *(const u32x4*)(lds + ((pl_ * 8 + e) * 8) * TP + v * 16);
-                }
-            }
-            return;
-        }
-        if (p.vec_epi) {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int cl = (wn * NB + i) * 32;                       // first channel of the block inside the workgroup tile
-                f32x4 sc[4], sh[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    sc[g] = *(const f32x4*)(ldsS + cl + 8 * g + 4 * khalf);
-                    sh[g] = *(const f32x4*)(ldsS + NBT * 32 + cl + 8 * g + 4 * khalf);
-                }
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const bool okp = opix[mb] >= 0;
-                    const size_t obase = (size_t)(okp ? opix[mb] : 0);
-                    unsigned d[4][2];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[mb][i][4 * g + e] * sc[g][e] + sh[g][e];
-                        const int co = nb0 * 32 + cl + 8 * g + 4 * khalf;
-                        if (rg && okp && co < p.Cout) {
-                            const u16x4 rv = *(const u16x4*)(rg + obase * p.r_cstride + p.r_coff + co);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += elem<T>::from_bits16(rv[e]);
-                        }
-                        if (p.relu) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                        }
-                        d[g][0] = (unsigned)elem<T>::bits16(v[0]) | ((unsigned)elem<T>::bits16(v[1]) << 16);
-                        d[g][1] = (unsigned)elem<T>::bits16(v[2]) | ((unsigned)elem<T>::bits16(v[3]) << 16);
-                    }
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {                        // register quads (2h, 2h + 1) -> one 16-byte run per lane
-                        lane32_swap(d[2 * h][0], d[2 * h + 1][0]);
-                        lane32_swap(d[2 * h][1], d[2 * h + 1][1]);
-                        const int co = nb0 * 32 + cl + 16 * h + 8 * khalf;
-                        if (okp && co < p.Cout) {
-                            const u32x4 o = {d[2 * h][0], d[2 * h][1], d[2 * h + 1][0], d[2 * h + 1][1]};
-                            *(u32x4*)(yg + obase * p.y_cstride + p.y_coff + co) = o;
-                        }
-                    }
-                }
-            }
-#ifdef STEP_PROBE
-            STEP_PROBE_MARK(p, 3);
-            __builtin_amdgcn_s_waitcnt(0);                    // every store acknowledged
-            probe_clock_end(p.probe);
-            STEP_PROBE_MARK(p, 4);
-#endif
-            return;
-        }
-        // channel counts / offsets off the 16-byte grid: element stores (same transposed ownership)
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int cl = (wn * NB + i) * 32;
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = nb0 * 32 + cl + cd_row(r, lane);
-                    if (opix[mb] >= 0 && co < p.Cout) {
-                        const size_t o = (size_t)opix[mb];
-                        float v = acc[mb][i][r] * ldsS[cl + cd_row(r, lane)] + ldsS[NBT * 32 + cl + cd_row(r, lane)];
-                        if (rg) v += elem<T>::to_f32(rg[o * p.r_cstride + p.r_coff + co]);
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        yg[o * p.y_cstride + p.y_coff + co] = elem<T>::from_f32(v);
-                    }
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int nbg = nb0 + wn * NB + i;
-        const int co = nbg * 32 + (lane & 31);
-        if (nbg < p.nblk32 && co < p.Cout) {
-            const float sc = p.scale ? p.scale[co] : 1.f;
-            const float sh = p.shift ? p.shift[co] : 0.f;
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int mm = wm * (MB * 32) + mb * 32 + cd_row(r, lane);
-                    int tdl, thl, twl;
-                    const bool inbox = tile_pix(mm, tdl, thl, twl);
-                    const int od = d0 + tdl, oh = h0 + thl, ow = w0 + tile_col(thl, twl);
-                    if (inbox && od < p.D && oh < p.H && ow < p.W) {
-                        const size_t opix = (((size_t)n * p.D + od) * p.H + oh) * p.W + ow;
-                        float v = acc[mb][i][r] * sc + sh;
-                        if (rg) v += elem<T>::to_f32(rg[opix * p.r_cstride + p.r_coff + co]);
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        yg[opix * p.y_cstride + p.y_coff + co] = elem<T>::from_f32(v);
-                    }
-                }
-            }
-        }
-    }
+    epilogue([]() {});
 }
 
 
@@ -915,8 +1051,17 @@ void conv_tap_kernel(ConvParams p) {
 
 // The same workgroups for up to CONV_GROUP_MAX independent problems in one grid (an Inception block's branch_1 and branch_2 3x3x3
 // convs: neither fills the chip's second round alone, and a launch boundary between them idles every CU for a prologue + an epilogue).
+// NB = 1 (the 14x14 blocks' grouped launches): registers capped at 128 so that TWO workgroups are resident per CU (68-74 KiB of LDS each) --
+// these launches are one under-filled round of 35-45 us workgroups, and a second resident workgroup (of this launch or, with several batches
+// in flight, of the other batch's) hides the load phases and barriers of the first.  The cap costs ~10 spilled registers, all in the
+// prologue / epilogue (ISA checked: none between the K loop's barriers).  (experiment builds: -DSTEP_EXP_GRP_OCC1 keeps one per CU)
+#ifdef STEP_EXP_GRP_OCC1
+#define STEP_GRP_NB1_WAVES 2
+#else
+#define STEP_GRP_NB1_WAVES 4
+#endif
 template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB, int WV, int PH>
-__global__ __launch_bounds__(WV * 64, 2)
+__global__ __launch_bounds__(WV * 64, (WV == 8 && NB == 1) ? STEP_GRP_NB1_WAVES : 2)
 void conv_tap_group_kernel(ConvGroupParams g) {
     const int k = (g.n > 1 && blockIdx.x >= (unsigned)g.p[1].gbase) ? 1 : 0;
     conv_tap_body<T, TWL, NB, KD, KH, KW, TPS, MB, WV, PH, true>(g.p[k]);
@@ -1010,8 +1155,19 @@ static int launch_tap_pre(const ConvParams& p, int NB, dim3 grid, step_stream_t 
     return STEP_LAUNCH_CHECK();
 }
 
+// ... as a persistent tile loop (PERSIST): gridDim.x workgroups walk p.gcount virtual block ids
+template <typename T, int NB>
+__global__ __launch_bounds__(512, 2)
+void conv_tap_pre_pool_persist_kernel(ConvParams p) {
+    conv_tap_body<T, 3, NB, 3, 3, 3, 2, 2, 8, 1, false, true, true, true>(p);
+}
+
 template <typename T>
 static int launch_tap_pre_pool(const ConvParams& p, int NB, dim3 grid, step_stream_t stream) {
+    if (p.gpersist > 0 && NB == 3) {                       // (the full rounds of a one-channel-group layer; the NB = 1 tail launch stays one tile per workgroup)
+        STEP_LAUNCH((conv_tap_pre_pool_persist_kernel<T, 3>), dim3((unsigned)p.gpersist), dim3(512), stream, p);
+        return STEP_LAUNCH_CHECK();
+    }
     switch (NB) {
         case 1: STEP_LAUNCH((conv_tap_pre_pool_kernel<T, 1>), grid, dim3(512), stream, p); break;
         case 2: STEP_LAUNCH((conv_tap_pre_pool_kernel<T, 2>), grid, dim3(512), stream, p); break;

@@ -62,6 +62,26 @@ __global__ __launch_bounds__(256) void hbm_stream_probe_kernel(const u32x4* __re
     }
 }
 
+// step_clock_sample: the EFFECTIVE shader clock while other work runs.  One wavefront per workgroup reads s_memtime (shader cycles) and
+// s_memrealtime (100 MHz), sleeps until `ticks` of the 100 MHz counter have passed and reads both again; launched on a side stream beside
+// a loop it costs one wave slot with a handful of registers and no memory traffic.  (The driver's DPM table, which sysfs / amd-smi report,
+// is not this number: under matrix load the chip runs 1.3-1.9 GHz inside a 2.4 GHz DPM state.)
+__global__ __launch_bounds__(64) void clock_sample_kernel(unsigned long long* __restrict__ out, unsigned ticks) {
+#ifdef STEP_EMUL
+    if (threadIdx.x == 0) { out[2 * (size_t)blockIdx.x] = 0; out[2 * (size_t)blockIdx.x + 1] = ticks; }
+#else
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t1 = t0;
+    while (t1 - t0 < ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        t1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    t1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[2 * (size_t)blockIdx.x] = c1 - c0; out[2 * (size_t)blockIdx.x + 1] = t1 - t0; }
+#endif
+}
+
 }  // namespace step
 
 using namespace step;
@@ -73,6 +93,14 @@ int step_mfma_clock_probe(unsigned long long* out, int workgroups, int iters, st
     if (workgroups == 0) return STEP_OK;
     if (!out) return STEP_E_NULL;
     STEP_LAUNCH(mfma_clock_probe_kernel, dim3((unsigned)workgroups), dim3(256), stream, out, iters);
+    return STEP_LAUNCH_CHECK();
+}
+
+int step_clock_sample(unsigned long long* out, int workgroups, int ticks_100mhz, step_stream_t stream) {
+    if (workgroups < 0 || ticks_100mhz < 0 || ticks_100mhz > 100000000) return STEP_E_SHAPE;
+    if (workgroups == 0) return STEP_OK;
+    if (!out) return STEP_E_NULL;
+    STEP_LAUNCH(clock_sample_kernel, dim3((unsigned)workgroups), dim3(64), stream, out, (unsigned)ticks_100mhz);
     return STEP_LAUNCH_CHECK();
 }
 

@@ -278,8 +278,9 @@ def conv_forward_pre_pool(x, w_packed, Cout, k, scale, shift, relu, pre):
         return None
     out = torch.empty((N, D, Hp, Wp, Cout), dtype=x.dtype, device=x.device)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-    info = (ctypes.c_int * 10)()
-    L.step_conv_plan_info(ctypes.byref(d), info, 10)
+    info = (ctypes.c_int * 12)()
+    if L.step_conv_pre_pool_plan_info(ctypes.byref(d), info, 12) != 0:     # the plan the POOLED call uses (it may re-plan a general-box layer onto 4 x 8 x 8 tiles)
+        return None
     refused = []
 
     def launch():
@@ -295,7 +296,7 @@ def conv_forward_pre_pool(x, w_packed, Cout, k, scale, shift, relu, pre):
         _capi.check(L.step_conv_pre_pool_finish(ctypes.byref(d), _lib.dptr(out), _lib.dptr(ws), wsb, _lib.stream_ptr(x.device)), "step_conv_pre_pool_finish")
 
     def describe_finish():
-        th, tw = -(-H // 8), -(-W // 8)
+        th, tw = info[10], info[11]
         seam = N * D * ((th - 1) * Wp + (tw - 1) * Hp) * Cout
         rows = N * D * (th * W + tw * H) * Cout
         return ("step::pool_seam_fix_kernel(step::PoolFixParams)", 0.0, (2 * seam + rows) * _ES[x.dtype])

@@ -213,23 +213,31 @@ class C4TrainStep:
         grouped = self.reducer.active
         backend = dd.get_backend() if (dd.is_available() and dd.is_initialized()) else None
         if mode == "auto":
+            # "one" on RCCL: the watchdog drain below is deterministic (it refuses and falls back to "split" where it cannot be), and a
+            # capture that raises falls back too
             mode = "one" if (not grouped or backend == "nccl") else "split"
         if mode not in ("one", "split"):
             raise ValueError("C4TrainStep.capture: mode is 'auto', 'one' or 'split'")
         if mode == "one" and grouped and backend != "nccl":
             raise RuntimeError("C4TrainStep.capture(mode='one'): only RCCL ('nccl') collectives can be recorded in a HIP graph; use mode='split'")
         gc.collect()                                             # (torch.cuda.graph collects too: dead nets must not drop out of the re-pack table mid-capture)
-        self._warm(warmup)
+        # at least TWO eager steps: the second one is the first that re-packs every weight in one launch (backbone._repack_all) and builds
+        # that launch's device tables with host -> device copies, which a capture cannot record (seen in round 6 with warmup = 1:
+        # hipErrorStreamCaptureUnsupported in both capture modes)
+        self._warm(max(int(warmup), 2))
         dev = self.x.device
-        if grouped and backend == "nccl":
+        if grouped and backend == "nccl" and mode == "one":
             # The process group's watchdog thread polls the completion events of the collectives the warm-up steps issued (every ~100 ms).
             # If it still holds some when the capture begins, it queries them while the group's internal stream is capturing -- HIP answers
-            # hipErrorCapturedEvent and the watchdog takes the process down (seen once in four runs of `bench.py --config c4 --force-exchange`).
-            # Let it finish its list first: everything is complete after the synchronize, a few polling intervals empty the list.
-            import os
-            import time
-            torch.cuda.synchronize(dev)
-            time.sleep(float(os.environ.get("STEP_PG_DRAIN_S", "1.0")))
+            # hipErrorCapturedEvent and the watchdog takes the process down (round 5: 1 of 8 runs of `bench.py --config c4 --force-exchange`).
+            # Round 6: no timing -- dist.drain_watchdog synchronises the device and then waits until the group's flight recorder shows NO
+            # active entry (the watchdog retires an entry in the pass that drops the work from its list).  Where that cannot be observed
+            # (recorder disabled / absent) the collectives are NOT recorded: the split form captures nothing of the process group.
+            if not sdist.drain_watchdog(dev):
+                import warnings
+                warnings.warn("C4TrainStep.capture: the process group's pending work cannot be observed (flight recorder off: call "
+                              "step_amd.dist.enable_flight_recorder() before init_process_group); using the split form")
+                mode = "split"
         # with a live process group its watchdog / heartbeat threads may touch the runtime while this thread records: only THIS thread's
         # calls are checked against the capture
         kw = {"capture_error_mode": "thread_local"} if grouped else {}
@@ -239,9 +247,12 @@ class C4TrainStep:
                 with torch.cuda.graph(g, **kw):
                     self._eager_step()
                 self.graph, self.graph_mode, self._g_update = g, "one", None
+                if grouped:
+                    sdist.note_captured()
             except RuntimeError as e:
                 if not grouped:
                     raise
+                sdist.note_captured()
                 import warnings
                 warnings.warn("C4TrainStep.capture: recording the gradient exchange failed (%s); falling back to the split form" % (str(e).splitlines()[0],))
                 torch.cuda.synchronize(dev)

@@ -1847,7 +1847,13 @@ def case_conv_forward_pre_pool_matches_separate_calls(bk, golden):
     rs = np.random.RandomState(61)
     info = (ctypes.c_int * 10)()
     ran = 0
+    # (round 6) the PERSISTENT tile loop of the NB = 3 launch (conv_tap_pre_pool_persist_kernel: `conv_slots` workgroups walk the tiles):
+    # 16 tiles on 8 workgroups + an NB = 1 tail launch of 2; 27 tiles in ONE launch of 8 workgroups (32 virtual ids: padding ids are skipped,
+    # workgroups run 3 or 4 tiles); and the same layer one workgroup per tile (conv_persist = 0) -- all bit-identical to the separate calls
     for dt, (N, D, H, W), Cout, opts, ycs, yco in ((BF16, (1, 4, 24, 24), 192, dict(conv_slots=4, conv_nb=3, conv_waves=8), 192, 0),
+                                                   (BF16, (1, 8, 24, 24), 192, dict(conv_slots=8, conv_nb=3, conv_waves=8, conv_gen=0), 192, 0),
+                                                   (F16, (1, 12, 24, 20), 192, dict(conv_slots=8, conv_nb=3, conv_waves=8, conv_gen=0), 200, 8),
+                                                   (BF16, (1, 8, 24, 24), 192, dict(conv_slots=8, conv_nb=3, conv_waves=8, conv_gen=0, conv_persist=0), 192, 0),
                                                    (F16, (1, 7, 21, 24), 72, dict(conv_gen=0, conv_waves=8), 88, 8),
                                                    (BF16, (1, 8, 16, 8), 64, dict(conv_gen=0, conv_waves=8), 64, 0)):
         x = rs.randn(N, 64, D, H, W).astype(np.float32)
@@ -1889,7 +1895,7 @@ def case_conv_forward_pre_pool_matches_separate_calls(bk, golden):
         assert np.array_equal(g_, w_), (dt, N, D, H, W, Cout, int((g_ != w_).sum()), np.argwhere(g_ != w_)[:4].tolist())
         assert (decode(g_[..., yco:yco + Cout], dt) >= 0).all()
         ran += 1
-    assert ran == 3
+    assert ran == 6
     # outside the contract: a general-box layer (the 14 x 14 map), no ReLU, fp32
     d14 = _capi.ConvDesc(dtype=BF16, N=3, D=8, H=14, W=14, Cin=64, Cout=64, kd=3, kh=3, kw=3, x_cstride=64, x_coff=0, y_cstride=64, y_coff=0,
                          res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)

@@ -1371,7 +1371,7 @@ def case_c2_full_size_properties(dev, golden):
         assert eb < 1e-2, eb                                       # one bf16 rounding per layer over 45 layers (C1: 5.0e-3 of 8e-3)
         eh = rel(np_(net(x[3:4].half())), yo)
         record("c2_full_size_fp16_vs_oracle", eh)
-        assert eh < 2e-3, eh
+        assert eh < 1e-3, eh                                       # fp16 storage is INSIDE north_star's 1e-3 at the headline size (measured 9.3e-4); bench.py reports its rate under "fp16"
         e = rel(np_(y1), np_(yf))
         record("c2_full_size_bf16_vs_fp32", e)
         assert e < 1e-2, e

@@ -192,6 +192,8 @@ def _rccl_captured_step_body(port, q):
 
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
+    from step_amd import dist as sdist
+    sdist.enable_flight_recorder()                                # capture()'s watchdog drain reads it (no sleep, round 6)
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
     steps, warm = 4, 2
     out = {}
@@ -254,6 +256,62 @@ def test_captured_step_with_the_gradient_exchange_recorded_in_the_graph():
     assert res["split_mode"] == "split" and res["split_identical"], res
     assert res["one_mode"] in ("one", "split"), res               # ("split" only if this RCCL build refused the capture: recorded in captured_exchange.json)
     assert res["one_identical"], res
+
+
+def _rccl_capture_loop_worker(port, q, rounds):
+    try:
+        import time
+        import torch.distributed as dist
+        from step_amd import dist as sdist, workloads
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        sdist.enable_flight_recorder()
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+        w = workloads.C4TrainStep(dev, batch=1, seed=123, dtype=torch.bfloat16, capturable=True, force_exchange=True)
+        modes, drains = [], []
+        for r in range(rounds):
+            t0 = time.time()
+            w.capture(warmup=2, mode="one")                       # two eager exchanged steps (12 bucket all-reduces the watchdog then holds), drain, record
+            drains.append(round(time.time() - t0, 3))
+            modes.append(w.graph_mode)
+            w.step()
+            w.step()
+        torch.cuda.synchronize()
+        q.put({"modes": modes, "capture_s": drains, "pending_after": sdist.pending_collectives(), "steps": int(w.opt.step_count), "loss": float(w.loss)})
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException:
+        import traceback
+        q.put({"error": traceback.format_exc()[-3000:]})
+        raise
+
+
+@pytest.mark.timeout(900)
+def test_capture_with_collectives_thirty_times_without_a_pause():
+    """VERDICT r05 item 8 / ADVICE medium: the capture that records the RCCL collectives used to be guarded against the process
+    group's watchdog (which polls the warm-up collectives' events and aborts the process with hipErrorCapturedEvent if it does so
+    while the group's stream is capturing) by a one-second sleep.  Now capture() waits until the group's flight recorder shows no
+    un-retired eager collective (step_amd.dist.drain_watchdog) -- no timing.  30 captures in a row on one workload, each right
+    behind an eager exchanged step, in a subprocess (a watchdog abort would kill it): all 30 recorded in mode "one"."""
+    rounds = 30
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_capture_loop_worker, args=(_free_port(), q, rounds))
+    p.start()
+    try:
+        res = q.get(timeout=800)
+    finally:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert "error" not in res, res["error"]
+    assert p.exitcode == 0
+    import json, os
+    d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ""), "gpurun_out")
+    if os.environ.get("GRAFT_REPO_ROOT") and os.path.isdir(d):
+        json.dump(res, open(os.path.join(d, "capture_loop.json"), "w"))
+    assert res["modes"] == ["one"] * rounds, res
+    assert res["steps"] == 4 * rounds and np.isfinite(res["loss"]), res
 
 
 @pytest.mark.timeout(900)

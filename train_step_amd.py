@@ -128,11 +128,23 @@ def main():
         print(json.dumps({"summary": True, "world_size": world, "global_batch": gb, "clips_per_rank": len(mine), "iters": a.iters,
                           "ms_per_iter": round(el / max(a.iters, 1) * 1e3, 3), "clips_per_s": round(gb * a.iters / el, 3),
                           "launch": ("hipGraph replay (%s)" % w.graph_mode) if w.graph is not None else "eager",
-                          "gradient_exchange": ("bucketed RCCL all-reduce, %d buckets" % len(w.reducer.buckets)) if w.reducer.active else None,
+                          "gradient_exchange": _exchange_label(w, world),
                           "feed": a.feed, "dtype": a.dtype, "final_loss": round(float(w.loss), 6), "adam_steps": w.opt.step_count}), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def _exchange_label(w, world):
+    """What the step's gradient exchange really was: the split form and gloo run ONE eager flat all-reduce, not the buckets."""
+    if not w.reducer.active:
+        return None
+    backend = torch.distributed.get_backend()
+    lib = "RCCL" if backend == "nccl" else backend
+    if getattr(w, "graph_mode", None) == "split":
+        return "one eager flat %s all-reduce of the gradient arena between the two graphs, %d ranks" % (lib, world)
+    where = "recorded in the step's graph" if w.graph is not None else "eager, overlapped with backward"
+    return "bucketed %s all-reduce, %d buckets, %s, %d ranks" % (lib, len(w.reducer.buckets), where, world)
 
 
 if __name__ == "__main__":
