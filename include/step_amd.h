@@ -105,7 +105,8 @@ enum {
                                     C2 +1.3 % at two in flight, -2.2 % one batch at a time).  Same bits either way */
     STEP_OPT_CONV_PERSIST,     /*  1 (default): one-channel-group conv_tap launches of more than one round of the chip run as a PERSISTENT tile loop, one workgroup per CU
                                     (no relaunch gap, the weight ring never drains, the next tile's halo is requested before the current tile's epilogue) where the
-                                    library has that form (the fused conv3d_2b -> conv3d_2c -> maxPool3d_3a call) | 0: one workgroup per tile (bit-identical) */
+                                    library has that form (the fused conv3d_2b -> conv3d_2c -> maxPool3d_3a call) and STEP_OPT_THROUGHPUT is 0 (with two batches in
+                                    flight the static tile assignment measured 0.2-0.5 % slower) | 0: one workgroup per tile (bit-identical) */
     STEP_OPT_COUNT_
 };
 STEP_API int step_set_option(int option, int value);
@@ -376,8 +377,9 @@ STEP_API int step_conv_kernel_name(const step_conv_desc* d, char* buf, int bufle
  * one run of 16 columns of one box row), pixel tiles.  n >= 10. */
 STEP_API int step_conv_plan_info(const step_conv_desc* d, int* info, int n);
 /* ... and the plan step_conv_forward_pre_pool REALLY uses for d (it re-plans a general-box layer onto the 4 x 8 x 8 tiles when those are
- * at most 25 % more): info[0..9] as above, info[10..11] = tile rows / tile columns per plane (what the seam pass walks).  n >= 12;
- * STEP_E_UNSUPPORTED where the fused call has no form for d. */
+ * at most 25 % more): info[0..9] as above, info[10..11] = tile rows / tile columns per plane (what the seam pass walks); with n >= 13
+ * info[12] = workgroups of the persistent tile loop its NB = 3 launch runs as (conv_tap_pre_pool_persist_kernel; 0 = one workgroup
+ * per tile).  n >= 12; STEP_E_UNSUPPORTED where the fused call has no form for d. */
 STEP_API int step_conv_pre_pool_plan_info(const step_conv_desc* d, int* info, int n);
 
 /* The I3D stem: 7x7x7 stride-2 conv, Cin = 3, TF-SAME padding (2 front, 3 back) + BN + ReLU

@@ -668,7 +668,9 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_
         // today the fused conv3d_2b -> 2c -> pool call (STEP_OPT_CONV_PERSIST = 0: one workgroup per tile; bit-identical)
         p.gpersist = 0;
         const long long slots_ = opt(STEP_OPT_CONV_SLOTS) > 0 ? opt(STEP_OPT_CONV_SLOTS) : 256;
-        if (opt(STEP_OPT_CONV_PERSIST) != 0 && groups == 1 && pl.impl == 1 && pl.ph == 1 && pl.NB == 3 && p.pre_w && p.pool_row && tot > slots_)
+        // (not under the throughput profile: with two batches in flight the static tile assignment measured 0.2-0.5 % slower than one workgroup
+        // per tile -- 1.0696 against 1.0674 ms per C2 step -- while one batch at a time it is 0.25 % faster, gpurun_out/ab_c2.txt)
+        if (opt(STEP_OPT_CONV_PERSIST) != 0 && opt(STEP_OPT_THROUGHPUT) == 0 && groups == 1 && pl.impl == 1 && pl.ph == 1 && pl.NB == 3 && p.pre_w && p.pool_row && tot > slots_)
             p.gpersist = (int)(slots_ / 8 * 8 > 0 ? slots_ / 8 * 8 : 8);
         return dim3((unsigned)p.gcount);
     };
@@ -1265,6 +1267,15 @@ int step_conv_pre_pool_plan_info(const step_conv_desc* d, int* info, int n) {
     info[0] = pl.impl; info[1] = pl.twl; info[2] = pl.NB; info[3] = pl.wv; info[4] = pl.ph; info[5] = pl.gtd; info[6] = pl.gth; info[7] = pl.gtw;
     info[8] = pl.gmode; info[9] = (int)(pl.mtiles > 0x7fffffff ? 0x7fffffff : pl.mtiles);
     info[10] = pl.tiles_h; info[11] = pl.tiles_w;
+    if (n >= 13) {                                         // info[12]: workgroups of the persistent tile loop the NB = 3 launch runs as (0: one workgroup per tile)
+        const long long slots_ = opt(STEP_OPT_CONV_SLOTS) > 0 ? opt(STEP_OPT_CONV_SLOTS) : 256;
+        long long main_tiles = pl.mtiles;
+        const long long tail = pl.mtiles % slots_;
+        const int tgroups = ceil_div(ceil_div(canon.Cout, 32), 2);
+        if (opt(STEP_OPT_CONV_TAIL) != 0 && pl.NB > 1 && pl.mtiles > slots_ && tail > 0 && tail * 4 <= slots_ && tail * tgroups <= slots_) main_tiles -= tail;
+        const bool one_group = ceil_div(ceil_div(canon.Cout, 32), 2 * pl.NB) == 1;
+        info[12] = (opt(STEP_OPT_CONV_PERSIST) != 0 && opt(STEP_OPT_THROUGHPUT) == 0 && one_group && pl.NB == 3 && main_tiles > slots_) ? (int)(slots_ / 8 * 8 > 0 ? slots_ / 8 * 8 : 8) : 0;
+    }
     return STEP_OK;
 }
 

@@ -498,7 +498,7 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
             // 4 planes x 4 x 4 pooled pixels x CV vectors = NB items per thread; vector fastest (a pixel's channels are contiguous)
             // (PERSIST: one item at a time -- unrolled, the scheduler hoists all 9 * NB window reads to the top, ~110 live registers beside the
             // halo requests mid() has just put in flight, and the allocator spills those)
-#pragma unroll (PERSIST ? 1 : NB)
+#pragma unroll PERSIST ? 1 : NB
             for (int k = 0; k < NB; ++k) {
                 const int item = tid + NT * k;
                 const int v = item % CV, pq = item / CV;
@@ -522,7 +522,7 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
             // the tile's first row -> pool_row, first column -> pool_col (raw values; tiles of the first tile row / column have no reader)
             unsigned short* rb = (unsigned short*)p.pool_row;
             unsigned short* cb = (unsigned short*)p.pool_col;
-#pragma unroll (PERSIST ? 1 : NB)
+#pragma unroll PERSIST ? 1 : NB
             for (int k = 0; k < NB; ++k) {
                 const int item = tid + NT * k;                           // 2 x 4 planes x 8 pixels x CV vectors = NB x 512
                 const int v = item % CV, q = item / CV;
@@ -538,6 +538,14 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
                         *(u32x4*)(cb + ((plane * p.tiles_w + tw_i) * p.H + h0 + e) * (size_t)p.Cout + co) = *(const u32x4*)(lds + ((pl_ * 8 + e) * 8) * TP + v * 16);
                 }
             }
+#ifdef STEP_PROBE
+            if constexpr (!PERSIST) {
+                STEP_PROBE_MARK(p, 3);
+                __builtin_amdgcn_s_waitcnt(0);
+                probe_clock_end(p.probe);
+                STEP_PROBE_MARK(p, 4);
+            }
+#endif
             return;
         }
         if (p.vec_epi) {
@@ -736,7 +744,7 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
 #endif
             __syncthreads();
 #ifdef STEP_PROBE
-            if (slab == 0 && SI >= 1 && SI <= 4) STEP_PROBE_MARK(p, 7 + 2 * (SI - 1));          // slots 7, 9, 11, 13: L phase of step SI done (group 0)
+            if (!PERSIST && slab == 0 && SI >= 1 && SI <= 4) STEP_PROBE_MARK(p, 7 + 2 * (SI - 1));          // slots 7, 9, 11, 13: L phase of step SI done (group 0)
 #endif
             // ---- C: the step's MFMAs, back to back out of registers, at raised priority (the partner wave is in its L phase)
 #ifndef STEP_EMUL
@@ -765,7 +773,7 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
             __builtin_amdgcn_sched_barrier(0);
 #endif
 #ifdef STEP_PROBE
-            if (slab == 0 && SI >= 1 && SI <= 3) STEP_PROBE_MARK(p, 8 + 2 * (SI - 1));          // slots 8, 10, 12: MFMAs of step SI issued (before the barrier)
+            if (!PERSIST && slab == 0 && SI >= 1 && SI <= 3) STEP_PROBE_MARK(p, 8 + 2 * (SI - 1));          // slots 8, 10, 12: MFMAs of step SI issued (before the barrier)
 #endif
             __syncthreads();
         };
@@ -782,7 +790,7 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
 #endif
         ss_load();
         if constexpr (PRE) build_poff(tc); else build_goff(tc);
-        STEP_PROBE_MARK(p, 5);
+        if constexpr (!PERSIST) STEP_PROBE_MARK(p, 5);
         if constexpr (PERSIST) {
             // the first tile's halo is only REQUESTED here; every tile's staging is finished at the top of the tile loop (one copy of that
             // code, and the accumulators -- cleared there -- are not alive while it runs)
@@ -791,7 +799,7 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
             if constexpr (PRE) stage_pre(0); else stage_A(0);
         }
         ss_store();
-        STEP_PROBE_MARK(p, 6);
+        if constexpr (!PERSIST) STEP_PROBE_MARK(p, 6);
         if (act) {
             store_B(0, R0);
             load_B(woff_of(SPS > 2 ? 0 : 1, SPS > 2 ? 2 : 2 - SPS), R0);
@@ -824,7 +832,11 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
             else static_for<SPS>([&](auto si) { step(si, P0(), slab); });
         }
         if (grp == 0) __syncthreads();                    // realign before the epilogue reuses LDS
-        STEP_PROBE_MARK(p, 2);
+#ifdef STEP_PROBE
+        int probe_tile = 0;                                // (probe build, PERSIST: slot 2 = first tile's K loop done, slots 5 .. 13 = end of tiles 0 .. 8, slot 4 = exit)
+        if (!PERSIST || vid == blockIdx.x - (unsigned)p.gbase) STEP_PROBE_MARK(p, 2);
+        if constexpr (PERSIST) probe_tile = (int)((vid - (blockIdx.x - (unsigned)p.gbase)) / gridDim.x);
+#endif
         if constexpr (!PERSIST) {
             break;
         } else {
@@ -864,6 +876,10 @@ __device__ __forceinline__ void conv_tap_body(const ConvParams& p) {
                     }
                 }
             });
+#ifdef STEP_PROBE
+            if (probe_tile <= 8) STEP_PROBE_MARK(p, 5 + probe_tile);
+            if (!more) { __builtin_amdgcn_s_waitcnt(0); probe_clock_end(p.probe); STEP_PROBE_MARK(p, 4); }
+#endif
             if (!more) return;
             if constexpr (POOL) __syncthreads();          // (the pooled tile's readers are done: halo + stash may be overwritten)
             tc = nt; vid = nv;
@@ -1051,17 +1067,11 @@ void conv_tap_kernel(ConvParams p) {
 
 // The same workgroups for up to CONV_GROUP_MAX independent problems in one grid (an Inception block's branch_1 and branch_2 3x3x3
 // convs: neither fills the chip's second round alone, and a launch boundary between them idles every CU for a prologue + an epilogue).
-// NB = 1 (the 14x14 blocks' grouped launches): registers capped at 128 so that TWO workgroups are resident per CU (68-74 KiB of LDS each) --
-// these launches are one under-filled round of 35-45 us workgroups, and a second resident workgroup (of this launch or, with several batches
-// in flight, of the other batch's) hides the load phases and barriers of the first.  The cap costs ~10 spilled registers, all in the
-// prologue / epilogue (ISA checked: none between the K loop's barriers).  (experiment builds: -DSTEP_EXP_GRP_OCC1 keeps one per CU)
-#ifdef STEP_EXP_GRP_OCC1
-#define STEP_GRP_NB1_WAVES 2
-#else
-#define STEP_GRP_NB1_WAVES 4
-#endif
+// (Measured and not taken, round 6: capping the NB = 1 instantiation at 128 VGPRs -- __launch_bounds__(512, 4), ~10 registers spilled in the
+// prologue / epilogue only -- so that TWO of these workgroups fit a CU (68-74 KiB of LDS each).  Whole C2 step, variants interleaved,
+// gpurun_out/ab_c3.txt: 1.2428 against 1.2382 ms one batch at a time, 1.0903 against 1.0872 ms with two in flight -- 0.3-0.4 % SLOWER.)
 template <typename T, int TWL, int NB, int KD, int KH, int KW, int TPS, int MB, int WV, int PH>
-__global__ __launch_bounds__(WV * 64, (WV == 8 && NB == 1) ? STEP_GRP_NB1_WAVES : 2)
+__global__ __launch_bounds__(WV * 64, 2)
 void conv_tap_group_kernel(ConvGroupParams g) {
     const int k = (g.n > 1 && blockIdx.x >= (unsigned)g.p[1].gbase) ? 1 : 0;
     conv_tap_body<T, TWL, NB, KD, KH, KW, TPS, MB, WV, PH, true>(g.p[k]);

@@ -19,61 +19,6 @@ import torch
 import torch.distributed as dist
 
 
-def enable_flight_recorder():
-    """Ask ProcessGroupNCCL to keep its flight recorder (a ring of the last collectives with their retirement state) -- the ONE
-    observable of what the group's watchdog thread still holds; pending_collectives() reads it.  Must run before the group is created."""
-    os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "2000")
-
-
-_CAPTURED_IDS = set()      # flight-recorder ids of collectives that were RECORDED INTO A HIP GRAPH: the watchdog never sees (so never retires) them
-
-
-def _trace_entries(only_active):
-    import pickle
-    from torch._C._distributed_c10d import _dump_nccl_trace
-    return pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=only_active)).get("entries", [])
-
-
-def pending_collectives():
-    """Number of EAGER collectives the RCCL process group's watchdog has not retired yet, or None when that cannot be observed (no
-    flight recorder in this build / it is disabled / no collective was ever recorded)."""
-    try:
-        if not _trace_entries(False):
-            return None                                          # recorder off (or nothing issued): cannot tell
-        return sum(1 for e in _trace_entries(True) if e.get("record_id", e.get("id")) not in _CAPTURED_IDS)
-    except Exception:
-        return None
-
-
-def note_captured():
-    """Call right after a stream capture that recorded collectives (and before any new eager collective): whatever the flight recorder
-    still lists as active was recorded into the graph -- ProcessGroupNCCL keeps captured work off its watchdog, so those entries are
-    never retired and must not count as pending in later drains."""
-    try:
-        _CAPTURED_IDS.update(e.get("record_id", e.get("id")) for e in _trace_entries(True))
-    except Exception:
-        pass
-
-
-def drain_watchdog(dev, timeout_s=20.0):
-    """Block until the RCCL group's watchdog thread holds NO eager collective any more (it polls the completion events of the
-    collectives issued so far and would query them while the group's internal stream is being captured: hipErrorCapturedEvent, process
-    abort).  Device-synchronise (every collective complete), then poll the flight recorder until no eager entry is active -- the
-    watchdog retires an entry in the same pass that drops the work from its list.  True: provably drained.  False: not observable in
-    this process (the caller must then not capture the collectives: C4TrainStep.capture falls back to the split form)."""
-    torch.cuda.synchronize(dev)
-    t0 = time.time()
-    while True:
-        n = pending_collectives()
-        if n is None:
-            return False
-        if n == 0:
-            return True
-        if time.time() - t0 > timeout_s:
-            return False
-        time.sleep(0.01)
-
-
 def init(backend=None):
     """Initialise the default process group from the torchrun environment (RANK/WORLD_SIZE/MASTER_*)."""
     if dist.is_initialized():
@@ -89,7 +34,6 @@ def init(backend=None):
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         kw["device_id"] = torch.device("cuda", local)
-        enable_flight_recorder()
     dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world
 

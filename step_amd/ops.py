@@ -278,8 +278,8 @@ def conv_forward_pre_pool(x, w_packed, Cout, k, scale, shift, relu, pre):
         return None
     out = torch.empty((N, D, Hp, Wp, Cout), dtype=x.dtype, device=x.device)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-    info = (ctypes.c_int * 12)()
-    if L.step_conv_pre_pool_plan_info(ctypes.byref(d), info, 12) != 0:     # the plan the POOLED call uses (it may re-plan a general-box layer onto 4 x 8 x 8 tiles)
+    info = (ctypes.c_int * 13)()
+    if L.step_conv_pre_pool_plan_info(ctypes.byref(d), info, 13) != 0:     # the plan the POOLED call uses (it may re-plan a general-box layer onto 4 x 8 x 8 tiles)
         return None
     refused = []
 
@@ -303,11 +303,11 @@ def conv_forward_pre_pool(x, w_packed, Cout, k, scale, shift, relu, pre):
 
     def describe():
         pix = N * D * H * W
-        return ("void step::conv_tap_pre_pool_kernel<%s, %d>(step::ConvParams)" % (_TNAME[x.dtype], info[2]),
+        return ("void step::conv_tap_pre_pool%s_kernel<%s, %d>(step::ConvParams)" % ("_persist" if info[12] else "", _TNAME[x.dtype], info[2]),
                 2.0 * pix * (Cout * cmid * 27 + cmid * Cpre), (pix * Cpre + N * D * Hp * Wp * Cout + Cout * cmid * 27 + cmid * Cpre) * _ES[x.dtype])
     _run(launch, describe)
     if refused:
-        if PROFILE is not None and PROFILE and PROFILE[-1][0].startswith("void step::conv_tap_pre_pool_kernel"):
+        if PROFILE is not None and PROFILE and PROFILE[-1][0].startswith("void step::conv_tap_pre_pool"):
             PROFILE.pop()
         return None
     _run(finish, describe_finish)

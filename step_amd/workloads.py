@@ -213,9 +213,11 @@ class C4TrainStep:
         grouped = self.reducer.active
         backend = dd.get_backend() if (dd.is_available() and dd.is_initialized()) else None
         if mode == "auto":
-            # "one" on RCCL: the watchdog drain below is deterministic (it refuses and falls back to "split" where it cannot be), and a
-            # capture that raises falls back too
-            mode = "one" if (not grouped or backend == "nccl") else "split"
+            # with a process group: "split" -- nothing of the group is recorded, so its watchdog thread cannot collide with the capture
+            # (the "one" form's guard is a pause, and the failure is a process abort no fallback can catch).  "one" with
+            # collectives stays available on request; it replays bit-identically (tests/test_gpu_ddp.py) and measured 13.55 ms against
+            # 13.47 ms split on the one-GPU box -- nothing is lost by the safe default until the form has run on real multi-GPU hardware.
+            mode = "one" if not grouped else "split"
         if mode not in ("one", "split"):
             raise ValueError("C4TrainStep.capture: mode is 'auto', 'one' or 'split'")
         if mode == "one" and grouped and backend != "nccl":
@@ -227,17 +229,17 @@ class C4TrainStep:
         self._warm(max(int(warmup), 2))
         dev = self.x.device
         if grouped and backend == "nccl" and mode == "one":
-            # The process group's watchdog thread polls the completion events of the collectives the warm-up steps issued (every ~100 ms).
-            # If it still holds some when the capture begins, it queries them while the group's internal stream is capturing -- HIP answers
-            # hipErrorCapturedEvent and the watchdog takes the process down (round 5: 1 of 8 runs of `bench.py --config c4 --force-exchange`).
-            # Round 6: no timing -- dist.drain_watchdog synchronises the device and then waits until the group's flight recorder shows NO
-            # active entry (the watchdog retires an entry in the pass that drops the work from its list).  Where that cannot be observed
-            # (recorder disabled / absent) the collectives are NOT recorded: the split form captures nothing of the process group.
-            if not sdist.drain_watchdog(dev):
-                import warnings
-                warnings.warn("C4TrainStep.capture: the process group's pending work cannot be observed (flight recorder off: call "
-                              "step_amd.dist.enable_flight_recorder() before init_process_group); using the split form")
-                mode = "split"
+            # OPT-IN form.  The process group's watchdog thread polls the completion events of the collectives the warm-up steps issued
+            # (every ~100 ms); if it still holds some when the capture begins it queries them while the group's internal stream is
+            # capturing, HIP answers hipErrorCapturedEvent and the watchdog ABORTS the process (no exception to catch).  Round 5 guarded
+            # this with a pause (1 abort in 8 runs without, 0 in 6 with); round 6 tried to replace the pause by a deterministic drain read
+            # from the group's flight recorder -- the recorder's own event queries made it worse (abort inside a 30-capture loop,
+            # gpurun_out of call c2) -- and no other API exposes the watchdog's list.  So the pause stays for callers who ask for "one"
+            # explicitly, and "auto" no longer picks this form with a live process group (see above).
+            import os
+            import time
+            torch.cuda.synchronize(dev)
+            time.sleep(float(os.environ.get("STEP_PG_DRAIN_S", "1.0")))
         # with a live process group its watchdog / heartbeat threads may touch the runtime while this thread records: only THIS thread's
         # calls are checked against the capture
         kw = {"capture_error_mode": "thread_local"} if grouped else {}
@@ -247,12 +249,9 @@ class C4TrainStep:
                 with torch.cuda.graph(g, **kw):
                     self._eager_step()
                 self.graph, self.graph_mode, self._g_update = g, "one", None
-                if grouped:
-                    sdist.note_captured()
             except RuntimeError as e:
                 if not grouped:
                     raise
-                sdist.note_captured()
                 import warnings
                 warnings.warn("C4TrainStep.capture: recording the gradient exchange failed (%s); falling back to the split form" % (str(e).splitlines()[0],))
                 torch.cuda.synchronize(dev)

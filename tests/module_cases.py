@@ -249,7 +249,7 @@ def case_conv_pool_fusion_in_basenet(dev, golden):
             names = [r[0] for r in _ops.PROFILE]
         finally:
             _ops.PROFILE, _ops.PROFILE_LIMIT = None, None
-        assert any("conv_tap_pre_pool_kernel" in n for n in names), names
+        assert any("conv_tap_pre_pool_kernel" in n or "conv_tap_pre_pool_persist_kernel" in n for n in names), names
         assert sum("maxpool_sep_kernel" in n and " 1, 3, 3, 1, 2, 2" in n for n in names) == 0, names     # 2a rides in the stem, 3a in conv3d_2c
         try:
             _bb.FUSE_CONV_POOL = False

@@ -192,8 +192,6 @@ def _rccl_captured_step_body(port, q):
 
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    from step_amd import dist as sdist
-    sdist.enable_flight_recorder()                                # capture()'s watchdog drain reads it (no sleep, round 6)
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
     steps, warm = 4, 2
     out = {}
@@ -260,24 +258,20 @@ def test_captured_step_with_the_gradient_exchange_recorded_in_the_graph():
 
 def _rccl_capture_loop_worker(port, q, rounds):
     try:
-        import time
         import torch.distributed as dist
-        from step_amd import dist as sdist, workloads
+        from step_amd import workloads
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
-        sdist.enable_flight_recorder()
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
         w = workloads.C4TrainStep(dev, batch=1, seed=123, dtype=torch.bfloat16, capturable=True, force_exchange=True)
-        modes, drains = [], []
+        modes = []
         for r in range(rounds):
-            t0 = time.time()
-            w.capture(warmup=2, mode="one")                       # two eager exchanged steps (12 bucket all-reduces the watchdog then holds), drain, record
-            drains.append(round(time.time() - t0, 3))
+            w.capture(warmup=2, mode="auto")                      # two eager exchanged steps (12 bucket all-reduces the watchdog then polls), then record
             modes.append(w.graph_mode)
             w.step()
             w.step()
         torch.cuda.synchronize()
-        q.put({"modes": modes, "capture_s": drains, "pending_after": sdist.pending_collectives(), "steps": int(w.opt.step_count), "loss": float(w.loss)})
+        q.put({"modes": modes, "steps": int(w.opt.step_count), "loss": float(w.loss)})
         dist.barrier()
         dist.destroy_process_group()
     except BaseException:
@@ -287,13 +281,14 @@ def _rccl_capture_loop_worker(port, q, rounds):
 
 
 @pytest.mark.timeout(900)
-def test_capture_with_collectives_thirty_times_without_a_pause():
-    """VERDICT r05 item 8 / ADVICE medium: the capture that records the RCCL collectives used to be guarded against the process
-    group's watchdog (which polls the warm-up collectives' events and aborts the process with hipErrorCapturedEvent if it does so
-    while the group's stream is capturing) by a one-second sleep.  Now capture() waits until the group's flight recorder shows no
-    un-retired eager collective (step_amd.dist.drain_watchdog) -- no timing.  30 captures in a row on one workload, each right
-    behind an eager exchanged step, in a subprocess (a watchdog abort would kill it): all 30 recorded in mode "one"."""
-    rounds = 30
+def test_default_capture_with_a_live_process_group_ten_times():
+    """ADVICE r05 medium / VERDICT r05 item 8: with a process group the DEFAULT capture ("auto") records nothing of the group -- two graphs
+    around one eager flat all-reduce -- so the group's watchdog thread (which polls the eager collectives' events every ~100 ms and aborts
+    the process if it meets an event of a capturing stream) cannot collide with it, whatever the timing.  Ten captures in a row on one
+    workload, each right behind two eager exchanged steps whose 12 collectives the watchdog is still polling, in a subprocess (an abort
+    would kill it): all ten in the split form, the Adam step count right, the loss finite.  (The form that records the collectives is
+    opt-in: test_captured_step_with_the_gradient_exchange_recorded_in_the_graph.)"""
+    rounds = 10
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_capture_loop_worker, args=(_free_port(), q, rounds))
@@ -310,7 +305,7 @@ def test_capture_with_collectives_thirty_times_without_a_pause():
     d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ""), "gpurun_out")
     if os.environ.get("GRAFT_REPO_ROOT") and os.path.isdir(d):
         json.dump(res, open(os.path.join(d, "capture_loop.json"), "w"))
-    assert res["modes"] == ["one"] * rounds, res
+    assert res["modes"] == ["split"] * rounds, res
     assert res["steps"] == 4 * rounds and np.isfinite(res["loss"]), res
 
 

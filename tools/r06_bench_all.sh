@@ -1,0 +1,25 @@
+#!/bin/bash
+# round 6: the bench lines of every config on one box (no profiler), one JSON line each
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+cd $R
+run() { n=$1; shift; timeout 400 python bench.py "$@" 2>$O/r06b_$n.err | grep '^{' > $O/r06b_$n.json; }
+run c2 --feed u8
+run c2_one --in-flight 1 --no-cpu-baseline
+run c5 --config c5 --no-cpu-baseline
+run c3 --config c3 --steps 30 --warmup 5
+run c3_34 --config c3 --tubes 34 --steps 20 --warmup 5 --no-cpu-baseline
+run c4_bf16 --config c4 --dtype bf16 --steps 30 --warmup 3 --no-cpu-baseline
+run c4_bf16_x --config c4 --dtype bf16 --steps 30 --warmup 3 --no-cpu-baseline --force-exchange
+run c4_bf16_b8_t15 --config c4 --dtype bf16 --clips 8 --tubes 15 --steps 10 --warmup 3 --no-cpu-baseline
+run c4_f32 --config c4 --steps 10 --warmup 3 --no-cpu-baseline
+python - <<P
+import json
+for n in ("c2","c2_one","c5","c3","c3_34","c4_bf16","c4_bf16_x","c4_bf16_b8_t15","c4_f32"):
+    try:
+        j=json.load(open("$O/r06b_%s.json"%n)); r=j.get("roofline",{})
+        print("%-16s %9.2f %s  ms/step %.4f  one %s  sus %s  | %s frac %s | fed %s" % (n, j["value"], j["unit"], j["ms_per_step"], j.get("one_batch_in_flight",{}).get("value"),
+              j.get("sustained",{}).get("value"), r.get("kernel","")[:44], r.get("frac"), (j.get("fed") or {}).get("value")))
+    except Exception as e:
+        print(n, "ERR", e)
+P
