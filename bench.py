@@ -704,8 +704,10 @@ def fp16_leg(a, net, x, dev, nfl, thr_profile):
     return {"value": round(n * a.steps / el, 2), "unit": "clips/s", "ms_per_step": round(el / a.steps * 1e3, 4), "batches_in_flight": nfl,
             "one_batch_in_flight": {"value": round(n * a.steps / el1, 2), "ms_per_step": round(el1 / a.steps * 1e3, 4)},
             "rel_err_vs_fp32": float("%.3e" % rel), "bf16_rel_err_vs_fp32": float("%.3e" % relb),
-            "rel_err_vs_oracle": "asserted < 1e-3 on the oracle's full [1,8,832,14,14] tensor in tests/module_cases.py case_c2_full_size_properties (measured 9.3e-4; bf16 6.7e-3)",
-            "note": "the same loop as `value` with fp16 storage (fp32 accumulate): same MFMA rate and bytes as bf16, inside north_star's 1e-3; bf16 stays the headline because BASELINE names it"}
+            "rel_err_vs_oracle": "asserted < 1e-3 on the oracle's full [1,8,832,14,14] tensor (golden weights and clip) in tests/module_cases.py case_c2_full_size_properties (measured 9.3e-4; bf16 6.7e-3)",
+            "note": "the same loop as `value` with fp16 storage (fp32 accumulate): same MFMA rate and bytes as bf16, ~8x closer to fp32 (one 11-bit instead of one 8-bit mantissa rounding per "
+                    "layer); rel_err_vs_fp32 = max |y16 - y32| / max |y32| on THIS run's random weights and clips (1.1-1.2e-3 measured: at north_star's 1e-3 bar, which the golden "
+                    "configuration meets against the oracle); bf16 stays the headline because BASELINE names it"}
 
 
 def spawn_ranks(n):
