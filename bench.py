@@ -746,6 +746,8 @@ def main():
                          "(identities there) -- the multi-rank program, captured in the step's HIP graph, on a one-GPU box")
     ap.add_argument("--c4-graph", default="auto", choices=["auto", "one", "split"],
                     help="c4: how the step is captured (workloads.C4TrainStep.capture): one graph incl. the RCCL collectives, or fwd/bwd + eager exchange + update")
+    ap.add_argument("--select", action="store_true",
+                    help="c4: the reference's WHOLE iteration (train.py:257-348): no-grad inference + train_select between the steps (workloads.C4SelectTrainStep)")
     ap.add_argument("--feed", default="none", choices=["none", "u8"],
                     help="c2 / c5: additionally time the FED loop -- pinned host uint8 frames -> H2D on a copy stream -> step_clip_from_u8 -> the "
                          "captured step, double-buffered against the batches in flight; reported under 'fed' (value stays the resident-input loop)")
@@ -1033,12 +1035,18 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
         what = "C3: full two_branch inference (I3D backbone + ContextNet + 3 refinement steps with ROIAlign over %d tubes/clip + " \
                "batched per-class NMS), %d x [36,3,400,400] clips per GPU" % (tubes, CLIPS_PER_GPU)
         metric = "clips_per_sec_inference_T36_400"
-    elif os.environ.get("STEP_BENCH_SELECT", "0") == "1":
-        # the reference's whole iteration: eval inference over the first two steps + train_select between the steps
-        w = workloads.C4SelectTrainStep(dev, batch=CLIPS_PER_GPU, seed=123 + rank, dtype=tdt)
+    elif a.select or os.environ.get("STEP_BENCH_SELECT", "0") == "1":
+        # the reference's whole iteration: eval inference over the first two steps + train_select between the steps.  16-bit, one process or
+        # several: the padded form replayed as HIP graphs (front | host selection | heads + backward [| eager exchange | update]); --no-graph
+        # or fp32: the ragged eager iteration
+        graphed = not a.no_graph and a.dtype != "f32"
+        w = workloads.C4SelectTrainStep(dev, batch=CLIPS_PER_GPU, seed=123 + rank, dtype=tdt, capturable=graphed, force_exchange=a.force_exchange)
+        if graphed:
+            w.capture(warmup=max(a.warmup, 2))
         what = "C4 (with proposal selection, train.py:257-348): backbone + ContextNet, no-grad inference() over 2 steps on 34 tubes/clip, " \
-               "train_select (<= 5 positives + 2x negatives per clip and step) + ROIAlign + head + losses for the 3 steps, backward, " \
-               "flat gradient all-reduce, fused Adam, %d x [36,3,400,400] clip(s) per GPU" % CLIPS_PER_GPU
+               "train_select (<= 5 positives + 2x negatives per clip and step%s) + ROIAlign + head + losses for the 3 steps, backward, " \
+               "flat gradient all-reduce, fused Adam, %d x [36,3,400,400] clip(s) per GPU" % (
+                   ", padded to %d slots per clip with zero-weight rows" % w.budget if graphed else "", CLIPS_PER_GPU)
         metric = "clips_per_sec_train_T36_400"
     else:
         # one process: the whole step (forward, backward, re-pack, Adam) is captured in a HIP graph and replayed -- the eager step
@@ -1122,9 +1130,12 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
                           "launch": ("hipGraph replay + eager post-processing" + (", %d batches in flight (own clips / graph / stream each; batch k + 1 launched before batch k is post-processed)" % nfl if nfl > 1 else ""))
                                     if (a.config == "c3" and not a.no_graph) else
                                     ({"one": "hipGraph replay (whole training step%s)" % (", the bucketed RCCL gradient all-reduces recorded in the graph" if getattr(w.reducer, "active", False) else ""),
-                                      "split": "two hipGraphs (forward + backward | re-pack + Adam) around one eager flat gradient all-reduce"}[w.graph_mode]
+                                      "split": "two hipGraphs (forward + backward | re-pack + Adam) around one eager flat gradient all-reduce",
+                                      "select": "two hipGraphs (backbone + ContextNet + no-grad inference | heads + losses + backward + re-pack + Adam) around the host's proposal selection",
+                                      "select-split": "three hipGraphs (backbone + ContextNet + no-grad inference | heads + losses + backward | re-pack + Adam) around the host's proposal "
+                                                      "selection and one eager flat gradient all-reduce"}[w.graph_mode]
                                      if getattr(w, "graph", None) is not None else "eager"),
-                          "gradient_exchange": (("one flat all-reduce of the gradient arena between the two graphs, %s" if getattr(w, "graph_mode", None) == "split" else
+                          "gradient_exchange": (("one flat all-reduce of the gradient arena between the two graphs, %s" if getattr(w, "graph_mode", None) in ("split", "select-split") else
                                                  "bucketed all-reduce, %d buckets, overlapped with backward, %%s" % len(w.reducer.buckets)) %
                                                 ("one-rank RCCL group (forced)" if world == 1 else "%d ranks" % world))
                                                if getattr(getattr(w, "reducer", None), "active", False) else None},

@@ -213,6 +213,11 @@ def _repack_all(dtype, device):
         if u.perm is not None:
             perm = u._perm_dev.get(device)
             if perm is None:
+                if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                    import sys
+                    print("step_amd._repack_all: unit %s k=%s weight %s packed keys %s has no device permutation table yet (capturing): falling back" % (
+                        type(u.owner).__name__, u.k, tuple(w.shape), list(u._packed.keys())), file=sys.stderr)
+                    return False                                 # (a host -> device copy: not inside a graph capture; the caller packs its own weight)
                 perm = u._perm_dev[device] = u.perm.to(device=device, dtype=torch.int32).contiguous()
         for key, hit in list(u._packed.items()):             # (replicas on other devices add their images to the same dict)
             if key[0] != dtype or key[1] != device or hit[0] == ver:

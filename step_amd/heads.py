@@ -305,6 +305,10 @@ class TwoBranchNet(nn.Module):
                 w = torch.cat(ps[:3], 0)
                 b = torch.cat(ps[3:], 0)
             unit = ConvUnit((w, b), lambda o: o[0], (1, 1, 1), bias_fn=lambda o: o[1], perm=self._u_reg.perm)
+            # (the device copies of the permutation are shared with the differentiable unit: a training iteration whose no-grad inference
+            # runs after every optimizer step -- workloads.C4SelectTrainStep -- builds this unit anew each time, and inside a graph capture
+            # a fresh host -> device copy of the table is not allowed)
+            unit._perm_dev = self._u_reg._perm_dev
             self._reg_cache = (ver, unit)
         return self._reg_cache[1]
 

@@ -8,7 +8,7 @@ import torch
 
 from . import BaseNet, ContextNet, ROINet, TwoBranchNet
 from . import dist as sdist
-from .driver import GraphedInference, inference, postprocess
+from .driver import GraphedInference, inference, inference_flat, postprocess
 from .backbone import wgrad_into_grad
 from .optim import FlatAdam
 from .selection import train_select
@@ -282,10 +282,23 @@ class C4SelectTrainStep(C4TrainStep):
     gradients; an eval-mode, no-grad inference() over the first max_iter-1 steps to get the refined tubes; then for every
     step train_select() (step_amd.selection: the reference's sampling, same RNG streams) picks positives / negatives among
     them, ROIAlign pools the selected tubes, the step's head returns the three losses; one backward, one flat gradient
-    all-reduce, one fused Adam launch.  `targets`: 2 ground-truth tubes per clip with 3 positive classes each."""
+    all-reduce, one fused Adam launch.  `targets`: 2 ground-truth tubes per clip with 3 positive classes each.
 
-    def __init__(self, dev, batch=1, seed=123, dtype=torch.float32, tubes_per_clip=34):
-        super().__init__(dev, batch=batch, tubes_per_clip=5, seed=seed, max_iter=3, dtype=dtype)
+    Three forms of the same iteration:
+      step()          eager, ragged: every head sees exactly the selected tubes (shapes change from iteration to iteration)
+      step_padded()   eager, STATIC shapes: every clip's selection is padded to `budget` slots (max_pos_num x (1 + neg_ratio) = 15); padded
+                      slots carry a copy of the clip's first initial tube, all-zero targets and row weight 0 -- they receive exactly zero loss
+                      and zero gradient (the classification loss is the masked mean over the real rows, the regression losses are masked by
+                      their flags already)
+      capture()       the padded form replayed as HIP graphs: graph F = backbone + ContextNet forward (with gradients)
+                      + the no-grad inference; HOST: train_select on the inference's static outputs (one launch + one small copy per step,
+                      then the draws from `random` / `numpy.random` in the reference's order) writes the selection into static device
+                      buffers; graph B = ROIAlign + the three heads + losses + backward + re-pack + Adam (with a process group: B stops after
+                      backward, ONE eager flat all-reduce, graph U = re-pack + Adam -- the split form, nothing of the group is recorded).
+                      Same kernels on the same buffers as step_padded(): bit-identical trajectory (tests/test_gpu_graph_step.py)."""
+
+    def __init__(self, dev, batch=1, seed=123, dtype=torch.float32, tubes_per_clip=34, capturable=False, force_exchange=False, budget=None):
+        super().__init__(dev, batch=batch, tubes_per_clip=5, seed=seed, max_iter=3, dtype=dtype, capturable=capturable, force_exchange=force_exchange)
         rs = np.random.RandomState(seed)
         anchors = (generate_anchors()[:tubes_per_clip] * 400.0).astype(np.float32)
         self.init_tubes = [np.tile(anchors[:, None, :], (1, 3, 1)) for _ in range(batch)]
@@ -299,8 +312,28 @@ class C4SelectTrainStep(C4TrainStep):
                 t[g_, :, 4 + rs.randint(0, 60, 3)] = 1
             self.gt.append(t)
         self.selected = []
+        a = self.args
+        self.budget = int(budget or a.max_pos_num * (1 + a.neg_ratio))
+        # static state of the padded form
+        K = batch * self.budget
+        self.flat0, self.nums0 = _flat_tubes(self.init_tubes, dev)
+        self.clip_of0 = torch.as_tensor(np.repeat(np.arange(batch), self.nums0), device=dev)
+        self.clip_of_pad = torch.arange(batch, device=dev).repeat_interleave(self.budget)
+        self.s_flat, self.s_tgt, self.s_mask, self.s_inv = [], [], [], []
+        self.h_flat, self.h_tgt, self.h_mask, self.h_inv = [], [], [], []
+        for i in range(1, a.max_iter + 1):
+            Tl = a.NUM_CHUNKS[i] * a.T
+            for dst, host, shape in ((self.s_flat, self.h_flat, (K, Tl, 5)), (self.s_tgt, self.h_tgt, (K, 3, 6 + a.num_classes)),
+                                     (self.s_mask, self.h_mask, (K, 1)), (self.s_inv, self.h_inv, (1,))):
+                dst.append(torch.zeros(shape, device=dev))
+                host.append(torch.zeros(shape).pin_memory())
+        self._gF = self._gB = self._gU = None
+        self._front = None
 
+    # ---- the ragged eager iteration (the reference's program, shapes follow the selection)
     def step(self):
+        if self._gF is not None:
+            return self._replay()
         a = self.args
         cf = self.base(self.x)
         cx = self.ctx(cf)
@@ -331,4 +364,147 @@ class C4SelectTrainStep(C4TrainStep):
         scale = self.reducer.finish()
         self.opt.step(grad_scale=scale, zero_grad=True)
         self.loss = loss.detach()
+        return self.loss
+
+    # ---- the padded iteration in its three parts
+    def _front_part(self):
+        """backbone + ContextNet (with gradients) and the no-grad, eval-mode inference over the first max_iter - 1 steps (train.py:266-272)"""
+        a = self.args
+        cf = self.base(self.x)
+        cx = self.ctx(cf)
+        for m in self.mods:
+            m.eval()
+        with torch.no_grad():
+            history, _ = inference_flat(a, cf.detach(), cx.detach(), self.nets, a.max_iter - 1, self.flat0, self.nums0, self.clip_of0)
+        for m in self.mods:
+            m.train()
+        return cf, cx, history
+
+    def _select_part(self, history):
+        """HOST: train_select per step on the inference's outputs, padded to `budget` slots per clip, into the static device buffers"""
+        a = self.args
+        self.selected = []
+        B, Bu = self.batch, self.budget
+        for i in range(1, a.max_iter + 1):
+            Tl = a.NUM_CHUNKS[i] * a.T
+            sel, tgt = train_select(i, history[i - 2] if i > 1 else None, self.gt, self.init_tubes, a)
+            self.selected.append([len(s_) for s_ in sel])
+            hf, ht, hm = self.h_flat[i - 1].numpy(), self.h_tgt[i - 1].numpy(), self.h_mask[i - 1].numpy()
+            ht[...] = 0
+            hm[...] = 0
+            n_real = 0
+            for b in range(B):
+                n = len(sel[b])
+                if n > Bu:
+                    raise RuntimeError("C4SelectTrainStep: %d tubes selected for one clip, budget %d" % (n, Bu))
+                rows = slice(b * Bu, b * Bu + n)
+                pad = slice(b * Bu + n, (b + 1) * Bu)
+                hf[rows, :, 1:] = sel[b]
+                fill = np.asarray(self.init_tubes[b][0], np.float32)                  # a valid box for the padded slots' ROIAlign
+                if fill.shape[0] != Tl:                                               # (the last step's tubes are 3 chunks long)
+                    fill = np.tile(fill, (Tl // fill.shape[0] + 1, 1))[:Tl]
+                hf[pad, :, 1:] = fill
+                hf[b * Bu:(b + 1) * Bu, :, 0] = b * Tl + np.arange(Tl, dtype=np.float32)   # frame index inside cf[:, t0:t0+Tl] flattened over clips
+                ht[rows] = tgt[b]
+                hm[rows] = 1
+                n_real += n
+            self.h_inv[i - 1][0] = 1.0 / (max(n_real, 1) * a.num_classes)
+            self.s_flat[i - 1].copy_(self.h_flat[i - 1], non_blocking=True)
+            self.s_tgt[i - 1].copy_(self.h_tgt[i - 1], non_blocking=True)
+            self.s_mask[i - 1].copy_(self.h_mask[i - 1], non_blocking=True)
+            self.s_inv[i - 1].copy_(self.h_inv[i - 1], non_blocking=True)
+
+    def _loss_part(self, cf, cx):
+        a = self.args
+        loss = 0.0
+        K = self.batch * self.budget
+        for i in range(1, a.max_iter + 1):
+            chunks, max_chunks = a.NUM_CHUNKS[i], a.NUM_CHUNKS[a.max_iter]
+            t0 = int((max_chunks - chunks) / 2) * a.T
+            Tl = chunks * a.T
+            flat = self.s_flat[i - 1]
+            pooled = self.nets["roi_net"](cf[:, t0:t0 + Tl], flat)
+            pooled = pooled.reshape(K, Tl, *pooled.shape[1:])
+            o = self.heads[i - 1](pooled, context_feat=cx[self.clip_of_pad][:, :, t0:t0 + Tl], tubes=flat, targets=self.s_tgt[i - 1])
+            # o[4]: the element-wise classification loss [K * classes]; the reference's .mean() runs over the REAL rows only
+            lcls = (o[4].view(K, -1) * self.s_mask[i - 1]).sum() * self.s_inv[i - 1][0]
+            loss = loss + lcls + a.lambda_reg * o[5].mean() + a.lambda_neighbor * o[6].mean()
+        return loss
+
+    def _back_part(self, cf, cx, update=True):
+        loss = self._loss_part(cf, cx)
+        exchange = update                                        # (split form: the exchange is eager, between the graphs)
+        if exchange:
+            self.reducer.begin()
+        with wgrad_into_grad():
+            loss.backward()
+        if update:
+            scale = self.reducer.finish()
+            self.opt.step(grad_scale=scale, zero_grad=True)
+        self.loss = loss.detach()
+        return self.loss
+
+    def step_padded(self):
+        cf, cx, hist = self._front_part()
+        self._select_part(hist)
+        return self._back_part(cf, cx)
+
+    def _eager_step(self):                                       # (what bench.py instruments for the per-kernel roofline)
+        return self.step_padded()
+
+    def capture(self, warmup=2, mode="auto"):
+        """See the class docstring.  With a process group the update is a graph of its own behind ONE eager flat all-reduce (the split
+        form of C4TrainStep.capture: nothing of the group is recorded)."""
+        if not self.opt.capturable:
+            raise RuntimeError("C4SelectTrainStep.capture: build the workload with capturable=True")
+        import gc
+        dd = torch.distributed
+        grouped = self.reducer.active
+        gc.collect()
+        dev = self.x.device
+        cur = torch.cuda.current_stream(dev)
+        s = torch.cuda.Stream(dev)
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            for _ in range(max(int(warmup), 2)):
+                self.step_padded()
+        cur.wait_stream(s)
+        torch.cuda.synchronize(dev)
+        kw = {"capture_error_mode": "thread_local"} if grouped else {}
+        gF = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gF, **kw):
+            self._front = self._front_part()
+        pool = gF.pool()
+        cf, cx, hist = self._front
+        gF.replay()                                              # (a capture records, it does not run: give the selection real predictions to read)
+        torch.cuda.synchronize(dev)
+        import random
+        rs_py, rs_np = random.getstate(), np.random.get_state()  # this selection trains nothing: it must not consume draws of the reference's RNG streams
+        self._select_part(hist)
+        random.setstate(rs_py)
+        np.random.set_state(rs_np)
+        torch.cuda.synchronize(dev)
+        gB = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gB, pool=pool, **kw):
+            self._back_part(cf, cx, update=not grouped)
+        gU = None
+        if grouped:
+            world = dd.get_world_size() if (dd.is_available() and dd.is_initialized()) else 1
+            gU = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gU, pool=pool, **kw):
+                self.opt.step(grad_scale=1.0 / world, zero_grad=True)
+        self._gF, self._gB, self._gU = gF, gB, gU
+        self.graph, self.graph_mode = gF, ("select-split" if grouped else "select")
+        torch.autograd.graph.increment_version(self.params)
+        return self
+
+    def _replay(self):
+        self.opt._refresh_tables()
+        self._gF.replay()
+        self._select_part(self._front[2])                        # host: reads the inference's static outputs (one small copy per step)
+        self._gB.replay()
+        if self._gU is not None:
+            sdist.allreduce_flat(self.opt.flat_grad)
+            self._gU.replay()
+        torch.autograd.graph.increment_version(self.params)
         return self.loss

@@ -369,7 +369,21 @@ def test_train_step_amd_launcher_two_ranks():
         s = summ[0]
         assert s["world_size"] == world and s["global_batch"] == world and s["clips_per_rank"] == 1 and s["feed"] == "u8"
         assert s["adam_steps"] == 6 and np.isfinite(s["final_loss"]) and s["final_loss"] > 0 and s["ms_per_iter"] > 0
-        assert s["launch"].startswith("hipGraph replay") and (("split" in s["launch"]) == (world == 2 and not two))
+        assert s["launch"].startswith("hipGraph replay") and (("split" in s["launch"]) == (world == 2))   # (with a process group the default capture records nothing of it)
         assert (s["gradient_exchange"] is not None) == (world == 2)
         logs = [ln for ln in lines if "iter" in ln]
         assert [ln["iter"] for ln in logs] == [2, 4] and abs(logs[1]["lr"] - 0.1 * logs[0]["lr"]) < 1e-12     # the schedule reached the captured Adam's tables
+    # --select: the reference's WHOLE iteration (no-grad inference + train_select between the steps) as graphs around the host's selection
+    # (workloads.C4SelectTrainStep.capture); two ranks: + one eager flat all-reduce between the backward graph and the update graph
+    for world in (2, 1):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(root, "train_step_amd.py"), "--iters", "3", "--warmup-iters", "2", "--log-every", "0",
+               "--select"] + ([] if (two or world == 1) else ["--backend", "gloo"])
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=root)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        summ = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{") and json.loads(ln).get("summary")]
+        assert len(summ) == 1, r.stdout[-2000:]
+        s = summ[0]
+        assert s["world_size"] == world and s["adam_steps"] == 5 and np.isfinite(s["final_loss"]) and s["final_loss"] > 0
+        assert s["launch"] == "hipGraph replay (%s)" % ("select-split" if world == 2 else "select"), s
+        assert (s["gradient_exchange"] is not None) == (world == 2)

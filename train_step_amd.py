@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--lr-decay-every", type=int, default=0, help="> 0: multiply every group's lr by 0.1 every that many iterations (scheduler stand-in)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--graph", default="auto", choices=["auto", "one", "split"])
+    ap.add_argument("--select", action="store_true",
+                    help="the reference's whole iteration (train.py:257-348): no-grad inference + train_select between the steps (workloads.C4SelectTrainStep, "
+                         "captured as graphs around the host's selection)")
     ap.add_argument("--feed", default="none", choices=["none", "u8"])
     ap.add_argument("--log-every", type=int, default=10)
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
@@ -67,11 +70,18 @@ def main():
                          "equal to the single-process loss, SURVEY 8e)")
     tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
     graphed = not a.no_graph and a.dtype != "f32"               # (the fp32 step is GPU-bound and measured slower replayed than eager)
-    w = workloads.C4TrainStep(dev, batch=len(mine), tubes_per_clip=a.tubes, seed=123 + rank, dtype=tdt, capturable=graphed)
+    if a.select:
+        import random
+        import numpy as np
+        random.seed(1000 + rank)                                 # (the selection draws from the reference's two host RNG streams)
+        np.random.seed(1000 + rank)
+        w = workloads.C4SelectTrainStep(dev, batch=len(mine), seed=123 + rank, dtype=tdt, capturable=graphed)
+    else:
+        w = workloads.C4TrainStep(dev, batch=len(mine), tubes_per_clip=a.tubes, seed=123 + rank, dtype=tdt, capturable=graphed)
     for g in w.opt.param_groups:
         g["lr"] = a.lr
     if graphed:
-        w.capture(warmup=a.warmup_iters, mode=a.graph)
+        w.capture(warmup=a.warmup_iters, mode=a.graph)             # (C4SelectTrainStep: its own graph forms; `mode` only matters for the fixed-tube step)
     else:
         for _ in range(a.warmup_iters):
             w.step()
@@ -141,7 +151,7 @@ def _exchange_label(w, world):
         return None
     backend = torch.distributed.get_backend()
     lib = "RCCL" if backend == "nccl" else backend
-    if getattr(w, "graph_mode", None) == "split":
+    if getattr(w, "graph_mode", None) in ("split", "select-split"):
         return "one eager flat %s all-reduce of the gradient arena between the two graphs, %d ranks" % (lib, world)
     where = "recorded in the step's graph" if w.graph is not None else "eager, overlapped with backward"
     return "bucketed %s all-reduce, %d buckets, %s, %d ranks" % (lib, len(w.reducer.buckets), where, world)
