@@ -311,13 +311,17 @@ class EffClock:
     Unlike the DPM state the driver reports (ClockSampler), this is the clock the CUs really ran at while the loop's kernels
     executed around the sampler wave.  median / p5 / p95 over all samples, GHz."""
 
-    def __init__(self, dev, slots=64, wgs=8, ticks=5000):
+    def __init__(self, dev, slots=64, wgs=8, ticks=5000, stream=None):
         import ctypes
         from step_amd import _capi, _lib
         self.L, self._capi, self._lib, self.ct = _lib.lib(), _capi, _lib, ctypes
         self.dev, self.slots, self.wgs, self.ticks = dev, slots, wgs, ticks
         self.buf = torch.zeros(slots * wgs * 2, dtype=torch.int64, device=dev)
-        self.stream = torch.cuda.Stream(priority=-1)
+        # `stream`: an EXISTING stream that is idle or lightly used beside the loop (bench.py hands over the second batch's stream).  Creating
+        # streams here is not harmless: HIP maps streams onto a few hardware queues in creation order, and three extra priority streams in
+        # front of the fed loop's copy stream made that stream share a queue with a compute stream -- the fed rate fell from ~6.9 k to 4.8 k
+        # clips/s (round 6, call c12; the aliasing itself: tools/feed_probe.py, round 5)
+        self.stream = stream if stream is not None else torch.cuda.Stream()
         self.n = 0
 
     def sample(self):
@@ -530,7 +534,7 @@ def fed_loop(a, net, flights, x, dev, tdt, dist, resident_s_per_step):
     # queues, and a copy stream that shares a queue with a compute stream waits behind that stream's whole captured step (measured,
     # tools/feed_probe.py: 4.5 k clips/s fed with an aliased copy stream, 6.8 k with streams of their own, 7.2 k resident)
     streams = [torch.cuda.Stream() for _ in range(nfl)]
-    copy_stream = torch.cuda.Stream(priority=-1)
+    copy_stream = torch.cuda.Stream(priority=int(os.environ.get("STEP_FEED_PRIO", "-1")))   # (STEP_FEED_PRIO: A/B aid of tools/r06_fed_call.sh)
     ev_copied = [torch.cuda.Event() for _ in range(nfl)]
     ev_free = [torch.cuda.Event() for _ in range(nfl)]             # the staging buffer may be overwritten
     nbytes = hosts[0].numel()
@@ -917,7 +921,7 @@ def main():
                 dist.all_reduce(tp, op=dist.ReduceOp.MAX)
                 pilot = float(tp.item())
             a.steps, a.warmup = max(keep_steps, int(a.sustained_seconds * 1.1 / pilot) + 1), 0
-            ec_s = EffClock(dev)
+            ec_s = EffClock(dev, stream=flights[1][0] if nfl > 1 else None)
             every_s = max(1, a.steps // ec_s.slots)
             _timed_hook[0] = lambda k: ec_s.sample() if k % every_s == 0 else None
             with ClockSampler(local_dev) as cs:
@@ -937,7 +941,7 @@ def main():
         if nfl > 1:
             keep_steps, keep_warm = a.steps, a.warmup
             a.steps, a.warmup = max(keep_steps, int(0.5 / max(el / keep_steps, 1e-5)) + 1), 0
-            ec = EffClock(dev)
+            ec = EffClock(dev, stream=flights[1][0])                # (the second batch's stream: idle in this loop)
             every = max(1, a.steps // ec.slots)
             _timed_hook[0] = lambda k: ec.sample() if k % every == 0 else None
             timed(1)

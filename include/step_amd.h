@@ -106,7 +106,8 @@ enum {
     STEP_OPT_CONV_PERSIST,     /*  1 (default): one-channel-group conv_tap launches of more than one round of the chip run as a PERSISTENT tile loop, one workgroup per CU
                                     (no relaunch gap, the weight ring never drains, the next tile's halo is requested before the current tile's epilogue) where the
                                     library has that form (the fused conv3d_2b -> conv3d_2c -> maxPool3d_3a call) and STEP_OPT_THROUGHPUT is 0 (with two batches in
-                                    flight the static tile assignment measured 0.2-0.5 % slower) | 0: one workgroup per tile (bit-identical) */
+                                    flight the static tile assignment measured 0.2-0.5 % slower) | 2: also under the throughput profile (A/B runs) | 0: one workgroup per tile
+                                    (bit-identical) */
     STEP_OPT_COUNT_
 };
 STEP_API int step_set_option(int option, int value);

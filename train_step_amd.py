@@ -92,7 +92,10 @@ def main():
         g_ = torch.Generator().manual_seed(999 + rank)
         host = [torch.randint(0, 256, (N, T, H, W, 3), dtype=torch.uint8, generator=g_).pin_memory() for _ in range(2)]
         stage = [torch.empty((N, T, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
-        copy_stream = torch.cuda.Stream(priority=-1)             # own hardware queue: never behind the captured step (tools/feed_probe.py)
+        # a stream of its own at DEFAULT priority.  (Round 5 gave it high priority, as bench.py's forward-only fed loop does; beside the captured
+        # TRAINING step -- whose graph forks onto side streams -- a high-priority stream that spends its time waiting on the main stream made
+        # the whole iteration 3x slower: 40.3 against 13.6 ms, tools/feed_train_probe.py, profiles/r06_feed_train_probe.txt)
+        copy_stream = torch.cuda.Stream()
         copied = [torch.cuda.Event() for _ in range(2)]
         main_stream = torch.cuda.current_stream()
 
