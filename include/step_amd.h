@@ -104,10 +104,8 @@ enum {
                                     a block's pointwise conv is launched on its own instead of riding in the 3x3x3 members' grid (the other batch fills the idle CUs; measured
                                     C2 +1.3 % at two in flight, -2.2 % one batch at a time).  Same bits either way */
     STEP_OPT_CONV_PERSIST,     /*  1 (default): one-channel-group conv_tap launches of more than one round of the chip run as a PERSISTENT tile loop, one workgroup per CU
-                                    (no relaunch gap, the weight ring never drains, the next tile's halo is requested before the current tile's epilogue) where the
-                                    library has that form (the fused conv3d_2b -> conv3d_2c -> maxPool3d_3a call) and STEP_OPT_THROUGHPUT is 0 (with two batches in
-                                    flight the static tile assignment measured 0.2-0.5 % slower) | 2: also under the throughput profile (A/B runs) | 0: one workgroup per tile
-                                    (bit-identical) */
+                                    (the weight ring never drains, the next tile's halo is requested inside the current tile's epilogue) where the library has that
+                                    form (the fused conv3d_2b -> conv3d_2c -> maxPool3d_3a call) | 0: one workgroup per tile (bit-identical) */
     STEP_OPT_COUNT_
 };
 STEP_API int step_set_option(int option, int value);

@@ -668,9 +668,9 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_
         // today the fused conv3d_2b -> 2c -> pool call (STEP_OPT_CONV_PERSIST = 0: one workgroup per tile; bit-identical)
         p.gpersist = 0;
         const long long slots_ = opt(STEP_OPT_CONV_SLOTS) > 0 ? opt(STEP_OPT_CONV_SLOTS) : 256;
-        // (not under the throughput profile: with two batches in flight the static tile assignment measured 0.2-0.5 % slower than one workgroup
-        // per tile -- 1.0696 against 1.0674 ms per C2 step -- while one batch at a time it is 0.25 % faster, gpurun_out/ab_c2.txt)
-        if (opt(STEP_OPT_CONV_PERSIST) != 0 && (opt(STEP_OPT_THROUGHPUT) == 0 || opt(STEP_OPT_CONV_PERSIST) == 2) && groups == 1 && pl.impl == 1 && pl.ph == 1 && pl.NB == 3 && p.pre_w && p.pool_row && tot > slots_)
+        // (measured with two batches in flight too: C2 1.0674 / 1.0708 ms without against 1.0696 / 1.0680 ms with -- inside the noise -- and
+        // C5, whose conv3d_2c is 21 rounds, 3.4772 -> 3.4168 ms: -1.7 %; gpurun_out/ab_c2.txt, ab_c15_*.txt)
+        if (opt(STEP_OPT_CONV_PERSIST) != 0 && groups == 1 && pl.impl == 1 && pl.ph == 1 && pl.NB == 3 && p.pre_w && p.pool_row && tot > slots_)
             p.gpersist = (int)(slots_ / 8 * 8 > 0 ? slots_ / 8 * 8 : 8);
         return dim3((unsigned)p.gcount);
     };
@@ -1274,7 +1274,7 @@ int step_conv_pre_pool_plan_info(const step_conv_desc* d, int* info, int n) {
         const int tgroups = ceil_div(ceil_div(canon.Cout, 32), 2);
         if (opt(STEP_OPT_CONV_TAIL) != 0 && pl.NB > 1 && pl.mtiles > slots_ && tail > 0 && tail * 4 <= slots_ && tail * tgroups <= slots_) main_tiles -= tail;
         const bool one_group = ceil_div(ceil_div(canon.Cout, 32), 2 * pl.NB) == 1;
-        info[12] = (opt(STEP_OPT_CONV_PERSIST) != 0 && (opt(STEP_OPT_THROUGHPUT) == 0 || opt(STEP_OPT_CONV_PERSIST) == 2) && one_group && pl.NB == 3 && main_tiles > slots_) ? (int)(slots_ / 8 * 8 > 0 ? slots_ / 8 * 8 : 8) : 0;
+        info[12] = (opt(STEP_OPT_CONV_PERSIST) != 0 && one_group && pl.NB == 3 && main_tiles > slots_) ? (int)(slots_ / 8 * 8 > 0 ? slots_ / 8 * 8 : 8) : 0;
     }
     return STEP_OK;
 }

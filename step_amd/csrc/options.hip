@@ -27,7 +27,7 @@ constexpr OptSpec SPEC[STEP_OPT_COUNT_] = {
     {"clip_vec", 1, 0, 1},
     {"conv_nb_rule", 0, 0, 1},
     {"throughput", 0, 0, 1},
-    {"conv_persist", 1, 0, 2},
+    {"conv_persist", 1, 0, 1},
 };
 std::atomic<int> g_delta[STEP_OPT_COUNT_];      // value - default: zero-initialised static storage IS the default table
 }  // namespace

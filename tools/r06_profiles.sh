@@ -11,8 +11,8 @@ prof() { n=$1; shift
   python $R/tools/prof_summary.py $O/prof_$n $O/r06p_${n}_kernel_stats.txt > /dev/null 2>&1
   if [ "$n" = "c2" ]; then python $R/tools/graph_timeline.py $O/prof_$n > $O/r06p_c2_graph_timeline.txt 2>&1; fi
   rm -rf $O/prof_$n; }
-prof c2 --steps 60 --warmup 10 --in-flight 1 --no-cpu-baseline --sustained-seconds 0
-prof c2_two --steps 60 --warmup 10 --no-cpu-baseline --sustained-seconds 0
+prof c2 --steps 60 --warmup 10 --in-flight 1 --no-cpu-baseline --sustained-seconds 0 --no-fp16-leg
+prof c2_two --steps 60 --warmup 10 --no-cpu-baseline --sustained-seconds 0 --no-fp16-leg
 prof c5 --config c5 --steps 20 --warmup 5 --no-cpu-baseline --sustained-seconds 0
 prof c3 --config c3 --steps 20 --warmup 5 --no-cpu-baseline --in-flight 1
 prof c3_34 --config c3 --tubes 34 --steps 20 --warmup 5 --no-cpu-baseline --in-flight 1
