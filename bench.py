@@ -435,6 +435,24 @@ def roofline(net, x, dtype_name):
     finally:
         ops.PROFILE, ops.PROFILE_LIMIT = None, None
     rec = [(name, flops, nbytes, max(times[k + 1] - times[k], 1e-4)) for k, (name, flops, nbytes, _, _) in enumerate(plan)]
+    # cross-check with HIP events (the contract's wording): the same step launched EAGERLY, every instrumented call bracketed by events on its
+    # launch stream, median of 7 passes.  Long kernels behind a long predecessor are exact (the host is far ahead); short ones carry the host's
+    # record -> launch gap.  Reported per kernel name as `events_avg_launch_ms` beside the prefix-graph figure.
+    ev = {}
+    try:
+        for _ in range(8):
+            ops.PROFILE, ops.PROFILE_LIMIT = [], None
+            with torch.no_grad():
+                net(x)
+            torch.cuda.synchronize()
+            for k, (name, _, _, q0, q1) in enumerate(ops.PROFILE):
+                ev.setdefault(k, []).append(q0.elapsed_time(q1))
+    finally:
+        ops.PROFILE, ops.PROFILE_LIMIT = None, None
+    ev_by_name = {}
+    for k, (name, _, _, _, _) in enumerate(plan):
+        v = sorted(ev.get(k, [0.0])[1:])
+        ev_by_name.setdefault(name, []).append(v[len(v) // 2] if v else 0.0)
     agg = {}
     for name, flops, nbytes, t in rec:
         a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
@@ -474,7 +492,9 @@ def roofline(net, x, dtype_name):
             ach = (nbytes / cnt) / (avg_ms * 1e-3) / 1e9
             out = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                    "frac": round(ach / PEAK_HBM_GBS, 4)}
+        evl = ev_by_name.get(name)
         out.update({"traffic": traffic, "launches_per_step": cnt // 3, "avg_launch_ms": round(avg_ms, 4),
+                    "events_avg_launch_ms": round(sum(evl) / len(evl), 4) if evl else None,
                     "share_of_gpu_time": round(ms / total_ms, 3),
                     "algorithmic_gflop_per_launch": round(flops / cnt / 1e9, 3),
                     "algorithmic_mb_per_launch": round(nbytes / cnt / 1e6, 3)})
