@@ -212,3 +212,20 @@ def test_deepcopy_owns_its_parameters_and_data_parallel_replicas_own_their_helpe
                 if isinstance(u, (backbone.ConvUnit, backbone._FusedPointwise)):
                     ru = vars(r)[k]
                     assert ru is not u and ru.owner is r and ru._src is u
+
+
+@pytest.mark.parametrize("config", ["c2", "c4"])
+def test_bench_rank_of_an_eight_gpu_launch_parses_its_arguments_and_environment(config):
+    """The driver's scaling run is `python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps K --warmup W`: every rank
+    reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.  Without a GPU a rank of that launch must get exactly as far as the device check
+    (arguments parsed, world size matched against --gpus, no spawn of its own), and a world size that contradicts --gpus must be named."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="3", LOCAL_RANK="3", WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--config", config] + (["--dtype", "bf16", "--select"] if config == "c4" else [])
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode != 0 and "needs a ROCm device" in (r.stderr + r.stdout), r.stderr[-800:]
+    env["WORLD_SIZE"] = "4"
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode != 0 and "--gpus 8 but WORLD_SIZE=4" in (r.stderr + r.stdout), r.stderr[-800:]
