@@ -772,7 +772,7 @@ def main():
                     help="c4: how the step is captured (workloads.C4TrainStep.capture): one graph incl. the RCCL collectives, or fwd/bwd + eager exchange + update")
     ap.add_argument("--select", action="store_true",
                     help="c4: the reference's WHOLE iteration (train.py:257-348): no-grad inference + train_select between the steps (workloads.C4SelectTrainStep)")
-    ap.add_argument("--feed", default="none", choices=["none", "u8"],
+    ap.add_argument("--feed", default=None, choices=["none", "u8"],
                     help="c2 / c5: additionally time the FED loop -- pinned host uint8 frames -> H2D on a copy stream -> step_clip_from_u8 -> the "
                          "captured step, double-buffered against the batches in flight; reported under 'fed' (value stays the resident-input loop)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
@@ -784,6 +784,10 @@ def main():
     c = CONFIGS[a.config]
     CLIPS_PER_GPU, T_IN, HW_IN, GFLOP_PER_CLIP, ACT_MB_PER_CLIP = a.clips or c["clips"], c["T"], c["HW"], c["gflop"], c["act_mb"]
     a.dtype = a.dtype or c["dtype"]
+    if a.feed is None:
+        # the headline config also times the FED loop by default on ONE GPU (the driver's command has no --feed); with several
+        # ranks it stays opt-in (`--feed u8`): the scaling run's line must not depend on a loop that has never run on more than one device
+        a.feed = "u8" if (a.config == "c2" and a.gpus == 1) else "none"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -184,6 +184,19 @@ def batchnorm_train(z, bn, relu):
     return _BatchNormTrainFn.apply(z, bn.weight, bn.bias, bn, relu)
 
 
+class _PermuteColsFn(torch.autograd.Function):
+    """w[:, perm] for a permutation `perm` of the columns (inv = its inverse): forward and backward are both gathers."""
+
+    @staticmethod
+    def forward(ctx, w, perm, inv):
+        ctx.inv = inv
+        return w.index_select(1, perm)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.index_select(1, ctx.inv), None, None
+
+
 BATCH_PACK = True        # one-launch re-pack of every stale weight image (False: each unit packs its own; module switch for tests)
 _UNITS = weakref.WeakSet()     # every live ConvUnit: an optimizer step stales all their packed images at once
 _TABLES = {}                   # (dtype, device) -> (signature, device table, [(unit, cache key)]) of the last batched re-pack
@@ -328,7 +341,23 @@ class ConvUnit:
             pl = self._perm_dev.get((w.device, "long"))          # (cached: a host tensor would be copied -- and waited for -- per call)
             if pl is None:
                 pl = self._perm_dev[(w.device, "long")] = self.perm.to(device=w.device, dtype=torch.long)
-            w = w.index_select(1, pl)
+            if torch.is_grad_enabled() and w.requires_grad:
+                # differentiable path: the gather is a PERMUTATION, so its backward is the gather with the inverse permutation -- autograd's own
+                # backward of index_select is an atomic index_add_ (38 us per 60 x 12544 classifier weight and step in the round-6 trace, and a
+                # summation order the hardware picks, although every destination receives exactly one value)
+                inv = self._perm_dev.get((w.device, "inv"))
+                if inv is None:
+                    p_host = self.perm.detach().cpu().to(torch.long)
+                    if p_host.numel() == w.shape[1] and bool((torch.sort(p_host).values == torch.arange(p_host.numel())).all()):
+                        inv_h = torch.empty_like(p_host)
+                        inv_h[p_host] = torch.arange(p_host.numel())
+                        inv = inv_h.to(w.device)
+                    else:
+                        inv = False                              # (not a bijection of this weight's columns: autograd's index_select)
+                    self._perm_dev[(w.device, "inv")] = inv
+                w = _PermuteColsFn.apply(w, pl, inv) if inv is not False else w.index_select(1, pl)
+            else:
+                w = w.index_select(1, pl)
         return w.reshape(w.shape[0], w.shape[1], *self.k)
 
     def packed(self, dtype):

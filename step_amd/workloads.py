@@ -143,6 +143,14 @@ class C4TrainStep:
         self.batch, self.K = batch, K
         self.loss = None
 
+    @staticmethod
+    def _ctx_per_tube(cx, k):
+        """The clip's context feature for each of its k tubes (utils.py:55-57 indexes it per tube): with the SAME number of tubes per clip this
+        is a broadcast, whose backward is a fixed-order sum over the k copies -- `cx[clip_of]` is an index_select whose backward is an
+        atomic index_add (24 us x 6 per step in the round-6 trace, and the one place of the step whose summation order the hardware picks)."""
+        B = cx.shape[0]
+        return cx.unsqueeze(1).expand(B, k, *cx.shape[1:]).reshape(B * k, *cx.shape[1:])
+
     def forward_backward(self, exchange=False):
         """Losses of the three steps and their gradients (into FlatAdam's gradient arena); no update.  exchange=True overlaps
         the bucketed gradient all-reduce with the backward pass and leaves the averaging factor in self.scale."""
@@ -152,7 +160,7 @@ class C4TrainStep:
         for head, (Tl, t0, flat) in zip(self.heads, self.steps):
             pooled = self.nets["roi_net"](cf, flat)               # the frame-index column addresses frame b*9 + t of cf
             pooled = pooled.reshape(self.batch * self.K, Tl, *pooled.shape[1:])
-            o = head(pooled, context_feat=cx[self.clip_of][:, :, t0:t0 + Tl], tubes=flat, targets=self.targets)
+            o = head(pooled, context_feat=self._ctx_per_tube(cx, self.K)[:, :, t0:t0 + Tl], tubes=flat, targets=self.targets)
             loss = loss + o[4].mean() + 5 * o[5].mean() + o[6].mean()
         if exchange:
             self.reducer.begin()
@@ -425,7 +433,7 @@ class C4SelectTrainStep(C4TrainStep):
             flat = self.s_flat[i - 1]
             pooled = self.nets["roi_net"](cf[:, t0:t0 + Tl], flat)
             pooled = pooled.reshape(K, Tl, *pooled.shape[1:])
-            o = self.heads[i - 1](pooled, context_feat=cx[self.clip_of_pad][:, :, t0:t0 + Tl], tubes=flat, targets=self.s_tgt[i - 1])
+            o = self.heads[i - 1](pooled, context_feat=self._ctx_per_tube(cx, self.budget)[:, :, t0:t0 + Tl], tubes=flat, targets=self.s_tgt[i - 1])
             # o[4]: the element-wise classification loss [K * classes]; the reference's .mean() runs over the REAL rows only
             lcls = (o[4].view(K, -1) * self.s_mask[i - 1]).sum() * self.s_inv[i - 1][0]
             loss = loss + lcls + a.lambda_reg * o[5].mean() + a.lambda_neighbor * o[6].mean()
