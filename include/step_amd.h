@@ -423,6 +423,14 @@ STEP_API size_t step_stem_pool_workspace_bytes(int dtype, int N, int T, int H, i
 STEP_API int step_stem_pool_forward(int dtype, const void* x, int N, int T, int H, int W, const void* w_packed, const float* scale,
                                     const float* shift, int Cout, void* y, int y_cstride, int y_coff, void* ws, size_t ws_bytes,
                                     step_stream_t stream);
+/* The call in its two parts (what step_stem_pool_forward does in one): _tiles = the stem's launch (pooled tiles + their first rows / columns into
+ * ws), _finish = the seam pass over y and ws.  Same arguments and checks (finish: x is only checked, not read); callers that time the two
+ * launches separately (bench.py's per-kernel roofline) use these. */
+STEP_API int step_stem_pool_forward_tiles(int dtype, const void* x, int N, int T, int H, int W, const void* w_packed, const float* scale,
+                                          const float* shift, int Cout, void* y, int y_cstride, int y_coff, void* ws, size_t ws_bytes,
+                                          step_stream_t stream);
+STEP_API int step_stem_pool_finish(int dtype, const void* x, int N, int T, int H, int W, int Cout, void* y, int y_cstride, int y_coff, void* ws,
+                                   size_t ws_bytes, step_stream_t stream);
 /* The same call reading the decoder's uint8 frames [N,T,H,W,3] directly (device memory, 4-byte aligned): step_clip_from_u8's
  * normalisation -- scale 0 / 1 / 2, then (v - mean[c]) / std[c], data/augmentations.py:68-111 -- and the rounding to `dtype` happen
  * while the stem stages its frames (a 3 x 256-entry table built per workgroup with the same fp32 operations), so the normalised

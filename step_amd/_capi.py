@@ -5,7 +5,7 @@ import ctypes as C
 F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
 ROI_BWD_GATHER, ROI_BWD_ATOMIC = 0, 1
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 vp, fp, ip, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # raw device addresses
 i, f, ll, sz = C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -89,6 +89,8 @@ SIGNATURES = {
     "step_stem_forward": (i, [i, vp, i, i, i, i, vp, fp, fp, i, i, vp, i, i, vp]),
     "step_stem_pool_workspace_bytes": (sz, [i, i, i, i, i, i]),
     "step_stem_pool_forward": (i, [i, vp, i, i, i, i, vp, fp, fp, i, vp, i, i, vp, sz, vp]),
+    "step_stem_pool_forward_tiles": (i, [i, vp, i, i, i, i, vp, fp, fp, i, vp, i, i, vp, sz, vp]),
+    "step_stem_pool_finish": (i, [i, vp, i, i, i, i, i, vp, i, i, vp, sz, vp]),
     "step_stem_pool_forward_u8": (i, [i, vp, i, i, i, i, i, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, fp, fp, i, vp, i, i, vp, sz, vp]),
     "step_stem_kernel_name": (i, [i, C.c_char_p, i]),
     "step_stem_wgrad": (i, [i, vp, i, i, i, i, fp, i, fp, i, vp]),

@@ -1283,7 +1283,7 @@ int step_conv_pre_pool_plan_info(const step_conv_desc* d, int* info, int n) {
 __attribute__((visibility("default"))) void step_probe_set(void* buf) { step::g_probe_buf = (unsigned long long*)buf; }
 #endif
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 33; }
+int step_abi_version(void) { return 34; }
 
 }  // extern "C"
 

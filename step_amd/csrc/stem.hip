@@ -815,8 +815,9 @@ size_t step_stem_pool_workspace_bytes(int dtype, int N, int T, int H, int W, int
     return planes * ((size_t)ceil_div(Ho, 16) * Wo + (size_t)ceil_div(Wo, 16) * Ho) * Cout * 2 + 32;
 }
 
-int step_stem_pool_forward(int dtype, const void* x, int N, int T, int H, int W, const void* w_packed, const float* scale, const float* shift,
-                           int Cout, void* y, int y_cstride, int y_coff, void* ws, size_t ws_bytes, step_stream_t stream) {
+// parts: 1 = the stem launch (tiles + their first rows / columns), 2 = the seam pass, 3 = both
+static int stem_pool_forward_impl(int dtype, const void* x, int N, int T, int H, int W, const void* w_packed, const float* scale, const float* shift,
+                                  int Cout, void* y, int y_cstride, int y_coff, void* ws, size_t ws_bytes, int parts, step_stream_t stream) {
     if (N < 0 || T <= 0 || H <= 0 || W <= 0 || Cout <= 0) return STEP_E_SHAPE;
     if (y_coff < 0 || y_coff + Cout > y_cstride) return STEP_E_SHAPE;
     if (N == 0) return STEP_OK;
@@ -840,18 +841,36 @@ int step_stem_pool_forward(int dtype, const void* x, int N, int T, int H, int W,
 #endif
     const long long tiles = (long long)p.N * p.To * p.tiles_h * p.tiles_w;
     dim3 grid((unsigned)tiles, 1);
-    if (dtype == STEP_BF16) {
-        p.w = (const bf16_t*)w_packed + stem_stream_offset(Cout);
-        STEP_LAUNCH((stem_stream_kernel<bf16_t, 2, true, true>), grid, dim3(256), stream, p);
-    } else {
-        p.w = (const f16_t*)w_packed + stem_stream_offset(Cout);
-        STEP_LAUNCH((stem_stream_kernel<f16_t, 2, true, true>), grid, dim3(256), stream, p);
+    if (parts & 1) {
+        if (dtype == STEP_BF16) {
+            p.w = (const bf16_t*)w_packed + stem_stream_offset(Cout);
+            STEP_LAUNCH((stem_stream_kernel<bf16_t, 2, true, true>), grid, dim3(256), stream, p);
+        } else {
+            p.w = (const f16_t*)w_packed + stem_stream_offset(Cout);
+            STEP_LAUNCH((stem_stream_kernel<f16_t, 2, true, true>), grid, dim3(256), stream, p);
+        }
     }
-    if (p.tiles_h > 1 || p.tiles_w > 1) {
+    if ((parts & 2) && (p.tiles_h > 1 || p.tiles_w > 1)) {
         const long long items = ((long long)(p.tiles_h - 1) * p.Wp + (long long)(p.tiles_w - 1) * p.Hp) * (Cout / 8) * p.N * p.To;
         STEP_LAUNCH(stem_pool_fix_kernel, dim3(flat_grid(items, 256)), dim3(256), stream, p);
     }
     return STEP_LAUNCH_CHECK();
+}
+
+int step_stem_pool_forward(int dtype, const void* x, int N, int T, int H, int W, const void* w_packed, const float* scale, const float* shift,
+                           int Cout, void* y, int y_cstride, int y_coff, void* ws, size_t ws_bytes, step_stream_t stream) {
+    return stem_pool_forward_impl(dtype, x, N, T, H, W, w_packed, scale, shift, Cout, y, y_cstride, y_coff, ws, ws_bytes, 3, stream);
+}
+
+int step_stem_pool_forward_tiles(int dtype, const void* x, int N, int T, int H, int W, const void* w_packed, const float* scale, const float* shift,
+                                 int Cout, void* y, int y_cstride, int y_coff, void* ws, size_t ws_bytes, step_stream_t stream) {
+    return stem_pool_forward_impl(dtype, x, N, T, H, W, w_packed, scale, shift, Cout, y, y_cstride, y_coff, ws, ws_bytes, 1, stream);
+}
+
+int step_stem_pool_finish(int dtype, const void* x, int N, int T, int H, int W, int Cout, void* y, int y_cstride, int y_coff, void* ws, size_t ws_bytes,
+                          step_stream_t stream) {
+    // (x is only checked for alignment / presence by the shared argument checks: pass the clip the tiles launch read)
+    return stem_pool_forward_impl(dtype, x, N, T, H, W, x, nullptr, nullptr, Cout, y, y_cstride, y_coff, ws, ws_bytes, 2, stream);
 }
 
 int step_stem_pool_forward_u8(int dtype, const unsigned char* frames, int N, int T, int H, int W, int u8_scale, const float* mean3, const float* std3,

@@ -623,9 +623,22 @@ def stem_pool_forward(x, w_packed, Cout, scale, shift):
                 (x.numel() + out.numel() + Cout * 1029) * _ES[x.dtype])
 
     def launch():
-        _capi.check(L.step_stem_pool_forward(_dt(x), _lib.dptr(x), N, T, H, W, _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift), Cout,
-                                             _lib.dptr(out), Cout, 0, _lib.dptr(ws), wsb, _lib.stream_ptr(x.device)), "step_stem_pool_forward")
+        # (the call in its two parts -- the stem's launch, then the seam pass -- so that the instrumented legs time them separately, as for the
+        # fused conv3d_2c call: bench.py's roofline is the stem KERNEL's duration)
+        _capi.check(L.step_stem_pool_forward_tiles(_dt(x), _lib.dptr(x), N, T, H, W, _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift), Cout,
+                                                   _lib.dptr(out), Cout, 0, _lib.dptr(ws), wsb, _lib.stream_ptr(x.device)), "step_stem_pool_forward_tiles")
+
+    def finish():
+        _capi.check(L.step_stem_pool_finish(_dt(x), _lib.dptr(x), N, T, H, W, Cout, _lib.dptr(out), Cout, 0, _lib.dptr(ws), wsb, _lib.stream_ptr(x.device)),
+                    "step_stem_pool_finish")
+
+    def describe_finish():
+        th, tw = -(-Ho // 16), -(-Wo // 16)
+        seam = N * To * ((th - 1) * Wp + (tw - 1) * Hp) * Cout
+        rows = N * To * (th * Wo + tw * Ho) * Cout
+        return ("step::stem_pool_fix_kernel(step::StemParams)", 0.0, (2 * seam + rows) * _ES[x.dtype])
     _run(launch, describe)
+    _run(finish, describe_finish)
     return out
 
 
