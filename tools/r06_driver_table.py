@@ -1,0 +1,58 @@
+"""tools/r06_driver_table.py -- profiles/r06_driver_command.txt from the gpurun_out/driver_cmd_<lease>.json files of tools/r06_call.sh (round 6)."""
+import json
+import os
+import sys
+
+O = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+NOTES = {"c2": "before the amd-smi poller was joined (the contract window ran beside a live poller); stem row = stem + its seam pass",
+         "c5": "poller joined", "c6": "", "c10": "", "c21": "persistent form also under the throughput profile",
+         "c22": "HEAD; the stem call timed in its two parts (stem_pool_fix_kernel has a row of its own)"}
+rows = []
+for tag in ("c2", "c5", "c6", "c10", "c21", "c22"):
+    p = os.path.join(O, "driver_cmd_%s.json" % tag)
+    if os.path.exists(p) and os.path.getsize(p) > 10:
+        rows.append((tag, json.load(open(p))))
+out = ["# round 6, VERDICT r05 item 2: the driver's exact command -- `python3 bench.py --gpus 1 --steps 20 --warmup 5` -- on %d leases of the pool (fresh MI355X box each, tools/r06_call.sh)" % len(rows),
+       "# value = the contract window (two batches in flight), sustained = the same captured steps over >= 2 s right before it, one = the same K steps one batch at a time (after ~0.5 s of that loop),",
+       "# kt = sum of the per-launch durations of one step (prefix-graph differences), clocks = EFFECTIVE shader clock (step_clock_sample) beside the sustained loop / the one-batch loop / the prefix replays",
+       "%-5s %9s %9s %9s %8s %8s %9s %9s | %-22s | %s" % ("lease", "value", "sustained", "one", "one_ms", "kt_ms", "fp16", "fed", "clock GHz sus/one/pre", "note")]
+for tag, j in rows:
+    c = j.get("clock_ghz", {})
+    g = lambda k: (c.get(k) or {}).get("ghz_median")
+    out.append("%-5s %9.1f %9.1f %9.1f %8.4f %8.4f %9.1f %9s | %-22s | %s" % (
+        tag, j["value"], j["sustained"]["value"], j["one_batch_in_flight"]["value"], j["one_batch_in_flight"]["ms_per_step"], j["kernel_time_ms_per_step"],
+        (j.get("fp16") or {}).get("value", 0), ("%.1f" % j["fed"]["value"]) if j.get("fed") else "-", "%s / %s / %s" % (g("two_in_flight_sustained"), g("one_batch_loop"), g("prefix_graph_replays")), NOTES.get(tag, "")))
+out += ["", "# per-launch table of every lease (microseconds, launch order; conv_tap_pre_pool* = the conv3d_2b -> 2c -> pool CALL incl. its NB = 1 tail launch;",
+        "# the prefix-graph differences put the seam pass's ~14 us on the call in front of it: read the two rows together)"]
+keys = []
+for tag, j in rows:
+    seen = {}
+    for r in j["kernel_table"]:
+        k = r["kernel"].replace("void ", "").replace("_persist_kernel", "_kernel")
+        seen[k] = seen.get(k, 0) + 1
+        if (k, seen[k]) not in keys:
+            keys.append((k, seen[k]))
+# order keys as in the lease with most rows
+best = max(rows, key=lambda r: len(r[1]["kernel_table"]))[1]
+order, seen = [], {}
+for r in best["kernel_table"]:
+    k = r["kernel"].replace("void ", "").replace("_persist_kernel", "_kernel")
+    seen[k] = seen.get(k, 0) + 1
+    order.append((k, seen[k]))
+out.append("%-60s" % "kernel" + "".join("%8s" % t for t, _ in rows))
+for key in order:
+    line = "%-60s" % key[0][:59]
+    for tag, j in rows:
+        seen, val = {}, None
+        for r in j["kernel_table"]:
+            k = r["kernel"].replace("void ", "").replace("_persist_kernel", "_kernel")
+            seen[k] = seen.get(k, 0) + 1
+            if (k, seen[k]) == key:
+                val = r["us"]
+        line += "%8s" % ("-" if val is None else "%.1f" % val)
+    out.append(line)
+one = [j["one_batch_in_flight"]["ms_per_step"] for _, j in rows]
+out += ["", "# reading: the one-batch step spans %.3f-%.3f ms over the %d boxes (round 5: 1.227-1.235 on the builder's boxes, 1.45 on the driver's); no lease of this round shows the 1.45 ms box." % (min(one), max(one), len(rows)),
+        "# The spread between boxes sits in the full-grid matrix kernels (stem, the conv3d_2c call, the 3b / 3c grouped launches): the ~5 % box-to-box spread DESIGN.md has recorded since round 2."]
+open(os.path.join(os.path.dirname(O), "profiles", "r06_driver_command.txt"), "w").write("\n".join(out) + "\n")
+print("\n".join(out[:12]))
