@@ -27,7 +27,7 @@ __device__ __forceinline__ void mfma(f32x16& acc, const u16x8& a, const u16x8& b
     else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 
-template <int READS, bool AGPR>
+template <int READS, bool AGPR, int NM = 24>
 __global__ __launch_bounds__(512, 2) void k(unsigned long long* out, int iters) {
     __shared__ u16x8 lds[8192];                     // 128 KB
     for (int i = threadIdx.x; i < 8192; i += 512) {
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(512, 2) void k(unsigned long long* out, int iters) 
     const int grp = wave >> 2;                      // waves w and w + 4 share a SIMD
     f32x16 acc[6];
     for (int a = 0; a < 6; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = (float)(a + 1);
-    constexpr int NF = 20;
+    constexpr int NF = NM == 24 ? 20 : 30;         // fragments of a step: 2 taps x 2 k16 x (2 + 3), or three taps
     u16x8 f[NF];
     for (int q = 0; q < NF; ++q) f[q] = lds[(q * 512 + wave * 64 + lane) & 8191];
     __syncthreads();
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(512, 2) void k(unsigned long long* out, int iters) 
         const unsigned long long m0 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NM / 6; ++j)
 #pragma unroll
             for (int a = 0; a < 6; ++a) mfma<AGPR>(acc[a], f[(j * 5 + a % 3) % NF], f[(j * 5 + 3 + a / 3) % NF]);
         __builtin_amdgcn_s_setprio(0);
@@ -75,11 +75,11 @@ __global__ __launch_bounds__(512, 2) void k(unsigned long long* out, int iters) 
     if (s == 123.456f) out[0] = 0;
 }
 
-template <int READS, bool AGPR>
+template <int READS, bool AGPR, int NM = 24>
 static void run(int grid, int iters) {
     unsigned long long* d;
     hipMalloc(&d, sizeof(unsigned long long) * 3 * grid);
-    for (int w = 0; w < 20; ++w) k<READS, AGPR><<<grid, 512>>>(d, iters);
+    for (int w = 0; w < 20; ++w) k<READS, AGPR, NM><<<grid, 512>>>(d, iters);
     hipDeviceSynchronize();
     std::vector<unsigned long long> h(3 * grid);
     hipMemcpy(h.data(), d, sizeof(unsigned long long) * 3 * grid, hipMemcpyDeviceToHost);
@@ -92,8 +92,8 @@ static void run(int grid, int iters) {
     }
     auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
     const double g = med(ghz), hs = med(half), cp = med(cph), t = med(us);
-    printf("reads %2d  acc in %s: clock %.3f GHz | half-step %.0f cycles = %.3f us | wave 0's 24 MFMAs issue in %.0f cycles (%.1f per MFMA) | %.0f TFLOP/s\n",
-           READS, AGPR ? "AGPRs" : "VGPRs", g, hs, hs / g * 1e-3, cp, cp / 24.0, grid * 8.0 * 24 * 32768.0 * iters / (t * 1e-6) / 1e12);
+    printf("reads %2d  acc in %s: clock %.3f GHz | half-step %.0f cycles = %.3f us | wave 0's %d MFMAs issue in %.0f cycles (%.1f per MFMA) | %.0f TFLOP/s\n",
+           READS, AGPR ? "AGPRs" : "VGPRs", g, hs, hs / g * 1e-3, NM, cp, cp / NM, grid * 8.0 * NM * 32768.0 * iters / (t * 1e-6) / 1e12);
     hipFree(d);
 }
 
@@ -104,5 +104,7 @@ int main() {
     run<0, false>(grid, it); run<10, false>(grid, it); run<20, false>(grid, it); run<30, false>(grid, it);
     run<0, true>(grid, it); run<10, true>(grid, it); run<20, true>(grid, it); run<30, true>(grid, it);
     run<20, false>(grid, it);
+    // three taps per phase: 36 MFMAs out of 30 fragments between two phase switches
+    run<30, false, 36>(grid, it); run<20, false>(grid, it); run<30, false, 36>(grid, it);
     return 0;
 }
