@@ -6,9 +6,10 @@ import sys
 O = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 NOTES = {"c2": "before the amd-smi poller was joined (the contract window ran beside a live poller); stem row = stem + its seam pass",
          "c5": "poller joined", "c6": "", "c10": "", "c21": "persistent form also under the throughput profile",
-         "c22": "HEAD; the stem call timed in its two parts (stem_pool_fix_kernel has a row of its own)"}
+         "c22": "the stem call timed in its two parts (stem_pool_fix_kernel has a row of its own); fp16 leg behind the fed loop",
+         "c24": "fp16 leg on the bf16 loop's streams, still behind the fed loop", "c25": "HEAD: fp16 leg before the fed loop"}
 rows = []
-for tag in ("c2", "c5", "c6", "c10", "c21", "c22"):
+for tag in ("c2", "c5", "c6", "c10", "c21", "c22", "c24", "c25"):
     p = os.path.join(O, "driver_cmd_%s.json" % tag)
     if os.path.exists(p) and os.path.getsize(p) > 10:
         rows.append((tag, json.load(open(p))))
