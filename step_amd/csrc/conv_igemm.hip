@@ -498,7 +498,10 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true, int fo
         // step_conv_forward_ws; STEP_OPT_CONV_SPLITK = 0 disables)
         const bool splitk_ok = opt(STEP_OPT_CONV_SPLITK) != 0;
         const long long M = (long long)d->N * d->D * d->H * d->W;
-        if (splitk_ok && ov1 != 0 && d->Cin >= 512 && (d->Cin % 8) == 0 && M <= 1024 && pl.mtiles * nblk32 < 64) {     // (>= 512: the 1024-channel context half of global_cls on ~130 rows ran 37 us as two serial workgroups)
+        // rows: up to 4096 (round 6; 1024 until then).  The reference's default of 34 tubes per clip makes the last step's Linear layers 4 x 34 x 9 =
+        // 1224 rows: just past the old bound they fell onto the tiled kernel -- 20 workgroups walking K = 12544 one slab after the other, 233 us a
+        // launch, three launches = 11 % of the C3 step at 34 tubes (profiles/r06_c3_34_kernel_stats.txt)
+        if (splitk_ok && ov1 != 0 && d->Cin >= 512 && (d->Cin % 8) == 0 && M <= 4096 && pl.mtiles * nblk32 < 64) {     // (>= 512: the 1024-channel context half of global_cls on ~130 rows ran 37 us as two serial workgroups)
             pl.impl = 3;
             pl.mbk = M <= 32 ? 1 : (M <= 64 ? 2 : 4);
             const int KC16 = ceil_div(d->Cin, CK) * 2;

@@ -1245,7 +1245,7 @@ def case_conv_splitk_few_rows_deep_k(bk, golden):
     """The heads' Linear layers: a handful of rows, K in the thousands, 12 / 60 outputs -> K split over workgroups
     through the caller's workspace; without a workspace the tiled kernel must give the same numbers."""
     rs = np.random.RandomState(21)
-    for (rows, Cin, Cout) in ((5, 2056, 12), (70, 2048, 60)):          # ragged K (2056 = 128*16 + 8), 1 and 3 row blocks
+    for (rows, Cin, Cout) in ((5, 2056, 12), (70, 2048, 60), (1100, 1024, 12)):   # ragged K (2056 = 128*16 + 8), 1 and 3 row blocks; nine 128-row tiles (> 1024 rows: round 6)
         x = rs.randn(rows, Cin, 1, 1, 1).astype(np.float32)
         w = (rs.randn(Cout, Cin, 1, 1, 1) / np.sqrt(Cin)).astype(np.float32)
         shift = (0.2 * rs.randn(Cout)).astype(np.float32)

@@ -48,6 +48,8 @@ def test_planner_dispatch(lib):
     for dt in (BF, F32):
         n, ws = name(lib, dt, 132, 12544, 60, (1, 1, 1), 1, 1, 1)
         assert "pw_splitk_kernel" in n and ws > 0 and ws % 4 == 0
+    # ... and on the 1224 rows of the last refinement step at the reference's 34 tubes per clip (4 clips x 34 tubes x 9 frames)
+    assert "pw_splitk_kernel" in name(lib, BF, 1224, 12544, 60, (1, 1, 1), 1, 1, 1)[0]
     # tensors of >= 2^32 elements fall back to the 64-bit-offset kernel
     n, _ = name(lib, BF, 64, 64, 192, (3, 3, 3), 64, 512, 512)
     assert "conv_igemm_kernel" in n
