@@ -87,7 +87,8 @@ enum {
     STEP_OPT_CONV_IMPL = 0,    /* -1 auto | 0 tiled 4-wave kernel | 1 conv_tap, one tap per step | 2 conv_tap, two taps | 5 streaming pointwise GEMM for every 1x1x1 */
     STEP_OPT_CONV_NB,          /*  0 auto | 1..3 accumulator depth of conv_tap / conv_pw */
     STEP_OPT_CONV_WAVES,       /*  0 auto | 4 | 8 wavefronts per workgroup of conv_tap / conv_pw */
-    STEP_OPT_CONV_PHASED,      /*  1 (default) two-phase conv_tap for 16-bit 3x3x3 | 0 classic pipeline (bit-identical results) */
+    STEP_OPT_CONV_PHASED,      /*  2 (default) two-phase conv_tap for 16-bit 3x3x3 and, at NB <= 2 on general boxes, 1x3x3 windows | 1: 3x3x3 only | 0 classic pipeline
+                                    (bit-identical results) */
     STEP_OPT_CONV_GEN,         /*  93 (default): a general tile box when it needs <= this percent of the best power-of-two tiling's tiles; 0 never */
     STEP_OPT_CONV_GMODE,       /*  1 (default) conflict-free pixel assignment inside general boxes | 0 linear walk (bit-identical) */
     STEP_OPT_CONV_PWS,         /* -1 auto | 0 never | 1 wherever its contract allows: the weight-stationary pointwise stream (bit-identical) */

@@ -625,6 +625,10 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true, int fo
         if (d->dtype != STEP_F32 && pl.tps == 2 && k333) {
             pl.ph = opt(STEP_OPT_CONV_PHASED) ? 1 : 0;            // tests / A-B timing: 0 = the classic form
         }
+        // ... and the 1x3x3 windows of the heads on general boxes at NB <= 2 (round 6: launch_tap_ph_133, conv_tap_kernel.h).  Measured on the C3
+        // pipeline, variants alternating on one box (profiles/r06_ab_k133_two_phase.txt): 4 clips x 11 tubes 1 035-1 044 -> 1 053-1 055 clips/s
+        // (+1.4 %), x 34 tubes 657-663 -> 662-664, the C4 step unchanged.  STEP_OPT_CONV_PHASED = 1 keeps them on the classic form (A/B).
+        if (d->dtype != STEP_F32 && pl.tps == 2 && k133 && pl.twl == 0 && pl.NB <= 2 && opt(STEP_OPT_CONV_PHASED) == 2) pl.ph = 1;
         if (have4 && ov != 1 && (waves_env == 4 || (waves_env != 8 && prefer_four_waves(pl, p4, d)))) return p4;
         return pl;
     }

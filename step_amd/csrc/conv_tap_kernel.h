@@ -1186,8 +1186,23 @@ static int launch_tap_pre_pool(const ConvParams& p, int NB, dim3 grid, step_stre
     return STEP_LAUNCH_CHECK();
 }
 
+// ... and 1x3x3 windows (the heads' 2-D Bottleneck convs on plane-folded general boxes, round 6): 9 taps = four two-tap steps + one single-tap
+// step per slab (the padding tap is not multiplied), the odd step count alternates the ring parity per slab, so the slab body exists twice.  NB <= 2
+// only: NB = 1 allocates 164 VGPRs without a spill, NB = 2 256 with 18 spilled registers that are all touched OUTSIDE the steps (ISA checked: prologue,
+// slab switch, epilogue); NB = 3 spills 200 and stays on the classic form.
+template <typename T>
+static int launch_tap_ph_133(const ConvParams& p, int NB, dim3 grid, step_stream_t stream) {
+    switch (NB) {
+        case 1: STEP_LAUNCH((conv_tap_kernel<T, 0, 1, 1, 3, 3, 2, 2, 8, 1>), grid, dim3(512), stream, p); break;
+        case 2: STEP_LAUNCH((conv_tap_kernel<T, 0, 2, 1, 3, 3, 2, 2, 8, 1>), grid, dim3(512), stream, p); break;
+        default: return STEP_E_UNSUPPORTED;
+    }
+    return STEP_LAUNCH_CHECK();
+}
+
 template <typename T>
 int conv_tap_ph_launch_impl(const ConvPlan& pl, const ConvParams& p, int kd, dim3 grid, step_stream_t stream) {
+    if (kd == 1 && pl.ph == 1 && pl.twl == 0 && !p.pre_w) return launch_tap_ph_133<T>(p, pl.NB, grid, stream);
     if (kd != 3 || pl.ph != 1) return STEP_E_UNSUPPORTED;
     if (p.pre_w && p.pool_row) {                           // ... with the (1,3,3) / (1,2,2) max pool on the tile: the 4 x 8 x 8 tile form only
         if (pl.twl != 3) return STEP_E_UNSUPPORTED;

@@ -13,7 +13,7 @@ constexpr OptSpec SPEC[STEP_OPT_COUNT_] = {
     {"conv_impl", -1, -1, 5},
     {"conv_nb", 0, 0, 3},
     {"conv_waves", 0, 0, 8},
-    {"conv_phased", 1, 0, 1},
+    {"conv_phased", 2, 0, 2},
     {"conv_gen", 93, 0, 100},
     {"conv_gmode", 1, 0, 1},
     {"conv_pws", -1, -1, 1},

@@ -1133,7 +1133,7 @@ def case_conv_units_four_wave_form(bk, golden):
 
 def case_conv_units_two_phase_form(bk, golden):
     """The TWO-PHASE form of conv_tap_kernel (anti-phase wave groups: a step is a load phase and a multiply phase separated
-    by barriers, the two channel-half groups of the workgroup run them alternately; option conv_phased = 1, the default, selects it wherever
+    by barriers, the two channel-half groups of the workgroup run them alternately; option conv_phased >= 1 -- 2 is the default -- selects it wherever
     the 8-wave tap kernel runs in 16-bit storage): same shapes as the classic form, checked against the fp32 reference AND
     bit for bit against the classic form (the accumulation order is the same)."""
     buf = ctypes.create_string_buffer(256)
@@ -1171,6 +1171,32 @@ def case_conv_units_two_phase_form(bk, golden):
                 assert np.array_equal(got, y0), (case, float(np.abs(got - y0).max()))
             assert seen >= 4, seen
             _conv_case(bk, extra[0], (F16,))
+        # conv_phased = 2 (round 6): the two-phase form for 1x3x3 windows too (general boxes, NB <= 2: five steps per slab, the last a single tap,
+        # ring parity alternating per slab) -- bit for bit the classic form
+        with _capi.options(bk.lib, conv_phased=2):
+            seen2 = 0
+            for case in [c for c in cases if c[6] == (1, 3, 3)] + [(3, 72, 100, 1, 7, 7, (1, 3, 3))]:      # + the heads' plane-folded 7x7 maps, three slabs (odd count: both parities)
+                N, Cin, Cout, D, H, W, k = case
+                if case in classic:
+                    x, w, scale, shift, y0 = classic[case]
+                else:
+                    rs = np.random.RandomState(Cin * 7 + Cout)
+                    x = rs.randn(N, Cin, D, H, W).astype(np.float32)
+                    w = (rs.randn(Cout, Cin, *k) / np.sqrt(Cin * np.prod(k))).astype(np.float32)
+                    scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32)
+                    shift = (0.2 * rs.randn(Cout)).astype(np.float32)
+                    with _capi.options(bk.lib, conv_phased=0):
+                        y0 = run_conv(bk, x, w, scale, shift, BF16, x_pad=(8, 8), y_pad=(16, 8))
+                d = _capi.ConvDesc(dtype=BF16, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=1, kh=3, kw=3, x_cstride=Cin, x_coff=0,
+                                   y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+                info = (ctypes.c_int * 10)()
+                assert bk.lib.step_conv_plan_info(ctypes.byref(d), info, 10) == 0
+                if info[0] == 1 and info[1] == 0 and info[2] <= 2 and info[3] == 8:
+                    assert info[4] == 1, list(info)
+                    seen2 += 1
+                got = run_conv(bk, x, w, scale, shift, BF16, x_pad=(8, 8), y_pad=(16, 8))
+                assert np.array_equal(got, y0), (case, float(np.abs(got - y0).max()))
+            assert seen2 >= 1, seen2
 
 
 def case_tube_update(bk, golden):

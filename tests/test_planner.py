@@ -165,7 +165,7 @@ def test_options_api_and_no_environment(lib):
         assert _capi.get_option(lib, "conv_phased") == 0
         n4, _ = name(lib, BF, 8, 96, 208, (3, 3, 3), 8, 14, 14)
         assert n4.endswith(", 2, 4, 0>(step::ConvParams)"), n4
-    assert _capi.get_option(lib, "conv_phased") == 1 and _capi.get_option(lib, "conv_waves") == 0
+    assert _capi.get_option(lib, "conv_phased") == 2 and _capi.get_option(lib, "conv_waves") == 0
     assert name(lib, BF, 8, 96, 208, (3, 3, 3), 8, 14, 14)[0] == base
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for f in glob.glob(os.path.join(root, "step_amd", "csrc", "*.h*")):
