@@ -501,7 +501,9 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true, int fo
         // rows: up to 4096 (round 6; 1024 until then).  The reference's default of 34 tubes per clip makes the last step's Linear layers 4 x 34 x 9 =
         // 1224 rows: just past the old bound they fell onto the tiled kernel -- 20 workgroups walking K = 12544 one slab after the other, 233 us a
         // launch, three launches = 11 % of the C3 step at 34 tubes (profiles/r06_c3_34_kernel_stats.txt)
-        if (splitk_ok && ov1 != 0 && d->Cin >= 512 && (d->Cin % 8) == 0 && M <= 4096 && pl.mtiles * nblk32 < 64) {     // (>= 512: the 1024-channel context half of global_cls on ~130 rows ran 37 us as two serial workgroups)
+        // (the wider bound only where no streaming form exists, Cout < 64: a backbone layer such as 528 -> 128 on ONE clip's 1568 rows would otherwise
+        // change its K summation order with the batch size -- case_c2_full_size_properties holds a clip's features bit-identical across batches)
+        if (splitk_ok && ov1 != 0 && d->Cin >= 512 && (d->Cin % 8) == 0 && (M <= 1024 || (M <= 4096 && d->Cout < 64)) && pl.mtiles * nblk32 < 64) {     // (>= 512: the 1024-channel context half of global_cls on ~130 rows ran 37 us as two serial workgroups)
             pl.impl = 3;
             pl.mbk = M <= 32 ? 1 : (M <= 64 ? 2 : 4);
             const int KC16 = ceil_div(d->Cin, CK) * 2;
