@@ -107,6 +107,9 @@ enum {
     STEP_OPT_CONV_PERSIST,     /*  1 (default): one-channel-group conv_tap launches of more than one round of the chip run as a PERSISTENT tile loop, one workgroup per CU
                                     (the weight ring never drains, the next tile's halo is requested inside the current tile's epilogue) where the library has that
                                     form (the fused conv3d_2b -> conv3d_2c -> maxPool3d_3a call) | 0: one workgroup per tile (bit-identical) */
+    STEP_OPT_CONV_PWS_WAVES,   /*  0 (default): the weight-stationary pointwise stream runs sixteen waves per workgroup where that gives every wave at most ONE 32-pixel
+                                    group and eight waves do not (the 28x28 maps of 8 clips: 3136 groups), outside the throughput profile; eight otherwise | 8 | 16
+                                    (bit-identical) */
     STEP_OPT_COUNT_
 };
 STEP_API int step_set_option(int option, int value);

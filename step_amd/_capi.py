@@ -144,7 +144,7 @@ def check(status, what):
 # ---- planner options (include/step_amd.h: step_set_option) -----------------------------------------------------------
 OPTION_IDS = {name: k for k, name in enumerate((
     "conv_impl", "conv_nb", "conv_waves", "conv_phased", "conv_gen", "conv_gmode", "conv_pws", "conv_splitk", "conv_tail",
-    "conv_slots", "pool_direct", "wgrad_minpix", "wgrad16_lds", "conv_group_pw", "clip_vec", "conv_nb_rule", "throughput", "conv_persist"))}
+    "conv_slots", "pool_direct", "wgrad_minpix", "wgrad16_lds", "conv_group_pw", "clip_vec", "conv_nb_rule", "throughput", "conv_persist", "conv_pws_waves"))}
 
 
 def set_option(lib, name, value):

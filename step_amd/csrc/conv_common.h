@@ -220,6 +220,17 @@ template <> int conv_tap_group_launch<f16_t>(int twl, int NB, const ConvGroupPar
 template <typename T> int conv_pw_launch(int NB, int wv, const ConvParams& p, dim3 grid, step_stream_t stream);                        // conv_pw.hip
 template <typename T> int conv_pws_launch(int nbw, const ConvParams& p, dim3 grid, step_stream_t stream);                              // conv_pw.hip (weight-stationary stream, 16-bit)
 // conv_pws_kernel: nbw channel blocks per workgroup, KC16 16-channel chunks -> blocks per pass (<= 3: registers), 64-channel steps
+// sixteen waves per workgroup (conv_pw.hip, conv_pws_kernel<.., 16>) where eight would leave every wave with 1 .. 3 pixel groups: `gx` = pixel-axis
+// workgroups of the launch, M = rows.  STEP_OPT_CONV_PWS_WAVES: 0 auto | 8 | 16
+// Measured (round 6, profiles/r06_ab_pws_waves.txt): 28x28 maps of 8 clips (3136 groups on 2048 | 4096 waves) 3b 24.6 -> 21.8 us, 3c 35.4 -> 32.5 us, the
+// C2 step one batch at a time 1.2710 -> 1.2559 ms; 50x50 maps of 4 clips (2.75 groups per wave at eight: already balanced) 4-9 % SLOWER, and with two
+// batches in flight the step is 1.6 % slower (the other batch fills the imbalance anyway, and 1024-thread workgroups leave it no room): so only where
+// sixteen waves give every wave at most ONE group and eight do not, and not under the throughput profile.
+static inline bool pws_sixteen(long long M, long long gx) {
+    const int o = opt(STEP_OPT_CONV_PWS_WAVES);
+    const long long g = (M + 31) >> 5;
+    return o == 16 || (o == 0 && opt(STEP_OPT_THROUGHPUT) == 0 && g > gx * 8 && g <= gx * 16);
+}
 static inline void pws_shape(int nbw, int KC16, int& NB, int& S) {
     NB = nbw >= 3 ? 3 : nbw;
     if (nbw == 4) NB = 2;                                     // two even passes

@@ -1244,7 +1244,8 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
     else if (pl.impl == 4) {
         int nb, ksteps;
         pws_shape(pl.NB, ceil_div(d->Cin, CK) * 2, nb, ksteps);
-        snprintf(buf, (size_t)buflen, "void step::conv_pws_kernel<%s, %d, %d>(step::ConvParams, int)", t, nb, ksteps);
+        const bool w16 = pws_sixteen((long long)d->N * d->D * d->H * d->W, pl.mtiles);
+        snprintf(buf, (size_t)buflen, "void step::conv_pws_kernel<%s, %d, %d, %d>(step::ConvParams, int)", t, w16 ? (nb > 2 ? 2 : nb) : nb, ksteps, w16 ? 16 : 8);
     }
     else if (pl.impl == 2)
         snprintf(buf, (size_t)buflen, "void step::conv_pw_kernel<%s, %d, %d>(step::ConvParams)", t, pl.NB, pl.wv);

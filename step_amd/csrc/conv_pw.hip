@@ -139,8 +139,13 @@ constexpr int PWS_LDSW = 152 * 1024;                        // weight image: up 
 constexpr int PWS_WV = 8;
 constexpr int PWS_MAXB = 16;                                // channel blocks per workgroup
 
-template <typename T, int NB, int S>
-__global__ __launch_bounds__(PWS_WV * 64) void conv_pws_kernel(ConvParams p, int NBW) {
+// WV = 16 (round 6): sixteen waves per workgroup, ONE operand set (no prefetch of the next group: <= 128 VGPRs).  A wave's unit of work is a
+// 32-pixel group; with 8 waves per CU the 28x28 maps of C2 are 3136 groups on 2048 waves -- every wave waits for the ones that got two (1.53 on
+// average: a quarter of the launch is imbalance).  4096 waves take at most one group each, and the latency the prefetch hid is covered by the
+// other waves of the SIMD.
+template <typename T, int NB, int S, int WV = PWS_WV>
+__global__ __launch_bounds__(WV * 64) void conv_pws_kernel(ConvParams p, int NBW) {
+    constexpr bool DBUF = WV == 8;
     static_assert(sizeof(T) == 2, "16-bit storage types");
     typedef typename frag<T>::type frag_t;
     __shared__ __attribute__((aligned(16))) unsigned char lds[PWS_LDSW + 2 * PWS_MAXB * 32 * 4];
@@ -157,12 +162,12 @@ __global__ __launch_bounds__(PWS_WV * 64) void conv_pws_kernel(ConvParams p, int
     {                                                         // so that the chunk loop below has no run-time bound (no branches)
         const u32x4* src = (const u32x4*)((const unsigned char*)p.w + (size_t)nbw0 * KC16 * 1024);
         const u32x4 z = {0u, 0u, 0u, 0u};
-        for (int v = tid; v < nbwv * KCP * 64; v += PWS_WV * 64) {
+        for (int v = tid; v < nbwv * KCP * 64; v += WV * 64) {
             const int blk = v / (KCP * 64), rem = v % (KCP * 64), kc = rem >> 6;
             ((u32x4*)lds)[v] = kc < KC16 ? src[(blk * KC16 + kc) * 64 + (rem & 63)] : z;
         }
         float* sc = (float*)(lds + PWS_LDSW);
-        for (int i = tid; i < nbwv * 32; i += PWS_WV * 64) {
+        for (int i = tid; i < nbwv * 32; i += WV * 64) {
             const int co = nbw0 * 32 + i;
             sc[i] = (p.scale && co < p.Cout) ? p.scale[co] : 1.f;
             sc[PWS_MAXB * 32 + i] = (p.shift && co < p.Cout) ? p.shift[co] : 0.f;
@@ -172,12 +177,12 @@ __global__ __launch_bounds__(PWS_WV * 64) void conv_pws_kernel(ConvParams p, int
     const float* scl = (const float*)(lds + PWS_LDSW);
     const float* shl = scl + PWS_MAXB * 32;
     const long long ngroups = (p.Mtot + 31) >> 5;
-    const long long gstride = (long long)gridDim.x * PWS_WV;
+    const long long gstride = (long long)gridDim.x * WV;
     const T* xg = (const T*)p.x;
 
-    frag_t xa[2][S * 4];
+    frag_t xa[DBUF ? 2 : 1][S * 4];
     auto load_group = [&](auto setc, long long g) {
-        constexpr int SET = decltype(setc)::value;
+        constexpr int SET = DBUF ? decltype(setc)::value : 0;
         const long long gm = g * 32 + (lane & 31);
         const bool ok = g < ngroups && gm < p.Mtot;
         const T* xp = xg + (size_t)(ok ? gm : 0) * p.x_cstride + p.x_coff + 8 * khalf;
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(PWS_WV * 64) void conv_pws_kernel(ConvParams p, int
         }
     };
     auto group = [&](auto setc, long long g) {
-        constexpr int SET = decltype(setc)::value;
+        constexpr int SET = DBUF ? decltype(setc)::value : 0;
         const long long gm = g * 32 + (lane & 31);
         const bool ok = gm < p.Mtot;
         for (int b0 = 0; b0 < nbwv; b0 += NB) {
@@ -240,8 +245,15 @@ __global__ __launch_bounds__(PWS_WV * 64) void conv_pws_kernel(ConvParams p, int
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
-    long long g = (long long)blockIdx.x * PWS_WV + wave;
+    long long g = (long long)blockIdx.x * WV + wave;
     if (g >= ngroups) return;
+    if constexpr (!DBUF) {
+        for (; g < ngroups; g += gstride) {
+            load_group(I0(), g);
+            group(I0(), g);
+        }
+        return;
+    }
     load_group(I0(), g);
     while (true) {
         load_group(I1(), g + gstride);                        // (past the last group: no loads)
@@ -256,6 +268,15 @@ __global__ __launch_bounds__(PWS_WV * 64) void conv_pws_kernel(ConvParams p, int
 }
 
 template <typename T, int NB>
+static void conv_pws_launch_s16(int S, const ConvParams& p, int nbw, dim3 grid, step_stream_t stream) {
+    switch (S) {
+        case 1: STEP_LAUNCH((conv_pws_kernel<T, NB, 1, 16>), grid, dim3(1024), stream, p, nbw); break;
+        case 2: STEP_LAUNCH((conv_pws_kernel<T, NB, 2, 16>), grid, dim3(1024), stream, p, nbw); break;
+        case 3: STEP_LAUNCH((conv_pws_kernel<T, NB, 3, 16>), grid, dim3(1024), stream, p, nbw); break;
+        default: STEP_LAUNCH((conv_pws_kernel<T, NB, 4, 16>), grid, dim3(1024), stream, p, nbw); break;
+    }
+}
+template <typename T, int NB>
 static void conv_pws_launch_s(int S, const ConvParams& p, int nbw, dim3 grid, step_stream_t stream) {
     switch (S) {
         case 1: STEP_LAUNCH((conv_pws_kernel<T, NB, 1>), grid, dim3(PWS_WV * 64), stream, p, nbw); break;
@@ -269,6 +290,12 @@ template <typename T>
 int conv_pws_launch(int nbw, const ConvParams& p, dim3 grid, step_stream_t stream) {
     int NB, S;
     pws_shape(nbw, p.nchunks32 * 2, NB, S);
+    // sixteen waves where eight leave the waves with 1 .. 3 groups each (a fractional count is imbalance): option conv_pws_waves 0 auto | 8 | 16
+    if (pws_sixteen(p.Mtot, grid.x)) {
+        if (NB == 1) conv_pws_launch_s16<T, 1>(S, p, nbw, grid, stream);
+        else conv_pws_launch_s16<T, 2>(S, p, nbw, grid, stream);           // (NB <= 2: 128 VGPRs hold one operand set + two accumulator tiles)
+        return STEP_LAUNCH_CHECK();
+    }
     if (NB == 1) conv_pws_launch_s<T, 1>(S, p, nbw, grid, stream);
     else if (NB == 2) conv_pws_launch_s<T, 2>(S, p, nbw, grid, stream);
     else conv_pws_launch_s<T, 3>(S, p, nbw, grid, stream);

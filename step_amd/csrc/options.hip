@@ -28,6 +28,7 @@ constexpr OptSpec SPEC[STEP_OPT_COUNT_] = {
     {"conv_nb_rule", 0, 0, 1},
     {"throughput", 0, 0, 1},
     {"conv_persist", 1, 0, 1},
+    {"conv_pws_waves", 0, 0, 16},
 };
 std::atomic<int> g_delta[STEP_OPT_COUNT_];      // value - default: zero-initialised static storage IS the default table
 }  // namespace
@@ -44,6 +45,7 @@ int step_set_option(int option, int value) {
     if (option < 0 || option >= STEP_OPT_COUNT_) return STEP_E_SHAPE;
     if (value < SPEC[option].lo || value > SPEC[option].hi) return STEP_E_SHAPE;
     if (option == STEP_OPT_CONV_WAVES && value != 0 && value != 4 && value != 8) return STEP_E_SHAPE;
+    if (option == STEP_OPT_CONV_PWS_WAVES && value != 0 && value != 8 && value != 16) return STEP_E_SHAPE;
     if (option == STEP_OPT_CONV_IMPL && (value == 3 || value == 4)) return STEP_E_SHAPE;
     g_delta[option].store(value - SPEC[option].def, std::memory_order_relaxed);
     return STEP_OK;

@@ -2079,8 +2079,9 @@ def case_conv_pointwise_weight_stationary(bk, golden):
                 ca = split if split else Cout
                 sc, sh = bk.dev(scale), bk.dev(shift)
                 outs = {}
-                for mode in ("1", "0"):
-                    _capi.set_option(bk.lib, "conv_pws", int(mode))
+                for mode in ("1", "0", "16"):                                   # "16": the stream with sixteen waves per workgroup (one operand set)
+                    _capi.set_option(bk.lib, "conv_pws", int(mode != "0"))
+                    _capi.set_option(bk.lib, "conv_pws_waves", 16 if mode == "16" else 8)
                     ya = bk.dev(np.zeros((N, D, H, W, yp[0] + ca + yp[1]), NP_DT[dt]))
                     yb = bk.dev(np.zeros((N, D, H, W, 8 + (Cout - ca)), NP_DT[dt]))
                     d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=xb.shape[-1], x_coff=xp[0],
@@ -2088,7 +2089,9 @@ def case_conv_pointwise_weight_stationary(bk, golden):
                                        y2_cstride=8 + (Cout - ca), y2_coff=8)
                     name = ctypes.create_string_buffer(256)
                     assert bk.lib.step_conv_kernel_name(ctypes.byref(d), name, 256) == 0
-                    assert (b"conv_pws_kernel" in name.value) == (mode == "1" and Cin <= 256), (mode, name.value)   # (K <= 256: the whole K of a pixel group lives in registers)
+                    assert (b"conv_pws_kernel" in name.value) == (mode != "0" and Cin <= 256), (mode, name.value)   # (K <= 256: the whole K of a pixel group lives in registers)
+                    if mode != "0" and Cin <= 256:
+                        assert (b", 16>(" if mode == "16" else b", 8>(") in name.value, name.value
                     assert bk.lib.step_conv_forward(ctypes.byref(d), xe.ptr, wp.ptr, sc.ptr, sh.ptr, None, ya.ptr, yb.ptr if split else None,
                                                     bk.stream) == 0
                     a = decode(ya.get(), dt)
@@ -2101,9 +2104,10 @@ def case_conv_pointwise_weight_stationary(bk, golden):
                     outs[mode] = got
                     assert np.abs(got - ref).max() / np.abs(ref).max() < tol(dt), (mode, Cin, Cout, dt)
                 # same operands, same fp32 accumulation order along K: the two kernels agree to the last bit
-                assert np.array_equal(outs["1"], outs["0"]), (Cin, Cout, dt)
+                assert np.array_equal(outs["1"], outs["0"]) and np.array_equal(outs["1"], outs["16"]), (Cin, Cout, dt)
     finally:
         _capi.set_option(bk.lib, "conv_pws", -1)
+        _capi.set_option(bk.lib, "conv_pws_waves", 0)
 
 
 def case_pack_weight_perm_folds_flatten_order(bk, golden):
