@@ -226,6 +226,15 @@ template <typename T> int conv_pws_launch(int nbw, const ConvParams& p, dim3 gri
 // C2 step one batch at a time 1.2710 -> 1.2559 ms; 50x50 maps of 4 clips (2.75 groups per wave at eight: already balanced) 4-9 % SLOWER, and with two
 // batches in flight the step is 1.6 % slower (the other batch fills the imbalance anyway, and 1024-thread workgroups leave it no room): so only where
 // sixteen waves give every wave at most ONE group and eight do not, and not under the throughput profile.
+// Measured (round 6, profiles/r06_ab_pws_waves.txt): 28x28 maps of 8 clips (3136 groups on 2048 | 4096 waves) 3b 24.6 -> 21.8 us, 3c 35.4 -> 32.5 us, the
+// C2 step one batch at a time 1.2710 -> 1.2559 ms; 50x50 maps of 4 clips (2.75 groups per wave at eight: already balanced) 4-9 % SLOWER, and with two
+// batches in flight the step is 1.6 % slower (the other batch fills the imbalance anyway, and 1024-thread workgroups leave it no room): so only where
+// sixteen waves give every wave at most ONE group and eight do not, and not under the throughput profile.
+// the residual form (round 6): sixteen waves on request only until measured
+static inline bool pws_sixteen_res(long long M, long long gx) {
+    (void)M; (void)gx;
+    return opt(STEP_OPT_CONV_PWS_WAVES) == 16;
+}
 static inline bool pws_sixteen(long long M, long long gx) {
     const int o = opt(STEP_OPT_CONV_PWS_WAVES);
     const long long g = (M + 31) >> 5;

@@ -461,13 +461,16 @@ static ConvPlan conv_plan(const step_conv_desc* d, bool allow_pws = true, int fo
             const int KC16 = ceil_div(d->Cin, CK) * 2;
             const long long M = (long long)d->N * d->D * d->H * d->W;
             const bool can = d->dtype != STEP_F32 && (d->Cin % 8) == 0 && (d->x_cstride % 8) == 0 && (d->x_coff % 8) == 0 && KC16 <= 16 &&
-                             (d->y_cstride % 8) == 0 && (d->y_coff % 8) == 0 && (d->Cout % 8) == 0 && d->res_cstride == 0 &&
+                             (d->y_cstride % 8) == 0 && (d->y_coff % 8) == 0 && (d->Cout % 8) == 0 && (d->res_cstride % 8) == 0 && (d->res_coff % 8) == 0 &&
                              (d->split == 0 || ((d->split % 8) == 0 && (d->y2_cstride % 8) == 0 && (d->y2_coff % 8) == 0)) && M >= 1024;
             // measured (tools/ab_bench.py, bf16): it wins with K = 192 .. 256 and many channel blocks on a large map -- the 3c fused
             // triple 43.1 -> 37.4 us at 28x28 (batch 8), 65.2 -> 55.3 us at 50x50 (batch 4), and with the 16-byte register epilogue
             // (round 3) 34.2 / 48.7 us; the 3b triple (K = 192) 26.1 -> 24.3 us since that epilogue; equal or slower on conv3d_2b
             // and the narrow branch_3 layers: the default covers that class only
-            const bool wins = KC16 >= 12 && nblk32 >= 6 && M >= 65536;
+            // with a residual (round 6, the heads' Bottleneck conv3 256 -> 1024 at the reference's 34 tubes per clip: 59 976 rows) 124 -> 107 us
+            // (8-byte residual loads) -> see profiles/r06_ab_pws_heads.txt for the 16-byte form; 19 992 rows: 38 -> 42 us, and 256 -> 256 a tie
+            // at best: wide outputs on many rows only
+            const bool wins = d->res_cstride == 0 ? (KC16 >= 12 && nblk32 >= 6 && M >= 65536) : (KC16 >= 12 && nblk32 >= 16 && M >= 49152);
             if (allow_pws && can && pws_env != 0 && (pws_env == 1 || wins) && ov1 == -1) {
                 int nbmax = 152 / (ceil_div(KC16, 4) * 4);               // (LDS holds K padded to whole 64-channel steps)
                 if (nbmax > 16) nbmax = 16;
@@ -684,7 +687,7 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_
         return dim3((unsigned)p.gcount);
     };
     if (pl.impl == 4) {
-        if (!p.res && p.vec_epi)
+        if (p.vec_epi && (!p.res || ((p.r_cstride % 8) == 0 && (p.r_coff % 8) == 0 && ((uintptr_t)p.res % 16) == 0)))
             return conv_pws_launch<T>(pl.NB, p, dim3((unsigned)pl.mtiles, (unsigned)ceil_div(p.nblk32, pl.NB)), stream);
         pl = conv_plan(d, false);                               // (an output pointer off the 16-byte grid: the general kernels)
     }
@@ -1244,8 +1247,11 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
     else if (pl.impl == 4) {
         int nb, ksteps;
         pws_shape(pl.NB, ceil_div(d->Cin, CK) * 2, nb, ksteps);
-        const bool w16 = pws_sixteen((long long)d->N * d->D * d->H * d->W, pl.mtiles);
-        snprintf(buf, (size_t)buflen, "void step::conv_pws_kernel<%s, %d, %d, %d>(step::ConvParams, int)", t, w16 ? (nb > 2 ? 2 : nb) : nb, ksteps, w16 ? 16 : 8);
+        const long long M_ = (long long)d->N * d->D * d->H * d->W;
+        const bool w16 = d->res_cstride == 0 && pws_sixteen(M_, pl.mtiles);
+        if (d->res_cstride != 0) {
+            snprintf(buf, (size_t)buflen, "void step::conv_pws_kernel<%s, %d, %d, 8, true>(step::ConvParams, int)", t, nb, ksteps);
+        } else snprintf(buf, (size_t)buflen, "void step::conv_pws_kernel<%s, %d, %d, %d>(step::ConvParams, int)", t, w16 ? (nb > 2 ? 2 : nb) : nb, ksteps, w16 ? 16 : 8);
     }
     else if (pl.impl == 2)
         snprintf(buf, (size_t)buflen, "void step::conv_pw_kernel<%s, %d, %d>(step::ConvParams)", t, pl.NB, pl.wv);

@@ -143,7 +143,13 @@ constexpr int PWS_MAXB = 16;                                // channel blocks pe
 // 32-pixel group; with 8 waves per CU the 28x28 maps of C2 are 3136 groups on 2048 waves -- every wave waits for the ones that got two (1.53 on
 // average: a quarter of the launch is imbalance).  4096 waves take at most one group each, and the latency the prefetch hid is covered by the
 // other waves of the SIMD.
-template <typename T, int NB, int S, int WV = PWS_WV>
+// RES (round 6): a residual tensor added before the ReLU (the heads' Bottleneck conv3, 256 -> 1024 on 20-60 k rows: two_branch.py:60-84) -- each lane
+// loads the 8 bytes of its pixel x 4-channel accumulator groups BEFORE the multiply loop of the pass (the loop covers the latency).
+// depth of the weight-fragment ring (register quads in flight) per instantiation: what the register file leaves (no scratch)
+constexpr int pws_pf(int WV, int NB, int S, bool RES) {
+    return WV == 16 ? ((NB == 2 && S == 4) ? 2 : 4) : (RES ? ((NB == 3 && S == 4) ? 4 : 6) : 8);
+}
+template <typename T, int NB, int S, int WV = PWS_WV, bool RES = false>
 __global__ __launch_bounds__(WV * 64) void conv_pws_kernel(ConvParams p, int NBW) {
     constexpr bool DBUF = WV == 8;
     static_assert(sizeof(T) == 2, "16-bit storage types");
@@ -206,16 +212,59 @@ __global__ __launch_bounds__(WV * 64) void conv_pws_kernel(ConvParams p, int NBW
             const unsigned char* wb[NB];
 #pragma unroll
             for (int i = 0; i < NB; ++i) wb[i] = lds + ((size_t)min(b0 + i, nbwv - 1) * KCP * 64 + lane) * 16;   // (a surplus block repeats the last one and is not stored)
+            // (16 bytes per lane in the layout of the STORES below -- 8 channels at 16 h + 8 khalf -- and v_permlane32_swap, its own inverse,
+            // takes them back to the accumulators' layout in the epilogue: 8-byte loads of the 4-channel accumulator groups touched 32
+            // lines for 512 bytes per instruction, and the vector L1's line rate, not HBM, bounds this kernel: tools/ubench/l1_pattern.hip)
+            u32x4 rv[RES ? NB : 1][2];
+            if constexpr (RES) {
+                const T* rp = (const T*)p.res + (size_t)(ok ? gm : 0) * p.r_cstride + p.r_coff + nbw0 * 32 + 8 * khalf;
 #pragma unroll
-            for (int j = 0; j < KCP; ++j)
+                for (int i = 0; i < NB; ++i)
 #pragma unroll
-                for (int i = 0; i < NB; ++i) mma_k16(lds_read_bfrag<T>(wb[i] + j * 1024), xa[SET][j], acc[i], T());
+                    for (int h = 0; h < 2; ++h) {
+                        const int c8 = (b0 + i) * 32 + 16 * h;
+                        u32x4 r = {0u, 0u, 0u, 0u};
+                        if (ok && b0 + i < nbwv && nbw0 * 32 + c8 + 8 * khalf < p.Cout) r = *(const u32x4*)(rp + c8);
+                        rv[i][h] = r;
+                    }
+            }
+            // the weight fragments come from LDS PF multiplies ahead of their use (a ring of PF register quads, everything unrolled): written as
+            // `mma(read(j, i), ...)` the compiler kept two reads in flight and every MFMA waited out the LDS latency of its own operand -- with
+            // two waves per SIMD the multiply phase ran at a third of the pipe's rate (round 6: the 256 -> 1024 layer of 60 k rows without its
+            // stores 47.6 us against 17 us of MFMA time; tools/ab_bench.py, profiles/r06_ab_pws_heads.txt)
+            constexpr int NF = KCP * NB, PF = NF < pws_pf(WV, NB, S, RES) ? NF : pws_pf(WV, NB, S, RES);
+            frag_t wf[PF];
+#pragma unroll
+            for (int t = 0; t < PF; ++t) wf[t] = lds_read_bfrag<T>(wb[t % NB] + (t / NB) * 1024);
+#pragma unroll
+            for (int t = 0; t < NF; ++t) {
+                const frag_t cur = wf[t % PF];
+                if (t + PF < NF) wf[t % PF] = lds_read_bfrag<T>(wb[(t + PF) % NB] + ((t + PF) / NB) * 1024);
+#ifdef STEP_EXP_PWS_NOMMA                                      // (timing experiments, tools/ab_bench.py lib=...: never the product library)
+                if (t < NB) acc[t][0] += (float)xa[SET][KCP - 1][0] + (float)xa[SET][0][1] + (float)cur[0];
+#else
+                mma_k16(cur, xa[SET][t / NB], acc[t % NB], T());
+#endif
+#ifndef STEP_EMUL
+                __builtin_amdgcn_sched_barrier(0);            // (the scheduler otherwise sinks every read back to its use)
+#endif
+            }
             // epilogue (the planner sends only layers whose channel counts / offsets / pitches are multiples of 8 here): one
             // v_permlane32_swap per packed dword pair (register quads 2h, 2h + 1) hands the lower lane channels 16h .. 16h+7 and the
             // upper lane 16h+8 .. 16h+15 of its pixel (conv_tap_kernel.h, epilogue): 16-byte stores straight from registers
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 unsigned d[4][2];
+                unsigned rq[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+                if constexpr (RES) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        unsigned r0 = rv[i][h][0], r1 = rv[i][h][1], r2 = rv[i][h][2], r3 = rv[i][h][3];
+                        lane32_swap(r0, r2);
+                        lane32_swap(r1, r3);
+                        rq[2 * h][0] = r0; rq[2 * h][1] = r1; rq[2 * h + 1][0] = r2; rq[2 * h + 1][1] = r3;
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int c4 = (b0 + i) * 32 + 8 * q + 4 * khalf;
@@ -224,6 +273,7 @@ __global__ __launch_bounds__(WV * 64) void conv_pws_kernel(ConvParams p, int NBW
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[e] = acc[i][4 * q + e] * s4[e] + h4[e];
+                        if constexpr (RES) v[e] += elem<T>::from_bits16((unsigned short)(rq[q][e >> 1] >> (16 * (e & 1))));
                         if (p.relu) v[e] = fmaxf(v[e], 0.f);
                     }
                     d[q][0] = (unsigned)elem<T>::bits16(v[0]) | ((unsigned)elem<T>::bits16(v[1]) << 16);
@@ -234,7 +284,11 @@ __global__ __launch_bounds__(WV * 64) void conv_pws_kernel(ConvParams p, int NBW
                     lane32_swap(d[2 * h][0], d[2 * h + 1][0]);
                     lane32_swap(d[2 * h][1], d[2 * h + 1][1]);
                     const int co = nbw0 * 32 + (b0 + i) * 32 + 16 * h + 8 * khalf;
+#ifdef STEP_EXP_PWS_NOSTORE
+                    if (ok && b0 + i < nbwv && co < p.Cout && d[2 * h][0] == 0x7fc17fc1u) {
+#else
                     if (ok && b0 + i < nbwv && co < p.Cout) {
+#endif
                         const u32x4 o = {d[2 * h][0], d[2 * h][1], d[2 * h + 1][0], d[2 * h + 1][1]};
                         if (p.split > 0 && co >= p.split) *(u32x4*)((T*)p.y2 + (size_t)gm * p.y2_cstride + p.y2_coff + (co - p.split)) = o;
                         else *(u32x4*)((T*)p.y + (size_t)gm * p.y_cstride + p.y_coff + co) = o;
@@ -277,6 +331,15 @@ static void conv_pws_launch_s16(int S, const ConvParams& p, int nbw, dim3 grid, 
     }
 }
 template <typename T, int NB>
+static void conv_pws_launch_res(int S, const ConvParams& p, int nbw, dim3 grid, step_stream_t stream) {
+    switch (S) {
+        case 1: STEP_LAUNCH((conv_pws_kernel<T, NB, 1, PWS_WV, true>), grid, dim3(PWS_WV * 64), stream, p, nbw); break;
+        case 2: STEP_LAUNCH((conv_pws_kernel<T, NB, 2, PWS_WV, true>), grid, dim3(PWS_WV * 64), stream, p, nbw); break;
+        case 3: STEP_LAUNCH((conv_pws_kernel<T, NB, 3, PWS_WV, true>), grid, dim3(PWS_WV * 64), stream, p, nbw); break;
+        default: STEP_LAUNCH((conv_pws_kernel<T, NB, 4, PWS_WV, true>), grid, dim3(PWS_WV * 64), stream, p, nbw); break;
+    }
+}
+template <typename T, int NB>
 static void conv_pws_launch_s(int S, const ConvParams& p, int nbw, dim3 grid, step_stream_t stream) {
     switch (S) {
         case 1: STEP_LAUNCH((conv_pws_kernel<T, NB, 1>), grid, dim3(PWS_WV * 64), stream, p, nbw); break;
@@ -290,6 +353,12 @@ template <typename T>
 int conv_pws_launch(int nbw, const ConvParams& p, dim3 grid, step_stream_t stream) {
     int NB, S;
     pws_shape(nbw, p.nchunks32 * 2, NB, S);
+    if (p.res) {                                                             // (eight waves: sixteen measured 5-40 % slower with the residual groups, r06_ab_pws_heads.txt)
+        if (NB == 1) conv_pws_launch_res<T, 1>(S, p, nbw, grid, stream);
+        else if (NB == 2) conv_pws_launch_res<T, 2>(S, p, nbw, grid, stream);
+        else conv_pws_launch_res<T, 3>(S, p, nbw, grid, stream);
+        return STEP_LAUNCH_CHECK();
+    }
     // sixteen waves where eight leave the waves with 1 .. 3 groups each (a fractional count is imbalance): option conv_pws_waves 0 auto | 8 | 16
     if (pws_sixteen(p.Mtot, grid.x)) {
         if (NB == 1) conv_pws_launch_s16<T, 1>(S, p, nbw, grid, stream);

@@ -2054,24 +2054,35 @@ def case_conv_pointwise_weight_stationary(bk, golden):
     """conv_pws_kernel (the weight-stationary short-K pointwise stream, option conv_pws = 1) against the oracle and against the
     default kernel: one to four 64-channel steps, a K tail that is not a multiple of 64 or 32, one to four passes over the
     channel blocks with a partial last block, ragged pixel count, input and output channel slices, two destinations, no ReLU / no
-    affine; K > 256 stays with the default kernels."""
+    affine, a residual tensor (a channel slice of a wider one; round 6: the heads' Bottleneck conv3); K > 256 stays with the default
+    kernels."""
     rs = np.random.RandomState(31)
-    # (N, Cin, Cout, D, H, W, split, relu, affine, x_pad, y_pad)
+    # (N, Cin, Cout, D, H, W, split, relu, affine, x_pad, y_pad[, res_pad])
     cases = ((1, 64, 64, 2, 16, 33, 0, True, True, (0, 0), (0, 0)),
              (1, 192, 176, 1, 20, 53, 64, True, True, (8, 16), (8, 8)),
              (1, 528, 128, 1, 32, 33, 0, True, True, (0, 0), (0, 0)),
              (1, 144, 40, 2, 8, 67, 0, False, False, (0, 8), (16, 0)),
              (2, 32, 200, 1, 24, 23, 0, True, True, (0, 0), (0, 0)),
              (1, 64, 296, 1, 16, 65, 96, True, True, (0, 0), (0, 0)),          # 10 blocks: four passes
-             (1, 256, 328, 1, 16, 65, 0, True, True, (0, 0), (0, 0)))          # 11 blocks x 16 chunks > 152: two workgroup-level channel groups
+             (1, 256, 328, 1, 16, 65, 0, True, True, (0, 0), (0, 0)),          # 11 blocks x 16 chunks > 152: two workgroup-level channel groups
+             (3, 256, 328, 1, 7, 49, 0, True, False, (0, 0), (0, 0), (8, 24)),  # residual: the heads' conv3 (no affine), 7-row maps
+             (1, 96, 72, 2, 9, 61, 0, False, True, (8, 0), (0, 8), (0, 0)),     # residual, no ReLU, partial last block
+             (1, 192, 176, 1, 20, 53, 64, True, True, (0, 0), (8, 8), (16, 0)))  # residual and two destinations
     try:
-        for (N, Cin, Cout, D, H, W, split, relu, affine, xp, yp) in cases:
+        for case in cases:
+            (N, Cin, Cout, D, H, W, split, relu, affine, xp, yp), rp = case[:11], (case[11] if len(case) > 11 else None)
             x = rs.randn(N, Cin, D, H, W).astype(np.float32)
             w = (rs.randn(Cout, Cin, 1, 1, 1) / np.sqrt(Cin)).astype(np.float32)
             scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32) if affine else None
             shift = (0.2 * rs.randn(Cout)).astype(np.float32) if affine else None
             for dt in (BF16, F16):
-                ref = ref_conv(x, w, scale, shift, dt, relu=relu)
+                r = rs.randn(N, Cout, D, H, W).astype(np.float32) if rp is not None else None
+                ref = ref_conv(x, w, scale, shift, dt, relu=relu, res=r)
+                re_ = None
+                if rp is not None:
+                    rb = np.full((N, D, H, W, rp[0] + Cout + rp[1]), -77.0, np.float32)
+                    rb[..., rp[0]:rp[0] + Cout] = cl(r)
+                    re_ = bk.dev(encode(rb, dt))
                 xb = np.full((N, D, H, W, xp[0] + Cin + xp[1]), 33.0, np.float32)
                 xb[..., xp[0]:xp[0] + Cin] = cl(x)
                 xe = bk.dev(encode(xb, dt))
@@ -2085,15 +2096,16 @@ def case_conv_pointwise_weight_stationary(bk, golden):
                     ya = bk.dev(np.zeros((N, D, H, W, yp[0] + ca + yp[1]), NP_DT[dt]))
                     yb = bk.dev(np.zeros((N, D, H, W, 8 + (Cout - ca)), NP_DT[dt]))
                     d = _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=xb.shape[-1], x_coff=xp[0],
-                                       y_cstride=yp[0] + ca + yp[1], y_coff=yp[0], res_cstride=0, res_coff=0, relu=int(relu), split=split,
+                                       y_cstride=yp[0] + ca + yp[1], y_coff=yp[0], res_cstride=(rp[0] + Cout + rp[1]) if rp is not None else 0,
+                                       res_coff=rp[0] if rp is not None else 0, relu=int(relu), split=split,
                                        y2_cstride=8 + (Cout - ca), y2_coff=8)
                     name = ctypes.create_string_buffer(256)
                     assert bk.lib.step_conv_kernel_name(ctypes.byref(d), name, 256) == 0
                     assert (b"conv_pws_kernel" in name.value) == (mode != "0" and Cin <= 256), (mode, name.value)   # (K <= 256: the whole K of a pixel group lives in registers)
                     if mode != "0" and Cin <= 256:
-                        assert (b", 16>(" if mode == "16" else b", 8>(") in name.value, name.value
-                    assert bk.lib.step_conv_forward(ctypes.byref(d), xe.ptr, wp.ptr, sc.ptr, sh.ptr, None, ya.ptr, yb.ptr if split else None,
-                                                    bk.stream) == 0
+                        assert (b", 8, true>(" if rp is not None else (b", 16>(" if mode == "16" else b", 8>(")) in name.value, name.value   # (the residual form: eight waves)
+                    assert bk.lib.step_conv_forward(ctypes.byref(d), xe.ptr, wp.ptr, sc.ptr, sh.ptr, re_.ptr if re_ is not None else None, ya.ptr,
+                                                    yb.ptr if split else None, bk.stream) == 0
                     a = decode(ya.get(), dt)
                     assert not a[..., :yp[0]].any() and not a[..., yp[0] + ca:].any()
                     got = uncl(a[..., yp[0]:yp[0] + ca])

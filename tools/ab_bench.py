@@ -116,7 +116,9 @@ def main():
         print("%-8s %s" % ("stem", "  ".join("%7.1f us %6.0f TF %-12s" % (m * 1e3, gf / m, "stem_stream") for m in med)))
         if a.set == "stem":
             return
-    for name, ci, co, k, D, H, W in layers:
+    for lay in layers:
+        name, ci, co, k, D, H, W = lay[:7]
+        with_res = len(lay) > 7 and lay[7]                 # --custom name,Cin,Cout,k,D,H,W,1: a residual tensor of the output's shape
         if only and name not in only:
             continue
         x = torch.randn(B, D, H, W, ci, device=dev).to(tdt)
@@ -125,13 +127,14 @@ def main():
         _capi.check(L.step_conv_pack_weight(_lib.dptr(w), co, ci, k, k, k, dt, None, _lib.dptr(wp), st), "pack")
         sc, sh = torch.ones(co, device=dev), torch.zeros(co, device=dev)
         y = torch.empty(B, D, H, W, co, dtype=tdt, device=dev)
+        res = torch.randn(B, D, H, W, co, device=dev).to(tdt) if with_res else None
         d = _capi.ConvDesc(dtype=dt, N=B, D=D, H=H, W=W, Cin=ci, Cout=co, kd=k, kh=k, kw=k, x_cstride=ci, x_coff=0,
-                           y_cstride=co, y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+                           y_cstride=co, y_coff=0, res_cstride=co if with_res else 0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
 
         cur = [L]
 
         def run():
-            _capi.check(cur[0].step_conv_forward(ctypes.byref(d), _lib.dptr(x), _lib.dptr(wp), _lib.dptr(sc), _lib.dptr(sh), None, _lib.dptr(y), None, st), name)
+            _capi.check(cur[0].step_conv_forward(ctypes.byref(d), _lib.dptr(x), _lib.dptr(wp), _lib.dptr(sc), _lib.dptr(sh), _lib.dptr(res) if with_res else None, _lib.dptr(y), None, st), name)
 
         def setenv(v):                       # a variant = planner options (include/step_amd.h), everything else at its default
             cur[0] = lib_of(v)
