@@ -291,6 +291,17 @@ STEP_API int step_pool_conv_forward(int dtype, const void* x, int N, int D, int 
                                     int py_cstride, int py_coff, const step_conv_desc* d, const void* cx, const void* w_packed,
                                     const float* scale, const float* shift, void* y, void* y2, step_stream_t stream);
 
+/* step_conv_forward over the channel CONCAT of two tensors that is never materialised (round 6): the reference's resample Bottleneck
+ * applies conv1 / conv2 to torch.cat((global_feat, downsampled), 1) (models/two_branch.py:86-111, 313-319); here d->Cin = cin_a + cin_b,
+ * channels [0, cin_a) are read from x (d's x_cstride / x_coff) and channels [cin_a, d->Cin) from xb (xb_cstride / xb_coff), same pixels.
+ * One fp32 accumulation over the whole K, as the reference's conv over the concat has (two accumulating launches round the partial
+ * sum to the storage type in between).  The form that exists: 16-bit storage, pointwise layers the planner streams (conv_pw_kernel
+ * shapes), cin_a % 32 == 0, cin_b / xb_cstride / xb_coff % 8 == 0, xb 16-byte aligned; otherwise STEP_E_UNSUPPORTED and the caller
+ * launches the halves one after the other (step_conv_forward with res = the first half's output). */
+STEP_API int step_conv_forward_cat(const step_conv_desc* d, const void* x, int cin_a, const void* xb, int xb_cstride, int xb_coff,
+                                   const void* w_packed, const float* scale, const float* shift, const void* res, void* y, void* y2,
+                                   step_stream_t stream);
+
 /* step_conv_forward with its INPUT produced on the fly: y = conv3x3x3(relu(pre_scale * conv1x1x1(x, pre_w) + pre_shift)) -- the pair
  * conv3d_2b_1x1 -> conv3d_2c_3x3 of the backbone (models/i3dpt.py:207-209) without the tensor between them.  x [N,D,H,W,pre_cin]
  * (d->x_cstride / x_coff describe it), pre_w_packed = step_conv_pack_weight of the [d->Cin, pre_cin, 1,1,1] weight, d->Cin = its

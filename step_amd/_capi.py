@@ -5,7 +5,7 @@ import ctypes as C
 F32, BF16, F16 = 0, 1, 2
 NCHW, NHWC = 0, 1
 ROI_BWD_GATHER, ROI_BWD_ATOMIC = 0, 1
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 vp, fp, ip, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # raw device addresses
 i, f, ll, sz = C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -66,6 +66,7 @@ SIGNATURES = {
     "step_conv_group_kernel_name": (i, [C.POINTER(ConvItem), i, C.c_char_p, i]),
     "step_conv_workspace_bytes": (sz, [C.POINTER(ConvDesc)]),
     "step_pool_conv_forward": (i, [i, vp, i, i, i, i, i, i, i, vp, i, i, C.POINTER(ConvDesc), vp, vp, fp, fp, vp, vp, vp]),
+    "step_conv_forward_cat": (i, [C.POINTER(ConvDesc), vp, i, vp, i, i, vp, fp, fp, vp, vp, vp, vp]),
     "step_conv_forward_pre": (i, [C.POINTER(ConvDesc), vp, vp, fp, fp, vp, fp, fp, i, vp, vp]),
     "step_conv_pre_pool_workspace_bytes": (sz, [C.POINTER(ConvDesc)]),
     "step_conv_forward_pre_pool": (i, [C.POINTER(ConvDesc), vp, vp, fp, fp, vp, fp, fp, i, vp, vp, sz, vp]),

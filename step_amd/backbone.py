@@ -197,6 +197,7 @@ class _PermuteColsFn(torch.autograd.Function):
         return g.index_select(1, ctx.inv), None, None
 
 
+CAT_FUSE = True          # no-grad convs over a channel concat as ONE launch (ConvUnit.cat; False: two accumulating launches -- module switch for A/B and tests)
 BATCH_PACK = True        # one-launch re-pack of every stale weight image (False: each unit packs its own; module switch for tests)
 _UNITS = weakref.WeakSet()     # every live ConvUnit: an optimizer step stales all their packed images at once
 _TABLES = {}                   # (dtype, device) -> (signature, device table, [(unit, cache key)]) of the last batched re-pack
@@ -434,6 +435,20 @@ class ConvUnit:
         if shift is not None:
             shift = shift.detach().contiguous()
         return ops.conv_forward(x, self.packed(x.dtype), self.cout, self.k, scale, shift, relu, res, out)
+
+    def cat(self, xa, xb, relu=True, res=None):
+        """This (pointwise, unsliced) conv over the channel concat [xa | xb] as ONE launch (ops.conv_forward_cat), or None: when a
+        gradient is wanted, under batch-statistics BatchNorm, or where the library has no such form -- the caller then runs its two
+        cin_slice units one after the other."""
+        if not CAT_FUSE or self.cin_slice is not None or self.perm is not None or self.bn_training or self.k != (1, 1, 1):
+            return None
+        if torch.is_grad_enabled() and (xa.requires_grad or xb.requires_grad or self.weight_fn().requires_grad
+                                        or (res is not None and res.requires_grad)):
+            return None
+        scale, shift = self.affine()
+        if shift is not None:
+            shift = shift.detach().contiguous()
+        return ops.conv_forward_cat(xa, xb, self.packed(xa.dtype), self.cout, scale, shift, relu, res)
 
     def __call__(self, x, relu=True, res=None, out=None):
         w = self.weight_fn()

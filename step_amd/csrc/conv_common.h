@@ -31,6 +31,9 @@ struct ConvParams {
     int gbase, gcount;   // this problem's workgroups are blockIdx.x in [gbase, gbase + gcount) (gcount % 8 == 0 when remapped): the whole grid, or one
                          // member's share of a grouped launch (step_conv_forward_group)
     int tile0;           // conv_tap_kernel: first pixel tile of this launch (a layer may be launched in two parts, see conv_forward_t)
+    // step_conv_forward_cat (conv_pw2_kernel): a pointwise conv over the channel CONCAT of two tensors without materialising it -- K steps
+    // [0, s_split) read x, the rest x2 (same pixels); x2 = null everywhere else
+    const void* x2; int x2_cstride, x2_coff, s_split;
     int gpersist;        // > 0: launch the PERSISTENT form with this many workgroups (each walks virtual ids id, id + gpersist, ... < gcount); 0: one workgroup per id
     int nchunks;   // ceil(Cin / 32)
     int nchunks32; // same (the packed-weight K extent is 2*nchunks32 k16 blocks)

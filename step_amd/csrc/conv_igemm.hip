@@ -661,8 +661,10 @@ static int conv_forward_t(const step_conv_desc* d, ConvParams p, void* ws, size_
     constexpr int VEC = elem<T>::VEC;
     if (d->Cin % VEC || d->x_cstride % VEC || d->x_coff % VEC) return STEP_E_ALIGN;
     if (((uintptr_t)p.x % 16) || ((uintptr_t)p.w % 16)) return STEP_E_ALIGN;
-    ConvPlan pl = conv_plan(d, true, 0, p.pool_row != nullptr && p.pool_p2);
+    ConvPlan pl = conv_plan(d, p.x2 == nullptr, 0, p.pool_row != nullptr && p.pool_p2);
     if (!pl.ok) return STEP_E_UNSUPPORTED;
+    if (p.x2 && pl.impl != 2) return STEP_E_UNSUPPORTED;        // (two sources: the streaming GEMM only; the caller launches the halves one after the other)
+    if (p.x2 && pl.wv == 8 && pl.NB == 3) pl.NB = 2;            // (conv_pw2_kernel has no eight-wave NB = 3 form: registers)
     if (pl.impl == 3) {
         const size_t need = (size_t)pl.ksplit * pl.mpad * pl.cpad * sizeof(float);
         if (ws && ws_bytes >= need && ((uintptr_t)ws % 16) == 0) return conv_splitk_launch<T>(pl, p, (float*)ws, stream);
@@ -839,6 +841,7 @@ static int conv_fill_params(const step_conv_desc* d, const void* x, const void* 
     p.r_cstride = d->res_cstride; p.r_coff = d->res_coff;
     p.relu = d->relu;
     p.tiles_h = p.tiles_w = 0; p.tiles_d = d->D; p.gtd = p.gth = p.gtw = 1; p.gmode = 0; p.gx = p.gy = 0; p.tile0 = 0; p.gbase = 0; p.gcount = 0; p.gpersist = 0;
+    p.x2 = nullptr; p.x2_cstride = p.x2_coff = p.s_split = 0;
     p.nchunks = ceil_div(d->Cin, CK);
     p.nchunks32 = p.nchunks;
     p.vec_epi = (d->y_cstride % 8 == 0) && (d->y_coff % 8 == 0) && (d->Cout % 8 == 0) && (((uintptr_t)y) % 16 == 0) &&
@@ -865,6 +868,33 @@ int step_conv_forward_ws(const step_conv_desc* d, const void* x, const void* w_p
         case STEP_F32: return conv_forward_t<float>(&canon, p, ws, ws_bytes, stream);
         case STEP_BF16: return conv_forward_t<bf16_t>(&canon, p, ws, ws_bytes, stream);
         case STEP_F16: return conv_forward_t<f16_t>(&canon, p, ws, ws_bytes, stream);
+    }
+    return STEP_E_DTYPE;
+}
+
+int step_conv_forward_cat(const step_conv_desc* d, const void* x, int cin_a, const void* xb, int xb_cstride, int xb_coff, const void* w_packed,
+                          const float* scale, const float* shift, const void* res, void* y, void* y2, step_stream_t stream) {
+    if (!d) return STEP_E_NULL;
+    if (cin_a <= 0 || cin_a >= d->Cin) return STEP_E_SHAPE;
+    const int cin_b = d->Cin - cin_a;
+    if (xb_coff < 0 || xb_coff + cin_b > xb_cstride) return STEP_E_SHAPE;
+    step_conv_desc da = *d;
+    da.Cin = cin_a;                                             // (the first source's slice is what d's x_cstride / x_coff describe)
+    step_conv_desc canon;
+    ConvParams p;
+    const int rc = conv_fill_params(&da, x, w_packed, scale, shift, res, y, y2, canon, p);
+    if (rc != STEP_OK || p.N == 0) return rc;
+    if (!xb) return STEP_E_NULL;
+    // the form that exists: a 16-bit pointwise conv the planner streams, the first source in whole 32-channel K steps
+    if (canon.dtype == STEP_F32 || !(canon.kd == 1 && canon.kh == 1 && canon.kw == 1) || (cin_a % 32) || (cin_b % 8) || (xb_cstride % 8) || (xb_coff % 8))
+        return STEP_E_UNSUPPORTED;
+    if ((uintptr_t)xb % 16) return STEP_E_ALIGN;
+    canon.Cin = d->Cin;
+    p.Cin = d->Cin; p.nchunks = ceil_div(d->Cin, CK); p.nchunks32 = p.nchunks;
+    p.x2 = xb; p.x2_cstride = xb_cstride; p.x2_coff = xb_coff; p.s_split = cin_a / 32;
+    switch (canon.dtype) {
+        case STEP_BF16: return conv_forward_t<bf16_t>(&canon, p, nullptr, 0, stream);
+        case STEP_F16: return conv_forward_t<f16_t>(&canon, p, nullptr, 0, stream);
     }
     return STEP_E_DTYPE;
 }
@@ -1299,7 +1329,7 @@ int step_conv_pre_pool_plan_info(const step_conv_desc* d, int* info, int n) {
 __attribute__((visibility("default"))) void step_probe_set(void* buf) { step::g_probe_buf = (unsigned long long*)buf; }
 #endif
 const char* step_version(void) { return "step_amd 0.1.0 gfx950"; }
-int step_abi_version(void) { return 34; }
+int step_abi_version(void) { return 35; }
 
 }  // extern "C"
 

@@ -377,6 +377,26 @@ template int conv_pws_launch<f16_t>(int, const ConvParams&, dim3, step_stream_t)
 
 template <typename T>
 int conv_pw_launch(int NB, int wv, const ConvParams& p, dim3 grid, step_stream_t stream) {
+    if (p.x2) {                                                // two sources (step_conv_forward_cat): 16-bit storage
+        if constexpr (sizeof(T) == 2) {
+            if (wv == 4) {
+                switch (NB) {
+                    case 1: STEP_LAUNCH((conv_pw2_kernel<T, 1, 4>), grid, dim3(256), stream, p); break;
+                    case 2: STEP_LAUNCH((conv_pw2_kernel<T, 2, 4>), grid, dim3(256), stream, p); break;
+                    default: STEP_LAUNCH((conv_pw2_kernel<T, 3, 4>), grid, dim3(256), stream, p); break;
+                }
+                return STEP_LAUNCH_CHECK();
+            }
+            switch (NB) {
+                case 1: STEP_LAUNCH((conv_pw2_kernel<T, 1, 8>), grid, dim3(512), stream, p); break;
+                case 2: STEP_LAUNCH((conv_pw2_kernel<T, 2, 8>), grid, dim3(512), stream, p); break;
+                default: return STEP_E_UNSUPPORTED;                                      // (conv_forward_t never plans it)
+            }
+            return STEP_LAUNCH_CHECK();
+        } else {
+            return STEP_E_UNSUPPORTED;
+        }
+    }
     if (wv == 4) {
         switch (NB) {
             case 1: STEP_LAUNCH((conv_pw_kernel<T, 1, 4>), grid, dim3(256), stream, p); break;

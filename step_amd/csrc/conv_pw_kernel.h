@@ -27,7 +27,10 @@ constexpr int conv_pw_lds_bytes() {
     constexpr int NT = WV * 64, ATILE = (WV / 2) * 64 * 80, BVEC = 2 * NB * (64 / (int)sizeof(T) / 16) * 512 * (int)sizeof(T) / 16;
     return 3 * ATILE + 3 * ((BVEC + NT - 1) / NT) * NT * 16;
 }
-template <typename T, int NB, int WV, bool EXT = false, int DRX = 0>
+// TWO (round 6, conv_pw2_kernel): the input channels are the concat of two tensors -- K steps [0, p.s_split) come from p.x, the rest from
+// p.x2 (the resample Bottleneck of the heads, two_branch.py:86-111: conv1 / conv2 over cat(global feature, downsampled feature) used to run
+// as two accumulating launches with the 1024-channel partial sum written, rounded and re-read in between).
+template <typename T, int NB, int WV, bool EXT = false, int DRX = 0, bool TWO = false>
 __device__ __forceinline__ void conv_pw_body(const ConvParams& p, unsigned char* arena = nullptr) {
     static_assert(WV == 8 || WV == 4, "8 or 4 waves");
     constexpr int NT = WV * 64, WM = WV / 2, TPX = WM * 64, EROWS = WM * 32;
@@ -88,6 +91,15 @@ __device__ __forceinline__ void conv_pw_body(const ConvParams& p, unsigned char*
         amask[q] = ok ? 0xffffffffu : 0u;
         acol[q] = slot * VEC;
     }
+    // TWO: the second source's row, moved back by the first source's K extent so that one channel offset serves both
+    const unsigned char* athr2[TWO ? 2 : 1];
+    if constexpr (TWO) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const long long gm = m0 + ((tid + q * NT) >> 2);
+            athr2[q] = (const unsigned char*)p.x2 + ((size_t)(gm < p.Mtot ? gm : 0) * p.x2_cstride + p.x2_coff) * ES - (size_t)p.s_split * CKT * ES;
+        }
+    }
     // B: this thread's vectors of a step tile (as conv_tap_kernel)
     const unsigned char* wthr[Q];
     int ldsoff[Q];
@@ -116,11 +128,16 @@ __device__ __forceinline__ void conv_pw_body(const ConvParams& p, unsigned char*
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             if (FULL) {
-                RA[RS][q] = *(const u32x4*)(athr[q] + (size_t)(min(s_, S - 1) * CKT + acol[q]) * ES);   // past the end: re-read the last slab
+                const int sc = min(s_, S - 1);                                                          // past the end: re-read the last slab
+                const unsigned char* src = athr[q];
+                if constexpr (TWO) src = sc >= p.s_split ? athr2[q] : src;
+                RA[RS][q] = *(const u32x4*)(src + (size_t)(sc * CKT + acol[q]) * ES);
             } else {
                 const int c = s_ * CKT + acol[q];
                 const bool cok = c < p.Cin;                               // whole vector in or out (Cin % VEC == 0)
-                RA[RS][q] = *(const u32x4*)(athr[q] + (size_t)(cok ? c : 0) * ES); // masked when it is written to LDS: an
+                const unsigned char* src = athr[q];
+                if constexpr (TWO) src = (cok && s_ >= p.s_split) ? athr2[q] : src;
+                RA[RS][q] = *(const u32x4*)(src + (size_t)(cok ? c : 0) * ES);     // masked when it is written to LDS: an
             }                                                                       // AND here would wait for the load at once
         }
         const size_t off = (size_t)(min(s_, S - 1) * KS) * FRAGB;       // past the end: a harmless re-read of the last tile
@@ -302,5 +319,8 @@ __device__ __forceinline__ void conv_pw_body(const ConvParams& p, unsigned char*
 
 template <typename T, int NB, int WV>
 __global__ __launch_bounds__(WV * 64, 2) void conv_pw_kernel(ConvParams p) { conv_pw_body<T, NB, WV>(p); }
+// (not instantiated at NB = 3 with eight waves: that form sits at 256 VGPRs without the second source's row pointers -- conv_forward_t plans NB = 2)
+template <typename T, int NB, int WV>
+__global__ __launch_bounds__(WV * 64, 2) void conv_pw2_kernel(ConvParams p) { conv_pw_body<T, NB, WV, false, 0, true>(p); }
 
 }  // namespace step

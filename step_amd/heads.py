@@ -201,10 +201,18 @@ class _BottleneckResample(nn.Module):
         self.u2b = ConvUnit(self, lambda m: m.conv2.weight, (1, 1, 1), cin_slice=(in_a, inplanes))
         self.u3 = ConvUnit(self, lambda m: m.conv3.weight, (1, 3, 3))
         self.u4 = ConvUnit(self, lambda m: m.conv4.weight, (1, 1, 1))
+        # the same two convs over the concat in ONE launch each where no gradient is wanted (inference, the no-grad passes of the training
+        # iteration): step_conv_forward_cat -- one fp32 accumulation over K = in_a + in_b, as the reference's conv over torch.cat has
+        self.u1 = ConvUnit(self, lambda m: m.conv1.weight, (1, 1, 1))
+        self.u2 = ConvUnit(self, lambda m: m.conv2.weight, (1, 1, 1))
 
     def forward(self, a, b):
-        res = self.u1b(b, relu=False, res=self.u1a(a, relu=False))
-        o = self.u2b(b, relu=True, res=self.u2a(a, relu=False))
+        res = self.u1.cat(a, b, relu=False)
+        if res is None:
+            res = self.u1b(b, relu=False, res=self.u1a(a, relu=False))
+        o = self.u2.cat(a, b, relu=True)
+        if o is None:
+            o = self.u2b(b, relu=True, res=self.u2a(a, relu=False))
         o = self.u3(o, relu=True)
         return self.u4(o, relu=True, res=res)
 

@@ -178,6 +178,48 @@ def conv_forward(x, w_packed, Cout, k, scale=None, shift=None, relu=True, res=No
     return out
 
 
+def conv_forward_cat(xa, xb, w_packed, Cout, scale=None, shift=None, relu=True, res=None, out=None):
+    """Pointwise conv over the channel concat [xa | xb] that is never materialised (step_conv_forward_cat: conv1 / conv2 of the heads'
+    resample Bottleneck, two_branch.py:86-111): ONE launch and one fp32 accumulation over the whole K instead of two accumulating
+    launches with the partial sum rounded to the storage type in between.  w_packed: the packed image of the WHOLE weight
+    [Cout, Ca + Cb].  Returns None when the library has no such form for the shapes (the caller launches the halves)."""
+    L = _lib.lib()
+    N, D, H, W, Ca = xa.shape
+    Cb = xb.shape[-1]
+    if xa.dtype == torch.float32 or xb.dtype != xa.dtype or tuple(xb.shape[:4]) != (N, D, H, W) or Ca % 32 or Cb % 8:
+        return None
+    if out is None:
+        out = torch.empty((N, D, H, W, Cout), dtype=xa.dtype, device=xa.device)
+    d = _capi.ConvDesc(dtype=_dt(xa), N=N, D=D, H=H, W=W, Cin=Ca + Cb, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=_chan_slice(xa), x_coff=0,
+                       y_cstride=_chan_slice(out), y_coff=0, res_cstride=(_chan_slice(res) if res is not None else 0), res_coff=0,
+                       relu=int(bool(relu)), split=0, y2_cstride=0, y2_coff=0)
+    dp = _capi.ConvDesc(dtype=_dt(xa), N=N, D=D, H=H, W=W, Cin=Ca + Cb, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=Ca + Cb, x_coff=0,
+                        y_cstride=_chan_slice(out), y_coff=0, res_cstride=0, res_coff=0, relu=int(bool(relu)), split=0, y2_cstride=0, y2_coff=0)
+    info = (ctypes.c_int * 10)()
+    if L.step_conv_plan_info(ctypes.byref(dp), info, 10) != 0 or info[0] != 2:
+        return None                                                      # (the streaming GEMM only: the test step_conv_forward_cat makes)
+    refused = []
+
+    def launch():
+        rc = L.step_conv_forward_cat(ctypes.byref(d), _lib.dptr(xa), int(Ca), _lib.dptr(xb), _chan_slice(xb), 0, _lib.dptr(w_packed),
+                                     _lib.dptr(scale), _lib.dptr(shift), _lib.dptr(res), _lib.dptr(out), None, _lib.stream_ptr(xa.device))
+        if rc in (-4, -5):
+            refused.append(rc)
+            return
+        _capi.check(rc, "step_conv_forward_cat")
+
+    def describe():
+        pix = N * D * H * W
+        return ("void step::conv_pw2_kernel<%s, %d, %d>(step::ConvParams)" % (_TNAME[xa.dtype], min(info[2], 2) if info[3] == 8 else info[2], info[3]),
+                2.0 * pix * Cout * (Ca + Cb), (pix * (Ca + Cb + Cout * (2 if res is not None else 1)) + Cout * (Ca + Cb)) * _ES[xa.dtype])
+    _run(launch, describe)
+    if refused:
+        if PROFILE is not None and PROFILE and PROFILE[-1][0].startswith("void step::conv_pw2_kernel"):
+            PROFILE.pop()
+        return None
+    return out
+
+
 POOL_CONV_MAX_NB = 2   # pool_conv_forward: deepest accumulator form of the standalone pointwise launch that still rides with the pool (module switch for A/B timing)
 
 

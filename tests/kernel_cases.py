@@ -2122,6 +2122,78 @@ def case_conv_pointwise_weight_stationary(bk, golden):
         _capi.set_option(bk.lib, "conv_pws_waves", 0)
 
 
+def case_conv_pointwise_cat(bk, golden):
+    """step_conv_forward_cat (conv_pw2_kernel): a pointwise conv over the channel concat of two tensors that is never materialised -- against
+    the oracle's conv over the concatenated input, and bit-identical to step_conv_forward on a materialised concat (same K order); whole
+    and ragged tiles, a K tail, channel slices of wider tensors for both sources, residual / no affine, 4 and 8 waves, NB 1..3; the shapes
+    the form does not cover are refused (STEP_E_UNSUPPORTED) so that the caller launches the halves."""
+    rs = np.random.RandomState(77)
+    # (N, Ca, Cb, Cout, D, H, W, relu, affine, with_res, xa_pad, xb_pad)
+    cases = ((1, 96, 72, 136, 1, 64, 65, True, True, True, (32, 8), (8, 16)),      # ragged pixel tile, K = 168 (tail of 8 channels), residual
+             (1, 64, 64, 128, 1, 64, 64, False, False, False, (0, 0), (0, 0)))      # whole tiles, whole K steps: the mask-free loop
+    try:
+        for (N, Ca, Cb, Cout, D, H, W, relu, affine, with_res, ap, bp) in cases:
+            xa = rs.randn(N, Ca, D, H, W).astype(np.float32)
+            xb = rs.randn(N, Cb, D, H, W).astype(np.float32)
+            w = (rs.randn(Cout, Ca + Cb, 1, 1, 1) / np.sqrt(Ca + Cb)).astype(np.float32)
+            scale = (1 + 0.1 * rs.randn(Cout)).astype(np.float32) if affine else None
+            shift = (0.2 * rs.randn(Cout)).astype(np.float32) if affine else None
+            r = rs.randn(N, Cout, D, H, W).astype(np.float32) if with_res else None
+            xc = np.concatenate([xa, xb], 1)
+            for dt in (BF16, F16):
+                ref = ref_conv(xc, w, scale, shift, dt, relu=relu, res=r)
+                ab = np.full((N, D, H, W, ap[0] + Ca + ap[1]), 33.0, np.float32)
+                ab[..., ap[0]:ap[0] + Ca] = cl(xa)
+                bb = np.full((N, D, H, W, bp[0] + Cb + bp[1]), -44.0, np.float32)
+                bb[..., bp[0]:bp[0] + Cb] = cl(xb)
+                ae, be, ce = bk.dev(encode(ab, dt)), bk.dev(encode(bb, dt)), bk.dev(encode(cl(xc), dt))
+                re_ = bk.dev(encode(cl(r), dt)) if with_res else None
+                wp = pack_weight(bk, w, dt)
+                sc, sh = bk.dev(scale), bk.dev(shift)
+
+                def desc(cstride, coff):
+                    return _capi.ConvDesc(dtype=dt, N=N, D=D, H=H, W=W, Cin=Ca + Cb, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=cstride, x_coff=coff,
+                                          y_cstride=Cout, y_coff=0, res_cstride=Cout if with_res else 0, res_coff=0, relu=int(relu), split=0,
+                                          y2_cstride=0, y2_coff=0)
+                for waves, nb in ((8, 0), (8, 3), (8, 1), (4, 0), (4, 3)):
+                    _capi.set_option(bk.lib, "conv_waves", waves)
+                    _capi.set_option(bk.lib, "conv_nb", nb)
+                    y1 = bk.dev(np.zeros((N, D, H, W, Cout), NP_DT[dt]))
+                    d = desc(ab.shape[-1], ap[0])
+                    rc = bk.lib.step_conv_forward_cat(ctypes.byref(d), ae.ptr, Ca, be.ptr, bb.shape[-1], bp[0], wp.ptr, sc.ptr, sh.ptr,
+                                                      re_.ptr if re_ is not None else None, y1.ptr, None, bk.stream)
+                    assert rc == 0, (rc, waves, nb)
+                    got = uncl(decode(y1.get(), dt))
+                    assert np.abs(got - ref).max() / np.abs(ref).max() < tol(dt), (Ca, Cb, dt, waves, nb)
+                    y2 = bk.dev(np.zeros((N, D, H, W, Cout), NP_DT[dt]))
+                    dc = desc(Ca + Cb, 0)
+                    assert bk.lib.step_conv_forward(ctypes.byref(dc), ce.ptr, wp.ptr, sc.ptr, sh.ptr, re_.ptr if re_ is not None else None, y2.ptr,
+                                                    None, bk.stream) == 0
+                    assert np.array_equal(got, uncl(decode(y2.get(), dt))), (Ca, Cb, dt, waves, nb)      # one accumulation over the same K order
+                _capi.set_option(bk.lib, "conv_waves", 0)
+                _capi.set_option(bk.lib, "conv_nb", 0)
+                # refused: a first source that does not end on a 32-channel K step; too few pixels for the streaming GEMM
+                y1 = bk.dev(np.zeros((N, D, H, W, Cout), NP_DT[dt]))
+                d = desc(ab.shape[-1], ap[0])
+                d.res_cstride = 0
+                rc = bk.lib.step_conv_forward_cat(ctypes.byref(d), ae.ptr, Ca - 8, be.ptr, bb.shape[-1], 0, wp.ptr, sc.ptr, sh.ptr, None, y1.ptr,
+                                                  None, bk.stream)
+                assert rc == (-4 if bp[0] + bp[1] >= 8 else -2), rc          # (-2: the second source has no room for 8 more channels)
+                ds = _capi.ConvDesc(dtype=dt, N=1, D=1, H=4, W=4, Cin=Ca + Cb, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=ab.shape[-1], x_coff=ap[0],
+                                    y_cstride=Cout, y_coff=0, res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+                assert bk.lib.step_conv_forward_cat(ctypes.byref(ds), ae.ptr, Ca, be.ptr, bb.shape[-1], bp[0], wp.ptr, sc.ptr, sh.ptr, None, y1.ptr,
+                                                    None, bk.stream) == -4
+        # fp32 storage: no such form
+        d32 = _capi.ConvDesc(dtype=F32, N=1, D=1, H=64, W=64, Cin=128, Cout=128, kd=1, kh=1, kw=1, x_cstride=64, x_coff=0, y_cstride=128, y_coff=0,
+                             res_cstride=0, res_coff=0, relu=1, split=0, y2_cstride=0, y2_coff=0)
+        z = bk.dev(np.zeros((1, 1, 64, 64, 128), np.float32))
+        wz = bk.dev(np.zeros(bk.lib.step_conv_packed_elems(128, 128, 1, 1, 1), np.float32))
+        assert bk.lib.step_conv_forward_cat(ctypes.byref(d32), z.ptr, 64, z.ptr, 128, 64, wz.ptr, None, None, None, z.ptr, None, bk.stream) == -4
+    finally:
+        _capi.set_option(bk.lib, "conv_waves", 0)
+        _capi.set_option(bk.lib, "conv_nb", 0)
+
+
 def case_pack_weight_perm_folds_flatten_order(bk, golden):
     # Linear over an NCHW-flattened feature (c*HW+hw) evaluated on an NHWC-flattened one (hw*C+c)
     rs = np.random.RandomState(12)

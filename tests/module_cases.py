@@ -375,6 +375,65 @@ def case_twobranch_variants_golden(dev, golden):
                 assert e < 1e-3, (tag, nme, e)
 
 
+def case_resample_bottleneck_concat_in_one_launch(dev, golden):
+    """The heads' resample Bottleneck (models/two_branch.py:86-111: conv1 / conv2 over torch.cat((global, downsampled), 1)) without
+    gradients in 16-bit storage: the convs over the concat run as ONE launch each (ConvUnit.cat -> step_conv_forward_cat,
+    conv_pw2_kernel) where the planner streams the layer, with one fp32 accumulation over the whole K as the reference has -- no
+    further from the fp32 torch restatement than the two accumulating launches (backbone.CAT_FUSE = False), whose partial sum is
+    rounded to the storage type in between; with gradients wanted the two-launch units run (their autograd nodes)."""
+    import torch.nn.functional as F
+    from step_amd import backbone as _bb
+    from step_amd import ops as _ops
+    big = dev != "cpu"
+    ia, ib, outp, planes, maps = (832, 256, 1024, 256, 100) if big else (96, 32, 128, 64, 84)
+    blk = heads._BottleneckResample(ia, ib, outp, planes)
+    g = torch.Generator().manual_seed(41)
+    with torch.no_grad():
+        for prm in blk.parameters():
+            prm.copy_(torch.randn(prm.shape, generator=g) / (prm[0].numel() ** 0.5))
+    blk = blk.to(dev)
+    a = torch.relu(torch.randn(maps, 1, 7, 7, ia, generator=g)).to(dev)
+    b = torch.relu(torch.randn(maps, 1, 7, 7, ib, generator=g)).to(dev)
+
+    def ref():                                                    # fp32, NCHW, the reference's four convs
+        x = torch.cat([a, b], -1).reshape(maps, 7, 7, ia + ib).permute(0, 3, 1, 2).float()
+        w = {k: v.float() for k, v in blk.state_dict().items()}
+        res = F.conv2d(x, w["conv1.weight"])
+        o = F.relu(F.conv2d(x, w["conv2.weight"]))
+        o = F.relu(F.conv2d(o, w["conv3.weight"], padding=1))
+        return F.relu(F.conv2d(o, w["conv4.weight"]) + res).permute(0, 2, 3, 1).reshape(maps, 1, 7, 7, outp)
+    want = np_(ref())
+    a16, b16 = a.to(torch.bfloat16), b.to(torch.bfloat16)
+    errs, names = {}, {}
+    with torch.no_grad():
+        for fuse in (True, False):
+            try:
+                _bb.CAT_FUSE = fuse
+                _ops.PROFILE, _ops.PROFILE_LIMIT = [], 1 << 30
+                y = blk(a16, b16)
+                names[fuse] = [r[0] for r in _ops.PROFILE]
+            finally:
+                _bb.CAT_FUSE = True
+                _ops.PROFILE, _ops.PROFILE_LIMIT = None, None
+            errs[fuse] = rel(np_(y), want)
+    assert sum("conv_pw2_kernel" in n for n in names[True]) >= 1, names[True]                  # conv1 at least (conv2: where the planner streams it)
+    assert sum("conv_pw2_kernel" in n for n in names[False]) == 0, names[False]
+    assert len(names[True]) < len(names[False]), (names[True], names[False])
+    assert errs[True] < 1.5e-2 and errs[True] <= errs[False] * 1.25 + 1e-4, errs
+    record("resample_bottleneck_bf16_rel_err_one_launch_vs_two", [errs[True], errs[False]])
+    # gradients wanted: the two-launch units (no conv_pw2_kernel), same values as the no-grad two-launch run
+    for prm in blk.parameters():
+        prm.requires_grad_(True)
+    try:
+        _ops.PROFILE, _ops.PROFILE_LIMIT = [], 1 << 30
+        yg = blk(a16, b16)
+        ng = [r[0] for r in _ops.PROFILE]
+    finally:
+        _ops.PROFILE, _ops.PROFILE_LIMIT = None, None
+    assert sum("conv_pw2_kernel" in n for n in ng) == 0, ng
+    assert yg.requires_grad and rel(np_(yg), want) < 1.5e-2
+
+
 def case_twobranch_T9_golden(dev, golden):
     _twobranch(dev, golden, 9)
 
@@ -1475,5 +1534,6 @@ CPU_CASES = ["case_state_dict_contract", "case_mixed_golden", "case_basenet_c1_g
              "case_reg_unit_pack_follows_weight_updates", "case_basenet_backward_matches_oracle_autograd",
              "case_contextnet_backward_matches_oracle_autograd", "case_basenet_batch_statistics_bn_golden", "case_postprocess_golden",
              "case_batched_repack_follows_weight_updates", "case_stem_backward_16bit",
-             "case_loss_masks_without_host_branches", "case_data_parallel_replicas", "case_train_select_device_front_end", "case_nms_operator_api"]
+             "case_loss_masks_without_host_branches", "case_data_parallel_replicas", "case_train_select_device_front_end", "case_nms_operator_api",
+             "case_resample_bottleneck_concat_in_one_launch"]
 GPU_CASES = CPU_CASES + ["case_basenet_forward_u8", "case_conv_pool_fusion_in_basenet", "case_fp16_training_step_loss_scaling", "case_base_context_chain_backward", "case_wgrad_into_grad_matches_autograd", "case_training_iteration_with_selection", "case_training_step_16bit_storage", "case_c2_full_size_properties", "case_c5_full_size_properties", "case_basenet_c1_16bit_error", "case_twobranch_T9_golden", "case_i3d_classifier_golden", "case_inference_golden", "case_inference_modes_golden", "case_inference_golden_34", "case_e2e_c3_golden"]
