@@ -1281,7 +1281,7 @@ int step_conv_kernel_name(const step_conv_desc* d, char* buf, int buflen) {
         const bool w16 = d->res_cstride == 0 && pws_sixteen(M_, pl.mtiles);
         if (d->res_cstride != 0) {
             snprintf(buf, (size_t)buflen, "void step::conv_pws_kernel<%s, %d, %d, 8, true>(step::ConvParams, int)", t, nb, ksteps);
-        } else snprintf(buf, (size_t)buflen, "void step::conv_pws_kernel<%s, %d, %d, %d>(step::ConvParams, int)", t, w16 ? (nb > 2 ? 2 : nb) : nb, ksteps, w16 ? 16 : 8);
+        } else snprintf(buf, (size_t)buflen, "void step::conv_pws_kernel<%s, %d, %d, %d, false>(step::ConvParams, int)", t, w16 ? (nb > 2 ? 2 : nb) : nb, ksteps, w16 ? 16 : 8);
     }
     else if (pl.impl == 2)
         snprintf(buf, (size_t)buflen, "void step::conv_pw_kernel<%s, %d, %d>(step::ConvParams)", t, pl.NB, pl.wv);

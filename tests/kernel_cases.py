@@ -2103,7 +2103,7 @@ def case_conv_pointwise_weight_stationary(bk, golden):
                     assert bk.lib.step_conv_kernel_name(ctypes.byref(d), name, 256) == 0
                     assert (b"conv_pws_kernel" in name.value) == (mode != "0" and Cin <= 256), (mode, name.value)   # (K <= 256: the whole K of a pixel group lives in registers)
                     if mode != "0" and Cin <= 256:
-                        assert (b", 8, true>(" if rp is not None else (b", 16>(" if mode == "16" else b", 8>(")) in name.value, name.value   # (the residual form: eight waves)
+                        assert (b", 8, true>(" if rp is not None else (b", 16, false>(" if mode == "16" else b", 8, false>(")) in name.value, name.value   # (the residual form: eight waves)
                     assert bk.lib.step_conv_forward(ctypes.byref(d), xe.ptr, wp.ptr, sc.ptr, sh.ptr, re_.ptr if re_ is not None else None, ya.ptr,
                                                     yb.ptr if split else None, bk.stream) == 0
                     a = decode(ya.get(), dt)

@@ -42,8 +42,8 @@ def test_planner_dispatch(lib):
     # on a large map (the 3c fused triple) takes the weight-stationary stream, fp32 and residual layers never do
     assert "conv_pw_kernel" in name(lib, BF, 8, 480, 304, (1, 1, 1), 8, 14, 14)[0]
     # (3136 pixel groups on 2048 waves: the sixteen-wave form, at most one group per wave; the 56x56 map of the same layer keeps eight waves)
-    assert "conv_pws_kernel<step::bf16_t, 2, 4, 16>" in name(lib, BF, 8, 256, 288, (1, 1, 1), 16, 28, 28)[0]
-    assert "conv_pws_kernel<step::bf16_t, 3, 4, 8>" in name(lib, BF, 8, 256, 288, (1, 1, 1), 16, 56, 56)[0]
+    assert "conv_pws_kernel<step::bf16_t, 2, 4, 16, false>" in name(lib, BF, 8, 256, 288, (1, 1, 1), 16, 28, 28)[0]
+    assert "conv_pws_kernel<step::bf16_t, 3, 4, 8, false>" in name(lib, BF, 8, 256, 288, (1, 1, 1), 16, 56, 56)[0]
     assert "conv_pw_kernel" in name(lib, F32, 8, 256, 288, (1, 1, 1), 16, 28, 28)[0]
     assert "conv_igemm_kernel" in name(lib, BF, 8, 64, 64, (1, 1, 1), 16, 56, 56)[0]
     # few rows x very deep K (Linear 12544 -> 60 on 132 rows): split-K with a caller-owned workspace, fp32 included
