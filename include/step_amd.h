@@ -291,6 +291,10 @@ STEP_API int step_pool_conv_forward(int dtype, const void* x, int N, int D, int 
                                     int py_cstride, int py_coff, const step_conv_desc* d, const void* cx, const void* w_packed,
                                     const float* scale, const float* shift, void* y, void* y2, step_stream_t stream);
 
+/* What step_pool_conv_forward would do with the conv d: 0 = no combined form (the caller launches pool and conv separately), 1 | 2 = the
+ * accumulator depth of its pointwise workgroups (64 | 128 output channels each; the kernel's second template argument). */
+STEP_API int step_pool_conv_plan_nb(const step_conv_desc* d);
+
 /* step_conv_forward over the channel CONCAT of two tensors that is never materialised (round 6): the reference's resample Bottleneck
  * applies conv1 / conv2 to torch.cat((global_feat, downsampled), 1) (models/two_branch.py:86-111, 313-319); here d->Cin = cin_a + cin_b,
  * channels [0, cin_a) are read from x (d's x_cstride / x_coff) and channels [cin_a, d->Cin) from xb (xb_cstride / xb_coff), same pixels.

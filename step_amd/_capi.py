@@ -66,6 +66,7 @@ SIGNATURES = {
     "step_conv_group_kernel_name": (i, [C.POINTER(ConvItem), i, C.c_char_p, i]),
     "step_conv_workspace_bytes": (sz, [C.POINTER(ConvDesc)]),
     "step_pool_conv_forward": (i, [i, vp, i, i, i, i, i, i, i, vp, i, i, C.POINTER(ConvDesc), vp, vp, fp, fp, vp, vp, vp]),
+    "step_pool_conv_plan_nb": (i, [C.POINTER(ConvDesc)]),
     "step_conv_forward_cat": (i, [C.POINTER(ConvDesc), vp, i, vp, i, i, vp, fp, fp, vp, vp, vp, vp]),
     "step_conv_forward_pre": (i, [C.POINTER(ConvDesc), vp, vp, fp, fp, vp, fp, fp, i, vp, vp]),
     "step_conv_pre_pool_workspace_bytes": (sz, [C.POINTER(ConvDesc)]),

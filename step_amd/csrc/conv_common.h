@@ -59,7 +59,7 @@ struct ConvParams {
 // parameter block and a contiguous share of blockIdx.x (p[k].gbase ascending, p[0].gbase == 0).
 // pool.hip: the block's 3x3x3 / 1 max pool and a pointwise conv (conv_pw_body<T, 1, 4>, parameter block cp with gx / gy set) as one grid
 int pool333_pw_launch(int dtype, const void* x, int N, int D, int H, int W, int C, int x_cstride, int x_coff, void* y, int y_cstride, int y_coff,
-                      ConvParams cp, long long conv_blocks, step_stream_t stream);
+                      ConvParams cp, long long conv_blocks, int nbc, step_stream_t stream);
 
 constexpr int CONV_GROUP_MAX = 2;
 // pw (conv_tap_group_pw_kernel only): a pointwise conv whose 256-thread workgroups follow the members' in the same grid (pw.gbase =

@@ -872,6 +872,24 @@ int step_conv_forward_ws(const step_conv_desc* d, const void* x, const void* w_p
     return STEP_E_DTYPE;
 }
 
+// accumulator depth of the pointwise workgroups inside step_pool_conv_forward's grid: 128-channel workgroups (NB = 2) where they fill the
+// chip's two-per-CU slots three times over (round 6; option conv_nb = 1 | 2 forces).  Measured on the C3 pipeline, variants alternating on one
+// box (profiles/r06_ab_pws_heads.txt, call c42): with the bound at 1024 workgroups the 25x25 backbone maps of 4 clips (1056-1408) went to NB = 2
+// as well and the 11-tube line LOST 1.5 % (the pool's workgroups share the arena and drop from three to two per CU with it); the heads' Mixed_5b /
+// 5c at 4 x 34 tubes x 9 frames (1876 / 2345 workgroups, GEMM-dominated) gain: 34 tubes +0.6 % even with the backbone's loss inside.
+static int pool_conv_nbc(const ConvPlan& pl, long long M, int nblk32) {
+    const int nb_env = opt(STEP_OPT_CONV_NB);
+    if (nb_env == 1 || nb_env == 2) return nb_env;
+    return (pl.NB == 2 && ceil_div64(M, 128) * ceil_div(nblk32, 4) >= 1536) ? 2 : 1;
+}
+
+int step_pool_conv_plan_nb(const step_conv_desc* d) {
+    if (!d || d->dtype == STEP_F32 || !(d->kd == 1 && d->kh == 1 && d->kw == 1) || d->N <= 0) return 0;
+    const ConvPlan pl = conv_plan(d, false);
+    if (!pl.ok || pl.impl != 2 || pl.NB > 2) return 0;
+    return pool_conv_nbc(pl, (long long)d->N * d->D * d->H * d->W, ceil_div(d->Cout, 32));
+}
+
 int step_conv_forward_cat(const step_conv_desc* d, const void* x, int cin_a, const void* xb, int xb_cstride, int xb_coff, const void* w_packed,
                           const float* scale, const float* shift, const void* res, void* y, void* y2, step_stream_t stream) {
     if (!d) return STEP_E_NULL;
@@ -924,10 +942,11 @@ int step_pool_conv_forward(int dtype, const void* x, int N, int D, int H, int W,
     p.tiles_h = pl.tiles_h; p.tiles_w = pl.tiles_w; p.tiles_d = pl.tiles_d;
     p.gtd = pl.gtd; p.gth = pl.gth; p.gtw = pl.gtw; p.gmode = pl.gmode;
     const long long mtiles = ceil_div64(p.Mtot, 128);
-    const int groups = ceil_div(p.nblk32, 2);
+    const int nbc = pool_conv_nbc(pl, p.Mtot, p.nblk32);
+    const int groups = ceil_div(p.nblk32, 2 * nbc);
     p.gx = (int)mtiles; p.gy = groups;
     const long long tot = (mtiles * groups + 7) / 8 * 8;
-    return pool333_pw_launch(dtype, x, N, D, H, W, C, x_cstride, x_coff, pool_y, py_cstride, py_coff, p, tot, stream);
+    return pool333_pw_launch(dtype, x, N, D, H, W, C, x_cstride, x_coff, pool_y, py_cstride, py_coff, p, tot, nbc, stream);
 }
 
 int step_conv_forward_pre(const step_conv_desc* d, const void* x, const void* w_packed, const float* scale, const float* shift,

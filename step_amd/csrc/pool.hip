@@ -277,13 +277,17 @@ __global__ __launch_bounds__(NT) void maxpool_sep_kernel(const T* __restrict__ x
 // bodies' LDS images share ONE 43 KB arena (as static arrays of the two functions they added up to 75 KB) and the pointwise body runs
 // a two-deep global -> register ring here (154 instead of 182 VGPRs): THREE workgroups of either kind per CU instead of two --
 // C2 +0.4-1.0 %, C3 +1-2 % (same box, libraries swapped; the ring depth changes no arithmetic).
-template <typename T>
-__global__ __launch_bounds__(256, 3) void pool333_pw_kernel(const T* __restrict__ x, T* __restrict__ y, PoolParams p, int TH, int TW, int tiles_h,
-                                                            int tiles_w, int cchunks, int dseg, int nseg, int npool, ConvParams cp) {
-    constexpr int ARENA = PP_LDS_BYTES > conv_pw_lds_bytes<T, 1, 4>() ? PP_LDS_BYTES : conv_pw_lds_bytes<T, 1, 4>();
+// NBC = 2 (round 6): the pointwise workgroups own 128 pixels x 128 channels (54 KB of LDS: two workgroups per CU) -- on MANY rows (the 25x25
+// maps of 4 AVA clips, the heads' 7x7 maps of 4 x 34 tubes: 45-60 k rows, where both halves fill the chip several times over) the NB = 1 form's
+// 64-channel workgroups re-read the input once per 64 output channels and run the GEMM at two thirds of the NB = 2 rate
+// (profiles/r06_ab_pws_heads.txt: 832 -> 256 on 60 k rows 58.8 against 41.9 us stand-alone).
+template <typename T, int NBC = 1>
+__global__ __launch_bounds__(256, NBC == 1 ? 3 : 2) void pool333_pw_kernel(const T* __restrict__ x, T* __restrict__ y, PoolParams p, int TH, int TW, int tiles_h,
+                                                                           int tiles_w, int cchunks, int dseg, int nseg, int npool, ConvParams cp) {
+    constexpr int ARENA = PP_LDS_BYTES > conv_pw_lds_bytes<T, NBC, 4>() ? PP_LDS_BYTES : conv_pw_lds_bytes<T, NBC, 4>();
     __shared__ __attribute__((aligned(16))) unsigned char arena[ARENA];     // ONE arena for whichever body this workgroup runs
     if ((int)blockIdx.x < npool) maxpool_sep_body<T, 3, 3, 3, 1, 1, 1, 256, true>(x, y, p, TH, TW, tiles_h, tiles_w, cchunks, dseg, nseg, (int)blockIdx.x, npool, arena);
-    else conv_pw_body<T, 1, 4, true, 2>(cp, arena);
+    else conv_pw_body<T, NBC, 4, true, 2>(cp, arena);
 }
 
 // Backward of the TF-SAME max pool (training): the gradient of an output goes to the FIRST maximum of its window in
@@ -919,7 +923,7 @@ static int bwd_gather_t(const void* x, int gy_dtype, const void* gy, int gx_dtyp
 
 // the combined launch behind step_pool_conv_forward (conv_igemm.hip prepares the conv's parameter block): 16-bit storage only
 int pool333_pw_launch(int dtype, const void* x, int N, int D, int H, int W, int C, int x_cstride, int x_coff, void* y, int y_cstride, int y_coff,
-                      ConvParams cp, long long conv_blocks, step_stream_t stream) {
+                      ConvParams cp, long long conv_blocks, int nbc, step_stream_t stream) {
     if (dtype != STEP_BF16 && dtype != STEP_F16) return STEP_E_UNSUPPORTED;
     constexpr int V = 8;
     if (C % V || x_cstride % V || x_coff % V || y_cstride % V || y_coff % V) return STEP_E_UNSUPPORTED;
@@ -935,8 +939,14 @@ int pool333_pw_launch(int dtype, const void* x, int N, int D, int H, int W, int 
     if (npool <= 0 || npool + conv_blocks > 0x7fffffffLL) return STEP_E_UNSUPPORTED;
     cp.gbase = (int)npool; cp.gcount = (int)conv_blocks;
     const dim3 grid((unsigned)(npool + conv_blocks));
-    if (dtype == STEP_BF16)
+    if (dtype == STEP_BF16 && nbc == 2)
+        STEP_LAUNCH((pool333_pw_kernel<bf16_t, 2>), grid, dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, p, sp.TH, sp.TW, sp.tiles_h, sp.tiles_w, sp.cchunks,
+                    sp.dseg, sp.nseg, (int)npool, cp);
+    else if (dtype == STEP_BF16)
         STEP_LAUNCH((pool333_pw_kernel<bf16_t>), grid, dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, p, sp.TH, sp.TW, sp.tiles_h, sp.tiles_w, sp.cchunks,
+                    sp.dseg, sp.nseg, (int)npool, cp);
+    else if (nbc == 2)
+        STEP_LAUNCH((pool333_pw_kernel<f16_t, 2>), grid, dim3(256), stream, (const f16_t*)x, (f16_t*)y, p, sp.TH, sp.TW, sp.tiles_h, sp.tiles_w, sp.cchunks,
                     sp.dseg, sp.nseg, (int)npool, cp);
     else
         STEP_LAUNCH((pool333_pw_kernel<f16_t>), grid, dim3(256), stream, (const f16_t*)x, (f16_t*)y, p, sp.TH, sp.TW, sp.tiles_h, sp.tiles_w, sp.cchunks,

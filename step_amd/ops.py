@@ -220,6 +220,7 @@ def conv_forward_cat(xa, xb, w_packed, Cout, scale=None, shift=None, relu=True, 
     return out
 
 
+POOL_CONV_FORCE_NB = 0  # pool_conv_forward: 1 | 2 force the accumulator depth of the pointwise workgroups inside the combined grid (A/B timing; 0: the library's choice)
 POOL_CONV_MAX_NB = 2   # pool_conv_forward: deepest accumulator form of the standalone pointwise launch that still rides with the pool (module switch for A/B timing)
 
 
@@ -237,13 +238,19 @@ def pool_conv_forward(x, w_packed, Cout, scale, shift, relu, out, out2=None, spl
     info = (ctypes.c_int * 10)()
     if L.step_conv_plan_info(ctypes.byref(d), info, 10) != 0 or info[0] != 2 or info[2] > POOL_CONV_MAX_NB:
         return None                                                      # (the test step_pool_conv_forward makes)
+    force = {"conv_nb": POOL_CONV_FORCE_NB} if POOL_CONV_FORCE_NB else {}
+    with _capi.options(L, **force):
+        nbc = L.step_pool_conv_plan_nb(ctypes.byref(d))
+    if nbc <= 0:
+        return None
     pooled = torch.empty((N, D, H, W, Cin), dtype=x.dtype, device=x.device)
     refused = []
 
     def launch():
-        rc = L.step_pool_conv_forward(_dt(x), _lib.dptr(x), N, D, H, W, Cin, _chan_slice(x), 0, _lib.dptr(pooled), Cin, 0, ctypes.byref(d),
-                                      _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift), _lib.dptr(out), _lib.dptr(out2),
-                                      _lib.stream_ptr(x.device))
+        with _capi.options(L, **force):
+            rc = L.step_pool_conv_forward(_dt(x), _lib.dptr(x), N, D, H, W, Cin, _chan_slice(x), 0, _lib.dptr(pooled), Cin, 0, ctypes.byref(d),
+                                          _lib.dptr(x), _lib.dptr(w_packed), _lib.dptr(scale), _lib.dptr(shift), _lib.dptr(out), _lib.dptr(out2),
+                                          _lib.stream_ptr(x.device))
         if rc in (-4, -5):          # STEP_E_UNSUPPORTED / STEP_E_ALIGN: the library's own contract checks (alignment, 32-bit offsets, ...) are
             refused.append(rc)      # stricter than the plan test above -- the caller then launches pool and conv one after the other
             return
@@ -251,8 +258,8 @@ def pool_conv_forward(x, w_packed, Cout, scale, shift, relu, out, out2=None, spl
 
     def describe():
         pix = N * D * H * W
-        return ("void step::pool333_pw_kernel<%s>(%s const*, %s*, step::PoolParams, int, int, int, int, int, int, int, int, step::ConvParams)" % (
-            _TNAME[x.dtype], _TNAME[x.dtype], _TNAME[x.dtype]), 2.0 * pix * Cout * Cin, (pix * (3 * Cin + Cout) + Cout * Cin) * _ES[x.dtype])
+        return ("void step::pool333_pw_kernel<%s, %d>(%s const*, %s*, step::PoolParams, int, int, int, int, int, int, int, int, step::ConvParams)" % (
+            _TNAME[x.dtype], nbc, _TNAME[x.dtype], _TNAME[x.dtype]), 2.0 * pix * Cout * Cin, (pix * (3 * Cin + Cout) + Cout * Cin) * _ES[x.dtype])
     _run(launch, describe)
     if refused:
         if PROFILE is not None and PROFILE and PROFILE[-1][0].startswith("void step::pool333_pw_kernel"):

@@ -1956,25 +1956,30 @@ def case_pool_conv_forward_matches_two_launches(bk, golden):
                            res_cstride=0, res_coff=0, relu=1, split=split, y2_cstride=Cout - split if split else 0, y2_coff=0)
         assert bk.lib.step_conv_plan_info(ctypes.byref(d), info, 10) == 0
         outs = []
-        for fused in (True, False):
+        for fused in (True, 2, 1, False):                    # True: the library's choice; 2 | 1: 128- | 64-channel pointwise workgroups forced (option conv_nb)
             py = bk.dev(np.full((N, D, H, W, Cin), 3, NP_DT[dt]))
             y = bk.dev(np.zeros((N, D, H, W, c0 + 8), NP_DT[dt]))
             y2 = bk.dev(np.zeros((N, D, H, W, max(Cout - split, 1)), NP_DT[dt]))
             if fused:
+                _capi.set_option(bk.lib, "conv_nb", 0 if fused is True else fused)
+                want_nb = bk.lib.step_pool_conv_plan_nb(ctypes.byref(d))
                 rc = bk.lib.step_pool_conv_forward(dt, xe.ptr, N, D, H, W, Cin, Cin, 0, py.ptr, Cin, 0, ctypes.byref(d), xe.ptr, wp.ptr, dsc.ptr, dsh.ptr,
                                                    y.ptr, y2.ptr if split else None, bk.stream)
+                _capi.set_option(bk.lib, "conv_nb", 0)
                 ok = info[0] == 2 and info[2] <= 2
                 assert rc == (0 if ok else -4), (rc, list(info))
+                assert want_nb == ((1 if fused is True else fused) if ok else 0), (want_nb, fused, list(info))     # (these maps are small: 64-channel workgroups unless forced)
                 if not ok:
                     break
             else:
                 assert bk.lib.step_maxpool3d_tf(dt, xe.ptr, N, D, H, W, Cin, Cin, 0, 3, 3, 3, 1, 1, 1, py.ptr, Cin, 0, bk.stream) == 0
                 assert bk.lib.step_conv_forward(ctypes.byref(d), xe.ptr, wp.ptr, dsc.ptr, dsh.ptr, None, y.ptr, y2.ptr if split else None, bk.stream) == 0
             outs.append((py.get(), y.get(), y2.get()))
-        if len(outs) == 2:
+        if len(outs) == 4:
             ran += 1
-            for a, b in zip(*outs):
-                assert np.array_equal(a, b), (dt, N, Cin, Cout, split)
+            for o in outs[:3]:
+                for a, b in zip(o, outs[3]):
+                    assert np.array_equal(a, b), (dt, N, Cin, Cout, split)
             assert not decode(outs[0][1], dt)[..., :8].any()
     assert ran >= 2, ran
     df = _capi.ConvDesc(dtype=F32, N=1, D=3, H=14, W=14, Cin=128, Cout=96, kd=1, kh=1, kw=1, x_cstride=128, x_coff=0, y_cstride=96, y_coff=0,
