@@ -7,9 +7,12 @@ O = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "g
 NOTES = {"c2": "before the amd-smi poller was joined (the contract window ran beside a live poller); stem row = stem + its seam pass",
          "c5": "poller joined", "c6": "", "c10": "", "c21": "persistent form also under the throughput profile",
          "c22": "the stem call timed in its two parts (stem_pool_fix_kernel has a row of its own); fp16 leg behind the fed loop",
-         "c24": "fp16 leg on the bf16 loop's streams, still behind the fed loop", "c25": "HEAD: fp16 leg before the fed loop"}
+         "c24": "fp16 leg on the bf16 loop's streams, still behind the fed loop", "c25": "fp16 leg before the fed loop",
+         "c28": "split-K bound, 1x3x3 two-phase (C3 work; the C2 step unchanged)", "c29": "",
+         "c31": "the slowest box of the round: every kernel 3-12 % slower (stem 268 against 239 us on c29, effective clock 1.75 against 1.87 GHz)",
+         "c43": "HEAD: concat form / residual stream / pool + pointwise NB = 2 for the heads (C3 work; the C2 step unchanged)"}
 rows = []
-for tag in ("c2", "c5", "c6", "c10", "c21", "c22", "c24", "c25"):
+for tag in ("c2", "c5", "c6", "c10", "c21", "c22", "c24", "c25", "c28", "c29", "c31", "c43"):
     p = os.path.join(O, "driver_cmd_%s.json" % tag)
     if os.path.exists(p) and os.path.getsize(p) > 10:
         rows.append((tag, json.load(open(p))))
