@@ -25,7 +25,8 @@ namespace step {
 template <typename T, int NB, int WV>
 constexpr int conv_pw_lds_bytes() {
     constexpr int NT = WV * 64, ATILE = (WV / 2) * 64 * 80, BVEC = 2 * NB * (64 / (int)sizeof(T) / 16) * 512 * (int)sizeof(T) / 16;
-    return 3 * ATILE + 3 * ((BVEC + NT - 1) / NT) * NT * 16;
+    constexpr int NBUF = WV == 8 ? 4 : 3;                    // eight waves: a ring of FOUR slab buffers, one barrier per TWO K steps (see PAIR)
+    return NBUF * ATILE + NBUF * ((BVEC + NT - 1) / NT) * NT * 16;
 }
 // TWO (round 6, conv_pw2_kernel): the input channels are the concat of two tensors -- K steps [0, p.s_split) come from p.x, the rest from
 // p.x2 (the resample Bottleneck of the heads, two_branch.py:86-111: conv1 / conv2 over cat(global feature, downsampled feature) used to run
@@ -47,16 +48,22 @@ __device__ __forceinline__ void conv_pw_body(const ConvParams& p, unsigned char*
     typedef typename frag<T>::type frag_t;
 
     constexpr int BSTRIDE = Q * NT * 16;                    // weight buffer pitch: every thread stores all its Q vectors (no predicate)
-    static_assert(conv_pw_lds_bytes<T, NB, WV>() == 3 * ATILE + 3 * BSTRIDE, "conv_pw_lds_bytes");
+    // PAIR (round 6, the eight-wave form): the slab ring in LDS is FOUR deep and the loop synchronises once per TWO K steps -- a step is only
+    // 8 NB / 2 MFMAs per wave, and with one barrier each the heads' deep pointwise GEMMs (K = 832 .. 1088 on 20-60 k rows) ran at 610-660 TFLOP/s
+    // against the ~1 PFLOP/s of the 3x3x3 kernel (24 MFMAs between two phase switches).  Same slabs, same order of the MFMAs: bit-identical.
+    constexpr bool PAIR = WV == 8;
+    constexpr int NBUF = PAIR ? 4 : 3;
+    static_assert(!PAIR || !EXT, "the four-deep ring needs the kernel's own LDS");
+    static_assert(conv_pw_lds_bytes<T, NB, WV>() == NBUF * ATILE + NBUF * BSTRIDE, "conv_pw_lds_bytes");
     unsigned char* lds;
     if constexpr (EXT) {
         lds = arena;
     } else {
-        __shared__ __attribute__((aligned(16))) unsigned char own[3 * ATILE + 3 * BSTRIDE];
+        __shared__ __attribute__((aligned(16))) unsigned char own[NBUF * ATILE + NBUF * BSTRIDE];
         lds = own;
     }
     unsigned char* const ldsA = lds;
-    unsigned char* const ldsB = lds + 3 * ATILE;
+    unsigned char* const ldsB = lds + NBUF * ATILE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -118,6 +125,7 @@ __device__ __forceinline__ void conv_pw_body(const ConvParams& p, unsigned char*
     // (four-wave NB = 3: 3 weight vectors per thread per step -- four register sets would spill; two suffice when a second
     // resident workgroup covers the latency)
     constexpr int DR = DRX > 0 ? DRX : ((WV == 4 && NB == 3) ? 2 : 4);
+    static_assert(!PAIR || DR == 4, "the paired loop keeps slab k in register set k % 4 and LDS buffer k % 4");
     u32x4 RA[DR][2], RB[DR][Q];
     // FULL = whole slabs (Cin % CKT == 0) and a whole 256-pixel tile: no channel / pixel masks anywhere in the loop
     // (workgroup-uniform; the vector ALU work per step drops by two thirds)
@@ -214,6 +222,32 @@ __device__ __forceinline__ void conv_pw_body(const ConvParams& p, unsigned char*
         load_step(I0(), DR, fullc); load_step(I1(), DR + 1, fullc);
         __syncthreads();
         read_frags(I0(), 0);
+        if constexpr (PAIR) {
+            // two steps per barrier: slab k lives in register set k % 4 and LDS buffer k % 4.  While the waves multiply slabs s and s + 1
+            // (buffers s, s + 1) they fill buffers s + 2 and s + 3 -- last read two barriers ago.
+            auto pair = [&](auto ra, auto rb) {
+                constexpr int A = decltype(ra)::value, B = decltype(rb)::value;          // (s + 2) % 4, (s + 3) % 4
+                read_frags(I1(), (A + 3) & 3);                                           // slab s + 1
+                mma_all(I0());                                                           // slab s
+                store_step(ra, A, s_ + 2, fullc);
+                store_step(rb, B, s_ + 3, fullc);
+                load_step(ra, s_ + 2 + DR, fullc);
+                load_step(rb, s_ + 3 + DR, fullc);
+                __syncthreads();
+                read_frags(I0(), A);                                                     // slab s + 2 (a surplus read past the end hits a valid buffer)
+                mma_all(I1());                                                           // slab s + 1
+                s_ += 2;
+            };
+#pragma unroll 1
+            while (s_ + 4 <= S) {
+                pair(I2(), I3());
+                pair(I0(), I1());
+            }
+            if (s_ + 2 <= S) pair(I2(), I3());
+            if (s_ < S) mma_all(I0());                                                   // an odd last slab: its fragments are in set 0
+            __syncthreads();                                                             // (the epilogue re-uses the ring: every wave's last fragment read -- issued BEHIND the last barrier -- has landed)
+            return;
+        }
         auto step = [&](auto setc, auto rc) {
             constexpr int SET = decltype(setc)::value;
             read_frags(std::integral_constant<int, SET ^ 1>(), b1);

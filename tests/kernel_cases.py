@@ -2199,6 +2199,39 @@ def case_conv_pointwise_cat(bk, golden):
         _capi.set_option(bk.lib, "conv_nb", 0)
 
 
+def case_conv_pointwise_eight_wave_ring(bk, golden):
+    """conv_pw_kernel with eight waves (round 6: a four-deep slab ring in LDS, one barrier per TWO K steps) on every loop shape -- 1, 2, 3, 4, 5
+    and 7 K steps (odd counts end on a single step), whole and ragged pixel tiles, a K tail -- against the oracle and BIT-IDENTICAL to the
+    four-wave form (three-deep ring, one barrier per step): same slabs, same order of the multiplications."""
+    rs = np.random.RandomState(83)
+    try:
+        for (Cin, Cout, H, W, relu) in ((32, 64, 64, 64, True), (64, 128, 64, 65, True), (96, 96, 64, 64, False), (128, 64, 32, 128, True),
+                                        (160, 128, 64, 65, True), (200, 72, 64, 64, True)):
+            x = rs.randn(1, Cin, 1, H, W).astype(np.float32)
+            w = (rs.randn(Cout, Cin, 1, 1, 1) / np.sqrt(Cin)).astype(np.float32)
+            scale, shift = (1 + 0.1 * rs.randn(Cout)).astype(np.float32), (0.2 * rs.randn(Cout)).astype(np.float32)
+            for dt in (BF16, F16):
+                ref = ref_conv(x, w, scale, shift, dt, relu=relu)
+                xe, wp, sc, sh = bk.dev(encode(cl(x), dt)), pack_weight(bk, w, dt), bk.dev(scale), bk.dev(shift)
+                d = _capi.ConvDesc(dtype=dt, N=1, D=1, H=H, W=W, Cin=Cin, Cout=Cout, kd=1, kh=1, kw=1, x_cstride=Cin, x_coff=0, y_cstride=Cout, y_coff=0,
+                                   res_cstride=0, res_coff=0, relu=int(relu), split=0, y2_cstride=0, y2_coff=0)
+                outs = {}
+                for waves in (8, 4):
+                    _capi.set_option(bk.lib, "conv_impl", 5)
+                    _capi.set_option(bk.lib, "conv_waves", waves)
+                    name = ctypes.create_string_buffer(256)
+                    assert bk.lib.step_conv_kernel_name(ctypes.byref(d), name, 256) == 0
+                    assert b"conv_pw_kernel" in name.value and (b", %d>(" % waves) in name.value, name.value
+                    y = bk.dev(np.zeros((1, 1, H, W, Cout), NP_DT[dt]))
+                    assert bk.lib.step_conv_forward(ctypes.byref(d), xe.ptr, wp.ptr, sc.ptr, sh.ptr, None, y.ptr, None, bk.stream) == 0
+                    outs[waves] = uncl(decode(y.get(), dt))
+                    assert np.abs(outs[waves] - ref).max() / np.abs(ref).max() < tol(dt), (Cin, Cout, dt, waves)
+                assert np.array_equal(outs[8], outs[4]), (Cin, Cout, dt)
+    finally:
+        _capi.set_option(bk.lib, "conv_impl", -1)
+        _capi.set_option(bk.lib, "conv_waves", 0)
+
+
 def case_pack_weight_perm_folds_flatten_order(bk, golden):
     # Linear over an NCHW-flattened feature (c*HW+hw) evaluated on an NHWC-flattened one (hw*C+c)
     rs = np.random.RandomState(12)
