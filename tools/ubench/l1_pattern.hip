@@ -21,6 +21,7 @@ __global__ __launch_bounds__(512) void k(const unsigned char* __restrict__ x, un
             for (int j = 0; j < NL; ++j) {
                 size_t off;
                 if (PAT == 32) off = (size_t)(gg * 32 + (lane & 31)) * pitch + j * 32 + 16 * (lane >> 5);
+                else if (PAT == 16) off = (size_t)(gg * 32 + (j % 2) * 16 + (lane >> 2)) * pitch + (j / 2) * 64 + 16 * (lane & 3);   // conv_pw_kernel's slab staging: 16 rows x 64 B
                 else off = (size_t)(gg * 32 + (j % 4) * 8 + (lane >> 3)) * pitch + (j / 4) * 128 + 16 * (lane & 7);
                 v[j] = *(const u32x4*)(x + off);
             }
@@ -54,6 +55,9 @@ int main() {
     run<8, 16>(x, out, rows, 512, "8 rows x 128 B per load (row-major)");
     run<32, 16>(x, out, rows, 2048, "lane = row, 32 B (pitch 2048: a slice of 1024 ch)");
     run<8, 16>(x, out, rows, 2048, "8 rows x 128 B (pitch 2048)");
+    run<16, 16>(x, out, rows, 512, "16 rows x 64 B per load (conv_pw slab staging)");
+    run<16, 16>(x, out, rows, 2048, "16 rows x 64 B (pitch 2048)");
+    run<16, 64>(x, out, rows, 2048, "16 rows x 64 B, whole 2048-B rows, 64 loads");
     run<32, 64>(x, out, rows, 2048, "lane = row, whole 2048-B rows, 64 loads");
     run<8, 64>(x, out, rows, 2048, "8 rows x 128 B, whole 2048-B rows, 64 loads");
     return 0;
