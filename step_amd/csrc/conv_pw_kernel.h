@@ -24,7 +24,7 @@ namespace step {
 // DRX > 0 overrides the depth of the global -> register ring (see DR below).
 template <typename T, int NB, int WV>
 constexpr int conv_pw_lds_bytes() {
-    constexpr int NT = WV * 64, ATILE = (WV / 2) * 64 * 80, BVEC = 2 * NB * (64 / (int)sizeof(T) / 16) * 512 * (int)sizeof(T) / 16;
+    constexpr int NT = WV * 64, ATILE = (WV / 2) * 64 * (sizeof(T) == 2 ? 64 : 80), BVEC = 2 * NB * (64 / (int)sizeof(T) / 16) * 512 * (int)sizeof(T) / 16;
     constexpr int NBUF = WV == 8 ? 4 : 3;                    // eight waves: a ring of FOUR slab buffers, one barrier per TWO K steps (see PAIR)
     return NBUF * ATILE + NBUF * ((BVEC + NT - 1) / NT) * NT * 16;
 }
@@ -38,8 +38,13 @@ __device__ __forceinline__ void conv_pw_body(const ConvParams& p, unsigned char*
     constexpr int ES = (int)sizeof(T);
     constexpr int VEC = 16 / ES;
     constexpr int CKT = 64 / ES, KS = CKT / 16;
-    constexpr int PITCH = 80;
-    constexpr int ATILE = TPX * PITCH;                       // 20480 B (WV = 8) / 10240 B
+    // 16-bit storage (round 6): the slab rows sit at their natural 64-byte pitch with the four 16-byte slots of pixel p XOR-ed by (p >> 2) & 3 --
+    // conflict-free for the fragment reads (16 lanes = 16 rows, one slot) AND for the staging writes (16 lanes = 4 pixels x 4 slots); the
+    // padded 80-byte pitch was conflict-free for the reads only (profiles/r06_pmc_conv_pw.txt: 23 % of the LDS-active cycles were bank
+    // conflicts) and 25 % larger.  fp32 keeps the padded pitch (its fragment is two slots wide).
+    constexpr bool SWZ = ES == 2;
+    constexpr int PITCH = SWZ ? 64 : 80;
+    constexpr int ATILE = TPX * PITCH;                       // 16384 B (WV = 8) / 8192 B; fp32 20480 / 10240 B
     constexpr int FRAGB = 512 * ES, FRAGV = FRAGB / 16;
     constexpr int NBT = 2 * NB;
     constexpr int BTILE = NBT * KS * FRAGB;
@@ -159,10 +164,10 @@ __device__ __forceinline__ void conv_pw_body(const ConvParams& p, unsigned char*
         for (int q = 0; q < 2; ++q) {
             const int v = tid + q * NT;
             if (FULL) {
-                *(u32x4*)(ldsA + buf * ATILE + (v >> 2) * PITCH + ((v & 3) << 4)) = RA[RS][q];
+                *(u32x4*)(ldsA + buf * ATILE + (v >> 2) * PITCH + (((v & 3) ^ (SWZ ? ((v >> 4) & 3) : 0)) << 4)) = RA[RS][q];
             } else {
                 const unsigned int mk = (slab * CKT + acol[q] < p.Cin) ? amask[q] : 0u;
-                *(u32x4*)(ldsA + buf * ATILE + (v >> 2) * PITCH + ((v & 3) << 4)) = RA[RS][q] & mk;
+                *(u32x4*)(ldsA + buf * ATILE + (v >> 2) * PITCH + (((v & 3) ^ (SWZ ? ((v >> 4) & 3) : 0)) << 4)) = RA[RS][q] & mk;
             }
         }
 #pragma unroll
@@ -172,7 +177,10 @@ __device__ __forceinline__ void conv_pw_body(const ConvParams& p, unsigned char*
 
     const unsigned char* abase[2];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) abase[mb] = ldsA + (wm * 64 + mb * 32 + (lane & 31)) * PITCH + khalf * (ES == 4 ? 32 : 16);
+    for (int mb = 0; mb < 2; ++mb) abase[mb] = ldsA + (wm * 64 + mb * 32 + (lane & 31)) * PITCH + (SWZ ? 0 : khalf * (ES == 4 ? 32 : 16));
+    int aoff[KS];                                            // byte offset of this lane's fragment of k16 step j inside its pixel's slab row
+#pragma unroll
+    for (int j = 0; j < KS; ++j) aoff[j] = SWZ ? (((2 * j + khalf) ^ ((lane >> 2) & 3)) << 4) : j * 32;
     const unsigned char* const bwave = ldsB + (wn * NB) * KS * FRAGB + lane * (8 * ES);
 
     f32x16 acc[2][NB];
@@ -189,7 +197,7 @@ __device__ __forceinline__ void conv_pw_body(const ConvParams& p, unsigned char*
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) fa[SET][j][mb] = lds_read_bfrag<T>(abase[mb] + buf * ATILE + j * 32);
+            for (int mb = 0; mb < 2; ++mb) fa[SET][j][mb] = lds_read_bfrag<T>(abase[mb] + buf * ATILE + aoff[j]);
 #pragma unroll
             for (int i = 0; i < NB; ++i) fb[SET][j][i] = lds_read_bfrag<T>(bwave + buf * BSTRIDE + (i * KS + j) * FRAGB);
         }

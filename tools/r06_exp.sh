@@ -1,12 +1,14 @@
-R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out
-cd /tmp; export TMPDIR=/tmp
-i=0
-for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD" "SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM"; do
-  i=$((i+1))
-  timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_pw_$i -- python $R/tools/ab_bench.py --batch 136 --rounds 1 --iters 2 --custom a832_1024,832,1024,1,9,7,7 --custom c1024_256,1024,256,1,9,7,7 --var conv_pws=0 --var conv_pws=0,conv_nb=3 > /dev/null 2> $O/pmc_pw_$i.err
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "pointwise or conv_units or pool_conv or big_conv or group" 2>&1 | tail -2
+echo "== heads' shapes: XOR-swizzled 64-byte slab pitch (working tree) against the 80-byte pitch (lib=prev: the ring build)"
+for D in 9 3; do
+python tools/ab_bench.py --batch 136 --rounds 5 --iters 10 \
+  --custom a832_1024,832,1024,1,$D,7,7 --custom c1024_256,1024,256,1,$D,7,7 --custom d832_256,832,256,1,$D,7,7 --custom b256_1024r,256,1024,1,$D,7,7,1 \
+  --var conv_pws=0,lib=prev --var conv_pws=0 --var conv_pws=0,conv_waves=4,lib=prev --var conv_pws=0,conv_waves=4 --var conv_pws=0,conv_nb=3,lib=prev --var conv_pws=0,conv_nb=3 2>&1 | tail -6
 done
-cd $R
-python tools/pmc_dump.py conv_pw_kernel $O/pmc_pw_1 $O/pmc_pw_2 $O/pmc_pw_3 $O/pmc_pw_4 > $O/pmc_pw.txt 2>&1
-rm -rf $O/pmc_pw_1 $O/pmc_pw_2 $O/pmc_pw_3 $O/pmc_pw_4
-cat $O/pmc_pw.txt
+python tools/step_ab.py --var lib=prev --var default 2>&1 | tail -4
+for t in 34 11; do for l in none prev none prev; do
+if [ $l = none ]; then A=""; else A="lib=$l"; fi
+python tools/bench_with.py $A -- --config c3 --tubes $t --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{' | python -c "
+import json,sys; j=json.loads(sys.stdin.read()); print('c3 tubes $t lib=$l:', j['value'], 'clips/s', j['ms_per_step'], 'ms; one at a time', j['one_batch_in_flight']['value'])"
+done; done
