@@ -861,8 +861,9 @@ def main():
             # CLIPS_PER_GPU clips, but step k + 1 (its own input / activation buffers, its own captured graph) is replayed on a second
             # stream while step k drains -- the last launches of a step leave most CUs idle (one-round 3x3x3 grids with 40-57 us
             # workgroups on the 14x14 maps) and the next step's stem fills them.  Same kernels, same results, +12 % clips/s
-            # (tools/two_in_flight.py; three in flight +13 %, four +10 %).  --in-flight 1 times the one-batch-at-a-time loop; the
-            # JSON line carries both.
+            # (tools/two_in_flight.py, round 3: three in flight +13 %, four +10 %; re-measured in round 6 on the final kernels, same box, alternating:
+            # two 7 539 / 7 582 clips/s, three 7 184 / 7 096 -- a third batch now only adds contention).  --in-flight 1 times the one-batch-at-a-time
+            # loop; the JSON line carries both.
             torch.cuda.synchronize()
             # The steps of the multi-batch loop are captured under the library's THROUGHPUT profile (planner option `throughput`, include/step_amd.h:
             # launch shapes for several independent batches in flight -- a block's pointwise conv on its own instead of inside the 3x3x3
