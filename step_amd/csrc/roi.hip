@@ -162,7 +162,9 @@ __global__ void roi_align_fwd_nhwc_kernel(const T* __restrict__ feat, const floa
 
 // (round 6: a 16-bit variant with the loads of up to four samples of a row in flight at once measured SLOWER -- 132.7 against 90.4 us per
 // launch at 4 x 34 tubes, C3 670.6 against 686.6 clips/s, profiles/r06_ab_pws_heads.txt: the adaptive grid of the tubes is mostly 2 x 2, so
-// half the batched loads were padding, and 64 more VGPRs cost occupancy.  The loop above stays.)
+// half the batched loads were padding, and 64 more VGPRs cost occupancy; the same with the bin's samples FLATTENED so that a 2 x 2 grid is
+// exactly one batch of 16 loads, no padding: 674.6 / 679.6 against 685.3 / 688.4 clips/s -- the kernel is bound by the L1 / L2 throughput of
+// its taps at full occupancy, not by a dependent-latency chain.  The loop above stays.)
 // ROIAlign forward, NCHW (thread per output scalar; same arithmetic).
 template <typename T>
 __global__ void roi_align_fwd_nchw_kernel(const T* __restrict__ feat, const float* __restrict__ rois, long long total,
