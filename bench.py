@@ -1157,7 +1157,8 @@ def pipeline_bench(a, c, dev, tdt, rank, world, dist):
         out = {"metric": metric, "value": round(val, 2), "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": max(a.warmup, 2),
                "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": what + ", inputs resident in HBM, random-init weights", "clips_per_gpu": CLIPS_PER_GPU, "tubes_per_clip": tubes, "T": 36, "HW": 400,
+               "config": {"workload": what + (", inputs resident in HBM (in the captured step's own input buffer, as the C2 loop has them), random-init weights" if (a.config == "c3" and not a.no_graph)
+                                              else ", inputs resident in HBM, random-init weights"), "clips_per_gpu": CLIPS_PER_GPU, "tubes_per_clip": tubes, "T": 36, "HW": 400,
                           "parallelism": "clip-sharded replicas x%d (%s)" % (world, "no data-path collective" if a.config == "c3" else "one gradient all-reduce per step"),
                           "batches_in_flight": nfl,
                           "launch": ("hipGraph replay + eager post-processing" + (", %d batches in flight (own clips / graph / stream each; batch k + 1 launched before batch k is post-processed)" % nfl if nfl > 1 else ""))

@@ -60,6 +60,8 @@ class C3Inference:
         self.tubes = [np.tile(anchors[:, None, :], (1, 3, 1)).astype(np.float32) for _ in range(batch)]
         self.batch = batch
         self.graphed = GraphedInference(self.args, self.base, self.ctx, self.nets, self.x, self.tubes) if graph else None
+        if self.graphed is not None:
+            self.x = self.graphed.images                      # the clips are RESIDENT in the captured step's input buffer (as bench.py's C2 loop has them)
 
     def eager(self):
         with torch.no_grad():
