@@ -202,6 +202,17 @@ STEP_API int step_detect_nms(const float* prob, long long prob_stride, int NC, c
                              const int32_t* tube_start, const int32_t* tube_count, int B, int kmax, float conf_thresh,
                              float nms_thresh, float width, float height, uint8_t* keep, float* boxes_out, step_stream_t stream);
 
+/* The rows the evaluation loop appends behind the NMS (test.py:196-204), for up to STEP_DETECT_ITERS_MAX refinement iterations and all clips in
+ * ONE launch: keep [I, B, NC, kmax] (step_detect_nms' masks), boxes[i] [N,4] (its clamped boxes) and scores[i] [N, >= NC] (row stride
+ * score_strides[i]) of iteration i -- `boxes`, `scores`, `score_strides` are HOST arrays of I entries.  Group g = i * B + b owns the rows
+ * [g * cap, g * cap + counts[g]) of the outputs, cap = NC * kmax, in the reference's order (classes ascending, kept tubes in ascending
+ * original order): out_boxes [I*B*cap, 4] = box / [W,H,W,H] (test.py:197-198), out_scores, out_cls (class index), out_tube (index of the
+ * tube inside its clip), counts [I*B] int32. */
+#define STEP_DETECT_ITERS_MAX 8
+STEP_API int step_detect_compact(const uint8_t* keep, const float* const* boxes, const float* const* scores, const long long* score_strides,
+                                 const int32_t* tube_start, int I, int B, int NC, int kmax, float width, float height, float* out_boxes,
+                                 float* out_scores, long long* out_cls, long long* out_tube, int32_t* counts, step_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused convolution unit on channels-last activations:
  *     y = act( conv(x, w) * scale[c] + shift[c] (+ residual) )

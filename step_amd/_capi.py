@@ -56,6 +56,7 @@ SIGNATURES = {
     "step_nms_scratch_bytes": (sz, [i, i]),
     "step_nms_batched": (i, [fp, fp, ip, i, i, f, u8p, vp, vp]),
     "step_nms_batched_f64": (i, [fp, fp, ip, i, i, f, u8p, vp, vp]),
+    "step_detect_compact": (i, [u8p, vp, vp, vp, ip, i, i, i, i, f, f, fp, fp, vp, vp, ip, vp]),
     "step_detect_nms": (i, [fp, ll, i, fp, ll, ip, ip, i, i, f, f, f, f, u8p, fp, vp]),
     "step_conv_packed_elems": (sz, [i, i, i, i, i]),
     "step_conv_pack_weight": (i, [fp, i, i, i, i, i, i, ip, vp, vp]),

@@ -204,11 +204,82 @@ static int nms_batched_t(const F* boxes, const F* scores, const int32_t* counts,
     return STEP_LAUNCH_CHECK();
 }
 
+// detect_compact_kernel -- the rows test.py:196-204 appends after the NMS of an iteration, for ALL iterations and clips in one launch: one
+// 256-thread workgroup per (iteration, clip) walks its NC x kmax keep flags in row-major order (classes ascending, kept tubes in ascending
+// original order: the reference's row order), numbers the set flags with a ballot prefix and writes box / [W,H,W,H], score, class, tube of
+// row r to slot g * cap + r of its own fixed-capacity segment (cap = NC * kmax) -- no prefix sum across workgroups, the host reads the
+// I x B counts once and slices.  (Before: nonzero + index + cat + gather + bincount, ~25 launches and two host synchronisations per step.)
+struct DetectCompactParams {
+    const float* boxes[STEP_DETECT_ITERS_MAX];
+    const float* scores[STEP_DETECT_ITERS_MAX];
+    long long score_stride[STEP_DETECT_ITERS_MAX];
+    const uint8_t* keep; const int32_t* start;
+    int B, NC, kmax;
+    float w, h;
+    float* out_boxes; float* out_scores; long long* out_cls; long long* out_tube; int32_t* counts;
+};
+__global__ __launch_bounds__(256) void detect_compact_kernel(DetectCompactParams p) {
+    __shared__ int wsum[4];
+    const int g = blockIdx.x, it = g / p.B, b = g % p.B;
+    const int F = p.NC * p.kmax;
+    const uint8_t* kp = p.keep + (size_t)g * F;
+    const float* bx = p.boxes[it];
+    const float* sc = p.scores[it];
+    const long long ss = p.score_stride[it];
+    const int t0 = F > 0 ? p.start[b] : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int base = 0;
+    for (int f0 = 0; f0 < F; f0 += 256) {
+        const int f = f0 + (int)threadIdx.x;
+        const bool on = f < F && kp[f] != 0;
+        const unsigned long long m = __ballot(on);
+        const int before = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __builtin_popcountll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (on) {
+            const int c = f / p.kmax, j = f - c * p.kmax;
+            const size_t row = (size_t)g * F + off + before;
+            const float* bb = bx + (size_t)(t0 + j) * 4;
+            p.out_boxes[row * 4 + 0] = bb[0] / p.w; p.out_boxes[row * 4 + 1] = bb[1] / p.h;
+            p.out_boxes[row * 4 + 2] = bb[2] / p.w; p.out_boxes[row * 4 + 3] = bb[3] / p.h;
+            p.out_scores[row] = sc[(size_t)(t0 + j) * ss + c];
+            p.out_cls[row] = c;
+            p.out_tube[row] = j;
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.counts[g] = base;
+}
+
 }  // namespace step
 
 using namespace step;
 
 extern "C" {
+
+int step_detect_compact(const uint8_t* keep, const float* const* boxes, const float* const* scores, const long long* score_strides,
+                        const int32_t* tube_start, int I, int B, int NC, int kmax, float width, float height, float* out_boxes,
+                        float* out_scores, long long* out_cls, long long* out_tube, int32_t* counts, step_stream_t stream) {
+    if (I < 0 || I > STEP_DETECT_ITERS_MAX || B < 0 || NC < 0 || kmax < 0) return STEP_E_SHAPE;
+    if (I == 0 || B == 0) return STEP_OK;
+    if (!counts) return STEP_E_NULL;
+    const bool none = NC == 0 || kmax == 0;                    // (no flags: the launch only writes the zero counts)
+    if (!none && (!keep || !boxes || !scores || !score_strides || !tube_start || !out_boxes || !out_scores || !out_cls || !out_tube)) return STEP_E_NULL;
+    DetectCompactParams p;
+    for (int i = 0; i < STEP_DETECT_ITERS_MAX; ++i) {
+        const bool in = i < I && !none;
+        p.boxes[i] = in ? boxes[i] : nullptr; p.scores[i] = in ? scores[i] : nullptr; p.score_stride[i] = in ? score_strides[i] : 0;
+        if (in && (!p.boxes[i] || !p.scores[i] || p.score_stride[i] < NC)) return STEP_E_SHAPE;
+    }
+    p.keep = keep; p.start = tube_start; p.B = B; p.NC = NC; p.kmax = kmax; p.w = width; p.h = height;
+    p.out_boxes = out_boxes; p.out_scores = out_scores; p.out_cls = out_cls; p.out_tube = out_tube; p.counts = counts;
+    STEP_LAUNCH((detect_compact_kernel), dim3((unsigned)(I * B)), dim3(256), stream, p);
+    return STEP_LAUNCH_CHECK();
+}
 
 size_t step_nms_scratch_bytes(int G, int kmax) {
     if (G <= 0 || kmax <= 64) return 0;

@@ -1035,6 +1035,30 @@ def detect_nms(prob, loc, tube_start, tube_count, kmax, conf_thresh, nms_thresh,
     return keep, boxes
 
 
+def detect_compact(keep, boxes, scores, tube_start, width, height):
+    """step_detect_compact: keep [I,B,NC,kmax] uint8, boxes / scores = lists of I tensors ([N,4] / [N,NC] fp32), tube_start [B] int32 ->
+    (out_boxes [I*B*cap,4] normalised, out_scores, out_cls, out_tube, counts [I*B] int32), cap = NC * kmax: group g = i * B + b owns rows
+    [g * cap, g * cap + counts[g]) in the reference's row order."""
+    L = _lib.lib()
+    I, B, NC, kmax = keep.shape
+    dev = keep.device
+    cap = NC * kmax
+    boxes = [b if (b.dtype == torch.float32 and b.is_contiguous()) else b.float().contiguous() for b in boxes]
+    scores = [s_ if (s_.dtype == torch.float32 and s_.stride(1) == 1) else s_.float().contiguous() for s_ in scores]
+    ob = torch.empty((I * B * cap, 4), dtype=torch.float32, device=dev)
+    os_ = torch.empty((I * B * cap,), dtype=torch.float32, device=dev)
+    oc = torch.empty((I * B * cap,), dtype=torch.int64, device=dev)
+    ot = torch.empty((I * B * cap,), dtype=torch.int64, device=dev)
+    counts = torch.empty((I * B,), dtype=torch.int32, device=dev)
+    bp = (ctypes.c_void_p * I)(*[b.data_ptr() for b in boxes])
+    sp = (ctypes.c_void_p * I)(*[s_.data_ptr() for s_ in scores])
+    ss = (ctypes.c_longlong * I)(*[s_.stride(0) for s_ in scores])
+    _capi.check(L.step_detect_compact(_lib.dptr(keep), ctypes.cast(bp, ctypes.c_void_p), ctypes.cast(sp, ctypes.c_void_p), ctypes.cast(ss, ctypes.c_void_p),
+                                      _lib.dptr(tube_start), I, B, NC, kmax, float(width), float(height), _lib.dptr(ob), _lib.dptr(os_), _lib.dptr(oc),
+                                      _lib.dptr(ot), _lib.dptr(counts), _lib.stream_ptr(dev)), "step_detect_compact")
+    return ob, os_, oc, ot, counts
+
+
 def select_prepare(prob, loc, first, last, clip_of, gt_mid, gt_count, width, height):
     """step_select_prepare: prob [N,T,NC], loc [N,T,4], first / last [N,Tw,4] | None, clip_of [N] int32, gt_mid [B,Gmax,4], gt_count [B]
     int32 (one device) -> (mean_prob [N,NC], vloc [N,T,4], vfirst, vlast ([N,Tw,4] | None), iou [N,Gmax]), fp32 on that device."""

@@ -2232,6 +2232,51 @@ def case_conv_pointwise_eight_wave_ring(bk, golden):
         _capi.set_option(bk.lib, "conv_waves", 0)
 
 
+def case_detect_compact(bk, golden):
+    """step_detect_compact (the rows test.py:196-204 appends behind the NMS, all iterations and clips in one launch) against a numpy
+    restatement: per (iteration, clip) the set flags of keep[i, b] in row-major order -- classes ascending, tubes ascending -- with
+    box / [W,H,W,H] (IEEE division, bit-exact), the tube's score of that class, class and tube index; ragged clips, an empty clip,
+    an all-zero and an all-one mask, flag counts that are not a multiple of the workgroup; no flags at all."""
+    rs = np.random.RandomState(101)
+    for (I, nums, NC, kmax, dens) in ((3, (11, 0, 7, 34), 60, 34, 0.05), (1, (5,), 3, 7, 1.0), (2, (64, 3), 17, 64, 0.0), (8, (2, 2), 300, 2, 0.5)):
+        B, N = len(nums), max(sum(nums), 1)
+        start = (np.cumsum(nums) - np.asarray(nums)).astype(np.int32)
+        keep = (rs.rand(I, B, NC, kmax) < dens).astype(np.uint8)
+        for b, n in enumerate(nums):
+            keep[:, b, :, n:] = 0                                                       # (slots past a clip's tubes are never set by step_detect_nms)
+        boxes = [(rs.rand(N, 4) * 400).astype(np.float32) for _ in range(I)]
+        scores = [rs.rand(N, NC + 3).astype(np.float32) for _ in range(I)]              # (row stride > NC)
+        cap = NC * kmax
+        dk, ds = bk.dev(keep), bk.dev(start)
+        db, dsx = [bk.dev(b_) for b_ in boxes], [bk.dev(s_) for s_ in scores]
+        ob, os_ = bk.dev(np.full((I * B * cap, 4), -1, np.float32)), bk.dev(np.full((I * B * cap,), -1, np.float32))
+        oc, ot = bk.dev(np.full((I * B * cap,), -1, np.int64)), bk.dev(np.full((I * B * cap,), -1, np.int64))
+        cnt = bk.dev(np.full((I * B,), -1, np.int32))
+        bp = (ctypes.c_void_p * I)(*[int(b_.ptr.value if hasattr(b_.ptr, "value") else b_.ptr) for b_ in db])
+        sp = (ctypes.c_void_p * I)(*[int(s_.ptr.value if hasattr(s_.ptr, "value") else s_.ptr) for s_ in dsx])
+        ss = (ctypes.c_longlong * I)(*[NC + 3] * I)
+        rc = bk.lib.step_detect_compact(dk.ptr, ctypes.cast(bp, ctypes.c_void_p), ctypes.cast(sp, ctypes.c_void_p), ctypes.cast(ss, ctypes.c_void_p), ds.ptr,
+                                        I, B, NC, kmax, 400.0, 300.0, ob.ptr, os_.ptr, oc.ptr, ot.ptr, cnt.ptr, bk.stream)
+        assert rc == 0, rc
+        gb, gs, gc, gt, gn = ob.get(), os_.get(), oc.get(), ot.get(), cnt.get()
+        wh = np.asarray([400.0, 300.0, 400.0, 300.0], np.float32)
+        for i in range(I):
+            for b in range(B):
+                g = i * B + b
+                c_, j_ = np.nonzero(keep[i, b])
+                assert gn[g] == len(c_), (I, g, gn[g], len(c_))
+                sl = slice(g * cap, g * cap + len(c_))
+                assert np.array_equal(gc[sl], c_) and np.array_equal(gt[sl], j_)
+                assert np.array_equal(gb[sl], boxes[i][start[b] + j_] / wh)
+                assert np.array_equal(gs[sl], scores[i][start[b] + j_, c_])
+                assert (gc[g * cap + len(c_):(g + 1) * cap] == -1).all()               # nothing written past the group's rows
+    # no classes: only the zero counts are written; too many iterations are refused
+    cnt = bk.dev(np.full((4,), -1, np.int32))
+    assert bk.lib.step_detect_compact(None, None, None, None, None, 2, 2, 0, 5, 1.0, 1.0, None, None, None, None, cnt.ptr, bk.stream) == 0
+    assert (cnt.get() == 0).all()
+    assert bk.lib.step_detect_compact(None, None, None, None, None, 9, 2, 4, 5, 1.0, 1.0, None, None, None, None, cnt.ptr, bk.stream) == -2
+
+
 def case_pack_weight_perm_folds_flatten_order(bk, golden):
     # Linear over an NCHW-flattened feature (c*HW+hw) evaluated on an NHWC-flattened one (hw*C+c)
     rs = np.random.RandomState(12)

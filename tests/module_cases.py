@@ -580,6 +580,19 @@ def case_postprocess_golden(dev, golden):
     assert d0[1]["scores"].numel() == 0
     full = postprocess(cfg(), hist, iterations=(0,))[0]
     assert torch.equal(d0[0]["boxes"], full[0]["boxes"]) and torch.equal(d0[2]["scores"], full[1]["scores"])
+    # the one-launch row compaction (step_detect_compact, round 6) against the tensor-op form it replaced: the same rows, bit for bit
+    assert driver.COMPACT_KERNEL
+    try:
+        driver.COMPACT_KERNEL = False
+        old = postprocess(cfg(conf_thresh=0.01, nms_thresh=0.4, evaluate_topk=-1, topk=-1), hist)
+        old0 = postprocess(cfg(), [h0])[0]
+    finally:
+        driver.COMPACT_KERNEL = True
+    for it in range(3):
+        for a_, b_ in zip(old[it], fastp[it]):
+            assert all(torch.equal(a_[k_], b_[k_]) and a_[k_].dtype == b_[k_].dtype for k_ in ("boxes", "scores", "labels", "tubes"))
+    for a_, b_ in zip(old0, d0):
+        assert all(torch.equal(a_[k_], b_[k_]) for k_ in ("boxes", "scores", "labels", "tubes"))
 
 
 def case_inference_golden_34(dev, golden):
