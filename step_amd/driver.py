@@ -62,10 +62,11 @@ def inference(args, conv_feat, context_feat, nets, exec_iter, tubes):
     return history, trajectory
 
 
-def inference_flat(args, conv_feat, context_feat, nets, exec_iter, flat, nums, clip_of):
+def inference_flat(args, conv_feat, context_feat, nets, exec_iter, flat, nums, clip_of, want_classes=True):
     """The device-resident core of `inference`: flat [N,T,5] tubes (col 0 = frame index), nums = tubes per
     clip, clip_of [N] = clip index of every tube.  Pure tensor ops with static shapes and no host
-    synchronisation, so the whole multi-step pipeline can be captured in a hipGraph (GraphedInference)."""
+    synchronisation, so the whole multi-step pipeline can be captured in a hipGraph (GraphedInference).
+    want_classes=False: the trajectory's class index (an argmax per step that only `inference` hands on) is None."""
     dev = conv_feat.device
     history, trajectory = [], []
     clip32 = None
@@ -95,7 +96,7 @@ def inference_flat(args, conv_feat, context_feat, nets, exec_iter, flat, nums, c
                 args.image_size[0], args.image_size[1])
             history.append({"pred_prob": pred_prob.detach(), "pred_loc": pred_loc, "pred_first_loc": pred_first,
                             "pred_last_loc": pred_last, "tubes_nums": list(nums)})
-            trajectory.append((flat[:, :, 1:], torch.argmax(prob, dim=-1)))
+            trajectory.append((flat[:, :, 1:], torch.argmax(prob, dim=-1) if want_classes else None))
             continue
         flat = flat.to(local_loc)
         pred_loc = decode_coef(flat.reshape(-1, 5)[:, 1:], local_loc.reshape(-1, 4)).view(local_loc.shape)
@@ -119,7 +120,7 @@ def inference_flat(args, conv_feat, context_feat, nets, exec_iter, flat, nums, c
         else:
             prop = pred_loc
         prop = valid_tubes(prop, width=args.image_size[0], height=args.image_size[1])
-        trajectory.append((prop, torch.argmax(prob, dim=-1)))
+        trajectory.append((prop, torch.argmax(prob, dim=-1) if want_classes else None))
         Tn = prop.shape[1]
         idx = (clip_of.to(prop.dtype) * Tn).view(-1, 1, 1) + torch.arange(Tn, device=dev, dtype=prop.dtype).view(1, Tn, 1)
         flat = torch.cat([idx, prop], dim=2)
@@ -302,7 +303,7 @@ class GraphedInference:
     def _run(self):
         cf = self.base(self.images)
         cx = self.ctx(cf) if not self.args.no_context else None
-        hist, _ = inference_flat(self.args, cf, cx, self.nets, self.args.max_iter, self.flat0, self.nums, self.clip_of)
+        hist, _ = inference_flat(self.args, cf, cx, self.nets, self.args.max_iter, self.flat0, self.nums, self.clip_of, want_classes=False)
         return hist, cf, cx
 
     def __call__(self, images=None, tubes=None):

@@ -385,7 +385,7 @@ class C4SelectTrainStep(C4TrainStep):
         for m in self.mods:
             m.eval()
         with torch.no_grad():
-            history, _ = inference_flat(a, cf.detach(), cx.detach(), self.nets, a.max_iter - 1, self.flat0, self.nums0, self.clip_of0)
+            history, _ = inference_flat(a, cf.detach(), cx.detach(), self.nets, a.max_iter - 1, self.flat0, self.nums0, self.clip_of0, want_classes=False)
         for m in self.mods:
             m.train()
         return cf, cx, history
