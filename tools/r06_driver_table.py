@@ -11,10 +11,11 @@ NOTES = {"c2": "before the amd-smi poller was joined (the contract window ran be
          "c28": "split-K bound, 1x3x3 two-phase (C3 work; the C2 step unchanged)", "c29": "",
          "c31": "the slowest box of the round: every kernel 3-12 % slower (stem 268 against 239 us on c29, effective clock 1.75 against 1.87 GHz)",
          "c43": "concat form / residual stream / pool + pointwise NB = 2 for the heads (C3 work; the C2 step unchanged)",
-         "c48": "HEAD (C3 work since c47: row compaction kernel, no hand-over copy; the C2 step unchanged)",
+         "c49": "HEAD (documentation only since c48); the same call's C3 lines: 1 118 clips/s at 11 tubes, 703 at 34",
+         "c48": "(C3 work since c47: row compaction kernel, no hand-over copy; the C2 step unchanged)",
          "c47": "conv_pw slab ring four deep + XOR-swizzled 64-byte pitch (the C2 step's pointwise workgroups inside the grouped launches)"}
 rows = []
-for tag in ("c2", "c5", "c6", "c10", "c21", "c22", "c24", "c25", "c28", "c29", "c31", "c43", "c47", "c48"):
+for tag in ("c2", "c5", "c6", "c10", "c21", "c22", "c24", "c25", "c28", "c29", "c31", "c43", "c47", "c48", "c49"):
     p = os.path.join(O, "driver_cmd_%s.json" % tag)
     if os.path.exists(p) and os.path.getsize(p) > 10:
         rows.append((tag, json.load(open(p))))
